@@ -1,0 +1,126 @@
+"""Synthetic MulRan-shape inputs for tests and bench.py.
+
+No MulRan data exists offline, so every workload is generated: radar feature clouds in the
+sensor frame (what /orora/cloud_local carries), keyframe sequences with planted revisits,
+matched point pairs for ORORA, and 400 x 3360 polar power images.  Pure numpy; seeds fixed by
+the callers (1234 DB / 4321 queries / 777 ORORA).
+"""
+import numpy as np
+
+NUM_RING, NUM_SECTOR, MAX_RADIUS = 20, 60, 80.0
+
+
+def radar_cloud(rng, n_points=None, binary_z=True, guard=0.0):
+    """One feature cloud as (n, 4) float32 x,y,z,intensity (pcl::PointXYZI payload).
+
+    ranges ~ mixture(uniform[2,80] background, wall/cluster structures); a few points beyond
+    80 m (ignored by the descriptor, Scancontext.cpp:175).  binary_z: z = 0 (2-D radar
+    features => every occupied bin = LIDAR_HEIGHT); else z ~ U(-1, 4).  guard > 0 pushes
+    points away from ring/sector bin edges by that fraction of a bin (parity runs that must not
+    depend on the last ulp of atan/sqrt).
+    """
+    if n_points is None:
+        n_points = int(rng.integers(500, 4001))
+    n_bg = n_points // 3
+    n_st = n_points - n_bg
+    r = rng.uniform(2.0, 88.0, n_bg)
+    th = rng.uniform(0.0, 2 * np.pi, n_bg)
+    # structures: a handful of wall segments (line pieces) and blobs
+    n_seg = int(rng.integers(4, 12))
+    seg_id = rng.integers(0, n_seg, n_st)
+    c_r = rng.uniform(5.0, 75.0, n_seg)
+    c_t = rng.uniform(0.0, 2 * np.pi, n_seg)
+    cx, cy = c_r * np.cos(c_t), c_r * np.sin(c_t)
+    ang = rng.uniform(0.0, np.pi, n_seg)
+    half = rng.uniform(1.0, 15.0, n_seg)
+    t = rng.uniform(-1.0, 1.0, n_st) * half[seg_id]
+    sx = cx[seg_id] + t * np.cos(ang[seg_id]) + rng.normal(0, 0.15, n_st)
+    sy = cy[seg_id] + t * np.sin(ang[seg_id]) + rng.normal(0, 0.15, n_st)
+    x = np.concatenate([r * np.cos(th), sx])
+    y = np.concatenate([r * np.sin(th), sy])
+    if guard > 0.0:
+        x, y = _apply_guard(x, y, guard)
+    if binary_z:
+        z = np.zeros_like(x)
+    else:
+        z = rng.uniform(-1.0, 4.0, x.shape[0])
+    inten = rng.uniform(0.0, 1.0, x.shape[0])
+    return np.stack([x, y, z, inten], axis=1).astype(np.float32)
+
+
+def _apply_guard(x, y, guard):
+    """Move points so that range/angle sit at least `guard` bins away from any bin edge."""
+    r = np.hypot(x, y)
+    th = np.mod(np.arctan2(y, x), 2 * np.pi)
+    rb = r / (MAX_RADIUS / NUM_RING)
+    fr = rb - np.floor(rb)
+    rb = np.floor(rb) + np.clip(fr, guard, 1 - guard)
+    tb = th / (2 * np.pi / NUM_SECTOR)
+    ft = tb - np.floor(tb)
+    tb = np.floor(tb) + np.clip(ft, guard, 1 - guard)
+    r = rb * (MAX_RADIUS / NUM_RING)
+    th = tb * (2 * np.pi / NUM_SECTOR)
+    return r * np.cos(th), r * np.sin(th)
+
+
+def revisit(rng, cloud, yaw, jitter=0.05, drop=0.1, guard=0.0):
+    """A later observation of the same place: rotate by yaw, jitter, drop/add some points."""
+    keep = rng.uniform(size=cloud.shape[0]) > drop
+    c = cloud[keep].astype(np.float64)
+    cs, sn = np.cos(yaw), np.sin(yaw)
+    x = cs * c[:, 0] - sn * c[:, 1] + rng.normal(0, jitter, c.shape[0])
+    y = sn * c[:, 0] + cs * c[:, 1] + rng.normal(0, jitter, c.shape[0])
+    if guard > 0.0:
+        x, y = _apply_guard(x, y, guard)
+    out = np.stack([x, y, c[:, 2], c[:, 3]], axis=1)
+    n_new = max(1, int(0.05 * cloud.shape[0]))
+    extra = radar_cloud(rng, n_new, binary_z=bool(np.all(cloud[:, 2] == 0)), guard=guard)
+    return np.concatenate([out, extra], axis=0).astype(np.float32)
+
+
+def keyframe_clouds(seed, n, binary_z=True, loop_frac=0.05, guard=0.0, min_gap=50,
+                    n_points=None):
+    """n keyframe clouds; ~loop_frac of them are planted revisits of an earlier keyframe.
+
+    Returns (clouds, truth) with truth[i] = (earlier index, yaw sector shift) or None.
+    """
+    rng = np.random.default_rng(seed)
+    clouds, truth = [], []
+    for i in range(n):
+        if i > min_gap and rng.uniform() < loop_frac:
+            j = int(rng.integers(0, i - min_gap))
+            while truth[j] is not None:  # revisit originals only
+                j = int(rng.integers(0, i - min_gap))
+            ks = int(rng.integers(0, NUM_SECTOR))
+            yaw = ks * (2 * np.pi / NUM_SECTOR)
+            clouds.append(revisit(rng, clouds[j], yaw, guard=guard))
+            truth.append((j, ks))
+        else:
+            clouds.append(radar_cloud(rng, n_points, binary_z=binary_z, guard=guard))
+            truth.append(None)
+    return clouds, truth
+
+
+def random_descriptors(seed, n, binary=True, fill=0.25):
+    """Fast descriptor-level generator for very large DBs (n x 1200 float32, sector-major
+    [s*20+r]); values are fp32 by construction.  Used where pushing 10^5 clouds through the
+    build path would dominate a test's run time."""
+    rng = np.random.default_rng(seed)
+    occ = rng.uniform(size=(n, NUM_SECTOR * NUM_RING)) < fill
+    # empty sectors happen in real scans: blank a random arc in some entries
+    arc = rng.integers(0, NUM_SECTOR, n)
+    width = rng.integers(0, 8, n)
+    cols = np.arange(NUM_SECTOR)[None, :]
+    blank = ((cols - arc[:, None]) % NUM_SECTOR) < width[:, None]
+    occ &= ~np.repeat(blank, NUM_RING, axis=1)
+    if binary:
+        d = np.where(occ, np.float32(2.0), np.float32(0.0))
+    else:
+        d = np.where(occ, rng.uniform(1.0, 6.0, occ.shape).astype(np.float32), np.float32(0.0))
+    return np.ascontiguousarray(d, dtype=np.float32)
+
+
+def rotate_descriptor(desc_f32, k):
+    """Column-rotate right by k sectors: new[(s+k)%60] = old[s] (Scancontext.cpp:39-59)."""
+    d = desc_f32.reshape(NUM_SECTOR, NUM_RING)
+    return np.roll(d, k, axis=0).reshape(-1).copy()

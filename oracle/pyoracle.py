@@ -1,0 +1,312 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so, oracle/_ref/libref_kdtree.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+NR, NS, DS = 20, 60, 1200
+
+
+class Hit(C.Structure):
+    _fields_ = [("dist", C.c_double), ("index", C.c_int32), ("shift", C.c_int32)]
+
+
+HIT_DTYPE = np.dtype([("dist", "<f8"), ("index", "<i4"), ("shift", "<i4")])
+
+
+def build(force=False):
+    """(Re)build liboracle.so and, when /root/reference exists, _ref/libref_kdtree.so."""
+    so = os.path.join(_HERE, "liboracle.so")
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libref_kdtree.so")
+    if os.path.isdir("/root/reference/pgo/SC-A-LOAM/include/scancontext") and (force or not os.path.exists(ref_so)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+_lib = None
+_ref = None
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L.scref_xy2theta.restype = C.c_float
+        L.scref_xy2theta.argtypes = [C.c_float, C.c_float]
+        L.scref_deg2rad_f.restype = C.c_float
+        L.scref_deg2rad_f.argtypes = [C.c_float]
+        L.scref_dist_direct.restype = C.c_double
+        L.scref_fast_align.restype = C.c_int
+        L.scref_ringkey_l2.restype = C.c_float
+        L.scref_create.restype = C.c_void_p
+        L.scref_destroy.argtypes = [C.c_void_p]
+        L.scref_set_dist_thres.argtypes = [C.c_void_p, C.c_double]
+        L.scref_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_int, C.c_int, C.c_double]
+        L.scref_size.restype = C.c_int64
+        L.scref_size.argtypes = [C.c_void_p]
+        L.scref_tree_size.restype = C.c_int64
+        L.scref_tree_size.argtypes = [C.c_void_p]
+        L.scref_add_points.restype = C.c_int64
+        L.scref_add_points.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        L.scref_add_descriptor.restype = C.c_int64
+        L.scref_add_descriptor.argtypes = [C.c_void_p, C.c_void_p]
+        L.scref_get_descriptor.restype = C.POINTER(C.c_double)
+        L.scref_get_descriptor.argtypes = [C.c_void_p, C.c_int64]
+        L.scref_get_ringkey_f32.restype = C.POINTER(C.c_float)
+        L.scref_get_ringkey_f32.argtypes = [C.c_void_p, C.c_int64]
+        L.scref_get_sectorkey.restype = C.POINTER(C.c_double)
+        L.scref_get_sectorkey.argtypes = [C.c_void_p, C.c_int64]
+        L.scref_knn.restype = C.c_int
+        L.scref_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_void_p]
+        L.scref_detect_loop_closure.restype = C.c_int
+        L.scref_detect_loop_closure.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.scref_detect_between_session.restype = C.c_int
+        L.scref_detect_between_session.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.scref_exhaustive.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
+        L.scref_pair_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.scref_merge_topk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.scref_make_scancontext.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_void_p]
+        L.scref_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        L.scref_distance_literal.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]
+        L.scref_circshift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.scref_ringkey.argtypes = [C.c_void_p, C.c_void_p]
+        L.scref_sectorkey.argtypes = [C.c_void_p, C.c_void_p]
+        L.scref_ringkey_f32.argtypes = [C.c_void_p, C.c_void_p]
+        L.scref_dist_direct.argtypes = [C.c_void_p, C.c_void_p]
+        L.scref_fast_align.argtypes = [C.c_void_p, C.c_void_p]
+        L.scref_ringkey_l2.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def ref_lib():
+    """The reference's own nanoflann kd-tree (oracle/_ref); None when it was never built."""
+    global _ref
+    if _ref is None:
+        build()
+        p = os.path.join(_HERE, "_ref", "libref_kdtree.so")
+        if not os.path.exists(p):
+            return None
+        R = C.CDLL(p)
+        R.ref_kdtree_build.restype = C.c_void_p
+        R.ref_kdtree_build.argtypes = [C.c_void_p, C.c_int64, C.c_int]
+        R.ref_kdtree_knn.restype = C.c_int
+        R.ref_kdtree_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        R.ref_kdtree_free.argtypes = [C.c_void_p]
+        _ref = R
+    return _ref
+
+
+# ------------------------------------------------------------------------------------------
+# numpy-level helpers
+# ------------------------------------------------------------------------------------------
+
+def xy2theta(x, y):
+    return lib().scref_xy2theta(float(np.float32(x)), float(np.float32(y)))
+
+
+def make_scancontext(pts, lidar_height=2.0, max_radius=80.0):
+    """pts: (n, >=3) float32 -> (1200,) float64 column-major 20x60."""
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    out = np.empty(DS, dtype=np.float64)
+    lib().scref_make_scancontext(pts.ctypes.data, pts.shape[0], pts.shape[1], lidar_height, max_radius, out.ctypes.data)
+    return out
+
+
+def ringkey(desc):
+    desc = np.ascontiguousarray(desc, dtype=np.float64)
+    out = np.empty(NR, dtype=np.float64)
+    lib().scref_ringkey(desc.ctypes.data, out.ctypes.data)
+    return out
+
+
+def ringkey_f32(desc):
+    desc = np.ascontiguousarray(desc, dtype=np.float64)
+    out = np.empty(NR, dtype=np.float32)
+    lib().scref_ringkey_f32(desc.ctypes.data, out.ctypes.data)
+    return out
+
+
+def sectorkey(desc):
+    desc = np.ascontiguousarray(desc, dtype=np.float64)
+    out = np.empty(NS, dtype=np.float64)
+    lib().scref_sectorkey(desc.ctypes.data, out.ctypes.data)
+    return out
+
+
+def circshift(desc, k):
+    desc = np.ascontiguousarray(desc, dtype=np.float64)
+    out = np.empty_like(desc)
+    lib().scref_circshift(desc.ctypes.data, NR, NS, int(k), out.ctypes.data)
+    return out
+
+
+def dist_direct(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    return lib().scref_dist_direct(a.ctypes.data, b.ctypes.data)
+
+
+def fast_align(v1, v2):
+    v1 = np.ascontiguousarray(v1, dtype=np.float64)
+    v2 = np.ascontiguousarray(v2, dtype=np.float64)
+    return lib().scref_fast_align(v1.ctypes.data, v2.ctypes.data)
+
+
+def distance(a, b, search_ratio=0.1, literal=False):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    d = C.c_double()
+    s = C.c_int()
+    f = lib().scref_distance_literal if literal else lib().scref_distance
+    f(a.ctypes.data, b.ctypes.data, search_ratio, C.byref(d), C.byref(s))
+    return d.value, s.value
+
+
+def ringkey_l2(a, b):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return lib().scref_ringkey_l2(a.ctypes.data, b.ctypes.data, a.size)
+
+
+class Manager:
+    """Oracle counterpart of the reference SCManager (Scancontext.h:62-122)."""
+
+    def __init__(self, dist_thres=None):
+        self._L = lib()
+        self._h = self._L.scref_create()
+        if dist_thres is not None:
+            self.set_dist_thres(dist_thres)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.scref_destroy(self._h)
+            self._h = None
+
+    def set_dist_thres(self, t):
+        self._L.scref_set_dist_thres(self._h, float(t))
+
+    def set_params(self, lidar_height=2.0, max_radius=80.0, num_exclude_recent=30, num_candidates=3,
+                   tree_making_period=30, search_ratio=0.1):
+        self._L.scref_set_params(self._h, lidar_height, max_radius, num_exclude_recent, num_candidates,
+                                 tree_making_period, search_ratio)
+
+    def __len__(self):
+        return self._L.scref_size(self._h)
+
+    @property
+    def tree_size(self):
+        return self._L.scref_tree_size(self._h)
+
+    def add_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float32)
+        return self._L.scref_add_points(self._h, pts.ctypes.data, pts.shape[0], pts.shape[1])
+
+    def add_descriptor(self, desc):
+        desc = np.ascontiguousarray(desc, dtype=np.float64).reshape(-1)
+        assert desc.size == DS
+        return self._L.scref_add_descriptor(self._h, desc.ctypes.data)
+
+    def add_descriptors(self, descs):
+        for d in descs:
+            self.add_descriptor(d)
+
+    def descriptor(self, i):
+        return np.ctypeslib.as_array(self._L.scref_get_descriptor(self._h, i), shape=(DS,)).copy()
+
+    def ringkey_f32(self, i):
+        return np.ctypeslib.as_array(self._L.scref_get_ringkey_f32(self._h, i), shape=(NR,)).copy()
+
+    def sectorkey(self, i):
+        return np.ctypeslib.as_array(self._L.scref_get_sectorkey(self._h, i), shape=(NS,)).copy()
+
+    def knn(self, key, n_search, k=3):
+        key = np.ascontiguousarray(key, dtype=np.float32)
+        idx = np.zeros(k, dtype=np.int64)
+        dist = np.zeros(k, dtype=np.float32)
+        found = self._L.scref_knn(self._h, key.ctypes.data, n_search, k, idx.ctypes.data, dist.ctypes.data)
+        return found, idx, dist
+
+    def detect_loop_closure(self):
+        yaw = C.c_float()
+        md = C.c_double()
+        nn = C.c_int()
+        lid = self._L.scref_detect_loop_closure(self._h, C.byref(yaw), C.byref(md), C.byref(nn))
+        return lid, yaw.value, md.value, nn.value
+
+    def detect_between_session(self, key, desc):
+        key = np.ascontiguousarray(key, dtype=np.float32)
+        desc = np.ascontiguousarray(desc, dtype=np.float64)
+        yaw = C.c_float()
+        md = C.c_double()
+        nn = C.c_int()
+        lid = self._L.scref_detect_between_session(self._h, key.ctypes.data, desc.ctypes.data,
+                                                   C.byref(yaw), C.byref(md), C.byref(nn))
+        return lid, yaw.value, md.value, nn.value
+
+    def exhaustive(self, qdesc, n_eligible=None, k=1, nthreads=1):
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.float64)
+        if n_eligible is None:
+            n_eligible = len(self)
+        out = np.zeros(k, dtype=HIT_DTYPE)
+        self._L.scref_exhaustive(self._h, qdesc.ctypes.data, n_eligible, k, out.ctypes.data, nthreads)
+        return out
+
+    def pair_distances(self, qdesc, first=0, count=None, nthreads=1):
+        qdesc = np.ascontiguousarray(qdesc, dtype=np.float64)
+        if count is None:
+            count = len(self) - first
+        dist = np.empty(count, dtype=np.float64)
+        shift = np.empty(count, dtype=np.int32)
+        self._L.scref_pair_distances(self._h, qdesc.ctypes.data, first, count, dist.ctypes.data,
+                                     shift.ctypes.data, nthreads)
+        return dist, shift
+
+
+def merge_topk(parts, k):
+    """parts: (nparts, k) HIT_DTYPE -> (k,) HIT_DTYPE."""
+    parts = np.ascontiguousarray(parts, dtype=HIT_DTYPE)
+    out = np.zeros(k, dtype=HIT_DTYPE)
+    lib().scref_merge_topk(parts.ctypes.data, parts.shape[0], k, out.ctypes.data)
+    return out
+
+
+class RefKdTree:
+    """The reference's InvKeyTree (nanoflann) compiled from /root/reference (oracle/_ref)."""
+
+    def __init__(self, keys):
+        self._R = ref_lib()
+        if self._R is None:
+            raise RuntimeError("oracle/_ref/libref_kdtree.so not built")
+        keys = np.ascontiguousarray(keys, dtype=np.float32)
+        self._h = self._R.ref_kdtree_build(keys.ctypes.data, keys.shape[0], keys.shape[1])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._R.ref_kdtree_free(self._h)
+            self._h = None
+
+    def knn(self, q, k=3):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        idx = np.zeros(k, dtype=np.uint64)
+        dist = np.zeros(k, dtype=np.float32)
+        n = self._R.ref_kdtree_knn(self._h, q.ctypes.data, k, idx.ctypes.data, dist.ctypes.data)
+        return n, idx.astype(np.int64), dist
