@@ -1,0 +1,163 @@
+/*
+ * rsx.h -- C-ABI of librsx.so: the MI355X-native (gfx950, HIP) ScanContext + ORORA hot path of
+ * navtech-radar-slam.  Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Reference interfaces each group replaces (paths under the reference checkout):
+ *   SC  = pgo/SC-A-LOAM/include/scancontext/Scancontext.{h,cpp}
+ *   PGO = pgo/SC-A-LOAM/src/laserPosegraphOptimization.cpp
+ *
+ * Conventions
+ *   - every function returns an rsx_status (0 = ok, <0 = error); a loop id of -1 is DATA ("no
+ *     loop", SC.cpp:333), not an error.  No C++ exception crosses the ABI.
+ *     rsx_last_error_string() gives a thread-local diagnostic.
+ *   - the caller owns every buffer it passes; the library copies inputs before returning and
+ *     writes outputs into caller memory.  Pointers named d_* are DEVICE (HBM) pointers of the
+ *     handle's GPU and are used asynchronously on the given hipStream_t (passed as void*).
+ *   - a handle is internally synchronised: one writer (PGO.cpp:492, process_pg) and one reader
+ *     (PGO.cpp:561, process_lcd) may call concurrently (the reference itself races here).
+ *   - there is NO CPU fallback: without a usable HIP device rsx_*_create fails with
+ *     RSX_ERR_NO_DEVICE.
+ *
+ * Descriptor layouts
+ *   - "colmajor double": 20 x 60 Eigen::MatrixXd memory order (SC.cpp:159), element
+ *     (ring r, sector s) at [s*20 + r]; 9600 B.
+ *   - "f32 sector-major": the same order in float, 4800 B; every descriptor the reference can
+ *     build is exactly representable in fp32 (SC.cpp:168: pt.z is a float).
+ */
+#ifndef RSX_H
+#define RSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSX_SC_NUM_RING 20    /* SC.h:85  PC_NUM_RING   */
+#define RSX_SC_NUM_SECTOR 60  /* SC.h:86  PC_NUM_SECTOR */
+#define RSX_SC_DESC_SIZE 1200
+#define RSX_SC_MAX_TOPK 32
+
+typedef enum {
+  RSX_OK = 0,
+  RSX_ERR_BAD_ARG = -1,
+  RSX_ERR_NO_DEVICE = -2,
+  RSX_ERR_HIP = -3,
+  RSX_ERR_OOM = -4,
+  RSX_ERR_NOT_FP32_EXACT = -5, /* a colmajor-double descriptor does not round-trip through fp32 */
+  RSX_ERR_RANGE = -6,
+  RSX_ERR_INTERNAL = -7
+} rsx_status;
+
+const char *rsx_last_error_string(void);
+/* "rsx <version> gfx950 ..." */
+const char *rsx_version(void);
+/* number of visible HIP devices (0 on a box without a GPU; never an error) */
+int rsx_device_count(void);
+
+/* ============================== ScanContext (SC.h:62-122) ============================== */
+
+typedef struct rsx_sc rsx_sc; /* replaces a `SCManager` instance (PGO.cpp:99) */
+
+/* one loop candidate: distanceBtnScanContext() result (SC.cpp:116-148) + DB index */
+typedef struct {
+  double dist;   /* min over the searched column shifts of the mean column cosine distance */
+  int32_t index; /* GLOBAL keyframe index */
+  int32_t shift; /* argmin column shift; yaw = shift * 6 deg */
+} rsx_sc_hit;
+
+typedef struct {
+  double lidar_height;        /* SC.h:83  LIDAR_HEIGHT = 2.0 */
+  double max_radius;          /* SC.h:87  PC_MAX_RADIUS = 80 */
+  int32_t num_exclude_recent; /* SC.h:92  = 30 */
+  int32_t num_candidates;     /* SC.h:93  NUM_CANDIDATES_FROM_TREE = 3 (<= 32) */
+  double search_ratio;        /* SC.h:96  = 0.1 (kernels are specialised for the resulting +-3 window) */
+  double dist_thres;          /* SC.h:99  SC_DIST_THRES = 0.2 (sc_pgo.launch:4 sets 0.45) */
+  int32_t tree_making_period; /* SC.h:103 = 30 */
+  int32_t device;             /* HIP device ordinal */
+  /* DB sharding over GPUs: this handle stores the entries whose global index i has
+   * i % shard_world == shard_rank (block-cyclic), local slot i / shard_world. */
+  int32_t shard_rank;         /* default 0 */
+  int32_t shard_world;        /* default 1 */
+  int64_t capacity_hint;      /* initial DB capacity in entries (grows by doubling) */
+} rsx_sc_params;
+
+typedef enum {
+  RSX_SC_MODE_CANDIDATE = 0, /* reference semantics: ring-key 3-NN then 3 pair distances (SC.cpp:331-422) */
+  RSX_SC_MODE_EXHAUSTIVE = 1 /* same pair function against every eligible entry */
+} rsx_sc_mode;
+
+int rsx_sc_default_params(rsx_sc_params *p);
+int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out);   /* SCManager() */
+int rsx_sc_destroy(rsx_sc *h);
+int rsx_sc_set_dist_thres(rsx_sc *h, double thres);        /* setSCdistThres, SC.cpp:262-265 */
+/* number of keyframes known to this handle (GLOBAL count; a shard stores ~1/world of them) */
+int rsx_sc_size(rsx_sc *h, int64_t *n_global);
+int rsx_sc_local_size(rsx_sc *h, int64_t *n_local);
+
+/* makeAndSaveScancontextAndKeys (SC.cpp:249-260).  pts: n points, stride_bytes apart
+ * (32 for pcl::PointXYZI), float x,y,z at byte offsets 0,4,8.  The descriptor, ring key, sector
+ * key and column norms are built on the GPU.  In a sharded handle every rank must call this for
+ * every keyframe (same order); ranks that do not own the slot only advance the global count.
+ * out_index (optional) = global index of the new keyframe. */
+int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index);
+/* saveScancontextAndKeys (SC.cpp:236-246), colmajor double; RSX_ERR_NOT_FP32_EXACT if lossy */
+int rsx_sc_add_descriptor(rsx_sc *h, const double *desc_colmajor, int32_t *out_index);
+/* bulk import of n f32 sector-major descriptors (host memory); same sharding rule */
+int rsx_sc_add_descriptors_f32(rsx_sc *h, const float *descs, int64_t n);
+/* the same from DEVICE memory (no host round trip), n consecutive global keyframes */
+int rsx_sc_add_descriptors_f32_device(rsx_sc *h, const float *d_descs, int64_t n, void *stream);
+
+/* polarcontexts_[i] / getConstRefRecentSCD (SC.h:79,111): global index must be owned by this shard */
+int rsx_sc_get_descriptor(rsx_sc *h, int64_t index, double *out_colmajor);
+int rsx_sc_get_ringkey(rsx_sc *h, int64_t index, float *out20);     /* polarcontext_invkeys_mat_ */
+int rsx_sc_get_sectorkey(rsx_sc *h, int64_t index, double *out60);  /* polarcontext_vkeys_ */
+
+/* detectLoopClosureID (SC.cpp:331-422).  loop_id/-1 and yaw are the reference's return pair;
+ * min_dist / nn_idx (optional) are the values of its log line (SC.cpp:406,412).
+ * mode CANDIDATE reproduces the reference (frozen searchable prefix rebuilt every
+ * tree_making_period calls, NUM_EXCLUDE_RECENT, kNN order, strict-< first-wins);
+ * mode EXHAUSTIVE scores the whole frozen prefix.  Unsharded handles only. */
+int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw_diff_rad,
+                               double *min_dist, int32_t *nn_idx);
+/* detectLoopClosureIDBetweenSession (SC.cpp:267-328): query passed in, tree over the whole DB
+ * as of the first call. */
+int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const double *curr_desc_colmajor,
+                                  int32_t *loop_id, float *yaw_diff_rad, double *min_dist,
+                                  int32_t *nn_idx);
+/* current frozen searchable prefix length ("tree" size, SC.cpp:352-353) */
+int rsx_sc_tree_size(rsx_sc *h, int64_t *n);
+
+/* Exhaustive batched query (the north-star path): nq f32 sector-major query descriptors against
+ * every LOCAL entry whose global index < n_eligible (n_eligible < 0: all); out = nq x k records
+ * sorted by (dist, index), padded with {1e7, 0, 0} (SC.cpp:362-364 initial values).
+ * Host-buffer form (synchronous): */
+int rsx_sc_query(rsx_sc *h, const float *q_descs, int32_t nq, int32_t k, int64_t n_eligible,
+                 rsx_sc_hit *out);
+/* Device-buffer form: asynchronous on `stream` (hipStream_t); d_out stays on the GPU so a sharded
+ * caller can all-gather it (RCCL) without a host hop. */
+int rsx_sc_query_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k, int64_t n_eligible,
+                        rsx_sc_hit *d_out, void *stream);
+/* queries = DB entries [q_first, q_first+nq) of this handle (all-pairs runs, BASELINE config 5);
+ * each query i uses n_eligible = min(n_eligible, q_first+i - exclude_recent) when exclude_recent >= 0 */
+int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, int64_t n_eligible,
+                             int32_t exclude_recent, rsx_sc_hit *d_out, void *stream);
+/* parity helper: dist/shift of ONE query against local entries [first, first+count) (host out) */
+int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t count,
+                          double *out_dist, int32_t *out_shift);
+/* merge nparts per-shard top-k lists (layout [part][nq][k]) into out[nq][k]; pure host logic */
+int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out);
+/* the same on the GPU (d_parts is what an RCCL all-gather of d_out produces) */
+int rsx_sc_merge_topk_device(rsx_sc *h, const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq,
+                             int32_t k, rsx_sc_hit *d_out, void *stream);
+/* apply the loop threshold + yaw conversion of SC.cpp:401-417 to a top-1 record */
+int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float *yaw_diff_rad);
+
+/* instrumentation for bench.py: name and launch count of the dominant kernel */
+const char *rsx_sc_dominant_kernel_name(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSX_H */

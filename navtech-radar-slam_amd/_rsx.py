@@ -1,0 +1,104 @@
+"""ctypes binding of librsx.so (include/rsx.h).  Thin: argument marshalling and status -> exception.
+
+The library is the product; this module never computes anything itself and there is no CPU
+fallback: if librsx.so is missing or no GPU is visible, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librsx.so")
+
+NUM_RING, NUM_SECTOR, DESC_SIZE, MAX_TOPK = 20, 60, 1200, 32
+MODE_CANDIDATE, MODE_EXHAUSTIVE = 0, 1
+
+HIT_DTYPE = np.dtype([("dist", "<f8"), ("index", "<i4"), ("shift", "<i4")])
+
+
+class RsxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"rsx status {status}: {msg}")
+        self.status = status
+
+
+class ScParams(C.Structure):
+    _fields_ = [
+        ("lidar_height", C.c_double),
+        ("max_radius", C.c_double),
+        ("num_exclude_recent", C.c_int32),
+        ("num_candidates", C.c_int32),
+        ("search_ratio", C.c_double),
+        ("dist_thres", C.c_double),
+        ("tree_making_period", C.c_int32),
+        ("device", C.c_int32),
+        ("shard_rank", C.c_int32),
+        ("shard_world", C.c_int32),
+        ("capacity_hint", C.c_int64),
+    ]
+
+
+_lib = None
+
+# every symbol include/rsx.h declares (tests check the .so exports exactly these)
+SYMBOLS = [
+    "rsx_last_error_string", "rsx_version", "rsx_device_count",
+    "rsx_sc_default_params", "rsx_sc_create", "rsx_sc_destroy", "rsx_sc_set_dist_thres", "rsx_sc_size",
+    "rsx_sc_local_size", "rsx_sc_add_points", "rsx_sc_add_descriptor", "rsx_sc_add_descriptors_f32",
+    "rsx_sc_add_descriptors_f32_device", "rsx_sc_get_descriptor", "rsx_sc_get_ringkey",
+    "rsx_sc_get_sectorkey", "rsx_sc_detect_loop_closure", "rsx_sc_detect_between_session",
+    "rsx_sc_tree_size", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_self_device",
+    "rsx_sc_pair_distances", "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
+    "rsx_sc_dominant_kernel_name",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RsxError(-7, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = C.CDLL(LIB_PATH)
+        L.rsx_last_error_string.restype = C.c_char_p
+        L.rsx_version.restype = C.c_char_p
+        L.rsx_sc_dominant_kernel_name.restype = C.c_char_p
+        vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+        L.rsx_sc_default_params.argtypes = [C.POINTER(ScParams)]
+        L.rsx_sc_create.argtypes = [C.POINTER(ScParams), C.POINTER(vp)]
+        L.rsx_sc_destroy.argtypes = [vp]
+        L.rsx_sc_set_dist_thres.argtypes = [vp, dbl]
+        L.rsx_sc_size.argtypes = [vp, C.POINTER(i64)]
+        L.rsx_sc_local_size.argtypes = [vp, C.POINTER(i64)]
+        L.rsx_sc_tree_size.argtypes = [vp, C.POINTER(i64)]
+        L.rsx_sc_add_points.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(i32)]
+        L.rsx_sc_add_descriptor.argtypes = [vp, vp, C.POINTER(i32)]
+        L.rsx_sc_add_descriptors_f32.argtypes = [vp, vp, i64]
+        L.rsx_sc_add_descriptors_f32_device.argtypes = [vp, vp, i64, vp]
+        L.rsx_sc_get_descriptor.argtypes = [vp, i64, vp]
+        L.rsx_sc_get_ringkey.argtypes = [vp, i64, vp]
+        L.rsx_sc_get_sectorkey.argtypes = [vp, i64, vp]
+        L.rsx_sc_detect_loop_closure.argtypes = [vp, C.c_int, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(i32)]
+        L.rsx_sc_detect_between_session.argtypes = [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(i32)]
+        L.rsx_sc_query.argtypes = [vp, vp, i32, i32, i64, vp]
+        L.rsx_sc_query_device.argtypes = [vp, vp, i32, i32, i64, vp, vp]
+        L.rsx_sc_query_self_device.argtypes = [vp, i64, i32, i32, i64, i32, vp, vp]
+        L.rsx_sc_pair_distances.argtypes = [vp, vp, i64, i64, vp, vp]
+        L.rsx_sc_merge_topk.argtypes = [vp, i32, i32, i32, vp]
+        L.rsx_sc_merge_topk_device.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+        L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != 0:
+        raise RsxError(status, lib().rsx_last_error_string().decode())
+
+
+def device_count():
+    return lib().rsx_device_count()
+
+
+def version():
+    return lib().rsx_version().decode()

@@ -1,0 +1,79 @@
+// rsx_common.h -- shared host-side plumbing of librsx.so (error reporting, HIP checks).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <string>
+
+#include "rsx.h"
+
+namespace rsx {
+
+std::string &last_error();
+
+inline int fail(int code, const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error() = buf;
+  return code;
+}
+
+#define RSX_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess)                                                                     \
+      return rsx::fail(_e == hipErrorOutOfMemory ? RSX_ERR_OOM : RSX_ERR_HIP, "%s failed: %s", \
+                       #expr, hipGetErrorString(_e));                                         \
+  } while (0)
+
+#define RSX_TRY(expr)          \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != RSX_OK) return _s; \
+  } while (0)
+
+// growable device buffer (never shrinks); contents preserved on growth when keep=true
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t want, hipStream_t s, bool keep) {
+    if (want <= bytes) return RSX_OK;
+    size_t nb = bytes ? bytes : 4096;
+    while (nb < want) nb *= 2;
+    void *np = nullptr;
+    RSX_HIP(hipMalloc(&np, nb));
+    if (keep && p && bytes) {
+      hipError_t e = hipMemcpyAsync(np, p, bytes, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) {
+        (void)hipFree(np);
+        return fail(RSX_ERR_HIP, "DevBuf grow copy: %s", hipGetErrorString(e));
+      }
+    } else if (p) {
+      hipError_t e = hipStreamSynchronize(s);
+      if (e != hipSuccess) {
+        (void)hipFree(np);
+        return fail(RSX_ERR_HIP, "DevBuf grow sync: %s", hipGetErrorString(e));
+      }
+    }
+    if (p) (void)hipFree(p);
+    p = np;
+    bytes = nb;
+    return RSX_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  template <typename T>
+  T *as() const {
+    return static_cast<T *>(p);
+  }
+};
+
+}  // namespace rsx

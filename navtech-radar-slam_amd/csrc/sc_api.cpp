@@ -1,0 +1,580 @@
+// sc_api.cpp -- C-ABI of the ScanContext path (include/rsx.h): database shard management and the
+// reference's detector state machine (Scancontext.cpp:236-422) on top of the HIP kernels.
+// Host logic only; every descriptor/key/distance is computed on the GPU.  There is no CPU fallback.
+#include <cmath>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rsx_common.h"
+#include "sc_kernels.h"
+
+namespace rsx {
+std::string &last_error() {
+  static thread_local std::string e;
+  return e;
+}
+}  // namespace rsx
+
+using namespace rsx;
+using namespace rsx::sc;
+
+struct rsx_sc {
+  rsx_sc_params p;
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  // database shard (SoA in HBM)
+  int64_t n_global = 0, n_local = 0, cap = 0;
+  DevBuf desc, vkey, norm, rkey;
+  // detector state (SC.h:104,117-120)
+  int tree_counter = 0;
+  int64_t tree_size = 0;
+  bool batch_made = false;
+  int64_t batch_size = 0;
+  // workspaces
+  DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
+  void *pinned = nullptr;  // small pinned host staging (results)
+  size_t pinned_bytes = 0;
+};
+
+namespace {
+
+int set_device(rsx_sc *h) {
+  RSX_HIP(hipSetDevice(h->p.device));
+  return RSX_OK;
+}
+
+int ensure_capacity(rsx_sc *h, int64_t want_local) {
+  if (want_local <= h->cap) return RSX_OK;
+  int64_t nc = h->cap ? h->cap : 1024;
+  while (nc < want_local) nc *= 2;
+  RSX_TRY(h->desc.reserve((size_t)nc * DS * sizeof(float), h->stream, true));
+  RSX_TRY(h->vkey.reserve((size_t)nc * NS * sizeof(double), h->stream, true));
+  RSX_TRY(h->norm.reserve((size_t)nc * NS * sizeof(double), h->stream, true));
+  RSX_TRY(h->rkey.reserve((size_t)nc * NR * sizeof(float), h->stream, true));
+  h->cap = nc;
+  return RSX_OK;
+}
+
+DbView db_view(const rsx_sc *h) {
+  DbView v;
+  v.desc = h->desc.as<float>();
+  v.vkey = h->vkey.as<double>();
+  v.norm = h->norm.as<double>();
+  v.rkey = h->rkey.as<float>();
+  v.n_local = h->n_local;
+  v.idx_base = h->p.shard_rank;
+  v.idx_stride = h->p.shard_world;
+  return v;
+}
+
+bool owns(const rsx_sc *h, int64_t g) { return (g % h->p.shard_world) == h->p.shard_rank; }
+
+// number of local slots whose global index is < n_eligible
+int64_t local_count_below(const rsx_sc *h, int64_t n_eligible) {
+  if (n_eligible < 0 || n_eligible > h->n_global) n_eligible = h->n_global;
+  const int64_t w = h->p.shard_world, r = h->p.shard_rank;
+  if (n_eligible <= r) return 0;
+  int64_t c = (n_eligible - r + w - 1) / w;
+  return c < h->n_local ? c : h->n_local;
+}
+
+// SC.cpp:17-20,417: deg2rad(float) of nn_align * PC_UNIT_SECTORANGLE
+float yaw_from_shift(int shift) {
+  const double unit = 360.0 / (double)NS;  // SC.h:88
+  const float deg = (float)(shift * unit);
+  return (float)((double)deg * M_PI / 180.0);
+}
+
+int ensure_pinned(rsx_sc *h, size_t bytes) {
+  if (bytes <= h->pinned_bytes) return RSX_OK;
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  h->pinned = nullptr;
+  h->pinned_bytes = 0;
+  size_t nb = 4096;
+  while (nb < bytes) nb *= 2;
+  RSX_HIP(hipHostMalloc(&h->pinned, nb, hipHostMallocDefault));
+  h->pinned_bytes = nb;
+  return RSX_OK;
+}
+
+// keys for nq query descriptors already in h->q_desc (or external device pointer)
+int prepare_queries(rsx_sc *h, const float *d_q, int32_t nq, hipStream_t s, QueryView *qv) {
+  RSX_TRY(h->q_vkey.reserve((size_t)nq * NS * sizeof(double), s, false));
+  RSX_TRY(h->q_norm.reserve((size_t)nq * NS * sizeof(double), s, false));
+  RSX_TRY(h->q_rkey.reserve((size_t)nq * NR * sizeof(float), s, false));
+  RSX_TRY(launch_keys(d_q, nq, h->q_vkey.as<double>(), h->q_norm.as<double>(), h->q_rkey.as<float>(), s));
+  qv->desc = d_q;
+  qv->vkey = h->q_vkey.as<double>();
+  qv->norm = h->q_norm.as<double>();
+  qv->nq = nq;
+  return RSX_OK;
+}
+
+int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
+             int32_t k, rsx_sc_hit *d_out, hipStream_t s) {
+  RSX_TRY(h->partial.reserve(pair_partial_bytes(n_items > 0 ? n_items : 1, qv.nq, k), s, false));
+  return launch_pairs(db_view(h), qv, nullptr, 0, n_items, n_eligible, d_q_elig, nullptr, nullptr,
+                      h->partial.as<rsx_sc_hit>(), d_out, k, s);
+}
+
+// candidate scoring shared by detect_loop_closure / between_session (SC.cpp:362-417)
+int score_candidates_and_finish(rsx_sc *h, const QueryView &qv, const float *d_qkey, int64_t n_search,
+                                int mode, int32_t *loop_id, float *yaw, double *min_dist, int32_t *nn_idx) {
+  hipStream_t s = h->stream;
+  const int k = h->p.num_candidates;
+  double best_d = 10000000;  // SC.cpp:362
+  int best_align = 0, best_idx = 0;
+  if (mode == RSX_SC_MODE_CANDIDATE) {
+    RSX_TRY(h->knn_ws.reserve((size_t)(n_search > 0 ? n_search : 1) * sizeof(float), s, false));
+    RSX_TRY(h->small.reserve(4096, s, false));
+    int32_t *d_idx = h->small.as<int32_t>();              // [k]
+    float *d_kd = reinterpret_cast<float *>(d_idx + 64);  // [k]
+    int32_t *d_found = d_idx + 128;
+    RSX_TRY(launch_knn(h->rkey.as<float>(), n_search, d_qkey, k, h->knn_ws.as<float>(), d_idx, d_kd, d_found, s));
+    RSX_TRY(h->pair_out.reserve((size_t)k * (sizeof(double) + sizeof(int32_t)), s, false));
+    double *d_dist = h->pair_out.as<double>();
+    int32_t *d_shift = reinterpret_cast<int32_t *>(d_dist + k);
+    RSX_TRY(launch_pairs(db_view(h), qv, d_idx, 0, k, -1, nullptr, d_dist, d_shift, nullptr, nullptr, 0, s));
+    RSX_TRY(ensure_pinned(h, 1024));
+    char *hp = static_cast<char *>(h->pinned);
+    RSX_HIP(hipMemcpyAsync(hp, d_idx, k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipMemcpyAsync(hp + 256, d_dist, k * sizeof(double), hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipMemcpyAsync(hp + 512, d_shift, k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipStreamSynchronize(s));
+    const int32_t *ci = reinterpret_cast<const int32_t *>(hp);
+    const double *cd = reinterpret_cast<const double *>(hp + 256);
+    const int32_t *cs = reinterpret_cast<const int32_t *>(hp + 512);
+    for (int c = 0; c < k; c++) {  // SC.cpp:380-395: kNN order, strict <
+      if (cd[c] < best_d) {
+        best_d = cd[c];
+        best_align = cs[c];
+        best_idx = ci[c];
+      }
+    }
+  } else {
+    RSX_TRY(h->topk.reserve(sizeof(rsx_sc_hit), s, false));
+    RSX_TRY(run_topk(h, qv, n_search, n_search, nullptr, 1, h->topk.as<rsx_sc_hit>(), s));
+    RSX_TRY(ensure_pinned(h, 1024));
+    RSX_HIP(hipMemcpyAsync(h->pinned, h->topk.p, sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipStreamSynchronize(s));
+    const rsx_sc_hit *r = static_cast<const rsx_sc_hit *>(h->pinned);
+    if (r->dist < best_d) {
+      best_d = r->dist;
+      best_align = r->shift;
+      best_idx = r->index;
+    }
+  }
+  int lid = -1;
+  if (best_d < h->p.dist_thres) lid = best_idx;  // SC.cpp:401-403
+  if (loop_id) *loop_id = lid;
+  if (yaw) *yaw = yaw_from_shift(best_align);    // SC.cpp:417
+  if (min_dist) *min_dist = best_d;
+  if (nn_idx) *nn_idx = best_idx;
+  return RSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *rsx_last_error_string(void) { return rsx::last_error().c_str(); }
+
+const char *rsx_version(void) { return "rsx 0.1 (gfx950, HIP; ScanContext + ORORA hot path)"; }
+
+int rsx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char *rsx_sc_dominant_kernel_name(void) { return pair_kernel_name(); }
+
+int rsx_sc_default_params(rsx_sc_params *p) {
+  if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
+  p->lidar_height = 2.0;
+  p->max_radius = 80.0;
+  p->num_exclude_recent = 30;
+  p->num_candidates = 3;
+  p->search_ratio = 0.1;
+  p->dist_thres = 0.2;
+  p->tree_making_period = 30;
+  p->device = 0;
+  p->shard_rank = 0;
+  p->shard_world = 1;
+  p->capacity_hint = 1024;
+  return RSX_OK;
+}
+
+int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) {
+  if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
+  *out = nullptr;
+  rsx_sc_params d;
+  rsx_sc_default_params(&d);
+  if (p) d = *p;
+  if (d.shard_world < 1 || d.shard_rank < 0 || d.shard_rank >= d.shard_world)
+    return fail(RSX_ERR_BAD_ARG, "bad shard %d/%d", d.shard_rank, d.shard_world);
+  if (d.num_candidates < 1 || d.num_candidates > RSX_SC_MAX_TOPK)
+    return fail(RSX_ERR_BAD_ARG, "num_candidates must be in [1,%d]", RSX_SC_MAX_TOPK);
+  if ((int)std::lround(0.5 * d.search_ratio * NS) != 3)
+    return fail(RSX_ERR_BAD_ARG, "kernels are specialised for SEARCH_RADIUS 3 (search_ratio 0.1, SC.h:96)");
+  if (d.tree_making_period < 1 || d.num_exclude_recent < 0) return fail(RSX_ERR_BAD_ARG, "bad detector params");
+  int ndev = rsx_device_count();
+  if (ndev <= 0) return fail(RSX_ERR_NO_DEVICE, "no HIP device visible (librsx has no CPU fallback)");
+  if (d.device < 0 || d.device >= ndev) return fail(RSX_ERR_NO_DEVICE, "device %d out of range (%d visible)", d.device, ndev);
+  rsx_sc *h = new (std::nothrow) rsx_sc();
+  if (!h) return fail(RSX_ERR_OOM, "host alloc");
+  h->p = d;
+  int st = set_device(h);
+  if (st == RSX_OK) {
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) st = fail(RSX_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  if (st == RSX_OK) st = ensure_capacity(h, d.capacity_hint > 0 ? d.capacity_hint : 1024);
+  if (st != RSX_OK) {
+    rsx_sc_destroy(h);
+    return st;
+  }
+  *out = h;
+  return RSX_OK;
+}
+
+int rsx_sc_destroy(rsx_sc *h) {
+  if (!h) return RSX_OK;
+  (void)hipSetDevice(h->p.device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
+                    &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
+    b->release();
+  if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return RSX_OK;
+}
+
+int rsx_sc_set_dist_thres(rsx_sc *h, double thres) {
+  if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->p.dist_thres = thres;
+  return RSX_OK;
+}
+
+int rsx_sc_size(rsx_sc *h, int64_t *n) {
+  if (!h || !n) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  *n = h->n_global;
+  return RSX_OK;
+}
+
+int rsx_sc_local_size(rsx_sc *h, int64_t *n) {
+  if (!h || !n) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  *n = h->n_local;
+  return RSX_OK;
+}
+
+int rsx_sc_tree_size(rsx_sc *h, int64_t *n) {
+  if (!h || !n) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  *n = h->tree_size;
+  return RSX_OK;
+}
+
+int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index) {
+  if (!h || (!pts && n)) return fail(RSX_ERR_BAD_ARG, "null arg");
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  const int64_t g = h->n_global;
+  if (owns(h, g)) {
+    const int64_t slot = h->n_local;
+    RSX_TRY(ensure_capacity(h, slot + 1));
+    const size_t bytes = n * stride_bytes;
+    RSX_TRY(h->pts_ws.reserve(bytes ? bytes : 16, h->stream, false));
+    if (bytes) RSX_HIP(hipMemcpyAsync(h->pts_ws.p, pts, bytes, hipMemcpyHostToDevice, h->stream));
+    RSX_TRY(launch_build(h->pts_ws.p, (int64_t)n, (int64_t)stride_bytes, h->p.lidar_height, h->p.max_radius,
+                         h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS,
+                         h->norm.as<double>() + slot * NS, h->rkey.as<float>() + slot * NR, h->stream));
+    RSX_HIP(hipStreamSynchronize(h->stream));  // caller may reuse pts; entry visible to detect()
+    h->n_local = slot + 1;
+  }
+  h->n_global = g + 1;
+  if (out_index) *out_index = (int32_t)g;
+  return RSX_OK;
+}
+
+static int add_f32_locked(rsx_sc *h, const float *src, int64_t n, bool src_is_device, hipStream_t s) {
+  // n consecutive global keyframes starting at h->n_global; copy the owned rows
+  const int64_t g0 = h->n_global;
+  const int64_t w = h->p.shard_world, r = h->p.shard_rank;
+  int64_t first = g0 + (((r - g0) % w) + w) % w;  // first owned global index >= g0
+  int64_t count = first < g0 + n ? (g0 + n - first + w - 1) / w : 0;
+  if (count > 0) {
+    const int64_t slot = h->n_local;
+    RSX_TRY(ensure_capacity(h, slot + count));
+    float *dst = h->desc.as<float>() + slot * DS;
+    RSX_HIP(hipMemcpy2DAsync(dst, DS * sizeof(float), src + (first - g0) * DS, (size_t)w * DS * sizeof(float),
+                             DS * sizeof(float), (size_t)count,
+                             src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
+    RSX_TRY(launch_keys(dst, count, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
+                        h->rkey.as<float>() + slot * NR, s));
+    RSX_HIP(hipStreamSynchronize(s));
+    h->n_local = slot + count;
+  }
+  h->n_global = g0 + n;
+  return RSX_OK;
+}
+
+int rsx_sc_add_descriptor(rsx_sc *h, const double *desc, int32_t *out_index) {
+  if (!h || !desc) return fail(RSX_ERR_BAD_ARG, "null arg");
+  float f[DS];
+  for (int i = 0; i < DS; i++) {
+    f[i] = (float)desc[i];
+    if (!((double)f[i] == desc[i]))  // also rejects NaN
+      return fail(RSX_ERR_NOT_FP32_EXACT, "descriptor element %d (%.17g) is not exactly representable in fp32", i, desc[i]);
+  }
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  const int64_t g = h->n_global;
+  RSX_TRY(add_f32_locked(h, f, 1, false, h->stream));
+  if (out_index) *out_index = (int32_t)g;
+  return RSX_OK;
+}
+
+int rsx_sc_add_descriptors_f32(rsx_sc *h, const float *descs, int64_t n) {
+  if (!h || (!descs && n) || n < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (n == 0) return RSX_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  return add_f32_locked(h, descs, n, false, h->stream);
+}
+
+int rsx_sc_add_descriptors_f32_device(rsx_sc *h, const float *d_descs, int64_t n, void *stream) {
+  if (!h || (!d_descs && n) || n < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (n == 0) return RSX_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  return add_f32_locked(h, d_descs, n, true, s);
+}
+
+static int local_slot_of(rsx_sc *h, int64_t index, int64_t *slot) {
+  if (index < 0 || index >= h->n_global) return fail(RSX_ERR_RANGE, "index %lld out of range [0,%lld)", (long long)index, (long long)h->n_global);
+  if (!owns(h, index)) return fail(RSX_ERR_RANGE, "index %lld is not stored on shard %d/%d", (long long)index, h->p.shard_rank, h->p.shard_world);
+  *slot = index / h->p.shard_world;
+  return RSX_OK;
+}
+
+int rsx_sc_get_descriptor(rsx_sc *h, int64_t index, double *out) {
+  if (!h || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  int64_t slot;
+  RSX_TRY(local_slot_of(h, index, &slot));
+  float f[DS];
+  RSX_HIP(hipMemcpyAsync(f, h->desc.as<float>() + slot * DS, sizeof(f), hipMemcpyDeviceToHost, h->stream));
+  RSX_HIP(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < DS; i++) out[i] = (double)f[i];
+  return RSX_OK;
+}
+
+int rsx_sc_get_ringkey(rsx_sc *h, int64_t index, float *out20) {
+  if (!h || !out20) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  int64_t slot;
+  RSX_TRY(local_slot_of(h, index, &slot));
+  RSX_HIP(hipMemcpyAsync(out20, h->rkey.as<float>() + slot * NR, NR * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  RSX_HIP(hipStreamSynchronize(h->stream));
+  return RSX_OK;
+}
+
+int rsx_sc_get_sectorkey(rsx_sc *h, int64_t index, double *out60) {
+  if (!h || !out60) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  int64_t slot;
+  RSX_TRY(local_slot_of(h, index, &slot));
+  RSX_HIP(hipMemcpyAsync(out60, h->vkey.as<double>() + slot * NS, NS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  RSX_HIP(hipStreamSynchronize(h->stream));
+  return RSX_OK;
+}
+
+int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw, double *min_dist, int32_t *nn_idx) {
+  if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
+  if (mode != RSX_SC_MODE_CANDIDATE && mode != RSX_SC_MODE_EXHAUSTIVE) return fail(RSX_ERR_BAD_ARG, "bad mode %d", mode);
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "detect_loop_closure needs an unsharded handle; use rsx_sc_query_device + merge");
+  RSX_TRY(set_device(h));
+  const int64_t N = h->n_global;  // snapshot under the lock (the reference races here, PGO.cpp:561)
+  if (N == 0 || N < h->p.num_exclude_recent + 1) {  // SC.cpp:341-345
+    if (loop_id) *loop_id = -1;
+    if (yaw) *yaw = 0.0f;
+    if (min_dist) *min_dist = 10000000;
+    if (nn_idx) *nn_idx = 0;
+    return RSX_OK;
+  }
+  if (h->tree_counter % h->p.tree_making_period == 0)  // SC.cpp:348-359
+    h->tree_size = N - h->p.num_exclude_recent;
+  h->tree_counter = h->tree_counter + 1;               // SC.cpp:360
+  QueryView qv;
+  qv.desc = h->desc.as<float>() + (N - 1) * DS;        // SC.cpp:336
+  qv.vkey = h->vkey.as<double>() + (N - 1) * NS;
+  qv.norm = h->norm.as<double>() + (N - 1) * NS;
+  qv.nq = 1;
+  return score_candidates_and_finish(h, qv, h->rkey.as<float>() + (N - 1) * NR /* SC.cpp:335 */, h->tree_size,
+                                     mode, loop_id, yaw, min_dist, nn_idx);
+}
+
+int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const double *curr_desc, int32_t *loop_id,
+                                  float *yaw, double *min_dist, int32_t *nn_idx) {
+  if (!h || !curr_key20 || !curr_desc) return fail(RSX_ERR_BAD_ARG, "null arg");
+  float f[DS];
+  for (int i = 0; i < DS; i++) {
+    f[i] = (float)curr_desc[i];
+    if (!((double)f[i] == curr_desc[i])) return fail(RSX_ERR_NOT_FP32_EXACT, "query descriptor element %d is not fp32-exact", i);
+  }
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "unsharded handles only");
+  if (h->n_global == 0) return fail(RSX_ERR_RANGE, "empty database");  // reference asserts (KDA.h:61)
+  RSX_TRY(set_device(h));
+  if (!h->batch_made) {  // SC.cpp:275-284
+    h->batch_size = h->n_global;
+    h->batch_made = true;
+  }
+  hipStream_t s = h->stream;
+  RSX_TRY(h->q_desc.reserve(sizeof(f) + 128, s, false));
+  RSX_HIP(hipMemcpyAsync(h->q_desc.p, f, sizeof(f), hipMemcpyHostToDevice, s));
+  float *d_key = reinterpret_cast<float *>(static_cast<char *>(h->q_desc.p) + sizeof(f));
+  RSX_HIP(hipMemcpyAsync(d_key, curr_key20, NR * sizeof(float), hipMemcpyHostToDevice, s));
+  QueryView qv;
+  RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), 1, s, &qv));
+  return score_candidates_and_finish(h, qv, d_key, h->batch_size, RSX_SC_MODE_CANDIDATE, loop_id, yaw, min_dist, nn_idx);
+}
+
+int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out, void *stream) {
+  if (!h || !d_q || !d_out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  QueryView qv;
+  RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
+  const int64_t items = local_count_below(h, n_eligible);
+  return run_topk(h, qv, items, n_eligible < 0 ? h->n_global : n_eligible, nullptr, k, d_out, s);
+}
+
+int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) {
+  if (!h || !q || !out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    RSX_TRY(set_device(h));
+    RSX_TRY(h->q_desc.reserve((size_t)nq * DS * sizeof(float), h->stream, false));
+    RSX_TRY(h->topk.reserve((size_t)nq * k * sizeof(rsx_sc_hit), h->stream, false));
+    RSX_HIP(hipMemcpyAsync(h->q_desc.p, q, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  }
+  RSX_TRY(rsx_sc_query_device(h, h->q_desc.as<float>(), nq, k, n_eligible, h->topk.as<rsx_sc_hit>(), h->stream));
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipMemcpyAsync(out, h->topk.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, h->stream));
+  RSX_HIP(hipStreamSynchronize(h->stream));
+  return RSX_OK;
+}
+
+int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, int64_t n_eligible, int32_t exclude_recent,
+                             rsx_sc_hit *d_out, void *stream) {
+  if (!h || !d_out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "query_self needs an unsharded handle (queries must be local)");
+  if (q_first < 0 || q_first + nq > h->n_global) return fail(RSX_ERR_RANGE, "query range out of bounds");
+  RSX_TRY(set_device(h));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  QueryView qv;
+  qv.desc = h->desc.as<float>() + q_first * DS;
+  qv.vkey = h->vkey.as<double>() + q_first * NS;
+  qv.norm = h->norm.as<double>() + q_first * NS;
+  qv.nq = nq;
+  if (n_eligible < 0 || n_eligible > h->n_global) n_eligible = h->n_global;
+  const int64_t *d_elig = nullptr;
+  if (exclude_recent >= 0) {
+    std::vector<int64_t> e((size_t)nq);
+    for (int i = 0; i < nq; i++) {
+      int64_t v = q_first + i - exclude_recent;
+      e[(size_t)i] = v < 0 ? 0 : v;
+    }
+    RSX_TRY(h->q_elig.reserve((size_t)nq * sizeof(int64_t), s, false));
+    RSX_HIP(hipMemcpyAsync(h->q_elig.p, e.data(), (size_t)nq * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    RSX_HIP(hipStreamSynchronize(s));  // e is a stack/heap temporary
+    d_elig = h->q_elig.as<int64_t>();
+  }
+  return run_topk(h, qv, local_count_below(h, n_eligible), n_eligible, d_elig, k, d_out, s);
+}
+
+int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t count, double *out_dist, int32_t *out_shift) {
+  if (!h || !q_desc || !out_dist || !out_shift) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (first < 0 || count < 0 || first + count > h->n_local) return fail(RSX_ERR_RANGE, "range out of bounds");
+  if (count == 0) return RSX_OK;
+  RSX_TRY(set_device(h));
+  hipStream_t s = h->stream;
+  RSX_TRY(h->q_desc.reserve(DS * sizeof(float), s, false));
+  RSX_HIP(hipMemcpyAsync(h->q_desc.p, q_desc, DS * sizeof(float), hipMemcpyHostToDevice, s));
+  QueryView qv;
+  RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), 1, s, &qv));
+  RSX_TRY(h->pair_out.reserve((size_t)count * (sizeof(double) + sizeof(int32_t)), s, false));
+  double *d_dist = h->pair_out.as<double>();
+  int32_t *d_shift = reinterpret_cast<int32_t *>(d_dist + count);
+  RSX_TRY(launch_pairs(db_view(h), qv, nullptr, first, count, -1, nullptr, d_dist, d_shift, nullptr, nullptr, 0, s));
+  RSX_HIP(hipMemcpyAsync(out_dist, d_dist, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipMemcpyAsync(out_shift, d_shift, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  return RSX_OK;
+}
+
+int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out) {
+  if (!parts || !out || nparts < 1 || nq < 1 || k < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  for (int q = 0; q < nq; q++) {
+    rsx_sc_hit *o = out + (size_t)q * k;
+    int count = 0;
+    for (int p = 0; p < nparts; p++)
+      for (int i = 0; i < k; i++) {
+        const rsx_sc_hit &r = parts[((size_t)p * nq + q) * k + i];
+        if (!(r.dist < 10000000)) continue;  // padding / never-a-hit (SC.cpp:388)
+        int pos = count < k ? count : k;
+        while (pos > 0 && ((r.dist < o[pos - 1].dist) || (r.dist == o[pos - 1].dist && r.index < o[pos - 1].index))) pos--;
+        if (pos >= k) continue;
+        int last = count < k ? count : k - 1;
+        for (int j = last; j > pos; j--) o[j] = o[j - 1];
+        o[pos] = r;
+        if (count < k) count++;
+      }
+    for (int i = count; i < k; i++) {
+      o[i].dist = 10000000;
+      o[i].index = 0;
+      o[i].shift = 0;
+    }
+  }
+  return RSX_OK;
+}
+
+int rsx_sc_merge_topk_device(rsx_sc *h, const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t k,
+                             rsx_sc_hit *d_out, void *stream) {
+  if (!h || !d_parts || !d_out || nparts < 1 || nq < 1 || k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  return launch_merge(d_parts, nparts, nq, k, d_out, s);
+}
+
+int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float *yaw) {
+  if (!h || !hit) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (loop_id) *loop_id = (hit->dist < h->p.dist_thres) ? hit->index : -1;  // SC.cpp:401-403
+  if (yaw) *yaw = yaw_from_shift(hit->shift);                               // SC.cpp:417
+  return RSX_OK;
+}
+
+}  // extern "C"

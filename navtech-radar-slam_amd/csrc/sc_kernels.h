@@ -1,0 +1,70 @@
+// sc_kernels.h -- launch wrappers of the ScanContext HIP kernels (sc_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rsx.h"
+
+namespace rsx {
+namespace sc {
+
+constexpr int NR = RSX_SC_NUM_RING;
+constexpr int NS = RSX_SC_NUM_SECTOR;
+constexpr int DS = RSX_SC_DESC_SIZE;
+
+// One database shard in HBM (SoA, see DESIGN.md "Data layout"):
+struct DbView {
+  const float *desc;   // [n_local][60][20] fp32, sector-major == Eigen col-major order
+  const double *vkey;  // [n_local][60] sector keys (SC.cpp:214-227)
+  const double *norm;  // [n_local][60] column norms (shift-invariant part of SC.cpp:78,81)
+  const float *rkey;   // [n_local][20] ring keys as float (SC.cpp:198-211 + 62-66)
+  int64_t n_local;
+  int64_t idx_base;    // global index of local slot s = idx_base + s * idx_stride
+  int64_t idx_stride;
+};
+
+struct QueryView {
+  const float *desc;   // [nq][1200]
+  const double *vkey;  // [nq][60]
+  const double *norm;  // [nq][60]
+  int32_t nq;
+};
+
+// keys for n descriptors (device pointers)
+int launch_keys(const float *desc, int64_t n, double *vkey, double *norm, float *rkey, hipStream_t s);
+
+// descriptor from one point cloud resident in device memory, written to out_desc (1200 floats)
+// followed by its keys
+int launch_build(const void *d_pts, int64_t n_pts, int64_t stride_bytes, double lidar_height,
+                 double max_radius, float *out_desc, double *out_vkey, double *out_norm,
+                 float *out_rkey, hipStream_t s);
+
+// number of partial top-k slots per query the pair kernel will produce for this problem
+int pair_num_slots(int64_t n_items, int32_t nq);
+size_t pair_partial_bytes(int64_t n_items, int32_t nq, int32_t k);
+
+// score nq queries against db entries.
+//   gather == nullptr: local slots [first, first+n_items); else slots gather[0..n_items)
+//   n_eligible: only entries with global index < min(n_eligible, q_elig[q] if given) are ranked
+//   out_dist/out_shift (optional, [nq][n_items]): every pair, eligibility ignored
+//   d_partial (optional): workspace of pair_partial_bytes(); d_topk [nq][k] receives the merged
+//   result sorted by (dist, index), padded with {1e7,0,0}
+int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, int64_t first,
+                 int64_t n_items, int64_t n_eligible, const int64_t *q_elig, double *out_dist,
+                 int32_t *out_shift, rsx_sc_hit *d_partial, rsx_sc_hit *d_topk, int32_t k,
+                 hipStream_t s);
+
+// merge [nparts][nq][k] -> [nq][k]
+int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *d_out,
+                 hipStream_t s);
+
+// exact k-NN over ring keys [0, n_search) with nanoflann's float L2 (NF.hpp:383-408);
+// d_dist_ws: n_search floats of workspace; out_idx[k] (unfilled = 0), out_found[1]
+int launch_knn(const float *rkeys, int64_t n_search, const float *qkey, int32_t k, float *d_dist_ws,
+               int32_t *out_idx, float *out_dist, int32_t *out_found, hipStream_t s);
+
+const char *pair_kernel_name();
+
+}  // namespace sc
+}  // namespace rsx

@@ -1,0 +1,640 @@
+// sc_kernels.hip -- hand-written gfx950 (CDNA4) kernels of the ScanContext hot path.
+//
+// What each kernel replaces in the reference (pgo/SC-A-LOAM/include/scancontext/Scancontext.cpp):
+//   sc_build_kernel   makeScancontext + the three key builders           SC.cpp:151-227
+//   sc_keys_kernel    makeRingkey/makeSectorkey (+ column norms)         SC.cpp:198-227, 78
+//   sc_pair_kernel    distanceBtnScanContext for (query, DB entry) pairs SC.cpp:69-148
+//   sc_merge_kernel   the strict-< "first wins" candidate loop           SC.cpp:380-395 (generalised to top-k)
+//   sc_knn_kernel     nanoflann 3-NN on ring keys                        SC.cpp:367-374, NF.hpp:383-408
+//
+// Numerics contract (tests/test_gpu_sc.py asserts it bit-for-bit against oracle/sc_ref.c):
+//   all reductions are sequential in ascending index in fp64, exactly like the oracle; this file is
+//   compiled with -ffp-contract=off and uses fma() only where the product is exact (fp32 x fp32 in
+//   fp64), so results are identical to mul+add.  fp64 sqrt and divide are IEEE correctly rounded.
+//
+// Mapping (one 64-lane wavefront = one query x B database entries per iteration):
+//   stage 1  lane = column shift k (60 of 64 lanes): S_k = sum_c (v1[c] - v2[(c-k)%60])^2, sequential
+//            in c; the entry's sector key sits twice in LDS so lane k reads v2d[60+c-k] with an
+//            immediate offset -> conflict-free ds_read_b64, no address VALU in the loop.
+//   stage 2  lane = query column c: the query column lives in 40 VGPRs as fp64; the entry's columns
+//            are read from its fp32 LDS image (5 x ds_read_b128 per shift), 7 shifts, 20 fma each.
+//   stage 3  the reference sums the 60 column similarities sequentially (SC.cpp:83); the 7 x B
+//            series are transposed through LDS (aliasing the entry image, which is dead by then) so
+//            lane (b,t) adds its own series in order.
+//   top-k    each wave keeps a sorted k-list one record per lane; per-wave lists are merged by
+//            sc_merge_kernel under the total order (dist, global index).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "rsx_common.h"
+#include "sc_kernels.h"
+
+namespace rsx {
+namespace sc {
+
+namespace {
+
+constexpr double kBig = 10000000.0;  // SC.cpp:96,134,362 "init with something large"
+
+__device__ __forceinline__ void wave_lds_fence() {
+  // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
+  // accesses across the point where lanes exchange data through LDS.
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------
+// keys: one wave per descriptor
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_keys(const float *__restrict__ d, double *__restrict__ vkey,
+                                          double *__restrict__ norm, float *__restrict__ rkey, int lane) {
+  if (lane < NS) {
+    const float4 *p = reinterpret_cast<const float4 *>(d + lane * NR);
+    double s = 0.0, sq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      float4 v = p[i];
+      double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+      s = s + x0; sq = fma(x0, x0, sq);  // x*x exact in fp64 -> fma == mul+add
+      s = s + x1; sq = fma(x1, x1, sq);
+      s = s + x2; sq = fma(x2, x2, sq);
+      s = s + x3; sq = fma(x3, x3, sq);
+    }
+    vkey[lane] = s / (double)NR;  // SC.cpp:223 mean()
+    norm[lane] = sqrt(sq);        // Eigen norm()
+  }
+  if (lane < NR) {
+    double s = 0.0;
+    for (int c = 0; c < NS; c++) s = s + (double)d[c * NR + lane];
+    rkey[lane] = (float)(s / (double)NS);  // SC.cpp:207 mean(), SC.cpp:64 float narrowing
+  }
+}
+
+__global__ __launch_bounds__(256) void sc_keys_kernel(const float *__restrict__ desc, int64_t n,
+                                                      double *__restrict__ vkey, double *__restrict__ norm,
+                                                      float *__restrict__ rkey) {
+  const int lane = threadIdx.x & 63;
+  int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= n) return;
+  wave_keys(desc + i * DS, vkey + i * NS, norm + i * NS, rkey + i * NR, lane);
+}
+
+// ------------------------------------------------------------------------------------------
+// build: one 256-thread block per cloud; LDS max-histogram on order-preserving int encodings
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned enc_f32(float f) {
+  unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(unsigned u) {
+  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+  return __uint_as_float(u);
+}
+
+// SC.cpp:23-36; float division, atan in double, result narrowed to float (oracle/sc_ref.c)
+__device__ __forceinline__ float xy2theta_dev(float x, float y) {
+  const double k = 180 / M_PI;
+  if ((x >= 0) & (y >= 0)) return (float)(k * atan((double)__fdiv_rn(y, x)));
+  if ((x < 0) & (y >= 0)) return (float)(180 - (k * atan((double)__fdiv_rn(y, -x))));
+  if ((x < 0) & (y < 0)) return (float)(180 + (k * atan((double)__fdiv_rn(y, x))));
+  if ((x >= 0) & (y < 0)) return (float)(360 - (k * atan((double)__fdiv_rn(-y, x))));
+  return __builtin_nanf("");
+}
+
+__device__ __forceinline__ int ceil_clamp(double v, int hi) {
+  double c = ceil(v);
+  int i;
+  if (!(c == c)) i = 1;  // NaN: x86 cvttsd2si gives INT_MIN, then max(.,1) (SC.cpp:178-179)
+  else if (c >= (double)hi) i = hi;
+  else if (c <= 1.0) i = 1;
+  else i = (int)c;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void sc_build_kernel(const char *__restrict__ pts, int64_t n_pts,
+                                                       int64_t stride, double lidar_height,
+                                                       double max_radius, float *__restrict__ out_desc,
+                                                       double *__restrict__ out_vkey,
+                                                       double *__restrict__ out_norm,
+                                                       float *__restrict__ out_rkey) {
+  __shared__ __attribute__((aligned(16))) unsigned bins[DS];
+  const unsigned no_point = enc_f32(-1000.0f);  // SC.cpp:158-159
+  for (int i = threadIdx.x; i < DS; i += 256) bins[i] = no_point;
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < n_pts; i += 256) {
+    const float *p = reinterpret_cast<const float *>(pts + i * stride);
+    float x = p[0], y = p[1];
+    float z = (float)((double)p[2] + lidar_height);  // SC.cpp:168
+    if (!(x == x) || !(y == y) || !(z == z)) continue;
+    float ss = __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y));
+    float azim_range = (float)sqrt((double)ss);  // SC.cpp:171 (== correctly rounded sqrtf)
+    float azim_angle = xy2theta_dev(x, y);       // SC.cpp:172
+    if ((double)azim_range > max_radius) continue;  // SC.cpp:175
+    int ring = ceil_clamp(((double)azim_range / max_radius) * NR, NR);   // SC.cpp:178
+    int sector = ceil_clamp(((double)azim_angle / 360.0) * NS, NS);      // SC.cpp:179
+    atomicMax(&bins[(sector - 1) * NR + (ring - 1)], enc_f32(z));        // SC.cpp:182-183
+  }
+  __syncthreads();
+  float *sd = reinterpret_cast<float *>(bins);
+  for (int i = threadIdx.x; i < DS; i += 256) {
+    unsigned u = bins[i];
+    float v = (u == no_point) ? 0.0f : dec_f32(u);  // SC.cpp:187-190
+    sd[i] = v;
+    out_desc[i] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) wave_keys(sd, out_vkey, out_norm, out_rkey, threadIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// pair kernel
+// ------------------------------------------------------------------------------------------
+template <int B>
+struct WaveLds {
+  static constexpr int OFF_DESC = 0;                    // B x 4800 B fp32 image (later: sims)
+  static constexpr int OFF_VKEY = B * 4800;             // B x 120 doubles (sector key twice)
+  static constexpr int OFF_NORM = OFF_VKEY + B * 960;   // B x 64 doubles
+  static constexpr int OFF_V1 = OFF_NORM + B * 512;     // 64 doubles: query sector key
+  static constexpr int OFF_MISC = OFF_V1 + 512;         // B x 8 ints neff + B ints kstar (padded)
+  static constexpr int SIZE = OFF_MISC + B * 32 + 64;
+};
+
+struct PairArgs {
+  DbView db;
+  QueryView q;
+  const int32_t *gather;
+  int64_t first, n_items, n_eligible;
+  const int64_t *q_elig;
+  double *out_dist;
+  int32_t *out_shift;
+  rsx_sc_hit *partial;
+  int32_t k, nslots;
+};
+
+__device__ __forceinline__ bool hit_before(double ad, int ai, double bd, int bi) {
+  return (ad < bd) || (ad == bd && ai < bi);
+}
+
+template <int B>
+__global__ __launch_bounds__(256) void sc_pair_kernel(PairArgs a) {
+  using L = WaveLds<B>;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  char *smem = smem_all + wave * L::SIZE;
+  const int qi = blockIdx.y;
+  const int slot = blockIdx.x * 4 + wave;
+  const int nwaves = gridDim.x * 4;
+  const int cl = lane < NS ? lane : 0;   // column owned in stage 2
+  const int kk = lane < NS ? lane : NS - 1;  // shift owned in stage 1
+
+  // ---- query: column cl as 20 doubles in registers, norm, sector key to LDS ----
+  double qc[NR];
+  {
+    const float4 *qp = reinterpret_cast<const float4 *>(a.q.desc + (int64_t)qi * DS + cl * NR);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      float4 v = qp[i];
+      qc[4 * i + 0] = v.x; qc[4 * i + 1] = v.y; qc[4 * i + 2] = v.z; qc[4 * i + 3] = v.w;
+    }
+  }
+  const double n1 = a.q.norm[(int64_t)qi * NS + cl];
+  double *v1 = reinterpret_cast<double *>(smem + L::OFF_V1);
+  if (lane < NS) v1[lane] = a.q.vkey[(int64_t)qi * NS + lane];
+  int *misc = reinterpret_cast<int *>(smem + L::OFF_MISC);
+
+  int64_t n_elig = a.n_eligible;
+  if (a.q_elig) {
+    int64_t e = a.q_elig[qi];
+    n_elig = e < n_elig ? e : n_elig;
+  }
+
+  // per-wave sorted top-k, one record per lane
+  double ld = INFINITY;
+  int li = 0x7fffffff, ls = 0;
+
+  const int64_t ngroups = (a.n_items + B - 1) / B;
+  for (int64_t g = slot; g < ngroups; g += nwaves) {
+    // ---- stage 0: stage B entries into this wave's LDS region ----
+    int64_t eslot[B];
+    bool evalid[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      int64_t item = g * B + b;
+      evalid[b] = item < a.n_items;
+      int64_t it = evalid[b] ? item : (a.n_items - 1);
+      eslot[b] = a.gather ? (int64_t)a.gather[it] : (a.first + it);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const float4 *src = reinterpret_cast<const float4 *>(a.db.desc + eslot[b] * DS);
+      float4 *dst = reinterpret_cast<float4 *>(smem + L::OFF_DESC + b * 4800);
+#pragma unroll
+      for (int i = 0; i < 4; i++) dst[i * 64 + lane] = src[i * 64 + lane];
+      if (lane < 44) dst[256 + lane] = src[256 + lane];
+      double *vk = reinterpret_cast<double *>(smem + L::OFF_VKEY + b * 960);
+      double *nm = reinterpret_cast<double *>(smem + L::OFF_NORM + b * 512);
+      if (lane < NS) {
+        double v = a.db.vkey[eslot[b] * NS + lane];
+        vk[lane] = v;
+        vk[lane + NS] = v;
+        nm[lane] = a.db.norm[eslot[b] * NS + lane];
+      }
+    }
+    wave_lds_fence();
+
+    // ---- stage 1: fastAlignUsingVkey (SC.cpp:93-113), lane = shift ----
+    double acc[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) acc[b] = 0.0;
+    {
+      const double *v2[B];
+#pragma unroll
+      for (int b = 0; b < B; b++)
+        v2[b] = reinterpret_cast<const double *>(smem + L::OFF_VKEY + b * 960) + (NS - kk);
+#pragma unroll
+      for (int c = 0; c < NS; c++) {
+        const double x = v1[c];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          double d = x - v2[b][c];
+          double dd = d * d;
+          acc[b] = acc[b] + dd;
+        }
+      }
+    }
+    int kstar[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      double nrm = sqrt(acc[b]);                 // SC.cpp:103 norm()
+      bool ok = (lane < NS) && (nrm < kBig);     // SC.cpp:96,104 (NaN never passes `<`)
+      double m = ok ? nrm : INFINITY;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+      unsigned long long bal = __ballot(ok && nrm == m);
+      kstar[b] = bal ? (__ffsll((long long)bal) - 1) : 0;  // first strict minimum = lowest shift
+    }
+
+    // ---- stage 2: column cosine terms for the 7 shifts k*-3..k*+3 (SC.cpp:123-144, 69-90) ----
+#pragma unroll 1
+    for (int b = 0; b < B; b++) {
+      int ks = kstar[0];
+#pragma unroll
+      for (int bb = 1; bb < B; bb++) ks = (b == bb) ? kstar[bb] : ks;
+      const float *descb = reinterpret_cast<const float *>(smem + L::OFF_DESC + b * 4800);
+      const double *normb = reinterpret_cast<const double *>(smem + L::OFF_NORM + b * 512);
+      double sim[7];
+      int neff[7];
+#pragma unroll
+      for (int t = 0; t < 7; t++) {
+        int k = ks + t - 3;
+        k += (k < 0) ? NS : 0;
+        k -= (k >= NS) ? NS : 0;
+        int j = cl - k;  // column of the entry that lands on column cl after shifting by k
+        j += (j < 0) ? NS : 0;
+        const float4 *cp = reinterpret_cast<const float4 *>(descb + j * NR);
+        double dot = 0.0;
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+          float4 v = cp[i];
+          dot = fma(qc[4 * i + 0], (double)v.x, dot);  // fp32 x fp32 exact in fp64
+          dot = fma(qc[4 * i + 1], (double)v.y, dot);
+          dot = fma(qc[4 * i + 2], (double)v.z, dot);
+          dot = fma(qc[4 * i + 3], (double)v.w, dot);
+        }
+        const double n2 = normb[j];
+        const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));  // SC.cpp:78
+        const double s = dot / (n1 * n2);                                  // SC.cpp:81
+        sim[t] = valid ? s : 0.0;
+        neff[t] = __popcll(__ballot(valid));
+      }
+      wave_lds_fence();  // every lane has consumed the fp32 image of entry b
+      double *simp = reinterpret_cast<double *>(smem + L::OFF_DESC + b * 4800);
+      if (lane < NS) {
+#pragma unroll
+        for (int t = 0; t < 7; t++) simp[lane * 7 + t] = sim[t];
+      }
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < 7; t++) misc[b * 8 + t] = neff[t];
+        misc[b * 8 + 7] = ks;
+      }
+    }
+    wave_lds_fence();
+
+    // ---- stage 3: sequential column sum (SC.cpp:83,87-88), lane = (entry b, shift t) ----
+    const int bb = lane >> 3, tt = lane & 7;
+    double bd = INFINITY;
+    int bk = 0x7fffffff;
+    if (bb < B && tt < 7) {
+      const double *sp = reinterpret_cast<const double *>(smem + L::OFF_DESC + bb * 4800) + tt;
+      double s = 0.0;
+#pragma unroll
+      for (int c = 0; c < NS; c++) s = s + sp[c * 7];
+      const int ne = misc[bb * 8 + tt];
+      const double d = 1.0 - s / (double)ne;  // 0/0 -> NaN when no effective column
+      int k = misc[bb * 8 + 7] + tt - 3;
+      k += (k < 0) ? NS : 0;
+      k -= (k >= NS) ? NS : 0;
+      if (d < kBig) {  // SC.cpp:134,139: strict `<` against the 1e7 init; NaN fails
+        bd = d;
+        bk = k;
+      }
+    }
+    // window values are evaluated in ascending shift VALUE (SC.cpp:130) with strict `<`:
+    // the winner is the minimum under (dist, shift value)
+#pragma unroll
+    for (int off = 1; off <= 4; off <<= 1) {
+      double od = __shfl_xor(bd, off);
+      int ok = __shfl_xor(bk, off);
+      if (hit_before(od, ok, bd, bk)) {
+        bd = od;
+        bk = ok;
+      }
+    }
+    if (bd == INFINITY) {  // SC.cpp:133-134 initial values survive
+      bd = kBig;
+      bk = 0;
+    }
+
+    // ---- outputs ----
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const double dist = __shfl(bd, b * 8);
+      const int shift = __shfl(bk, b * 8);
+      if (!evalid[b]) continue;
+      const int64_t item = g * B + b;
+      if (a.out_dist && lane == 0) {
+        a.out_dist[(int64_t)qi * a.n_items + item] = dist;
+        a.out_shift[(int64_t)qi * a.n_items + item] = shift;
+      }
+      if (a.partial) {
+        const int64_t gidx = a.db.idx_base + eslot[b] * a.db.idx_stride;
+        if (gidx < n_elig && dist < kBig) {  // SC.cpp:388: must beat the 1e7 init
+          const int idx = (int)gidx;
+          const bool before = (lane < a.k) && hit_before(ld, li, dist, idx);
+          const int pos = __popcll(__ballot(before));
+          if (pos < a.k) {
+            double ud = __shfl_up(ld, 1);
+            int ui = __shfl_up(li, 1), us = __shfl_up(ls, 1);
+            if (lane > pos) {
+              ld = ud; li = ui; ls = us;
+            } else if (lane == pos) {
+              ld = dist; li = idx; ls = shift;
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (a.partial && lane < a.k) {
+    rsx_sc_hit h;
+    h.dist = ld;
+    h.index = li;
+    h.shift = ls;
+    a.partial[((int64_t)qi * a.nslots + slot) * a.k + lane] = h;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// merge: per query, k rounds of "smallest record strictly after the previous pick"
+// records are unique in (dist,index) except the padding {inf, INT_MAX} / {1e7,0,0}
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sc_merge_kernel(const rsx_sc_hit *__restrict__ parts, int32_t nparts,
+                                                      int64_t part_stride, int32_t per_part, int32_t k,
+                                                      rsx_sc_hit *__restrict__ out) {
+  // parts: record (p, q, i) at parts[p*part_stride + q*per_part + i], i < per_part
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x;
+  double pd = -INFINITY;
+  int pi = -1;
+  const int64_t total = (int64_t)nparts * per_part;
+  for (int r = 0; r < k; r++) {
+    double bd = INFINITY;
+    int bi = 0x7fffffff, bs = 0;
+    for (int64_t t = lane; t < total; t += 64) {
+      const int p = (int)(t / per_part), i = (int)(t % per_part);
+      rsx_sc_hit h = parts[(int64_t)p * part_stride + (int64_t)q * per_part + i];
+      // padding ({inf,..} from the pair kernel, {1e7,0,0} from merged lists) and anything that
+      // could not beat the 1e7 init (SC.cpp:388) is never a hit
+      const bool pad = !(h.dist < kBig);
+      if (pad) continue;
+      if (hit_before(pd, pi, h.dist, h.index) && hit_before(h.dist, h.index, bd, bi)) {
+        bd = h.dist; bi = h.index; bs = h.shift;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      double od = __shfl_xor(bd, off);
+      int oi = __shfl_xor(bi, off), os = __shfl_xor(bs, off);
+      if (hit_before(od, oi, bd, bi)) {
+        bd = od; bi = oi; bs = os;
+      }
+    }
+    if (lane == 0) {
+      rsx_sc_hit h;
+      if (bd == INFINITY) {
+        h.dist = kBig; h.index = 0; h.shift = 0;  // SC.cpp:362-364
+      } else {
+        h.dist = bd; h.index = bi; h.shift = bs;
+      }
+      out[(int64_t)q * k + r] = h;
+    }
+    pd = bd;
+    pi = bi;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// knn over ring keys (candidate stage): one 1024-thread block
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sc_knn_kernel(const float *__restrict__ rkeys, int64_t n,
+                                                      const float *__restrict__ qkey, int32_t k,
+                                                      float *__restrict__ dist_ws, int32_t *__restrict__ out_idx,
+                                                      float *__restrict__ out_dist, int32_t *__restrict__ out_found) {
+  __shared__ float sq[NR];
+  __shared__ float rd[16];
+  __shared__ int ri[16];
+  __shared__ float pick_d;
+  __shared__ int pick_i;
+  if (threadIdx.x < NR) sq[threadIdx.x] = qkey[threadIdx.x];
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float4 *p = reinterpret_cast<const float4 *>(rkeys + i * NR);
+    float result = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 5; g++) {  // NF.hpp:391-401: 4 at a time, left-to-right sum, no contraction
+      float4 v = p[g];
+      float d0 = __fsub_rn(sq[4 * g + 0], v.x), d1 = __fsub_rn(sq[4 * g + 1], v.y);
+      float d2 = __fsub_rn(sq[4 * g + 2], v.z), d3 = __fsub_rn(sq[4 * g + 3], v.w);
+      float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)),
+                          __fmul_rn(d3, d3));
+      result = __fadd_rn(result, t);
+    }
+    dist_ws[i] = result;
+  }
+  __syncthreads();
+  float pd = -1.0f;
+  int pi = -1;
+  int found = 0;
+  for (int r = 0; r < k; r++) {
+    float bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) {
+      float d = dist_ws[i];
+      bool after = (d > pd) || (d == pd && (int)i > pi);
+      if (after && ((d < bd) || (d == bd && (int)i < bi))) {
+        bd = d;
+        bi = (int)i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      float od = __shfl_xor(bd, off);
+      int oi = __shfl_xor(bi, off);
+      if ((od < bd) || (od == bd && oi < bi)) {
+        bd = od; bi = oi;
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+      rd[threadIdx.x >> 6] = bd;
+      ri[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float d = rd[0];
+      int ix = ri[0];
+      for (int w = 1; w < 16; w++)
+        if ((rd[w] < d) || (rd[w] == d && ri[w] < ix)) {
+          d = rd[w]; ix = ri[w];
+        }
+      pick_d = d;
+      pick_i = ix;
+    }
+    __syncthreads();
+    pd = pick_d;
+    pi = pick_i;
+    if (pi != 0x7fffffff) found++;
+    if (threadIdx.x == 0) {
+      out_idx[r] = (pi == 0x7fffffff) ? 0 : pi;  // SC.cpp:367 zero-initialised slots
+      out_dist[r] = pd;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out_found[0] = found;
+}
+
+template <int B>
+int launch_pairs_t(const PairArgs &a, int gx, hipStream_t s) {
+  static bool attr_set = false;
+  const int lds = 4 * WaveLds<B>::SIZE;
+  if (!attr_set) {
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_pair_kernel<B>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  dim3 grid(gx, a.q.nq);
+  hipLaunchKernelGGL(sc_pair_kernel<B>, grid, dim3(256), lds, s, a);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+constexpr int kB = 4;
+
+int choose_gx(int64_t n_items, int32_t nq) {
+  const int64_t ngroups = (n_items + kB - 1) / kB;
+  int64_t max_gx = (ngroups + 3) / 4;
+  if (max_gx < 1) max_gx = 1;
+  int64_t want = (2048 + 4 * (int64_t)nq - 1) / (4 * (int64_t)nq);  // ~2048 waves in flight
+  if (want < 1) want = 1;
+  return (int)(want < max_gx ? want : max_gx);
+}
+
+}  // namespace
+
+const char *pair_kernel_name() { return "sc_pair_kernel"; }
+
+int pair_num_slots(int64_t n_items, int32_t nq) { return choose_gx(n_items, nq) * 4; }
+
+size_t pair_partial_bytes(int64_t n_items, int32_t nq, int32_t k) {
+  return (size_t)pair_num_slots(n_items, nq) * (size_t)nq * (size_t)k * sizeof(rsx_sc_hit);
+}
+
+int launch_keys(const float *desc, int64_t n, double *vkey, double *norm, float *rkey, hipStream_t s) {
+  if (n <= 0) return RSX_OK;
+  hipLaunchKernelGGL(sc_keys_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, desc, n, vkey, norm, rkey);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_build(const void *d_pts, int64_t n_pts, int64_t stride_bytes, double lidar_height,
+                 double max_radius, float *out_desc, double *out_vkey, double *out_norm,
+                 float *out_rkey, hipStream_t s) {
+  hipLaunchKernelGGL(sc_build_kernel, dim3(1), dim3(256), 0, s, static_cast<const char *>(d_pts), n_pts,
+                     stride_bytes, lidar_height, max_radius, out_desc, out_vkey, out_norm, out_rkey);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *d_out,
+                 hipStream_t s) {
+  if (nq <= 0) return RSX_OK;
+  hipLaunchKernelGGL(sc_merge_kernel, dim3(nq), dim3(64), 0, s, d_parts, nparts, (int64_t)nq * k, k, k, d_out);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, int64_t first,
+                 int64_t n_items, int64_t n_eligible, const int64_t *q_elig, double *out_dist,
+                 int32_t *out_shift, rsx_sc_hit *d_partial, rsx_sc_hit *d_topk, int32_t k,
+                 hipStream_t s) {
+  if (q.nq <= 0) return RSX_OK;
+  if (k < 0 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [0,%d]", k, RSX_SC_MAX_TOPK);
+  if (n_items <= 0) {
+    // nothing to score: result is all padding
+    if (d_topk && k > 0) {
+      // a merge over zero parts writes the padding
+      hipLaunchKernelGGL(sc_merge_kernel, dim3(q.nq), dim3(64), 0, s, (const rsx_sc_hit *)nullptr, 0,
+                         (int64_t)0, k, k, d_topk);
+      RSX_HIP(hipGetLastError());
+    }
+    return RSX_OK;
+  }
+  PairArgs a;
+  a.db = db;
+  a.q = q;
+  a.gather = gather;
+  a.first = first;
+  a.n_items = n_items;
+  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
+  a.q_elig = q_elig;
+  a.out_dist = out_dist;
+  a.out_shift = out_shift;
+  const int gx = choose_gx(n_items, q.nq);
+  a.partial = (d_topk && k > 0) ? d_partial : nullptr;
+  a.k = k;
+  a.nslots = gx * 4;
+  RSX_TRY(launch_pairs_t<kB>(a, gx, s));
+  if (a.partial) {
+    // partial layout [q][slot][k]: one "part" per slot with part_stride = k, query stride nslots*k
+    hipLaunchKernelGGL(sc_merge_kernel, dim3(q.nq), dim3(64), 0, s, (const rsx_sc_hit *)d_partial, 1,
+                       (int64_t)0, a.nslots * k, k, d_topk);
+    RSX_HIP(hipGetLastError());
+  }
+  return RSX_OK;
+}
+
+int launch_knn(const float *rkeys, int64_t n_search, const float *qkey, int32_t k, float *d_dist_ws,
+               int32_t *out_idx, float *out_dist, int32_t *out_found, hipStream_t s) {
+  hipLaunchKernelGGL(sc_knn_kernel, dim3(1), dim3(1024), 0, s, rkeys, n_search, qkey, k, d_dist_ws, out_idx,
+                     out_dist, out_found);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+}  // namespace sc
+}  // namespace rsx

@@ -1,0 +1,180 @@
+"""Host-side mirror of the reference `SCManager` (Scancontext.h:62-122) on top of librsx.so.
+
+Method names and argument meaning follow the reference so parity tests read like reference
+code: makeAndSaveScancontextAndKeys / detectLoopClosureID / saveScancontextAndKeys /
+detectLoopClosureIDBetweenSession / getConstRefRecentSCD / setSCdistThres.  Everything is
+computed by the HIP kernels behind the C-ABI; this class only marshals buffers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _rsx
+from ._rsx import HIT_DTYPE, MODE_CANDIDATE, MODE_EXHAUSTIVE, check, lib
+
+
+class SCManager:
+    # hyper parameters (Scancontext.h:83-104); fixed at construction like the reference's consts
+    LIDAR_HEIGHT = 2.0
+    PC_NUM_RING = 20
+    PC_NUM_SECTOR = 60
+    PC_MAX_RADIUS = 80.0
+    NUM_EXCLUDE_RECENT = 30
+    NUM_CANDIDATES_FROM_TREE = 3
+    SEARCH_RATIO = 0.1
+    TREE_MAKING_PERIOD_ = 30
+
+    def __init__(self, device=0, shard_rank=0, shard_world=1, capacity_hint=1024, sc_dist_thres=0.2,
+                 lidar_height=None, num_exclude_recent=None, num_candidates=None, tree_making_period=None):
+        L = lib()
+        p = _rsx.ScParams()
+        check(L.rsx_sc_default_params(C.byref(p)))
+        p.device, p.shard_rank, p.shard_world = device, shard_rank, shard_world
+        p.capacity_hint = capacity_hint
+        p.dist_thres = sc_dist_thres
+        if lidar_height is not None:
+            p.lidar_height = lidar_height
+        if num_exclude_recent is not None:
+            p.num_exclude_recent = num_exclude_recent
+        if num_candidates is not None:
+            p.num_candidates = num_candidates
+        if tree_making_period is not None:
+            p.tree_making_period = tree_making_period
+        self.NUM_EXCLUDE_RECENT = p.num_exclude_recent
+        self.NUM_CANDIDATES_FROM_TREE = p.num_candidates
+        self.SC_DIST_THRES = sc_dist_thres
+        self._h = C.c_void_p()
+        self._L = L
+        check(L.rsx_sc_create(C.byref(p), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.rsx_sc_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- reference user API -------------------------------------------------------------
+    def makeAndSaveScancontextAndKeys(self, scan_down):
+        """scan_down: (n, >=3) float32 points x,y,z[,intensity...] (pcl::PointCloud<PointXYZI>)."""
+        pts = np.ascontiguousarray(scan_down, dtype=np.float32)
+        idx = C.c_int32()
+        check(self._L.rsx_sc_add_points(self._h, pts.ctypes.data, pts.shape[0], pts.shape[1] * 4, C.byref(idx)))
+        return idx.value
+
+    def saveScancontextAndKeys(self, scd):
+        """scd: 20x60 descriptor, column-major double (1200,) like Eigen::MatrixXd."""
+        d = np.ascontiguousarray(scd, dtype=np.float64).reshape(-1)
+        idx = C.c_int32()
+        check(self._L.rsx_sc_add_descriptor(self._h, d.ctypes.data, C.byref(idx)))
+        return idx.value
+
+    def detectLoopClosureID(self, mode=MODE_CANDIDATE, full=False):
+        """-> (loop_id, yaw_diff_rad) like the reference; full=True adds (min_dist, nn_idx)."""
+        lid, yaw, md, nn = C.c_int32(), C.c_float(), C.c_double(), C.c_int32()
+        check(self._L.rsx_sc_detect_loop_closure(self._h, mode, C.byref(lid), C.byref(yaw), C.byref(md), C.byref(nn)))
+        if full:
+            return lid.value, yaw.value, md.value, nn.value
+        return lid.value, yaw.value
+
+    def detectLoopClosureIDBetweenSession(self, curr_key, curr_desc, full=False):
+        key = np.ascontiguousarray(curr_key, dtype=np.float32)
+        d = np.ascontiguousarray(curr_desc, dtype=np.float64).reshape(-1)
+        lid, yaw, md, nn = C.c_int32(), C.c_float(), C.c_double(), C.c_int32()
+        check(self._L.rsx_sc_detect_between_session(self._h, key.ctypes.data, d.ctypes.data, C.byref(lid),
+                                                    C.byref(yaw), C.byref(md), C.byref(nn)))
+        if full:
+            return lid.value, yaw.value, md.value, nn.value
+        return lid.value, yaw.value
+
+    def getConstRefRecentSCD(self):
+        return self.descriptor(len(self) - 1)
+
+    def setSCdistThres(self, new_thres):
+        self.SC_DIST_THRES = new_thres
+        check(self._L.rsx_sc_set_dist_thres(self._h, float(new_thres)))
+
+    # ---- data access (public members polarcontexts_ etc., Scancontext.h:110-115) ---------
+    def __len__(self):
+        n = C.c_int64()
+        check(self._L.rsx_sc_size(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def local_size(self):
+        n = C.c_int64()
+        check(self._L.rsx_sc_local_size(self._h, C.byref(n)))
+        return n.value
+
+    @property
+    def tree_size(self):
+        n = C.c_int64()
+        check(self._L.rsx_sc_tree_size(self._h, C.byref(n)))
+        return n.value
+
+    def descriptor(self, i):
+        out = np.empty(1200, dtype=np.float64)
+        check(self._L.rsx_sc_get_descriptor(self._h, i, out.ctypes.data))
+        return out
+
+    def ringkey(self, i):
+        out = np.empty(20, dtype=np.float32)
+        check(self._L.rsx_sc_get_ringkey(self._h, i, out.ctypes.data))
+        return out
+
+    def sectorkey(self, i):
+        out = np.empty(60, dtype=np.float64)
+        check(self._L.rsx_sc_get_sectorkey(self._h, i, out.ctypes.data))
+        return out
+
+    # ---- batched / exhaustive extensions ------------------------------------
+    def add_descriptors_f32(self, descs):
+        d = np.ascontiguousarray(descs, dtype=np.float32).reshape(-1, 1200)
+        check(self._L.rsx_sc_add_descriptors_f32(self._h, d.ctypes.data, d.shape[0]))
+
+    def add_descriptors_device(self, dev_ptr, n, stream=0):
+        check(self._L.rsx_sc_add_descriptors_f32_device(self._h, dev_ptr, n, stream))
+
+    def query(self, q_descs, k=1, n_eligible=-1):
+        q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
+        out = np.zeros((q.shape[0], k), dtype=HIT_DTYPE)
+        check(self._L.rsx_sc_query(self._h, q.ctypes.data, q.shape[0], k, n_eligible, out.ctypes.data))
+        return out
+
+    def query_device(self, q_ptr, nq, k, out_ptr, n_eligible=-1, stream=0):
+        check(self._L.rsx_sc_query_device(self._h, q_ptr, nq, k, n_eligible, out_ptr, stream))
+
+    def query_self_device(self, q_first, nq, k, out_ptr, n_eligible=-1, exclude_recent=-1, stream=0):
+        check(self._L.rsx_sc_query_self_device(self._h, q_first, nq, k, n_eligible, exclude_recent, out_ptr, stream))
+
+    def pair_distances(self, q_desc, first=0, count=None):
+        q = np.ascontiguousarray(q_desc, dtype=np.float32).reshape(-1)
+        if count is None:
+            count = self.local_size - first
+        dist = np.empty(count, dtype=np.float64)
+        shift = np.empty(count, dtype=np.int32)
+        check(self._L.rsx_sc_pair_distances(self._h, q.ctypes.data, first, count, dist.ctypes.data, shift.ctypes.data))
+        return dist, shift
+
+    def merge_device(self, parts_ptr, nparts, nq, k, out_ptr, stream=0):
+        check(self._L.rsx_sc_merge_topk_device(self._h, parts_ptr, nparts, nq, k, out_ptr, stream))
+
+    def hit_to_loop(self, hit):
+        h = np.zeros(1, dtype=HIT_DTYPE)
+        h[0] = hit
+        lid, yaw = C.c_int32(), C.c_float()
+        check(self._L.rsx_sc_hit_to_loop(self._h, h.ctypes.data, C.byref(lid), C.byref(yaw)))
+        return lid.value, yaw.value
+
+
+def merge_topk(parts, k=None):
+    """Host merge of per-shard lists: parts (nparts, nq, k) HIT_DTYPE -> (nq, k)."""
+    parts = np.ascontiguousarray(parts, dtype=HIT_DTYPE)
+    nparts, nq, kk = parts.shape
+    out = np.zeros((nq, kk), dtype=HIT_DTYPE)
+    check(lib().rsx_sc_merge_topk(parts.ctypes.data, nparts, nq, kk, out.ctypes.data))
+    return out

@@ -517,7 +517,9 @@ void scref_exhaustive(const scref_mgr *m, const double *query_desc, int64_t n_el
   int count = 0;
   for (int64_t i = 0; i < n_eligible; i++) {
     scref_hit h = {dist[i], (int32_t)i, shift[i]};
-    topk_insert(out, k, &count, &h);
+    /* SC.cpp:388: a candidate must pass `candidate_dist < min_dist` against the 1e7 init, so an
+     * entry whose distance is 1e7 (no effective column at any shift) is never a hit */
+    if (h.dist < 10000000) topk_insert(out, k, &count, &h);
   }
   for (int i = count; i < k; i++) { /* SC.cpp:362-364 initial values */
     out[i].dist = 10000000;
@@ -534,7 +536,7 @@ void scref_merge_topk(const scref_hit *parts, int nparts, int k, scref_hit *out)
     for (int i = 0; i < k; i++) {
       const scref_hit *h = &parts[p * k + i];
       /* padding records {1e7,0,0} from short shards are re-padded below */
-      if (h->dist >= 10000000 && h->index == 0 && h->shift == 0) continue;
+      if (!(h->dist < 10000000)) continue;
       topk_insert(out, k, &count, h);
     }
   for (int i = count; i < k; i++) {

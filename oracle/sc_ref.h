@@ -103,8 +103,9 @@ int64_t scref_tree_size(const scref_mgr *m);
 
 /* exhaustive mode: score entries {first + i*stride : i < count} (local shard
  * view: global index = index_base + i*index_stride) that satisfy global index < n_eligible with
- * scref_distance; return the k best under the total order (dist, index); NaN never wins; unfilled
- * slots are {1e7, 0, 0} like SC.cpp:362-364.  nthreads>1 uses OpenMP over entries. */
+ * scref_distance; return the k best under the total order (dist, index) among entries with
+ * dist < 1e7 (SC.cpp:388 strict `<` against the 1e7 init; NaN never wins); unfilled slots are
+ * {1e7, 0, 0} like SC.cpp:362-364.  nthreads>1 uses OpenMP over entries. */
 void scref_exhaustive(const scref_mgr *m, const double *query_desc, int64_t n_eligible, int k,
                       scref_hit *out, int nthreads);
 /* dist/shift of the query against every entry in [first, first+count) */

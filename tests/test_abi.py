@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: librsx.so loads without a GPU, exports exactly the
+symbols include/rsx.h declares, fails loudly (no CPU fallback) when no device is present, and its
+pure-host logic (top-k merge) agrees with the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def rsx():
+    import __graft_entry__ as ge
+    from navtech_radar_slam_amd import _rsx
+    if not os.path.exists(_rsx.LIB_PATH):
+        ge.build()
+    return _rsx
+
+
+def _header_symbols():
+    names = set()
+    for fn in os.listdir(os.path.join(ROOT, "include")):
+        txt = open(os.path.join(ROOT, "include", fn)).read()
+        txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        names |= set(re.findall(r"\b(rsx_[a-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_exports_match_header(rsx):
+    declared = _header_symbols()
+    assert declared == set(rsx.SYMBOLS), declared ^ set(rsx.SYMBOLS)
+    out = subprocess.check_output(["nm", "-D", "--defined-only", rsx.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (rsx_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    L = rsx.lib()
+    for s in declared:
+        getattr(L, s)
+    assert "gfx950" in rsx.version()
+
+
+def test_no_cpu_fallback(rsx):
+    """Without a GPU, creating a handle must fail with RSX_ERR_NO_DEVICE -- never compute on the CPU."""
+    if rsx.device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    h = C.c_void_p()
+    st = rsx.lib().rsx_sc_create(None, C.byref(h))
+    assert st == -2 and not h.value
+    assert b"no HIP device" in rsx.lib().rsx_last_error_string()
+    from navtech_radar_slam_amd import scancontext
+    with pytest.raises(rsx.RsxError):
+        scancontext.SCManager()
+
+
+def test_param_defaults_match_reference(rsx):
+    p = rsx.ScParams()
+    assert rsx.lib().rsx_sc_default_params(C.byref(p)) == 0
+    # Scancontext.h:83-104
+    assert (p.lidar_height, p.max_radius, p.num_exclude_recent, p.num_candidates) == (2.0, 80.0, 30, 3)
+    assert (p.search_ratio, p.dist_thres, p.tree_making_period) == (0.1, 0.2, 30)
+    assert (p.shard_rank, p.shard_world) == (0, 1)
+
+
+def test_host_merge_matches_oracle(rsx, oracle):
+    from navtech_radar_slam_amd import scancontext, synth
+    m = oracle.Manager()
+    descs = synth.random_descriptors(3, 200, binary=True).astype(np.float64)
+    m.add_descriptors(descs)
+    G, k, nq = 8, 10, 3
+    qs = [descs[5], oracle.circshift(descs[77], 13), np.zeros(1200)]
+    parts = np.zeros((G, nq, k), dtype=scancontext.HIT_DTYPE)
+    for qi, q in enumerate(qs):
+        dist, shift = m.pair_distances(q)
+        for g in range(G):
+            rec = sorted((dist[i], i, shift[i]) for i in range(g, 170, G) if dist[i] < 1e7)[:k]  # n_eligible = 170
+            rec += [(1e7, 0, 0)] * (k - len(rec))
+            for j, (d, i, s) in enumerate(rec):
+                parts[g, qi, j] = (d, i, s)
+    merged = scancontext.merge_topk(parts)
+    for qi, q in enumerate(qs):
+        want = m.exhaustive(q, n_eligible=170, k=k)
+        assert np.array_equal(merged[qi], want.astype(scancontext.HIT_DTYPE))
+    # bad arguments are status codes, not crashes
+    assert rsx.lib().rsx_sc_merge_topk(None, 1, 1, 1, None) == -1
