@@ -154,8 +154,13 @@ int rsx_sc_merge_topk_device(rsx_sc *h, const rsx_sc_hit *d_parts, int32_t npart
 /* apply the loop threshold + yaw conversion of SC.cpp:401-417 to a top-1 record */
 int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float *yaw_diff_rad);
 
-/* instrumentation for bench.py: name and launch count of the dominant kernel */
+/* instrumentation for bench.py: name of the dominant kernel (as rocprofv3 reports it) and, when
+ * enabled, hipEvent pairs recorded around every launch of it on the stream it runs on.
+ * rsx_sc_profile_read synchronises, returns launches and summed milliseconds since the last read,
+ * and resets the counters. */
 const char *rsx_sc_dominant_kernel_name(void);
+int rsx_sc_profile_enable(rsx_sc *h, int on);
+int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms);
 
 #ifdef __cplusplus
 }

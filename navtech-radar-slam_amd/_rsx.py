@@ -50,7 +50,7 @@ SYMBOLS = [
     "rsx_sc_get_sectorkey", "rsx_sc_detect_loop_closure", "rsx_sc_detect_between_session",
     "rsx_sc_tree_size", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_self_device",
     "rsx_sc_pair_distances", "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
-    "rsx_sc_dominant_kernel_name",
+    "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read",
 ]
 
 
@@ -86,6 +86,8 @@ def lib():
         L.rsx_sc_pair_distances.argtypes = [vp, vp, i64, i64, vp, vp]
         L.rsx_sc_merge_topk.argtypes = [vp, i32, i32, i32, vp]
         L.rsx_sc_merge_topk_device.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+        L.rsx_sc_profile_enable.argtypes = [vp, C.c_int]
+        L.rsx_sc_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl)]
         L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
         _lib = L
     return _lib

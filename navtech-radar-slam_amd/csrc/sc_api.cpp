@@ -35,6 +35,7 @@ struct rsx_sc {
   int64_t batch_size = 0;
   // workspaces
   DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
+  PairProfiler prof;
   void *pinned = nullptr;  // small pinned host staging (results)
   size_t pinned_bytes = 0;
 };
@@ -116,6 +117,10 @@ int prepare_queries(rsx_sc *h, const float *d_q, int32_t nq, hipStream_t s, Quer
 int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
              int32_t k, rsx_sc_hit *d_out, hipStream_t s) {
   RSX_TRY(h->partial.reserve(pair_partial_bytes(n_items > 0 ? n_items : 1, qv.nq, k), s, false));
+  struct Hook {
+    explicit Hook(PairProfiler *p) { set_pair_profiler(p); }
+    ~Hook() { set_pair_profiler(nullptr); }
+  } hook(&h->prof);
   return launch_pairs(db_view(h), qv, nullptr, 0, n_items, n_eligible, d_q_elig, nullptr, nullptr,
                       h->partial.as<rsx_sc_hit>(), d_out, k, s);
 }
@@ -249,6 +254,10 @@ int rsx_sc_destroy(rsx_sc *h) {
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
   if (h->pinned) (void)hipHostFree(h->pinned);
+  if (h->prof.ev) {
+    for (int i = 0; i < 2 * PairProfiler::kMax; i++) (void)hipEventDestroy(h->prof.ev[i]);
+    delete[] h->prof.ev;
+  }
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
@@ -567,6 +576,37 @@ int rsx_sc_merge_topk_device(rsx_sc *h, const rsx_sc_hit *d_parts, int32_t npart
   RSX_TRY(set_device(h));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   return launch_merge(d_parts, nparts, nq, k, d_out, s);
+}
+
+int rsx_sc_profile_enable(rsx_sc *h, int on) {
+  if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  if (on && !h->prof.ev) {
+    h->prof.ev = new (std::nothrow) hipEvent_t[2 * PairProfiler::kMax];
+    if (!h->prof.ev) return fail(RSX_ERR_OOM, "host alloc");
+    for (int i = 0; i < 2 * PairProfiler::kMax; i++) RSX_HIP(hipEventCreate(&h->prof.ev[i]));
+  }
+  h->prof.on = on != 0;
+  h->prof.used = 0;
+  return RSX_OK;
+}
+
+int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms) {
+  if (!h || !launches || !total_ms) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  *launches = 0;
+  *total_ms = 0.0;
+  for (int i = 0; i < h->prof.used; i++) {
+    RSX_HIP(hipEventSynchronize(h->prof.ev[2 * i + 1]));
+    float ms = 0.f;
+    RSX_HIP(hipEventElapsedTime(&ms, h->prof.ev[2 * i], h->prof.ev[2 * i + 1]));
+    *total_ms += ms;
+    (*launches)++;
+  }
+  h->prof.used = 0;
+  return RSX_OK;
 }
 
 int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float *yaw) {

@@ -66,5 +66,14 @@ int launch_knn(const float *rkeys, int64_t n_search, const float *qkey, int32_t 
 
 const char *pair_kernel_name();
 
+// optional hipEvent bracket around the dominant (pair) kernel
+struct PairProfiler {
+  bool on = false;
+  static constexpr int kMax = 4096;
+  hipEvent_t *ev = nullptr;  // 2*kMax events, created lazily
+  int used = 0;
+};
+void set_pair_profiler(PairProfiler *p);  // thread-local hook consulted by launch_pairs
+
 }  // namespace sc
 }  // namespace rsx

@@ -558,6 +558,9 @@ int choose_gx(int64_t n_items, int32_t nq) {
 
 const char *pair_kernel_name() { return "sc_pair_kernel"; }
 
+static thread_local PairProfiler *g_prof = nullptr;
+void set_pair_profiler(PairProfiler *p) { g_prof = p; }
+
 int pair_num_slots(int64_t n_items, int32_t nq) { return choose_gx(n_items, nq) * 4; }
 
 size_t pair_partial_bytes(int64_t n_items, int32_t nq, int32_t k) {
@@ -618,7 +621,13 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   a.partial = (d_topk && k > 0) ? d_partial : nullptr;
   a.k = k;
   a.nslots = gx * 4;
+  PairProfiler *pp = (g_prof && g_prof->on && g_prof->ev && g_prof->used < PairProfiler::kMax) ? g_prof : nullptr;
+  if (pp) RSX_HIP(hipEventRecord(pp->ev[2 * pp->used], s));
   RSX_TRY(launch_pairs_t<kB>(a, gx, s));
+  if (pp) {
+    RSX_HIP(hipEventRecord(pp->ev[2 * pp->used + 1], s));
+    pp->used++;
+  }
   if (a.partial) {
     // partial layout [q][slot][k]: one "part" per slot with part_stride = k, query stride nslots*k
     hipLaunchKernelGGL(sc_merge_kernel, dim3(q.nq), dim3(64), 0, s, (const rsx_sc_hit *)d_partial, 1,

@@ -163,6 +163,15 @@ class SCManager:
     def merge_device(self, parts_ptr, nparts, nq, k, out_ptr, stream=0):
         check(self._L.rsx_sc_merge_topk_device(self._h, parts_ptr, nparts, nq, k, out_ptr, stream))
 
+    def profile_enable(self, on=True):
+        check(self._L.rsx_sc_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        """-> (launches, total_ms) of the dominant kernel since the last read (HIP events)."""
+        n, ms = C.c_int64(), C.c_double()
+        check(self._L.rsx_sc_profile_read(self._h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
     def hit_to_loop(self, hit):
         h = np.zeros(1, dtype=HIT_DTYPE)
         h[0] = hit

@@ -133,7 +133,8 @@ def test_pair_edge_cases(sc, oracle):
     d, s = g.pair_distances(z)
     assert np.all(d == 1e7) and np.all(s == 0)                        # SC.cpp:87,134: NaN never wins
     d, s = g.pair_distances(wrap)                                     # k* = 1,2,3,57.. wrap-around windows
-    assert list(s[5:]) == [0, 1, 2, 3, 57, 58, 59] and np.all(np.abs(d[5:]) < 1e-15)
+    # entry = rot_k(query) -> the entry must be shifted by 60-k to land on the query
+    assert list(s[5:]) == [0, 59, 58, 57, 3, 2, 1] and np.all(np.abs(d[5:]) < 1e-15)
 
 
 # ---------------------------------------------------------------------------------------------
