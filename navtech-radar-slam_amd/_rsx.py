@@ -59,6 +59,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RsxError(-7, f"{LIB_PATH} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        # One HIP runtime per process: the PyTorch wheel bundles its own libamdhip64 (same SONAME
+        # as /opt/rocm's).  If librsx pulled in the system runtime first, a later `import torch`
+        # would load a second runtime and find no GPU; loading torch first makes librsx bind to
+        # the runtime torch already loaded.  (A C++/ROS host has only the system runtime.)
+        if os.environ.get("RSX_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         L.rsx_last_error_string.restype = C.c_char_p
         L.rsx_version.restype = C.c_char_p

@@ -16,17 +16,19 @@
 //   stage 1  lane = column shift k (60 of 64 lanes): S_k = sum_c (v1[c] - v2[(c-k)%60])^2, sequential
 //            in c; the entry's sector key sits twice in LDS so lane k reads v2d[60+c-k] with an
 //            immediate offset -> conflict-free ds_read_b64, no address VALU in the loop.
-//   stage 2  lane = query column c: the query column lives in 40 VGPRs as fp64; the entry's columns
-//            are read from its fp32 LDS image (5 x ds_read_b128 per shift), 7 shifts, 20 fma each.
+//   stage 2  lane = entry column j, held in 40 VGPRs as fp64 (20 cvt per entry, loaded straight from
+//            HBM/L2 -- the entry image never goes through LDS); the query lives once per block in LDS
+//            as an fp64 image and lane j reads query column (j+k)%60 (10 x ds_read_b128 per shift),
+//            7 shifts, 20 fma each.
 //   stage 3  the reference sums the 60 column similarities sequentially (SC.cpp:83); the 7 x B
-//            series are transposed through LDS (aliasing the entry image, which is dead by then) so
-//            lane (b,t) adds its own series in order.
+//            series are transposed through LDS so lane (b,t) adds its own series in order.
 //   top-k    each wave keeps a sorted k-list one record per lane; per-wave lists are merged by
 //            sc_merge_kernel under the total order (dist, global index).
 #include <hip/hip_runtime.h>
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
@@ -151,14 +153,26 @@ __global__ __launch_bounds__(256) void sc_build_kernel(const char *__restrict__ 
 // ------------------------------------------------------------------------------------------
 // pair kernel
 // ------------------------------------------------------------------------------------------
+// LDS of one 256-thread block (all 4 waves score the SAME query, blockIdx.y):
+//   [0, 10560)          query image in fp64, column stride 176 B (44 dwords: conflict-free
+//                       ds_read_b128 for 16 consecutive columns), converted once per block
+//   [10560, +512)       query column norms n1[60]
+//   [11072, +512)       query sector key v1[60]
+//   per wave: B x { sector key of the entry twice (960 B) | similarity terms 60 x 7 doubles (3360 B)
+//                   | neff[7] + k* (32 B) | pad }
+constexpr int Q_COL_STRIDE = 176;
+constexpr int OFF_QIMG = 0;
+constexpr int OFF_QN1 = 60 * Q_COL_STRIDE;       // 10560
+constexpr int OFF_QV1 = OFF_QN1 + 512;           // 11072
+constexpr int OFF_WAVES = OFF_QV1 + 512;         // 11584
+constexpr int ENT_VKEY = 0, ENT_SIM = 960, ENT_MISC = 960 + 3360;
+// 4416 B = 1104 dwords = 16 (mod 64): the B per-entry blocks sit on disjoint LDS banks in stage 3
+constexpr int ENT_SIZE = 4416;
+
 template <int B>
-struct WaveLds {
-  static constexpr int OFF_DESC = 0;                    // B x 4800 B fp32 image (later: sims)
-  static constexpr int OFF_VKEY = B * 4800;             // B x 120 doubles (sector key twice)
-  static constexpr int OFF_NORM = OFF_VKEY + B * 960;   // B x 64 doubles
-  static constexpr int OFF_V1 = OFF_NORM + B * 512;     // 64 doubles: query sector key
-  static constexpr int OFF_MISC = OFF_V1 + 512;         // B x 8 ints neff + B ints kstar (padded)
-  static constexpr int SIZE = OFF_MISC + B * 32 + 64;
+struct PairLds {
+  static constexpr int WAVE_SIZE = B * ENT_SIZE;
+  static constexpr int SIZE = OFF_WAVES + 4 * WAVE_SIZE;
 };
 
 struct PairArgs {
@@ -177,33 +191,40 @@ __device__ __forceinline__ bool hit_before(double ad, int ai, double bd, int bi)
   return (ad < bd) || (ad == bd && ai < bi);
 }
 
+// waves per SIMD the LDS footprint allows (4 waves per 256-thread block, 160 KiB LDS per CU)
 template <int B>
-__global__ __launch_bounds__(256) void sc_pair_kernel(PairArgs a) {
-  using L = WaveLds<B>;
-  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+constexpr int pair_waves_per_simd() {
+  constexpr int blocks = (160 * 1024) / PairLds<B>::SIZE;
+  return blocks < 1 ? 1 : (blocks > 4 ? 4 : blocks);
+}
+
+template <int B>
+__global__ __launch_bounds__(256, pair_waves_per_simd<B>()) void sc_pair_kernel(PairArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  char *smem = smem_all + wave * L::SIZE;
+  char *wsm = smem + OFF_WAVES + wave * PairLds<B>::WAVE_SIZE;
   const int qi = blockIdx.y;
   const int slot = blockIdx.x * 4 + wave;
   const int nwaves = gridDim.x * 4;
-  const int cl = lane < NS ? lane : 0;   // column owned in stage 2
+  const int cl = lane < NS ? lane : 0;       // entry column owned in stage 2
   const int kk = lane < NS ? lane : NS - 1;  // shift owned in stage 1
 
-  // ---- query: column cl as 20 doubles in registers, norm, sector key to LDS ----
-  double qc[NR];
+  // ---- query -> LDS (once per block): fp64 image, norms, sector key ----
   {
-    const float4 *qp = reinterpret_cast<const float4 *>(a.q.desc + (int64_t)qi * DS + cl * NR);
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      float4 v = qp[i];
-      qc[4 * i + 0] = v.x; qc[4 * i + 1] = v.y; qc[4 * i + 2] = v.z; qc[4 * i + 3] = v.w;
+    const float *qd = a.q.desc + (int64_t)qi * DS;
+    for (int i = threadIdx.x; i < DS; i += 256) {
+      const int c = i / NR, r = i - c * NR;
+      *reinterpret_cast<double *>(smem + OFF_QIMG + c * Q_COL_STRIDE + r * 8) = (double)qd[i];
+    }
+    if (threadIdx.x < NS) {
+      reinterpret_cast<double *>(smem + OFF_QN1)[threadIdx.x] = a.q.norm[(int64_t)qi * NS + threadIdx.x];
+      reinterpret_cast<double *>(smem + OFF_QV1)[threadIdx.x] = a.q.vkey[(int64_t)qi * NS + threadIdx.x];
     }
   }
-  const double n1 = a.q.norm[(int64_t)qi * NS + cl];
-  double *v1 = reinterpret_cast<double *>(smem + L::OFF_V1);
-  if (lane < NS) v1[lane] = a.q.vkey[(int64_t)qi * NS + lane];
-  int *misc = reinterpret_cast<int *>(smem + L::OFF_MISC);
+  __syncthreads();
+  const double *v1 = reinterpret_cast<const double *>(smem + OFF_QV1);
+  const double *qn1 = reinterpret_cast<const double *>(smem + OFF_QN1);
 
   int64_t n_elig = a.n_eligible;
   if (a.q_elig) {
@@ -217,9 +238,12 @@ __global__ __launch_bounds__(256) void sc_pair_kernel(PairArgs a) {
 
   const int64_t ngroups = (a.n_items + B - 1) / B;
   for (int64_t g = slot; g < ngroups; g += nwaves) {
-    // ---- stage 0: stage B entries into this wave's LDS region ----
+    // ---- stage 0: issue the entry loads (column cl of each entry stays in registers as fp32
+    //      until stage 2; the sector key goes to LDS twice for the rotated reads of stage 1) ----
     int64_t eslot[B];
     bool evalid[B];
+    float4 ecol[B][5];
+    double en2[B];
 #pragma unroll
     for (int b = 0; b < B; b++) {
       int64_t item = g * B + b;
@@ -230,18 +254,15 @@ __global__ __launch_bounds__(256) void sc_pair_kernel(PairArgs a) {
     wave_lds_fence();
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      const float4 *src = reinterpret_cast<const float4 *>(a.db.desc + eslot[b] * DS);
-      float4 *dst = reinterpret_cast<float4 *>(smem + L::OFF_DESC + b * 4800);
+      const double v = a.db.vkey[eslot[b] * NS + cl];
+      const float4 *src = reinterpret_cast<const float4 *>(a.db.desc + eslot[b] * DS + cl * NR);
 #pragma unroll
-      for (int i = 0; i < 4; i++) dst[i * 64 + lane] = src[i * 64 + lane];
-      if (lane < 44) dst[256 + lane] = src[256 + lane];
-      double *vk = reinterpret_cast<double *>(smem + L::OFF_VKEY + b * 960);
-      double *nm = reinterpret_cast<double *>(smem + L::OFF_NORM + b * 512);
+      for (int i = 0; i < 5; i++) ecol[b][i] = src[i];
+      en2[b] = a.db.norm[eslot[b] * NS + cl];
+      double *vk = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY);
       if (lane < NS) {
-        double v = a.db.vkey[eslot[b] * NS + lane];
         vk[lane] = v;
         vk[lane + NS] = v;
-        nm[lane] = a.db.norm[eslot[b] * NS + lane];
       }
     }
     wave_lds_fence();
@@ -254,15 +275,19 @@ __global__ __launch_bounds__(256) void sc_pair_kernel(PairArgs a) {
       const double *v2[B];
 #pragma unroll
       for (int b = 0; b < B; b++)
-        v2[b] = reinterpret_cast<const double *>(smem + L::OFF_VKEY + b * 960) + (NS - kk);
+        v2[b] = reinterpret_cast<const double *>(wsm + b * ENT_SIZE + ENT_VKEY) + (NS - kk);
+      // chunks of 12 columns: bounded live ranges, immediate offsets inside a chunk
+#pragma unroll 1
+      for (int c0 = 0; c0 < NS; c0 += 12) {
 #pragma unroll
-      for (int c = 0; c < NS; c++) {
-        const double x = v1[c];
+        for (int cc = 0; cc < 12; cc++) {
+          const double x = v1[c0 + cc];
 #pragma unroll
-        for (int b = 0; b < B; b++) {
-          double d = x - v2[b][c];
-          double dd = d * d;
-          acc[b] = acc[b] + dd;
+          for (int b = 0; b < B; b++) {
+            double d = x - v2[b][c0 + cc];
+            double dd = d * d;
+            acc[b] = acc[b] + dd;
+          }
         }
       }
     }
@@ -279,49 +304,42 @@ __global__ __launch_bounds__(256) void sc_pair_kernel(PairArgs a) {
     }
 
     // ---- stage 2: column cosine terms for the 7 shifts k*-3..k*+3 (SC.cpp:123-144, 69-90) ----
-#pragma unroll 1
-    for (int b = 0; b < B; b++) {
-      int ks = kstar[0];
+    // lane = entry column j; shifted by k it lands on query column c = (j + k) % 60
 #pragma unroll
-      for (int bb = 1; bb < B; bb++) ks = (b == bb) ? kstar[bb] : ks;
-      const float *descb = reinterpret_cast<const float *>(smem + L::OFF_DESC + b * 4800);
-      const double *normb = reinterpret_cast<const double *>(smem + L::OFF_NORM + b * 512);
-      double sim[7];
-      int neff[7];
+    for (int b = 0; b < B; b++) {
+      const int ks = kstar[b];
+      double e[NR];
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        e[4 * i + 0] = ecol[b][i].x; e[4 * i + 1] = ecol[b][i].y;
+        e[4 * i + 2] = ecol[b][i].z; e[4 * i + 3] = ecol[b][i].w;
+      }
+      const double n2 = en2[b];
+      double *simp = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_SIM);
+      int *misc = reinterpret_cast<int *>(wsm + b * ENT_SIZE + ENT_MISC);
 #pragma unroll
       for (int t = 0; t < 7; t++) {
         int k = ks + t - 3;
         k += (k < 0) ? NS : 0;
         k -= (k >= NS) ? NS : 0;
-        int j = cl - k;  // column of the entry that lands on column cl after shifting by k
-        j += (j < 0) ? NS : 0;
-        const float4 *cp = reinterpret_cast<const float4 *>(descb + j * NR);
+        int c = cl + k;
+        c -= (c >= NS) ? NS : 0;
+        const double2 *qp = reinterpret_cast<const double2 *>(smem + OFF_QIMG + c * Q_COL_STRIDE);
         double dot = 0.0;
 #pragma unroll
-        for (int i = 0; i < 5; i++) {
-          float4 v = cp[i];
-          dot = fma(qc[4 * i + 0], (double)v.x, dot);  // fp32 x fp32 exact in fp64
-          dot = fma(qc[4 * i + 1], (double)v.y, dot);
-          dot = fma(qc[4 * i + 2], (double)v.z, dot);
-          dot = fma(qc[4 * i + 3], (double)v.w, dot);
+        for (int i = 0; i < 10; i++) {
+          double2 q2 = qp[i];
+          dot = fma(q2.x, e[2 * i + 0], dot);  // fp32 x fp32 exact in fp64: fma == mul + add
+          dot = fma(q2.y, e[2 * i + 1], dot);
         }
-        const double n2 = normb[j];
+        const double n1 = qn1[c];
         const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));  // SC.cpp:78
         const double s = dot / (n1 * n2);                                  // SC.cpp:81
-        sim[t] = valid ? s : 0.0;
-        neff[t] = __popcll(__ballot(valid));
+        if (lane < NS) simp[c * 7 + t] = valid ? s : 0.0;
+        const int ne = __popcll(__ballot(valid));
+        if (lane == 0) misc[t] = ne;
       }
-      wave_lds_fence();  // every lane has consumed the fp32 image of entry b
-      double *simp = reinterpret_cast<double *>(smem + L::OFF_DESC + b * 4800);
-      if (lane < NS) {
-#pragma unroll
-        for (int t = 0; t < 7; t++) simp[lane * 7 + t] = sim[t];
-      }
-      if (lane == 0) {
-#pragma unroll
-        for (int t = 0; t < 7; t++) misc[b * 8 + t] = neff[t];
-        misc[b * 8 + 7] = ks;
-      }
+      if (lane == 0) misc[7] = ks;
     }
     wave_lds_fence();
 
@@ -330,13 +348,17 @@ __global__ __launch_bounds__(256) void sc_pair_kernel(PairArgs a) {
     double bd = INFINITY;
     int bk = 0x7fffffff;
     if (bb < B && tt < 7) {
-      const double *sp = reinterpret_cast<const double *>(smem + L::OFF_DESC + bb * 4800) + tt;
+      const double *sp = reinterpret_cast<const double *>(wsm + bb * ENT_SIZE + ENT_SIM) + tt;
+      const int *misc = reinterpret_cast<const int *>(wsm + bb * ENT_SIZE + ENT_MISC);
       double s = 0.0;
+#pragma unroll 1
+      for (int c0 = 0; c0 < NS; c0 += 12) {
 #pragma unroll
-      for (int c = 0; c < NS; c++) s = s + sp[c * 7];
-      const int ne = misc[bb * 8 + tt];
+        for (int cc = 0; cc < 12; cc++) s = s + sp[(c0 + cc) * 7];
+      }
+      const int ne = misc[tt];
       const double d = 1.0 - s / (double)ne;  // 0/0 -> NaN when no effective column
-      int k = misc[bb * 8 + 7] + tt - 3;
+      int k = misc[7] + tt - 3;
       k += (k < 0) ? NS : 0;
       k -= (k >= NS) ? NS : 0;
       if (d < kBig) {  // SC.cpp:134,139: strict `<` against the 1e7 init; NaN fails
@@ -531,7 +553,7 @@ __global__ __launch_bounds__(1024) void sc_knn_kernel(const float *__restrict__ 
 template <int B>
 int launch_pairs_t(const PairArgs &a, int gx, hipStream_t s) {
   static bool attr_set = false;
-  const int lds = 4 * WaveLds<B>::SIZE;
+  const int lds = PairLds<B>::SIZE;
   if (!attr_set) {
     RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_pair_kernel<B>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -543,9 +565,18 @@ int launch_pairs_t(const PairArgs &a, int gx, hipStream_t s) {
   return RSX_OK;
 }
 
-constexpr int kB = 4;
+// entries per wave iteration: compiled for 1, 2, 4; RSX_SC_PAIR_B overrides the tuned default
+int pair_B() {
+  static int b = [] {
+    const char *e = getenv("RSX_SC_PAIR_B");
+    int v = e ? atoi(e) : 2;
+    return (v == 1 || v == 2 || v == 4) ? v : 2;
+  }();
+  return b;
+}
 
 int choose_gx(int64_t n_items, int32_t nq) {
+  const int kB = pair_B();
   const int64_t ngroups = (n_items + kB - 1) / kB;
   int64_t max_gx = (ngroups + 3) / 4;
   if (max_gx < 1) max_gx = 1;
@@ -623,7 +654,11 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   a.nslots = gx * 4;
   PairProfiler *pp = (g_prof && g_prof->on && g_prof->ev && g_prof->used < PairProfiler::kMax) ? g_prof : nullptr;
   if (pp) RSX_HIP(hipEventRecord(pp->ev[2 * pp->used], s));
-  RSX_TRY(launch_pairs_t<kB>(a, gx, s));
+  switch (pair_B()) {
+    case 1: RSX_TRY(launch_pairs_t<1>(a, gx, s)); break;
+    case 2: RSX_TRY(launch_pairs_t<2>(a, gx, s)); break;
+    default: RSX_TRY(launch_pairs_t<4>(a, gx, s)); break;
+  }
   if (pp) {
     RSX_HIP(hipEventRecord(pp->ev[2 * pp->used + 1], s));
     pp->used++;

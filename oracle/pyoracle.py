@@ -81,6 +81,7 @@ def lib():
         L.scref_detect_between_session.restype = C.c_int
         L.scref_detect_between_session.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.scref_exhaustive.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int]
+        L.scref_exhaustive_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_int]
         L.scref_pair_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         L.scref_merge_topk.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.scref_make_scancontext.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_double, C.c_double, C.c_void_p]
@@ -268,6 +269,14 @@ class Manager:
             n_eligible = len(self)
         out = np.zeros(k, dtype=HIT_DTYPE)
         self._L.scref_exhaustive(self._h, qdesc.ctypes.data, n_eligible, k, out.ctypes.data, nthreads)
+        return out
+
+    def exhaustive_batch(self, qdescs, n_eligible=None, k=1, nthreads=1):
+        q = np.ascontiguousarray(qdescs, dtype=np.float64).reshape(-1, DS)
+        if n_eligible is None:
+            n_eligible = len(self)
+        out = np.zeros((q.shape[0], k), dtype=HIT_DTYPE)
+        self._L.scref_exhaustive_batch(self._h, q.ctypes.data, q.shape[0], n_eligible, k, out.ctypes.data, nthreads)
         return out
 
     def pair_distances(self, qdesc, first=0, count=None, nthreads=1):

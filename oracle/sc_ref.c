@@ -545,3 +545,12 @@ void scref_merge_topk(const scref_hit *parts, int nparts, int k, scref_hit *out)
     out[i].shift = 0;
   }
 }
+
+/* nq queries, OpenMP over queries (each query scans the DB on one thread): the fair multi-core
+ * form of the CPU baseline (bench.py cpu_baseline). */
+void scref_exhaustive_batch(const scref_mgr *m, const double *query_descs, int nq, int64_t n_eligible,
+                            int k, scref_hit *out, int nthreads) {
+#pragma omp parallel for schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+  for (int q = 0; q < nq; q++)
+    scref_exhaustive(m, query_descs + (size_t)q * DS, n_eligible, k, out + (size_t)q * k, 1);
+}

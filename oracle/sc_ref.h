@@ -108,6 +108,9 @@ int64_t scref_tree_size(const scref_mgr *m);
  * {1e7, 0, 0} like SC.cpp:362-364.  nthreads>1 uses OpenMP over entries. */
 void scref_exhaustive(const scref_mgr *m, const double *query_desc, int64_t n_eligible, int k,
                       scref_hit *out, int nthreads);
+/* nq queries at once, OpenMP over queries */
+void scref_exhaustive_batch(const scref_mgr *m, const double *query_descs, int nq, int64_t n_eligible,
+                            int k, scref_hit *out, int nthreads);
 /* dist/shift of the query against every entry in [first, first+count) */
 void scref_pair_distances(const scref_mgr *m, const double *query_desc, int64_t first,
                           int64_t count, double *dist, int32_t *shift, int nthreads);
