@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd databases (gpurun_out/prof_<tag>/*/*.db) into a text report that is
+small enough to commit under profiles/.  Usage: tools/rocpd_summary.py gpurun_out/prof_r01a > profiles/...txt"""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def main(root):
+    trace = glob.glob(os.path.join(root, "trace", "*.db"))
+    if trace:
+        con = sqlite3.connect(trace[0])
+        print("== rocprofv3 --kernel-trace --stats (top kernels; durations in us) ==")
+        print(f"{'calls':>7} {'total_us':>14} {'avg_us':>12} {'pct':>7}  name")
+        for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels limit 12"):
+            print(f"{calls:7d} {total:14.3f} {avg:12.3f} {pct:7.2f}  {name[:110]}")
+        print("\n== per-dispatch durations of the dominant kernel (largest grids first) ==")
+        q = ("select name, grid_x*grid_y*grid_z as g, count(*), avg(duration)/1000.0, min(duration)/1000.0, max(duration)/1000.0 "
+             "from kernels where name like '%_kernel%' and name like '%rsx%' group by name, g order by avg(duration) desc limit 8")
+        try:
+            for name, grid, n, avg, mn, mx in con.execute(q):
+                print(f"grid={grid:>10} launches={n:4d} avg_us={avg:12.3f} min_us={mn:12.3f} max_us={mx:12.3f}  {name[:60]}")
+        except sqlite3.Error as e:
+            print("  (kernels view unavailable:", e, ")")
+    for db in sorted(glob.glob(os.path.join(root, "pmc*", "*.db"))):
+        con = sqlite3.connect(db)
+        print(f"\n== PMC pass {os.path.basename(os.path.dirname(db))} (largest-grid dispatches of each kernel only) ==")
+        q = ("select kernel_name, counter_name, count(*), avg(value), grid_size, vgpr_count, lds_block_size from counters_collection c "
+             "where grid_size = (select max(grid_size) from counters_collection d where d.kernel_name = c.kernel_name) "
+             "group by kernel_name, counter_name order by kernel_name, counter_name")
+        for name, cname, n, avg, grid, vgpr, lds in con.execute(q):
+            if "rsx" not in name:
+                continue
+            short = name.split("::")[-1][:40]
+            print(f"{short:42s} {cname:24s} dispatches={n:3d} avg_per_dispatch={avg:18.1f} grid={grid} vgpr={vgpr} lds={lds}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])
