@@ -71,6 +71,50 @@ def cpu_baseline(descs, queries, k):
     }
 
 
+def orora_leg(device, skip_cpu):
+    """Second half of the metric: ORORA scan-pairs/sec (BASELINE configs[2]: one KAIST03-length
+    sequence, 3500 consecutive pairs, 300-1500 matches each, batched registration on one GPU)."""
+    import torch
+    from navtech_radar_slam_amd import orora, synth
+    n_pairs = 3500
+    src, dst, off, truth = synth.orora_pairs(777, n_pairs)
+    reg = orora.Orora(device=device)
+    d_src, d_dst = torch.from_numpy(src).cuda(), torch.from_numpy(dst).cuda()
+    d_off = torch.from_numpy(off).cuda()
+    d_res = torch.zeros((n_pairs, 5), dtype=torch.float64, device="cuda")  # 40-byte rsx_orora_result
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        reg.register_batch_device(d_src.data_ptr(), d_dst.data_ptr(), d_off.data_ptr(), n_pairs, d_res.data_ptr(), stream=stream)
+
+    for _ in range(2):
+        run()
+    torch.cuda.synchronize()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    res = d_res.cpu().numpy().view(orora.ORORA_RESULT_DTYPE).reshape(n_pairs)
+    err = max(np.abs(res["x"] - truth[:, 0]).max(), np.abs(res["y"] - truth[:, 1]).max())
+    leg = {"pairs_per_sec": n_pairs / dt, "ms_per_batch": dt * 1e3, "n_pairs": n_pairs,
+           "matches_per_pair": "300-1500", "outliers": "20-60%", "max_abs_translation_error_m": float(err),
+           "max_abs_yaw_error_rad": float(np.abs(res["yaw"] - truth[:, 2]).max()), "dtype": "f64",
+           "note": "latency/VALU-bound per pair (K x 16 B input); no HBM roofline applies (SURVEY 8d)"}
+    if not skip_cpu:
+        from oracle import pyoracle as po
+        cores = os.cpu_count() or 1
+        t0 = time.perf_counter()
+        want = po.orora_register_batch(src, dst, off, nthreads=cores)
+        cdt = time.perf_counter() - t0
+        leg["cpu_baseline"] = {"value": n_pairs / cdt, "unit": "pairs/s", "cores": cores, "kind": "port",
+                               "sample": f"the same {n_pairs} pairs, OpenMP over pairs (oracle/orora_ref.c)"}
+        leg["max_abs_pose_diff_vs_oracle"] = float(max(np.abs(res[f] - want[f]).max() for f in ("x", "y", "yaw")))
+    reg.close()
+    return leg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,6 +228,7 @@ def main():
             small.query(queries[:1], k=1, n_eligible=970)
         out["latency_q1_n1k_us"] = (time.perf_counter() - t0) / 50 * 1e6
         small.close()
+        out["orora"] = orora_leg(local_rank, args.no_cpu_baseline)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(descs, queries, k)
         print(json.dumps(out), flush=True)

@@ -162,6 +162,47 @@ const char *rsx_sc_dominant_kernel_name(void);
 int rsx_sc_profile_enable(rsx_sc *h, int on);
 int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms);
 
+/* ============================== ORORA registration ======================================
+ * Replaces the solver stage of the upstream file-based `odometry.cpp` entry (reference
+ * README.md:27; package `orora`, launch/navtech_radar_slam_mulran.launch:5-8).  The ORORA sources
+ * are an empty submodule in the reference checkout (.gitmodules:1-3), so these entry points follow
+ * the published algorithm (oracle/orora_ref.h) -- parity unpinned.
+ * Stateless per call; a handle only owns a stream and staging buffers. */
+
+typedef struct rsx_orora rsx_orora;
+
+typedef struct {
+  double tim_noise_bound;        /* bound on ||b - R a|| of an inlier TIM (2 x point noise bound) */
+  double noise_bound_radial;     /* A-COTE radial bound [m] */
+  double noise_bound_tangential; /* A-COTE tangential bound [rad] (x range) */
+  double gnc_factor;             /* mu growth per GNC iteration (1.4) */
+  double cost_threshold;         /* GNC stops when |cost - prev_cost| < this */
+  int32_t max_iterations;        /* GNC iteration cap */
+  int32_t reserved;
+} rsx_orora_params;
+
+typedef struct {
+  double x, y, yaw;      /* dst = R(yaw) src + (x, y) */
+  int32_t iterations;    /* GNC iterations executed */
+  int32_t rot_inliers;   /* TIMs with final weight >= 0.5 */
+  int32_t trans_inliers; /* matches inside both axis intervals at the estimate */
+  int32_t status;        /* 0 ok; 1 fewer than 2 matches (identity); 2 more than
+                            rsx_orora_max_correspondences() matches (identity) */
+} rsx_orora_result;
+
+int rsx_orora_default_params(rsx_orora_params *p);
+int rsx_orora_max_correspondences(void);
+int rsx_orora_create(int device, rsx_orora **out);
+int rsx_orora_destroy(rsx_orora *h);
+/* n_pairs scan pairs; pair i owns matches [offsets[i], offsets[i+1]) of the concatenated
+ * src_xy/dst_xy arrays (float x,y per match).  Host buffers, synchronous. */
+int rsx_orora_register_batch(rsx_orora *h, const float *src_xy, const float *dst_xy, const int64_t *offsets,
+                             int32_t n_pairs, const rsx_orora_params *params, rsx_orora_result *out);
+/* device buffers, asynchronous on `stream` */
+int rsx_orora_register_batch_device(rsx_orora *h, const float *d_src_xy, const float *d_dst_xy,
+                                    const int64_t *d_offsets, int32_t n_pairs, const rsx_orora_params *params,
+                                    rsx_orora_result *d_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

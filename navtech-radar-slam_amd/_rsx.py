@@ -39,6 +39,15 @@ class ScParams(C.Structure):
     ]
 
 
+class OroraParams(C.Structure):
+    _fields_ = [("tim_noise_bound", C.c_double), ("noise_bound_radial", C.c_double),
+                ("noise_bound_tangential", C.c_double), ("gnc_factor", C.c_double),
+                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+
+
+ORORA_RESULT_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("iterations", "<i4"),
+                               ("rot_inliers", "<i4"), ("trans_inliers", "<i4"), ("status", "<i4")])
+
 _lib = None
 
 # every symbol include/rsx.h declares (tests check the .so exports exactly these)
@@ -51,6 +60,8 @@ SYMBOLS = [
     "rsx_sc_tree_size", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_self_device",
     "rsx_sc_pair_distances", "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
     "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read",
+    "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
+    "rsx_orora_register_batch", "rsx_orora_register_batch_device",
 ]
 
 
@@ -98,6 +109,11 @@ def lib():
         L.rsx_sc_profile_enable.argtypes = [vp, C.c_int]
         L.rsx_sc_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl)]
         L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
+        L.rsx_orora_default_params.argtypes = [C.POINTER(OroraParams)]
+        L.rsx_orora_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.rsx_orora_destroy.argtypes = [vp]
+        L.rsx_orora_register_batch.argtypes = [vp, vp, vp, vp, i32, C.POINTER(OroraParams), vp]
+        L.rsx_orora_register_batch_device.argtypes = [vp, vp, vp, vp, i32, C.POINTER(OroraParams), vp, vp]
         _lib = L
     return _lib
 

@@ -124,3 +124,46 @@ def rotate_descriptor(desc_f32, k):
     """Column-rotate right by k sectors: new[(s+k)%60] = old[s] (Scancontext.cpp:39-59)."""
     d = desc_f32.reshape(NUM_SECTOR, NUM_RING)
     return np.roll(d, k, axis=0).reshape(-1).copy()
+
+
+# ---------------------------------------------------------------------------------------------
+# ORORA: matched feature pairs between consecutive scans (SURVEY.md 8d, config 3; seed 777)
+# ---------------------------------------------------------------------------------------------
+def orora_pairs(seed, n_pairs, k_range=(300, 1500), outlier_range=(0.2, 0.6), max_range=150.0):
+    """n_pairs scan pairs.  Each: K matches, a fraction of them outliers, inliers perturbed by
+    anisotropic polar noise (radial sigma 0.06 m, tangential sigma = range * 0.2 deg).
+
+    Returns src (M,2) f32, dst (M,2) f32, offsets (n_pairs+1,) i64, truth (n_pairs,3) f64 with
+    dst = R(yaw) src + (x, y).
+    """
+    rng = np.random.default_rng(seed)
+    ks = rng.integers(k_range[0], k_range[1] + 1, n_pairs)
+    offsets = np.zeros(n_pairs + 1, dtype=np.int64)
+    offsets[1:] = np.cumsum(ks)
+    m = int(offsets[-1])
+    src = np.empty((m, 2), dtype=np.float32)
+    dst = np.empty((m, 2), dtype=np.float32)
+    truth = np.empty((n_pairs, 3), dtype=np.float64)
+    for i in range(n_pairs):
+        k = int(ks[i])
+        r = rng.uniform(4.0, max_range, k)
+        th = rng.uniform(0.0, 2 * np.pi, k)
+        s = np.stack([r * np.cos(th), r * np.sin(th)], axis=1)
+        yaw = rng.uniform(-0.2, 0.2)
+        t = rng.uniform(-2.5, 2.5, 2)
+        c, sn = np.cos(yaw), np.sin(yaw)
+        d = s @ np.array([[c, sn], [-sn, c]]) + t
+        # anisotropic noise in the polar frame of the destination point
+        rd = np.hypot(d[:, 0], d[:, 1])
+        ud = d / rd[:, None]
+        td = np.stack([-ud[:, 1], ud[:, 0]], axis=1)
+        d = d + ud * rng.normal(0, 0.06, k)[:, None] + td * (rd * np.deg2rad(0.2) * rng.normal(0, 1.0, k))[:, None]
+        n_out = int(rng.uniform(*outlier_range) * k)
+        out_idx = rng.choice(k, n_out, replace=False)
+        ro = rng.uniform(4.0, max_range, n_out)
+        to = rng.uniform(0.0, 2 * np.pi, n_out)
+        d[out_idx] = np.stack([ro * np.cos(to), ro * np.sin(to)], axis=1)
+        src[offsets[i]:offsets[i + 1]] = s
+        dst[offsets[i]:offsets[i + 1]] = d
+        truth[i] = (t[0], t[1], yaw)
+    return src, dst, offsets, truth

@@ -319,3 +319,48 @@ class RefKdTree:
         dist = np.zeros(k, dtype=np.float32)
         n = self._R.ref_kdtree_knn(self._h, q.ctypes.data, k, idx.ctypes.data, dist.ctypes.data)
         return n, idx.astype(np.int64), dist
+
+
+# ------------------------------------------------------------------------------------------
+# ORORA (oracle/orora_ref.c) -- PARITY UNPINNED, see the header of orora_ref.h
+# ------------------------------------------------------------------------------------------
+class OroraParams(C.Structure):
+    _fields_ = [("tim_noise_bound", C.c_double), ("noise_bound_radial", C.c_double),
+                ("noise_bound_tangential", C.c_double), ("gnc_factor", C.c_double),
+                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+
+
+ORORA_RESULT_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("iterations", "<i4"),
+                               ("rot_inliers", "<i4"), ("trans_inliers", "<i4"), ("status", "<i4")])
+
+
+def orora_default_params():
+    p = OroraParams()
+    lib().ororaref_default_params(C.byref(p))
+    return p
+
+
+def orora_register_batch(src, dst, offsets, params=None, nthreads=1):
+    L = lib()
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    dst = np.ascontiguousarray(dst, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    if params is None:
+        params = orora_default_params()
+    n = offsets.size - 1
+    out = np.zeros(n, dtype=ORORA_RESULT_DTYPE)
+    L.ororaref_register_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int]
+    L.ororaref_register_batch(src.ctypes.data, dst.ctypes.data, offsets.ctypes.data, n, C.byref(params),
+                              out.ctypes.data, nthreads)
+    return out
+
+
+def orora_scalar_tls(x, beta):
+    L = lib()
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    beta = np.ascontiguousarray(beta, dtype=np.float64)
+    L.ororaref_scalar_tls.restype = C.c_double
+    L.ororaref_scalar_tls.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    n_in = C.c_int32()
+    est = L.ororaref_scalar_tls(x.ctypes.data, beta.ctypes.data, x.size, C.byref(n_in))
+    return est, n_in.value

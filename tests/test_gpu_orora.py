@@ -1,0 +1,75 @@
+"""GPU parity of ORORA registration (orora.hip through the C-ABI) against the CPU oracle.
+Tolerance (north_star): pose within 1e-4 of the oracle (reductions run in a different order on the
+GPU, so this is a tolerance test, not a bit-exact one)."""
+import numpy as np
+import pytest
+
+from navtech_radar_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def reg():
+    from navtech_radar_slam_amd import orora, _rsx
+    assert _rsx.device_count() >= 1
+    return orora.Orora()
+
+
+def _check(got, want):
+    assert np.array_equal(got["status"], want["status"])
+    ok = want["status"] == 0
+    for f in ("x", "y", "yaw"):
+        assert np.abs(got[f][ok] - want[f][ok]).max() < POSE_TOL, f
+    assert np.array_equal(got["iterations"], want["iterations"])
+    assert np.abs(got["rot_inliers"] - want["rot_inliers"]).max() <= 1
+    assert np.abs(got["trans_inliers"] - want["trans_inliers"]).max() <= 1
+
+
+def test_batch_matches_oracle(reg, oracle):
+    src, dst, off, truth = synth.orora_pairs(777, 300)
+    got = reg.register_batch(src, dst, off)
+    want = oracle.orora_register_batch(src, dst, off, nthreads=8)
+    _check(got, want)
+    assert np.abs(got["x"] - truth[:, 0]).max() < 0.05 and np.abs(got["yaw"] - truth[:, 2]).max() < 2e-3
+
+
+def test_edge_sizes(reg, oracle):
+    from navtech_radar_slam_amd import orora
+    maxk = orora.max_correspondences()
+    sizes = [0, 1, 2, 3, 5, 255, 256, 257, 511, 512, 1024, maxk, maxk + 1]
+    rng = np.random.default_rng(5)
+    src, dst, off = [], [], [0]
+    for k in sizes:
+        s = rng.uniform(-80, 80, (k, 2))
+        d = s @ np.array([[np.cos(0.05), np.sin(0.05)], [-np.sin(0.05), np.cos(0.05)]]) + [0.5, 0.25]
+        d += rng.normal(0, 0.03, d.shape)
+        if k > 10:
+            d[: k // 3] = rng.uniform(-80, 80, (k // 3, 2))
+        src.append(s); dst.append(d); off.append(off[-1] + k)
+    src = np.concatenate(src).astype(np.float32)
+    dst = np.concatenate(dst).astype(np.float32)
+    off = np.array(off, dtype=np.int64)
+    got = reg.register_batch(src, dst, off)
+    want = oracle.orora_register_batch(src, dst, off)
+    assert list(got["status"][:2]) == [1, 1] and got["status"][-1] == 2   # too few / too many matches
+    want["status"][-1] = 2                                                  # the oracle has no size cap
+    for f in ("x", "y", "yaw", "iterations", "rot_inliers", "trans_inliers"):
+        want[f][-1] = 0
+    _check(got, want)
+
+
+def test_clean_and_all_outlier_pairs(reg, oracle):
+    rng = np.random.default_rng(9)
+    s = rng.uniform(-50, 50, (400, 2)).astype(np.float32)
+    c, sn = np.cos(-0.15), np.sin(-0.15)
+    clean = (s.astype(np.float64) @ np.array([[c, sn], [-sn, c]]) + [-1.5, 2.0]).astype(np.float32)
+    junk = rng.uniform(-50, 50, (400, 2)).astype(np.float32)
+    src = np.concatenate([s, s]); dst = np.concatenate([clean, junk]); off = np.array([0, 400, 800])
+    got = reg.register_batch(src, dst, off)
+    want = oracle.orora_register_batch(src, dst, off)
+    assert got["iterations"][0] == 1 and abs(got["yaw"][0] + 0.15) < 1e-5
+    assert got["status"][1] == 0                                            # garbage in, finite pose out
+    _check(got[:1], want[:1])
+    assert np.all(np.isfinite([got["x"][1], got["y"][1], got["yaw"][1]]))
