@@ -203,6 +203,31 @@ int rsx_orora_register_batch_device(rsx_orora *h, const float *d_src_xy, const f
                                     const int64_t *d_offsets, int32_t n_pairs, const rsx_orora_params *params,
                                     rsx_orora_result *d_out, void *stream);
 
+/* ============================== cen2019 keypoint extraction ============================
+ * Replaces the feature-extraction stage of the upstream file-based `odometry.cpp` entry
+ * (reference README.md:27,29).  Source absent from the reference checkout (empty submodule):
+ * follows the published method (oracle/cen2019_ref.c) -- parity unpinned. */
+
+typedef struct rsx_cen2019 rsx_cen2019;
+
+typedef struct {
+  int32_t max_points; /* budget of marked regions (10000) */
+  int32_t min_range;  /* first range bin considered for keypoints (58) */
+} rsx_cen2019_params;
+
+int rsx_cen2019_default_params(rsx_cen2019_params *p);
+/* one handle per image shape: rows azimuths x cols range bins (MulRan/Navtech: 400 x 3360) */
+int rsx_cen2019_create(int device, int32_t rows, int32_t cols, rsx_cen2019 **out);
+int rsx_cen2019_destroy(rsx_cen2019 *h);
+/* img: rows x row_stride bytes (host), power samples at [col_offset, col_offset+cols) of each row
+ * (col_offset = 11 for MulRan polar_oxford_form rows).  out_targets: (azimuth idx, range idx) int32
+ * pairs in row-major order.  If azimuths (rows floats, rad) is given, out_xy (optional) receives
+ * x = (r+0.5)*resolution*cos(az), y = ...*sin(az) -- the /orora/cloud_local points.
+ * *out_count = keypoints found (only the first max_targets are written). */
+int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, int32_t col_offset,
+                        const rsx_cen2019_params *params, const float *azimuths, float resolution,
+                        int32_t *out_targets, float *out_xy, int32_t max_targets, int32_t *out_count);
+
 #ifdef __cplusplus
 }
 #endif

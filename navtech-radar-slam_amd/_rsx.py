@@ -45,6 +45,10 @@ class OroraParams(C.Structure):
                 ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
 
 
+class Cen2019Params(C.Structure):
+    _fields_ = [("max_points", C.c_int32), ("min_range", C.c_int32)]
+
+
 ORORA_RESULT_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("iterations", "<i4"),
                                ("rot_inliers", "<i4"), ("trans_inliers", "<i4"), ("status", "<i4")])
 
@@ -62,6 +66,7 @@ SYMBOLS = [
     "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read",
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
     "rsx_orora_register_batch", "rsx_orora_register_batch_device",
+    "rsx_cen2019_default_params", "rsx_cen2019_create", "rsx_cen2019_destroy", "rsx_cen2019_extract",
 ]
 
 
@@ -114,6 +119,11 @@ def lib():
         L.rsx_orora_destroy.argtypes = [vp]
         L.rsx_orora_register_batch.argtypes = [vp, vp, vp, vp, i32, C.POINTER(OroraParams), vp]
         L.rsx_orora_register_batch_device.argtypes = [vp, vp, vp, vp, i32, C.POINTER(OroraParams), vp, vp]
+        L.rsx_cen2019_default_params.argtypes = [C.POINTER(Cen2019Params)]
+        L.rsx_cen2019_create.argtypes = [C.c_int, i32, i32, C.POINTER(vp)]
+        L.rsx_cen2019_destroy.argtypes = [vp]
+        L.rsx_cen2019_extract.argtypes = [vp, vp, i32, i32, C.POINTER(Cen2019Params), vp, C.c_float, vp, vp, i32,
+                                          C.POINTER(i32)]
         _lib = L
     return _lib
 

@@ -167,3 +167,44 @@ def orora_pairs(seed, n_pairs, k_range=(300, 1500), outlier_range=(0.2, 0.6), ma
         dst[offsets[i]:offsets[i + 1]] = d
         truth[i] = (t[0], t[1], yaw)
     return src, dst, offsets, truth
+
+
+# ---------------------------------------------------------------------------------------------
+# polar radar images in MulRan "polar_oxford_form" (SURVEY.md B.1): one row per azimuth,
+# bytes 0-7 int64 timestamp, 8-9 uint16 encoder count (azimuth = count * 2 pi / 5600), 10 valid
+# flag, 11.. power bytes (3360 bins for the Navtech CIR204-H, ~0.0595 m per bin)
+# ---------------------------------------------------------------------------------------------
+OXFORD_META = 11
+RADAR_RESOLUTION = 0.0595
+
+
+def polar_image(seed, rows=400, cols=3360, n_targets=1200, shift_rows=0, t0=1_560_000_000_000_000_000):
+    """Synthetic scan: speckle noise floor that decays with range + bright extended targets.
+    shift_rows rolls the scene in azimuth (a pure sensor rotation).  Returns (img uint8
+    [rows, 11+cols], azimuths float32 [rows] in rad, target centres (n,2) as (a, r))."""
+    rng = np.random.default_rng(seed)
+    r_idx = np.arange(cols, dtype=np.float32)[None, :]
+    floor = 18.0 + 30.0 * np.exp(-r_idx / 900.0)
+    power = rng.gamma(2.0, floor / 2.0, size=(rows, cols)).astype(np.float32)
+    ta = rng.integers(0, rows, n_targets)
+    tr = rng.integers(70, cols - 40, n_targets)
+    amp = rng.uniform(90.0, 220.0, n_targets)
+    wa = rng.integers(1, 4, n_targets)
+    wr = rng.integers(2, 9, n_targets)
+    for a0, r0, am, da, dr in zip(ta, tr, amp, wa, wr):
+        aa = (np.arange(-da, da + 1) + a0) % rows
+        rr = np.arange(max(0, r0 - dr), min(cols, r0 + dr + 1))
+        prof = np.exp(-0.5 * ((rr - r0) / (0.5 * dr + 0.5)) ** 2)[None, :] * \
+            np.exp(-0.5 * (np.arange(-da, da + 1) / (0.5 * da + 0.5)) ** 2)[:, None]
+        power[np.ix_(aa, rr)] += am * prof
+    power = np.roll(power, shift_rows, axis=0)
+    img = np.zeros((rows, OXFORD_META + cols), dtype=np.uint8)
+    img[:, OXFORD_META:] = np.clip(power, 0, 255).astype(np.uint8)
+    counts = (np.arange(rows) * (5600 // rows)).astype(np.uint16)
+    ts = (t0 + np.arange(rows, dtype=np.int64) * 625_000).astype("<i8")
+    img[:, 0:8] = ts.view(np.uint8).reshape(rows, 8)
+    img[:, 8:10] = counts.astype("<u2").view(np.uint8).reshape(rows, 2)
+    img[:, 10] = 255
+    az = (counts.astype(np.float64) * 2 * np.pi / 5600.0).astype(np.float32)
+    centres = np.stack([(ta + shift_rows) % rows, tr], axis=1)
+    return img, az, centres

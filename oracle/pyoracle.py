@@ -364,3 +364,37 @@ def orora_scalar_tls(x, beta):
     n_in = C.c_int32()
     est = L.ororaref_scalar_tls(x.ctypes.data, beta.ctypes.data, x.size, C.byref(n_in))
     return est, n_in.value
+
+
+# ------------------------------------------------------------------------------------------
+# cen2019 (oracle/cen2019_ref.c) -- PARITY UNPINNED, see the header of cen2019_ref.c
+# ------------------------------------------------------------------------------------------
+def cen2019_extract(img, cols=None, col_offset=11, max_points=10000, min_range=58, max_targets=200000, debug=False):
+    """img: (rows, row_stride) uint8 -> (n,2) int32 (azimuth idx, range idx) [+ debug dict]."""
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rows, stride = img.shape
+    if cols is None:
+        cols = stride - col_offset
+    out = np.zeros((max_targets, 2), dtype=np.int32)
+    L.cen2019ref_extract.restype = C.c_int32
+    L.cen2019ref_extract.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    h = np.empty((rows, cols), dtype=np.float32) if debug else None
+    mean_h, ncand, jstar = C.c_float(), C.c_int64(), C.c_int64()
+    n = L.cen2019ref_extract(img.ctypes.data, rows, cols, stride, col_offset, max_points, min_range, out.ctypes.data,
+                             max_targets, h.ctypes.data if debug else None, C.byref(mean_h), C.byref(ncand), C.byref(jstar))
+    res = out[:min(n, max_targets)].copy()
+    if debug:
+        return res, {"h": h, "mean_h": mean_h.value, "ncand": ncand.value, "jstar": jstar.value, "count": n}
+    return res
+
+
+def cen2019_to_cartesian(targets, azimuths, resolution):
+    L = lib()
+    t = np.ascontiguousarray(targets, dtype=np.int32)
+    az = np.ascontiguousarray(azimuths, dtype=np.float32)
+    out = np.empty((t.shape[0], 2), dtype=np.float32)
+    L.cen2019ref_to_cartesian.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]
+    L.cen2019ref_to_cartesian(t.ctypes.data, t.shape[0], az.ctypes.data, resolution, out.ctypes.data)
+    return out
