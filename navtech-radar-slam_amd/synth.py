@@ -178,14 +178,20 @@ OXFORD_META = 11
 RADAR_RESOLUTION = 0.0595
 
 
-def polar_image(seed, rows=400, cols=3360, n_targets=1200, shift_rows=0, t0=1_560_000_000_000_000_000):
+def polar_image(seed, rows=400, cols=3360, n_targets=1200, shift_rows=0, t0=1_560_000_000_000_000_000,
+                noise_seed=None):
     """Synthetic scan: speckle noise floor that decays with range + bright extended targets.
-    shift_rows rolls the scene in azimuth (a pure sensor rotation).  Returns (img uint8
+    shift_rows rolls the scene in azimuth (a pure sensor rotation); noise_seed draws a different
+    speckle realisation over the same targets (a later scan from the same pose).  Returns (img uint8
     [rows, 11+cols], azimuths float32 [rows] in rad, target centres (n,2) as (a, r))."""
     rng = np.random.default_rng(seed)
     r_idx = np.arange(cols, dtype=np.float32)[None, :]
     floor = 18.0 + 30.0 * np.exp(-r_idx / 900.0)
-    power = rng.gamma(2.0, floor / 2.0, size=(rows, cols)).astype(np.float32)
+    nrng = rng if noise_seed is None else np.random.default_rng(noise_seed)
+    noise = nrng.gamma(2.0, floor / 2.0, size=(rows, cols)).astype(np.float32)
+    if noise_seed is not None:
+        rng.gamma(2.0, floor / 2.0, size=(rows, cols))  # keep the target stream aligned with noise_seed=None
+    power = noise
     ta = rng.integers(0, rows, n_targets)
     tr = rng.integers(70, cols - 40, n_targets)
     amp = rng.uniform(90.0, 220.0, n_targets)
