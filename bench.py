@@ -128,7 +128,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from navtech_radar_slam_amd import scancontext
+    from navtech_radar_slam_amd import scancontext, sharded
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -146,25 +146,22 @@ def main():
     descs, queries, src, rot = make_db_and_queries(n_db, nq)
     n_elig = n_db - 30  # NUM_EXCLUDE_RECENT (SC.h:92): the newest 30 keyframes are never candidates
 
-    mgr = scancontext.SCManager(device=local_rank, shard_rank=rank, shard_world=world, capacity_hint=n_db // world + 8)
     # an explicit (non-null) torch stream: the C-ABI launches on it, torch.distributed collectives
     # and torch.cuda.Event see the same stream
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
     stream = tstream.cuda_stream
+    # DB shard of this rank (keyframe i lives on rank i % world); one all-gather + merge per step
+    ssc = sharded.ShardedScanContext(device=local_rank, capacity_hint=n_db // world + 8)
+    mgr = ssc.backend
     d_db = torch.from_numpy(descs).cuda()
-    mgr.add_descriptors_device(d_db.data_ptr(), n_db, stream=stream)  # DB resident in HBM (keys built on GPU)
+    ssc.add_descriptors_device(d_db.data_ptr(), n_db, stream=stream)  # DB resident in HBM (keys built on GPU)
     del d_db
     d_q = torch.from_numpy(queries).cuda()
-    d_out = torch.zeros((nq, k, 2), dtype=torch.float64, device="cuda")  # 16-byte rsx_sc_hit records
-    d_parts = torch.zeros((world, nq, k, 2), dtype=torch.float64, device="cuda") if world > 1 else None
-    d_final = torch.zeros_like(d_out) if world > 1 else d_out
+    result = {}
 
     def step():
-        mgr.query_device(d_q.data_ptr(), nq, k, d_out.data_ptr(), n_eligible=n_elig, stream=stream)
-        if world > 1:
-            dist.all_gather_into_tensor(d_parts.view(world * nq * k * 2), d_out.view(-1))
-            mgr.merge_device(d_parts.data_ptr(), world, nq, k, d_final.data_ptr(), stream=stream)
+        result["hits"] = ssc.query_device(d_q.data_ptr(), nq, k, n_eligible=n_elig, stream=stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -189,7 +186,7 @@ def main():
         dt = float(t.item())
 
     # correctness of what was timed: planted loops must come back as top-1 (index, shift)
-    res = d_final.cpu().numpy().view(scancontext.HIT_DTYPE).reshape(nq, k)
+    res = result["hits"].cpu().numpy().view(scancontext.HIT_DTYPE).reshape(nq, k)
     ok = (src < n_elig)
     planted_ok = bool(np.all(res["index"][ok, 0] == src[ok]) and np.all(res["shift"][ok, 0] == rot[ok]))
 
