@@ -158,16 +158,21 @@ __global__ __launch_bounds__(256) void sc_build_kernel(const char *__restrict__ 
 //                       ds_read_b128 for 16 consecutive columns), converted once per block
 //   [10560, +512)       query column norms n1[60]
 //   [11072, +512)       query sector key v1[60]
-//   per wave: B x { sector key of the entry twice (960 B) | similarity terms 60 x 7 doubles (3360 B)
-//                   | neff[7] + k* (32 B) | pad }
+//   per wave: B x { sector key images A and B (2 x ~968 B) | similarity terms 7 x 60 doubles (3360 B)
+//                   | neff[7] + k* (32 B) }
 constexpr int Q_COL_STRIDE = 176;
 constexpr int OFF_QIMG = 0;
 constexpr int OFF_QN1 = 60 * Q_COL_STRIDE;       // 10560
 constexpr int OFF_QV1 = OFF_QN1 + 512;           // 11072
 constexpr int OFF_WAVES = OFF_QV1 + 512;         // 11584
-constexpr int ENT_VKEY = 0, ENT_SIM = 960, ENT_MISC = 960 + 3360;
-// 4416 B = 1104 dwords = 16 (mod 64): the B per-entry blocks sit on disjoint LDS banks in stage 3
-constexpr int ENT_SIZE = 4416;
+// per entry: the sector key twice in a row (vk2[e] = v[e % 60], 120 doubles) for the rotated reads of
+// stage 1, in TWO images -- A at element offset 0, B shifted by one element -- so that every lane can
+// fetch two consecutive elements with ONE 16-byte-aligned ds_read_b128 (the compiler otherwise pairs
+// ds_read_b64s into half-rate ds_read2_b64); then the 7 x 60 similarity terms as sim[t][c].
+constexpr int ENT_VKEY_A = 0, ENT_VKEY_B = 960, ENT_SIM = 1936, ENT_MISC = 1936 + 3360;
+// 5328 B = 1332 dwords = 52 (mod 64): an odd multiple of 4 dwords, so the per-entry blocks land on
+// disjoint LDS slots in the ds_read_b128 lane groups of stage 3; 3 blocks of B=2 still fit 160 KiB
+constexpr int ENT_SIZE = 5328;
 
 template <int B>
 struct PairLds {
@@ -259,10 +264,13 @@ __global__ __launch_bounds__(256, pair_waves_per_simd<B>()) void sc_pair_kernel(
 #pragma unroll
       for (int i = 0; i < 5; i++) ecol[b][i] = src[i];
       en2[b] = a.db.norm[eslot[b] * NS + cl];
-      double *vk = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY);
+      double *vka = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY_A);
+      double *vkb = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY_B);
       if (lane < NS) {
-        vk[lane] = v;
-        vk[lane + NS] = v;
+        vka[lane] = v;
+        vka[lane + NS] = v;
+        vkb[lane + 1] = v;
+        vkb[lane + NS + 1] = v;
       }
     }
     wave_lds_fence();
@@ -272,21 +280,28 @@ __global__ __launch_bounds__(256, pair_waves_per_simd<B>()) void sc_pair_kernel(
 #pragma unroll
     for (int b = 0; b < B; b++) acc[b] = 0.0;
     {
-      const double *v2[B];
+      // lane k needs vk2[60 + c - k] for c = 0..59.  Even k: image A, odd k: image B -- either way the
+      // pair (c, c+1), c even, is one aligned 16-byte read
+      const double2 *v2[B];
+      const int eoff = (kk & 1) ? (ENT_VKEY_B + (NS + 1 - kk) * 8) : (ENT_VKEY_A + (NS - kk) * 8);
 #pragma unroll
-      for (int b = 0; b < B; b++)
-        v2[b] = reinterpret_cast<const double *>(wsm + b * ENT_SIZE + ENT_VKEY) + (NS - kk);
+      for (int b = 0; b < B; b++) v2[b] = reinterpret_cast<const double2 *>(wsm + b * ENT_SIZE + eoff);
+      const double2 *v1p = reinterpret_cast<const double2 *>(v1);
       // chunks of 12 columns: bounded live ranges, immediate offsets inside a chunk
 #pragma unroll 1
-      for (int c0 = 0; c0 < NS; c0 += 12) {
+      for (int c0 = 0; c0 < NS / 2; c0 += 6) {
 #pragma unroll
-        for (int cc = 0; cc < 12; cc++) {
-          const double x = v1[c0 + cc];
+        for (int cc = 0; cc < 6; cc++) {
+          const double2 x = v1p[c0 + cc];
 #pragma unroll
           for (int b = 0; b < B; b++) {
-            double d = x - v2[b][c0 + cc];
-            double dd = d * d;
-            acc[b] = acc[b] + dd;
+            const double2 y = v2[b][c0 + cc];
+            double d0 = x.x - y.x;
+            double dd0 = d0 * d0;
+            acc[b] = acc[b] + dd0;
+            double d1 = x.y - y.y;
+            double dd1 = d1 * d1;
+            acc[b] = acc[b] + dd1;
           }
         }
       }
@@ -335,7 +350,7 @@ __global__ __launch_bounds__(256, pair_waves_per_simd<B>()) void sc_pair_kernel(
         const double n1 = qn1[c];
         const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));  // SC.cpp:78
         const double s = dot / (n1 * n2);                                  // SC.cpp:81
-        if (lane < NS) simp[c * 7 + t] = valid ? s : 0.0;
+        if (lane < NS) simp[t * NS + c] = valid ? s : 0.0;
         const int ne = __popcll(__ballot(valid));
         if (lane == 0) misc[t] = ne;
       }
@@ -348,13 +363,17 @@ __global__ __launch_bounds__(256, pair_waves_per_simd<B>()) void sc_pair_kernel(
     double bd = INFINITY;
     int bk = 0x7fffffff;
     if (bb < B && tt < 7) {
-      const double *sp = reinterpret_cast<const double *>(wsm + bb * ENT_SIZE + ENT_SIM) + tt;
+      const double2 *sp = reinterpret_cast<const double2 *>(wsm + bb * ENT_SIZE + ENT_SIM + tt * (NS * 8));
       const int *misc = reinterpret_cast<const int *>(wsm + bb * ENT_SIZE + ENT_MISC);
       double s = 0.0;
 #pragma unroll 1
-      for (int c0 = 0; c0 < NS; c0 += 12) {
+      for (int c0 = 0; c0 < NS / 2; c0 += 6) {
 #pragma unroll
-        for (int cc = 0; cc < 12; cc++) s = s + sp[(c0 + cc) * 7];
+        for (int cc = 0; cc < 6; cc++) {
+          const double2 v = sp[c0 + cc];
+          s = s + v.x;
+          s = s + v.y;
+        }
       }
       const int ne = misc[tt];
       const double d = 1.0 - s / (double)ne;  // 0/0 -> NaN when no effective column
