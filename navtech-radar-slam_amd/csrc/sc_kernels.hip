@@ -169,10 +169,11 @@ constexpr int OFF_WAVES = OFF_QV1 + 512;         // 11584
 // stage 1, in TWO images -- A at element offset 0, B shifted by one element -- so that every lane can
 // fetch two consecutive elements with ONE 16-byte-aligned ds_read_b128 (the compiler otherwise pairs
 // ds_read_b64s into half-rate ds_read2_b64); then the 7 x 60 similarity terms as sim[t][c].
-constexpr int ENT_VKEY_A = 0, ENT_VKEY_B = 960, ENT_SIM = 1936, ENT_MISC = 1936 + 3360;
-// 5328 B = 1332 dwords = 52 (mod 64): an odd multiple of 4 dwords, so the per-entry blocks land on
-// disjoint LDS slots in the ds_read_b128 lane groups of stage 3; 3 blocks of B=2 still fit 160 KiB
-constexpr int ENT_SIZE = 5328;
+// The similarity terms ALIAS the key images, which are dead once stage 1 has produced k*.
+constexpr int ENT_VKEY_A = 0, ENT_VKEY_B = 960, ENT_SIM = 0, ENT_MISC = 3360;
+// 3408 B = 852 dwords = 20 (mod 64): an odd multiple of 4 dwords, so the per-entry blocks land on
+// disjoint LDS slots in the ds_read_b128 lane groups of stage 3
+constexpr int ENT_SIZE = 3408;
 
 template <int B>
 struct PairLds {
@@ -320,6 +321,7 @@ __global__ __launch_bounds__(256, pair_waves_per_simd<B>()) void sc_pair_kernel(
 
     // ---- stage 2: column cosine terms for the 7 shifts k*-3..k*+3 (SC.cpp:123-144, 69-90) ----
     // lane = entry column j; shifted by k it lands on query column c = (j + k) % 60
+    wave_lds_fence();  // the similarity terms overwrite the key images read by stage 1
 #pragma unroll
     for (int b = 0; b < B; b++) {
       const int ks = kstar[b];
