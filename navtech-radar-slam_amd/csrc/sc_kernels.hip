@@ -28,6 +28,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 
 #include "rsx_common.h"
@@ -204,8 +205,9 @@ constexpr int pair_waves_per_simd() {
   return blocks < 1 ? 1 : (blocks > 4 ? 4 : blocks);
 }
 
-template <int B>
-__global__ __launch_bounds__(256, pair_waves_per_simd<B>()) void sc_pair_kernel(PairArgs a) {
+// W = waves per SIMD the register allocator must leave room for (<= what the LDS footprint allows)
+template <int B, int W>
+__global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -571,30 +573,38 @@ __global__ __launch_bounds__(1024) void sc_knn_kernel(const float *__restrict__ 
   if (threadIdx.x == 0) out_found[0] = found;
 }
 
-template <int B>
+template <int B, int W>
 int launch_pairs_t(const PairArgs &a, int gx, hipStream_t s) {
+  static_assert(W <= pair_waves_per_simd<B>(), "LDS footprint does not allow this occupancy");
   static bool attr_set = false;
   const int lds = PairLds<B>::SIZE;
   if (!attr_set) {
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_pair_kernel<B>),
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_pair_kernel<B, W>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   dim3 grid(gx, a.q.nq);
-  hipLaunchKernelGGL(sc_pair_kernel<B>, grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((sc_pair_kernel<B, W>), grid, dim3(256), lds, s, a);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 
-// entries per wave iteration: compiled for 1, 2, 4; RSX_SC_PAIR_B overrides the tuned default
-int pair_B() {
-  static int b = [] {
-    const char *e = getenv("RSX_SC_PAIR_B");
-    int v = e ? atoi(e) : 2;
-    return (v == 1 || v == 2 || v == 4) ? v : 2;
+// kernel variant = entries per wave iteration (B) x register-occupancy target (W waves/SIMD);
+// RSX_SC_PAIR_VARIANT="B,W" overrides the tuned default (measured on MI355X)
+struct Variant { int b, w; };
+Variant pair_variant() {
+  static Variant v = [] {
+    Variant d{2, 4};
+    const char *e = getenv("RSX_SC_PAIR_VARIANT");
+    int b = 0, w = 0;
+    if (e && sscanf(e, "%d,%d", &b, &w) == 2) {
+      if ((b == 1 && w == 4) || (b == 2 && (w == 3 || w == 4)) || (b == 4 && w == 2)) d = Variant{b, w};
+    }
+    return d;
   }();
-  return b;
+  return v;
 }
+int pair_B() { return pair_variant().b; }
 
 int choose_gx(int64_t n_items, int32_t nq) {
   const int kB = pair_B();
@@ -675,11 +685,11 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   a.nslots = gx * 4;
   PairProfiler *pp = (g_prof && g_prof->on && g_prof->ev && g_prof->used < PairProfiler::kMax) ? g_prof : nullptr;
   if (pp) RSX_HIP(hipEventRecord(pp->ev[2 * pp->used], s));
-  switch (pair_B()) {
-    case 1: RSX_TRY(launch_pairs_t<1>(a, gx, s)); break;
-    case 2: RSX_TRY(launch_pairs_t<2>(a, gx, s)); break;
-    default: RSX_TRY(launch_pairs_t<4>(a, gx, s)); break;
-  }
+  const Variant var = pair_variant();
+  if (var.b == 1) RSX_TRY((launch_pairs_t<1, 4>(a, gx, s)));
+  else if (var.b == 2 && var.w == 3) RSX_TRY((launch_pairs_t<2, 3>(a, gx, s)));
+  else if (var.b == 2) RSX_TRY((launch_pairs_t<2, 4>(a, gx, s)));
+  else RSX_TRY((launch_pairs_t<4, 2>(a, gx, s)));
   if (pp) {
     RSX_HIP(hipEventRecord(pp->ev[2 * pp->used + 1], s));
     pp->used++;
