@@ -81,6 +81,11 @@ typedef struct {
   int32_t shard_rank;         /* default 0 */
   int32_t shard_world;        /* default 1 */
   int64_t capacity_hint;      /* initial DB capacity in entries (grows by doubling) */
+  /* exhaustive queries: 0 = auto (batched queries go through the MFMA lower-bound filter and only
+   * the entries that can still reach the top-k are scored by the exact fp64 kernel), 1 = always
+   * score every entry exactly, 2 = always filter.  Results are identical in every mode. */
+  int32_t filter_mode;
+  int32_t reserved;
 } rsx_sc_params;
 
 typedef enum {
@@ -146,6 +151,11 @@ int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, 
 /* parity helper: dist/shift of ONE query against local entries [first, first+count) (host out) */
 int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t count,
                           double *out_dist, int32_t *out_shift);
+/* parity helper for the MFMA filter: out_lb[q * n_local + slot] = the filter's lower bound of
+ * dist(query q, local slot) for every local entry (host out).  Contract checked by the tests:
+ * out_lb - rsx_sc_filter_eps() <= the exact distance, for every pair. */
+int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out_lb);
+double rsx_sc_filter_eps(void);
 /* merge nparts per-shard top-k lists (layout [part][nq][k]) into out[nq][k]; pure host logic */
 int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out);
 /* the same on the GPU (d_parts is what an RCCL all-gather of d_out produces) */
@@ -159,6 +169,9 @@ int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float
  * rsx_sc_profile_read synchronises, returns launches and summed milliseconds since the last read,
  * and resets the counters. */
 const char *rsx_sc_dominant_kernel_name(void);
+/* name of the kernel the profiler events of this handle bracketed in its last exhaustive query:
+ * "sc_filter_kernel" when the query went through the filter, else "sc_pair_kernel" */
+const char *rsx_sc_profiled_kernel_name(rsx_sc *h);
 int rsx_sc_profile_enable(rsx_sc *h, int on);
 int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms);
 

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "librsx.so")
 
 NUM_RING, NUM_SECTOR, DESC_SIZE, MAX_TOPK = 20, 60, 1200, 32
 MODE_CANDIDATE, MODE_EXHAUSTIVE = 0, 1
+FILTER_AUTO, FILTER_OFF, FILTER_FORCE = 0, 1, 2
 
 HIT_DTYPE = np.dtype([("dist", "<f8"), ("index", "<i4"), ("shift", "<i4")])
 
@@ -36,6 +37,8 @@ class ScParams(C.Structure):
         ("shard_rank", C.c_int32),
         ("shard_world", C.c_int32),
         ("capacity_hint", C.c_int64),
+        ("filter_mode", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -62,7 +65,8 @@ SYMBOLS = [
     "rsx_sc_add_descriptors_f32_device", "rsx_sc_get_descriptor", "rsx_sc_get_ringkey",
     "rsx_sc_get_sectorkey", "rsx_sc_detect_loop_closure", "rsx_sc_detect_between_session",
     "rsx_sc_tree_size", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_self_device",
-    "rsx_sc_pair_distances", "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
+    "rsx_sc_pair_distances", "rsx_sc_filter_bounds", "rsx_sc_filter_eps", "rsx_sc_profiled_kernel_name",
+    "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
     "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read",
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
     "rsx_orora_register_batch", "rsx_orora_register_batch_device",
@@ -88,6 +92,10 @@ def lib():
         L.rsx_last_error_string.restype = C.c_char_p
         L.rsx_version.restype = C.c_char_p
         L.rsx_sc_dominant_kernel_name.restype = C.c_char_p
+        L.rsx_sc_profiled_kernel_name.restype = C.c_char_p
+        L.rsx_sc_profiled_kernel_name.argtypes = [C.c_void_p]
+        L.rsx_sc_filter_eps.restype = C.c_double
+        L.rsx_sc_filter_bounds.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
         L.rsx_sc_default_params.argtypes = [C.POINTER(ScParams)]
         L.rsx_sc_create.argtypes = [C.POINTER(ScParams), C.POINTER(vp)]

@@ -2,6 +2,7 @@
 // reference's detector state machine (Scancontext.cpp:236-422) on top of the HIP kernels.
 // Host logic only; every descriptor/key/distance is computed on the GPU.  There is no CPU fallback.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -28,6 +29,7 @@ struct rsx_sc {
   // database shard (SoA in HBM)
   int64_t n_global = 0, n_local = 0, cap = 0;
   DevBuf desc, vkey, norm, rkey;
+  DevBuf hn, cmask;  // fp16 filter image (tile-major) + column masks (sc_filter.hip)
   // detector state (SC.h:104,117-120)
   int tree_counter = 0;
   int64_t tree_size = 0;
@@ -35,7 +37,9 @@ struct rsx_sc {
   int64_t batch_size = 0;
   // workspaces
   DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
+  DevBuf f_qimg, f_qmask, f_lb, f_cand, f_cnt, f_seed;  // filter path
   PairProfiler prof;
+  const char *prof_kernel = "sc_pair_kernel";  // which kernel the profiler events bracket
   void *pinned = nullptr;  // small pinned host staging (results)
   size_t pinned_bytes = 0;
 };
@@ -55,6 +59,8 @@ int ensure_capacity(rsx_sc *h, int64_t want_local) {
   RSX_TRY(h->vkey.reserve((size_t)nc * NS * sizeof(double), h->stream, true));
   RSX_TRY(h->norm.reserve((size_t)nc * NS * sizeof(double), h->stream, true));
   RSX_TRY(h->rkey.reserve((size_t)nc * NR * sizeof(float), h->stream, true));
+  RSX_TRY(h->hn.reserve((size_t)nc * FILTER_DB_BYTES_PER_ENTRY, h->stream, true));  // nc is a multiple of 32
+  RSX_TRY(h->cmask.reserve((size_t)nc * sizeof(uint64_t), h->stream, true));
   h->cap = nc;
   return RSX_OK;
 }
@@ -65,6 +71,8 @@ DbView db_view(const rsx_sc *h) {
   v.vkey = h->vkey.as<double>();
   v.norm = h->norm.as<double>();
   v.rkey = h->rkey.as<float>();
+  v.hnT = h->hn.p;
+  v.cmask = h->cmask.as<uint64_t>();
   v.n_local = h->n_local;
   v.idx_base = h->p.shard_rank;
   v.idx_stride = h->p.shard_world;
@@ -114,8 +122,85 @@ int prepare_queries(rsx_sc *h, const float *d_q, int32_t nq, hipStream_t s, Quer
   return RSX_OK;
 }
 
+// RSX_SC_FILTER=0/1 overrides rsx_sc_params.filter_mode (0 auto, 1 off, 2 force)
+int filter_mode_of(const rsx_sc *h) {
+  static const int env = [] {
+    const char *e = getenv("RSX_SC_FILTER");
+    if (!e || !*e) return -1;
+    return atoi(e) ? 2 : 1;
+  }();
+  return env >= 0 ? env : h->p.filter_mode;
+}
+
+bool use_filter(const rsx_sc *h, int32_t nq, int64_t n_items) {
+  const int m = filter_mode_of(h);
+  if (m == 1 || n_items <= 0) return false;
+  if (m == 2) return true;
+  // the filter amortises a 300-register DB tile load over the queries of a block and costs five
+  // extra launches: worth it for batched queries against a sizeable DB
+  return nq >= 8 && (int64_t)nq * n_items >= (1ll << 20);
+}
+
+struct ProfScope {
+  PairProfiler *pp;
+  hipStream_t s;
+  bool armed = false;
+  ProfScope(PairProfiler *p, hipStream_t st) : pp(p), s(st) {
+    if (pp && pp->on && pp->ev && pp->used < PairProfiler::kMax) armed = hipEventRecord(pp->ev[2 * pp->used], s) == hipSuccess;
+  }
+  void stop() {
+    if (armed && hipEventRecord(pp->ev[2 * pp->used + 1], s) == hipSuccess) pp->used++;
+    armed = false;
+  }
+};
+
+// exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> k seeds -> exact
+// -> tau -> candidates -> exact.  Everything stays on the stream; no host synchronisation.
+int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
+                      int32_t k, rsx_sc_hit *d_out, hipStream_t s) {
+  const DbView db = db_view(h);
+  const int64_t ld = (n_items + 31) / 32 * 32;
+  int64_t qb = (1ll << 28) / ld;  // <= 1 GiB of bounds per batch
+  if (qb < 64) qb = 64;
+  if (qb > qv.nq) qb = qv.nq;
+  RSX_TRY(h->f_qimg.reserve(filter_qimg_bytes((int32_t)qb), s, false));
+  RSX_TRY(h->f_qmask.reserve((size_t)qb * sizeof(uint64_t), s, false));
+  RSX_TRY(h->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
+  RSX_TRY(h->f_cand.reserve((size_t)qb * ld * sizeof(int32_t), s, false));
+  RSX_TRY(h->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
+  RSX_TRY(h->f_seed.reserve((size_t)qb * k * sizeof(rsx_sc_hit), s, false));
+  RSX_TRY(h->partial.reserve(pair_lists_partial_bytes((int32_t)qb, k), s, false));
+  h->prof_kernel = filter_kernel_name();
+  for (int64_t b0 = 0; b0 < qv.nq; b0 += qb) {
+    const int32_t bn = (int32_t)((qv.nq - b0 < qb) ? (qv.nq - b0) : qb);
+    QueryView q = qv;
+    q.desc = qv.desc + b0 * DS;
+    q.vkey = qv.vkey + b0 * NS;
+    q.norm = qv.norm + b0 * NS;
+    q.nq = bn;
+    const int64_t *elig = d_q_elig ? d_q_elig + b0 : nullptr;
+    RSX_TRY(launch_query_images(q.desc, q.norm, bn, h->f_qimg.p, h->f_qmask.as<uint64_t>(), s));
+    {
+      ProfScope ps(&h->prof, s);
+      RSX_TRY(launch_filter(db, h->f_qimg.p, h->f_qmask.as<uint64_t>(), bn, n_items, n_eligible, elig,
+                            h->f_lb.as<float>(), ld, s));
+      ps.stop();
+    }
+    RSX_TRY(launch_seeds(h->f_lb.as<float>(), ld, n_items, bn, k, h->f_cand.as<int32_t>(), ld, h->f_cnt.as<int32_t>(), s));
+    RSX_TRY(launch_pairs_lists(db, q, h->f_cand.as<int32_t>(), ld, h->f_cnt.as<int32_t>(), n_eligible, elig,
+                               h->partial.as<rsx_sc_hit>(), h->f_seed.as<rsx_sc_hit>(), k, s));
+    RSX_TRY(launch_compact(h->f_lb.as<float>(), ld, n_items, bn, h->f_seed.as<rsx_sc_hit>(), k,
+                           h->f_cand.as<int32_t>(), ld, h->f_cnt.as<int32_t>(), s));
+    RSX_TRY(launch_pairs_lists(db, q, h->f_cand.as<int32_t>(), ld, h->f_cnt.as<int32_t>(), n_eligible, elig,
+                               h->partial.as<rsx_sc_hit>(), d_out + b0 * k, k, s));
+  }
+  return RSX_OK;
+}
+
 int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
              int32_t k, rsx_sc_hit *d_out, hipStream_t s) {
+  if (use_filter(h, qv.nq, n_items)) return run_topk_filtered(h, qv, n_items, n_eligible, d_q_elig, k, d_out, s);
+  h->prof_kernel = pair_kernel_name();
   RSX_TRY(h->partial.reserve(pair_partial_bytes(n_items > 0 ? n_items : 1, qv.nq, k), s, false));
   struct Hook {
     explicit Hook(PairProfiler *p) { set_pair_profiler(p); }
@@ -197,6 +282,12 @@ int rsx_device_count(void) {
 
 const char *rsx_sc_dominant_kernel_name(void) { return pair_kernel_name(); }
 
+const char *rsx_sc_profiled_kernel_name(rsx_sc *h) {
+  if (!h) return "";
+  std::lock_guard<std::mutex> lk(h->mu);
+  return h->prof_kernel;
+}
+
 int rsx_sc_default_params(rsx_sc_params *p) {
   if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
   p->lidar_height = 2.0;
@@ -210,6 +301,7 @@ int rsx_sc_default_params(rsx_sc_params *p) {
   p->shard_rank = 0;
   p->shard_world = 1;
   p->capacity_hint = 1024;
+  p->filter_mode = 0;
   return RSX_OK;
 }
 
@@ -226,6 +318,7 @@ int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) {
   if ((int)std::lround(0.5 * d.search_ratio * NS) != 3)
     return fail(RSX_ERR_BAD_ARG, "kernels are specialised for SEARCH_RADIUS 3 (search_ratio 0.1, SC.h:96)");
   if (d.tree_making_period < 1 || d.num_exclude_recent < 0) return fail(RSX_ERR_BAD_ARG, "bad detector params");
+  if (d.filter_mode < 0 || d.filter_mode > 2) return fail(RSX_ERR_BAD_ARG, "filter_mode must be 0 (auto), 1 (off) or 2 (force)");
   int ndev = rsx_device_count();
   if (ndev <= 0) return fail(RSX_ERR_NO_DEVICE, "no HIP device visible (librsx has no CPU fallback)");
   if (d.device < 0 || d.device >= ndev) return fail(RSX_ERR_NO_DEVICE, "device %d out of range (%d visible)", d.device, ndev);
@@ -250,6 +343,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_qmask, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_seed}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
@@ -306,6 +400,7 @@ int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes,
     RSX_TRY(launch_build(h->pts_ws.p, (int64_t)n, (int64_t)stride_bytes, h->p.lidar_height, h->p.max_radius,
                          h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS,
                          h->norm.as<double>() + slot * NS, h->rkey.as<float>() + slot * NR, h->stream));
+    RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, 1, h->hn.p, h->cmask.as<uint64_t>(), h->stream));
     RSX_HIP(hipStreamSynchronize(h->stream));  // caller may reuse pts; entry visible to detect()
     h->n_local = slot + 1;
   }
@@ -329,6 +424,7 @@ static int add_f32_locked(rsx_sc *h, const float *src, int64_t n, bool src_is_de
                              src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     RSX_TRY(launch_keys(dst, count, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
                         h->rkey.as<float>() + slot * NR, s));
+    RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->hn.p, h->cmask.as<uint64_t>(), s));
     RSX_HIP(hipStreamSynchronize(s));
     h->n_local = slot + count;
   }
@@ -542,6 +638,31 @@ int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
 }
+
+int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out_lb) {
+  if (!h || !q_descs || !out_lb || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  hipStream_t s = h->stream;
+  const int64_t n = h->n_local;
+  if (n == 0) return RSX_OK;
+  const int64_t ld = (n + 31) / 32 * 32;
+  RSX_TRY(h->q_desc.reserve((size_t)nq * DS * sizeof(float), s, false));
+  RSX_HIP(hipMemcpyAsync(h->q_desc.p, q_descs, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, s));
+  QueryView qv;
+  RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), nq, s, &qv));
+  RSX_TRY(h->f_qimg.reserve(filter_qimg_bytes(nq), s, false));
+  RSX_TRY(h->f_qmask.reserve((size_t)nq * sizeof(uint64_t), s, false));
+  RSX_TRY(h->f_lb.reserve((size_t)nq * ld * sizeof(float), s, false));
+  RSX_TRY(launch_query_images(qv.desc, qv.norm, nq, h->f_qimg.p, h->f_qmask.as<uint64_t>(), s));
+  RSX_TRY(launch_filter(db_view(h), h->f_qimg.p, h->f_qmask.as<uint64_t>(), nq, n, -1, nullptr, h->f_lb.as<float>(), ld, s));
+  RSX_HIP(hipMemcpy2DAsync(out_lb, (size_t)n * sizeof(float), h->f_lb.p, (size_t)ld * sizeof(float), (size_t)n * sizeof(float),
+                           (size_t)nq, hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  return RSX_OK;
+}
+
+double rsx_sc_filter_eps(void) { return filter_eps(); }
 
 int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out) {
   if (!parts || !out || nparts < 1 || nq < 1 || k < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");

@@ -1,0 +1,488 @@
+// sc_filter.hip -- MFMA lower-bound filter of the exhaustive ScanContext search (gfx950 / CDNA4).
+//
+// Why it exists.  distanceBtnScanContext (SC.cpp:116-148) is the minimum of the column-cosine
+// distance d_k (SC.cpp:69-90) over a 7-shift window chosen by the sector-key alignment
+// (SC.cpp:93-113).  For ANY window
+//        dist(query, entry)  >=  L(query, entry) := min over ALL 60 shifts k of d_k ,
+// and the 60 values  S_k = sum_j cos(query column (j+k)%60, entry column j)  are one circular
+// cross-correlation of the two column-normalised 20x60 images -- a GEMM with K = 1200 whose A
+// operand is a circulant of the query:  S[k][n] = sum_i q2[i + 20k] * e_n[i].  That is the one place
+// in this path where the matrix cores pay: 144 kflop per (query, entry) pair in fp16 on the MFMA
+// pipe instead of ~44k fp64 lane-operations on the VALU.  The filter computes L~ (fp16 inputs, fp32
+// accumulation) for every pair, the exact fp64 kernel (sc_pair_kernel) then re-scores only the
+// entries whose bound can still reach the top-k:
+//        keep entry  <=>  not ( L~ - eps > tau ),   tau = k-th best EXACT distance among k seeds.
+// Because |L~ - L| <= eps (derivation below) and L <= dist, no entry of the exact top-k is ever
+// dropped, so the results stay bit-identical to the oracle (tests/test_gpu_sc.py).
+//
+// Error bound eps (all quantities are means over n_eff effective columns, so bounds on one column
+// pair carry over unchanged):
+//   * operands are x^ = x/||column|| (fp64), scaled by 2^15 and rounded to fp16: relative error
+//     u = 2^-11 per element (the scaling keeps every element that matters in the normal range:
+//     fp16 subnormals start at 2^-29 relative to a unit column);
+//     |cos~ - cos| <= (2u + u^2) * sum_r |q^_r e^_r| <= 2u + u^2 = 9.77e-4   (Cauchy-Schwarz)
+//   * products of two fp16 values are exact in fp32; accumulating <= 1200 of them in fp32:
+//     <= 1200 * 2^-23 relative to sum |terms| <= n_eff  (2^-23: no assumption on the MFMA's rounding
+//     mode) = 1.43e-4
+//   * epilogue (rcp, fma): < 1e-6;  fp64 roundings of the exact side: < 1e-12
+//   total < 1.13e-3; kFilterEps = 1.25e-3.
+// Non-finite descriptors (NaN/inf elements) are flagged in bit 63 of the column mask and always
+// passed on to the exact kernel (L~ = -inf).
+//
+// Mapping (sc_filter_kernel, one wave per 32 database entries, 4 waves = 128 entries per block):
+//   * B operand (entries): the wave's 32 entries x 1200 fp16 stay in 300 VGPRs for the whole kernel
+//     (75 K-steps x v_mfma_f32_32x32x16_f16 B fragments; the DB image is stored tile-major so every
+//     fragment load is one coalesced 1 KiB read).  One wave per SIMD, 512-register budget.
+//   * A operand (query shifts): row k of the circulant is the query image read at element offset
+//     20k, so a lane fetches its A fragment with ONE ds_read_b128 from a doubled query image in LDS
+//     (two copies, the second displaced by 4 elements, make the read 16-byte aligned for odd k; the
+//     copies sit 4992 B apart which makes the access bank-conflict free).  Shifts 32..63 (tile 1) at
+//     K-step s need exactly the fragment of shifts 0..31 (tile 0) at step s+40, so each query costs
+//     115 LDS reads for 150 MFMAs.
+//   * queries stream through LDS in phases of 4 (double buffered, global_load_lds DMA, one
+//     s_barrier per phase).
+//   * epilogue per (query, entry): n_eff(k) = popcount(rot60(query mask, k) & entry mask) from two
+//     64-bit column masks, d_k = 1 - S_k / n_eff(k), min over the lane's 32 shifts, one cross-half
+//     exchange, one float per entry written (128 B per wave per query).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+
+#include "rsx_common.h"
+#include "sc_kernels.h"
+
+namespace rsx {
+namespace sc {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+#define AS1 __attribute__((address_space(1)))
+#define AS3 __attribute__((address_space(3)))
+
+constexpr int F_STEPS = DS / 16;  // 75 K-steps of 16
+constexpr int F_TILE1 = 40;       // 32 shifts * 20 elements = 640 = 40 K-steps
+constexpr int F_T = F_STEPS + F_TILE1;  // 115 A fragments per query
+constexpr int QIMG_ODD = 4992;    // byte offset of the copy read by odd shifts (holds q2[4..])
+constexpr int QIMG_EVEN_CHUNKS = 308;  // 2464 elements
+constexpr int QIMG_GAP_CHUNKS = 4;
+constexpr int QIMG_CHUNKS = FILTER_QIMG_BYTES / 16;  // 624
+constexpr int F_QPP = 4;          // queries per LDS phase
+constexpr int F_DEPTH = 8;        // A fragments in flight
+constexpr int F_PHASE_BYTES = F_QPP * FILTER_QIMG_BYTES;  // 39936 = 39 KiB
+constexpr double kImgScale = 32768.0;                 // 2^15 on both operands
+constexpr float kAccScale = 1073741824.0f;            // 2^30 carried by the accumulators
+constexpr u64 kNonFinite = 1ull << 63;
+constexpr double kBig = 10000000.0;
+
+static_assert(FILTER_QIMG_BYTES == 9984, "layout");
+static_assert(F_PHASE_BYTES % 1024 == 0, "phase must be whole 1 KiB DMA pieces");
+
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// column j of one descriptor -> 20 scaled fp16 values in st[j*20 ..]; returns (nonzero, nonfinite)
+__device__ __forceinline__ void normalise_column(const float *__restrict__ d, double nrm, _Float16 *st,
+                                                 bool &nonzero, bool &bad) {
+  const float4 *p = reinterpret_cast<const float4 *>(d);
+  nonzero = !(nrm == 0.0);  // SC.cpp:78: a column takes part unless its norm == 0
+  bad = false;
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const float4 v = p[i];
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      double y = nonzero ? ((double)x[e] / nrm) * kImgScale : 0.0;
+      bad |= !(fabs(y) <= kImgScale);  // NaN or inf
+      st[4 * i + e] = (_Float16)(float)y;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// database image: fp16, tile-major [tile of 32 entries][75 K-steps][64 lanes][8 halves]
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sc_img_db_kernel(const float *__restrict__ desc,
+                                                        const double *__restrict__ norm, int64_t first,
+                                                        int64_t count, uint4 *__restrict__ hnT,
+                                                        u64 *__restrict__ cmask) {
+  __shared__ __attribute__((aligned(16))) _Float16 st[4][DS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t it = (int64_t)blockIdx.x * 4 + wave;
+  if (it >= count) return;
+  const int64_t slot = first + it;
+  bool nonzero = false, bad = false;
+  if (lane < NS) normalise_column(desc + slot * DS + lane * NR, norm[slot * NS + lane], &st[wave][lane * NR], nonzero, bad);
+  u64 m = __ballot(nonzero && lane < NS);
+  if (__ballot(bad && lane < NS)) m |= kNonFinite;
+  wave_lds_fence();
+  const int64_t tile = slot >> 5;
+  const int col = (int)(slot & 31);
+  for (int c = lane; c < 2 * F_STEPS; c += 64) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(&st[wave][c * 8]);
+    hnT[(tile * F_STEPS + (c >> 1)) * 64 + (c & 1) * 32 + col] = v;
+  }
+  if (lane == 0) cmask[slot] = m;
+}
+
+// ------------------------------------------------------------------------------------------
+// query image: the LDS layout of the filter kernel, 9984 B per query
+//   [0, 4928)     q2[0..2464)      (q2[e] = q^[e mod 1200]), read by even shifts
+//   [4928, 4992)  zero
+//   [4992, 9984)  q2[4..2500)      read by odd shifts
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sc_img_query_kernel(const float *__restrict__ desc,
+                                                           const double *__restrict__ norm, int32_t nq,
+                                                           char *__restrict__ qimg, u64 *__restrict__ qmask) {
+  __shared__ __attribute__((aligned(16))) _Float16 st[4][DS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= nq) return;
+  bool nonzero = false, bad = false;
+  if (lane < NS) normalise_column(desc + (int64_t)q * DS + lane * NR, norm[(int64_t)q * NS + lane], &st[wave][lane * NR], nonzero, bad);
+  u64 m = __ballot(nonzero && lane < NS);
+  if (__ballot(bad && lane < NS)) m |= kNonFinite;
+  wave_lds_fence();
+  uint4 *out = reinterpret_cast<uint4 *>(qimg + (int64_t)q * FILTER_QIMG_BYTES);
+  for (int c = lane; c < QIMG_CHUNKS; c += 64) {
+    half8 v;
+    if (c < QIMG_EVEN_CHUNKS) {
+      const int e0 = (8 * c) % DS;  // 1200 is a multiple of 8: no wrap inside a chunk
+      v = *reinterpret_cast<const half8 *>(&st[wave][e0]);
+    } else if (c < QIMG_EVEN_CHUNKS + QIMG_GAP_CHUNKS) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = (_Float16)0.0f;
+    } else {
+      const int e0 = 4 + 8 * (c - QIMG_EVEN_CHUNKS - QIMG_GAP_CHUNKS);
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = st[wave][(e0 + i) % DS];
+    }
+    out[c] = *reinterpret_cast<const uint4 *>(&v);
+  }
+  if (lane == 0) qmask[q] = m;
+}
+
+// ------------------------------------------------------------------------------------------
+// the filter
+// ------------------------------------------------------------------------------------------
+struct FilterArgs {
+  const uint4 *hnT;
+  const u64 *cmask;
+  const char *qimg;
+  const u64 *qmask;
+  int64_t n_items;
+  int32_t nq, q_per_block;
+  float *lb;
+  int64_t ld_lb;
+  int64_t idx_base, idx_stride, n_eligible;
+  const int64_t *q_elig;
+};
+
+__device__ __forceinline__ void stage_queries(const char *gsrc, char *ldst, int nbytes, int wave, int lane) {
+  const int npieces = (nbytes + 1023) >> 10;
+  for (int c = wave; c < npieces; c += 4)
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(gsrc + c * 1024 + lane * 16)),
+                                     (AS3 void *)(ldst + c * 1024), 16, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, hh = lane >> 5;
+  const int64_t ntiles = (a.n_items + 31) >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const bool tile_ok = tile < ntiles;  // wave-uniform
+  const int64_t n = tile * 32 + col;
+  const bool n_ok = tile_ok && n < a.n_items;
+  const int q0 = blockIdx.y * a.q_per_block;
+  const int q1 = (q0 + a.q_per_block < a.nq) ? (q0 + a.q_per_block) : a.nq;
+  const int nphase = (q1 - q0 + F_QPP - 1) / F_QPP;
+
+  // phase 0 of the query stream (DMA, overlaps the B loads below)
+  {
+    const int nqs = (q1 - q0 < F_QPP) ? (q1 - q0) : F_QPP;
+    stage_queries(a.qimg + (int64_t)q0 * FILTER_QIMG_BYTES, smem, nqs * FILTER_QIMG_BYTES, wave, lane);
+  }
+
+  // B operand: 32 entries x 1200 fp16, register-resident for the whole kernel
+  half8 B[F_STEPS];
+  {
+    const uint4 *src = a.hnT + ((tile_ok ? tile : 0) * F_STEPS) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < F_STEPS; s++) {
+      const uint4 v = src[s * 64];
+      B[s] = *reinterpret_cast<const half8 *>(&v);
+    }
+  }
+  const u64 m2 = n_ok ? a.cmask[n] : 0ull;
+  const int64_t gidx = a.idx_base + n * a.idx_stride;
+  // A fragment address of this lane inside a query image (row = shift col of tile 0)
+  const int aoff = ((col & 1) ? (QIMG_ODD + 40 * col - 8) : (40 * col)) + 16 * hh;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int p = 0; p < nphase; p++) {
+    const int qp = q0 + p * F_QPP;
+    if (p + 1 < nphase) {
+      const int qn = qp + F_QPP;
+      const int nqs = (q1 - qn < F_QPP) ? (q1 - qn) : F_QPP;
+      stage_queries(a.qimg + (int64_t)qn * FILTER_QIMG_BYTES, smem + ((p + 1) & 1) * F_PHASE_BYTES,
+                    nqs * FILTER_QIMG_BYTES, wave, lane);
+    }
+    const char *buf = smem + (p & 1) * F_PHASE_BYTES;
+    const int nq_here = (q1 - qp < F_QPP) ? (q1 - qp) : F_QPP;
+    if (tile_ok) {
+      for (int qq = 0; qq < nq_here; qq++) {
+        const int q = qp + qq;
+        floatx16 acc0, acc1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+          acc0[i] = 0.0f;
+          acc1[i] = 0.0f;
+        }
+        const char *ap = buf + qq * FILTER_QIMG_BYTES + aoff;
+        // software pipeline: F_DEPTH A fragments in flight ahead of the MFMAs that consume them; the
+        // sched_group_barriers pin the issue order (1 LDS read, then the 1-2 MFMAs of a step)
+        half8 ring[F_DEPTH];
+#pragma unroll
+        for (int t = 0; t < F_DEPTH; t++) ring[t] = *reinterpret_cast<const half8 *>(ap + 32 * t);
+        __builtin_amdgcn_sched_group_barrier(0x100, F_DEPTH, 0);
+#pragma unroll
+        for (int t = 0; t < F_T; t++) {
+          const half8 af = ring[t % F_DEPTH];
+          if (t + F_DEPTH < F_T) ring[t % F_DEPTH] = *reinterpret_cast<const half8 *>(ap + 32 * (t + F_DEPTH));
+          if (t < F_STEPS) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t], acc0, 0, 0, 0);
+          if (t >= F_TILE1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t - F_TILE1], acc1, 0, 0, 0);
+          if (t >= F_TILE1 && t < F_STEPS) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (t + F_DEPTH < F_T) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        // ---- epilogue: d_k = 1 - S_k / n_eff(k), min over this lane's 32 shifts ----
+        const u64 m1 = a.qmask[q];  // uniform
+        const u64 m1c = m1 & ~kNonFinite;
+        const u64 lo = m1c | (m1c << 60), hi = m1c >> 4;  // the 60-bit mask twice in a row
+        const u64 lo_h = hh ? ((lo >> 4) | (hi << 60)) : lo;  // pre-shifted by 4 * (lane >> 5)
+        const u64 hi_h = hh ? (hi >> 4) : hi;
+        const u64 m2c = m2 & ~kNonFinite;
+        float best = INFINITY;
+#pragma unroll
+        for (int tl = 0; tl < 2; tl++) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            // C/D layout of v_mfma_f32_32x32x16: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+            const int c = 32 * tl + (r & 3) + 8 * (r >> 2);
+            const u64 rot = (c == 0) ? lo_h : ((lo_h >> c) | (hi_h << (64 - c)));
+            const int ne = __popcll(rot & m2c);
+            const float S = tl ? acc1[r] : acc0[r];
+            // ne == 0  =>  S == 0 exactly and rcp = inf: d = NaN, which fminf drops (that shift has
+            // no effective column: SC.cpp:87-88 gives NaN, never the minimum)
+            float d = fmaf(-S, __builtin_amdgcn_rcpf((float)ne * kAccScale), 1.0f);
+            if (tl == 1 && r >= 12) d = hh ? INFINITY : d;  // rows 60..63 are padding
+            best = fminf(best, d);
+          }
+        }
+        best = fminf(best, __shfl_xor(best, 32));
+        if ((m1 | m2) & kNonFinite) best = -INFINITY;  // non-finite input: always re-score exactly
+        int64_t elig = a.n_eligible;
+        if (a.q_elig) {
+          const int64_t e = a.q_elig[q];
+          elig = e < elig ? e : elig;
+        }
+        if (gidx >= elig) best = INFINITY;  // never a candidate
+        if (n_ok && hh == 0) a.lb[(int64_t)q * a.ld_lb + n] = best;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// seeds: the k entries with the smallest bound (ties: lower slot), k rounds of block arg-min
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sc_seed_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items,
+                                                      int32_t k, int32_t *__restrict__ cand, int64_t cand_stride,
+                                                      int32_t *__restrict__ cand_cnt) {
+  __shared__ float rd[4];
+  __shared__ int ri[4];
+  __shared__ float pick_d;
+  __shared__ int pick_i;
+  const int q = blockIdx.x;
+  const float *row = lb + (int64_t)q * ld;
+  float pd = -INFINITY;
+  int pi = -1;
+  int found = 0;
+  for (int r = 0; r < k; r++) {
+    float bd = INFINITY;
+    int bi = 0x7fffffff;
+    for (int64_t i = threadIdx.x; i < n_items; i += 256) {
+      float d = row[i];
+      if (d == INFINITY) continue;  // not eligible
+      if (d != d) d = -INFINITY;
+      const bool after = (d > pd) || (d == pd && (int)i > pi);
+      if (after && ((d < bd) || (d == bd && (int)i < bi))) {
+        bd = d;
+        bi = (int)i;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float od = __shfl_xor(bd, off);
+      const int oi = __shfl_xor(bi, off);
+      if ((od < bd) || (od == bd && oi < bi)) {
+        bd = od;
+        bi = oi;
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+      rd[threadIdx.x >> 6] = bd;
+      ri[threadIdx.x >> 6] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float d = rd[0];
+      int ix = ri[0];
+      for (int w = 1; w < 4; w++)
+        if ((rd[w] < d) || (rd[w] == d && ri[w] < ix)) {
+          d = rd[w];
+          ix = ri[w];
+        }
+      pick_d = d;
+      pick_i = ix;
+    }
+    __syncthreads();
+    pd = pick_d;
+    pi = pick_i;
+    __syncthreads();
+    if (pi == 0x7fffffff) break;  // fewer than k eligible entries
+    if (threadIdx.x == 0) cand[(int64_t)q * cand_stride + r] = pi;
+    found++;
+  }
+  if (threadIdx.x == 0) cand_cnt[q] = found;
+}
+
+// ------------------------------------------------------------------------------------------
+// candidates: every eligible entry whose bound can still reach the top-k
+//   tau = exact distance of the k-th seed hit (+inf when the seeds gave fewer than k hits)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sc_compact_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items,
+                                                         const rsx_sc_hit *__restrict__ seed_hits, int32_t k,
+                                                         double eps, int32_t *__restrict__ cand, int64_t cand_stride,
+                                                         int32_t *__restrict__ cand_cnt) {
+  __shared__ int total;
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const float *row = lb + (int64_t)q * ld;
+  double tau = seed_hits[(int64_t)q * k + (k - 1)].dist;
+  if (!(tau < kBig)) tau = INFINITY;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  int32_t *out = cand + (int64_t)q * cand_stride;
+  for (int64_t base = 0; base < n_items; base += 256) {
+    const int64_t i = base + threadIdx.x;
+    bool pass = false;
+    if (i < n_items) {
+      const float d = row[i];
+      pass = (d != INFINITY) && !((double)d - eps > tau);  // NaN passes
+    }
+    const u64 bal = __ballot(pass);
+    int wbase = 0;
+    if (lane == 0 && bal) wbase = atomicAdd(&total, __popcll(bal));
+    wbase = __shfl(wbase, 0);
+    if (pass) out[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) cand_cnt[q] = total;
+}
+
+}  // namespace
+
+double filter_eps() { return 1.25e-3; }
+
+size_t filter_qimg_bytes(int32_t nq) { return (size_t)nq * FILTER_QIMG_BYTES + 1024; }
+
+int launch_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *hnT, uint64_t *cmask,
+                     hipStream_t s) {
+  if (count <= 0) return RSX_OK;
+  hipLaunchKernelGGL(sc_img_db_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, desc, norm, first, count,
+                     static_cast<uint4 *>(hnT), reinterpret_cast<u64 *>(cmask));
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, uint64_t *qmask, hipStream_t s) {
+  if (nq <= 0) return RSX_OK;
+  hipLaunchKernelGGL(sc_img_query_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, desc, norm, nq,
+                     static_cast<char *>(qimg), reinterpret_cast<u64 *>(qmask));
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+const char *filter_kernel_name() { return "sc_filter_kernel"; }
+
+int launch_filter(const DbView &db, const void *qimg, const uint64_t *qmask, int32_t nq, int64_t n_items,
+                  int64_t n_eligible, const int64_t *q_elig, float *lb, int64_t ld_lb, hipStream_t s) {
+  if (nq <= 0 || n_items <= 0) return RSX_OK;
+  static bool attr_set = false;
+  const int lds = 2 * F_PHASE_BYTES;
+  if (!attr_set) {
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_filter_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  FilterArgs a;
+  a.hnT = static_cast<const uint4 *>(db.hnT);
+  a.cmask = reinterpret_cast<const u64 *>(db.cmask);
+  a.qimg = static_cast<const char *>(qimg);
+  a.qmask = reinterpret_cast<const u64 *>(qmask);
+  a.n_items = n_items;
+  a.nq = nq;
+  a.lb = lb;
+  a.ld_lb = ld_lb;
+  a.idx_base = db.idx_base;
+  a.idx_stride = db.idx_stride;
+  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
+  a.q_elig = q_elig;
+  const int64_t ntiles = (n_items + 31) / 32;
+  const int64_t bx = (ntiles + 3) / 4;
+  // ~8 blocks per CU for dynamic balance, but at least 4 phases (16 queries) per block so that the
+  // 300-register B load is amortised
+  int64_t by = (8 * 256 + bx - 1) / bx;
+  int64_t qpb = (nq + by - 1) / by;
+  if (qpb < 16) qpb = 16;
+  qpb = (qpb + F_QPP - 1) / F_QPP * F_QPP;
+  by = (nq + qpb - 1) / qpb;
+  a.q_per_block = (int32_t)qpb;
+  hipLaunchKernelGGL(sc_filter_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), lds, s, a);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_seeds(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int32_t k, int32_t *cand,
+                 int64_t cand_stride, int32_t *cand_cnt, hipStream_t s) {
+  if (nq <= 0) return RSX_OK;
+  hipLaunchKernelGGL(sc_seed_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, k, cand, cand_stride, cand_cnt);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_compact(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const rsx_sc_hit *seed_hits, int32_t k,
+                   int32_t *cand, int64_t cand_stride, int32_t *cand_cnt, hipStream_t s) {
+  if (nq <= 0) return RSX_OK;
+  hipLaunchKernelGGL(sc_compact_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, seed_hits, k, filter_eps(), cand,
+                     cand_stride, cand_cnt);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+}  // namespace sc
+}  // namespace rsx

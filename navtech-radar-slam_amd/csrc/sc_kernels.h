@@ -19,6 +19,8 @@ struct DbView {
   const double *vkey;  // [n_local][60] sector keys (SC.cpp:214-227)
   const double *norm;  // [n_local][60] column norms (shift-invariant part of SC.cpp:78,81)
   const float *rkey;   // [n_local][20] ring keys as float (SC.cpp:198-211 + 62-66)
+  const void *hnT;     // filter image: column-normalised fp16, tile-major (sc_filter.hip); 2400 B per entry
+  const uint64_t *cmask;  // [n_local] bit j = column j has a non-zero norm; bit 63 = non-finite element
   int64_t n_local;
   int64_t idx_base;    // global index of local slot s = idx_base + s * idx_stride
   int64_t idx_stride;
@@ -64,7 +66,34 @@ int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t 
 int launch_knn(const float *rkeys, int64_t n_search, const float *qkey, int32_t k, float *d_dist_ws,
                int32_t *out_idx, float *out_dist, int32_t *out_found, hipStream_t s);
 
+// the same against PER-QUERY candidate lists: query q scores local slots cand[q*cand_stride + i],
+// i < cand_cnt[q] (device arrays; the counts are never read by the host)
+int launch_pairs_lists(const DbView &db, const QueryView &q, const int32_t *cand, int64_t cand_stride,
+                       const int32_t *cand_cnt, int64_t n_eligible, const int64_t *q_elig,
+                       rsx_sc_hit *d_partial, rsx_sc_hit *d_topk, int32_t k, hipStream_t s);
+size_t pair_lists_partial_bytes(int32_t nq, int32_t k);
+
+// ---- MFMA lower-bound filter (sc_filter.hip) ----
+constexpr int FILTER_QIMG_BYTES = 9984;  // LDS image of one query (two displaced fp16 copies)
+constexpr int FILTER_DB_BYTES_PER_ENTRY = 2 * DS;
+double filter_eps();
+size_t filter_qimg_bytes(int32_t nq);
+// fp16 filter images of local slots [first, first+count) (needs their norms)
+int launch_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *hnT,
+                     uint64_t *cmask, hipStream_t s);
+int launch_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, uint64_t *qmask,
+                        hipStream_t s);
+// lb[q*ld_lb + slot] = lower bound of dist(query q, local slot), slots [0, n_items); +inf when the
+// entry is not eligible for that query, -inf when it must be re-scored regardless
+int launch_filter(const DbView &db, const void *qimg, const uint64_t *qmask, int32_t nq, int64_t n_items,
+                  int64_t n_eligible, const int64_t *q_elig, float *lb, int64_t ld_lb, hipStream_t s);
+int launch_seeds(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int32_t k, int32_t *cand,
+                 int64_t cand_stride, int32_t *cand_cnt, hipStream_t s);
+int launch_compact(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const rsx_sc_hit *seed_hits,
+                   int32_t k, int32_t *cand, int64_t cand_stride, int32_t *cand_cnt, hipStream_t s);
+
 const char *pair_kernel_name();
+const char *filter_kernel_name();
 
 // optional hipEvent bracket around the dominant (pair) kernel
 struct PairProfiler {

@@ -186,6 +186,9 @@ struct PairArgs {
   DbView db;
   QueryView q;
   const int32_t *gather;
+  const int32_t *cand;      // per-query candidate lists (overrides gather / n_items when set)
+  const int32_t *cand_cnt;
+  int64_t cand_stride;
   int64_t first, n_items, n_eligible;
   const int64_t *q_elig;
   double *out_dist;
@@ -244,7 +247,13 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
   double ld = INFINITY;
   int li = 0x7fffffff, ls = 0;
 
-  const int64_t ngroups = (a.n_items + B - 1) / B;
+  const int32_t *gath = a.gather;
+  int64_t n_items = a.n_items;
+  if (a.cand) {
+    gath = a.cand + (int64_t)qi * a.cand_stride;
+    n_items = a.cand_cnt[qi];
+  }
+  const int64_t ngroups = (n_items + B - 1) / B;
   for (int64_t g = slot; g < ngroups; g += nwaves) {
     // ---- stage 0: issue the entry loads (column cl of each entry stays in registers as fp32
     //      until stage 2; the sector key goes to LDS twice for the rotated reads of stage 1) ----
@@ -255,9 +264,9 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
 #pragma unroll
     for (int b = 0; b < B; b++) {
       int64_t item = g * B + b;
-      evalid[b] = item < a.n_items;
-      int64_t it = evalid[b] ? item : (a.n_items - 1);
-      eslot[b] = a.gather ? (int64_t)a.gather[it] : (a.first + it);
+      evalid[b] = item < n_items;
+      int64_t it = evalid[b] ? item : (n_items - 1);
+      eslot[b] = gath ? (int64_t)gath[it] : (a.first + it);
     }
     wave_lds_fence();
 #pragma unroll
@@ -413,8 +422,8 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
       if (!evalid[b]) continue;
       const int64_t item = g * B + b;
       if (a.out_dist && lane == 0) {
-        a.out_dist[(int64_t)qi * a.n_items + item] = dist;
-        a.out_shift[(int64_t)qi * a.n_items + item] = shift;
+        a.out_dist[(int64_t)qi * n_items + item] = dist;
+        a.out_shift[(int64_t)qi * n_items + item] = shift;
       }
       if (a.partial) {
         const int64_t gidx = a.db.idx_base + eslot[b] * a.db.idx_stride;
@@ -673,6 +682,9 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   a.db = db;
   a.q = q;
   a.gather = gather;
+  a.cand = nullptr;
+  a.cand_cnt = nullptr;
+  a.cand_stride = 0;
   a.first = first;
   a.n_items = n_items;
   a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
@@ -700,6 +712,48 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
                        (int64_t)0, a.nslots * k, k, d_topk);
     RSX_HIP(hipGetLastError());
   }
+  return RSX_OK;
+}
+
+static int lists_gx(int32_t nq) {
+  int64_t want = (2048 + 4 * (int64_t)nq - 1) / (4 * (int64_t)nq);  // ~2048 waves in flight
+  return (int)(want < 1 ? 1 : (want > 8 ? 8 : want));
+}
+
+size_t pair_lists_partial_bytes(int32_t nq, int32_t k) {
+  return (size_t)lists_gx(nq) * 4 * (size_t)nq * (size_t)k * sizeof(rsx_sc_hit);
+}
+
+int launch_pairs_lists(const DbView &db, const QueryView &q, const int32_t *cand, int64_t cand_stride,
+                       const int32_t *cand_cnt, int64_t n_eligible, const int64_t *q_elig,
+                       rsx_sc_hit *d_partial, rsx_sc_hit *d_topk, int32_t k, hipStream_t s) {
+  if (q.nq <= 0) return RSX_OK;
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
+  PairArgs a;
+  a.db = db;
+  a.q = q;
+  a.gather = nullptr;
+  a.cand = cand;
+  a.cand_cnt = cand_cnt;
+  a.cand_stride = cand_stride;
+  a.first = 0;
+  a.n_items = 0;
+  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
+  a.q_elig = q_elig;
+  a.out_dist = nullptr;
+  a.out_shift = nullptr;
+  const int gx = lists_gx(q.nq);
+  a.partial = d_partial;
+  a.k = k;
+  a.nslots = gx * 4;
+  const Variant var = pair_variant();
+  if (var.b == 1) RSX_TRY((launch_pairs_t<1, 4>(a, gx, s)));
+  else if (var.b == 2 && var.w == 3) RSX_TRY((launch_pairs_t<2, 3>(a, gx, s)));
+  else if (var.b == 2) RSX_TRY((launch_pairs_t<2, 4>(a, gx, s)));
+  else RSX_TRY((launch_pairs_t<4, 2>(a, gx, s)));
+  hipLaunchKernelGGL(sc_merge_kernel, dim3(q.nq), dim3(64), 0, s, (const rsx_sc_hit *)d_partial, 1, (int64_t)0,
+                     a.nslots * k, k, d_topk);
+  RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 

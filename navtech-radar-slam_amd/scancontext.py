@@ -25,13 +25,15 @@ class SCManager:
     TREE_MAKING_PERIOD_ = 30
 
     def __init__(self, device=0, shard_rank=0, shard_world=1, capacity_hint=1024, sc_dist_thres=0.2,
-                 lidar_height=None, num_exclude_recent=None, num_candidates=None, tree_making_period=None):
+                 lidar_height=None, num_exclude_recent=None, num_candidates=None, tree_making_period=None,
+                 filter_mode=_rsx.FILTER_AUTO):
         L = lib()
         p = _rsx.ScParams()
         check(L.rsx_sc_default_params(C.byref(p)))
         p.device, p.shard_rank, p.shard_world = device, shard_rank, shard_world
         p.capacity_hint = capacity_hint
         p.dist_thres = sc_dist_thres
+        p.filter_mode = filter_mode
         if lidar_height is not None:
             p.lidar_height = lidar_height
         if num_exclude_recent is not None:
@@ -159,6 +161,20 @@ class SCManager:
         shift = np.empty(count, dtype=np.int32)
         check(self._L.rsx_sc_pair_distances(self._h, q.ctypes.data, first, count, dist.ctypes.data, shift.ctypes.data))
         return dist, shift
+
+    def filter_bounds(self, q_descs):
+        """MFMA filter lower bounds of dist(query, entry) for every local entry: (nq, n_local) fp32."""
+        q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
+        out = np.empty((q.shape[0], self.local_size), dtype=np.float32)
+        check(self._L.rsx_sc_filter_bounds(self._h, q.ctypes.data, q.shape[0], out.ctypes.data))
+        return out
+
+    @staticmethod
+    def filter_eps():
+        return lib().rsx_sc_filter_eps()
+
+    def profiled_kernel_name(self):
+        return self._L.rsx_sc_profiled_kernel_name(self._h).decode()
 
     def merge_device(self, parts_ptr, nparts, nq, k, out_ptr, stream=0):
         check(self._L.rsx_sc_merge_topk_device(self._h, parts_ptr, nparts, nq, k, out_ptr, stream))

@@ -1,0 +1,211 @@
+"""GPU parity tests of the MFMA lower-bound filter (csrc/sc_filter.hip) in front of the exact kernel.
+
+Two contracts:
+  1. bound:   filter_bounds(q, e) - eps <= exact distance(q, e) for EVERY pair, and the bound is the
+              all-60-shift minimum of the column-cosine distance up to eps (checks the MFMA fragment /
+              circulant layout, not just looseness);
+  2. results: an exhaustive query through the filter returns byte-identical top-k records to the
+              oracle (and to the unfiltered exact path), including ties, padding and eligibility.
+"""
+import numpy as np
+import pytest
+
+from navtech_radar_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+FORCE, OFF = 2, 1
+
+
+@pytest.fixture(scope="module")
+def sc():
+    from navtech_radar_slam_amd import _rsx, scancontext
+    assert _rsx.device_count() >= 1, "no HIP device: GPU tests must run on the MI355X box"
+    return scancontext
+
+
+def all_shift_bound(q, descs):
+    """fp64 reference of the filter's quantity: min over all 60 shifts of distDirectSC (SC.cpp:69-90)."""
+    D = descs.reshape(-1, 60, 20).astype(np.float64)
+    Q = q.reshape(60, 20).astype(np.float64)
+    dn = np.sqrt((D ** 2).sum(2))
+    qn = np.sqrt((Q ** 2).sum(1))
+    Dn = np.where(dn[..., None] > 0, D / np.where(dn == 0, 1, dn)[..., None], 0)
+    Qn = np.where(qn[:, None] > 0, Q / np.where(qn == 0, 1, qn)[:, None], 0)
+    lb = np.full(len(D), np.inf)
+    for k in range(60):
+        S = np.einsum("jr,njr->n", np.roll(Qn, -k, axis=0), Dn)
+        ne = (np.roll(qn > 0, -k)[None, :] & (dn > 0)).sum(1)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            d = np.where(ne > 0, 1.0 - S / ne, np.inf)
+        lb = np.minimum(lb, d)
+    return lb
+
+
+def make_db(seed, n, binary):
+    descs = synth.random_descriptors(seed, n, binary=binary)
+    rng = np.random.default_rng(seed + 1)
+    for i in range(0, n, 7):  # rotated (and partly corrupted) copies: near-zero distances and exact ties
+        j = int(rng.integers(0, n))
+        descs[i] = synth.rotate_descriptor(descs[j], int(rng.integers(0, 60)))
+        if i % 3 == 0:
+            descs[i][rng.integers(0, 1200, 50)] = 0
+    descs[5] = 0                       # all-zero descriptor: never a hit (SC.cpp:87)
+    descs[6][20 * 7:20 * 9] = 0        # blank sectors
+    if not binary:
+        descs[8][0:20] = 1e-4          # a column of tiny values next to O(1) columns
+        descs[9] *= -1.0               # negative heights (z < -2)
+    return descs
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_filter_bounds(sc, oracle, binary):
+    n, nq = 1000 + 13, 20                                # not a multiple of 32: ragged last tile
+    descs = make_db(100 + binary, n, binary)
+    rng = np.random.default_rng(9)
+    queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+    queries[:, rng.integers(0, 1200, 20)] = 0
+    queries[1] = descs[5]                                # all-zero query
+    queries[2] = descs[8] if not binary else descs[6]
+    g = sc.SCManager()
+    g.add_descriptors_f32(descs)
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    eps = g.filter_eps()
+    lb = g.filter_bounds(queries)
+    assert lb.shape == (nq, n)
+    for qi in range(nq):
+        dist, _ = o.pair_distances(queries[qi].astype(np.float64), nthreads=4)
+        want = all_shift_bound(queries[qi], descs)
+        fin = np.isfinite(want)
+        assert np.all(lb[qi][~fin] == np.inf), "no effective column at any shift -> +inf"
+        assert not fin.any() or np.abs(lb[qi][fin] - want[fin]).max() <= eps, f"q={qi}: bound is not the all-shift minimum"
+        hit = dist < 1e7
+        assert np.all(lb[qi][hit].astype(np.float64) - eps <= dist[hit]), f"q={qi}: not a lower bound"
+    # the observed error is far inside the budget (documents the margin)
+    qi = 3
+    want = all_shift_bound(queries[qi], descs)
+    fin = np.isfinite(want)
+    assert np.abs(lb[qi][fin] - want[fin]).max() < 0.6 * eps
+
+
+@pytest.mark.parametrize("binary", [True, False])
+@pytest.mark.parametrize("k", [1, 10, 32])
+def test_filtered_query_matches_oracle(sc, oracle, binary, k):
+    n, nq = 2500 + 5, 40
+    descs = make_db(7 + binary, n, binary)
+    rng = np.random.default_rng(11)
+    queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+    queries[::2, rng.integers(0, 1200, 60)] = 0
+    queries[1] = 0
+    g = sc.SCManager(filter_mode=FORCE)
+    g.add_descriptors_f32(descs)
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    got = g.query(queries, k=k, n_eligible=n - 30)
+    assert g.profiled_kernel_name() == "sc_filter_kernel"
+    for qi in range(nq):
+        want = o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=4)
+        assert np.array_equal(got[qi], want), f"query {qi}"
+    assert np.all(got[1]["dist"] == 1e7) and np.all(got[1]["index"] == 0)   # zero query: padding only
+
+
+def test_filtered_equals_unfiltered_10k(sc, oracle):
+    n, nq, k = 10000, 256, 10
+    descs = synth.random_descriptors(1234, n, binary=True)
+    rng = np.random.default_rng(4321)
+    src = rng.integers(0, n - 100, nq)
+    rot = rng.integers(0, 60, nq)
+    queries = np.stack([synth.rotate_descriptor(descs[s], int(r)) for s, r in zip(src, rot)])
+    np.put_along_axis(queries, rng.integers(0, 1200, (nq, 24)), 0.0, axis=1)
+    a = sc.SCManager(capacity_hint=n, filter_mode=FORCE)
+    b = sc.SCManager(capacity_hint=n, filter_mode=OFF)
+    a.add_descriptors_f32(descs)
+    b.add_descriptors_f32(descs)
+    ga = a.query(queries, k=k, n_eligible=n - 30)
+    gb = b.query(queries, k=k, n_eligible=n - 30)
+    assert a.profiled_kernel_name() == "sc_filter_kernel" and b.profiled_kernel_name() == "sc_pair_kernel"
+    assert np.array_equal(ga, gb)
+    assert np.array_equal(ga["index"][:, 0], src) and np.array_equal(ga["shift"][:, 0], rot)
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    for qi in (0, 100, 255):
+        assert np.array_equal(ga[qi], o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=8))
+    assert np.array_equal(a.query(queries, k=k, n_eligible=n - 30), ga)   # deterministic
+    # auto mode takes the filter for this batch size
+    c = sc.SCManager(capacity_hint=n)
+    c.add_descriptors_f32(descs)
+    assert np.array_equal(c.query(queries, k=k, n_eligible=n - 30), ga)
+    assert c.profiled_kernel_name() == "sc_filter_kernel"
+
+
+def test_filtered_edge_cases(sc, oracle):
+    descs = make_db(3, 70, binary=False)
+    bad = descs.copy()
+    bad[11][3] = np.nan                                   # non-finite entries are always re-scored exactly
+    bad[12][100] = np.inf
+    for n in (1, 5, 31, 32, 33, 70):
+        g = sc.SCManager(filter_mode=FORCE)
+        g.add_descriptors_f32(bad[:n])
+        o = oracle.Manager()
+        o.add_descriptors(bad[:n].astype(np.float64))
+        queries = np.stack([bad[0], synth.rotate_descriptor(bad[min(n - 1, 20)], 7), np.zeros(1200, np.float32), bad[min(n - 1, 11)]])
+        for k, ne in ((1, -1), (10, -1), (32, -1), (3, max(0, n - 2)), (4, 0)):
+            got = g.query(queries, k=k, n_eligible=ne)
+            for qi in range(len(queries)):
+                want = o.exhaustive(queries[qi].astype(np.float64), n_eligible=(n if ne < 0 else ne), k=k)
+                assert np.array_equal(got[qi], want), f"n={n} k={k} ne={ne} q={qi}"
+        g.close()
+
+
+def test_filtered_ties_binary_duplicates(sc, oracle):
+    # many exact duplicates: the top-k is decided by the index tie-break alone
+    base = synth.random_descriptors(5, 6, binary=True)
+    descs = np.stack([synth.rotate_descriptor(base[i % 6], (i * 7) % 60) for i in range(600)])
+    g = sc.SCManager(filter_mode=FORCE)
+    g.add_descriptors_f32(descs)
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    queries = np.stack([synth.rotate_descriptor(base[i], 3 * i) for i in range(6)])
+    got = g.query(queries, k=32)
+    for qi in range(6):
+        assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), k=32))
+        assert np.all(np.abs(got[qi]["dist"]) < 1e-14) and np.all(np.diff(got[qi]["index"]) > 0)
+
+
+def test_filtered_query_self_with_exclusion(sc, oracle):
+    import torch
+    n = 400
+    clouds, truth = synth.keyframe_clouds(1234, n, binary_z=True, loop_frac=0.1, n_points=500)
+    g = sc.SCManager(filter_mode=FORCE)
+    o = oracle.Manager()
+    for c in clouds:
+        g.makeAndSaveScancontextAndKeys(c)            # filter images built by the add_points path
+        o.add_points(c)
+    out = torch.zeros((n, 2, 2), dtype=torch.float64, device="cuda")
+    g.query_self_device(0, n, 2, out.data_ptr(), exclude_recent=30, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, 2)
+    for i in list(range(0, 40)) + [i for i, t in enumerate(truth) if t is not None]:
+        want = o.exhaustive(o.descriptor(i), n_eligible=max(0, i - 30), k=2)
+        assert np.array_equal(got[i], want), f"query {i}"
+
+
+def test_filtered_sharded_equals_unsharded(sc, oracle):
+    import torch
+    n, nq, k, world = 2003, 16, 10, 4
+    descs = synth.random_descriptors(21, n, binary=True)
+    queries = np.stack([synth.rotate_descriptor(descs[i * 17], i) for i in range(nq)])
+    full = sc.SCManager(filter_mode=OFF)
+    full.add_descriptors_f32(descs)
+    want = full.query(queries, k=k, n_eligible=n - 30)
+    shards = [sc.SCManager(shard_rank=r, shard_world=world, filter_mode=FORCE) for r in range(world)]
+    dq = torch.from_numpy(queries).cuda()
+    parts = torch.zeros((world, nq, k, 2), dtype=torch.float64, device="cuda")
+    for r, s in enumerate(shards):
+        s.add_descriptors_f32(descs)
+        s.query_device(dq.data_ptr(), nq, k, parts[r].data_ptr(), n_eligible=n - 30,
+                       stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    host_parts = parts.cpu().numpy().view(sc.HIT_DTYPE).reshape(world, nq, k)
+    assert np.array_equal(sc.merge_topk(host_parts), want)
