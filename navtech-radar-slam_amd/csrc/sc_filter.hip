@@ -307,98 +307,111 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// seeds: the k entries with the smallest bound (ties: lower slot), k rounds of block arg-min
+// thresholds: 2048-bin histogram of one query's bounds over [0, 1) (bounds outside land in the end
+// bins), prefix sum, first bin edge with at least target[r] bounds below it.  bin(x) <= b  <=>
+// x < (b+1)/2048 exactly (power-of-two scaling), so "bound < t_r" selects whole bins.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sc_seed_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items,
-                                                      int32_t k, int32_t *__restrict__ cand, int64_t cand_stride,
-                                                      int32_t *__restrict__ cand_cnt) {
-  __shared__ float rd[4];
-  __shared__ int ri[4];
-  __shared__ float pick_d;
-  __shared__ int pick_i;
+constexpr int H_BINS = 2048;
+
+__device__ __forceinline__ int lb_bin(float d) {
+  if (!(d > 0.0f)) return 0;  // negative, -inf, NaN
+  const float x = d * (float)H_BINS;
+  return x >= (float)(H_BINS - 1) ? H_BINS - 1 : (int)x;
+}
+
+struct RoundTargets {
+  int32_t t[FILTER_MAX_ROUNDS];
+};
+
+__global__ __launch_bounds__(256) void sc_threshold_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items,
+                                                           RoundTargets targets, int32_t n_thr,
+                                                           float *__restrict__ thr) {
+  __shared__ int hist[H_BINS];
+  __shared__ int wsum[4];
   const int q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float *row = lb + (int64_t)q * ld;
-  float pd = -INFINITY;
-  int pi = -1;
-  int found = 0;
-  for (int r = 0; r < k; r++) {
-    float bd = INFINITY;
-    int bi = 0x7fffffff;
-    for (int64_t i = threadIdx.x; i < n_items; i += 256) {
-      float d = row[i];
-      if (d == INFINITY) continue;  // not eligible
-      if (d != d) d = -INFINITY;
-      const bool after = (d > pd) || (d == pd && (int)i > pi);
-      if (after && ((d < bd) || (d == bd && (int)i < bi))) {
-        bd = d;
-        bi = (int)i;
-      }
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const float od = __shfl_xor(bd, off);
-      const int oi = __shfl_xor(bi, off);
-      if ((od < bd) || (od == bd && oi < bi)) {
-        bd = od;
-        bi = oi;
-      }
-    }
-    if ((threadIdx.x & 63) == 0) {
-      rd[threadIdx.x >> 6] = bd;
-      ri[threadIdx.x >> 6] = bi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      float d = rd[0];
-      int ix = ri[0];
-      for (int w = 1; w < 4; w++)
-        if ((rd[w] < d) || (rd[w] == d && ri[w] < ix)) {
-          d = rd[w];
-          ix = ri[w];
-        }
-      pick_d = d;
-      pick_i = ix;
-    }
-    __syncthreads();
-    pd = pick_d;
-    pi = pick_i;
-    __syncthreads();
-    if (pi == 0x7fffffff) break;  // fewer than k eligible entries
-    if (threadIdx.x == 0) cand[(int64_t)q * cand_stride + r] = pi;
-    found++;
+  for (int i = threadIdx.x; i < H_BINS; i += 256) hist[i] = 0;
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < n_items; i += 256) {
+    const float d = row[i];
+    if (d == INFINITY) continue;  // not eligible
+    atomicAdd(&hist[lb_bin(d)], 1);
   }
-  if (threadIdx.x == 0) cand_cnt[q] = found;
+  __syncthreads();
+  // inclusive prefix over the 2048 bins: thread t owns bins [8t, 8t+8)
+  int v[8];
+  int run = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    run += hist[threadIdx.x * 8 + i];
+    v[i] = run;
+  }
+  int incl = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - run;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; i++) hist[threadIdx.x * 8 + i] = base + v[i];  // inclusive cumulative counts
+  __syncthreads();
+  if (threadIdx.x < n_thr) {
+    const int target = targets.t[threadIdx.x];
+    // smallest b with cum[b] >= target (binary search); none -> +inf
+    int lo = 0, hi = H_BINS;  // answer in [lo, hi]; hi == H_BINS means none
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (hist[mid] >= target) hi = mid;
+      else lo = mid + 1;
+    }
+    thr[(int64_t)q * FILTER_MAX_ROUNDS + threadIdx.x] = (lo >= H_BINS - 1) ? INFINITY : (float)(lo + 1) / (float)H_BINS;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
-// candidates: every eligible entry whose bound can still reach the top-k
-//   tau = exact distance of the k-th seed hit (+inf when the seeds gave fewer than k hits)
+// candidates of one round
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sc_compact_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items,
-                                                         const rsx_sc_hit *__restrict__ seed_hits, int32_t k,
-                                                         double eps, int32_t *__restrict__ cand, int64_t cand_stride,
+                                                         const float *__restrict__ thr, int32_t round, int32_t n_rounds,
+                                                         const rsx_sc_hit *__restrict__ topk, int32_t k, double eps,
+                                                         int32_t *__restrict__ cand, int64_t cand_stride,
                                                          int32_t *__restrict__ cand_cnt) {
   __shared__ int total;
   const int q = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const float *row = lb + (int64_t)q * ld;
-  double tau = seed_hits[(int64_t)q * k + (k - 1)].dist;
-  if (!(tau < kBig)) tau = INFINITY;
+  double tau = INFINITY;
+  if (topk) {
+    tau = topk[(int64_t)q * k + (k - 1)].dist;  // k-th best exact distance so far
+    if (!(tau < kBig)) tau = INFINITY;          // fewer than k hits so far
+  }
+  const float lo = round > 0 ? thr[(int64_t)q * FILTER_MAX_ROUNDS + round - 1] : -INFINITY;
+  const float hi = round < n_rounds - 1 ? thr[(int64_t)q * FILTER_MAX_ROUNDS + round] : INFINITY;
   if (threadIdx.x == 0) total = 0;
   __syncthreads();
   int32_t *out = cand + (int64_t)q * cand_stride;
-  for (int64_t base = 0; base < n_items; base += 256) {
-    const int64_t i = base + threadIdx.x;
-    bool pass = false;
-    if (i < n_items) {
-      const float d = row[i];
-      pass = (d != INFINITY) && !((double)d - eps > tau);  // NaN passes
+  if (lo < INFINITY) {  // (uniform) an earlier round already took every eligible entry otherwise
+    for (int64_t base = 0; base < n_items; base += 256) {
+      const int64_t i = base + threadIdx.x;
+      bool pass = false;
+      if (i < n_items) {
+        const float d = row[i];
+        // round 0 also owns NaN (d >= hi is false for NaN); +inf (not eligible) fails d < hi / passes d >= hi
+        const bool in_round = round == 0 ? !(d >= hi) : (d >= lo && d < hi);
+        pass = in_round && !((double)d - eps > tau);
+      }
+      const u64 bal = __ballot(pass);
+      int wbase = 0;
+      if (lane == 0 && bal) wbase = atomicAdd(&total, __popcll(bal));
+      wbase = __shfl(wbase, 0);
+      if (pass) out[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
     }
-    const u64 bal = __ballot(pass);
-    int wbase = 0;
-    if (lane == 0 && bal) wbase = atomicAdd(&total, __popcll(bal));
-    wbase = __shfl(wbase, 0);
-    if (pass) out[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
   }
   __syncthreads();
   if (threadIdx.x == 0) cand_cnt[q] = total;
@@ -467,19 +480,23 @@ int launch_filter(const DbView &db, const void *qimg, const uint64_t *qmask, int
   return RSX_OK;
 }
 
-int launch_seeds(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int32_t k, int32_t *cand,
-                 int64_t cand_stride, int32_t *cand_cnt, hipStream_t s) {
-  if (nq <= 0) return RSX_OK;
-  hipLaunchKernelGGL(sc_seed_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, k, cand, cand_stride, cand_cnt);
+int launch_thresholds(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const int32_t *round_targets,
+                      int32_t n_rounds, float *thr, hipStream_t s) {
+  if (nq <= 0 || n_rounds <= 1) return RSX_OK;
+  if (n_rounds > FILTER_MAX_ROUNDS) return fail(RSX_ERR_INTERNAL, "too many filter rounds");
+  RoundTargets t;
+  for (int i = 0; i < FILTER_MAX_ROUNDS; i++) t.t[i] = i < n_rounds - 1 ? round_targets[i] : 0;
+  hipLaunchKernelGGL(sc_threshold_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, t, n_rounds - 1, thr);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 
-int launch_compact(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const rsx_sc_hit *seed_hits, int32_t k,
-                   int32_t *cand, int64_t cand_stride, int32_t *cand_cnt, hipStream_t s) {
+int launch_compact(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const float *thr, int32_t round,
+                   int32_t n_rounds, const rsx_sc_hit *topk_so_far, int32_t k, int32_t *cand, int64_t cand_stride,
+                   int32_t *cand_cnt, hipStream_t s) {
   if (nq <= 0) return RSX_OK;
-  hipLaunchKernelGGL(sc_compact_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, seed_hits, k, filter_eps(), cand,
-                     cand_stride, cand_cnt);
+  hipLaunchKernelGGL(sc_compact_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, thr, round, n_rounds,
+                     topk_so_far, k, filter_eps(), cand, cand_stride, cand_cnt);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

@@ -195,6 +195,7 @@ struct PairArgs {
   int32_t *out_shift;
   rsx_sc_hit *partial;
   int32_t k, nslots;
+  int32_t slot_base, slot_stride;  // partial record of (query, slot): [q*slot_stride + slot_base + slot][k]
 };
 
 __device__ __forceinline__ bool hit_before(double ad, int ai, double bd, int bi) {
@@ -450,7 +451,7 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
     h.dist = ld;
     h.index = li;
     h.shift = ls;
-    a.partial[((int64_t)qi * a.nslots + slot) * a.k + lane] = h;
+    a.partial[((int64_t)qi * a.slot_stride + a.slot_base + slot) * a.k + lane] = h;
   }
 }
 
@@ -459,9 +460,9 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
 // records are unique in (dist,index) except the padding {inf, INT_MAX} / {1e7,0,0}
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void sc_merge_kernel(const rsx_sc_hit *__restrict__ parts, int32_t nparts,
-                                                      int64_t part_stride, int32_t per_part, int32_t k,
-                                                      rsx_sc_hit *__restrict__ out) {
-  // parts: record (p, q, i) at parts[p*part_stride + q*per_part + i], i < per_part
+                                                      int64_t part_stride, int64_t q_stride, int32_t per_part,
+                                                      int32_t k, rsx_sc_hit *__restrict__ out) {
+  // parts: record (p, q, i) at parts[p*part_stride + q*q_stride + i], i < per_part
   const int q = blockIdx.x;
   const int lane = threadIdx.x;
   double pd = -INFINITY;
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(64) void sc_merge_kernel(const rsx_sc_hit *__restri
     int bi = 0x7fffffff, bs = 0;
     for (int64_t t = lane; t < total; t += 64) {
       const int p = (int)(t / per_part), i = (int)(t % per_part);
-      rsx_sc_hit h = parts[(int64_t)p * part_stride + (int64_t)q * per_part + i];
+      rsx_sc_hit h = parts[(int64_t)p * part_stride + (int64_t)q * q_stride + i];
       // padding ({inf,..} from the pair kernel, {1e7,0,0} from merged lists) and anything that
       // could not beat the 1e7 init (SC.cpp:388) is never a hit
       const bool pad = !(h.dist < kBig);
@@ -657,7 +658,7 @@ int launch_build(const void *d_pts, int64_t n_pts, int64_t stride_bytes, double 
 int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *d_out,
                  hipStream_t s) {
   if (nq <= 0) return RSX_OK;
-  hipLaunchKernelGGL(sc_merge_kernel, dim3(nq), dim3(64), 0, s, d_parts, nparts, (int64_t)nq * k, k, k, d_out);
+  hipLaunchKernelGGL(sc_merge_kernel, dim3(nq), dim3(64), 0, s, d_parts, nparts, (int64_t)nq * k, (int64_t)k, k, k, d_out);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
@@ -673,7 +674,7 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
     if (d_topk && k > 0) {
       // a merge over zero parts writes the padding
       hipLaunchKernelGGL(sc_merge_kernel, dim3(q.nq), dim3(64), 0, s, (const rsx_sc_hit *)nullptr, 0,
-                         (int64_t)0, k, k, d_topk);
+                         (int64_t)0, (int64_t)k, k, k, d_topk);
       RSX_HIP(hipGetLastError());
     }
     return RSX_OK;
@@ -695,6 +696,8 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   a.partial = (d_topk && k > 0) ? d_partial : nullptr;
   a.k = k;
   a.nslots = gx * 4;
+  a.slot_base = 0;
+  a.slot_stride = a.nslots;
   PairProfiler *pp = (g_prof && g_prof->on && g_prof->ev && g_prof->used < PairProfiler::kMax) ? g_prof : nullptr;
   if (pp) RSX_HIP(hipEventRecord(pp->ev[2 * pp->used], s));
   const Variant var = pair_variant();
@@ -709,7 +712,7 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   if (a.partial) {
     // partial layout [q][slot][k]: one "part" per slot with part_stride = k, query stride nslots*k
     hipLaunchKernelGGL(sc_merge_kernel, dim3(q.nq), dim3(64), 0, s, (const rsx_sc_hit *)d_partial, 1,
-                       (int64_t)0, a.nslots * k, k, d_topk);
+                       (int64_t)0, (int64_t)a.nslots * k, a.nslots * k, k, d_topk);
     RSX_HIP(hipGetLastError());
   }
   return RSX_OK;
@@ -720,13 +723,12 @@ static int lists_gx(int32_t nq) {
   return (int)(want < 1 ? 1 : (want > 8 ? 8 : want));
 }
 
-size_t pair_lists_partial_bytes(int32_t nq, int32_t k) {
-  return (size_t)lists_gx(nq) * 4 * (size_t)nq * (size_t)k * sizeof(rsx_sc_hit);
-}
+int pair_lists_slots(int32_t nq) { return lists_gx(nq) * 4; }
 
 int launch_pairs_lists(const DbView &db, const QueryView &q, const int32_t *cand, int64_t cand_stride,
                        const int32_t *cand_cnt, int64_t n_eligible, const int64_t *q_elig,
-                       rsx_sc_hit *d_partial, rsx_sc_hit *d_topk, int32_t k, hipStream_t s) {
+                       rsx_sc_hit *d_partial, int32_t round, int32_t n_rounds, rsx_sc_hit *d_topk, int32_t k,
+                       hipStream_t s) {
   if (q.nq <= 0) return RSX_OK;
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
   PairArgs a;
@@ -746,13 +748,16 @@ int launch_pairs_lists(const DbView &db, const QueryView &q, const int32_t *cand
   a.partial = d_partial;
   a.k = k;
   a.nslots = gx * 4;
+  a.slot_base = round * a.nslots;
+  a.slot_stride = n_rounds * a.nslots;
   const Variant var = pair_variant();
   if (var.b == 1) RSX_TRY((launch_pairs_t<1, 4>(a, gx, s)));
   else if (var.b == 2 && var.w == 3) RSX_TRY((launch_pairs_t<2, 3>(a, gx, s)));
   else if (var.b == 2) RSX_TRY((launch_pairs_t<2, 4>(a, gx, s)));
   else RSX_TRY((launch_pairs_t<4, 2>(a, gx, s)));
+  // top-k over the partial lists of rounds 0..round
   hipLaunchKernelGGL(sc_merge_kernel, dim3(q.nq), dim3(64), 0, s, (const rsx_sc_hit *)d_partial, 1, (int64_t)0,
-                     a.nslots * k, k, d_topk);
+                     (int64_t)a.slot_stride * k, (round + 1) * a.nslots * k, k, d_topk);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
