@@ -36,7 +36,7 @@
 //   * A operand (query shifts): row k of the circulant is the query image read at element offset
 //     20k, so a lane fetches its A fragment with ONE ds_read_b128 from a doubled query image in LDS
 //     (two copies, the second displaced by 4 elements, make the read 16-byte aligned for odd k; the
-//     copies sit 4992 B apart which makes the access bank-conflict free).  Shifts 32..63 (tile 1) at
+//     copies sit 4960 B (= 96 mod 256) apart, the one displacement that makes the access bank-conflict free).  Shifts 32..63 (tile 1) at
 //     K-step s need exactly the fragment of shifts 0..31 (tile 0) at step s+40, so each query costs
 //     115 LDS reads for 150 MFMAs.
 //   * queries stream through LDS in phases of 4 (double buffered, global_load_lds DMA, one
@@ -49,6 +49,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
@@ -68,12 +70,13 @@ typedef unsigned long long u64;
 constexpr int F_STEPS = DS / 16;  // 75 K-steps of 16
 constexpr int F_TILE1 = 40;       // 32 shifts * 20 elements = 640 = 40 K-steps
 constexpr int F_T = F_STEPS + F_TILE1;  // 115 A fragments per query
-constexpr int QIMG_ODD = 4992;    // byte offset of the copy read by odd shifts (holds q2[4..])
+constexpr int QIMG_ODD = 4960;    // byte offset of the copy read by odd shifts (holds q2[4..]); = 96 mod 256
 constexpr int QIMG_EVEN_CHUNKS = 308;  // 2464 elements
-constexpr int QIMG_GAP_CHUNKS = 4;
+constexpr int QIMG_GAP_CHUNKS = 2;
 constexpr int QIMG_CHUNKS = FILTER_QIMG_BYTES / 16;  // 624
 constexpr int F_QPP = 4;          // queries per LDS phase
 constexpr int F_DEPTH = 8;        // A fragments in flight
+constexpr int F_B_VGPR = 44;      // B fragments kept in VGPRs; the rest live in AGPRs
 constexpr int F_PHASE_BYTES = F_QPP * FILTER_QIMG_BYTES;  // 39936 = 39 KiB
 constexpr double kImgScale = 32768.0;                 // 2^15 on both operands
 constexpr float kAccScale = 1073741824.0f;            // 2^30 carried by the accumulators
@@ -136,8 +139,8 @@ __global__ __launch_bounds__(256) void sc_img_db_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------
 // query image: the LDS layout of the filter kernel, 9984 B per query
 //   [0, 4928)     q2[0..2464)      (q2[e] = q^[e mod 1200]), read by even shifts
-//   [4928, 4992)  zero
-//   [4992, 9984)  q2[4..2500)      read by odd shifts
+//   [4928, 4960)  zero
+//   [4960, 9984)  q2[4..2516)      read by odd shifts
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sc_img_query_kernel(const float *__restrict__ desc,
                                                            const double *__restrict__ norm, int32_t nq,
@@ -193,6 +196,104 @@ __device__ __forceinline__ void stage_queries(const char *gsrc, char *ldst, int 
                                      (AS3 void *)(ldst + c * 1024), 16, 0, 0);
 }
 
+// per-lane state of the epilogue of one (query, 32-entry tile): the query's 60-bit column mask,
+// doubled and pre-shifted by 4 * (lane >> 5), as four 32-bit words; two running maxima
+struct Epi {
+  unsigned w[4];
+  float m0, m1;
+};
+
+__device__ __forceinline__ void epi_begin(Epi &e, u64 qm, int hh) {
+  const u64 m1c = qm & ~kNonFinite;
+  const u64 lo = m1c | (m1c << 60), hi = m1c >> 4;  // the 60-bit mask twice in a row (120 bits)
+  const u64 lo4 = (lo >> 4) | (hi << 60), hi4 = hi >> 4;
+  const u64 l = hh ? lo4 : lo, h = hh ? hi4 : hi;
+  e.w[0] = (unsigned)l;
+  e.w[1] = (unsigned)(l >> 32);
+  e.w[2] = (unsigned)h;
+  e.w[3] = (unsigned)(h >> 32);
+  e.m0 = -INFINITY;
+  e.m1 = -INFINITY;
+}
+
+// one output of the 32x32 C/D tile: register r of tile tl is shift k = 32*tl + (r&3) + 8*(r>>2) + 4*(lane>>5).
+// value = S_k / n_eff(k); n_eff == 0 => S == 0 exactly and rcp = inf: NaN, which fmaxf drops (that
+// shift has no effective column: SC.cpp:87-88 gives NaN, never the minimum)
+template <int TL, int R>
+__device__ __forceinline__ void epi_piece(Epi &e, float S, unsigned m2lo, unsigned m2hi, int hh) {
+  constexpr int b = (R & 3) + 8 * (R >> 2);
+  const unsigned rlo = __builtin_amdgcn_alignbit(e.w[TL + 1], e.w[TL], b);
+  const unsigned rhi = __builtin_amdgcn_alignbit(e.w[TL + 2], e.w[TL + 1], b);
+  const int ne = __builtin_popcount(rlo & m2lo) + __builtin_popcount(rhi & m2hi);
+  float v = S * __builtin_amdgcn_rcpf((float)ne);
+  if (TL == 1 && R >= 12) v = hh ? -INFINITY : v;  // rows 60..63 are padding
+  if (R & 1) e.m1 = fmaxf(e.m1, v);
+  else e.m0 = fmaxf(e.m0, v);
+}
+
+template <int I>
+__device__ __forceinline__ void epi_piece_i(Epi &e, const floatx16 &p0, const floatx16 &p1, unsigned m2lo,
+                                            unsigned m2hi, int hh) {
+  if constexpr (I < 16) epi_piece<0, I & 15>(e, p0[I & 15], m2lo, m2hi, hh);
+  else epi_piece<1, I & 15>(e, p1[I & 15], m2lo, m2hi, hh);
+}
+
+// lower bound of this lane's entry for the finished query: 1 - max_k S_k / n_eff(k) / 2^30
+__device__ __forceinline__ float epi_end(const Epi &e) {
+  float m = fmaxf(e.m0, e.m1);
+  m = fmaxf(m, __shfl_xor(m, 32));
+  return fmaf(m, -1.0f / kAccScale, 1.0f);  // m == -inf (no effective column at any shift) -> +inf
+}
+
+// One software-pipeline stage: the 150 MFMAs of the current query (DO_MFMA) interleaved with the
+// epilogue of the previous one (DO_EPI) whose accumulators were parked in p0/p1.  The
+// sched_group_barriers pin the issue order: per K-step one LDS read, the 1-2 MFMAs that consume
+// the fragment read F_DEPTH steps earlier, and a few VALU instructions of the epilogue.
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <bool DO_MFMA, bool DO_EPI>
+__device__ __forceinline__ void filter_stage(const char *ap, const half8 (&B)[F_STEPS], floatx16 &acc0,
+                                             floatx16 &acc1, const floatx16 &p0, const floatx16 &p1, Epi &e,
+                                             unsigned m2lo, unsigned m2hi, int hh) {
+  half8 ring[F_DEPTH];
+  if constexpr (DO_MFMA) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+      acc0[i] = 0.0f;
+      acc1[i] = 0.0f;
+    }
+#pragma unroll
+    for (int t = 0; t < F_DEPTH; t++) ring[t] = *reinterpret_cast<const half8 *>(ap + 32 * t);
+    __builtin_amdgcn_sched_group_barrier(0x100, F_DEPTH, 0);
+  }
+  static_for<F_T>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if constexpr (DO_MFMA) {
+      const half8 af = ring[t % F_DEPTH];
+      if constexpr (t + F_DEPTH < F_T) ring[t % F_DEPTH] = *reinterpret_cast<const half8 *>(ap + 32 * (t + F_DEPTH));
+      if constexpr (t < F_STEPS) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t], acc0, 0, 0, 0);
+      if constexpr (t >= F_TILE1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t - F_TILE1], acc1, 0, 0, 0);
+    }
+    // 32 epilogue pieces spread over steps 8, 11, 14, ... (one piece = ~10 VALU)
+    if constexpr (DO_EPI && t >= 8 && (t - 8) % 3 == 0 && (t - 8) / 3 < 32)
+      epi_piece_i<(t - 8) / 3>(e, p0, p1, m2lo, m2hi, hh);
+    if constexpr (DO_MFMA) {
+      if constexpr (t >= F_TILE1 && t < F_STEPS) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+      else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      if constexpr (DO_EPI) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+      if constexpr (t + F_DEPTH < F_T) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+  });
+}
+
 __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -221,15 +322,38 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
       const uint4 v = src[s * 64];
       B[s] = *reinterpret_cast<const half8 *>(&v);
     }
+    // 300 registers of B do not fit the 256 architectural VGPRs: give the tail fragments an AGPR
+    // register class up front, otherwise the allocator treats AGPRs as spill space and re-copies
+    // ~110 registers per query
+#pragma unroll
+    for (int s = F_B_VGPR; s < F_STEPS; s++) asm volatile("" : "+a"(B[s]));
   }
   const u64 m2 = n_ok ? a.cmask[n] : 0ull;
+  const unsigned m2lo = (unsigned)m2, m2hi = (unsigned)(m2 >> 32) & 0x0fffffffu;
   const int64_t gidx = a.idx_base + n * a.idx_stride;
   // A fragment address of this lane inside a query image (row = shift col of tile 0)
   const int aoff = ((col & 1) ? (QIMG_ODD + 40 * col - 8) : (40 * col)) + 16 * hh;
 
+  // finish one (query, tile): eligibility, non-finite flag, store (128 B per wave)
+  auto finish = [&](const Epi &e, int q) {
+    float best = epi_end(e);
+    const u64 m1 = a.qmask[q];
+    if ((m1 | m2) & kNonFinite) best = -INFINITY;  // non-finite input: always re-score exactly
+    int64_t elig = a.n_eligible;
+    if (a.q_elig) {
+      const int64_t v = a.q_elig[q];
+      elig = v < elig ? v : elig;
+    }
+    if (gidx >= elig) best = INFINITY;  // never a candidate
+    if (n_ok && hh == 0) a.lb[(int64_t)q * a.ld_lb + n] = best;
+  };
+
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
+  floatx16 acc0, acc1, p0, p1;
+  Epi e;
+  int prev_q = -1;
   for (int p = 0; p < nphase; p++) {
     const int qp = q0 + p * F_QPP;
     if (p + 1 < nphase) {
@@ -242,67 +366,26 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
     const int nq_here = (q1 - qp < F_QPP) ? (q1 - qp) : F_QPP;
     if (tile_ok) {
       for (int qq = 0; qq < nq_here; qq++) {
-        const int q = qp + qq;
-        floatx16 acc0, acc1;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-          acc0[i] = 0.0f;
-          acc1[i] = 0.0f;
-        }
         const char *ap = buf + qq * FILTER_QIMG_BYTES + aoff;
-        // software pipeline: F_DEPTH A fragments in flight ahead of the MFMAs that consume them; the
-        // sched_group_barriers pin the issue order (1 LDS read, then the 1-2 MFMAs of a step)
-        half8 ring[F_DEPTH];
-#pragma unroll
-        for (int t = 0; t < F_DEPTH; t++) ring[t] = *reinterpret_cast<const half8 *>(ap + 32 * t);
-        __builtin_amdgcn_sched_group_barrier(0x100, F_DEPTH, 0);
-#pragma unroll
-        for (int t = 0; t < F_T; t++) {
-          const half8 af = ring[t % F_DEPTH];
-          if (t + F_DEPTH < F_T) ring[t % F_DEPTH] = *reinterpret_cast<const half8 *>(ap + 32 * (t + F_DEPTH));
-          if (t < F_STEPS) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t], acc0, 0, 0, 0);
-          if (t >= F_TILE1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t - F_TILE1], acc1, 0, 0, 0);
-          if (t >= F_TILE1 && t < F_STEPS) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-          else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          if (t + F_DEPTH < F_T) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        if (prev_q >= 0) {
+          epi_begin(e, a.qmask[prev_q], hh);
+          filter_stage<true, true>(ap, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
+          finish(e, prev_q);
+        } else {
+          filter_stage<true, false>(ap, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
         }
-        // ---- epilogue: d_k = 1 - S_k / n_eff(k), min over this lane's 32 shifts ----
-        const u64 m1 = a.qmask[q];  // uniform
-        const u64 m1c = m1 & ~kNonFinite;
-        const u64 lo = m1c | (m1c << 60), hi = m1c >> 4;  // the 60-bit mask twice in a row
-        const u64 lo_h = hh ? ((lo >> 4) | (hi << 60)) : lo;  // pre-shifted by 4 * (lane >> 5)
-        const u64 hi_h = hh ? (hi >> 4) : hi;
-        const u64 m2c = m2 & ~kNonFinite;
-        float best = INFINITY;
-#pragma unroll
-        for (int tl = 0; tl < 2; tl++) {
-#pragma unroll
-          for (int r = 0; r < 16; r++) {
-            // C/D layout of v_mfma_f32_32x32x16: row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-            const int c = 32 * tl + (r & 3) + 8 * (r >> 2);
-            const u64 rot = (c == 0) ? lo_h : ((lo_h >> c) | (hi_h << (64 - c)));
-            const int ne = __popcll(rot & m2c);
-            const float S = tl ? acc1[r] : acc0[r];
-            // ne == 0  =>  S == 0 exactly and rcp = inf: d = NaN, which fminf drops (that shift has
-            // no effective column: SC.cpp:87-88 gives NaN, never the minimum)
-            float d = fmaf(-S, __builtin_amdgcn_rcpf((float)ne * kAccScale), 1.0f);
-            if (tl == 1 && r >= 12) d = hh ? INFINITY : d;  // rows 60..63 are padding
-            best = fminf(best, d);
-          }
-        }
-        best = fminf(best, __shfl_xor(best, 32));
-        if ((m1 | m2) & kNonFinite) best = -INFINITY;  // non-finite input: always re-score exactly
-        int64_t elig = a.n_eligible;
-        if (a.q_elig) {
-          const int64_t e = a.q_elig[q];
-          elig = e < elig ? e : elig;
-        }
-        if (gidx >= elig) best = INFINITY;  // never a candidate
-        if (n_ok && hh == 0) a.lb[(int64_t)q * a.ld_lb + n] = best;
+        p0 = acc0;
+        p1 = acc1;
+        prev_q = qp + qq;
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if (prev_q >= 0) {
+    epi_begin(e, a.qmask[prev_q], hh);
+    filter_stage<false, true>(nullptr, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
+    finish(e, prev_q);
   }
 }
 
