@@ -37,7 +37,7 @@ struct rsx_sc {
   int64_t batch_size = 0;
   // workspaces
   DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
-  DevBuf f_qimg, f_qmask, f_lb, f_cand, f_cnt, f_seed, f_thr;  // filter path
+  DevBuf f_qimg, f_lb, f_cand, f_cnt, f_seed, f_thr;  // filter path
   PairProfiler prof;
   const char *prof_kernel = "sc_pair_kernel";  // which kernel the profiler events bracket
   void *pinned = nullptr;  // small pinned host staging (results)
@@ -164,18 +164,10 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
   if (qb < 64) qb = 64;
   if (qb > qv.nq) qb = qv.nq;
   RSX_TRY(h->f_qimg.reserve(filter_qimg_bytes((int32_t)qb), s, false));
-  RSX_TRY(h->f_qmask.reserve((size_t)qb * sizeof(uint64_t), s, false));
   RSX_TRY(h->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
-  RSX_TRY(h->f_cand.reserve((size_t)qb * ld * sizeof(int32_t), s, false));
+  RSX_TRY(h->f_cand.reserve((size_t)qb * RESCORE_SHORTLIST_CAP * sizeof(RescoreEntry), s, false));
   RSX_TRY(h->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
-  RSX_TRY(h->f_seed.reserve((size_t)qb * k * sizeof(rsx_sc_hit), s, false));
-  RSX_TRY(h->f_thr.reserve((size_t)qb * FILTER_MAX_ROUNDS * sizeof(float), s, false));
-  // rounds over the entries in ascending order of their bound: the ~128 smallest first (their k-th
-  // exact distance tau is usually already the final one), then up to ~1024, then whatever tau still
-  // admits.  Every round only scores entries with bound - eps <= current tau.
-  const int32_t targets[2] = {k > 32 ? 4 * k : 128, 1024};
-  const int32_t n_rounds = 3;
-  RSX_TRY(h->partial.reserve((size_t)n_rounds * pair_lists_slots((int32_t)qb) * (size_t)qb * k * sizeof(rsx_sc_hit), s, false));
+  RSX_TRY(h->f_thr.reserve((size_t)qb * RESCORE_NUM_THR * sizeof(float), s, false));
   h->prof_kernel = filter_kernel_name();
   for (int64_t b0 = 0; b0 < qv.nq; b0 += qb) {
     const int32_t bn = (int32_t)((qv.nq - b0 < qb) ? (qv.nq - b0) : qb);
@@ -186,20 +178,18 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     q.nq = bn;
     const int64_t *elig = d_q_elig ? d_q_elig + b0 : nullptr;
     float *lb = h->f_lb.as<float>();
-    int32_t *cand = h->f_cand.as<int32_t>(), *cnt = h->f_cnt.as<int32_t>();
-    RSX_TRY(launch_query_images(q.desc, q.norm, bn, h->f_qimg.p, h->f_qmask.as<uint64_t>(), s));
+    RSX_TRY(launch_query_images(q.desc, q.norm, bn, h->f_qimg.p, s));
     {
       ProfScope ps(&h->prof, s);
-      RSX_TRY(launch_filter(db, h->f_qimg.p, h->f_qmask.as<uint64_t>(), bn, n_items, n_eligible, elig, lb, ld, s));
+      RSX_TRY(launch_filter(db, h->f_qimg.p, bn, n_items, lb, ld, s));
       ps.stop();
     }
-    RSX_TRY(launch_thresholds(lb, ld, n_items, bn, targets, n_rounds, h->f_thr.as<float>(), s));
-    for (int32_t r = 0; r < n_rounds; r++) {
-      rsx_sc_hit *topk = (r == n_rounds - 1) ? d_out + b0 * k : h->f_seed.as<rsx_sc_hit>();
-      RSX_TRY(launch_compact(lb, ld, n_items, bn, h->f_thr.as<float>(), r, n_rounds,
-                             r == 0 ? nullptr : h->f_seed.as<rsx_sc_hit>(), k, cand, ld, cnt, s));
-      RSX_TRY(launch_pairs_lists(db, q, cand, ld, cnt, n_eligible, elig, h->partial.as<rsx_sc_hit>(), r, n_rounds, topk, k, s));
-    }
+    // short list (the <= 2048 smallest bounds) + round edges, then one workgroup per query scores it
+    // in rounds of ascending bound with tau tightening
+    RSX_TRY(launch_select(db, lb, ld, n_items, bn, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
+                          h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), s));
+    RSX_TRY(launch_rescore(db, q, lb, ld, n_items, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
+                           h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), filter_eps(), d_out + b0 * k, k, s));
   }
   return RSX_OK;
 }
@@ -350,7 +340,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_qmask, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_seed, &h->f_thr}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_seed, &h->f_thr}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
@@ -659,10 +649,9 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
   QueryView qv;
   RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), nq, s, &qv));
   RSX_TRY(h->f_qimg.reserve(filter_qimg_bytes(nq), s, false));
-  RSX_TRY(h->f_qmask.reserve((size_t)nq * sizeof(uint64_t), s, false));
   RSX_TRY(h->f_lb.reserve((size_t)nq * ld * sizeof(float), s, false));
-  RSX_TRY(launch_query_images(qv.desc, qv.norm, nq, h->f_qimg.p, h->f_qmask.as<uint64_t>(), s));
-  RSX_TRY(launch_filter(db_view(h), h->f_qimg.p, h->f_qmask.as<uint64_t>(), nq, n, -1, nullptr, h->f_lb.as<float>(), ld, s));
+  RSX_TRY(launch_query_images(qv.desc, qv.norm, nq, h->f_qimg.p, s));
+  RSX_TRY(launch_filter(db_view(h), h->f_qimg.p, nq, n, h->f_lb.as<float>(), ld, s));
   RSX_HIP(hipMemcpy2DAsync(out_lb, (size_t)n * sizeof(float), h->f_lb.p, (size_t)ld * sizeof(float), (size_t)n * sizeof(float),
                            (size_t)nq, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));

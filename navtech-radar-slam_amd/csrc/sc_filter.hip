@@ -139,12 +139,13 @@ __global__ __launch_bounds__(256) void sc_img_db_kernel(const float *__restrict_
 // ------------------------------------------------------------------------------------------
 // query image: the LDS layout of the filter kernel, 9984 B per query
 //   [0, 4928)     q2[0..2464)      (q2[e] = q^[e mod 1200]), read by even shifts
-//   [4928, 4960)  zero
+//   [4928, 4936)  the query's column mask (bit j = column j non-zero, bit 63 = non-finite element)
+//   [4936, 4960)  zero
 //   [4960, 9984)  q2[4..2516)      read by odd shifts
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sc_img_query_kernel(const float *__restrict__ desc,
                                                            const double *__restrict__ norm, int32_t nq,
-                                                           char *__restrict__ qimg, u64 *__restrict__ qmask) {
+                                                           char *__restrict__ qimg) {
   __shared__ __attribute__((aligned(16))) _Float16 st[4][DS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = blockIdx.x * 4 + wave;
@@ -161,8 +162,9 @@ __global__ __launch_bounds__(256) void sc_img_query_kernel(const float *__restri
       const int e0 = (8 * c) % DS;  // 1200 is a multiple of 8: no wrap inside a chunk
       v = *reinterpret_cast<const half8 *>(&st[wave][e0]);
     } else if (c < QIMG_EVEN_CHUNKS + QIMG_GAP_CHUNKS) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) v[i] = (_Float16)0.0f;
+      // the gap carries the query's column mask (read by the filter kernel with one ds_read_b64)
+      const uint4 g = {c == QIMG_EVEN_CHUNKS ? (unsigned)m : 0u, c == QIMG_EVEN_CHUNKS ? (unsigned)(m >> 32) : 0u, 0u, 0u};
+      v = *reinterpret_cast<const half8 *>(&g);
     } else {
       const int e0 = 4 + 8 * (c - QIMG_EVEN_CHUNKS - QIMG_GAP_CHUNKS);
 #pragma unroll
@@ -170,7 +172,6 @@ __global__ __launch_bounds__(256) void sc_img_query_kernel(const float *__restri
     }
     out[c] = *reinterpret_cast<const uint4 *>(&v);
   }
-  if (lane == 0) qmask[q] = m;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -180,13 +181,11 @@ struct FilterArgs {
   const uint4 *hnT;
   const u64 *cmask;
   const char *qimg;
-  const u64 *qmask;
   int64_t n_items;
-  int32_t nq, q_per_block;
+  int32_t nq;
+  int64_t per_block;  // (tile-block, query) work items per workgroup
   float *lb;
   int64_t ld_lb;
-  int64_t idx_base, idx_stride, n_eligible;
-  const int64_t *q_elig;
 };
 
 __device__ __forceinline__ void stage_queries(const char *gsrc, char *ldst, int nbytes, int wave, int lane) {
@@ -294,98 +293,107 @@ __device__ __forceinline__ void filter_stage(const char *ap, const half8 (&B)[F_
   });
 }
 
+constexpr int QIMG_MASK_OFF = QIMG_EVEN_CHUNKS * 16;  // 4928
+
+// The (tile-block, query) work items -- tile-block = 4 tiles = 128 entries, linear index
+// tb * nq + q -- are cut into equal contiguous segments, one per workgroup (one workgroup per CU,
+// one wave per SIMD), so every CU gets the same number of MFMAs; a segment touches at most two
+// tile-blocks (one extra 300-register B load).
 __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, hh = lane >> 5;
   const int64_t ntiles = (a.n_items + 31) >> 5;
-  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
-  const bool tile_ok = tile < ntiles;  // wave-uniform
-  const int64_t n = tile * 32 + col;
-  const bool n_ok = tile_ok && n < a.n_items;
-  const int q0 = blockIdx.y * a.q_per_block;
-  const int q1 = (q0 + a.q_per_block < a.nq) ? (q0 + a.q_per_block) : a.nq;
-  const int nphase = (q1 - q0 + F_QPP - 1) / F_QPP;
-
-  // phase 0 of the query stream (DMA, overlaps the B loads below)
-  {
-    const int nqs = (q1 - q0 < F_QPP) ? (q1 - q0) : F_QPP;
-    stage_queries(a.qimg + (int64_t)q0 * FILTER_QIMG_BYTES, smem, nqs * FILTER_QIMG_BYTES, wave, lane);
-  }
-
-  // B operand: 32 entries x 1200 fp16, register-resident for the whole kernel
-  half8 B[F_STEPS];
-  {
-    const uint4 *src = a.hnT + ((tile_ok ? tile : 0) * F_STEPS) * 64 + lane;
-#pragma unroll
-    for (int s = 0; s < F_STEPS; s++) {
-      const uint4 v = src[s * 64];
-      B[s] = *reinterpret_cast<const half8 *>(&v);
-    }
-    // 300 registers of B do not fit the 256 architectural VGPRs: give the tail fragments an AGPR
-    // register class up front, otherwise the allocator treats AGPRs as spill space and re-copies
-    // ~110 registers per query
-#pragma unroll
-    for (int s = F_B_VGPR; s < F_STEPS; s++) asm volatile("" : "+a"(B[s]));
-  }
-  const u64 m2 = n_ok ? a.cmask[n] : 0ull;
-  const unsigned m2lo = (unsigned)m2, m2hi = (unsigned)(m2 >> 32) & 0x0fffffffu;
-  const int64_t gidx = a.idx_base + n * a.idx_stride;
+  const int64_t total = ((ntiles + 3) >> 2) * (int64_t)a.nq;
+  int64_t L0 = (int64_t)blockIdx.x * a.per_block;
+  const int64_t L1 = (L0 + a.per_block < total) ? (L0 + a.per_block) : total;
   // A fragment address of this lane inside a query image (row = shift col of tile 0)
   const int aoff = ((col & 1) ? (QIMG_ODD + 40 * col - 8) : (40 * col)) + 16 * hh;
 
-  // finish one (query, tile): eligibility, non-finite flag, store (128 B per wave)
-  auto finish = [&](const Epi &e, int q) {
-    float best = epi_end(e);
-    const u64 m1 = a.qmask[q];
-    if ((m1 | m2) & kNonFinite) best = -INFINITY;  // non-finite input: always re-score exactly
-    int64_t elig = a.n_eligible;
-    if (a.q_elig) {
-      const int64_t v = a.q_elig[q];
-      elig = v < elig ? v : elig;
-    }
-    if (gidx >= elig) best = INFINITY;  // never a candidate
-    if (n_ok && hh == 0) a.lb[(int64_t)q * a.ld_lb + n] = best;
-  };
+  while (L0 < L1) {
+    const int64_t tb = L0 / a.nq;
+    const int q0 = (int)(L0 - tb * a.nq);
+    const int q1 = (L1 - L0 < (int64_t)(a.nq - q0)) ? (int)(q0 + (L1 - L0)) : a.nq;
+    L0 += q1 - q0;
+    const int64_t tile = tb * 4 + wave;
+    const bool tile_ok = tile < ntiles;  // wave-uniform
+    const int64_t n = tile * 32 + col;
+    const bool n_ok = tile_ok && n < a.n_items;
+    const int nphase = (q1 - q0 + F_QPP - 1) / F_QPP;
 
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  floatx16 acc0, acc1, p0, p1;
-  Epi e;
-  int prev_q = -1;
-  for (int p = 0; p < nphase; p++) {
-    const int qp = q0 + p * F_QPP;
-    if (p + 1 < nphase) {
-      const int qn = qp + F_QPP;
-      const int nqs = (q1 - qn < F_QPP) ? (q1 - qn) : F_QPP;
-      stage_queries(a.qimg + (int64_t)qn * FILTER_QIMG_BYTES, smem + ((p + 1) & 1) * F_PHASE_BYTES,
-                    nqs * FILTER_QIMG_BYTES, wave, lane);
+    // phase 0 of the query stream (DMA, overlaps the B loads below)
+    {
+      const int nqs = (q1 - q0 < F_QPP) ? (q1 - q0) : F_QPP;
+      stage_queries(a.qimg + (int64_t)q0 * FILTER_QIMG_BYTES, smem, nqs * FILTER_QIMG_BYTES, wave, lane);
     }
-    const char *buf = smem + (p & 1) * F_PHASE_BYTES;
-    const int nq_here = (q1 - qp < F_QPP) ? (q1 - qp) : F_QPP;
-    if (tile_ok) {
-      for (int qq = 0; qq < nq_here; qq++) {
-        const char *ap = buf + qq * FILTER_QIMG_BYTES + aoff;
-        if (prev_q >= 0) {
-          epi_begin(e, a.qmask[prev_q], hh);
-          filter_stage<true, true>(ap, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
-          finish(e, prev_q);
-        } else {
-          filter_stage<true, false>(ap, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
-        }
-        p0 = acc0;
-        p1 = acc1;
-        prev_q = qp + qq;
+
+    // B operand: 32 entries x 1200 fp16, register-resident for the whole segment
+    half8 B[F_STEPS];
+    {
+      const uint4 *src = a.hnT + ((tile_ok ? tile : 0) * F_STEPS) * 64 + lane;
+#pragma unroll
+      for (int s = 0; s < F_STEPS; s++) {
+        const uint4 v = src[s * 64];
+        B[s] = *reinterpret_cast<const half8 *>(&v);
       }
+      // 300 registers of B do not fit the 256 architectural VGPRs: give the tail fragments an AGPR
+      // register class up front, otherwise the allocator treats AGPRs as spill space and re-copies
+      // ~110 registers per query
+#pragma unroll
+      for (int s = F_B_VGPR; s < F_STEPS; s++) asm volatile("" : "+a"(B[s]));
     }
+    const u64 m2 = n_ok ? a.cmask[n] : 0ull;
+    const unsigned m2lo = (unsigned)m2, m2hi = (unsigned)(m2 >> 32) & 0x0fffffffu;
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-  }
-  if (prev_q >= 0) {
-    epi_begin(e, a.qmask[prev_q], hh);
-    filter_stage<false, true>(nullptr, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
-    finish(e, prev_q);
+
+    floatx16 acc0, acc1, p0, p1;
+    Epi e;
+    int prev_q = -1;
+    u64 prev_mask = 0;
+    // finish one (query, tile): non-finite flag, store (128 B per wave); eligibility is applied by
+    // the selection kernels, not here
+    auto finish = [&](const Epi &ep, int q, u64 qm) {
+      float best = epi_end(ep);
+      if ((qm | m2) & kNonFinite) best = -INFINITY;  // non-finite input: always re-score exactly
+      if (n_ok && hh == 0) a.lb[(int64_t)q * a.ld_lb + n] = best;
+    };
+    for (int p = 0; p < nphase; p++) {
+      const int qp = q0 + p * F_QPP;
+      if (p + 1 < nphase) {
+        const int qn = qp + F_QPP;
+        const int nqs = (q1 - qn < F_QPP) ? (q1 - qn) : F_QPP;
+        stage_queries(a.qimg + (int64_t)qn * FILTER_QIMG_BYTES, smem + ((p + 1) & 1) * F_PHASE_BYTES,
+                      nqs * FILTER_QIMG_BYTES, wave, lane);
+      }
+      const char *buf = smem + (p & 1) * F_PHASE_BYTES;
+      const int nq_here = (q1 - qp < F_QPP) ? (q1 - qp) : F_QPP;
+      if (tile_ok) {
+        for (int qq = 0; qq < nq_here; qq++) {
+          const char *img = buf + qq * FILTER_QIMG_BYTES;
+          const u64 cur_mask = *reinterpret_cast<const u64 *>(img + QIMG_MASK_OFF);  // broadcast read
+          if (prev_q >= 0) {
+            epi_begin(e, prev_mask, hh);
+            filter_stage<true, true>(img + aoff, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
+            finish(e, prev_q, prev_mask);
+          } else {
+            filter_stage<true, false>(img + aoff, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
+          }
+          p0 = acc0;
+          p1 = acc1;
+          prev_q = qp + qq;
+          prev_mask = cur_mask;
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (prev_q >= 0) {
+      epi_begin(e, prev_mask, hh);
+      filter_stage<false, true>(nullptr, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
+      finish(e, prev_q, prev_mask);
+    }
   }
 }
 
@@ -406,19 +414,37 @@ struct RoundTargets {
   int32_t t[FILTER_MAX_ROUNDS];
 };
 
-__global__ __launch_bounds__(256) void sc_threshold_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items,
-                                                           RoundTargets targets, int32_t n_thr,
+// entries [0, n_elig_items(q)) of a row are eligible for query q: local slot i has global index
+// idx_base + i * idx_stride, eligible iff that is < min(n_eligible, q_elig[q])
+struct Elig {
+  int64_t idx_base, idx_stride, n_eligible;
+  const int64_t *q_elig;
+};
+__device__ __forceinline__ int64_t n_elig_items(const Elig &el, int q, int64_t n_items) {
+  int64_t lim = el.n_eligible;
+  if (el.q_elig) {
+    const int64_t v = el.q_elig[q];
+    lim = v < lim ? v : lim;
+  }
+  if (lim <= el.idx_base) return 0;
+  const int64_t c = (lim - el.idx_base + el.idx_stride - 1) / el.idx_stride;
+  return c < n_items ? c : n_items;
+}
+
+__global__ __launch_bounds__(256) void sc_threshold_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items_all,
+                                                           Elig el, RoundTargets targets, int32_t n_thr,
                                                            float *__restrict__ thr) {
   __shared__ int hist[H_BINS];
   __shared__ int wsum[4];
   const int q = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float *row = lb + (int64_t)q * ld;
+  const int64_t n_items = n_elig_items(el, q, n_items_all);
   for (int i = threadIdx.x; i < H_BINS; i += 256) hist[i] = 0;
   __syncthreads();
   for (int64_t i = threadIdx.x; i < n_items; i += 256) {
     const float d = row[i];
-    if (d == INFINITY) continue;  // not eligible
+    if (d == INFINITY) continue;  // no effective column at any shift: never a hit
     atomicAdd(&hist[lb_bin(d)], 1);
   }
   __syncthreads();
@@ -460,8 +486,8 @@ __global__ __launch_bounds__(256) void sc_threshold_kernel(const float *__restri
 // ------------------------------------------------------------------------------------------
 // candidates of one round
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sc_compact_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items,
-                                                         const float *__restrict__ thr, int32_t round, int32_t n_rounds,
+__global__ __launch_bounds__(256) void sc_compact_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items_all,
+                                                         Elig el, const float *__restrict__ thr, int32_t round, int32_t n_rounds,
                                                          const rsx_sc_hit *__restrict__ topk, int32_t k, double eps,
                                                          int32_t *__restrict__ cand, int64_t cand_stride,
                                                          int32_t *__restrict__ cand_cnt) {
@@ -469,6 +495,7 @@ __global__ __launch_bounds__(256) void sc_compact_kernel(const float *__restrict
   const int q = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const float *row = lb + (int64_t)q * ld;
+  const int64_t n_items = n_elig_items(el, q, n_items_all);
   double tau = INFINITY;
   if (topk) {
     tau = topk[(int64_t)q * k + (k - 1)].dist;  // k-th best exact distance so far
@@ -485,7 +512,7 @@ __global__ __launch_bounds__(256) void sc_compact_kernel(const float *__restrict
       bool pass = false;
       if (i < n_items) {
         const float d = row[i];
-        // round 0 also owns NaN (d >= hi is false for NaN); +inf (not eligible) fails d < hi / passes d >= hi
+        // round 0 also owns NaN (d >= hi is false for NaN); +inf (never a hit) fails d < hi / passes d >= hi
         const bool in_round = round == 0 ? !(d >= hi) : (d >= lo && d < hi);
         pass = in_round && !((double)d - eps > tau);
       }
@@ -498,6 +525,108 @@ __global__ __launch_bounds__(256) void sc_compact_kernel(const float *__restrict
   }
   __syncthreads();
   if (threadIdx.x == 0) cand_cnt[q] = total;
+}
+
+// ------------------------------------------------------------------------------------------
+// short list + round edges of one query (feeds sc_rescore_kernel): histogram of the eligible bounds,
+// prefix sum, then
+//   t_cap  = edge of the last bin b_cap whose cumulative count still fits RESCORE_SHORTLIST_CAP
+//   t_r    = edge of the first bin with at least target[r] bounds at or below it, clamped to t_cap
+//   slist  = (bound, slot) of every eligible entry in bins <= b_cap  (bound < t_cap)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bin_edge(int b) {  // upper edge of bin b as a "bound < edge" test
+  return b < 0 ? -INFINITY : (b >= H_BINS - 1 ? INFINITY : (float)(b + 1) / (float)H_BINS);
+}
+
+__global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items_all,
+                                                        Elig el, RescoreEntry *__restrict__ slist,
+                                                        int32_t *__restrict__ sl_cnt, float *__restrict__ thr) {
+  __shared__ int hist[H_BINS];
+  __shared__ int wsum[4];
+  __shared__ int s_bcap;
+  __shared__ int s_total;
+  const int q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *row = lb + (int64_t)q * ld;
+  const int64_t n_items = n_elig_items(el, q, n_items_all);
+  for (int i = threadIdx.x; i < H_BINS; i += 256) hist[i] = 0;
+  if (threadIdx.x == 0) s_total = 0;
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < n_items; i += 256) {
+    const float d = row[i];
+    if (d == INFINITY) continue;  // no effective column at any shift: never a hit
+    atomicAdd(&hist[lb_bin(d)], 1);
+  }
+  __syncthreads();
+  int v[8];
+  int run = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    run += hist[threadIdx.x * 8 + i];
+    v[i] = run;
+  }
+  int incl = run;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(incl, off);
+    if (lane >= off) incl += o;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int base = incl - run;
+  for (int w = 0; w < wave; w++) base += wsum[w];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 8; i++) hist[threadIdx.x * 8 + i] = base + v[i];  // inclusive cumulative counts
+  __syncthreads();
+  // first bin whose cumulative count reaches `target` (H_BINS when none)
+  auto first_reaching = [&](int target) {
+    int lo = 0, hi = H_BINS;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (hist[mid] >= target) hi = mid;
+      else lo = mid + 1;
+    }
+    return lo;
+  };
+  if (threadIdx.x == 0) s_bcap = first_reaching(RESCORE_SHORTLIST_CAP + 1) - 1;  // last bin with cum <= CAP
+  __syncthreads();
+  const int b_cap = s_bcap;
+  if (threadIdx.x < RESCORE_NUM_THR) {
+    const int targets[RESCORE_NUM_THR - 1] = {64, 128, 256, 512, 1024};
+    int b = b_cap;
+    if (threadIdx.x < RESCORE_NUM_THR - 1) {
+      b = first_reaching(targets[threadIdx.x]);
+      if (b > H_BINS - 1) b = H_BINS - 1;
+      if (b > b_cap) b = b_cap;
+    }
+    thr[(int64_t)q * RESCORE_NUM_THR + threadIdx.x] = bin_edge(b);
+  }
+  // compaction of bins <= b_cap
+  RescoreEntry *out = slist + (int64_t)q * RESCORE_SHORTLIST_CAP;
+  if (b_cap >= 0) {
+    for (int64_t base_i = 0; base_i < n_items; base_i += 256) {
+      const int64_t i = base_i + threadIdx.x;
+      bool pass = false;
+      float d = 0.0f;
+      if (i < n_items) {
+        d = row[i];
+        pass = (d != INFINITY) && lb_bin(d) <= b_cap;
+      }
+      const u64 bal = __ballot(pass);
+      int wbase = 0;
+      if (lane == 0 && bal) wbase = atomicAdd(&s_total, __popcll(bal));
+      wbase = __shfl(wbase, 0);
+      if (pass) {
+        RescoreEntry e;
+        e.lb = d;
+        e.slot = (int32_t)i;
+        out[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = e;
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) sl_cnt[q] = s_total;
 }
 
 }  // namespace
@@ -515,70 +644,79 @@ int launch_db_images(const float *desc, const double *norm, int64_t first, int64
   return RSX_OK;
 }
 
-int launch_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, uint64_t *qmask, hipStream_t s) {
+int launch_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, hipStream_t s) {
   if (nq <= 0) return RSX_OK;
   hipLaunchKernelGGL(sc_img_query_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, desc, norm, nq,
-                     static_cast<char *>(qimg), reinterpret_cast<u64 *>(qmask));
+                     static_cast<char *>(qimg));
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 
 const char *filter_kernel_name() { return "sc_filter_kernel"; }
 
-int launch_filter(const DbView &db, const void *qimg, const uint64_t *qmask, int32_t nq, int64_t n_items,
-                  int64_t n_eligible, const int64_t *q_elig, float *lb, int64_t ld_lb, hipStream_t s) {
+int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
+                  hipStream_t s) {
   if (nq <= 0 || n_items <= 0) return RSX_OK;
-  static bool attr_set = false;
+  static int n_cu = 0;
   const int lds = 2 * F_PHASE_BYTES;
-  if (!attr_set) {
+  if (!n_cu) {
     RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_filter_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_set = true;
+    int dev = 0, cu = 0;
+    RSX_HIP(hipGetDevice(&dev));
+    RSX_HIP(hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev));
+    n_cu = cu > 0 ? cu : 256;
   }
   FilterArgs a;
   a.hnT = static_cast<const uint4 *>(db.hnT);
   a.cmask = reinterpret_cast<const u64 *>(db.cmask);
   a.qimg = static_cast<const char *>(qimg);
-  a.qmask = reinterpret_cast<const u64 *>(qmask);
   a.n_items = n_items;
   a.nq = nq;
   a.lb = lb;
   a.ld_lb = ld_lb;
-  a.idx_base = db.idx_base;
-  a.idx_stride = db.idx_stride;
-  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
-  a.q_elig = q_elig;
   const int64_t ntiles = (n_items + 31) / 32;
-  const int64_t bx = (ntiles + 3) / 4;
-  // ~8 blocks per CU for dynamic balance, but at least 4 phases (16 queries) per block so that the
-  // 300-register B load is amortised
-  int64_t by = (8 * 256 + bx - 1) / bx;
-  int64_t qpb = (nq + by - 1) / by;
-  if (qpb < 16) qpb = 16;
-  qpb = (qpb + F_QPP - 1) / F_QPP * F_QPP;
-  by = (nq + qpb - 1) / qpb;
-  a.q_per_block = (int32_t)qpb;
-  hipLaunchKernelGGL(sc_filter_kernel, dim3((unsigned)bx, (unsigned)by), dim3(256), lds, s, a);
+  const int64_t total = ((ntiles + 3) / 4) * (int64_t)nq;
+  // one workgroup per CU with an equal share; small problems use fewer workgroups so that a
+  // 300-register B load is amortised over >= 16 queries
+  int64_t per = (total + n_cu - 1) / n_cu;
+  if (per < 16) per = 16;
+  const int64_t nblk = (total + per - 1) / per;
+  a.per_block = per;
+  hipLaunchKernelGGL(sc_filter_kernel, dim3((unsigned)nblk), dim3(256), lds, s, a);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 
-int launch_thresholds(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const int32_t *round_targets,
-                      int32_t n_rounds, float *thr, hipStream_t s) {
+int launch_select(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
+                  const int64_t *q_elig, RescoreEntry *slist, int32_t *sl_cnt, float *thr, hipStream_t s) {
+  if (nq <= 0) return RSX_OK;
+  const Elig el{db.idx_base, db.idx_stride, n_eligible < 0 ? INT64_MAX : n_eligible, q_elig};
+  hipLaunchKernelGGL(sc_select_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, el, slist, sl_cnt, thr);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_thresholds(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq,
+                      int64_t n_eligible, const int64_t *q_elig, const int32_t *round_targets, int32_t n_rounds,
+                      float *thr, hipStream_t s) {
   if (nq <= 0 || n_rounds <= 1) return RSX_OK;
   if (n_rounds > FILTER_MAX_ROUNDS) return fail(RSX_ERR_INTERNAL, "too many filter rounds");
   RoundTargets t;
   for (int i = 0; i < FILTER_MAX_ROUNDS; i++) t.t[i] = i < n_rounds - 1 ? round_targets[i] : 0;
-  hipLaunchKernelGGL(sc_threshold_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, t, n_rounds - 1, thr);
+  const Elig el{db.idx_base, db.idx_stride, n_eligible < 0 ? INT64_MAX : n_eligible, q_elig};
+  hipLaunchKernelGGL(sc_threshold_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, el, t, n_rounds - 1, thr);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 
-int launch_compact(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const float *thr, int32_t round,
-                   int32_t n_rounds, const rsx_sc_hit *topk_so_far, int32_t k, int32_t *cand, int64_t cand_stride,
-                   int32_t *cand_cnt, hipStream_t s) {
+int launch_compact(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
+                   const int64_t *q_elig, const float *thr, int32_t round, int32_t n_rounds,
+                   const rsx_sc_hit *topk_so_far, int32_t k, int32_t *cand, int64_t cand_stride, int32_t *cand_cnt,
+                   hipStream_t s) {
   if (nq <= 0) return RSX_OK;
-  hipLaunchKernelGGL(sc_compact_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, thr, round, n_rounds,
+  const Elig el{db.idx_base, db.idx_stride, n_eligible < 0 ? INT64_MAX : n_eligible, q_elig};
+  hipLaunchKernelGGL(sc_compact_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, el, thr, round, n_rounds,
                      topk_so_far, k, filter_eps(), cand, cand_stride, cand_cnt);
   RSX_HIP(hipGetLastError());
   return RSX_OK;

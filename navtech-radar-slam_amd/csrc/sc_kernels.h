@@ -77,6 +77,23 @@ int launch_pairs_lists(const DbView &db, const QueryView &q, const int32_t *cand
                        hipStream_t s);
 int pair_lists_slots(int32_t nq);
 
+// ---- exact re-scoring behind the filter ----
+constexpr int RESCORE_SHORTLIST_CAP = 2048;  // short-list records per query
+constexpr int RESCORE_NUM_THR = 6;           // round edges t_0..t_4 and t_cap
+struct RescoreEntry {
+  float lb;      // filter bound
+  int32_t slot;  // local DB slot
+};
+// short list of every query: the eligible entries with bound < t_cap, where t_cap is the largest
+// histogram-bin edge with at most RESCORE_SHORTLIST_CAP bounds below it (+inf when all fit, -inf
+// when not even the first bin fits), and the round edges (targets 64, 128, 256, 512, 1024 bounds)
+int launch_select(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
+                  const int64_t *q_elig, RescoreEntry *slist, int32_t *sl_cnt, float *thr, hipStream_t s);
+// one workgroup per query: rounds of ascending bound with tau tightening; writes the final top-k
+int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
+                   int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
+                   const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s);
+
 // ---- MFMA lower-bound filter (sc_filter.hip) ----
 constexpr int FILTER_QIMG_BYTES = 9984;  // LDS image of one query (two displaced fp16 copies)
 constexpr int FILTER_DB_BYTES_PER_ENTRY = 2 * DS;
@@ -85,23 +102,25 @@ size_t filter_qimg_bytes(int32_t nq);
 // fp16 filter images of local slots [first, first+count) (needs their norms)
 int launch_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *hnT,
                      uint64_t *cmask, hipStream_t s);
-int launch_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, uint64_t *qmask,
-                        hipStream_t s);
-// lb[q*ld_lb + slot] = lower bound of dist(query q, local slot), slots [0, n_items); +inf when the
-// entry is not eligible for that query, -inf when it must be re-scored regardless
-int launch_filter(const DbView &db, const void *qimg, const uint64_t *qmask, int32_t nq, int64_t n_items,
-                  int64_t n_eligible, const int64_t *q_elig, float *lb, int64_t ld_lb, hipStream_t s);
+int launch_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, hipStream_t s);
+// lb[q*ld_lb + slot] = lower bound of dist(query q, local slot), slots [0, n_items); +inf when no
+// shift has an effective column (never a hit), -inf when the pair must be re-scored regardless
+int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
+                  hipStream_t s);
 // per-query thresholds t_r (r < n_rounds-1): the smallest bin edge below which at least
-// round_targets[r] eligible bounds lie (thr[q*FILTER_MAX_ROUNDS + r]; +inf when there are fewer)
+// round_targets[r] eligible bounds lie (thr[q*FILTER_MAX_ROUNDS + r]; +inf when there are fewer).
+// Eligible = global index < min(n_eligible, q_elig[q]).
 constexpr int FILTER_MAX_ROUNDS = 4;
-int launch_thresholds(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const int32_t *round_targets,
-                      int32_t n_rounds, float *thr, hipStream_t s);
+int launch_thresholds(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq,
+                      int64_t n_eligible, const int64_t *q_elig, const int32_t *round_targets, int32_t n_rounds,
+                      float *thr, hipStream_t s);
 // candidates of round r: eligible entries with t_{r-1} <= bound < t_r (round 0 also takes the
 // "always re-score" entries) that can still reach the top-k: not (bound - eps > tau), tau = k-th
 // exact distance found so far (topk_so_far; nullptr in round 0)
-int launch_compact(const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, const float *thr, int32_t round,
-                   int32_t n_rounds, const rsx_sc_hit *topk_so_far, int32_t k, int32_t *cand, int64_t cand_stride,
-                   int32_t *cand_cnt, hipStream_t s);
+int launch_compact(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
+                   const int64_t *q_elig, const float *thr, int32_t round, int32_t n_rounds,
+                   const rsx_sc_hit *topk_so_far, int32_t k, int32_t *cand, int64_t cand_stride, int32_t *cand_cnt,
+                   hipStream_t s);
 
 const char *pair_kernel_name();
 const char *filter_kernel_name();

@@ -209,74 +209,29 @@ constexpr int pair_waves_per_simd() {
   return blocks < 1 ? 1 : (blocks > 4 ? 4 : blocks);
 }
 
-// W = waves per SIMD the register allocator must leave room for (<= what the LDS footprint allows)
-template <int B, int W>
-__global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
-  char *wsm = smem + OFF_WAVES + wave * PairLds<B>::WAVE_SIZE;
-  const int qi = blockIdx.y;
-  const int slot = blockIdx.x * 4 + wave;
-  const int nwaves = gridDim.x * 4;
+// ------------------------------------------------------------------------------------------
+// distanceBtnScanContext (SC.cpp:116-148) of the block's query (fp64 image, norms and sector key at
+// smem + OFF_Q*) against B database entries, by one wavefront.  wsm = the wave's private LDS region
+// (B x ENT_SIZE).  Result of entry b: lanes 8*b .. 8*b+7 all hold (bd, bk) = (distance, shift),
+// {1e7, 0} when no shift of the window has an effective column (SC.cpp:133-134 initial values).
+// ------------------------------------------------------------------------------------------
+template <int B>
+__device__ __forceinline__ void pair_group(const DbView &db, const char *smem, char *wsm, int lane,
+                                           const int64_t (&eslot)[B], double &bd_out, int &bk_out) {
   const int cl = lane < NS ? lane : 0;       // entry column owned in stage 2
   const int kk = lane < NS ? lane : NS - 1;  // shift owned in stage 1
-
-  // ---- query -> LDS (once per block): fp64 image, norms, sector key ----
-  {
-    const float *qd = a.q.desc + (int64_t)qi * DS;
-    for (int i = threadIdx.x; i < DS; i += 256) {
-      const int c = i / NR, r = i - c * NR;
-      *reinterpret_cast<double *>(smem + OFF_QIMG + c * Q_COL_STRIDE + r * 8) = (double)qd[i];
-    }
-    if (threadIdx.x < NS) {
-      reinterpret_cast<double *>(smem + OFF_QN1)[threadIdx.x] = a.q.norm[(int64_t)qi * NS + threadIdx.x];
-      reinterpret_cast<double *>(smem + OFF_QV1)[threadIdx.x] = a.q.vkey[(int64_t)qi * NS + threadIdx.x];
-    }
-  }
-  __syncthreads();
   const double *v1 = reinterpret_cast<const double *>(smem + OFF_QV1);
   const double *qn1 = reinterpret_cast<const double *>(smem + OFF_QN1);
-
-  int64_t n_elig = a.n_eligible;
-  if (a.q_elig) {
-    int64_t e = a.q_elig[qi];
-    n_elig = e < n_elig ? e : n_elig;
-  }
-
-  // per-wave sorted top-k, one record per lane
-  double ld = INFINITY;
-  int li = 0x7fffffff, ls = 0;
-
-  const int32_t *gath = a.gather;
-  int64_t n_items = a.n_items;
-  if (a.cand) {
-    gath = a.cand + (int64_t)qi * a.cand_stride;
-    n_items = a.cand_cnt[qi];
-  }
-  const int64_t ngroups = (n_items + B - 1) / B;
-  for (int64_t g = slot; g < ngroups; g += nwaves) {
-    // ---- stage 0: issue the entry loads (column cl of each entry stays in registers as fp32
-    //      until stage 2; the sector key goes to LDS twice for the rotated reads of stage 1) ----
-    int64_t eslot[B];
-    bool evalid[B];
-    float4 ecol[B][5];
-    double en2[B];
-#pragma unroll
-    for (int b = 0; b < B; b++) {
-      int64_t item = g * B + b;
-      evalid[b] = item < n_items;
-      int64_t it = evalid[b] ? item : (n_items - 1);
-      eslot[b] = gath ? (int64_t)gath[it] : (a.first + it);
-    }
+  float4 ecol[B][5];
+  double en2[B];
     wave_lds_fence();
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      const double v = a.db.vkey[eslot[b] * NS + cl];
-      const float4 *src = reinterpret_cast<const float4 *>(a.db.desc + eslot[b] * DS + cl * NR);
+      const double v = db.vkey[eslot[b] * NS + cl];
+      const float4 *src = reinterpret_cast<const float4 *>(db.desc + eslot[b] * DS + cl * NR);
 #pragma unroll
       for (int i = 0; i < 5; i++) ecol[b][i] = src[i];
-      en2[b] = a.db.norm[eslot[b] * NS + cl];
+      en2[b] = db.norm[eslot[b] * NS + cl];
       double *vka = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY_A);
       double *vkb = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY_B);
       if (lane < NS) {
@@ -415,6 +370,86 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
       bk = 0;
     }
 
+    bd_out = bd;
+    bk_out = bk;
+}
+
+// query -> LDS (once per block): fp64 image (column stride Q_COL_STRIDE), norms, sector key
+__device__ __forceinline__ void load_query_to_lds(const QueryView &q, int qi, char *smem, int tid, int nthreads) {
+  const float *qd = q.desc + (int64_t)qi * DS;
+  for (int i = tid; i < DS; i += nthreads) {
+    const int c = i / NR, r = i - c * NR;
+    *reinterpret_cast<double *>(smem + OFF_QIMG + c * Q_COL_STRIDE + r * 8) = (double)qd[i];
+  }
+  if (tid < NS) {
+    reinterpret_cast<double *>(smem + OFF_QN1)[tid] = q.norm[(int64_t)qi * NS + tid];
+    reinterpret_cast<double *>(smem + OFF_QV1)[tid] = q.vkey[(int64_t)qi * NS + tid];
+  }
+}
+
+// insert (dist, idx, shift) into the wave's sorted top-k list (one record per lane, lanes < k)
+__device__ __forceinline__ void topk_insert(double &ld, int &li, int &ls, int lane, int k, double dist, int idx,
+                                            int shift) {
+  const bool before = (lane < k) && hit_before(ld, li, dist, idx);
+  const int pos = __popcll(__ballot(before));
+  if (pos < k) {
+    double ud = __shfl_up(ld, 1);
+    int ui = __shfl_up(li, 1), us = __shfl_up(ls, 1);
+    if (lane > pos) {
+      ld = ud; li = ui; ls = us;
+    } else if (lane == pos) {
+      ld = dist; li = idx; ls = shift;
+    }
+  }
+}
+
+// W = waves per SIMD the register allocator must leave room for (<= what the LDS footprint allows)
+template <int B, int W>
+__global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  char *wsm = smem + OFF_WAVES + wave * PairLds<B>::WAVE_SIZE;
+  const int qi = blockIdx.y;
+  const int slot = blockIdx.x * 4 + wave;
+  const int nwaves = gridDim.x * 4;
+
+  load_query_to_lds(a.q, qi, smem, threadIdx.x, 256);
+  __syncthreads();
+
+  int64_t n_elig = a.n_eligible;
+  if (a.q_elig) {
+    int64_t e = a.q_elig[qi];
+    n_elig = e < n_elig ? e : n_elig;
+  }
+
+  // per-wave sorted top-k, one record per lane
+  double ld = INFINITY;
+  int li = 0x7fffffff, ls = 0;
+
+  const int32_t *gath = a.gather;
+  int64_t n_items = a.n_items;
+  if (a.cand) {
+    gath = a.cand + (int64_t)qi * a.cand_stride;
+    n_items = a.cand_cnt[qi];
+  }
+  const int64_t ngroups = (n_items + B - 1) / B;
+  for (int64_t g = slot; g < ngroups; g += nwaves) {
+    // ---- stage 0: issue the entry loads (column cl of each entry stays in registers as fp32
+    //      until stage 2; the sector key goes to LDS twice for the rotated reads of stage 1) ----
+    int64_t eslot[B];
+    bool evalid[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      int64_t item = g * B + b;
+      evalid[b] = item < n_items;
+      int64_t it = evalid[b] ? item : (n_items - 1);
+      eslot[b] = gath ? (int64_t)gath[it] : (a.first + it);
+    }
+    double bd;
+    int bk;
+    pair_group<B>(a.db, smem, wsm, lane, eslot, bd, bk);
+
     // ---- outputs ----
 #pragma unroll
     for (int b = 0; b < B; b++) {
@@ -429,18 +464,7 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
       if (a.partial) {
         const int64_t gidx = a.db.idx_base + eslot[b] * a.db.idx_stride;
         if (gidx < n_elig && dist < kBig) {  // SC.cpp:388: must beat the 1e7 init
-          const int idx = (int)gidx;
-          const bool before = (lane < a.k) && hit_before(ld, li, dist, idx);
-          const int pos = __popcll(__ballot(before));
-          if (pos < a.k) {
-            double ud = __shfl_up(ld, 1);
-            int ui = __shfl_up(li, 1), us = __shfl_up(ls, 1);
-            if (lane > pos) {
-              ld = ud; li = ui; ls = us;
-            } else if (lane == pos) {
-              ld = dist; li = idx; ls = shift;
-            }
-          }
+          topk_insert(ld, li, ls, lane, a.k, dist, (int)gidx, shift);
         }
       }
     }
@@ -583,6 +607,224 @@ __global__ __launch_bounds__(1024) void sc_knn_kernel(const float *__restrict__ 
   if (threadIdx.x == 0) out_found[0] = found;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// sc_rescore_kernel: exact re-scoring behind the MFMA filter (sc_filter.hip), one 16-wave workgroup
+// per query.  The query's candidates arrive as a short list of (bound, slot) records -- the entries
+// with the smallest filter bounds -- and are scored in rounds of ascending bound: after every round
+// the workgroup merges its per-wave top-k lists into tau (the k-th best exact distance so far) and
+// the next round only scores entries with bound - eps <= tau.  It stops as soon as the next bound
+// range cannot reach the top-k; entries beyond the short list (bound >= t_cap) are only scanned when
+// tau still admits them.  Output: the final top-k, sorted by (dist, global index), padded {1e7,0,0}.
+// ------------------------------------------------------------------------------------------
+constexpr int RS_CAND_CAP = RESCORE_SHORTLIST_CAP;  // 2048
+
+template <int B, int RS_WAVES>
+struct RescoreLds {
+  static constexpr int OFF_CAND = OFF_WAVES + RS_WAVES * B * ENT_SIZE;
+  static constexpr int OFF_XCH = OFF_CAND + RS_CAND_CAP * 4;                       // int32 candidate slots
+  static constexpr int OFF_MISC = OFF_XCH + RS_WAVES * RSX_SC_MAX_TOPK * 16;       // per-wave top-k lists
+  static constexpr int SIZE = OFF_MISC + 64;
+};
+
+struct RescoreArgs {
+  DbView db;
+  QueryView q;
+  const float *lb;  // filter bounds [nq][ld_lb] (only read past the short list)
+  int64_t ld_lb, n_items, n_eligible;
+  const int64_t *q_elig;
+  const RescoreEntry *slist;  // [nq][RS_CAND_CAP]
+  const int32_t *sl_cnt;      // [nq]
+  const float *thr;           // [nq][RESCORE_NUM_THR]: round edges t_0 <= t_1 <= ... ; the last one is t_cap
+  rsx_sc_hit *out;            // [nq][k]
+  double eps;
+  int32_t k;
+};
+
+// k-th smallest valid record (by (dist, index)) of the nrec records in xch, found by k rounds of
+// "smallest record after the previous pick" on ONE wave; when out != nullptr the picks are written
+// to out[0..k) padded with {1e7,0,0} (SC.cpp:362-364).  Returns the k-th distance or +inf.
+__device__ __forceinline__ double wave_select_kth(const rsx_sc_hit *xch, int nrec, int k, int lane, rsx_sc_hit *out) {
+  double pd = -INFINITY;
+  int pi = -1;
+  double kth = INFINITY;
+  for (int r = 0; r < k; r++) {
+    double bd = INFINITY;
+    int bi = 0x7fffffff, bs = 0;
+    for (int t = lane; t < nrec; t += 64) {
+      const rsx_sc_hit h = xch[t];
+      if (!(h.dist < kBig)) continue;  // padding
+      if (hit_before(pd, pi, h.dist, h.index) && hit_before(h.dist, h.index, bd, bi)) {
+        bd = h.dist; bi = h.index; bs = h.shift;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double od = __shfl_xor(bd, off);
+      const int oi = __shfl_xor(bi, off), os = __shfl_xor(bs, off);
+      if (hit_before(od, oi, bd, bi)) {
+        bd = od; bi = oi; bs = os;
+      }
+    }
+    if (out && lane == 0) {
+      rsx_sc_hit h;
+      if (bd == INFINITY) {
+        h.dist = kBig; h.index = 0; h.shift = 0;
+      } else {
+        h.dist = bd; h.index = bi; h.shift = bs;
+      }
+      out[r] = h;
+    }
+    if (r == k - 1) kth = bd;
+    pd = bd;
+    pi = bi;
+    if (bd == INFINITY && !out) break;  // fewer than k hits so far
+  }
+  return kth;
+}
+
+template <int B, int RS_WAVES>
+__global__ __launch_bounds__(RS_WAVES * 64) void sc_rescore_kernel(RescoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = RescoreLds<B, RS_WAVES>;
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x;
+  char *wsm = smem + OFF_WAVES + wave * (B * ENT_SIZE);
+  int32_t *cand = reinterpret_cast<int32_t *>(smem + L::OFF_CAND);
+  rsx_sc_hit *xch = reinterpret_cast<rsx_sc_hit *>(smem + L::OFF_XCH);
+  int *s_ncand = reinterpret_cast<int *>(smem + L::OFF_MISC);
+  double *s_tau = reinterpret_cast<double *>(smem + L::OFF_MISC + 8);
+
+  load_query_to_lds(a.q, qi, smem, threadIdx.x, RS_WAVES * 64);
+  if (threadIdx.x == 0) {
+    *s_ncand = 0;
+    *s_tau = INFINITY;
+  }
+  __syncthreads();
+
+  int64_t n_elig = a.n_eligible;
+  if (a.q_elig) {
+    const int64_t e = a.q_elig[qi];
+    n_elig = e < n_elig ? e : n_elig;
+  }
+  // local slots [0, n_rows) are the eligible ones
+  int64_t n_rows = 0;
+  if (n_elig > a.db.idx_base) {
+    n_rows = (n_elig - a.db.idx_base + a.db.idx_stride - 1) / a.db.idx_stride;
+    n_rows = n_rows < a.n_items ? n_rows : a.n_items;
+  }
+
+  double ld = INFINITY;  // per-wave sorted top-k, one record per lane; lives across rounds
+  int li = 0x7fffffff, ls = 0;
+  double tau = INFINITY;
+
+  // score cand[0..ncand) (all waves), then refresh tau
+  auto score_and_merge = [&](int ncand) {
+    const int ngroups = (ncand + B - 1) / B;
+    for (int g = wave; g < ngroups; g += RS_WAVES) {
+      int64_t eslot[B];
+      bool evalid[B];
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const int item = g * B + b;
+        evalid[b] = item < ncand;
+        eslot[b] = cand[evalid[b] ? item : (ncand - 1)];
+      }
+      double bd;
+      int bk;
+      pair_group<B>(a.db, smem, wsm, lane, eslot, bd, bk);
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const double dist = __shfl(bd, b * 8);
+        const int shift = __shfl(bk, b * 8);
+        if (!evalid[b]) continue;
+        const int64_t gidx = a.db.idx_base + eslot[b] * a.db.idx_stride;
+        if (gidx < n_elig && dist < kBig) topk_insert(ld, li, ls, lane, a.k, dist, (int)gidx, shift);
+      }
+    }
+    if (lane < a.k) {
+      rsx_sc_hit h;
+      h.dist = ld; h.index = li; h.shift = ls;
+      xch[wave * a.k + lane] = h;
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const double t = wave_select_kth(xch, RS_WAVES * a.k, a.k, lane, nullptr);
+      if (lane == 0) {
+        *s_tau = t;
+        *s_ncand = 0;
+      }
+    }
+    __syncthreads();
+    tau = *s_tau;
+  };
+
+  // block-wide append of this thread's candidate (wave ballot + one LDS atomic per wave)
+  auto append = [&](bool pass, int32_t slot) {
+    const unsigned long long bal = __ballot(pass);
+    int wbase = 0;
+    if (lane == 0 && bal) wbase = atomicAdd(s_ncand, __popcll(bal));
+    wbase = __shfl(wbase, 0);
+    if (pass) cand[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = slot;
+  };
+
+  // ---- rounds over the short list ----
+  const int sl_cnt = a.sl_cnt[qi];
+  const RescoreEntry *sl = a.slist + (int64_t)qi * RS_CAND_CAP;
+  const float *thr = a.thr + (int64_t)qi * RESCORE_NUM_THR;
+  const float t_cap = thr[RESCORE_NUM_THR - 1];
+  float lo = -INFINITY;
+  bool done = false;
+  for (int r = 0; r < RESCORE_NUM_THR; r++) {
+    const float hi = thr[r];
+    if (!(lo < hi)) continue;  // empty range (uniform)
+    for (int i = threadIdx.x; i < sl_cnt; i += RS_WAVES * 64) {  // sl_cnt <= 2048: at most 2 trips
+      const RescoreEntry e = sl[i];
+      // the first non-empty round also owns NaN / -inf bounds ("always re-score")
+      const bool in_round = (lo == -INFINITY) ? !(e.lb >= hi) : (e.lb >= lo && e.lb < hi);
+      append(in_round && !((double)e.lb - a.eps > tau), e.slot);
+    }
+    __syncthreads();
+    const int ncand = *s_ncand;
+    score_and_merge(ncand);
+    lo = hi;
+    if ((double)lo - a.eps > tau) {  // every remaining bound is >= lo: nothing can reach the top-k
+      done = true;
+      break;
+    }
+  }
+
+  // ---- entries beyond the short list (bound >= t_cap), only while tau admits them ----
+  if (!done && t_cap < INFINITY) {
+    const float *row = a.lb + (int64_t)qi * a.ld_lb;
+    const bool take_all = (t_cap == -INFINITY);  // empty short list: NaN bounds are here too
+    int64_t pos = 0;
+    while (pos < n_rows) {
+      // gather up to RS_CAND_CAP candidates, 1024 rows at a time
+      int ncand = 0;
+      while (pos < n_rows && ncand <= RS_CAND_CAP - RS_WAVES * 64) {
+        const int64_t i = pos + threadIdx.x;
+        bool pass = false;
+        if (i < n_rows) {
+          const float d = row[i];
+          const bool beyond = take_all ? true : (d >= t_cap);
+          pass = beyond && (d != INFINITY) && !((double)d - a.eps > tau);
+        }
+        append(pass, (int32_t)i);
+        pos += RS_WAVES * 64;
+        __syncthreads();
+        ncand = *s_ncand;
+        __syncthreads();
+      }
+      score_and_merge(ncand);
+    }
+  }
+
+  // ---- output: final top-k ----
+  if (wave == 0) wave_select_kth(xch, RS_WAVES * a.k, a.k, lane, a.out + (int64_t)qi * a.k);
+}
+
 template <int B, int W>
 int launch_pairs_t(const PairArgs &a, int gx, hipStream_t s) {
   static_assert(W <= pair_waves_per_simd<B>(), "LDS footprint does not allow this occupancy");
@@ -715,6 +957,47 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
                        (int64_t)0, (int64_t)a.nslots * k, a.nslots * k, k, d_topk);
     RSX_HIP(hipGetLastError());
   }
+  return RSX_OK;
+}
+
+int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
+                   int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
+                   const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s) {
+  if (q.nq <= 0) return RSX_OK;
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
+  // workgroup shape = waves x entries per wave iteration; RSX_SC_RESCORE_VARIANT=0: 12 waves x 2
+  // (162 VGPRs, 3 waves/SIMD), 1: 16 waves x 1 (126 VGPRs, 4 waves/SIMD)
+  static const int variant = [] {
+    const char *e = getenv("RSX_SC_RESCORE_VARIANT");
+    return (e && *e) ? atoi(e) : 0;
+  }();
+  RescoreArgs a;
+  a.db = db;
+  a.q = q;
+  a.lb = lb;
+  a.ld_lb = ld_lb;
+  a.n_items = n_items;
+  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
+  a.q_elig = q_elig;
+  a.slist = slist;
+  a.sl_cnt = sl_cnt;
+  a.thr = thr;
+  a.out = d_out;
+  a.eps = eps;
+  a.k = k;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<2, 12>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RescoreLds<2, 12>::SIZE));
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<1, 16>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, RescoreLds<1, 16>::SIZE));
+    attr_set = true;
+  }
+  if (variant == 1)
+    hipLaunchKernelGGL((sc_rescore_kernel<1, 16>), dim3(q.nq), dim3(16 * 64), RescoreLds<1, 16>::SIZE, s, a);
+  else
+    hipLaunchKernelGGL((sc_rescore_kernel<2, 12>), dim3(q.nq), dim3(12 * 64), RescoreLds<2, 12>::SIZE, s, a);
+  RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 
