@@ -37,7 +37,7 @@ struct rsx_sc {
   int64_t batch_size = 0;
   // workspaces
   DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
-  DevBuf f_qimg, f_lb, f_cand, f_cnt, f_seed, f_thr;  // filter path
+  DevBuf f_qimg, f_lb, f_cand, f_cnt, f_thr;  // filter path
   PairProfiler prof;
   const char *prof_kernel = "sc_pair_kernel";  // which kernel the profiler events bracket
   void *pinned = nullptr;  // small pinned host staging (results)
@@ -340,7 +340,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_seed, &h->f_thr}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();

@@ -81,7 +81,6 @@ constexpr int F_PHASE_BYTES = F_QPP * FILTER_QIMG_BYTES;  // 39936 = 39 KiB
 constexpr double kImgScale = 32768.0;                 // 2^15 on both operands
 constexpr float kAccScale = 1073741824.0f;            // 2^30 carried by the accumulators
 constexpr u64 kNonFinite = 1ull << 63;
-constexpr double kBig = 10000000.0;
 
 static_assert(FILTER_QIMG_BYTES == 9984, "layout");
 static_assert(F_PHASE_BYTES % 1024 == 0, "phase must be whole 1 KiB DMA pieces");
@@ -398,9 +397,8 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
-// thresholds: 2048-bin histogram of one query's bounds over [0, 1) (bounds outside land in the end
-// bins), prefix sum, first bin edge with at least target[r] bounds below it.  bin(x) <= b  <=>
-// x < (b+1)/2048 exactly (power-of-two scaling), so "bound < t_r" selects whole bins.
+// bound histogram: 2048 bins over [0, 1) (bounds outside land in the end bins).  bin(x) <= b  <=>
+// x < (b+1)/2048 exactly (power-of-two scaling), so a "bound < edge" test selects whole bins.
 // ------------------------------------------------------------------------------------------
 constexpr int H_BINS = 2048;
 
@@ -409,10 +407,6 @@ __device__ __forceinline__ int lb_bin(float d) {
   const float x = d * (float)H_BINS;
   return x >= (float)(H_BINS - 1) ? H_BINS - 1 : (int)x;
 }
-
-struct RoundTargets {
-  int32_t t[FILTER_MAX_ROUNDS];
-};
 
 // entries [0, n_elig_items(q)) of a row are eligible for query q: local slot i has global index
 // idx_base + i * idx_stride, eligible iff that is < min(n_eligible, q_elig[q])
@@ -429,102 +423,6 @@ __device__ __forceinline__ int64_t n_elig_items(const Elig &el, int q, int64_t n
   if (lim <= el.idx_base) return 0;
   const int64_t c = (lim - el.idx_base + el.idx_stride - 1) / el.idx_stride;
   return c < n_items ? c : n_items;
-}
-
-__global__ __launch_bounds__(256) void sc_threshold_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items_all,
-                                                           Elig el, RoundTargets targets, int32_t n_thr,
-                                                           float *__restrict__ thr) {
-  __shared__ int hist[H_BINS];
-  __shared__ int wsum[4];
-  const int q = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *row = lb + (int64_t)q * ld;
-  const int64_t n_items = n_elig_items(el, q, n_items_all);
-  for (int i = threadIdx.x; i < H_BINS; i += 256) hist[i] = 0;
-  __syncthreads();
-  for (int64_t i = threadIdx.x; i < n_items; i += 256) {
-    const float d = row[i];
-    if (d == INFINITY) continue;  // no effective column at any shift: never a hit
-    atomicAdd(&hist[lb_bin(d)], 1);
-  }
-  __syncthreads();
-  // inclusive prefix over the 2048 bins: thread t owns bins [8t, 8t+8)
-  int v[8];
-  int run = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    run += hist[threadIdx.x * 8 + i];
-    v[i] = run;
-  }
-  int incl = run;
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(incl, off);
-    if (lane >= off) incl += o;
-  }
-  if (lane == 63) wsum[wave] = incl;
-  __syncthreads();
-  int base = incl - run;
-  for (int w = 0; w < wave; w++) base += wsum[w];
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 8; i++) hist[threadIdx.x * 8 + i] = base + v[i];  // inclusive cumulative counts
-  __syncthreads();
-  if (threadIdx.x < n_thr) {
-    const int target = targets.t[threadIdx.x];
-    // smallest b with cum[b] >= target (binary search); none -> +inf
-    int lo = 0, hi = H_BINS;  // answer in [lo, hi]; hi == H_BINS means none
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (hist[mid] >= target) hi = mid;
-      else lo = mid + 1;
-    }
-    thr[(int64_t)q * FILTER_MAX_ROUNDS + threadIdx.x] = (lo >= H_BINS - 1) ? INFINITY : (float)(lo + 1) / (float)H_BINS;
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// candidates of one round
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sc_compact_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items_all,
-                                                         Elig el, const float *__restrict__ thr, int32_t round, int32_t n_rounds,
-                                                         const rsx_sc_hit *__restrict__ topk, int32_t k, double eps,
-                                                         int32_t *__restrict__ cand, int64_t cand_stride,
-                                                         int32_t *__restrict__ cand_cnt) {
-  __shared__ int total;
-  const int q = blockIdx.x;
-  const int lane = threadIdx.x & 63;
-  const float *row = lb + (int64_t)q * ld;
-  const int64_t n_items = n_elig_items(el, q, n_items_all);
-  double tau = INFINITY;
-  if (topk) {
-    tau = topk[(int64_t)q * k + (k - 1)].dist;  // k-th best exact distance so far
-    if (!(tau < kBig)) tau = INFINITY;          // fewer than k hits so far
-  }
-  const float lo = round > 0 ? thr[(int64_t)q * FILTER_MAX_ROUNDS + round - 1] : -INFINITY;
-  const float hi = round < n_rounds - 1 ? thr[(int64_t)q * FILTER_MAX_ROUNDS + round] : INFINITY;
-  if (threadIdx.x == 0) total = 0;
-  __syncthreads();
-  int32_t *out = cand + (int64_t)q * cand_stride;
-  if (lo < INFINITY) {  // (uniform) an earlier round already took every eligible entry otherwise
-    for (int64_t base = 0; base < n_items; base += 256) {
-      const int64_t i = base + threadIdx.x;
-      bool pass = false;
-      if (i < n_items) {
-        const float d = row[i];
-        // round 0 also owns NaN (d >= hi is false for NaN); +inf (never a hit) fails d < hi / passes d >= hi
-        const bool in_round = round == 0 ? !(d >= hi) : (d >= lo && d < hi);
-        pass = in_round && !((double)d - eps > tau);
-      }
-      const u64 bal = __ballot(pass);
-      int wbase = 0;
-      if (lane == 0 && bal) wbase = atomicAdd(&total, __popcll(bal));
-      wbase = __shfl(wbase, 0);
-      if (pass) out[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = (int32_t)i;
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) cand_cnt[q] = total;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -693,31 +591,6 @@ int launch_select(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_it
   if (nq <= 0) return RSX_OK;
   const Elig el{db.idx_base, db.idx_stride, n_eligible < 0 ? INT64_MAX : n_eligible, q_elig};
   hipLaunchKernelGGL(sc_select_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, el, slist, sl_cnt, thr);
-  RSX_HIP(hipGetLastError());
-  return RSX_OK;
-}
-
-int launch_thresholds(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq,
-                      int64_t n_eligible, const int64_t *q_elig, const int32_t *round_targets, int32_t n_rounds,
-                      float *thr, hipStream_t s) {
-  if (nq <= 0 || n_rounds <= 1) return RSX_OK;
-  if (n_rounds > FILTER_MAX_ROUNDS) return fail(RSX_ERR_INTERNAL, "too many filter rounds");
-  RoundTargets t;
-  for (int i = 0; i < FILTER_MAX_ROUNDS; i++) t.t[i] = i < n_rounds - 1 ? round_targets[i] : 0;
-  const Elig el{db.idx_base, db.idx_stride, n_eligible < 0 ? INT64_MAX : n_eligible, q_elig};
-  hipLaunchKernelGGL(sc_threshold_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, el, t, n_rounds - 1, thr);
-  RSX_HIP(hipGetLastError());
-  return RSX_OK;
-}
-
-int launch_compact(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
-                   const int64_t *q_elig, const float *thr, int32_t round, int32_t n_rounds,
-                   const rsx_sc_hit *topk_so_far, int32_t k, int32_t *cand, int64_t cand_stride, int32_t *cand_cnt,
-                   hipStream_t s) {
-  if (nq <= 0) return RSX_OK;
-  const Elig el{db.idx_base, db.idx_stride, n_eligible < 0 ? INT64_MAX : n_eligible, q_elig};
-  hipLaunchKernelGGL(sc_compact_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, el, thr, round, n_rounds,
-                     topk_so_far, k, filter_eps(), cand, cand_stride, cand_cnt);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

@@ -66,17 +66,6 @@ int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t 
 int launch_knn(const float *rkeys, int64_t n_search, const float *qkey, int32_t k, float *d_dist_ws,
                int32_t *out_idx, float *out_dist, int32_t *out_found, hipStream_t s);
 
-// the same against PER-QUERY candidate lists: query q scores local slots cand[q*cand_stride + i],
-// i < cand_cnt[q] (device arrays; the counts are never read by the host).  The search runs in
-// n_rounds rounds over disjoint candidate sets: round r writes its per-wave lists into region r of
-// d_partial ([nq][n_rounds * pair_lists_slots(nq)][k] records) and d_topk receives the merged top-k
-// of rounds 0..r.
-int launch_pairs_lists(const DbView &db, const QueryView &q, const int32_t *cand, int64_t cand_stride,
-                       const int32_t *cand_cnt, int64_t n_eligible, const int64_t *q_elig,
-                       rsx_sc_hit *d_partial, int32_t round, int32_t n_rounds, rsx_sc_hit *d_topk, int32_t k,
-                       hipStream_t s);
-int pair_lists_slots(int32_t nq);
-
 // ---- exact re-scoring behind the filter ----
 constexpr int RESCORE_SHORTLIST_CAP = 2048;  // short-list records per query
 constexpr int RESCORE_NUM_THR = 6;           // round edges t_0..t_4 and t_cap
@@ -107,21 +96,6 @@ int launch_query_images(const float *desc, const double *norm, int32_t nq, void 
 // shift has an effective column (never a hit), -inf when the pair must be re-scored regardless
 int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
                   hipStream_t s);
-// per-query thresholds t_r (r < n_rounds-1): the smallest bin edge below which at least
-// round_targets[r] eligible bounds lie (thr[q*FILTER_MAX_ROUNDS + r]; +inf when there are fewer).
-// Eligible = global index < min(n_eligible, q_elig[q]).
-constexpr int FILTER_MAX_ROUNDS = 4;
-int launch_thresholds(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq,
-                      int64_t n_eligible, const int64_t *q_elig, const int32_t *round_targets, int32_t n_rounds,
-                      float *thr, hipStream_t s);
-// candidates of round r: eligible entries with t_{r-1} <= bound < t_r (round 0 also takes the
-// "always re-score" entries) that can still reach the top-k: not (bound - eps > tau), tau = k-th
-// exact distance found so far (topk_so_far; nullptr in round 0)
-int launch_compact(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
-                   const int64_t *q_elig, const float *thr, int32_t round, int32_t n_rounds,
-                   const rsx_sc_hit *topk_so_far, int32_t k, int32_t *cand, int64_t cand_stride, int32_t *cand_cnt,
-                   hipStream_t s);
-
 const char *pair_kernel_name();
 const char *filter_kernel_name();
 

@@ -186,16 +186,12 @@ struct PairArgs {
   DbView db;
   QueryView q;
   const int32_t *gather;
-  const int32_t *cand;      // per-query candidate lists (overrides gather / n_items when set)
-  const int32_t *cand_cnt;
-  int64_t cand_stride;
   int64_t first, n_items, n_eligible;
   const int64_t *q_elig;
   double *out_dist;
   int32_t *out_shift;
   rsx_sc_hit *partial;
   int32_t k, nslots;
-  int32_t slot_base, slot_stride;  // partial record of (query, slot): [q*slot_stride + slot_base + slot][k]
 };
 
 __device__ __forceinline__ bool hit_before(double ad, int ai, double bd, int bi) {
@@ -428,11 +424,7 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
   int li = 0x7fffffff, ls = 0;
 
   const int32_t *gath = a.gather;
-  int64_t n_items = a.n_items;
-  if (a.cand) {
-    gath = a.cand + (int64_t)qi * a.cand_stride;
-    n_items = a.cand_cnt[qi];
-  }
+  const int64_t n_items = a.n_items;
   const int64_t ngroups = (n_items + B - 1) / B;
   for (int64_t g = slot; g < ngroups; g += nwaves) {
     // ---- stage 0: issue the entry loads (column cl of each entry stays in registers as fp32
@@ -475,7 +467,7 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
     h.dist = ld;
     h.index = li;
     h.shift = ls;
-    a.partial[((int64_t)qi * a.slot_stride + a.slot_base + slot) * a.k + lane] = h;
+    a.partial[((int64_t)qi * a.nslots + slot) * a.k + lane] = h;
   }
 }
 
@@ -683,8 +675,10 @@ __device__ __forceinline__ double wave_select_kth(const rsx_sc_hit *xch, int nre
   return kth;
 }
 
-template <int B, int RS_WAVES>
-__global__ __launch_bounds__(RS_WAVES * 64) void sc_rescore_kernel(RescoreArgs a) {
+// RS_WAVES waves per workgroup, W = waves per SIMD the register allocator leaves room for (several
+// workgroups share a CU so that one query's barriers / merges hide behind another's scoring)
+template <int B, int RS_WAVES, int W>
+__global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = RescoreLds<B, RS_WAVES>;
   const int lane = threadIdx.x & 63;
@@ -925,9 +919,6 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   a.db = db;
   a.q = q;
   a.gather = gather;
-  a.cand = nullptr;
-  a.cand_cnt = nullptr;
-  a.cand_stride = 0;
   a.first = first;
   a.n_items = n_items;
   a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
@@ -938,8 +929,6 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   a.partial = (d_topk && k > 0) ? d_partial : nullptr;
   a.k = k;
   a.nslots = gx * 4;
-  a.slot_base = 0;
-  a.slot_stride = a.nslots;
   PairProfiler *pp = (g_prof && g_prof->on && g_prof->ev && g_prof->used < PairProfiler::kMax) ? g_prof : nullptr;
   if (pp) RSX_HIP(hipEventRecord(pp->ev[2 * pp->used], s));
   const Variant var = pair_variant();
@@ -960,13 +949,26 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   return RSX_OK;
 }
 
+template <int B, int NW, int W>
+static int launch_rescore_t(const RescoreArgs &a, hipStream_t s) {
+  static bool attr_set = false;
+  constexpr int lds = RescoreLds<B, NW>::SIZE;
+  if (!attr_set) {
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<B, NW, W>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((sc_rescore_kernel<B, NW, W>), dim3(a.q.nq), dim3(NW * 64), lds, s, a);
+  return RSX_OK;
+}
+
 int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
                    int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
                    const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s) {
   if (q.nq <= 0) return RSX_OK;
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
-  // workgroup shape = waves x entries per wave iteration; RSX_SC_RESCORE_VARIANT=0: 12 waves x 2
-  // (162 VGPRs, 3 waves/SIMD), 1: 16 waves x 1 (126 VGPRs, 4 waves/SIMD)
+  // workgroup shape (entries per wave iteration, waves, waves/SIMD); RSX_SC_RESCORE_VARIANT picks one:
+  // 0: (1, 8, 4) two workgroups per CU   1: (1, 16, 4)   2: (2, 12, 3)   3: (2, 6, 3) two per CU
   static const int variant = [] {
     const char *e = getenv("RSX_SC_RESCORE_VARIANT");
     return (e && *e) ? atoi(e) : 0;
@@ -985,62 +987,12 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
   a.out = d_out;
   a.eps = eps;
   a.k = k;
-  static bool attr_set = false;
-  if (!attr_set) {
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<2, 12>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, RescoreLds<2, 12>::SIZE));
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<1, 16>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, RescoreLds<1, 16>::SIZE));
-    attr_set = true;
+  switch (variant) {
+    case 1: RSX_TRY((launch_rescore_t<1, 16, 4>(a, s))); break;
+    case 2: RSX_TRY((launch_rescore_t<2, 12, 3>(a, s))); break;
+    case 3: RSX_TRY((launch_rescore_t<2, 6, 3>(a, s))); break;
+    default: RSX_TRY((launch_rescore_t<1, 8, 4>(a, s))); break;
   }
-  if (variant == 1)
-    hipLaunchKernelGGL((sc_rescore_kernel<1, 16>), dim3(q.nq), dim3(16 * 64), RescoreLds<1, 16>::SIZE, s, a);
-  else
-    hipLaunchKernelGGL((sc_rescore_kernel<2, 12>), dim3(q.nq), dim3(12 * 64), RescoreLds<2, 12>::SIZE, s, a);
-  RSX_HIP(hipGetLastError());
-  return RSX_OK;
-}
-
-static int lists_gx(int32_t nq) {
-  int64_t want = (2048 + 4 * (int64_t)nq - 1) / (4 * (int64_t)nq);  // ~2048 waves in flight
-  return (int)(want < 1 ? 1 : (want > 8 ? 8 : want));
-}
-
-int pair_lists_slots(int32_t nq) { return lists_gx(nq) * 4; }
-
-int launch_pairs_lists(const DbView &db, const QueryView &q, const int32_t *cand, int64_t cand_stride,
-                       const int32_t *cand_cnt, int64_t n_eligible, const int64_t *q_elig,
-                       rsx_sc_hit *d_partial, int32_t round, int32_t n_rounds, rsx_sc_hit *d_topk, int32_t k,
-                       hipStream_t s) {
-  if (q.nq <= 0) return RSX_OK;
-  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
-  PairArgs a;
-  a.db = db;
-  a.q = q;
-  a.gather = nullptr;
-  a.cand = cand;
-  a.cand_cnt = cand_cnt;
-  a.cand_stride = cand_stride;
-  a.first = 0;
-  a.n_items = 0;
-  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
-  a.q_elig = q_elig;
-  a.out_dist = nullptr;
-  a.out_shift = nullptr;
-  const int gx = lists_gx(q.nq);
-  a.partial = d_partial;
-  a.k = k;
-  a.nslots = gx * 4;
-  a.slot_base = round * a.nslots;
-  a.slot_stride = n_rounds * a.nslots;
-  const Variant var = pair_variant();
-  if (var.b == 1) RSX_TRY((launch_pairs_t<1, 4>(a, gx, s)));
-  else if (var.b == 2 && var.w == 3) RSX_TRY((launch_pairs_t<2, 3>(a, gx, s)));
-  else if (var.b == 2) RSX_TRY((launch_pairs_t<2, 4>(a, gx, s)));
-  else RSX_TRY((launch_pairs_t<4, 2>(a, gx, s)));
-  // top-k over the partial lists of rounds 0..round
-  hipLaunchKernelGGL(sc_merge_kernel, dim3(q.nq), dim3(64), 0, s, (const rsx_sc_hit *)d_partial, 1, (int64_t)0,
-                     (int64_t)a.slot_stride * k, (round + 1) * a.nslots * k, k, d_topk);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
