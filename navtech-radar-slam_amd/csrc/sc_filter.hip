@@ -75,7 +75,7 @@ constexpr int QIMG_EVEN_CHUNKS = 308;  // 2464 elements
 constexpr int QIMG_GAP_CHUNKS = 2;
 constexpr int QIMG_CHUNKS = FILTER_QIMG_BYTES / 16;  // 624
 constexpr int F_QPP = 4;          // queries per LDS phase
-constexpr int F_DEPTH = 8;        // A fragments in flight
+constexpr int F_DEPTH = 5;        // A fragments in flight; divides F_T so the ring carries over from query to query
 constexpr int F_B_VGPR = 44;      // B fragments kept in VGPRs; the rest live in AGPRs
 constexpr int F_PHASE_BYTES = F_QPP * FILTER_QIMG_BYTES;  // 39936 = 39 KiB
 constexpr double kImgScale = 32768.0;                 // 2^15 on both operands
@@ -83,6 +83,7 @@ constexpr float kAccScale = 1073741824.0f;            // 2^30 carried by the acc
 constexpr u64 kNonFinite = 1ull << 63;
 
 static_assert(FILTER_QIMG_BYTES == 9984, "layout");
+static_assert(F_T % F_DEPTH == 0, "ring slot of fragment j of the next query must be j % F_DEPTH");
 static_assert(F_PHASE_BYTES % 1024 == 0, "phase must be whole 1 KiB DMA pieces");
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -229,17 +230,13 @@ __device__ __forceinline__ void epi_piece(Epi &e, float S, unsigned m2lo, unsign
   else e.m0 = fmaxf(e.m0, v);
 }
 
-template <int I>
-__device__ __forceinline__ void epi_piece_i(Epi &e, const floatx16 &p0, const floatx16 &p1, unsigned m2lo,
-                                            unsigned m2hi, int hh) {
-  if constexpr (I < 16) epi_piece<0, I & 15>(e, p0[I & 15], m2lo, m2hi, hh);
-  else epi_piece<1, I & 15>(e, p1[I & 15], m2lo, m2hi, hh);
-}
-
 // lower bound of this lane's entry for the finished query: 1 - max_k S_k / n_eff(k) / 2^30
 __device__ __forceinline__ float epi_end(const Epi &e) {
   float m = fmaxf(e.m0, e.m1);
-  m = fmaxf(m, __shfl_xor(m, 32));
+  // lanes l and l ^ 32 hold the two halves of the shifts of one entry: v_permlane32_swap of (m, m)
+  // yields {m[l & 31]} and {m[(l & 31) + 32]} in every lane
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+  m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
   return fmaf(m, -1.0f / kAccScale, 1.0f);  // m == -inf (no effective column at any shift) -> +inf
 }
 
@@ -257,37 +254,82 @@ __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
 }
 
-template <bool DO_MFMA, bool DO_EPI>
-__device__ __forceinline__ void filter_stage(const char *ap, const half8 (&B)[F_STEPS], floatx16 &acc0,
-                                             floatx16 &acc1, const floatx16 &p0, const floatx16 &p1, Epi &e,
-                                             unsigned m2lo, unsigned m2hi, int hh) {
-  half8 ring[F_DEPTH];
-  if constexpr (DO_MFMA) {
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-      acc0[i] = 0.0f;
-      acc1[i] = 0.0f;
-    }
-#pragma unroll
-    for (int t = 0; t < F_DEPTH; t++) ring[t] = *reinterpret_cast<const half8 *>(ap + 32 * t);
-    __builtin_amdgcn_sched_group_barrier(0x100, F_DEPTH, 0);
-  }
+// A-fragment reads are issued through inline asm with hand-counted s_waitcnt: LDS returns data in
+// issue order, so "the fragment of step t has landed" == "at most min(F_DEPTH-1, F_T-t-1) younger
+// reads are outstanding".  (Left to the compiler the waits degrade to lgkmcnt(0) after every few
+// reads, which parks the wave for a full LDS round trip ~40 times per query.)  The wait takes the
+// fragment as an in/out operand so that the consuming MFMA cannot be scheduled above it.
+__device__ __forceinline__ void lds_read_frag(half8 &dst, unsigned addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_frag(half8 &frag) {
+  asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+}
+
+// the first F_DEPTH fragments of a query (issued before its stage: by the previous stage's tail, or
+// explicitly at the start of an LDS phase)
+__device__ __forceinline__ void ring_prologue(half8 (&ring)[F_DEPTH], unsigned ap_lds) {
+  static_for<F_DEPTH>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    lds_read_frag(ring[t], ap_lds, 32 * t);
+  });
+}
+
+// which epilogue piece (0..15) is issued at step t of its 40-step window (-1: none)
+constexpr int piece_at(int t) {
+  for (int i = 0; i < 16; i++)
+    if ((i * 5) / 2 == t) return i;
+  return -1;
+}
+
+// One software-pipeline stage = one query.  Tile 0 (shifts 0..31, acc0) accumulates during steps
+// 0..74 and tile 1 (shifts 32..63, acc1) during steps 40..114, so each accumulator is idle for 40
+// steps per query and the epilogue reads it in place during exactly that window:
+//   steps   0..39   epilogue of the PREVIOUS query's tile 1 (acc1 still holds it), then `fin`
+//   steps  40..74   two MFMAs per step, nothing else
+//   steps  75..114  epilogue of THIS query's tile 0 (acc0 is complete)
+// No accumulator is ever copied, and the ring of A fragments carries over from query to query (the
+// last F_DEPTH steps read the first fragments at next_lds), so MFMAs issue back to back across
+// queries.  `e` carries the running maxima of the query whose tile 0 is done into the next stage.
+template <bool DO_MFMA, bool DO_PREV, typename Fin>
+__device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds, half8 (&ring)[F_DEPTH],
+                                             const half8 (&B)[F_STEPS], floatx16 &acc0, floatx16 &acc1, Epi &e,
+                                             u64 cur_mask, unsigned m2lo, unsigned m2hi, int hh, Fin &&fin) {
   static_for<F_T>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     if constexpr (DO_MFMA) {
+      // younger reads than fragment t: always F_DEPTH - 1 (the tail reads of the next query included)
+      lds_wait_frag<F_DEPTH - 1>(ring[t % F_DEPTH]);
       const half8 af = ring[t % F_DEPTH];
-      if constexpr (t + F_DEPTH < F_T) ring[t % F_DEPTH] = *reinterpret_cast<const half8 *>(ap + 32 * (t + F_DEPTH));
-      if constexpr (t < F_STEPS) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t], acc0, 0, 0, 0);
-      if constexpr (t >= F_TILE1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t - F_TILE1], acc1, 0, 0, 0);
+      if constexpr (t == 0) {
+        floatx16 z;
+#pragma unroll
+        for (int i = 0; i < 16; i++) z[i] = 0.0f;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[0], z, 0, 0, 0);
+      } else if constexpr (t < F_STEPS) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t], acc0, 0, 0, 0);
+      }
+      if constexpr (t == F_TILE1) {
+        floatx16 z;
+#pragma unroll
+        for (int i = 0; i < 16; i++) z[i] = 0.0f;
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[0], z, 0, 0, 0);
+      } else if constexpr (t > F_TILE1) {
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t - F_TILE1], acc1, 0, 0, 0);
+      }
+      if constexpr (t + F_DEPTH < F_T) lds_read_frag(ring[t % F_DEPTH], ap_lds, 32 * (t + F_DEPTH));
+      else lds_read_frag(ring[t % F_DEPTH], next_lds, 32 * (t + F_DEPTH - F_T));
     }
-    // 32 epilogue pieces spread over steps 8, 11, 14, ... (one piece = ~10 VALU)
-    if constexpr (DO_EPI && t >= 8 && (t - 8) % 3 == 0 && (t - 8) / 3 < 32)
-      epi_piece_i<(t - 8) / 3>(e, p0, p1, m2lo, m2hi, hh);
-    if constexpr (DO_MFMA) {
-      if constexpr (t >= F_TILE1 && t < F_STEPS) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-      else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      if constexpr (DO_EPI) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-      if constexpr (t + F_DEPTH < F_T) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    if constexpr (DO_PREV && t < F_TILE1) {
+      constexpr int i = piece_at(t);
+      if constexpr (i >= 0) epi_piece<1, i>(e, acc1[i], m2lo, m2hi, hh);
+      if constexpr (t == F_TILE1 - 1) fin(e);
+    }
+    if constexpr (DO_MFMA && t >= F_STEPS) {
+      if constexpr (t == F_STEPS) epi_begin(e, cur_mask, hh);
+      constexpr int i = piece_at(t - F_STEPS);
+      if constexpr (i >= 0) epi_piece<0, i>(e, acc0[i], m2lo, m2hi, hh);
     }
   });
 }
@@ -308,6 +350,7 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
   const int64_t L1 = (L0 + a.per_block < total) ? (L0 + a.per_block) : total;
   // A fragment address of this lane inside a query image (row = shift col of tile 0)
   const int aoff = ((col & 1) ? (QIMG_ODD + 40 * col - 8) : (40 * col)) + 16 * hh;
+  const unsigned lds_base = (unsigned)(uintptr_t)((AS3 char *)smem);
 
   while (L0 < L1) {
     const int64_t tb = L0 / a.nq;
@@ -347,16 +390,17 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    floatx16 acc0, acc1, p0, p1;
+    floatx16 acc0, acc1;
+    half8 ring[F_DEPTH];
     Epi e;
     int prev_q = -1;
     u64 prev_mask = 0;
     // finish one (query, tile): non-finite flag, store (128 B per wave); eligibility is applied by
     // the selection kernels, not here
-    auto finish = [&](const Epi &ep, int q, u64 qm) {
+    auto fin = [&](const Epi &ep) {
       float best = epi_end(ep);
-      if ((qm | m2) & kNonFinite) best = -INFINITY;  // non-finite input: always re-score exactly
-      if (n_ok && hh == 0) a.lb[(int64_t)q * a.ld_lb + n] = best;
+      if ((prev_mask | m2) & kNonFinite) best = -INFINITY;  // non-finite input: always re-score exactly
+      if (n_ok && hh == 0) a.lb[(int64_t)prev_q * a.ld_lb + n] = best;
     };
     for (int p = 0; p < nphase; p++) {
       const int qp = q0 + p * F_QPP;
@@ -366,33 +410,27 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
         stage_queries(a.qimg + (int64_t)qn * FILTER_QIMG_BYTES, smem + ((p + 1) & 1) * F_PHASE_BYTES,
                       nqs * FILTER_QIMG_BYTES, wave, lane);
       }
-      const char *buf = smem + (p & 1) * F_PHASE_BYTES;
       const int nq_here = (q1 - qp < F_QPP) ? (q1 - qp) : F_QPP;
       if (tile_ok) {
+        const unsigned phase_lds = lds_base + (unsigned)((p & 1) * F_PHASE_BYTES + aoff);
+        ring_prologue(ring, phase_lds);
         for (int qq = 0; qq < nq_here; qq++) {
-          const char *img = buf + qq * FILTER_QIMG_BYTES;
-          const u64 cur_mask = *reinterpret_cast<const u64 *>(img + QIMG_MASK_OFF);  // broadcast read
-          if (prev_q >= 0) {
-            epi_begin(e, prev_mask, hh);
-            filter_stage<true, true>(img + aoff, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
-            finish(e, prev_q, prev_mask);
-          } else {
-            filter_stage<true, false>(img + aoff, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
-          }
-          p0 = acc0;
-          p1 = acc1;
+          const unsigned ap_lds = phase_lds + (unsigned)(qq * FILTER_QIMG_BYTES);
+          const unsigned next_lds = (qq + 1 < nq_here) ? ap_lds + FILTER_QIMG_BYTES : ap_lds;
+          const u64 cur_mask = *reinterpret_cast<const u64 *>(smem + (p & 1) * F_PHASE_BYTES + qq * FILTER_QIMG_BYTES + QIMG_MASK_OFF);
+          if (prev_q < 0) filter_stage<true, false>(ap_lds, next_lds, ring, B, acc0, acc1, e, cur_mask, m2lo, m2hi, hh, fin);
+          else filter_stage<true, true>(ap_lds, next_lds, ring, B, acc0, acc1, e, cur_mask, m2lo, m2hi, hh, fin);
           prev_q = qp + qq;
           prev_mask = cur_mask;
         }
+        // the last stage of the phase refilled the ring with fragments nobody will use: drain them
+        // before the buffer can be overwritten by the DMA of phase p + 2
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    if (prev_q >= 0) {
-      epi_begin(e, prev_mask, hh);
-      filter_stage<false, true>(nullptr, B, acc0, acc1, p0, p1, e, m2lo, m2hi, hh);
-      finish(e, prev_q, prev_mask);
-    }
+    if (prev_q >= 0) filter_stage<false, true>(0u, 0u, ring, B, acc0, acc1, e, 0ull, m2lo, m2hi, hh, fin);
   }
 }
 
