@@ -13,6 +13,8 @@
  *   - the caller owns every buffer it passes; the library copies inputs before returning and
  *     writes outputs into caller memory.  Pointers named d_* are DEVICE (HBM) pointers of the
  *     handle's GPU and are used asynchronously on the given hipStream_t (passed as void*).
+ *     A NULL stream selects the handle's own private (non-blocking) stream, NOT the legacy default
+ *     stream: callers that mix several handles or other GPU work must pass one explicit stream.
  *   - a handle is internally synchronised: one writer (PGO.cpp:492, process_pg) and one reader
  *     (PGO.cpp:561, process_lcd) may call concurrently (the reference itself races here).
  *   - there is NO CPU fallback: without a usable HIP device rsx_*_create fails with
@@ -144,6 +146,20 @@ int rsx_sc_query(rsx_sc *h, const float *q_descs, int32_t nq, int32_t k, int64_t
  * caller can all-gather it (RCCL) without a host hop. */
 int rsx_sc_query_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k, int64_t n_eligible,
                         rsx_sc_hit *d_out, void *stream);
+/* The same query in two stages, for a DB sharded over several GPUs.  With one stage
+ * every shard would have to re-score the entries that look promising against ITS OWN k-th best
+ * distance; with two, the shards first agree on a global bound:
+ *   stage 1  filter + this shard's share of the lowest-bound entries   -> d_partial[nq][k]
+ *   caller   all-gather d_partial over the ranks (RCCL), rsx_sc_merge_topk_device -> d_global[nq][k]
+ *   stage 2  only entries whose bound can still beat the k-th distance of d_global are scored;
+ *            d_out[nq][k] = this shard's top-k including its stage-1 hits
+ *   caller   all-gather d_out, rsx_sc_merge_topk_device -> the global top-k
+ * d_q_descs must stay valid until stage 2 has run; stage 2 must follow stage 1 on the same handle
+ * with the same nq and k.  The merged result is identical to rsx_sc_query_device + merge. */
+int rsx_sc_query_stage1_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k, int64_t n_eligible,
+                               rsx_sc_hit *d_partial, void *stream);
+int rsx_sc_query_stage2_device(rsx_sc *h, int32_t nq, int32_t k, const rsx_sc_hit *d_global, rsx_sc_hit *d_out,
+                               void *stream);
 /* queries = DB entries [q_first, q_first+nq) of this handle (all-pairs runs, BASELINE config 5);
  * each query i uses n_eligible = min(n_eligible, q_first+i - exclude_recent) when exclude_recent >= 0 */
 int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, int64_t n_eligible,

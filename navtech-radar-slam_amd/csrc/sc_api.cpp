@@ -40,6 +40,14 @@ struct rsx_sc {
   DevBuf f_qimg, f_lb, f_cand, f_cnt, f_thr;  // filter path
   PairProfiler prof;
   const char *prof_kernel = "sc_pair_kernel";  // which kernel the profiler events bracket
+  // state between rsx_sc_query_stage1_device and rsx_sc_query_stage2_device
+  struct {
+    bool valid = false, filtered = false;
+    int32_t nq = 0, k = 0;
+    int64_t n_items = 0, n_eligible = 0;
+    QueryView qv{};
+  } st;
+  DevBuf st_partial;  // this shard's stage-1 hits
   void *pinned = nullptr;  // small pinned host staging (results)
   size_t pinned_bytes = 0;
 };
@@ -156,18 +164,55 @@ struct ProfScope {
 
 // exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> k seeds -> exact
 // -> tau -> candidates -> exact.  Everything stays on the stream; no host synchronisation.
-int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
-                      int32_t k, rsx_sc_hit *d_out, hipStream_t s) {
-  const DbView db = db_view(h);
+// query batch size the filter workspaces are sized for (<= 1 GiB of bounds)
+int64_t filter_batch(int64_t n_items, int64_t nq) {
   const int64_t ld = (n_items + 31) / 32 * 32;
-  int64_t qb = (1ll << 28) / ld;  // <= 1 GiB of bounds per batch
+  int64_t qb = (1ll << 28) / ld;
   if (qb < 64) qb = 64;
-  if (qb > qv.nq) qb = qv.nq;
+  return qb > nq ? nq : qb;
+}
+
+int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
+  const int64_t ld = (n_items + 31) / 32 * 32;
   RSX_TRY(h->f_qimg.reserve(filter_qimg_bytes((int32_t)qb), s, false));
   RSX_TRY(h->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
   RSX_TRY(h->f_cand.reserve((size_t)qb * RESCORE_SHORTLIST_CAP * sizeof(RescoreEntry), s, false));
   RSX_TRY(h->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
   RSX_TRY(h->f_thr.reserve((size_t)qb * RESCORE_NUM_THR * sizeof(float), s, false));
+  return RSX_OK;
+}
+
+// images -> MFMA filter -> short list + round edges of one query batch
+int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig,
+                      int32_t first_target, hipStream_t s) {
+  const DbView db = db_view(h);
+  const int64_t ld = (n_items + 31) / 32 * 32;
+  float *lb = h->f_lb.as<float>();
+  RSX_TRY(launch_query_images(q.desc, q.norm, q.nq, h->f_qimg.p, s));
+  {
+    ProfScope ps(&h->prof, s);
+    RSX_TRY(launch_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, s));
+    ps.stop();
+  }
+  return launch_select(db, lb, ld, n_items, q.nq, n_eligible, elig, first_target, h->f_cand.as<RescoreEntry>(),
+                       h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), s);
+}
+
+int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig, int32_t round_begin,
+            int32_t round_end, const rsx_sc_hit *tau_src, const rsx_sc_hit *seed, int32_t k, rsx_sc_hit *d_out,
+            hipStream_t s) {
+  const int64_t ld = (n_items + 31) / 32 * 32;
+  return launch_rescore(db_view(h), q, h->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
+                        h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), filter_eps(), round_begin, round_end, tau_src,
+                        seed, d_out, k, s);
+}
+
+// exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> short list ->
+// exact re-scoring in rounds of ascending bound.  Everything stays on the stream; no host sync.
+int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
+                      int32_t k, rsx_sc_hit *d_out, hipStream_t s) {
+  const int64_t qb = filter_batch(n_items, qv.nq);
+  RSX_TRY(filter_reserve(h, n_items, qb, s));
   h->prof_kernel = filter_kernel_name();
   for (int64_t b0 = 0; b0 < qv.nq; b0 += qb) {
     const int32_t bn = (int32_t)((qv.nq - b0 < qb) ? (qv.nq - b0) : qb);
@@ -177,19 +222,8 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     q.norm = qv.norm + b0 * NS;
     q.nq = bn;
     const int64_t *elig = d_q_elig ? d_q_elig + b0 : nullptr;
-    float *lb = h->f_lb.as<float>();
-    RSX_TRY(launch_query_images(q.desc, q.norm, bn, h->f_qimg.p, s));
-    {
-      ProfScope ps(&h->prof, s);
-      RSX_TRY(launch_filter(db, h->f_qimg.p, bn, n_items, lb, ld, s));
-      ps.stop();
-    }
-    // short list (the <= 2048 smallest bounds) + round edges, then one workgroup per query scores it
-    // in rounds of ascending bound with tau tightening
-    RSX_TRY(launch_select(db, lb, ld, n_items, bn, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
-                          h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), s));
-    RSX_TRY(launch_rescore(db, q, lb, ld, n_items, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
-                           h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), filter_eps(), d_out + b0 * k, k, s));
+    RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, 64, s));
+    RSX_TRY(rescore(h, q, n_items, n_eligible, elig, 0, RESCORE_ALL_ROUNDS, nullptr, nullptr, k, d_out + b0 * k, s));
   }
   return RSX_OK;
 }
@@ -340,7 +374,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->st_partial}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
@@ -582,6 +616,58 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipMemcpyAsync(out, h->topk.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
+  return RSX_OK;
+}
+
+int rsx_sc_query_stage1_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible,
+                               rsx_sc_hit *d_partial, void *stream) {
+  if (!h || !d_q || !d_partial || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  h->st.valid = false;
+  QueryView qv;
+  RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
+  const int64_t items = local_count_below(h, n_eligible);
+  const int64_t n_elig = n_eligible < 0 ? h->n_global : n_eligible;
+  RSX_TRY(h->st_partial.reserve((size_t)nq * k * sizeof(rsx_sc_hit), s, false));
+  const bool filtered = use_filter(h, nq, items) && filter_batch(items, nq) >= nq;
+  if (filtered) {
+    // round 0 only: this shard's share of the ~64 lowest bounds per query
+    int32_t first = (64 + h->p.shard_world - 1) / h->p.shard_world;
+    if (first < 8) first = 8;
+    RSX_TRY(filter_reserve(h, items, nq, s));
+    h->prof_kernel = filter_kernel_name();
+    RSX_TRY(filter_and_select(h, qv, items, n_elig, nullptr, first, s));
+    RSX_TRY(rescore(h, qv, items, n_elig, nullptr, 0, 1, nullptr, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));
+  } else {
+    RSX_TRY(run_topk(h, qv, items, n_elig, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));  // complete already
+  }
+  RSX_HIP(hipMemcpyAsync(d_partial, h->st_partial.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToDevice, s));
+  h->st.valid = true;
+  h->st.filtered = filtered;
+  h->st.nq = nq;
+  h->st.k = k;
+  h->st.n_items = items;
+  h->st.n_eligible = n_elig;
+  h->st.qv = qv;
+  return RSX_OK;
+}
+
+int rsx_sc_query_stage2_device(rsx_sc *h, int32_t nq, int32_t k, const rsx_sc_hit *d_global, rsx_sc_hit *d_out,
+                               void *stream) {
+  if (!h || !d_global || !d_out) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->st.valid || h->st.nq != nq || h->st.k != k)
+    return fail(RSX_ERR_BAD_ARG, "stage 2 without a matching stage 1 (nq=%d k=%d)", nq, k);
+  RSX_TRY(set_device(h));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  h->st.valid = false;
+  if (h->st.filtered)
+    return rescore(h, h->st.qv, h->st.n_items, h->st.n_eligible, nullptr, 1, RESCORE_ALL_ROUNDS, d_global,
+                   h->st_partial.as<rsx_sc_hit>(), k, d_out, s);
+  RSX_HIP(hipMemcpyAsync(d_out, h->st_partial.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToDevice, s));
   return RSX_OK;
 }
 

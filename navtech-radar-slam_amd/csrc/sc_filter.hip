@@ -62,6 +62,7 @@ namespace {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned frag4 __attribute__((ext_vector_type(4)));  // one MFMA A fragment in flight (8 x fp16)
 typedef unsigned long long u64;
 
 #define AS1 __attribute__((address_space(1)))
@@ -259,17 +260,17 @@ __device__ __forceinline__ void static_for(F &&f) {
 // reads are outstanding".  (Left to the compiler the waits degrade to lgkmcnt(0) after every few
 // reads, which parks the wave for a full LDS round trip ~40 times per query.)  The wait takes the
 // fragment as an in/out operand so that the consuming MFMA cannot be scheduled above it.
-__device__ __forceinline__ void lds_read_frag(half8 &dst, unsigned addr, int off) {
+__device__ __forceinline__ void lds_read_frag(frag4 &dst, unsigned addr, int off) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
 }
 template <int N>
-__device__ __forceinline__ void lds_wait_frag(half8 &frag) {
+__device__ __forceinline__ void lds_wait_frag(frag4 &frag) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
 }
 
 // the first F_DEPTH fragments of a query (issued before its stage: by the previous stage's tail, or
 // explicitly at the start of an LDS phase)
-__device__ __forceinline__ void ring_prologue(half8 (&ring)[F_DEPTH], unsigned ap_lds) {
+__device__ __forceinline__ void ring_prologue(frag4 (&ring)[F_DEPTH], unsigned ap_lds) {
   static_for<F_DEPTH>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     lds_read_frag(ring[t], ap_lds, 32 * t);
@@ -293,7 +294,7 @@ constexpr int piece_at(int t) {
 // last F_DEPTH steps read the first fragments at next_lds), so MFMAs issue back to back across
 // queries.  `e` carries the running maxima of the query whose tile 0 is done into the next stage.
 template <bool DO_MFMA, bool DO_PREV, typename Fin>
-__device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds, half8 (&ring)[F_DEPTH],
+__device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds, frag4 (&ring)[F_DEPTH],
                                              const half8 (&B)[F_STEPS], floatx16 &acc0, floatx16 &acc1, Epi &e,
                                              u64 cur_mask, unsigned m2lo, unsigned m2hi, int hh, Fin &&fin) {
   static_for<F_T>([&](auto tc) {
@@ -301,7 +302,7 @@ __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds,
     if constexpr (DO_MFMA) {
       // younger reads than fragment t: always F_DEPTH - 1 (the tail reads of the next query included)
       lds_wait_frag<F_DEPTH - 1>(ring[t % F_DEPTH]);
-      const half8 af = ring[t % F_DEPTH];
+      const half8 af = __builtin_bit_cast(half8, ring[t % F_DEPTH]);
       if constexpr (t == 0) {
         floatx16 z;
 #pragma unroll
@@ -332,6 +333,15 @@ __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds,
       if constexpr (i >= 0) epi_piece<0, i>(e, acc0[i], m2lo, m2hi, hh);
     }
   });
+  // The ring now holds the next query's first fragments, still in flight.  They must have landed
+  // before control leaves this straight-line block: at a loop edge the compiler is free to copy the
+  // ring registers, and a copy of a register whose LDS data has not arrived yet reads garbage.
+  if constexpr (DO_MFMA) {
+    static_for<F_DEPTH>([&](auto tc) {
+      constexpr int i = decltype(tc)::value;
+      lds_wait_frag<0>(ring[i]);
+    });
+  }
 }
 
 constexpr int QIMG_MASK_OFF = QIMG_EVEN_CHUNKS * 16;  // 4928
@@ -391,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
     __syncthreads();
 
     floatx16 acc0, acc1;
-    half8 ring[F_DEPTH];
+    frag4 ring[F_DEPTH];
     Epi e;
     int prev_q = -1;
     u64 prev_mask = 0;
@@ -414,6 +424,10 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
       if (tile_ok) {
         const unsigned phase_lds = lds_base + (unsigned)((p & 1) * F_PHASE_BYTES + aoff);
         ring_prologue(ring, phase_lds);
+        static_for<F_DEPTH>([&](auto tc) {
+          constexpr int i = decltype(tc)::value;
+          lds_wait_frag<0>(ring[i]);
+        });
         for (int qq = 0; qq < nq_here; qq++) {
           const unsigned ap_lds = phase_lds + (unsigned)(qq * FILTER_QIMG_BYTES);
           const unsigned next_lds = (qq + 1 < nq_here) ? ap_lds + FILTER_QIMG_BYTES : ap_lds;
@@ -423,9 +437,6 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
           prev_q = qp + qq;
           prev_mask = cur_mask;
         }
-        // the last stage of the phase refilled the ring with fragments nobody will use: drain them
-        // before the buffer can be overwritten by the DMA of phase p + 2
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
@@ -475,7 +486,8 @@ __device__ __forceinline__ float bin_edge(int b) {  // upper edge of bin b as a 
 }
 
 __global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items_all,
-                                                        Elig el, RescoreEntry *__restrict__ slist,
+                                                        Elig el, int32_t first_target,
+                                                        RescoreEntry *__restrict__ slist,
                                                         int32_t *__restrict__ sl_cnt, float *__restrict__ thr) {
   __shared__ int hist[H_BINS];
   __shared__ int wsum[4];
@@ -529,10 +541,9 @@ __global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict_
   __syncthreads();
   const int b_cap = s_bcap;
   if (threadIdx.x < RESCORE_NUM_THR) {
-    const int targets[RESCORE_NUM_THR - 1] = {64, 128, 256, 512, 1024};
     int b = b_cap;
     if (threadIdx.x < RESCORE_NUM_THR - 1) {
-      b = first_reaching(targets[threadIdx.x]);
+      b = first_reaching(first_target << threadIdx.x);
       if (b > H_BINS - 1) b = H_BINS - 1;
       if (b > b_cap) b = b_cap;
     }
@@ -625,10 +636,12 @@ int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_item
 }
 
 int launch_select(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
-                  const int64_t *q_elig, RescoreEntry *slist, int32_t *sl_cnt, float *thr, hipStream_t s) {
+                  const int64_t *q_elig, int32_t first_target, RescoreEntry *slist, int32_t *sl_cnt, float *thr,
+                  hipStream_t s) {
   if (nq <= 0) return RSX_OK;
+  if (first_target < 1 || first_target > 128) return fail(RSX_ERR_INTERNAL, "bad first_target");
   const Elig el{db.idx_base, db.idx_stride, n_eligible < 0 ? INT64_MAX : n_eligible, q_elig};
-  hipLaunchKernelGGL(sc_select_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, el, slist, sl_cnt, thr);
+  hipLaunchKernelGGL(sc_select_kernel, dim3(nq), dim3(256), 0, s, lb, ld_lb, n_items, el, first_target, slist, sl_cnt, thr);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

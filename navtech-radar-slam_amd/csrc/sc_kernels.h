@@ -75,13 +75,20 @@ struct RescoreEntry {
 };
 // short list of every query: the eligible entries with bound < t_cap, where t_cap is the largest
 // histogram-bin edge with at most RESCORE_SHORTLIST_CAP bounds below it (+inf when all fit, -inf
-// when not even the first bin fits), and the round edges (targets 64, 128, 256, 512, 1024 bounds)
+// when not even the first bin fits), and the round edges (first_target << r bounds, r = 0..4)
+// first_target: bounds in round 0; round r covers first_target << r
 int launch_select(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
-                  const int64_t *q_elig, RescoreEntry *slist, int32_t *sl_cnt, float *thr, hipStream_t s);
-// one workgroup per query: rounds of ascending bound with tau tightening; writes the final top-k
+                  const int64_t *q_elig, int32_t first_target, RescoreEntry *slist, int32_t *sl_cnt, float *thr,
+                  hipStream_t s);
+// one workgroup per query: rounds [round_begin, round_end) of ascending bound with tau tightening
+// (round_end = RESCORE_ALL_ROUNDS: also the entries beyond the short list); writes the top-k it knows.
+// tau_src (optional): a top-k that covers more than this shard -- its k-th distance caps tau;
+// seed (optional): this shard's hits from an earlier stage, merged into the output.
+constexpr int RESCORE_ALL_ROUNDS = RESCORE_NUM_THR + 1;
 int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
                    int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
-                   const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s);
+                   const float *thr, double eps, int32_t round_begin, int32_t round_end, const rsx_sc_hit *tau_src,
+                   const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s);
 
 // ---- MFMA lower-bound filter (sc_filter.hip) ----
 constexpr int FILTER_QIMG_BYTES = 9984;  // LDS image of one query (two displaced fp16 copies)

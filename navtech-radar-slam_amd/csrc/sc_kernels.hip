@@ -629,8 +629,11 @@ struct RescoreArgs {
   const int32_t *sl_cnt;      // [nq]
   const float *thr;           // [nq][RESCORE_NUM_THR]: round edges t_0 <= t_1 <= ... ; the last one is t_cap
   rsx_sc_hit *out;            // [nq][k]
+  const rsx_sc_hit *tau_src;  // optional [nq][k]: a top-k over MORE than this shard (its k-th distance bounds tau)
+  const rsx_sc_hit *seed;     // optional [nq][k]: hits this shard already found in an earlier stage
   double eps;
   int32_t k;
+  int32_t round_begin, round_end;  // rounds [begin, end) of the short list; end > RESCORE_NUM_THR: also the rest
 };
 
 // k-th smallest valid record (by (dist, index)) of the nrec records in xch, found by k rounds of
@@ -711,7 +714,20 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
 
   double ld = INFINITY;  // per-wave sorted top-k, one record per lane; lives across rounds
   int li = 0x7fffffff, ls = 0;
-  double tau = INFINITY;
+  // tau never exceeds the k-th distance of a top-k that covers more than this shard (multi-GPU
+  // stage 2): any upper bound of the global k-th best distance prunes correctly
+  double tau_init = INFINITY;
+  if (a.tau_src) {
+    const double d = a.tau_src[(int64_t)qi * a.k + (a.k - 1)].dist;
+    if (d < kBig) tau_init = d;
+  }
+  double tau = tau_init;
+  if (a.seed && wave == 0 && lane < a.k) {  // sorted, padded {1e7,0,0} at the end
+    const rsx_sc_hit h = a.seed[(int64_t)qi * a.k + lane];
+    if (h.dist < kBig) {
+      ld = h.dist; li = h.index; ls = h.shift;
+    }
+  }
 
   // score cand[0..ncand) (all waves), then refresh tau
   auto score_and_merge = [&](int ncand) {
@@ -746,7 +762,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
     if (wave == 0) {
       const double t = wave_select_kth(xch, RS_WAVES * a.k, a.k, lane, nullptr);
       if (lane == 0) {
-        *s_tau = t;
+        *s_tau = t < tau_init ? t : tau_init;
         *s_ncand = 0;
       }
     }
@@ -768,11 +784,16 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   const RescoreEntry *sl = a.slist + (int64_t)qi * RS_CAND_CAP;
   const float *thr = a.thr + (int64_t)qi * RESCORE_NUM_THR;
   const float t_cap = thr[RESCORE_NUM_THR - 1];
-  float lo = -INFINITY;
+  float lo = a.round_begin > 0 ? thr[a.round_begin - 1] : -INFINITY;
   bool done = false;
-  for (int r = 0; r < RESCORE_NUM_THR; r++) {
+  const int r_end = a.round_end < RESCORE_NUM_THR ? a.round_end : RESCORE_NUM_THR;
+  for (int r = a.round_begin; r < r_end; r++) {
     const float hi = thr[r];
     if (!(lo < hi)) continue;  // empty range (uniform)
+    if ((double)lo - a.eps > tau) {  // (stage 2: the global tau may already exclude everything left)
+      done = true;
+      break;
+    }
     for (int i = threadIdx.x; i < sl_cnt; i += RS_WAVES * 64) {  // sl_cnt <= 2048: at most 2 trips
       const RescoreEntry e = sl[i];
       // the first non-empty round also owns NaN / -inf bounds ("always re-score")
@@ -790,7 +811,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   }
 
   // ---- entries beyond the short list (bound >= t_cap), only while tau admits them ----
-  if (!done && t_cap < INFINITY) {
+  if (!done && a.round_end > RESCORE_NUM_THR && t_cap < INFINITY && !((double)t_cap - a.eps > tau)) {
     const float *row = a.lb + (int64_t)qi * a.ld_lb;
     const bool take_all = (t_cap == -INFINITY);  // empty short list: NaN bounds are here too
     int64_t pos = 0;
@@ -815,7 +836,14 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
     }
   }
 
-  // ---- output: final top-k ----
+  // ---- output: top-k of everything this workgroup knows (its lists as of the last merge; when no
+  //      round ran, the lists still have to be published) ----
+  if (lane < a.k) {
+    rsx_sc_hit h;
+    h.dist = ld; h.index = li; h.shift = ls;
+    xch[wave * a.k + lane] = h;
+  }
+  __syncthreads();
   if (wave == 0) wave_select_kth(xch, RS_WAVES * a.k, a.k, lane, a.out + (int64_t)qi * a.k);
 }
 
@@ -964,7 +992,8 @@ static int launch_rescore_t(const RescoreArgs &a, hipStream_t s) {
 
 int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
                    int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
-                   const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s) {
+                   const float *thr, double eps, int32_t round_begin, int32_t round_end, const rsx_sc_hit *tau_src,
+                   const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s) {
   if (q.nq <= 0) return RSX_OK;
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
   // workgroup shape (entries per wave iteration, waves, waves/SIMD); RSX_SC_RESCORE_VARIANT picks one:
@@ -985,8 +1014,12 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
   a.sl_cnt = sl_cnt;
   a.thr = thr;
   a.out = d_out;
+  a.tau_src = tau_src;
+  a.seed = seed;
   a.eps = eps;
   a.k = k;
+  a.round_begin = round_begin;
+  a.round_end = round_end;
   switch (variant) {
     case 1: RSX_TRY((launch_rescore_t<1, 16, 4>(a, s))); break;
     case 2: RSX_TRY((launch_rescore_t<2, 12, 3>(a, s))); break;

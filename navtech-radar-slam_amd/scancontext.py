@@ -150,6 +150,12 @@ class SCManager:
     def query_device(self, q_ptr, nq, k, out_ptr, n_eligible=-1, stream=0):
         check(self._L.rsx_sc_query_device(self._h, q_ptr, nq, k, n_eligible, out_ptr, stream))
 
+    def query_stage1_device(self, q_ptr, nq, k, partial_ptr, n_eligible=-1, stream=0):
+        check(self._L.rsx_sc_query_stage1_device(self._h, q_ptr, nq, k, n_eligible, partial_ptr, stream))
+
+    def query_stage2_device(self, nq, k, global_ptr, out_ptr, stream=0):
+        check(self._L.rsx_sc_query_stage2_device(self._h, nq, k, global_ptr, out_ptr, stream))
+
     def query_self_device(self, q_first, nq, k, out_ptr, n_eligible=-1, exclude_recent=-1, stream=0):
         check(self._L.rsx_sc_query_self_device(self._h, q_first, nq, k, n_eligible, exclude_recent, out_ptr, stream))
 

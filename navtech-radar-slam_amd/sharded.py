@@ -1,15 +1,21 @@
 """ScanContext database sharded over the ranks of a torch.distributed process group.
 
 Keyframe i lives on rank i % world (block-cyclic, so a growing DB stays balanced).  A query runs
-on every rank against its shard (HIP kernels through librsx.so), the per-rank top-k lists
-(16-byte rsx_sc_hit records) are exchanged with ONE all-gather -- RCCL over xGMI when the group's
-backend is "nccl" -- and merged under the total order (dist, global index), which reproduces the
-sequential lowest-index-wins scan of the reference exactly.  The message is tiny (nq * k * 16 B per
-rank): the exchange is latency-bound, so queries are batched.
+on every rank against its shard (HIP kernels through librsx.so) in two stages with one all-gather
+each -- RCCL over xGMI when the group's backend is "nccl":
+  stage 1  MFMA filter over the shard + exact scores of the shard's share of the lowest-bound
+           entries; all-gather of the per-rank top-k lists (16-byte rsx_sc_hit records), merge:
+           the k-th distance of the merged list is a GLOBAL upper bound tau of the final k-th best;
+  stage 2  every shard scores only what its filter bounds still admit under tau (instead of under
+           its own, much looser, local k-th best); all-gather + merge of the final per-rank lists.
+The merge is under the total order (dist, global index), which reproduces the sequential
+lowest-index-wins scan of the reference exactly.  Messages are tiny (nq * k * 16 B per rank): the
+exchanges are latency-bound, so queries are batched.
 
 `local_backend` is a seam for the CPU (gloo) tests, which have no GPU: anything with
-add_descriptors_f32(descs) and query(q, k, n_eligible) -> (nq, k) HIT_DTYPE records.  The default
-is the GPU SCManager; there is no CPU fallback in the product path.
+add_descriptors_f32(descs), query_stage1(q, k, n_eligible) and query_stage2(global_topk), both
+-> (nq, k) HIT_DTYPE records.  The default is the GPU SCManager; there is no CPU fallback in the
+product path.
 """
 import numpy as np
 
@@ -53,17 +59,43 @@ class ShardedScanContext:
             self._bufs[name] = t
         return t
 
-    def query_device(self, q_ptr, nq, k, n_eligible=-1, stream=0):
-        """GPU path: device query pointer in, device tensor (nq, k, 2) f64 = rsx_sc_hit records out."""
-        local = self._buf("local", (nq, k, 2))
-        self.backend.query_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream)
-        if self.world == 1:
-            return local
-        parts = self._buf("parts", (self.world, nq, k, 2))
+    def _gather_merge(self, local, name, nq, k, stream):
+        parts = self._buf(name + "_parts", (self.world, nq, k, 2))
         self._dist.all_gather_into_tensor(parts.view(-1), local.view(-1), group=self.group)
-        out = self._buf("out", (nq, k, 2))
+        out = self._buf(name + "_merged", (nq, k, 2))
         self.backend.merge_device(parts.data_ptr(), self.world, nq, k, out.data_ptr(), stream=stream)
         return out
+
+    def query_device(self, q_ptr, nq, k, n_eligible=-1, stream=0):
+        """GPU path: device query pointer in, device tensor (nq, k, 2) f64 = rsx_sc_hit records out.
+        `stream` must be the (non-default) torch stream current on this device: the library launches on
+        it and the collectives run on it too.  stream=0 would make librsx use the handle's private
+        stream, unordered with torch's -- then everything runs on an own side stream instead."""
+        if stream == 0:
+            torch = self._torch
+            if getattr(self, "_side", None) is None:
+                self._side = torch.cuda.Stream(device=self.device)
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                out = self.query_device(q_ptr, nq, k, n_eligible, stream=self._side.cuda_stream)
+            torch.cuda.current_stream(self.device).wait_stream(self._side)
+            return out
+        local = self._buf("local", (nq, k, 2))
+        if self.world == 1:
+            self.backend.query_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream)
+            return local
+        self.backend.query_stage1_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream)
+        bound = self._gather_merge(local, "s1", nq, k, stream)
+        final = self._buf("final", (nq, k, 2))
+        self.backend.query_stage2_device(nq, k, bound.data_ptr(), final.data_ptr(), stream=stream)
+        return self._gather_merge(final, "s2", nq, k, stream)
+
+    def _gather_merge_host(self, local, nq, k):
+        torch = self._torch
+        lt = torch.from_numpy(np.ascontiguousarray(local, dtype=HIT_DTYPE).view(np.float64).reshape(-1).copy())
+        parts = torch.zeros(self.world * lt.numel(), dtype=torch.float64)
+        self._dist.all_gather_into_tensor(parts, lt, group=self.group)
+        return scancontext.merge_topk(parts.numpy().view(HIT_DTYPE).reshape(self.world, nq, k))
 
     def query(self, q_descs, k=1, n_eligible=-1):
         """Host-array convenience form -> (nq, k) HIT_DTYPE, identical on every rank."""
@@ -76,10 +108,9 @@ class ShardedScanContext:
             out = self.query_device(dq.data_ptr(), nq, k, n_eligible, stream=s)
             torch.cuda.synchronize()
             return out.cpu().numpy().view(HIT_DTYPE).reshape(nq, k)
-        local = np.ascontiguousarray(self.backend.query(q, k, n_eligible), dtype=HIT_DTYPE)
+        part = np.ascontiguousarray(self.backend.query_stage1(q, k, n_eligible), dtype=HIT_DTYPE)
         if self.world == 1:
-            return local
-        lt = torch.from_numpy(local.view(np.float64).reshape(-1).copy())
-        parts = torch.zeros(self.world * lt.numel(), dtype=torch.float64)
-        self._dist.all_gather_into_tensor(parts, lt, group=self.group)
-        return scancontext.merge_topk(parts.numpy().view(HIT_DTYPE).reshape(self.world, nq, k))
+            return np.ascontiguousarray(self.backend.query_stage2(part), dtype=HIT_DTYPE)
+        bound = self._gather_merge_host(part, nq, k)
+        final = self.backend.query_stage2(bound)
+        return self._gather_merge_host(final, nq, k)

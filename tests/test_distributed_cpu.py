@@ -1,7 +1,8 @@
 """world_size-2/3 `gloo` tests of the sharded ScanContext query (N > 1 path) on CPU.
 
 There is no GPU here, so each rank's LOCAL search is done by the oracle (allowed in tests); what
-is under test is the product's distributed logic: block-cyclic ownership, the single all-gather of
+is under test is the product's distributed logic: block-cyclic ownership, the two-stage protocol
+(stage-1 lists -> all-gather -> merge -> global bound tau -> stage 2 -> all-gather -> merge) with
 16-byte records through torch.distributed, and librsx's host merge under the (dist, index) order.
 The merged result must equal the unsharded oracle bit for bit on every rank."""
 import os
@@ -30,17 +31,33 @@ class OracleShard:
                 self.m.add_descriptor(d.astype(np.float64))
             self.n_global += 1
 
-    def query(self, q, k, n_eligible):
+    def _search(self, q, k, n_eligible, subset_mod=None, tau=None):
+        """Exact local top-k; subset_mod: only local slots s with s % 3 == 0 (a stage-1 stand-in);
+        tau (per query): drop hits a global bound already excludes (what stage 2 may skip)."""
         if n_eligible < 0:
             n_eligible = self.n_global
         n_local_elig = len(range(self.rank, min(n_eligible, self.n_global), self.world))
         out = np.zeros((q.shape[0], k), dtype=self.o.HIT_DTYPE)
         for i in range(q.shape[0]):
-            r = self.m.exhaustive(q[i].astype(np.float64), n_eligible=n_local_elig, k=k)
-            real = r["dist"] < 1e7
-            r["index"][real] = r["index"][real] * self.world + self.rank
-            out[i] = r
+            r = self.m.exhaustive(q[i].astype(np.float64), n_eligible=n_local_elig, k=max(k, n_local_elig))
+            keep = r["dist"] < 1e7
+            if subset_mod is not None:
+                keep &= (r["index"] % subset_mod) == 0
+            if tau is not None:
+                keep &= r["dist"] <= tau[i]
+            r = r[keep][:k]
+            r["index"] = r["index"] * self.world + self.rank
+            out[i]["dist"] = 1e7
+            out[i][:len(r)] = r
         return out
+
+    def query_stage1(self, q, k, n_eligible):
+        self._q, self._k, self._ne = q, k, n_eligible
+        return self._search(q, k, n_eligible, subset_mod=3)
+
+    def query_stage2(self, global_topk):
+        kth = np.where(global_topk["dist"][:, -1] < 1e7, global_topk["dist"][:, -1], np.inf)
+        return self._search(self._q, self._k, self._ne, tau=kth)
 
 
 def _worker(rank, world, port, ret):

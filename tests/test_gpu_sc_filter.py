@@ -209,3 +209,56 @@ def test_filtered_sharded_equals_unsharded(sc, oracle):
     torch.cuda.synchronize()
     host_parts = parts.cpu().numpy().view(sc.HIT_DTYPE).reshape(world, nq, k)
     assert np.array_equal(sc.merge_topk(host_parts), want)
+
+
+@pytest.mark.parametrize("world,mode", [(2, FORCE), (8, FORCE), (3, OFF)])
+def test_two_stage_sharded_query(sc, oracle, world, mode):
+    """The multi-GPU protocol on one device: stage 1 per shard -> merge -> global bound -> stage 2 per
+    shard -> merge must give exactly the unsharded top-k (what sharded.ShardedScanContext does with
+    RCCL all-gathers between the stages)."""
+    import torch
+    n, nq, k = 6000 + 7, 48, 10
+    descs = make_db(31, n, binary=True)
+    rng = np.random.default_rng(5)
+    queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+    queries[::3, rng.integers(0, 1200, 40)] = 0
+    queries[2] = 0
+    full = sc.SCManager(filter_mode=OFF)
+    full.add_descriptors_f32(descs)
+    want = full.query(queries, k=k, n_eligible=n - 30)
+    shards = [sc.SCManager(shard_rank=r, shard_world=world, filter_mode=mode) for r in range(world)]
+    for s in shards:
+        s.add_descriptors_f32(descs)
+    # ONE explicit stream for every handle (stream 0 would select each handle's private stream and the
+    # shards' stages would be unordered with the merges)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    st = tstream.cuda_stream
+    dq = torch.from_numpy(queries).cuda()
+    parts = torch.zeros((world, nq, k, 2), dtype=torch.float64, device="cuda")
+    glob = torch.zeros((nq, k, 2), dtype=torch.float64, device="cuda")
+    for r, s in enumerate(shards):
+        s.query_stage1_device(dq.data_ptr(), nq, k, parts[r].data_ptr(), n_eligible=n - 30, stream=st)
+    shards[0].merge_device(parts.data_ptr(), world, nq, k, glob.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    stage1 = glob.cpu().numpy().view(sc.HIT_DTYPE).reshape(nq, k)
+    # the stage-1 bound is a valid upper bound of the final k-th best distance
+    assert np.all(stage1["dist"][:, -1] >= want["dist"][:, -1])
+    finals = torch.zeros((world, nq, k, 2), dtype=torch.float64, device="cuda")
+    for r, s in enumerate(shards):
+        s.query_stage2_device(nq, k, glob.data_ptr(), finals[r].data_ptr(), stream=st)
+    out = torch.zeros((nq, k, 2), dtype=torch.float64, device="cuda")
+    shards[0].merge_device(finals.data_ptr(), world, nq, k, out.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(sc.HIT_DTYPE).reshape(nq, k)
+    assert np.array_equal(got, want)
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    for qi in (0, 2, 47):
+        assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=4))
+    # stage 2 without stage 1 is an error, not a silent wrong answer
+    from navtech_radar_slam_amd._rsx import RsxError
+    with pytest.raises(RsxError):
+        shards[0].query_stage2_device(nq, k, glob.data_ptr(), finals[0].data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
