@@ -76,7 +76,7 @@ constexpr int QIMG_EVEN_CHUNKS = 308;  // 2464 elements
 constexpr int QIMG_GAP_CHUNKS = 2;
 constexpr int QIMG_CHUNKS = FILTER_QIMG_BYTES / 16;  // 624
 constexpr int F_QPP = 4;          // queries per LDS phase
-constexpr int F_DEPTH = 5;        // A fragments in flight; divides F_T so the ring carries over from query to query
+constexpr int F_DEPTH = 5;        // A fragments in flight
 constexpr int F_B_VGPR = 44;      // B fragments kept in VGPRs; the rest live in AGPRs
 constexpr int F_PHASE_BYTES = F_QPP * FILTER_QIMG_BYTES;  // 39936 = 39 KiB
 constexpr double kImgScale = 32768.0;                 // 2^15 on both operands
@@ -84,7 +84,6 @@ constexpr float kAccScale = 1073741824.0f;            // 2^30 carried by the acc
 constexpr u64 kNonFinite = 1ull << 63;
 
 static_assert(FILTER_QIMG_BYTES == 9984, "layout");
-static_assert(F_T % F_DEPTH == 0, "ring slot of fragment j of the next query must be j % F_DEPTH");
 static_assert(F_PHASE_BYTES % 1024 == 0, "phase must be whole 1 KiB DMA pieces");
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -268,12 +267,32 @@ __device__ __forceinline__ void lds_wait_frag(frag4 &frag) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
 }
 
-// the first F_DEPTH fragments of a query (issued before its stage: by the previous stage's tail, or
-// explicitly at the start of an LDS phase)
-__device__ __forceinline__ void ring_prologue(frag4 (&ring)[F_DEPTH], unsigned ap_lds) {
+// Fragment schedule of one stage (all reads are asynchronous; LDS returns them in issue order):
+//   fragments 0..F_DEPTH-1      come from `first[]`, read by the PREVIOUS stage at its steps
+//                                F_PRE..F_PRE+F_DEPTH-1 (or by first_prologue at the start of a phase)
+//   fragment  t >= F_DEPTH       is read into ring[t % F_DEPTH] right after the MFMAs of step t-F_DEPTH
+// so nothing is in flight when a stage ends: the ring is consumed and `first` (read >= 15 steps before
+// the end) has landed -- the compiler may copy those registers at the loop edge.
+constexpr int F_PRE = 95;  // first step that prefetches the next query's first fragments
+
+// reads issued after fragment t's own read and before the wait of step t (t >= F_DEPTH)
+constexpr int younger_reads(int t) {
+  int n = 0;
+  for (int s = t - F_DEPTH; s < t; s++) {
+    if (s > t - F_DEPTH && s + F_DEPTH < F_T) n++;          // ring read of step s (younger than ours)
+    if (s >= F_PRE && s < F_PRE + F_DEPTH) n++;              // prefetch read of step s (issued after the ring read)
+  }
+  return n;
+}
+
+__device__ __forceinline__ void first_prologue(frag4 (&first)[F_DEPTH], unsigned ap_lds) {
   static_for<F_DEPTH>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
-    lds_read_frag(ring[t], ap_lds, 32 * t);
+    lds_read_frag(first[t], ap_lds, 32 * t);
+  });
+  static_for<F_DEPTH>([&](auto tc) {
+    constexpr int i = decltype(tc)::value;
+    lds_wait_frag<0>(first[i]);
   });
 }
 
@@ -290,19 +309,25 @@ constexpr int piece_at(int t) {
 //   steps   0..39   epilogue of the PREVIOUS query's tile 1 (acc1 still holds it), then `fin`
 //   steps  40..74   two MFMAs per step, nothing else
 //   steps  75..114  epilogue of THIS query's tile 0 (acc0 is complete)
-// No accumulator is ever copied, and the ring of A fragments carries over from query to query (the
-// last F_DEPTH steps read the first fragments at next_lds), so MFMAs issue back to back across
-// queries.  `e` carries the running maxima of the query whose tile 0 is done into the next stage.
+// No accumulator is ever copied, and the first fragments of the next query (at next_lds: the next
+// query of the LDS phase, or any valid image when there is none) are prefetched, so MFMAs issue back
+// to back across queries.  `e` carries the running maxima of the query whose tile 0 is done into
+// the next stage.
 template <bool DO_MFMA, bool DO_PREV, typename Fin>
-__device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds, frag4 (&ring)[F_DEPTH],
+__device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds, frag4 (&first)[F_DEPTH],
                                              const half8 (&B)[F_STEPS], floatx16 &acc0, floatx16 &acc1, Epi &e,
                                              u64 cur_mask, unsigned m2lo, unsigned m2hi, int hh, Fin &&fin) {
+  frag4 ring[F_DEPTH];
   static_for<F_T>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     if constexpr (DO_MFMA) {
-      // younger reads than fragment t: always F_DEPTH - 1 (the tail reads of the next query included)
-      lds_wait_frag<F_DEPTH - 1>(ring[t % F_DEPTH]);
-      const half8 af = __builtin_bit_cast(half8, ring[t % F_DEPTH]);
+      half8 af;
+      if constexpr (t < F_DEPTH) {
+        af = __builtin_bit_cast(half8, first[t]);
+      } else {
+        lds_wait_frag<younger_reads(t)>(ring[t % F_DEPTH]);
+        af = __builtin_bit_cast(half8, ring[t % F_DEPTH]);
+      }
       if constexpr (t == 0) {
         floatx16 z;
 #pragma unroll
@@ -320,7 +345,7 @@ __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds,
         acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, B[t - F_TILE1], acc1, 0, 0, 0);
       }
       if constexpr (t + F_DEPTH < F_T) lds_read_frag(ring[t % F_DEPTH], ap_lds, 32 * (t + F_DEPTH));
-      else lds_read_frag(ring[t % F_DEPTH], next_lds, 32 * (t + F_DEPTH - F_T));
+      if constexpr (t >= F_PRE && t < F_PRE + F_DEPTH) lds_read_frag(first[t - F_PRE], next_lds, 32 * (t - F_PRE));
     }
     if constexpr (DO_PREV && t < F_TILE1) {
       constexpr int i = piece_at(t);
@@ -333,15 +358,6 @@ __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds,
       if constexpr (i >= 0) epi_piece<0, i>(e, acc0[i], m2lo, m2hi, hh);
     }
   });
-  // The ring now holds the next query's first fragments, still in flight.  They must have landed
-  // before control leaves this straight-line block: at a loop edge the compiler is free to copy the
-  // ring registers, and a copy of a register whose LDS data has not arrived yet reads garbage.
-  if constexpr (DO_MFMA) {
-    static_for<F_DEPTH>([&](auto tc) {
-      constexpr int i = decltype(tc)::value;
-      lds_wait_frag<0>(ring[i]);
-    });
-  }
 }
 
 constexpr int QIMG_MASK_OFF = QIMG_EVEN_CHUNKS * 16;  // 4928
@@ -401,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
     __syncthreads();
 
     floatx16 acc0, acc1;
-    frag4 ring[F_DEPTH];
+    frag4 first[F_DEPTH];  // fragments 0..F_DEPTH-1 of the query about to be processed (landed)
     Epi e;
     int prev_q = -1;
     u64 prev_mask = 0;
@@ -423,17 +439,13 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
       const int nq_here = (q1 - qp < F_QPP) ? (q1 - qp) : F_QPP;
       if (tile_ok) {
         const unsigned phase_lds = lds_base + (unsigned)((p & 1) * F_PHASE_BYTES + aoff);
-        ring_prologue(ring, phase_lds);
-        static_for<F_DEPTH>([&](auto tc) {
-          constexpr int i = decltype(tc)::value;
-          lds_wait_frag<0>(ring[i]);
-        });
+        first_prologue(first, phase_lds);
         for (int qq = 0; qq < nq_here; qq++) {
           const unsigned ap_lds = phase_lds + (unsigned)(qq * FILTER_QIMG_BYTES);
           const unsigned next_lds = (qq + 1 < nq_here) ? ap_lds + FILTER_QIMG_BYTES : ap_lds;
           const u64 cur_mask = *reinterpret_cast<const u64 *>(smem + (p & 1) * F_PHASE_BYTES + qq * FILTER_QIMG_BYTES + QIMG_MASK_OFF);
-          if (prev_q < 0) filter_stage<true, false>(ap_lds, next_lds, ring, B, acc0, acc1, e, cur_mask, m2lo, m2hi, hh, fin);
-          else filter_stage<true, true>(ap_lds, next_lds, ring, B, acc0, acc1, e, cur_mask, m2lo, m2hi, hh, fin);
+          if (prev_q < 0) filter_stage<true, false>(ap_lds, next_lds, first, B, acc0, acc1, e, cur_mask, m2lo, m2hi, hh, fin);
+          else filter_stage<true, true>(ap_lds, next_lds, first, B, acc0, acc1, e, cur_mask, m2lo, m2hi, hh, fin);
           prev_q = qp + qq;
           prev_mask = cur_mask;
         }
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    if (prev_q >= 0) filter_stage<false, true>(0u, 0u, ring, B, acc0, acc1, e, 0ull, m2lo, m2hi, hh, fin);
+    if (prev_q >= 0) filter_stage<false, true>(0u, 0u, first, B, acc0, acc1, e, 0ull, m2lo, m2hi, hh, fin);
   }
 }
 
