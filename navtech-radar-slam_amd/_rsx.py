@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librsx.so")
+LIB_PATH = os.environ.get("RSX_LIB_PATH") or os.path.join(_HERE, "librsx.so")  # override: kernel experiments
 
 NUM_RING, NUM_SECTOR, DESC_SIZE, MAX_TOPK = 20, 60, 1200, 32
 MODE_CANDIDATE, MODE_EXHAUSTIVE = 0, 1

@@ -266,6 +266,13 @@ template <int N>
 __device__ __forceinline__ void lds_wait_frag(frag4 &frag) {
   asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
 }
+// the same without operands (the "+v" form makes the compiler treat the fragment as freshly written
+// by a VALU instruction and pad every MFMA with an s_nop): the caller orders it against the consuming
+// MFMA with __builtin_amdgcn_sched_barrier(0) on both sides
+template <int N>
+__device__ __forceinline__ void lds_wait_count() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
 
 // Fragment schedule of one stage (all reads are asynchronous; LDS returns them in issue order):
 //   fragments 0..F_DEPTH-1      come from `first[]`, read by the PREVIOUS stage at its steps
@@ -296,7 +303,7 @@ __device__ __forceinline__ void first_prologue(frag4 (&first)[F_DEPTH], unsigned
   });
 }
 
-// which epilogue piece (0..15) is issued at step t of its 40-step window (-1: none)
+// which accumulator register (0..15) is read out at step t of its 40-step idle window (-1: none)
 constexpr int piece_at(int t) {
   for (int i = 0; i < 16; i++)
     if ((i * 5) / 2 == t) return i;
@@ -305,19 +312,23 @@ constexpr int piece_at(int t) {
 
 // One software-pipeline stage = one query.  Tile 0 (shifts 0..31, acc0) accumulates during steps
 // 0..74 and tile 1 (shifts 32..63, acc1) during steps 40..114, so each accumulator is idle for 40
-// steps per query and the epilogue reads it in place during exactly that window:
-//   steps   0..39   epilogue of the PREVIOUS query's tile 1 (acc1 still holds it), then `fin`
-//   steps  40..74   two MFMAs per step, nothing else
-//   steps  75..114  epilogue of THIS query's tile 0 (acc0 is complete)
-// No accumulator is ever copied, and the first fragments of the next query (at next_lds: the next
-// query of the LDS phase, or any valid image when there is none) are prefetched, so MFMAs issue back
-// to back across queries.  `e` carries the running maxima of the query whose tile 0 is done into
-// the next stage.
+// steps per query.  The matrix pipe hides about five other instructions per MFMA, so the epilogue is
+// placed where the MFMAs are dense:
+//   steps   0..39   (1 MFMA/step) read the PREVIOUS query's tile 1 out of acc1 (16 v_accvgpr_read)
+//   steps  40..74   (2 MFMA/step) all the epilogue arithmetic of the previous query (32 outputs x ~9
+//                   VALU), then `fin` (store)
+//   steps  75..114  (1 MFMA/step) read THIS query's tile 0 out of acc0 into p0 for the next stage
+// No accumulator is copied besides those reads, and the first fragments of the next query (at
+// next_lds: the next query of the LDS phase, or any valid image when there is none) are prefetched,
+// so MFMAs issue back to back across queries.
 template <bool DO_MFMA, bool DO_PREV, typename Fin>
 __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds, frag4 (&first)[F_DEPTH],
-                                             const half8 (&B)[F_STEPS], floatx16 &acc0, floatx16 &acc1, Epi &e,
-                                             u64 cur_mask, unsigned m2lo, unsigned m2hi, int hh, Fin &&fin) {
+                                             const half8 (&B)[F_STEPS], floatx16 &acc0, floatx16 &acc1,
+                                             floatx16 &p0, u64 prev_mask, unsigned m2lo, unsigned m2hi, int hh,
+                                             Fin &&fin) {
   frag4 ring[F_DEPTH];
+  floatx16 p1;
+  Epi e;
   static_for<F_T>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     if constexpr (DO_MFMA) {
@@ -325,7 +336,8 @@ __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds,
       if constexpr (t < F_DEPTH) {
         af = __builtin_bit_cast(half8, first[t]);
       } else {
-        lds_wait_frag<younger_reads(t)>(ring[t % F_DEPTH]);
+        lds_wait_count<younger_reads(t)>();
+        __builtin_amdgcn_sched_barrier(0);  // the MFMA below stays below the wait
         af = __builtin_bit_cast(half8, ring[t % F_DEPTH]);
       }
       if constexpr (t == 0) {
@@ -347,16 +359,25 @@ __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds,
       if constexpr (t + F_DEPTH < F_T) lds_read_frag(ring[t % F_DEPTH], ap_lds, 32 * (t + F_DEPTH));
       if constexpr (t >= F_PRE && t < F_PRE + F_DEPTH) lds_read_frag(first[t - F_PRE], next_lds, 32 * (t - F_PRE));
     }
-    if constexpr (DO_PREV && t < F_TILE1) {
-      constexpr int i = piece_at(t);
-      if constexpr (i >= 0) epi_piece<1, i>(e, acc1[i], m2lo, m2hi, hh);
-      if constexpr (t == F_TILE1 - 1) fin(e);
+    if constexpr (DO_PREV) {
+      if constexpr (t < F_TILE1) {  // acc1 still holds the previous query's tile 1
+        constexpr int i = piece_at(t);
+        if constexpr (i >= 0) p1[i] = acc1[i];
+      } else if constexpr (t < F_STEPS) {  // 35 dense steps: 32 outputs, then the store
+        if constexpr (t == F_TILE1) epi_begin(e, prev_mask, hh);
+        constexpr int i = t - F_TILE1;
+        if constexpr (i < 16) epi_piece<0, i & 15>(e, p0[i & 15], m2lo, m2hi, hh);
+        else if constexpr (i < 32) epi_piece<1, i & 15>(e, p1[i & 15], m2lo, m2hi, hh);
+        if constexpr (t == F_STEPS - 1) fin(e);
+      }
     }
-    if constexpr (DO_MFMA && t >= F_STEPS) {
-      if constexpr (t == F_STEPS) epi_begin(e, cur_mask, hh);
+    if constexpr (DO_MFMA && t >= F_STEPS) {  // acc0 is complete: park it for the next stage
       constexpr int i = piece_at(t - F_STEPS);
-      if constexpr (i >= 0) epi_piece<0, i>(e, acc0[i], m2lo, m2hi, hh);
+      if constexpr (i >= 0) p0[i] = acc0[i];
     }
+    // nothing moves across a step boundary: the compiler would otherwise hoist the (asm) reads of
+    // several steps above the MFMAs that should cover their latency, and wait right after issuing
+    __builtin_amdgcn_sched_barrier(0);
   });
 }
 
@@ -416,9 +437,8 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    floatx16 acc0, acc1;
-    frag4 first[F_DEPTH];  // fragments 0..F_DEPTH-1 of the query about to be processed (landed)
-    Epi e;
+    floatx16 acc0, acc1, p0;  // p0: tile 0 of the previous query, read out of acc0 at the end of its stage
+    frag4 first[F_DEPTH];     // fragments 0..F_DEPTH-1 of the query about to be processed (landed)
     int prev_q = -1;
     u64 prev_mask = 0;
     // finish one (query, tile): non-finite flag, store (128 B per wave); eligibility is applied by
@@ -444,8 +464,8 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
           const unsigned ap_lds = phase_lds + (unsigned)(qq * FILTER_QIMG_BYTES);
           const unsigned next_lds = (qq + 1 < nq_here) ? ap_lds + FILTER_QIMG_BYTES : ap_lds;
           const u64 cur_mask = *reinterpret_cast<const u64 *>(smem + (p & 1) * F_PHASE_BYTES + qq * FILTER_QIMG_BYTES + QIMG_MASK_OFF);
-          if (prev_q < 0) filter_stage<true, false>(ap_lds, next_lds, first, B, acc0, acc1, e, cur_mask, m2lo, m2hi, hh, fin);
-          else filter_stage<true, true>(ap_lds, next_lds, first, B, acc0, acc1, e, cur_mask, m2lo, m2hi, hh, fin);
+          if (prev_q < 0) filter_stage<true, false>(ap_lds, next_lds, first, B, acc0, acc1, p0, prev_mask, m2lo, m2hi, hh, fin);
+          else filter_stage<true, true>(ap_lds, next_lds, first, B, acc0, acc1, p0, prev_mask, m2lo, m2hi, hh, fin);
           prev_q = qp + qq;
           prev_mask = cur_mask;
         }
@@ -453,7 +473,7 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
-    if (prev_q >= 0) filter_stage<false, true>(0u, 0u, first, B, acc0, acc1, e, 0ull, m2lo, m2hi, hh, fin);
+    if (prev_q >= 0) filter_stage<false, true>(0u, 0u, first, B, acc0, acc1, p0, prev_mask, m2lo, m2hi, hh, fin);
   }
 }
 
