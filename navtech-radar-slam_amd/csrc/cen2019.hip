@@ -47,6 +47,8 @@ struct Scal {
   unsigned int n_cand;
   long long jstar;
   unsigned int n_targets;
+  unsigned int done;     // the region budget ran out (or every candidate was visited): J* is final
+  unsigned int regions;  // new regions opened by the candidate windows processed so far
   unsigned int pad;
 };
 
@@ -59,17 +61,20 @@ __device__ __forceinline__ unsigned ord_f32(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// one block per azimuth: the row is 3.3 KB and stays in L1, no index arithmetic per pixel
 __global__ __launch_bounds__(256) void cen_stats(const uint8_t *__restrict__ img, int rows, int cols, int stride, int off,
                                                  Scal *sc) {
-  const int64_t n = (int64_t)rows * cols;
+  __shared__ unsigned long long s_sum[4];
+  __shared__ float s_max[4];
+  const int a = blockIdx.x;
+  const uint8_t *row = img + (int64_t)a * stride + off;
   unsigned long long sb = 0;
   float mg = 0.0f;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int a = (int)(i / cols), r = (int)(i - (int64_t)a * cols);
-    sb += img[(int64_t)a * stride + off + r];
+  for (int r = threadIdx.x; r < cols; r += 256) {
+    sb += row[r];
     if (cols > 1) {
       const int rp = (r + 1 < cols) ? r + 1 : cols - 2, rm = (r >= 1) ? r - 1 : 1;  // reflect 101
-      mg = fmaxf(mg, fabsf(__fsub_rn(px(img, a, rp, stride, off), px(img, a, rm, stride, off))));
+      mg = fmaxf(mg, fabsf(__fsub_rn(__fdiv_rn((float)row[rp], 255.0f), __fdiv_rn((float)row[rm], 255.0f))));
     }
   }
   for (int o = 32; o >= 1; o >>= 1) {
@@ -77,8 +82,13 @@ __global__ __launch_bounds__(256) void cen_stats(const uint8_t *__restrict__ img
     mg = fmaxf(mg, __shfl_xor(mg, o));
   }
   if ((threadIdx.x & 63) == 0) {
-    atomicAdd(&sc->sum_bytes, sb);
-    atomicMax(&sc->max_g_bits, __float_as_uint(mg));  // non-negative floats order like their bits
+    s_sum[threadIdx.x >> 6] = sb;
+    s_max[threadIdx.x >> 6] = mg;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sc->sum_bytes, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+    atomicMax(&sc->max_g_bits, __float_as_uint(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]))));  // non-negative floats order like their bits
   }
 }
 
@@ -89,38 +99,67 @@ __device__ __forceinline__ float mean_h(const Scal *sc, int64_t n) { return (flo
 
 __global__ __launch_bounds__(256) void cen_h(const uint8_t *__restrict__ img, int rows, int cols, int stride, int off,
                                              Scal *sc, float *__restrict__ h) {
+  __shared__ long long s_fix[4];
   const int64_t n = (int64_t)rows * cols;
   const float mean = mean_fft(sc, n);
   const float maxg = __uint_as_float(sc->max_g_bits);
+  const int a = blockIdx.x;
+  const uint8_t *row = img + (int64_t)a * stride + off;
+  float *hrow = h + (int64_t)a * cols;
   long long fix = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const int a = (int)(i / cols), r = (int)(i - (int64_t)a * cols);
+  for (int r = threadIdx.x; r < cols; r += 256) {
     float g = 0.0f;
     if (cols > 1) {
       const int rp = (r + 1 < cols) ? r + 1 : cols - 2, rm = (r >= 1) ? r - 1 : 1;
-      g = fabsf(__fsub_rn(px(img, a, rp, stride, off), px(img, a, rm, stride, off)));
+      g = fabsf(__fsub_rn(__fdiv_rn((float)row[rp], 255.0f), __fdiv_rn((float)row[rm], 255.0f)));
     }
     const float gn = (maxg > 0.0f) ? __fdiv_rn(g, maxg) : 0.0f;
-    const float s = __fsub_rn(px(img, a, r, stride, off), mean);
-    const float hv = __fmul_rn(s, __fsub_rn(1.0f, gn));
-    h[i] = hv;
+    const float sv = __fsub_rn(__fdiv_rn((float)row[r], 255.0f), mean);
+    const float hv = __fmul_rn(sv, __fsub_rn(1.0f, gn));
+    hrow[r] = hv;
     fix += __double2ll_rn((double)hv * FIX);
   }
   for (int o = 32; o >= 1; o >>= 1) fix += __shfl_xor(fix, o);
-  if ((threadIdx.x & 63) == 0) atomicAdd(reinterpret_cast<unsigned long long *>(&sc->fix_sum), (unsigned long long)fix);
+  if ((threadIdx.x & 63) == 0) s_fix[threadIdx.x >> 6] = fix;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicAdd(reinterpret_cast<unsigned long long *>(&sc->fix_sum), (unsigned long long)(s_fix[0] + s_fix[1] + s_fix[2] + s_fix[3]));
 }
 
+// one block per azimuth; two walks over the row (it stays in L1): count, ONE atomic per block to
+// reserve the block's slice of the key list, then write.  Key order is irrelevant (sorted next).
 __global__ __launch_bounds__(256) void cen_candidates(const float *__restrict__ h, int rows, int cols, Scal *sc,
                                                       unsigned long long *__restrict__ keys, unsigned *__restrict__ row_count) {
+  __shared__ unsigned s_cnt[4];
+  __shared__ unsigned s_base;
   const int64_t n = (int64_t)rows * cols;
   const float mh = mean_h(sc, n);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float hv = h[i];
-    if (hv > mh) {
-      const unsigned pos = atomicAdd(&sc->n_cand, 1u);
-      keys[pos] = ((unsigned long long)(~ord_f32(hv)) << 32) | (unsigned long long)(unsigned)i;
-      atomicAdd(&row_count[(int)(i / cols)], 1u);
-    }
+  const int a = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float *hrow = h + (int64_t)a * cols;
+  unsigned mine = 0;
+  for (int base = wave * 64; base < cols; base += 256) {
+    const int r = base + lane;
+    mine += (unsigned)__popcll(__ballot(r < cols && hrow[r] > mh));
+  }
+  if (lane == 0) s_cnt[wave] = mine;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    row_count[a] = tot;
+    s_base = tot ? atomicAdd(&sc->n_cand, tot) : 0u;
+  }
+  __syncthreads();
+  unsigned pos = s_base;
+  for (int w = 0; w < wave; w++) pos += s_cnt[w];
+  for (int base = wave * 64; base < cols; base += 256) {
+    const int r = base + lane;
+    const float hv = r < cols ? hrow[r] : 0.0f;
+    const bool is = r < cols && hv > mh;
+    const unsigned long long bal = __ballot(is);
+    if (is)
+      keys[pos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] =
+          ((unsigned long long)(~ord_f32(hv)) << 32) | (unsigned long long)(unsigned)(a * cols + r);
+    pos += (unsigned)__popcll(bal);
   }
 }
 
@@ -150,25 +189,43 @@ __global__ __launch_bounds__(1024) void cen_row_offsets(const unsigned *__restri
   if (t == 0) row_off[0] = 0;
 }
 
-// one wavefront per azimuth: replay the azimuth's candidates in global rank order
+// one wavefront per azimuth: replay the azimuth's candidates in global rank order.
+// The sequential method stops when max_points regions have been opened, usually after a few percent
+// of the candidates, so the replay runs in rank WINDOWS [win_lo, win_hi): after each window
+// cen_budget counts the regions opened so far and sets sc->done once the budget is exhausted; later
+// windows return at once.  Between windows the row's marks live in `mark` and its position in the
+// (rank-sorted) candidate list in row_cur.
 __global__ __launch_bounds__(64) void cen_mark(const uint8_t *__restrict__ img, int rows, int cols, int stride, int off,
                                                const Scal *sc, const unsigned long long *__restrict__ keys_sorted,
                                                const unsigned *__restrict__ rank_by_row, const unsigned *__restrict__ row_off,
+                                               unsigned win_hi, int first, unsigned *__restrict__ row_cur,
                                                int *__restrict__ mark, uint8_t *__restrict__ inc) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   int *mk = reinterpret_cast<int *>(lds);                        // [cols] rank of the marking candidate
   uint8_t *neg = reinterpret_cast<uint8_t *>(lds) + (size_t)cols * 4;  // [cols] s < 0
+  if (sc->done) return;
   const int a = blockIdx.x, lane = threadIdx.x;
   const float mean = mean_fft(sc, (int64_t)rows * cols);
   for (int r = lane; r < cols; r += 64) {
-    mk[r] = 0x7fffffff;
+    mk[r] = first ? 0x7fffffff : mark[(int64_t)a * cols + r];
     neg[r] = __fsub_rn(px(img, a, r, stride, off), mean) < 0.0f;
   }
   __syncthreads();
-  const unsigned t0 = row_off[a], t1 = row_off[a + 1];
-  for (unsigned t = t0; t < t1; t++) {
-    const unsigned j = rank_by_row[t];
-    const int r = (int)((unsigned)(keys_sorted[j] & 0xffffffffull) - (unsigned)a * (unsigned)cols);
+  const unsigned t1 = row_off[a + 1];
+  unsigned cur = first ? row_off[a] : row_cur[a];
+  bool more = true;
+  while (more && cur < t1) {
+   // 64 candidates of this azimuth at a time: two dependent global loads per CHUNK, not per candidate
+   const unsigned my_t = cur + lane;
+   const unsigned my_j = my_t < t1 ? rank_by_row[my_t] : 0xffffffffu;
+   const int my_r = my_t < t1 ? (int)((unsigned)(keys_sorted[my_j] & 0xffffffffull) - (unsigned)a * (unsigned)cols) : 0;
+   // the row's list is sorted by rank: the candidates inside the window are a prefix of the chunk
+   const unsigned cnt = (unsigned)__popcll(__ballot(my_t < t1 && my_j < win_hi));
+   more = cnt == 64u;
+   cur += cnt;
+   for (unsigned i = 0; i < cnt; i++) {
+    const unsigned j = __shfl(my_j, (int)i);
+    const int r = __shfl(my_r, (int)i);
     if (mk[r] != 0x7fffffff) {  // wave-uniform
       if (lane == 0) inc[j] = 0;
       continue;
@@ -200,22 +257,44 @@ __global__ __launch_bounds__(64) void cen_mark(const uint8_t *__restrict__ img, 
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) inc[j] = already ? 0 : 1;
+   }
   }
   __syncthreads();
   for (int r = lane; r < cols; r += 64) mark[(int64_t)a * cols + r] = mk[r];
+  if (lane == 0) row_cur[a] = cur;
 }
 
 // J* = number of candidates visited by `while (l < max_points && j < M)`: the first rank whose
-// exclusive prefix count of new regions reaches max_points, or M
-__global__ __launch_bounds__(1024) void cen_budget(const uint8_t *__restrict__ inc, Scal *sc, int max_points) {
+// exclusive prefix count of new regions reaches max_points, or M.  inc[] holds 0/1 bytes in rank
+// order; this looks at the window [win_lo, win_hi) (win_lo a multiple of 16) on top of the regions
+// counted in earlier windows; every thread sums a contiguous 16-byte aligned chunk with 16-byte loads.
+__global__ __launch_bounds__(1024) void cen_budget(const uint8_t *__restrict__ inc, Scal *sc, int max_points, unsigned win_lo,
+                                                   unsigned win_hi) {
   __shared__ unsigned s[1024];
+  if (sc->done) return;
   const unsigned m = sc->n_cand;
   const unsigned t = threadIdx.x;
-  const unsigned chunk = (m + 1023) / 1024;
-  const unsigned lo = t * chunk < m ? t * chunk : m;
-  const unsigned hi = lo + chunk < m ? lo + chunk : m;
+  if (max_points <= 0) {  // while (0 < 0 ...) never runs
+    if (t == 0) {
+      sc->jstar = 0;
+      sc->done = 1;
+    }
+    return;
+  }
+  const unsigned before = sc->regions;
+  const unsigned w_hi = win_hi < m ? win_hi : m;
+  const unsigned w_lo = win_lo < w_hi ? win_lo : w_hi;
+  const unsigned len = w_hi - w_lo;
+  const unsigned chunk = (((len + 1023) / 1024) + 15u) & ~15u;
+  const unsigned lo = w_lo + (t * chunk < len ? t * chunk : len);
+  const unsigned hi = lo + chunk < w_hi ? lo + chunk : w_hi;
   unsigned c = 0;
-  for (unsigned j = lo; j < hi; j++) c += inc[j];
+  unsigned j = lo;
+  for (; j + 16 <= hi; j += 16) {
+    const uint4 v = *reinterpret_cast<const uint4 *>(inc + j);
+    c += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
+  }
+  for (; j < hi; j++) c += inc[j] & 1u;
   s[t] = c;
   __syncthreads();
   for (int d = 1; d < 1024; d <<= 1) {
@@ -224,62 +303,83 @@ __global__ __launch_bounds__(1024) void cen_budget(const uint8_t *__restrict__ i
     s[t] += v;
     __syncthreads();
   }
-  const unsigned total = s[1023];
-  if (t == 0 && (max_points <= 0 || total < (unsigned)max_points)) sc->jstar = max_points <= 0 ? 0 : (long long)m;
-  if (max_points > 0 && total >= (unsigned)max_points) {
-    unsigned excl = s[t] - c;  // new regions before this chunk
+  const unsigned total = before + s[1023];
+  if (total >= (unsigned)max_points) {
+    const unsigned excl = before + s[t] - c;  // new regions before this chunk
     if (excl < (unsigned)max_points && excl + c >= (unsigned)max_points) {
       // the candidate that opens region number max_points is the last one visited
       unsigned l = excl;
-      for (unsigned j = lo; j < hi; j++) {
-        l += inc[j];
+      for (unsigned jj = lo; jj < hi; jj++) {
+        l += inc[jj] & 1u;
         if (l >= (unsigned)max_points) {
-          sc->jstar = (long long)j + 1;
+          sc->jstar = (long long)jj + 1;
+          sc->done = 1;
           break;
         }
       }
     }
+  } else if (t == 0) {
+    sc->regions = total;
+    if (w_hi >= m) {  // every candidate was visited
+      sc->jstar = (long long)m;
+      sc->done = 1;
+    }
   }
 }
 
+// one wavefront per azimuth.  LDS: per pixel a flag byte (bit 0: marked by a visited candidate,
+// bit 1: a marked pixel at the same range on the azimuth above or below) and the result slot of a run
+// (indexed by the run's first pixel).  Runs are short, so the lane that owns a run's first pixel walks
+// it; an ordered ballot compaction then restores ascending range order.
 __global__ __launch_bounds__(64) void cen_extract(const float *__restrict__ h, const int *__restrict__ mark, int rows, int cols,
                                                   const Scal *sc, int min_range, int *__restrict__ row_out,
                                                   unsigned *__restrict__ row_n) {
-  const int a = blockIdx.x * 64 + threadIdx.x;
-  if (a >= rows) return;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  int *res = reinterpret_cast<int *>(lds);                             // [cols]
+  uint8_t *flag = reinterpret_cast<uint8_t *>(lds) + (size_t)cols * 4;  // [cols]
+  const int a = blockIdx.x, lane = threadIdx.x;
   const int js = (int)(sc->jstar > 0x7fffffff ? 0x7fffffff : sc->jstar);
   const int *mr = mark + (int64_t)a * cols;
   const int *below = mark + (int64_t)((a - 1 + rows) % rows) * cols;
   const int *above = mark + (int64_t)((a + 1) % rows) * cols;
   const float *hr = h + (int64_t)a * cols;
-  int start = 0, end = 0;
-  bool counting = false;
-  unsigned cnt = 0;
-  for (int r = min_range < 0 ? 0 : min_range; r < cols; r++) {
-    if (mr[r] < js) {
-      if (!counting) {
-        start = r;
-        counting = true;
-      }
-      end = r;
-    } else if (counting) {
-      bool adj = false;
-      for (int i = start; i <= end && !adj; i++) adj = (below[i] < js) || (above[i] < js);
-      if (adj) {
-        int max_r = start;
-        float mx = -INFINITY;
-        for (int i = start; i <= end; i++)
-          if (hr[i] > mx) {
-            mx = hr[i];
-            max_r = i;
-          }
-        if (cnt < ROW_CAP) row_out[(int64_t)a * ROW_CAP + cnt] = max_r;
-        cnt++;
-      }
-      counting = false;
-    }
+  for (int r = lane; r < cols; r += 64) {
+    flag[r] = (uint8_t)((mr[r] < js ? 1 : 0) | ((below[r] < js || above[r] < js) ? 2 : 0));
+    res[r] = -1;
   }
-  row_n[a] = cnt < ROW_CAP ? cnt : ROW_CAP;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const int rmin = min_range < 0 ? 0 : min_range;
+  for (int r = rmin + lane; r < cols; r += 64) {
+    if (!(flag[r] & 1)) continue;
+    if (r > rmin && (flag[r - 1] & 1)) continue;  // not the first pixel of its run (runs are cut at rmin)
+    bool adj = false;
+    int max_r = r;
+    float mx = -INFINITY;
+    int i = r;
+    for (; i < cols && (flag[i] & 1); i++) {
+      adj |= (flag[i] & 2) != 0;
+      const float hv = hr[i];
+      if (hv > mx) {  // first maximum
+        mx = hv;
+        max_r = i;
+      }
+    }
+    // a run only counts once an unmarked pixel closes it: a run that reaches the end of the row does not
+    if (i < cols && adj) res[r] = max_r;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  unsigned cnt = 0;
+  for (int base = 0; base < cols; base += 64) {
+    const int r = base + lane;
+    const int v = r < cols ? res[r] : -1;
+    const unsigned long long bal = __ballot(v >= 0);
+    const unsigned pos = cnt + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+    if (v >= 0 && pos < ROW_CAP) row_out[(int64_t)a * ROW_CAP + pos] = v;
+    cnt += (unsigned)__popcll(bal);
+  }
+  if (lane == 0) row_n[a] = cnt < ROW_CAP ? cnt : ROW_CAP;
 }
 
 __global__ __launch_bounds__(256) void cen_compact(const int *__restrict__ row_out, const unsigned *__restrict__ row_n,
@@ -310,7 +410,7 @@ struct rsx_cen2019 {
   std::mutex mu;
   hipStream_t stream = nullptr;
   rsx::DevBuf img, h, keys, keys2, rowkey, rowkey2, rank, rank2, inc, mark, scal, row_count, row_off, row_out, row_n, row_off2,
-      targets, xy, az, temp;
+      targets, xy, az, temp, row_cur;
   bool attr_set = false;
 };
 
@@ -353,7 +453,7 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (rsx::DevBuf *b : {&h->img, &h->h, &h->keys, &h->keys2, &h->rowkey, &h->rowkey2, &h->rank, &h->rank2, &h->inc, &h->mark,
                          &h->scal, &h->row_count, &h->row_off, &h->row_out, &h->row_n, &h->row_off2, &h->targets, &h->xy, &h->az,
-                         &h->temp})
+                         &h->temp, &h->row_cur})
     b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -386,10 +486,9 @@ static int extract_device(rsx_cen2019 *h, const uint8_t *d_img, int32_t stride, 
   Scal *sc = h->scal.as<Scal>();
   RSX_HIP(hipMemsetAsync(sc, 0, sizeof(Scal), s));
   RSX_HIP(hipMemsetAsync(h->row_count.p, 0, (size_t)rows * 4, s));
-  const int grid = 2048;
-  hipLaunchKernelGGL(cen_stats, dim3(grid), dim3(256), 0, s, d_img, rows, cols, stride, off, sc);
-  hipLaunchKernelGGL(cen_h, dim3(grid), dim3(256), 0, s, d_img, rows, cols, stride, off, sc, h->h.as<float>());
-  hipLaunchKernelGGL(cen_candidates, dim3(grid), dim3(256), 0, s, h->h.as<float>(), rows, cols, sc,
+  hipLaunchKernelGGL(cen_stats, dim3(rows), dim3(256), 0, s, d_img, rows, cols, stride, off, sc);
+  hipLaunchKernelGGL(cen_h, dim3(rows), dim3(256), 0, s, d_img, rows, cols, stride, off, sc, h->h.as<float>());
+  hipLaunchKernelGGL(cen_candidates, dim3(rows), dim3(256), 0, s, h->h.as<float>(), rows, cols, sc,
                      h->keys.as<unsigned long long>(), h->row_count.as<unsigned>());
   RSX_HIP(hipGetLastError());
   // the candidate count is needed on the host to size the sorts
@@ -412,12 +511,29 @@ static int extract_device(rsx_cen2019 *h, const uint8_t *d_img, int32_t stride, 
   const size_t lds = (size_t)cols * 5;
   if (!h->attr_set) {
     RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cen_mark), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 5));
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cen_extract), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 5));
     h->attr_set = true;
   }
-  hipLaunchKernelGGL(cen_mark, dim3(rows), dim3(64), lds, s, d_img, rows, cols, stride, off, sc, h->keys2.as<unsigned long long>(),
-                     h->rank2.as<unsigned>(), h->row_off.as<unsigned>(), h->mark.as<int>(), h->inc.as<uint8_t>());
-  hipLaunchKernelGGL(cen_budget, dim3(1), dim3(1024), 0, s, h->inc.as<uint8_t>(), sc, p.max_points);
-  hipLaunchKernelGGL(cen_extract, dim3((rows + 63) / 64), dim3(64), 0, s, h->h.as<float>(), h->mark.as<int>(), rows, cols, sc,
+  // rank windows [0, W), [W, 4W), [4W, 16W) ...: the budget usually runs out in the first one
+  RSX_TRY(h->row_cur.reserve((size_t)rows * 4, s, false));
+  {
+    unsigned w = p.max_points > 0 ? 2u * (unsigned)p.max_points : 16384u;
+    w = (w + 16383u) & ~16383u;
+    unsigned lo = 0;
+    int first = 1;
+    while (true) {
+      const unsigned hi = (m - lo <= w) ? m : lo + w;
+      hipLaunchKernelGGL(cen_mark, dim3(rows), dim3(64), lds, s, d_img, rows, cols, stride, off, sc,
+                         h->keys2.as<unsigned long long>(), h->rank2.as<unsigned>(), h->row_off.as<unsigned>(), hi, first,
+                         h->row_cur.as<unsigned>(), h->mark.as<int>(), h->inc.as<uint8_t>());
+      hipLaunchKernelGGL(cen_budget, dim3(1), dim3(1024), 0, s, h->inc.as<uint8_t>(), sc, p.max_points, lo, hi);
+      first = 0;
+      if (hi >= m) break;
+      lo = hi;
+      w *= 4;
+    }
+  }
+  hipLaunchKernelGGL(cen_extract, dim3(rows), dim3(64), lds, s, h->h.as<float>(), h->mark.as<int>(), rows, cols, sc,
                      p.min_range, h->row_out.as<int>(), h->row_n.as<unsigned>());
   hipLaunchKernelGGL(cen_row_offsets, dim3(1), dim3(1024), 0, s, h->row_n.as<unsigned>(), rows, h->row_off2.as<unsigned>());
   hipLaunchKernelGGL(cen_compact, dim3(rows), dim3(256), 0, s, h->row_out.as<int>(), h->row_n.as<unsigned>(),
