@@ -119,6 +119,30 @@ def orora_leg(device, skip_cpu):
     return leg
 
 
+def profiled_traffic():
+    """HBM-side bytes per sc_filter_kernel launch from the COMMITTED rocprofv3 PMC passes (tools/prof.sh
+    runs this same workload; counters cannot be collected from inside the bench).  FETCH_SIZE is
+    doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md), both are KB."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sc_filter_v*_rocprofv3.txt")))
+    if not files:
+        return None, None
+    fetch = write = None
+    for line in open(files[-1]):
+        if "FilterArgs" not in line:
+            continue
+        m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", line)
+        if m:
+            if m.group(1) == "FETCH_SIZE":
+                fetch = float(m.group(2))
+            else:
+                write = float(m.group(2))
+    if fetch is None or write is None:
+        return None, None
+    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT)
+
+
 def cen2019_leg(device):
     """Third part of the path: cen2019 keypoint extraction on MulRan-shape polar
     scans (400 azimuths x 3360 range bins, 11 metadata bytes per row).  rsx_cen2019_extract takes a HOST
@@ -228,8 +252,10 @@ def main():
         if kernel == "sc_filter_kernel":
             alg_flop = local_pairs * ALG_FLOP_PER_PAIR
             achieved = alg_flop / avg_kern_s / 1e12 if avg_kern_s > 0 else 0.0
+            traffic, traffic_src = profiled_traffic() if world == 1 and (n_db, nq) == (10000, 2048) else (None, None)
             roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": None, "kernel": kernel,
+                        "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
+                        "traffic_source": traffic_src, "kernel": kernel,
                         "launches": launches, "avg_launch_ms": kern_ms / max(launches, 1),
                         "algorithmic_flop_per_launch": alg_flop,
                         "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",

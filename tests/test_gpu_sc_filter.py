@@ -262,3 +262,31 @@ def test_two_stage_sharded_query(sc, oracle, world, mode):
         shards[0].query_stage2_device(nq, k, glob.data_ptr(), finals[0].data_ptr(), stream=st)
     torch.cuda.synchronize()
     torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_full_size_100k_properties(sc, oracle):
+    """BASELINE config 5 scale on one GPU: 100 000-keyframe DB (0.8 GB resident), batched exhaustive
+    top-10.  Size-independent properties (planted loops come back as top-1 with distance ~0 and the
+    right shift, lists sorted, deterministic, filtered == unfiltered on a sample) + oracle spot checks."""
+    n, nq, k = 100_000, 96, 10
+    descs = synth.random_descriptors(777, n, binary=True)
+    rng = np.random.default_rng(778)
+    src = rng.integers(0, n - 100, nq)
+    rot = rng.integers(0, 60, nq)
+    queries = np.stack([synth.rotate_descriptor(descs[s], int(r)) for s, r in zip(src, rot)])
+    g = sc.SCManager(capacity_hint=n)                     # auto mode: 96 x 100k pairs -> filter path
+    g.add_descriptors_f32(descs)
+    assert len(g) == n
+    got = g.query(queries, k=k, n_eligible=n - 30)
+    assert g.profiled_kernel_name() == "sc_filter_kernel"
+    assert np.array_equal(got["index"][:, 0], src) and np.array_equal(got["shift"][:, 0], rot)
+    assert np.all(np.abs(got["dist"][:, 0]) < 1e-15)
+    assert np.all(np.diff(got["dist"], axis=1) >= 0) and np.all(got["dist"] < 1e7)
+    assert np.array_equal(g.query(queries, k=k, n_eligible=n - 30), got)
+    e = sc.SCManager(capacity_hint=n, filter_mode=OFF)
+    e.add_descriptors_f32(descs)
+    assert np.array_equal(e.query(queries[:8], k=k, n_eligible=n - 30), got[:8])
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    for qi in (0, 95):
+        assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=16))
