@@ -257,6 +257,28 @@ int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, 
                         const rsx_cen2019_params *params, const float *azimuths, float resolution,
                         int32_t *out_targets, float *out_xy, int32_t max_targets, int32_t *out_count);
 
+/* ============================== VoxelGrid downsample ===================================
+ * pcl::VoxelGrid<pcl::PointXYZI>::filter with setLeafSize(leaf, leaf, leaf): the step right before
+ * makeAndSaveScancontextAndKeys in the reference's keyframe path (PGO.cpp:98,482-484; leaf 0.4 set at
+ * PGO.cpp:687-688).  PCL is not part of the reference checkout: follows the published algorithm
+ * (oracle/voxelgrid_ref.c) -- parity unpinned.  Output = one centroid {x,y,z,intensity} per occupied
+ * voxel, packed float4, in ascending voxel-index order.  If the voxel grid would overflow int32
+ * ("leaf size too small") the input is returned unchanged, like PCL does. */
+
+typedef struct rsx_voxelgrid rsx_voxelgrid;
+
+int rsx_voxelgrid_create(int device, rsx_voxelgrid **out);
+int rsx_voxelgrid_destroy(rsx_voxelgrid *h);
+/* pts: n points stride_bytes apart, float x,y,z at byte offsets 0,4,8, float intensity at
+ * intensity_offset (16 for pcl::PointXYZI; < 0: none, output 0).  Non-finite points are dropped.
+ * *out_count = number of output points (only the first max_out are written). */
+int rsx_voxelgrid_filter(rsx_voxelgrid *h, const void *pts, size_t n, size_t stride_bytes, int32_t intensity_offset,
+                         float leaf, float *out_xyzi, int64_t max_out, int64_t *out_count);
+/* downSizeFilterScancontext.filter(...) + scManager.makeAndSaveScancontextAndKeys(...) in one call
+ * (PGO.cpp:482-492): the downsampled cloud never leaves the GPU.  vg and h must be on the same device. */
+int rsx_sc_add_points_downsampled(rsx_sc *h, rsx_voxelgrid *vg, const void *pts, size_t n, size_t stride_bytes,
+                                  float leaf, int32_t *out_index);
+
 #ifdef __cplusplus
 }
 #endif

@@ -72,6 +72,7 @@ SYMBOLS = [
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
     "rsx_orora_register_batch", "rsx_orora_register_batch_device",
     "rsx_cen2019_default_params", "rsx_cen2019_create", "rsx_cen2019_destroy", "rsx_cen2019_extract",
+    "rsx_voxelgrid_create", "rsx_voxelgrid_destroy", "rsx_voxelgrid_filter", "rsx_sc_add_points_downsampled",
 ]
 
 
@@ -135,6 +136,10 @@ def lib():
         L.rsx_cen2019_destroy.argtypes = [vp]
         L.rsx_cen2019_extract.argtypes = [vp, vp, i32, i32, C.POINTER(Cen2019Params), vp, C.c_float, vp, vp, i32,
                                           C.POINTER(i32)]
+        L.rsx_voxelgrid_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.rsx_voxelgrid_destroy.argtypes = [vp]
+        L.rsx_voxelgrid_filter.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i32, C.c_float, vp, i64, C.POINTER(i64)]
+        L.rsx_sc_add_points_downsampled.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_float, C.POINTER(i32)]
         _lib = L
     return _lib
 

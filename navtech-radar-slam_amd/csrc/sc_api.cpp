@@ -11,6 +11,7 @@
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
+#include "voxelgrid.h"
 
 namespace rsx {
 std::string &last_error() {
@@ -433,6 +434,36 @@ int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes,
                          h->norm.as<double>() + slot * NS, h->rkey.as<float>() + slot * NR, h->stream));
     RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, 1, h->hn.p, h->cmask.as<uint64_t>(), h->stream));
     RSX_HIP(hipStreamSynchronize(h->stream));  // caller may reuse pts; entry visible to detect()
+    h->n_local = slot + 1;
+  }
+  h->n_global = g + 1;
+  if (out_index) *out_index = (int32_t)g;
+  return RSX_OK;
+}
+
+int rsx_sc_add_points_downsampled(rsx_sc *h, rsx_voxelgrid *vg, const void *pts, size_t n, size_t stride_bytes, float leaf,
+                                  int32_t *out_index) {
+  if (!h || !vg || (!pts && n)) return fail(RSX_ERR_BAD_ARG, "null arg");
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+  if (!(leaf > 0.0f)) return fail(RSX_ERR_BAD_ARG, "leaf must be positive");
+  if (rsx::vg::device_of(vg) != h->p.device) return fail(RSX_ERR_BAD_ARG, "voxel grid and ScanContext handles are on different devices");
+  std::lock_guard<std::mutex> lk(h->mu);
+  std::lock_guard<std::mutex> lkv(rsx::vg::mutex_of(vg));
+  RSX_TRY(set_device(h));
+  const int64_t g = h->n_global;
+  if (owns(h, g)) {
+    // intensity is not used by the descriptor (SC.cpp:151-195 reads x, y, z only)
+    const float *d_ds = nullptr;
+    int64_t nds = 0;
+    RSX_TRY(rsx::vg::upload_and_filter(vg, pts, (int64_t)n, (int64_t)stride_bytes, -1, leaf, (int64_t)(n ? n : 1), &d_ds, &nds));
+    const int64_t slot = h->n_local;
+    RSX_TRY(ensure_capacity(h, slot + 1));
+    // upload_and_filter synchronised vg's stream: d_ds is complete and stays valid under vg's lock
+    RSX_TRY(launch_build(d_ds ? static_cast<const void *>(d_ds) : h->desc.p, nds, 16, h->p.lidar_height, h->p.max_radius,
+                         h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
+                         h->rkey.as<float>() + slot * NR, h->stream));
+    RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, 1, h->hn.p, h->cmask.as<uint64_t>(), h->stream));
+    RSX_HIP(hipStreamSynchronize(h->stream));
     h->n_local = slot + 1;
   }
   h->n_global = g + 1;

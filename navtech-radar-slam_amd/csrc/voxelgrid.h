@@ -1,0 +1,22 @@
+// voxelgrid.h -- internal interface of the VoxelGrid handle (voxelgrid.hip) for sc_api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+
+#include "rsx.h"
+
+namespace rsx {
+namespace vg {
+
+// host points -> device, downsample; *d_out = packed float4 {x,y,z,intensity} owned by the handle
+// (valid until its next call), *n_out = number of output points.  Synchronises the handle's stream.
+int upload_and_filter(rsx_voxelgrid *h, const void *pts, int64_t n, int64_t stride, int32_t ioff, float leaf, int64_t max_out,
+                      const float **d_out, int64_t *n_out);
+std::mutex &mutex_of(rsx_voxelgrid *h);
+hipStream_t stream_of(rsx_voxelgrid *h);
+int device_of(rsx_voxelgrid *h);
+
+}  // namespace vg
+}  // namespace rsx

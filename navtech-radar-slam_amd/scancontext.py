@@ -68,6 +68,15 @@ class SCManager:
         check(self._L.rsx_sc_add_points(self._h, pts.ctypes.data, pts.shape[0], pts.shape[1] * 4, C.byref(idx)))
         return idx.value
 
+    def makeAndSaveScancontextAndKeysDownsampled(self, scan, voxelgrid):
+        """downSizeFilterScancontext.filter + makeAndSaveScancontextAndKeys (PGO.cpp:482-492) in one
+        call: the downsampled cloud stays on the GPU.  voxelgrid: navtech_radar_slam_amd.voxelgrid.VoxelGrid."""
+        pts = np.ascontiguousarray(scan, dtype=np.float32)
+        idx = C.c_int32()
+        check(self._L.rsx_sc_add_points_downsampled(self._h, voxelgrid._h, pts.ctypes.data, pts.shape[0], pts.shape[1] * 4,
+                                                    voxelgrid.leaf, C.byref(idx)))
+        return idx.value
+
     def saveScancontextAndKeys(self, scd):
         """scd: 20x60 descriptor, column-major double (1200,) like Eigen::MatrixXd."""
         d = np.ascontiguousarray(scd, dtype=np.float64).reshape(-1)

@@ -398,3 +398,20 @@ def cen2019_to_cartesian(targets, azimuths, resolution):
     L.cen2019ref_to_cartesian.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_float, C.c_void_p]
     L.cen2019ref_to_cartesian(t.ctypes.data, t.shape[0], az.ctypes.data, resolution, out.ctypes.data)
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# VoxelGrid downsample (oracle/voxelgrid_ref.c) -- PARITY UNPINNED, see the header of that file
+# ---------------------------------------------------------------------------------------------
+def voxelgrid_filter(pts, leaf=0.4, intensity_col=3):
+    """pts: (n, >=3) float32 rows x,y,z[,intensity at column intensity_col].  -> ((m,4) float32, overflow)."""
+    L = lib()
+    p = np.ascontiguousarray(pts, dtype=np.float32)
+    n = p.shape[0]
+    out = np.zeros((max(n, 1), 4), dtype=np.float32)
+    ov = C.c_int32()
+    L.vgref_filter.restype = C.c_int64
+    L.vgref_filter.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p, C.c_int64, C.POINTER(C.c_int32)]
+    ioff = 4 * intensity_col if (intensity_col is not None and p.shape[1] > intensity_col) else -1
+    m = L.vgref_filter(p.ctypes.data, n, p.shape[1] * 4, ioff, leaf, out.ctypes.data, out.shape[0], C.byref(ov))
+    return out[:m].copy(), bool(ov.value)
