@@ -58,7 +58,9 @@ int main() {
     for (int i = 0; i < 120; i++) {  // process_pg, PGO.cpp:492
       const bool revisit = i >= 60 && i % 10 == 0;
       clouds.push_back(revisit ? synth_cloud(rng, 0.5236f, &clouds[i - 55]) : synth_cloud(rng, 0.f, nullptr));
-      scManager.makeAndSaveScancontextAndKeys(&clouds.back()[0].x, clouds.back().size(), sizeof(Pt));
+      // odd keyframes take the fused VoxelGrid(0.4 m) + build path (PGO.cpp:482-492 in one call)
+      if (i & 1) scManager.makeAndSaveScancontextAndKeysDownsampled(&clouds.back()[0].x, clouds.back().size(), sizeof(Pt));
+      else scManager.makeAndSaveScancontextAndKeys(&clouds.back()[0].x, clouds.back().size(), sizeof(Pt));
       std::this_thread::sleep_for(std::chrono::milliseconds(3));
     }
     done = true;

@@ -52,6 +52,7 @@ class SCManager {
  public:
   SCManager() = default;
   ~SCManager() {
+    if (vg_) rsx_voxelgrid_destroy(vg_);
     if (h_) rsx_sc_destroy(h_);
   }
   SCManager(const SCManager &) = delete;
@@ -69,6 +70,21 @@ class SCManager {
   void makeAndSaveScancontextAndKeys(const float *xyz, std::size_t n, std::size_t stride_bytes) {
     check(rsx_sc_add_points(handle(), xyz, n, stride_bytes, nullptr), "makeAndSaveScancontextAndKeys");
   }
+
+  // Opt-in fusion of the caller's `downSizeFilterScancontext.filter(*thisKeyFrameDS)` with the build
+  // (laserPosegraphOptimization.cpp:482-492): the raw keyframe goes in, the VoxelGrid downsample
+  // (leaf as set at PGO.cpp:687-688) and the descriptor build both run on the GPU.
+  void makeAndSaveScancontextAndKeysDownsampled(const float *xyz, std::size_t n, std::size_t stride_bytes, float leaf = 0.4f) {
+    rsx_sc *h = handle();
+    if (!vg_) check(rsx_voxelgrid_create(device_, &vg_), "rsx_voxelgrid_create");
+    check(rsx_sc_add_points_downsampled(h, vg_, xyz, n, stride_bytes, leaf, nullptr), "makeAndSaveScancontextAndKeysDownsampled");
+  }
+#ifdef RSX_HAVE_PCL
+  void makeAndSaveScancontextAndKeysDownsampled(pcl::PointCloud<SCPointType> &scan, float leaf = 0.4f) {
+    makeAndSaveScancontextAndKeysDownsampled(scan.points.empty() ? nullptr : &scan.points[0].x, scan.points.size(),
+                                             sizeof(SCPointType), leaf);
+  }
+#endif
 
   // int: nearest node index or -1, float: relative yaw [rad]
   std::pair<int, float> detectLoopClosureID(void) {
@@ -177,6 +193,7 @@ class SCManager {
     if (rows != RSX_SC_NUM_RING || cols != RSX_SC_NUM_SECTOR) throw std::runtime_error("descriptor must be 20 x 60");
   }
   rsx_sc *h_ = nullptr;
+  rsx_voxelgrid *vg_ = nullptr;
   int mode_ = RSX_SC_MODE_CANDIDATE;
   int device_ = 0;
   double last_min_dist_ = 0.0;
