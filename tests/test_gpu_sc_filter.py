@@ -290,3 +290,38 @@ def test_full_size_100k_properties(sc, oracle):
     o.add_descriptors(descs.astype(np.float64))
     for qi in (0, 95):
         assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=16))
+
+
+def test_rescore_beyond_the_short_list(sc, oracle):
+    """Duplicate-heavy databases: more equal bounds than the 2048-entry short list holds, so the
+    re-scoring has to fall back to scanning the bound row (sc_rescore_kernel's rest path)."""
+    rng = np.random.default_rng(17)
+    base = synth.random_descriptors(40, 8, binary=False)
+    rand = make_db(41, 900, binary=False)
+    # (i) 5000 rotated copies of ONE descriptor + 900 others: the first histogram bin alone overflows
+    #     the short list (empty short list, everything through the rest path)
+    dup = np.stack([synth.rotate_descriptor(base[0], int(r)) for r in rng.integers(0, 60, 5000)])
+    db1 = np.concatenate([rand[:450], dup, rand[450:]])
+    # (ii) 5 strictly better entries + 3000 identical runners-up: the short list holds only the 5, the
+    #      k-th best lies in the overflowing bin
+    q2 = base[1].copy()
+    near = []
+    for i in range(5):
+        d = q2.copy()
+        d[rng.integers(0, 1200, 3 + i)] = 0
+        near.append(d)
+    far = q2.copy()
+    far[rng.integers(0, 1200, 300)] = 0
+    db2 = np.concatenate([rand[:100], np.tile(far, (3000, 1)), np.stack(near), rand[100:]])
+    for db, q in ((db1, base[0]), (db2, q2)):
+        g = sc.SCManager(filter_mode=FORCE, capacity_hint=len(db))
+        g.add_descriptors_f32(db)
+        o = oracle.Manager()
+        o.add_descriptors(db.astype(np.float64))
+        queries = np.stack([q, synth.rotate_descriptor(q, 11), rand[3], np.zeros(1200, np.float32)])
+        for k, ne in ((1, -1), (10, -1), (32, -1), (10, 2000)):
+            got = g.query(queries, k=k, n_eligible=ne)
+            for qi in range(len(queries)):
+                want = o.exhaustive(queries[qi].astype(np.float64), n_eligible=(len(db) if ne < 0 else ne), k=k, nthreads=4)
+                assert np.array_equal(got[qi], want), f"db{1 if db is db1 else 2} k={k} ne={ne} q={qi}"
+        g.close()
