@@ -163,7 +163,7 @@ struct ProfScope {
   }
 };
 
-// exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> k seeds -> exact
+// exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> short list -> exact
 // -> tau -> candidates -> exact.  Everything stays on the stream; no host synchronisation.
 // query batch size the filter workspaces are sized for (<= 1 GiB of bounds)
 int64_t filter_batch(int64_t n_items, int64_t nq) {

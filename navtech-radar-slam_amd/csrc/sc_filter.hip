@@ -11,7 +11,7 @@
 // pipe instead of ~44k fp64 lane-operations on the VALU.  The filter computes L~ (fp16 inputs, fp32
 // accumulation) for every pair, the exact fp64 kernel (sc_pair_kernel) then re-scores only the
 // entries whose bound can still reach the top-k:
-//        keep entry  <=>  not ( L~ - eps > tau ),   tau = k-th best EXACT distance among k seeds.
+//        keep entry  <=>  not ( L~ - eps > tau ),   tau = k-th best EXACT distance found so far.
 // Because |L~ - L| <= eps (derivation below) and L <= dist, no entry of the exact top-k is ever
 // dropped, so the results stay bit-identical to the oracle (tests/test_gpu_sc.py).
 //

@@ -3,7 +3,11 @@
 // What each kernel replaces in the reference (pgo/SC-A-LOAM/include/scancontext/Scancontext.cpp):
 //   sc_build_kernel   makeScancontext + the three key builders           SC.cpp:151-227
 //   sc_keys_kernel    makeRingkey/makeSectorkey (+ column norms)         SC.cpp:198-227, 78
-//   sc_pair_kernel    distanceBtnScanContext for (query, DB entry) pairs SC.cpp:69-148
+//   pair_group<B>     distanceBtnScanContext for one query x B entries   SC.cpp:69-148   (device function)
+//   sc_pair_kernel    pair_group over every entry / a gather list        SC.cpp:380-395  (small problems, the 3
+//                     kd-tree candidates, rsx_sc_pair_distances)
+//   sc_rescore_kernel pair_group over the entries the MFMA filter (sc_filter.hip) could not exclude,
+//                     in rounds of ascending bound with tau tightening (batched exhaustive queries)
 //   sc_merge_kernel   the strict-< "first wins" candidate loop           SC.cpp:380-395 (generalised to top-k)
 //   sc_knn_kernel     nanoflann 3-NN on ring keys                        SC.cpp:367-374, NF.hpp:383-408
 //
