@@ -163,8 +163,6 @@ struct ProfScope {
   }
 };
 
-// exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> short list -> exact
-// -> tau -> candidates -> exact.  Everything stays on the stream; no host synchronisation.
 // query batch size the filter workspaces are sized for (<= 1 GiB of bounds)
 int64_t filter_batch(int64_t n_items, int64_t nq) {
   const int64_t ld = (n_items + 31) / 32 * 32;
