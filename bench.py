@@ -8,13 +8,15 @@ batch of Q = 8192 exhaustive queries (distanceBtnScanContext against EVERY eligi
 the 10 000-keyframe synthetic DB -- the configuration the north-star target is quoted on
 (>= 10k queries/s vs a 10k-scan DB on one MI355X).  Inputs (DB and queries) are resident in HBM
 before the timed region starts.  With --gpus G the DB is sharded block-cyclically over G ranks
-(same total DB => strong scaling); each rank scores its shard, the per-rank top-k lists are
-all-gathered with RCCL (torch.distributed backend "nccl") and merged on the GPU.
+(same total DB and batch => strong scaling); a query batch is two stages with one RCCL all-gather of
+the per-rank top-k lists each (torch.distributed backend "nccl"), merged on the GPU (sharded.py).
 
 Extra objects on the same line:
-  roofline      algorithmic bytes of the dominant kernel (sc_pair_kernel) / its HIP-event time
+  roofline      algorithmic flops of the dominant kernel (sc_filter_kernel, fp16 MFMA) / its HIP-event
+                time; the SURVEY 8d algorithmic-byte figure rides along as roofline.hbm_algorithmic
   cpu_baseline  the CPU oracle (port of Scancontext.cpp) timed on this box's host cores, rank 0
   latency_q1_n1k_us   BASELINE configs[1]: one query vs a 1k-keyframe DB, end-to-end host call
+  orora, cen2019      the other two parts of the path: scan pairs/s (BASELINE configs[2]) and scans/s
 """
 import argparse
 import json
