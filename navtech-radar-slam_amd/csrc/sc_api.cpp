@@ -663,9 +663,19 @@ int rsx_sc_query_stage1_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t 
   RSX_TRY(h->st_partial.reserve((size_t)nq * k * sizeof(rsx_sc_hit), s, false));
   const bool filtered = use_filter(h, nq, items) && filter_batch(items, nq) >= nq;
   if (filtered) {
-    // round 0 only: this shard's share of the ~64 lowest bounds per query
-    int32_t first = (64 + h->p.shard_world - 1) / h->p.shard_world;
+    // round 0 only: this shard's share of the ~160 lowest bounds per query -- enough for the merged
+    // k-th distance to be the final one for almost every query (a single GPU needs ~120 exact scores
+    // per query because it can tighten tau after every 64; a shard cannot see the others' hits until
+    // the exchange, so stage 1 over-samples instead).  Measured per-rank cost of both stages with 8
+    // shards of the 10k DB, 8192 queries: 64 -> 3.4 ms, 128 -> 1.9, 192 -> 1.7, 256 -> 1.8.
+    static const int stage1_total = [] {
+      const char *e = getenv("RSX_SC_STAGE1_TOTAL");  // tuning knob: lowest bounds scored in stage 1, over all shards
+      const int v = (e && *e) ? atoi(e) : 0;
+      return v > 0 ? v : 160;
+    }();
+    int32_t first = (stage1_total + h->p.shard_world - 1) / h->p.shard_world;
     if (first < 8) first = 8;
+    if (first > 128) first = 128;
     RSX_TRY(filter_reserve(h, items, nq, s));
     h->prof_kernel = filter_kernel_name();
     RSX_TRY(filter_and_select(h, qv, items, n_elig, nullptr, first, s));

@@ -697,7 +697,10 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   int *s_ncand = reinterpret_cast<int *>(smem + L::OFF_MISC);
   double *s_tau = reinterpret_cast<double *>(smem + L::OFF_MISC + 8);
 
-  load_query_to_lds(a.q, qi, smem, threadIdx.x, RS_WAVES * 64);
+  // the query image is only brought into LDS when the first candidate shows up: in the later stages
+  // of a sharded search most queries have nothing left to score
+  bool query_loaded = false;
+  bool scored_any = false;
   if (threadIdx.x == 0) {
     *s_ncand = 0;
     *s_tau = INFINITY;
@@ -735,6 +738,13 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
 
   // score cand[0..ncand) (all waves), then refresh tau
   auto score_and_merge = [&](int ncand) {
+    if (ncand == 0) return;  // (uniform) nothing selected: lists and tau are unchanged
+    if (!query_loaded) {
+      load_query_to_lds(a.q, qi, smem, threadIdx.x, RS_WAVES * 64);
+      __syncthreads();
+      query_loaded = true;
+    }
+    scored_any = true;
     const int ngroups = (ncand + B - 1) / B;
     for (int g = wave; g < ngroups; g += RS_WAVES) {
       int64_t eslot[B];
@@ -840,8 +850,11 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
     }
   }
 
-  // ---- output: top-k of everything this workgroup knows (its lists as of the last merge; when no
-  //      round ran, the lists still have to be published) ----
+  // ---- output: top-k of everything this workgroup knows ----
+  if (!scored_any && a.seed) {  // nothing scored in this stage: the earlier hits are the answer
+    if (threadIdx.x < a.k) a.out[(int64_t)qi * a.k + threadIdx.x] = a.seed[(int64_t)qi * a.k + threadIdx.x];
+    return;
+  }
   if (lane < a.k) {
     rsx_sc_hit h;
     h.dist = ld; h.index = li; h.shift = ls;
