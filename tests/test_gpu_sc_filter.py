@@ -325,3 +325,51 @@ def test_rescore_beyond_the_short_list(sc, oracle):
                 want = o.exhaustive(queries[qi].astype(np.float64), n_eligible=(len(db) if ne < 0 else ne), k=k, nthreads=4)
                 assert np.array_equal(got[qi], want), f"db{1 if db is db1 else 2} k={k} ne={ne} q={qi}"
         g.close()
+
+
+def test_streaming_slam_sharded(sc, oracle):
+    """BASELINE config 4 in miniature: the DB grows keyframe by keyframe (descriptor build on the GPU,
+    4 shards); at every 4th keyframe the newest descriptor is searched both ways -- reference
+    semantics (3 kd-tree candidates, unsharded handle) and exhaustively over the shards with the
+    two-stage protocol -- and both must equal the oracle."""
+    import torch
+    world, n, k = 4, 600, 3
+    clouds, truth = synth.keyframe_clouds(99, n, binary_z=True, loop_frac=0.15, n_points=600, min_gap=40)
+    ref = sc.SCManager(sc_dist_thres=0.45)
+    shards = [sc.SCManager(shard_rank=r, shard_world=world, filter_mode=FORCE) for r in range(world)]
+    o = oracle.Manager(dist_thres=0.45)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    st = tstream.cuda_stream
+    parts = torch.zeros((world, 1, k, 2), dtype=torch.float64, device="cuda")
+    glob = torch.zeros((1, k, 2), dtype=torch.float64, device="cuda")
+    out = torch.zeros((1, k, 2), dtype=torch.float64, device="cuda")
+    found = 0
+    for i, c in enumerate(clouds):
+        assert ref.makeAndSaveScancontextAndKeys(c) == i
+        for s in shards:
+            assert s.makeAndSaveScancontextAndKeys(c) == i      # every rank sees every keyframe
+        o.add_points(c)
+        got = ref.detectLoopClosureID(full=True)
+        want = o.detect_loop_closure()
+        assert got == want, f"keyframe {i}: {got} vs {want}"
+        if i % 4 or i < 31:
+            continue
+        n_elig = i + 1 - 30                                       # NUM_EXCLUDE_RECENT
+        q = torch.from_numpy(o.descriptor(i).astype(np.float32)).cuda()
+        for r, s in enumerate(shards):
+            s.query_stage1_device(q.data_ptr(), 1, k, parts[r].data_ptr(), n_eligible=n_elig, stream=st)
+        shards[0].merge_device(parts.data_ptr(), world, 1, k, glob.data_ptr(), stream=st)
+        for r, s in enumerate(shards):
+            s.query_stage2_device(1, k, glob.data_ptr(), parts[r].data_ptr(), stream=st)
+        shards[0].merge_device(parts.data_ptr(), world, 1, k, out.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        hits = out.cpu().numpy().view(sc.HIT_DTYPE).reshape(k)
+        wantx = o.exhaustive(o.descriptor(i), n_eligible=n_elig, k=k)
+        assert np.array_equal(hits, wantx), f"keyframe {i}"
+        if truth[i] is not None and truth[i][0] < n_elig:
+            assert hits[0]["index"] == truth[i][0] and hits[0]["shift"] == truth[i][1]
+            found += 1
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    assert found >= 10 and sum(s.local_size for s in shards) == n
