@@ -169,6 +169,36 @@ def cen2019_leg(device):
                     "~0.5 M candidates + one host sync for the candidate count), not HBM-bound"}
 
 
+def icp_leg(device):
+    """the ICP loop verification that follows a ScanContext candidate
+    (PGO.cpp:357-403): one keyframe scan against a +-25-keyframe submap, host buffers in."""
+    from navtech_radar_slam_amd import icp
+    rng = np.random.default_rng(5)
+    walls = []
+    for _ in range(40):
+        a, b = rng.uniform(-80, 80, 2), rng.uniform(-80, 80, 2)
+        t = rng.uniform(0, 1, 1500)[:, None]
+        walls.append(np.c_[a + t * (b - a), rng.uniform(0, 3, 1500)])
+    tgt = np.concatenate(walls).astype(np.float32)                      # 60 000-point submap
+    yaw = 0.04
+    R = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+    sub = tgt[rng.choice(len(tgt), 1500, replace=False)] + rng.normal(0, 0.02, (1500, 3))
+    src = ((sub - np.array([0.8, -0.5, 0.0])) @ R).astype(np.float32)   # tgt = R src + t
+    ic = icp.Icp(device=device)
+    res = ic.align(src, tgt)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        res = ic.align(src, tgt)
+    dt = (time.perf_counter() - t0) / reps
+    ic.close()
+    return {"ms_per_align": dt * 1e3, "source_points": len(src), "target_points": len(tgt), "iterations": res["iterations"],
+            "converged": res["converged"], "fitness": res["fitness"], "accepted": bool(res["converged"] and res["fitness"] <= 0.3),
+            "dtype": "f32 (fp64 moment sums)",
+            "note": "brute-force nearest neighbour, %.1e distance evaluations per iteration; host-buffer entry "
+                    "(uploads both clouds, one 16-byte read-back per iteration)" % (len(src) * len(tgt))}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,6 +330,7 @@ def main():
         small.close()
         out["orora"] = orora_leg(local_rank, args.no_cpu_baseline)
         out["cen2019"] = cen2019_leg(local_rank)
+        out["icp"] = icp_leg(local_rank)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(descs, queries, k)
         print(json.dumps(out), flush=True)

@@ -279,6 +279,40 @@ int rsx_voxelgrid_filter(rsx_voxelgrid *h, const void *pts, size_t n, size_t str
 int rsx_sc_add_points_downsampled(rsx_sc *h, rsx_voxelgrid *vg, const void *pts, size_t n, size_t stride_bytes,
                                   float leaf, int32_t *out_index);
 
+/* ============================== ICP loop verification ===================================
+ * pcl::IterativeClosestPoint<PointXYZI, PointXYZI> as the reference configures it in
+ * doICPVirtualRelative (PGO.cpp:371-392): point-to-point, SVD (Umeyama) step, PCL's default
+ * convergence criteria, fitness = mean squared nearest-neighbour distance.  PCL is not part of the
+ * reference checkout: follows the published algorithm (oracle/icp_ref.c) -- parity unpinned. */
+
+typedef struct rsx_icp rsx_icp;
+
+typedef struct {
+  double max_corr_dist;             /* setMaxCorrespondenceDistance(150), PGO.cpp:374 */
+  double transformation_epsilon;    /* setTransformationEpsilon(1e-6),    PGO.cpp:376 */
+  double euclidean_fitness_epsilon; /* setEuclideanFitnessEpsilon(1e-6),  PGO.cpp:377 */
+  int32_t max_iterations;           /* setMaximumIterations(100),         PGO.cpp:375 */
+  int32_t reserved;
+} rsx_icp_params;
+
+typedef struct {
+  float transform[16]; /* getFinalTransformation(): row-major 4x4, target <- source */
+  double fitness;      /* getFitnessScore() */
+  int32_t iterations;
+  int32_t converged;   /* hasConverged() */
+  int32_t state;       /* 1 iterations, 2 transform, 3 abs MSE, 4 rel MSE, 5 not enough correspondences */
+  int32_t reserved;
+} rsx_icp_result;
+
+int rsx_icp_default_params(rsx_icp_params *p);
+int rsx_icp_create(int device, rsx_icp **out);
+int rsx_icp_destroy(rsx_icp *h);
+/* icp.setInputSource(src); icp.setInputTarget(tgt); icp.align(unused, guess).  Points: float x,y,z at
+ * byte offsets 0,4,8 of each stride; guess: optional row-major 4x4 (NULL = identity).  The caller
+ * applies the acceptance test of PGO.cpp:385-387 (converged && fitness <= 0.3). */
+int rsx_icp_align(rsx_icp *h, const void *src, size_t ns, size_t src_stride, const void *tgt, size_t nt, size_t tgt_stride,
+                  const rsx_icp_params *params, const float *guess, rsx_icp_result *out);
+
 #ifdef __cplusplus
 }
 #endif

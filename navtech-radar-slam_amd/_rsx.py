@@ -48,6 +48,16 @@ class OroraParams(C.Structure):
                 ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
 
 
+class IcpParams(C.Structure):
+    _fields_ = [("max_corr_dist", C.c_double), ("transformation_epsilon", C.c_double),
+                ("euclidean_fitness_epsilon", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+
+
+class IcpResult(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("fitness", C.c_double), ("iterations", C.c_int32),
+                ("converged", C.c_int32), ("state", C.c_int32), ("reserved", C.c_int32)]
+
+
 class Cen2019Params(C.Structure):
     _fields_ = [("max_points", C.c_int32), ("min_range", C.c_int32)]
 
@@ -73,6 +83,7 @@ SYMBOLS = [
     "rsx_orora_register_batch", "rsx_orora_register_batch_device",
     "rsx_cen2019_default_params", "rsx_cen2019_create", "rsx_cen2019_destroy", "rsx_cen2019_extract",
     "rsx_voxelgrid_create", "rsx_voxelgrid_destroy", "rsx_voxelgrid_filter", "rsx_sc_add_points_downsampled",
+    "rsx_icp_default_params", "rsx_icp_create", "rsx_icp_destroy", "rsx_icp_align",
 ]
 
 
@@ -140,6 +151,11 @@ def lib():
         L.rsx_voxelgrid_destroy.argtypes = [vp]
         L.rsx_voxelgrid_filter.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i32, C.c_float, vp, i64, C.POINTER(i64)]
         L.rsx_sc_add_points_downsampled.argtypes = [vp, vp, vp, C.c_size_t, C.c_size_t, C.c_float, C.POINTER(i32)]
+        L.rsx_icp_default_params.argtypes = [C.POINTER(IcpParams)]
+        L.rsx_icp_create.argtypes = [C.c_int, C.POINTER(vp)]
+        L.rsx_icp_destroy.argtypes = [vp]
+        L.rsx_icp_align.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.POINTER(IcpParams), vp,
+                                    C.POINTER(IcpResult)]
         _lib = L
     return _lib
 

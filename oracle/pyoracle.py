@@ -415,3 +415,38 @@ def voxelgrid_filter(pts, leaf=0.4, intensity_col=3):
     ioff = 4 * intensity_col if (intensity_col is not None and p.shape[1] > intensity_col) else -1
     m = L.vgref_filter(p.ctypes.data, n, p.shape[1] * 4, ioff, leaf, out.ctypes.data, out.shape[0], C.byref(ov))
     return out[:m].copy(), bool(ov.value)
+
+
+# ---------------------------------------------------------------------------------------------
+# ICP loop verification (oracle/icp_ref.c) -- PARITY UNPINNED, see the header of that file
+# ---------------------------------------------------------------------------------------------
+class IcpRefParams(C.Structure):
+    _fields_ = [("max_corr_dist", C.c_double), ("transformation_epsilon", C.c_double),
+                ("euclidean_fitness_epsilon", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+
+
+class IcpRefResult(C.Structure):
+    _fields_ = [("transform", C.c_float * 16), ("fitness", C.c_double), ("iterations", C.c_int32),
+                ("converged", C.c_int32), ("state", C.c_int32), ("reserved", C.c_int32)]
+
+
+def icp_rotation_from_covariance(H):
+    L = lib()
+    h = np.ascontiguousarray(H, dtype=np.float64).reshape(9)
+    r = np.zeros(9, dtype=np.float64)
+    L.icpref_rotation_from_covariance(_dp(h), _dp(r))
+    return r.reshape(3, 3)
+
+
+def icp_align(source, target, max_corr_dist=150.0, transformation_epsilon=1e-6, euclidean_fitness_epsilon=1e-6,
+              max_iterations=100, guess=None):
+    L = lib()
+    s = np.ascontiguousarray(np.asarray(source, dtype=np.float32)[:, :3])
+    t = np.ascontiguousarray(np.asarray(target, dtype=np.float32)[:, :3])
+    p = IcpRefParams(max_corr_dist, transformation_epsilon, euclidean_fitness_epsilon, max_iterations, 0)
+    g = np.ascontiguousarray(guess, dtype=np.float32).reshape(16) if guess is not None else None
+    r = IcpRefResult()
+    L.icpref_align.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(IcpRefParams), C.c_void_p, C.POINTER(IcpRefResult)]
+    L.icpref_align(s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], C.byref(p), g.ctypes.data if g is not None else None, C.byref(r))
+    return {"transform": np.array(r.transform, dtype=np.float32).reshape(4, 4), "fitness": r.fitness,
+            "iterations": r.iterations, "converged": bool(r.converged), "state": r.state}

@@ -1,0 +1,64 @@
+"""GPU parity of the ICP loop verification (icp.hip through the C-ABI) against the oracle.  Floating
+point: the nearest-neighbour correspondences are identical by construction (same float expression,
+same tie rule); the moment sums run in parallel in fp64 on the GPU and sequentially in float in the
+oracle, so poses agree to 1e-4 (the north-star pose tolerance), not bit for bit."""
+import numpy as np
+import pytest
+
+from test_oracle_icp import rot, scene
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def icpmod():
+    from navtech_radar_slam_amd import _rsx, icp
+    assert _rsx.device_count() >= 1
+    return icp
+
+
+@pytest.mark.parametrize("seed,ns,nt", [(1, 500, 1500), (2, 2000, 6000), (3, 1200, 40000)])
+def test_align_matches_oracle(icpmod, oracle, seed, ns, nt):
+    tgt = scene(seed, nt)
+    R, t = rot(0.05 * seed, 0.01, -0.01), np.array([0.5, -0.3 * seed, 0.04])
+    rng = np.random.default_rng(seed)
+    sub = tgt[rng.choice(len(tgt), ns, replace=False)] + rng.normal(0, 0.02, (ns, 3))
+    src = ((sub - t) @ R).astype(np.float32)
+    ic = icpmod.Icp()
+    got = ic.align(src, tgt)
+    want = oracle.icp_align(src, tgt)
+    assert got["converged"] == want["converged"]
+    assert np.abs(got["transform"] - want["transform"]).max() < TOL
+    assert abs(got["fitness"] - want["fitness"]) < TOL * max(1.0, want["fitness"])
+    assert abs(got["iterations"] - want["iterations"]) <= 2          # thresholds at 1e-6 see the sum order
+    assert np.allclose(got["transform"][:3, :3], R, atol=5e-3) and np.allclose(got["transform"][:3, 3], t, atol=5e-2)
+    assert ic.accepts(got)
+    # PointXYZI-strided input (32 bytes per point) gives the same answer
+    s32 = np.zeros((ns, 8), np.float32)
+    s32[:, :3] = src
+    assert np.array_equal(ic.align(s32, tgt)["transform"], got["transform"])
+
+
+def test_states_and_rejection(icpmod, oracle):
+    tgt = scene(4)
+    src = (tgt[::3] + np.float32([2.0, 1.0, 0.0])).astype(np.float32)
+    ic = icpmod.Icp()
+    ic.params.max_iterations = 1
+    r1 = ic.align(src, tgt)
+    w1 = oracle.icp_align(src, tgt, max_iterations=1)
+    assert r1["converged"] and r1["state"] == 1 and r1["iterations"] == 1
+    assert np.abs(r1["transform"] - w1["transform"]).max() < TOL
+    ic.params.max_iterations = 100
+    ic.params.max_corr_dist = 1e-4
+    r0 = ic.align(src, tgt)
+    assert not r0["converged"] and r0["state"] == 5 and r0["iterations"] == 0
+    assert np.array_equal(r0["transform"], np.eye(4, dtype=np.float32))
+    ic.params.max_corr_dist = 150.0
+    g = np.eye(4, dtype=np.float32)
+    g[:3, 3] = [-2.0, -1.0, 0.0]
+    rg = ic.align(src, tgt, guess=g)
+    assert rg["converged"] and rg["iterations"] <= 3 and rg["fitness"] < 1e-9
+    wrong = ic.align(src, scene(9))
+    assert not ic.accepts(wrong)                                       # a different place: fitness > 0.3
+    assert abs(wrong["fitness"] - oracle.icp_align(src, scene(9))["fitness"]) < 1e-3 * wrong["fitness"]
