@@ -53,6 +53,17 @@ def test_no_cpu_fallback(rsx):
     from navtech_radar_slam_amd import scancontext
     with pytest.raises(rsx.RsxError):
         scancontext.SCManager()
+    L = rsx.lib()
+    for create in (lambda: L.rsx_orora_create(0, C.byref(h)), lambda: L.rsx_cen2019_create(0, 400, 3360, C.byref(h)),
+                   lambda: L.rsx_voxelgrid_create(0, C.byref(h)), lambda: L.rsx_icp_create(0, C.byref(h))):
+        assert create() == -2 and not h.value
+
+
+def test_new_rows_param_defaults(rsx):
+    # ICP settings of doICPVirtualRelative (laserPosegraphOptimization.cpp:374-377)
+    p = rsx.IcpParams()
+    assert rsx.lib().rsx_icp_default_params(C.byref(p)) == 0
+    assert (p.max_corr_dist, p.max_iterations, p.transformation_epsilon, p.euclidean_fitness_epsilon) == (150.0, 100, 1e-6, 1e-6)
 
 
 def test_param_defaults_match_reference(rsx):
