@@ -373,3 +373,44 @@ def test_streaming_slam_sharded(sc, oracle):
     torch.cuda.synchronize()
     torch.cuda.set_stream(torch.cuda.default_stream())
     assert found >= 10 and sum(s.local_size for s in shards) == n
+
+
+def test_filter_bounds_adversarial(sc, oracle):
+    """The bound must hold for every pair also on descriptors built to stress the fp16 filter: columns
+    mixing magnitudes over six decades, negative values, single-element columns, many empty columns,
+    huge and tiny overall scales."""
+    rng = np.random.default_rng(23)
+    n = 640
+    base = synth.random_descriptors(50, n, binary=False).reshape(n, 60, 20)
+    scale = 10.0 ** rng.uniform(-3, 3, (n, 60, 20))
+    d = (base * scale).astype(np.float32)
+    d[100:200] *= np.where(rng.uniform(size=(100, 60, 20)) < 0.5, -1.0, 1.0).astype(np.float32)   # mixed signs
+    d[200:260, :, 1:] = 0                                                                           # one ring only
+    d[260:320][rng.uniform(size=(60, 60)) < 0.8] = 0                                                # mostly empty
+    d[320:340] *= np.float32(1e30)                                                                  # huge (finite norms in fp64)
+    d[340:360] *= np.float32(1e-30)                                                                 # tiny
+    descs = np.ascontiguousarray(d.reshape(n, 1200))
+    queries = np.stack([descs[5], synth.rotate_descriptor(descs[150], 17), descs[230], descs[300], descs[330], descs[350],
+                        synth.rotate_descriptor(descs[40], 59)])
+    g = sc.SCManager()
+    g.add_descriptors_f32(descs)
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    eps = g.filter_eps()
+    lb = g.filter_bounds(queries)
+    worst = 0.0
+    for qi in range(len(queries)):
+        dist, _ = o.pair_distances(queries[qi].astype(np.float64), nthreads=4)
+        want = all_shift_bound(queries[qi], descs)
+        fin = np.isfinite(want)
+        assert np.all(lb[qi][~fin] == np.inf)
+        worst = max(worst, np.abs(lb[qi][fin] - want[fin]).max())
+        hit = dist < 1e7
+        assert np.all(lb[qi][hit].astype(np.float64) - eps <= dist[hit]), f"q={qi}: not a lower bound"
+    assert worst <= eps, worst
+    # and the filtered top-k equals the oracle on the same data
+    f = sc.SCManager(filter_mode=FORCE)
+    f.add_descriptors_f32(descs)
+    got = f.query(queries, k=10)
+    for qi in range(len(queries)):
+        assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), k=10, nthreads=4)), qi
