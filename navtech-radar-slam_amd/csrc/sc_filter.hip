@@ -303,6 +303,14 @@ __device__ __forceinline__ void first_prologue(frag4 (&first)[F_DEPTH], unsigned
   });
 }
 
+// read one accumulator register into a VGPR exactly HERE.  Written as `x = acc[i]` the optimiser hoists
+// all 32 reads to the top of the loop body, where they wait for the last MFMA of the previous query.
+__device__ __forceinline__ float acc_read(float a) {
+  float v;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a));
+  return v;
+}
+
 // which accumulator register (0..15) is read out at step t of its 40-step idle window (-1: none)
 constexpr int piece_at(int t) {
   for (int i = 0; i < 16; i++)
@@ -362,7 +370,7 @@ __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds,
     if constexpr (DO_PREV) {
       if constexpr (t < F_TILE1) {  // acc1 still holds the previous query's tile 1
         constexpr int i = piece_at(t);
-        if constexpr (i >= 0) p1[i] = acc1[i];
+        if constexpr (i >= 0) p1[i] = acc_read(acc1[i]);
       } else if constexpr (t < F_STEPS) {  // 35 dense steps: 32 outputs, then the store
         if constexpr (t == F_TILE1) epi_begin(e, prev_mask, hh);
         constexpr int i = t - F_TILE1;
@@ -373,7 +381,7 @@ __device__ __forceinline__ void filter_stage(unsigned ap_lds, unsigned next_lds,
     }
     if constexpr (DO_MFMA && t >= F_STEPS) {  // acc0 is complete: park it for the next stage
       constexpr int i = piece_at(t - F_STEPS);
-      if constexpr (i >= 0) p0[i] = acc0[i];
+      if constexpr (i >= 0) p0[i] = acc_read(acc0[i]);
     }
     // nothing moves across a step boundary: the compiler would otherwise hoist the (asm) reads of
     // several steps above the MFMAs that should cover their latency, and wait right after issuing
