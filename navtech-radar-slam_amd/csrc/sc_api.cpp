@@ -38,7 +38,7 @@ struct rsx_sc {
   int64_t batch_size = 0;
   // workspaces
   DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
-  DevBuf f_qimg, f_lb, f_cand, f_cnt, f_thr;  // filter path
+  DevBuf f_qimg, f_lb, f_cand, f_cnt, f_thr, f_plan;  // filter path
   PairProfiler prof;
   const char *prof_kernel = "sc_pair_kernel";  // which kernel the profiler events bracket
   // state between rsx_sc_query_stage1_device and rsx_sc_query_stage2_device
@@ -182,15 +182,19 @@ int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
 }
 
 // images -> MFMA filter -> short list + round edges of one query batch
+// elig_monotone: the per-query limits elig[] do not decrease with the query index (self queries)
 int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig,
-                      int32_t first_target, hipStream_t s) {
+                      int32_t first_target, hipStream_t s, bool elig_monotone = false) {
   const DbView db = db_view(h);
   const int64_t ld = (n_items + 31) / 32 * 32;
   float *lb = h->f_lb.as<float>();
   RSX_TRY(launch_query_images(q.desc, q.norm, q.nq, h->f_qimg.p, s));
   {
     ProfScope ps(&h->prof, s);
-    RSX_TRY(launch_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, s));
+    FilterPlanInput plan{n_eligible, elig};
+    const bool planned = elig_monotone && elig != nullptr;
+    if (planned) RSX_TRY(h->f_plan.reserve(filter_plan_bytes(n_items), s, false));
+    RSX_TRY(launch_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, planned ? &plan : nullptr, planned ? h->f_plan.p : nullptr, s));
     ps.stop();
   }
   return launch_select(db, lb, ld, n_items, q.nq, n_eligible, elig, first_target, h->f_cand.as<RescoreEntry>(),
@@ -209,7 +213,7 @@ int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, 
 // exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> short list ->
 // exact re-scoring in rounds of ascending bound.  Everything stays on the stream; no host sync.
 int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
-                      int32_t k, rsx_sc_hit *d_out, hipStream_t s) {
+                      int32_t k, rsx_sc_hit *d_out, hipStream_t s, bool elig_monotone) {
   const int64_t qb = filter_batch(n_items, qv.nq);
   RSX_TRY(filter_reserve(h, n_items, qb, s));
   h->prof_kernel = filter_kernel_name();
@@ -221,15 +225,15 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     q.norm = qv.norm + b0 * NS;
     q.nq = bn;
     const int64_t *elig = d_q_elig ? d_q_elig + b0 : nullptr;
-    RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, 64, s));
+    RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, 64, s, elig_monotone));
     RSX_TRY(rescore(h, q, n_items, n_eligible, elig, 0, RESCORE_ALL_ROUNDS, nullptr, nullptr, k, d_out + b0 * k, s));
   }
   return RSX_OK;
 }
 
 int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
-             int32_t k, rsx_sc_hit *d_out, hipStream_t s) {
-  if (use_filter(h, qv.nq, n_items)) return run_topk_filtered(h, qv, n_items, n_eligible, d_q_elig, k, d_out, s);
+             int32_t k, rsx_sc_hit *d_out, hipStream_t s, bool elig_monotone = false) {
+  if (use_filter(h, qv.nq, n_items)) return run_topk_filtered(h, qv, n_items, n_eligible, d_q_elig, k, d_out, s, elig_monotone);
   h->prof_kernel = pair_kernel_name();
   RSX_TRY(h->partial.reserve(pair_partial_bytes(n_items > 0 ? n_items : 1, qv.nq, k), s, false));
   struct Hook {
@@ -373,7 +377,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->st_partial}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
@@ -737,7 +741,8 @@ int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, 
     RSX_HIP(hipStreamSynchronize(s));  // e is a stack/heap temporary
     d_elig = h->q_elig.as<int64_t>();
   }
-  return run_topk(h, qv, local_count_below(h, n_eligible), n_eligible, d_elig, k, d_out, s);
+  // the limits q_first + i - exclude_recent grow with i: the filter skips what a query cannot see
+  return run_topk(h, qv, local_count_below(h, n_eligible), n_eligible, d_elig, k, d_out, s, /*elig_monotone=*/true);
 }
 
 int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t count, double *out_dist, int32_t *out_shift) {
@@ -776,7 +781,7 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
   RSX_TRY(h->f_qimg.reserve(filter_qimg_bytes(nq), s, false));
   RSX_TRY(h->f_lb.reserve((size_t)nq * ld * sizeof(float), s, false));
   RSX_TRY(launch_query_images(qv.desc, qv.norm, nq, h->f_qimg.p, s));
-  RSX_TRY(launch_filter(db_view(h), h->f_qimg.p, nq, n, h->f_lb.as<float>(), ld, s));
+  RSX_TRY(launch_filter(db_view(h), h->f_qimg.p, nq, n, h->f_lb.as<float>(), ld, nullptr, nullptr, s));
   RSX_HIP(hipMemcpy2DAsync(out_lb, (size_t)n * sizeof(float), h->f_lb.p, (size_t)ld * sizeof(float), (size_t)n * sizeof(float),
                            (size_t)nq, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));

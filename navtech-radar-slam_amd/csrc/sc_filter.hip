@@ -183,9 +183,14 @@ struct FilterArgs {
   const char *qimg;
   int64_t n_items;
   int32_t nq;
-  int64_t per_block;  // (tile-block, query) work items per workgroup
+  int64_t per_block;  // (tile-block, query) work items per workgroup (no plan)
   float *lb;
   int64_t ld_lb;
+  // optional plan (queries whose eligibility grows with the query index, e.g. every keyframe against the
+  // keyframes older than itself): tile-block tb only matters to queries >= tb_qmin[tb];
+  // tb_cum[tb] = work items before tb, tb_cum[ntb] = total
+  const int32_t *tb_qmin;
+  const int64_t *tb_cum;
 };
 
 __device__ __forceinline__ void stage_queries(const char *gsrc, char *ldst, int nbytes, int wave, int lane) {
@@ -400,17 +405,37 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 31, hh = lane >> 5;
   const int64_t ntiles = (a.n_items + 31) >> 5;
-  const int64_t total = ((ntiles + 3) >> 2) * (int64_t)a.nq;
-  int64_t L0 = (int64_t)blockIdx.x * a.per_block;
-  const int64_t L1 = (L0 + a.per_block < total) ? (L0 + a.per_block) : total;
+  const int64_t ntb = (ntiles + 3) >> 2;
+  const int64_t total = a.tb_cum ? a.tb_cum[ntb] : ntb * (int64_t)a.nq;
+  const int64_t per = a.tb_cum ? (total + gridDim.x - 1) / gridDim.x : a.per_block;
+  int64_t L0 = (int64_t)blockIdx.x * per;
+  const int64_t L1 = (L0 + per < total) ? (L0 + per) : total;
   // A fragment address of this lane inside a query image (row = shift col of tile 0)
   const int aoff = ((col & 1) ? (QIMG_ODD + 40 * col - 8) : (40 * col)) + 16 * hh;
   const unsigned lds_base = (unsigned)(uintptr_t)((AS3 char *)smem);
 
+  int64_t tb = 0;
+  if (a.tb_cum && L0 < L1) {  // last tile-block whose first item is <= L0
+    int64_t lo = 0, hi = ntb - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (a.tb_cum[mid] <= L0) lo = mid;
+      else hi = mid - 1;
+    }
+    tb = lo;
+  }
   while (L0 < L1) {
-    const int64_t tb = L0 / a.nq;
-    const int q0 = (int)(L0 - tb * a.nq);
-    const int q1 = (L1 - L0 < (int64_t)(a.nq - q0)) ? (int)(q0 + (L1 - L0)) : a.nq;
+    int q0, qend;
+    if (a.tb_cum) {
+      while (a.tb_cum[tb + 1] <= L0) tb++;  // skip tile-blocks without items
+      q0 = a.tb_qmin[tb] + (int)(L0 - a.tb_cum[tb]);
+      qend = a.nq;
+    } else {
+      tb = L0 / a.nq;
+      q0 = (int)(L0 - tb * a.nq);
+      qend = a.nq;
+    }
+    const int q1 = (L1 - L0 < (int64_t)(qend - q0)) ? (int)(q0 + (L1 - L0)) : qend;
     L0 += q1 - q0;
     const int64_t tile = tb * 4 + wave;
     const bool tile_ok = tile < ntiles;  // wave-uniform
@@ -616,6 +641,51 @@ __global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict_
   if (threadIdx.x == 0) sl_cnt[q] = s_total;
 }
 
+// ------------------------------------------------------------------------------------------
+// filter plan for queries whose eligibility limit does not decrease with the query index: the
+// tile-block tb (128 entries, first global index g0) is invisible to every query q with limit(q) <= g0,
+// and those queries form a prefix [0, tb_qmin[tb]).  tb_cum = exclusive prefix sums of nq - tb_qmin.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sc_filter_plan_kernel(Elig el, int32_t nq, int64_t n_items,
+                                                              int32_t *__restrict__ tb_qmin, int64_t *__restrict__ tb_cum) {
+  __shared__ long long sh[1024];
+  const int64_t ntb = (((n_items + 31) >> 5) + 3) >> 2;
+  const int t = threadIdx.x;
+  long long running = 0;
+  for (int64_t base = 0; base < ntb; base += 1024) {
+    const int64_t tb = base + t;
+    long long items = 0;
+    if (tb < ntb) {
+      const int64_t g0 = el.idx_base + tb * 128 * el.idx_stride;
+      int lo = 0, hi = nq;  // first q whose limit exceeds g0
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        int64_t lim = el.n_eligible;
+        if (el.q_elig) {
+          const int64_t v = el.q_elig[mid];
+          lim = v < lim ? v : lim;
+        }
+        if (lim > g0) hi = mid;
+        else lo = mid + 1;
+      }
+      tb_qmin[tb] = lo;
+      items = nq - lo;
+    }
+    sh[t] = items;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+      const long long v = t >= d ? sh[t - d] : 0;
+      __syncthreads();
+      sh[t] += v;
+      __syncthreads();
+    }
+    if (tb < ntb) tb_cum[tb] = running + sh[t] - items;
+    running += sh[1023];
+    __syncthreads();
+  }
+  if (t == 0) tb_cum[ntb] = running;
+}
+
 }  // namespace
 
 double filter_eps() { return 1.25e-3; }
@@ -641,8 +711,13 @@ int launch_query_images(const float *desc, const double *norm, int32_t nq, void 
 
 const char *filter_kernel_name() { return "sc_filter_kernel"; }
 
+size_t filter_plan_bytes(int64_t n_items) {
+  const int64_t ntb = (((n_items + 31) / 32) + 3) / 4;
+  return (size_t)(ntb + 1) * sizeof(int64_t) + (size_t)ntb * sizeof(int32_t) + 64;
+}
+
 int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
-                  hipStream_t s) {
+                  const FilterPlanInput *plan, void *plan_ws, hipStream_t s) {
   if (nq <= 0 || n_items <= 0) return RSX_OK;
   static int n_cu = 0;
   const int lds = 2 * F_PHASE_BYTES;
@@ -670,7 +745,20 @@ int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_item
   if (per < 16) per = 16;
   const int64_t nblk = (total + per - 1) / per;
   a.per_block = per;
-  hipLaunchKernelGGL(sc_filter_kernel, dim3((unsigned)nblk), dim3(256), lds, s, a);
+  a.tb_qmin = nullptr;
+  a.tb_cum = nullptr;
+  unsigned grid = (unsigned)nblk;
+  if (plan && plan_ws) {
+    const int64_t ntb = (ntiles + 3) / 4;
+    int64_t *cum = static_cast<int64_t *>(plan_ws);
+    int32_t *qmin = reinterpret_cast<int32_t *>(cum + ntb + 1);
+    const Elig el{db.idx_base, db.idx_stride, plan->n_eligible < 0 ? INT64_MAX : plan->n_eligible, plan->q_elig};
+    hipLaunchKernelGGL(sc_filter_plan_kernel, dim3(1), dim3(1024), 0, s, el, nq, n_items, qmin, cum);
+    a.tb_qmin = qmin;
+    a.tb_cum = cum;
+    grid = (unsigned)n_cu;  // the total is only known on the device: every workgroup takes total / n_cu
+  }
+  hipLaunchKernelGGL(sc_filter_kernel, dim3(grid), dim3(256), lds, s, a);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

@@ -101,8 +101,16 @@ int launch_db_images(const float *desc, const double *norm, int64_t first, int64
 int launch_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, hipStream_t s);
 // lb[q*ld_lb + slot] = lower bound of dist(query q, local slot), slots [0, n_items); +inf when no
 // shift has an effective column (never a hit), -inf when the pair must be re-scored regardless
+// plan (optional, with plan_ws of filter_plan_bytes(n_items) bytes): the queries' eligibility limits
+// min(n_eligible, q_elig[q]) do not decrease with q, so the (tile-block, query) pairs a query cannot see
+// are skipped altogether (their lb entries stay unwritten; they lie outside the query's eligible rows)
+struct FilterPlanInput {
+  int64_t n_eligible;
+  const int64_t *q_elig;
+};
+size_t filter_plan_bytes(int64_t n_items);
 int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
-                  hipStream_t s);
+                  const FilterPlanInput *plan, void *plan_ws, hipStream_t s);
 const char *pair_kernel_name();
 const char *filter_kernel_name();
 

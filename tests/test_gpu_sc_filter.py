@@ -414,3 +414,30 @@ def test_filter_bounds_adversarial(sc, oracle):
     got = f.query(queries, k=10)
     for qi in range(len(queries)):
         assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), k=10, nthreads=4)), qi
+
+
+def test_self_queries_skip_invisible_tile_blocks(sc):
+    """query_self with a growing eligibility prefix runs the filter on a triangular plan (tile-blocks a
+    query cannot see are skipped): identical to the exact path for every query."""
+    import torch
+    n, k = 3000 + 17, 5
+    descs = make_db(61, n, binary=True)
+    a = sc.SCManager(filter_mode=FORCE, capacity_hint=n)
+    b = sc.SCManager(filter_mode=OFF, capacity_hint=n)
+    a.add_descriptors_f32(descs)
+    b.add_descriptors_f32(descs)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    st = tstream.cuda_stream
+    oa = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+    ob = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+    for first, cnt, excl in ((0, n, 30), (1000, 1500, 0), (5, 64, 200)):
+        oa.zero_()
+        ob.zero_()
+        a.query_self_device(first, cnt, k, oa.data_ptr(), exclude_recent=excl, stream=st)
+        b.query_self_device(first, cnt, k, ob.data_ptr(), exclude_recent=excl, stream=st)
+        torch.cuda.synchronize()
+        ga = oa.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)[:cnt]
+        gb = ob.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)[:cnt]
+        assert np.array_equal(ga, gb), (first, cnt, excl)
+    torch.cuda.set_stream(torch.cuda.default_stream())
