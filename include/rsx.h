@@ -158,6 +158,14 @@ int rsx_sc_query_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k
  * with the same nq and k.  The merged result is identical to rsx_sc_query_device + merge. */
 int rsx_sc_query_stage1_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k, int64_t n_eligible,
                                rsx_sc_hit *d_partial, void *stream);
+/* the same with a per-query eligibility limit (device array, nq entries): query i only sees entries
+ * with global index < min(n_eligible, d_q_elig[i]) -- e.g. "every keyframe against the keyframes at
+ * least 30 older than itself" over a sharded DB (BASELINE configs 4 and 5).  elig_monotone != 0
+ * promises that d_q_elig does not decrease with i, which lets the filter skip the tile-blocks a
+ * query cannot see.  d_q_elig must stay valid until stage 2 has run. */
+int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k, int64_t n_eligible,
+                                    const int64_t *d_q_elig, int32_t elig_monotone, rsx_sc_hit *d_partial,
+                                    void *stream);
 int rsx_sc_query_stage2_device(rsx_sc *h, int32_t nq, int32_t k, const rsx_sc_hit *d_global, rsx_sc_hit *d_out,
                                void *stream);
 /* queries = DB entries [q_first, q_first+nq) of this handle (all-pairs runs, BASELINE config 5);

@@ -75,6 +75,7 @@ SYMBOLS = [
     "rsx_sc_add_descriptors_f32_device", "rsx_sc_get_descriptor", "rsx_sc_get_ringkey",
     "rsx_sc_get_sectorkey", "rsx_sc_detect_loop_closure", "rsx_sc_detect_between_session",
     "rsx_sc_tree_size", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_stage1_device",
+    "rsx_sc_query_stage1_elig_device",
     "rsx_sc_query_stage2_device", "rsx_sc_query_self_device",
     "rsx_sc_pair_distances", "rsx_sc_filter_bounds", "rsx_sc_filter_eps", "rsx_sc_profiled_kernel_name",
     "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
@@ -129,6 +130,7 @@ def lib():
         L.rsx_sc_query.argtypes = [vp, vp, i32, i32, i64, vp]
         L.rsx_sc_query_device.argtypes = [vp, vp, i32, i32, i64, vp, vp]
         L.rsx_sc_query_stage1_device.argtypes = [vp, vp, i32, i32, i64, vp, vp]
+        L.rsx_sc_query_stage1_elig_device.argtypes = [vp, vp, i32, i32, i64, vp, i32, vp, vp]
         L.rsx_sc_query_stage2_device.argtypes = [vp, i32, i32, vp, vp, vp]
         L.rsx_sc_query_self_device.argtypes = [vp, i64, i32, i32, i64, i32, vp, vp]
         L.rsx_sc_pair_distances.argtypes = [vp, vp, i64, i64, vp, vp]

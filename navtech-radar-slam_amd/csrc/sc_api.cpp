@@ -46,6 +46,7 @@ struct rsx_sc {
     bool valid = false, filtered = false;
     int32_t nq = 0, k = 0;
     int64_t n_items = 0, n_eligible = 0;
+    const int64_t *q_elig = nullptr;
     QueryView qv{};
   } st;
   DevBuf st_partial;  // this shard's stage-1 hits
@@ -654,6 +655,11 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
 
 int rsx_sc_query_stage1_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible,
                                rsx_sc_hit *d_partial, void *stream) {
+  return rsx_sc_query_stage1_elig_device(h, d_q, nq, k, n_eligible, nullptr, 0, d_partial, stream);
+}
+
+int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible,
+                                    const int64_t *d_q_elig, int32_t elig_monotone, rsx_sc_hit *d_partial, void *stream) {
   if (!h || !d_q || !d_partial || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
@@ -682,10 +688,10 @@ int rsx_sc_query_stage1_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t 
     if (first > 128) first = 128;
     RSX_TRY(filter_reserve(h, items, nq, s));
     h->prof_kernel = filter_kernel_name();
-    RSX_TRY(filter_and_select(h, qv, items, n_elig, nullptr, first, s));
-    RSX_TRY(rescore(h, qv, items, n_elig, nullptr, 0, 1, nullptr, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));
+    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, s, elig_monotone != 0));
+    RSX_TRY(rescore(h, qv, items, n_elig, d_q_elig, 0, 1, nullptr, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));
   } else {
-    RSX_TRY(run_topk(h, qv, items, n_elig, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));  // complete already
+    RSX_TRY(run_topk(h, qv, items, n_elig, d_q_elig, k, h->st_partial.as<rsx_sc_hit>(), s, elig_monotone != 0));  // complete already
   }
   RSX_HIP(hipMemcpyAsync(d_partial, h->st_partial.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToDevice, s));
   h->st.valid = true;
@@ -694,6 +700,7 @@ int rsx_sc_query_stage1_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t 
   h->st.k = k;
   h->st.n_items = items;
   h->st.n_eligible = n_elig;
+  h->st.q_elig = d_q_elig;
   h->st.qv = qv;
   return RSX_OK;
 }
@@ -708,7 +715,7 @@ int rsx_sc_query_stage2_device(rsx_sc *h, int32_t nq, int32_t k, const rsx_sc_hi
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   h->st.valid = false;
   if (h->st.filtered)
-    return rescore(h, h->st.qv, h->st.n_items, h->st.n_eligible, nullptr, 1, RESCORE_ALL_ROUNDS, d_global,
+    return rescore(h, h->st.qv, h->st.n_items, h->st.n_eligible, h->st.q_elig, 1, RESCORE_ALL_ROUNDS, d_global,
                    h->st_partial.as<rsx_sc_hit>(), k, d_out, s);
   RSX_HIP(hipMemcpyAsync(d_out, h->st_partial.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToDevice, s));
   return RSX_OK;

@@ -159,8 +159,13 @@ class SCManager:
     def query_device(self, q_ptr, nq, k, out_ptr, n_eligible=-1, stream=0):
         check(self._L.rsx_sc_query_device(self._h, q_ptr, nq, k, n_eligible, out_ptr, stream))
 
-    def query_stage1_device(self, q_ptr, nq, k, partial_ptr, n_eligible=-1, stream=0):
-        check(self._L.rsx_sc_query_stage1_device(self._h, q_ptr, nq, k, n_eligible, partial_ptr, stream))
+    def query_stage1_device(self, q_ptr, nq, k, partial_ptr, n_eligible=-1, stream=0, q_elig_ptr=0, elig_monotone=False):
+        """q_elig_ptr: optional device int64[nq] per-query eligibility limits (must outlive stage 2)."""
+        if q_elig_ptr:
+            check(self._L.rsx_sc_query_stage1_elig_device(self._h, q_ptr, nq, k, n_eligible, q_elig_ptr,
+                                                          1 if elig_monotone else 0, partial_ptr, stream))
+        else:
+            check(self._L.rsx_sc_query_stage1_device(self._h, q_ptr, nq, k, n_eligible, partial_ptr, stream))
 
     def query_stage2_device(self, nq, k, global_ptr, out_ptr, stream=0):
         check(self._L.rsx_sc_query_stage2_device(self._h, nq, k, global_ptr, out_ptr, stream))

@@ -66,7 +66,7 @@ class ShardedScanContext:
         self.backend.merge_device(parts.data_ptr(), self.world, nq, k, out.data_ptr(), stream=stream)
         return out
 
-    def query_device(self, q_ptr, nq, k, n_eligible=-1, stream=0):
+    def query_device(self, q_ptr, nq, k, n_eligible=-1, stream=0, q_elig_ptr=0, elig_monotone=False):
         """GPU path: device query pointer in, device tensor (nq, k, 2) f64 = rsx_sc_hit records out.
         `stream` must be the (non-default) torch stream current on this device: the library launches on
         it and the collectives run on it too.  stream=0 would make librsx use the handle's private
@@ -77,14 +77,21 @@ class ShardedScanContext:
                 self._side = torch.cuda.Stream(device=self.device)
             self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
-                out = self.query_device(q_ptr, nq, k, n_eligible, stream=self._side.cuda_stream)
+                out = self.query_device(q_ptr, nq, k, n_eligible, stream=self._side.cuda_stream, q_elig_ptr=q_elig_ptr,
+                                        elig_monotone=elig_monotone)
             torch.cuda.current_stream(self.device).wait_stream(self._side)
             return out
         local = self._buf("local", (nq, k, 2))
-        if self.world == 1:
+        if self.world == 1 and not q_elig_ptr:
             self.backend.query_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream)
             return local
-        self.backend.query_stage1_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream)
+        # q_elig_ptr: device int64[nq], query i only sees global indices < q_elig[i] (kept alive by the caller)
+        self.backend.query_stage1_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream,
+                                         q_elig_ptr=q_elig_ptr, elig_monotone=elig_monotone)
+        if self.world == 1:
+            final = self._buf("final", (nq, k, 2))
+            self.backend.query_stage2_device(nq, k, local.data_ptr(), final.data_ptr(), stream=stream)
+            return final
         bound = self._gather_merge(local, "s1", nq, k, stream)
         final = self._buf("final", (nq, k, 2))
         self.backend.query_stage2_device(nq, k, bound.data_ptr(), final.data_ptr(), stream=stream)

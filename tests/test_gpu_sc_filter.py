@@ -441,3 +441,47 @@ def test_self_queries_skip_invisible_tile_blocks(sc):
         gb = ob.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)[:cnt]
         assert np.array_equal(ga, gb), (first, cnt, excl)
     torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_all_pairs_over_shards(sc, world):
+    """BASELINE config 5's protocol on one device: every keyframe against the keyframes at least 30
+    older than itself, DB striped over `world` shards, queries replicated, per-query eligibility in
+    the staged query == the unsharded self-query."""
+    import torch
+    n, k, excl = 2501, 10, 30
+    descs = make_db(91, n, binary=True)
+    descs[1700] = synth.rotate_descriptor(descs[40], 13)
+    descs[2100] = synth.rotate_descriptor(descs[1700], 5)
+    full = sc.SCManager(filter_mode=OFF)
+    full.add_descriptors_f32(descs)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    st = tstream.cuda_stream
+    want_d = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+    full.query_self_device(0, n, k, want_d.data_ptr(), exclude_recent=excl, stream=st)
+    torch.cuda.synchronize()
+    want = want_d.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)
+    assert want[1700, 0]["index"] == 40 and want[2100, 0]["index"] in (40, 1700)
+    for mode in (FORCE, OFF):
+        shards = [sc.SCManager(shard_rank=r, shard_world=world, filter_mode=mode) for r in range(world)]
+        for s in shards:
+            s.add_descriptors_f32(descs)
+        dq = torch.from_numpy(descs).cuda()
+        lim = torch.clamp(torch.arange(n, dtype=torch.int64, device="cuda") - excl, min=0)
+        parts = torch.zeros((world, n, k, 2), dtype=torch.float64, device="cuda")
+        glob = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+        finals = torch.zeros((world, n, k, 2), dtype=torch.float64, device="cuda")
+        out = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+        for r, s in enumerate(shards):
+            s.query_stage1_device(dq.data_ptr(), n, k, parts[r].data_ptr(), stream=st, q_elig_ptr=lim.data_ptr(),
+                                  elig_monotone=True)
+        shards[0].merge_device(parts.data_ptr(), world, n, k, glob.data_ptr(), stream=st)
+        for r, s in enumerate(shards):
+            s.query_stage2_device(n, k, glob.data_ptr(), finals[r].data_ptr(), stream=st)
+        shards[0].merge_device(finals.data_ptr(), world, n, k, out.data_ptr(), stream=st)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)
+        assert np.array_equal(got, want), mode
+    torch.cuda.set_stream(torch.cuda.default_stream())
