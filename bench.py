@@ -35,6 +35,10 @@ ALG_BYTES_PER_PAIR = 4800  # one 20x60 fp32 descriptor per (query, DB
 # the filter's algorithmic work: the 60-shift circular cross-correlation of two column-normalised
 # 20x60 images = 60 shifts x 1200 multiply-adds per (query, DB entry) pair
 ALG_FLOP_PER_PAIR = 2 * 60 * 1200
+# the spectral form of the filter computes the same 60 values with a Z15 DFT: per pair
+# stage 1 (8 frequencies x 4 Z4-shifts x K=80 complex, Hermitian half) 9280 MAC + stage 2 (4 x 15 x 16) 960 MAC
+# + the exact n_eff correlation of the column masks (60 x 60) 3600 MAC
+SPEC_FLOP_PER_PAIR = 2 * (9280 + 960 + 3600)
 
 
 def make_db_and_queries(n_db, n_q, seed_db=1234, seed_q=4321):
@@ -121,18 +125,19 @@ def orora_leg(device, skip_cpu):
     return leg
 
 
-def profiled_traffic():
-    """HBM-side bytes per sc_filter_kernel launch from the COMMITTED rocprofv3 PMC passes (tools/prof.sh
+def profiled_traffic(kernel):
+    """HBM-side bytes per filter-kernel launch from the COMMITTED rocprofv3 PMC passes (tools/prof.sh
     runs this same workload; counters cannot be collected from inside the bench).  FETCH_SIZE is
     doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md), both are KB."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_sc_filter_v*_rocprofv3.txt")))
+    pat, tag = ("r*_sc_filter_v*_rocprofv3.txt", "FilterArgs") if kernel == "sc_filter_kernel" else ("r*_sc_spec_v*_rocprofv3.txt", "SpecArgs")
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
         return None, None
     fetch = write = None
     for line in open(files[-1]):
-        if "FilterArgs" not in line:
+        if tag not in line:
             continue
         m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", line)
         if m:
@@ -281,23 +286,33 @@ def main():
         avg_kern_s = (kern_ms / max(launches, 1)) * 1e-3
         kernel = mgr.profiled_kernel_name()
         hbm_alg = alg_bytes / avg_kern_s / 1e9 if avg_kern_s > 0 else 0.0
-        if kernel == "sc_filter_kernel":
-            alg_flop = local_pairs * ALG_FLOP_PER_PAIR
+        if kernel in ("sc_filter_kernel", "sc_spec_filter_kernel"):
+            spectral = kernel == "sc_spec_filter_kernel"
+            alg_flop = local_pairs * (SPEC_FLOP_PER_PAIR if spectral else ALG_FLOP_PER_PAIR)
             achieved = alg_flop / avg_kern_s / 1e12 if avg_kern_s > 0 else 0.0
-            traffic, traffic_src = profiled_traffic() if world == 1 and (n_db, nq) == (10000, 8192) else (None, None)
+            traffic, traffic_src = profiled_traffic(kernel) if world == 1 and (n_db, nq) == (10000, 8192) else (None, None)
             roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
                         "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
                         "traffic_source": traffic_src, "kernel": kernel,
                         "launches": launches, "avg_launch_ms": kern_ms / max(launches, 1),
                         "algorithmic_flop_per_launch": alg_flop,
+                        "algorithmic_flop_per_pair": SPEC_FLOP_PER_PAIR if spectral else ALG_FLOP_PER_PAIR,
+                        "direct_form_equivalent_tflops": local_pairs * ALG_FLOP_PER_PAIR / avg_kern_s / 1e12 if avg_kern_s > 0 else 0.0,
                         "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": hbm_alg / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
-                        "note": "dominant kernel = fp16 MFMA lower-bound filter (144 kflop per (query, entry) pair: "
-                                "60-shift circular cross-correlation, K = 1200); the DB tile is register-resident "
-                                "and the 24 MB fp16 DB image is read about once per query block from L2/Infinity "
-                                "Cache, so the 4800 B/pair algorithmic-byte figure (hbm_algorithmic, SURVEY 8d) "
-                                "exceeds the HBM peak by design; exact fp64 re-scoring of the surviving candidates "
-                                "is included in value/ms_per_step"}
+                        "note": ("dominant kernel = spectral fp16 MFMA lower-bound filter: the 60-shift circular "
+                                 "cross-correlation of a pair via a Z15 DFT + direct Z4 correlation (27.7 kflop per pair "
+                                 "incl. the exact n_eff mask correlation on the int8 matrix cores) instead of 144 kflop "
+                                 "per pair in the direct K = 1200 form (direct_form_equivalent_tflops = the rate a direct "
+                                 "kernel would need for the same time); `achieved` counts the spectral algorithm's own "
+                                 "flops against the dense fp16 peak. "
+                                 if spectral else
+                                 "dominant kernel = fp16 MFMA lower-bound filter (144 kflop per (query, entry) pair: "
+                                 "60-shift circular cross-correlation, K = 1200). ") +
+                                "The DB tile is register-resident and the fp16 DB image is read about once per query "
+                                "block from L2/Infinity Cache, so the 4800 B/pair algorithmic-byte figure "
+                                "(hbm_algorithmic, SURVEY 8d) exceeds the HBM peak by design; exact fp64 re-scoring of "
+                                "the surviving candidates is included in value/ms_per_step"}
         else:
             roofline = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": hbm_alg / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "launches": launches,
@@ -309,7 +324,7 @@ def main():
             "metric": "sc_loop_queries_per_sec_vs_10k_scan_db", "value": qps, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f16 filter + f64 exact" if kernel == "sc_filter_kernel" else "f64",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16 filter + f64 exact" if kernel in ("sc_filter_kernel", "sc_spec_filter_kernel") else "f64",
             "data": "synthetic",
             "config": {"workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n_db}", "db_keyframes": n_db,
                        "queries_per_step": nq, "topk": k, "rings_x_sectors": "20x60",

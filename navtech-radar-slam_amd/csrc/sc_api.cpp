@@ -31,6 +31,7 @@ struct rsx_sc {
   int64_t n_global = 0, n_local = 0, cap = 0;
   DevBuf desc, vkey, norm, rkey;
   DevBuf hn, cmask;  // fp16 filter image (tile-major) + column masks (sc_filter.hip)
+  DevBuf sp;         // fp16 spectral filter image (sc_spec.hip)
   // detector state (SC.h:104,117-120)
   int tree_counter = 0;
   int64_t tree_size = 0;
@@ -71,6 +72,7 @@ int ensure_capacity(rsx_sc *h, int64_t want_local) {
   RSX_TRY(h->rkey.reserve((size_t)nc * NR * sizeof(float), h->stream, true));
   RSX_TRY(h->hn.reserve((size_t)nc * FILTER_DB_BYTES_PER_ENTRY, h->stream, true));  // nc is a multiple of 32
   RSX_TRY(h->cmask.reserve((size_t)nc * sizeof(uint64_t), h->stream, true));
+  RSX_TRY(h->sp.reserve((size_t)nc * SPEC_DB_BYTES_PER_ENTRY, h->stream, true));
   h->cap = nc;
   return RSX_OK;
 }
@@ -83,10 +85,19 @@ DbView db_view(const rsx_sc *h) {
   v.rkey = h->rkey.as<float>();
   v.hnT = h->hn.p;
   v.cmask = h->cmask.as<uint64_t>();
+  v.spT = h->sp.p;
   v.n_local = h->n_local;
   v.idx_base = h->p.shard_rank;
   v.idx_stride = h->p.shard_world;
   return v;
+}
+
+// both filter images + column masks of local slots [slot, slot+count); synchronises s
+int build_db_images(rsx_sc *h, int64_t slot, int64_t count, hipStream_t s) {
+  RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->hn.p, h->cmask.as<uint64_t>(), s));
+  RSX_TRY(launch_spec_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->sp.p, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  return RSX_OK;
 }
 
 bool owns(const rsx_sc *h, int64_t g) { return (g % h->p.shard_world) == h->p.shard_rank; }
@@ -164,6 +175,48 @@ struct ProfScope {
   }
 };
 
+// which form of the lower-bound filter: 0 = direct (sc_filter.hip), 1 = spectral (sc_spec.hip, the default:
+// same bounds up to a slightly larger error budget, ~6x fewer MFMAs).  rsx_sc_params.filter_kind or
+// RSX_SC_FILTER_KIND=direct|spectral override.
+int filter_kind_of(const rsx_sc *h) {
+  static const int env = [] {
+    const char *e = getenv("RSX_SC_FILTER_KIND");
+    if (!e || !*e) return -1;
+    return (e[0] == 's' || e[0] == '1') ? 1 : 0;
+  }();
+  if (h->p.filter_kind) return h->p.filter_kind - 1;
+  return env >= 0 ? env : 1;
+}
+
+size_t any_qimg_bytes(int32_t nq) {
+  const size_t a = filter_qimg_bytes(nq), b = spec_qimg_bytes(nq);
+  return a > b ? a : b;
+}
+
+// query images + bounds of one batch with the chosen filter form
+int run_filter(rsx_sc *h, const QueryView &q, int64_t n_items, float *lb, int64_t ld, const FilterPlanInput *plan,
+               hipStream_t s) {
+  const DbView db = db_view(h);
+  if (plan) RSX_TRY(h->f_plan.reserve(filter_plan_bytes(n_items), s, false));
+  if (filter_kind_of(h) == 1) {
+    h->prof_kernel = spec_filter_kernel_name();
+    RSX_TRY(launch_spec_query_images(q.desc, q.norm, q.nq, h->f_qimg.p, s));
+    const int32_t *qmin = nullptr;
+    const int64_t *cum = nullptr;
+    if (plan) RSX_TRY(launch_filter_plan(db, *plan, q.nq, n_items, 4, h->f_plan.p, &qmin, &cum, s));
+    ProfScope ps(&h->prof, s);
+    RSX_TRY(launch_spec_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, qmin, cum, s));
+    ps.stop();
+    return RSX_OK;
+  }
+  h->prof_kernel = filter_kernel_name();
+  RSX_TRY(launch_query_images(q.desc, q.norm, q.nq, h->f_qimg.p, s));
+  ProfScope ps(&h->prof, s);
+  RSX_TRY(launch_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, plan, plan ? h->f_plan.p : nullptr, s));
+  ps.stop();
+  return RSX_OK;
+}
+
 // query batch size the filter workspaces are sized for (<= 1 GiB of bounds)
 int64_t filter_batch(int64_t n_items, int64_t nq) {
   const int64_t ld = (n_items + 31) / 32 * 32;
@@ -174,7 +227,7 @@ int64_t filter_batch(int64_t n_items, int64_t nq) {
 
 int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
   const int64_t ld = (n_items + 31) / 32 * 32;
-  RSX_TRY(h->f_qimg.reserve(filter_qimg_bytes((int32_t)qb), s, false));
+  RSX_TRY(h->f_qimg.reserve(any_qimg_bytes((int32_t)qb), s, false));
   RSX_TRY(h->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
   RSX_TRY(h->f_cand.reserve((size_t)qb * RESCORE_SHORTLIST_CAP * sizeof(RescoreEntry), s, false));
   RSX_TRY(h->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
@@ -189,14 +242,10 @@ int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_
   const DbView db = db_view(h);
   const int64_t ld = (n_items + 31) / 32 * 32;
   float *lb = h->f_lb.as<float>();
-  RSX_TRY(launch_query_images(q.desc, q.norm, q.nq, h->f_qimg.p, s));
   {
-    ProfScope ps(&h->prof, s);
     FilterPlanInput plan{n_eligible, elig};
     const bool planned = elig_monotone && elig != nullptr;
-    if (planned) RSX_TRY(h->f_plan.reserve(filter_plan_bytes(n_items), s, false));
-    RSX_TRY(launch_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, planned ? &plan : nullptr, planned ? h->f_plan.p : nullptr, s));
-    ps.stop();
+    RSX_TRY(run_filter(h, q, n_items, lb, ld, planned ? &plan : nullptr, s));
   }
   return launch_select(db, lb, ld, n_items, q.nq, n_eligible, elig, first_target, h->f_cand.as<RescoreEntry>(),
                        h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), s);
@@ -217,7 +266,6 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
                       int32_t k, rsx_sc_hit *d_out, hipStream_t s, bool elig_monotone) {
   const int64_t qb = filter_batch(n_items, qv.nq);
   RSX_TRY(filter_reserve(h, n_items, qb, s));
-  h->prof_kernel = filter_kernel_name();
   for (int64_t b0 = 0; b0 < qv.nq; b0 += qb) {
     const int32_t bn = (int32_t)((qv.nq - b0 < qb) ? (qv.nq - b0) : qb);
     QueryView q = qv;
@@ -337,6 +385,7 @@ int rsx_sc_default_params(rsx_sc_params *p) {
   p->shard_world = 1;
   p->capacity_hint = 1024;
   p->filter_mode = 0;
+  p->filter_kind = 0;
   return RSX_OK;
 }
 
@@ -354,6 +403,7 @@ int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) {
     return fail(RSX_ERR_BAD_ARG, "kernels are specialised for SEARCH_RADIUS 3 (search_ratio 0.1, SC.h:96)");
   if (d.tree_making_period < 1 || d.num_exclude_recent < 0) return fail(RSX_ERR_BAD_ARG, "bad detector params");
   if (d.filter_mode < 0 || d.filter_mode > 2) return fail(RSX_ERR_BAD_ARG, "filter_mode must be 0 (auto), 1 (off) or 2 (force)");
+  if (d.filter_kind < 0 || d.filter_kind > 2) return fail(RSX_ERR_BAD_ARG, "filter_kind must be 0 (auto), 1 (direct) or 2 (spectral)");
   int ndev = rsx_device_count();
   if (ndev <= 0) return fail(RSX_ERR_NO_DEVICE, "no HIP device visible (librsx has no CPU fallback)");
   if (d.device < 0 || d.device >= ndev) return fail(RSX_ERR_NO_DEVICE, "device %d out of range (%d visible)", d.device, ndev);
@@ -378,7 +428,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
@@ -435,8 +485,7 @@ int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes,
     RSX_TRY(launch_build(h->pts_ws.p, (int64_t)n, (int64_t)stride_bytes, h->p.lidar_height, h->p.max_radius,
                          h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS,
                          h->norm.as<double>() + slot * NS, h->rkey.as<float>() + slot * NR, h->stream));
-    RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, 1, h->hn.p, h->cmask.as<uint64_t>(), h->stream));
-    RSX_HIP(hipStreamSynchronize(h->stream));  // caller may reuse pts; entry visible to detect()
+    RSX_TRY(build_db_images(h, slot, 1, h->stream));  // synchronises: caller may reuse pts; entry visible to detect()
     h->n_local = slot + 1;
   }
   h->n_global = g + 1;
@@ -465,8 +514,7 @@ int rsx_sc_add_points_downsampled(rsx_sc *h, rsx_voxelgrid *vg, const void *pts,
     RSX_TRY(launch_build(d_ds ? static_cast<const void *>(d_ds) : h->desc.p, nds, 16, h->p.lidar_height, h->p.max_radius,
                          h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
                          h->rkey.as<float>() + slot * NR, h->stream));
-    RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, 1, h->hn.p, h->cmask.as<uint64_t>(), h->stream));
-    RSX_HIP(hipStreamSynchronize(h->stream));
+    RSX_TRY(build_db_images(h, slot, 1, h->stream));
     h->n_local = slot + 1;
   }
   h->n_global = g + 1;
@@ -489,8 +537,7 @@ static int add_f32_locked(rsx_sc *h, const float *src, int64_t n, bool src_is_de
                              src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     RSX_TRY(launch_keys(dst, count, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
                         h->rkey.as<float>() + slot * NR, s));
-    RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->hn.p, h->cmask.as<uint64_t>(), s));
-    RSX_HIP(hipStreamSynchronize(s));
+    RSX_TRY(build_db_images(h, slot, count, s));
     h->n_local = slot + count;
   }
   h->n_global = g0 + n;
@@ -687,7 +734,6 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
     if (first < 8) first = 8;
     if (first > 128) first = 128;
     RSX_TRY(filter_reserve(h, items, nq, s));
-    h->prof_kernel = filter_kernel_name();
     RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, s, elig_monotone != 0));
     RSX_TRY(rescore(h, qv, items, n_elig, d_q_elig, 0, 1, nullptr, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));
   } else {
@@ -785,10 +831,9 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
   RSX_HIP(hipMemcpyAsync(h->q_desc.p, q_descs, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, s));
   QueryView qv;
   RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), nq, s, &qv));
-  RSX_TRY(h->f_qimg.reserve(filter_qimg_bytes(nq), s, false));
+  RSX_TRY(h->f_qimg.reserve(any_qimg_bytes(nq), s, false));
   RSX_TRY(h->f_lb.reserve((size_t)nq * ld * sizeof(float), s, false));
-  RSX_TRY(launch_query_images(qv.desc, qv.norm, nq, h->f_qimg.p, s));
-  RSX_TRY(launch_filter(db_view(h), h->f_qimg.p, nq, n, h->f_lb.as<float>(), ld, nullptr, nullptr, s));
+  RSX_TRY(run_filter(h, qv, n, h->f_lb.as<float>(), ld, nullptr, s));
   RSX_HIP(hipMemcpy2DAsync(out_lb, (size_t)n * sizeof(float), h->f_lb.p, (size_t)ld * sizeof(float), (size_t)n * sizeof(float),
                            (size_t)nq, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));

@@ -646,7 +646,7 @@ __global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict_
 // tile-block tb (128 entries, first global index g0) is invisible to every query q with limit(q) <= g0,
 // and those queries form a prefix [0, tb_qmin[tb]).  tb_cum = exclusive prefix sums of nq - tb_qmin.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void sc_filter_plan_kernel(Elig el, int32_t nq, int64_t n_items,
+__global__ __launch_bounds__(1024) void sc_filter_plan_kernel(Elig el, int32_t nq, int64_t n_items, int32_t qgroup,
                                                               int32_t *__restrict__ tb_qmin, int64_t *__restrict__ tb_cum) {
   __shared__ long long sh[1024];
   const int64_t ntb = (((n_items + 31) >> 5) + 3) >> 2;
@@ -668,8 +668,8 @@ __global__ __launch_bounds__(1024) void sc_filter_plan_kernel(Elig el, int32_t n
         if (lim > g0) hi = mid;
         else lo = mid + 1;
       }
-      tb_qmin[tb] = lo;
-      items = nq - lo;
+      tb_qmin[tb] = lo / qgroup;  // in units of qgroup queries (a group that straddles the limit is kept whole)
+      items = (nq + qgroup - 1) / qgroup - lo / qgroup;
     }
     sh[t] = items;
     __syncthreads();
@@ -688,7 +688,15 @@ __global__ __launch_bounds__(1024) void sc_filter_plan_kernel(Elig el, int32_t n
 
 }  // namespace
 
-double filter_eps() { return 1.25e-3; }
+double filter_eps() {
+  // RSX_SC_FILTER_EPS can only LOOSEN the bound (experiments on how the exact stage grows with eps)
+  static const double eps = [] {
+    const char *e = getenv("RSX_SC_FILTER_EPS");
+    const double v = e ? atof(e) : 0.0;
+    return v > 1.25e-3 ? v : 1.25e-3;
+  }();
+  return eps;
+}
 
 size_t filter_qimg_bytes(int32_t nq) { return (size_t)nq * FILTER_QIMG_BYTES + 1024; }
 
@@ -714,6 +722,19 @@ const char *filter_kernel_name() { return "sc_filter_kernel"; }
 size_t filter_plan_bytes(int64_t n_items) {
   const int64_t ntb = (((n_items + 31) / 32) + 3) / 4;
   return (size_t)(ntb + 1) * sizeof(int64_t) + (size_t)ntb * sizeof(int32_t) + 64;
+}
+
+int launch_filter_plan(const DbView &db, const FilterPlanInput &plan, int32_t nq, int64_t n_items, int32_t qgroup,
+                       void *plan_ws, const int32_t **tb_qmin, const int64_t **tb_cum, hipStream_t s) {
+  const int64_t ntb = (((n_items + 31) / 32) + 3) / 4;
+  int64_t *cum = static_cast<int64_t *>(plan_ws);
+  int32_t *qmin = reinterpret_cast<int32_t *>(cum + ntb + 1);
+  const Elig el{db.idx_base, db.idx_stride, plan.n_eligible < 0 ? INT64_MAX : plan.n_eligible, plan.q_elig};
+  hipLaunchKernelGGL(sc_filter_plan_kernel, dim3(1), dim3(1024), 0, s, el, nq, n_items, qgroup, qmin, cum);
+  RSX_HIP(hipGetLastError());
+  *tb_qmin = qmin;
+  *tb_cum = cum;
+  return RSX_OK;
 }
 
 int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
@@ -749,13 +770,7 @@ int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_item
   a.tb_cum = nullptr;
   unsigned grid = (unsigned)nblk;
   if (plan && plan_ws) {
-    const int64_t ntb = (ntiles + 3) / 4;
-    int64_t *cum = static_cast<int64_t *>(plan_ws);
-    int32_t *qmin = reinterpret_cast<int32_t *>(cum + ntb + 1);
-    const Elig el{db.idx_base, db.idx_stride, plan->n_eligible < 0 ? INT64_MAX : plan->n_eligible, plan->q_elig};
-    hipLaunchKernelGGL(sc_filter_plan_kernel, dim3(1), dim3(1024), 0, s, el, nq, n_items, qmin, cum);
-    a.tb_qmin = qmin;
-    a.tb_cum = cum;
+    RSX_TRY(launch_filter_plan(db, *plan, nq, n_items, 1, plan_ws, &a.tb_qmin, &a.tb_cum, s));
     grid = (unsigned)n_cu;  // the total is only known on the device: every workgroup takes total / n_cu
   }
   hipLaunchKernelGGL(sc_filter_kernel, dim3(grid), dim3(256), lds, s, a);

@@ -21,6 +21,7 @@ struct DbView {
   const float *rkey;   // [n_local][20] ring keys as float (SC.cpp:198-211 + 62-66)
   const void *hnT;     // filter image: column-normalised fp16, tile-major (sc_filter.hip); 2400 B per entry
   const uint64_t *cmask;  // [n_local] bit j = column j has a non-zero norm; bit 63 = non-finite element
+  const void *spT;     // spectral filter image: fp16 Z15 spectra, tile-major (sc_spec.hip); 2432 B per entry
   int64_t n_local;
   int64_t idx_base;    // global index of local slot s = idx_base + s * idx_stride
   int64_t idx_stride;
@@ -109,10 +110,24 @@ struct FilterPlanInput {
   const int64_t *q_elig;
 };
 size_t filter_plan_bytes(int64_t n_items);
+// the plan itself (device): tb_qmin in units of `qgroup` queries (1: direct filter, 4: spectral filter's query
+// tiles), tb_cum = exclusive prefix sums of ceil(nq / qgroup) - tb_qmin; both inside plan_ws
+int launch_filter_plan(const DbView &db, const FilterPlanInput &plan, int32_t nq, int64_t n_items, int32_t qgroup,
+                       void *plan_ws, const int32_t **tb_qmin, const int64_t **tb_cum, hipStream_t s);
 int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
                   const FilterPlanInput *plan, void *plan_ws, hipStream_t s);
 const char *pair_kernel_name();
 const char *filter_kernel_name();
+
+// ---- spectral form of the filter (sc_spec.hip): same bounds contract, ~7x fewer MFMAs ----
+constexpr int SPEC_QIMG_BYTES = 10368;
+constexpr int SPEC_DB_BYTES_PER_ENTRY = 2432;
+size_t spec_qimg_bytes(int32_t nq);
+int launch_spec_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *spT, hipStream_t s);
+int launch_spec_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, hipStream_t s);
+int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
+                       const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s);
+const char *spec_filter_kernel_name();
 
 // optional hipEvent bracket around the dominant (pair) kernel
 struct PairProfiler {

@@ -15,6 +15,7 @@ from navtech_radar_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 FORCE, OFF = 2, 1
+FILTER_KERNELS = ("sc_filter_kernel", "sc_spec_filter_kernel")
 
 
 @pytest.fixture(scope="module")
@@ -22,6 +23,15 @@ def sc():
     from navtech_radar_slam_amd import _rsx, scancontext
     assert _rsx.device_count() >= 1, "no HIP device: GPU tests must run on the MI355X box"
     return scancontext
+
+
+@pytest.fixture(autouse=True, params=["direct", "spectral"])
+def filter_kind(request):
+    """every test of this module runs with both forms of the filter (sc_filter.hip / sc_spec.hip)"""
+    from navtech_radar_slam_amd import _rsx
+    _rsx.default_filter_kind = _rsx.KIND_DIRECT if request.param == "direct" else _rsx.KIND_SPECTRAL
+    yield request.param
+    _rsx.default_filter_kind = _rsx.KIND_AUTO
 
 
 def all_shift_bound(q, descs):
@@ -59,7 +69,9 @@ def make_db(seed, n, binary):
 
 
 @pytest.mark.parametrize("binary", [True, False])
-def test_filter_bounds(sc, oracle, binary):
+def test_filter_bounds(sc, oracle, binary, filter_kind):
+    if filter_kind != "direct":
+        pytest.skip("two-sided bound of the direct form; the spectral form: test_gpu_sc_spec.py")
     n, nq = 1000 + 13, 20                                # not a multiple of 32: ragged last tile
     descs = make_db(100 + binary, n, binary)
     rng = np.random.default_rng(9)
@@ -91,7 +103,7 @@ def test_filter_bounds(sc, oracle, binary):
 
 @pytest.mark.parametrize("binary", [True, False])
 @pytest.mark.parametrize("k", [1, 10, 32])
-def test_filtered_query_matches_oracle(sc, oracle, binary, k):
+def test_filtered_query_matches_oracle(sc, oracle, binary, k, filter_kind):
     n, nq = 2500 + 5, 40
     descs = make_db(7 + binary, n, binary)
     rng = np.random.default_rng(11)
@@ -103,7 +115,7 @@ def test_filtered_query_matches_oracle(sc, oracle, binary, k):
     o = oracle.Manager()
     o.add_descriptors(descs.astype(np.float64))
     got = g.query(queries, k=k, n_eligible=n - 30)
-    assert g.profiled_kernel_name() == "sc_filter_kernel"
+    assert g.profiled_kernel_name() == ("sc_filter_kernel" if filter_kind == "direct" else "sc_spec_filter_kernel")
     for qi in range(nq):
         want = o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=4)
         assert np.array_equal(got[qi], want), f"query {qi}"
@@ -124,7 +136,7 @@ def test_filtered_equals_unfiltered_10k(sc, oracle):
     b.add_descriptors_f32(descs)
     ga = a.query(queries, k=k, n_eligible=n - 30)
     gb = b.query(queries, k=k, n_eligible=n - 30)
-    assert a.profiled_kernel_name() == "sc_filter_kernel" and b.profiled_kernel_name() == "sc_pair_kernel"
+    assert a.profiled_kernel_name() in FILTER_KERNELS and b.profiled_kernel_name() == "sc_pair_kernel"
     assert np.array_equal(ga, gb)
     assert np.array_equal(ga["index"][:, 0], src) and np.array_equal(ga["shift"][:, 0], rot)
     o = oracle.Manager()
@@ -136,7 +148,7 @@ def test_filtered_equals_unfiltered_10k(sc, oracle):
     c = sc.SCManager(capacity_hint=n)
     c.add_descriptors_f32(descs)
     assert np.array_equal(c.query(queries, k=k, n_eligible=n - 30), ga)
-    assert c.profiled_kernel_name() == "sc_filter_kernel"
+    assert c.profiled_kernel_name() in FILTER_KERNELS
 
 
 def test_filtered_edge_cases(sc, oracle):
@@ -278,7 +290,7 @@ def test_full_size_100k_properties(sc, oracle):
     g.add_descriptors_f32(descs)
     assert len(g) == n
     got = g.query(queries, k=k, n_eligible=n - 30)
-    assert g.profiled_kernel_name() == "sc_filter_kernel"
+    assert g.profiled_kernel_name() in FILTER_KERNELS
     assert np.array_equal(got["index"][:, 0], src) and np.array_equal(got["shift"][:, 0], rot)
     assert np.all(np.abs(got["dist"][:, 0]) < 1e-15)
     assert np.all(np.diff(got["dist"], axis=1) >= 0) and np.all(got["dist"] < 1e7)
@@ -375,7 +387,7 @@ def test_streaming_slam_sharded(sc, oracle):
     assert found >= 10 and sum(s.local_size for s in shards) == n
 
 
-def test_filter_bounds_adversarial(sc, oracle):
+def test_filter_bounds_adversarial(sc, oracle, filter_kind):
     """The bound must hold for every pair also on descriptors built to stress the fp16 filter: columns
     mixing magnitudes over six decades, negative values, single-element columns, many empty columns,
     huge and tiny overall scales."""
@@ -404,7 +416,10 @@ def test_filter_bounds_adversarial(sc, oracle):
         want = all_shift_bound(queries[qi], descs)
         fin = np.isfinite(want)
         assert np.all(lb[qi][~fin] == np.inf)
-        worst = max(worst, np.abs(lb[qi][fin] - want[fin]).max())
+        if filter_kind == "direct":
+            worst = max(worst, np.abs(lb[qi][fin] - want[fin]).max())       # two-sided: it IS the all-shift minimum
+        else:
+            worst = max(worst, (lb[qi][fin] - eps - want[fin]).max() + eps)   # one-sided: never above it
         hit = dist < 1e7
         assert np.all(lb[qi][hit].astype(np.float64) - eps <= dist[hit]), f"q={qi}: not a lower bound"
     assert worst <= eps, worst

@@ -1,0 +1,165 @@
+"""Spectral form of the lower-bound filter (csrc/sc_spec.hip) on a real MI355X: its bounds are valid lower
+bounds of the fp64 all-shift minimum and close to it, and every query path gives the oracle's results
+with filter_kind = spectral exactly as with the direct filter."""
+import numpy as np
+import pytest
+
+from test_gpu_sc_filter import all_shift_bound, make_db
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    from navtech_radar_slam_amd import scancontext
+    return scancontext
+
+
+@pytest.fixture(scope="module")
+def rsx():
+    from navtech_radar_slam_amd import _rsx
+    return _rsx
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from navtech_radar_slam_amd import synth
+    return synth
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    from oracle import pyoracle
+    return pyoracle
+
+
+def n_cols(d):
+    return (np.sqrt((d.reshape(-1, 60, 20).astype(np.float64) ** 2).sum(2)) > 0).sum(1)
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_spectral_bounds(sc, rsx, synth, binary):
+    n, nq = 1000 + 13, 24                                # ragged last tile, 6 query tiles
+    descs = make_db(100 + binary, n, binary)
+    rng = np.random.default_rng(9)
+    queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+    queries[::2, rng.integers(0, 1200, 20)] = 0
+    queries[1] = 0                                       # empty query
+    queries[3].reshape(60, 20)[7:31] = 0                 # 24 empty sectors: wide [n_lo, n_hi]
+    g = sc.SCManager(filter_kind=rsx.KIND_SPECTRAL)
+    g.add_descriptors_f32(descs)
+    eps = g.filter_eps()
+    lb = g.filter_bounds(queries)
+    ne = n_cols(descs)
+    worst_tight = 0.0
+    for qi in range(nq):
+        want = all_shift_bound(queries[qi], descs)
+        fin = np.isfinite(want)
+        assert np.all(lb[qi][~fin] == np.inf), "no effective column at any shift -> +inf"
+        if not fin.any():
+            continue
+        assert (lb[qi][fin] - eps - want[fin]).max() <= 0.0, f"q={qi}: not a lower bound"
+        # tightness where S >= 0 (negative heights are clamped to S = 0: valid, looser): within the spectral
+        # error budget 2.5e-3 sqrt(nq ne) / n_lo plus the reciprocal bound's excess
+        nq_c = int(n_cols(queries[qi])[0])
+        nlo = np.maximum(nq_c + ne - 60, 1)
+        nhi = np.maximum(np.minimum(nq_c, ne), nlo)
+        slack = 2.5e-3 * np.sqrt(nq_c * ne) / nlo + eps + (nhi - nlo) ** 3 / (4.0 * nlo * nhi ** 2) + 1e-5
+        ok = fin & (want <= 1.0)
+        gap = want[ok] - (lb[qi][ok] - eps)
+        assert np.all(gap <= slack[ok] + eps), f"q={qi}: bound looser than the budget"
+        if nq_c >= 50:
+            worst_tight = max(worst_tight, float(np.max(gap - 2.5e-3 * np.sqrt(nq_c * ne[ok]) / nlo[ok])))
+    assert worst_tight < 2e-3      # observed error is far inside the budget
+
+
+@pytest.mark.parametrize("k", [1, 10, 32])
+def test_spectral_query_matches_oracle(sc, rsx, synth, oracle, k):
+    n, nq = 2500 + 5, 41
+    descs = make_db(7, n, True)
+    rng = np.random.default_rng(3)
+    queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+    queries[::3, rng.integers(0, 1200, 40)] = 0
+    queries[5] = 0
+    g = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+    g.add_descriptors_f32(descs)
+    got = g.query(queries, k=k, n_eligible=n - 30)
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    for qi in range(nq):
+        assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=4)), qi
+
+
+def test_spectral_equals_direct_10k(sc, rsx, synth):
+    n, nq, k = 10_000, 300, 10
+    descs = synth.random_descriptors(42, n, binary=True)
+    rng = np.random.default_rng(43)
+    queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+    queries[::4, rng.integers(0, 1200, 60)] = 0
+    res = []
+    for kind in (rsx.KIND_DIRECT, rsx.KIND_SPECTRAL):
+        g = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=kind, capacity_hint=n)
+        g.add_descriptors_f32(descs)
+        res.append(g.query(queries, k=k))
+    off = sc.SCManager(filter_mode=rsx.FILTER_OFF, capacity_hint=n)
+    off.add_descriptors_f32(descs)
+    want = off.query(queries, k=k)
+    assert np.array_equal(res[0], want)
+    assert np.array_equal(res[1], want)
+
+
+def test_spectral_self_queries_and_shards(sc, rsx, synth):
+    """triangular plan in query-tile units + the staged protocol over 3 shard handles"""
+    import torch
+    n, k, excl = 3017, 10, 30
+    descs = make_db(55, n, True)
+    off = sc.SCManager(filter_mode=rsx.FILTER_OFF)
+    off.add_descriptors_f32(descs)
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    st = tstream.cuda_stream
+    want_d = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+    off.query_self_device(0, n, k, want_d.data_ptr(), exclude_recent=excl, stream=st)
+    torch.cuda.synchronize()
+    want = want_d.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)
+    g = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+    g.add_descriptors_f32(descs)
+    out = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+    for first, cnt in ((0, n), (1001, 777)):
+        out.zero_()
+        g.query_self_device(first, cnt, k, out.data_ptr(), exclude_recent=excl, stream=st)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)[:cnt]
+        assert np.array_equal(got, want[first:first + cnt]), (first, cnt)
+    world = 3
+    shards = [sc.SCManager(shard_rank=r, shard_world=world, filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+              for r in range(world)]
+    for s in shards:
+        s.add_descriptors_f32(descs)
+    dq = torch.from_numpy(descs).cuda()
+    lim = torch.clamp(torch.arange(n, dtype=torch.int64, device="cuda") - excl, min=0)
+    parts = torch.zeros((world, n, k, 2), dtype=torch.float64, device="cuda")
+    glob = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+    finals = torch.zeros((world, n, k, 2), dtype=torch.float64, device="cuda")
+    for r, s in enumerate(shards):
+        s.query_stage1_device(dq.data_ptr(), n, k, parts[r].data_ptr(), stream=st, q_elig_ptr=lim.data_ptr(), elig_monotone=True)
+    shards[0].merge_device(parts.data_ptr(), world, n, k, glob.data_ptr(), stream=st)
+    for r, s in enumerate(shards):
+        s.query_stage2_device(n, k, glob.data_ptr(), finals[r].data_ptr(), stream=st)
+    shards[0].merge_device(finals.data_ptr(), world, n, k, out.data_ptr(), stream=st)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k), want)
+    torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_default_kind_is_spectral(sc, rsx, synth):
+    n = 2000
+    holes = synth.random_descriptors(5, n, binary=True)
+    g = sc.SCManager(filter_mode=rsx.FILTER_FORCE)
+    g.add_descriptors_f32(holes)
+    g.query(holes[:16], k=3)
+    assert g.profiled_kernel_name() == "sc_spec_filter_kernel"
+    g2 = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_DIRECT)
+    g2.add_descriptors_f32(holes)
+    g2.query(holes[:16], k=3)
+    assert g2.profiled_kernel_name() == "sc_filter_kernel"
