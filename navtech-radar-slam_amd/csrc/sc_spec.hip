@@ -27,8 +27,9 @@
 //             scaled by 15/16 so that the weight of C_0 (1/16) is exact in fp16.
 // n_eff(k) (the number of columns that are non-empty in both images at shift k, SC.cpp:78-88) is a
 // circular cross-correlation too, of the two 60-bit column masks: exact small integers, computed by the
-// matrix cores as well (v_mfma_i32_32x32x32_i8: A = circulant of the query mask, rows ordered like the
-// shifts of the stage-2 output; B = the entries' mask bytes; 4 MFMAs per query).  The division
+// matrix cores as well (v_mfma_f32_32x32x64_f8f6f4 on fp8 0/1 bytes, K = 64 in one instruction: A = circulant
+// of the query mask, rows ordered like the shifts of the stage-2 output; B = the entries' mask bytes; 2 MFMAs
+// per query, fp32 result).  The division
 // S_k / n_eff(k) is replaced by a multiplication with a quadratic upper bound of 1/n on
 // [n_lo, n_hi] = [n_q + n_e - 60, min(n_q, n_e)] (chord minus c (n-n_lo)(n_hi-n), c = 1/(n_lo n_hi^2): exact
 // at both ends, relative excess < (n_hi-n_lo)^3 / (4 n_lo n_hi^2), ~1e-4 for the usual few empty sectors),
@@ -49,10 +50,11 @@
 // Mapping: one wave per 32 entries (304 registers of entry spectra, resident), 4 waves = 128 entries per
 // block, queries streamed through LDS in tiles of 4 (one tile per phase, double buffered, global_load_lds).
 // Per (4 queries x 32 entries): 76 stage-1 MFMAs (one ds_read_b128 A fragment each) + 16 stage-2 MFMAs +
-// 16 mask MFMAs, against 600 MFMAs for the same pairs in the direct filter.
+// 8 (double-length fp8) mask MFMAs, against 600 MFMAs for the same pairs in the direct filter.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdio>
 #include <cstdint>
 #include <cstdlib>
 #include <type_traits>
@@ -101,7 +103,36 @@ constexpr int SP_QPT = 4;                           // queries per MFMA tile
 constexpr int SP_TPP = 1;                           // tiles per LDS phase
 constexpr int SP_QPP = SP_QPT * SP_TPP;
 constexpr int SP_PHASE_BYTES = SP_QPP * SP_QS;      // 41472 = 40.5 KiB
-constexpr int SP_B_VGPR = 12;                       // B fragments kept in VGPRs; the rest (64 x 4 registers) live in AGPRs
+#ifndef SP_OPT_NBUF
+#define SP_OPT_NBUF 3
+#endif
+#ifndef SP_OPT_LOCKSTEP
+#define SP_OPT_LOCKSTEP 0   // 1: one unit per workgroup, query ranges outermost (no gain measured: the query stream is not L2-bound)
+#endif
+constexpr int SP_NBUF = SP_OPT_NBUF;                // LDS tile buffers: the DMA runs SP_NBUF - 1 tiles ahead
+static_assert(SP_PHASE_BYTES / 1024 / 4 + 1 <= 11, "wait_vmcnt_le covers <= 11 DMA instructions per wave and tile");
+#ifndef SP_OPT_BV
+#define SP_OPT_BV 12   // VGPR-resident B fragments are SP_B_LDS .. SP_OPT_BV-1
+#endif
+constexpr int SP_B_VGPR = SP_OPT_BV;  // B fragments kept in VGPRs; the rest live in AGPRs
+// 76 B fragments = 304 registers: 64 fragments fill the 256 AGPRs, 8 sit in VGPRs, and the first SP_B_LDS
+// (the K-steps of f = 0) are parked in LDS (6 KiB per wave) and fetched with the A fragments of each tile
+// -- left to the register allocator they were spilled to scratch and reloaded every tile, and every scratch
+// reload drains the vmcnt queue (DMA and bound stores in flight)
+#ifndef SP_OPT_BLDS
+#define SP_OPT_BLDS 6
+#endif
+constexpr int SP_B_LDS = SP_OPT_BLDS;
+constexpr int SP_BPARK_OFF = SP_NBUF * SP_PHASE_BYTES;       // after the tile buffers
+constexpr int SP_LDS_BYTES = SP_BPARK_OFF + 4 * SP_B_LDS * 1024;
+static_assert(SP_LDS_BYTES <= 160 * 1024, "LDS budget");
+
+// -DRSX_SPEC_INSTRUMENT=1 compiles in the timing experiments (RSX_SPEC_DBG: skip parts of the tile) and the
+// per-region s_memtime profile (RSX_SPEC_PROF); they cost registers, so normal builds leave them out
+#ifndef RSX_SPEC_INSTRUMENT
+#define RSX_SPEC_INSTRUMENT 0
+#endif
+constexpr bool kInstr = RSX_SPEC_INSTRUMENT != 0;
 
 constexpr float kSpecEps = 2.5e-3f;
 constexpr u64 kNonFinite = 1ull << 63;
@@ -240,7 +271,7 @@ __global__ __launch_bounds__(256) void sc_spec_query_kernel(const float *__restr
       const int j = byte0 / SP_MASK_COPY, i0 = byte0 - j * SP_MASK_COPY;  // 112 = 7 chunks: no chunk straddles copies
       unsigned w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-      for (int i = 0; i < 16; i++) w[i >> 2] |= (unsigned)((m >> ((j + i0 + i) % NS)) & 1ull) << (8 * (i & 3));
+      for (int i = 0; i < 16; i++) w[i >> 2] |= (unsigned)(((m >> ((j + i0 + i) % NS)) & 1ull) * 0x38ull) << (8 * (i & 3));
       o = uint4{w[0], w[1], w[2], w[3]};
     }
     if (c == SP_TAIL / 16) {
@@ -263,20 +294,43 @@ struct SpecArgs {
   const char *qimg;
   int64_t n_items;
   int32_t nq;
-  int64_t per_block;  // (tile-block, query tile) work items per workgroup (no plan)
+  int32_t unit_len;   // no plan: workgroup u = (query range u / ntb, tile-block u % ntb), unit_len query tiles per range
   float *lb;
   int64_t ld_lb;
   float eps_direct;
+  int32_t dbg;  // timing experiments (RSX_SPEC_DBG): 1 = skip the tail, 2 = skip stage 1, 4 = no DMA, 8 = no stores
+  unsigned long long *prof;  // RSX_SPEC_PROF: s_memtime sums per region of (workgroup 0, wave 0)
   const int32_t *tb_qmin;  // optional plan, in query-tile units (see sc_filter.hip)
   const int64_t *tb_cum;
 };
 
-__device__ __forceinline__ void stage_queries(const char *gsrc, char *ldst, int nbytes, int wave, int lane) {
+// global -> LDS DMA of one query tile, 1 KiB pieces dealt round-robin to the 4 waves; returns the number of
+// DMA instructions this wave issued (each counts once on vmcnt)
+__device__ __forceinline__ int stage_queries(const char *gsrc, char *ldst, int nbytes, int wave, int lane) {
   const int npieces = (nbytes + 1023) >> 10;
   for (int c = wave; c < npieces; c += 4)
     if (c * 1024 + lane * 16 < nbytes)  // nbytes is a multiple of 16; the last piece may be partial
       __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(gsrc + c * 1024 + lane * 16)),
                                        (AS3 void *)(ldst + c * 1024), 16, 0, 0);
+  return npieces > wave ? (npieces - wave + 3) >> 2 : 0;
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+  }
 }
 
 __device__ __forceinline__ half8 lds_frag(const char *p) { return *reinterpret_cast<const half8 *>(p); }
@@ -287,107 +341,276 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
   return __builtin_bit_cast(unsigned, h);
 }
 
-typedef int intx16 __attribute__((ext_vector_type(16)));
-typedef int intx4 __attribute__((ext_vector_type(4)));
+typedef int intx8 __attribute__((ext_vector_type(8)));
+typedef unsigned frag4 __attribute__((ext_vector_type(4)));  // one MFMA A fragment in flight (8 x fp16 / 16 x fp8)
 
 // per-lane constants of one segment
 struct SpecLane {
-  int dc_off, f_off;   // A-fragment offsets inside a tile of 4 query images (f = 0 / f >= 1 streams)
-  int m_off[2];        // mask-row offsets of the two n_eff M-tiles (k4 = 0,1 / 2,3)
+  unsigned dc_off, f_off;  // A-fragment offsets inside a tile of 4 query images (f = 0 / f >= 1 streams)
+  unsigned m_off[2];       // mask-row offsets of the two n_eff M-tiles (k4 = 0,1 / 2,3)
+  unsigned bpark;          // LDS byte address of this lane's parked B fragments (1 KiB apart)
   int hh;
-  half8 W;             // stage-2 A operand (inverse DFT weights)
-  intx4 Bm[2];         // this lane's entry: column-mask bytes (B operand of the n_eff MFMAs)
+  half8 W;                 // stage-2 A operand (inverse DFT weights)
+  intx8 Bm;                // this lane's entry: column-mask bytes as fp8 0 / 1 (B operand of the n_eff MFMAs)
   int n_e;
   float sqrt_ne;
   bool e_bad;
 };
 
-// one (4 queries x 32 entries) tile at LDS address `tbase`; best[q] = max_k (15/16) S_k * u(n_eff(k)),
-// u = quadratic upper bound of 1/n on [n_lo, n_hi]; rl[q] = 1/n_lo
-__device__ __forceinline__ void spec_tile(const char *tbase, const half8 (&B)[SP_FRAGS], const SpecLane &ln,
-                                          float (&best)[SP_QPT], float (&rl)[SP_QPT]) {
-  const char *dc_ptr = tbase + ln.dc_off, *f_ptr = tbase + ln.f_off;
+// A-fragment reads are issued through inline asm with hand-counted s_waitcnt (see sc_filter.hip: left to
+// the compiler every read is followed by s_waitcnt lgkmcnt(0), a full LDS round trip per MFMA).  LDS
+// returns data in issue order, so "fragment t has landed" == "at most (number of reads issued after it)
+// are outstanding".
+__device__ __forceinline__ void lds_read_frag(frag4 &dst, unsigned addr, int off) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_count() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N));
+}
+
+// region timer for RSX_SPEC_PROF (drains the LDS queue: s_memtime returns on lgkmcnt, out of order with LDS)
+__device__ __forceinline__ unsigned long long prof_now() {
+  unsigned long long t;
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+
+constexpr int SP_S1 = SP_FRAGS;   // 76 stage-1 MFMA slots per tile
+#ifndef SP_OPT_DEPTH
+#define SP_OPT_DEPTH 6
+#endif
+constexpr int SP_DEPTH = SP_OPT_DEPTH;  // A fragments in flight
+constexpr int SP_MREADS = 4;      // mask reads per query (2 M-tiles x 32 bytes)
+
+// Stage-1 slot schedule.  Two frequencies are always in progress and their MFMAs alternate, so that no MFMA
+// follows another one on the SAME accumulator with LDS reads / VALU instructions in between (that pattern
+// loses the accumulator forwarding of back-to-back dependent MFMAs: ~+40 cycles per MFMA).  When a
+// frequency finishes the next one takes its place: f0 (6 steps) and f1 start, f2 replaces f0, f3 replaces
+// f1, ...  Frequency f accumulates into acc[f % 4].
+struct S1Slot {
+  int f, s;  // frequency, K-step
+};
+struct S1Sched {
+  S1Slot slot[SP_S1];
+  int done[8];  // slot of the last MFMA of frequency f
+};
+constexpr int s1_steps(int f) { return f == 0 ? SP_DC_STEPS : SP_F_STEPS; }
+constexpr bool kS1Interleave = false;  // measured: alternating two frequencies is not faster than one after the other
+constexpr S1Sched make_s1_sched() {
+  S1Sched r{};
+  if (!kS1Interleave) {
+    int t = 0;
+    for (int f = 0; f < 8; f++) {
+      for (int st = 0; st < s1_steps(f); st++) r.slot[t++] = S1Slot{f, st};
+      r.done[f] = t - 1;
+    }
+    return r;
+  }
+  int act[2] = {0, 1}, pos[2] = {0, 0}, next_f = 2, turn = 0;
+  for (int t = 0; t < SP_S1; t++) {
+    if (act[turn] < 0) turn ^= 1;
+    r.slot[t] = S1Slot{act[turn], pos[turn]};
+    pos[turn]++;
+    if (pos[turn] == s1_steps(act[turn])) {
+      r.done[act[turn]] = t;
+      act[turn] = next_f < 8 ? next_f++ : -1;
+      pos[turn] = 0;
+    }
+    if (act[turn ^ 1] >= 0) turn ^= 1;
+  }
+  return r;
+}
+constexpr S1Sched kS1 = make_s1_sched();
+// LDS byte offset of the fragment of slot t (relative to the lane's f = 0 or f >= 1 stream base) and its B index
+constexpr int s1_off(int t) { return kS1.slot[t].f == 0 ? 32 * kS1.slot[t].s : (kS1.slot[t].f - 1) * SP_F_BYTES + 32 * kS1.slot[t].s; }
+constexpr int s1_b(int t) { return kS1.slot[t].f == 0 ? kS1.slot[t].s : SP_DC_STEPS + (kS1.slot[t].f - 1) * SP_F_STEPS + kS1.slot[t].s; }
+// fp16 packing of the finished pair G_g = (f_2g, f_2g+1): 4 j per slot from two slots after the pair is
+// complete; it must be over before f_2g+4 re-uses acc[2g % 4]
+constexpr int pack_begin(int g) { return (kS1.done[2 * g] > kS1.done[2 * g + 1] ? kS1.done[2 * g] : kS1.done[2 * g + 1]) + 2; }
+constexpr int first_slot_of(int f) {
+  for (int t = 0; t < SP_S1; t++)
+    if (kS1.slot[t].f == f) return t;
+  return SP_S1;
+}
+
+// 1/n <= u(n) = A + n (Bc + n C) on [L, H] = [n_lo, n_hi]
+struct Recip {
+  float2v A2, B2, C2;
+  float rL;
+  int n_q;
+  unsigned flags;
+  float sqrt_nq;
+};
+__device__ __forceinline__ Recip recip_setup(const char *qbase, const SpecLane &ln) {
+  const uint4 tail = *reinterpret_cast<const uint4 *>(qbase + SP_TAIL);
+  Recip r;
+  r.n_q = (int)tail.x;
+  r.flags = tail.y;
+  r.sqrt_nq = __uint_as_float(tail.z);
+  const int li = (r.n_q + ln.n_e - NS > 1) ? (r.n_q + ln.n_e - NS) : 1;
+  const int hmin = r.n_q < ln.n_e ? r.n_q : ln.n_e;
+  const float L = (float)li, H = (float)(hmin > li ? hmin : li);
+  const float rH = __builtin_amdgcn_rcpf(H), rLH = __builtin_amdgcn_rcpf(L * H);
+  const float C = rLH * rH;
+  const float A = fmaf(L + H, rLH, rH), Bc = -fmaf(C, L + H, rLH);
+  r.A2 = float2v{A, A};
+  r.B2 = float2v{Bc, Bc};
+  r.C2 = float2v{C, C};
+  r.rL = __builtin_amdgcn_rcpf(L);
+  return r;
+}
+
+// One (4 queries x 32 entries) tile at LDS byte address `tile_lds`.
+//   slots 0..75    stage 1: one MFMA per slot, fragment t+SP_DEPTH requested right after MFMA t; frequency f
+//                  accumulates into acc[f % 3], and the fp16 packing of a finished frequency pair
+//                  (P[j][g] = {C_2g, C_2g+1} of (query j/4, k4 = j%4)) is spread over the slots of the next frequency
+//   tail           per query: n_eff of the 60 shifts (2 fp8 MFMAs, K = 64), 4 stage-2 MFMAs (inverse DFT of one
+//                  k4 each), S * u(n_eff) and the running maximum in packed fp32; the mask bytes of the next
+//                  query are in flight meanwhile
+// out[q] = the bound of (query q, this lane's entry), identical in both lane halves
+#ifndef SP_OPT_PACK
+#define SP_OPT_PACK 2   // j packed per slot
+#endif
+#ifndef SP_OPT_MK2
+#define SP_OPT_MK2 0    // 1: mask bytes double buffered (no gain measured)
+#endif
+constexpr int kPackPerSlot = SP_OPT_PACK;
+constexpr int kPackSlots = 16 / kPackPerSlot;
+// three accumulator sets, frequency f -> acc[f % 3]: the pair (f_2g, f_2g+1) is packed while f_2g+2 runs and
+// must be done before f_2g+3 re-uses the set of f_2g; the hi/lo split of C_0 (in place) runs during f1
+constexpr int kAccSets = 3;
+static_assert(pack_begin(0) + kPackSlots <= first_slot_of(3) && pack_begin(1) + kPackSlots <= first_slot_of(5) &&
+                  pack_begin(2) + kPackSlots <= first_slot_of(7), "accumulators are re-used before they are packed");
+constexpr int split_begin() { return kS1.done[0] + 2; }
+static_assert(s1_b(0) == 0 && s1_b(SP_B_LDS - 1) == SP_B_LDS - 1 && SP_B_LDS <= SP_DEPTH, "the parked fragments are the first slots");
+static_assert(!kS1Interleave && split_begin() + 8 <= pack_begin(0) && split_begin() + 8 <= first_slot_of(3), "C_0 split window");
+
+__device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, const half8 (&B)[SP_FRAGS], const SpecLane &ln,
+                                          float eps_direct, float (&out)[SP_QPT], int dbg, unsigned long long *tmid) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
-  u4 P[16];  // P[j] = the stage-2 B fragment of (query j/4, k4 = j%4): parts {C_0, C_1}, {C_2, C_3}, ...
+  typedef unsigned u8v __attribute__((ext_vector_type(8)));
+  u4 P[16];
+  floatx16 acc[kAccSets];
+  frag4 ring[SP_DEPTH];
+  frag4 mk[SP_OPT_MK2 ? 2 : 1][SP_MREADS];  // mask bytes of the current (/ next) query
+  const unsigned a_dc = tile_lds + ln.dc_off, a_f = tile_lds + ln.f_off;
+  const unsigned a_m0 = tile_lds + ln.m_off[0], a_m1 = tile_lds + ln.m_off[1];
   floatx16 z;
 #pragma unroll
   for (int i = 0; i < 16; i++) z[i] = 0.0f;
-  // stage 1, f = 0 and 1
-  {
-    floatx16 a0 = z, a1 = z;
-#pragma unroll
-    for (int s = 0; s < SP_DC_STEPS; s++) a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(dc_ptr + 32 * s), B[s], a0, 0, 0, 0);
-#pragma unroll
-    for (int s = 0; s < SP_F_STEPS; s++)
-      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(f_ptr + 32 * s), B[SP_DC_STEPS + s], a1, 0, 0, 0);
-#pragma unroll
-    for (int j = 0; j < 16; j++) {
-      // C_0 as fp16 hi + lo: lanes 0..31 carry hi (k = 0), lanes 32..63 lo (k = 8); both weigh 1/16
-      const float v = a0[j];
-      const _Float16 h = (_Float16)v;
-      const float lo = v - (float)h;
-      P[j][0] = pack2(ln.hh ? lo : (float)h, a1[j]);
+
+  frag4 bx[SP_B_LDS];  // the parked B fragments
+  static_for<SP_DEPTH>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    lds_read_frag(ring[t], kS1.slot[t].f == 0 ? a_dc : a_f, s1_off(t));
+  });
+  static_for<SP_B_LDS>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    lds_read_frag(bx[t], ln.bpark, 1024 * t);
+  });
+  static_for<SP_S1>([&](auto tc) {
+    constexpr int t = decltype(tc)::value;
+    constexpr int f = kS1.slot[t].f;
+    // reads issued after fragment t's: fragments t+1 .. min(t+DEPTH-1, S1-1), plus the mask reads of query 0
+    // (issued at slots S1-4 .. S1-1, each after that slot's ring read slot is gone)
+    constexpr int younger_ring = (t + SP_DEPTH - 1 < SP_S1 ? SP_DEPTH - 1 : SP_S1 - 1 - t);
+    constexpr int younger_mask = (t > SP_S1 - SP_MREADS) ? (t - (SP_S1 - SP_MREADS)) : 0;
+    // slots 0..3 also need parked fragment t, read after the SP_DEPTH prologue fragments: younger than it are
+    // the parked fragments t+1..3 and the ring reads of slots 0..t-1
+    if constexpr (t < SP_B_LDS) lds_wait_count<SP_B_LDS - 1>();
+    else lds_wait_count<younger_ring + younger_mask>();
+    __builtin_amdgcn_sched_barrier(0);
+    const half8 af = __builtin_bit_cast(half8, ring[t % SP_DEPTH]);
+    half8 bf;
+    if constexpr (t < SP_B_LDS) bf = __builtin_bit_cast(half8, bx[t]);
+    else bf = B[s1_b(t)];
+    if constexpr (kS1.slot[t].s == 0) acc[f % kAccSets] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, z, 0, 0, 0);
+    else acc[f % kAccSets] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[f % kAccSets], 0, 0, 0);
+    if constexpr (t + SP_DEPTH < SP_S1)
+      lds_read_frag(ring[t % SP_DEPTH], kS1.slot[t + SP_DEPTH].f == 0 ? a_dc : a_f, s1_off(t + SP_DEPTH));
+    if constexpr (t >= SP_S1 - SP_MREADS) {  // mask bytes of query 0
+      constexpr int r = t - (SP_S1 - SP_MREADS);
+      lds_read_frag(mk[0][r], (r >> 1) ? a_m1 : a_m0, 16 * (r & 1));
     }
+    if constexpr (t >= split_begin() && t < split_begin() + 8) {
+      // C_0 as fp16 hi + lo: lanes 0..31 carry hi (k = 0), lanes 32..63 lo (k = 8); both weigh 1/16.  hi = C_0
+      // truncated to 11 significant bits (exact in fp16), lo = the rest (rounded to fp16 by the packing)
+#pragma unroll
+      for (int j = 2 * (t - split_begin()); j < 2 * (t - split_begin()) + 2; j++) {
+        const float v = acc[0][j];
+        const float hi = __uint_as_float(__float_as_uint(v) & 0xffffe000u);
+        acc[0][j] = ln.hh ? v - hi : hi;
+      }
+    }
+    // packing of finished frequency pairs, spread over the slots of the following frequency
+    static_for<3>([&](auto gc) {
+      constexpr int g = decltype(gc)::value;
+      if constexpr (t >= pack_begin(g) && t < pack_begin(g) + kPackSlots) {
+#pragma unroll
+        for (int j = kPackPerSlot * (t - pack_begin(g)); j < kPackPerSlot * (t - pack_begin(g) + 1); j++) {
+          P[j][g] = pack2(acc[(2 * g) % kAccSets][j], acc[(2 * g + 1) % kAccSets][j]);
+        }
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+  });
+  if (kInstr && tmid) {
+    asm volatile("" : "+v"(acc[0]), "+v"(acc[1]));
+    *tmid = prof_now();
   }
 #pragma unroll
-  for (int g = 1; g < 4; g++) {
-    floatx16 a0 = z, a1 = z;
-#pragma unroll
-    for (int s = 0; s < SP_F_STEPS; s++) {
-      a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(f_ptr + (2 * g - 1) * SP_F_BYTES + 32 * s),
-                                                  B[SP_DC_STEPS + (2 * g - 1) * SP_F_STEPS + s], a0, 0, 0, 0);
+  for (int j = 0; j < 16; j++) P[j][3] = pack2(acc[6 % kAccSets][j], acc[7 % kAccSets][j]);
+
+  static_for<SP_QPT>([&](auto qc) {
+    constexpr int q = decltype(qc)::value;
+    constexpr int cur = SP_OPT_MK2 ? (q & 1) : 0;
+    if constexpr (SP_OPT_MK2 && q + 1 < SP_QPT) {
+      static_for<SP_MREADS>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        lds_read_frag(mk[(q + 1) & 1][r], (r >> 1) ? a_m1 : a_m0, (q + 1) * SP_QS + 16 * (r & 1));
+      });
+      lds_wait_count<SP_MREADS>();
+    } else {
+      lds_wait_count<0>();
     }
-#pragma unroll
-    for (int s = 0; s < SP_F_STEPS; s++) {
-      a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lds_frag(f_ptr + (2 * g) * SP_F_BYTES + 32 * s),
-                                                  B[SP_DC_STEPS + (2 * g) * SP_F_STEPS + s], a1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int j = 0; j < 16; j++) P[j][g] = pack2(a0[j], a1[j]);
-  }
-  // per query: n_eff of the 60 shifts (2 x 2 int8 MFMAs), inverse DFT of every k4 (stage 2), running maximum
-#pragma unroll
-  for (int q = 0; q < SP_QPT; q++) {
-    intx16 nacc[2];
+    __builtin_amdgcn_sched_barrier(0);
+    const Recip r = recip_setup(tbase + q * SP_QS, ln);
+    float m = 0.0f;  // rows 15..31 of the weight matrix are zero anyway (S >= 0 or clamped: valid)
+    floatx16 nacc[2];
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
-      intx16 acc;
-#pragma unroll
-      for (int i = 0; i < 16; i++) acc[i] = 0;
-#pragma unroll
-      for (int s = 0; s < 2; s++)
-        acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const intx4 *>(tbase + q * SP_QS + ln.m_off[mt] + 32 * s),
-                                                    ln.Bm[s], acc, 0, 0, 0);
-      nacc[mt] = acc;
+      const frag4 lo = mk[cur][2 * mt], hi = mk[cur][2 * mt + 1];
+      const u8v am = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      nacc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), ln.Bm, z, 0, 0, 0, 0, 0, 0);
     }
-    // 1/n <= u(n) = A + n (Bc + n C) on [L, H]
-    const uint4 tail = *reinterpret_cast<const uint4 *>(tbase + q * SP_QS + SP_TAIL);
-    const int n_q = (int)tail.x;
-    const int li = (n_q + ln.n_e - NS > 1) ? (n_q + ln.n_e - NS) : 1;
-    const int hmin = n_q < ln.n_e ? n_q : ln.n_e;
-    const float L = (float)li, H = (float)(hmin > li ? hmin : li);
-    const float rH = __builtin_amdgcn_rcpf(H), rLH = __builtin_amdgcn_rcpf(L * H);
-    const float C = rLH * rH;
-    const float A = fmaf(L + H, rLH, rH), Bc = -fmaf(C, L + H, rLH);
-    const float2v A2 = {A, A}, B2 = {Bc, Bc}, C2 = {C, C};
-    float m = 0.0f;  // rows 15..31 of the weight matrix are zero anyway (S >= 0 or clamped: valid)
+    if constexpr (!SP_OPT_MK2 && q + 1 < SP_QPT) {
+      static_for<SP_MREADS>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        lds_read_frag(mk[0][r], (r >> 1) ? a_m1 : a_m0, (q + 1) * SP_QS + 16 * (r & 1));
+      });
+    }
 #pragma unroll
     for (int k4 = 0; k4 < 4; k4++) {
-      const int j = q * 4 + k4;
-      const floatx16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[j]), z, 0, 0, 0);
+      const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[q * 4 + k4]), z, 0, 0, 0);
 #pragma unroll
-      for (int i = 0; i < 8; i += 2) {
-        const float2v n2 = {(float)nacc[k4 >> 1][(k4 & 1) * 8 + i], (float)nacc[k4 >> 1][(k4 & 1) * 8 + i + 1]};
-        const float2v s2 = {d[i], d[i + 1]};
-        const float2v u2 = __builtin_elementwise_fma(n2, __builtin_elementwise_fma(n2, C2, B2), A2);
+      for (int e = 0; e < 8; e += 2) {
+        const float2v n2 = {nacc[k4 >> 1][(k4 & 1) * 8 + e], nacc[k4 >> 1][(k4 & 1) * 8 + e + 1]};
+        const float2v s2 = {dd[e], dd[e + 1]};
+        const float2v u2 = __builtin_elementwise_fma(n2, __builtin_elementwise_fma(n2, r.C2, r.B2), r.A2);
         const float2v v2 = s2 * u2;
         m = fmaxf(m, fmaxf(v2[0], v2[1]));
       }
     }
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-    best[q] = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-    rl[q] = __builtin_amdgcn_rcpf(L);
-  }
+    const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // 15/16 max_k S_k u(n_k)
+    // the error of S is divided by n_k >= n_lo
+    const float err = kSpecEps * r.sqrt_nq * ln.sqrt_ne;
+    float v = (1.0f + eps_direct) - fmaf(best, (16.0f / 15.0f) * (1.0f + 4e-6f), err * r.rL);
+    if (r.n_q == 0 || ln.n_e == 0) v = INFINITY;    // no effective column at any shift: never a hit
+    if (r.flags != 0u || ln.e_bad) v = -INFINITY;   // non-finite input: always re-score exactly
+    out[q] = v;
+  });
 }
 
 __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
@@ -398,11 +621,26 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
   const int64_t ntb = (ntiles + 3) >> 2;
   const int nqt = (a.nq + SP_QPT - 1) / SP_QPT;
   const int64_t total = a.tb_cum ? a.tb_cum[ntb] : ntb * (int64_t)nqt;
-  const int64_t per = a.tb_cum ? (total + gridDim.x - 1) / gridDim.x : a.per_block;
-  int64_t L0 = (int64_t)blockIdx.x * per;
-  const int64_t L1 = (L0 + per < total) ? (L0 + per) : total;
+  // Work split.  With a plan: equal contiguous segments of the (tile-block, query tile) list.  Without: one
+  // unit per workgroup = one tile-block x one contiguous range of query tiles, ranges outermost, so that the
+  // workgroups in flight at any time (consecutive indices) stream the SAME query images at about the same
+  // time: each image then comes out of HBM / Infinity Cache once per XCD and out of that XCD's L2 for the
+  // other workgroups (the query stream is 10 KB per 4 x 128 pairs -- five times the direct filter's rate).
+  int64_t L0, L1;
+  if (a.tb_cum || !SP_OPT_LOCKSTEP) {
+    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    L0 = (int64_t)blockIdx.x * per;
+    L1 = (L0 + per < total) ? (L0 + per) : total;
+  } else {
+    const int64_t r = blockIdx.x / ntb, utb = blockIdx.x - r * ntb;
+    const int64_t u0 = r * a.unit_len, u1 = (u0 + a.unit_len < nqt) ? (u0 + a.unit_len) : nqt;
+    L0 = utb * nqt + u0;
+    L1 = u0 < u1 ? utb * nqt + u1 : L0;
+  }
+  const unsigned lds_base = (unsigned)(uintptr_t)((AS3 char *)smem);
   SpecLane ln;
   ln.hh = hh;
+  ln.bpark = lds_base + (unsigned)(SP_BPARK_OFF + wave * (SP_B_LDS * 1024) + lane * 16);
   {
     // A-fragment address of this lane inside a tile of 4 query images: row = col = 8 * query + 4 * variant + k4
     const int rq = col >> 3, rv = (col >> 2) & 1, rk = col & 3;
@@ -413,7 +651,7 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
     for (int mt = 0; mt < 2; mt++) {
       const int k4 = 2 * mt + (col >> 4), k15 = (col & 15) == 15 ? 0 : (col & 15);
       const int k = (45 * k4 + 16 * k15) % NS;  // CRT
-      ln.m_off[mt] = SP_MASK_OFF + (k & 15) * SP_MASK_COPY + (k & ~15) + hh * 16;
+      ln.m_off[mt] = SP_MASK_OFF + (k & 15) * SP_MASK_COPY + (k & ~15) + hh * 32;
     }
     // stage-2 A operand: row k15 = col (rows >= 15 are zero), k = part index: lanes 0..31 {C_0 hi, Re C_1..7},
     // lanes 32..63 {C_0 lo, Im C_1..7}; weights scaled by 15/16
@@ -460,10 +698,14 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
     const bool n_ok = tile_ok && n < a.n_items;
     const int nphase = (q1 - q0 + SP_QPP - 1) / SP_QPP;
 
-    {  // phase 0 of the query stream (DMA, overlaps the B loads below)
-      const int nqs = (q1 - q0 < SP_QPP) ? (q1 - q0) : SP_QPP;
-      stage_queries(a.qimg + (int64_t)q0 * SP_QS, smem, nqs * SP_QS, wave, lane);
-    }
+    auto stage_tile = [&](int p) {  // query tile p of this segment -> LDS buffer p % SP_NBUF
+      const int qn = q0 + p * SP_QPP;
+      const int nqs = (q1 - qn < SP_QPP) ? (q1 - qn) : SP_QPP;
+      if (kInstr && (a.dbg & 4)) return 0;
+      return stage_queries(a.qimg + (int64_t)qn * SP_QS, smem + (p % SP_NBUF) * SP_PHASE_BYTES, nqs * SP_QS, wave, lane);
+    };
+    (void)stage_tile(0);  // overlaps the B loads below
+    if (SP_NBUF > 2 && nphase > 1) (void)stage_tile(1);
     half8 B[SP_FRAGS];
     {
       const uint4 *src = a.spT + ((tile_ok ? tile : 0) * SP_FRAGS) * 64 + lane;
@@ -474,55 +716,80 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
       }
 #pragma unroll
       for (int s = SP_B_VGPR; s < SP_FRAGS; s++) asm volatile("" : "+a"(B[s]));
+      // park fragments 0..SP_B_LDS-1 in LDS (this wave's private 4 KiB; the previous segment's tiles are done)
+#pragma unroll
+      for (int s = 0; s < SP_B_LDS; s++)
+        *reinterpret_cast<half8 *>(smem + SP_BPARK_OFF + wave * (SP_B_LDS * 1024) + s * 1024 + lane * 16) = B[s];
     }
     const u64 m2 = n_ok ? a.cmask[n] : 0ull;
     ln.n_e = __popcll(m2 & kMask60);
     ln.sqrt_ne = sqrtf((float)ln.n_e);
     ln.e_bad = (m2 & kNonFinite) != 0;
+    {
+      const unsigned bits = (unsigned)((m2 & kMask60) >> (32 * hh));  // columns 32 hh .. 32 hh + 31 (K index of the lane half)
 #pragma unroll
-    for (int s = 0; s < 2; s++) {
-      const unsigned bits = (unsigned)((m2 & kMask60) >> (32 * s + 16 * hh)) & 0xffffu;
-#pragma unroll
-      for (int r = 0; r < 4; r++)  // 4 bits -> 4 bytes of 0/1
-        ln.Bm[s][r] = (int)((((bits >> (4 * r)) & 0xfu) * 0x00204081u) & 0x01010101u);
+      for (int r = 0; r < 8; r++)  // 4 bits -> 4 bytes of fp8 (e4m3) 0.0 / 1.0 = 0x00 / 0x38
+        ln.Bm[r] = (int)(((((bits >> (4 * r)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0x38u);
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
+    // Tile p is computed from buffer p % 3 while the DMA of tile p + 2 is in flight.  At the end of tile p the
+    // wave waits for ITS pieces of tile p + 1 only -- vmcnt(n_young), n_young = the DMA instructions of tile
+    // p + 2 it has just issued (VMEM operations retire in issue order; this tile's stores, younger still, stay
+    // in flight: waiting for their acknowledgement every tile cost more than the stage-1 MFMAs) -- and the
+    // raw barrier (no vmcnt(0), unlike __syncthreads with an LDS-DMA pending) makes the other waves' pieces
+    // visible and frees buffer (p + 3) % 3 = p % 3 for the next DMA.
+    const bool prof = kInstr && a.prof && blockIdx.x == 0 && wave == 0;
+    unsigned long long ps[5] = {0, 0, 0, 0, 0};
     for (int p = 0; p < nphase; p++) {
       const int qp = q0 + p * SP_QPP;
-      if (p + 1 < nphase) {
-        const int qn = qp + SP_QPP;
-        const int nqs = (q1 - qn < SP_QPP) ? (q1 - qn) : SP_QPP;
-        stage_queries(a.qimg + (int64_t)qn * SP_QS, smem + ((p + 1) & 1) * SP_PHASE_BYTES, nqs * SP_QS, wave, lane);
-      }
+      unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
+      if (prof) t0 = prof_now();
+      const int n_issued = (p + SP_NBUF - 1 < nphase) ? stage_tile(p + SP_NBUF - 1) : 0;
+      const int n_young = SP_NBUF > 2 ? n_issued : 0;  // DMA instructions younger than those of tile p + 1
+      if (prof) t1 = prof_now();
       const int nq_here = (q1 - qp < SP_QPP) ? (q1 - qp) : SP_QPP;
       if (tile_ok) {
-        const char *phase = smem + (p & 1) * SP_PHASE_BYTES;
-        for (int t = 0; t * SP_QPT < nq_here; t++) {
-          const char *tbase = phase + t * SP_QPT * SP_QS;
-          float best[SP_QPT], rl[SP_QPT];
-          spec_tile(tbase, B, ln, best, rl);
+        const char *tbase = smem + (p % SP_NBUF) * SP_PHASE_BYTES;
+        float out[SP_QPT];
+        spec_tile(lds_base + (unsigned)(tbase - smem), tbase, B, ln, a.eps_direct, out, a.dbg, prof ? &t2 : nullptr);
+        if (prof) {
+          asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]));
+          t3 = prof_now();
+        }
+        // both lane halves hold all four bounds: lanes 0..31 store queries 0 and 1, lanes 32..63 queries 2 and 3
+        // (two store instructions per tile instead of four)
 #pragma unroll
-          for (int qq = 0; qq < SP_QPT; qq++) {
-            const int q = qp + t * SP_QPT + qq;
-            if (q < q1) {
-              const uint4 tail = *reinterpret_cast<const uint4 *>(tbase + qq * SP_QS + SP_TAIL);
-              const int n_q = (int)tail.x;
-              const float err = kSpecEps * __uint_as_float(tail.z) * ln.sqrt_ne;
-              // best = 15/16 max_k S_k u(n_k); the error of S is divided by n_k >= n_lo
-              float v = (1.0f + a.eps_direct) - fmaf(best[qq], (16.0f / 15.0f) * (1.0f + 4e-6f), err * rl[qq]);
-              if (n_q == 0 || ln.n_e == 0) v = INFINITY;    // no effective column at any shift: never a hit
-              if (tail.y != 0u || ln.e_bad) v = -INFINITY;  // non-finite input: always re-score exactly
-              if (n_ok && hh == 0) a.lb[(int64_t)q * a.ld_lb + n] = v;
-            }
-          }
+        for (int i = 0; i < 2; i++) {
+          const int qq = 2 * hh + i;
+          const float v = i ? (hh ? out[3] : out[1]) : (hh ? out[2] : out[0]);
+          if (n_ok && qq < nq_here && !(kInstr && (a.dbg & 8) && v != 12345.0f)) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = v;
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (prof) t4 = prof_now();
+      if (p + 1 < nphase) {
+        wait_vmcnt_le(n_young);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if (prof) {
+        const unsigned long long t5 = prof_now();
+        ps[0] += t1 - t0;  // DMA issue
+        ps[1] += t2 - t1;  // stage 1
+        ps[2] += t3 - t2;  // tail
+        ps[3] += t4 - t3;  // stores
+        ps[4] += t5 - t4;  // wait + barrier
+      }
     }
+    if (prof && lane == 0) {
+      for (int i = 0; i < 5; i++) a.prof[i] = ps[i];
+      a.prof[5] = (unsigned long long)nphase;
+    }
+    // segment end: everything retired before the next segment's DMA reuses the buffers
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
 }
 
@@ -552,7 +819,7 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
                        const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s) {
   if (nq <= 0 || n_items <= 0) return RSX_OK;
   static int n_cu = 0;
-  const int lds = 2 * SP_PHASE_BYTES;
+  const int lds = SP_LDS_BYTES;
   if (!n_cu) {
     RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_spec_filter_kernel),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -570,19 +837,53 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
   a.lb = lb;
   a.ld_lb = ld_lb;
   a.eps_direct = (float)filter_eps();
+  {
+    const char *e = getenv("RSX_SPEC_DBG");
+    a.dbg = e ? atoi(e) : 0;
+  }
   const int64_t ntiles = (n_items + 31) / 32;
   const int64_t nqt = (nq + SP_QPT - 1) / SP_QPT;
-  const int64_t total = ((ntiles + 3) / 4) * nqt;
-  // one workgroup per CU with an equal share; small problems use fewer workgroups so that a
-  // 304-register B load is amortised over >= 4 query tiles
-  int64_t per = (total + n_cu - 1) / n_cu;
-  if (per < 4) per = 4;
-  a.per_block = per;
+  const int64_t ntb = (ntiles + 3) / 4;
   a.tb_qmin = tb_qmin;
   a.tb_cum = tb_cum;
-  const unsigned grid = tb_cum ? (unsigned)n_cu : (unsigned)((total + per - 1) / per);
+  unsigned grid = (unsigned)n_cu;
+  a.unit_len = (int32_t)nqt;
+  if (!SP_OPT_LOCKSTEP) {
+    int64_t per = (ntb * nqt + n_cu - 1) / n_cu;
+    if (per < 4) per = 4;
+    grid = (unsigned)((ntb * nqt + per - 1) / per);
+  } else if (!tb_cum) {
+    // number of query ranges R: fill whole rounds of n_cu workgroups as evenly as possible; a unit keeps
+    // >= 16 query tiles so that the 304-register B load stays amortised
+    int64_t best_r = 1;
+    double best_eff = 0.0;
+    for (int64_t r = 1; r <= 64 && (r == 1 || (nqt + r - 1) / r >= 16); r++) {
+      const int64_t len = (nqt + r - 1) / r, rr = (nqt + len - 1) / len;  // rr ranges actually used
+      const int64_t units = rr * ntb, rounds = (units + n_cu - 1) / n_cu;
+      const double eff = (double)(ntb * nqt) / (double)(rounds * n_cu * len);
+      if (eff > best_eff + 1e-9) {
+        best_eff = eff;
+        best_r = rr;
+      }
+    }
+    a.unit_len = (int32_t)((nqt + best_r - 1) / best_r);
+    const int64_t rr = (nqt + a.unit_len - 1) / a.unit_len;
+    grid = (unsigned)(rr * ntb);
+  }
+  static unsigned long long *d_prof = nullptr;
+  static const bool want_prof = getenv("RSX_SPEC_PROF") != nullptr;
+  if (want_prof && !d_prof) RSX_HIP(hipMalloc(&d_prof, 8 * sizeof(unsigned long long)));
+  a.prof = want_prof ? d_prof : nullptr;
   hipLaunchKernelGGL(sc_spec_filter_kernel, dim3(grid), dim3(256), lds, s, a);
   RSX_HIP(hipGetLastError());
+  if (want_prof) {  // debugging aid only: synchronises
+    unsigned long long h[8] = {0};
+    RSX_HIP(hipStreamSynchronize(s));
+    RSX_HIP(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
+    const double n = h[5] ? (double)h[5] : 1.0;
+    fprintf(stderr, "[sc_spec prof] tiles %llu: cycles per tile  dma %.0f  stage1 %.0f  tail %.0f  stores %.0f  wait+barrier %.0f\n",
+            h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+  }
   return RSX_OK;
 }
 
