@@ -173,29 +173,29 @@ __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const dou
   u64 m = __ballot(nonzero && lane < NS);
   if (__ballot(bad && lane < NS)) m |= kNonFinite;
   wave_lds_fence();
-  // twiddles e^(-2 pi i m / 15)
-  double cs[15], sn[15];
-#pragma unroll
-  for (int i = 0; i < 15; i++) {
-    cs[i] = cospi(2.0 * i / 15.0);
-    sn[i] = sinpi(2.0 * i / 15.0);
+  // twiddles e^(-2 pi i m / 15), in the tail of the (now consumed-in-place) scratch: xn has DS doubles, tw sits behind
+  double *tw = xn + DS;  // [0..15) cos, [16..31) sin
+  if (lane < 15) {
+    tw[lane] = cospi(2.0 * lane / 15.0);
+    tw[16 + lane] = sinpi(2.0 * lane / 15.0);
   }
+  wave_lds_fence();
   for (int idx = lane; idx < 8 * 80; idx += 64) {
     const int f = idx / 80, rem = idx - f * 80, a = rem / NR, r = rem - a * NR;
     double re = 0.0, im = 0.0;
+    int c = 45 * a;  // CRT: c = a mod 4, c = b mod 15  ->  c = (45 a + 16 b) mod 60
+    c -= (c >= 120) ? 120 : 0;
+    c -= (c >= 60) ? 60 : 0;
+    int t = 0;       // (f b) mod 15
 #pragma unroll
     for (int b = 0; b < 15; b++) {
-      const int c = (45 * a + 16 * b) % 60;  // CRT: c = a mod 4, c = b mod 15
       const double x = xn[r * NS + c];
-      const int t = (f * b) % 15;
-      double co = 0.0, si = 0.0;
-#pragma unroll
-      for (int i = 0; i < 15; i++) {  // select without a dynamically indexed (scratch) array
-        co = (t == i) ? cs[i] : co;
-        si = (t == i) ? sn[i] : si;
-      }
-      re += x * co;
-      im -= x * si;
+      re += x * tw[t];
+      im -= x * tw[16 + t];
+      c += 16;
+      c -= (c >= 60) ? 60 : 0;
+      t += f;
+      t -= (t >= 15) ? 15 : 0;
     }
     if (f == 0) {
       kv[a * 24 + r] = (_Float16)(float)re;
@@ -213,7 +213,7 @@ __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const dou
 // database image: tile-major [tile of 32 entries][76 K-steps][64 lanes][8 halves]
 __global__ __launch_bounds__(256) void sc_spec_db_kernel(const float *__restrict__ desc, const double *__restrict__ norm,
                                                          int64_t first, int64_t count, uint4 *__restrict__ spT) {
-  __shared__ double xn[4][DS];
+  __shared__ double xn[4][DS + 32];
   __shared__ __attribute__((aligned(16))) _Float16 kv[4][SP_KV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t it = (int64_t)blockIdx.x * 4 + wave;
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void sc_spec_db_kernel(const float *__restrict
 //   [8576, 10368)           16 displaced copies of the column-mask byte stream
 __global__ __launch_bounds__(256) void sc_spec_query_kernel(const float *__restrict__ desc, const double *__restrict__ norm,
                                                             int32_t nq, char *__restrict__ qimg) {
-  __shared__ double xn[4][DS];
+  __shared__ double xn[4][DS + 32];
   __shared__ __attribute__((aligned(16))) _Float16 kv[4][SP_KV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = blockIdx.x * 4 + wave;
