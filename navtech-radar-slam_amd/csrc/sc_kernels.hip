@@ -175,7 +175,11 @@ constexpr int OFF_WAVES = OFF_QV1 + 512;         // 11584
 // fetch two consecutive elements with ONE 16-byte-aligned ds_read_b128 (the compiler otherwise pairs
 // ds_read_b64s into half-rate ds_read2_b64); then the 7 x 60 similarity terms as sim[t][c].
 // The similarity terms ALIAS the key images, which are dead once stage 1 has produced k*.
-constexpr int ENT_VKEY_A = 0, ENT_VKEY_B = 960, ENT_SIM = 0, ENT_MISC = 3360;
+// Image B starts 72 LDS slots (of 16 B) after image A: with the lane groups of ds_read_b128
+// ({0-3,12-15,20-27}, {4-11,16-19,28-31}, ...) the even lanes of a group (image A, 16 B apart per 2 lanes) and
+// its odd lanes (image B) then land on 16 different slots mod 16 -- at the natural offset 960 B (60 slots) they
+// collided pairwise (SQ_LDS_BANK_CONFLICT = 22 % of the LDS cycles of the re-scoring kernel)
+constexpr int ENT_VKEY_A = 0, ENT_VKEY_B = 1152, ENT_SIM = 0, ENT_MISC = 3360;
 // 3408 B = 852 dwords = 20 (mod 64): an odd multiple of 4 dwords, so the per-entry blocks land on
 // disjoint LDS slots in the ds_read_b128 lane groups of stage 3
 constexpr int ENT_SIZE = 3408;

@@ -60,16 +60,16 @@ def test_spectral_bounds(sc, rsx, synth, binary):
             continue
         assert (lb[qi][fin] - eps - want[fin]).max() <= 0.0, f"q={qi}: not a lower bound"
         # tightness where S >= 0 (negative heights are clamped to S = 0: valid, looser): within the spectral
-        # error budget 2.5e-3 sqrt(nq ne) / n_lo plus the reciprocal bound's excess
+        # error budget 2.05e-3 sqrt(nq ne) / n_lo plus the reciprocal bound's excess
         nq_c = int(n_cols(queries[qi])[0])
         nlo = np.maximum(nq_c + ne - 60, 1)
         nhi = np.maximum(np.minimum(nq_c, ne), nlo)
-        slack = 2.5e-3 * np.sqrt(nq_c * ne) / nlo + eps + (nhi - nlo) ** 3 / (4.0 * nlo * nhi ** 2) + 1e-5
+        slack = 2.05e-3 * np.sqrt(nq_c * ne) / nlo + eps + (nhi - nlo) ** 3 / (4.0 * nlo * nhi ** 2) + 1e-5
         ok = fin & (want <= 1.0)
         gap = want[ok] - (lb[qi][ok] - eps)
         assert np.all(gap <= slack[ok] + eps), f"q={qi}: bound looser than the budget"
         if nq_c >= 50:
-            worst_tight = max(worst_tight, float(np.max(gap - 2.5e-3 * np.sqrt(nq_c * ne[ok]) / nlo[ok])))
+            worst_tight = max(worst_tight, float(np.max(gap - 2.05e-3 * np.sqrt(nq_c * ne[ok]) / nlo[ok])))
     assert worst_tight < 2e-3      # observed error is far inside the budget
 
 

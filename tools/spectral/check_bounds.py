@@ -30,7 +30,7 @@ for binary in (True, False):
         full = fin & ((dn == 60) | (qn == 60)) & (want <= 1.0)   # S < 0 (negative heights) is clamped to 0: valid, looser
         if full.any():
             nlo = np.maximum(qn + dn - 60, 1)
-            expect = want - 2.5e-3 * np.sqrt(qn * dn) / nlo + eps
+            expect = want - 2.05e-3 * np.sqrt(qn * dn) / nlo + eps
             worst_gap_full = max(worst_gap_full, np.abs(ls[qi][full] - expect[full]).max())
         if qi < 3:
             print(f" q{qi}: nq={qn} spectral-direct mean {np.mean(ls[qi][fin]-ld[qi][fin]):+.5f} min {np.min(ls[qi][fin]-ld[qi][fin]):+.5f} max {np.max(ls[qi][fin]-ld[qi][fin]):+.5f}")
