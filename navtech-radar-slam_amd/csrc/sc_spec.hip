@@ -592,17 +592,35 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
         lds_read_frag(mk[0][r], (r >> 1) ? a_m1 : a_m0, (q + 1) * SP_QS + 16 * (r & 1));
       });
     }
+    // u(n) of all 32 n_eff values of the query first (independent of stage 2), then per k4: S * u and the maximum;
+    // written stage by stage over 4 independent pairs so that no packed instruction waits for the previous one
+    float2v u2[4][4];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; k4++) {
+      float2v t2[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float2v n2 = {nacc[k4 >> 1][(k4 & 1) * 8 + 2 * e], nacc[k4 >> 1][(k4 & 1) * 8 + 2 * e + 1]};
+        t2[e] = __builtin_elementwise_fma(n2, r.C2, r.B2);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const float2v n2 = {nacc[k4 >> 1][(k4 & 1) * 8 + 2 * e], nacc[k4 >> 1][(k4 & 1) * 8 + 2 * e + 1]};
+        u2[k4][e] = __builtin_elementwise_fma(n2, t2[e], r.A2);
+      }
+    }
 #pragma unroll
     for (int k4 = 0; k4 < 4; k4++) {
       const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[q * 4 + k4]), z, 0, 0, 0);
+      float2v v2[4];
 #pragma unroll
-      for (int e = 0; e < 8; e += 2) {
-        const float2v n2 = {nacc[k4 >> 1][(k4 & 1) * 8 + e], nacc[k4 >> 1][(k4 & 1) * 8 + e + 1]};
-        const float2v s2 = {dd[e], dd[e + 1]};
-        const float2v u2 = __builtin_elementwise_fma(n2, __builtin_elementwise_fma(n2, r.C2, r.B2), r.A2);
-        const float2v v2 = s2 * u2;
-        m = fmaxf(m, fmaxf(v2[0], v2[1]));
+      for (int e = 0; e < 4; e++) {
+        const float2v s2 = {dd[2 * e], dd[2 * e + 1]};
+        v2[e] = s2 * u2[k4][e];
       }
+      const float m01 = fmaxf(fmaxf(v2[0][0], v2[0][1]), fmaxf(v2[1][0], v2[1][1]));
+      const float m23 = fmaxf(fmaxf(v2[2][0], v2[2][1]), fmaxf(v2[3][0], v2[3][1]));
+      m = fmaxf(m, fmaxf(m01, m23));
     }
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
     const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // 15/16 max_k S_k u(n_k)
@@ -867,6 +885,10 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
         best_eff = eff;
         best_r = rr;
       }
+    }
+    if (const char *e = getenv("RSX_SPEC_R")) {  // experiments: force the number of query ranges
+      const int64_t v = atoll(e);
+      if (v >= 1 && v <= nqt) best_r = v;
     }
     a.unit_len = (int32_t)((nqt + best_r - 1) / best_r);
     const int64_t rr = (nqt + a.unit_len - 1) / a.unit_len;
