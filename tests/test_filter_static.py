@@ -11,7 +11,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_no_instruction_touches_inflight_lds_destinations():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lds_ring.py")], capture_output=True, text=True, timeout=600)
+import pytest
+
+
+@pytest.mark.parametrize("kind", ["direct", "spectral"])
+def test_no_instruction_touches_inflight_lds_destinations(kind):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lds_ring.py"), kind], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 violations" in r.stdout and "ds_read_b128" in r.stdout

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""Static check of sc_filter_kernel's hand-issued LDS reads (inline-asm ds_read_b128 + counted
+"""Static check of the filter kernels' hand-issued LDS reads (inline-asm ds_read_b128 + counted
 s_waitcnt): no instruction may touch the destination registers of a read that can still be in
-flight.  Usage: tools/check_lds_ring.py  (compiles sc_filter.hip to ISA with hipcc and scans it)."""
+flight.  Usage: tools/check_lds_ring.py [direct|spectral]  (compiles sc_filter.hip / sc_spec.hip to ISA
+with hipcc and scans sc_filter_kernel / sc_spec_filter_kernel)."""
 import os
 import re
 import subprocess
@@ -20,16 +21,23 @@ def regs(tok):
     return {int(m.group(1))} if m else set()
 
 
+KERNELS = {"direct": ("sc_filter.hip", "sc_filter_kernel", []),
+           "spectral": ("sc_spec.hip", "sc_spec_filter_kernel", ["-mllvm", "-amdgpu-mfma-vgpr-form"])}
+
+
 def main():
+    src, kernel, extra = KERNELS[sys.argv[1] if len(sys.argv) > 1 else "direct"]
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "f.s")
         subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "--offload-arch=gfx950", "-O3", "-std=c++17",
                                "-ffp-contract=off", "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt",
-                               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-x", "hip",
-                               os.path.join(CSRC, "sc_filter.hip"), "-S", "--cuda-device-only", "-o", out],
+                               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + extra + ["-x", "hip",
+                               os.path.join(CSRC, src), "-S", "--cuda-device-only", "-o", out],
                               stderr=subprocess.DEVNULL)
         text = open(out).read()
-    body = text[text.index("sc_filter_kernel"):]
+    # the kernel's body starts at its label (mangled name + ":"), not at the first mention of the name
+    m = re.search(r"^_Z\w*" + kernel + r"\w*:", text, re.M)
+    body = text[m.start():]
     body = body[:body.index("s_endpgm")]
     outstanding, bad, nreads = [], 0, 0
     for i, line in enumerate(body.split("\n")):
@@ -54,7 +62,7 @@ def main():
                 while len(outstanding) > int(m.group(1)):
                     outstanding.pop(0)
             continue
-        if op.startswith("ds_") or op.startswith("s_load"):
+        if op.startswith("ds_") or op.startswith("s_load") or op == "s_memtime":
             outstanding.append((set(), i))
             continue
         used = set()
