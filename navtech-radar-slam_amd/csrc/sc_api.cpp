@@ -283,7 +283,21 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
       return (v >= 1 && v <= 128) ? v : 64;
     }();
     RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, first_target, s, elig_monotone));
-    RSX_TRY(rescore(h, q, n_items, n_eligible, elig, 0, RESCORE_ALL_ROUNDS, nullptr, nullptr, k, d_out + b0 * k, s));
+    // exact re-scoring: the 8-wave workgroup in rounds (sc_rescore_kernel; also what the sharded stages use), or
+    // -- RSX_SC_RESCORE=walk, experimental -- one wave per query walking the bound-ordered short list with
+    // the fp32 pruning preview (sc_walk_kernel: identical results, 6.3 instead of 5.6 ms per step on the bench:
+    // the per-query chain of ~125 dependent candidates is latency-bound at 2 waves per SIMD)
+    static const bool use_walk = [] {
+      const char *e = getenv("RSX_SC_RESCORE");
+      return e && e[0] == 'w';
+    }();
+    if (use_walk) {
+      const int64_t ld = (n_items + 31) / 32 * 32;
+      RSX_TRY(launch_walk(db_view(h), q, h->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
+                          h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), filter_eps(), d_out + b0 * k, k, s));
+    } else {
+      RSX_TRY(rescore(h, q, n_items, n_eligible, elig, 0, RESCORE_ALL_ROUNDS, nullptr, nullptr, k, d_out + b0 * k, s));
+    }
   }
   return RSX_OK;
 }

@@ -614,29 +614,26 @@ __global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict_
     }
     thr[(int64_t)q * RESCORE_NUM_THR + threadIdx.x] = bin_edge(b);
   }
-  // compaction of bins <= b_cap
+  // compaction of bins <= b_cap, ORDERED BY BIN (counting sort: entry of bin b goes to [cum[b-1], cum[b]),
+  // any order inside a bin): sc_walk_kernel walks the list in ascending-bound order, sc_rescore_kernel
+  // does not care
   RescoreEntry *out = slist + (int64_t)q * RESCORE_SHORTLIST_CAP;
+  __shared__ int fill[H_BINS];
+  for (int i = threadIdx.x; i < H_BINS; i += 256) fill[i] = i ? hist[i - 1] : 0;  // exclusive prefix = first position
+  __syncthreads();
   if (b_cap >= 0) {
-    for (int64_t base_i = 0; base_i < n_items; base_i += 256) {
-      const int64_t i = base_i + threadIdx.x;
-      bool pass = false;
-      float d = 0.0f;
-      if (i < n_items) {
-        d = row[i];
-        pass = (d != INFINITY) && lb_bin(d) <= b_cap;
-      }
-      const u64 bal = __ballot(pass);
-      int wbase = 0;
-      if (lane == 0 && bal) wbase = atomicAdd(&s_total, __popcll(bal));
-      wbase = __shfl(wbase, 0);
-      if (pass) {
-        RescoreEntry e;
-        e.lb = d;
-        e.slot = (int32_t)i;
-        out[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = e;
-      }
+    for (int64_t i = threadIdx.x; i < n_items; i += 256) {
+      const float d = row[i];
+      if (d == INFINITY) continue;
+      const int b = lb_bin(d);
+      if (b > b_cap) continue;
+      RescoreEntry e;
+      e.lb = d;
+      e.slot = (int32_t)i;
+      out[atomicAdd(&fill[b], 1)] = e;
     }
   }
+  if (threadIdx.x == 0) s_total = b_cap >= 0 ? hist[b_cap] : 0;
   __syncthreads();
   if (threadIdx.x == 0) sl_cnt[q] = s_total;
 }

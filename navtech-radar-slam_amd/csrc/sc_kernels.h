@@ -91,6 +91,12 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
                    const float *thr, double eps, int32_t round_begin, int32_t round_end, const rsx_sc_hit *tau_src,
                    const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s);
 
+// the same job by one wave per query walking the short list in ascending-bound order (needs the short list
+// ordered by histogram bin, which launch_select produces); single-shard, single-stage
+int launch_walk(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
+                int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
+                const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s);
+
 // ---- MFMA lower-bound filter (sc_filter.hip) ----
 constexpr int FILTER_QIMG_BYTES = 9984;  // LDS image of one query (two displaced fp16 copies)
 constexpr int FILTER_DB_BYTES_PER_ENTRY = 2 * DS;

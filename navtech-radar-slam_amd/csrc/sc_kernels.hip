@@ -170,6 +170,12 @@ constexpr int OFF_QIMG = 0;
 constexpr int OFF_QN1 = 60 * Q_COL_STRIDE;       // 10560
 constexpr int OFF_QV1 = OFF_QN1 + 512;           // 11072
 constexpr int OFF_WAVES = OFF_QV1 + 512;         // 11584
+// pruning preview (sc_walk_kernel): the query's unit columns in fp32 (column stride 80 B = 5 LDS slots, odd:
+// conflict-free ds_read_b128 across the lanes of a group) + a flag "every non-empty column norm is in
+// [1e-15, 1e15]"; lives behind the per-wave region of the kernels that use it
+constexpr int QP_COL_STRIDE = NR * 4;            // 80
+constexpr int QP_FLAG = NS * QP_COL_STRIDE;      // 4800
+constexpr int QP_SIZE = QP_FLAG + 16;
 // per entry: the sector key twice in a row (vk2[e] = v[e % 60], 120 doubles) for the rotated reads of
 // stage 1, in TWO images -- A at element offset 0, B shifted by one element -- so that every lane can
 // fetch two consecutive elements with ONE 16-byte-aligned ds_read_b128 (the compiler otherwise pairs
@@ -219,9 +225,51 @@ constexpr int pair_waves_per_simd() {
 // (B x ENT_SIZE).  Result of entry b: lanes 8*b .. 8*b+7 all hold (bd, bk) = (distance, shift),
 // {1e7, 0} when no shift of the window has an effective column (SC.cpp:133-134 initial values).
 // ------------------------------------------------------------------------------------------
-template <int B>
+// sum of v over the 64 lanes (DPP butterfly inside each row of 16, row broadcasts across rows)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_f32(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+  v += dpp_f32<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_f32<0x140, 0xf>(v);  // row_mirror: every lane = its row's sum
+  v += dpp_f32<0x142, 0xa>(v);  // row_bcast:15 into rows 1, 3
+  v += dpp_f32<0x143, 0xc>(v);  // row_bcast:31 into rows 2, 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+// PREVIEW (sc_walk_kernel): once the alignment k* is known, the 7 window distances are first evaluated
+// cheaply in fp32 -- dot products of the query's unit columns (fp32 image in LDS at smem + off_preview)
+// with the entry's raw fp32 column, scaled by 1/n2, summed by a wave reduction: no fp64 division, no
+// sequential sum -- and the exact stages 2-3 only run when that preview, minus a margin far above its
+// error (a few 1e-6: 20-term dot products and a 60-term sum of values <= 1 in fp32), can still reach
+// tau_prune = the k-th best exact distance so far.  Column norms outside [1e-15, 1e15] (fp32 products
+// could under- or overflow) and non-finite previews disable it.  A pruned group returns {+inf, ...}
+// ("not a hit"); with tau_prune = +inf nothing is pruned.
+constexpr float kPreviewMargin = 1e-4f;
+
+// the per-lane registers of one entry (lane = column): loaded by pair_group itself, or ahead of time by a
+// caller that overlaps the global-memory latency with the previous entry's arithmetic (sc_walk_kernel)
+struct EntryRegs {
+  float4 ecol[5];
+  double v, n2;
+};
+__device__ __forceinline__ void load_entry(const DbView &db, int64_t slot, int lane, EntryRegs &r) {
+  const int cl = lane < NS ? lane : 0;
+  r.v = db.vkey[slot * NS + cl];
+  const float4 *src = reinterpret_cast<const float4 *>(db.desc + slot * DS + cl * NR);
+#pragma unroll
+  for (int i = 0; i < 5; i++) r.ecol[i] = src[i];
+  r.n2 = db.norm[slot * NS + cl];
+}
+
+template <int B, bool PREVIEW = false>
 __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, char *wsm, int lane,
-                                           const int64_t (&eslot)[B], double &bd_out, int &bk_out) {
+                                           const int64_t (&eslot)[B], double &bd_out, int &bk_out,
+                                           double tau_prune = INFINITY, int off_preview = 0,
+                                           const EntryRegs *pre = nullptr) {
   const int cl = lane < NS ? lane : 0;       // entry column owned in stage 2
   const int kk = lane < NS ? lane : NS - 1;  // shift owned in stage 1
   const double *v1 = reinterpret_cast<const double *>(smem + OFF_QV1);
@@ -231,11 +279,19 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
     wave_lds_fence();
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      const double v = db.vkey[eslot[b] * NS + cl];
-      const float4 *src = reinterpret_cast<const float4 *>(db.desc + eslot[b] * DS + cl * NR);
+      double v;
+      if (pre) {
+        v = pre[b].v;
 #pragma unroll
-      for (int i = 0; i < 5; i++) ecol[b][i] = src[i];
-      en2[b] = db.norm[eslot[b] * NS + cl];
+        for (int i = 0; i < 5; i++) ecol[b][i] = pre[b].ecol[i];
+        en2[b] = pre[b].n2;
+      } else {
+        v = db.vkey[eslot[b] * NS + cl];
+        const float4 *src = reinterpret_cast<const float4 *>(db.desc + eslot[b] * DS + cl * NR);
+#pragma unroll
+        for (int i = 0; i < 5; i++) ecol[b][i] = src[i];
+        en2[b] = db.norm[eslot[b] * NS + cl];
+      }
       double *vka = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY_A);
       double *vkb = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY_B);
       if (lane < NS) {
@@ -288,6 +344,55 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
       for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off));
       unsigned long long bal = __ballot(ok && nrm == m);
       kstar[b] = bal ? (__ffsll((long long)bal) - 1) : 0;  // first strict minimum = lowest shift
+    }
+
+    if constexpr (PREVIEW) {
+      if (tau_prune < INFINITY && *reinterpret_cast<const int *>(smem + off_preview + QP_FLAG)) {  // wave-uniform
+        bool any_alive = false;
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          const int ks = kstar[b];
+          const double n2 = en2[b];
+          const bool n2_ok = (n2 == 0.0) || (n2 >= 1e-15 && n2 <= 1e15);
+          if (__ballot(!n2_ok && lane < NS)) {  // unusual scale (or NaN): no preview for this entry
+            any_alive = true;
+            continue;
+          }
+          const float r2 = (n2 == 0.0) ? 0.0f : (float)(1.0 / n2);
+          float best = INFINITY;
+#pragma unroll 1
+          for (int t = 0; t < 7; t++) {
+            int k = ks + t - 3;
+            k += (k < 0) ? NS : 0;
+            k -= (k >= NS) ? NS : 0;
+            int c = cl + k;
+            c -= (c >= NS) ? NS : 0;
+            const float4 *qp = reinterpret_cast<const float4 *>(smem + off_preview + c * QP_COL_STRIDE);
+            float dot = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 5; i++) {
+              const float4 q4 = qp[i];
+              dot = fmaf(q4.x, ecol[b][i].x, dot);
+              dot = fmaf(q4.y, ecol[b][i].y, dot);
+              dot = fmaf(q4.z, ecol[b][i].z, dot);
+              dot = fmaf(q4.w, ecol[b][i].w, dot);
+            }
+            const bool valid = (lane < NS) && !((qn1[c] == 0.0) | (n2 == 0.0));  // SC.cpp:78
+            const float sum = wave_sum_f32(valid ? dot * r2 : 0.0f);
+            const int ne = __popcll(__ballot(valid));
+            const float d = 1.0f - sum / (float)ne;  // ne == 0: NaN, ignored like SC.cpp:87-88,134
+            if (!(d == d) && ne != 0) best = -INFINITY;  // non-finite data: never prune
+            best = fminf(best, d);                        // fminf drops the 0/0 NaN
+          }
+          // exact distance >= preview - error: it cannot enter a top-k whose k-th distance is tau_prune
+          if (!(best - kPreviewMargin > (float)tau_prune)) any_alive = true;
+        }
+        if (!any_alive) {
+          bd_out = INFINITY;
+          bk_out = 0x7fffffff;
+          return;
+        }
+      }
     }
 
     // ---- stage 2: column cosine terms for the 7 shifts k*-3..k*+3 (SC.cpp:123-144, 69-90) ----
@@ -379,8 +484,24 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
 }
 
 // query -> LDS (once per block): fp64 image (column stride Q_COL_STRIDE), norms, sector key
-__device__ __forceinline__ void load_query_to_lds(const QueryView &q, int qi, char *smem, int tid, int nthreads) {
+// off_preview >= 0: also the fp32 unit-column image of the pruning preview at smem + off_preview
+__device__ __forceinline__ void load_query_to_lds(const QueryView &q, int qi, char *smem, int tid, int nthreads,
+                                                  int off_preview = -1) {
   const float *qd = q.desc + (int64_t)qi * DS;
+  if (off_preview >= 0) {
+    for (int i = tid; i < DS; i += nthreads) {  // unit columns in fp32 (0 for an empty column)
+      const int c = i / NR;
+      const double n1 = q.norm[(int64_t)qi * NS + c];
+      *reinterpret_cast<float *>(smem + off_preview + i * 4) = (n1 == 0.0) ? 0.0f : (float)((double)qd[i] / n1);
+    }
+    bool bad = false;
+    if (tid < NS) {
+      const double n1 = q.norm[(int64_t)qi * NS + tid];
+      bad = (n1 != 0.0) && !(n1 >= 1e-15 && n1 <= 1e15);  // also NaN
+    }
+    // (called by whole waves) any bad column in this wave's share clears the flag; the caller zero-fills it first
+    if (__ballot(bad)) *reinterpret_cast<int *>(smem + off_preview + QP_FLAG) = 0;
+  }
   for (int i = tid; i < DS; i += nthreads) {
     const int c = i / NR, r = i - c * NR;
     *reinterpret_cast<double *>(smem + OFF_QIMG + c * Q_COL_STRIDE + r * 8) = (double)qd[i];
@@ -995,6 +1116,170 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
                        (int64_t)0, (int64_t)a.nslots * k, a.nslots * k, k, d_topk);
     RSX_HIP(hipGetLastError());
   }
+  return RSX_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// sc_walk_kernel: exact re-scoring behind the filter, ONE WAVE per query (single-GPU path).  The short
+// list arrives ordered by bound (by histogram bin, sc_select_kernel), so the wave walks it in ascending
+// order: every candidate sees the tau (k-th best exact distance) of everything before it -- no rounds,
+// no barriers, no cross-wave merges -- and from the k-th hit on most candidates leave pair_group after
+// the alignment + fp32 preview.  It stops at the first bin whose lower edge minus eps exceeds tau.
+// Entries beyond the short list (bound >= t_cap) are scanned from the bounds row only while tau still
+// admits them.  Output: the final top-k, sorted by (dist, global index), padded {1e7,0,0}.
+// LDS per wave: query images (fp64 + fp32 preview) + one pair_group region = 19.9 KB -> 8 waves per CU,
+// 2 per SIMD, 256 registers each (the preview does not spill).
+// ------------------------------------------------------------------------------------------
+struct WalkLds {
+  static constexpr int OFF_QP32 = OFF_WAVES + ENT_SIZE;
+  static constexpr int SIZE = OFF_QP32 + QP_SIZE;
+};
+
+__device__ __forceinline__ float bound_bin_lo(float lb) {  // lower edge of the 2048-bin histogram bin of lb
+  if (!(lb > 0.0f)) return -INFINITY;
+  const float x = lb * 2048.0f;
+  return x >= 2047.0f ? 2047.0f / 2048.0f : floorf(x) / 2048.0f;
+}
+
+__global__ __launch_bounds__(64, 2) void sc_walk_kernel(RescoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x;
+  char *wsm = smem + OFF_WAVES;
+
+  int64_t n_elig = a.n_eligible;
+  if (a.q_elig) {
+    const int64_t e = a.q_elig[qi];
+    n_elig = e < n_elig ? e : n_elig;
+  }
+  int64_t n_rows = 0;  // local slots [0, n_rows) are the eligible ones
+  if (n_elig > a.db.idx_base) {
+    n_rows = (n_elig - a.db.idx_base + a.db.idx_stride - 1) / a.db.idx_stride;
+    n_rows = n_rows < a.n_items ? n_rows : a.n_items;
+  }
+
+  double ld = INFINITY;  // sorted top-k, one record per lane
+  int li = 0x7fffffff, ls = 0;
+  double tau = INFINITY;
+  bool query_loaded = false;
+
+  auto ensure_query = [&]() {
+    if (!query_loaded) {
+      if (lane == 0) *reinterpret_cast<int *>(smem + WalkLds::OFF_QP32 + QP_FLAG) = 1;
+      load_query_to_lds(a.q, qi, smem, lane, 64, WalkLds::OFF_QP32);
+      query_loaded = true;
+    }
+  };
+  // score one entry whose registers are already loaded (or being loaded)
+  auto score_regs = [&](int32_t slot, const EntryRegs &er) {
+    ensure_query();
+    const int64_t eslot[1] = {slot};
+    double bd;
+    int bk;
+    pair_group<1, true>(a.db, smem, wsm, lane, eslot, bd, bk, a.round_begin ? INFINITY : tau, WalkLds::OFF_QP32, &er);
+    const double dist = __shfl(bd, 0);
+    const int shift = __shfl(bk, 0);
+    const int64_t gidx = a.db.idx_base + (int64_t)slot * a.db.idx_stride;
+    if (gidx < n_elig && dist < kBig) {
+      topk_insert(ld, li, ls, lane, a.k, dist, (int)gidx, shift);
+      tau = __shfl(ld, a.k - 1);  // +inf until k hits exist
+    }
+  };
+  auto score = [&](int32_t slot) {
+    EntryRegs er;
+    load_entry(a.db, slot, lane, er);
+    score_regs(slot, er);
+  };
+
+  // ---- the short list, ascending bin order; the registers of entry i+1 are requested before entry i is
+  // scored, so their global-memory latency hides behind its arithmetic ----
+  const int sl_cnt = a.sl_cnt[qi];
+  const RescoreEntry *sl = a.slist + (int64_t)qi * RS_CAND_CAP;
+  const float t_cap = a.thr[(int64_t)qi * RESCORE_NUM_THR + (RESCORE_NUM_THR - 1)];
+  bool done = false;
+  for (int base = 0; base < sl_cnt && !done; base += 64) {
+    const int n_here = (sl_cnt - base < 64) ? (sl_cnt - base) : 64;
+    RescoreEntry mine;  // one coalesced read per 64 candidates
+    mine.lb = INFINITY;
+    mine.slot = 0;
+    if (lane < n_here) mine = sl[base + lane];
+    EntryRegs cur, nxt;
+    load_entry(a.db, __shfl(mine.slot, 0), lane, cur);
+    for (int i = 0; i < n_here; i++) {
+      const float lb = __shfl(mine.lb, i);
+      const int32_t slot = __shfl(mine.slot, i);
+      if (i + 1 < n_here) load_entry(a.db, __shfl(mine.slot, i + 1), lane, nxt);
+      // every later entry sits in this bin or a higher one
+      if ((double)bound_bin_lo(lb) - a.eps > tau) {
+        done = true;
+        break;
+      }
+      if (!((double)lb - a.eps > tau)) score_regs(slot, cur);  // NaN / -inf bounds: always scored
+      cur = nxt;
+    }
+  }
+
+  // ---- entries beyond the short list (bound >= t_cap), only while tau admits them ----
+  if (!done && t_cap < INFINITY && !((double)t_cap - a.eps > tau)) {
+    const float *row = a.lb + (int64_t)qi * a.ld_lb;
+    const bool take_all = (t_cap == -INFINITY);  // empty short list: NaN bounds are here too
+    for (int64_t pos = 0; pos < n_rows; pos += 64) {
+      const int64_t i = pos + lane;
+      const float d = (i < n_rows) ? row[i] : INFINITY;
+      const bool beyond = take_all ? true : (d >= t_cap);
+      unsigned long long bal = __ballot((i < n_rows) && beyond && (d != INFINITY));
+      while (bal) {
+        const int l = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const float dl = __shfl(d, l);
+        if ((double)dl - a.eps > tau) continue;
+        score((int32_t)(pos + l));
+      }
+    }
+  }
+
+  if (lane < a.k) {
+    rsx_sc_hit h;
+    if (ld == INFINITY) {
+      h.dist = kBig; h.index = 0; h.shift = 0;
+    } else {
+      h.dist = ld; h.index = li; h.shift = ls;
+    }
+    a.out[(int64_t)qi * a.k + lane] = h;
+  }
+}
+
+int launch_walk(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
+                int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
+                const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s) {
+  if (q.nq <= 0) return RSX_OK;
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                WalkLds::SIZE));
+    attr_set = true;
+  }
+  RescoreArgs a;
+  a.db = db;
+  a.q = q;
+  a.lb = lb;
+  a.ld_lb = ld_lb;
+  a.n_items = n_items;
+  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
+  a.q_elig = q_elig;
+  a.slist = slist;
+  a.sl_cnt = sl_cnt;
+  a.thr = thr;
+  a.out = d_out;
+  a.tau_src = nullptr;
+  a.seed = nullptr;
+  a.eps = eps;
+  a.k = k;
+  a.round_begin = getenv("RSX_WALK_NOPREVIEW") ? 1 : 0;  // experiment: disable the pruning preview
+  a.round_end = RESCORE_ALL_ROUNDS;
+  hipLaunchKernelGGL(sc_walk_kernel, dim3(q.nq), dim3(64), WalkLds::SIZE, s, a);
+  RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 
