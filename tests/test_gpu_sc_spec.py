@@ -163,3 +163,34 @@ def test_default_kind_is_spectral(sc, rsx, synth):
     g2.add_descriptors_f32(holes)
     g2.query(holes[:16], k=3)
     assert g2.profiled_kernel_name() == "sc_filter_kernel"
+
+
+def test_walk_rescoring_matches_rounds():
+    """RSX_SC_RESCORE=walk (one wave per query over the bound-ordered short list, fp32 pruning preview) returns
+    the same records as the default rounds kernel and the unfiltered path; the switch is read once per
+    process, hence the subprocess."""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np
+from navtech_radar_slam_amd import scancontext as sc, synth, _rsx
+n, nq, k = 6000, 96, 10
+descs = synth.random_descriptors(11, n, binary=False)
+descs[100:130] *= np.float32(1e-20)          # scales at which the preview must switch itself off
+descs[200] = 0
+rng = np.random.default_rng(2)
+q = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+q[::5, rng.integers(0, 1200, 80)] = 0
+q[3] = 0
+q[7] = descs[110]
+f = sc.SCManager(filter_mode=_rsx.FILTER_FORCE, capacity_hint=n); f.add_descriptors_f32(descs)
+o = sc.SCManager(filter_mode=_rsx.FILTER_OFF, capacity_hint=n); o.add_descriptors_f32(descs)
+for kk, ne in ((k, n - 30), (1, n), (32, 500)):
+    assert np.array_equal(f.query(q, k=kk, n_eligible=ne), o.query(q, k=kk, n_eligible=ne)), (kk, ne)
+print("WALK-OK")
+'''
+    env = dict(os.environ, RSX_SC_RESCORE="walk")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert "WALK-OK" in r.stdout, r.stdout + r.stderr
