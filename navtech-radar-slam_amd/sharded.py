@@ -13,7 +13,7 @@ lowest-index-wins scan of the reference exactly.  Messages are tiny (nq * k * 16
 exchanges are latency-bound, so queries are batched.
 
 `local_backend` is a seam for the CPU (gloo) tests, which have no GPU: anything with
-add_descriptors_f32(descs), query_stage1(q, k, n_eligible) and query_stage2(global_topk), both
+add_descriptors_f32(descs), query_stage1(q, k, n_eligible[, q_elig]) and query_stage2(global_topk), both
 -> (nq, k) HIT_DTYPE records.  The default is the GPU SCManager; there is no CPU fallback in the
 product path.
 """
@@ -104,18 +104,27 @@ class ShardedScanContext:
         self._dist.all_gather_into_tensor(parts, lt, group=self.group)
         return scancontext.merge_topk(parts.numpy().view(HIT_DTYPE).reshape(self.world, nq, k))
 
-    def query(self, q_descs, k=1, n_eligible=-1):
-        """Host-array convenience form -> (nq, k) HIT_DTYPE, identical on every rank."""
+    def query(self, q_descs, k=1, n_eligible=-1, q_elig=None):
+        """Host-array convenience form -> (nq, k) HIT_DTYPE, identical on every rank.
+        q_elig (optional, int64[nq]): query i only sees global indices < min(n_eligible, q_elig[i])."""
         torch = self._torch
         q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
         nq = q.shape[0]
+        if q_elig is not None:
+            q_elig = np.ascontiguousarray(q_elig, dtype=np.int64).reshape(nq)
         if self.on_gpu:
             dq = torch.from_numpy(q).to(self.device)
             s = torch.cuda.current_stream().cuda_stream
-            out = self.query_device(dq.data_ptr(), nq, k, n_eligible, stream=s)
+            de = torch.from_numpy(q_elig).to(self.device) if q_elig is not None else None
+            mono = bool(q_elig is not None and np.all(np.diff(q_elig) >= 0))
+            out = self.query_device(dq.data_ptr(), nq, k, n_eligible, stream=s, q_elig_ptr=de.data_ptr() if de is not None else 0,
+                                    elig_monotone=mono)
             torch.cuda.synchronize()
             return out.cpu().numpy().view(HIT_DTYPE).reshape(nq, k)
-        part = np.ascontiguousarray(self.backend.query_stage1(q, k, n_eligible), dtype=HIT_DTYPE)
+        if q_elig is not None:
+            part = np.ascontiguousarray(self.backend.query_stage1(q, k, n_eligible, q_elig), dtype=HIT_DTYPE)
+        else:
+            part = np.ascontiguousarray(self.backend.query_stage1(q, k, n_eligible), dtype=HIT_DTYPE)
         if self.world == 1:
             return np.ascontiguousarray(self.backend.query_stage2(part), dtype=HIT_DTYPE)
         bound = self._gather_merge_host(part, nq, k)

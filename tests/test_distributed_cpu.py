@@ -31,14 +31,16 @@ class OracleShard:
                 self.m.add_descriptor(d.astype(np.float64))
             self.n_global += 1
 
-    def _search(self, q, k, n_eligible, subset_mod=None, tau=None):
+    def _search(self, q, k, n_eligible, subset_mod=None, tau=None, q_elig=None):
         """Exact local top-k; subset_mod: only local slots s with s % 3 == 0 (a stage-1 stand-in);
-        tau (per query): drop hits a global bound already excludes (what stage 2 may skip)."""
+        tau (per query): drop hits a global bound already excludes (what stage 2 may skip);
+        q_elig (per query): additional eligibility limit on the global index."""
         if n_eligible < 0:
             n_eligible = self.n_global
-        n_local_elig = len(range(self.rank, min(n_eligible, self.n_global), self.world))
         out = np.zeros((q.shape[0], k), dtype=self.o.HIT_DTYPE)
         for i in range(q.shape[0]):
+            lim = min(n_eligible, self.n_global) if q_elig is None else min(n_eligible, self.n_global, int(q_elig[i]))
+            n_local_elig = len(range(self.rank, lim, self.world))
             r = self.m.exhaustive(q[i].astype(np.float64), n_eligible=n_local_elig, k=max(k, n_local_elig))
             keep = r["dist"] < 1e7
             if subset_mod is not None:
@@ -51,13 +53,13 @@ class OracleShard:
             out[i][:len(r)] = r
         return out
 
-    def query_stage1(self, q, k, n_eligible):
-        self._q, self._k, self._ne = q, k, n_eligible
-        return self._search(q, k, n_eligible, subset_mod=3)
+    def query_stage1(self, q, k, n_eligible, q_elig=None):
+        self._q, self._k, self._ne, self._qe = q, k, n_eligible, q_elig
+        return self._search(q, k, n_eligible, subset_mod=3, q_elig=q_elig)
 
     def query_stage2(self, global_topk):
         kth = np.where(global_topk["dist"][:, -1] < 1e7, global_topk["dist"][:, -1], np.inf)
-        return self._search(self._q, self._k, self._ne, tau=kth)
+        return self._search(self._q, self._k, self._ne, tau=kth, q_elig=self._qe)
 
 
 def _worker(rank, world, port, ret):
@@ -83,6 +85,13 @@ def _worker(rank, world, port, ret):
             for i in range(nq):
                 want = full.exhaustive(queries[i].astype(np.float64), n_eligible=n if n_elig < 0 else n_elig, k=k)
                 assert np.array_equal(got[i], want), (rank, n_elig, i, got[i], want)
+        # every keyframe against the keyframes at least 30 older than itself (BASELINE configs 4/5 over shards)
+        sub = np.arange(40, n, 23)
+        lim = np.maximum(sub - 30, 0)
+        got = sc.query(descs[sub], k=3, q_elig=lim)
+        for j, i in enumerate(sub):
+            want = full.exhaustive(descs[i].astype(np.float64), n_eligible=int(lim[j]), k=3)
+            assert np.array_equal(got[j], want), (rank, i, got[j], want)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
