@@ -231,7 +231,7 @@ int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
   RSX_TRY(h->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
   RSX_TRY(h->f_cand.reserve((size_t)qb * RESCORE_SHORTLIST_CAP * sizeof(RescoreEntry), s, false));
   RSX_TRY(h->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
-  RSX_TRY(h->f_thr.reserve((size_t)qb * RESCORE_NUM_THR * sizeof(float), s, false));
+  RSX_TRY(h->f_thr.reserve((size_t)qb * RESCORE_THR_STRIDE * sizeof(float), s, false));
   return RSX_OK;
 }
 
@@ -275,8 +275,7 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     q.nq = bn;
     const int64_t *elig = d_q_elig ? d_q_elig + b0 : nullptr;
     // size of the first re-scoring round (scored with tau = +inf); later rounds double.  Measured on MI355X
-    // (10k DB, 8192 queries): 64 -> 6.05 ms per step, 32 -> 6.17, 16 -> 6.43 (every extra round costs a scan of the
-    // short list, two barriers and a merge)
+    // (10k DB, 8192 queries): 64 -> 5.48 ms per step, 32 -> 5.53, 16 -> 5.68
     static const int32_t first_target = [] {
       const char *e = getenv("RSX_SC_FIRST_TARGET");
       const int v = e ? atoi(e) : 0;

@@ -612,7 +612,8 @@ __global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict_
       if (b > H_BINS - 1) b = H_BINS - 1;
       if (b > b_cap) b = b_cap;
     }
-    thr[(int64_t)q * RESCORE_NUM_THR + threadIdx.x] = bin_edge(b);
+    thr[(int64_t)q * RESCORE_THR_STRIDE + threadIdx.x] = bin_edge(b);
+    reinterpret_cast<int32_t *>(thr)[(int64_t)q * RESCORE_THR_STRIDE + RESCORE_NUM_THR + threadIdx.x] = b >= 0 ? hist[b] : 0;
   }
   // compaction of bins <= b_cap, ORDERED BY BIN (counting sort: entry of bin b goes to [cum[b-1], cum[b]),
   // any order inside a bin): sc_walk_kernel walks the list in ascending-bound order, sc_rescore_kernel

@@ -70,6 +70,9 @@ int launch_knn(const float *rkeys, int64_t n_search, const float *qkey, int32_t 
 // ---- exact re-scoring behind the filter ----
 constexpr int RESCORE_SHORTLIST_CAP = 2048;  // short-list records per query
 constexpr int RESCORE_NUM_THR = 6;           // round edges t_0..t_4 and t_cap
+// per query: RESCORE_NUM_THR float edges, then RESCORE_NUM_THR int32 counts (short-list entries below each edge:
+// the list is ordered by bin, so round r is the range [count[r-1], count[r]))
+constexpr int RESCORE_THR_STRIDE = 2 * RESCORE_NUM_THR;
 struct RescoreEntry {
   float lb;      // filter bound
   int32_t slot;  // local DB slot

@@ -739,13 +739,18 @@ __global__ __launch_bounds__(1024) void sc_knn_kernel(const float *__restrict__ 
 // tau still admits them.  Output: the final top-k, sorted by (dist, global index), padded {1e7,0,0}.
 // ------------------------------------------------------------------------------------------
 constexpr int RS_CAND_CAP = RESCORE_SHORTLIST_CAP;  // 2048
+#ifndef RSX_RESCORE_PREVIEW
+#define RSX_RESCORE_PREVIEW 1
+#endif
+constexpr bool kRescorePreview = RSX_RESCORE_PREVIEW != 0;
 
 template <int B, int RS_WAVES>
 struct RescoreLds {
   static constexpr int OFF_CAND = OFF_WAVES + RS_WAVES * B * ENT_SIZE;
   static constexpr int OFF_XCH = OFF_CAND + RS_CAND_CAP * 4;                       // int32 candidate slots
   static constexpr int OFF_MISC = OFF_XCH + RS_WAVES * RSX_SC_MAX_TOPK * 16;       // per-wave top-k lists
-  static constexpr int SIZE = OFF_MISC + 64;
+  static constexpr int OFF_QP32 = OFF_MISC + 64;                                    // fp32 preview image of the query
+  static constexpr int SIZE = OFF_QP32 + QP_SIZE;
 };
 
 struct RescoreArgs {
@@ -756,7 +761,8 @@ struct RescoreArgs {
   const int64_t *q_elig;
   const RescoreEntry *slist;  // [nq][RS_CAND_CAP]
   const int32_t *sl_cnt;      // [nq]
-  const float *thr;           // [nq][RESCORE_NUM_THR]: round edges t_0 <= t_1 <= ... ; the last one is t_cap
+  const float *thr;           // [nq][RESCORE_THR_STRIDE]: round edges t_0 <= t_1 <= ... (the last one is t_cap), then the
+                              // number of short-list entries below each edge as int32
   rsx_sc_hit *out;            // [nq][k]
   const rsx_sc_hit *tau_src;  // optional [nq][k]: a top-k over MORE than this shard (its k-th distance bounds tau)
   const rsx_sc_hit *seed;     // optional [nq][k]: hits this shard already found in an earlier stage
@@ -765,44 +771,44 @@ struct RescoreArgs {
   int32_t round_begin, round_end;  // rounds [begin, end) of the short list; end > RESCORE_NUM_THR: also the rest
 };
 
-// k-th smallest valid record (by (dist, index)) of the nrec records in xch, found by k rounds of
-// "smallest record after the previous pick" on ONE wave; when out != nullptr the picks are written
-// to out[0..k) padded with {1e7,0,0} (SC.cpp:362-364).  Returns the k-th distance or +inf.
+// k-th smallest valid record (by (dist, index)) of the nrec records in xch, by RANK COUNTING on one wave:
+// every lane takes a record and counts the valid records before it (nrec broadcast LDS reads, no
+// dependent cross-lane steps -- the first version selected the minimum k times with a 6-step shuffle
+// reduction each, ~20 k cycles per merge, which made every re-scoring round cost as much as 3 pair
+// evaluations).  Records are distinct under the order (every entry is scored once).  When out != nullptr
+// the k smallest are written to out[0..k) in order, padded with {1e7,0,0} (SC.cpp:362-364).  Returns the
+// k-th distance or +inf.
 __device__ __forceinline__ double wave_select_kth(const rsx_sc_hit *xch, int nrec, int k, int lane, rsx_sc_hit *out) {
-  double pd = -INFINITY;
-  int pi = -1;
   double kth = INFINITY;
-  for (int r = 0; r < k; r++) {
-    double bd = INFINITY;
-    int bi = 0x7fffffff, bs = 0;
-    for (int t = lane; t < nrec; t += 64) {
-      const rsx_sc_hit h = xch[t];
-      if (!(h.dist < kBig)) continue;  // padding
-      if (hit_before(pd, pi, h.dist, h.index) && hit_before(h.dist, h.index, bd, bi)) {
-        bd = h.dist; bi = h.index; bs = h.shift;
-      }
-    }
+  int nvalid = 0;
+  for (int base = 0; base < nrec; base += 64) {  // uniform trip count
+    const int t = base + lane;
+    rsx_sc_hit me;
+    me.dist = kBig; me.index = 0; me.shift = 0;
+    if (t < nrec) me = xch[t];
+    const bool valid = me.dist < kBig;  // padding is {>= 1e7, ...}
+    int rank = 0;
+    int j = 0;
+    for (; j + 8 <= nrec; j += 8) {  // 8 reads in flight per step (one LDS round trip per 8 records, not per record)
+      rsx_sc_hit o[8];
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-      const double od = __shfl_xor(bd, off);
-      const int oi = __shfl_xor(bi, off), os = __shfl_xor(bs, off);
-      if (hit_before(od, oi, bd, bi)) {
-        bd = od; bi = oi; bs = os;
-      }
+      for (int u = 0; u < 8; u++) o[u] = xch[j + u];  // same address in every lane: broadcast reads
+#pragma unroll
+      for (int u = 0; u < 8; u++) rank += ((o[u].dist < kBig) && hit_before(o[u].dist, o[u].index, me.dist, me.index)) ? 1 : 0;
     }
-    if (out && lane == 0) {
-      rsx_sc_hit h;
-      if (bd == INFINITY) {
-        h.dist = kBig; h.index = 0; h.shift = 0;
-      } else {
-        h.dist = bd; h.index = bi; h.shift = bs;
-      }
-      out[r] = h;
+    for (; j < nrec; j++) {
+      const rsx_sc_hit o = xch[j];
+      rank += ((o.dist < kBig) && hit_before(o.dist, o.index, me.dist, me.index)) ? 1 : 0;
     }
-    if (r == k - 1) kth = bd;
-    pd = bd;
-    pi = bi;
-    if (bd == INFINITY && !out) break;  // fewer than k hits so far
+    if (out && valid && rank < k) out[rank] = me;
+    const unsigned long long is_kth = __ballot(valid && rank == k - 1);
+    if (is_kth) kth = __shfl(me.dist, __ffsll((long long)is_kth) - 1);
+    nvalid += __popcll(__ballot(valid));
+  }
+  if (out) {
+    rsx_sc_hit pad;
+    pad.dist = kBig; pad.index = 0; pad.shift = 0;
+    for (int r = nvalid + lane; r < k; r += 64) out[r] = pad;
   }
   return kth;
 }
@@ -865,7 +871,9 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   auto score_and_merge = [&](int ncand) {
     if (ncand == 0) return;  // (uniform) nothing selected: lists and tau are unchanged
     if (!query_loaded) {
-      load_query_to_lds(a.q, qi, smem, threadIdx.x, RS_WAVES * 64);
+      if (threadIdx.x == 0) *reinterpret_cast<int *>(smem + L::OFF_QP32 + QP_FLAG) = 1;
+      __syncthreads();
+      load_query_to_lds(a.q, qi, smem, threadIdx.x, RS_WAVES * 64, L::OFF_QP32);
       __syncthreads();
       query_loaded = true;
     }
@@ -882,7 +890,9 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
       }
       double bd;
       int bk;
-      pair_group<B>(a.db, smem, wsm, lane, eslot, bd, bk);
+      // tau is finite from the second round on: candidates then leave after the alignment + fp32 preview unless
+      // they can still reach the top-k
+      pair_group<B, kRescorePreview>(a.db, smem, wsm, lane, eslot, bd, bk, tau, L::OFF_QP32);
 #pragma unroll
       for (int b = 0; b < B; b++) {
         const double dist = __shfl(bd, b * 8);
@@ -921,7 +931,8 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   // ---- rounds over the short list ----
   const int sl_cnt = a.sl_cnt[qi];
   const RescoreEntry *sl = a.slist + (int64_t)qi * RS_CAND_CAP;
-  const float *thr = a.thr + (int64_t)qi * RESCORE_NUM_THR;
+  const float *thr = a.thr + (int64_t)qi * RESCORE_THR_STRIDE;
+  const int32_t *rcnt = reinterpret_cast<const int32_t *>(thr) + RESCORE_NUM_THR;
   const float t_cap = thr[RESCORE_NUM_THR - 1];
   float lo = a.round_begin > 0 ? thr[a.round_begin - 1] : -INFINITY;
   bool done = false;
@@ -933,11 +944,12 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
       done = true;
       break;
     }
-    for (int i = threadIdx.x; i < sl_cnt; i += RS_WAVES * 64) {  // sl_cnt <= 2048: at most 2 trips
+    // the short list is ordered by bin and the round edges are bin edges: round r is one contiguous range
+    // (bin 0, first in the list, also holds the NaN / -inf "always re-score" bounds)
+    const int i0 = r > 0 ? rcnt[r - 1] : 0, i1 = rcnt[r] < sl_cnt ? rcnt[r] : sl_cnt;
+    for (int i = i0 + threadIdx.x; i < i1; i += RS_WAVES * 64) {
       const RescoreEntry e = sl[i];
-      // the first non-empty round also owns NaN / -inf bounds ("always re-score")
-      const bool in_round = (lo == -INFINITY) ? !(e.lb >= hi) : (e.lb >= lo && e.lb < hi);
-      append(in_round && !((double)e.lb - a.eps > tau), e.slot);
+      append(!((double)e.lb - a.eps > tau), e.slot);
     }
     __syncthreads();
     const int ncand = *s_ncand;
@@ -1195,7 +1207,7 @@ __global__ __launch_bounds__(64, 2) void sc_walk_kernel(RescoreArgs a) {
   // scored, so their global-memory latency hides behind its arithmetic ----
   const int sl_cnt = a.sl_cnt[qi];
   const RescoreEntry *sl = a.slist + (int64_t)qi * RS_CAND_CAP;
-  const float t_cap = a.thr[(int64_t)qi * RESCORE_NUM_THR + (RESCORE_NUM_THR - 1)];
+  const float t_cap = a.thr[(int64_t)qi * RESCORE_THR_STRIDE + (RESCORE_NUM_THR - 1)];
   bool done = false;
   for (int base = 0; base < sl_cnt && !done; base += 64) {
     const int n_here = (sl_cnt - base < 64) ? (sl_cnt - base) : 64;
