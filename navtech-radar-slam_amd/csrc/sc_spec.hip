@@ -49,10 +49,12 @@
 //        L~ = 1 - max_k S_k u(n_eff(k)) - kSpecEps sqrt(n_q n_e) / n_lo + filter_eps()
 //   so that the direct filter's contract (L~ - filter_eps() <= L) holds unchanged downstream.
 //
-// Mapping: one wave per 32 entries (304 registers of entry spectra, resident), 4 waves = 128 entries per
-// block, queries streamed through LDS in tiles of 4 (one tile per phase, double buffered, global_load_lds).
-// Per (4 queries x 32 entries): 76 stage-1 MFMAs (one ds_read_b128 A fragment each) + 16 stage-2 MFMAs +
-// 8 (double-length fp8) mask MFMAs, against 600 MFMAs for the same pairs in the direct filter.
+// Mapping: one wave per 32 entries (76 B fragments = 304 registers of entry spectra: 64 fragments in the AGPRs,
+// 6 in VGPRs, the 6 of f = 0 parked in LDS), 4 waves = 128 entries per block, one wave per SIMD; queries
+// streamed through LDS in tiles of 4 (three tile buffers, global_load_lds two tiles ahead, counted vmcnt +
+// raw s_barrier).  Per (4 queries x 32 entries): 76 stage-1 MFMAs (one ds_read_b128 A fragment each, hand-
+// issued ring) + 16 stage-2 MFMAs + 8 (double-length fp8) mask MFMAs, against 600 MFMAs for the same pairs
+// in the direct filter.  DESIGN.md 4.1b has the cycle budget of a tile and what limits it.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -129,8 +131,8 @@ constexpr int SP_BPARK_OFF = SP_NBUF * SP_PHASE_BYTES;       // after the tile b
 constexpr int SP_LDS_BYTES = SP_BPARK_OFF + 4 * SP_B_LDS * 1024;
 static_assert(SP_LDS_BYTES <= 160 * 1024, "LDS budget");
 
-// -DRSX_SPEC_INSTRUMENT=1 compiles in the timing experiments (RSX_SPEC_DBG: skip parts of the tile) and the
-// per-region s_memtime profile (RSX_SPEC_PROF); they cost registers, so normal builds leave them out
+// -DRSX_SPEC_INSTRUMENT=1 compiles in the timing experiments (RSX_SPEC_DBG: run without the DMA / the stores) and
+// the per-region s_memtime profile (RSX_SPEC_PROF); they cost registers, so normal builds leave them out
 #ifndef RSX_SPEC_INSTRUMENT
 #define RSX_SPEC_INSTRUMENT 0
 #endif
@@ -300,7 +302,7 @@ struct SpecArgs {
   float *lb;
   int64_t ld_lb;
   float eps_direct;
-  int32_t dbg;  // timing experiments (RSX_SPEC_DBG): 1 = skip the tail, 2 = skip stage 1, 4 = no DMA, 8 = no stores
+  int32_t dbg;  // timing experiments of RSX_SPEC_INSTRUMENT builds (RSX_SPEC_DBG): 4 = no DMA, 8 = no stores
   unsigned long long *prof;  // RSX_SPEC_PROF: s_memtime sums per region of (workgroup 0, wave 0)
   const int32_t *tb_qmin;  // optional plan, in query-tile units (see sc_filter.hip)
   const int64_t *tb_cum;
