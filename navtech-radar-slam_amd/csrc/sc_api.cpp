@@ -31,7 +31,7 @@ struct rsx_sc {
   int64_t n_global = 0, n_local = 0, cap = 0;
   DevBuf desc, vkey, norm, rkey;
   DevBuf hn, cmask;  // fp16 filter image (tile-major) + column masks (sc_filter.hip)
-  DevBuf sp;         // fp16 spectral filter image (sc_spec.hip)
+  DevBuf sp, sp_aux; // fp16 spectral filter image + per-entry error-budget scalar (sc_spec.hip)
   // detector state (SC.h:104,117-120)
   int tree_counter = 0;
   int64_t tree_size = 0;
@@ -73,6 +73,7 @@ int ensure_capacity(rsx_sc *h, int64_t want_local) {
   RSX_TRY(h->hn.reserve((size_t)nc * FILTER_DB_BYTES_PER_ENTRY, h->stream, true));  // nc is a multiple of 32
   RSX_TRY(h->cmask.reserve((size_t)nc * sizeof(uint64_t), h->stream, true));
   RSX_TRY(h->sp.reserve((size_t)nc * SPEC_DB_BYTES_PER_ENTRY, h->stream, true));
+  RSX_TRY(h->sp_aux.reserve((size_t)nc * sizeof(float), h->stream, true));
   h->cap = nc;
   return RSX_OK;
 }
@@ -86,6 +87,7 @@ DbView db_view(const rsx_sc *h) {
   v.hnT = h->hn.p;
   v.cmask = h->cmask.as<uint64_t>();
   v.spT = h->sp.p;
+  v.sp_aux = h->sp_aux.as<float>();
   v.n_local = h->n_local;
   v.idx_base = h->p.shard_rank;
   v.idx_stride = h->p.shard_world;
@@ -95,7 +97,7 @@ DbView db_view(const rsx_sc *h) {
 // both filter images + column masks of local slots [slot, slot+count); synchronises s
 int build_db_images(rsx_sc *h, int64_t slot, int64_t count, hipStream_t s) {
   RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->hn.p, h->cmask.as<uint64_t>(), s));
-  RSX_TRY(launch_spec_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->sp.p, s));
+  RSX_TRY(launch_spec_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->sp.p, h->sp_aux.as<float>(), s));
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
 }
@@ -449,7 +451,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();

@@ -22,6 +22,7 @@ struct DbView {
   const void *hnT;     // filter image: column-normalised fp16, tile-major (sc_filter.hip); 2400 B per entry
   const uint64_t *cmask;  // [n_local] bit j = column j has a non-zero norm; bit 63 = non-finite element
   const void *spT;     // spectral filter image: fp16 Z15 spectra, tile-major (sc_spec.hip); 2432 B per entry
+  const float *sp_aux; // [n_local] sqrt of the spectral energy outside f = 0 (error budget of the spectral filter)
   int64_t n_local;
   int64_t idx_base;    // global index of local slot s = idx_base + s * idx_stride
   int64_t idx_stride;
@@ -132,7 +133,8 @@ const char *filter_kernel_name();
 constexpr int SPEC_QIMG_BYTES = 10368;
 constexpr int SPEC_DB_BYTES_PER_ENTRY = 2432;
 size_t spec_qimg_bytes(int32_t nq);
-int launch_spec_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *spT, hipStream_t s);
+int launch_spec_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *spT, float *aux,
+                          hipStream_t s);
 int launch_spec_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, hipStream_t s);
 int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
                        const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s);

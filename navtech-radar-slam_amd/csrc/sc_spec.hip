@@ -45,8 +45,10 @@
 //     <= (2u+u^2) sqrt(n_q n_e)                                                                     = 9.77e-4 sqrt(n_q n_e)
 //   * fp32 accumulation (K = 160: 160 * 2^-23 relative to sum |terms|, and K = 16), C_0 hi/lo split (2^-21),
 //     fp16 subnormals (2^-25 absolute per element), epilogue arithmetic:                             < 4e-5 sqrt(n_q n_e)
-//   total < 1.994e-3 sqrt(n_q n_e); kSpecEps = 2.05e-3.  The kernel returns
-//        L~ = 1 - max_k S_k u(n_eff(k)) - kSpecEps sqrt(n_q n_e) / n_lo + filter_eps()
+//   The stage-2 term only involves the frequencies f != 0, so its Cauchy-Schwarz bound uses the energy outside
+//   f = 0:  a := n - 1/15 sum_{a,r} |X_0[a][r]|^2  (per image, from the exact spectra)  ->  (2u+u^2) sqrt(a_q a_e).
+//   kE1 = 1.02e-3 (spectra rounding + the small terms), kE2 = 1.0e-3.  The kernel returns
+//        L~ = 1 - max_k S_k u(n_eff(k)) - (kE1 sqrt(n_q n_e) + kE2 sqrt(a_q a_e)) / n_lo + filter_eps()
 //   so that the direct filter's contract (L~ - filter_eps() <= L) holds unchanged downstream.
 //
 // Mapping: one wave per 32 entries (76 B fragments = 304 registers of entry spectra: 64 fragments in the AGPRs,
@@ -138,7 +140,7 @@ static_assert(SP_LDS_BYTES <= 160 * 1024, "LDS budget");
 #endif
 constexpr bool kInstr = RSX_SPEC_INSTRUMENT != 0;
 
-constexpr float kSpecEps = 2.05e-3f;
+constexpr float kE1 = 1.02e-3f, kE2 = 1.0e-3f;
 constexpr u64 kNonFinite = 1ull << 63;
 constexpr u64 kMask60 = (1ull << 60) - 1ull;
 
@@ -162,7 +164,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 // returns the column mask (bit j = column j non-zero, bit 63 = non-finite element)
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const double *__restrict__ nrm, double *xn,
-                                          _Float16 *kv, int lane) {
+                                          _Float16 *kv, int lane, float &sqrt_a) {
   bool nonzero = false, bad = false;
   if (lane < NS) {
     const double n = nrm[lane];
@@ -184,6 +186,7 @@ __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const dou
     tw[16 + lane] = sinpi(2.0 * lane / 15.0);
   }
   wave_lds_fence();
+  double dc_energy = 0.0;  // this lane's share of sum |X_0|^2
   for (int idx = lane; idx < 8 * 80; idx += 64) {
     const int f = idx / 80, rem = idx - f * 80, a = rem / NR, r = rem - a * NR;
     double re = 0.0, im = 0.0;
@@ -203,6 +206,7 @@ __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const dou
     }
     if (f == 0) {
       kv[a * 24 + r] = (_Float16)(float)re;
+      dc_energy += re * re;
     } else {
       const int base = 96 + (f - 1) * 160 + a * 40 + r;
       kv[base] = (_Float16)(float)re;
@@ -211,19 +215,27 @@ __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const dou
   }
   if (lane < 16) kv[(lane >> 2) * 24 + 20 + (lane & 3)] = (_Float16)0.0f;  // K padding of f = 0
   wave_lds_fence();
+  // energy outside f = 0 (error budget of stage 2): a = n - sum |X_0|^2 / 15, rounded up a little
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) dc_energy += __shfl_xor(dc_energy, off);
+  const double a_out = (double)__popcll(m & kMask60) - dc_energy / 15.0;
+  sqrt_a = (a_out > 0.0) ? (float)(sqrt(a_out) * (1.0 + 1e-6)) + 1e-6f : 1e-6f;
   return m;
 }
 
 // database image: tile-major [tile of 32 entries][76 K-steps][64 lanes][8 halves]
 __global__ __launch_bounds__(256) void sc_spec_db_kernel(const float *__restrict__ desc, const double *__restrict__ norm,
-                                                         int64_t first, int64_t count, uint4 *__restrict__ spT) {
+                                                         int64_t first, int64_t count, uint4 *__restrict__ spT,
+                                                         float *__restrict__ aux) {
   __shared__ double xn[4][DS + 32];
   __shared__ __attribute__((aligned(16))) _Float16 kv[4][SP_KV];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t it = (int64_t)blockIdx.x * 4 + wave;
   if (it >= count) return;
   const int64_t slot = first + it;
-  (void)spectra_of(desc + slot * DS, norm + slot * NS, xn[wave], kv[wave], lane);
+  float sqrt_a;
+  (void)spectra_of(desc + slot * DS, norm + slot * NS, xn[wave], kv[wave], lane, sqrt_a);
+  if (lane == 0) aux[slot] = sqrt_a;
   const int64_t tile = slot >> 5;
   const int col = (int)(slot & 31);
   for (int c = lane; c < 2 * SP_FRAGS; c += 64)
@@ -233,7 +245,7 @@ __global__ __launch_bounds__(256) void sc_spec_db_kernel(const float *__restrict
 // query image: the LDS layout of the filter kernel, SP_QS bytes per query
 //   [0, 384)                f = 0 stream: 7 blocks (a = 0,1,2,3,0,1,2) x 24
 //   [384 + (f-1)*1152 ...)  re stream: 7 blocks x [Qr | Qi];  + 576: im stream: 7 blocks x [Qi | -Qr]
-//   [8448, 8576)            n_q, flags, sqrt(n_q)
+//   [8448, 8576)            n_q, flags, sqrt(n_q), sqrt(a_q)
 //   [8576, 10368)           16 displaced copies of the column-mask byte stream
 __global__ __launch_bounds__(256) void sc_spec_query_kernel(const float *__restrict__ desc, const double *__restrict__ norm,
                                                             int32_t nq, char *__restrict__ qimg) {
@@ -242,7 +254,8 @@ __global__ __launch_bounds__(256) void sc_spec_query_kernel(const float *__restr
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = blockIdx.x * 4 + wave;
   if (q >= nq) return;
-  const u64 m = spectra_of(desc + (int64_t)q * DS, norm + (int64_t)q * NS, xn[wave], kv[wave], lane);
+  float sqrt_a;
+  const u64 m = spectra_of(desc + (int64_t)q * DS, norm + (int64_t)q * NS, xn[wave], kv[wave], lane, sqrt_a);
   const _Float16 *k = kv[wave];
   uint4 *out = reinterpret_cast<uint4 *>(qimg + (int64_t)q * SP_QS);
   for (int c = lane; c < SP_QS / 16; c += 64) {
@@ -283,7 +296,7 @@ __global__ __launch_bounds__(256) void sc_spec_query_kernel(const float *__restr
       o.x = (unsigned)n;
       o.y = (m & kNonFinite) ? 1u : 0u;
       o.z = __float_as_uint(sqrtf((float)n));
-      o.w = 0u;
+      o.w = __float_as_uint(sqrt_a);
     }
     out[c] = o;
   }
@@ -295,6 +308,7 @@ __global__ __launch_bounds__(256) void sc_spec_query_kernel(const float *__restr
 struct SpecArgs {
   const uint4 *spT;
   const u64 *cmask;
+  const float *aux;  // [n] sqrt of the entry's spectral energy outside f = 0
   const char *qimg;
   int64_t n_items;
   int32_t nq;
@@ -357,7 +371,7 @@ struct SpecLane {
   half8 W;                 // stage-2 A operand (inverse DFT weights)
   intx8 Bm;                // this lane's entry: column-mask bytes as fp8 0 / 1 (B operand of the n_eff MFMAs)
   int n_e;
-  float sqrt_ne;
+  float sqrt_ne, sqrt_ae;
   bool e_bad;
 };
 
@@ -444,7 +458,7 @@ struct Recip {
   float rL;
   int n_q;
   unsigned flags;
-  float sqrt_nq;
+  float sqrt_nq, sqrt_aq;
 };
 __device__ __forceinline__ Recip recip_setup(const char *qbase, const SpecLane &ln) {
   const uint4 tail = *reinterpret_cast<const uint4 *>(qbase + SP_TAIL);
@@ -452,6 +466,7 @@ __device__ __forceinline__ Recip recip_setup(const char *qbase, const SpecLane &
   r.n_q = (int)tail.x;
   r.flags = tail.y;
   r.sqrt_nq = __uint_as_float(tail.z);
+  r.sqrt_aq = __uint_as_float(tail.w);
   const int li = (r.n_q + ln.n_e - NS > 1) ? (r.n_q + ln.n_e - NS) : 1;
   const int hmin = r.n_q < ln.n_e ? r.n_q : ln.n_e;
   const float L = (float)li, H = (float)(hmin > li ? hmin : li);
@@ -627,7 +642,7 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
     const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // 15/16 max_k S_k u(n_k)
     // the error of S is divided by n_k >= n_lo
-    const float err = kSpecEps * r.sqrt_nq * ln.sqrt_ne;
+    const float err = kE1 * r.sqrt_nq * ln.sqrt_ne + kE2 * r.sqrt_aq * ln.sqrt_ae;
     float v = (1.0f + eps_direct) - fmaf(best, (16.0f / 15.0f) * (1.0f + 4e-6f), err * r.rL);
     if (r.n_q == 0 || ln.n_e == 0) v = INFINITY;    // no effective column at any shift: never a hit
     if (r.flags != 0u || ln.e_bad) v = -INFINITY;   // non-finite input: always re-score exactly
@@ -746,6 +761,7 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
     const u64 m2 = n_ok ? a.cmask[n] : 0ull;
     ln.n_e = __popcll(m2 & kMask60);
     ln.sqrt_ne = sqrtf((float)ln.n_e);
+    ln.sqrt_ae = n_ok ? a.aux[n] : 0.0f;
     ln.e_bad = (m2 & kNonFinite) != 0;
     {
       const unsigned bits = (unsigned)((m2 & kMask60) >> (32 * hh));  // columns 32 hh .. 32 hh + 31 (K index of the lane half)
@@ -819,10 +835,11 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
 
 size_t spec_qimg_bytes(int32_t nq) { return (size_t)nq * SPEC_QIMG_BYTES + 1024; }
 
-int launch_spec_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *spT, hipStream_t s) {
+int launch_spec_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *spT, float *aux,
+                          hipStream_t s) {
   if (count <= 0) return RSX_OK;
   hipLaunchKernelGGL(sc_spec_db_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, desc, norm, first, count,
-                     static_cast<uint4 *>(spT));
+                     static_cast<uint4 *>(spT), aux);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
@@ -853,6 +870,7 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
   SpecArgs a;
   a.spT = static_cast<const uint4 *>(db.spT);
   a.cmask = reinterpret_cast<const u64 *>(db.cmask);
+  a.aux = db.sp_aux;
   a.qimg = static_cast<const char *>(qimg);
   a.n_items = n_items;
   a.nq = nq;
