@@ -52,7 +52,7 @@
 //   so that the direct filter's contract (L~ - filter_eps() <= L) holds unchanged downstream.
 //
 // Mapping: one wave per 32 entries (76 B fragments = 304 registers of entry spectra: 64 fragments in the AGPRs,
-// 6 in VGPRs, the 6 of f = 0 parked in LDS), 4 waves = 128 entries per block, one wave per SIMD; queries
+// 4 in VGPRs, the first 8 parked in LDS), 4 waves = 128 entries per block, one wave per SIMD; queries
 // streamed through LDS in tiles of 4 (three tile buffers, global_load_lds two tiles ahead, counted vmcnt +
 // raw s_barrier).  Per (4 queries x 32 entries): 76 stage-1 MFMAs (one ds_read_b128 A fragment each, hand-
 // issued ring) + 16 stage-2 MFMAs + 8 (double-length fp8) mask MFMAs, against 600 MFMAs for the same pairs
@@ -117,16 +117,17 @@ constexpr int SP_PHASE_BYTES = SP_QPP * SP_QS;      // 41472 = 40.5 KiB
 #endif
 constexpr int SP_NBUF = SP_OPT_NBUF;                // LDS tile buffers: the DMA runs SP_NBUF - 1 tiles ahead
 static_assert(SP_PHASE_BYTES / 1024 / 4 + 1 <= 11, "wait_vmcnt_le covers <= 11 DMA instructions per wave and tile");
+static_assert(SP_PHASE_BYTES / 1024 / 4 + 1 <= 3 * SP_QPT, "the tail issues 3 DMA pieces per query");
 #ifndef SP_OPT_BV
 #define SP_OPT_BV 12   // VGPR-resident B fragments are SP_B_LDS .. SP_OPT_BV-1
 #endif
 constexpr int SP_B_VGPR = SP_OPT_BV;  // B fragments kept in VGPRs; the rest live in AGPRs
-// 76 B fragments = 304 registers: 64 fragments fill the 256 AGPRs, 8 sit in VGPRs, and the first SP_B_LDS
-// (the K-steps of f = 0) are parked in LDS (6 KiB per wave) and fetched with the A fragments of each tile
+// 76 B fragments = 304 registers: 64 fragments fill the 256 AGPRs, 4 sit in VGPRs, and the first SP_B_LDS
+// (the 6 K-steps of f = 0 and the first 2 of f = 1) are parked in LDS (8 KiB per wave) and fetched with the A fragments of each tile
 // -- left to the register allocator they were spilled to scratch and reloaded every tile, and every scratch
 // reload drains the vmcnt queue (DMA and bound stores in flight)
 #ifndef SP_OPT_BLDS
-#define SP_OPT_BLDS 6
+#define SP_OPT_BLDS 8
 #endif
 constexpr int SP_B_LDS = SP_OPT_BLDS;
 constexpr int SP_BPARK_OFF = SP_NBUF * SP_PHASE_BYTES;       // after the tile buffers
@@ -333,6 +334,31 @@ __device__ __forceinline__ int stage_queries(const char *gsrc, char *ldst, int n
   return npieces > wave ? (npieces - wave + 3) >> 2 : 0;
 }
 
+// the DMA of a later tile, issued piecewise from inside the tail of the current one: an LDS-DMA instruction
+// costs 100-185 cycles of issue next to ds_reads (stage 1) and 25-60 in VALU-only stretches (the tail)
+struct TileDma {
+  const char *gsrc;
+  char *ldst;
+  int nbytes;  // 0: nothing to load
+};
+__device__ __forceinline__ int dma_pieces_of_wave(int nbytes, int wave) {
+  const int npieces = (nbytes + 1023) >> 10;
+  return npieces > wave ? (npieces - wave + 3) >> 2 : 0;
+}
+// pieces j0 .. j0+count-1 of this wave (piece j of wave w is chunk w + 4 j)
+__device__ __forceinline__ void dma_issue(const TileDma &d, int wave, int lane, int j0, int count) {
+  for (int j = j0; j < j0 + count; j++) {
+    const int c = wave + 4 * j;
+    // scalar base + 32-bit lane offset, formed HERE: hoisted to the top of the tile the dozen 64-bit addresses
+    // do not fit the register file and come back from scratch
+    unsigned off = (unsigned)(c * 1024 + lane * 16);
+    asm volatile("" : "+v"(off));
+    if ((int)off < d.nbytes)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(d.gsrc) + off),
+                                       (AS3 void *)(d.ldst + c * 1024), 16, 0, 0);
+  }
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
   switch (n) {
@@ -396,7 +422,7 @@ __device__ __forceinline__ unsigned long long prof_now() {
 
 constexpr int SP_S1 = SP_FRAGS;   // 76 stage-1 MFMA slots per tile
 #ifndef SP_OPT_DEPTH
-#define SP_OPT_DEPTH 6
+#define SP_OPT_DEPTH 8
 #endif
 constexpr int SP_DEPTH = SP_OPT_DEPTH;  // A fragments in flight
 constexpr int SP_MREADS = 4;      // mask reads per query (2 M-tiles x 32 bytes)
@@ -506,7 +532,8 @@ static_assert(s1_b(0) == 0 && s1_b(SP_B_LDS - 1) == SP_B_LDS - 1 && SP_B_LDS <= 
 static_assert(!kS1Interleave && split_begin() + 8 <= pack_begin(0) && split_begin() + 8 <= first_slot_of(3), "C_0 split window");
 
 __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, const half8 (&B)[SP_FRAGS], const SpecLane &ln,
-                                          float eps_direct, float (&out)[SP_QPT], int dbg, unsigned long long *tmid) {
+                                          float eps_direct, float (&out)[SP_QPT], int dbg, unsigned long long *tmid,
+                                          const TileDma &dma, int wave, int lane) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   typedef unsigned u8v __attribute__((ext_vector_type(8)));
   u4 P[16];
@@ -595,6 +622,7 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     }
     __builtin_amdgcn_sched_barrier(0);
     const Recip r = recip_setup(tbase + q * SP_QS, ln);
+    dma_issue(dma, wave, lane, 3 * q, 3);  // <= 11 pieces per wave and tile
     float m = 0.0f;  // rows 15..31 of the weight matrix are zero anyway (S >= 0 or clamped: valid)
     floatx16 nacc[2];
 #pragma unroll
@@ -785,14 +813,22 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
       const int qp = q0 + p * SP_QPP;
       unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
       if (prof) t0 = prof_now();
-      const int n_issued = (p + SP_NBUF - 1 < nphase) ? stage_tile(p + SP_NBUF - 1) : 0;
+      // the DMA of tile p + SP_NBUF - 1: issued piecewise inside this tile's tail (waves without a tile issue it here)
+      TileDma dma{nullptr, nullptr, 0};
+      if (p + SP_NBUF - 1 < nphase && !(kInstr && (a.dbg & 4))) {
+        const int pn = p + SP_NBUF - 1, qn = q0 + pn * SP_QPP;
+        const int nqs = (q1 - qn < SP_QPP) ? (q1 - qn) : SP_QPP;
+        dma = TileDma{a.qimg + (int64_t)qn * SP_QS, smem + (pn % SP_NBUF) * SP_PHASE_BYTES, nqs * SP_QS};
+      }
+      const int n_issued = dma_pieces_of_wave(dma.nbytes, wave);
+      if (!tile_ok) dma_issue(dma, wave, lane, 0, 3 * SP_QPT);
       const int n_young = SP_NBUF > 2 ? n_issued : 0;  // DMA instructions younger than those of tile p + 1
       if (prof) t1 = prof_now();
       const int nq_here = (q1 - qp < SP_QPP) ? (q1 - qp) : SP_QPP;
       if (tile_ok) {
         const char *tbase = smem + (p % SP_NBUF) * SP_PHASE_BYTES;
         float out[SP_QPT];
-        spec_tile(lds_base + (unsigned)(tbase - smem), tbase, B, ln, a.eps_direct, out, a.dbg, prof ? &t2 : nullptr);
+        spec_tile(lds_base + (unsigned)(tbase - smem), tbase, B, ln, a.eps_direct, out, a.dbg, prof ? &t2 : nullptr, dma, wave, lane);
         if (prof) {
           asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]));
           t3 = prof_now();
