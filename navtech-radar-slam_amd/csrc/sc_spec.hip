@@ -341,6 +341,13 @@ struct TileDma {
   char *ldst;
   int nbytes;  // 0: nothing to load
 };
+// where the bounds of a tile go: row0 = &lb[first query of the tile][this lane's entry]
+struct TileOut {
+  float *row0;
+  int64_t ld;
+  int nq_here;  // valid queries in the tile
+  bool n_ok;    // this lane's entry exists
+};
 __device__ __forceinline__ int dma_pieces_of_wave(int nbytes, int wave) {
   const int npieces = (nbytes + 1023) >> 10;
   return npieces > wave ? (npieces - wave + 3) >> 2 : 0;
@@ -533,7 +540,7 @@ static_assert(!kS1Interleave && split_begin() + 8 <= pack_begin(0) && split_begi
 
 __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, const half8 (&B)[SP_FRAGS], const SpecLane &ln,
                                           float eps_direct, float (&out)[SP_QPT], int dbg, unsigned long long *tmid,
-                                          const TileDma &dma, int wave, int lane) {
+                                          const TileDma &dma, int wave, int lane, const TileOut &to) {
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   typedef unsigned u8v __attribute__((ext_vector_type(8)));
   u4 P[16];
@@ -675,6 +682,13 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     if (r.n_q == 0 || ln.n_e == 0) v = INFINITY;    // no effective column at any shift: never a hit
     if (r.flags != 0u || ln.e_bad) v = -INFINITY;   // non-finite input: always re-score exactly
     out[q] = v;
+    // both lane halves hold the bounds: lanes 0..31 store the even query of a pair, lanes 32..63 the odd one --
+    // one store instruction per two queries, issued here inside the VALU-bound tail rather than after it
+    if constexpr (q & 1) {
+      const int qq = (q - 1) + ln.hh;
+      const float vv = ln.hh ? out[q] : out[q - 1];
+      if (to.n_ok && qq < to.nq_here && !(kInstr && (dbg & 8) && vv != 12345.0f)) to.row0[(int64_t)qq * to.ld] = vv;
+    }
   });
 }
 
@@ -828,18 +842,11 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
       if (tile_ok) {
         const char *tbase = smem + (p % SP_NBUF) * SP_PHASE_BYTES;
         float out[SP_QPT];
-        spec_tile(lds_base + (unsigned)(tbase - smem), tbase, B, ln, a.eps_direct, out, a.dbg, prof ? &t2 : nullptr, dma, wave, lane);
+        spec_tile(lds_base + (unsigned)(tbase - smem), tbase, B, ln, a.eps_direct, out, a.dbg, prof ? &t2 : nullptr, dma, wave, lane,
+                  TileOut{a.lb + (int64_t)qp * a.ld_lb + n, a.ld_lb, nq_here, n_ok});
         if (prof) {
           asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]));
           t3 = prof_now();
-        }
-        // both lane halves hold all four bounds: lanes 0..31 store queries 0 and 1, lanes 32..63 queries 2 and 3
-        // (two store instructions per tile instead of four)
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-          const int qq = 2 * hh + i;
-          const float v = i ? (hh ? out[3] : out[1]) : (hh ? out[2] : out[0]);
-          if (n_ok && qq < nq_here && !(kInstr && (a.dbg & 8) && v != 12345.0f)) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = v;
         }
       }
       if (prof) t4 = prof_now();
