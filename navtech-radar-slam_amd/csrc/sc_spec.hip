@@ -670,9 +670,8 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
         const float2v s2 = {dd[2 * e], dd[2 * e + 1]};
         v2[e] = s2 * u2[k4][e];
       }
-      const float m01 = fmaxf(fmaxf(v2[0][0], v2[0][1]), fmaxf(v2[1][0], v2[1][1]));
-      const float m23 = fmaxf(fmaxf(v2[2][0], v2[2][1]), fmaxf(v2[3][0], v2[3][1]));
-      m = fmaxf(m, fmaxf(m01, m23));
+#pragma unroll
+      for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, v2[e][0]), v2[e][1]);  // one v_max3_f32 per pair
     }
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
     const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // 15/16 max_k S_k u(n_k)
