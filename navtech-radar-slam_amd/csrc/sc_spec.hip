@@ -814,12 +814,14 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // Tile p is computed from buffer p % 3 while the DMA of tile p + 2 is in flight.  At the end of tile p the
-    // wave waits for ITS pieces of tile p + 1 only -- vmcnt(n_young), n_young = the DMA instructions of tile
-    // p + 2 it has just issued (VMEM operations retire in issue order; this tile's stores, younger still, stay
-    // in flight: waiting for their acknowledgement every tile cost more than the stage-1 MFMAs) -- and the
-    // raw barrier (no vmcnt(0), unlike __syncthreads with an LDS-DMA pending) makes the other waves' pieces
-    // visible and frees buffer (p + 3) % 3 = p % 3 for the next DMA.
+    // Tile p is computed from buffer p % 3 while the DMA of tile p + 2 is being issued (piecewise, inside the
+    // tail of tile p, interleaved with the tile's two bound stores).  At the end of tile p the wave waits for
+    // ITS pieces of tile p + 1 only: vmcnt(n_young), n_young = the number of DMA instructions of tile p + 2 it
+    // has issued.  VMEM operations retire in issue order and at least n_young + 3 operations are younger than
+    // the last piece of tile p + 1 (a store of tile p - 1, the pieces of tile p + 2, the stores of tile p), so
+    // that piece has landed; the youngest stores stay in flight (waiting for their acknowledgement every
+    // tile cost more than the stage-1 MFMAs).  The raw barrier (no vmcnt(0), unlike __syncthreads with an
+    // LDS-DMA pending) makes the other waves' pieces visible and frees buffer (p + 3) % 3 = p % 3.
     const bool prof = kInstr && a.prof && blockIdx.x == 0 && wave == 0;
     unsigned long long ps[5] = {0, 0, 0, 0, 0};
     for (int p = 0; p < nphase; p++) {
