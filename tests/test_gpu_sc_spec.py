@@ -194,3 +194,25 @@ print("WALK-OK")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert "WALK-OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_spectral_random_shapes(sc, rsx, synth):
+    """ragged sizes: 1..70 queries (partial query tiles), 1..1500 entries (partial 32-entry tiles and 128-entry
+    tile-blocks, workgroups that straddle tile-blocks), k in {1, 3, 10}, eligibility prefixes -- spectral filter ==
+    exact path, record for record"""
+    rng = np.random.default_rng(2024)
+    for trial in range(14):
+        n = int(rng.integers(1, 1500))
+        nq = int(rng.integers(1, 70))
+        k = int(rng.choice([1, 3, 10]))
+        binary = bool(trial & 1)
+        descs = synth.random_descriptors(900 + trial, n, binary=binary)
+        q = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+        q[::3, rng.integers(0, 1200, 30)] = 0
+        n_elig = int(rng.integers(0, n + 1)) if trial % 3 == 0 else -1
+        f = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+        o = sc.SCManager(filter_mode=rsx.FILTER_OFF)
+        f.add_descriptors_f32(descs)
+        o.add_descriptors_f32(descs)
+        got, want = f.query(q, k=k, n_eligible=n_elig), o.query(q, k=k, n_eligible=n_elig)
+        assert np.array_equal(got, want), (trial, n, nq, k, n_elig)
