@@ -730,7 +730,7 @@ __global__ __launch_bounds__(1024) void sc_knn_kernel(const float *__restrict__ 
 
 
 // ------------------------------------------------------------------------------------------
-// sc_rescore_kernel: exact re-scoring behind the MFMA filter (sc_filter.hip), one 16-wave workgroup
+// sc_rescore_kernel: exact re-scoring behind the MFMA filter (sc_filter.hip / sc_spec.hip), one RS_WAVES-wave workgroup
 // per query.  The query's candidates arrive as a short list of (bound, slot) records -- the entries
 // with the smallest filter bounds -- and are scored in rounds of ascending bound: after every round
 // the workgroup merges its per-wave top-k lists into tau (the k-th best exact distance so far) and
