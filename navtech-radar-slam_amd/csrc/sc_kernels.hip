@@ -12,13 +12,16 @@
 //   sc_knn_kernel     nanoflann 3-NN on ring keys                        SC.cpp:367-374, NF.hpp:383-408
 //
 // Numerics contract (tests/test_gpu_sc.py asserts it bit-for-bit against oracle/sc_ref.c):
-//   all reductions are sequential in ascending index in fp64, exactly like the oracle; this file is
+//   the reductions the reference takes through Eigen (mean, norm, dot) follow Eigen 3.3's redux order for
+//   the reference build (SSE2: term i -> accumulator i % 4, (a0 + a2) + (a1 + a3)), the one it takes in
+//   a scalar loop (SC.cpp:83) is sequential -- exactly like the oracle, which is itself checked bit for bit
+//   against the reference's own Scancontext.cpp (tests/test_oracle_pin.py); this file is
 //   compiled with -ffp-contract=off and uses fma() only where the product is exact (fp32 x fp32 in
 //   fp64), so results are identical to mul+add.  fp64 sqrt and divide are IEEE correctly rounded.
 //
 // Mapping (one 64-lane wavefront = one query x B database entries per iteration):
-//   stage 1  lane = column shift k (60 of 64 lanes): S_k = sum_c (v1[c] - v2[(c-k)%60])^2, sequential
-//            in c; the entry's sector key sits twice in LDS so lane k reads v2d[60+c-k] with an
+//   stage 1  lane = column shift k (60 of 64 lanes): S_k = sum_c (v1[c] - v2[(c-k)%60])^2, four interleaved
+//            chains in c (Eigen's order); the entry's sector key sits twice in LDS so lane k reads v2d[60+c-k] with an
 //            immediate offset -> conflict-free ds_read_b64, no address VALU in the loop.
 //   stage 2  lane = entry column j, held in 40 VGPRs as fp64 (20 cvt per entry, loaded straight from
 //            HBM/L2 -- the entry image never goes through LDS); the query lives once per block in LDS
@@ -57,25 +60,38 @@ __device__ __forceinline__ void wave_lds_fence() {
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wave_keys(const float *__restrict__ d, double *__restrict__ vkey,
                                           double *__restrict__ norm, float *__restrict__ rkey, int lane) {
+  // Eigen 3.3 redux order of the reference build (SSE2, 2-double packets; oracle/sc_ref.c "reductions"):
+  // term i goes to accumulator i % 4 = (packet accumulator i/2 % 2, lane i % 2); result (a0 + a2) + (a1 + a3)
   if (lane < NS) {
     const float4 *p = reinterpret_cast<const float4 *>(d + lane * NR);
-    double s = 0.0, sq = 0.0;
+    double s0, s1, s2, s3, q0, q1, q2, q3;
+    {
+      float4 v = p[0];
+      double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+      s0 = x0; s1 = x1; s2 = x2; s3 = x3;
+      q0 = x0 * x0; q1 = x1 * x1; q2 = x2 * x2; q3 = x3 * x3;  // exact in fp64
+    }
 #pragma unroll
-    for (int i = 0; i < 5; i++) {
+    for (int i = 1; i < 5; i++) {
       float4 v = p[i];
       double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-      s = s + x0; sq = fma(x0, x0, sq);  // x*x exact in fp64 -> fma == mul+add
-      s = s + x1; sq = fma(x1, x1, sq);
-      s = s + x2; sq = fma(x2, x2, sq);
-      s = s + x3; sq = fma(x3, x3, sq);
+      s0 = s0 + x0; q0 = fma(x0, x0, q0);  // x*x exact in fp64 -> fma == mul+add
+      s1 = s1 + x1; q1 = fma(x1, x1, q1);
+      s2 = s2 + x2; q2 = fma(x2, x2, q2);
+      s3 = s3 + x3; q3 = fma(x3, x3, q3);
     }
-    vkey[lane] = s / (double)NR;  // SC.cpp:223 mean()
-    norm[lane] = sqrt(sq);        // Eigen norm()
+    vkey[lane] = ((s0 + s2) + (s1 + s3)) / (double)NR;  // SC.cpp:224 mean()
+    norm[lane] = sqrt((q0 + q2) + (q1 + q3));           // Eigen norm()
   }
   if (lane < NR) {
-    double s = 0.0;
-    for (int c = 0; c < NS; c++) s = s + (double)d[c * NR + lane];
-    rkey[lane] = (float)(s / (double)NS);  // SC.cpp:207 mean(), SC.cpp:64 float narrowing
+    double a[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) a[c] = (double)d[c * NR + lane];
+    for (int c = 4; c < NS; c += 4) {
+#pragma unroll
+      for (int l = 0; l < 4; l++) a[l] = a[l] + (double)d[(c + l) * NR + lane];
+    }
+    rkey[lane] = (float)(((a[0] + a[2]) + (a[1] + a[3])) / (double)NS);  // SC.cpp:208 mean(), SC.cpp:64 float narrowing
   }
 }
 
@@ -304,9 +320,13 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
     wave_lds_fence();
 
     // ---- stage 1: fastAlignUsingVkey (SC.cpp:93-113), lane = shift ----
-    double acc[B];
+    // Eigen's redux order (SSE2 build of the reference): term c goes to accumulator c % 4, the norm is
+    // sqrt((a0 + a2) + (a1 + a3)); the first term of each accumulator initialises it (0.0 + x*x == x*x)
+    double acc[B][4];
 #pragma unroll
-    for (int b = 0; b < B; b++) acc[b] = 0.0;
+    for (int b = 0; b < B; b++)
+#pragma unroll
+      for (int l = 0; l < 4; l++) acc[b][l] = 0.0;
     {
       // lane k needs vk2[60 + c - k] for c = 0..59.  Even k: image A, odd k: image B -- either way the
       // pair (c, c+1), c even, is one aligned 16-byte read
@@ -326,10 +346,10 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
             const double2 y = v2[b][c0 + cc];
             double d0 = x.x - y.x;
             double dd0 = d0 * d0;
-            acc[b] = acc[b] + dd0;
+            acc[b][2 * (cc & 1)] = acc[b][2 * (cc & 1)] + dd0;          // columns 2(c0+cc): c % 4 in {0, 2}
             double d1 = x.y - y.y;
             double dd1 = d1 * d1;
-            acc[b] = acc[b] + dd1;
+            acc[b][2 * (cc & 1) + 1] = acc[b][2 * (cc & 1) + 1] + dd1;  // c % 4 in {1, 3}
           }
         }
       }
@@ -337,7 +357,7 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
     int kstar[B];
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      double nrm = sqrt(acc[b]);                 // SC.cpp:103 norm()
+      double nrm = sqrt((acc[b][0] + acc[b][2]) + (acc[b][1] + acc[b][3]));  // SC.cpp:105 norm()
       bool ok = (lane < NS) && (nrm < kBig);     // SC.cpp:96,104 (NaN never passes `<`)
       double m = ok ? nrm : INFINITY;
 #pragma unroll
@@ -418,13 +438,15 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
         int c = cl + k;
         c -= (c >= NS) ? NS : 0;
         const double2 *qp = reinterpret_cast<const double2 *>(smem + OFF_QIMG + c * Q_COL_STRIDE);
-        double dot = 0.0;
+        // Eigen's redux order (SSE2 build): term r goes to accumulator r % 4, dot = (a0 + a2) + (a1 + a3)
+        double da[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < 10; i++) {
           double2 q2 = qp[i];
-          dot = fma(q2.x, e[2 * i + 0], dot);  // fp32 x fp32 exact in fp64: fma == mul + add
-          dot = fma(q2.y, e[2 * i + 1], dot);
+          da[2 * (i & 1)] = fma(q2.x, e[2 * i + 0], da[2 * (i & 1)]);  // fp32 x fp32 exact in fp64: fma == mul + add
+          da[2 * (i & 1) + 1] = fma(q2.y, e[2 * i + 1], da[2 * (i & 1) + 1]);
         }
+        const double dot = (da[0] + da[2]) + (da[1] + da[3]);
         const double n1 = qn1[c];
         const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));  // SC.cpp:78
         const double s = dot / (n1 * n2);                                  // SC.cpp:81

@@ -214,3 +214,114 @@ def polar_image(seed, rows=400, cols=3360, n_targets=1200, shift_rows=0, t0=1_56
     az = (counts.astype(np.float64) * 2 * np.pi / 5600.0).astype(np.float32)
     centres = np.stack([(ta + shift_rows) % rows, tr], axis=1)
     return img, az, centres
+
+
+# ---------------------------------------------------------------------------------------------
+# Trajectory-shaped keyframe sequences (SURVEY.md 8d config 2 / "value distributions"): a vehicle
+# driving a street grid through one fixed world of wall segments and poles, one radar feature cloud per
+# keyframe.  Consecutive keyframes overlap almost completely, streets are driven several times in both
+# directions (real revisits), and the descriptors come out of the descriptor-BUILD path (the caller
+# pushes these clouds through rsx_sc_add_points), not out of a descriptor-level generator.
+# ---------------------------------------------------------------------------------------------
+class World:
+    """Fixed landmark map: wall segments along the streets of a `blocks` x `blocks` grid (block edge
+    `block_m`), poles and clutter.  Every landmark has a fixed height z in [-1, 4) (used by the
+    continuous-z family; radar features themselves are z = 0)."""
+
+    def __init__(self, seed, blocks=14, block_m=110.0, density=0.09):
+        from scipy.spatial import cKDTree
+        rng = np.random.default_rng(seed)
+        self.blocks, self.block_m = blocks, block_m
+        size = blocks * block_m
+        pts = []
+        # walls: both sides of every street, set back 7-16 m, pieces of 8-45 m with gaps
+        for axis in (0, 1):
+            for line in range(blocks + 1):
+                for side in (-1.0, 1.0):
+                    t = rng.uniform(0.0, 20.0)
+                    while t < size:
+                        ln = rng.uniform(8.0, 45.0)
+                        back = rng.uniform(7.0, 16.0)
+                        n = max(2, int(ln / rng.uniform(0.5, 1.4)))
+                        u = t + np.sort(rng.uniform(0.0, ln, n))
+                        v = line * block_m + side * back + rng.normal(0.0, 0.12, n)
+                        pts.append(np.stack([u, v] if axis == 0 else [v, u], axis=1))
+                        t += ln + rng.uniform(3.0, 30.0)
+        walls = np.concatenate(pts)
+        n_clutter = int(density * size * size) - len(walls)
+        clutter = rng.uniform(-60.0, size + 60.0, (max(n_clutter, 0), 2))
+        self.xy = np.concatenate([walls, clutter])
+        self.z = rng.uniform(-1.0, 4.0, len(self.xy))
+        self.tree = cKDTree(self.xy)
+
+    def drive(self, rng, n, step_m=2.0):
+        """n poses (x, y, heading) of a random drive along the street grid, `step_m` apart."""
+        b, L = self.blocks, self.block_m
+        node = np.array([int(rng.integers(0, b + 1)), int(rng.integers(0, b + 1))])
+        dirs = np.array([[1, 0], [0, 1], [-1, 0], [0, -1]])
+        d = int(rng.integers(0, 4))
+        poses = []
+        while len(poses) < n:
+            # at an intersection: mostly straight on, sometimes turn, (almost) never back
+            options = [(d, 0.55), ((d + 1) % 4, 0.21), ((d + 3) % 4, 0.21), ((d + 2) % 4, 0.03)]
+            options = [(o, w) for o, w in options if np.all(node + dirs[o] >= 0) and np.all(node + dirs[o] <= b)]
+            w = np.array([w for _, w in options])
+            d = options[int(rng.choice(len(options), p=w / w.sum()))][0]
+            lane = rng.normal(0.0, 0.4)                     # lateral offset of this pass
+            k = int(round(L / step_m))
+            s = (np.arange(k) + rng.uniform(0.0, 1.0)) * step_m
+            base = node * L
+            xy = base[None, :] + s[:, None] * dirs[d][None, :] + lane * np.array([-dirs[d][1], dirs[d][0]])[None, :]
+            hd = np.arctan2(dirs[d][1], dirs[d][0]) + rng.normal(0.0, 0.02, k)
+            poses.append(np.concatenate([xy, hd[:, None]], axis=1))
+            node = node + dirs[d]
+        return np.concatenate(poses)[:n]
+
+    def observe(self, rng, poses, binary_z=True, p_detect=0.7, sigma=0.08, clutter_frac=0.05, r_max=84.0):
+        """Feature clouds in the sensor frame of each pose -> (points (M,4) f32, offsets (n+1,) i64)."""
+        hits = self.tree.query_ball_point(poses[:, :2], r_max, return_sorted=False)
+        out, off = [], [0]
+        for p, h in zip(poses, hits):
+            h = np.asarray(h, dtype=np.int64)
+            h = h[rng.uniform(size=len(h)) < p_detect]
+            dxy = self.xy[h] - p[None, :2] + rng.normal(0.0, sigma, (len(h), 2))
+            c, s = np.cos(-p[2]), np.sin(-p[2])
+            x = c * dxy[:, 0] - s * dxy[:, 1]
+            y = s * dxy[:, 0] + c * dxy[:, 1]
+            z = np.zeros(len(h)) if binary_z else self.z[h]
+            nc = int(clutter_frac * len(h)) + 1
+            rr, tt = rng.uniform(2.0, 88.0, nc), rng.uniform(0.0, 2 * np.pi, nc)
+            x = np.concatenate([x, rr * np.cos(tt)])
+            y = np.concatenate([y, rr * np.sin(tt)])
+            z = np.concatenate([z, np.zeros(nc) if binary_z else rng.uniform(-1.0, 4.0, nc)])
+            out.append(np.stack([x, y, z, np.ones_like(x)], axis=1).astype(np.float32))
+            off.append(off[-1] + len(x))
+        return np.concatenate(out), np.asarray(off, dtype=np.int64)
+
+
+def trajectory_keyframes(seed_db, n_db, seed_q, n_q, binary_z=True, revisit_frac=0.5, min_gap=64):
+    """A drive of n_db keyframes + n_q query scans.  revisit_frac of the queries are new observations of a
+    place the drive passed (near keyframe src >= 0, arbitrary heading, up to 1 m off the driven line);
+    the rest are places in the same world the drive never saw (src = -1, no loop expected).
+    -> db_points, db_offsets, q_points, q_offsets, q_src (int64[n_q])."""
+    world = World(seed_db)
+    rng = np.random.default_rng(seed_db + 1)
+    poses = world.drive(rng, n_db)
+    db_pts, db_off = world.observe(rng, poses, binary_z=binary_z)
+    rq = np.random.default_rng(seed_q)
+    src = np.full(n_q, -1, dtype=np.int64)
+    n_rev = int(revisit_frac * n_q)
+    src[:n_rev] = rq.integers(0, max(1, n_db - min_gap), n_rev)
+    rq.shuffle(src)
+    qposes = np.empty((n_q, 3))
+    rev = src >= 0
+    qposes[rev, :2] = poses[src[rev], :2] + rq.normal(0.0, 0.5, (int(rev.sum()), 2))
+    size = world.blocks * world.block_m
+    # novel places: mid-block positions (the drive stays on the streets)
+    nb = int((~rev).sum())
+    cell = rq.integers(0, world.blocks, (nb, 2))
+    qposes[~rev, :2] = (cell + rq.uniform(0.3, 0.7, (nb, 2))) * world.block_m
+    qposes[:, 2] = rq.uniform(0.0, 2 * np.pi, n_q)
+    q_pts, q_off = world.observe(rq, qposes, binary_z=binary_z)
+    del size
+    return db_pts, db_off, q_pts, q_off, src

@@ -27,9 +27,12 @@ def build(force=False):
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
-    ref_so = os.path.join(_HERE, "_ref", "libref_kdtree.so")
-    if os.path.isdir("/root/reference/pgo/SC-A-LOAM/include/scancontext") and (force or not os.path.exists(ref_so)):
-        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+    ref_sos = [os.path.join(_HERE, "_ref", f) for f in ("libref_kdtree.so", "libref_sc_seq.so", "libref_sc_sse2.so", "libref_sc_avxfma.so")]
+    if os.path.isdir("/root/reference/pgo/SC-A-LOAM/include/scancontext"):
+        ref_srcs = [os.path.join(_HERE, "ref_kdtree.cpp"), os.path.join(_HERE, "ref_sc.cpp"), os.path.join(_HERE, "standin", "Eigen", "Dense")]
+        stale_ref = any((not os.path.exists(so)) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in ref_srcs) for so in ref_sos)
+        if force or stale_ref:
+            subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
 _lib = None
@@ -450,3 +453,170 @@ def icp_align(source, target, max_corr_dist=150.0, transformation_epsilon=1e-6, 
     L.icpref_align(s.ctypes.data, s.shape[0], t.ctypes.data, t.shape[0], C.byref(p), g.ctypes.data if g is not None else None, C.byref(r))
     return {"transform": np.array(r.transform, dtype=np.float32).reshape(4, 4), "fitness": r.fitness,
             "iterations": r.iterations, "converged": bool(r.converged), "state": r.state}
+
+
+# ------------------------------------------------------------------------------------------
+# The reference's own Scancontext.cpp, compiled unmodified against oracle/standin (oracle/ref_sc.cpp)
+# ------------------------------------------------------------------------------------------
+ORDER_SEQ, ORDER_EIGEN_SSE2, ORDER_EIGEN_AVX_FMA = 0, 1, 2
+REF_SC_VARIANTS = {ORDER_SEQ: "seq", ORDER_EIGEN_SSE2: "sse2", ORDER_EIGEN_AVX_FMA: "avxfma"}
+
+
+def set_sum_order(order):
+    """Summation order of the oracle's Eigen-style reductions (sc_ref.h SCREF_ORDER_*)."""
+    lib().scref_set_sum_order(int(order))
+
+
+def get_sum_order():
+    return lib().scref_get_sum_order()
+
+
+class RefSC:
+    """ctypes view of oracle/_ref/libref_sc_<variant>.so = /root/reference's Scancontext.cpp itself."""
+
+    def __init__(self, order=ORDER_EIGEN_SSE2):
+        build()
+        p = os.path.join(_HERE, "_ref", f"libref_sc_{REF_SC_VARIANTS[order]}.so")
+        if not os.path.exists(p):
+            raise FileNotFoundError(p)
+        if order == ORDER_EIGEN_AVX_FMA and " fma " not in open("/proc/cpuinfo").read():
+            raise FileNotFoundError("host CPU has no FMA: cannot run " + p)
+        R = C.CDLL(p)
+        R.ref_sc_build_info.restype = C.c_char_p
+        R.ref_sc_xy2theta.restype = C.c_float
+        R.ref_sc_xy2theta.argtypes = [C.c_float, C.c_float]
+        R.ref_sc_make_scancontext.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+        R.ref_sc_ringkey.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_sc_ringkey_f32.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_sc_sectorkey.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_sc_dist_direct.restype = C.c_double
+        R.ref_sc_dist_direct.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_sc_fast_align.restype = C.c_int
+        R.ref_sc_fast_align.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_sc_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        R.ref_sc_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        R.ref_sc_circshift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        R.ref_sc_create.restype = C.c_void_p
+        R.ref_sc_destroy.argtypes = [C.c_void_p]
+        R.ref_sc_set_dist_thres.argtypes = [C.c_void_p, C.c_double]
+        R.ref_sc_size.restype = C.c_int64
+        R.ref_sc_size.argtypes = [C.c_void_p]
+        R.ref_sc_add_points.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]
+        R.ref_sc_add_descriptor.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_sc_get.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        R.ref_sc_detect_loop_closure.restype = C.c_int
+        R.ref_sc_detect_loop_closure.argtypes = [C.c_void_p, C.c_void_p]
+        R.ref_sc_detect_between_session.restype = C.c_int
+        R.ref_sc_detect_between_session.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        R.ref_sc_last_log.restype = C.c_char_p
+        self.R = R
+        self.order = order
+
+    def build_info(self):
+        return self.R.ref_sc_build_info().decode()
+
+    def xy2theta(self, x, y):
+        return self.R.ref_sc_xy2theta(float(np.float32(x)), float(np.float32(y)))
+
+    def make_scancontext(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float32)
+        out = np.empty(DS, dtype=np.float64)
+        self.R.ref_sc_make_scancontext(pts.ctypes.data, pts.shape[0], pts.shape[1], out.ctypes.data)
+        return out
+
+    def ringkey(self, desc):
+        desc = np.ascontiguousarray(desc, dtype=np.float64)
+        out = np.empty(NR, dtype=np.float64)
+        self.R.ref_sc_ringkey(desc.ctypes.data, out.ctypes.data)
+        return out
+
+    def ringkey_f32(self, desc):
+        desc = np.ascontiguousarray(desc, dtype=np.float64)
+        out = np.empty(NR, dtype=np.float32)
+        self.R.ref_sc_ringkey_f32(desc.ctypes.data, out.ctypes.data)
+        return out
+
+    def sectorkey(self, desc):
+        desc = np.ascontiguousarray(desc, dtype=np.float64)
+        out = np.empty(NS, dtype=np.float64)
+        self.R.ref_sc_sectorkey(desc.ctypes.data, out.ctypes.data)
+        return out
+
+    def dist_direct(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        return self.R.ref_sc_dist_direct(a.ctypes.data, b.ctypes.data)
+
+    def fast_align(self, v1, v2):
+        v1 = np.ascontiguousarray(v1, dtype=np.float64)
+        v2 = np.ascontiguousarray(v2, dtype=np.float64)
+        return self.R.ref_sc_fast_align(v1.ctypes.data, v2.ctypes.data)
+
+    def circshift(self, desc, k):
+        desc = np.ascontiguousarray(desc, dtype=np.float64)
+        out = np.empty_like(desc)
+        self.R.ref_sc_circshift(desc.ctypes.data, NR, NS, int(k), out.ctypes.data)
+        return out
+
+    def distance(self, a, b):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        d, s = C.c_double(), C.c_int()
+        self.R.ref_sc_distance(a.ctypes.data, b.ctypes.data, C.byref(d), C.byref(s))
+        return d.value, s.value
+
+    def distances(self, q, descs):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        descs = np.ascontiguousarray(descs, dtype=np.float64).reshape(-1, DS)
+        dist = np.empty(descs.shape[0], dtype=np.float64)
+        shift = np.empty(descs.shape[0], dtype=np.int32)
+        self.R.ref_sc_distances(q.ctypes.data, descs.ctypes.data, descs.shape[0], dist.ctypes.data, shift.ctypes.data)
+        return dist, shift
+
+
+class RefManager:
+    """The reference's SCManager object itself (Scancontext.h:57-122) behind ref_sc.cpp."""
+
+    def __init__(self, order=ORDER_EIGEN_SSE2, dist_thres=None):
+        self._sc = RefSC(order)
+        self._R = self._sc.R
+        self._h = self._R.ref_sc_create()
+        if dist_thres is not None:
+            self._R.ref_sc_set_dist_thres(self._h, float(dist_thres))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._R.ref_sc_destroy(self._h)
+            self._h = None
+
+    def __len__(self):
+        return self._R.ref_sc_size(self._h)
+
+    def add_points(self, pts):
+        pts = np.ascontiguousarray(pts, dtype=np.float32)
+        self._R.ref_sc_add_points(self._h, pts.ctypes.data, pts.shape[0], pts.shape[1])
+
+    def add_descriptor(self, desc):
+        desc = np.ascontiguousarray(desc, dtype=np.float64).reshape(-1)
+        self._R.ref_sc_add_descriptor(self._h, desc.ctypes.data)
+
+    def get(self, i):
+        d, rk, sk = np.empty(DS), np.empty(NR, dtype=np.float32), np.empty(NS)
+        self._R.ref_sc_get(self._h, i, d.ctypes.data, rk.ctypes.data, sk.ctypes.data)
+        return d, rk, sk
+
+    def detect_loop_closure(self):
+        yaw = C.c_float()
+        lid = self._R.ref_sc_detect_loop_closure(self._h, C.byref(yaw))
+        return lid, yaw.value
+
+    def last_log(self):
+        """stdout of the last detect call (Scancontext.cpp:406,412)."""
+        return self._R.ref_sc_last_log().decode()
+
+    def detect_between_session(self, key, desc):
+        key = np.ascontiguousarray(key, dtype=np.float32)
+        desc = np.ascontiguousarray(desc, dtype=np.float64)
+        yaw = C.c_float()
+        lid = self._R.ref_sc_detect_between_session(self._h, key.ctypes.data, desc.ctypes.data, C.byref(yaw))
+        return lid, yaw.value

@@ -20,6 +20,63 @@
 #define DS SCREF_DESC_SIZE
 
 /* ------------------------------------------------------------------------------------------ */
+/* reductions                                                                                 */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Every sum the reference takes through Eigen (mean, norm, dot: SC.cpp:78,81,105,208,224) is a linear
+ * redux over a freshly allocated dynamic-size object.  Eigen 3.3 (Redux.h, LinearVectorizedTraversal /
+ * NoUnrolling) evaluates it with TWO packet accumulators of P doubles over the first floor(n/2P)*2P
+ * terms, adds the accumulators, adds one more packet if floor(n/P) is odd, adds the packet's lanes
+ * horizontally and finishes with the scalar tail; without vectorisation it adds in ascending order.
+ * P is a property of the BUILD of the reference: 2 for x86-64 as the reference's CMakeLists.txt
+ * builds it (-O3, SSE2 baseline), 4 (plus fused multiply-adds) if something injects -march=native.
+ * The order is selectable so that each can be checked against the reference's own Scancontext.cpp
+ * compiled with the matching stand-in (oracle/ref_sc.cpp, tests/test_oracle_pin.py). */
+static int g_sum_order = SCREF_ORDER_EIGEN_SSE2;
+
+void scref_set_sum_order(int order) {
+  if (order >= SCREF_ORDER_SEQ && order <= SCREF_ORDER_EIGEN_AVX_FMA) g_sum_order = order;
+}
+int scref_get_sum_order(void) { return g_sum_order; }
+
+static inline double madd(double a, double b, double acc, int fused) {
+  if (fused) return fma(a, b, acc);
+  double p = a * b;
+  return acc + p;
+}
+
+/* sum_i a[i]*b[i] (b != NULL) or sum_i a[i] (b == NULL) in the selected order */
+static double redux(int n, const double *a, const double *b) {
+  const int P = g_sum_order == SCREF_ORDER_SEQ ? 1 : (g_sum_order == SCREF_ORDER_EIGEN_SSE2 ? 2 : 4);
+  const int fused = g_sum_order == SCREF_ORDER_EIGEN_AVX_FMA;
+  if (n == 0) return 0.0;
+  const int aligned2 = (n / (2 * P)) * (2 * P), aligned = (n / P) * P;
+  double res;
+  if (P > 1 && aligned) {
+    double r0[4], r1[4];
+    for (int l = 0; l < P; l++) r0[l] = b ? a[l] * b[l] : a[l];
+    if (aligned > P) {
+      for (int l = 0; l < P; l++) r1[l] = b ? a[P + l] * b[P + l] : a[P + l];
+      for (int i = 2 * P; i < aligned2; i += 2 * P)
+        for (int l = 0; l < P; l++) {
+          r0[l] = b ? madd(a[i + l], b[i + l], r0[l], fused) : r0[l] + a[i + l];
+          r1[l] = b ? madd(a[i + P + l], b[i + P + l], r1[l], fused) : r1[l] + a[i + P + l];
+        }
+      for (int l = 0; l < P; l++) r0[l] = r0[l] + r1[l];
+      if (aligned > aligned2)
+        for (int l = 0; l < P; l++)
+          r0[l] = b ? madd(a[aligned2 + l], b[aligned2 + l], r0[l], fused) : r0[l] + a[aligned2 + l];
+    }
+    res = P == 2 ? r0[0] + r0[1] : (r0[0] + r0[1]) + (r0[2] + r0[3]); /* predux, Eigen 3.3 */
+    for (int i = aligned; i < n; i++) res = b ? madd(a[i], b[i], res, fused) : res + a[i];
+  } else {
+    res = b ? a[0] * b[0] : a[0];
+    for (int i = 1; i < n; i++) res = b ? madd(a[i], b[i], res, fused) : res + a[i];
+  }
+  return res;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* helpers                                                                                    */
 /* ------------------------------------------------------------------------------------------ */
 
@@ -102,19 +159,15 @@ void scref_make_scancontext(const float *pts, size_t n, size_t stride_floats, do
 /* SC.cpp:198-211: row-wise mean (sum of 60 / 60). */
 void scref_ringkey(const double *desc, double *key20) {
   for (int r = 0; r < NR; r++) {
-    double s = 0;
-    for (int c = 0; c < NS; c++) s += desc[c * NR + r];
-    key20[r] = s / (double)NS;
+    double row[NS]; /* SC.cpp:207: MatrixXd curr_row = _desc.row(row_idx) */
+    for (int c = 0; c < NS; c++) row[c] = desc[c * NR + r];
+    key20[r] = redux(NS, row, NULL) / (double)NS; /* SC.cpp:208 mean() = sum / size */
   }
 }
 
 /* SC.cpp:214-227: column-wise mean (sum of 20 / 20). */
 void scref_sectorkey(const double *desc, double *key60) {
-  for (int c = 0; c < NS; c++) {
-    double s = 0;
-    for (int r = 0; r < NR; r++) s += desc[c * NR + r];
-    key60[c] = s / (double)NR;
-  }
+  for (int c = 0; c < NS; c++) key60[c] = redux(NR, desc + c * NR, NULL) / (double)NR; /* SC.cpp:224 */
 }
 
 /* SC.cpp:62-66 (eig2stdvec) applied to the ring key: double -> float narrowing. */
@@ -125,11 +178,8 @@ void scref_ringkey_f32(const double *desc, float *key20) {
 }
 
 static void col_norms(const double *desc, double *norm60) {
-  for (int c = 0; c < NS; c++) {
-    double s = 0;
-    for (int r = 0; r < NR; r++) s += desc[c * NR + r] * desc[c * NR + r];
-    norm60[c] = sqrt(s); /* Eigen norm() = sqrt(squaredNorm()) */
-  }
+  for (int c = 0; c < NS; c++)
+    norm60[c] = sqrt(redux(NR, desc + c * NR, desc + c * NR)); /* Eigen norm() = sqrt(squaredNorm()) */
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -142,13 +192,9 @@ double scref_dist_direct(const double *sc1, const double *sc2) {
   double sum_sector_similarity = 0;
   for (int c = 0; c < NS; c++) {
     const double *a = sc1 + c * NR, *b = sc2 + c * NR;
-    double na = 0, nb = 0, dot = 0;
-    for (int r = 0; r < NR; r++) na += a[r] * a[r];
-    for (int r = 0; r < NR; r++) nb += b[r] * b[r];
-    na = sqrt(na);
-    nb = sqrt(nb);
+    double na = sqrt(redux(NR, a, a)), nb = sqrt(redux(NR, b, b));
     if ((na == 0) | (nb == 0)) continue;                   /* SC.cpp:78-79 */
-    for (int r = 0; r < NR; r++) dot += a[r] * b[r];
+    double dot = redux(NR, a, b);
     double sim = dot / (na * nb);                          /* SC.cpp:81 */
     sum_sector_similarity = sum_sector_similarity + sim;   /* SC.cpp:83 */
     num_eff_cols = num_eff_cols + 1;
@@ -162,12 +208,9 @@ int scref_fast_align(const double *vkey1, const double *vkey2) {
   int argmin = 0;
   double minv = 10000000;
   for (int k = 0; k < NS; k++) {
-    double s = 0;
-    for (int c = 0; c < NS; c++) {
-      double d = vkey1[c] - vkey2[(c - k + NS) % NS]; /* shifted[(j+k)%60] = vkey2[j] */
-      s += d * d;
-    }
-    double nrm = sqrt(s);
+    double diff[NS]; /* SC.cpp:103: MatrixXd vkey_diff = _vkey1 - vkey2_shifted */
+    for (int c = 0; c < NS; c++) diff[c] = vkey1[c] - vkey2[(c - k + NS) % NS]; /* shifted[(j+k)%60] = vkey2[j] */
+    double nrm = sqrt(redux(NS, diff, diff));
     if (nrm < minv) {
       argmin = k;
       minv = nrm;
@@ -201,12 +244,9 @@ void scref_distance_literal(const double *sc1, const double *sc2, double search_
   double minv = 10000000;
   for (int k = 0; k < NS; k++) {
     scref_circshift(vkey2, 1, NS, k, shifted_key);
-    double s = 0;
-    for (int c = 0; c < NS; c++) {
-      double d = vkey1[c] - shifted_key[c];
-      s += d * d;
-    }
-    double nrm = sqrt(s);
+    double diff[NS];
+    for (int c = 0; c < NS; c++) diff[c] = vkey1[c] - shifted_key[c];
+    double nrm = sqrt(redux(NS, diff, diff));
     if (nrm < minv) {
       argmin_vkey_shift = k;
       minv = nrm;
@@ -248,8 +288,7 @@ static void distance_pre(const double *sc1, const double *vkey1, const double *n
       int j = (c - k + NS) % NS; /* column of sc2 that lands on column c after the shift */
       if ((n1[c] == 0) | (n2[j] == 0)) continue;
       const double *a = sc1 + c * NR, *b = sc2 + j * NR;
-      double dot = 0;
-      for (int r = 0; r < NR; r++) dot += a[r] * b[r];
+      double dot = redux(NR, a, b);
       sum = sum + dot / (n1[c] * n2[j]);
       neff++;
     }

@@ -1,0 +1,147 @@
+"""Pins oracle/sc_ref.c to the reference's OWN Scancontext.cpp.
+
+oracle/_ref/libref_sc_<order>.so is /root/reference/pgo/SC-A-LOAM/include/scancontext/Scancontext.cpp
+compiled unmodified (oracle/ref_sc.cpp #includes it where it lies) against oracle/standin/, whose
+Eigen stand-in reproduces Eigen 3.3's reduction order for a given SIMD packet size.  Each variant is
+compared with the oracle in the same summation order -- bit for bit, every function of the path:
+xy2theta, makeScancontext, both keys, circshift, distDirectSC, fastAlignUsingVkey,
+distanceBtnScanContext on all pairs, and the SCManager detector keyframe by keyframe (which runs the
+reference's real nanoflann tree).  The last test measures what the summation order can change at all.
+The .so files are built here (where /root/reference exists) and travel to the GPU box prebuilt."""
+import numpy as np
+import pytest
+
+from navtech_radar_slam_amd import synth
+
+ORDERS = [0, 1, 2]
+
+
+def _ref(oracle, order):
+    try:
+        return oracle.RefSC(order)
+    except FileNotFoundError as e:
+        pytest.skip(f"reference build not available: {e}")
+
+
+@pytest.fixture(autouse=True)
+def _restore_order(oracle):
+    before = oracle.get_sum_order()
+    yield
+    oracle.set_sum_order(before)
+
+
+def _descs(oracle, seed, n, binary_z):
+    clouds, _ = synth.keyframe_clouds(seed, n, binary_z=binary_z, loop_frac=0.3, min_gap=5, n_points=700)
+    return clouds, np.stack([oracle.make_scancontext(c) for c in clouds])
+
+
+def test_default_order_is_the_reference_build(oracle):
+    # the reference's CMakeLists.txt (pgo/SC-A-LOAM/CMakeLists.txt:5-7) compiles with -O3 and no -march:
+    # x86-64 baseline = SSE2 = 2-double packets
+    assert oracle.get_sum_order() == oracle.ORDER_EIGEN_SSE2
+    assert _ref(oracle, 1).build_info() == "packet=2 fma=0 predux34=0"
+
+
+@pytest.mark.parametrize("order", ORDERS)
+def test_build_and_keys_bitwise(oracle, order):
+    ref = _ref(oracle, order)
+    oracle.set_sum_order(order)
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([rng.normal(0, 40, 4000), [0, 0, 1, -1, 80, -80, 0.0, 1e-30]]).astype(np.float32)
+    ys = np.concatenate([rng.normal(0, 40, 4000), [0, 5, 0, 0, 0, 1e-7, -3, 1e-30]]).astype(np.float32)
+    a = np.array([ref.xy2theta(x, y) for x, y in zip(xs, ys)], dtype=np.float32)
+    b = np.array([oracle.xy2theta(x, y) for x, y in zip(xs, ys)], dtype=np.float32)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))     # includes the NaN of (0, 0)
+    for binary_z in (True, False):
+        clouds, descs = _descs(oracle, 5 + binary_z, 24, binary_z)
+        clouds.append(np.zeros((0, 4), dtype=np.float32))                       # empty cloud
+        clouds.append(np.array([[0, 0, 1, 0], [79.99, 0, 3, 0], [0, 80.0, -1, 0], [60, 60, 9, 0]], dtype=np.float32))
+        for c in clouds:
+            d_ref, d_or = ref.make_scancontext(c), oracle.make_scancontext(c)
+            assert np.array_equal(d_ref, d_or)
+            assert np.array_equal(ref.ringkey(d_ref), oracle.ringkey(d_or))
+            assert np.array_equal(ref.ringkey_f32(d_ref), oracle.ringkey_f32(d_or))
+            assert np.array_equal(ref.sectorkey(d_ref), oracle.sectorkey(d_or))
+        for k in (0, 1, 17, 59):
+            assert np.array_equal(ref.circshift(descs[0], k), oracle.circshift(descs[0], k))
+
+
+@pytest.mark.parametrize("order", ORDERS)
+def test_pair_function_bitwise_all_pairs(oracle, order):
+    ref = _ref(oracle, order)
+    oracle.set_sum_order(order)
+    rng = np.random.default_rng(3)
+    sets = []
+    for binary_z in (True, False):
+        sets.append(_descs(oracle, 21 + binary_z, 48, binary_z)[1])
+    cont = synth.random_descriptors(9, 40, binary=False).astype(np.float64)      # arbitrary fp32 values
+    cont[3].reshape(60, 20)[10:25] = 0                                            # blank sectors
+    cont[4][:] = 0                                                                # no effective column at all
+    sets.append(cont)
+    sets.append(rng.normal(0, 1, (24, 1200)))                                     # full doubles, signed
+    for descs in sets:
+        n = len(descs)
+        m = oracle.Manager()
+        m.add_descriptors(descs)
+        for i in range(n):
+            d_ref, s_ref = ref.distances(descs[i], descs)
+            d_or, s_or = m.pair_distances(descs[i], 0, n)
+            # the reference returns NaN -> never "< min" -> (1e7, 0) for pairs without an effective column
+            assert np.array_equal(d_ref, d_or), (order, i)
+            assert np.array_equal(s_ref, s_or), (order, i)
+        for i in range(0, n, 7):
+            for j in range(0, n, 5):
+                assert ref.dist_direct(descs[i], descs[j]) == oracle.dist_direct(descs[i], descs[j]) or \
+                    (np.isnan(ref.dist_direct(descs[i], descs[j])) and np.isnan(oracle.dist_direct(descs[i], descs[j])))
+                assert ref.fast_align(oracle.sectorkey(descs[i]), oracle.sectorkey(descs[j])) == \
+                    oracle.fast_align(oracle.sectorkey(descs[i]), oracle.sectorkey(descs[j]))
+                assert ref.distance(descs[i], descs[j]) == oracle.distance(descs[i], descs[j], literal=True)
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("binary_z", [True, False])
+def test_detector_matches_reference_manager(oracle, order, binary_z):
+    """The whole SCManager (Scancontext.cpp:249-260, 331-422) keyframe by keyframe: frozen tree prefix,
+    30-exclusion, nanoflann 3-NN, kNN-order strict-< scoring, threshold, yaw."""
+    _ref(oracle, order)
+    oracle.set_sum_order(order)
+    clouds, _ = synth.keyframe_clouds(77 + binary_z, 150, binary_z=binary_z, loop_frac=0.25, min_gap=35, n_points=500)
+    rm = oracle.RefManager(order, dist_thres=0.45)
+    om = oracle.Manager(dist_thres=0.45)
+    loops = 0
+    for i, c in enumerate(clouds):
+        rm.add_points(c)
+        om.add_points(c)
+        d, rk, sk = rm.get(i)
+        assert np.array_equal(d, om.descriptor(i)) and np.array_equal(rk, om.ringkey_f32(i)) and np.array_equal(sk, om.sectorkey(i))
+        got = om.detect_loop_closure()
+        want = rm.detect_loop_closure()
+        # exact ring-key ties are returned in tree-visit order by nanoflann and in index order by the oracle
+        # (DESIGN.md): none occur on this data, so the candidate sets and hence the results are identical
+        assert (got[0], got[1]) == want, (i, got, want)
+        loops += want[0] >= 0
+    assert loops > 10
+
+
+def test_what_the_summation_order_can_change(oracle):
+    """Reference build vs reference build: the same Scancontext.cpp with 1-, 2- and 4-double packets.
+    Distances move by a few ulps; the alignment argmin (hence the window, hence the distance) can move only
+    where two shifts tie to within rounding.  Reported, and bounded so that a regression shows."""
+    refs = {o: _ref(oracle, o) for o in ORDERS}
+    _, descs = _descs(oracle, 31, 64, False)
+    _, bdescs = _descs(oracle, 32, 64, True)
+    for name, D in (("continuous-z", descs), ("binary", bdescs)):
+        out = {o: [refs[o].distances(D[i], D) for i in range(len(D))] for o in ORDERS}
+        d0 = np.stack([x[0] for x in out[1]])
+        s0 = np.stack([x[1] for x in out[1]])
+        for o in (0, 2):
+            d = np.stack([x[0] for x in out[o]])
+            s = np.stack([x[1] for x in out[o]])
+            moved = int((s != s0).sum())
+            big = int((np.abs(d - d0) > 1e-12).sum())
+            print(f"{name}: packet order {o} vs SSE2: shift differs on {moved} of {s.size} pairs, "
+                  f"|ddist| > 1e-12 on {big}, max |ddist| {np.abs(d - d0).max():.3e}")
+            assert big <= moved                      # a distance only moves beyond rounding when the argmin moved
+            assert moved < 0.05 * s.size
+            if name == "continuous-z":
+                assert moved == 0 and big == 0       # no exact ties between shifts: the order is invisible
