@@ -2,25 +2,46 @@
 """bench.py -- headline benchmark of the ScanContext + ORORA hot path on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W` prints ONE JSON line on rank 0.
+With --gpus N > 1 and no torch.distributed environment the script starts its own N ranks (one per
+GPU, `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...`);
+launched under torch.distributed.run it uses the ranks it is given.  It fails if fewer than N GPUs
+are visible and reports the number of ranks that actually took part (`n_gpus`, `rccl_ranks`).
 
 Metric (BASELINE.json): ScanContext loop-queries/sec against an N-scan keyframe DB.  A "step" is one
-batch of Q = 8192 exhaustive queries (distanceBtnScanContext against EVERY eligible DB entry, top-k) against
-the 10 000-keyframe synthetic DB -- the configuration the north-star target is quoted on
-(>= 10k queries/s vs a 10k-scan DB on one MI355X).  Inputs (DB and queries) are resident in HBM
-before the timed region starts.  With --gpus G the DB is sharded block-cyclically over G ranks
-(same total DB and batch => strong scaling); a query batch is two stages with one RCCL all-gather of
-the per-rank top-k lists each (torch.distributed backend "nccl"), merged on the GPU (sharded.py).
+batch of Q = 8192 exhaustive queries (distanceBtnScanContext against EVERY eligible DB entry, top-10)
+against a 10 000-keyframe DB resident in HBM -- the configuration the north-star target is quoted on
+(>= 10k queries/s vs a 10k-scan DB on one MI355X).
 
-Extra objects on the same line:
-  roofline      algorithmic flops of the dominant kernel (sc_filter_kernel, fp16 MFMA) / its HIP-event
-                time; the SURVEY 8d algorithmic-byte figure rides along as roofline.hbm_algorithmic
-  cpu_baseline  the CPU oracle (port of Scancontext.cpp) timed on this box's host cores, rank 0
-  latency_q1_n1k_us   BASELINE configs[1]: one query vs a 1k-keyframe DB, end-to-end host call
-  orora, cen2019      the other two parts of the path: scan pairs/s (BASELINE configs[2]) and scans/s
+Data ("value distributions"): the DB is a synthetic DRIVE -- 10 000 keyframes 2 m
+apart on the street grid of one fixed world of walls and clutter, every feature cloud pushed through the
+descriptor-BUILD path (rsx_sc_add_points) -- so consecutive keyframes overlap, streets are revisited in
+both directions and the descriptors are as dense and as similar to each other as a real sequence's.
+Queries: 8192 new scans, half of them revisits of a driven place (arbitrary heading), half places the
+drive never saw.  Nothing is planted at descriptor level; correctness of what was timed is checked
+against the CPU oracle on >= 256 queries of the timed batch (`oracle_checked_queries`).
+
+Besides `value` (that workload through the default path: fp16 MFMA lower-bound filter -> exact fp64
+re-scoring of the survivors) the line carries
+  data_dependence   the same batch shape on (a) the round-1 descriptor-level random DB with planted rotated
+                    copies and (b) the exact-all path (filter off: every pair scored in fp64) = the
+                    data-independent floor, each with queries/s and exact evaluations per query
+  scale_100k        8192 queries vs a 100 000-keyframe DB (the size where DB shards pay), same sharding
+  roofline          the dominant kernel (spectral MFMA filter): algorithmic flops / hipEvent time, vs the dense fp16 peak
+  cpu_baseline      the CPU oracle (== the reference's Scancontext.cpp, tests/test_oracle_pin.py) on this box's cores
+  latency_q1_n1k_us BASELINE configs[1]; orora / cen2019 / icp: the other parts of the path
+With --gpus G the DB is sharded block-cyclically over G ranks (same DB, same batch => strong scaling); a
+query batch is two stages with one RCCL all-gather of per-rank top-k lists each (sharded.py).
+
+RSX_BENCH_LOCAL_BACKEND=module:function (tests only) replaces the GPU shard by a CPU stand-in and RCCL by
+gloo so that the launcher / timing / reduction logic can be driven at world 2 without GPUs
+(tests/test_bench_launcher.py); such a run is marked "dry_run": true and measures nothing.
 """
 import argparse
+import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,9 +62,38 @@ ALG_FLOP_PER_PAIR = 2 * 60 * 1200
 SPEC_FLOP_PER_PAIR = 2 * (9280 + 960 + 3600)
 
 
-def make_db_and_queries(n_db, n_q, seed_db=1234, seed_q=4321):
-    """Synthetic MulRan-shape data: descriptor-level generator (binary radar descriptors with blank
-    arcs), queries = rotated, slightly corrupted copies of DB entries (planted loops)."""
+# ----------------------------------------------------------------------------------------------
+# launcher
+# ----------------------------------------------------------------------------------------------
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, dry_run):
+    """Re-execute this script as n ranks under torch.distributed.run (one process per GPU)."""
+    if not dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) visible; refusing to measure {have} GPU(s) {n} times")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ----------------------------------------------------------------------------------------------
+# workloads
+# ----------------------------------------------------------------------------------------------
+def random_db_and_queries(n_db, n_q, seed_db=1234, seed_q=4321):
+    """Round-1 workload: descriptor-level generator (iid binary descriptors with blank arcs), queries =
+    rotated, slightly corrupted copies of DB entries (planted loops with a known answer)."""
     from navtech_radar_slam_amd import synth
     descs = synth.random_descriptors(seed_db, n_db, binary=True)
     rng = np.random.default_rng(seed_q)
@@ -55,30 +105,178 @@ def make_db_and_queries(n_db, n_q, seed_db=1234, seed_q=4321):
     return descs, q, src, rot
 
 
-def cpu_baseline(descs, queries, k):
-    """Time the oracle (exhaustive loop of the reference's pair function) on the host cores."""
+class Workload:
+    """One DB (sharded over the ranks) + one resident query batch + the timed step."""
+
+    def __init__(self, ctx, name, k, capacity, filter_mode=0):
+        from navtech_radar_slam_amd import sharded
+        self.ctx, self.name, self.k = ctx, name, k
+        if ctx.stub:
+            self.ssc = sharded.ShardedScanContext(local_backend=ctx.stub(ctx.rank, ctx.world))
+        else:
+            self.ssc = sharded.ShardedScanContext(device=ctx.local_rank, capacity_hint=capacity // ctx.world + 8,
+                                                  filter_mode=filter_mode)
+        self.mgr = self.ssc.backend
+        self.hits = None
+
+    def add_clouds(self, pts, off):
+        for i in range(len(off) - 1):
+            self.mgr.makeAndSaveScancontextAndKeys(pts[off[i]:off[i + 1]])
+
+    def add_descriptors(self, descs):
+        if self.ctx.stub:
+            self.ssc.add_descriptors_f32(descs)
+            return
+        import torch
+        d = torch.from_numpy(descs).cuda()
+        self.ssc.add_descriptors_device(d.data_ptr(), len(descs), stream=self.ctx.stream)
+        torch.cuda.synchronize()
+
+    def set_queries(self, q_f32, n_elig):
+        self.nq, self.n_elig = len(q_f32), n_elig
+        self.q_host = q_f32
+        if not self.ctx.stub:
+            import torch
+            self.d_q = torch.from_numpy(q_f32).cuda()
+
+    def step(self):
+        if self.ctx.stub:
+            self.hits = self.ssc.query(self.q_host, k=self.k, n_eligible=self.n_elig)
+        else:
+            self.hits = self.ssc.query_device(self.d_q.data_ptr(), self.nq, self.k, n_eligible=self.n_elig, stream=self.ctx.stream)
+
+    def results(self):
+        from navtech_radar_slam_amd import scancontext
+        if self.ctx.stub:
+            return np.ascontiguousarray(self.hits)
+        return self.hits.cpu().numpy().view(scancontext.HIT_DTYPE).reshape(self.nq, self.k)
+
+    def timed(self, steps, warmup, profile=False):
+        """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides.
+        -> (max-over-ranks seconds, per-rank seconds, (launches, kernel ms), (exact evals, queries rescored))"""
+        ctx = self.ctx
+        for _ in range(warmup):
+            self.step()
+        ctx.barrier()
+        if profile and not ctx.stub:
+            self.mgr.profile_enable(True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        ctx.barrier()
+        dt = time.perf_counter() - t0
+        prof, resc = (0, 0.0), (0, 0)
+        if profile and not ctx.stub:
+            prof = self.mgr.profile_read()
+            resc = self.mgr.profile_read_rescoring()
+            self.mgr.profile_enable(False)
+        per_rank = ctx.all_gather_float(dt)
+        return max(per_rank), per_rank, prof, resc
+
+    def close(self):
+        if hasattr(self.mgr, "close"):
+            self.mgr.close()
+
+
+class Ctx:
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        spec = os.environ.get("RSX_BENCH_LOCAL_BACKEND")
+        self.stub = None
+        if spec:
+            mod, fn = spec.split(":")
+            self.stub = getattr(importlib.import_module(mod), fn)
+        if args.gpus != self.world:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}")
+        self.stream = 0
+        if not self.stub:
+            if not torch.cuda.is_available():
+                raise SystemExit("bench.py needs a GPU (librsx has no CPU fallback)")
+            if torch.cuda.device_count() <= self.local_rank:
+                raise SystemExit(f"bench.py: rank {self.rank} has no GPU {self.local_rank} ({torch.cuda.device_count()} visible)")
+            torch.cuda.set_device(self.local_rank)
+        if self.world > 1 or args.force_dist:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(_free_port()))
+            if self.stub:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                        device_id=torch.device("cuda", self.local_rank))
+        if not self.stub:
+            # an explicit (non-null) torch stream: the C-ABI launches on it, torch.distributed collectives and
+            # torch.cuda.Event see the same stream
+            self.tstream = torch.cuda.Stream()
+            torch.cuda.set_stream(self.tstream)
+            self.stream = self.tstream.cuda_stream
+
+    @property
+    def distributed(self):
+        return self.dist.is_initialized()
+
+    def barrier(self):
+        if not self.stub:
+            self.torch.cuda.synchronize()
+        if self.distributed:
+            self.dist.barrier()
+        if not self.stub:
+            self.torch.cuda.synchronize()
+
+    def all_gather_float(self, x):
+        if not self.distributed:
+            return [float(x)]
+        t = self.torch.tensor([x], dtype=self.torch.float64, device="cpu" if self.stub else "cuda")
+        out = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def shutdown(self):
+        if self.distributed:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ----------------------------------------------------------------------------------------------
+# CPU baseline + oracle check (rank 0, after timing)
+# ----------------------------------------------------------------------------------------------
+def cpu_baseline_and_check(db_pts, db_off, q_descs, n_elig, k, gpu_hits, min_checked=256):
+    """Times the oracle (exhaustive loop of the reference's pair function) on the host cores AND uses its
+    results as the checker: the first `nq` queries of the timed batch, GPU records vs oracle records."""
     from oracle import pyoracle as po
     cores = os.cpu_count() or 1
     m = po.Manager()
-    m.add_descriptors(descs.astype(np.float64))
+    for i in range(len(db_off) - 1):          # the oracle builds its own descriptors from the same clouds
+        m.add_points(db_pts[db_off[i]:db_off[i + 1]])
     n = len(m)
-    # calibrate: one query single-threaded
     t0 = time.perf_counter()
-    m.exhaustive(queries[0].astype(np.float64), n_eligible=n - 30, k=k, nthreads=1)
+    m.exhaustive(q_descs[0].astype(np.float64), n_eligible=n_elig, k=k, nthreads=1)
     t1 = time.perf_counter() - t0
     one_thread_qps = 1.0 / t1
-    # ~10-20 s of CPU work spread over all cores (one query per thread at a time)
-    nq = int(max(cores, min(4 * cores, (15.0 * cores) / max(t1, 1e-6))))
-    qs = np.stack([queries[i % len(queries)] for i in range(nq)]).astype(np.float64)
+    # ~10-20 s of CPU work spread over all cores (one query per thread at a time), at least min_checked queries
+    nq = int(max(min_checked, min(4 * cores, (15.0 * cores) / max(t1, 1e-6))))
+    nq = min(nq, len(q_descs))
+    qs = q_descs[:nq].astype(np.float64)
     t0 = time.perf_counter()
-    m.exhaustive_batch(qs, n_eligible=n - 30, k=k, nthreads=cores)
+    want = m.exhaustive_batch(qs, n_eligible=n_elig, k=k, nthreads=cores)
     dt = time.perf_counter() - t0
-    return {
+    got = gpu_hits[:nq]
+    same = [bool(np.array_equal(got[i], want[i])) for i in range(nq)]
+    top1_same = int(np.sum((got["index"][:, 0] == want["index"][:, 0]) & (got["shift"][:, 0] == want["shift"][:, 0])))
+    base = {
         "value": nq / dt, "unit": "queries/s", "cores": cores, "kind": "port",
-        "sample": f"{nq} exhaustive queries vs the same {n}-keyframe DB, OpenMP over queries on {cores} threads "
-                  f"(oracle/sc_ref.c, restatement of Scancontext.cpp:116-148); 1 thread: {one_thread_qps:.2f} queries/s",
+        "sample": f"{nq} exhaustive top-{k} queries (the first {nq} of the timed batch) vs the same {n}-keyframe DB, OpenMP "
+                  f"over queries on {cores} threads (oracle/sc_ref.c = the reference's Scancontext.cpp:116-148 bit for "
+                  f"bit, tests/test_oracle_pin.py); 1 thread: {one_thread_qps:.2f} queries/s",
         "one_thread_value": one_thread_qps,
     }
+    check = {"oracle_checked_queries": nq, "oracle_identical_queries": int(np.sum(same)), "oracle_top1_identical": top1_same,
+             "first_mismatch": None if all(same) else int(same.index(False))}
+    return base, check
 
 
 def orora_leg(device, skip_cpu):
@@ -125,19 +323,20 @@ def orora_leg(device, skip_cpu):
     return leg
 
 
-def profiled_traffic(kernel):
-    """HBM-side bytes per filter-kernel launch from the COMMITTED rocprofv3 PMC passes (tools/prof.sh
-    runs this same workload; counters cannot be collected from inside the bench).  FETCH_SIZE is
-    doubled (gfx950 reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md), both are KB."""
+def committed_profile(kernel):
+    """What the COMMITTED rocprofv3 passes (tools/prof.sh runs this same workload; counters cannot be collected
+    from inside the bench) say about the dominant kernel: HBM-side bytes per launch (FETCH_SIZE doubled: gfx950
+    reports half the bytes of wide coalesced reads, MI355X_MICROARCH.md; both counters are KB) and its average
+    duration in the kernel trace.  -> dict or None"""
     import glob
     import re
     pat, tag = ("r*_sc_filter_v*_rocprofv3.txt", "FilterArgs") if kernel == "sc_filter_kernel" else ("r*_sc_spec_v*_rocprofv3.txt", "SpecArgs")
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
     if not files:
-        return None, None
-    fetch = write = None
+        return None
+    fetch = write = avg_us = None
     for line in open(files[-1]):
-        if tag not in line:
+        if kernel not in line and tag not in line:
             continue
         m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+dispatches=\s*\d+\s+avg_per_dispatch=\s*([0-9.]+)", line)
         if m:
@@ -145,9 +344,12 @@ def profiled_traffic(kernel):
                 fetch = float(m.group(2))
             else:
                 write = float(m.group(2))
-    if fetch is None or write is None:
-        return None, None
-    return (2.0 * fetch + write) * 1024.0, os.path.relpath(files[-1], ROOT)
+        m = re.search(r"avg_us=\s*([0-9.]+)", line)
+        if m and avg_us is None:
+            avg_us = float(m.group(1))
+    out = {"source": os.path.relpath(files[-1], ROOT), "kernel_trace_avg_launch_ms": None if avg_us is None else avg_us / 1e3}
+    out["hbm_bytes_per_launch"] = None if fetch is None or write is None else (2.0 * fetch + write) * 1024.0
+    return out
 
 
 def cen2019_leg(device):
@@ -204,6 +406,47 @@ def icp_leg(device):
                     "(uploads both clouds, one 16-byte read-back per iteration)" % (len(src) * len(tgt))}
 
 
+def roofline_of(wl, launches, kern_ms, n_elig):
+    ctx = wl.ctx
+    local_pairs = wl.nq * len(range(ctx.rank, n_elig, ctx.world))  # pairs one launch of this rank scores
+    alg_bytes = local_pairs * ALG_BYTES_PER_PAIR + wl.nq * 4800 + wl.nq * wl.k * 16
+    avg_kern_s = (kern_ms / max(launches, 1)) * 1e-3
+    kernel = wl.mgr.profiled_kernel_name()
+    if kernel in ("sc_filter_kernel", "sc_spec_filter_kernel"):
+        spectral = kernel == "sc_spec_filter_kernel"
+        alg_flop = local_pairs * (SPEC_FLOP_PER_PAIR if spectral else ALG_FLOP_PER_PAIR)
+        achieved = alg_flop / avg_kern_s / 1e12 if avg_kern_s > 0 else 0.0
+        prof = committed_profile(kernel) if ctx.world == 1 and (wl.nq, n_elig) == (8192, 9970) else None
+        return kernel, {
+            "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / MFMA_F16_PEAK_TFLOPS, "kernel": kernel, "launches": launches,
+            "avg_launch_ms": kern_ms / max(launches, 1), "avg_launch_ms_source": "hipEvents recorded by librsx around every launch on its stream, this run",
+            "traffic": prof["hbm_bytes_per_launch"] if prof else None, "traffic_unit": "bytes per launch",
+            "traffic_source": (prof["source"] + " (committed rocprofv3 PMC passes of this workload; not measured in this run)") if prof else None,
+            "committed_profile_avg_launch_ms": prof["kernel_trace_avg_launch_ms"] if prof else None,
+            "algorithmic_flop_per_launch": alg_flop,
+            "algorithmic_flop_per_pair": SPEC_FLOP_PER_PAIR if spectral else ALG_FLOP_PER_PAIR,
+            "direct_form_equivalent_tflops": local_pairs * ALG_FLOP_PER_PAIR / avg_kern_s / 1e12 if avg_kern_s > 0 else 0.0,
+            "algorithmic_bytes_per_launch": alg_bytes,
+            "note": ("dominant kernel = spectral fp16 MFMA lower-bound filter: the 60-shift circular cross-correlation of "
+                     "a pair via a Z15 DFT + direct Z4 correlation (27.7 kflop per pair incl. the exact n_eff mask "
+                     "correlation on the fp8 matrix cores) instead of 144 kflop per pair in the direct K = 1200 form; "
+                     "`achieved` counts the spectral algorithm's own flops against the dense fp16 peak. "
+                     if spectral else
+                     "dominant kernel = fp16 MFMA lower-bound filter (144 kflop per (query, entry) pair: 60-shift circular "
+                     "cross-correlation, K = 1200). ") +
+                    "DB tiles are register-resident across the query batch, so the SURVEY 8d byte figure "
+                    "(algorithmic_bytes_per_launch = 4800 B per pair) is not HBM traffic and no HBM fraction is quoted; "
+                    "exact fp64 re-scoring of the survivors is inside value/ms_per_step"}
+    hbm_alg = alg_bytes / avg_kern_s / 1e9 if avg_kern_s > 0 else 0.0
+    return kernel, {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": hbm_alg / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "launches": launches,
+                    "avg_launch_ms": kern_ms / max(launches, 1), "algorithmic_bytes_per_launch": alg_bytes,
+                    "note": "algorithmic bytes = 4800 B per (query, entry) pair; batched queries re-use DB tiles from "
+                            "L2/Infinity Cache, so this is an algorithmic-throughput figure; the kernel itself is "
+                            "fp64-VALU-bound (see DESIGN.md)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,145 +456,180 @@ def main():
     ap.add_argument("--queries", type=int, default=8192, help="queries per step")
     ap.add_argument("--topk", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--only-main", action="store_true", help="time only the headline workload (profiling runs)")
+    ap.add_argument("--data", choices=["trajectory", "random"], default="trajectory",
+                    help="headline DB: descriptors built from a synthetic drive (default) or the round-1 random descriptors")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world 1")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
-    from navtech_radar_slam_amd import scancontext, sharded
+    dry = bool(os.environ.get("RSX_BENCH_LOCAL_BACKEND"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus, dry))
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (librsx has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    # the contract is ONE JSON line on stdout: libraries that chat on stdout (RCCL prints a version banner there)
+    # are sent to stderr for the whole run; the line itself goes to the original descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
+    ctx = Ctx(args)
+    from navtech_radar_slam_amd import scancontext, synth
+    rank, world = ctx.rank, ctx.world
     n_db, nq, k = args.db, args.queries, args.topk
-    descs, queries, src, rot = make_db_and_queries(n_db, nq)
     n_elig = n_db - 30  # NUM_EXCLUDE_RECENT (SC.h:92): the newest 30 keyframes are never candidates
+    out = {}
 
-    # an explicit (non-null) torch stream: the C-ABI launches on it, torch.distributed collectives
-    # and torch.cuda.Event see the same stream
-    tstream = torch.cuda.Stream()
-    torch.cuda.set_stream(tstream)
-    stream = tstream.cuda_stream
-    # DB shard of this rank (keyframe i lives on rank i % world); one all-gather + merge per step
-    ssc = sharded.ShardedScanContext(device=local_rank, capacity_hint=n_db // world + 8)
-    mgr = ssc.backend
-    d_db = torch.from_numpy(descs).cuda()
-    ssc.add_descriptors_device(d_db.data_ptr(), n_db, stream=stream)  # DB resident in HBM (keys built on GPU)
-    del d_db
-    d_q = torch.from_numpy(queries).cuda()
-    result = {}
+    # ---- headline workload ------------------------------------------------------------------
+    t_gen = time.perf_counter()
+    db_pts = db_off = None
+    if args.data == "trajectory" and not ctx.stub:
+        db_pts, db_off, q_pts, q_off, q_src = synth.trajectory_keyframes(1234, n_db, 4321, nq, binary_z=True)
+        main_wl = Workload(ctx, "trajectory", k, n_db)
+        main_wl.add_clouds(db_pts, db_off)                       # descriptor-BUILD path, keyframe by keyframe
+        qb = scancontext.SCManager(device=ctx.local_rank, capacity_hint=nq + 8)
+        for i in range(nq):
+            qb.makeAndSaveScancontextAndKeys(q_pts[q_off[i]:q_off[i + 1]])
+        q_descs = qb.export_descriptors_f32(0, nq)
+        qb.close()
+        del q_pts
+        data_note = (f"DB = {n_db} keyframes of a synthetic drive (2 m apart, street grid, revisits in both directions), radar "
+                     f"feature clouds (z = 0, ~1200 points) through the descriptor-build path; queries = {nq} new scans, "
+                     f"{int((q_src >= 0).sum())} revisits of driven places + {int((q_src < 0).sum())} places never seen")
+    else:
+        descs, q_descs, r_src, r_rot = random_db_and_queries(n_db, nq)
+        main_wl = Workload(ctx, "random", k, n_db)
+        main_wl.add_descriptors(descs)
+        data_note = "descriptor-level random binary DB, queries = rotated corrupted copies (planted loops)"
+    main_wl.set_queries(q_descs, n_elig)
+    gen_s = time.perf_counter() - t_gen
 
-    def step():
-        result["hits"] = ssc.query_device(d_q.data_ptr(), nq, k, n_eligible=n_elig, stream=stream)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    mgr.profile_enable(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
-    launches, kern_ms = mgr.profile_read()
-    mgr.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # correctness of what was timed: planted loops must come back as top-1 (index, shift)
-    res = result["hits"].cpu().numpy().view(scancontext.HIT_DTYPE).reshape(nq, k)
-    ok = (src < n_elig)
-    planted_ok = bool(np.all(res["index"][ok, 0] == src[ok]) and np.all(res["shift"][ok, 0] == rot[ok]))
+    dt, per_rank, (launches, kern_ms), (evals, _) = main_wl.timed(args.steps, args.warmup, profile=True)
+    res = main_wl.results()
+    failures = []
+    if args.data != "trajectory" or ctx.stub:
+        ok = r_src < n_elig
+        planted_ok = bool(np.all(res["index"][ok, 0] == r_src[ok]) and np.all(res["shift"][ok, 0] == r_rot[ok]))
+        if not planted_ok:
+            failures.append("planted loops not recovered as top-1")
+    else:
+        planted_ok = None
 
     if rank == 0:
         qps = nq * args.steps / dt
-        local_pairs = nq * len(range(rank, n_elig, world))  # pairs one launch of this rank scores
-        alg_bytes = local_pairs * ALG_BYTES_PER_PAIR + nq * 4800 + nq * k * 16
-        avg_kern_s = (kern_ms / max(launches, 1)) * 1e-3
-        kernel = mgr.profiled_kernel_name()
-        hbm_alg = alg_bytes / avg_kern_s / 1e9 if avg_kern_s > 0 else 0.0
-        if kernel in ("sc_filter_kernel", "sc_spec_filter_kernel"):
-            spectral = kernel == "sc_spec_filter_kernel"
-            alg_flop = local_pairs * (SPEC_FLOP_PER_PAIR if spectral else ALG_FLOP_PER_PAIR)
-            achieved = alg_flop / avg_kern_s / 1e12 if avg_kern_s > 0 else 0.0
-            traffic, traffic_src = profiled_traffic(kernel) if world == 1 and (n_db, nq) == (10000, 8192) else (None, None)
-            roofline = {"bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                        "frac": achieved / MFMA_F16_PEAK_TFLOPS, "traffic": traffic, "traffic_unit": "bytes per launch",
-                        "traffic_source": traffic_src, "kernel": kernel,
-                        "launches": launches, "avg_launch_ms": kern_ms / max(launches, 1),
-                        "algorithmic_flop_per_launch": alg_flop,
-                        "algorithmic_flop_per_pair": SPEC_FLOP_PER_PAIR if spectral else ALG_FLOP_PER_PAIR,
-                        "direct_form_equivalent_tflops": local_pairs * ALG_FLOP_PER_PAIR / avg_kern_s / 1e12 if avg_kern_s > 0 else 0.0,
-                        "hbm_algorithmic": {"achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                            "frac": hbm_alg / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes},
-                        "note": ("dominant kernel = spectral fp16 MFMA lower-bound filter: the 60-shift circular "
-                                 "cross-correlation of a pair via a Z15 DFT + direct Z4 correlation (27.7 kflop per pair "
-                                 "incl. the exact n_eff mask correlation on the int8 matrix cores) instead of 144 kflop "
-                                 "per pair in the direct K = 1200 form (direct_form_equivalent_tflops = the rate a direct "
-                                 "kernel would need for the same time); `achieved` counts the spectral algorithm's own "
-                                 "flops against the dense fp16 peak. "
-                                 if spectral else
-                                 "dominant kernel = fp16 MFMA lower-bound filter (144 kflop per (query, entry) pair: "
-                                 "60-shift circular cross-correlation, K = 1200). ") +
-                                "The DB tile is register-resident and the fp16 DB image is read about once per query "
-                                "block from L2/Infinity Cache, so the 4800 B/pair algorithmic-byte figure "
-                                "(hbm_algorithmic, SURVEY 8d) exceeds the HBM peak by design; exact fp64 re-scoring of "
-                                "the surviving candidates is included in value/ms_per_step"}
-        else:
-            roofline = {"bound": "hbm", "achieved": hbm_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": hbm_alg / HBM_PEAK_GBS, "traffic": None, "kernel": kernel, "launches": launches,
-                        "avg_launch_ms": kern_ms / max(launches, 1), "algorithmic_bytes_per_launch": alg_bytes,
-                        "note": "algorithmic bytes = 4800 B per (query, entry) pair; batched queries re-use DB "
-                                "tiles from L2/Infinity Cache, so this is an algorithmic-throughput figure; the "
-                                "kernel itself is fp64-VALU-bound (see DESIGN.md)"}
         out = {
             "metric": "sc_loop_queries_per_sec_vs_10k_scan_db", "value": qps, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f16 filter + f64 exact" if kernel in ("sc_filter_kernel", "sc_spec_filter_kernel") else "f64",
+            "scaling": "strong", "vs_baseline": None, "dtype": "f16 filter + f64 exact",
             "data": "synthetic",
-            "config": {"workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n_db}", "db_keyframes": n_db,
+            "config": {"workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n_db}_{main_wl.name}", "db_keyframes": n_db,
                        "queries_per_step": nq, "topk": k, "rings_x_sectors": "20x60",
                        "parallelism": f"db_shard{world}" if world > 1 else "single_gpu",
-                       "pairs_per_sec": qps * n_elig},
-            "roofline": roofline,
-            "planted_loops_recovered": planted_ok,
+                       "pairs_per_sec": qps * n_elig, "data_note": data_note, "data_generation_s": gen_s},
+            "rccl_ranks": ctx.dist.get_world_size() if ctx.distributed else 1,
+            "backend": (ctx.dist.get_backend() if ctx.distributed else "none"),
+            "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
         }
-        # BASELINE configs[1]: 1 query vs 1k-keyframe DB (latency of the synchronous host call)
-        small = scancontext.SCManager(device=local_rank)
-        small.add_descriptors_f32(descs[:1000])
-        for _ in range(5):
-            small.query(queries[:1], k=1, n_eligible=970)
-        t0 = time.perf_counter()
-        for _ in range(50):
-            small.query(queries[:1], k=1, n_eligible=970)
-        out["latency_q1_n1k_us"] = (time.perf_counter() - t0) / 50 * 1e6
-        small.close()
-        out["orora"] = orora_leg(local_rank, args.no_cpu_baseline)
-        out["cen2019"] = cen2019_leg(local_rank)
-        out["icp"] = icp_leg(local_rank)
+        if ctx.stub:
+            out["dry_run"] = True
+            out["planted_loops_recovered"] = planted_ok
+        else:
+            kernel, roof = roofline_of(main_wl, launches, kern_ms, n_elig)
+            out["dtype"] = "f16 filter + f64 exact" if "filter" in kernel else "f64"
+            out["roofline"] = roof
+            out["exact_evals_per_query"] = evals / max(1, nq * args.steps)
+            if planted_ok is not None:
+                out["planted_loops_recovered"] = planted_ok
+
+    # ---- data dependence: the random DB and the exact-all floor, same batch shape --------------
+    if not ctx.stub and not args.only_main:
+        dd = {}
+        if args.data == "trajectory":
+            descs, rq, r_src, r_rot = random_db_and_queries(n_db, nq)
+            wl = Workload(ctx, "random", k, n_db)
+            wl.add_descriptors(descs)
+            wl.set_queries(rq, n_elig)
+            dtr, _, _, (ev, _) = wl.timed(max(3, args.steps // 2), 2, profile=True)
+            r = wl.results()
+            ok = r_src < n_elig
+            rp = bool(np.all(r["index"][ok, 0] == r_src[ok]) and np.all(r["shift"][ok, 0] == r_rot[ok]))
+            if not rp:
+                failures.append("random DB: planted loops not recovered as top-1")
+            steps_r = max(3, args.steps // 2)
+            dd["random_db"] = {"queries_per_sec": nq * steps_r / dtr, "ms_per_step": dtr / steps_r * 1e3,
+                               "exact_evals_per_query": ev / (nq * steps_r), "planted_loops_recovered": rp,
+                               "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n_db}_random (round-1 headline data)"}
+            wl.close()
+            del descs, rq
+        # exact-all: filter off, every (query, entry) pair through the fp64 pair kernel
+        wl = Workload(ctx, "exact_all", k, n_db, filter_mode=1)
+        if db_pts is not None:
+            wl.add_clouds(db_pts, db_off)
+        else:
+            wl.add_descriptors(random_db_and_queries(n_db, 1)[0])
+        wl.set_queries(q_descs, n_elig)
+        dte, _, _, _ = wl.timed(3, 1)
+        same = bool(np.array_equal(wl.results(), res))
+        if not same:
+            failures.append("filtered path and exact-all path disagree")
+        dd["exact_all_floor"] = {"queries_per_sec": nq * 3 / dte, "ms_per_step": dte / 3 * 1e3, "exact_evals_per_query": float(len(range(rank, n_elig, world))),
+                                 "identical_to_filtered_path": same,
+                                 "note": "filter_mode = 1: every eligible pair scored by the exact fp64 kernel -- what the path "
+                                         "costs when the data lets the filter prune nothing"}
+        wl.close()
+        # 100k-keyframe DB: where DB shards pay
+        n100 = 100000
+        d100, q100, s100, r100 = random_db_and_queries(n100, nq, seed_db=2234, seed_q=5321)
+        wl = Workload(ctx, "random100k", k, n100)
+        wl.add_descriptors(d100)
+        del d100
+        wl.set_queries(q100, n100 - 30)
+        st100 = max(3, args.steps // 4)
+        dt100, pr100, _, (ev100, _) = wl.timed(st100, 2, profile=True)
+        r = wl.results()
+        ok = s100 < n100 - 30
+        p100 = bool(np.all(r["index"][ok, 0] == s100[ok]) and np.all(r["shift"][ok, 0] == r100[ok]))
+        if not p100:
+            failures.append("100k DB: planted loops not recovered as top-1")
+        wl.close()
+        if rank == 0:
+            out["data_dependence"] = dd
+            out["scale_100k"] = {"value": nq * st100 / dt100, "unit": "queries/s", "ms_per_step": dt100 / st100 * 1e3, "steps": st100,
+                                 "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n100}_random", "n_gpus": world, "scaling": "strong",
+                                 "per_rank_ms_per_step": [t / st100 * 1e3 for t in pr100],
+                                 "exact_evals_per_query": ev100 / (nq * st100), "planted_loops_recovered": p100}
+
+    if rank == 0 and not ctx.stub:
+        if not args.only_main:
+            # BASELINE configs[1]: 1 query vs 1k-keyframe DB (latency of the synchronous host call)
+            small = scancontext.SCManager(device=ctx.local_rank)
+            small.add_descriptors_f32(main_wl.mgr.export_descriptors_f32(0, min(1000, main_wl.mgr.local_size)))
+            for _ in range(5):
+                small.query(q_descs[:1], k=1, n_eligible=970)
+            t0 = time.perf_counter()
+            for _ in range(50):
+                small.query(q_descs[:1], k=1, n_eligible=970)
+            out["latency_q1_n1k_us"] = (time.perf_counter() - t0) / 50 * 1e6
+            small.close()
+            out["orora"] = orora_leg(ctx.local_rank, args.no_cpu_baseline)
+            out["cen2019"] = cen2019_leg(ctx.local_rank)
+            out["icp"] = icp_leg(ctx.local_rank)
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(descs, queries, k)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+            if db_pts is None:
+                raise SystemExit("cpu_baseline needs --data trajectory (the oracle rebuilds the DB from the clouds)")
+            base, chk = cpu_baseline_and_check(db_pts, db_off, q_descs, n_elig, k, res)
+            out["cpu_baseline"] = base
+            out.update(chk)
+            if chk["oracle_identical_queries"] != chk["oracle_checked_queries"]:
+                failures.append(f"GPU top-{k} differs from the oracle on query {chk['first_mismatch']}")
+    if rank == 0:
+        out["failures"] = failures
+    main_wl.close()
+    ctx.shutdown()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if failures:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -15,8 +15,11 @@
  *     handle's GPU and are used asynchronously on the given hipStream_t (passed as void*).
  *     A NULL stream selects the handle's own private (non-blocking) stream, NOT the legacy default
  *     stream: callers that mix several handles or other GPU work must pass one explicit stream.
- *   - a handle is internally synchronised: one writer (PGO.cpp:492, process_pg) and one reader
- *     (PGO.cpp:561, process_lcd) may call concurrently (the reference itself races here).
+ *   - a handle is internally synchronised: every entry point holds the handle's mutex for its whole
+ *     duration, so any number of threads may call concurrently (the reference itself races between its
+ *     writer, PGO.cpp:492 process_pg, and its reader, PGO.cpp:561 process_lcd).  The one multi-call
+ *     protocol, query stage 1 -> stage 2, is invalidated (stage 2 fails with RSX_ERR_BAD_ARG) by any
+ *     other query-type call on the same handle in between, instead of reading clobbered workspaces.
  *   - there is NO CPU fallback: without a usable HIP device rsx_*_create fails with
  *     RSX_ERR_NO_DEVICE.
  *
@@ -114,10 +117,24 @@ int rsx_sc_local_size(rsx_sc *h, int64_t *n_local);
 int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index);
 /* saveScancontextAndKeys (SC.cpp:236-246), colmajor double; RSX_ERR_NOT_FP32_EXACT if lossy */
 int rsx_sc_add_descriptor(rsx_sc *h, const double *desc_colmajor, int32_t *out_index);
+/* the same for descriptors that did not come out of makeScancontext (e.g. SCDs re-read from decimal text
+ * files in multi-session use): every element is rounded to fp32 -- the DB stores fp32 -- and the largest
+ * absolute rounding error is reported (optional).  NaN elements are still rejected. */
+int rsx_sc_add_descriptor_rounded(rsx_sc *h, const double *desc_colmajor, int32_t *out_index, double *max_abs_rounding);
 /* bulk import of n f32 sector-major descriptors (host memory); same sharding rule */
 int rsx_sc_add_descriptors_f32(rsx_sc *h, const float *descs, int64_t n);
 /* the same from DEVICE memory (no host round trip), n consecutive global keyframes */
 int rsx_sc_add_descriptors_f32_device(rsx_sc *h, const float *d_descs, int64_t n, void *stream);
+
+/* bulk export: the f32 sector-major descriptors of LOCAL slots [first_slot, first_slot + count) (host out) */
+int rsx_sc_export_descriptors_f32(rsx_sc *h, int64_t first_slot, int64_t count, float *out);
+/* on-disk database (the re-ingest side is saveScancontextAndKeys, SC.cpp:236-246): a 64-byte
+ * little-endian header {"RSXSCDB1", version, rings, sectors, dtype, n_global, n_local, shard_rank, shard_world}
+ * followed by the handle's n_local fp32 sector-major descriptors.  Keys, norms and filter images are rebuilt on the
+ * GPU by rsx_sc_load.  An unsharded file appends to any handle (each shard keeps its residue class); a shard file
+ * restores that shard into an empty handle with the same shard_rank / shard_world. */
+int rsx_sc_save(rsx_sc *h, const char *path);
+int rsx_sc_load(rsx_sc *h, const char *path, int64_t *n_loaded);
 
 /* polarcontexts_[i] / getConstRefRecentSCD (SC.h:79,111): global index must be owned by this shard */
 int rsx_sc_get_descriptor(rsx_sc *h, int64_t index, double *out_colmajor);
@@ -201,6 +218,9 @@ const char *rsx_sc_dominant_kernel_name(void);
 const char *rsx_sc_profiled_kernel_name(rsx_sc *h);
 int rsx_sc_profile_enable(rsx_sc *h, int on);
 int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms);
+/* while profiling is enabled the exact re-scoring kernel also counts its work: exact (fp64) pair evaluations and
+ * (query, launch) pairs that scored at least one candidate, since the last read (device-synchronising) */
+int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored);
 
 /* ============================== ORORA registration ======================================
  * Replaces the solver stage of the upstream file-based `odometry.cpp` entry (reference

@@ -74,14 +74,15 @@ SYMBOLS = [
     "rsx_last_error_string", "rsx_version", "rsx_device_count",
     "rsx_sc_default_params", "rsx_sc_create", "rsx_sc_destroy", "rsx_sc_set_dist_thres", "rsx_sc_size",
     "rsx_sc_local_size", "rsx_sc_add_points", "rsx_sc_add_descriptor", "rsx_sc_add_descriptors_f32",
-    "rsx_sc_add_descriptors_f32_device", "rsx_sc_get_descriptor", "rsx_sc_get_ringkey",
+    "rsx_sc_add_descriptors_f32_device", "rsx_sc_add_descriptor_rounded", "rsx_sc_export_descriptors_f32",
+    "rsx_sc_save", "rsx_sc_load", "rsx_sc_get_descriptor", "rsx_sc_get_ringkey",
     "rsx_sc_get_sectorkey", "rsx_sc_detect_loop_closure", "rsx_sc_detect_between_session",
     "rsx_sc_tree_size", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_stage1_device",
     "rsx_sc_query_stage1_elig_device",
     "rsx_sc_query_stage2_device", "rsx_sc_query_self_device",
     "rsx_sc_pair_distances", "rsx_sc_filter_bounds", "rsx_sc_filter_eps", "rsx_sc_profiled_kernel_name",
     "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
-    "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read",
+    "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read", "rsx_sc_profile_read_rescoring",
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
     "rsx_orora_register_batch", "rsx_orora_register_batch_device",
     "rsx_cen2019_default_params", "rsx_cen2019_create", "rsx_cen2019_destroy", "rsx_cen2019_extract",
@@ -124,6 +125,10 @@ def lib():
         L.rsx_sc_add_descriptor.argtypes = [vp, vp, C.POINTER(i32)]
         L.rsx_sc_add_descriptors_f32.argtypes = [vp, vp, i64]
         L.rsx_sc_add_descriptors_f32_device.argtypes = [vp, vp, i64, vp]
+        L.rsx_sc_add_descriptor_rounded.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(dbl)]
+        L.rsx_sc_export_descriptors_f32.argtypes = [vp, i64, i64, vp]
+        L.rsx_sc_save.argtypes = [vp, C.c_char_p]
+        L.rsx_sc_load.argtypes = [vp, C.c_char_p, C.POINTER(i64)]
         L.rsx_sc_get_descriptor.argtypes = [vp, i64, vp]
         L.rsx_sc_get_ringkey.argtypes = [vp, i64, vp]
         L.rsx_sc_get_sectorkey.argtypes = [vp, i64, vp]
@@ -140,6 +145,7 @@ def lib():
         L.rsx_sc_merge_topk_device.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.rsx_sc_profile_enable.argtypes = [vp, C.c_int]
         L.rsx_sc_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl)]
+        L.rsx_sc_profile_read_rescoring.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
         L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
         L.rsx_orora_default_params.argtypes = [C.POINTER(OroraParams)]
         L.rsx_orora_create.argtypes = [C.c_int, C.POINTER(vp)]

@@ -2,6 +2,7 @@
 // reference's detector state machine (Scancontext.cpp:236-422) on top of the HIP kernels.
 // Host logic only; every descriptor/key/distance is computed on the GPU.  There is no CPU fallback.
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -51,6 +52,7 @@ struct rsx_sc {
     QueryView qv{};
   } st;
   DevBuf st_partial;  // this shard's stage-1 hits
+  DevBuf stats;       // 2 x u64 (profiling only): exact pair evaluations, queries that scored any candidate
   void *pinned = nullptr;  // small pinned host staging (results)
   size_t pinned_bytes = 0;
 };
@@ -134,6 +136,7 @@ int ensure_pinned(rsx_sc *h, size_t bytes) {
 
 // keys for nq query descriptors already in h->q_desc (or external device pointer)
 int prepare_queries(rsx_sc *h, const float *d_q, int32_t nq, hipStream_t s, QueryView *qv) {
+  h->st.valid = false;  // q_vkey / q_norm are about to be overwritten: a pending stage 2 would read the wrong keys
   RSX_TRY(h->q_vkey.reserve((size_t)nq * NS * sizeof(double), s, false));
   RSX_TRY(h->q_norm.reserve((size_t)nq * NS * sizeof(double), s, false));
   RSX_TRY(h->q_rkey.reserve((size_t)nq * NR * sizeof(float), s, false));
@@ -145,14 +148,16 @@ int prepare_queries(rsx_sc *h, const float *d_q, int32_t nq, hipStream_t s, Quer
   return RSX_OK;
 }
 
-// RSX_SC_FILTER=0/1 overrides rsx_sc_params.filter_mode (0 auto, 1 off, 2 force)
+// rsx_sc_params.filter_mode (1 off, 2 force) decides; when it says 0 = auto, RSX_SC_FILTER=0/1 may
+// force it off / on (profiling scripts).  Same precedence as filter_kind_of: explicit params first.
 int filter_mode_of(const rsx_sc *h) {
   static const int env = [] {
     const char *e = getenv("RSX_SC_FILTER");
     if (!e || !*e) return -1;
     return atoi(e) ? 2 : 1;
   }();
-  return env >= 0 ? env : h->p.filter_mode;
+  if (h->p.filter_mode) return h->p.filter_mode;
+  return env >= 0 ? env : 0;
 }
 
 bool use_filter(const rsx_sc *h, int32_t nq, int64_t n_items) {
@@ -228,6 +233,7 @@ int64_t filter_batch(int64_t n_items, int64_t nq) {
 }
 
 int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
+  h->st.valid = false;  // bounds / short lists of a pending stage 2 are about to be overwritten
   const int64_t ld = (n_items + 31) / 32 * 32;
   RSX_TRY(h->f_qimg.reserve(any_qimg_bytes((int32_t)qb), s, false));
   RSX_TRY(h->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
@@ -259,7 +265,7 @@ int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, 
   const int64_t ld = (n_items + 31) / 32 * 32;
   return launch_rescore(db_view(h), q, h->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
                         h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), filter_eps(), round_begin, round_end, tau_src,
-                        seed, d_out, k, s);
+                        seed, d_out, k, s, (h->prof.on && h->stats.p) ? h->stats.as<unsigned long long>() : nullptr);
 }
 
 // exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> short list ->
@@ -451,7 +457,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial, &h->stats}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
@@ -567,20 +573,34 @@ static int add_f32_locked(rsx_sc *h, const float *src, int64_t n, bool src_is_de
   return RSX_OK;
 }
 
-int rsx_sc_add_descriptor(rsx_sc *h, const double *desc, int32_t *out_index) {
+static int add_descriptor_f64(rsx_sc *h, const double *desc, bool allow_rounding, int32_t *out_index, double *max_err) {
   if (!h || !desc) return fail(RSX_ERR_BAD_ARG, "null arg");
   float f[DS];
+  double worst = 0.0;
   for (int i = 0; i < DS; i++) {
     f[i] = (float)desc[i];
-    if (!((double)f[i] == desc[i]))  // also rejects NaN
-      return fail(RSX_ERR_NOT_FP32_EXACT, "descriptor element %d (%.17g) is not exactly representable in fp32", i, desc[i]);
+    if (!((double)f[i] == desc[i])) {  // also NaN
+      if (!allow_rounding || !(desc[i] == desc[i]))
+        return fail(RSX_ERR_NOT_FP32_EXACT, "descriptor element %d (%.17g) is not exactly representable in fp32", i, desc[i]);
+      const double e = std::fabs((double)f[i] - desc[i]);
+      if (e > worst) worst = e;
+    }
   }
+  if (max_err) *max_err = worst;
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   const int64_t g = h->n_global;
   RSX_TRY(add_f32_locked(h, f, 1, false, h->stream));
   if (out_index) *out_index = (int32_t)g;
   return RSX_OK;
+}
+
+int rsx_sc_add_descriptor(rsx_sc *h, const double *desc, int32_t *out_index) {
+  return add_descriptor_f64(h, desc, false, out_index, nullptr);
+}
+
+int rsx_sc_add_descriptor_rounded(rsx_sc *h, const double *desc, int32_t *out_index, double *max_abs_rounding) {
+  return add_descriptor_f64(h, desc, true, out_index, max_abs_rounding);
 }
 
 int rsx_sc_add_descriptors_f32(rsx_sc *h, const float *descs, int64_t n) {
@@ -598,6 +618,102 @@ int rsx_sc_add_descriptors_f32_device(rsx_sc *h, const float *d_descs, int64_t n
   RSX_TRY(set_device(h));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   return add_f32_locked(h, d_descs, n, true, s);
+}
+
+int rsx_sc_export_descriptors_f32(rsx_sc *h, int64_t first_slot, int64_t count, float *out) {
+  if (!h || (!out && count)) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (first_slot < 0 || count < 0 || first_slot + count > h->n_local) return fail(RSX_ERR_RANGE, "slot range out of bounds");
+  if (count == 0) return RSX_OK;
+  RSX_TRY(set_device(h));
+  RSX_HIP(hipMemcpyAsync(out, h->desc.as<float>() + first_slot * DS, (size_t)count * DS * sizeof(float), hipMemcpyDeviceToHost,
+                         h->stream));
+  RSX_HIP(hipStreamSynchronize(h->stream));
+  return RSX_OK;
+}
+
+// ---- on-disk database.  Little-endian; 64-byte header, then n_local fp32 sector-major
+// descriptors of 4800 B in slot order.  Keys, norms and filter images are derived data: rebuilt on load.
+namespace {
+struct DbFileHeader {
+  char magic[8];        // "RSXSCDB1"
+  uint32_t version;     // 1
+  uint32_t num_ring;    // 20
+  uint32_t num_sector;  // 60
+  uint32_t dtype;       // 0 = fp32
+  int64_t n_global;     // keyframes known to the saving handle
+  int64_t n_local;      // descriptors in this file
+  int32_t shard_rank, shard_world;
+  uint8_t reserved[16];
+};
+static_assert(sizeof(DbFileHeader) == 64, "header layout");
+}  // namespace
+
+int rsx_sc_save(rsx_sc *h, const char *path) {
+  if (!h || !path) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  std::vector<float> buf((size_t)h->n_local * DS);
+  if (h->n_local) {
+    RSX_HIP(hipMemcpyAsync(buf.data(), h->desc.p, buf.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    RSX_HIP(hipStreamSynchronize(h->stream));
+  }
+  DbFileHeader hd{};
+  std::memcpy(hd.magic, "RSXSCDB1", 8);
+  hd.version = 1;
+  hd.num_ring = NR;
+  hd.num_sector = NS;
+  hd.dtype = 0;
+  hd.n_global = h->n_global;
+  hd.n_local = h->n_local;
+  hd.shard_rank = h->p.shard_rank;
+  hd.shard_world = h->p.shard_world;
+  FILE *f = std::fopen(path, "wb");
+  if (!f) return fail(RSX_ERR_BAD_ARG, "cannot open %s for writing", path);
+  bool ok = std::fwrite(&hd, sizeof(hd), 1, f) == 1;
+  ok = ok && (buf.empty() || std::fwrite(buf.data(), sizeof(float), buf.size(), f) == buf.size());
+  ok = (std::fclose(f) == 0) && ok;
+  if (!ok) return fail(RSX_ERR_INTERNAL, "short write to %s", path);
+  return RSX_OK;
+}
+
+int rsx_sc_load(rsx_sc *h, const char *path, int64_t *n_loaded) {
+  if (!h || !path) return fail(RSX_ERR_BAD_ARG, "null arg");
+  FILE *f = std::fopen(path, "rb");
+  if (!f) return fail(RSX_ERR_BAD_ARG, "cannot open %s", path);
+  DbFileHeader hd{};
+  std::vector<float> buf;
+  bool ok = std::fread(&hd, sizeof(hd), 1, f) == 1 && std::memcmp(hd.magic, "RSXSCDB1", 8) == 0 && hd.version == 1 &&
+            hd.num_ring == (uint32_t)NR && hd.num_sector == (uint32_t)NS && hd.dtype == 0 && hd.n_local >= 0 &&
+            hd.n_local <= hd.n_global && hd.shard_world >= 1;
+  if (ok) {
+    buf.resize((size_t)hd.n_local * DS);
+    ok = buf.empty() || std::fread(buf.data(), sizeof(float), buf.size(), f) == buf.size();
+  }
+  std::fclose(f);
+  if (!ok) return fail(RSX_ERR_BAD_ARG, "%s is not a complete RSXSCDB1 file for 20 x 60 fp32 descriptors", path);
+  std::lock_guard<std::mutex> lk(h->mu);
+  // a shard file restores the shard it was saved from; an unsharded file can be loaded into any (sharded) handle,
+  // which keeps its own residue class
+  if (hd.shard_world != 1) {
+    if (hd.shard_world != h->p.shard_world || hd.shard_rank != h->p.shard_rank || h->n_global != 0)
+      return fail(RSX_ERR_BAD_ARG, "%s holds shard %d/%d: load it into an empty handle of the same shard", path, hd.shard_rank,
+                  hd.shard_world);
+    RSX_TRY(set_device(h));
+    if (hd.n_local) {
+      RSX_TRY(ensure_capacity(h, hd.n_local));
+      RSX_HIP(hipMemcpyAsync(h->desc.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      RSX_TRY(launch_keys(h->desc.as<float>(), hd.n_local, h->vkey.as<double>(), h->norm.as<double>(), h->rkey.as<float>(), h->stream));
+      RSX_TRY(build_db_images(h, 0, hd.n_local, h->stream));
+    }
+    h->n_local = hd.n_local;
+    h->n_global = hd.n_global;
+  } else {
+    RSX_TRY(set_device(h));
+    if (hd.n_local) RSX_TRY(add_f32_locked(h, buf.data(), hd.n_local, false, h->stream));
+  }
+  if (n_loaded) *n_loaded = hd.n_local;
+  return RSX_OK;
 }
 
 static int local_slot_of(rsx_sc *h, int64_t index, int64_t *slot) {
@@ -694,30 +810,32 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
   return score_candidates_and_finish(h, qv, d_key, h->batch_size, RSX_SC_MODE_CANDIDATE, loop_id, yaw, min_dist, nn_idx);
 }
 
-int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out, void *stream) {
-  if (!h || !d_q || !d_out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
-  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
-  std::lock_guard<std::mutex> lk(h->mu);
-  RSX_TRY(set_device(h));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+static int query_device_locked(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out,
+                               hipStream_t s) {
   QueryView qv;
   RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
   const int64_t items = local_count_below(h, n_eligible);
   return run_topk(h, qv, items, n_eligible < 0 ? h->n_global : n_eligible, nullptr, k, d_out, s);
 }
 
+int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out, void *stream) {
+  if (!h || !d_q || !d_out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  return query_device_locked(h, d_q, nq, k, n_eligible, d_out, stream ? static_cast<hipStream_t>(stream) : h->stream);
+}
+
 int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) {
   if (!h || !q || !out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
-  {
-    std::lock_guard<std::mutex> lk(h->mu);
-    RSX_TRY(set_device(h));
-    RSX_TRY(h->q_desc.reserve((size_t)nq * DS * sizeof(float), h->stream, false));
-    RSX_TRY(h->topk.reserve((size_t)nq * k * sizeof(rsx_sc_hit), h->stream, false));
-    RSX_HIP(hipMemcpyAsync(h->q_desc.p, q, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  }
-  RSX_TRY(rsx_sc_query_device(h, h->q_desc.as<float>(), nq, k, n_eligible, h->topk.as<rsx_sc_hit>(), h->stream));
+  // one lock for staging, query and read-back: two concurrent callers share q_desc / topk
   std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  RSX_TRY(h->q_desc.reserve((size_t)nq * DS * sizeof(float), h->stream, false));
+  RSX_TRY(h->topk.reserve((size_t)nq * k * sizeof(rsx_sc_hit), h->stream, false));
+  RSX_HIP(hipMemcpyAsync(h->q_desc.p, q, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  RSX_TRY(query_device_locked(h, h->q_desc.as<float>(), nq, k, n_eligible, h->topk.as<rsx_sc_hit>(), h->stream));
   RSX_HIP(hipMemcpyAsync(out, h->topk.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
   return RSX_OK;
@@ -909,8 +1027,29 @@ int rsx_sc_profile_enable(rsx_sc *h, int on) {
     if (!h->prof.ev) return fail(RSX_ERR_OOM, "host alloc");
     for (int i = 0; i < 2 * PairProfiler::kMax; i++) RSX_HIP(hipEventCreate(&h->prof.ev[i]));
   }
+  if (on) {
+    RSX_TRY(h->stats.reserve(16, h->stream, false));
+    RSX_HIP(hipMemsetAsync(h->stats.p, 0, 16, h->stream));
+    RSX_HIP(hipStreamSynchronize(h->stream));
+  }
   h->prof.on = on != 0;
   h->prof.used = 0;
+  return RSX_OK;
+}
+
+int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored) {
+  if (!h || !exact_evals || !queries_rescored) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  *exact_evals = 0;
+  *queries_rescored = 0;
+  if (!h->stats.p) return RSX_OK;
+  RSX_HIP(hipDeviceSynchronize());  // the counters are bumped by kernels on the caller's stream
+  unsigned long long v[2] = {0, 0};
+  RSX_HIP(hipMemcpy(v, h->stats.p, 16, hipMemcpyDeviceToHost));
+  RSX_HIP(hipMemset(h->stats.p, 0, 16));
+  *exact_evals = (int64_t)v[0];
+  *queries_rescored = (int64_t)v[1];
   return RSX_OK;
 }
 

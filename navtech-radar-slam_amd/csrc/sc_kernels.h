@@ -93,7 +93,8 @@ constexpr int RESCORE_ALL_ROUNDS = RESCORE_NUM_THR + 1;
 int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
                    int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
                    const float *thr, double eps, int32_t round_begin, int32_t round_end, const rsx_sc_hit *tau_src,
-                   const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s);
+                   const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s,
+                   unsigned long long *d_stats = nullptr);
 
 // the same job by one wave per query walking the short list in ascending-bound order (needs the short list
 // ordered by histogram bin, which launch_select produces); single-shard, single-stage

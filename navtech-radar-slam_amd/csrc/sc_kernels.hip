@@ -791,6 +791,7 @@ struct RescoreArgs {
   double eps;
   int32_t k;
   int32_t round_begin, round_end;  // rounds [begin, end) of the short list; end > RESCORE_NUM_THR: also the rest
+  unsigned long long *stats;       // optional (bench instrumentation): [0] += exact pair evaluations, [1] += queries that scored any
 };
 
 // k-th smallest valid record (by (dist, index)) of the nrec records in xch, by RANK COUNTING on one wave:
@@ -892,6 +893,10 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   // score cand[0..ncand) (all waves), then refresh tau
   auto score_and_merge = [&](int ncand) {
     if (ncand == 0) return;  // (uniform) nothing selected: lists and tau are unchanged
+    if (a.stats && threadIdx.x == 0) {
+      atomicAdd(a.stats, (unsigned long long)ncand);
+      if (!scored_any) atomicAdd(a.stats + 1, 1ull);
+    }
     if (!query_loaded) {
       if (threadIdx.x == 0) *reinterpret_cast<int *>(smem + L::OFF_QP32 + QP_FLAG) = 1;
       __syncthreads();
@@ -1333,7 +1338,7 @@ static int launch_rescore_t(const RescoreArgs &a, hipStream_t s) {
 int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
                    int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
                    const float *thr, double eps, int32_t round_begin, int32_t round_end, const rsx_sc_hit *tau_src,
-                   const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s) {
+                   const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s, unsigned long long *d_stats) {
   if (q.nq <= 0) return RSX_OK;
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
   // workgroup shape (entries per wave iteration, waves, waves/SIMD); RSX_SC_RESCORE_VARIANT picks one:
@@ -1363,6 +1368,7 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
   a.k = k;
   a.round_begin = round_begin;
   a.round_end = round_end;
+  a.stats = d_stats;
   switch (variant) {
     case 1: RSX_TRY((launch_rescore_t<1, 16, 4>(a, s))); break;
     case 2: RSX_TRY((launch_rescore_t<2, 12, 3>(a, s))); break;

@@ -6,6 +6,7 @@ detectLoopClosureIDBetweenSession / getConstRefRecentSCD / setSCdistThres.  Ever
 computed by the HIP kernels behind the C-ABI; this class only marshals buffers.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -85,6 +86,14 @@ class SCManager:
         check(self._L.rsx_sc_add_descriptor(self._h, d.ctypes.data, C.byref(idx)))
         return idx.value
 
+    def saveScancontextAndKeysRounded(self, scd):
+        """The same for arbitrary doubles (e.g. SCDs re-read from text files): rounds to fp32, returns
+        (index, largest absolute rounding error)."""
+        d = np.ascontiguousarray(scd, dtype=np.float64).reshape(-1)
+        idx, err = C.c_int32(), C.c_double()
+        check(self._L.rsx_sc_add_descriptor_rounded(self._h, d.ctypes.data, C.byref(idx), C.byref(err)))
+        return idx.value, err.value
+
     def detectLoopClosureID(self, mode=MODE_CANDIDATE, full=False):
         """-> (loop_id, yaw_diff_rad) like the reference; full=True adds (min_dist, nn_idx)."""
         lid, yaw, md, nn = C.c_int32(), C.c_float(), C.c_double(), C.c_int32()
@@ -151,6 +160,22 @@ class SCManager:
     def add_descriptors_device(self, dev_ptr, n, stream=0):
         check(self._L.rsx_sc_add_descriptors_f32_device(self._h, dev_ptr, n, stream))
 
+    def export_descriptors_f32(self, first_slot=0, count=None):
+        """f32 sector-major descriptors of local slots [first_slot, first_slot + count) -> (count, 1200)."""
+        if count is None:
+            count = self.local_size - first_slot
+        out = np.empty((count, 1200), dtype=np.float32)
+        check(self._L.rsx_sc_export_descriptors_f32(self._h, first_slot, count, out.ctypes.data))
+        return out
+
+    def save(self, path):
+        check(self._L.rsx_sc_save(self._h, os.fsencode(path)))
+
+    def load(self, path):
+        n = C.c_int64()
+        check(self._L.rsx_sc_load(self._h, os.fsencode(path), C.byref(n)))
+        return n.value
+
     def query(self, q_descs, k=1, n_eligible=-1):
         q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
         out = np.zeros((q.shape[0], k), dtype=HIT_DTYPE)
@@ -208,6 +233,12 @@ class SCManager:
         n, ms = C.c_int64(), C.c_double()
         check(self._L.rsx_sc_profile_read(self._h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
+
+    def profile_read_rescoring(self):
+        """-> (exact pair evaluations, queries that scored any candidate) since the last read."""
+        a, b = C.c_int64(), C.c_int64()
+        check(self._L.rsx_sc_profile_read_rescoring(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def hit_to_loop(self, hit):
         h = np.zeros(1, dtype=HIT_DTYPE)

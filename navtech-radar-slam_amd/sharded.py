@@ -24,7 +24,7 @@ from ._rsx import HIT_DTYPE
 
 
 class ShardedScanContext:
-    def __init__(self, group=None, device=None, local_backend=None, capacity_hint=1024):
+    def __init__(self, group=None, device=None, local_backend=None, capacity_hint=1024, filter_mode=0):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -35,7 +35,7 @@ class ShardedScanContext:
         if self.on_gpu:
             dev = torch.cuda.current_device() if device is None else device
             self.backend = scancontext.SCManager(device=dev, shard_rank=self.rank, shard_world=self.world,
-                                                 capacity_hint=capacity_hint)
+                                                 capacity_hint=capacity_hint, filter_mode=filter_mode)
             self.device = torch.device("cuda", dev)
         else:
             self.backend = local_backend

@@ -1,0 +1,58 @@
+"""bench.py must start its own ranks: `python bench.py --gpus N` with no torch.distributed environment
+re-executes itself under torch.distributed.run with N processes.  There is no GPU
+here, so the ranks run a CPU stand-in shard over gloo (tests/bench_stub.py); what is under test is the
+launcher, the rank bookkeeping, the barrier-bracketed timing, the max-over-ranks reduction and the
+one-JSON-line contract."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(gpus, extra_env=None):
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["RSX_BENCH_LOCAL_BACKEND"] = "tests.bench_stub:make"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env.update(extra_env or {})
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+           "--db", "150", "--queries", "4", "--topk", "3", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p, lines
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_spawns_its_own_ranks(gpus):
+    p, lines = _run(gpus)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, (p.stdout, p.stderr[-2000:])          # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == gpus and out["rccl_ranks"] == gpus
+    assert len(out["per_rank_ms_per_step"]) == gpus
+    assert out["steps"] == 2 and out["warmup"] == 1 and out["dry_run"] is True
+    assert out["planted_loops_recovered"] is True and out["failures"] == []
+    assert out["ms_per_step"] == pytest.approx(max(out["per_rank_ms_per_step"]))   # MAX over ranks
+    assert out["value"] == pytest.approx(4 / (out["ms_per_step"] * 1e-3), rel=1e-6)
+    if gpus > 1:
+        assert out["backend"] == "gloo" and out["config"]["parallelism"] == "db_shard2"
+
+
+def test_bench_refuses_a_world_that_does_not_match():
+    p, _ = _run(2, {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    # without the test backend the launcher counts GPUs first: none here
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "RSX_BENCH_LOCAL_BACKEND"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)
