@@ -148,6 +148,20 @@ int rsx_sc_get_sectorkey(rsx_sc *h, int64_t index, double *out60);  /* polarcont
  * mode EXHAUSTIVE scores the whole frozen prefix.  Unsharded handles only. */
 int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw_diff_rad,
                                double *min_dist, int32_t *nn_idx);
+/* the same with everything the reference's log line shows (SC.cpp:406,412: "[Loop found] Nearest distance: <min_dist>
+ * btn <query_idx> and <nn_idx>."), taken under one lock so that query_idx is the keyframe that was actually the query */
+typedef struct {
+  int32_t loop_id;      /* nn_idx if min_dist < dist_thres else -1 */
+  float yaw_diff_rad;
+  double min_dist;
+  int32_t nn_idx;
+  int32_t query_idx;    /* polarcontexts_.size() - 1 at the time of the call */
+  int32_t searched;     /* 0: the early return of SC.cpp:341-345 (fewer than NUM_EXCLUDE_RECENT + 1 keyframes; the
+                           reference prints nothing then) */
+  int32_t reserved;
+  double dist_thres;    /* the threshold that was applied */
+} rsx_sc_detection;
+int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out);
 /* detectLoopClosureIDBetweenSession (SC.cpp:267-328): query passed in, tree over the whole DB
  * as of the first call. */
 int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const double *curr_desc_colmajor,
@@ -155,6 +169,21 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
                                   int32_t *nn_idx);
 /* current frozen searchable prefix length ("tree" size, SC.cpp:352-353) */
 int rsx_sc_tree_size(rsx_sc *h, int64_t *n);
+
+/* The reference's public helper methods (SC.h:60-66), stateless: the handle only lends its device, stream and
+ * staging memory.  They run on the GPU in fp64 on the doubles as given (no fp32 storage involved, any MatrixXd
+ * content is accepted) and equal the reference bit for bit.  One small launch per call: API completeness, not
+ * the batched path.
+ *   makeScancontext (SC.cpp:151-195)                          -> 20 x 60 colmajor double */
+int rsx_sc_make_scancontext(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, double *out_desc_colmajor);
+/*   makeRingkeyFromScancontext / makeSectorkeyFromScancontext (SC.cpp:198-227), either output optional */
+int rsx_sc_make_keys(rsx_sc *h, const double *desc_colmajor, double *out_ringkey20, double *out_sectorkey60);
+/*   distDirectSC (SC.cpp:69-90): no alignment, no shift; NaN when no column is effective */
+int rsx_sc_dist_direct(rsx_sc *h, const double *sc1_colmajor, const double *sc2_colmajor, double *out_dist);
+/*   fastAlignUsingVkey (SC.cpp:93-113) on two 1 x 60 sector keys */
+int rsx_sc_fast_align(rsx_sc *h, const double *vkey1_60, const double *vkey2_60, int32_t *out_shift);
+/*   distanceBtnScanContext (SC.cpp:116-148) */
+int rsx_sc_distance(rsx_sc *h, const double *sc1_colmajor, const double *sc2_colmajor, double *out_dist, int32_t *out_shift);
 
 /* Exhaustive batched query (the north-star path): nq f32 sector-major query descriptors against
  * every LOCAL entry whose global index < n_eligible (n_eligible < 0: all); out = nq x k records
@@ -207,6 +236,26 @@ int rsx_sc_merge_topk_device(rsx_sc *h, const rsx_sc_hit *d_parts, int32_t npart
                              int32_t k, rsx_sc_hit *d_out, void *stream);
 /* apply the loop threshold + yaw conversion of SC.cpp:401-417 to a top-1 record */
 int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float *yaw_diff_rad);
+
+/* ---- one process, several GPUs (SURVEY 8e for a single C++ host such as alaserPGO, PGO.cpp:99,706-710) ----
+ * rsx_scs = a ScanContext database sharded over the listed devices (keyframe i on shard i % n_devices), driven
+ * by the calling process: one stream per device, the two-stage query above with the exchanges done as peer
+ * copies over xGMI.  Results are identical to an unsharded handle.  The same device may be listed more than once
+ * (several shards on one GPU: used by the tests on one-GPU boxes).  Internally synchronised. */
+typedef struct rsx_scs rsx_scs;
+int rsx_scs_create(const rsx_sc_params *p, const int32_t *devices, int32_t n_devices, rsx_scs **out);
+int rsx_scs_destroy(rsx_scs *h);
+int rsx_scs_num_shards(rsx_scs *h);
+int rsx_scs_set_dist_thres(rsx_scs *h, double thres);
+int rsx_scs_size(rsx_scs *h, int64_t *n_global);
+int rsx_scs_add_points(rsx_scs *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index);
+int rsx_scs_add_descriptors_f32(rsx_scs *h, const float *descs, int64_t n);
+int rsx_scs_get_descriptor(rsx_scs *h, int64_t index, double *out_colmajor);
+/* exhaustive batched query, host buffers in and out (synchronous); same contract as rsx_sc_query */
+int rsx_scs_query(rsx_scs *h, const float *q_descs, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out);
+/* detectLoopClosureID over the sharded database in EXHAUSTIVE mode (frozen prefix, 30-exclusion, threshold and yaw
+ * as the reference; every entry of the prefix scored) */
+int rsx_scs_detect_loop_closure(rsx_scs *h, rsx_sc_detection *out);
 
 /* instrumentation for bench.py: name of the dominant kernel (as rocprofv3 reports it) and, when
  * enabled, hipEvent pairs recorded around every launch of it on the stream it runs on.

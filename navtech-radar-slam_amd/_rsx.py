@@ -44,6 +44,11 @@ class ScParams(C.Structure):
     ]
 
 
+class ScDetection(C.Structure):
+    _fields_ = [("loop_id", C.c_int32), ("yaw_diff_rad", C.c_float), ("min_dist", C.c_double), ("nn_idx", C.c_int32),
+                ("query_idx", C.c_int32), ("searched", C.c_int32), ("reserved", C.c_int32), ("dist_thres", C.c_double)]
+
+
 class OroraParams(C.Structure):
     _fields_ = [("tim_noise_bound", C.c_double), ("noise_bound_radial", C.c_double),
                 ("noise_bound_tangential", C.c_double), ("gnc_factor", C.c_double),
@@ -76,13 +81,17 @@ SYMBOLS = [
     "rsx_sc_local_size", "rsx_sc_add_points", "rsx_sc_add_descriptor", "rsx_sc_add_descriptors_f32",
     "rsx_sc_add_descriptors_f32_device", "rsx_sc_add_descriptor_rounded", "rsx_sc_export_descriptors_f32",
     "rsx_sc_save", "rsx_sc_load", "rsx_sc_get_descriptor", "rsx_sc_get_ringkey",
-    "rsx_sc_get_sectorkey", "rsx_sc_detect_loop_closure", "rsx_sc_detect_between_session",
+    "rsx_sc_get_sectorkey", "rsx_sc_detect_loop_closure", "rsx_sc_detect_loop_closure_ex", "rsx_sc_make_scancontext",
+    "rsx_sc_make_keys", "rsx_sc_dist_direct", "rsx_sc_fast_align", "rsx_sc_distance", "rsx_sc_detect_between_session",
     "rsx_sc_tree_size", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_stage1_device",
     "rsx_sc_query_stage1_elig_device",
     "rsx_sc_query_stage2_device", "rsx_sc_query_self_device",
     "rsx_sc_pair_distances", "rsx_sc_filter_bounds", "rsx_sc_filter_eps", "rsx_sc_profiled_kernel_name",
     "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
     "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read", "rsx_sc_profile_read_rescoring",
+    "rsx_scs_create", "rsx_scs_destroy", "rsx_scs_num_shards", "rsx_scs_set_dist_thres", "rsx_scs_size",
+    "rsx_scs_add_points", "rsx_scs_add_descriptors_f32", "rsx_scs_get_descriptor", "rsx_scs_query",
+    "rsx_scs_detect_loop_closure",
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
     "rsx_orora_register_batch", "rsx_orora_register_batch_device",
     "rsx_cen2019_default_params", "rsx_cen2019_create", "rsx_cen2019_destroy", "rsx_cen2019_extract",
@@ -133,6 +142,12 @@ def lib():
         L.rsx_sc_get_ringkey.argtypes = [vp, i64, vp]
         L.rsx_sc_get_sectorkey.argtypes = [vp, i64, vp]
         L.rsx_sc_detect_loop_closure.argtypes = [vp, C.c_int, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(i32)]
+        L.rsx_sc_detect_loop_closure_ex.argtypes = [vp, C.c_int, C.POINTER(ScDetection)]
+        L.rsx_sc_make_scancontext.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp]
+        L.rsx_sc_make_keys.argtypes = [vp, vp, vp, vp]
+        L.rsx_sc_dist_direct.argtypes = [vp, vp, vp, C.POINTER(dbl)]
+        L.rsx_sc_fast_align.argtypes = [vp, vp, vp, C.POINTER(i32)]
+        L.rsx_sc_distance.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(i32)]
         L.rsx_sc_detect_between_session.argtypes = [vp, vp, vp, C.POINTER(i32), C.POINTER(C.c_float), C.POINTER(dbl), C.POINTER(i32)]
         L.rsx_sc_query.argtypes = [vp, vp, i32, i32, i64, vp]
         L.rsx_sc_query_device.argtypes = [vp, vp, i32, i32, i64, vp, vp]
@@ -147,6 +162,16 @@ def lib():
         L.rsx_sc_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl)]
         L.rsx_sc_profile_read_rescoring.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
         L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
+        L.rsx_scs_create.argtypes = [C.POINTER(ScParams), C.POINTER(i32), i32, C.POINTER(vp)]
+        L.rsx_scs_destroy.argtypes = [vp]
+        L.rsx_scs_num_shards.argtypes = [vp]
+        L.rsx_scs_set_dist_thres.argtypes = [vp, dbl]
+        L.rsx_scs_size.argtypes = [vp, C.POINTER(i64)]
+        L.rsx_scs_add_points.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(i32)]
+        L.rsx_scs_add_descriptors_f32.argtypes = [vp, vp, i64]
+        L.rsx_scs_get_descriptor.argtypes = [vp, i64, vp]
+        L.rsx_scs_query.argtypes = [vp, vp, i32, i32, i64, vp]
+        L.rsx_scs_detect_loop_closure.argtypes = [vp, C.POINTER(ScDetection)]
         L.rsx_orora_default_params.argtypes = [C.POINTER(OroraParams)]
         L.rsx_orora_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.rsx_orora_destroy.argtypes = [vp]

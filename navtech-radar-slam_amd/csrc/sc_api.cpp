@@ -52,6 +52,7 @@ struct rsx_sc {
     QueryView qv{};
   } st;
   DevBuf st_partial;  // this shard's stage-1 hits
+  DevBuf helper_ws;   // staging of the stateless helper calls (Scancontext.h:60-66)
   DevBuf stats;       // 2 x u64 (profiling only): exact pair evaluations, queries that scored any candidate
   void *pinned = nullptr;  // small pinned host staging (results)
   size_t pinned_bytes = 0;
@@ -457,7 +458,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial, &h->stats}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial, &h->stats, &h->helper_ws}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
@@ -758,20 +759,21 @@ int rsx_sc_get_sectorkey(rsx_sc *h, int64_t index, double *out60) {
   return RSX_OK;
 }
 
-int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw, double *min_dist, int32_t *nn_idx) {
-  if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
+int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out) {
+  if (!h || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (mode != RSX_SC_MODE_CANDIDATE && mode != RSX_SC_MODE_EXHAUSTIVE) return fail(RSX_ERR_BAD_ARG, "bad mode %d", mode);
   std::lock_guard<std::mutex> lk(h->mu);
-  if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "detect_loop_closure needs an unsharded handle; use rsx_sc_query_device + merge");
+  if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "detect_loop_closure needs an unsharded handle; use rsx_scs_* or rsx_sc_query_device + merge");
   RSX_TRY(set_device(h));
   const int64_t N = h->n_global;  // snapshot under the lock (the reference races here, PGO.cpp:561)
-  if (N == 0 || N < h->p.num_exclude_recent + 1) {  // SC.cpp:341-345
-    if (loop_id) *loop_id = -1;
-    if (yaw) *yaw = 0.0f;
-    if (min_dist) *min_dist = 10000000;
-    if (nn_idx) *nn_idx = 0;
-    return RSX_OK;
-  }
+  out->loop_id = -1;
+  out->yaw_diff_rad = 0.0f;
+  out->min_dist = 10000000;
+  out->nn_idx = 0;
+  out->query_idx = (int32_t)(N - 1);
+  out->searched = 0;
+  out->dist_thres = h->p.dist_thres;
+  if (N == 0 || N < h->p.num_exclude_recent + 1) return RSX_OK;  // SC.cpp:341-345
   if (h->tree_counter % h->p.tree_making_period == 0)  // SC.cpp:348-359
     h->tree_size = N - h->p.num_exclude_recent;
   h->tree_counter = h->tree_counter + 1;               // SC.cpp:360
@@ -780,8 +782,82 @@ int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw
   qv.vkey = h->vkey.as<double>() + (N - 1) * NS;
   qv.norm = h->norm.as<double>() + (N - 1) * NS;
   qv.nq = 1;
-  return score_candidates_and_finish(h, qv, h->rkey.as<float>() + (N - 1) * NR /* SC.cpp:335 */, h->tree_size,
-                                     mode, loop_id, yaw, min_dist, nn_idx);
+  out->searched = 1;
+  return score_candidates_and_finish(h, qv, h->rkey.as<float>() + (N - 1) * NR /* SC.cpp:335 */, h->tree_size, mode,
+                                     &out->loop_id, &out->yaw_diff_rad, &out->min_dist, &out->nn_idx);
+}
+
+int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw, double *min_dist, int32_t *nn_idx) {
+  rsx_sc_detection d;
+  RSX_TRY(rsx_sc_detect_loop_closure_ex(h, mode, &d));
+  if (loop_id) *loop_id = d.loop_id;
+  if (yaw) *yaw = d.yaw_diff_rad;
+  if (min_dist) *min_dist = d.min_dist;
+  if (nn_idx) *nn_idx = d.nn_idx;
+  return RSX_OK;
+}
+
+// ---- Scancontext.h:60-66: the public helper methods, stateless, on arbitrary double descriptors ----
+static int helper_call(rsx_sc *h, int op, const double *a, size_t na, const double *b, size_t nb, double *out_d, size_t nd,
+                       int32_t *out_i) {
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  hipStream_t s = h->stream;
+  RSX_TRY(h->helper_ws.reserve((2 * DS + 128) * sizeof(double), s, false));
+  double *d_a = h->helper_ws.as<double>(), *d_b = d_a + DS, *d_o = d_b + DS;
+  int32_t *d_i = reinterpret_cast<int32_t *>(d_o + 96);
+  RSX_HIP(hipMemcpyAsync(d_a, a, na * sizeof(double), hipMemcpyHostToDevice, s));
+  if (b) RSX_HIP(hipMemcpyAsync(d_b, b, nb * sizeof(double), hipMemcpyHostToDevice, s));
+  RSX_TRY(launch_helper(op, d_a, b ? d_b : nullptr, d_o, d_i, s));
+  if (out_d) RSX_HIP(hipMemcpyAsync(out_d, d_o, nd * sizeof(double), hipMemcpyDeviceToHost, s));
+  if (out_i) RSX_HIP(hipMemcpyAsync(out_i, d_i, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  return RSX_OK;
+}
+
+int rsx_sc_make_keys(rsx_sc *h, const double *desc, double *out_ringkey20, double *out_sectorkey60) {
+  if (!h || !desc) return fail(RSX_ERR_BAD_ARG, "null arg");
+  double o[NR + NS];
+  RSX_TRY(helper_call(h, 0, desc, DS, nullptr, 0, o, NR + NS, nullptr));
+  if (out_ringkey20) std::memcpy(out_ringkey20, o, NR * sizeof(double));
+  if (out_sectorkey60) std::memcpy(out_sectorkey60, o + NR, NS * sizeof(double));
+  return RSX_OK;
+}
+
+int rsx_sc_dist_direct(rsx_sc *h, const double *sc1, const double *sc2, double *out_dist) {
+  if (!h || !sc1 || !sc2 || !out_dist) return fail(RSX_ERR_BAD_ARG, "null arg");
+  return helper_call(h, 1, sc1, DS, sc2, DS, out_dist, 1, nullptr);
+}
+
+int rsx_sc_fast_align(rsx_sc *h, const double *vkey1, const double *vkey2, int32_t *out_shift) {
+  if (!h || !vkey1 || !vkey2 || !out_shift) return fail(RSX_ERR_BAD_ARG, "null arg");
+  return helper_call(h, 2, vkey1, NS, vkey2, NS, nullptr, 0, out_shift);
+}
+
+int rsx_sc_distance(rsx_sc *h, const double *sc1, const double *sc2, double *out_dist, int32_t *out_shift) {
+  if (!h || !sc1 || !sc2 || !out_dist || !out_shift) return fail(RSX_ERR_BAD_ARG, "null arg");
+  return helper_call(h, 3, sc1, DS, sc2, DS, out_dist, 1, out_shift);
+}
+
+int rsx_sc_make_scancontext(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, double *out_desc) {
+  if (!h || (!pts && n) || !out_desc) return fail(RSX_ERR_BAD_ARG, "null arg");
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  hipStream_t s = h->stream;
+  const size_t bytes = n * stride_bytes;
+  RSX_TRY(h->pts_ws.reserve(bytes ? bytes : 16, s, false));
+  if (bytes) RSX_HIP(hipMemcpyAsync(h->pts_ws.p, pts, bytes, hipMemcpyHostToDevice, s));
+  RSX_TRY(h->helper_ws.reserve((2 * DS + 128) * sizeof(double), s, false));
+  float *d_desc = h->helper_ws.as<float>();                        // 1200 floats
+  double *d_vk = reinterpret_cast<double *>(d_desc + DS);          // + keys (discarded)
+  RSX_TRY(launch_build(h->pts_ws.p, (int64_t)n, (int64_t)stride_bytes, h->p.lidar_height, h->p.max_radius, d_desc, d_vk,
+                       d_vk + NS, reinterpret_cast<float *>(d_vk + 2 * NS), s));
+  float f[DS];
+  RSX_HIP(hipMemcpyAsync(f, d_desc, sizeof(f), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  for (int i = 0; i < DS; i++) out_desc[i] = (double)f[i];
+  return RSX_OK;
 }
 
 int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const double *curr_desc, int32_t *loop_id,

@@ -141,6 +141,11 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
                        const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s);
 const char *spec_filter_kernel_name();
 
+// ---- the reference's public helper methods on arbitrary double descriptors (sc_helpers.hip) ----
+// op 0: keys of d_a (out_d = ring key [20] + sector key [60]); 1: distDirectSC(d_a, d_b) -> out_d[0];
+// 2: fastAlignUsingVkey(d_a, d_b) (60-element keys) -> out_i[0]; 3: distanceBtnScanContext -> out_d[0], out_i[0]
+int launch_helper(int op, const double *d_a, const double *d_b, double *d_out_d, int32_t *d_out_i, hipStream_t s);
+
 // optional hipEvent bracket around the dominant (pair) kernel
 struct PairProfiler {
   bool on = false;

@@ -1,0 +1,252 @@
+// sc_sharded.cpp -- rsx_scs_*: ONE process driving a ScanContext database sharded over several GPUs
+// (VERDICT r1 "missing" item 7).  The reference's loop-closure node is a single C++ process
+// (laserPosegraphOptimization.cpp:99,706-710); this gives it all GPUs of the node without MPI/torch: G shard
+// handles (keyframe i on shard i % G, include/rsx.h sharding rule), one stream per device, and the two-stage
+// query of rsx.h with the exchanges done as peer copies over xGMI (hipMemcpyPeerAsync) instead of an
+// RCCL all-gather -- same records, same merge (rsx_sc_merge_topk_device), same results as one GPU.
+// Built only on the public C-ABI of the per-shard handle plus HIP memory/stream calls.
+#include <cmath>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "rsx_common.h"
+
+using namespace rsx;
+
+namespace {
+struct Shard {
+  rsx_sc *h = nullptr;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
+  DevBuf q, part, bound, out;
+};
+}  // namespace
+
+struct rsx_scs {
+  std::mutex mu;
+  rsx_sc_params p;
+  std::vector<Shard> sh;
+  DevBuf all, merged;  // on shard 0's device: the gathered per-shard lists and their merge
+  hipEvent_t ev_merged = nullptr;
+  int tree_counter = 0;
+  int64_t tree_size = 0;
+};
+
+namespace {
+
+int use(const Shard &s) {
+  RSX_HIP(hipSetDevice(s.device));
+  return RSX_OK;
+}
+
+// gather every shard's `src` list on shard 0's device and merge -> h->merged (on shard 0's stream)
+int gather_merge(rsx_scs *h, bool from_out, int32_t nq, int32_t k) {
+  const size_t bytes = (size_t)nq * k * sizeof(rsx_sc_hit);
+  const int G = (int)h->sh.size();
+  Shard &s0 = h->sh[0];
+  RSX_TRY(use(s0));
+  RSX_TRY(h->all.reserve(bytes * G, s0.stream, false));
+  RSX_TRY(h->merged.reserve(bytes, s0.stream, false));
+  for (int g = 0; g < G; g++) {
+    Shard &s = h->sh[g];
+    RSX_HIP(hipStreamWaitEvent(s0.stream, s.ev, 0));
+    RSX_HIP(hipMemcpyPeerAsync(static_cast<char *>(h->all.p) + bytes * g, s0.device, from_out ? s.out.p : s.part.p, s.device,
+                               bytes, s0.stream));
+  }
+  RSX_TRY(rsx_sc_merge_topk_device(s0.h, h->all.as<rsx_sc_hit>(), G, nq, k, h->merged.as<rsx_sc_hit>(), s0.stream));
+  RSX_HIP(hipEventRecord(h->ev_merged, s0.stream));
+  return RSX_OK;
+}
+
+int query_locked(rsx_scs *h, const float *q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) {
+  const size_t qbytes = (size_t)nq * RSX_SC_DESC_SIZE * sizeof(float);
+  const size_t bytes = (size_t)nq * k * sizeof(rsx_sc_hit);
+  // stage 1 on every device (asynchronous: the devices work concurrently)
+  for (Shard &s : h->sh) {
+    RSX_TRY(use(s));
+    RSX_TRY(s.q.reserve(qbytes, s.stream, false));
+    RSX_TRY(s.part.reserve(bytes, s.stream, false));
+    RSX_TRY(s.bound.reserve(bytes, s.stream, false));
+    RSX_TRY(s.out.reserve(bytes, s.stream, false));
+    RSX_HIP(hipMemcpyAsync(s.q.p, q, qbytes, hipMemcpyHostToDevice, s.stream));
+    RSX_TRY(rsx_sc_query_stage1_device(s.h, s.q.as<float>(), nq, k, n_eligible, s.part.as<rsx_sc_hit>(), s.stream));
+    RSX_HIP(hipEventRecord(s.ev, s.stream));
+  }
+  RSX_TRY(gather_merge(h, false, nq, k));  // the k-th distance of the merged lists = global bound tau
+  // stage 2: what tau still admits
+  for (Shard &s : h->sh) {
+    RSX_TRY(use(s));
+    RSX_HIP(hipStreamWaitEvent(s.stream, h->ev_merged, 0));
+    RSX_HIP(hipMemcpyPeerAsync(s.bound.p, s.device, h->merged.p, h->sh[0].device, bytes, s.stream));
+    RSX_TRY(rsx_sc_query_stage2_device(s.h, nq, k, s.bound.as<rsx_sc_hit>(), s.out.as<rsx_sc_hit>(), s.stream));
+    RSX_HIP(hipEventRecord(s.ev, s.stream));
+  }
+  // shard 0 must not overwrite `merged` before every shard has copied it: its stream waits for the stage-2 events
+  RSX_TRY(gather_merge(h, true, nq, k));
+  Shard &s0 = h->sh[0];
+  RSX_TRY(use(s0));
+  RSX_HIP(hipMemcpyAsync(out, h->merged.p, bytes, hipMemcpyDeviceToHost, s0.stream));
+  RSX_HIP(hipStreamSynchronize(s0.stream));
+  return RSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsx_scs_create(const rsx_sc_params *p, const int32_t *devices, int32_t n_devices, rsx_scs **out) {
+  if (!out || !devices || n_devices < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  *out = nullptr;
+  rsx_scs *h = new (std::nothrow) rsx_scs();
+  if (!h) return fail(RSX_ERR_OOM, "host alloc");
+  rsx_sc_default_params(&h->p);
+  if (p) h->p = *p;
+  h->sh.resize((size_t)n_devices);
+  int st = RSX_OK;
+  for (int g = 0; g < n_devices && st == RSX_OK; g++) {
+    Shard &s = h->sh[(size_t)g];
+    s.device = devices[g];
+    rsx_sc_params sp = h->p;
+    sp.device = devices[g];
+    sp.shard_rank = g;
+    sp.shard_world = n_devices;
+    if (sp.capacity_hint > 0) sp.capacity_hint = sp.capacity_hint / n_devices + 32;
+    st = rsx_sc_create(&sp, &s.h);
+    if (st != RSX_OK) break;
+    hipError_t e = hipSetDevice(s.device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev, hipEventDisableTiming);
+    if (e != hipSuccess) st = fail(RSX_ERR_HIP, "stream/event on device %d: %s", s.device, hipGetErrorString(e));
+    for (int o = 0; o < g && st == RSX_OK; o++) {  // direct xGMI copies where the topology allows; staged otherwise
+      const int od = h->sh[(size_t)o].device;
+      if (od == s.device) continue;
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, s.device, od) == hipSuccess && can) {
+        (void)hipSetDevice(s.device);
+        (void)hipDeviceEnablePeerAccess(od, 0);
+        (void)hipSetDevice(od);
+        (void)hipDeviceEnablePeerAccess(s.device, 0);
+        (void)hipGetLastError();  // "already enabled" is fine
+      }
+    }
+  }
+  if (st == RSX_OK) {
+    hipError_t e = hipSetDevice(h->sh[0].device);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_merged, hipEventDisableTiming);
+    if (e != hipSuccess) st = fail(RSX_ERR_HIP, "event: %s", hipGetErrorString(e));
+  }
+  if (st != RSX_OK) {
+    const std::string keep = last_error();
+    rsx_scs_destroy(h);
+    last_error() = keep;
+    return st;
+  }
+  *out = h;
+  return RSX_OK;
+}
+
+int rsx_scs_destroy(rsx_scs *h) {
+  if (!h) return RSX_OK;
+  for (Shard &s : h->sh) {
+    (void)hipSetDevice(s.device);
+    if (s.stream) (void)hipStreamSynchronize(s.stream);
+    s.q.release();
+    s.part.release();
+    s.bound.release();
+    s.out.release();
+    if (s.ev) (void)hipEventDestroy(s.ev);
+    if (s.stream) (void)hipStreamDestroy(s.stream);
+    if (s.h) rsx_sc_destroy(s.h);
+  }
+  if (!h->sh.empty()) (void)hipSetDevice(h->sh[0].device);
+  h->all.release();
+  h->merged.release();
+  if (h->ev_merged) (void)hipEventDestroy(h->ev_merged);
+  delete h;
+  return RSX_OK;
+}
+
+int rsx_scs_num_shards(rsx_scs *h) { return h ? (int)h->sh.size() : 0; }
+
+int rsx_scs_set_dist_thres(rsx_scs *h, double thres) {
+  if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->p.dist_thres = thres;
+  for (Shard &s : h->sh) RSX_TRY(rsx_sc_set_dist_thres(s.h, thres));
+  return RSX_OK;
+}
+
+int rsx_scs_size(rsx_scs *h, int64_t *n_global) {
+  if (!h || !n_global) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  return rsx_sc_size(h->sh[0].h, n_global);
+}
+
+// every shard sees every keyframe (the owner builds and stores it, the others advance their count)
+int rsx_scs_add_points(rsx_scs *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index) {
+  if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  int32_t idx = 0;
+  for (Shard &s : h->sh) RSX_TRY(rsx_sc_add_points(s.h, pts, n, stride_bytes, &idx));
+  if (out_index) *out_index = idx;
+  return RSX_OK;
+}
+
+int rsx_scs_add_descriptors_f32(rsx_scs *h, const float *descs, int64_t n) {
+  if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  for (Shard &s : h->sh) RSX_TRY(rsx_sc_add_descriptors_f32(s.h, descs, n));
+  return RSX_OK;
+}
+
+int rsx_scs_get_descriptor(rsx_scs *h, int64_t index, double *out_colmajor) {
+  if (!h || !out_colmajor) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (index < 0) return fail(RSX_ERR_RANGE, "index %lld out of range", (long long)index);
+  return rsx_sc_get_descriptor(h->sh[(size_t)(index % (int64_t)h->sh.size())].h, index, out_colmajor);
+}
+
+int rsx_scs_query(rsx_scs *h, const float *q_descs, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) {
+  if (!h || !q_descs || !out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
+  std::lock_guard<std::mutex> lk(h->mu);
+  return query_locked(h, q_descs, nq, k, n_eligible, out);
+}
+
+// detectLoopClosureID (SC.cpp:331-422) over the sharded database, exhaustive mode: the frozen
+// searchable prefix and the 30-keyframe exclusion are the reference's; every entry of the prefix is scored.
+int rsx_scs_detect_loop_closure(rsx_scs *h, rsx_sc_detection *out) {
+  if (!h || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  int64_t N = 0;
+  RSX_TRY(rsx_sc_size(h->sh[0].h, &N));
+  out->loop_id = -1;
+  out->yaw_diff_rad = 0.0f;
+  out->min_dist = 10000000;
+  out->nn_idx = 0;
+  out->query_idx = (int32_t)(N - 1);
+  out->searched = 0;
+  out->reserved = 0;
+  out->dist_thres = h->p.dist_thres;
+  if (N == 0 || N < h->p.num_exclude_recent + 1) return RSX_OK;                                       // SC.cpp:341-345
+  if (h->tree_counter % h->p.tree_making_period == 0) h->tree_size = N - h->p.num_exclude_recent;   // SC.cpp:348-359
+  h->tree_counter = h->tree_counter + 1;                                                             // SC.cpp:360
+  double d[RSX_SC_DESC_SIZE];
+  float f[RSX_SC_DESC_SIZE];
+  RSX_TRY(rsx_sc_get_descriptor(h->sh[(size_t)((N - 1) % (int64_t)h->sh.size())].h, N - 1, d));      // SC.cpp:336
+  for (int i = 0; i < RSX_SC_DESC_SIZE; i++) f[i] = (float)d[i];  // stored as fp32: exact
+  rsx_sc_hit hit;
+  RSX_TRY(query_locked(h, f, 1, 1, h->tree_size, &hit));
+  out->searched = 1;
+  if (hit.dist < 10000000) {  // SC.cpp:388 strict `<` against the 1e7 init
+    out->min_dist = hit.dist;
+    out->nn_idx = hit.index;
+  }
+  RSX_TRY(rsx_sc_hit_to_loop(h->sh[0].h, &hit, &out->loop_id, &out->yaw_diff_rad));                  // SC.cpp:401-417
+  if (!(hit.dist < 10000000)) out->yaw_diff_rad = 0.0f;
+  return RSX_OK;
+}
+
+}  // extern "C"

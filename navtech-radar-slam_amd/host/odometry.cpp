@@ -156,7 +156,8 @@ void associate(const Scan &prev, const Scan &cur, float gate, std::vector<float>
 int main(int argc, char **argv) {
   try {
     std::string seq_dir, out_path;
-    int max_frames = -1;
+    int max_frames = -1, device = 0;
+    double rate_hz = 0.0;
     float gate = 6.0f;
     for (int i = 1; i < argc; i++) {
       const std::string a = argv[i];
@@ -165,8 +166,12 @@ int main(int argc, char **argv) {
       else if (a == "--gate" && i + 1 < argc) gate = (float)std::atof(argv[++i]);
       else if (a.rfind("seq_dir:=", 0) == 0) seq_dir = a.substr(9);  // roslaunch-style arg
       else if (a.rfind("do_slam:=", 0) == 0) continue;                // accepted for launch compatibility
+      else if (a.rfind("device:=", 0) == 0) device = std::atoi(a.c_str() + 8);    // run_orora.launch
+      else if (a.rfind("rate_hz:=", 0) == 0) rate_hz = std::atof(a.c_str() + 9);  // pacing of the publishers
+      else if (a.rfind("__", 0) == 0 || a.find(":=") != std::string::npos) continue;  // roslaunch remaps (__name:=...)
       else seq_dir = a;
     }
+    (void)rate_hz;  // only the ROS publishers are paced
     if (seq_dir.empty()) die("usage: odometry <seq_dir> [--out poses.txt] [--max_frames N] [--gate metres]");
     const std::string dir = seq_dir + "/polar_oxford_form";
     std::vector<std::string> files;
@@ -194,7 +199,7 @@ int main(int argc, char **argv) {
 
     rsx_cen2019 *cen = nullptr;
     rsx_orora *reg = nullptr;
-    check(rsx_orora_create(0, &reg), "rsx_orora_create");
+    check(rsx_orora_create(device, &reg), "rsx_orora_create");
     rsx_cen2019_params cp;
     rsx_cen2019_default_params(&cp);
     double px = 0, py = 0, pyaw = 0;  // accumulated pose of the sensor in the odom frame
@@ -208,7 +213,7 @@ int main(int argc, char **argv) {
       if (!cen) {
         rows = h;
         cols = w - kMeta;
-        check(rsx_cen2019_create(0, rows, cols, &cen), "rsx_cen2019_create");
+        check(rsx_cen2019_create(device, rows, cols, &cen), "rsx_cen2019_create");
         az.resize((size_t)rows);
       } else if (h != rows || w - kMeta != cols) {
         die(files[fi] + ": image shape changed");
@@ -281,6 +286,8 @@ int main(int argc, char **argv) {
       }
       pub_cloud.publish(pc);
       ros::spinOnce();
+      if (rate_hz > 0.0) ros::Duration(1.0 / rate_hz).sleep();
+      if (!ros::ok()) break;
 #endif
       prev = std::move(cur);
     }

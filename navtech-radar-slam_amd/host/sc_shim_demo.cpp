@@ -5,6 +5,8 @@
 #include <atomic>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <iostream>
 #include <random>
 #include <thread>
@@ -34,8 +36,68 @@ static std::vector<Pt> synth_cloud(std::mt19937 &rng, float yaw, const std::vect
   return c;
 }
 
-int main() {
+// --replay <file> [--devices a,b,..] [--exhaustive]: feed recorded clouds (int32 n_clouds, then per cloud
+// int32 n_points + n_points x {x,y,z,intensity} floats) through the shim exactly like process_pg / process_lcd do,
+// one detectLoopClosureID() per keyframe.  stdout = the shim's own "[Loop found] / [Not loop]" lines
+// (Scancontext.cpp:406,412) followed by one "RESULT i loop_id yaw" line per keyframe; tests/test_gpu_host.py
+// compares both with the reference build's output on the same clouds.
+static int replay(const char *path, const std::vector<int> &devices, bool exhaustive) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) {
+    std::fprintf(stderr, "cannot open %s\n", path);
+    return 1;
+  }
+  int32_t n_clouds = 0;
+  if (std::fread(&n_clouds, 4, 1, f) != 1) return 1;
+  SCManager sc;
+  sc.setSCdistThres(0.45);
+  if (devices.size() > 1) sc.setDevices(devices);
+  else if (devices.size() == 1) sc.setDevice(devices[0]);
+  sc.setExhaustive(exhaustive);
+  std::vector<float> raw;
+  std::vector<Pt> cloud;
+  for (int i = 0; i < n_clouds; i++) {
+    int32_t n = 0;
+    if (std::fread(&n, 4, 1, f) != 1) return 1;
+    raw.resize((size_t)n * 4);
+    if (n && std::fread(raw.data(), 16, (size_t)n, f) != (size_t)n) return 1;
+    cloud.clear();
+    for (int j = 0; j < n; j++) cloud.push_back(Pt{raw[4 * j], raw[4 * j + 1], raw[4 * j + 2], raw[4 * j + 3], {}});
+    sc.makeAndSaveScancontextAndKeys(n ? &cloud[0].x : nullptr, cloud.size(), sizeof(Pt));
+    auto r = sc.detectLoopClosureID();
+    std::printf("RESULT %d %d %.9g\n", i, r.first, (double)r.second);
+    std::fflush(stdout);
+  }
+  std::fclose(f);
+  // the public helpers (Scancontext.h:60-66) on the last two keyframes
+  std::vector<double> a = sc.descriptor(n_clouds - 1), b = sc.descriptor(n_clouds - 2);
+  double rk[20], vk1[60], vk2[60];
+  sc.makeRingkeyFromScancontext(a.data(), rk);
+  sc.makeSectorkeyFromScancontext(a.data(), vk1);
+  sc.makeSectorkeyFromScancontext(b.data(), vk2);
+  auto d = sc.distanceBtnScanContext(a.data(), b.data());
+  std::printf("HELPERS %.17g %.17g %d %.17g %d %.17g\n", rk[3], vk1[7], sc.fastAlignUsingVkey(vk1, vk2), d.first, d.second,
+              sc.distDirectSC(a.data(), b.data()));
+  return 0;
+}
+
+int main(int argc, char **argv) {
   try {
+    if (argc >= 3 && std::string(argv[1]) == "--replay") {
+      std::vector<int> devices;
+      bool exhaustive = false;
+      for (int i = 3; i < argc; i++) {
+        if (std::string(argv[i]) == "--exhaustive") exhaustive = true;
+        if (std::string(argv[i]) == "--devices" && i + 1 < argc) {
+          for (const char *p = argv[++i]; *p;) {
+            devices.push_back(std::atoi(p));
+            while (*p && *p != ',') p++;
+            if (*p == ',') p++;
+          }
+        }
+      }
+      return replay(argv[2], devices, exhaustive);
+    }
     coreImportTest();
     scManager.setSCdistThres(0.45);  // PGO.cpp:677,685 + sc_pgo.launch:4
     scManager.handle();              // create the GPU handle up front: no device -> fail here, loudly

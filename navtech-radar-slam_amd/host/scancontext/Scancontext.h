@@ -16,14 +16,24 @@
 //   * without them (this container): the POD overloads below carry the same semantics.
 //
 // Differences a maintainer should know (DESIGN.md "boundary"):
-//   * SCManager is internally synchronised (the reference races between PGO.cpp:492 and :561);
+//   * SCManager is internally synchronised (the reference races between PGO.cpp:492 and :561): the GPU
+//     handle is created once under a lock, every call locks the handle inside librsx, and the shim's own
+//     cached values (last log values, recent SCD) are per thread or guarded;
 //   * failures of the GPU library throw std::runtime_error (the reference has no error path);
 //   * the public std::vector members polarcontexts_ etc. are replaced by accessors
-//     (descriptor(i), ringkey(i), sectorkey(i)) that read the HBM-resident database.
+//     (descriptor(i), ringkey(i), sectorkey(i)) that read the HBM-resident database;
+//   * the database stores fp32: saveScancontextAndKeys(MatrixXd) rounds a descriptor that is not
+//     fp32-exact (every descriptor makeScancontext builds is) and remembers the largest rounding error
+//     (lastImportRounding()); setStrictImport(true) makes such a descriptor an error instead;
+//   * setDevice / setDevices / setExhaustive must be called before the first use (they throw afterwards);
+//   * detectLoopClosureID prints the reference's "[Loop found] / [Not loop] Nearest distance ..." line
+//     (Scancontext.cpp:406,412), including its std::cout.precision(3) side effect; setVerbose(false) mutes it.
 #pragma once
 
 #include <cstddef>
 #include <cstdint>
+#include <iostream>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -54,6 +64,7 @@ class SCManager {
   ~SCManager() {
     if (vg_) rsx_voxelgrid_destroy(vg_);
     if (h_) rsx_sc_destroy(h_);
+    if (hs_) rsx_scs_destroy(hs_);
   }
   SCManager(const SCManager &) = delete;
   SCManager &operator=(const SCManager &) = delete;
@@ -68,15 +79,20 @@ class SCManager {
 #endif
   // POD form: n points, stride_bytes apart, float x,y,z first
   void makeAndSaveScancontextAndKeys(const float *xyz, std::size_t n, std::size_t stride_bytes) {
-    check(rsx_sc_add_points(handle(), xyz, n, stride_bytes, nullptr), "makeAndSaveScancontextAndKeys");
+    if (sharded()) check(rsx_scs_add_points(shardedHandle(), xyz, n, stride_bytes, nullptr), "makeAndSaveScancontextAndKeys");
+    else check(rsx_sc_add_points(handle(), xyz, n, stride_bytes, nullptr), "makeAndSaveScancontextAndKeys");
   }
 
   // Opt-in fusion of the caller's `downSizeFilterScancontext.filter(*thisKeyFrameDS)` with the build
   // (laserPosegraphOptimization.cpp:482-492): the raw keyframe goes in, the VoxelGrid downsample
   // (leaf as set at PGO.cpp:687-688) and the descriptor build both run on the GPU.
   void makeAndSaveScancontextAndKeysDownsampled(const float *xyz, std::size_t n, std::size_t stride_bytes, float leaf = 0.4f) {
+    if (sharded()) throw std::runtime_error("makeAndSaveScancontextAndKeysDownsampled: single-device handles only");
     rsx_sc *h = handle();
-    if (!vg_) check(rsx_voxelgrid_create(device_, &vg_), "rsx_voxelgrid_create");
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!vg_) check(rsx_voxelgrid_create(device_, &vg_), "rsx_voxelgrid_create");
+    }
     check(rsx_sc_add_points_downsampled(h, vg_, xyz, n, stride_bytes, leaf, nullptr), "makeAndSaveScancontextAndKeysDownsampled");
   }
 #ifdef RSX_HAVE_PCL
@@ -88,13 +104,25 @@ class SCManager {
 
   // int: nearest node index or -1, float: relative yaw [rad]
   std::pair<int, float> detectLoopClosureID(void) {
-    int32_t id = -1, nn = 0;
-    float yaw = 0.f;
-    double md = 0;
-    check(rsx_sc_detect_loop_closure(handle(), mode_, &id, &yaw, &md, &nn), "detectLoopClosureID");
-    last_min_dist_ = md;
-    last_nn_idx_ = nn;
-    return {id, yaw};
+    rsx_sc_detection d;
+    if (sharded()) check(rsx_scs_detect_loop_closure(shardedHandle(), &d), "detectLoopClosureID");
+    else check(rsx_sc_detect_loop_closure_ex(handle(), mode_, &d), "detectLoopClosureID");
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      last_min_dist_ = d.min_dist;
+      last_nn_idx_ = d.nn_idx;
+    }
+    if (verbose_ && d.searched) {  // Scancontext.cpp:401-414, character for character
+      using std::cout;
+      using std::endl;
+      if (d.min_dist < d.dist_thres) {
+        cout << "[Loop found] Nearest distance: " << d.min_dist << " btn " << d.query_idx << " and " << d.nn_idx << "." << endl;
+      } else {
+        std::cout.precision(3);
+        cout << "[Not loop] Nearest distance: " << d.min_dist << " btn " << d.query_idx << " and " << d.nn_idx << "." << endl;
+      }
+    }
+    return {d.loop_id, d.yaw_diff_rad};
   }
 
 #ifdef RSX_HAVE_EIGEN
@@ -106,16 +134,91 @@ class SCManager {
     requireShape(curr_desc.rows(), curr_desc.cols());
     return detectLoopClosureIDBetweenSession(curr_key, curr_desc.data());
   }
+  // a reference into per-thread storage: valid until the calling thread's next call (the reference returns a
+  // reference into its vector, Scancontext.cpp:230-233, which the next push_back may invalidate just the same)
   const Eigen::MatrixXd &getConstRefRecentSCD(void) {
-    recent_ = Eigen::MatrixXd(RSX_SC_NUM_RING, RSX_SC_NUM_SECTOR);
-    int64_t n = size();
-    check(rsx_sc_get_descriptor(handle(), n - 1, recent_.data()), "getConstRefRecentSCD");
-    return recent_;
+    static thread_local Eigen::MatrixXd recent;
+    recent = Eigen::MatrixXd(RSX_SC_NUM_RING, RSX_SC_NUM_SECTOR);
+    getRecentSCD(recent.data());
+    return recent;
+  }
+  // ---- public helpers of the reference (Scancontext.h:60-66), computed on the GPU ----
+#ifdef RSX_HAVE_PCL
+  Eigen::MatrixXd makeScancontext(pcl::PointCloud<SCPointType> &scan_down) {
+    Eigen::MatrixXd d(RSX_SC_NUM_RING, RSX_SC_NUM_SECTOR);
+    makeScancontext(scan_down.points.empty() ? nullptr : &scan_down.points[0].x, scan_down.points.size(), sizeof(SCPointType), d.data());
+    return d;
   }
 #endif
+  Eigen::MatrixXd makeRingkeyFromScancontext(Eigen::MatrixXd &desc) {
+    requireShape(desc.rows(), desc.cols());
+    Eigen::MatrixXd k(RSX_SC_NUM_RING, 1);
+    makeRingkeyFromScancontext(desc.data(), k.data());
+    return k;
+  }
+  Eigen::MatrixXd makeSectorkeyFromScancontext(Eigen::MatrixXd &desc) {
+    requireShape(desc.rows(), desc.cols());
+    Eigen::MatrixXd k(1, RSX_SC_NUM_SECTOR);
+    makeSectorkeyFromScancontext(desc.data(), k.data());
+    return k;
+  }
+  int fastAlignUsingVkey(Eigen::MatrixXd &vkey1, Eigen::MatrixXd &vkey2) {
+    if (vkey1.size() != RSX_SC_NUM_SECTOR || vkey2.size() != RSX_SC_NUM_SECTOR) throw std::runtime_error("sector keys must have 60 entries");
+    return fastAlignUsingVkey(vkey1.data(), vkey2.data());
+  }
+  double distDirectSC(Eigen::MatrixXd &sc1, Eigen::MatrixXd &sc2) {
+    requireShape(sc1.rows(), sc1.cols());
+    requireShape(sc2.rows(), sc2.cols());
+    return distDirectSC(sc1.data(), sc2.data());
+  }
+  std::pair<double, int> distanceBtnScanContext(Eigen::MatrixXd &sc1, Eigen::MatrixXd &sc2) {
+    requireShape(sc1.rows(), sc1.cols());
+    requireShape(sc2.rows(), sc2.cols());
+    return distanceBtnScanContext(sc1.data(), sc2.data());
+  }
+#endif
+  // POD forms of the helpers: descriptors are 20 x 60 column-major doubles, keys 20 / 60 doubles
+  void makeScancontext(const float *xyz, std::size_t n, std::size_t stride_bytes, double *out_desc) {
+    check(rsx_sc_make_scancontext(anyHandle(), xyz, n, stride_bytes, out_desc), "makeScancontext");
+  }
+  void makeRingkeyFromScancontext(const double *desc, double *out20) {
+    check(rsx_sc_make_keys(anyHandle(), desc, out20, nullptr), "makeRingkeyFromScancontext");
+  }
+  void makeSectorkeyFromScancontext(const double *desc, double *out60) {
+    check(rsx_sc_make_keys(anyHandle(), desc, nullptr, out60), "makeSectorkeyFromScancontext");
+  }
+  int fastAlignUsingVkey(const double *vkey1, const double *vkey2) {
+    int32_t k = 0;
+    check(rsx_sc_fast_align(anyHandle(), vkey1, vkey2, &k), "fastAlignUsingVkey");
+    return k;
+  }
+  double distDirectSC(const double *sc1, const double *sc2) {
+    double d = 0;
+    check(rsx_sc_dist_direct(anyHandle(), sc1, sc2, &d), "distDirectSC");
+    return d;
+  }
+  std::pair<double, int> distanceBtnScanContext(const double *sc1, const double *sc2) {
+    double d = 0;
+    int32_t k = 0;
+    check(rsx_sc_distance(anyHandle(), sc1, sc2, &d, &k), "distanceBtnScanContext");
+    return {d, k};
+  }
+  void getRecentSCD(double *out_colmajor) {  // polarcontexts_.back()
+    const int64_t n = size();
+    if (sharded()) check(rsx_scs_get_descriptor(shardedHandle(), n - 1, out_colmajor), "getConstRefRecentSCD");
+    else check(rsx_sc_get_descriptor(handle(), n - 1, out_colmajor), "getConstRefRecentSCD");
+  }
   // POD forms: 20x60 column-major doubles (Eigen::MatrixXd memory order)
   void saveScancontextAndKeys(const double *scd_colmajor) {
-    check(rsx_sc_add_descriptor(handle(), scd_colmajor, nullptr), "saveScancontextAndKeys");
+    if (sharded()) throw std::runtime_error("saveScancontextAndKeys: single-device handles only");
+    if (strict_import_) {
+      check(rsx_sc_add_descriptor(handle(), scd_colmajor, nullptr), "saveScancontextAndKeys");
+      return;
+    }
+    double err = 0.0;
+    check(rsx_sc_add_descriptor_rounded(handle(), scd_colmajor, nullptr, &err), "saveScancontextAndKeys");
+    std::lock_guard<std::mutex> lk(mu_);
+    if (err > last_import_rounding_) last_import_rounding_ = err;
   }
   std::pair<int, float> detectLoopClosureIDBetweenSession(std::vector<float> &curr_key, const double *curr_desc_colmajor) {
     if (curr_key.size() != RSX_SC_NUM_RING) throw std::runtime_error("ring key must have 20 entries");
@@ -124,6 +227,7 @@ class SCManager {
     double md = 0;
     check(rsx_sc_detect_between_session(handle(), curr_key.data(), curr_desc_colmajor, &id, &yaw, &md, &nn),
           "detectLoopClosureIDBetweenSession");
+    std::lock_guard<std::mutex> lk(mu_);
     last_min_dist_ = md;
     last_nn_idx_ = nn;
     return {id, yaw};
@@ -143,24 +247,54 @@ class SCManager {
   const int TREE_MAKING_PERIOD_ = 30;
 
   void setSCdistThres(double new_thres) {  // Scancontext.h:107
+    std::lock_guard<std::mutex> lk(mu_);
     SC_DIST_THRES = new_thres;
     if (h_) check(rsx_sc_set_dist_thres(h_, new_thres), "setSCdistThres");
+    if (hs_) check(rsx_scs_set_dist_thres(hs_, new_thres), "setSCdistThres");
   }
 
   // ---- extensions (opt-in; defaults reproduce the reference) ----
   // score the whole searchable prefix instead of the 3 ring-key neighbours
   void setExhaustive(bool on) { mode_ = on ? RSX_SC_MODE_EXHAUSTIVE : RSX_SC_MODE_CANDIDATE; }
-  void setDevice(int device) { device_ = device; }  // before first use
+  void setVerbose(bool on) { verbose_ = on; }
+  void setStrictImport(bool on) { strict_import_ = on; }
+  void setDevice(int device) {  // before first use
+    std::lock_guard<std::mutex> lk(mu_);
+    if (h_ || hs_) throw std::runtime_error("setDevice after the GPU handle was created");
+    device_ = device;
+  }
+  // shard the database over several GPUs of this node (keyframe i on devices[i % n]); the detector then scores the
+  // whole searchable prefix (exhaustive mode) on all of them.  Before first use.
+  void setDevices(const std::vector<int> &devices) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (h_ || hs_) throw std::runtime_error("setDevices after the GPU handle was created");
+    if (devices.empty()) throw std::runtime_error("setDevices: empty list");
+    devices_.assign(devices.begin(), devices.end());
+    device_ = devices[0];
+  }
+  bool sharded() const { return devices_.size() > 1; }
   int64_t size() {
     int64_t n = 0;
-    check(rsx_sc_size(handle(), &n), "size");
+    if (sharded()) check(rsx_scs_size(shardedHandle(), &n), "size");
+    else check(rsx_sc_size(handle(), &n), "size");
     return n;
   }
-  double lastMinDist() const { return last_min_dist_; }  // the value of the reference's log line (SC.cpp:406,412)
-  int lastNearestIndex() const { return last_nn_idx_; }
+  double lastMinDist() {  // the value of the reference's log line (SC.cpp:406,412)
+    std::lock_guard<std::mutex> lk(mu_);
+    return last_min_dist_;
+  }
+  int lastNearestIndex() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return last_nn_idx_;
+  }
+  double lastImportRounding() {
+    std::lock_guard<std::mutex> lk(mu_);
+    return last_import_rounding_;
+  }
   std::vector<double> descriptor(int64_t i) {  // polarcontexts_[i], column-major 20x60
     std::vector<double> d(RSX_SC_DESC_SIZE);
-    check(rsx_sc_get_descriptor(handle(), i, d.data()), "descriptor");
+    if (sharded()) check(rsx_scs_get_descriptor(shardedHandle(), i, d.data()), "descriptor");
+    else check(rsx_sc_get_descriptor(handle(), i, d.data()), "descriptor");
     return d;
   }
   std::vector<float> ringkey(int64_t i) {  // polarcontext_invkeys_mat_[i]
@@ -173,7 +307,14 @@ class SCManager {
     check(rsx_sc_get_sectorkey(handle(), i, k.data()), "sectorkey");
     return k;
   }
+  // batched exhaustive query (the north-star path), host buffers: nq f32 sector-major descriptors -> nq x k hits
+  void query(const float *q_descs, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) {
+    if (sharded()) check(rsx_scs_query(shardedHandle(), q_descs, nq, k, n_eligible, out), "query");
+    else check(rsx_sc_query(handle(), q_descs, nq, k, n_eligible, out), "query");
+  }
   rsx_sc *handle() {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (sharded()) throw std::runtime_error("single-device call on a multi-device SCManager");
     if (!h_) {
       rsx_sc_params p;
       rsx_sc_default_params(&p);
@@ -182,6 +323,17 @@ class SCManager {
       check(rsx_sc_create(&p, &h_), "SCManager (rsx_sc_create)");
     }
     return h_;
+  }
+  rsx_scs *shardedHandle() {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!hs_) {
+      rsx_sc_params p;
+      rsx_sc_default_params(&p);
+      p.dist_thres = SC_DIST_THRES;
+      std::vector<int32_t> dev(devices_.begin(), devices_.end());
+      check(rsx_scs_create(&p, dev.data(), (int32_t)dev.size(), &hs_), "SCManager (rsx_scs_create)");
+    }
+    return hs_;
   }
 
  private:
@@ -192,16 +344,29 @@ class SCManager {
   static void requireShape(long rows, long cols) {
     if (rows != RSX_SC_NUM_RING || cols != RSX_SC_NUM_SECTOR) throw std::runtime_error("descriptor must be 20 x 60");
   }
+  // the stateless helpers need a device: the single-device handle, or in multi-device mode a small helper handle
+  rsx_sc *anyHandle() {
+    if (!sharded()) return handle();
+    std::lock_guard<std::mutex> lk(mu_);
+    if (!h_) {
+      rsx_sc_params p;
+      rsx_sc_default_params(&p);
+      p.device = device_;
+      p.capacity_hint = 32;
+      check(rsx_sc_create(&p, &h_), "SCManager (helper handle)");
+    }
+    return h_;
+  }
+  std::mutex mu_;  // guards handle creation and the cached values below
   rsx_sc *h_ = nullptr;
+  rsx_scs *hs_ = nullptr;
   rsx_voxelgrid *vg_ = nullptr;
   int mode_ = RSX_SC_MODE_CANDIDATE;
   int device_ = 0;
-  double last_min_dist_ = 0.0;
+  std::vector<int> devices_;
+  bool verbose_ = true, strict_import_ = false;
+  double last_min_dist_ = 0.0, last_import_rounding_ = 0.0;
   int last_nn_idx_ = 0;
-#ifdef RSX_HAVE_EIGEN
-  Eigen::MatrixXd recent_;
-#endif
 };
 
-#include <iostream>
 inline void coreImportTest(void) { std::cout << "scancontext lib (rsx / MI355X) is successfully imported." << std::endl; }

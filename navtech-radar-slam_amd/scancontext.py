@@ -112,6 +112,52 @@ class SCManager:
             return lid.value, yaw.value, md.value, nn.value
         return lid.value, yaw.value
 
+    # ---- the reference's public helpers (Scancontext.h:60-66), stateless ------------------------
+    def makeScancontext(self, scan_down):
+        pts = np.ascontiguousarray(scan_down, dtype=np.float32)
+        out = np.empty(1200, dtype=np.float64)
+        check(self._L.rsx_sc_make_scancontext(self._h, pts.ctypes.data, pts.shape[0], pts.shape[1] * 4, out.ctypes.data))
+        return out
+
+    def makeRingkeyFromScancontext(self, desc):
+        d = np.ascontiguousarray(desc, dtype=np.float64).reshape(-1)
+        out = np.empty(20, dtype=np.float64)
+        check(self._L.rsx_sc_make_keys(self._h, d.ctypes.data, out.ctypes.data, None))
+        return out
+
+    def makeSectorkeyFromScancontext(self, desc):
+        d = np.ascontiguousarray(desc, dtype=np.float64).reshape(-1)
+        out = np.empty(60, dtype=np.float64)
+        check(self._L.rsx_sc_make_keys(self._h, d.ctypes.data, None, out.ctypes.data))
+        return out
+
+    def distDirectSC(self, sc1, sc2):
+        a = np.ascontiguousarray(sc1, dtype=np.float64).reshape(-1)
+        b = np.ascontiguousarray(sc2, dtype=np.float64).reshape(-1)
+        d = C.c_double()
+        check(self._L.rsx_sc_dist_direct(self._h, a.ctypes.data, b.ctypes.data, C.byref(d)))
+        return d.value
+
+    def fastAlignUsingVkey(self, vkey1, vkey2):
+        a = np.ascontiguousarray(vkey1, dtype=np.float64).reshape(-1)
+        b = np.ascontiguousarray(vkey2, dtype=np.float64).reshape(-1)
+        k = C.c_int32()
+        check(self._L.rsx_sc_fast_align(self._h, a.ctypes.data, b.ctypes.data, C.byref(k)))
+        return k.value
+
+    def distanceBtnScanContext(self, sc1, sc2):
+        a = np.ascontiguousarray(sc1, dtype=np.float64).reshape(-1)
+        b = np.ascontiguousarray(sc2, dtype=np.float64).reshape(-1)
+        d, k = C.c_double(), C.c_int32()
+        check(self._L.rsx_sc_distance(self._h, a.ctypes.data, b.ctypes.data, C.byref(d), C.byref(k)))
+        return d.value, k.value
+
+    def detect_ex(self, mode=MODE_CANDIDATE):
+        """-> _rsx.ScDetection (everything of the reference's log line, one lock)."""
+        r = _rsx.ScDetection()
+        check(self._L.rsx_sc_detect_loop_closure_ex(self._h, mode, C.byref(r)))
+        return r
+
     def getConstRefRecentSCD(self):
         return self.descriptor(len(self) - 1)
 
@@ -246,6 +292,68 @@ class SCManager:
         lid, yaw = C.c_int32(), C.c_float()
         check(self._L.rsx_sc_hit_to_loop(self._h, h.ctypes.data, C.byref(lid), C.byref(yaw)))
         return lid.value, yaw.value
+
+
+class ShardedSet:
+    """rsx_scs_*: ONE process, the database sharded over several GPUs (keyframe i on devices[i % n]); the exchanges
+    of the two-stage query are peer copies.  What a single C++ host (alaserPGO) uses instead of torch.distributed."""
+
+    def __init__(self, devices, sc_dist_thres=0.2, capacity_hint=1024):
+        L = lib()
+        p = _rsx.ScParams()
+        check(L.rsx_sc_default_params(C.byref(p)))
+        p.dist_thres = sc_dist_thres
+        p.capacity_hint = capacity_hint
+        dev = (C.c_int32 * len(devices))(*devices)
+        self._h = C.c_void_p()
+        self._L = L
+        check(L.rsx_scs_create(C.byref(p), dev, len(devices), C.byref(self._h)))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._L.rsx_scs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_shards(self):
+        return self._L.rsx_scs_num_shards(self._h)
+
+    def __len__(self):
+        n = C.c_int64()
+        check(self._L.rsx_scs_size(self._h, C.byref(n)))
+        return n.value
+
+    def makeAndSaveScancontextAndKeys(self, scan_down):
+        pts = np.ascontiguousarray(scan_down, dtype=np.float32)
+        idx = C.c_int32()
+        check(self._L.rsx_scs_add_points(self._h, pts.ctypes.data, pts.shape[0], pts.shape[1] * 4, C.byref(idx)))
+        return idx.value
+
+    def add_descriptors_f32(self, descs):
+        d = np.ascontiguousarray(descs, dtype=np.float32).reshape(-1, 1200)
+        check(self._L.rsx_scs_add_descriptors_f32(self._h, d.ctypes.data, d.shape[0]))
+
+    def descriptor(self, i):
+        out = np.empty(1200, dtype=np.float64)
+        check(self._L.rsx_scs_get_descriptor(self._h, i, out.ctypes.data))
+        return out
+
+    def query(self, q_descs, k=1, n_eligible=-1):
+        q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
+        out = np.zeros((q.shape[0], k), dtype=HIT_DTYPE)
+        check(self._L.rsx_scs_query(self._h, q.ctypes.data, q.shape[0], k, n_eligible, out.ctypes.data))
+        return out
+
+    def detect(self):
+        r = _rsx.ScDetection()
+        check(self._L.rsx_scs_detect_loop_closure(self._h, C.byref(r)))
+        return r
 
 
 def merge_topk(parts, k=None):

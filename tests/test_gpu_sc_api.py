@@ -1,0 +1,136 @@
+"""C-ABI entry points added in round 2: the reference's public helper methods as GPU calls, the detection record,
+rounded import, bulk export, the on-disk database and the single-process multi-device handle (rsx_scs_*)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from navtech_radar_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    from navtech_radar_slam_amd import _rsx, scancontext
+    assert _rsx.device_count() >= 1
+    return scancontext
+
+
+def test_public_helpers_match_oracle_on_arbitrary_doubles(sc, oracle):
+    """Scancontext.h:60-66 through rsx_sc_make_* / rsx_sc_dist_direct / rsx_sc_fast_align / rsx_sc_distance:
+    bit-identical to the oracle (== the reference build) on built descriptors, on arbitrary fp32 values and on full
+    doubles that no fp32 database could hold."""
+    g = sc.SCManager()
+    rng = np.random.default_rng(4)
+    clouds, _ = synth.keyframe_clouds(8, 10, binary_z=False, loop_frac=0.4, min_gap=2, n_points=600)
+    built = [oracle.make_scancontext(c) for c in clouds]
+    for c, d in zip(clouds, built):
+        assert np.array_equal(g.makeScancontext(c), d)
+    sets = [np.stack(built), synth.random_descriptors(3, 8, binary=True).astype(np.float64), rng.normal(0, 1, (8, 1200))]
+    sets[1][2].reshape(60, 20)[5:30] = 0
+    sets[1][3][:] = 0
+    for D in sets:
+        for i in range(len(D)):
+            assert np.array_equal(g.makeRingkeyFromScancontext(D[i]), oracle.ringkey(D[i]))
+            assert np.array_equal(g.makeSectorkeyFromScancontext(D[i]), oracle.sectorkey(D[i]))
+            for j in range(len(D)):
+                a, b = g.distDirectSC(D[i], D[j]), oracle.dist_direct(D[i], D[j])
+                assert a == b or (np.isnan(a) and np.isnan(b))
+                assert g.fastAlignUsingVkey(oracle.sectorkey(D[i]), oracle.sectorkey(D[j])) == \
+                    oracle.fast_align(oracle.sectorkey(D[i]), oracle.sectorkey(D[j]))
+                assert g.distanceBtnScanContext(D[i], D[j]) == oracle.distance(D[i], D[j], literal=True)
+    g.close()
+
+
+def test_detect_ex_and_rounded_import(sc, oracle):
+    g = sc.SCManager(sc_dist_thres=0.45)
+    o = oracle.Manager(dist_thres=0.45)
+    clouds, _ = synth.keyframe_clouds(12, 70, binary_z=True, loop_frac=0.3, min_gap=35, n_points=400)
+    for i, c in enumerate(clouds):
+        g.makeAndSaveScancontextAndKeys(c)
+        o.add_points(c)
+        r = g.detect_ex()
+        want = o.detect_loop_closure()
+        assert r.query_idx == i and r.searched == (1 if i >= 30 else 0) and r.dist_thres == 0.45
+        assert (r.loop_id, r.yaw_diff_rad, r.min_dist, r.nn_idx) == want
+    # arbitrary doubles: the strict entry refuses, the rounded one reports the rounding
+    d = np.random.default_rng(0).uniform(0, 5, 1200)
+    from navtech_radar_slam_amd._rsx import RsxError
+    with pytest.raises(RsxError):
+        g.saveScancontextAndKeys(d)
+    idx, err = g.saveScancontextAndKeysRounded(d)
+    assert idx == 70 and 0 < err <= np.abs(d - d.astype(np.float32)).max() + 1e-30
+    assert np.array_equal(g.descriptor(70), d.astype(np.float32).astype(np.float64))
+    d[5] = np.nan
+    with pytest.raises(RsxError):
+        g.saveScancontextAndKeysRounded(d)
+    g.close()
+
+
+def test_export_save_load_roundtrip(sc, oracle, tmp_path):
+    descs = synth.random_descriptors(77, 301, binary=False)
+    g = sc.SCManager()
+    g.add_descriptors_f32(descs)
+    assert np.array_equal(g.export_descriptors_f32(), descs)
+    assert np.array_equal(g.export_descriptors_f32(17, 40), descs[17:57])
+    path = str(tmp_path / "db.rsxscdb")
+    g.save(path)
+    raw = open(path, "rb").read()
+    assert raw[:8] == b"RSXSCDB1" and len(raw) == 64 + 301 * 4800
+    q = descs[[5, 250]]
+    want = g.query(q, k=4)
+    # unsharded file -> fresh handle, and -> two shard handles (each keeps its residue class)
+    g2 = sc.SCManager()
+    assert g2.load(path) == 301 and len(g2) == 301
+    assert np.array_equal(g2.query(q, k=4), want)
+    assert np.array_equal(g2.sectorkey(123), g.sectorkey(123)) and np.array_equal(g2.ringkey(300), g.ringkey(300))
+    parts = []
+    for r in range(2):
+        s = sc.SCManager(shard_rank=r, shard_world=2)
+        s.load(path)
+        assert s.local_size == len(range(r, 301, 2))
+        parts.append(s.query(q, k=4))
+        # a shard file restores exactly that shard
+        sp = str(tmp_path / f"shard{r}.rsxscdb")
+        s.save(sp)
+        s2 = sc.SCManager(shard_rank=r, shard_world=2)
+        s2.load(sp)
+        assert len(s2) == 301 and np.array_equal(s2.query(q, k=4), parts[-1])
+        from navtech_radar_slam_amd._rsx import RsxError
+        with pytest.raises(RsxError):
+            sc.SCManager(shard_rank=1 - r, shard_world=2).load(sp)
+    assert np.array_equal(sc.merge_topk(np.stack(parts)), want)
+    from navtech_radar_slam_amd._rsx import RsxError
+    bad = tmp_path / "bad.rsxscdb"
+    bad.write_bytes(raw[:1000])
+    with pytest.raises(RsxError):
+        sc.SCManager().load(str(bad))
+
+
+@pytest.mark.parametrize("shards", [2, 5])
+def test_single_process_multi_device_handle(sc, oracle, shards):
+    """rsx_scs_*: G shard handles driven by one process (here all on device 0), peer-copy exchanges; queries and the
+    exhaustive detector equal the oracle / the unsharded handle."""
+    from navtech_radar_slam_amd._rsx import HIT_DTYPE
+    descs = synth.random_descriptors(5, 2600, binary=True)
+    rng = np.random.default_rng(6)
+    q = np.stack([synth.rotate_descriptor(descs[i], int(rng.integers(0, 60))) for i in rng.integers(0, 2500, 40)])
+    q[3][:] = 0
+    hs = sc.ShardedSet([0] * shards)
+    hs.add_descriptors_f32(descs[:1000])
+    hs.add_descriptors_f32(descs[1000:])
+    assert len(hs) == 2600 and hs.num_shards == shards
+    one = sc.SCManager()
+    one.add_descriptors_f32(descs)
+    for k, ne in ((10, 2570), (1, -1), (32, 40), (3, 0)):
+        got = hs.query(q, k=k, n_eligible=ne)
+        assert got.dtype == HIT_DTYPE and np.array_equal(got, one.query(q, k=k, n_eligible=ne)), (k, ne)
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    got = hs.query(q[:6], k=5, n_eligible=2570)
+    for i in range(6):
+        assert np.array_equal(got[i], o.exhaustive(q[i].astype(np.float64), n_eligible=2570, k=5))
+    assert np.array_equal(hs.descriptor(1234), descs[1234].astype(np.float64))
+    hs.close()
+    one.close()
