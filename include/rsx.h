@@ -270,6 +270,8 @@ int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms);
 /* while profiling is enabled the exact re-scoring kernel also counts its work: exact (fp64) pair evaluations and
  * (query, launch) pairs that scored at least one candidate, since the last read (device-synchronising) */
 int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored);
+/* the same plus the number of candidates that went through the cheap phase (alignment + fp32 preview) */
+int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored);
 
 /* ============================== ORORA registration ======================================
  * Replaces the solver stage of the upstream file-based `odometry.cpp` entry (reference

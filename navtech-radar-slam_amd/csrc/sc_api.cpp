@@ -53,7 +53,7 @@ struct rsx_sc {
   } st;
   DevBuf st_partial;  // this shard's stage-1 hits
   DevBuf helper_ws;   // staging of the stateless helper calls (Scancontext.h:60-66)
-  DevBuf stats;       // 2 x u64 (profiling only): exact pair evaluations, queries that scored any candidate
+  DevBuf stats;       // 3 x u64 (profiling only): candidates scored, queries that scored any, exact window evaluations
   void *pinned = nullptr;  // small pinned host staging (results)
   size_t pinned_bytes = 0;
 };
@@ -283,12 +283,15 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     q.norm = qv.norm + b0 * NS;
     q.nq = bn;
     const int64_t *elig = d_q_elig ? d_q_elig + b0 : nullptr;
-    // size of the first re-scoring round (scored with tau = +inf); later rounds double.  Measured on MI355X
-    // (10k DB, 8192 queries): 64 -> 5.48 ms per step, 32 -> 5.53, 16 -> 5.68
+    // size of the first re-scoring round; later rounds double.  With the two-phase scoring (every candidate of a round
+    // gets the cheap alignment + fp32 preview, only the few the previews cannot exclude are evaluated exactly) a round
+    // costs more in barriers than in arithmetic, so the first one is large: measured on MI355X (10k trajectory DB, 8192
+    // queries, ms per step / exact evaluations per query): 64 -> 4.24 / 11.2, 128 -> 4.18 / 10.4; the one-pass scoring of
+    // round 1 (RSX_SC_TWO_PHASE=0: first round scored exactly, 96 evaluations per query) 4.0 with 64
     static const int32_t first_target = [] {
       const char *e = getenv("RSX_SC_FIRST_TARGET");
       const int v = e ? atoi(e) : 0;
-      return (v >= 1 && v <= 128) ? v : 64;
+      return (v >= 1 && v <= 128) ? v : 128;
     }();
     RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, first_target, s, elig_monotone));
     // exact re-scoring: the 8-wave workgroup in rounds (sc_rescore_kernel; also what the sharded stages use), or
@@ -1104,8 +1107,8 @@ int rsx_sc_profile_enable(rsx_sc *h, int on) {
     for (int i = 0; i < 2 * PairProfiler::kMax; i++) RSX_HIP(hipEventCreate(&h->prof.ev[i]));
   }
   if (on) {
-    RSX_TRY(h->stats.reserve(16, h->stream, false));
-    RSX_HIP(hipMemsetAsync(h->stats.p, 0, 16, h->stream));
+    RSX_TRY(h->stats.reserve(32, h->stream, false));
+    RSX_HIP(hipMemsetAsync(h->stats.p, 0, 32, h->stream));
     RSX_HIP(hipStreamSynchronize(h->stream));
   }
   h->prof.on = on != 0;
@@ -1114,17 +1117,24 @@ int rsx_sc_profile_enable(rsx_sc *h, int on) {
 }
 
 int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored) {
-  if (!h || !exact_evals || !queries_rescored) return fail(RSX_ERR_BAD_ARG, "null arg");
+  int64_t cands = 0;
+  return rsx_sc_profile_read_rescoring2(h, &cands, exact_evals, queries_rescored);
+}
+
+int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored) {
+  if (!h || !candidates || !exact_evals || !queries_rescored) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
+  *candidates = 0;
   *exact_evals = 0;
   *queries_rescored = 0;
   if (!h->stats.p) return RSX_OK;
   RSX_HIP(hipDeviceSynchronize());  // the counters are bumped by kernels on the caller's stream
-  unsigned long long v[2] = {0, 0};
-  RSX_HIP(hipMemcpy(v, h->stats.p, 16, hipMemcpyDeviceToHost));
-  RSX_HIP(hipMemset(h->stats.p, 0, 16));
-  *exact_evals = (int64_t)v[0];
+  unsigned long long v[4] = {0, 0, 0, 0};
+  RSX_HIP(hipMemcpy(v, h->stats.p, 32, hipMemcpyDeviceToHost));
+  RSX_HIP(hipMemset(h->stats.p, 0, 32));
+  *candidates = (int64_t)v[0];
+  *exact_evals = v[2] ? (int64_t)v[2] : (int64_t)v[0];  // one-pass scoring: every candidate is an exact evaluation
   *queries_rescored = (int64_t)v[1];
   return RSX_OK;
 }

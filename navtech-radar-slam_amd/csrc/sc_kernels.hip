@@ -191,7 +191,9 @@ constexpr int OFF_WAVES = OFF_QV1 + 512;         // 11584
 // [1e-15, 1e15]"; lives behind the per-wave region of the kernels that use it
 constexpr int QP_COL_STRIDE = NR * 4;            // 80
 constexpr int QP_FLAG = NS * QP_COL_STRIDE;      // 4800
-constexpr int QP_SIZE = QP_FLAG + 16;
+constexpr int QP_MASK = QP_FLAG + 8;             // 4808: bit c = query column c is non-empty (norm != 0)
+constexpr int QP_V1F = QP_FLAG + 16;             // 4816: the query's sector key in fp32 (fast alignment, 240 B)
+constexpr int QP_SIZE = QP_V1F + NS * 4;         // 5056
 // per entry: the sector key twice in a row (vk2[e] = v[e % 60], 120 doubles) for the rotated reads of
 // stage 1, in TWO images -- A at element offset 0, B shifted by one element -- so that every lane can
 // fetch two consecutive elements with ONE 16-byte-aligned ds_read_b128 (the compiler otherwise pairs
@@ -256,6 +258,34 @@ __device__ __forceinline__ float wave_sum_f32(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+__device__ __forceinline__ float wave_min_f32(float v) {
+  v = fminf(v, dpp_f32<0xB1, 0xf>(v));
+  v = fminf(v, dpp_f32<0x4E, 0xf>(v));
+  v = fminf(v, dpp_f32<0x141, 0xf>(v));
+  v = fminf(v, dpp_f32<0x140, 0xf>(v));
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return fminf(fminf(r0, r1), fminf(r2, r3));
+}
+
+// FAST alignment (sc_rescore_kernel): fastAlignUsingVkey asks for the FIRST strict minimum over the 60 shifts of a
+// 60-term fp64 sum.  The 60 sums are first evaluated in fp32 (15 x ds_read_b128 + 4 packed VALU per lane instead of
+// 30 x 2 reads + 180 fp64 operations).  With E = ||v1||^2 + ||v2||^2, every fp32 value D~[k] is within
+//   eps_D = 129.3 * 2^-24 * E  (conversion + subtraction rounding 8.02 u E, 60 fused accumulations 121.3 u E)
+// of the real sum, the fp64 sums of the reference within 60 * 2^-53 of it, so every shift that can be the fp64
+// minimum satisfies D~[k] <= min D~ + 2 eps_D.  When exactly one shift does, it IS the reference's argmin (its
+// norm is also < 1e7, checked on D~); otherwise -- exact ties between shifts are common for binary radar
+// descriptors, whose sector keys are multiples of 0.1 -- the exact fp64 stage below decides as before.  Non-finite
+// or huge values take the exact stage too.
+constexpr float kFastAlignEps = 1.6e-5f;  // > 2^-16.5 = 129.3 * 2^-24 * 1.04, on E evaluated in fp32
+// four images of the entry's key in fp32, image j displaced by j elements (img_j[t] = vk2[t + j], vk2[e] = v[e % 60])
+// so that lane k reads vk2[60 - k + c .. + 3] with one aligned ds_read_b128 from image (-k) mod 4; the bases (in
+// 16-byte slots: 0, 37, 73, 109 = 0, 5, 9, 13 mod 16) leave a single 2-way bank conflict over the four lane groups
+__host__ __device__ constexpr int fimg_base(int j) { return (j == 0 ? 0 : j == 1 ? 37 : j == 2 ? 73 : 109) * 16; }
+typedef float float2p __attribute__((ext_vector_type(2)));
+
 // PREVIEW (sc_walk_kernel): once the alignment k* is known, the 7 window distances are first evaluated
 // cheaply in fp32 -- dot products of the query's unit columns (fp32 image in LDS at smem + off_preview)
 // with the entry's raw fp32 column, scaled by 1/n2, summed by a wave reduction: no fp64 division, no
@@ -281,33 +311,92 @@ __device__ __forceinline__ void load_entry(const DbView &db, int64_t slot, int l
   r.n2 = db.norm[slot * NS + cl];
 }
 
-template <int B, bool PREVIEW = false>
+// cache touch of an entry this wave will score one candidate later: one dword per lane and array (60 lanes x 80 B
+// cover every line of the 4800-byte descriptor), results discarded -- brings the lines towards this XCD's L2 without
+// holding registers (requesting the real registers a candidate ahead costs 24 live VGPRs and spills)
+__device__ __forceinline__ void touch_entry(const DbView &db, int64_t slot, int lane) {
+  const int cl = lane < NS ? lane : 0;
+  const float *pd = db.desc + slot * DS + cl * NR;
+  const double *pk = db.vkey + slot * NS + cl, *pn = db.norm + slot * NS + cl;
+  int d0, d1, d2;
+  asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
+               : "=&v"(d0), "=&v"(d1), "=&v"(d2)
+               : "v"(pd), "v"(pk), "v"(pn)
+               : "memory");
+}
+
+template <int B, bool PREVIEW = false, bool FAST = false>
 __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, char *wsm, int lane,
                                            const int64_t (&eslot)[B], double &bd_out, int &bk_out,
                                            double tau_prune = INFINITY, int off_preview = 0,
-                                           const EntryRegs *pre = nullptr) {
+                                           const EntryRegs *pre = nullptr, float e1 = 0.0f) {
+  static_assert(!FAST || B == 1, "the fast alignment takes its decisions per wave: one entry per group");
   const int cl = lane < NS ? lane : 0;       // entry column owned in stage 2
   const int kk = lane < NS ? lane : NS - 1;  // shift owned in stage 1
   const double *v1 = reinterpret_cast<const double *>(smem + OFF_QV1);
   const double *qn1 = reinterpret_cast<const double *>(smem + OFF_QN1);
   float4 ecol[B][5];
-  double en2[B];
+  double en2[B], ev[B];
     wave_lds_fence();
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      double v;
       if (pre) {
-        v = pre[b].v;
+        ev[b] = pre[b].v;
 #pragma unroll
         for (int i = 0; i < 5; i++) ecol[b][i] = pre[b].ecol[i];
         en2[b] = pre[b].n2;
       } else {
-        v = db.vkey[eslot[b] * NS + cl];
+        ev[b] = db.vkey[eslot[b] * NS + cl];
         const float4 *src = reinterpret_cast<const float4 *>(db.desc + eslot[b] * DS + cl * NR);
 #pragma unroll
         for (int i = 0; i < 5; i++) ecol[b][i] = src[i];
         en2[b] = db.norm[eslot[b] * NS + cl];
       }
+    }
+
+    int kstar[B];
+    bool need_exact = true;  // wave-uniform
+    if constexpr (FAST) {
+      const float vf = (float)ev[0];
+      if (lane < NS) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          float *img = reinterpret_cast<float *>(wsm + fimg_base(j));
+          if (lane >= j) img[lane - j] = vf;
+          img[lane + NS - j] = vf;
+          if (lane < j) img[lane + 2 * NS - j] = vf;
+        }
+      }
+      const float e2 = wave_sum_f32(lane < NS ? vf * vf : 0.0f);
+      wave_lds_fence();
+      const int j = (-kk) & 3;
+      const float4 *yp = reinterpret_cast<const float4 *>(wsm + fimg_base(j) + (NS - kk - j) * 4);
+      const float4 *xp = reinterpret_cast<const float4 *>(smem + off_preview + QP_V1F);
+      float2p a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+#pragma unroll
+      for (int i = 0; i < NS / 4; i++) {
+        const float4 x = xp[i], y = yp[i];
+        const float2p d0 = float2p{x.x, x.y} - float2p{y.x, y.y}, d1 = float2p{x.z, x.w} - float2p{y.z, y.w};
+        a0 = __builtin_elementwise_fma(d0, d0, a0);
+        a1 = __builtin_elementwise_fma(d1, d1, a1);
+      }
+      const float D = (a0[0] + a0[1]) + (a1[0] + a1[1]);
+      const float dmin = wave_min_f32(lane < NS ? D : INFINITY);  // fminf drops NaNs: they are caught by the ballot below
+      const float thr = dmin + 2.0f * kFastAlignEps * (e1 + e2);
+      const unsigned long long nan_bal = __ballot(lane < NS && !(D == D));
+      const unsigned long long cand = __ballot(lane < NS && D <= thr);
+      // dmin < 1e12: the winning norm is < 1e6 < the reference's 1e7 init (SC.cpp:96); thr finite: E finite
+      if (!nan_bal && dmin < 1e12f && thr < 3.0e38f && __popcll(cand) == 1) {
+        kstar[0] = __ffsll((long long)cand) - 1;
+        need_exact = false;
+      }
+      wave_lds_fence();  // the fp64 key images / similarity terms overwrite the fp32 images
+    }
+
+    if (need_exact) {
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const double v = ev[b];
       double *vka = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY_A);
       double *vkb = reinterpret_cast<double *>(wsm + b * ENT_SIZE + ENT_VKEY_B);
       if (lane < NS) {
@@ -354,7 +443,6 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
         }
       }
     }
-    int kstar[B];
 #pragma unroll
     for (int b = 0; b < B; b++) {
       double nrm = sqrt((acc[b][0] + acc[b][2]) + (acc[b][1] + acc[b][3]));  // SC.cpp:105 norm()
@@ -365,6 +453,7 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
       unsigned long long bal = __ballot(ok && nrm == m);
       kstar[b] = bal ? (__ffsll((long long)bal) - 1) : 0;  // first strict minimum = lowest shift
     }
+    }  // need_exact
 
     if constexpr (PREVIEW) {
       if (tau_prune < INFINITY && *reinterpret_cast<const int *>(smem + off_preview + QP_FLAG)) {  // wave-uniform
@@ -505,6 +594,258 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
     bk_out = bk;
 }
 
+// ------------------------------------------------------------------------------------------
+// The same pair function in two phases, one entry per wavefront (sc_rescore_kernel):
+//   phase A  alignment k* (fast fp32 form with exact fallback, see above) + the fp32 preview of the 7 window
+//            distances: a value pv with |pv - exact distance| <= kPreviewMargin -- cheap (~40 % of a full
+//            evaluation), and good for BOTH directions: pv - margin prunes, and the k-th smallest pv + margin over
+//            any set of entries is an upper bound of the final k-th best exact distance;
+//   phase B  the exact fp64 window evaluation (stages 2 and 3 of pair_group) for a known k*.
+// phase_a returns k*; pv = +inf when no shift of the window has an effective column (never a hit), NaN when no
+// preview is possible (norms outside [1e-15, 1e15], non-finite data): such an entry must go through phase B.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int phase_a(const char *smem, char *wsm, int lane, const EntryRegs &er, int off_preview,
+                                       float e1, float &pv) {
+  const int cl = lane < NS ? lane : 0;
+  const int kk = lane < NS ? lane : NS - 1;
+  const double *v1 = reinterpret_cast<const double *>(smem + OFF_QV1);
+  wave_lds_fence();
+  const double ev = er.v;
+  const float4 (&ecol)[5] = er.ecol;
+  const double n2 = er.n2;
+  int kstar = 0;
+  bool need_exact = true;
+  {
+    const float vf = (float)ev;
+    if (lane < NS) {
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        float *img = reinterpret_cast<float *>(wsm + fimg_base(j));
+        if (lane >= j) img[lane - j] = vf;
+        img[lane + NS - j] = vf;
+        if (lane < j) img[lane + 2 * NS - j] = vf;
+      }
+    }
+    const float e2 = wave_sum_f32(lane < NS ? vf * vf : 0.0f);
+    wave_lds_fence();
+    const int j = (-kk) & 3;
+    const float4 *yp = reinterpret_cast<const float4 *>(wsm + fimg_base(j) + (NS - kk - j) * 4);
+    const float4 *xp = reinterpret_cast<const float4 *>(smem + off_preview + QP_V1F);
+    float2p a0 = {0.0f, 0.0f}, a1 = {0.0f, 0.0f};
+#pragma unroll 5
+    for (int i = 0; i < NS / 4; i++) {
+      const float4 x = xp[i], y = yp[i];
+      const float2p d0 = float2p{x.x, x.y} - float2p{y.x, y.y}, d1 = float2p{x.z, x.w} - float2p{y.z, y.w};
+      a0 = __builtin_elementwise_fma(d0, d0, a0);
+      a1 = __builtin_elementwise_fma(d1, d1, a1);
+    }
+    const float D = (a0[0] + a0[1]) + (a1[0] + a1[1]);
+    const float dmin = wave_min_f32(lane < NS ? D : INFINITY);
+    const float thr = dmin + 2.0f * kFastAlignEps * (e1 + e2);
+    const unsigned long long nan_bal = __ballot(lane < NS && !(D == D));
+    const unsigned long long cand = __ballot(lane < NS && D <= thr);
+    if (!nan_bal && dmin < 1e12f && thr < 3.0e38f && __popcll(cand) == 1) {
+      kstar = __ffsll((long long)cand) - 1;
+      need_exact = false;
+    }
+    wave_lds_fence();
+  }
+  if (need_exact) {  // exact stage 1 of pair_group (SC.cpp:93-113), B = 1
+    double *vka = reinterpret_cast<double *>(wsm + ENT_VKEY_A);
+    double *vkb = reinterpret_cast<double *>(wsm + ENT_VKEY_B);
+    if (lane < NS) {
+      vka[lane] = ev;
+      vka[lane + NS] = ev;
+      vkb[lane + 1] = ev;
+      vkb[lane + NS + 1] = ev;
+    }
+    wave_lds_fence();
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const int eoff = (kk & 1) ? (ENT_VKEY_B + (NS + 1 - kk) * 8) : (ENT_VKEY_A + (NS - kk) * 8);
+    const double2 *v2 = reinterpret_cast<const double2 *>(wsm + eoff);
+    const double2 *v1p = reinterpret_cast<const double2 *>(v1);
+#pragma unroll 1
+    for (int c0 = 0; c0 < NS / 2; c0 += 6) {
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) {
+        const double2 x = v1p[c0 + cc], y = v2[c0 + cc];
+        const double d0 = x.x - y.x;
+        const double dd0 = d0 * d0;
+        acc[2 * (cc & 1)] = acc[2 * (cc & 1)] + dd0;
+        const double d1 = x.y - y.y;
+        const double dd1 = d1 * d1;
+        acc[2 * (cc & 1) + 1] = acc[2 * (cc & 1) + 1] + dd1;
+      }
+    }
+    const double nrm = sqrt((acc[0] + acc[2]) + (acc[1] + acc[3]));
+    const bool ok = (lane < NS) && (nrm < kBig);
+    double m = ok ? nrm : INFINITY;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+    const unsigned long long bal = __ballot(ok && nrm == m);
+    kstar = bal ? (__ffsll((long long)bal) - 1) : 0;
+    wave_lds_fence();
+  }
+  // fp32 preview of the window distances (see PREVIEW above), arranged for few instructions: the query's unit
+  // columns are 0 for an empty column and r2 is 0 for an empty entry column, so no per-lane validity select is
+  // needed; the effective-column counts come from the two 60-bit column masks on the scalar unit; the seven lane
+  // sums are taken by ONE halving butterfly (lane L ends up with the sum of shift L & 7) instead of seven reductions
+  pv = __builtin_nanf("");
+  if (*reinterpret_cast<const int *>(smem + off_preview + QP_FLAG)) {  // wave-uniform
+    const bool n2_ok = (n2 == 0.0) || (n2 >= 1e-15 && n2 <= 1e15);
+    if (!__ballot(!n2_ok && lane < NS)) {
+      const float r2 = (n2 == 0.0 || lane >= NS) ? 0.0f : (float)(1.0 / n2);
+      const unsigned long long me = __ballot(lane < NS && n2 != 0.0);
+      const unsigned long long mq = *reinterpret_cast<const unsigned long long *>(smem + off_preview + QP_MASK);
+      float p[8];
+      int k0 = kstar - 3;
+      k0 += (k0 < 0) ? NS : 0;
+      int k = k0;
+      int c = cl + k;
+      c -= (c >= NS) ? NS : 0;
+#pragma unroll
+      for (int t = 0; t < 7; t++) {
+        const float4 *qp = reinterpret_cast<const float4 *>(smem + off_preview + c * QP_COL_STRIDE);
+        float2p d0 = {0.0f, 0.0f}, d1 = {0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 5; i++) {
+          const float4 q4 = qp[i];
+          d0 = __builtin_elementwise_fma(float2p{q4.x, q4.y}, float2p{ecol[i].x, ecol[i].y}, d0);
+          d1 = __builtin_elementwise_fma(float2p{q4.z, q4.w}, float2p{ecol[i].z, ecol[i].w}, d1);
+        }
+        p[t] = ((d0[0] + d0[1]) + (d1[0] + d1[1])) * r2;
+        c = (c + 1 == NS) ? 0 : c + 1;
+      }
+      p[7] = 0.0f;
+      // halving butterfly: after the three steps lane L holds shift (L & 7) summed over its group of 8 lanes
+      const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4;
+      float q4v[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const float keep = b0 ? p[2 * i + 1] : p[2 * i], send = b0 ? p[2 * i] : p[2 * i + 1];
+        q4v[i] = keep + __shfl_xor(send, 1);
+      }
+      float q2v[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const float keep = b1 ? q4v[2 * i + 1] : q4v[2 * i], send = b1 ? q4v[2 * i] : q4v[2 * i + 1];
+        q2v[i] = keep + __shfl_xor(send, 2);
+      }
+      float sv;
+      {
+        const float keep = b2 ? q2v[1] : q2v[0], send = b2 ? q2v[0] : q2v[1];
+        sv = keep + __shfl_xor(send, 4);
+      }
+      sv += __shfl_xor(sv, 8);
+      sv += __shfl_xor(sv, 16);
+      sv += __shfl_xor(sv, 32);
+      // lane L: shift index (b0, b1, b2) -> t = (L & 1) + 2 * ((L >> 1) & 1) + 4 * ((L >> 2) & 1) = L & 7
+      float best = INFINITY;
+      bool broken = false;
+      k = k0;
+#pragma unroll
+      for (int t = 0; t < 7; t++) {
+        const float st = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sv), t));
+        // entry column j meets query column (j + k) % 60: bit j of the query mask rotated right by k (scalar unit)
+        const unsigned long long rq = ((mq >> k) | (mq << (NS - k))) & ((1ull << NS) - 1ull);
+        const int ne = __popcll(rq & me);
+        k = (k + 1 == NS) ? 0 : k + 1;
+        if (ne != 0) {  // uniform; ne == 0: no effective column at this shift, ignored like SC.cpp:87-88,134
+          const float d = 1.0f - st * __builtin_amdgcn_rcpf((float)ne);
+          if (!(d == d)) broken = true;  // non-finite data
+          best = fminf(best, d);
+        }
+      }
+      if (!broken) pv = best;  // +inf: no effective column at any shift of the window
+    }
+  }
+  return kstar;
+}
+
+// phase B: distDirectSC over the window of a known k* (stages 2 and 3 of pair_group, B = 1).  Every lane returns
+// (bd, bk) = (distance, shift), {1e7, 0} when no shift of the window has an effective column.
+__device__ __forceinline__ void phase_b(const char *smem, char *wsm, int lane, const EntryRegs &er, int ks, double &bd_out,
+                                        int &bk_out) {
+  const int cl = lane < NS ? lane : 0;
+  const double *qn1 = reinterpret_cast<const double *>(smem + OFF_QN1);
+  wave_lds_fence();
+  double e[NR];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const float4 v = er.ecol[i];
+    e[4 * i + 0] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
+  }
+  const double n2 = er.n2;
+  double *simp = reinterpret_cast<double *>(wsm + ENT_SIM);
+  int *misc = reinterpret_cast<int *>(wsm + ENT_MISC);
+#pragma unroll
+  for (int t = 0; t < 7; t++) {
+    int k = ks + t - 3;
+    k += (k < 0) ? NS : 0;
+    k -= (k >= NS) ? NS : 0;
+    int c = cl + k;
+    c -= (c >= NS) ? NS : 0;
+    const double2 *qp = reinterpret_cast<const double2 *>(smem + OFF_QIMG + c * Q_COL_STRIDE);
+    double da[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+      const double2 q2 = qp[i];
+      da[2 * (i & 1)] = fma(q2.x, e[2 * i + 0], da[2 * (i & 1)]);
+      da[2 * (i & 1) + 1] = fma(q2.y, e[2 * i + 1], da[2 * (i & 1) + 1]);
+    }
+    const double dot = (da[0] + da[2]) + (da[1] + da[3]);
+    const double n1 = qn1[c];
+    const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));
+    const double s = dot / (n1 * n2);
+    if (lane < NS) simp[t * NS + c] = valid ? s : 0.0;
+    const int ne = __popcll(__ballot(valid));
+    if (lane == 0) misc[t] = ne;
+  }
+  wave_lds_fence();
+  const int tt = lane & 7;
+  double bd = INFINITY;
+  int bk = 0x7fffffff;
+  if (lane < 8 && tt < 7) {
+    const double2 *sp = reinterpret_cast<const double2 *>(wsm + ENT_SIM + tt * (NS * 8));
+    double s = 0.0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < NS / 2; c0 += 6) {
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) {
+        const double2 v = sp[c0 + cc];
+        s = s + v.x;
+        s = s + v.y;
+      }
+    }
+    const int ne = misc[tt];
+    const double d = 1.0 - s / (double)ne;
+    int k = ks + tt - 3;
+    k += (k < 0) ? NS : 0;
+    k -= (k >= NS) ? NS : 0;
+    if (d < kBig) {
+      bd = d;
+      bk = k;
+    }
+  }
+#pragma unroll
+  for (int off = 1; off <= 4; off <<= 1) {
+    const double od = __shfl_xor(bd, off);
+    const int ok = __shfl_xor(bk, off);
+    if (hit_before(od, ok, bd, bk)) {
+      bd = od;
+      bk = ok;
+    }
+  }
+  bd = __shfl(bd, 0);
+  bk = __shfl(bk, 0);
+  if (bd == INFINITY) {
+    bd = kBig;
+    bk = 0;
+  }
+  bd_out = bd;
+  bk_out = bk;
+}
+
 // query -> LDS (once per block): fp64 image (column stride Q_COL_STRIDE), norms, sector key
 // off_preview >= 0: also the fp32 unit-column image of the pruning preview at smem + off_preview
 __device__ __forceinline__ void load_query_to_lds(const QueryView &q, int qi, char *smem, int tid, int nthreads,
@@ -523,6 +864,11 @@ __device__ __forceinline__ void load_query_to_lds(const QueryView &q, int qi, ch
     }
     // (called by whole waves) any bad column in this wave's share clears the flag; the caller zero-fills it first
     if (__ballot(bad)) *reinterpret_cast<int *>(smem + off_preview + QP_FLAG) = 0;
+    if (tid < NS) reinterpret_cast<float *>(smem + off_preview + QP_V1F)[tid] = (float)q.vkey[(int64_t)qi * NS + tid];
+    if (tid < 64) {  // (whole first wave) column mask of the query
+      const unsigned long long m = __ballot(tid < NS && q.norm[(int64_t)qi * NS + (tid < NS ? tid : 0)] != 0.0);
+      if (tid == 0) *reinterpret_cast<unsigned long long *>(smem + off_preview + QP_MASK) = m;
+    }
   }
   for (int i = tid; i < DS; i += nthreads) {
     const int c = i / NR, r = i - c * NR;
@@ -760,7 +1106,9 @@ __global__ __launch_bounds__(1024) void sc_knn_kernel(const float *__restrict__ 
 // range cannot reach the top-k; entries beyond the short list (bound >= t_cap) are only scanned when
 // tau still admits them.  Output: the final top-k, sorted by (dist, global index), padded {1e7,0,0}.
 // ------------------------------------------------------------------------------------------
-constexpr int RS_CAND_CAP = RESCORE_SHORTLIST_CAP;  // 2048
+constexpr int RS_CAND_CAP = 1024;  // candidates of one round (or chunk of a round) in LDS: slot | k* << 26, and their previews
+static_assert(RESCORE_SHORTLIST_CAP % RS_CAND_CAP == 0, "rounds are processed in chunks of RS_CAND_CAP list entries");
+constexpr int RS_SLOT_BITS = 26;   // local slots < 2^26 (64 M entries per shard) when the two-phase scoring is used
 #ifndef RSX_RESCORE_PREVIEW
 #define RSX_RESCORE_PREVIEW 1
 #endif
@@ -769,7 +1117,8 @@ constexpr bool kRescorePreview = RSX_RESCORE_PREVIEW != 0;
 template <int B, int RS_WAVES>
 struct RescoreLds {
   static constexpr int OFF_CAND = OFF_WAVES + RS_WAVES * B * ENT_SIZE;
-  static constexpr int OFF_XCH = OFF_CAND + RS_CAND_CAP * 4;                       // int32 candidate slots
+  static constexpr int OFF_PV = OFF_CAND + RS_CAND_CAP * 4;                        // int32 candidate slots (| k* << 26 after phase A)
+  static constexpr int OFF_XCH = OFF_PV + RS_CAND_CAP * 4;                         // fp32 previews of the candidates
   static constexpr int OFF_MISC = OFF_XCH + RS_WAVES * RSX_SC_MAX_TOPK * 16;       // per-wave top-k lists
   static constexpr int OFF_QP32 = OFF_MISC + 64;                                    // fp32 preview image of the query
   static constexpr int SIZE = OFF_QP32 + QP_SIZE;
@@ -791,7 +1140,9 @@ struct RescoreArgs {
   double eps;
   int32_t k;
   int32_t round_begin, round_end;  // rounds [begin, end) of the short list; end > RESCORE_NUM_THR: also the rest
-  unsigned long long *stats;       // optional (bench instrumentation): [0] += exact pair evaluations, [1] += queries that scored any
+  unsigned long long *stats;       // optional (bench instrumentation): [0] += candidates scored (phase A or full), [1] += queries
+                                   // that scored any, [2] += exact window evaluations (phase B; two-phase scoring only)
+  int32_t two_phase;               // B == 1: alignment + fp32 preview of every candidate first, exact evaluation of the few left
 };
 
 // k-th smallest valid record (by (dist, index)) of the nrec records in xch, by RANK COUNTING on one wave:
@@ -838,8 +1189,9 @@ __device__ __forceinline__ double wave_select_kth(const rsx_sc_hit *xch, int nre
 
 // RS_WAVES waves per workgroup, W = waves per SIMD the register allocator leaves room for (several
 // workgroups share a CU so that one query's barriers / merges hide behind another's scoring)
-template <int B, int RS_WAVES, int W>
+template <int B, int RS_WAVES, int W, bool TWO = false>
 __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArgs a) {
+  static_assert(!TWO || B == 1, "two-phase scoring handles one entry per wavefront");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = RescoreLds<B, RS_WAVES>;
   const int lane = threadIdx.x & 63;
@@ -905,7 +1257,73 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
       query_loaded = true;
     }
     scored_any = true;
+    // ||v1||^2 in fp32 for the error bound of the fast alignment (every wave for itself)
+    const float v1f = lane < NS ? reinterpret_cast<const float *>(smem + L::OFF_QP32 + QP_V1F)[lane] : 0.0f;
+    const float e1 = wave_sum_f32(v1f * v1f);
     const int ngroups = (ncand + B - 1) / B;
+    if constexpr (TWO) {
+      {
+        // ---- phase A: k* and the fp32 preview pv of every candidate; the k-th smallest (pv + margin) over this
+        // round's candidates and the exact hits known so far is an upper bound of the final k-th best distance ----
+        float *pvs = reinterpret_cast<float *>(smem + L::OFF_PV);
+        double ud = ld;  // this wave's exact hits so far + its candidates' preview upper bounds
+        int ui = li, us = ls;
+        // (requesting the next candidate's registers one candidate ahead was tried: 48 more live registers, one
+        // workgroup per CU fewer, 3 % slower -- four waves per SIMD already hide the entry loads)
+        EntryRegs cur;
+        for (int g = wave; g < ncand; g += RS_WAVES) {
+          const int64_t slot = cand[g];
+          const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
+          float pv = INFINITY;  // ineligible: never scored
+          int ks = 0;
+          if (gidx < n_elig) {
+            if (g + RS_WAVES < ncand) touch_entry(a.db, cand[g + RS_WAVES], lane);
+            load_entry(a.db, slot, lane, cur);
+            ks = phase_a(smem, wsm, lane, cur, L::OFF_QP32, e1, pv);
+            const bool usable = (pv == pv) && fabsf(pv) < 3.0e38f;  // NaN / -inf: no preview; +inf: never a hit
+            if (usable) topk_insert(ud, ui, us, lane, a.k, (double)pv + (double)kPreviewMargin, (int)gidx, 0);
+            if (!(pv == pv)) pv = -INFINITY;  // no preview: phase B must look at it
+          }
+          if (lane == 0) {
+            pvs[g] = pv;
+            cand[g] = (int32_t)slot | (ks << RS_SLOT_BITS);
+          }
+        }
+        if (lane < a.k) {
+          rsx_sc_hit h;
+          h.dist = ud; h.index = ui; h.shift = us;
+          xch[wave * a.k + lane] = h;
+        }
+        __syncthreads();
+        if (wave == 0) {
+          const double t = wave_select_kth(xch, RS_WAVES * a.k, a.k, lane, nullptr);
+          if (lane == 0) *s_tau = t < tau ? t : tau;  // tau: the exact bound carried in
+        }
+        __syncthreads();
+        const double tau_ub = *s_tau;
+        // (each wave using only its OWN k-th smallest upper bound saves the two barriers but quadruples the exact
+        // evaluations: 43 instead of 11 per query, 7.5 instead of 4.2 ms per step)
+        // ---- phase B: exact evaluation of the candidates the previews cannot exclude ----
+        for (int g = wave; g < ncand; g += RS_WAVES) {
+          const float pv = pvs[g];
+          // this wave's own k-th exact distance tightens the test as it goes
+          const double kth_local = __shfl(ld, a.k - 1);
+          const double t_eff = kth_local < tau_ub ? kth_local : tau_ub;
+          if ((double)pv - (double)kPreviewMargin > t_eff) continue;  // exact >= pv - margin > k-th best: not in the top-k
+          const int32_t packed = cand[g];
+          const int64_t slot = packed & ((1 << RS_SLOT_BITS) - 1);
+          load_entry(a.db, slot, lane, cur);
+          double bd;
+          int bk;
+          phase_b(smem, wsm, lane, cur, (packed >> RS_SLOT_BITS) & 63, bd, bk);
+          if (a.stats && lane == 0) atomicAdd(a.stats + 2, 1ull);
+          const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
+          if (bd < kBig) topk_insert(ld, li, ls, lane, a.k, bd, (int)gidx, bk);
+        }
+        __syncthreads();  // phase B of every wave is done with pvs / cand / xch before they are re-used
+      }
+    }
+    if constexpr (!TWO) {
     for (int g = wave; g < ngroups; g += RS_WAVES) {
       int64_t eslot[B];
       bool evalid[B];
@@ -919,7 +1337,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
       int bk;
       // tau is finite from the second round on: candidates then leave after the alignment + fp32 preview unless
       // they can still reach the top-k
-      pair_group<B, kRescorePreview>(a.db, smem, wsm, lane, eslot, bd, bk, tau, L::OFF_QP32);
+      pair_group<B, kRescorePreview, B == 1>(a.db, smem, wsm, lane, eslot, bd, bk, tau, L::OFF_QP32, nullptr, e1);
 #pragma unroll
       for (int b = 0; b < B; b++) {
         const double dist = __shfl(bd, b * 8);
@@ -928,6 +1346,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
         const int64_t gidx = a.db.idx_base + eslot[b] * a.db.idx_stride;
         if (gidx < n_elig && dist < kBig) topk_insert(ld, li, ls, lane, a.k, dist, (int)gidx, shift);
       }
+    }
     }
     if (lane < a.k) {
       rsx_sc_hit h;
@@ -957,7 +1376,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
 
   // ---- rounds over the short list ----
   const int sl_cnt = a.sl_cnt[qi];
-  const RescoreEntry *sl = a.slist + (int64_t)qi * RS_CAND_CAP;
+  const RescoreEntry *sl = a.slist + (int64_t)qi * RESCORE_SHORTLIST_CAP;
   const float *thr = a.thr + (int64_t)qi * RESCORE_THR_STRIDE;
   const int32_t *rcnt = reinterpret_cast<const int32_t *>(thr) + RESCORE_NUM_THR;
   const float t_cap = thr[RESCORE_NUM_THR - 1];
@@ -974,13 +1393,16 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
     // the short list is ordered by bin and the round edges are bin edges: round r is one contiguous range
     // (bin 0, first in the list, also holds the NaN / -inf "always re-score" bounds)
     const int i0 = r > 0 ? rcnt[r - 1] : 0, i1 = rcnt[r] < sl_cnt ? rcnt[r] : sl_cnt;
-    for (int i = i0 + threadIdx.x; i < i1; i += RS_WAVES * 64) {
-      const RescoreEntry e = sl[i];
-      append(!((double)e.lb - a.eps > tau), e.slot);
+    for (int c0 = i0; c0 < i1; c0 += RS_CAND_CAP) {  // (one chunk, unless a round is longer than the LDS candidate list)
+      const int c1 = c0 + RS_CAND_CAP < i1 ? c0 + RS_CAND_CAP : i1;
+      for (int i = c0 + threadIdx.x; i < c1; i += RS_WAVES * 64) {
+        const RescoreEntry e = sl[i];
+        append(!((double)e.lb - a.eps > tau), e.slot);
+      }
+      __syncthreads();
+      const int ncand = *s_ncand;
+      score_and_merge(ncand);
     }
-    __syncthreads();
-    const int ncand = *s_ncand;
-    score_and_merge(ncand);
     lo = hi;
     if ((double)lo - a.eps > tau) {  // every remaining bound is >= lo: nothing can reach the top-k
       done = true;
@@ -1233,7 +1655,7 @@ __global__ __launch_bounds__(64, 2) void sc_walk_kernel(RescoreArgs a) {
   // ---- the short list, ascending bin order; the registers of entry i+1 are requested before entry i is
   // scored, so their global-memory latency hides behind its arithmetic ----
   const int sl_cnt = a.sl_cnt[qi];
-  const RescoreEntry *sl = a.slist + (int64_t)qi * RS_CAND_CAP;
+  const RescoreEntry *sl = a.slist + (int64_t)qi * RESCORE_SHORTLIST_CAP;
   const float t_cap = a.thr[(int64_t)qi * RESCORE_THR_STRIDE + (RESCORE_NUM_THR - 1)];
   bool done = false;
   for (int base = 0; base < sl_cnt && !done; base += 64) {
@@ -1322,16 +1744,16 @@ int launch_walk(const DbView &db, const QueryView &q, const float *lb, int64_t l
   return RSX_OK;
 }
 
-template <int B, int NW, int W>
+template <int B, int NW, int W, bool TWO = false>
 static int launch_rescore_t(const RescoreArgs &a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int lds = RescoreLds<B, NW>::SIZE;
   if (!attr_set) {
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<B, NW, W>),
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<B, NW, W, TWO>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((sc_rescore_kernel<B, NW, W>), dim3(a.q.nq), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((sc_rescore_kernel<B, NW, W, TWO>), dim3(a.q.nq), dim3(NW * 64), lds, s, a);
   return RSX_OK;
 }
 
@@ -1369,13 +1791,21 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
   a.round_begin = round_begin;
   a.round_end = round_end;
   a.stats = d_stats;
+  static const bool no_two_phase = [] {
+    const char *e = getenv("RSX_SC_TWO_PHASE");  // experiments: 0 = the one-pass scoring of round 1
+    return e && e[0] == '0';
+  }();
+  a.two_phase = (!no_two_phase && variant == 0 && n_items < (1ll << RS_SLOT_BITS)) ? 1 : 0;
   switch (variant) {
     case 1: RSX_TRY((launch_rescore_t<1, 16, 4>(a, s))); break;
     case 2: RSX_TRY((launch_rescore_t<2, 12, 3>(a, s))); break;
     case 3: RSX_TRY((launch_rescore_t<2, 6, 3>(a, s))); break;
     case 4: RSX_TRY((launch_rescore_t<1, 8, 4>(a, s))); break;
     case 5: RSX_TRY((launch_rescore_t<1, 6, 4>(a, s))); break;
-    default: RSX_TRY((launch_rescore_t<1, 4, 4>(a, s))); break;
+    default:
+      if (a.two_phase) RSX_TRY((launch_rescore_t<1, 4, 4, true>(a, s)));
+      else RSX_TRY((launch_rescore_t<1, 4, 4>(a, s)));
+      break;
   }
   RSX_HIP(hipGetLastError());
   return RSX_OK;

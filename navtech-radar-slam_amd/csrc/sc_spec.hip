@@ -341,12 +341,15 @@ struct TileDma {
   char *ldst;
   int nbytes;  // 0: nothing to load
 };
-// where the bounds of a tile go: row0 = &lb[first query of the tile][this lane's entry]
+// where the bounds of a tile go: a wave-uniform row base (&lb[first query of the tile][0], scalar registers) plus a
+// 32-bit per-lane byte offset -- a 64-bit per-lane address was spilled to scratch, and every scratch reload in the
+// tile loop is followed by s_waitcnt vmcnt(0): a full drain of the DMA pieces and bound stores in flight
 struct TileOut {
-  float *row0;
-  int64_t ld;
-  int nq_here;  // valid queries in the tile
-  bool n_ok;    // this lane's entry exists
+  char *rowbase;      // uniform
+  unsigned lane_off;  // (this lane's entry + (lane >= 32 ? ld : 0)) * 4: lanes 32..63 store the odd query of a pair
+  unsigned ld_bytes;  // uniform
+  int nq_here;        // valid queries in the tile
+  bool n_ok;          // this lane's entry exists
 };
 __device__ __forceinline__ int dma_pieces_of_wave(int nbytes, int wave) {
   const int npieces = (nbytes + 1023) >> 10;
@@ -432,7 +435,11 @@ constexpr int SP_S1 = SP_FRAGS;   // 76 stage-1 MFMA slots per tile
 #define SP_OPT_DEPTH 8
 #endif
 constexpr int SP_DEPTH = SP_OPT_DEPTH;  // A fragments in flight
-constexpr int SP_MREADS = 4;      // mask reads per query (2 M-tiles x 32 bytes)
+// per-query LDS reads of the tail: 4 mask reads (2 M-tiles x 32 bytes) + the query's {n_q, flags, sqrt n_q, sqrt a_q}
+// words.  ALL of them go through inline asm: a plain C++ LDS load after a global_load_lds makes the compiler insert
+// s_waitcnt vmcnt(0) (the DMA writes LDS, so it orders the load behind every outstanding VMEM operation) -- one full
+// drain of the just-issued DMA pieces and bound stores per query, ~1 k cycles each (found in the ISA in round 2)
+constexpr int SP_MREADS = 5;
 
 // Stage-1 slot schedule.  Two frequencies are always in progress and their MFMAs alternate, so that no MFMA
 // follows another one on the SAME accumulator with LDS reads / VALU instructions in between (that pattern
@@ -493,13 +500,12 @@ struct Recip {
   unsigned flags;
   float sqrt_nq, sqrt_aq;
 };
-__device__ __forceinline__ Recip recip_setup(const char *qbase, const SpecLane &ln) {
-  const uint4 tail = *reinterpret_cast<const uint4 *>(qbase + SP_TAIL);
+__device__ __forceinline__ Recip recip_setup(const frag4 &tail, const SpecLane &ln) {
   Recip r;
-  r.n_q = (int)tail.x;
-  r.flags = tail.y;
-  r.sqrt_nq = __uint_as_float(tail.z);
-  r.sqrt_aq = __uint_as_float(tail.w);
+  r.n_q = (int)tail[0];
+  r.flags = tail[1];
+  r.sqrt_nq = __uint_as_float(tail[2]);
+  r.sqrt_aq = __uint_as_float(tail[3]);
   const int li = (r.n_q + ln.n_e - NS > 1) ? (r.n_q + ln.n_e - NS) : 1;
   const int hmin = r.n_q < ln.n_e ? r.n_q : ln.n_e;
   const float L = (float)li, H = (float)(hmin > li ? hmin : li);
@@ -549,6 +555,13 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
   frag4 mk[SP_OPT_MK2 ? 2 : 1][SP_MREADS];  // mask bytes of the current (/ next) query
   const unsigned a_dc = tile_lds + ln.dc_off, a_f = tile_lds + ln.f_off;
   const unsigned a_m0 = tile_lds + ln.m_off[0], a_m1 = tile_lds + ln.m_off[1];
+  const unsigned a_tl = tile_lds + SP_TAIL;
+  // read r of query q's tail data: r < 4 mask bytes, r == 4 the {n_q, flags, sqrt n_q, sqrt a_q} words
+  auto q_read = [&](frag4 &dst, auto qc, auto rc) {
+    constexpr int q = decltype(qc)::value, r = decltype(rc)::value;
+    if constexpr (r < 4) lds_read_frag(dst, (r >> 1) ? a_m1 : a_m0, q * SP_QS + 16 * (r & 1));
+    else lds_read_frag(dst, a_tl, q * SP_QS);
+  };
   floatx16 z;
 #pragma unroll
   for (int i = 0; i < 16; i++) z[i] = 0.0f;
@@ -582,9 +595,9 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     else acc[f % kAccSets] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[f % kAccSets], 0, 0, 0);
     if constexpr (t + SP_DEPTH < SP_S1)
       lds_read_frag(ring[t % SP_DEPTH], kS1.slot[t + SP_DEPTH].f == 0 ? a_dc : a_f, s1_off(t + SP_DEPTH));
-    if constexpr (t >= SP_S1 - SP_MREADS) {  // mask bytes of query 0
+    if constexpr (t >= SP_S1 - SP_MREADS) {  // mask bytes + tail words of query 0
       constexpr int r = t - (SP_S1 - SP_MREADS);
-      lds_read_frag(mk[0][r], (r >> 1) ? a_m1 : a_m0, 16 * (r & 1));
+      q_read(mk[0][r], std::integral_constant<int, 0>{}, std::integral_constant<int, r>{});
     }
     if constexpr (t >= split_begin() && t < split_begin() + 8) {
       // C_0 as fp16 hi + lo: lanes 0..31 carry hi (k = 0), lanes 32..63 lo (k = 8); both weigh 1/16.  hi = C_0
@@ -621,29 +634,45 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     if constexpr (SP_OPT_MK2 && q + 1 < SP_QPT) {
       static_for<SP_MREADS>([&](auto rc) {
         constexpr int r = decltype(rc)::value;
-        lds_read_frag(mk[(q + 1) & 1][r], (r >> 1) ? a_m1 : a_m0, (q + 1) * SP_QS + 16 * (r & 1));
+        q_read(mk[(q + 1) & 1][r], std::integral_constant<int, q + 1>{}, rc);
       });
       lds_wait_count<SP_MREADS>();
     } else {
       lds_wait_count<0>();
     }
     __builtin_amdgcn_sched_barrier(0);
-    const Recip r = recip_setup(tbase + q * SP_QS, ln);
+    frag4 tailw = mk[cur][4];
+    asm volatile("" : "+v"(tailw));  // a value of its own: mk[cur][4] is re-loaded for the next query below
+    const Recip r = recip_setup(tailw, ln);
     dma_issue(dma, wave, lane, 3 * q, 3);  // <= 11 pieces per wave and tile
+    // A query whose 60 columns are all non-empty (the usual case for a radar scan) meets every entry with
+    // n_eff(k) = n_e at EVERY shift (SC.cpp:78: a column pair is skipped only if one of the two is empty), so
+    // [n_lo, n_hi] = {n_e}: no mask correlation, no u(n) -- max_k S_k u(n_k) = (max_k S_k) / n_e.  Wave-uniform.
+    const bool full_q = __builtin_amdgcn_readfirstlane(r.n_q) == NS;
     float m = 0.0f;  // rows 15..31 of the weight matrix are zero anyway (S >= 0 or clamped: valid)
     floatx16 nacc[2];
+    if (!full_q) {
 #pragma unroll
-    for (int mt = 0; mt < 2; mt++) {
-      const frag4 lo = mk[cur][2 * mt], hi = mk[cur][2 * mt + 1];
-      const u8v am = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      nacc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), ln.Bm, z, 0, 0, 0, 0, 0, 0);
+      for (int mt = 0; mt < 2; mt++) {
+        const frag4 lo = mk[cur][2 * mt], hi = mk[cur][2 * mt + 1];
+        const u8v am = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        nacc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), ln.Bm, z, 0, 0, 0, 0, 0, 0);
+      }
+    } else {
+      asm volatile("" ::"v"(mk[cur][0]), "v"(mk[cur][1]), "v"(mk[cur][2]), "v"(mk[cur][3]));  // landed (lgkmcnt(0) above); keeps the reads of both paths identical
     }
     if constexpr (!SP_OPT_MK2 && q + 1 < SP_QPT) {
-      static_for<SP_MREADS>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        lds_read_frag(mk[0][r], (r >> 1) ? a_m1 : a_m0, (q + 1) * SP_QS + 16 * (r & 1));
-      });
+      static_for<SP_MREADS>([&](auto rc) { q_read(mk[0][rc], std::integral_constant<int, q + 1>{}, rc); });
     }
+    if (full_q) {
+#pragma unroll
+      for (int k4 = 0; k4 < 4; k4++) {
+        const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[q * 4 + k4]), z, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);  // one v_max3_f32 per pair
+      }
+      m *= r.rL;  // rcp(n_lo) = rcp(n_e): within 1 ulp of 1 / n_e, covered by the (1 + 4e-6) factor below
+    } else {
     // u(n) of all 32 n_eff values of the query first (independent of stage 2), then per k4: S * u and the maximum;
     // written stage by stage over 4 independent pairs so that no packed instruction waits for the previous one
     float2v u2[4][4];
@@ -673,6 +702,7 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
 #pragma unroll
       for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, v2[e][0]), v2[e][1]);  // one v_max3_f32 per pair
     }
+    }
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
     const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));  // 15/16 max_k S_k u(n_k)
     // the error of S is divided by n_k >= n_lo
@@ -686,7 +716,8 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     if constexpr (q & 1) {
       const int qq = (q - 1) + ln.hh;
       const float vv = ln.hh ? out[q] : out[q - 1];
-      if (to.n_ok && qq < to.nq_here && !(kInstr && (dbg & 8) && vv != 12345.0f)) to.row0[(int64_t)qq * to.ld] = vv;
+      if (to.n_ok && qq < to.nq_here && !(kInstr && (dbg & 8) && vv != 12345.0f))
+        *reinterpret_cast<float *>(to.rowbase + (size_t)((unsigned)(q - 1) * to.ld_bytes) + to.lane_off) = vv;
     }
   });
 }
@@ -844,7 +875,8 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
         const char *tbase = smem + (p % SP_NBUF) * SP_PHASE_BYTES;
         float out[SP_QPT];
         spec_tile(lds_base + (unsigned)(tbase - smem), tbase, B, ln, a.eps_direct, out, a.dbg, prof ? &t2 : nullptr, dma, wave, lane,
-                  TileOut{a.lb + (int64_t)qp * a.ld_lb + n, a.ld_lb, nq_here, n_ok});
+                  TileOut{reinterpret_cast<char *>(a.lb + (int64_t)qp * a.ld_lb), (unsigned)(n * 4) + (unsigned)hh * (unsigned)(a.ld_lb * 4),
+                          (unsigned)(a.ld_lb * 4), nq_here, n_ok});
         if (prof) {
           asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]));
           t3 = prof_now();

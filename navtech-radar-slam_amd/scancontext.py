@@ -286,6 +286,12 @@ class SCManager:
         check(self._L.rsx_sc_profile_read_rescoring(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def profile_read_rescoring2(self):
+        """-> (candidates through alignment + preview, exact window evaluations, queries that scored any)."""
+        c, a, b = C.c_int64(), C.c_int64(), C.c_int64()
+        check(self._L.rsx_sc_profile_read_rescoring2(self._h, C.byref(c), C.byref(a), C.byref(b)))
+        return c.value, a.value, b.value
+
     def hit_to_loop(self, hit):
         h = np.zeros(1, dtype=HIT_DTYPE)
         h[0] = hit
