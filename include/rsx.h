@@ -289,8 +289,10 @@ typedef struct {
   double gnc_factor;             /* mu growth per GNC iteration (1.4) */
   double cost_threshold;         /* GNC stops when |cost - prev_cost| < this */
   int32_t max_iterations;        /* GNC iteration cap */
-  int32_t reserved;
+  int32_t flags;                 /* RSX_ORORA_*: the modelling choices the (absent) upstream source would pin */
 } rsx_orora_params;
+#define RSX_ORORA_COMPLETE_GRAPH 1 /* rotation TIMs on all K (K-1) / 2 pairs instead of the ring of K (O(K^2) per GNC iteration) */
+#define RSX_ORORA_TEASER_COST 2    /* scalar TLS cost in TEASER++'s form: unweighted residuals + sum of the outliers' bounds */
 
 typedef struct {
   double x, y, yaw;      /* dst = R(yaw) src + (x, y) */
@@ -298,7 +300,8 @@ typedef struct {
   int32_t rot_inliers;   /* TIMs with final weight >= 0.5 */
   int32_t trans_inliers; /* matches inside both axis intervals at the estimate */
   int32_t status;        /* 0 ok; 1 fewer than 2 matches (identity); 2 more than
-                            rsx_orora_max_correspondences() matches (identity) */
+                            rsx_orora_max_correspondences() = 16384 matches (identity).  Pairs of up to 2048 matches
+                            run on-chip (LDS), larger ones through an HBM workspace: same results */
 } rsx_orora_result;
 
 int rsx_orora_default_params(rsx_orora_params *p);

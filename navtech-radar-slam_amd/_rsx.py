@@ -52,12 +52,12 @@ class ScDetection(C.Structure):
 class OroraParams(C.Structure):
     _fields_ = [("tim_noise_bound", C.c_double), ("noise_bound_radial", C.c_double),
                 ("noise_bound_tangential", C.c_double), ("gnc_factor", C.c_double),
-                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("flags", C.c_int32)]
 
 
 class IcpParams(C.Structure):
     _fields_ = [("max_corr_dist", C.c_double), ("transformation_epsilon", C.c_double),
-                ("euclidean_fitness_epsilon", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+                ("euclidean_fitness_epsilon", C.c_double), ("max_iterations", C.c_int32), ("flags", C.c_int32)]
 
 
 class IcpResult(C.Structure):

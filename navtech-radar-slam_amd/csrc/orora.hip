@@ -1,6 +1,7 @@
 // orora.hip -- ORORA scan registration on gfx950: GNC-TLS rotation + A-COTE translation, one
 // 256-thread workgroup per scan pair, everything on-chip (points and the interval endpoints live in
-// LDS, TIMs and GNC weights in registers).
+// LDS, TIMs and GNC weights in registers); pairs of more than 2048 matches (up to 16384) go through the same
+// code with 1024 threads and the arrays in an HBM workspace.
 //
 // The reference's ORORA sources are an empty submodule (/root/reference/.gitmodules:1-3,
 // README.md:19,26-27,44-48), so this implements the published algorithm as restated in
@@ -21,16 +22,22 @@
 
 namespace {
 
-constexpr int MAXK = 2048;   // correspondences per pair handled on-chip
-constexpr int TPT = MAXK / 256;  // TIMs / points per thread
-constexpr int MAXE = 2 * MAXK;   // interval endpoints per axis
+// Two instantiations of the same kernel:
+//   on-chip   256 threads, pairs of <= 2048 matches: points, interval endpoints and scan partials in LDS (90 KB);
+//   large     1024 threads, pairs of 2049 .. 16384 matches (cen2019 can emit 10 000 keypoints per scan): the same
+//             arrays in a per-workgroup HBM workspace (L2-resident), a few persistent workgroups pulling the large
+//             pairs from a list.  Round 1 returned identity + status 2 for such a pair -- a silently lost scan pair.
+constexpr int MAXK_LDS = 2048;
+constexpr int MAXK_BIG = 16384;
 
 struct Params {
   double c2, s_r, s_t, gnc_factor, cost_threshold;
   int max_iterations;
+  int complete_graph;  // TIMs on all pairs i < j instead of the ring
+  int teaser_cost;     // scalar TLS cost: unweighted residuals + sum of the outliers' bounds
 };
 
-// ---- workgroup reductions (4 waves), deterministic order ----
+// ---- workgroup reductions, deterministic order ----
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -42,14 +49,18 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
+template <int NW>
 struct Red {
-  double *buf;  // 16 doubles of LDS
+  double *buf;  // 2 * NW doubles of LDS
   __device__ double sum(double v) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
     __syncthreads();
-    return (buf[0] + buf[1]) + (buf[2] + buf[3]);
+    double r = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) r += buf[w];
+    return r;
   }
   __device__ void sum2(double &a, double &b) {
     a = wave_sum(a);
@@ -57,18 +68,26 @@ struct Red {
     __syncthreads();
     if ((threadIdx.x & 63) == 0) {
       buf[threadIdx.x >> 6] = a;
-      buf[4 + (threadIdx.x >> 6)] = b;
+      buf[NW + (threadIdx.x >> 6)] = b;
     }
     __syncthreads();
-    a = (buf[0] + buf[1]) + (buf[2] + buf[3]);
-    b = (buf[4] + buf[5]) + (buf[6] + buf[7]);
+    a = 0.0;
+    b = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      a += buf[w];
+      b += buf[NW + w];
+    }
   }
   __device__ double max(double v) {
     v = wave_max(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) buf[threadIdx.x >> 6] = v;
     __syncthreads();
-    return fmax(fmax(buf[0], buf[1]), fmax(buf[2], buf[3]));
+    double r = buf[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) r = fmax(r, buf[w]);
+    return r;
   }
 };
 
@@ -88,17 +107,28 @@ __device__ __forceinline__ bool ep_less(double av, int ai, double bv, int bi) {
   return (av < bv) || (av == bv && ai < bi);
 }
 
-// Scalar TLS estimate over K intervals x[i] +- beta[i] held TPT per thread (point i = tid + t*256).
-// LDS: sx[MAXK], sb[MAXK] doubles, ev[MAXE] doubles, ei[MAXE] ints, part[6*256] doubles.
+// GNC weight of a TIM with squared residual r2
+__device__ __forceinline__ double gnc_weight(double r2, double mu, double c2) {
+  const double th1 = (mu + 1.0) / mu * c2, th2 = mu / (mu + 1.0) * c2;
+  if (r2 >= th1) return 0.0;
+  if (r2 <= th2) return 1.0;
+  return sqrt(c2 * mu * (mu + 1.0) / r2) - mu;
+}
+
+// Scalar TLS estimate over K intervals x[i] +- beta[i] held TPT per thread (point i = tid + t*NT).
+// sx[K], sb[K] doubles, ev[2K'] doubles, ei[2K'] ints, part[6*NT] doubles (LDS or the HBM workspace).
+template <int NT, int TPT>
 __device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[TPT], int K, double *sx, double *sb,
-                                   double *ev, int *ei, double *part, Red &red) {
+                                   double *ev, int *ei, double *part, int teaser_cost) {
+  constexpr int NW = NT / 64;
   const int tid = threadIdx.x;
-  int n2 = 512;
+  int n2 = 2 * NT;
   while (n2 < 2 * K) n2 <<= 1;
   __syncthreads();
+  double l_sr = 0.0;
 #pragma unroll
   for (int t = 0; t < TPT; t++) {
-    const int i = tid + t * 256;
+    const int i = tid + t * NT;
     if (i < K) {
       sx[i] = x[t];
       sb[i] = beta[t];
@@ -106,9 +136,10 @@ __device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[
       ei[2 * i] = i + 1;
       ev[2 * i + 1] = x[t] + beta[t];
       ei[2 * i + 1] = -i - 1;
+      l_sr += beta[t];
     }
   }
-  for (int e = 2 * K + tid; e < n2; e += 256) {
+  for (int e = 2 * K + tid; e < n2; e += NT) {
     ev[e] = INFINITY;
     ei[e] = 0x7fffffff;
   }
@@ -116,7 +147,7 @@ __device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[
   // bitonic sort, ascending by (value, id)
   for (int size = 2; size <= n2; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int p = tid; p < (n2 >> 1); p += 256) {
+      for (int p = tid; p < (n2 >> 1); p += NT) {
         const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
         const int hi = lo | stride;
         const bool up = (lo & size) == 0;
@@ -131,10 +162,11 @@ __device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[
       __syncthreads();
     }
   }
-  // sweep as a scan: each thread owns a contiguous chunk of E endpoints
-  const int E = n2 >> 8;
+  // sweep as a scan: each thread owns a contiguous chunk of E endpoints; six running sums
+  // (sum w, sum w x, sum w x^2 for the normalised cost; sum x, sum x^2, sum beta for TEASER++'s form) + cardinality
+  const int E = n2 / NT;
   const int e0 = tid * E;
-  double l_sw = 0, l_swx = 0, l_swxx = 0;
+  double l[6] = {0, 0, 0, 0, 0, 0};
   int l_card = 0;
   for (int e = e0; e < e0 + E; e++) {
     const int id = ei[e];
@@ -144,28 +176,35 @@ __device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[
     const double b = sb[idx], xv = sx[idx];
     const double w = 1.0 / (b * b);
     const double wx = w * xv;
-    l_sw += eps * w;
-    l_swx += eps * wx;
-    l_swxx += eps * (wx * xv);
+    l[0] += eps * w;
+    l[1] += eps * wx;
+    l[2] += eps * (wx * xv);
+    l[3] += eps * xv;
+    l[4] += eps * (xv * xv);
+    l[5] += eps * b;
     l_card += id > 0 ? 1 : -1;
   }
-  part[tid] = l_sw;
-  part[256 + tid] = l_swx;
-  part[512 + tid] = l_swxx;
-  part[768 + tid] = (double)l_card;
+#pragma unroll
+  for (int q = 0; q < 6; q++) part[q * NT + tid] = l[q];
+  part[6 * NT + tid] = (double)l_card;
+  part[7 * NT + tid] = l_sr;
   __syncthreads();
-  if (tid < 4) {  // exclusive scan of the 256 chunk totals, one quantity per thread
+  if (tid < 8) {  // exclusive scan of the NT chunk totals, one quantity per thread (7: total of the bounds)
     double run = 0.0;
-    double *q = part + tid * 256;
-    for (int i = 0; i < 256; i++) {
+    double *q = part + tid * NT;
+    for (int i = 0; i < NT; i++) {
       const double v = q[i];
       q[i] = run;
       run += v;
     }
+    if (tid == 7) q[0] = run;  // sum of all bounds
   }
   __syncthreads();
-  double sw = part[tid], swx = part[256 + tid], swxx = part[512 + tid];
-  int card = (int)part[768 + tid];
+  double r[6];
+#pragma unroll
+  for (int q = 0; q < 6; q++) r[q] = part[q * NT + tid];
+  int card = (int)part[6 * NT + tid];
+  const double ranges_sum = part[7 * NT];
   double best_cost = INFINITY, best_x = 0.0;
   int best_pos = 0x7fffffff;
   for (int e = e0; e < e0 + E; e++) {
@@ -176,14 +215,18 @@ __device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[
     const double b = sb[idx], xv = sx[idx];
     const double w = 1.0 / (b * b);
     const double wx = w * xv;
-    sw += eps * w;
-    swx += eps * wx;
-    swxx += eps * (wx * xv);
+    r[0] += eps * w;
+    r[1] += eps * wx;
+    r[2] += eps * (wx * xv);
+    r[3] += eps * xv;
+    r[4] += eps * (xv * xv);
+    r[5] += eps * b;
     card += id > 0 ? 1 : -1;
     if (card <= 0) continue;
-    const double x_hat = swx / sw;
-    const double residual = swxx - 2.0 * swx * x_hat + sw * x_hat * x_hat;
-    const double cost = residual + (double)(K - card);
+    const double x_hat = r[1] / r[0];
+    double cost;
+    if (!teaser_cost) cost = (r[2] - 2.0 * r[1] * x_hat + r[0] * x_hat * x_hat) + (double)(K - card);
+    else cost = ((double)card * x_hat * x_hat + r[4] - 2.0 * r[3] * x_hat) + (ranges_sum - r[5]);
     if (cost < best_cost) {  // first minimum inside the chunk
       best_cost = cost;
       best_x = x_hat;
@@ -202,146 +245,203 @@ __device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[
   __syncthreads();
   if ((tid & 63) == 0) {
     part[tid >> 6] = best_cost;
-    part[4 + (tid >> 6)] = best_x;
-    part[8 + (tid >> 6)] = (double)best_pos;
+    part[NW + (tid >> 6)] = best_x;
+    part[2 * NW + (tid >> 6)] = (double)best_pos;
   }
   __syncthreads();
-  double bc = part[0], bx = part[4], bp = part[8];
-  for (int w = 1; w < 4; w++)
-    if (part[w] < bc || (part[w] == bc && part[8 + w] < bp)) {
-      bc = part[w]; bx = part[4 + w]; bp = part[8 + w];
+  double bc = part[0], bx = part[NW], bp = part[2 * NW];
+  for (int w = 1; w < NW; w++)
+    if (part[w] < bc || (part[w] == bc && part[2 * NW + w] < bp)) {
+      bc = part[w]; bx = part[NW + w]; bp = part[2 * NW + w];
     }
-  (void)red;
   return bx;
 }
 
-constexpr int LDS_PTS = MAXK * 16;                  // src+dst float2 (later sx, sb doubles)
-constexpr int LDS_EV = MAXE * 8;
-constexpr int LDS_EI = MAXE * 4;
-constexpr int LDS_PART = 1024 * 8;
-constexpr int LDS_RED = 16 * 8;
-constexpr int LDS_TOTAL = LDS_PTS + LDS_EV + LDS_EI + LDS_PART + LDS_RED;  // 90240 B
+// array sizes of one workgroup for pairs of up to MAXK matches
+template <int NT, int MAXK>
+struct Layout {
+  static constexpr int PTS = MAXK * 16;        // src + dst float2 (later sx, sb doubles)
+  static constexpr int EV = 2 * MAXK * 8;
+  static constexpr int EI = 2 * MAXK * 4;
+  static constexpr int PART = 8 * NT * 8;
+  static constexpr int TOTAL = PTS + EV + EI + PART;
+};
+constexpr int LDS_RED = 2 * 16 * 8;
 
-__global__ __launch_bounds__(256) void orora_register_kernel(const float2 *__restrict__ src, const float2 *__restrict__ dst,
-                                                             const int64_t *__restrict__ offsets, int n_pairs, Params p,
-                                                             rsx_orora_result *__restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  float2 *s_src = reinterpret_cast<float2 *>(smem);
+// One scan pair by one workgroup.  ws = the pair-sized arrays (LDS or HBM), red_lds = 32 doubles of LDS.
+template <int NT, int MAXK>
+__device__ void register_pair(const float2 *__restrict__ src, const float2 *__restrict__ dst, int64_t o, int K,
+                              const Params &p, char *ws, double *red_lds, rsx_orora_result *out) {
+  constexpr int TPT = MAXK / NT, NW = NT / 64;
+  using L = Layout<NT, MAXK>;
+  float2 *s_src = reinterpret_cast<float2 *>(ws);
   float2 *s_dst = s_src + MAXK;
-  double *sx = reinterpret_cast<double *>(smem);  // aliases the points once they are dead
+  double *sx = reinterpret_cast<double *>(ws);  // aliases the points once they are dead
   double *sb = sx + MAXK;
-  double *ev = reinterpret_cast<double *>(smem + LDS_PTS);
-  int *ei = reinterpret_cast<int *>(smem + LDS_PTS + LDS_EV);
-  double *part = reinterpret_cast<double *>(smem + LDS_PTS + LDS_EV + LDS_EI);
-  Red red{reinterpret_cast<double *>(smem + LDS_PTS + LDS_EV + LDS_EI + LDS_PART)};
-
-  const int pair = blockIdx.x;
-  if (pair >= n_pairs) return;
+  double *ev = reinterpret_cast<double *>(ws + L::PTS);
+  int *ei = reinterpret_cast<int *>(ws + L::PTS + L::EV);
+  double *part = reinterpret_cast<double *>(ws + L::PTS + L::EV + L::EI);
+  Red<NW> red{red_lds};
   const int tid = threadIdx.x;
-  const int64_t o = offsets[pair];
-  const int64_t K64 = offsets[pair + 1] - o;
-  if (K64 < 2 || K64 > MAXK) {
-    if (tid == 0) {
-      rsx_orora_result r;
-      r.x = r.y = r.yaw = 0.0;
-      r.iterations = r.rot_inliers = r.trans_inliers = 0;
-      r.status = K64 < 2 ? 1 : 2;
-      out[pair] = r;
-    }
-    return;
-  }
-  const int K = (int)K64;
-  for (int i = tid; i < K; i += 256) {
+  __syncthreads();  // (persistent workgroups: the previous pair is done with ws)
+  for (int i = tid; i < K; i += NT) {
     s_src[i] = src[o + i];
     s_dst[i] = dst[o + i];
   }
   __syncthreads();
 
-  // ---- TIMs on the closed chain, TPT per thread ----
-  double ax[TPT], ay[TPT], bx[TPT], by[TPT], w[TPT], r2[TPT];
-#pragma unroll
-  for (int t = 0; t < TPT; t++) {
-    const int j = tid + t * 256;
-    if (j < K) {
-      const int n = (j + 1 == K) ? 0 : j + 1;
-      ax[t] = (double)s_src[n].x - (double)s_src[j].x;
-      ay[t] = (double)s_src[n].y - (double)s_src[j].y;
-      bx[t] = (double)s_dst[n].x - (double)s_dst[j].x;
-      by[t] = (double)s_dst[n].y - (double)s_dst[j].y;
-      w[t] = 1.0;
-    } else {
-      ax[t] = ay[t] = bx[t] = by[t] = 0.0;
-      w[t] = 0.0;
-    }
-    r2[t] = 0.0;
-  }
-
-  // ---- GNC-TLS rotation ----
   double mu = 1.0, prev_cost = INFINITY, cs = 1.0, sn = 0.0;
-  int it = 0;
-  for (it = 0; it < p.max_iterations; it++) {
-    double C = 0.0, S = 0.0;
+  int it = 0, rot_inliers = 0;
+  if (!p.complete_graph) {
+    // ---- TIMs on the closed chain, TPT per thread, in registers ----
+    double ax[TPT], ay[TPT], bx[TPT], by[TPT], w[TPT], r2[TPT];
 #pragma unroll
     for (int t = 0; t < TPT; t++) {
-      C += w[t] * (ax[t] * bx[t] + ay[t] * by[t]);
-      S += w[t] * (ax[t] * by[t] - ay[t] * bx[t]);
+      const int j = tid + t * NT;
+      if (j < K) {
+        const int n = (j + 1 == K) ? 0 : j + 1;
+        ax[t] = (double)s_src[n].x - (double)s_src[j].x;
+        ay[t] = (double)s_src[n].y - (double)s_src[j].y;
+        bx[t] = (double)s_dst[n].x - (double)s_dst[j].x;
+        by[t] = (double)s_dst[n].y - (double)s_dst[j].y;
+        w[t] = 1.0;
+      } else {
+        ax[t] = ay[t] = bx[t] = by[t] = 0.0;
+        w[t] = 0.0;
+      }
+      r2[t] = 0.0;
     }
-    red.sum2(C, S);
-    const double nrm = sqrt(C * C + S * S);
-    if (nrm > 0.0) {
-      cs = C / nrm;
-      sn = S / nrm;
-    } else {
-      cs = 1.0;
-      sn = 0.0;
-    }
-    double max_r2 = 0.0;
+    for (it = 0; it < p.max_iterations; it++) {
+      double C = 0.0, S = 0.0;
 #pragma unroll
-    for (int t = 0; t < TPT; t++) {
-      const double ex = bx[t] - (cs * ax[t] - sn * ay[t]);
-      const double ey = by[t] - (sn * ax[t] + cs * ay[t]);
-      r2[t] = ex * ex + ey * ey;
-      max_r2 = fmax(max_r2, (tid + t * 256 < K) ? r2[t] : 0.0);
-    }
-    if (it == 0) {
-      max_r2 = red.max(max_r2);
-      mu = 1.0 / (2.0 * max_r2 / p.c2 - 1.0);
-      if (mu <= 0.0) {
-        it = 1;
+      for (int t = 0; t < TPT; t++) {
+        C += w[t] * (ax[t] * bx[t] + ay[t] * by[t]);
+        S += w[t] * (ax[t] * by[t] - ay[t] * bx[t]);
+      }
+      red.sum2(C, S);
+      const double nrm = sqrt(C * C + S * S);
+      if (nrm > 0.0) {
+        cs = C / nrm;
+        sn = S / nrm;
+      } else {
+        cs = 1.0;
+        sn = 0.0;
+      }
+      double max_r2 = 0.0;
+#pragma unroll
+      for (int t = 0; t < TPT; t++) {
+        const double ex = bx[t] - (cs * ax[t] - sn * ay[t]);
+        const double ey = by[t] - (sn * ax[t] + cs * ay[t]);
+        r2[t] = ex * ex + ey * ey;
+        max_r2 = fmax(max_r2, (tid + t * NT < K) ? r2[t] : 0.0);
+      }
+      if (it == 0) {
+        max_r2 = red.max(max_r2);
+        mu = 1.0 / (2.0 * max_r2 / p.c2 - 1.0);
+        if (mu <= 0.0) {
+          it = 1;
+          break;
+        }
+      }
+      double cost = 0.0;
+#pragma unroll
+      for (int t = 0; t < TPT; t++) {
+        cost += w[t] * r2[t];
+        if (tid + t * NT < K) w[t] = gnc_weight(r2[t], mu, p.c2);
+      }
+      cost = red.sum(cost);
+      const double cost_diff = fabs(cost - prev_cost);
+      mu = mu * p.gnc_factor;
+      prev_cost = cost;
+      if (cost_diff < p.cost_threshold) {
+        it++;
         break;
       }
     }
-    const double th1 = (mu + 1.0) / mu * p.c2;
-    const double th2 = mu / (mu + 1.0) * p.c2;
-    double cost = 0.0;
+    double cnt = 0.0;
 #pragma unroll
-    for (int t = 0; t < TPT; t++) {
-      cost += w[t] * r2[t];
-      if (tid + t * 256 < K) {
-        if (r2[t] >= th1) w[t] = 0.0;
-        else if (r2[t] <= th2) w[t] = 1.0;
-        else w[t] = sqrt(p.c2 * mu * (mu + 1.0) / r2[t]) - mu;
+    for (int t = 0; t < TPT; t++) cnt += (tid + t * NT < K && w[t] >= 0.5) ? 1.0 : 0.0;
+    rot_inliers = (int)red.sum(cnt);
+  } else {
+    // ---- TIMs on the complete graph: K (K-1) / 2 of them, too many to store.  The weight of a TIM is a function
+    // of its residual under the PREVIOUS rotation and the previous mu, so it is recomputed on the fly: every GNC
+    // iteration is two sweeps over all pairs i < j (thread = stripe of j), no per-TIM state at all ----
+    double cs_w = 1.0, sn_w = 0.0, mu_w = 0.0;  // the rotation / mu the current weights come from (mu_w == 0: all 1)
+    auto tim_weight = [&](double axx, double ayy, double bxx, double byy) {
+      if (mu_w == 0.0) return 1.0;
+      const double ex = bxx - (cs_w * axx - sn_w * ayy), ey = byy - (sn_w * axx + cs_w * ayy);
+      return gnc_weight(ex * ex + ey * ey, mu_w, p.c2);
+    };
+    for (it = 0; it < p.max_iterations; it++) {
+      double C = 0.0, S = 0.0;
+      for (int i = 0; i < K - 1; i++) {
+        const double six = s_src[i].x, siy = s_src[i].y, dix = s_dst[i].x, diy = s_dst[i].y;
+        for (int j = i + 1 + tid; j < K; j += NT) {
+          const double axx = (double)s_src[j].x - six, ayy = (double)s_src[j].y - siy;
+          const double bxx = (double)s_dst[j].x - dix, byy = (double)s_dst[j].y - diy;
+          const double w = tim_weight(axx, ayy, bxx, byy);
+          C += w * (axx * bxx + ayy * byy);
+          S += w * (axx * byy - ayy * bxx);
+        }
+      }
+      red.sum2(C, S);
+      const double nrm = sqrt(C * C + S * S);
+      if (nrm > 0.0) {
+        cs = C / nrm;
+        sn = S / nrm;
+      } else {
+        cs = 1.0;
+        sn = 0.0;
+      }
+      double max_r2 = 0.0, cost = 0.0;
+      for (int i = 0; i < K - 1; i++) {
+        const double six = s_src[i].x, siy = s_src[i].y, dix = s_dst[i].x, diy = s_dst[i].y;
+        for (int j = i + 1 + tid; j < K; j += NT) {
+          const double axx = (double)s_src[j].x - six, ayy = (double)s_src[j].y - siy;
+          const double bxx = (double)s_dst[j].x - dix, byy = (double)s_dst[j].y - diy;
+          const double ex = bxx - (cs * axx - sn * ayy), ey = byy - (sn * axx + cs * ayy);
+          const double r2 = ex * ex + ey * ey;
+          max_r2 = fmax(max_r2, r2);
+          cost += tim_weight(axx, ayy, bxx, byy) * r2;
+        }
+      }
+      if (it == 0) {
+        max_r2 = red.max(max_r2);
+        mu = 1.0 / (2.0 * max_r2 / p.c2 - 1.0);
+        if (mu <= 0.0) {
+          it = 1;
+          break;
+        }
+      }
+      cost = red.sum(cost);
+      cs_w = cs;  // the weights of the next iteration: residuals under this rotation, this mu
+      sn_w = sn;
+      mu_w = mu;
+      const double cost_diff = fabs(cost - prev_cost);
+      mu = mu * p.gnc_factor;
+      prev_cost = cost;
+      if (cost_diff < p.cost_threshold) {
+        it++;
+        break;
       }
     }
-    cost = red.sum(cost);
-    const double cost_diff = fabs(cost - prev_cost);
-    mu = mu * p.gnc_factor;
-    prev_cost = cost;
-    if (cost_diff < p.cost_threshold) {
-      it++;
-      break;
+    double cnt = 0.0;
+    for (int i = 0; i < K - 1; i++) {
+      const double six = s_src[i].x, siy = s_src[i].y, dix = s_dst[i].x, diy = s_dst[i].y;
+      for (int j = i + 1 + tid; j < K; j += NT) {
+        const double w = tim_weight((double)s_src[j].x - six, (double)s_src[j].y - siy, (double)s_dst[j].x - dix,
+                                    (double)s_dst[j].y - diy);
+        cnt += w >= 0.5 ? 1.0 : 0.0;
+      }
     }
+    rot_inliers = (int)red.sum(cnt);
   }
-  double cnt = 0.0;
-#pragma unroll
-  for (int t = 0; t < TPT; t++) cnt += (tid + t * 256 < K && w[t] >= 0.5) ? 1.0 : 0.0;
-  const int rot_inliers = (int)red.sum(cnt);
 
   // ---- A-COTE translation: residuals and anisotropic bounds, TPT per thread ----
   double vx[TPT], vy[TPT], betx[TPT], bety[TPT];
 #pragma unroll
   for (int t = 0; t < TPT; t++) {
-    const int i = tid + t * 256;
+    const int i = tid + t * NT;
     vx[t] = vy[t] = 0.0;
     betx[t] = bety[t] = 1.0;
     if (i < K) {
@@ -356,12 +456,12 @@ __global__ __launch_bounds__(256) void orora_register_kernel(const float2 *__res
       bety[t] = byy;
     }
   }
-  const double tx = scalar_tls_block(vx, betx, K, sx, sb, ev, ei, part, red);
-  const double ty = scalar_tls_block(vy, bety, K, sx, sb, ev, ei, part, red);
-  cnt = 0.0;
+  const double tx = scalar_tls_block<NT, TPT>(vx, betx, K, sx, sb, ev, ei, part, p.teaser_cost);
+  const double ty = scalar_tls_block<NT, TPT>(vy, bety, K, sx, sb, ev, ei, part, p.teaser_cost);
+  double cnt = 0.0;
 #pragma unroll
   for (int t = 0; t < TPT; t++)
-    cnt += (tid + t * 256 < K && fabs(vx[t] - tx) <= betx[t] && fabs(vy[t] - ty) <= bety[t]) ? 1.0 : 0.0;
+    cnt += (tid + t * NT < K && fabs(vx[t] - tx) <= betx[t] && fabs(vy[t] - ty) <= bety[t]) ? 1.0 : 0.0;
   const int trans_inliers = (int)red.sum(cnt);
   if (tid == 0) {
     rsx_orora_result r;
@@ -372,7 +472,55 @@ __global__ __launch_bounds__(256) void orora_register_kernel(const float2 *__res
     r.rot_inliers = rot_inliers;
     r.trans_inliers = trans_inliers;
     r.status = 0;
-    out[pair] = r;
+    *out = r;
+  }
+}
+
+using LdsLayout = Layout<256, MAXK_LDS>;
+constexpr int LDS_TOTAL = LdsLayout::TOTAL + LDS_RED;  // 106 KB... see static_assert
+static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+
+// on-chip kernel: one workgroup per pair; pairs that do not fit are written to the big list
+__global__ __launch_bounds__(256) void orora_register_kernel(const float2 *__restrict__ src, const float2 *__restrict__ dst,
+                                                             const int64_t *__restrict__ offsets, int n_pairs, Params p,
+                                                             rsx_orora_result *__restrict__ out, int *__restrict__ big_list) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int pair = blockIdx.x;
+  if (pair >= n_pairs) return;
+  const int64_t o = offsets[pair];
+  const int64_t K64 = offsets[pair + 1] - o;
+  if (K64 < 2 || K64 > MAXK_LDS) {
+    if (threadIdx.x == 0) {
+      if (K64 > MAXK_LDS && K64 <= MAXK_BIG) {
+        big_list[1 + atomicAdd(big_list, 1)] = pair;  // scored by orora_register_big_kernel
+      } else {
+        rsx_orora_result r;
+        r.x = r.y = r.yaw = 0.0;
+        r.iterations = r.rot_inliers = r.trans_inliers = 0;
+        r.status = K64 < 2 ? 1 : 2;
+        out[pair] = r;
+      }
+    }
+    return;
+  }
+  register_pair<256, MAXK_LDS>(src, dst, o, (int)K64, p, smem, reinterpret_cast<double *>(smem + LdsLayout::TOTAL), out + pair);
+}
+
+using BigLayout = Layout<1024, MAXK_BIG>;
+constexpr int BIG_BLOCKS = 32;
+
+// large pairs: persistent 1024-thread workgroups, arrays in the HBM workspace (BigLayout::TOTAL bytes per workgroup)
+__global__ __launch_bounds__(1024) void orora_register_big_kernel(const float2 *__restrict__ src, const float2 *__restrict__ dst,
+                                                                  const int64_t *__restrict__ offsets, Params p,
+                                                                  rsx_orora_result *__restrict__ out, const int *__restrict__ big_list,
+                                                                  char *__restrict__ workspace) {
+  __shared__ double red_lds[32];
+  const int n_big = big_list[0];
+  char *ws = workspace + (size_t)blockIdx.x * BigLayout::TOTAL;
+  for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
+    const int pair = big_list[1 + b];
+    const int64_t o = offsets[pair];
+    register_pair<1024, MAXK_BIG>(src, dst, o, (int)(offsets[pair + 1] - o), p, ws, red_lds, out + pair);
   }
 }
 
@@ -383,6 +531,7 @@ struct rsx_orora {
   std::mutex mu;
   hipStream_t stream = nullptr;
   rsx::DevBuf src, dst, off, res;
+  rsx::DevBuf big_list, big_ws;  // pairs of more than 2048 matches: their indices, and the HBM arrays of the workgroups that score them
   bool attr_set = false;
 };
 
@@ -398,11 +547,11 @@ int rsx_orora_default_params(rsx_orora_params *p) {
   p->gnc_factor = 1.4;
   p->cost_threshold = 1e-6;
   p->max_iterations = 100;
-  p->reserved = 0;
+  p->flags = 0;
   return RSX_OK;
 }
 
-int rsx_orora_max_correspondences(void) { return MAXK; }
+int rsx_orora_max_correspondences(void) { return MAXK_BIG; }
 
 int rsx_orora_create(int device, rsx_orora **out) {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
@@ -431,6 +580,8 @@ int rsx_orora_destroy(rsx_orora *h) {
   h->dst.release();
   h->off.release();
   h->res.release();
+  h->big_list.release();
+  h->big_ws.release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
@@ -459,10 +610,20 @@ int rsx_orora_register_batch_device(rsx_orora *h, const float *d_src_xy, const f
   kp.gnc_factor = dp.gnc_factor;
   kp.cost_threshold = dp.cost_threshold;
   kp.max_iterations = dp.max_iterations;
+  kp.complete_graph = (dp.flags & RSX_ORORA_COMPLETE_GRAPH) ? 1 : 0;
+  kp.teaser_cost = (dp.flags & RSX_ORORA_TEASER_COST) ? 1 : 0;
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  // the list of pairs too large for the on-chip kernel is built on the device (the offsets may live there only); the
+  // large-pair kernel always runs its few workgroups, which return at once when the list is empty
+  RSX_TRY(h->big_list.reserve((size_t)(n_pairs + 1) * sizeof(int), s, false));
+  RSX_TRY(h->big_ws.reserve((size_t)BIG_BLOCKS * BigLayout::TOTAL, s, false));
+  RSX_HIP(hipMemsetAsync(h->big_list.p, 0, sizeof(int), s));
   hipLaunchKernelGGL(orora_register_kernel, dim3(n_pairs), dim3(256), LDS_TOTAL, s,
                      reinterpret_cast<const float2 *>(d_src_xy), reinterpret_cast<const float2 *>(d_dst_xy), d_offsets,
-                     n_pairs, kp, d_out);
+                     n_pairs, kp, d_out, h->big_list.as<int>());
+  hipLaunchKernelGGL(orora_register_big_kernel, dim3(BIG_BLOCKS), dim3(1024), 0, s,
+                     reinterpret_cast<const float2 *>(d_src_xy), reinterpret_cast<const float2 *>(d_dst_xy), d_offsets, kp, d_out,
+                     h->big_list.as<int>(), h->big_ws.as<char>());
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

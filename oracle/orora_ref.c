@@ -17,7 +17,7 @@ void ororaref_default_params(ororaref_params *p) {
   p->gnc_factor = 1.4;
   p->cost_threshold = 1e-6;
   p->max_iterations = 100;
-  p->reserved = 0;
+  p->flags = 0; /* ring of K TIMs, per-point normalised TLS cost */
 }
 
 typedef struct {
@@ -32,8 +32,15 @@ static int cmp_endpoint(const void *a, const void *b) {
   return (p->id > q->id) - (p->id < q->id); /* std::pair order: value, then signed id */
 }
 
-/* TEASER++ ScalarTLSEstimator::estimate (adaptive voting), SURVEY B.4 */
-double ororaref_scalar_tls(const double *x, const double *beta, int32_t n, int32_t *n_inliers) {
+/* TEASER++ ScalarTLSEstimator::estimate (adaptive voting), SURVEY B.4.
+ * cost_mode 0 (default): truncated least squares normalised per point,
+ *     cost(x^) = sum_{k in C} w_k (x_k - x^)^2 + |outliers|,  w_k = beta_k^-2
+ *   (a point on its interval edge costs exactly 1 = an outlier); meaningful for per-point bounds such as A-COTE's.
+ * cost_mode 1: the form of TEASER++'s registration.cc as recalled (unverifiable here): UNWEIGHTED residuals of the
+ *   consensus set [m^2] plus the sum of the bounds of the outliers [m],
+ *     cost(x^) = sum_{k in C} (x_k - x^)^2 + sum_{k not in C} beta_k,
+ *   with the same weighted-mean estimate x^ = sum w x / sum w. */
+double ororaref_scalar_tls_mode(const double *x, const double *beta, int32_t n, int32_t cost_mode, int32_t *n_inliers) {
   if (n <= 0) {
     if (n_inliers) *n_inliers = 0;
     return 0.0;
@@ -48,15 +55,10 @@ double ororaref_scalar_tls(const double *x, const double *beta, int32_t n, int32
     ranges_sum += beta[i];
   }
   qsort(h, 2 * (size_t)n, sizeof(endpoint), cmp_endpoint);
-  /* truncated least squares, normalised per point: cost(x^) = sum_{k in C} w_k (x_k - x^)^2 +
-   * |outliers| with w_k = beta_k^-2 (a point on its interval edge costs exactly 1 = an outlier).
-   * The TEASER++ code adds unweighted residuals [m^2] to a sum of bounds [m], which is only
-   * meaningful for equal bounds; A-COTE's bounds are per-point, hence the normalised form. */
-  double sw = 0, swx = 0, swxx = 0;
+  double sw = 0, swx = 0, swxx = 0, sx = 0, sxx = 0, sr = 0;
   int32_t card = 0;
   double best_cost = INFINITY, best_x = 0.0;
   int have = 0;
-  (void)ranges_sum;
   for (int32_t i = 0; i < 2 * n; i++) {
     const int32_t idx = abs(h[i].id) - 1;
     const double eps = h[i].id > 0 ? 1.0 : -1.0;
@@ -66,10 +68,19 @@ double ororaref_scalar_tls(const double *x, const double *beta, int32_t n, int32
     sw += eps * w;
     swx += eps * wx;
     swxx += eps * (wx * x[idx]);
+    sx += eps * x[idx];
+    sxx += eps * (x[idx] * x[idx]);
+    sr += eps * beta[idx];
     if (card <= 0) continue; /* empty consensus set: no estimate */
     const double x_hat = swx / sw;
-    const double residual = swxx - 2.0 * swx * x_hat + sw * x_hat * x_hat;
-    const double cost = residual + (double)(n - card);
+    double cost;
+    if (cost_mode == 0) {
+      const double residual = swxx - 2.0 * swx * x_hat + sw * x_hat * x_hat;
+      cost = residual + (double)(n - card);
+    } else {
+      const double residual = (double)card * x_hat * x_hat + sxx - 2.0 * sx * x_hat;
+      cost = residual + (ranges_sum - sr);
+    }
     if (!have || cost < best_cost) {
       best_cost = cost;
       best_x = x_hat;
@@ -83,6 +94,10 @@ double ororaref_scalar_tls(const double *x, const double *beta, int32_t n, int32
     *n_inliers = c;
   }
   return best_x;
+}
+
+double ororaref_scalar_tls(const double *x, const double *beta, int32_t n, int32_t *n_inliers) {
+  return ororaref_scalar_tls_mode(x, beta, n, 0, n_inliers);
 }
 
 static void aniso_bound(double px, double py, double s_r, double s_t, double *bx, double *by) {
@@ -103,16 +118,32 @@ void ororaref_register(const float *src_xy, const float *dst_xy, int32_t k, cons
     out->status = 1;
     return;
   }
-  /* ---- GNC-TLS rotation on the ring of K TIMs ---- */
-  double *ax = (double *)malloc(sizeof(double) * 6 * (size_t)k);
-  double *ay = ax + k, *bx = ay + k, *by = bx + k, *w = by + k, *r2 = w + k;
-  for (int32_t j = 0; j < k; j++) {
-    const int32_t n = (j + 1) % k;
-    ax[j] = (double)src_xy[2 * n] - (double)src_xy[2 * j];
-    ay[j] = (double)src_xy[2 * n + 1] - (double)src_xy[2 * j + 1];
-    bx[j] = (double)dst_xy[2 * n] - (double)dst_xy[2 * j];
-    by[j] = (double)dst_xy[2 * n + 1] - (double)dst_xy[2 * j + 1];
-    w[j] = 1.0;
+  /* ---- GNC-TLS rotation on the TIM graph: the ring of K TIMs (default) or, with
+   * ORORAREF_FLAG_COMPLETE_GRAPH, all K (K-1) / 2 pairs i < j in row-major order ---- */
+  const int complete = (p->flags & ORORAREF_FLAG_COMPLETE_GRAPH) != 0;
+  const int64_t m = complete ? (int64_t)k * (k - 1) / 2 : k;
+  const int64_t mk = m > k ? m : k; /* the arrays are re-used for the K translation residuals below */
+  double *ax = (double *)malloc(sizeof(double) * 6 * (size_t)mk);
+  double *ay = ax + mk, *bx = ay + mk, *by = bx + mk, *w = by + mk, *r2 = w + mk;
+  if (complete) {
+    int64_t t = 0;
+    for (int32_t i = 0; i < k; i++)
+      for (int32_t j = i + 1; j < k; j++, t++) {
+        ax[t] = (double)src_xy[2 * j] - (double)src_xy[2 * i];
+        ay[t] = (double)src_xy[2 * j + 1] - (double)src_xy[2 * i + 1];
+        bx[t] = (double)dst_xy[2 * j] - (double)dst_xy[2 * i];
+        by[t] = (double)dst_xy[2 * j + 1] - (double)dst_xy[2 * i + 1];
+        w[t] = 1.0;
+      }
+  } else {
+    for (int32_t j = 0; j < k; j++) {
+      const int32_t n = (j + 1) % k;
+      ax[j] = (double)src_xy[2 * n] - (double)src_xy[2 * j];
+      ay[j] = (double)src_xy[2 * n + 1] - (double)src_xy[2 * j + 1];
+      bx[j] = (double)dst_xy[2 * n] - (double)dst_xy[2 * j];
+      by[j] = (double)dst_xy[2 * n + 1] - (double)dst_xy[2 * j + 1];
+      w[j] = 1.0;
+    }
   }
   double c2 = p->tim_noise_bound * p->tim_noise_bound;
   if (c2 < 1e-16) c2 = 1e-2;
@@ -121,7 +152,7 @@ void ororaref_register(const float *src_xy, const float *dst_xy, int32_t k, cons
   for (it = 0; it < p->max_iterations; it++) {
     /* weighted 2x2 Kabsch: yaw = atan2(sum w (a x b), sum w (a . b)) */
     double C = 0.0, S = 0.0;
-    for (int32_t j = 0; j < k; j++) {
+    for (int64_t j = 0; j < m; j++) {
       C += w[j] * (ax[j] * bx[j] + ay[j] * by[j]);
       S += w[j] * (ax[j] * by[j] - ay[j] * bx[j]);
     }
@@ -134,7 +165,7 @@ void ororaref_register(const float *src_xy, const float *dst_xy, int32_t k, cons
       sn = 0.0;
     }
     double max_r2 = 0.0;
-    for (int32_t j = 0; j < k; j++) {
+    for (int64_t j = 0; j < m; j++) {
       const double ex = bx[j] - (cs * ax[j] - sn * ay[j]);
       const double ey = by[j] - (sn * ax[j] + cs * ay[j]);
       r2[j] = ex * ex + ey * ey;
@@ -150,7 +181,7 @@ void ororaref_register(const float *src_xy, const float *dst_xy, int32_t k, cons
     const double th1 = (mu + 1.0) / mu * c2;
     const double th2 = mu / (mu + 1.0) * c2;
     double cost = 0.0;
-    for (int32_t j = 0; j < k; j++) {
+    for (int64_t j = 0; j < m; j++) {
       cost += w[j] * r2[j];
       if (r2[j] >= th1) w[j] = 0.0;
       else if (r2[j] <= th2) w[j] = 1.0;
@@ -165,7 +196,7 @@ void ororaref_register(const float *src_xy, const float *dst_xy, int32_t k, cons
     }
   }
   out->iterations = it;
-  for (int32_t j = 0; j < k; j++) out->rot_inliers += w[j] >= 0.5;
+  for (int64_t j = 0; j < m; j++) out->rot_inliers += w[j] >= 0.5;
   out->yaw = atan2(sn, cs);
 
   /* ---- A-COTE translation ---- */
@@ -182,8 +213,9 @@ void ororaref_register(const float *src_xy, const float *dst_xy, int32_t k, cons
     betx[i] = bxx;
     bety[i] = byy;
   }
-  out->x = ororaref_scalar_tls(vx, betx, k, NULL);
-  out->y = ororaref_scalar_tls(vy, bety, k, NULL);
+  const int32_t cost_mode = (p->flags & ORORAREF_FLAG_TEASER_COST) ? 1 : 0;
+  out->x = ororaref_scalar_tls_mode(vx, betx, k, cost_mode, NULL);
+  out->y = ororaref_scalar_tls_mode(vy, bety, k, cost_mode, NULL);
   for (int32_t i = 0; i < k; i++)
     out->trans_inliers += (fabs(vx[i] - out->x) <= betx[i]) && (fabs(vy[i] - out->y) <= bety[i]);
   free(ax);

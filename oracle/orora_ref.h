@@ -42,8 +42,10 @@ typedef struct {
   double gnc_factor;             /* 1.4 in TEASER++ */
   double cost_threshold;         /* stop when |cost - prev_cost| < this */
   int32_t max_iterations;        /* GNC iterations cap */
-  int32_t reserved;
+  int32_t flags;                 /* ORORAREF_FLAG_*: the unpinned modelling choices, switchable */
 } ororaref_params;
+#define ORORAREF_FLAG_COMPLETE_GRAPH 1 /* TIMs on all K (K-1) / 2 pairs instead of the ring of K */
+#define ORORAREF_FLAG_TEASER_COST 2    /* scalar TLS cost in TEASER++'s form (see orora_ref.c) */
 
 typedef struct {
   double x, y, yaw;        /* dst = R(yaw) src + (x,y) */
@@ -63,6 +65,7 @@ void ororaref_register_batch(const float *src_xy, const float *dst_xy, const int
                              int nthreads);
 /* scalar TLS estimator on its own (unit-testable): returns the estimate */
 double ororaref_scalar_tls(const double *x, const double *beta, int32_t n, int32_t *n_inliers);
+double ororaref_scalar_tls_mode(const double *x, const double *beta, int32_t n, int32_t cost_mode, int32_t *n_inliers);
 
 #ifdef __cplusplus
 }

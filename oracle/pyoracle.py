@@ -330,7 +330,7 @@ class RefKdTree:
 class OroraParams(C.Structure):
     _fields_ = [("tim_noise_bound", C.c_double), ("noise_bound_radial", C.c_double),
                 ("noise_bound_tangential", C.c_double), ("gnc_factor", C.c_double),
-                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("flags", C.c_int32)]
 
 
 ORORA_RESULT_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("iterations", "<i4"),
@@ -425,7 +425,7 @@ def voxelgrid_filter(pts, leaf=0.4, intensity_col=3):
 # ---------------------------------------------------------------------------------------------
 class IcpRefParams(C.Structure):
     _fields_ = [("max_corr_dist", C.c_double), ("transformation_epsilon", C.c_double),
-                ("euclidean_fitness_epsilon", C.c_double), ("max_iterations", C.c_int32), ("reserved", C.c_int32)]
+                ("euclidean_fitness_epsilon", C.c_double), ("max_iterations", C.c_int32), ("flags", C.c_int32)]
 
 
 class IcpRefResult(C.Structure):

@@ -38,7 +38,9 @@ def test_batch_matches_oracle(reg, oracle):
 def test_edge_sizes(reg, oracle):
     from navtech_radar_slam_amd import orora
     maxk = orora.max_correspondences()
-    sizes = [0, 1, 2, 3, 5, 255, 256, 257, 511, 512, 1024, maxk, maxk + 1]
+    assert maxk == 16384
+    # <= 2048 matches: on-chip kernel; 2049 .. 16384 (cen2019 can emit 10 000 keypoints): the HBM-workspace kernel
+    sizes = [0, 1, 2, 3, 5, 255, 256, 257, 511, 512, 1024, 2048, 2049, 3000, 10000, maxk, maxk + 1]
     rng = np.random.default_rng(5)
     src, dst, off = [], [], [0]
     for k in sizes:
@@ -73,3 +75,21 @@ def test_clean_and_all_outlier_pairs(reg, oracle):
     assert got["status"][1] == 0                                            # garbage in, finite pose out
     _check(got[:1], want[:1])
     assert np.all(np.isfinite([got["x"][1], got["y"][1], got["yaw"][1]]))
+
+
+@pytest.mark.parametrize("flags", [1, 2, 3])
+def test_modelling_switches_match_oracle(reg, oracle, flags):
+    """The two unpinned modelling choices as parameters: TIMs on the complete graph (flag 1) and TEASER++'s form of the
+    scalar TLS cost (flag 2); GPU == oracle within the pose tolerance for every combination, small and large pairs."""
+    from navtech_radar_slam_amd import orora
+    src, dst, off, truth = synth.orora_pairs(91, 24, k_range=(40, 400))
+    big = synth.orora_pairs(92, 1, k_range=(2300, 2300))
+    src = np.concatenate([src, big[0]]); dst = np.concatenate([dst, big[1]])
+    off = np.concatenate([off, [off[-1] + 2300]]); truth = np.concatenate([truth, big[3]])
+    gp, op = orora.default_params(), oracle.orora_default_params()
+    gp.flags = flags
+    op.flags = flags
+    got = reg.register_batch(src, dst, off, gp)
+    want = oracle.orora_register_batch(src, dst, off, op, nthreads=8)
+    _check(got, want)
+    assert np.abs(got["yaw"] - truth[:, 2]).max() < 3e-3 and np.abs(got["x"] - truth[:, 0]).max() < 0.08

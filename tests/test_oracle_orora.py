@@ -59,3 +59,30 @@ def test_scalar_tls_matches_bruteforce(oracle):
                 best = (cost, xh)
         assert abs(est - best[1]) < 1e-9
         assert n_in == int((np.abs(x - est) <= beta).sum())
+
+
+def test_modelling_switches(oracle):
+    """flags: 1 = TIMs on the complete graph, 2 = TEASER++'s form of the scalar TLS cost.  Both still recover the
+    planted motion; the complete graph sees K (K-1) / 2 TIMs (rot_inliers counts them)."""
+    import numpy as np
+    from navtech_radar_slam_amd import synth
+    src, dst, off, truth = synth.orora_pairs(5, 6, k_range=(60, 200))
+    base = oracle.orora_register_batch(src, dst, off)
+    for flags in (1, 2, 3):
+        p = oracle.orora_default_params()
+        p.flags = flags
+        r = oracle.orora_register_batch(src, dst, off, p)
+        assert np.abs(r["yaw"] - truth[:, 2]).max() < 3e-3 and np.abs(r["x"] - truth[:, 0]).max() < 0.08
+        if flags & 1:
+            k = np.diff(off)
+            assert np.all(r["rot_inliers"] > base["rot_inliers"]) and np.all(r["rot_inliers"] <= k * (k - 1) // 2)
+    # equal bounds: both cost forms pick the same consensus set
+    x = np.array([0.0, 0.05, -0.04, 0.02, 3.0, -2.5])
+    b = np.full(6, 0.2)
+    import ctypes as C
+    L = oracle.lib()
+    L.ororaref_scalar_tls_mode.restype = C.c_double
+    L.ororaref_scalar_tls_mode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    e0 = L.ororaref_scalar_tls_mode(x.ctypes.data, b.ctypes.data, 6, 0, None)
+    e1 = L.ororaref_scalar_tls_mode(x.ctypes.data, b.ctypes.data, 6, 1, None)
+    assert abs(e0 - x[:4].mean()) < 1e-12 and abs(e1 - x[:4].mean()) < 1e-12
