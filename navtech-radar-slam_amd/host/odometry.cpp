@@ -31,6 +31,7 @@
 #include <string>
 #include <vector>
 
+#include "rosmsg.h"
 #include "rsx.h"
 
 #ifdef RSX_WITH_ROS
@@ -155,13 +156,14 @@ void associate(const Scan &prev, const Scan &cur, float gate, std::vector<float>
 
 int main(int argc, char **argv) {
   try {
-    std::string seq_dir, out_path;
+    std::string seq_dir, out_path, record_path;
     int max_frames = -1, device = 0;
     double rate_hz = 0.0;
     float gate = 6.0f;
     for (int i = 1; i < argc; i++) {
       const std::string a = argv[i];
       if (a == "--out" && i + 1 < argc) out_path = argv[++i];
+      else if (a == "--record" && i + 1 < argc) record_path = argv[++i];  // ROS 1 wire bytes of both topics (rosmsg.h)
       else if (a == "--max_frames" && i + 1 < argc) max_frames = std::atoi(argv[++i]);
       else if (a == "--gate" && i + 1 < argc) gate = (float)std::atof(argv[++i]);
       else if (a.rfind("seq_dir:=", 0) == 0) seq_dir = a.substr(9);  // roslaunch-style arg
@@ -190,6 +192,18 @@ int main(int argc, char **argv) {
 
     FILE *out = out_path.empty() ? stdout : std::fopen(out_path.c_str(), "w");
     if (!out) die("cannot write " + out_path);
+    FILE *rec = nullptr;
+    if (!record_path.empty()) {
+      rec = std::fopen(record_path.c_str(), "wb");
+      if (!rec) die("cannot write " + record_path);
+      std::fwrite(rosmsg::kReplayMagic, 1, 10, rec);
+    }
+    auto record = [&](uint8_t topic, const std::vector<uint8_t> &bytes) {
+      const uint32_t len = (uint32_t)bytes.size();
+      std::fwrite(&topic, 1, 1, rec);
+      std::fwrite(&len, 4, 1, rec);
+      std::fwrite(bytes.data(), 1, bytes.size(), rec);
+    };
 #ifdef RSX_WITH_ROS
     ros::init(argc, argv, "orora");
     ros::NodeHandle nh;
@@ -260,6 +274,18 @@ int main(int argc, char **argv) {
         }
       }
       std::fprintf(out, "%lld %.6f %.6f %.6f %d %zu\n", (long long)cur.stamp_ns, px, py, pyaw, n, n_match);
+      if (rec) {  // what the publishers below put on /orora/odom and /orora/cloud_local, as ROS 1 wire bytes
+        rosmsg::Header h;
+        h.seq = (uint32_t)fi;
+        h.fromNSec(cur.stamp_ns);
+        h.frame_id = "odom";
+        const double pos[3] = {px, py, 0.0}, quat[4] = {0.0, 0.0, std::sin(0.5 * pyaw), std::cos(0.5 * pyaw)};
+        record(rosmsg::kOdom, rosmsg::serialize_odometry(h, "radar", pos, quat));
+        h.frame_id = "radar";
+        std::vector<rosmsg::PointXYZI> pc((size_t)n);
+        for (int k = 0; k < n; k++) pc[(size_t)k] = rosmsg::PointXYZI{cur.xy[2 * (size_t)k], cur.xy[2 * (size_t)k + 1], 0.f, 0.f};
+        record(rosmsg::kCloud, rosmsg::serialize_pointcloud2(h, pc));
+      }
 #ifdef RSX_WITH_ROS
       ros::Time stamp;
       stamp.fromNSec((uint64_t)cur.stamp_ns);
@@ -292,6 +318,7 @@ int main(int argc, char **argv) {
       prev = std::move(cur);
     }
     if (out != stdout) std::fclose(out);
+    if (rec) std::fclose(rec);
     rsx_cen2019_destroy(cen);
     rsx_orora_destroy(reg);
     return 0;

@@ -140,3 +140,81 @@ def test_shim_multi_device_detector(tmp_path, oracle):
         assert float(res[i][3]) == pytest.approx(want[1], abs=0, rel=1e-7), (i, res[i], want)
         loops += want[0] >= 0
     assert loops >= 3
+
+
+def test_ros_free_replay_of_the_loop_closure_side(tmp_path, oracle):
+    """pgo_replay: a recording of /orora/odom + /orora/cloud_local (ROS 1 wire bytes, host/rosmsg.h) through what
+    process_pg / performSCLoopClosure do with those messages (PGO.cpp:417-492, 556-571) on the GPU: stamp pairing,
+    keyframe selection by travelled distance, VoxelGrid(0.4) + ScanContext build, detection per keyframe.  The loops
+    reported must be the oracle's (oracle VoxelGrid + oracle ScanContext on the same keyframes)."""
+    import struct
+    import numpy as np
+    from navtech_radar_slam_amd import synth
+
+    def s(x):
+        return struct.pack("<I", len(x)) + x.encode()
+
+    def header(seq, t_ns, frame):
+        return struct.pack("<III", seq, t_ns // 10**9, t_ns % 10**9) + s(frame)
+
+    clouds, _ = synth.keyframe_clouds(41, 70, binary_z=True, loop_frac=0.3, min_gap=35, n_points=900)
+    rec = bytearray(b"RSXREPLAY1")
+    t0 = 1_560_000_000_000_000_000
+    kept = []
+    for i, c in enumerate(clouds):
+        t = t0 + i * 250_000_000
+        # the vehicle advances 1.5 m per scan along x for the first 20 scans (keyframe_meter_gap 2.0: every second one
+        # is a keyframe), then 2.5 m per scan (every scan is one)
+        xpos = 1.5 * i if i < 20 else 30.0 + 2.5 * (i - 20)
+        od = header(i, t, "odom") + s("radar") + struct.pack("<3d", xpos, 0.0, 0.0) + struct.pack("<4d", 0, 0, 0, 1) + bytes(8 * 78)
+        body = b"".join(struct.pack("<8f", p[0], p[1], p[2], 1.0, p[3], 0, 0, 0) for p in c)
+        pc = header(i, t, "radar") + struct.pack("<II", 1, len(c)) + struct.pack("<I", 4)
+        for name, off in (("x", 0), ("y", 4), ("z", 8), ("intensity", 16)):
+            pc += s(name) + struct.pack("<IBI", off, 7, 1)
+        pc += struct.pack("<BII", 0, 32, 32 * len(c)) + struct.pack("<I", len(body)) + body + struct.pack("<B", 1)
+        if i == 5:   # a stale odometry message (older than the next cloud) must be dropped, PGO.cpp:425-426
+            stale = header(999, t - 100_000_000, "odom") + s("radar") + struct.pack("<3d", -50.0, 0, 0) + struct.pack("<4d", 0, 0, 0, 1) + bytes(8 * 78)
+            rec += struct.pack("<BI", 0, len(stale)) + stale
+        rec += struct.pack("<BI", 0, len(od)) + od + struct.pack("<BI", 1, len(pc)) + pc
+    p = tmp_path / "run.rsxreplay"
+    p.write_bytes(bytes(rec))
+    exe = os.path.join(HOST, "pgo_replay")
+    r = subprocess.run([exe, str(p), "--keyframe_meter_gap", "2.0", "--sc_dist_thres", "0.45"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the oracle on the same keyframes
+    m = oracle.Manager(dist_thres=0.45)
+    want = []
+    acc = 1e6
+    for i, c in enumerate(clouds):
+        acc += 0.0 if i == 0 else (1.5 if i <= 20 else 2.5)
+        if not acc > 2.0:
+            continue
+        acc = 0.0
+        ds, _ = oracle.voxelgrid_filter(c, 0.4)
+        m.add_points(ds)
+        if len(m) < 30:
+            continue
+        lid, _, _, _ = m.detect_loop_closure()
+        if lid != -1:
+            want.append(f"Loop detected! - between {lid} and {len(m) - 1}")
+    lines = r.stdout.strip().splitlines()
+    assert lines[:-1] == want and len(want) >= 1, (lines, want)
+    assert lines[-1] == f"frames=70 keyframes={len(m)} loops={len(want)} dropped_odom=1"
+
+
+def test_odometry_recording_feeds_the_replay(tmp_path):
+    """odometry --record writes the two topics as ROS 1 wire bytes; pgo_replay reads them back."""
+    from PIL import Image
+    from navtech_radar_slam_amd import synth
+    d = tmp_path / "seq" / "polar_oxford_form"
+    d.mkdir(parents=True)
+    for i in range(3):
+        img, _, _ = synth.polar_image(5, n_targets=900, noise_seed=100 + i, t0=1_560_000_000_000_000_000 + i * 250_000_000)
+        Image.fromarray(img, mode="L").save(str(d / f"{1560000000000000000 + i * 250000000}.png"))
+    rec = tmp_path / "rec.rsxreplay"
+    r = subprocess.run([os.path.join(HOST, "odometry"), str(tmp_path / "seq"), "--record", str(rec)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert rec.read_bytes()[:10] == b"RSXREPLAY1"
+    r = subprocess.run([os.path.join(HOST, "pgo_replay"), str(rec), "--keyframe_meter_gap", "-1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.strip().splitlines()[-1] == "frames=3 keyframes=3 loops=0 dropped_odom=0"
