@@ -378,6 +378,39 @@ def cen2019_leg(device):
                     "~0.5 M candidates + one host sync for the candidate count), not HBM-bound"}
 
 
+def frontend_leg(device):
+    """the ORORA front end between the cen2019 keypoints and the solver -- polar -> Cartesian remap,
+    ORB-style descriptors, brute-force Hamming knnMatch(2) + ratio -- per scan, host buffers in and out."""
+    from navtech_radar_slam_amd import cen2019, frontend, synth
+    img0, az, _ = synth.polar_image(100, noise_seed=1)
+    img1, _, _ = synth.polar_image(100, noise_seed=2)
+    ex = cen2019.Cen2019(rows=400, cols=3360, device=device)
+    fe = frontend.Frontend(400, 3360, device=device)
+
+    def keypoints(img):
+        t = ex.extract(img)
+        rr = (t[:, 1] + 0.5) * synth.RADAR_RESOLUTION
+        return np.stack([rr * np.cos(az[t[:, 0]]), rr * np.sin(az[t[:, 0]])], axis=1).astype(np.float32)
+
+    xy0, xy1 = keypoints(img0), keypoints(img1)
+    fe.cartesian(img0, az, synth.RADAR_RESOLUTION, want_image=False)
+    d0, v0 = fe.describe(xy0)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fe.cartesian(img1, az, synth.RADAR_RESOLUTION, want_image=False)
+        d1, v1 = fe.describe(xy1)
+        idx, _, _ = fe.match(d0, v0, d1, v1)
+    dt = (time.perf_counter() - t0) / reps
+    ex.close()
+    fe.close()
+    return {"ms_per_scan": dt * 1e3, "keypoints": [int(len(xy0)), int(len(xy1))], "ratio_test_matches": int((idx >= 0).sum()),
+            "cartesian_image": "964x964 f32 @ 0.2592 m", "descriptor_bits": 256, "dtype": "u8/f32/u32 popcount",
+            "hamming_pairs_per_scan": int(len(xy0)) * int(len(xy1)),
+            "note": "remap + 7x7 blur + describe + knnMatch(2) incl. the PCIe copies of the synchronous host-buffer entry; "
+                    "a radar delivers 4 scans/s"}
+
+
 def icp_leg(device):
     """the ICP loop verification that follows a ScanContext candidate
     (PGO.cpp:357-403): one keyframe scan against a +-25-keyframe submap, host buffers in."""
@@ -624,6 +657,7 @@ def main():
             out["orora"] = orora_leg(ctx.local_rank, args.no_cpu_baseline)
             out["cen2019"] = cen2019_leg(ctx.local_rank)
             out["icp"] = icp_leg(ctx.local_rank)
+            out["frontend"] = frontend_leg(ctx.local_rank)
         if not args.no_cpu_baseline:
             if db_pts is None:
                 raise SystemExit("cpu_baseline needs --data trajectory (the oracle rebuilds the DB from the clouds)")

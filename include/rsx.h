@@ -342,6 +342,39 @@ int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, 
                         const rsx_cen2019_params *params, const float *azimuths, float resolution,
                         int32_t *out_targets, float *out_xy, int32_t max_targets, int32_t *out_count);
 
+/* ============================== ORORA front end ========================================
+ * The steps between the cen2019 keypoints and the solver in the upstream file-based entry (reference README.md:26-29;
+ * SURVEY 8f rank 3): polar -> Cartesian image, ORB-style binary descriptors at the keypoints, brute-force Hamming
+ * knnMatch(k = 2) + ratio test.  Upstream uses OpenCV for all three; the sources are absent from the reference checkout,
+ * so these follow the published steps as restated in oracle/frontend_ref.c -- parity unpinned (in particular the 256
+ * test pairs come from a seeded generator, not OpenCV's learned table: not byte-compatible with cv::ORB). */
+
+typedef struct rsx_frontend rsx_frontend;
+
+typedef struct {
+  int32_t cart_pixel_width; /* W: the Cartesian image is W x W, centred on the sensor (964) */
+  float cart_resolution;    /* metres per pixel (0.2592) */
+  float ratio;              /* default nearest-neighbour distance ratio of rsx_frontend_match callers (0.8) */
+  int32_t reserved;
+} rsx_frontend_params;
+
+int rsx_frontend_default_params(rsx_frontend_params *p);
+/* one handle per polar image shape (rows azimuths x cols range bins) */
+int rsx_frontend_create(int device, int32_t rows, int32_t cols, const rsx_frontend_params *params, rsx_frontend **out);
+int rsx_frontend_destroy(rsx_frontend *h);
+/* polar image (host bytes, same layout arguments as rsx_cen2019_extract; azimuths = rows floats in rad, increasing)
+ * -> Cartesian fp32 image, kept on the GPU together with its 7 x 7 Gaussian-smoothed copy for rsx_frontend_describe;
+ * out_cart (optional, W * W floats, row 0 = farthest forward, forward = azimuth 0, azimuth grows to the right) */
+int rsx_frontend_cartesian(rsx_frontend *h, const uint8_t *img, int32_t row_stride, int32_t col_offset, const float *azimuths,
+                           float resolution, float *out_cart);
+/* 256-bit descriptors of n keypoints given in metres in the sensor frame (x forward, y right: the out_xy of
+ * rsx_cen2019_extract) on the last image: out_desc n x 32 bytes, out_valid[i] = 0 when the patch leaves the image */
+int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *out_desc, uint8_t *out_valid);
+/* knnMatch(k = 2) + ratio test of nq query descriptors against nt train descriptors: out_train_idx[i] = the nearest
+ * train descriptor if d1 < ratio * d2, else -1; out_d1 / out_d2 (optional) the two smallest Hamming distances (-1: none) */
+int rsx_frontend_match(rsx_frontend *h, const uint8_t *q_desc, const uint8_t *q_valid, int32_t nq, const uint8_t *t_desc,
+                       const uint8_t *t_valid, int32_t nt, float ratio, int32_t *out_train_idx, int32_t *out_d1, int32_t *out_d2);
+
 /* ============================== VoxelGrid downsample ===================================
  * pcl::VoxelGrid<pcl::PointXYZI>::filter with setLeafSize(leaf, leaf, leaf): the step right before
  * makeAndSaveScancontextAndKeys in the reference's keyframe path (PGO.cpp:98,482-484; leaf 0.4 set at

@@ -65,6 +65,10 @@ class IcpResult(C.Structure):
                 ("converged", C.c_int32), ("state", C.c_int32), ("reserved", C.c_int32)]
 
 
+class FrontendParams(C.Structure):
+    _fields_ = [("cart_pixel_width", C.c_int32), ("cart_resolution", C.c_float), ("ratio", C.c_float), ("reserved", C.c_int32)]
+
+
 class Cen2019Params(C.Structure):
     _fields_ = [("max_points", C.c_int32), ("min_range", C.c_int32)]
 
@@ -95,6 +99,8 @@ SYMBOLS = [
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
     "rsx_orora_register_batch", "rsx_orora_register_batch_device",
     "rsx_cen2019_default_params", "rsx_cen2019_create", "rsx_cen2019_destroy", "rsx_cen2019_extract",
+    "rsx_frontend_default_params", "rsx_frontend_create", "rsx_frontend_destroy", "rsx_frontend_cartesian",
+    "rsx_frontend_describe", "rsx_frontend_match",
     "rsx_voxelgrid_create", "rsx_voxelgrid_destroy", "rsx_voxelgrid_filter", "rsx_sc_add_points_downsampled",
     "rsx_icp_default_params", "rsx_icp_create", "rsx_icp_destroy", "rsx_icp_align",
 ]
@@ -183,6 +189,12 @@ def lib():
         L.rsx_cen2019_destroy.argtypes = [vp]
         L.rsx_cen2019_extract.argtypes = [vp, vp, i32, i32, C.POINTER(Cen2019Params), vp, C.c_float, vp, vp, i32,
                                           C.POINTER(i32)]
+        L.rsx_frontend_default_params.argtypes = [C.POINTER(FrontendParams)]
+        L.rsx_frontend_create.argtypes = [C.c_int, i32, i32, C.POINTER(FrontendParams), C.POINTER(vp)]
+        L.rsx_frontend_destroy.argtypes = [vp]
+        L.rsx_frontend_cartesian.argtypes = [vp, vp, i32, i32, vp, C.c_float, vp]
+        L.rsx_frontend_describe.argtypes = [vp, vp, i32, vp, vp]
+        L.rsx_frontend_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, C.c_float, vp, vp, vp]
         L.rsx_voxelgrid_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.rsx_voxelgrid_destroy.argtypes = [vp]
         L.rsx_voxelgrid_filter.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i32, C.c_float, vp, i64, C.POINTER(i64)]

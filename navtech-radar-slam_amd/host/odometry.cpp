@@ -9,10 +9,11 @@
 // the GPU hot path through the C-ABI:
 //     rsx_cen2019_extract       polar image -> keypoints (+ Cartesian points)
 //     rsx_orora_register_batch  matched points -> SE(2) motion
-// Everything between the two calls (keypoint association) is host glue.  Upstream uses ORB
-// descriptors + brute-force Hamming matching + PMC max-clique pruning, which SURVEY.md marks
-// out of scope for this round (8f rank 3); a mutual-nearest-neighbour gate in the sensor frame
-// stands in for it here and leaves the outlier rejection to ORORA.
+//     rsx_frontend_*            polar -> Cartesian image, ORB-style descriptors at the keypoints, brute-force Hamming
+//                               knnMatch(2) + ratio test (what upstream does with cv::remap / cv::ORB / cv::BFMatcher)
+// Upstream also prunes the matches with a PMC max-clique step before the solver; that stays out (host heuristic,
+// SURVEY 8f): the ratio test + a cross check feed ORORA, whose GNC / consensus stages reject the remaining outliers.
+// `--matcher nn` selects the round-1 stand-in instead (mutual nearest neighbours in the sensor frame, no descriptors).
 //
 // Output: one line per frame on stdout / --out file:  stamp_ns x y yaw n_keypoints n_matches
 // With -DRSX_WITH_ROS (ROS 1 present) the same data is also published on /orora/odom and
@@ -120,7 +121,9 @@ std::vector<uint8_t> read_png_gray8(const std::string &path, int *width, int *he
 
 struct Scan {
   int64_t stamp_ns = 0;
-  std::vector<float> xy;  // keypoints in the sensor frame (x,y pairs)
+  std::vector<float> xy;       // keypoints in the sensor frame (x,y pairs)
+  std::vector<uint8_t> desc;   // 32 bytes per keypoint (rsx_frontend_describe)
+  std::vector<uint8_t> valid;  // descriptor available (patch inside the Cartesian image)
 };
 
 // mutual nearest neighbours within `gate` metres (stand-in for ORB + BF-Hamming + PMC)
@@ -156,7 +159,7 @@ void associate(const Scan &prev, const Scan &cur, float gate, std::vector<float>
 
 int main(int argc, char **argv) {
   try {
-    std::string seq_dir, out_path, record_path;
+    std::string seq_dir, out_path, record_path, matcher = "orb";
     int max_frames = -1, device = 0;
     double rate_hz = 0.0;
     float gate = 6.0f;
@@ -166,6 +169,7 @@ int main(int argc, char **argv) {
       else if (a == "--record" && i + 1 < argc) record_path = argv[++i];  // ROS 1 wire bytes of both topics (rosmsg.h)
       else if (a == "--max_frames" && i + 1 < argc) max_frames = std::atoi(argv[++i]);
       else if (a == "--gate" && i + 1 < argc) gate = (float)std::atof(argv[++i]);
+      else if (a == "--matcher" && i + 1 < argc) matcher = argv[++i];  // orb (default) | nn
       else if (a.rfind("seq_dir:=", 0) == 0) seq_dir = a.substr(9);  // roslaunch-style arg
       else if (a.rfind("do_slam:=", 0) == 0) continue;                // accepted for launch compatibility
       else if (a.rfind("device:=", 0) == 0) device = std::atoi(a.c_str() + 8);    // run_orora.launch
@@ -213,6 +217,9 @@ int main(int argc, char **argv) {
 
     rsx_cen2019 *cen = nullptr;
     rsx_orora *reg = nullptr;
+    rsx_frontend *fe = nullptr;
+    const bool use_orb = matcher != "nn";
+    if (matcher != "nn" && matcher != "orb") die("--matcher must be orb or nn");
     check(rsx_orora_create(device, &reg), "rsx_orora_create");
     rsx_cen2019_params cp;
     rsx_cen2019_default_params(&cp);
@@ -228,6 +235,7 @@ int main(int argc, char **argv) {
         rows = h;
         cols = w - kMeta;
         check(rsx_cen2019_create(device, rows, cols, &cen), "rsx_cen2019_create");
+        if (use_orb) check(rsx_frontend_create(device, rows, cols, nullptr, &fe), "rsx_frontend_create");
         az.resize((size_t)rows);
       } else if (h != rows || w - kMeta != cols) {
         die(files[fi] + ": image shape changed");
@@ -245,10 +253,32 @@ int main(int argc, char **argv) {
             "rsx_cen2019_extract");
       n = std::min(n, 200000);
       cur.xy.assign(xy.begin(), xy.begin() + 2 * (size_t)n);
+      if (use_orb) {
+        check(rsx_frontend_cartesian(fe, img.data(), w, kMeta, az.data(), kResolution, nullptr), "rsx_frontend_cartesian");
+        cur.desc.resize((size_t)n * 32);
+        cur.valid.resize((size_t)n);
+        check(rsx_frontend_describe(fe, cur.xy.data(), n, cur.desc.data(), cur.valid.data()), "rsx_frontend_describe");
+      }
       size_t n_match = 0;
       if (fi > 0) {
         std::vector<float> src, dst;
-        associate(prev, cur, gate, &src, &dst);
+        if (use_orb) {
+          // knnMatch(2) + ratio in both directions, kept when they agree (cross check)
+          const int32_t np = (int32_t)(prev.xy.size() / 2);
+          std::vector<int32_t> fwd((size_t)np, -1), bwd((size_t)n, -1);
+          check(rsx_frontend_match(fe, prev.desc.data(), prev.valid.data(), np, cur.desc.data(), cur.valid.data(), n, 0.8f, fwd.data(),
+                                   nullptr, nullptr), "rsx_frontend_match");
+          check(rsx_frontend_match(fe, cur.desc.data(), cur.valid.data(), n, prev.desc.data(), prev.valid.data(), np, 0.8f, bwd.data(),
+                                   nullptr, nullptr), "rsx_frontend_match");
+          for (int32_t i = 0; i < np; i++)
+            if (fwd[(size_t)i] >= 0 && bwd[(size_t)fwd[(size_t)i]] == i) {
+              const size_t j = (size_t)fwd[(size_t)i];
+              src.insert(src.end(), {prev.xy[2 * (size_t)i], prev.xy[2 * (size_t)i + 1]});
+              dst.insert(dst.end(), {cur.xy[2 * j], cur.xy[2 * j + 1]});
+            }
+        } else {
+          associate(prev, cur, gate, &src, &dst);
+        }
         n_match = src.size() / 2;
         const size_t cap = (size_t)rsx_orora_max_correspondences();
         if (n_match > cap) {  // keep an evenly spread subset
@@ -321,6 +351,7 @@ int main(int argc, char **argv) {
     if (rec) std::fclose(rec);
     rsx_cen2019_destroy(cen);
     rsx_orora_destroy(reg);
+    rsx_frontend_destroy(fe);
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "odometry: %s\n", e.what());

@@ -620,3 +620,67 @@ class RefManager:
         yaw = C.c_float()
         lid = self._R.ref_sc_detect_between_session(self._h, key.ctypes.data, desc.ctypes.data, C.byref(yaw))
         return lid, yaw.value
+
+
+# ------------------------------------------------------------------------------------------
+# ORORA front end (oracle/frontend_ref.c) -- PARITY UNPINNED, see the header of frontend_ref.c
+# ------------------------------------------------------------------------------------------
+class FrontendRef:
+    """Polar -> Cartesian remap, ORB-style descriptors and BF-Hamming knnMatch + ratio on the CPU."""
+
+    def __init__(self, rows=400, cols=3360, W=964, cart_res=0.2592):
+        self.L = lib()
+        # the C-ABI carries cart_resolution / radar resolution as fp32: the oracle starts from the same fp32 values
+        self.rows, self.cols, self.W, self.cart_res = rows, cols, W, float(np.float32(cart_res))
+        self.gauss = np.zeros(7, dtype=np.float32)
+        self.dirs = np.zeros(60, dtype=np.float32)
+        self.pairs = np.zeros(30 * 256 * 4, dtype=np.int8)
+        self.L.feref_tables(self.gauss.ctypes.data_as(C.c_void_p), self.dirs.ctypes.data_as(C.c_void_p),
+                            self.pairs.ctypes.data_as(C.c_void_p))
+        self._map_key = None
+
+    def cartesian(self, img, azimuths, resolution, col_offset=11):
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        az = np.asarray(azimuths, dtype=np.float32)
+        key = (float(np.float32(resolution)), float(az[0]), float(az[1]) - float(az[0]))
+        W = self.W
+        if key != self._map_key:
+            self.map_rb = np.empty(W * W, dtype=np.float32)
+            self.map_ab = np.empty(W * W, dtype=np.float32)
+            self.L.feref_cart_map.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p]
+            self.L.feref_cart_map(W, self.cart_res, key[0], key[1], key[2], self.rows, self.map_rb.ctypes.data, self.map_ab.ctypes.data)
+            self._map_key = key
+        self.cart = np.empty((W, W), dtype=np.float32)
+        self.L.feref_cart_remap.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.feref_cart_remap(img.ctypes.data, self.rows, self.cols, img.shape[1], col_offset, W, self.map_rb.ctypes.data,
+                                self.map_ab.ctypes.data, self.cart.ctypes.data)
+        tmp = np.empty((W, W), dtype=np.float32)
+        self.blur = np.empty((W, W), dtype=np.float32)
+        self.L.feref_blur.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.L.feref_blur(self.cart.ctypes.data, W, self.gauss.ctypes.data, tmp.ctypes.data, self.blur.ctypes.data)
+        return self.cart
+
+    def describe(self, xy):
+        xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        n = xy.shape[0]
+        desc = np.zeros((n, 32), dtype=np.uint8)
+        valid = np.zeros(n, dtype=np.uint8)
+        self.L.feref_describe.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p]
+        self.L.feref_describe(self.cart.ctypes.data, self.blur.ctypes.data, self.W, self.cart_res, xy.ctypes.data, n,
+                              self.dirs.ctypes.data, self.pairs.ctypes.data, desc.ctypes.data, valid.ctypes.data)
+        return desc, valid
+
+    def match(self, q, qv, t, tv, ratio=0.8):
+        q = np.ascontiguousarray(q, dtype=np.uint8).reshape(-1, 32)
+        t = np.ascontiguousarray(t, dtype=np.uint8).reshape(-1, 32)
+        qv = np.ascontiguousarray(qv, dtype=np.uint8)
+        tv = np.ascontiguousarray(tv, dtype=np.uint8)
+        idx = np.empty(len(q), dtype=np.int32)
+        d1 = np.empty(len(q), dtype=np.int32)
+        d2 = np.empty(len(q), dtype=np.int32)
+        self.L.feref_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]
+        self.L.feref_match(q.ctypes.data, qv.ctypes.data, len(q), t.ctypes.data, tv.ctypes.data, len(t), float(ratio),
+                           idx.ctypes.data, d1.ctypes.data, d2.ctypes.data)
+        return idx, d1, d2

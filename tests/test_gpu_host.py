@@ -19,7 +19,8 @@ def test_scmanager_shim_two_threads():
     assert "keyframes=120" in r.stdout
 
 
-def test_file_based_odometry_entry(tmp_path):
+@pytest.mark.parametrize("matcher", ["orb", "nn"])
+def test_file_based_odometry_entry(tmp_path, matcher):
     """odometry: <seq_dir>/polar_oxford_form/*.png -> cen2019 keypoints -> association -> ORORA,
     driven like the reference launch graph drives the upstream odometry.cpp (seq_dir arg).
     Four scans of the same scene from a parked sensor (independent speckle per scan): stamps must
@@ -34,7 +35,7 @@ def test_file_based_odometry_entry(tmp_path):
         Image.fromarray(img, mode="L").save(str(d / f"{1560000000000000000 + i * 250000000}.png"))
     exe = os.path.join(HOST, "odometry")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    r = subprocess.run([exe, f"seq_dir:={tmp_path / 'seq'}", "do_slam:=true"], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, f"seq_dir:={tmp_path / 'seq'}", "do_slam:=true", "--matcher", matcher], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     rows = [line.split() for line in r.stdout.strip().splitlines()]
     assert len(rows) == 4 and rows[0][1:4] == ["0.000000", "0.000000", "0.000000"]
@@ -42,7 +43,10 @@ def test_file_based_odometry_entry(tmp_path):
     assert stamps == sorted(stamps) and stamps[1] - stamps[0] == 250_000_000
     pose = np.array([[float(v) for v in x[1:4]] for x in rows])
     assert np.abs(pose[:, :2]).max() < 0.1 and np.abs(pose[:, 2]).max() < 2e-3, pose
-    assert all(int(x[4]) > 300 for x in rows) and all(int(x[5]) > 100 for x in rows[1:])
+    # orb: ORB-style descriptors + Hamming knnMatch(2) + ratio + cross check on the GPU (the upstream front end);
+    # nn: the round-1 stand-in (mutual nearest neighbours in the sensor frame)
+    print(matcher, "matches per frame", [int(x[5]) for x in rows[1:]])
+    assert all(int(x[4]) > 300 for x in rows) and all(int(x[5]) > (30 if matcher == "orb" else 100) for x in rows[1:])
     # a missing sequence directory is an error exit, not a crash
     r = subprocess.run([exe, str(tmp_path / "nope")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "cannot list" in r.stderr
