@@ -378,6 +378,92 @@ def cen2019_leg(device):
                     "~0.5 M candidates + one host sync for the candidate count), not HBM-bound"}
 
 
+def allpairs_leg(device, n=100000, k=10):
+    """BASELINE configs[4] on ONE GPU: every keyframe of a 100 000-keyframe DB against the keyframes at least 30 older
+    than itself (rsx_sc_query_self_device: the filter's work items are the triangle of visible (tile-block, query tile)
+    pairs), top-10.  Planted revisits must come back as top-1.  The 8-GPU form of the same job is tools/bench_allpairs.py."""
+    import torch
+    from navtech_radar_slam_amd import scancontext, synth
+    descs = synth.random_descriptors(777, n, binary=True)
+    rng = np.random.default_rng(1)
+    loops = rng.integers(n // 2, n, 200)
+    rots = rng.integers(0, 60, 200)
+    for i, r in zip(loops, rots):                 # keyframe i repeats keyframe i - n/2, rotated
+        descs[i] = synth.rotate_descriptor(descs[i - n // 2], int(r))
+    g = scancontext.SCManager(device=device, capacity_hint=n)
+    g.add_descriptors_f32(descs)
+    out = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    g.query_self_device(0, 4096, k, out.data_ptr(), exclude_recent=30, stream=st)   # warm-up (workspaces)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.query_self_device(0, n, k, out.data_ptr(), exclude_recent=30, stream=st)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    res = out.cpu().numpy().view(scancontext.HIT_DTYPE).reshape(n, k)
+    uniq = np.unique(loops, return_index=True)[1]            # a keyframe planted twice keeps its last rotation
+    ok = bool(all(res["index"][i, 0] == i - n // 2 for i in loops[uniq]))
+    g.close()
+    pairs = n * (n - 31) / 2
+    return {"seconds": dt, "queries_per_sec": n / dt, "eligible_pairs_per_sec": pairs / dt, "keyframes": n, "topk": k,
+            "planted_revisits_recovered": ok, "workload": f"scancontext_allpairs_self_top{k}_db{n}_exclude30_random",
+            "note": "BASELINE configs[4] (synthetic 100k-scan DB, all-queries distance matrix) on one MI355X; the matrix is "
+                    "never materialised"}
+
+
+def slam_stream_leg(device, db_pts, db_off, n_kf=3000, every=4):
+    """BASELINE configs[3] in its one-GPU form: streaming SLAM emulation.  The trajectory keyframes arrive one by one
+    (descriptor build on the GPU); at every 4th keyframe the detector runs in the reference's candidate mode
+    (ring-key 3-NN + 3 pair distances, frozen tree prefix) AND in exhaustive mode.  Reports keyframes/s including both
+    queries; results are compared with the oracle on the same stream."""
+    from navtech_radar_slam_amd import scancontext
+    from oracle import pyoracle as po
+    n_kf = min(n_kf, len(db_off) - 1)
+    cand = scancontext.SCManager(device=device, sc_dist_thres=0.45, capacity_hint=n_kf + 8)
+    exh = scancontext.SCManager(device=device, sc_dist_thres=0.45, capacity_hint=n_kf + 8)
+    got = []
+    t0 = time.perf_counter()
+    for i in range(n_kf):
+        c = db_pts[db_off[i]:db_off[i + 1]]
+        cand.makeAndSaveScancontextAndKeys(c)
+        exh.makeAndSaveScancontextAndKeys(c)
+        if i % every == every - 1:
+            got.append((i, cand.detectLoopClosureID(full=True), exh.detectLoopClosureID(mode=scancontext.MODE_EXHAUSTIVE, full=True)))
+    dt = time.perf_counter() - t0
+    cand.close()
+    exh.close()
+    # the oracle on the same stream (candidate mode; exhaustive = scan of the same frozen prefix)
+    o = po.Manager(dist_thres=0.45)
+    cores = os.cpu_count() or 1
+    j = 0
+    same_c = same_e = 0
+    counter, tree = 0, 0
+    for i in range(n_kf):
+        o.add_points(db_pts[db_off[i]:db_off[i + 1]])
+        if i % every == every - 1:
+            want_c = o.detect_loop_closure()
+            n = i + 1
+            want_e = (-1, 0.0, 1e7, 0)
+            if n >= 31:
+                if counter % 30 == 0:
+                    tree = n - 30
+                counter += 1
+                h = o.exhaustive(o.descriptor(i), n_eligible=tree, k=1, nthreads=cores)[0]
+                if h["dist"] < 1e7:
+                    yaw = float(np.float32(np.float64(np.float32(h["shift"] * 6.0)) * np.pi / 180.0))
+                    want_e = (int(h["index"]) if h["dist"] < 0.45 else -1, yaw, float(h["dist"]), int(h["index"]))
+            same_c += got[j][1] == want_c
+            same_e += got[j][2] == want_e
+            j += 1
+    loops_c = sum(1 for g_ in got if g_[1][0] >= 0)
+    loops_e = sum(1 for g_ in got if g_[2][0] >= 0)
+    return {"keyframes": n_kf, "keyframes_per_sec": n_kf / dt, "seconds": dt, "queries": len(got), "loops_candidate_mode": loops_c,
+            "loops_exhaustive_mode": loops_e, "candidate_mode_identical_to_oracle": int(same_c), "exhaustive_mode_identical_to_oracle": int(same_e),
+            "workload": f"streaming_slam_emulation_{n_kf}_trajectory_keyframes_detect_every_{every}",
+            "note": "BASELINE configs[3] on one MI355X (two handles fed in parallel: candidate and exhaustive detector); the "
+                    "sharded form is rsx_scs_* / sharded.py"}
+
+
 def frontend_leg(device):
     """the ORORA front end between the cen2019 keypoints and the solver -- polar -> Cartesian remap,
     ORB-style descriptors, brute-force Hamming knnMatch(2) + ratio -- per scan, host buffers in and out."""
@@ -658,6 +744,14 @@ def main():
             out["cen2019"] = cen2019_leg(ctx.local_rank)
             out["icp"] = icp_leg(ctx.local_rank)
             out["frontend"] = frontend_leg(ctx.local_rank)
+            out["allpairs_100k"] = allpairs_leg(ctx.local_rank)
+            if not out["allpairs_100k"]["planted_revisits_recovered"]:
+                failures.append("all-pairs: planted revisits not recovered")
+            if db_pts is not None and not args.no_cpu_baseline:
+                out["slam_stream"] = slam_stream_leg(ctx.local_rank, db_pts, db_off)
+                ss = out["slam_stream"]
+                if ss["candidate_mode_identical_to_oracle"] != ss["queries"] or ss["exhaustive_mode_identical_to_oracle"] != ss["queries"]:
+                    failures.append("streaming SLAM emulation differs from the oracle")
         if not args.no_cpu_baseline:
             if db_pts is None:
                 raise SystemExit("cpu_baseline needs --data trajectory (the oracle rebuilds the DB from the clouds)")

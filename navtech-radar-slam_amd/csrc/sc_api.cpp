@@ -1107,8 +1107,8 @@ int rsx_sc_profile_enable(rsx_sc *h, int on) {
     for (int i = 0; i < 2 * PairProfiler::kMax; i++) RSX_HIP(hipEventCreate(&h->prof.ev[i]));
   }
   if (on) {
-    RSX_TRY(h->stats.reserve(32, h->stream, false));
-    RSX_HIP(hipMemsetAsync(h->stats.p, 0, 32, h->stream));
+    RSX_TRY(h->stats.reserve(128, h->stream, false));
+    RSX_HIP(hipMemsetAsync(h->stats.p, 0, 128, h->stream));
     RSX_HIP(hipStreamSynchronize(h->stream));
   }
   h->prof.on = on != 0;
@@ -1130,9 +1130,13 @@ int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exac
   *queries_rescored = 0;
   if (!h->stats.p) return RSX_OK;
   RSX_HIP(hipDeviceSynchronize());  // the counters are bumped by kernels on the caller's stream
-  unsigned long long v[4] = {0, 0, 0, 0};
-  RSX_HIP(hipMemcpy(v, h->stats.p, 32, hipMemcpyDeviceToHost));
-  RSX_HIP(hipMemset(h->stats.p, 0, 32));
+  unsigned long long v[16] = {0};
+  RSX_HIP(hipMemcpy(v, h->stats.p, 128, hipMemcpyDeviceToHost));
+  RSX_HIP(hipMemset(h->stats.p, 0, 128));
+  if (getenv("RSX_RESCORE_PROF") && v[1])  // region cycles of wave 0, averaged per scoring workgroup
+    fprintf(stderr, "[sc_rescore prof] per query (cycles of wave 0): load %.0f  phaseA %.0f  mergeA %.0f  phaseB %.0f  mergeX %.0f  gather %.0f  total %.0f\n",
+            (double)v[4] / v[1], (double)v[5] / v[1], (double)v[6] / v[1], (double)v[7] / v[1], (double)v[8] / v[1], (double)v[9] / v[1],
+            (double)v[10] / v[1]);
   *candidates = (int64_t)v[0];
   *exact_evals = v[2] ? (int64_t)v[2] : (int64_t)v[0];  // one-pass scoring: every candidate is an exact evaluation
   *queries_rescored = (int64_t)v[1];

@@ -1242,8 +1242,21 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
     }
   }
 
+  // region timing for profiling runs (wave 0 of every workgroup, s_memtime): [4] query load, [5] phase A, [6] preview
+  // merge, [7] phase B, [8] exact merge, [9] gather / append, [10] whole workgroup
+  long long t_last = 0;
+  const bool timing = a.stats != nullptr && wave == 0;
+  auto tick = [&](int slot) {
+    if (!timing) return;
+    const long long t = clock64();
+    if (slot >= 0 && lane == 0) atomicAdd(a.stats + slot, (unsigned long long)(t - t_last));
+    t_last = t;
+  };
+  const long long t_begin = timing ? clock64() : 0;
+  tick(-1);
   // score cand[0..ncand) (all waves), then refresh tau
   auto score_and_merge = [&](int ncand) {
+    tick(9);
     if (ncand == 0) return;  // (uniform) nothing selected: lists and tau are unchanged
     if (a.stats && threadIdx.x == 0) {
       atomicAdd(a.stats, (unsigned long long)ncand);
@@ -1255,6 +1268,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
       load_query_to_lds(a.q, qi, smem, threadIdx.x, RS_WAVES * 64, L::OFF_QP32);
       __syncthreads();
       query_loaded = true;
+      tick(4);
     }
     scored_any = true;
     // ||v1||^2 in fp32 for the error bound of the fast alignment (every wave for itself)
@@ -1289,6 +1303,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
             cand[g] = (int32_t)slot | (ks << RS_SLOT_BITS);
           }
         }
+        tick(5);
         if (lane < a.k) {
           rsx_sc_hit h;
           h.dist = ud; h.index = ui; h.shift = us;
@@ -1301,6 +1316,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
         }
         __syncthreads();
         const double tau_ub = *s_tau;
+        tick(6);
         // (each wave using only its OWN k-th smallest upper bound saves the two barriers but quadruples the exact
         // evaluations: 43 instead of 11 per query, 7.5 instead of 4.2 ms per step)
         // ---- phase B: exact evaluation of the candidates the previews cannot exclude ----
@@ -1321,6 +1337,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
           if (bd < kBig) topk_insert(ld, li, ls, lane, a.k, bd, (int)gidx, bk);
         }
         __syncthreads();  // phase B of every wave is done with pvs / cand / xch before they are re-used
+        tick(7);
       }
     }
     if constexpr (!TWO) {
@@ -1363,6 +1380,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
     }
     __syncthreads();
     tau = *s_tau;
+    tick(8);
   };
 
   // block-wide append of this thread's candidate (wave ballot + one LDS atomic per wave)
@@ -1448,6 +1466,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   }
   __syncthreads();
   if (wave == 0) wave_select_kth(xch, RS_WAVES * a.k, a.k, lane, a.out + (int64_t)qi * a.k);
+  if (timing && lane == 0) atomicAdd(a.stats + 10, (unsigned long long)(clock64() - t_begin));
 }
 
 template <int B, int W>

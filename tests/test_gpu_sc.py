@@ -274,8 +274,8 @@ def test_full_size_10k_properties(sc, oracle):
     assert np.all(np.diff(got["dist"], axis=1) >= 0)                   # sorted
     o = oracle.Manager()
     o.add_descriptors(descs.astype(np.float64))
-    for qi in (0, 31, 63):
-        assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), k=10, nthreads=8))
+    want = o.exhaustive_batch(queries.astype(np.float64), k=10, nthreads=os.cpu_count() or 8)   # every query of the batch
+    assert np.array_equal(got, want)
     # idempotence / determinism: same launch twice gives identical bytes
     assert np.array_equal(g.query(queries, k=10), got)
 

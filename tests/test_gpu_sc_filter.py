@@ -7,6 +7,8 @@ Two contracts:
   2. results: an exhaustive query through the filter returns byte-identical top-k records to the
               oracle (and to the unfiltered exact path), including ties, padding and eligibility.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -141,8 +143,9 @@ def test_filtered_equals_unfiltered_10k(sc, oracle):
     assert np.array_equal(ga["index"][:, 0], src) and np.array_equal(ga["shift"][:, 0], rot)
     o = oracle.Manager()
     o.add_descriptors(descs.astype(np.float64))
-    for qi in (0, 100, 255):
-        assert np.array_equal(ga[qi], o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=8))
+    # EVERY query of the batch against the oracle (OpenMP over queries on all host cores)
+    want = o.exhaustive_batch(queries.astype(np.float64), n_eligible=n - 30, k=k, nthreads=os.cpu_count() or 8)
+    assert np.array_equal(ga, want)
     assert np.array_equal(a.query(queries, k=k, n_eligible=n - 30), ga)   # deterministic
     # auto mode takes the filter for this batch size
     c = sc.SCManager(capacity_hint=n)
@@ -300,8 +303,9 @@ def test_full_size_100k_properties(sc, oracle):
     assert np.array_equal(e.query(queries[:8], k=k, n_eligible=n - 30), got[:8])
     o = oracle.Manager()
     o.add_descriptors(descs.astype(np.float64))
-    for qi in (0, 95):
-        assert np.array_equal(got[qi], o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=16))
+    # every query of the batch against the oracle (96 x 100k exact pair evaluations, all host cores)
+    want = o.exhaustive_batch(queries.astype(np.float64), n_eligible=n - 30, k=k, nthreads=os.cpu_count() or 16)
+    assert np.array_equal(got, want)
 
 
 def test_rescore_beyond_the_short_list(sc, oracle):
