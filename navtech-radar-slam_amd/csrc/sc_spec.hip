@@ -671,6 +671,9 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
 #pragma unroll
         for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);  // one v_max3_f32 per pair
       }
+      // (issuing the four MFMAs back to back into four result sets and taking the maxima afterwards was tried: the 64
+      // live registers push two per-lane address registers to scratch, and their reload at the top of every tile
+      // is followed by s_waitcnt vmcnt(0) -- a drain of the DMA in flight)
       m *= r.rL;  // rcp(n_lo) = rcp(n_e): within 1 ulp of 1 / n_e, covered by the (1 + 4e-6) factor below
     } else {
     // u(n) of all 32 n_eff values of the query first (independent of stage 2), then per k4: S * u and the maximum;

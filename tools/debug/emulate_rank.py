@@ -11,7 +11,7 @@ from navtech_radar_slam_amd import scancontext as sc
 world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 n, k = 10000, 10
-descs, queries, src, rot = bench.make_db_and_queries(n, nq)
+descs, queries, src, rot = bench.random_db_and_queries(n, nq)
 tstream = torch.cuda.Stream(); torch.cuda.set_stream(tstream); st = tstream.cuda_stream
 shards = [sc.SCManager(shard_rank=r, shard_world=world, capacity_hint=n // world + 8) for r in range(world)]
 d_db = torch.from_numpy(descs).cuda()
