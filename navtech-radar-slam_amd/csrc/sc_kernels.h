@@ -131,7 +131,7 @@ const char *pair_kernel_name();
 const char *filter_kernel_name();
 
 // ---- spectral form of the filter (sc_spec.hip): same bounds contract, ~7x fewer MFMAs ----
-constexpr int SPEC_QIMG_BYTES = 10368;
+constexpr int SPEC_QIMG_BYTES = 4736;       // stream image of a query (sc_spec.hip); the mask image and flag byte follow the images
 constexpr int SPEC_DB_BYTES_PER_ENTRY = 2432;
 size_t spec_qimg_bytes(int32_t nq);
 int launch_spec_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *spT, float *aux,

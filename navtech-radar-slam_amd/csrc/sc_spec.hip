@@ -89,26 +89,40 @@ constexpr int SP_FRAGS = SP_DC_STEPS + 7 * SP_F_STEPS;  // 76 B fragments per 32
 constexpr int SP_KV = 16 * SP_FRAGS;                // 1216 fp16 per entry
 static_assert(SP_KV * 2 == SPEC_DB_BYTES_PER_ENTRY, "layout");
 
-// query image (bytes); the strides make every A-fragment read bank-conflict free: a ds_read_b128 is served
-// 16 lanes at a time and those 16 lanes (2 queries x 2 variants x 4 k4) must hit 16 different 16-byte
-// slots mod 256: k4 * 80 B (5 slots), variant stride = 4 slots mod 16, query stride = 8 slots mod 16
-constexpr int SP_DC_BYTES = 384;                    // 7 blocks x 48 B = 336, padded
-constexpr int SP_VS = 576;                          // one variant stream: 7 blocks x 80 B = 560, padded (36 slots)
-constexpr int SP_F_BYTES = 2 * SP_VS;               // 1152
-constexpr int SP_TAIL = SP_DC_BYTES + 7 * SP_F_BYTES;  // 8448: {int n_q, int flags, float sqrt(n_q)}
-// column-mask bytes for the n_eff MFMAs: M2[i] = mask bit (i mod 60); row k of the circulant reads 64
-// consecutive bytes from M2[k]; 16 copies displaced by one byte each make that read 16-byte aligned
-// (copy j = M2[j ..], row k uses copy k mod 16 at offset k - k mod 16) and, 112 B = 7 slots apart,
-// bank-conflict free for the row order of the MFMA
-constexpr int SP_MASK_OFF = SP_TAIL + 128;          // 8576
-constexpr int SP_MASK_COPY = 112;
-constexpr int SP_QS = SPEC_QIMG_BYTES;              // 10368 (648 slots = 8 mod 16)
-static_assert(SP_QS == SP_MASK_OFF + 16 * SP_MASK_COPY, "layout");
+// query image (bytes).  A stream holds the 4 `a` blocks ONCE; row k4 starts k4 blocks in and wraps around at the end of
+// the stream (round 1 stored 7 blocks so that no row wrapped: 1.75x the bytes through the LDS-DMA, whose ~10 issue
+// slots per wave and tile cost 1.5 k of the tile's 7.5 k cycles).  Every 16-byte chunk lies inside one block pair, so a
+// wrapped read is the same ds_read_b128 from (address - stream length): one v_cndmask per stage-1 slot.
+// The strides keep every A-fragment read bank-conflict free: a ds_read_b128 is served 16 lanes at a time and those
+// 16 lanes (2 queries x 2 variants x 4 k4) must hit 16 different 16-byte slots mod 256: k4 * 80 B = 5 slots (k4 * 48 B
+// = 3 slots for f = 0) gives each k4 its own class mod 4 -- a wrap moves a lane by -20 (+4 for f = 0) slots = the same
+// class -- and the variant stride (20 slots = 4 mod 16) and the query stride (296 slots = 8 mod 16) fill the class
+constexpr int SP_DC_BYTES = 192;                    // 4 blocks x 48 B (20 rings + 4 zeros)
+constexpr int SP_VS = 320;                          // one variant stream: 4 blocks x 80 B
+constexpr int SP_F_BYTES = 2 * SP_VS;               // 640
+constexpr int SP_TAIL = SP_DC_BYTES + 7 * SP_F_BYTES;  // 4672: {int n_q, int flags, float sqrt(n_q), float sqrt(a_q)}
+constexpr int SP_QS = SPEC_QIMG_BYTES;              // 4736 (296 slots = 8 mod 16)
+static_assert(SP_QS >= SP_TAIL + 16 && SP_QS % 16 == 0, "layout");
 static_assert((SP_VS / 16) % 16 == 4 && (SP_QS / 16) % 16 == 8, "bank-conflict-free strides");
+// column-mask bytes for the n_eff MFMAs, a second image per query (only tiles with a query that has an empty column
+// fetch it): M2[i] = mask bit (i mod 60); row k of the circulant reads 64 consecutive bytes from M2[k]; 16 copies
+// displaced by one byte each make that read 16-byte aligned (copy j = M2[j ..], row k uses copy k mod 16 at offset
+// k - k mod 16) and, 112 B = 7 slots apart, bank-conflict free for the row order of the MFMA
+constexpr int SP_MASK_COPY = 112;
+constexpr int SP_MASK_BYTES = 16 * SP_MASK_COPY;    // 1792 per query
 constexpr int SP_QPT = 4;                           // queries per MFMA tile
 constexpr int SP_TPP = 1;                           // tiles per LDS phase
 constexpr int SP_QPP = SP_QPT * SP_TPP;
-constexpr int SP_PHASE_BYTES = SP_QPP * SP_QS;      // 41472 = 40.5 KiB
+// one LDS tile buffer: the stream images of 4 queries in whole 1 KiB DMA pieces, then their mask images
+constexpr int SP_STREAM_PIECES = (SP_QPP * SP_QS + 1023) / 1024;   // 19
+constexpr int SP_MASKREG_OFF = SP_STREAM_PIECES * 1024;            // 19456
+constexpr int SP_MASK_PIECES = SP_QPP * SP_MASK_BYTES / 1024;      // 7
+static_assert(SP_QPP * SP_MASK_BYTES % 1024 == 0, "layout");
+constexpr int SP_PHASE_BYTES = SP_MASKREG_OFF + SP_QPP * SP_MASK_BYTES;  // 26624 = 26 KiB
+// global layout of a query batch: [nq4 stream images][nq4 mask images][nq4 flag bytes (1: the query has an empty column)]
+__host__ __device__ constexpr int64_t sp_nq4(int32_t nq) { return ((int64_t)nq + 3) / 4 * 4; }
+__host__ __device__ constexpr int64_t sp_masks_at(int32_t nq) { return sp_nq4(nq) * SP_QS; }
+__host__ __device__ constexpr int64_t sp_flags_at(int32_t nq) { return sp_nq4(nq) * (SP_QS + SP_MASK_BYTES); }
 #ifndef SP_OPT_NBUF
 #define SP_OPT_NBUF 3
 #endif
@@ -116,8 +130,9 @@ constexpr int SP_PHASE_BYTES = SP_QPP * SP_QS;      // 41472 = 40.5 KiB
 #define SP_OPT_LOCKSTEP 0   // 1: one unit per workgroup, query ranges outermost (no gain measured: the query stream is not L2-bound)
 #endif
 constexpr int SP_NBUF = SP_OPT_NBUF;                // LDS tile buffers: the DMA runs SP_NBUF - 1 tiles ahead
-static_assert(SP_PHASE_BYTES / 1024 / 4 + 1 <= 11, "wait_vmcnt_le covers <= 11 DMA instructions per wave and tile");
-static_assert(SP_PHASE_BYTES / 1024 / 4 + 1 <= 3 * SP_QPT, "the tail issues 3 DMA pieces per query");
+constexpr int SP_DMA_PER_Q = 2;  // DMA pieces a wave issues in the tail of one query
+static_assert((SP_STREAM_PIECES + SP_MASK_PIECES + 3) / 4 <= 11, "wait_vmcnt_le covers <= 11 DMA instructions per wave and tile");
+static_assert((SP_STREAM_PIECES + SP_MASK_PIECES + 3) / 4 <= SP_DMA_PER_Q * SP_QPT, "the tail issues SP_DMA_PER_Q DMA pieces per query");
 #ifndef SP_OPT_BV
 #define SP_OPT_BV 12   // VGPR-resident B fragments are SP_B_LDS .. SP_OPT_BV-1
 #endif
@@ -130,8 +145,11 @@ constexpr int SP_B_VGPR = SP_OPT_BV;  // B fragments kept in VGPRs; the rest liv
 #define SP_OPT_BLDS 8
 #endif
 constexpr int SP_B_LDS = SP_OPT_BLDS;
-constexpr int SP_BPARK_OFF = SP_NBUF * SP_PHASE_BYTES;       // after the tile buffers
-constexpr int SP_LDS_BYTES = SP_BPARK_OFF + 4 * SP_B_LDS * 1024;
+constexpr int SP_BPARK_OFF = 0;                              // before the tile buffers: a wrapped read address (row address
+                                                             // minus the stream length) then never runs below LDS address 0
+constexpr int SP_TILES_OFF = 4 * SP_B_LDS * 1024;
+constexpr int SP_LDS_BYTES = SP_TILES_OFF + SP_NBUF * SP_PHASE_BYTES;
+static_assert(SP_TILES_OFF >= SP_VS, "wrapped addresses stay non-negative");
 static_assert(SP_LDS_BYTES <= 160 * 1024, "LDS budget");
 
 // -DRSX_SPEC_INSTRUMENT=1 compiles in the timing experiments (RSX_SPEC_DBG: run without the DMA / the stores) and
@@ -164,6 +182,9 @@ __device__ __forceinline__ void static_for(F &&f) {
 // fp16 K-vector  [ f = 0: 4 x (20 values + 4 zeros) | f = 1..7: 4 x (20 re + 20 im) ]
 // returns the column mask (bit j = column j non-zero, bit 63 = non-finite element)
 // ------------------------------------------------------------------------------------------
+// QIMG: kv is the stream image of a query instead (f = 0: the same 96 halves; f >= 1: 320 halves, the re stream
+// 4 x [re 20 | im 20] followed by the im stream 4 x [im 20 | -re 20])
+template <bool QIMG>
 __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const double *__restrict__ nrm, double *xn,
                                           _Float16 *kv, int lane, float &sqrt_a) {
   bool nonzero = false, bad = false;
@@ -208,10 +229,17 @@ __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const dou
     if (f == 0) {
       kv[a * 24 + r] = (_Float16)(float)re;
       dc_energy += re * re;
-    } else {
+    } else if constexpr (!QIMG) {
       const int base = 96 + (f - 1) * 160 + a * 40 + r;
       kv[base] = (_Float16)(float)re;
       kv[base + 20] = (_Float16)(float)im;
+    } else {
+      const int base = (SP_DC_BYTES + (f - 1) * SP_F_BYTES) / 2 + a * 40 + r;
+      const _Float16 hr = (_Float16)(float)re, hi = (_Float16)(float)im;
+      kv[base] = hr;
+      kv[base + 20] = hi;
+      kv[base + SP_VS / 2] = hi;
+      kv[base + SP_VS / 2 + 20] = -hr;
     }
   }
   if (lane < 16) kv[(lane >> 2) * 24 + 20 + (lane & 3)] = (_Float16)0.0f;  // K padding of f = 0
@@ -235,7 +263,7 @@ __global__ __launch_bounds__(256) void sc_spec_db_kernel(const float *__restrict
   if (it >= count) return;
   const int64_t slot = first + it;
   float sqrt_a;
-  (void)spectra_of(desc + slot * DS, norm + slot * NS, xn[wave], kv[wave], lane, sqrt_a);
+  (void)spectra_of<false>(desc + slot * DS, norm + slot * NS, xn[wave], kv[wave], lane, sqrt_a);
   if (lane == 0) aux[slot] = sqrt_a;
   const int64_t tile = slot >> 5;
   const int col = (int)(slot & 31);
@@ -243,64 +271,39 @@ __global__ __launch_bounds__(256) void sc_spec_db_kernel(const float *__restrict
     spT[(tile * SP_FRAGS + (c >> 1)) * 64 + (c & 1) * 32 + col] = *reinterpret_cast<const uint4 *>(&kv[wave][c * 8]);
 }
 
-// query image: the LDS layout of the filter kernel, SP_QS bytes per query
-//   [0, 384)                f = 0 stream: 7 blocks (a = 0,1,2,3,0,1,2) x 24
-//   [384 + (f-1)*1152 ...)  re stream: 7 blocks x [Qr | Qi];  + 576: im stream: 7 blocks x [Qi | -Qr]
-//   [8448, 8576)            n_q, flags, sqrt(n_q), sqrt(a_q)
-//   [8576, 10368)           16 displaced copies of the column-mask byte stream
+// query images (see the layout constants): stream image = the LDS layout of the filter kernel
+//   [0, 192)                  f = 0 stream: 4 blocks (a = 0..3) x 24 halves
+//   [192 + (f-1)*640 ...)     re stream: 4 blocks x [Qr | Qi];  + 320: im stream: 4 blocks x [Qi | -Qr]
+//   [4672, 4688)              n_q, flags, sqrt(n_q), sqrt(a_q)
+// mask image = 16 displaced copies of the column-mask byte stream; flag byte = the query has an empty column
 __global__ __launch_bounds__(256) void sc_spec_query_kernel(const float *__restrict__ desc, const double *__restrict__ norm,
                                                             int32_t nq, char *__restrict__ qimg) {
   __shared__ double xn[4][DS + 32];
-  __shared__ __attribute__((aligned(16))) _Float16 kv[4][SP_KV];
+  __shared__ __attribute__((aligned(16))) _Float16 img[4][SP_TAIL / 2];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q = blockIdx.x * 4 + wave;
   if (q >= nq) return;
   float sqrt_a;
-  const u64 m = spectra_of(desc + (int64_t)q * DS, norm + (int64_t)q * NS, xn[wave], kv[wave], lane, sqrt_a);
-  const _Float16 *k = kv[wave];
+  const u64 m = spectra_of<true>(desc + (int64_t)q * DS, norm + (int64_t)q * NS, xn[wave], img[wave], lane, sqrt_a);
+  const int n = __popcll(m & kMask60);
   uint4 *out = reinterpret_cast<uint4 *>(qimg + (int64_t)q * SP_QS);
   for (int c = lane; c < SP_QS / 16; c += 64) {
-    half8 v;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int h = c * 8 + i;  // half index inside the image
-      _Float16 x = (_Float16)0.0f;
-      if (h < SP_DC_BYTES / 2) {
-        if (h < 7 * 24) x = k[h % 96];
-      } else if (h < SP_TAIL / 2) {
-        const int h2 = h - SP_DC_BYTES / 2;
-        const int f = h2 / (SP_F_BYTES / 2), w = h2 - f * (SP_F_BYTES / 2);  // f = 0..6 <-> frequency f+1
-        const int base = 96 + f * 160;
-        if (w < SP_VS / 2) {
-          if (w < 280) x = k[base + w % 160];
-        } else {
-          const int p = w - SP_VS / 2;
-          if (p < 280) {
-            const int blk = (p / 40) & 3, t = p % 40;
-            x = (t < 20) ? k[base + blk * 40 + 20 + t] : -k[base + blk * 40 + t - 20];
-          }
-        }
-      }
-      v[i] = x;
-    }
-    uint4 o = *reinterpret_cast<const uint4 *>(&v);
-    if (c >= SP_MASK_OFF / 16) {
-      const int byte0 = c * 16 - SP_MASK_OFF;
-      const int j = byte0 / SP_MASK_COPY, i0 = byte0 - j * SP_MASK_COPY;  // 112 = 7 chunks: no chunk straddles copies
-      unsigned w[4] = {0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int i = 0; i < 16; i++) w[i >> 2] |= (unsigned)(((m >> ((j + i0 + i) % NS)) & 1ull) * 0x38ull) << (8 * (i & 3));
-      o = uint4{w[0], w[1], w[2], w[3]};
-    }
-    if (c == SP_TAIL / 16) {
-      const int n = __popcll(m & kMask60);
-      o.x = (unsigned)n;
-      o.y = (m & kNonFinite) ? 1u : 0u;
-      o.z = __float_as_uint(sqrtf((float)n));
-      o.w = __float_as_uint(sqrt_a);
-    }
+    uint4 o = uint4{0u, 0u, 0u, 0u};
+    if (c < SP_TAIL / 16) o = *reinterpret_cast<const uint4 *>(&img[wave][c * 8]);
+    else if (c == SP_TAIL / 16)
+      o = uint4{(unsigned)n, (m & kNonFinite) ? 1u : 0u, __float_as_uint(sqrtf((float)n)), __float_as_uint(sqrt_a)};
     out[c] = o;
   }
+  uint4 *mout = reinterpret_cast<uint4 *>(qimg + sp_masks_at(nq) + (int64_t)q * SP_MASK_BYTES);
+  for (int c = lane; c < SP_MASK_BYTES / 16; c += 64) {
+    const int byte0 = c * 16;
+    const int j = byte0 / SP_MASK_COPY, i0 = byte0 - j * SP_MASK_COPY;  // 112 = 7 chunks: no chunk straddles copies
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int i = 0; i < 16; i++) w[i >> 2] |= (unsigned)(((m >> ((j + i0 + i) % NS)) & 1ull) * 0x38ull) << (8 * (i & 3));
+    mout[c] = uint4{w[0], w[1], w[2], w[3]};
+  }
+  if (lane == 0) reinterpret_cast<unsigned char *>(qimg + sp_flags_at(nq))[q] = (n != NS) ? 1 : 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -323,23 +326,14 @@ struct SpecArgs {
   const int64_t *tb_cum;
 };
 
-// global -> LDS DMA of one query tile, 1 KiB pieces dealt round-robin to the 4 waves; returns the number of
-// DMA instructions this wave issued (each counts once on vmcnt)
-__device__ __forceinline__ int stage_queries(const char *gsrc, char *ldst, int nbytes, int wave, int lane) {
-  const int npieces = (nbytes + 1023) >> 10;
-  for (int c = wave; c < npieces; c += 4)
-    if (c * 1024 + lane * 16 < nbytes)  // nbytes is a multiple of 16; the last piece may be partial
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(gsrc + c * 1024 + lane * 16)),
-                                       (AS3 void *)(ldst + c * 1024), 16, 0, 0);
-  return npieces > wave ? (npieces - wave + 3) >> 2 : 0;
-}
-
 // the DMA of a later tile, issued piecewise from inside the tail of the current one: an LDS-DMA instruction
 // costs 100-185 cycles of issue next to ds_reads (stage 1) and 25-60 in VALU-only stretches (the tail)
 struct TileDma {
-  const char *gsrc;
-  char *ldst;
-  int nbytes;  // 0: nothing to load
+  const char *gsrc;    // stream images of the tile's queries
+  const char *gsrc_m;  // their mask images
+  char *ldst;          // LDS tile buffer
+  int nbytes;          // 0: nothing to load
+  int nbytes_m;        // 0: no query of the tile has an empty column
 };
 // where the bounds of a tile go: a wave-uniform row base (&lb[first query of the tile][0], scalar registers) plus a
 // 32-bit per-lane byte offset -- a 64-bit per-lane address was spilled to scratch, and every scratch reload in the
@@ -351,22 +345,38 @@ struct TileOut {
   int nq_here;        // valid queries in the tile
   bool n_ok;          // this lane's entry exists
 };
-__device__ __forceinline__ int dma_pieces_of_wave(int nbytes, int wave) {
-  const int npieces = (nbytes + 1023) >> 10;
-  return npieces > wave ? (npieces - wave + 3) >> 2 : 0;
+// The pieces of a tile are numbered 0 .. SP_STREAM_PIECES-1 (streams) and SP_STREAM_PIECES .. +SP_MASK_PIECES-1 (masks);
+// piece c belongs to wave c % 4.  Number of DMA instructions the wave issues for the tile (each counts once on vmcnt):
+__device__ __forceinline__ int dma_pieces_of_wave(const TileDma &d, int wave) {
+  const int np = (d.nbytes + 1023) >> 10, npm = (d.nbytes_m + 1023) >> 10;
+  const int w_m = (wave - SP_STREAM_PIECES) & 3;  // first mask piece of this wave
+  return (np > wave ? (np - wave + 3) >> 2 : 0) + (npm > w_m ? (npm - w_m + 3) >> 2 : 0);
 }
 // pieces j0 .. j0+count-1 of this wave (piece j of wave w is chunk w + 4 j)
 __device__ __forceinline__ void dma_issue(const TileDma &d, int wave, int lane, int j0, int count) {
+  const int wu = __builtin_amdgcn_readfirstlane(wave);  // scalar piece number: scalar base address and LDS address
   for (int j = j0; j < j0 + count; j++) {
-    const int c = wave + 4 * j;
+    const int c = wu + 4 * j;
+    const bool is_mask = c >= SP_STREAM_PIECES;
+    const int cc = is_mask ? c - SP_STREAM_PIECES : c;
     // scalar base + 32-bit lane offset, formed HERE: hoisted to the top of the tile the dozen 64-bit addresses
     // do not fit the register file and come back from scratch
-    unsigned off = (unsigned)(c * 1024 + lane * 16);
+    unsigned off = (unsigned)(cc * 1024 + lane * 16);
     asm volatile("" : "+v"(off));
-    if ((int)off < d.nbytes)
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(d.gsrc) + off),
-                                       (AS3 void *)(d.ldst + c * 1024), 16, 0, 0);
+    if ((int)off < (is_mask ? d.nbytes_m : d.nbytes))
+      __builtin_amdgcn_global_load_lds(
+          reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(is_mask ? d.gsrc_m : d.gsrc) + off),
+          (AS3 void *)(d.ldst + c * 1024), 16, 0, 0);
   }
+}
+
+// one dword through the scalar cache, for a wave-uniform address, waited for on the spot (lgkmcnt(0): only where no
+// LDS read is meant to stay in flight).  Left to the compiler the flag words came through global_load_dword, and the
+// s_waitcnt vmcnt(0) before their use drained the DMA queue every tile.
+__device__ __forceinline__ unsigned scalar_load_u32(const unsigned *p) {
+  unsigned v;
+  asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+  return v;
 }
 
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n (the instruction takes an immediate)
@@ -401,7 +411,8 @@ typedef unsigned frag4 __attribute__((ext_vector_type(4)));  // one MFMA A fragm
 // per-lane constants of one segment
 struct SpecLane {
   unsigned dc_off, f_off;  // A-fragment offsets inside a tile of 4 query images (f = 0 / f >= 1 streams)
-  unsigned m_off[2];       // mask-row offsets of the two n_eff M-tiles (k4 = 0,1 / 2,3)
+  unsigned c_dc, c_f;      // first 16-byte chunk of the lane's row in its stream: the read of K-step s wraps when c + 2 s >= 12 / 20
+  unsigned m_off[2];       // mask-row offsets of the two n_eff M-tiles (k4 = 0,1 / 2,3) inside the tile buffer
   unsigned bpark;          // LDS byte address of this lane's parked B fragments (1 KiB apart)
   int hh;
   half8 W;                 // stage-2 A operand (inverse DFT weights)
@@ -417,6 +428,21 @@ struct SpecLane {
 // are outstanding".
 __device__ __forceinline__ void lds_read_frag(frag4 &dst, unsigned addr, int off) {
   asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+}
+// the A fragment of K-step s of a 4-block stream: lanes whose row has run off the end of the stream (chunk c + 2 s
+// >= NCH) read from `wrapped` = addr - stream length.  Whether any lane wraps at step s is known at compile time
+// (c <= CMAX), so the first steps cost nothing; the others one v_cmp + one v_cndmask in the slot's free VALU issue
+template <int S, int NCH, int CMAX>
+__device__ __forceinline__ void lds_read_stream(frag4 &dst, unsigned addr, unsigned wrapped, unsigned c, int off) {
+  if constexpr (CMAX + 2 * S < NCH) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off));
+  } else {
+    unsigned a;
+    asm volatile("v_cmp_lt_u32_e32 vcc, %4, %3\n\tv_cndmask_b32_e32 %1, %2, %5, vcc\n\tds_read_b128 %0, %1 offset:%6"
+                 : "=v"(dst), "=&v"(a)
+                 : "v"(addr), "v"(c), "n"(NCH - 1 - 2 * S), "v"(wrapped), "n"(off)
+                 : "vcc");
+  }
 }
 template <int N>
 __device__ __forceinline__ void lds_wait_count() {
@@ -435,11 +461,12 @@ constexpr int SP_S1 = SP_FRAGS;   // 76 stage-1 MFMA slots per tile
 #define SP_OPT_DEPTH 8
 #endif
 constexpr int SP_DEPTH = SP_OPT_DEPTH;  // A fragments in flight
-// per-query LDS reads of the tail: 4 mask reads (2 M-tiles x 32 bytes) + the query's {n_q, flags, sqrt n_q, sqrt a_q}
-// words.  ALL of them go through inline asm: a plain C++ LDS load after a global_load_lds makes the compiler insert
-// s_waitcnt vmcnt(0) (the DMA writes LDS, so it orders the load behind every outstanding VMEM operation) -- one full
-// drain of the just-issued DMA pieces and bound stores per query, ~1 k cycles each (found in the ISA in round 2)
-constexpr int SP_MREADS = 5;
+// per-query LDS reads of the tail: the query's {n_q, flags, sqrt n_q, sqrt a_q} words, requested one query ahead, and --
+// only for a query with an empty column -- 4 mask reads (2 M-tiles x 32 bytes).  ALL of them go through inline asm: a
+// plain C++ LDS load after a global_load_lds makes the compiler insert s_waitcnt vmcnt(0) (the DMA writes LDS, so it
+// orders the load behind every outstanding VMEM operation) -- one full drain of the just-issued DMA pieces and bound
+// stores per query, ~1 k cycles each (found in the ISA in round 2)
+constexpr int SP_MREADS = 1;  // reads of query 0's tail data issued inside stage 1
 
 // Stage-1 slot schedule.  Two frequencies are always in progress and their MFMAs alternate, so that no MFMA
 // follows another one on the SAME accumulator with LDS reads / VALU instructions in between (that pattern
@@ -530,9 +557,6 @@ __device__ __forceinline__ Recip recip_setup(const frag4 &tail, const SpecLane &
 #ifndef SP_OPT_PACK
 #define SP_OPT_PACK 2   // j packed per slot
 #endif
-#ifndef SP_OPT_MK2
-#define SP_OPT_MK2 0    // 1: mask bytes double buffered (no gain measured)
-#endif
 constexpr int kPackPerSlot = SP_OPT_PACK;
 constexpr int kPackSlots = 16 / kPackPerSlot;
 // three accumulator sets, frequency f -> acc[f % 3]: the pair (f_2g, f_2g+1) is packed while f_2g+2 runs and
@@ -552,25 +576,24 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
   u4 P[16];
   floatx16 acc[kAccSets];
   frag4 ring[SP_DEPTH];
-  frag4 mk[SP_OPT_MK2 ? 2 : 1][SP_MREADS];  // mask bytes of the current (/ next) query
+  frag4 tw;     // {n_q, flags, sqrt n_q, sqrt a_q} of the current query, requested one query ahead
+  frag4 mk[4];  // mask bytes (queries with an empty column only)
   const unsigned a_dc = tile_lds + ln.dc_off, a_f = tile_lds + ln.f_off;
+  const unsigned a_dcw = a_dc - SP_DC_BYTES, a_fw = a_f - SP_VS;
   const unsigned a_m0 = tile_lds + ln.m_off[0], a_m1 = tile_lds + ln.m_off[1];
   const unsigned a_tl = tile_lds + SP_TAIL;
-  // read r of query q's tail data: r < 4 mask bytes, r == 4 the {n_q, flags, sqrt n_q, sqrt a_q} words
-  auto q_read = [&](frag4 &dst, auto qc, auto rc) {
-    constexpr int q = decltype(qc)::value, r = decltype(rc)::value;
-    if constexpr (r < 4) lds_read_frag(dst, (r >> 1) ? a_m1 : a_m0, q * SP_QS + 16 * (r & 1));
-    else lds_read_frag(dst, a_tl, q * SP_QS);
+  // the A fragment of stage-1 slot t
+  auto a_read = [&](frag4 &dst, auto tc) {
+    constexpr int t = decltype(tc)::value;
+    if constexpr (kS1.slot[t].f == 0) lds_read_stream<kS1.slot[t].s, SP_DC_BYTES / 16, 10>(dst, a_dc, a_dcw, ln.c_dc, s1_off(t));
+    else lds_read_stream<kS1.slot[t].s, SP_VS / 16, 16>(dst, a_f, a_fw, ln.c_f, s1_off(t));
   };
   floatx16 z;
 #pragma unroll
   for (int i = 0; i < 16; i++) z[i] = 0.0f;
 
   frag4 bx[SP_B_LDS];  // the parked B fragments
-  static_for<SP_DEPTH>([&](auto tc) {
-    constexpr int t = decltype(tc)::value;
-    lds_read_frag(ring[t], kS1.slot[t].f == 0 ? a_dc : a_f, s1_off(t));
-  });
+  static_for<SP_DEPTH>([&](auto tc) { a_read(ring[decltype(tc)::value], tc); });
   static_for<SP_B_LDS>([&](auto tc) {
     constexpr int t = decltype(tc)::value;
     lds_read_frag(bx[t], ln.bpark, 1024 * t);
@@ -593,12 +616,8 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     else bf = B[s1_b(t)];
     if constexpr (kS1.slot[t].s == 0) acc[f % kAccSets] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, z, 0, 0, 0);
     else acc[f % kAccSets] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[f % kAccSets], 0, 0, 0);
-    if constexpr (t + SP_DEPTH < SP_S1)
-      lds_read_frag(ring[t % SP_DEPTH], kS1.slot[t + SP_DEPTH].f == 0 ? a_dc : a_f, s1_off(t + SP_DEPTH));
-    if constexpr (t >= SP_S1 - SP_MREADS) {  // mask bytes + tail words of query 0
-      constexpr int r = t - (SP_S1 - SP_MREADS);
-      q_read(mk[0][r], std::integral_constant<int, 0>{}, std::integral_constant<int, r>{});
-    }
+    if constexpr (t + SP_DEPTH < SP_S1) a_read(ring[t % SP_DEPTH], std::integral_constant<int, t + SP_DEPTH>{});
+    if constexpr (t >= SP_S1 - SP_MREADS) lds_read_frag(tw, a_tl, 0);  // tail words of query 0
     if constexpr (t >= split_begin() && t < split_begin() + 8) {
       // C_0 as fp16 hi + lo: lanes 0..31 carry hi (k = 0), lanes 32..63 lo (k = 8); both weigh 1/16.  hi = C_0
       // truncated to 11 significant bits (exact in fp16), lo = the rest (rounded to fp16 by the packing)
@@ -606,7 +625,9 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
       for (int j = 2 * (t - split_begin()); j < 2 * (t - split_begin()) + 2; j++) {
         const float v = acc[0][j];
         const float hi = __uint_as_float(__float_as_uint(v) & 0xffffe000u);
-        acc[0][j] = ln.hh ? v - hi : hi;
+        float sp = ln.hh ? v - hi : hi;
+        asm volatile("" : "+v"(sp));  // computed HERE, in the slot's free VALU issue (the compiler sinks it into the tail otherwise)
+        acc[0][j] = sp;
       }
     }
     // packing of finished frequency pairs, spread over the slots of the following frequency
@@ -615,7 +636,9 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
       if constexpr (t >= pack_begin(g) && t < pack_begin(g) + kPackSlots) {
 #pragma unroll
         for (int j = kPackPerSlot * (t - pack_begin(g)); j < kPackPerSlot * (t - pack_begin(g) + 1); j++) {
-          P[j][g] = pack2(acc[(2 * g) % kAccSets][j], acc[(2 * g + 1) % kAccSets][j]);
+          unsigned pk = pack2(acc[(2 * g) % kAccSets][j], acc[(2 * g + 1) % kAccSets][j]);
+          asm volatile("" : "+v"(pk));  // pinned to this slot: left alone the compiler keeps all 8 accumulator sets alive and
+          P[j][g] = pk;                 // packs in the tail, where the 64 conversions are not hidden by MFMAs
         }
       }
     });
@@ -630,21 +653,13 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
 
   static_for<SP_QPT>([&](auto qc) {
     constexpr int q = decltype(qc)::value;
-    constexpr int cur = SP_OPT_MK2 ? (q & 1) : 0;
-    if constexpr (SP_OPT_MK2 && q + 1 < SP_QPT) {
-      static_for<SP_MREADS>([&](auto rc) {
-        constexpr int r = decltype(rc)::value;
-        q_read(mk[(q + 1) & 1][r], std::integral_constant<int, q + 1>{}, rc);
-      });
-      lds_wait_count<SP_MREADS>();
-    } else {
-      lds_wait_count<0>();
-    }
+    lds_wait_count<0>();
     __builtin_amdgcn_sched_barrier(0);
-    frag4 tailw = mk[cur][4];
-    asm volatile("" : "+v"(tailw));  // a value of its own: mk[cur][4] is re-loaded for the next query below
+    frag4 tailw = tw;
+    asm volatile("" : "+v"(tailw));  // a value of its own: tw is re-loaded for the next query below
     const Recip r = recip_setup(tailw, ln);
-    dma_issue(dma, wave, lane, 3 * q, 3);  // <= 11 pieces per wave and tile
+    if constexpr (q + 1 < SP_QPT) lds_read_frag(tw, a_tl, (q + 1) * SP_QS);
+    dma_issue(dma, wave, lane, SP_DMA_PER_Q * q, SP_DMA_PER_Q);
     // A query whose 60 columns are all non-empty (the usual case for a radar scan) meets every entry with
     // n_eff(k) = n_e at EVERY shift (SC.cpp:78: a column pair is skipped only if one of the two is empty), so
     // [n_lo, n_hi] = {n_e}: no mask correlation, no u(n) -- max_k S_k u(n_k) = (max_k S_k) / n_e.  Wave-uniform.
@@ -652,17 +667,19 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     float m = 0.0f;  // rows 15..31 of the weight matrix are zero anyway (S >= 0 or clamped: valid)
     floatx16 nacc[2];
     if (!full_q) {
+      // the mask image of the tile is in LDS (the tile's flag word said so when its DMA was issued)
+      lds_read_frag(mk[0], a_m0, q * SP_MASK_BYTES);
+      lds_read_frag(mk[1], a_m0, q * SP_MASK_BYTES + 16);
+      lds_read_frag(mk[2], a_m1, q * SP_MASK_BYTES);
+      lds_read_frag(mk[3], a_m1, q * SP_MASK_BYTES + 16);
+      lds_wait_count<0>();
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mt = 0; mt < 2; mt++) {
-        const frag4 lo = mk[cur][2 * mt], hi = mk[cur][2 * mt + 1];
+        const frag4 lo = mk[2 * mt], hi = mk[2 * mt + 1];
         const u8v am = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         nacc[mt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), ln.Bm, z, 0, 0, 0, 0, 0, 0);
       }
-    } else {
-      asm volatile("" ::"v"(mk[cur][0]), "v"(mk[cur][1]), "v"(mk[cur][2]), "v"(mk[cur][3]));  // landed (lgkmcnt(0) above); keeps the reads of both paths identical
-    }
-    if constexpr (!SP_OPT_MK2 && q + 1 < SP_QPT) {
-      static_for<SP_MREADS>([&](auto rc) { q_read(mk[0][rc], std::integral_constant<int, q + 1>{}, rc); });
     }
     if (full_q) {
 #pragma unroll
@@ -756,14 +773,16 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
   {
     // A-fragment address of this lane inside a tile of 4 query images: row = col = 8 * query + 4 * variant + k4
     const int rq = col >> 3, rv = (col >> 2) & 1, rk = col & 3;
-    ln.dc_off = rq * SP_QS + rk * 48 + hh * 16;
-    ln.f_off = rq * SP_QS + SP_DC_BYTES + rv * SP_VS + rk * 80 + hh * 16;
+    ln.c_dc = rk * 3 + hh;
+    ln.c_f = rk * 5 + hh;
+    ln.dc_off = rq * SP_QS + ln.c_dc * 16;
+    ln.f_off = rq * SP_QS + SP_DC_BYTES + rv * SP_VS + ln.c_f * 16;
     // n_eff rows: row = col <-> (k4 = 2 * mt + col / 16, k15 = col % 16), the row order of the stage-2 output
 #pragma unroll
     for (int mt = 0; mt < 2; mt++) {
       const int k4 = 2 * mt + (col >> 4), k15 = (col & 15) == 15 ? 0 : (col & 15);
       const int k = (45 * k4 + 16 * k15) % NS;  // CRT
-      ln.m_off[mt] = SP_MASK_OFF + (k & 15) * SP_MASK_COPY + (k & ~15) + hh * 32;
+      ln.m_off[mt] = SP_MASKREG_OFF + (k & 15) * SP_MASK_COPY + (k & ~15) + hh * 32;
     }
     // stage-2 A operand: row k15 = col (rows >= 15 are zero), k = part index: lanes 0..31 {C_0 hi, Re C_1..7},
     // lanes 32..63 {C_0 lo, Im C_1..7}; weights scaled by 15/16
@@ -810,14 +829,22 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
     const bool n_ok = tile_ok && n < a.n_items;
     const int nphase = (q1 - q0 + SP_QPP - 1) / SP_QPP;
 
-    auto stage_tile = [&](int p) {  // query tile p of this segment -> LDS buffer p % SP_NBUF
+    // flag word of query tile t (4 flag bytes): non-zero when one of its queries has an empty column and the tile
+    // needs its mask image.  Wave-uniform scalar loads, requested a tile before they are used
+    const unsigned *qflags = reinterpret_cast<const unsigned *>(a.qimg + sp_flags_at(a.nq)) + __builtin_amdgcn_readfirstlane(t0);
+    auto tile_dma = [&](int p, unsigned flagword) {  // query tile p of this segment -> LDS buffer p % SP_NBUF
       const int qn = q0 + p * SP_QPP;
       const int nqs = (q1 - qn < SP_QPP) ? (q1 - qn) : SP_QPP;
-      if (kInstr && (a.dbg & 4)) return 0;
-      return stage_queries(a.qimg + (int64_t)qn * SP_QS, smem + (p % SP_NBUF) * SP_PHASE_BYTES, nqs * SP_QS, wave, lane);
+      return TileDma{a.qimg + (int64_t)qn * SP_QS, a.qimg + sp_masks_at(a.nq) + (int64_t)qn * SP_MASK_BYTES,
+                     smem + SP_TILES_OFF + (p % SP_NBUF) * SP_PHASE_BYTES, nqs * SP_QS, flagword ? nqs * SP_MASK_BYTES : 0};
     };
-    (void)stage_tile(0);  // overlaps the B loads below
-    if (SP_NBUF > 2 && nphase > 1) (void)stage_tile(1);
+    auto stage_tile = [&](int p) {
+      if (kInstr && (a.dbg & 4)) return;
+      dma_issue(tile_dma(p, scalar_load_u32(qflags + p)), wave, lane, 0, SP_DMA_PER_Q * SP_QPT);
+    };
+    stage_tile(0);  // overlaps the B loads below
+    if (SP_NBUF > 2 && nphase > 1) stage_tile(1);
+    unsigned flag_next = (SP_NBUF - 1 < nphase) ? scalar_load_u32(qflags + SP_NBUF - 1) : 0u;  // of tile p + SP_NBUF - 1, p = 0
     half8 B[SP_FRAGS];
     {
       const uint4 *src = a.spT + ((tile_ok ? tile : 0) * SP_FRAGS) * 64 + lane;
@@ -857,25 +884,27 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
     // tile cost more than the stage-1 MFMAs).  The raw barrier (no vmcnt(0), unlike __syncthreads with an
     // LDS-DMA pending) makes the other waves' pieces visible and frees buffer (p + 3) % 3 = p % 3.
     const bool prof = kInstr && a.prof && blockIdx.x == 0 && wave == 0;
+    const bool clk = a.prof && blockIdx.x == 0 && wave == 0;  // any build: the segment's cycles and wall time
     unsigned long long ps[5] = {0, 0, 0, 0, 0};
+    unsigned long long c_begin = 0, r_begin = 0;  // shader clock vs the constant 100 MHz clock: the clock the kernel ran at
+    if (clk) {
+      c_begin = prof_now();
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_begin)::"memory");
+    }
     for (int p = 0; p < nphase; p++) {
       const int qp = q0 + p * SP_QPP;
       unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0;
       if (prof) t0 = prof_now();
       // the DMA of tile p + SP_NBUF - 1: issued piecewise inside this tile's tail (waves without a tile issue it here)
-      TileDma dma{nullptr, nullptr, 0};
-      if (p + SP_NBUF - 1 < nphase && !(kInstr && (a.dbg & 4))) {
-        const int pn = p + SP_NBUF - 1, qn = q0 + pn * SP_QPP;
-        const int nqs = (q1 - qn < SP_QPP) ? (q1 - qn) : SP_QPP;
-        dma = TileDma{a.qimg + (int64_t)qn * SP_QS, smem + (pn % SP_NBUF) * SP_PHASE_BYTES, nqs * SP_QS};
-      }
-      const int n_issued = dma_pieces_of_wave(dma.nbytes, wave);
-      if (!tile_ok) dma_issue(dma, wave, lane, 0, 3 * SP_QPT);
+      TileDma dma{nullptr, nullptr, nullptr, 0, 0};
+      if (p + SP_NBUF - 1 < nphase && !(kInstr && (a.dbg & 4))) dma = tile_dma(p + SP_NBUF - 1, flag_next);
+      const int n_issued = dma_pieces_of_wave(dma, wave);
+      if (!tile_ok) dma_issue(dma, wave, lane, 0, SP_DMA_PER_Q * SP_QPT);
       const int n_young = SP_NBUF > 2 ? n_issued : 0;  // DMA instructions younger than those of tile p + 1
       if (prof) t1 = prof_now();
       const int nq_here = (q1 - qp < SP_QPP) ? (q1 - qp) : SP_QPP;
       if (tile_ok) {
-        const char *tbase = smem + (p % SP_NBUF) * SP_PHASE_BYTES;
+        const char *tbase = smem + SP_TILES_OFF + (p % SP_NBUF) * SP_PHASE_BYTES;
         float out[SP_QPT];
         spec_tile(lds_base + (unsigned)(tbase - smem), tbase, B, ln, a.eps_direct, out, a.dbg, prof ? &t2 : nullptr, dma, wave, lane,
                   TileOut{reinterpret_cast<char *>(a.lb + (int64_t)qp * a.ld_lb), (unsigned)(n * 4) + (unsigned)hh * (unsigned)(a.ld_lb * 4),
@@ -887,6 +916,8 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
       }
       if (prof) t4 = prof_now();
       if (p + 1 < nphase) {
+        // flag word of the tile whose DMA the next iteration issues; its latency falls into the wait for the DMA
+        flag_next = (p + SP_NBUF < nphase) ? scalar_load_u32(qflags + p + SP_NBUF) : 0u;
         wait_vmcnt_le(n_young);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -900,9 +931,16 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
         ps[4] += t5 - t4;  // wait + barrier
       }
     }
-    if (prof && lane == 0) {
-      for (int i = 0; i < 5; i++) a.prof[i] = ps[i];
-      a.prof[5] = (unsigned long long)nphase;
+    if (clk) {
+      unsigned long long r_end;
+      const unsigned long long c_end = prof_now();
+      asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_end)::"memory");
+      if (lane == 0) {
+        if (prof) for (int i = 0; i < 5; i++) a.prof[i] = ps[i];
+        a.prof[5] = (unsigned long long)nphase;
+        a.prof[6] = c_end - c_begin;
+        a.prof[7] = r_end - r_begin;
+      }
     }
     // segment end: everything retired before the next segment's DMA reuses the buffers
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -912,7 +950,7 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
 
 }  // namespace
 
-size_t spec_qimg_bytes(int32_t nq) { return (size_t)nq * SPEC_QIMG_BYTES + 1024; }
+size_t spec_qimg_bytes(int32_t nq) { return (size_t)(sp_flags_at(nq) + sp_nq4(nq)) + 1024; }  // + slack: the filter reads flag words up to 3 tiles ahead
 
 int launch_spec_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *spT, float *aux,
                           hipStream_t s) {
@@ -1004,8 +1042,9 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
     RSX_HIP(hipStreamSynchronize(s));
     RSX_HIP(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
     const double n = h[5] ? (double)h[5] : 1.0;
-    fprintf(stderr, "[sc_spec prof] tiles %llu: cycles per tile  dma %.0f  stage1 %.0f  tail %.0f  stores %.0f  wait+barrier %.0f\n",
-            h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+    fprintf(stderr, "[sc_spec prof] tiles %llu: cycles per tile  dma %.0f  stage1 %.0f  tail %.0f  stores %.0f  wait+barrier %.0f"
+                    "  | tile loop %.0f cycles in %.1f us: shader clock %.0f MHz\n",
+            h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, (double)h[6], h[7] / 100.0, h[7] ? 100.0 * h[6] / h[7] : 0.0);
   }
   return RSX_OK;
 }
