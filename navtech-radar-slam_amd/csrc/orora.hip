@@ -37,6 +37,26 @@ struct Params {
   int teaser_cost;     // scalar TLS cost: unweighted residuals + sum of the outliers' bounds
 };
 
+// -DRSX_ORORA_PROF=1: cycles per phase of the on-chip kernel (thread 0 of every workgroup, summed), printed by the launcher
+#ifndef RSX_ORORA_PROF
+#define RSX_ORORA_PROF 0
+#endif
+#if RSX_ORORA_PROF
+__device__ unsigned long long g_orora_prof[8];
+#define OPROF_DECL long long oprof_t = clock64()
+#define OPROF(slot)                                                            \
+  do {                                                                         \
+    if (threadIdx.x == 0) {                                                    \
+      const long long oprof_n = clock64();                                     \
+      atomicAdd(&g_orora_prof[slot], (unsigned long long)(oprof_n - oprof_t)); \
+      oprof_t = oprof_n;                                                       \
+    }                                                                          \
+  } while (0)
+#else
+#define OPROF_DECL
+#define OPROF(slot)
+#endif
+
 // ---- workgroup reductions, deterministic order ----
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -115,10 +135,112 @@ __device__ __forceinline__ double gnc_weight(double r2, double mu, double c2) {
   return sqrt(c2 * mu * (mu + 1.0) / r2) - mu;
 }
 
+// Bitonic sort of n2 = 256 * E (value, id) endpoints by a 256-thread workgroup, E per thread in registers (endpoint
+// g = tid * E + e: the chunk the sweep below gives to the thread anyway).  Compare-exchanges at a distance < E stay
+// inside the thread, at a distance < 64 E they cross lanes (__shfl_xor), and only the two largest distances (the other
+// waves) go through LDS: 3 barrier-separated passes instead of the 45 .. 78 of the plain LDS network, which was 60 % of
+// the kernel (RSX_ORORA_PROF build: 376 k of 624 k cycles per pair in the two sorts).  Same total order, so the result
+// is the same permutation bit for bit.
+template <int E>
+__device__ __forceinline__ void sort_cx(double &av, int &ai, double &bv, int &bi, bool up) {
+  const bool swap = up ? ep_less(bv, bi, av, ai) : ep_less(av, ai, bv, bi);
+  const double tv = swap ? bv : av, uv = swap ? av : bv;
+  const int ti = swap ? bi : ai, ui = swap ? ai : bi;
+  av = tv; bv = uv; ai = ti; bi = ui;
+}
+// compare-exchanges at the distances ST, ST / 2, .. 1 (compile-time register indices)
+template <int E, int ST>
+__device__ __forceinline__ void sort_in_thread(double (&v)[E], int (&id)[E], int tid, int size) {
+  if constexpr (ST >= 1) {
+    if (ST < size) {  // (uniform)
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        if ((e & ST) == 0) {
+          const bool up = ((tid * E + e) & size) == 0;
+          sort_cx<E>(v[e], id[e], v[e | ST], id[e | ST], up);
+        }
+      }
+    }
+    sort_in_thread<E, ST / 2>(v, id, tid, size);
+  }
+}
+template <int E>
+__device__ __forceinline__ void bitonic_sort_regs(int K, const double *sx, const double *sb, double *ev, int *ei) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int n2 = 256 * E;
+  double v[E];
+  int id[E];
+#pragma unroll
+  for (int e = 0; e < E; e++) {
+    const int g = tid * E + e, i = g >> 1;
+    if (i < K) {
+      const double xv = sx[i], b = sb[i];
+      v[e] = (g & 1) ? xv + b : xv - b;
+      id[e] = (g & 1) ? -i - 1 : i + 1;
+    } else {
+      v[e] = INFINITY;
+      id[e] = 0x7fffffff;
+    }
+  }
+#pragma unroll 1
+  for (int size = 2; size <= n2; size <<= 1) {
+    // distances >= 64 E: the partner is the same (lane, e) of another wave
+#pragma unroll 1
+    for (int stride = size >> 1; stride >= 64 * E; stride >>= 1) {
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        ev[tid * E + e] = v[e];
+        ei[tid * E + e] = id[e];
+      }
+      __syncthreads();
+      const bool lower = (wave & (stride / (64 * E))) == 0;
+#pragma unroll
+      for (int e = 0; e < E; e++) {
+        const int g = tid * E + e;
+        const double ov = ev[g ^ stride];
+        const int oi = ei[g ^ stride];
+        const bool up = (g & size) == 0;
+        const bool other_less = ep_less(ov, oi, v[e], id[e]);
+        const bool take = (lower == up) ? other_less : !other_less;  // keep the smaller one at the lower end of an ascending pair
+        v[e] = take ? ov : v[e];
+        id[e] = take ? oi : id[e];
+      }
+    }
+    // distances E .. 32 E: the partner is the same e of lane ^ (stride / E)
+    {
+      int stride = size >> 1;
+      if (stride > 32 * E) stride = 32 * E;
+#pragma unroll 1
+      for (; stride >= E; stride >>= 1) {
+        const int m = stride / E;
+        const bool lower = (lane & m) == 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+          const int g = tid * E + e;
+          const double ov = __shfl_xor(v[e], m);
+          const int oi = __shfl_xor(id[e], m);
+          const bool up = (g & size) == 0;
+          const bool other_less = ep_less(ov, oi, v[e], id[e]);
+          const bool take = (lower == up) ? other_less : !other_less;
+          v[e] = take ? ov : v[e];
+          id[e] = take ? oi : id[e];
+        }
+      }
+    }
+    // distances < E: inside the thread
+    sort_in_thread<E, E / 2>(v, id, tid, size);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < E; e++) ei[tid * E + e] = id[e];  // the sweep needs the order only
+  __syncthreads();
+}
+
 // Scalar TLS estimate over K intervals x[i] +- beta[i] held TPT per thread (point i = tid + t*NT).
 // sx[K], sb[K] doubles, ev[2K'] doubles, ei[2K'] ints, part[6*NT] doubles (LDS or the HBM workspace).
 template <int NT, int TPT>
-__device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[TPT], int K, double *sx, double *sb,
+__device__ __forceinline__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[TPT], int K, double *sx, double *sb,
                                    double *ev, int *ei, double *part, int teaser_cost) {
   constexpr int NW = NT / 64;
   const int tid = threadIdx.x;
@@ -132,36 +254,52 @@ __device__ double scalar_tls_block(const double (&x)[TPT], const double (&beta)[
     if (i < K) {
       sx[i] = x[t];
       sb[i] = beta[t];
-      ev[2 * i] = x[t] - beta[t];
-      ei[2 * i] = i + 1;
-      ev[2 * i + 1] = x[t] + beta[t];
-      ei[2 * i + 1] = -i - 1;
       l_sr += beta[t];
     }
   }
-  for (int e = 2 * K + tid; e < n2; e += NT) {
-    ev[e] = INFINITY;
-    ei[e] = 0x7fffffff;
-  }
   __syncthreads();
-  // bitonic sort, ascending by (value, id)
-  for (int size = 2; size <= n2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int p = tid; p < (n2 >> 1); p += NT) {
-        const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
-        const int hi = lo | stride;
-        const bool up = (lo & size) == 0;
-        const double a = ev[lo], b = ev[hi];
-        const int ia = ei[lo], ib = ei[hi];
-        const bool swap = up ? ep_less(b, ib, a, ia) : ep_less(a, ia, b, ib);
-        if (swap) {
-          ev[lo] = b; ev[hi] = a;
-          ei[lo] = ib; ei[hi] = ia;
+#if RSX_ORORA_PROF
+  long long oprof_t = clock64();
+#endif
+  if constexpr (NT == 256) {
+    switch (n2) {  // (uniform) n2 = 256 E
+      case 512: bitonic_sort_regs<2>(K, sx, sb, ev, ei); break;
+      case 1024: bitonic_sort_regs<4>(K, sx, sb, ev, ei); break;
+      case 2048: bitonic_sort_regs<8>(K, sx, sb, ev, ei); break;
+      default: bitonic_sort_regs<16>(K, sx, sb, ev, ei); break;
+    }
+  } else {
+    // large pairs (1024 threads, arrays in HBM): the plain network, ascending by (value, id)
+    for (int i = tid; i < K; i += NT) {
+      ev[2 * i] = sx[i] - sb[i];
+      ei[2 * i] = i + 1;
+      ev[2 * i + 1] = sx[i] + sb[i];
+      ei[2 * i + 1] = -i - 1;
+    }
+    for (int e = 2 * K + tid; e < n2; e += NT) {
+      ev[e] = INFINITY;
+      ei[e] = 0x7fffffff;
+    }
+    __syncthreads();
+    for (int size = 2; size <= n2; size <<= 1) {
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int p = tid; p < (n2 >> 1); p += NT) {
+          const int lo = ((p & ~(stride - 1)) << 1) | (p & (stride - 1));
+          const int hi = lo | stride;
+          const bool up = (lo & size) == 0;
+          const double a = ev[lo], b = ev[hi];
+          const int ia = ei[lo], ib = ei[hi];
+          const bool swap = up ? ep_less(b, ib, a, ia) : ep_less(a, ia, b, ib);
+          if (swap) {
+            ev[lo] = b; ev[hi] = a;
+            ei[lo] = ib; ei[hi] = ia;
+          }
         }
+        __syncthreads();
       }
-      __syncthreads();
     }
   }
+  OPROF(4);  // the sort alone (inside slot 2)
   // sweep as a scan: each thread owns a contiguous chunk of E endpoints; six running sums
   // (sum w, sum w x, sum w x^2 for the normalised cost; sum x, sum x^2, sum beta for TEASER++'s form) + cardinality
   const int E = n2 / NT;
@@ -283,6 +421,7 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
   double *part = reinterpret_cast<double *>(ws + L::PTS + L::EV + L::EI);
   Red<NW> red{red_lds};
   const int tid = threadIdx.x;
+  OPROF_DECL;
   __syncthreads();  // (persistent workgroups: the previous pair is done with ws)
   for (int i = tid; i < K; i += NT) {
     s_src[i] = src[o + i];
@@ -437,6 +576,10 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
     rot_inliers = (int)red.sum(cnt);
   }
 
+  OPROF(0);  // load + GNC rotation
+#if RSX_ORORA_PROF
+  if (tid == 0) atomicAdd(&g_orora_prof[6], (unsigned long long)it);
+#endif
   // ---- A-COTE translation: residuals and anisotropic bounds, TPT per thread ----
   double vx[TPT], vy[TPT], betx[TPT], bety[TPT];
 #pragma unroll
@@ -456,8 +599,22 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
       bety[t] = byy;
     }
   }
-  const double tx = scalar_tls_block<NT, TPT>(vx, betx, K, sx, sb, ev, ei, part, p.teaser_cost);
-  const double ty = scalar_tls_block<NT, TPT>(vy, bety, K, sx, sb, ev, ei, part, p.teaser_cost);
+  OPROF(1);  // residuals + bounds
+  // one copy of the estimator's code (it is inlined: taken by reference the TPT-element arrays would live in scratch)
+  double tx = 0.0, ty = 0.0;
+#pragma unroll 1
+  for (int axis = 0; axis < 2; axis++) {
+    double xs[TPT], bs[TPT];
+#pragma unroll
+    for (int t = 0; t < TPT; t++) {
+      xs[t] = axis ? vy[t] : vx[t];
+      bs[t] = axis ? bety[t] : betx[t];
+    }
+    const double est = scalar_tls_block<NT, TPT>(xs, bs, K, sx, sb, ev, ei, part, p.teaser_cost);
+    if (axis) ty = est;
+    else tx = est;
+  }
+  OPROF(2);  // two scalar TLS estimates
   double cnt = 0.0;
 #pragma unroll
   for (int t = 0; t < TPT; t++)
@@ -474,6 +631,7 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
     r.status = 0;
     *out = r;
   }
+  OPROF(3);
 }
 
 using LdsLayout = Layout<256, MAXK_LDS>;
@@ -625,6 +783,17 @@ int rsx_orora_register_batch_device(rsx_orora *h, const float *d_src_xy, const f
                      reinterpret_cast<const float2 *>(d_src_xy), reinterpret_cast<const float2 *>(d_dst_xy), d_offsets, kp, d_out,
                      h->big_list.as<int>(), h->big_ws.as<char>());
   RSX_HIP(hipGetLastError());
+#if RSX_ORORA_PROF
+  {
+    unsigned long long v[8] = {0}, z[8] = {0};
+    RSX_HIP(hipStreamSynchronize(s));
+    RSX_HIP(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_orora_prof), sizeof(v)));
+    RSX_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_orora_prof), z, sizeof(z)));
+    const double n = n_pairs;
+    fprintf(stderr, "[orora prof] per pair (cycles): gnc %.0f (%.1f iterations)  bounds %.0f  tls x+y %.0f (sorts %.0f)  rest %.0f\n",
+            v[0] / n, v[6] / n, v[1] / n, v[2] / n, v[4] / n, v[3] / n);
+  }
+#endif
   return RSX_OK;
 }
 
