@@ -23,7 +23,8 @@
 namespace {
 
 // Two instantiations of the same kernel:
-//   on-chip   256 threads, pairs of <= 2048 matches: points, interval endpoints and scan partials in LDS (90 KB);
+//   on-chip   256 threads, pairs of <= 2048 matches: points, interval endpoints and scan partials in LDS (64 KB: two
+//             workgroups per CU);
 //   large     1024 threads, pairs of 2049 .. 16384 matches (cen2019 can emit 10 000 keypoints per scan): the same
 //             arrays in a per-workgroup HBM workspace (L2-resident), a few persistent workgroups pulling the large
 //             pairs from a list.  Round 1 returned identity + status 2 for such a pair -- a silently lost scan pair.
@@ -268,6 +269,16 @@ __device__ __forceinline__ double scalar_tls_block(const double (&x)[TPT], const
       case 2048: bitonic_sort_regs<8>(K, sx, sb, ev, ei); break;
       default: bitonic_sort_regs<16>(K, sx, sb, ev, ei); break;
     }
+    // ev (the exchange buffer of the cross-wave passes) aliases sx / sb: put them back for the sweep
+#pragma unroll
+    for (int t = 0; t < TPT; t++) {
+      const int i = tid + t * NT;
+      if (i < K) {
+        sx[i] = x[t];
+        sb[i] = beta[t];
+      }
+    }
+    __syncthreads();
   } else {
     // large pairs (1024 threads, arrays in HBM): the plain network, ascending by (value, id)
     for (int i = tid; i < K; i += NT) {
@@ -396,10 +407,13 @@ __device__ __forceinline__ double scalar_tls_block(const double (&x)[TPT], const
 }
 
 // array sizes of one workgroup for pairs of up to MAXK matches
+// The on-chip kernel (NT = 256) sorts in registers and needs `ev` only as the exchange buffer of the three cross-wave
+// passes, while sx / sb are not read: there ev ALIASES the points / sx, sb (which are re-written after the sort), so a
+// workgroup needs 64 KB of LDS and two fit a CU (two waves per SIMD instead of one).
 template <int NT, int MAXK>
 struct Layout {
   static constexpr int PTS = MAXK * 16;        // src + dst float2 (later sx, sb doubles)
-  static constexpr int EV = 2 * MAXK * 8;
+  static constexpr int EV = NT == 256 ? 0 : 2 * MAXK * 8;
   static constexpr int EI = 2 * MAXK * 4;
   static constexpr int PART = 8 * NT * 8;
   static constexpr int TOTAL = PTS + EV + EI + PART;
@@ -416,7 +430,7 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
   float2 *s_dst = s_src + MAXK;
   double *sx = reinterpret_cast<double *>(ws);  // aliases the points once they are dead
   double *sb = sx + MAXK;
-  double *ev = reinterpret_cast<double *>(ws + L::PTS);
+  double *ev = reinterpret_cast<double *>(L::EV ? ws + L::PTS : ws);
   int *ei = reinterpret_cast<int *>(ws + L::PTS + L::EV);
   double *part = reinterpret_cast<double *>(ws + L::PTS + L::EV + L::EI);
   Red<NW> red{red_lds};
@@ -451,11 +465,14 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
       r2[t] = 0.0;
     }
     for (it = 0; it < p.max_iterations; it++) {
+      // (slots t with t * NT >= K hold no TIM in any thread: zero weight, zero contribution -- skipped, wave-uniformly)
       double C = 0.0, S = 0.0;
 #pragma unroll
       for (int t = 0; t < TPT; t++) {
-        C += w[t] * (ax[t] * bx[t] + ay[t] * by[t]);
-        S += w[t] * (ax[t] * by[t] - ay[t] * bx[t]);
+        if (t * NT < K) {
+          C += w[t] * (ax[t] * bx[t] + ay[t] * by[t]);
+          S += w[t] * (ax[t] * by[t] - ay[t] * bx[t]);
+        }
       }
       red.sum2(C, S);
       const double nrm = sqrt(C * C + S * S);
@@ -469,10 +486,12 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
       double max_r2 = 0.0;
 #pragma unroll
       for (int t = 0; t < TPT; t++) {
-        const double ex = bx[t] - (cs * ax[t] - sn * ay[t]);
-        const double ey = by[t] - (sn * ax[t] + cs * ay[t]);
-        r2[t] = ex * ex + ey * ey;
-        max_r2 = fmax(max_r2, (tid + t * NT < K) ? r2[t] : 0.0);
+        if (t * NT < K) {
+          const double ex = bx[t] - (cs * ax[t] - sn * ay[t]);
+          const double ey = by[t] - (sn * ax[t] + cs * ay[t]);
+          r2[t] = ex * ex + ey * ey;
+          max_r2 = fmax(max_r2, (tid + t * NT < K) ? r2[t] : 0.0);
+        }
       }
       if (it == 0) {
         max_r2 = red.max(max_r2);
@@ -485,8 +504,10 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
       double cost = 0.0;
 #pragma unroll
       for (int t = 0; t < TPT; t++) {
-        cost += w[t] * r2[t];
-        if (tid + t * NT < K) w[t] = gnc_weight(r2[t], mu, p.c2);
+        if (t * NT < K) {
+          cost += w[t] * r2[t];
+          if (tid + t * NT < K) w[t] = gnc_weight(r2[t], mu, p.c2);
+        }
       }
       cost = red.sum(cost);
       const double cost_diff = fabs(cost - prev_cost);
@@ -635,11 +656,11 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
 }
 
 using LdsLayout = Layout<256, MAXK_LDS>;
-constexpr int LDS_TOTAL = LdsLayout::TOTAL + LDS_RED;  // 106 KB... see static_assert
-static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+constexpr int LDS_TOTAL = LdsLayout::TOTAL + LDS_RED;
+static_assert(2 * LDS_TOTAL <= 160 * 1024, "LDS budget: two workgroups per CU");
 
 // on-chip kernel: one workgroup per pair; pairs that do not fit are written to the big list
-__global__ __launch_bounds__(256) void orora_register_kernel(const float2 *__restrict__ src, const float2 *__restrict__ dst,
+__global__ __launch_bounds__(256, 2) void orora_register_kernel(const float2 *__restrict__ src, const float2 *__restrict__ dst,
                                                              const int64_t *__restrict__ offsets, int n_pairs, Params p,
                                                              rsx_orora_result *__restrict__ out, int *__restrict__ big_list) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
