@@ -12,6 +12,7 @@
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
+#include "sc_kdtree.h"
 #include "voxelgrid.h"
 
 namespace rsx {
@@ -38,6 +39,14 @@ struct rsx_sc {
   int64_t tree_size = 0;
   bool batch_made = false;
   int64_t batch_size = 0;
+  // the ring-key search trees behind them (sc_kdtree.h): over the frozen prefix / over the whole DB of the first
+  // between-session call.  Entries are append-only, so a tree is a function of its size and is (re)built lazily
+  struct KdTreeDev {
+    DevBuf nodes, vind;
+    float low[KD_DIM], high[KD_DIM];
+    int64_t n = 0;  // 0: not built
+    int depth = 0;
+  } tree, tree_batch;
   // workspaces
   DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
   DevBuf f_qimg, f_lb, f_cand, f_cnt, f_thr, f_plan;  // filter path
@@ -326,20 +335,60 @@ int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible
                       h->partial.as<rsx_sc_hit>(), d_out, k, s);
 }
 
+// the search tree over the ring keys of entries [0, n): built on the host exactly like the reference's nanoflann tree
+// (SC.cpp:348-359 rebuilds it every TREE_MAKING_PERIOD detections on the CPU as well), searched on the device
+int ensure_tree(rsx_sc *h, rsx_sc::KdTreeDev *t, int64_t n) {
+  if (t->n == n) return RSX_OK;
+  hipStream_t s = h->stream;
+  std::vector<float> keys((size_t)n * NR);
+  RSX_HIP(hipMemcpyAsync(keys.data(), h->rkey.p, keys.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  KdTreeHost host;
+  RSX_TRY(kdtree_build_host(keys.data(), n, &host));
+  t->n = 0;
+  RSX_TRY(t->nodes.reserve(host.nodes.size() * sizeof(KdNode), s, false));
+  RSX_TRY(t->vind.reserve(host.vind.size() * sizeof(int32_t), s, false));
+  RSX_HIP(hipMemcpyAsync(t->nodes.p, host.nodes.data(), host.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, s));
+  RSX_HIP(hipMemcpyAsync(t->vind.p, host.vind.data(), host.vind.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  RSX_HIP(hipStreamSynchronize(s));  // `host` goes out of scope
+  std::memcpy(t->low, host.low, sizeof(t->low));
+  std::memcpy(t->high, host.high, sizeof(t->high));
+  t->depth = host.depth;
+  t->n = n;
+  return RSX_OK;
+}
+
 // candidate scoring shared by detect_loop_closure / between_session (SC.cpp:362-417)
-int score_candidates_and_finish(rsx_sc *h, const QueryView &qv, const float *d_qkey, int64_t n_search,
+int score_candidates_and_finish(rsx_sc *h, const QueryView &qv, const float *d_qkey, int64_t n_search, rsx_sc::KdTreeDev *tree,
                                 int mode, int32_t *loop_id, float *yaw, double *min_dist, int32_t *nn_idx) {
   hipStream_t s = h->stream;
   const int k = h->p.num_candidates;
   double best_d = 10000000;  // SC.cpp:362
   int best_align = 0, best_idx = 0;
   if (mode == RSX_SC_MODE_CANDIDATE) {
-    RSX_TRY(h->knn_ws.reserve((size_t)(n_search > 0 ? n_search : 1) * sizeof(float), s, false));
     RSX_TRY(h->small.reserve(4096, s, false));
     int32_t *d_idx = h->small.as<int32_t>();              // [k]
     float *d_kd = reinterpret_cast<float *>(d_idx + 64);  // [k]
     int32_t *d_found = d_idx + 128;
-    RSX_TRY(launch_knn(h->rkey.as<float>(), n_search, d_qkey, k, h->knn_ws.as<float>(), d_idx, d_kd, d_found, s));
+    if (n_search > 0) {
+      // nanoflann's own walk of nanoflann's own tree: the reference's candidates, ties included (sc_kdtree.h)
+      RSX_TRY(ensure_tree(h, tree, n_search));
+      KdSearchArgs ka;
+      ka.nodes = tree->nodes.as<KdNode>();
+      ka.vind = tree->vind.as<int32_t>();
+      ka.keys = h->rkey.as<float>();
+      ka.qkey = d_qkey;
+      std::memcpy(ka.low, tree->low, sizeof(ka.low));
+      std::memcpy(ka.high, tree->high, sizeof(ka.high));
+      ka.k = k;
+      ka.out_idx = d_idx;
+      ka.out_dist = d_kd;
+      ka.out_found = d_found;
+      RSX_TRY(launch_knn_tree(ka, s));
+    } else {  // an empty search set (tree_making_period > 1 with num_exclude_recent changes): no neighbour, slots stay 0
+      RSX_TRY(h->knn_ws.reserve(sizeof(float), s, false));
+      RSX_TRY(launch_knn(h->rkey.as<float>(), 0, d_qkey, k, h->knn_ws.as<float>(), d_idx, d_kd, d_found, s));
+    }
     RSX_TRY(h->pair_out.reserve((size_t)k * (sizeof(double) + sizeof(int32_t)), s, false));
     double *d_dist = h->pair_out.as<double>();
     int32_t *d_shift = reinterpret_cast<int32_t *>(d_dist + k);
@@ -461,7 +510,8 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial, &h->stats, &h->helper_ws}) b->release();
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial, &h->stats, &h->helper_ws, &h->tree.nodes, &h->tree.vind,
+                    &h->tree_batch.nodes, &h->tree_batch.vind}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
@@ -786,7 +836,7 @@ int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out) {
   qv.norm = h->norm.as<double>() + (N - 1) * NS;
   qv.nq = 1;
   out->searched = 1;
-  return score_candidates_and_finish(h, qv, h->rkey.as<float>() + (N - 1) * NR /* SC.cpp:335 */, h->tree_size, mode,
+  return score_candidates_and_finish(h, qv, h->rkey.as<float>() + (N - 1) * NR /* SC.cpp:335 */, h->tree_size, &h->tree, mode,
                                      &out->loop_id, &out->yaw_diff_rad, &out->min_dist, &out->nn_idx);
 }
 
@@ -886,7 +936,7 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
   RSX_HIP(hipMemcpyAsync(d_key, curr_key20, NR * sizeof(float), hipMemcpyHostToDevice, s));
   QueryView qv;
   RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), 1, s, &qv));
-  return score_candidates_and_finish(h, qv, d_key, h->batch_size, RSX_SC_MODE_CANDIDATE, loop_id, yaw, min_dist, nn_idx);
+  return score_candidates_and_finish(h, qv, d_key, h->batch_size, &h->tree_batch, RSX_SC_MODE_CANDIDATE, loop_id, yaw, min_dist, nn_idx);
 }
 
 static int query_device_locked(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out,

@@ -97,6 +97,12 @@ def lib():
         L.scref_dist_direct.argtypes = [C.c_void_p, C.c_void_p]
         L.scref_fast_align.argtypes = [C.c_void_p, C.c_void_p]
         L.scref_ringkey_l2.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.scref_set_knn_mode.argtypes = [C.c_void_p, C.c_int]
+        L.kdref_build.restype = C.c_void_p
+        L.kdref_build.argtypes = [C.c_void_p, C.c_int64]
+        L.kdref_free.argtypes = [C.c_void_p]
+        L.kdref_knn.restype = C.c_int
+        L.kdref_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -208,6 +214,11 @@ class Manager:
     def set_dist_thres(self, t):
         self._L.scref_set_dist_thres(self._h, float(t))
 
+    def set_knn_mode(self, tree_order=True):
+        """Candidate stage: True (default) = nanoflann's tree restated (ties in the reference's order),
+        False = brute force, lower index first among equal distances."""
+        self._L.scref_set_knn_mode(self._h, 1 if tree_order else 0)
+
     def set_params(self, lidar_height=2.0, max_radius=80.0, num_exclude_recent=30, num_candidates=3,
                    tree_making_period=30, search_ratio=0.1):
         self._L.scref_set_params(self._h, lidar_height, max_radius, num_exclude_recent, num_candidates,
@@ -299,6 +310,28 @@ def merge_topk(parts, k):
     out = np.zeros(k, dtype=HIT_DTYPE)
     lib().scref_merge_topk(parts.ctypes.data, parts.shape[0], k, out.ctypes.data)
     return out
+
+
+class KdTree:
+    """oracle/kdtree_ref.c: nanoflann's tree and search restated (what the oracle's detectors use)."""
+
+    def __init__(self, keys):
+        self._L = lib()
+        self._keys = np.ascontiguousarray(keys, dtype=np.float32)  # must outlive the tree
+        assert self._keys.ndim == 2 and self._keys.shape[1] == NR
+        self._h = self._L.kdref_build(self._keys.ctypes.data, self._keys.shape[0])
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.kdref_free(self._h)
+            self._h = None
+
+    def knn(self, q, k=3):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        idx = np.zeros(k, dtype=np.int64)
+        dist = np.zeros(k, dtype=np.float32)
+        n = self._L.kdref_knn(self._h, q.ctypes.data, k, idx.ctypes.data, dist.ctypes.data)
+        return n, idx, dist
 
 
 class RefKdTree:

@@ -7,6 +7,7 @@
  * Build: gcc -O2 -ffp-contract=off -fopenmp -fPIC -shared (oracle/Makefile).
  */
 #include "sc_ref.h"
+#include "kdtree_ref.h"
 
 #include <math.h>
 #include <stdlib.h>
@@ -344,6 +345,11 @@ struct scref_mgr {
   int64_t tree_size;              /* frozen prefix = polarcontext_invkeys_to_search_.size() */
   int batch_tree_made;            /* SC.h:119 */
   int64_t batch_tree_size;
+  /* candidate stage: 1 (default) = nanoflann's tree and walk restated (kdtree_ref.c: ties in tree visit order, like
+   * the reference), 0 = brute force with the lower index first among equal distances (round 1) */
+  int knn_mode;
+  kdref *tree[2];                 /* [0] detectLoopClosureID's tree, [1] the between-session tree; rebuilt when stale */
+  const float *tree_keys[2];
   /* SC.h:110-115 (SoA) */
   int64_t n, cap;
   double *desc;   /* n x 1200 */
@@ -361,6 +367,7 @@ scref_mgr *scref_create(void) {
   m->search_ratio = 0.1;      /* SC.h:96 */
   m->sc_dist_thres = 0.2;     /* SC.h:99 */
   m->tree_making_period = 30; /* SC.h:103 */
+  m->knn_mode = 1;
   return m;
 }
 
@@ -370,8 +377,12 @@ void scref_destroy(scref_mgr *m) {
   free(m->vkey);
   free(m->norm);
   free(m->rkey);
+  kdref_free(m->tree[0]);
+  kdref_free(m->tree[1]);
   free(m);
 }
+
+void scref_set_knn_mode(scref_mgr *m, int tree_order) { m->knn_mode = tree_order ? 1 : 0; }
 
 void scref_set_dist_thres(scref_mgr *m, double t) { m->sc_dist_thres = t; }
 
@@ -445,6 +456,18 @@ int scref_knn(const scref_mgr *m, const float *query_key, int64_t n_search, int 
   return found;
 }
 
+/* the candidates of SC.cpp:367-374 / 300-307: the tree over entries [0, n_search) as nanoflann builds it (a function of
+ * that prefix: rebuilt when the prefix, or the array behind it, changed) and nanoflann's search of it */
+static int mgr_knn(scref_mgr *m, int which, const float *query_key, int64_t n_search, int k, int64_t *out_idx, float *out_dist) {
+  if (!m->knn_mode || n_search < 1) return scref_knn(m, query_key, n_search, k, out_idx, out_dist);
+  if (!m->tree[which] || kdref_size(m->tree[which]) != n_search || m->tree_keys[which] != m->rkey) {
+    kdref_free(m->tree[which]);
+    m->tree[which] = kdref_build(m->rkey, n_search);
+    m->tree_keys[which] = m->rkey;
+  }
+  return kdref_knn(m->tree[which], query_key, k, out_idx, out_dist);
+}
+
 static int score_candidates(const scref_mgr *m, const double *q_desc, const int64_t *cand, int ncand,
                             float *yaw_diff_rad, double *min_dist_out, int *nn_idx_out) {
   double qv[NS], qn[NS];
@@ -493,7 +516,7 @@ int scref_detect_loop_closure(scref_mgr *m, float *yaw_diff_rad, double *min_dis
   int64_t cand[64];
   float cd[64];
   int k = m->num_candidates > 64 ? 64 : m->num_candidates;
-  scref_knn(m, curr_key, m->tree_size, k, cand, cd); /* SC.cpp:367-374 */
+  mgr_knn(m, 0, curr_key, m->tree_size, k, cand, cd); /* SC.cpp:367-374 */
   return score_candidates(m, curr_desc, cand, k, yaw_diff_rad, min_dist, nn_idx);
 }
 
@@ -507,7 +530,7 @@ int scref_detect_between_session(scref_mgr *m, const float *curr_key, const doub
   int64_t cand[64];
   float cd[64];
   int k = m->num_candidates > 64 ? 64 : m->num_candidates;
-  scref_knn(m, curr_key, m->batch_tree_size, k, cand, cd);
+  mgr_knn(m, 1, curr_key, m->batch_tree_size, k, cand, cd);
   return score_candidates(m, curr_desc, cand, k, yaw_diff_rad, min_dist, nn_idx);
 }
 

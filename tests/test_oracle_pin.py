@@ -116,8 +116,7 @@ def test_detector_matches_reference_manager(oracle, order, binary_z):
         assert np.array_equal(d, om.descriptor(i)) and np.array_equal(rk, om.ringkey_f32(i)) and np.array_equal(sk, om.sectorkey(i))
         got = om.detect_loop_closure()
         want = rm.detect_loop_closure()
-        # exact ring-key ties are returned in tree-visit order by nanoflann and in index order by the oracle
-        # (DESIGN.md): none occur on this data, so the candidate sets and hence the results are identical
+        # (exact ring-key ties come back in tree-visit order in both: oracle/kdtree_ref.c restates nanoflann's tree)
         assert (got[0], got[1]) == want, (i, got, want)
         loops += want[0] >= 0
     assert loops > 10
@@ -145,3 +144,76 @@ def test_what_the_summation_order_can_change(oracle):
             assert moved < 0.05 * s.size
             if name == "continuous-z":
                 assert moved == 0 and big == 0       # no exact ties between shifts: the order is invisible
+
+
+def _tie_heavy_keys(rng, n):
+    """Ring keys the way binary radar descriptors make them: multiples of 1/30 from a small range,
+    many exact duplicates -- equal distances everywhere."""
+    k = rng.integers(0, 7, size=(n, 20)).astype(np.float32) * np.float32(2.0 / 60.0)
+    dup = rng.integers(0, n, size=n // 3)
+    k[rng.integers(0, n, size=n // 3)] = k[dup]
+    return k
+
+
+@pytest.mark.parametrize("kind", ["ties", "continuous", "one_dim", "identical"])
+def test_restated_kdtree_is_nanoflann(oracle, kind):
+    """oracle/kdtree_ref.c against the reference's own nanoflann (oracle/_ref/libref_kdtree.so): the SAME neighbours in
+    the SAME order -- including neighbours at equal distance, whose order is the tree's visit order and therefore
+    depends on every split and on the order planeSplit leaves the points in."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    rng = np.random.default_rng({"ties": 1, "continuous": 2, "one_dim": 3, "identical": 4}[kind])
+    tied_orders = 0
+    for n in [1, 2, 3, 9, 10, 11, 12, 21, 64, 257, 1000, 4097]:
+        if kind == "ties":
+            keys = _tie_heavy_keys(rng, n)
+        elif kind == "continuous":
+            keys = rng.uniform(0, 2, size=(n, 20)).astype(np.float32)
+        elif kind == "one_dim":  # every split on one dimension, long runs of equal coordinates
+            keys = np.zeros((n, 20), dtype=np.float32)
+            keys[:, 7] = rng.integers(0, 5, size=n).astype(np.float32) / np.float32(3.0)
+        else:
+            keys = np.full((n, 20), np.float32(0.5))
+        mine, ref = oracle.KdTree(keys), oracle.RefKdTree(keys)
+        queries = [keys[rng.integers(0, n)] for _ in range(20)] + [_tie_heavy_keys(rng, 1)[0] for _ in range(20)]
+        queries += [rng.uniform(-1, 3, size=20).astype(np.float32) for _ in range(10)]
+        for q in queries:
+            for k in (1, 3, 10):
+                n1, i1, d1 = mine.knn(q, k)
+                n2, i2, d2 = ref.knn(q, k)
+                assert n1 == n2 and np.array_equal(i1[:n1], i2[:n2]) and np.array_equal(d1[:n1], d2[:n2]), (kind, n, k, i1, i2, d1, d2)
+                if n1 > 1 and np.any(np.diff(d1[:n1]) == 0) and np.any(np.diff(i1[:n1]) < 0):
+                    tied_orders += 1  # equal distances returned in an order that is NOT the index order
+    if kind == "ties":
+        assert tied_orders > 20  # the index tie rule of round 1 would have failed here
+
+
+@pytest.mark.parametrize("order", [1])
+def test_detector_matches_reference_manager_on_tied_ring_keys(oracle, order):
+    """Binary descriptors whose ring keys tie all the time (few occupied sectors per ring, repeated places): the candidates,
+    their order and the decision must still be the reference's.  The brute-force candidate stage (knn_mode 0) is run
+    beside it to show that the data does exercise the difference."""
+    _ref(oracle, order)
+    oracle.set_sum_order(order)
+    rng = np.random.default_rng(5)
+    places = []
+    for _ in range(12):  # sparse scans: ring occupancy counts are small integers
+        r = rng.uniform(2, 78, size=40)
+        a = rng.uniform(0, 2 * np.pi, size=40)
+        places.append(np.stack([r * np.cos(a), r * np.sin(a), np.zeros(40), np.zeros(40)], axis=1).astype(np.float32))
+    rm = oracle.RefManager(order, dist_thres=0.45)
+    om = oracle.Manager(dist_thres=0.45)
+    ob = oracle.Manager(dist_thres=0.45)
+    ob.set_knn_mode(False)
+    differs = 0
+    for i in range(260):
+        c = places[rng.integers(0, len(places))].copy()
+        c[rng.integers(0, 40, size=3), :2] *= np.float32(0.5)  # a few points move: near-duplicates, not copies
+        rm.add_points(c)
+        om.add_points(c)
+        ob.add_points(c)
+        got = om.detect_loop_closure()
+        want = rm.detect_loop_closure()
+        assert (got[0], got[1]) == want, (i, got, want)
+        differs += ob.detect_loop_closure()[0] != want[0]
+    assert differs > 0
