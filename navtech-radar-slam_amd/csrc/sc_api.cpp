@@ -45,6 +45,7 @@ struct rsx_sc {
     DevBuf nodes, vind;
     float low[KD_DIM], high[KD_DIM];
     int64_t n = 0;  // 0: not built
+    int32_t n_nodes = 0;
     int depth = 0;
   } tree, tree_batch;
   // workspaces
@@ -346,9 +347,21 @@ int ensure_tree(rsx_sc *h, rsx_sc::KdTreeDev *t, int64_t n) {
   KdTreeHost host;
   RSX_TRY(kdtree_build_host(keys.data(), n, &host));
   t->n = 0;
-  RSX_TRY(t->nodes.reserve(host.nodes.size() * sizeof(KdNode), s, false));
+  // the search kernel's 16-byte nodes (child1 = the next node: the build numbers the nodes in preorder)
+  std::vector<KdNode16> n16(host.nodes.size());
+  for (size_t i = 0; i < host.nodes.size(); i++) {
+    const KdNode &nd = host.nodes[i];
+    if (nd.child1 < 0) {
+      n16[i] = KdNode16{nd.left, -1 - (nd.right - nd.left), 0.0f, 0.0f};
+    } else {
+      if (nd.child1 != (int32_t)i + 1) return fail(RSX_ERR_RANGE, "kd-tree nodes are not in preorder");
+      n16[i] = KdNode16{nd.child2, nd.divfeat, nd.divlow, nd.divhigh};
+    }
+  }
+  t->n_nodes = (int32_t)n16.size();
+  RSX_TRY(t->nodes.reserve(n16.size() * sizeof(KdNode16), s, false));
   RSX_TRY(t->vind.reserve(host.vind.size() * sizeof(int32_t), s, false));
-  RSX_HIP(hipMemcpyAsync(t->nodes.p, host.nodes.data(), host.nodes.size() * sizeof(KdNode), hipMemcpyHostToDevice, s));
+  RSX_HIP(hipMemcpyAsync(t->nodes.p, n16.data(), n16.size() * sizeof(KdNode16), hipMemcpyHostToDevice, s));
   RSX_HIP(hipMemcpyAsync(t->vind.p, host.vind.data(), host.vind.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
   RSX_HIP(hipStreamSynchronize(s));  // `host` goes out of scope
   std::memcpy(t->low, host.low, sizeof(t->low));
@@ -373,8 +386,21 @@ int score_candidates_and_finish(rsx_sc *h, const QueryView &qv, const float *d_q
     if (n_search > 0) {
       // nanoflann's own walk of nanoflann's own tree: the reference's candidates, ties included (sc_kdtree.h)
       RSX_TRY(ensure_tree(h, tree, n_search));
+      // the true k-th smallest distance, by the parallel brute-force pass: lets the walk skip what cannot matter
+      int32_t *b_idx = d_idx + 192;
+      float *b_kd = reinterpret_cast<float *>(d_idx + 256);
+      int32_t *b_found = d_idx + 320;
+      RSX_TRY(h->knn_ws.reserve((size_t)n_search * 2 * sizeof(float), s, false));
+      float *dist_all = h->knn_ws.as<float>(), *dist_tree = dist_all + n_search;
+      RSX_TRY(launch_knn(h->rkey.as<float>(), n_search, d_qkey, k, dist_all, b_idx, b_kd, b_found, s));
+      RSX_TRY(launch_knn_tree_order(dist_all, tree->vind.as<int32_t>(), n_search, dist_tree, s));
       KdSearchArgs ka;
-      ka.nodes = tree->nodes.as<KdNode>();
+      ka.bound_dist = b_kd;
+      ka.bound_found = b_found;
+      ka.dist_tree = dist_tree;
+      ka.nodes = tree->nodes.as<KdNode16>();
+      ka.n_nodes = tree->n_nodes;
+      ka.n = n_search;
       ka.vind = tree->vind.as<int32_t>();
       ka.keys = h->rkey.as<float>();
       ka.qkey = d_qkey;

@@ -40,18 +40,35 @@ struct KdTreeHost {
 // keys: n x 20 floats, row-major.  Returns RSX_OK or an error status (last_error set).
 int kdtree_build_host(const float *keys, int64_t n, KdTreeHost *out);
 
+// what the search kernel reads: 16 bytes per node, child1 = the next node (the build numbers nodes in preorder)
+struct KdNode16 {
+  int32_t a;     // internal: child2;  leaf: first position in vind
+  int32_t b;     // internal: divfeat (>= 0);  leaf: -1 - number of points
+  float divlow, divhigh;
+};
+
 struct KdSearchArgs {
-  const KdNode *nodes;
+  const KdNode16 *nodes;
+  int32_t n_nodes;
+  int64_t n;           // points in the tree
   const int32_t *vind;
   const float *keys;   // the DB's ring keys (device)
   const float *qkey;   // 20 floats (device)
   float low[KD_DIM], high[KD_DIM];
   int32_t k;
+  // optional pruning bound: the true k-th smallest distance (bound_dist[k - 1], valid when bound_found[0] >= k), from
+  // the brute-force pass over all keys.  Subtrees that cannot hold a point at or below it are skipped; the result is
+  // unchanged (sc_kdtree.hip), the walk touches a handful of leaves instead of a third of the tree
+  const float *bound_dist;
+  const int32_t *bound_found;
+  const float *dist_tree; // optional: that pass's distances in tree order, dist_tree[i] = distance of key vind[i] (the same
+                          // float expression as evalMetric)
   int32_t *out_idx;    // [k], zero where no neighbour was found (Scancontext.cpp:367: zero-initialised vector)
   float *out_dist;     // [k]
   int32_t *out_found;  // [1]
 };
 int launch_knn_tree(const KdSearchArgs &a, hipStream_t s);
+int launch_knn_tree_order(const float *dist_all, const int32_t *vind, int64_t n, float *dist_tree, hipStream_t s);
 
 }  // namespace sc
 }  // namespace rsx

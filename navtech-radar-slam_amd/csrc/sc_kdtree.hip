@@ -1,8 +1,9 @@
 // sc_kdtree.hip -- exact k-NN in the ring-key tree, walked the way nanoflann walks it (sc_kdtree.h says why).
 //
-// One wavefront per query.  The descent is scalar work (every lane follows the same path; the state lives in LDS and
-// is written by lane 0), a leaf's <= 10 points are evaluated one per lane and then offered to the result set in the
-// leaf's order.  What is reproduced (nanoflann.hpp of the reference):
+// One wavefront per query.  The walk is scalar work that every lane performs identically (per-wave state in LDS, no
+// synchronisation inside the walk); a leaf's <= 10 distances -- from the parallel brute-force pass, in tree order --
+// are read one per lane and offered to the result set in the leaf's order.  Trees of up to ~12 000 keys are staged in
+// LDS first (16-byte nodes + distances), larger ones are read through the scalar cache.  What is reproduced (nanoflann.hpp of the reference):
 //   findNeighbors            :1222-1243   per-dimension offsets of the query from the root box, their sum
 //   searchLevel              :1347-1410   nearer child first ((val - divlow) + (val - divhigh) < 0 -> child1); the other
 //                                         child only if mindistsq + cut_dist - dists[idx] <= the k-th best (eps = 0:
@@ -10,6 +11,21 @@
 //   leaf                     :1354-1366   worst_dist is read ONCE per leaf; a point is offered iff dist < that value
 //   KNNResultSet::addPoint   :175-202     insertion that shifts strictly larger distances only (ties keep visit order)
 //   L2_Adaptor::evalMetric   :383-408     4 differences at a time, left-to-right float sums, no contraction
+//
+// Pruning with the true k-th distance D (optional; from the parallel brute-force pass over all keys).  nanoflann only
+// knows the k-th best SO FAR (>= D at every moment) and walks about a third of a 20-dimensional tree; here a subtree
+// whose lower bound exceeds D (1 + 1e-4) is skipped as well.  The result is the same:
+//  (i)   Which points at distance <= D end up in the result, and in which order, depends only on the ORDER in which the
+//        walk meets the points at distance <= D: such a point is inserted iff fewer than k points at a distance <= its
+//        own were met before its leaf was entered (the k-th best is > d iff that count is < k), and equal distances
+//        keep their visit order.  Farther points only pass through the result set.
+//  (ii)  The depth-first order of the leaves is a property of the tree and the query, not of the pruning, and every
+//        leaf that holds a point at distance <= D is visited by nanoflann (its bound is <= D <= the k-th best so far)
+//        and by this walk (bound <= D (1 + 1e-4)).
+//  (iii) The margin covers float rounding: the bound is accumulated along the path, the distance four dimensions at a
+//        time, so a bound can exceed the distance of a point on the cell boundary by an ulp or two (relative 1e-6); a
+//        disagreement between the two walks about a subtree in the margin would need a point whose distance is below
+//        its own subtree's bound by 1e-4 relative.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
@@ -25,15 +41,16 @@ namespace sc {
 namespace {
 
 constexpr int KD_KMAX = 64;
+constexpr int KD_LDS_BUDGET = 150 * 1024;  // nodes + tree-ordered distances are staged in LDS when they fit (~12 k keys)
 
+// One entry of the explicit stack.  node >= 0: the farther child of an inner node, still to be considered once the
+// nearer one is done (idx = split dimension, v = cut_dist, mind = the inner node's mindistsq); node < 0: restore
+// dists[idx] = v (the line after the second recursive call, nanoflann.hpp:1408).
 struct Frame {
   int32_t node;
-  float mindistsq;
-  int32_t state;   // 0: entered, 1: nearer child done, 2: other child done
-  int32_t idx;     // split dimension
-  int32_t other;   // the farther child
-  float cut_dist;
-  float saved;     // dists[idx] before the other child was entered
+  int32_t idx;
+  float v;
+  float mind;
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -41,146 +58,174 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64) void sc_knn_tree_kernel(KdSearchArgs a) {
+// Every lane runs the same scalar walk on the same values (the per-wave state in LDS is written by all lanes with
+// identical data, LDS operations of a wave execute in order): no lane-0 sections, no synchronisation inside the walk --
+// with those, a step cost three dependent LDS round trips and the walk of a 10 000-key tree 2 ms.
+template <bool RESIDENT>
+__device__ __forceinline__ void walk(const KdSearchArgs &a, const KdNode16 *nodes_lds, const float *dist_lds, float *q, float *dists,
+                                     Frame *stack, float *rd, int32_t *ri, float bound, float distsq, int lane) {
+  const int k = a.k;
+  int sp = 0, count = 0;
+  int cur = 0;
+  float mind = distsq;
+  float worst = FLT_MAX;  // mirrors rd[k - 1]
+  for (;;) {
+    // ---- descend to a leaf, nearer child first (searchLevel :1371-1391) ----
+    for (;;) {
+      KdNode16 nd;
+      if (RESIDENT) nd = nodes_lds[cur];
+      else nd = a.nodes[__builtin_amdgcn_readfirstlane(cur)];
+      if (nd.b < 0) {
+        // leaf (:1354-1366): worst_dist is read once; the points are offered in leaf order
+        const int cnt = -1 - nd.b, left = nd.a;
+        float dist = 0.0f;
+        if (lane < cnt) dist = RESIDENT ? dist_lds[left + lane] : a.dist_tree[left + lane];
+        const float worst_entry = worst;
+        for (int j = 0; j < cnt; j++) {
+          const float dj = __shfl(dist, j);
+          if (dj < worst_entry) {  // KNNResultSet::addPoint :175-202
+            const int32_t ij = a.vind[left + j];
+            int i;
+            for (i = count; i > 0; --i) {
+              const float prev = rd[i - 1];
+              if (prev > dj) {
+                if (i < k) {
+                  rd[i] = prev;
+                  ri[i] = ri[i - 1];
+                }
+              } else {
+                break;
+              }
+            }
+            if (i < k) {
+              rd[i] = dj;
+              ri[i] = ij;
+            }
+            if (count < k) count++;
+            worst = rd[k - 1];
+          }
+        }
+        break;
+      }
+      const int idx = nd.b;
+      const float val = q[idx];
+      const float diff1 = __fsub_rn(val, nd.divlow), diff2 = __fsub_rn(val, nd.divhigh);
+      int best, other;
+      float cut;
+      if (__fadd_rn(diff1, diff2) < 0.0f) {
+        best = cur + 1;
+        other = nd.a;
+        cut = __fmul_rn(diff2, diff2);  // accum_dist(val, divhigh)
+      } else {
+        best = nd.a;
+        other = cur + 1;
+        cut = __fmul_rn(diff1, diff1);  // accum_dist(val, divlow)
+      }
+      stack[sp++] = Frame{other, idx, cut, mind};
+      cur = best;
+    }
+    // ---- back up (:1397-1409) until a farther child has to be visited ----
+    bool again = false;
+    while (sp > 0) {
+      const Frame f = stack[--sp];
+      if (f.node < 0) {
+        dists[f.idx] = f.v;
+        continue;
+      }
+      const float dst = dists[f.idx];
+      const float m2 = __fsub_rn(__fadd_rn(f.mind, f.v), dst);
+      dists[f.idx] = f.v;
+      stack[sp++] = Frame{-1, f.idx, dst, 0.0f};
+      if (__fmul_rn(m2, 1.0f) <= worst && m2 <= bound) {  // mindistsq * epsError <= worstDist(), epsError = 1 + 0
+        cur = f.node;
+        mind = m2;
+        again = true;
+        break;
+      }
+    }
+    if (!again) break;
+  }
+  if (lane == 0) a.out_found[0] = count;
+}
+
+__global__ __launch_bounds__(64) void sc_knn_tree_kernel(KdSearchArgs a, int resident) {
+  extern __shared__ __attribute__((aligned(16))) char dyn[];
   __shared__ float q[KD_DIM];
   __shared__ float dists[KD_DIM];
-  __shared__ Frame stack[KD_STACK + 1];
+  __shared__ Frame stack[2 * KD_STACK + 2];
   __shared__ float rd[KD_KMAX];
   __shared__ int32_t ri[KD_KMAX];
-  __shared__ int32_t s_count, s_sp;
   const int lane = threadIdx.x;
   const int k = a.k;
+  const float bound = (a.bound_dist && a.bound_found && a.bound_found[0] >= k) ? a.bound_dist[k - 1] * 1.0001f + 1e-30f : INFINITY;
+  KdNode16 *nodes_lds = reinterpret_cast<KdNode16 *>(dyn);
+  float *dist_lds = reinterpret_cast<float *>(dyn + (size_t)a.n_nodes * sizeof(KdNode16));
+  if (resident) {
+    const uint4 *src = reinterpret_cast<const uint4 *>(a.nodes);
+    uint4 *dst = reinterpret_cast<uint4 *>(nodes_lds);
+    for (int i = lane; i < a.n_nodes; i += 64) dst[i] = src[i];
+    for (int64_t i = lane; i < a.n; i += 64) dist_lds[i] = a.dist_tree[i];
+  }
   if (lane < KD_DIM) q[lane] = a.qkey[lane];
   if (lane < k) {
     rd[lane] = 0.0f;
     ri[lane] = 0;  // Scancontext.cpp:367: the caller's vectors are zero-initialised
   }
   wave_sync();
-  if (lane == 0) {
-    rd[k - 1] = FLT_MAX;  // KNNResultSet::init
-    s_count = 0;
-    // computeInitialDistances (:1006-1023); `dists` starts at zero (:1235)
-    float distsq = 0.0f;
-    for (int i = 0; i < KD_DIM; i++) {
-      dists[i] = 0.0f;
-      if (q[i] < a.low[i]) {
-        const float d = __fsub_rn(q[i], a.low[i]);
-        dists[i] = __fmul_rn(d, d);
-        distsq = __fadd_rn(distsq, dists[i]);
-      }
-      if (q[i] > a.high[i]) {
-        const float d = __fsub_rn(q[i], a.high[i]);
-        dists[i] = __fmul_rn(d, d);
-        distsq = __fadd_rn(distsq, dists[i]);
-      }
+  rd[k - 1] = FLT_MAX;  // KNNResultSet::init (all lanes, the same value)
+  // computeInitialDistances (:1006-1023); `dists` starts at zero (:1235)
+  float distsq = 0.0f;
+  for (int i = 0; i < KD_DIM; i++) {
+    float di = 0.0f;
+    if (q[i] < a.low[i]) {
+      const float d = __fsub_rn(q[i], a.low[i]);
+      di = __fmul_rn(d, d);
+      distsq = __fadd_rn(distsq, di);
     }
-    stack[0] = Frame{0, distsq, 0, 0, 0, 0.0f, 0.0f};
-    s_sp = 1;
+    if (q[i] > a.high[i]) {
+      const float d = __fsub_rn(q[i], a.high[i]);
+      di = __fmul_rn(d, d);
+      distsq = __fadd_rn(distsq, di);
+    }
+    dists[i] = di;
   }
-  wave_sync();
-  for (;;) {
-    const int sp = s_sp;
-    if (sp == 0) break;
-    const Frame f = stack[sp - 1];
-    const KdNode nd = a.nodes[f.node];
-    if (nd.child1 < 0) {
-      // ---- leaf: distances one point per lane, then the sequential offers ----
-      const int cnt = nd.right - nd.left;
-      float dist = 0.0f;
-      int32_t index = 0;
-      if (lane < cnt) {
-        index = a.vind[nd.left + lane];
-        const float4 *p = reinterpret_cast<const float4 *>(a.keys + (int64_t)index * KD_DIM);
-#pragma unroll
-        for (int g = 0; g < 5; g++) {
-          const float4 v = p[g];
-          const float d0 = __fsub_rn(q[4 * g + 0], v.x), d1 = __fsub_rn(q[4 * g + 1], v.y);
-          const float d2 = __fsub_rn(q[4 * g + 2], v.z), d3 = __fsub_rn(q[4 * g + 3], v.w);
-          const float t = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(d0, d0), __fmul_rn(d1, d1)), __fmul_rn(d2, d2)), __fmul_rn(d3, d3));
-          dist = __fadd_rn(dist, t);
-        }
-      }
-      const float worst = rd[k - 1];  // read once per leaf
-      for (int j = 0; j < cnt; j++) {
-        const float dj = __shfl(dist, j);
-        const int32_t ij = __shfl(index, j);
-        if (lane == 0 && dj < worst) {
-          int count = s_count;
-          int i;
-          for (i = count; i > 0; --i) {
-            if (rd[i - 1] > dj) {
-              if (i < k) {
-                rd[i] = rd[i - 1];
-                ri[i] = ri[i - 1];
-              }
-            } else {
-              break;
-            }
-          }
-          if (i < k) {
-            rd[i] = dj;
-            ri[i] = ij;
-          }
-          if (count < k) s_count = count + 1;
-        }
-      }
-      if (lane == 0) s_sp = sp - 1;
-      wave_sync();
-      continue;
-    }
-    if (lane == 0) {
-      Frame &fr = stack[sp - 1];
-      if (f.state == 0) {
-        const int idx = nd.divfeat;
-        const float val = q[idx];
-        const float diff1 = __fsub_rn(val, nd.divlow), diff2 = __fsub_rn(val, nd.divhigh);
-        int best, other;
-        float cut;
-        if (__fadd_rn(diff1, diff2) < 0.0f) {
-          best = nd.child1;
-          other = nd.child2;
-          cut = __fmul_rn(diff2, diff2);  // accum_dist(val, divhigh)
-        } else {
-          best = nd.child2;
-          other = nd.child1;
-          cut = __fmul_rn(diff1, diff1);  // accum_dist(val, divlow)
-        }
-        fr.state = 1;
-        fr.idx = idx;
-        fr.other = other;
-        fr.cut_dist = cut;
-        stack[sp] = Frame{best, f.mindistsq, 0, 0, 0, 0.0f, 0.0f};
-        s_sp = sp + 1;
-      } else if (f.state == 1) {
-        const float dst = dists[f.idx];
-        const float m2 = __fsub_rn(__fadd_rn(f.mindistsq, f.cut_dist), dst);
-        dists[f.idx] = f.cut_dist;
-        fr.saved = dst;
-        fr.state = 2;
-        if (__fmul_rn(m2, 1.0f) <= rd[k - 1]) {  // mindistsq * epsError <= worstDist(), epsError = 1 + 0
-          stack[sp] = Frame{f.other, m2, 0, 0, 0, 0.0f, 0.0f};
-          s_sp = sp + 1;
-        }
-      } else {
-        dists[f.idx] = f.saved;
-        s_sp = sp - 1;
-      }
-    }
-    wave_sync();
-  }
+  if (resident) walk<true>(a, nodes_lds, dist_lds, q, dists, stack, rd, ri, bound, distsq, lane);
+  else walk<false>(a, nodes_lds, dist_lds, q, dists, stack, rd, ri, bound, distsq, lane);
   wave_sync();
   if (lane < k) {
     a.out_idx[lane] = ri[lane];
     a.out_dist[lane] = rd[lane];
   }
-  if (lane == 0) a.out_found[0] = s_count;
+}
+
+// distances in tree order: dist_tree[i] = dist_all[vind[i]], so that a leaf reads its <= 10 distances from one line
+__global__ __launch_bounds__(256) void sc_knn_tree_order_kernel(const float *__restrict__ dist_all, const int32_t *__restrict__ vind,
+                                                                int64_t n, float *__restrict__ dist_tree) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) dist_tree[i] = dist_all[vind[i]];
 }
 
 }  // namespace
 
+int launch_knn_tree_order(const float *dist_all, const int32_t *vind, int64_t n, float *dist_tree, hipStream_t s) {
+  if (n <= 0) return RSX_OK;
+  hipLaunchKernelGGL(sc_knn_tree_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dist_all, vind, n, dist_tree);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
 int launch_knn_tree(const KdSearchArgs &a, hipStream_t s) {
   if (a.k < 1 || a.k > KD_KMAX) return fail(RSX_ERR_BAD_ARG, "tree search with k = %d", a.k);
-  hipLaunchKernelGGL(sc_knn_tree_kernel, dim3(1), dim3(64), 0, s, a);
+  if (!a.dist_tree) return fail(RSX_ERR_BAD_ARG, "tree search without the distance pass");
+  const size_t need = (size_t)a.n_nodes * sizeof(KdNode16) + (size_t)a.n * sizeof(float);
+  const int resident = need <= (size_t)KD_LDS_BUDGET ? 1 : 0;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_knn_tree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                KD_LDS_BUDGET));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sc_knn_tree_kernel, dim3(1), dim3(64), resident ? need : 0, s, a, resident);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
