@@ -72,7 +72,7 @@ __device__ __forceinline__ double wave_max(double v) {
 
 template <int NW>
 struct Red {
-  double *buf;  // 2 * NW doubles of LDS
+  double *buf;  // 3 * NW doubles of LDS
   __device__ double sum(double v) {
     v = wave_sum(v);
     __syncthreads();
@@ -98,6 +98,27 @@ struct Red {
     for (int w = 0; w < NW; w++) {
       a += buf[w];
       b += buf[NW + w];
+    }
+  }
+  __device__ void sum3(double &a, double &b, double &c) {
+    a = wave_sum(a);
+    b = wave_sum(b);
+    c = wave_sum(c);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+      buf[threadIdx.x >> 6] = a;
+      buf[NW + (threadIdx.x >> 6)] = b;
+      buf[2 * NW + (threadIdx.x >> 6)] = c;
+    }
+    __syncthreads();
+    a = 0.0;
+    b = 0.0;
+    c = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+      a += buf[w];
+      b += buf[NW + w];
+      c += buf[2 * NW + w];
     }
   }
   __device__ double max(double v) {
@@ -418,7 +439,7 @@ struct Layout {
   static constexpr int PART = 8 * NT * 8;
   static constexpr int TOTAL = PTS + EV + EI + PART;
 };
-constexpr int LDS_RED = 2 * 16 * 8;
+constexpr int LDS_RED = 3 * 16 * 8;  // Red<NW>::sum3: 3 x NW doubles, NW <= 16
 
 // One scan pair by one workgroup.  ws = the pair-sized arrays (LDS or HBM), red_lds = 32 doubles of LDS.
 template <int NT, int MAXK>
@@ -464,17 +485,20 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
       }
       r2[t] = 0.0;
     }
-    for (it = 0; it < p.max_iterations; it++) {
-      // (slots t with t * NT >= K hold no TIM in any thread: zero weight, zero contribution -- skipped, wave-uniformly)
-      double C = 0.0, S = 0.0;
+    // (slots t with t * NT >= K hold no TIM in any thread: zero weight, zero contribution -- skipped, wave-uniformly)
+    // The weighted cross-covariance of iteration i + 1 only needs the weights iteration i has just updated, so its
+    // partial sums ride on iteration i's cost reduction: one workgroup reduction per iteration instead of two (same
+    // per-thread order, same reduction tree: the same values).
+    double C = 0.0, S = 0.0;
 #pragma unroll
-      for (int t = 0; t < TPT; t++) {
-        if (t * NT < K) {
-          C += w[t] * (ax[t] * bx[t] + ay[t] * by[t]);
-          S += w[t] * (ax[t] * by[t] - ay[t] * bx[t]);
-        }
+    for (int t = 0; t < TPT; t++) {
+      if (t * NT < K) {
+        C += w[t] * (ax[t] * bx[t] + ay[t] * by[t]);
+        S += w[t] * (ax[t] * by[t] - ay[t] * bx[t]);
       }
-      red.sum2(C, S);
+    }
+    red.sum2(C, S);
+    for (it = 0; it < p.max_iterations; it++) {
       const double nrm = sqrt(C * C + S * S);
       if (nrm > 0.0) {
         cs = C / nrm;
@@ -502,14 +526,18 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
         }
       }
       double cost = 0.0;
+      C = 0.0;
+      S = 0.0;
 #pragma unroll
       for (int t = 0; t < TPT; t++) {
         if (t * NT < K) {
           cost += w[t] * r2[t];
           if (tid + t * NT < K) w[t] = gnc_weight(r2[t], mu, p.c2);
+          C += w[t] * (ax[t] * bx[t] + ay[t] * by[t]);
+          S += w[t] * (ax[t] * by[t] - ay[t] * bx[t]);
         }
       }
-      cost = red.sum(cost);
+      red.sum3(cost, C, S);
       const double cost_diff = fabs(cost - prev_cost);
       mu = mu * p.gnc_factor;
       prev_cost = cost;
@@ -693,7 +721,7 @@ __global__ __launch_bounds__(1024) void orora_register_big_kernel(const float2 *
                                                                   const int64_t *__restrict__ offsets, Params p,
                                                                   rsx_orora_result *__restrict__ out, const int *__restrict__ big_list,
                                                                   char *__restrict__ workspace) {
-  __shared__ double red_lds[32];
+  __shared__ double red_lds[48];
   const int n_big = big_list[0];
   char *ws = workspace + (size_t)blockIdx.x * BigLayout::TOTAL;
   for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
