@@ -197,6 +197,37 @@ def test_detect_sequence_with_tied_ring_keys(sc, oracle):
     assert loops > 50 and differs > 0
 
 
+def test_detect_candidate_mode_large_tree(sc, oracle):
+    """30 000 keyframes: the ring-key tree no longer fits the search kernel's LDS staging (nodes and distances come
+    through the scalar cache / global memory instead), is ~15 levels deep and is rebuilt over a growing prefix.  Tie-heavy
+    keys again; detector == oracle (whose tree is pinned to nanoflann) on every detection."""
+    rng = np.random.default_rng(11)
+    n0 = 30000
+    base = (rng.random((64, 1200)) < 0.18).astype(np.float32) * np.float32(2.0)  # 64 sparse places, binary like radar scans
+    def keyframe():
+        d = base[rng.integers(0, 64)].copy()
+        flip = rng.integers(0, 1200, size=6)
+        d[flip] = np.float32(2.0) - d[flip]
+        return d
+    descs = np.stack([keyframe() for _ in range(n0)])
+    g = sc.SCManager(sc_dist_thres=0.45)
+    o = oracle.Manager(dist_thres=0.45)
+    g.add_descriptors_f32(descs)
+    for d in descs:
+        o.add_descriptor(d.astype(np.float64))
+    hits = 0
+    for i in range(70):  # crosses two tree rebuilds (period 30)
+        d = keyframe()
+        g.saveScancontextAndKeys(d.astype(np.float64))
+        o.add_descriptor(d.astype(np.float64))
+        got = g.detectLoopClosureID(full=True)
+        want = o.detect_loop_closure()
+        assert g.tree_size == o.tree_size
+        assert got == want, f"detection {i}: {got} vs {want}"
+        hits += got[0] >= 0
+    assert hits > 30
+
+
 def test_detect_golden(sc):
     gold = np.load(GOLDEN)
     g = sc.SCManager(sc_dist_thres=0.45)
