@@ -551,7 +551,7 @@ __device__ __forceinline__ Recip recip_setup(const frag4 &tail, const SpecLane &
 //                  accumulates into acc[f % 3], and the fp16 packing of a finished frequency pair
 //                  (P[j][g] = {C_2g, C_2g+1} of (query j/4, k4 = j%4)) is spread over the slots of the next frequency
 //   tail           per query: n_eff of the 60 shifts (2 fp8 MFMAs, K = 64), 4 stage-2 MFMAs (inverse DFT of one
-//                  k4 each), S * u(n_eff) and the running maximum in packed fp32; the mask bytes of the next
+//                  k4 each), S * u(n_eff) and the running maximum in packed fp32; the tail words of the next
 //                  query are in flight meanwhile
 // out[q] = the bound of (query q, this lane's entry), identical in both lane halves
 #ifndef SP_OPT_PACK
