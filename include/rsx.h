@@ -169,6 +169,11 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
                                   int32_t *nn_idx);
 /* current frozen searchable prefix length ("tree" size, SC.cpp:352-353) */
 int rsx_sc_tree_size(rsx_sc *h, int64_t *n);
+/* Introspection of the candidate stage (host only, no device needed): the ring-key search tree the detector would build
+ * over `n` keys of 20 floats -- nanoflann's tree (KDTreeVectorOfVectorsAdaptor.h:49-117, leaf size 10, Scancontext.cpp:284,356)
+ * rebuilt node for node, because the order in which tied neighbours come back is the order of its leaves.  out_vind[n] =
+ * the permutation of the keys as planeSplit leaves it (nanoflann.hpp:968-1004); optional out_n_nodes / out_depth. */
+int rsx_sc_ringkey_tree_layout(const float *keys20, int64_t n, int32_t *out_vind, int32_t *out_n_nodes, int32_t *out_depth);
 
 /* The reference's public helper methods (SC.h:60-66), stateless: the handle only lends its device, stream and
  * staging memory.  They run on the GPU in fp64 on the doubles as given (no fp32 storage involved, any MatrixXd

@@ -87,7 +87,7 @@ SYMBOLS = [
     "rsx_sc_save", "rsx_sc_load", "rsx_sc_get_descriptor", "rsx_sc_get_ringkey",
     "rsx_sc_get_sectorkey", "rsx_sc_detect_loop_closure", "rsx_sc_detect_loop_closure_ex", "rsx_sc_make_scancontext",
     "rsx_sc_make_keys", "rsx_sc_dist_direct", "rsx_sc_fast_align", "rsx_sc_distance", "rsx_sc_detect_between_session",
-    "rsx_sc_tree_size", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_stage1_device",
+    "rsx_sc_tree_size", "rsx_sc_ringkey_tree_layout", "rsx_sc_query", "rsx_sc_query_device", "rsx_sc_query_stage1_device",
     "rsx_sc_query_stage1_elig_device",
     "rsx_sc_query_stage2_device", "rsx_sc_query_self_device",
     "rsx_sc_pair_distances", "rsx_sc_filter_bounds", "rsx_sc_filter_eps", "rsx_sc_profiled_kernel_name",
@@ -136,6 +136,7 @@ def lib():
         L.rsx_sc_size.argtypes = [vp, C.POINTER(i64)]
         L.rsx_sc_local_size.argtypes = [vp, C.POINTER(i64)]
         L.rsx_sc_tree_size.argtypes = [vp, C.POINTER(i64)]
+        L.rsx_sc_ringkey_tree_layout.argtypes = [vp, i64, vp, vp, vp]
         L.rsx_sc_add_points.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(i32)]
         L.rsx_sc_add_descriptor.argtypes = [vp, vp, C.POINTER(i32)]
         L.rsx_sc_add_descriptors_f32.argtypes = [vp, vp, i64]

@@ -572,6 +572,16 @@ int rsx_sc_local_size(rsx_sc *h, int64_t *n) {
   return RSX_OK;
 }
 
+int rsx_sc_ringkey_tree_layout(const float *keys20, int64_t n, int32_t *out_vind, int32_t *out_n_nodes, int32_t *out_depth) {
+  if (!keys20 || !out_vind || n < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  KdTreeHost host;
+  RSX_TRY(kdtree_build_host(keys20, n, &host));
+  std::memcpy(out_vind, host.vind.data(), host.vind.size() * sizeof(int32_t));
+  if (out_n_nodes) *out_n_nodes = (int32_t)host.nodes.size();
+  if (out_depth) *out_depth = host.depth;
+  return RSX_OK;
+}
+
 int rsx_sc_tree_size(rsx_sc *h, int64_t *n) {
   if (!h || !n) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);

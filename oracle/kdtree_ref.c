@@ -183,6 +183,8 @@ void kdref_free(kdref *t) {
 
 int64_t kdref_size(const kdref *t) { return t ? t->n : 0; }
 
+void kdref_vind(const kdref *t, int64_t *out) { memcpy(out, t->vind, sizeof(int64_t) * (size_t)t->n); }
+
 /* ---- search ---- */
 typedef struct {
   int64_t *indices;

@@ -101,6 +101,7 @@ def lib():
         L.kdref_build.restype = C.c_void_p
         L.kdref_build.argtypes = [C.c_void_p, C.c_int64]
         L.kdref_free.argtypes = [C.c_void_p]
+        L.kdref_vind.argtypes = [C.c_void_p, C.c_void_p]
         L.kdref_knn.restype = C.c_int
         L.kdref_knn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
@@ -332,6 +333,11 @@ class KdTree:
         dist = np.zeros(k, dtype=np.float32)
         n = self._L.kdref_knn(self._h, q.ctypes.data, k, idx.ctypes.data, dist.ctypes.data)
         return n, idx, dist
+
+    def vind(self):
+        out = np.zeros(self._keys.shape[0], dtype=np.int64)
+        self._L.kdref_vind(self._h, out.ctypes.data)
+        return out
 
 
 class RefKdTree:

@@ -96,3 +96,30 @@ def test_host_merge_matches_oracle(rsx, oracle):
         assert np.array_equal(merged[qi], want.astype(scancontext.HIT_DTYPE))
     # bad arguments are status codes, not crashes
     assert rsx.lib().rsx_sc_merge_topk(None, 1, 1, 1, None) == -1
+
+
+def test_ringkey_tree_layout_matches_oracle(rsx, oracle):
+    """The product's HOST build of the candidate-stage search tree (csrc/sc_kdtree.cpp, no device involved) against the
+    oracle's restatement, which tests/test_oracle_pin.py pins to the reference's nanoflann: the same permutation of the
+    keys, i.e. the same leaves in the same order with the same order inside every leaf (what decides which tied
+    neighbour the detector picks)."""
+    import numpy as np
+    L = rsx.lib()
+    rng = np.random.default_rng(3)
+    for n in (1, 5, 10, 11, 40, 333, 2000, 20000):
+        for kind in range(3):
+            if kind == 0:      # tie-heavy: multiples of 1/30 from a small range, duplicates
+                keys = rng.integers(0, 7, size=(n, 20)).astype(np.float32) * np.float32(2.0 / 60.0)
+                keys[rng.integers(0, n, size=n // 3)] = keys[rng.integers(0, n, size=n // 3)]
+            elif kind == 1:    # continuous
+                keys = rng.uniform(0, 2, size=(n, 20)).astype(np.float32)
+            else:              # every point identical: the balanced-split rule alone shapes the tree
+                keys = np.full((n, 20), np.float32(0.25))
+            keys = np.ascontiguousarray(keys)
+            vind = np.zeros(n, dtype=np.int32)
+            nn, depth = C.c_int32(0), C.c_int32(0)
+            assert L.rsx_sc_ringkey_tree_layout(keys.ctypes.data, n, vind.ctypes.data, C.byref(nn), C.byref(depth)) == 0
+            want = oracle.KdTree(keys).vind()
+            assert np.array_equal(vind.astype(np.int64), want), (n, kind)
+            assert sorted(vind.tolist()) == list(range(n)) and nn.value >= 1 and 1 <= depth.value <= 64
+    assert L.rsx_sc_ringkey_tree_layout(None, 1, None, None, None) != 0

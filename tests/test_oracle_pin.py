@@ -217,3 +217,30 @@ def test_detector_matches_reference_manager_on_tied_ring_keys(oracle, order):
         assert (got[0], got[1]) == want, (i, got, want)
         differs += ob.detect_loop_closure()[0] != want[0]
     assert differs > 0
+
+
+def test_restated_kdtree_is_nanoflann_hypothesis(oracle):
+    """Property form of the pin above: arbitrary small key sets drawn from tiny value alphabets (so that whole groups of
+    points coincide or tie), arbitrary k: the restated tree returns nanoflann's neighbours in nanoflann's order."""
+    if oracle.ref_lib() is None:
+        pytest.skip("oracle/_ref not built (no /root/reference)")
+    hyp = pytest.importorskip("hypothesis")
+    st = pytest.importorskip("hypothesis.strategies")
+
+    @hyp.settings(max_examples=150, deadline=None, database=None)
+    @hyp.given(seed=st.integers(0, 2**31 - 1), n=st.integers(1, 400), levels=st.integers(1, 6), dims=st.integers(1, 20),
+               k=st.integers(1, 12))
+    def check(seed, n, levels, dims, k):
+        rng = np.random.default_rng(seed)
+        keys = np.zeros((n, 20), dtype=np.float32)
+        keys[:, :dims] = rng.integers(0, levels, size=(n, dims)).astype(np.float32) / np.float32(30.0)
+        mine, ref = oracle.KdTree(keys), oracle.RefKdTree(keys)
+        for _ in range(6):
+            q = keys[rng.integers(0, n)].copy()
+            if rng.random() < 0.5:
+                q[rng.integers(0, 20)] += np.float32(rng.integers(-2, 3)) / np.float32(30.0)
+            n1, i1, d1 = mine.knn(q, k)
+            n2, i2, d2 = ref.knn(q, k)
+            assert n1 == n2 and np.array_equal(i1[:n1], i2[:n2]) and np.array_equal(d1[:n1], d2[:n2])
+
+    check()
