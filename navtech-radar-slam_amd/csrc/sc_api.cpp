@@ -358,6 +358,18 @@ int ensure_tree(rsx_sc *h, rsx_sc::KdTreeDev *t, int64_t n) {
       n16[i] = KdNode16{nd.child2, nd.divfeat, nd.divlow, nd.divhigh};
     }
   }
+  // first vind position below child2 (the subtrees cover contiguous ranges of vind; children have larger node numbers)
+  {
+    std::vector<int32_t> lo(host.nodes.size());
+    for (size_t i = host.nodes.size(); i-- > 0;) {
+      const KdNode &nd = host.nodes[i];
+      lo[i] = nd.child1 < 0 ? nd.left : lo[(size_t)nd.child1];
+      if (nd.child1 >= 0) {
+        if (lo[(size_t)nd.child2] >= (1 << 26)) return fail(RSX_ERR_RANGE, "ring-key tree over more than 2^26 keys");
+        n16[i].b |= lo[(size_t)nd.child2] << 5;
+      }
+    }
+  }
   t->n_nodes = (int32_t)n16.size();
   RSX_TRY(t->nodes.reserve(n16.size() * sizeof(KdNode16), s, false));
   RSX_TRY(t->vind.reserve(host.vind.size() * sizeof(int32_t), s, false));
@@ -393,11 +405,14 @@ int score_candidates_and_finish(rsx_sc *h, const QueryView &qv, const float *d_q
       RSX_TRY(h->knn_ws.reserve((size_t)n_search * 2 * sizeof(float), s, false));
       float *dist_all = h->knn_ws.as<float>(), *dist_tree = dist_all + n_search;
       RSX_TRY(launch_knn(h->rkey.as<float>(), n_search, d_qkey, k, dist_all, b_idx, b_kd, b_found, s));
-      RSX_TRY(launch_knn_tree_order(dist_all, tree->vind.as<int32_t>(), n_search, dist_tree, s));
+      int32_t *cand_pos = d_idx + 384, *cand_count = d_idx + 384 + 64;
+      RSX_TRY(launch_knn_tree_order(dist_all, tree->vind.as<int32_t>(), n_search, dist_tree, k, b_kd, b_found, cand_pos, cand_count, s));
       KdSearchArgs ka;
       ka.bound_dist = b_kd;
       ka.bound_found = b_found;
       ka.dist_tree = dist_tree;
+      ka.cand_pos = cand_pos;
+      ka.cand_count = cand_count;
       ka.nodes = tree->nodes.as<KdNode16>();
       ka.n_nodes = tree->n_nodes;
       ka.n = n_search;

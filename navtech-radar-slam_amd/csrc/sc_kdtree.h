@@ -43,7 +43,7 @@ int kdtree_build_host(const float *keys, int64_t n, KdTreeHost *out);
 // what the search kernel reads: 16 bytes per node, child1 = the next node (the build numbers nodes in preorder)
 struct KdNode16 {
   int32_t a;     // internal: child2;  leaf: first position in vind
-  int32_t b;     // internal: divfeat (>= 0);  leaf: -1 - number of points
+  int32_t b;     // internal: divfeat | (first vind position of child2 << 5), >= 0;  leaf: -1 - number of points
   float divlow, divhigh;
 };
 
@@ -63,12 +63,15 @@ struct KdSearchArgs {
   const int32_t *bound_found;
   const float *dist_tree; // optional: that pass's distances in tree order, dist_tree[i] = distance of key vind[i] (the same
                           // float expression as evalMetric)
+  const int32_t *cand_pos;    // optional (with bound_*): tree positions of the keys within the bound, from the order pass
+  const int32_t *cand_count;  // [1]; 1 .. 64 of them -> the reduced walk (sc_kdtree.hip)
   int32_t *out_idx;    // [k], zero where no neighbour was found (Scancontext.cpp:367: zero-initialised vector)
   float *out_dist;     // [k]
   int32_t *out_found;  // [1]
 };
 int launch_knn_tree(const KdSearchArgs &a, hipStream_t s);
-int launch_knn_tree_order(const float *dist_all, const int32_t *vind, int64_t n, float *dist_tree, hipStream_t s);
+int launch_knn_tree_order(const float *dist_all, const int32_t *vind, int64_t n, float *dist_tree, int32_t k, const float *bound_dist,
+                          const int32_t *bound_found, int32_t *cand_pos, int32_t *cand_count, hipStream_t s);
 
 }  // namespace sc
 }  // namespace rsx

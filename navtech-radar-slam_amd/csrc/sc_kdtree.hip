@@ -41,6 +41,7 @@ namespace sc {
 namespace {
 
 constexpr int KD_KMAX = 64;
+constexpr int KD_CAND_CAP = 64;  // candidates of the reduced walk: one per lane
 constexpr int KD_LDS_BUDGET = 150 * 1024;  // nodes + tree-ordered distances are staged in LDS when they fit (~12 k keys)
 
 // One entry of the explicit stack.  node >= 0: the farther child of an inner node, still to be considered once the
@@ -51,6 +52,7 @@ struct Frame {
   int32_t idx;
   float v;
   float mind;
+  int32_t lo, hi;  // positions (in vind) the farther child covers
 };
 
 __device__ __forceinline__ void wave_sync() {
@@ -61,14 +63,27 @@ __device__ __forceinline__ void wave_sync() {
 // Every lane runs the same scalar walk on the same values (the per-wave state in LDS is written by all lanes with
 // identical data, LDS operations of a wave execute in order): no lane-0 sections, no synchronisation inside the walk --
 // with those, a step cost three dependent LDS round trips and the walk of a 10 000-key tree 2 ms.
-template <bool RESIDENT>
-__device__ __forceinline__ void walk(const KdSearchArgs &a, const KdNode16 *nodes_lds, const float *dist_lds, float *q, float *dists,
-                                     Frame *stack, float *rd, int32_t *ri, float bound, float distsq, int lane) {
+// q[] and dists[] live in one register each (lane i holds element i; v_readlane / a compare-select with the wave-uniform
+// split dimension), the result set and the stack in LDS.
+__device__ __forceinline__ float lane_get(float v, int i) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), i));
+}
+__device__ __forceinline__ float lane_set(float v, int i, float x, int lane) { return lane == i ? x : v; }
+
+// REDUCED: only the subtrees that hold a CANDIDATE -- a key whose distance is at most D (1 + 1e-4), D = the true k-th
+// smallest distance; their positions in tree order sit one per lane in `candpos` -- are entered.  The result is
+// nanoflann's (file header, (i)-(iii): it depends only on the order in which the walk meets those keys, and that order
+// is the depth-first order of their leaves), the bound tests along the way stay nanoflann's float expressions; the
+// walk touches (number of candidates) x (depth) nodes instead of a third of the tree.
+template <bool RESIDENT, bool REDUCED>
+__device__ __forceinline__ void walk(const KdSearchArgs &a, const KdNode16 *nodes_lds, const float *dist_lds, float qreg, float dreg,
+                                     Frame *stack, float *rd, int32_t *ri, float bound, float distsq, int candpos, int lane) {
   const int k = a.k;
   int sp = 0, count = 0;
-  int cur = 0;
+  int cur = 0, clo = 0, chi = (int)a.n;
   float mind = distsq;
   float worst = FLT_MAX;  // mirrors rd[k - 1]
+  auto holds_candidate = [&](int lo, int hi) { return !REDUCED || __ballot(candpos >= lo && candpos < hi) != 0ull; };
   for (;;) {
     // ---- descend to a leaf, nearer child first (searchLevel :1371-1391) ----
     for (;;) {
@@ -76,68 +91,76 @@ __device__ __forceinline__ void walk(const KdSearchArgs &a, const KdNode16 *node
       if (RESIDENT) nd = nodes_lds[cur];
       else nd = a.nodes[__builtin_amdgcn_readfirstlane(cur)];
       if (nd.b < 0) {
-        // leaf (:1354-1366): worst_dist is read once; the points are offered in leaf order
+        // leaf (:1354-1366): worst_dist is read once; the points closer than that are offered in leaf order.  Most
+        // leaves offer nothing: one ballot decides (a shuffle per point cost ~120 cycles each)
         const int cnt = -1 - nd.b, left = nd.a;
-        float dist = 0.0f;
+        float dist = INFINITY;
         if (lane < cnt) dist = RESIDENT ? dist_lds[left + lane] : a.dist_tree[left + lane];
-        const float worst_entry = worst;
-        for (int j = 0; j < cnt; j++) {
-          const float dj = __shfl(dist, j);
-          if (dj < worst_entry) {  // KNNResultSet::addPoint :175-202
-            const int32_t ij = a.vind[left + j];
-            int i;
-            for (i = count; i > 0; --i) {
-              const float prev = rd[i - 1];
-              if (prev > dj) {
-                if (i < k) {
-                  rd[i] = prev;
-                  ri[i] = ri[i - 1];
-                }
-              } else {
-                break;
+        unsigned long long offer = __ballot(lane < cnt && dist < worst);
+        while (offer) {
+          const int j = __ffsll((long long)offer) - 1;
+          offer &= offer - 1;
+          const float dj = lane_get(dist, j);
+          const int32_t ij = a.vind[left + j];
+          int i;  // KNNResultSet::addPoint :175-202
+          for (i = count; i > 0; --i) {
+            const float prev = rd[i - 1];
+            if (prev > dj) {
+              if (i < k) {
+                rd[i] = prev;
+                ri[i] = ri[i - 1];
               }
+            } else {
+              break;
             }
-            if (i < k) {
-              rd[i] = dj;
-              ri[i] = ij;
-            }
-            if (count < k) count++;
-            worst = rd[k - 1];
           }
+          if (i < k) {
+            rd[i] = dj;
+            ri[i] = ij;
+          }
+          if (count < k) count++;
         }
+        worst = rd[k - 1];
         break;
       }
-      const int idx = nd.b;
-      const float val = q[idx];
+      const int idx = __builtin_amdgcn_readfirstlane(nd.b & 31), mid = __builtin_amdgcn_readfirstlane(nd.b >> 5);
+      const float val = lane_get(qreg, idx);
       const float diff1 = __fsub_rn(val, nd.divlow), diff2 = __fsub_rn(val, nd.divhigh);
-      int best, other;
+      int best, other, blo, bhi, olo, ohi;
       float cut;
       if (__fadd_rn(diff1, diff2) < 0.0f) {
-        best = cur + 1;
-        other = nd.a;
+        best = cur + 1; blo = clo; bhi = mid;
+        other = nd.a; olo = mid; ohi = chi;
         cut = __fmul_rn(diff2, diff2);  // accum_dist(val, divhigh)
       } else {
-        best = nd.a;
-        other = cur + 1;
+        best = nd.a; blo = mid; bhi = chi;
+        other = cur + 1; olo = clo; ohi = mid;
         cut = __fmul_rn(diff1, diff1);  // accum_dist(val, divlow)
       }
-      stack[sp++] = Frame{other, idx, cut, mind};
+      stack[sp++] = Frame{other, idx, cut, mind, olo, ohi};
+      if (!holds_candidate(blo, bhi)) break;  // nothing in the nearer child can matter: as if it had returned
       cur = best;
+      clo = blo;
+      chi = bhi;
     }
     // ---- back up (:1397-1409) until a farther child has to be visited ----
     bool again = false;
     while (sp > 0) {
       const Frame f = stack[--sp];
+      const int fidx = __builtin_amdgcn_readfirstlane(f.idx);
       if (f.node < 0) {
-        dists[f.idx] = f.v;
+        dreg = lane_set(dreg, fidx, f.v, lane);
         continue;
       }
-      const float dst = dists[f.idx];
+      const float dst = lane_get(dreg, fidx);
       const float m2 = __fsub_rn(__fadd_rn(f.mind, f.v), dst);
-      dists[f.idx] = f.v;
-      stack[sp++] = Frame{-1, f.idx, dst, 0.0f};
-      if (__fmul_rn(m2, 1.0f) <= worst && m2 <= bound) {  // mindistsq * epsError <= worstDist(), epsError = 1 + 0
+      dreg = lane_set(dreg, fidx, f.v, lane);
+      stack[sp++] = Frame{-1, fidx, dst, 0.0f, 0, 0};
+      // mindistsq * epsError <= worstDist(), epsError = 1 + 0
+      if (__fmul_rn(m2, 1.0f) <= worst && m2 <= bound && holds_candidate(f.lo, f.hi)) {
         cur = f.node;
+        clo = f.lo;
+        chi = f.hi;
         mind = m2;
         again = true;
         break;
@@ -151,16 +174,18 @@ __device__ __forceinline__ void walk(const KdSearchArgs &a, const KdNode16 *node
 __global__ __launch_bounds__(64) void sc_knn_tree_kernel(KdSearchArgs a, int resident) {
   extern __shared__ __attribute__((aligned(16))) char dyn[];
   __shared__ float q[KD_DIM];
-  __shared__ float dists[KD_DIM];
   __shared__ Frame stack[2 * KD_STACK + 2];
   __shared__ float rd[KD_KMAX];
   __shared__ int32_t ri[KD_KMAX];
   const int lane = threadIdx.x;
   const int k = a.k;
   const float bound = (a.bound_dist && a.bound_found && a.bound_found[0] >= k) ? a.bound_dist[k - 1] * 1.0001f + 1e-30f : INFINITY;
+  const int ncand = a.cand_count ? a.cand_count[0] : 0;
+  const bool reduced = ncand >= 1 && ncand <= KD_CAND_CAP;  // (uniform) else: the full walk
+  const int candpos = (reduced && lane < ncand) ? a.cand_pos[lane] : -1;
   KdNode16 *nodes_lds = reinterpret_cast<KdNode16 *>(dyn);
   float *dist_lds = reinterpret_cast<float *>(dyn + (size_t)a.n_nodes * sizeof(KdNode16));
-  if (resident) {
+  if (resident && !reduced) {
     const uint4 *src = reinterpret_cast<const uint4 *>(a.nodes);
     uint4 *dst = reinterpret_cast<uint4 *>(nodes_lds);
     for (int i = lane; i < a.n_nodes; i += 64) dst[i] = src[i];
@@ -173,24 +198,27 @@ __global__ __launch_bounds__(64) void sc_knn_tree_kernel(KdSearchArgs a, int res
   }
   wave_sync();
   rd[k - 1] = FLT_MAX;  // KNNResultSet::init (all lanes, the same value)
-  // computeInitialDistances (:1006-1023); `dists` starts at zero (:1235)
-  float distsq = 0.0f;
+  // computeInitialDistances (:1006-1023); `dists` starts at zero (:1235).  Lane i keeps q[i] and dists[i].
+  const float qreg = lane < KD_DIM ? q[lane] : 0.0f;
+  float dreg = 0.0f, distsq = 0.0f;
   for (int i = 0; i < KD_DIM; i++) {
+    const float qi = q[i];
     float di = 0.0f;
-    if (q[i] < a.low[i]) {
-      const float d = __fsub_rn(q[i], a.low[i]);
+    if (qi < a.low[i]) {
+      const float d = __fsub_rn(qi, a.low[i]);
       di = __fmul_rn(d, d);
       distsq = __fadd_rn(distsq, di);
     }
-    if (q[i] > a.high[i]) {
-      const float d = __fsub_rn(q[i], a.high[i]);
+    if (qi > a.high[i]) {
+      const float d = __fsub_rn(qi, a.high[i]);
       di = __fmul_rn(d, d);
       distsq = __fadd_rn(distsq, di);
     }
-    dists[i] = di;
+    if (lane == i) dreg = di;
   }
-  if (resident) walk<true>(a, nodes_lds, dist_lds, q, dists, stack, rd, ri, bound, distsq, lane);
-  else walk<false>(a, nodes_lds, dist_lds, q, dists, stack, rd, ri, bound, distsq, lane);
+  if (reduced) walk<false, true>(a, nodes_lds, dist_lds, qreg, dreg, stack, rd, ri, bound, distsq, candpos, lane);
+  else if (resident) walk<true, false>(a, nodes_lds, dist_lds, qreg, dreg, stack, rd, ri, bound, distsq, candpos, lane);
+  else walk<false, false>(a, nodes_lds, dist_lds, qreg, dreg, stack, rd, ri, bound, distsq, candpos, lane);
   wave_sync();
   if (lane < k) {
     a.out_idx[lane] = ri[lane];
@@ -198,18 +226,33 @@ __global__ __launch_bounds__(64) void sc_knn_tree_kernel(KdSearchArgs a, int res
   }
 }
 
-// distances in tree order: dist_tree[i] = dist_all[vind[i]], so that a leaf reads its <= 10 distances from one line
+// distances in tree order: dist_tree[i] = dist_all[vind[i]], so that a leaf reads its <= 10 distances from one line;
+// and the candidates of the reduced walk: the tree positions of the keys at distance <= D (1 + 1e-4), in any order
+// (every key, when fewer than k keys exist).  cand_count[0] must be 0 on entry; it may exceed KD_CAND_CAP (full walk then)
 __global__ __launch_bounds__(256) void sc_knn_tree_order_kernel(const float *__restrict__ dist_all, const int32_t *__restrict__ vind,
-                                                                int64_t n, float *__restrict__ dist_tree) {
+                                                                int64_t n, float *__restrict__ dist_tree, int32_t k,
+                                                                const float *__restrict__ bound_dist,
+                                                                const int32_t *__restrict__ bound_found, int32_t *__restrict__ cand_pos,
+                                                                int32_t *__restrict__ cand_count) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) dist_tree[i] = dist_all[vind[i]];
+  if (i >= n) return;
+  const float d = dist_all[vind[i]];
+  dist_tree[i] = d;
+  const float bound = bound_found[0] >= k ? bound_dist[k - 1] * 1.0001f + 1e-30f : INFINITY;
+  if (d <= bound) {
+    const int slot = atomicAdd(cand_count, 1);
+    if (slot < KD_CAND_CAP) cand_pos[slot] = (int32_t)i;
+  }
 }
 
 }  // namespace
 
-int launch_knn_tree_order(const float *dist_all, const int32_t *vind, int64_t n, float *dist_tree, hipStream_t s) {
+int launch_knn_tree_order(const float *dist_all, const int32_t *vind, int64_t n, float *dist_tree, int32_t k, const float *bound_dist,
+                          const int32_t *bound_found, int32_t *cand_pos, int32_t *cand_count, hipStream_t s) {
   if (n <= 0) return RSX_OK;
-  hipLaunchKernelGGL(sc_knn_tree_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dist_all, vind, n, dist_tree);
+  RSX_HIP(hipMemsetAsync(cand_count, 0, sizeof(int32_t), s));
+  hipLaunchKernelGGL(sc_knn_tree_order_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dist_all, vind, n, dist_tree, k,
+                     bound_dist, bound_found, cand_pos, cand_count);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

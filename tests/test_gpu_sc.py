@@ -228,6 +228,36 @@ def test_detect_candidate_mode_large_tree(sc, oracle):
     assert hits > 30
 
 
+def test_detect_hundreds_of_identical_ring_keys(sc, oracle):
+    """More tied neighbours than the candidate-guided walk holds (64): exact copies of three scans, hundreds of times.
+    The search falls back to the full walk; which copies come back is still nanoflann's choice."""
+    rng = np.random.default_rng(21)
+    scans = []
+    for _ in range(3):
+        r = rng.uniform(2, 78, size=60)
+        a = rng.uniform(0, 2 * np.pi, size=60)
+        scans.append(np.stack([r * np.cos(a), r * np.sin(a), np.zeros(60), np.zeros(60)], axis=1).astype(np.float32))
+    g = sc.SCManager(sc_dist_thres=0.45)
+    o = oracle.Manager(dist_thres=0.45)
+    rm = None
+    if oracle.ref_lib() is not None:
+        try:
+            rm = oracle.RefManager(oracle.get_sum_order(), dist_thres=0.45)
+        except Exception:
+            rm = None
+    for i in range(420):
+        c = scans[rng.integers(0, 3)]
+        g.makeAndSaveScancontextAndKeys(c)
+        o.add_points(c)
+        got = g.detectLoopClosureID(full=True)
+        want = o.detect_loop_closure()
+        assert got == want, f"keyframe {i}: {got} vs {want}"
+        if rm is not None:
+            rm.add_points(c)
+            assert (got[0], got[1]) == rm.detect_loop_closure(), i
+    assert got[0] >= 0 and got[2] == 0.0
+
+
 def test_detect_golden(sc):
     gold = np.load(GOLDEN)
     g = sc.SCManager(sc_dist_thres=0.45)
