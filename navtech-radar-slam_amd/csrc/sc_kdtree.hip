@@ -26,6 +26,11 @@
 //        time, so a bound can exceed the distance of a point on the cell boundary by an ulp or two (relative 1e-6); a
 //        disagreement between the two walks about a subtree in the margin would need a point whose distance is below
 //        its own subtree's bound by 1e-4 relative.
+// The candidate-guided walk (walk<.., REDUCED = true>, the normal case) goes one step further with the same argument:
+// a subtree that holds NO key at distance <= D (1 + 1e-4) cannot change (i) at all, whatever its bound is, so it is
+// not entered -- the candidates' tree positions come from the order pass, one per lane, and "does [lo, hi) hold one" is a
+// compare and a ballot.  The float bound tests on the way to a candidate's leaf are still performed as nanoflann
+// performs them.
 #include <hip/hip_runtime.h>
 
 #include <cfloat>
