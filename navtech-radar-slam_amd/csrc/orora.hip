@@ -210,18 +210,21 @@ __device__ __forceinline__ void bitonic_sort_regs(int K, const double *sx, const
 #pragma unroll 1
     for (int stride = size >> 1; stride >= 64 * E; stride >>= 1) {
       __syncthreads();
+      // exchange buffer laid out [e][thread]: consecutive lanes, consecutive words (laid out [thread][e] the 64 lanes of
+      // an access were E doubles apart: 16- to 32-way bank conflicts)
 #pragma unroll
       for (int e = 0; e < E; e++) {
-        ev[tid * E + e] = v[e];
-        ei[tid * E + e] = id[e];
+        ev[e * 256 + tid] = v[e];
+        ei[e * 256 + tid] = id[e];
       }
       __syncthreads();
       const bool lower = (wave & (stride / (64 * E))) == 0;
+      const int ptid = tid ^ (stride / E);  // the partner endpoint g ^ stride is element e of that thread
 #pragma unroll
       for (int e = 0; e < E; e++) {
         const int g = tid * E + e;
-        const double ov = ev[g ^ stride];
-        const int oi = ei[g ^ stride];
+        const double ov = ev[e * 256 + ptid];
+        const int oi = ei[e * 256 + ptid];
         const bool up = (g & size) == 0;
         const bool other_less = ep_less(ov, oi, v[e], id[e]);
         const bool take = (lower == up) ? other_less : !other_less;  // keep the smaller one at the lower end of an ascending pair
@@ -255,7 +258,7 @@ __device__ __forceinline__ void bitonic_sort_regs(int K, const double *sx, const
   }
   __syncthreads();
 #pragma unroll
-  for (int e = 0; e < E; e++) ei[tid * E + e] = id[e];  // the sweep needs the order only
+  for (int e = 0; e < E; e++) ei[e * 256 + tid] = id[e];  // the sweep needs the order only; [e][thread] like the exchange buffer
   __syncthreads();
 }
 
@@ -339,7 +342,7 @@ __device__ __forceinline__ double scalar_tls_block(const double (&x)[TPT], const
   double l[6] = {0, 0, 0, 0, 0, 0};
   int l_card = 0;
   for (int e = e0; e < e0 + E; e++) {
-    const int id = ei[e];
+    const int id = (NT == 256) ? ei[(e - e0) * NT + tid] : ei[e];  // on-chip kernel: [e][thread] (bitonic_sort_regs)
     if (id == 0x7fffffff) continue;
     const int idx = (id > 0 ? id : -id) - 1;
     const double eps = id > 0 ? 1.0 : -1.0;
@@ -359,15 +362,37 @@ __device__ __forceinline__ double scalar_tls_block(const double (&x)[TPT], const
   part[6 * NT + tid] = (double)l_card;
   part[7 * NT + tid] = l_sr;
   __syncthreads();
-  if (tid < 8) {  // exclusive scan of the NT chunk totals, one quantity per thread (7: total of the bounds)
-    double run = 0.0;
-    double *q = part + tid * NT;
-    for (int i = 0; i < NT; i++) {
-      const double v = q[i];
-      q[i] = run;
-      run += v;
+  // exclusive scan of the NT chunk totals of the 8 quantities (7: only the total of the bounds is used).  One wavefront
+  // per quantity, NT / 64 consecutive totals per lane, a shuffle scan across the lanes -- a single thread per quantity
+  // walking its NT totals through LDS was 256 dependent round trips: 10 % of the kernel
+  {
+    constexpr int PER = NT / 64;
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int qn = wv; qn < 8; qn += NW) {
+      double *q = part + qn * NT;
+      double pre[PER];
+      double run = 0.0;
+#pragma unroll
+      for (int j = 0; j < PER; j++) {
+        pre[j] = run;
+        run += q[lane * PER + j];
+      }
+      double incl = run;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const double o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      const double base = incl - run;
+#pragma unroll
+      for (int j = 0; j < PER; j++) q[lane * PER + j] = base + pre[j];
+      if (qn == 7) {
+        const double total = __shfl(incl, 63);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) q[0] = total;  // sum of all bounds
+      }
     }
-    if (tid == 7) q[0] = run;  // sum of all bounds
   }
   __syncthreads();
   double r[6];
@@ -378,7 +403,7 @@ __device__ __forceinline__ double scalar_tls_block(const double (&x)[TPT], const
   double best_cost = INFINITY, best_x = 0.0;
   int best_pos = 0x7fffffff;
   for (int e = e0; e < e0 + E; e++) {
-    const int id = ei[e];
+    const int id = (NT == 256) ? ei[(e - e0) * NT + tid] : ei[e];  // on-chip kernel: [e][thread] (bitonic_sort_regs)
     if (id == 0x7fffffff) continue;
     const int idx = (id > 0 ? id : -id) - 1;
     const double eps = id > 0 ? 1.0 : -1.0;
