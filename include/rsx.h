@@ -346,6 +346,19 @@ int rsx_cen2019_destroy(rsx_cen2019 *h);
 int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, int32_t col_offset,
                         const rsx_cen2019_params *params, const float *azimuths, float resolution,
                         int32_t *out_targets, float *out_xy, int32_t max_targets, int32_t *out_count);
+/* The same for n_images scans in ONE chain of launches (a file-based sequence is known in advance: README.md:27,54-60).
+ * Images image_stride_bytes apart; azimuths: rows floats shared by all images, or n_images x rows when
+ * azimuths_per_image != 0.  out_targets [n_images][max_targets][2], out_xy [n_images][max_targets][2] (optional),
+ * out_counts [n_images].  Host buffers, synchronous. */
+int rsx_cen2019_extract_batch(rsx_cen2019 *h, const uint8_t *imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
+                              int32_t col_offset, const rsx_cen2019_params *params, const float *azimuths, int32_t azimuths_per_image,
+                              float resolution, int32_t *out_targets, float *out_xy, int32_t max_targets, int32_t *out_counts);
+/* Device buffers in and out, asynchronous on `stream`, no host synchronisation anywhere in the chain: d_targets / d_xy /
+ * d_counts as above in HBM (d_xy, d_counts optional), ready for rsx_frontend_describe_device without a host hop. */
+int rsx_cen2019_extract_batch_device(rsx_cen2019 *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes,
+                                     int32_t row_stride, int32_t col_offset, const rsx_cen2019_params *params, const float *d_azimuths,
+                                     int32_t azimuths_per_image, float resolution, int32_t *d_targets, float *d_xy, int32_t max_targets,
+                                     int32_t *d_counts, void *stream);
 
 /* ============================== ORORA front end ========================================
  * The steps between the cen2019 keypoints and the solver in the upstream file-based entry (reference README.md:26-29;

@@ -99,6 +99,7 @@ SYMBOLS = [
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
     "rsx_orora_register_batch", "rsx_orora_register_batch_device",
     "rsx_cen2019_default_params", "rsx_cen2019_create", "rsx_cen2019_destroy", "rsx_cen2019_extract",
+    "rsx_cen2019_extract_batch", "rsx_cen2019_extract_batch_device",
     "rsx_frontend_default_params", "rsx_frontend_create", "rsx_frontend_destroy", "rsx_frontend_cartesian",
     "rsx_frontend_describe", "rsx_frontend_match",
     "rsx_voxelgrid_create", "rsx_voxelgrid_destroy", "rsx_voxelgrid_filter", "rsx_sc_add_points_downsampled",
@@ -190,6 +191,9 @@ def lib():
         L.rsx_cen2019_destroy.argtypes = [vp]
         L.rsx_cen2019_extract.argtypes = [vp, vp, i32, i32, C.POINTER(Cen2019Params), vp, C.c_float, vp, vp, i32,
                                           C.POINTER(i32)]
+        L.rsx_cen2019_extract_batch.argtypes = [vp, vp, i32, i64, i32, i32, C.POINTER(Cen2019Params), vp, i32, C.c_float, vp, vp, i32, vp]
+        L.rsx_cen2019_extract_batch_device.argtypes = [vp, vp, i32, i64, i32, i32, C.POINTER(Cen2019Params), vp, i32, C.c_float, vp, vp,
+                                                       i32, vp, vp]
         L.rsx_frontend_default_params.argtypes = [C.POINTER(FrontendParams)]
         L.rsx_frontend_create.argtypes = [C.c_int, i32, i32, C.POINTER(FrontendParams), C.POINTER(vp)]
         L.rsx_frontend_destroy.argtypes = [vp]

@@ -48,3 +48,25 @@ class Cen2019:
         if xy is not None:
             return out[:k].copy(), xy[:k].copy()
         return out[:k].copy()
+
+    def extract_batch(self, imgs, col_offset=11, max_points=10000, min_range=58, azimuths=None, resolution=0.0595,
+                      max_targets=20000):
+        """imgs: (n, rows, row_stride) uint8 -> list of targets (k_i, 2) int32 [, list of xy (k_i, 2) float32]; one chain
+        of launches for the whole batch (rsx_cen2019_extract_batch).  azimuths: (rows,) shared or (n, rows)."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        n = imgs.shape[0]
+        assert imgs.shape[1] == self.rows
+        p = Cen2019Params(max_points, min_range)
+        out = np.zeros((n, max_targets, 2), dtype=np.int32)
+        az = np.ascontiguousarray(azimuths, dtype=np.float32) if azimuths is not None else None
+        xy = np.zeros((n, max_targets, 2), dtype=np.float32) if az is not None else None
+        counts = np.zeros(n, dtype=np.int32)
+        check(self._L.rsx_cen2019_extract_batch(self._h, imgs.ctypes.data, n, imgs.strides[0], imgs.shape[2], col_offset,
+                                                C.byref(p), az.ctypes.data if az is not None else None,
+                                                1 if (az is not None and az.ndim == 2) else 0, resolution, out.ctypes.data,
+                                                xy.ctypes.data if xy is not None else None, max_targets, counts.ctypes.data))
+        ks = np.minimum(counts, max_targets)
+        tg = [out[i, :ks[i]].copy() for i in range(n)]
+        if xy is not None:
+            return tg, [xy[i, :ks[i]].copy() for i in range(n)]
+        return tg

@@ -1,32 +1,39 @@
-// cen2019.hip -- cen2019 radar keypoint extraction on gfx950 (polar 400 x 3360 u8 image -> keypoints).
+// cen2019.hip -- cen2019 radar keypoint extraction on gfx950 (polar 400 x 3360 u8 images -> keypoints), batched.
 //
 // The reference gets these keypoints from its ORORA submodule, which is an empty directory in the
 // reference checkout (.gitmodules:1-3; README.md:29 "extracted via cen2019 method"), so this follows
 // the published method as restated in oracle/cen2019_ref.c (PARITY UNPINNED).
 // It replaces the feature-extraction call of the upstream file-based odometry.cpp entry (README.md:27).
 //
-// Kernel chain (all HBM-bound image passes except the sort; 1.34 MB u8 in, <= 8 B per keypoint out):
-//   cen_stats       bytes -> sum(bytes), max |fft(r+1) - fft(r-1)|              1 read of the image
-//   cen_h           h = (fft - mean)(1 - g/maxg) -> h image, fixed-point sum h   1 read, 1 f32 write
-//   cen_candidates  h > mean_h -> 64-bit keys (~order(h) << 32 | pixel index)    1 read of h
-//   rocPRIM radix sort of the keys (descending h, ties by azimuth, range) and a stable 9-bit
-//   sort of the ranks by azimuth: the greedy region marking of the method is sequential in global
-//   intensity order, but its state is per-azimuth -- only the region budget couples azimuths
-//   cen_mark        one wavefront per azimuth replays that azimuth's candidates in rank order
-//                   (LDS mark row), records which candidate marked each pixel and whether the
-//                   candidate opened a new region
-//   cen_budget      prefix count of "new region" flags in rank order -> J* = number of candidates
-//                   the sequential algorithm would have visited before the budget ran out
-//   cen_extract     per azimuth: runs of pixels marked by candidates ranked < J*, adjacency test
-//                   against the neighbouring azimuths, argmax of h -> keypoints
-//   cen_compact     row-major compaction (+ polar -> Cartesian)
-// Arithmetic is order independent by construction (integer byte sum, max, 2^40 fixed-point sum of
-// h), so the result is bit-identical to the oracle.
+// Round 3: NO SORT.  The method's greedy region marking walks the pixels in global intensity order
+// under a region budget; rounds 1-2 replayed that walk per azimuth after two rocPRIM radix sorts of
+// ~0.5 M candidates (36 launches, a host sync for the candidate count).  The walk has a closed form
+// (proof in oracle/cen2019_np.py, checked there against the sequential oracle on the CPU):
+//   key(p)  = (h(p) descending, pixel index ascending) as one uint64; neg(p) = s(p) < 0
+//   a pixel with s >= 0 is only ever marked by ITSELF; a maximal run N of neg pixels is marked as a
+//   whole by the first visited pixel among {left neighbour of N, right neighbour of N, pixels of N}:
+//       MK(p) = key(p) if !neg(p) else min key over those "touchers" of p's run          (mark key)
+//   a visited candidate p opens a NEW region  <=>  key(p) is the minimum of every run it touches
+//   the budget ends the walk at K* = the max_points-th smallest key among the region openers
+//   p is marked in the end  <=>  MK(p) <= K*  and  MK(p) is a candidate (h > mean_h)
+// so the chain is four image passes over L2-resident bytes and ONE selection, with no intermediate
+// image in HBM at all (h is recomputed from the bytes where it is needed):
+//   cen_stats    bytes -> sum(bytes), max |fft(r+1) - fft(r-1)|                     (global: mean, max g)
+//   cen_hist     per azimuth: keys, per-run minima (two segmented min-scans), "opens a region" flags
+//                -> 4096-bin histogram of the openers' h, fixed-point sum of h (mean_h)
+//   cen_pick     (one block per image) the bin B* that holds the max_points-th opener
+//   cen_collect  same evaluation, appends the openers of bin B* (a few dozen keys) to a list
+//   cen_resolve  (one block per image) radix-selects K* among them
+//   cen_extract  per azimuth: marks of rows a-1, a, a+1 from MK < limit, runs / adjacency / arg-max
+//                by one segmented max-scan, ordered compaction
+//   cen_pack     row-major packing of the rows' keypoints (+ polar -> Cartesian)
+// One workgroup per (azimuth, image): a launch over a batch of B images is B x rows workgroups, every
+// dependency between passes is a kernel boundary, nothing returns to the host.  (A first version
+// folded the three small kernels into "last block done" tickets: a device-scope __threadfence per
+// workgroup writes back / invalidates the XCD's L2 on this multi-die part and cost 40 us per block.)
+// Arithmetic is order independent by construction (integer byte sum, max, 2^40 fixed-point sum of h),
+// so the result is bit-identical to the oracle.
 #include <hip/hip_runtime.h>
-
-#include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
-
-#include <rocprim/rocprim.hpp>
 
 #include <cmath>
 #include <cstdint>
@@ -37,37 +44,44 @@
 
 namespace {
 
-constexpr int ROW_CAP = 1024;  // keypoints kept per azimuth (a 3360-bin row can hold at most 1680 runs)
+constexpr int NBIN = 4096;               // histogram of h over [-1, 1]
 constexpr double FIX = 1099511627776.0;  // 2^40
+constexpr unsigned long long KINF = ~0ull;
+constexpr int MAX_SUB_BATCH = 128;       // images per internal launch group (workspace = 14 MB per image)
 
-struct Scal {
+struct Scal {  // per image
   unsigned long long sum_bytes;
   long long fix_sum;
+  unsigned long long klimit;  // a pixel is marked in the end iff MK(p) < klimit
   unsigned int max_g_bits;
-  unsigned int n_cand;
-  long long jstar;
+  unsigned int pad0[3];
+  int bstar;               // histogram bin of the max_points-th region opener (-1: there are fewer openers)
+  unsigned int above;      // openers in the bins above bstar
+  unsigned int n_list;     // openers of bin bstar collected so far
   unsigned int n_targets;
-  unsigned int done;     // the region budget ran out (or every candidate was visited): J* is final
-  unsigned int regions;  // new regions opened by the candidate windows processed so far
-  unsigned int pad;
+  unsigned int pad[2];
 };
-
-__device__ __forceinline__ float px(const uint8_t *img, int a, int r, int stride, int off) {
-  return __fdiv_rn((float)img[(int64_t)a * stride + off + r], 255.0f);
-}
+static_assert(sizeof(Scal) == 64, "Scal layout");
 
 __device__ __forceinline__ unsigned ord_f32(float f) {
   unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
+__device__ __forceinline__ float canon0(float f) { return f == 0.0f ? 0.0f : f; }  // -0.0 sorts like +0.0 (oracle: h compares)
 
-// one block per azimuth: the row is 3.3 KB and stays in L1, no index arithmetic per pixel
-__global__ __launch_bounds__(256) void cen_stats(const uint8_t *__restrict__ img, int rows, int cols, int stride, int off,
-                                                 Scal *sc) {
+__device__ __forceinline__ float mean_fft(const Scal *sc, int64_t n) { return (float)((double)sc->sum_bytes / 255.0 / (double)n); }
+__device__ __forceinline__ float mean_h_of(long long fix_sum, int64_t n) { return (float)((double)fix_sum / FIX / (double)n); }
+// candidates are the pixels with h > mean_h  <=>  key < kmean
+__device__ __forceinline__ unsigned long long kmean_of(float mh) { return (unsigned long long)(~ord_f32(canon0(mh))) << 32; }
+
+// one block per (azimuth, image): the row is 3.3 KB and stays in L1
+__global__ __launch_bounds__(256) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
+                                                 int off, Scal *scal) {
   __shared__ unsigned long long s_sum[4];
   __shared__ float s_max[4];
   const int a = blockIdx.x;
-  const uint8_t *row = img + (int64_t)a * stride + off;
+  Scal *sc = scal + blockIdx.y;
+  const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
   unsigned long long sb = 0;
   float mg = 0.0f;
   for (int r = threadIdx.x; r < cols; r += 256) {
@@ -92,315 +106,543 @@ __global__ __launch_bounds__(256) void cen_stats(const uint8_t *__restrict__ img
   }
 }
 
-__device__ __forceinline__ float mean_fft(const Scal *sc, int64_t n) {
-  return (float)((double)sc->sum_bytes / 255.0 / (double)n);
+// ---------------------------------------------------------------------------------------------------------------
+// segmented scans over the NT threads of a block.  An element is (value, head flag); "a then b" combines to
+// (b.head ? b.value : op(a.value, b.value), a.head | b.head): a head starts a new segment.
+// ---------------------------------------------------------------------------------------------------------------
+struct SegMin {
+  unsigned long long v;
+  unsigned f;
+};
+__device__ __forceinline__ SegMin seg_min(SegMin a, SegMin b) {
+  SegMin r;
+  r.v = b.f ? b.v : (a.v < b.v ? a.v : b.v);
+  r.f = a.f | b.f;
+  return r;
 }
-__device__ __forceinline__ float mean_h(const Scal *sc, int64_t n) { return (float)((double)sc->fix_sum / FIX / (double)n); }
+struct SegMax {  // value = (ord(h) << 32 | ~range bin): max = largest h, first bin among equals; adj = OR over the segment
+  unsigned long long v;
+  unsigned f, adj;
+};
+__device__ __forceinline__ SegMax seg_max(SegMax a, SegMax b) {
+  SegMax r;
+  r.v = b.f ? b.v : (a.v > b.v ? a.v : b.v);
+  r.adj = b.f ? b.adj : (a.adj | b.adj);
+  r.f = a.f | b.f;
+  return r;
+}
+__device__ __forceinline__ SegMin shfl_up_seg(SegMin x, int d) { return SegMin{__shfl_up(x.v, d), (unsigned)__shfl_up((int)x.f, d)}; }
+__device__ __forceinline__ SegMin shfl_down_seg(SegMin x, int d) { return SegMin{__shfl_down(x.v, d), (unsigned)__shfl_down((int)x.f, d)}; }
+__device__ __forceinline__ SegMax shfl_up_seg(SegMax x, int d) {
+  return SegMax{__shfl_up(x.v, d), (unsigned)__shfl_up((int)x.f, d), (unsigned)__shfl_up((int)x.adj, d)};
+}
 
-__global__ __launch_bounds__(256) void cen_h(const uint8_t *__restrict__ img, int rows, int cols, int stride, int off,
-                                             Scal *sc, float *__restrict__ h) {
-  __shared__ long long s_fix[4];
-  const int64_t n = (int64_t)rows * cols;
-  const float mean = mean_fft(sc, n);
-  const float maxg = __uint_as_float(sc->max_g_bits);
-  const int a = blockIdx.x;
-  const uint8_t *row = img + (int64_t)a * stride + off;
-  float *hrow = h + (int64_t)a * cols;
-  long long fix = 0;
-  for (int r = threadIdx.x; r < cols; r += 256) {
-    float g = 0.0f;
-    if (cols > 1) {
-      const int rp = (r + 1 < cols) ? r + 1 : cols - 2, rm = (r >= 1) ? r - 1 : 1;
-      g = fabsf(__fsub_rn(__fdiv_rn((float)row[rp], 255.0f), __fdiv_rn((float)row[rm], 255.0f)));
+// exclusive scan of one aggregate per thread, in thread order (REV: from the last thread down); `ident` = the
+// element that changes nothing.  s_w: NT/64 elements of LDS scratch.  Two block barriers.
+template <int NT, bool REV, typename E, typename OP>
+__device__ __forceinline__ E block_excl_scan(E x, E ident, OP op, E *s_w) {
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    if constexpr (!REV) {
+      const E o = shfl_up_seg(x, d);
+      if (lane >= d) x = op(o, x);
+    } else {
+      const E o = shfl_down_seg(x, d);
+      if (lane + d < 64) x = op(o, x);
     }
-    const float gn = (maxg > 0.0f) ? __fdiv_rn(g, maxg) : 0.0f;
-    const float sv = __fsub_rn(__fdiv_rn((float)row[r], 255.0f), mean);
-    const float hv = __fmul_rn(sv, __fsub_rn(1.0f, gn));
-    hrow[r] = hv;
-    fix += __double2ll_rn((double)hv * FIX);
+  }
+  E e;
+  if constexpr (!REV) {
+    e = shfl_up_seg(x, 1);
+    if (lane == 0) e = ident;
+    if (lane == 63) s_w[w] = x;
+  } else {
+    e = shfl_down_seg(x, 1);
+    if (lane == 63) e = ident;
+    if (lane == 0) s_w[w] = x;
+  }
+  __syncthreads();
+  E acc = ident;
+  if constexpr (!REV) {
+    for (int ww = 0; ww < w; ww++) acc = op(acc, s_w[ww]);
+  } else {
+    for (int ww = NW - 1; ww > w; ww--) acc = op(acc, s_w[ww]);
+  }
+  __syncthreads();
+  return op(acc, e);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Evaluation of one azimuth row by a block of NT threads, C consecutive range bins per thread (NT * C >= cols):
+// per pixel the key, the mark key MK, h and neg.  LDS scratch: row bytes, the 256-entry byte -> fft table.
+// ---------------------------------------------------------------------------------------------------------------
+template <int C, int NT>
+struct RowLds {
+  float tab[256];
+  SegMin sw[NT / 64];
+  unsigned long long edge_first[NT], edge_last[NT];  // MK of a thread's first / last pixel
+  unsigned edge_neg[NT];                             // bit 0: first pixel neg, bit 1: last pixel neg
+};
+
+template <int C, int NT>
+struct RowRegs {
+  unsigned long long key[C], mk[C];
+  float h[C];
+  unsigned neg;  // bit i: s < 0
+};
+
+template <int C, int NT>
+__device__ __forceinline__ void row_table(RowLds<C, NT> &L) {
+  if (threadIdx.x < 256) L.tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
+}
+
+// the caller has filled L.tab; contains block barriers
+template <int C, int NT>
+__device__ __forceinline__ void row_eval(RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, unsigned pix_base, float mean, float maxg,
+                                         RowRegs<C, NT> &R) {
+  __syncthreads();  // previous users of L.sw / L.edge_* are done, L.tab is visible
+  static_assert(C == 16, "a thread's chunk is four dwords");
+  const int p0 = threadIdx.x * C;
+  R.neg = 0;
+  // the thread's 16 bytes and their two neighbours from ALIGNED dwords around row + p0 (an aligned dword that holds
+  // one byte of the image cannot cross a page, so the few bytes read beside the row are harmless)
+  unsigned w[6] = {0u, 0u, 0u, 0u, 0u, 0u};  // aligned words [-1 .. 4] relative to (row + p0) & ~3
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
+  const unsigned mis = (unsigned)(addr & 3u);
+  const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
+  if (p0 < cols) {
+    if (p0 > 0) w[0] = wp[-1];
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+      if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
+  }
+  unsigned char bt[C + 2];  // pixels p0-1 .. p0+16
+#pragma unroll
+  for (int i = -1; i <= C; i++) {
+    // byte (mis + i) of the stream that starts at word 1
+    const int jw = 1 + ((i + 4) >> 2) - 1;  // word index for offset i when mis = 0: (i >= 0 ? i / 4 : -1) + 1
+    const unsigned lo = w[jw], hi = w[jw + 1 < 6 ? jw + 1 : 5];
+    const unsigned v = __builtin_amdgcn_alignbyte(hi, lo, mis);  // bytes mis .. mis+3 of (hi:lo)
+    bt[i + 1] = (unsigned char)((v >> (8 * ((i + 4) & 3))) & 0xffu);
+  }
+  float ft[C + 2];
+#pragma unroll
+  for (int i = 0; i < C + 2; i++) ft[i] = L.tab[bt[i]];
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const int p = p0 + i;
+    if (p < cols) {
+      float g = 0.0f;
+      if (cols > 1) {
+        // reflect 101: the neighbour of bin 0 on the left is bin 1, of the last bin on the right the one before it
+        const float fp = (p + 1 < cols) ? ft[i + 2] : ft[i];
+        const float fm = (p >= 1) ? ft[i] : ft[i + 2];
+        g = fabsf(__fsub_rn(fp, fm));
+      }
+      const float gn = (maxg > 0.0f) ? __fdiv_rn(g, maxg) : 0.0f;
+      const float sv = __fsub_rn(ft[i + 1], mean);
+      const float hv = __fmul_rn(sv, __fsub_rn(1.0f, gn));
+      R.h[i] = hv;
+      R.key[i] = ((unsigned long long)(~ord_f32(canon0(hv))) << 32) | (unsigned long long)(pix_base + (unsigned)p);
+      if (sv < 0.0f) R.neg |= 1u << i;
+    } else {  // past the row end: a wall no run crosses
+      R.h[i] = 0.0f;
+      R.key[i] = KINF;
+    }
+  }
+  // forward: X(p) = min key over p's run up to p, including the pixel just left of the run
+  const SegMin ident{KINF, 0u};
+  unsigned long long x[C];
+  {
+    SegMin loc = ident;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      if ((R.neg >> i) & 1u) {
+        loc.v = loc.v < R.key[i] ? loc.v : R.key[i];
+      } else {
+        loc.v = R.key[i];
+        loc.f = 1u;
+      }
+      x[i] = loc.v;
+    }
+    const SegMin carry = block_excl_scan<NT, false>(loc, ident, seg_min, L.sw);
+    const int first_head = __builtin_ctz(~R.neg | (1u << C));  // pixels before the thread's first non-neg pixel continue the carry
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      if (i < first_head) x[i] = x[i] < carry.v ? x[i] : carry.v;
+  }
+  // backward: Y(p) likewise from the right; MK = min(X, Y) on neg pixels
+  {
+    SegMin loc = ident;
+    unsigned long long y[C];
+#pragma unroll
+    for (int i = C - 1; i >= 0; i--) {
+      if ((R.neg >> i) & 1u) {
+        loc.v = loc.v < R.key[i] ? loc.v : R.key[i];
+      } else {
+        loc.v = R.key[i];
+        loc.f = 1u;
+      }
+      y[i] = loc.v;
+    }
+    const SegMin carry = block_excl_scan<NT, true>(loc, ident, seg_min, L.sw);
+    const unsigned nn = ~R.neg & ((C == 32) ? 0xffffffffu : ((1u << C) - 1u));
+    const int last_head = nn ? 31 - __builtin_clz(nn) : -1;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      unsigned long long yy = y[i];
+      if (i > last_head) yy = yy < carry.v ? yy : carry.v;
+      R.mk[i] = ((R.neg >> i) & 1u) ? (x[i] < yy ? x[i] : yy) : R.key[i];
+    }
+  }
+}
+
+// bit i: pixel i of the thread's chunk, when visited, opens a new region (see the file header)
+template <int C, int NT>
+__device__ __forceinline__ unsigned row_opens(RowLds<C, NT> &L, const RowRegs<C, NT> &R, int cols) {
+  L.edge_first[threadIdx.x] = R.mk[0];
+  L.edge_last[threadIdx.x] = R.mk[C - 1];
+  L.edge_neg[threadIdx.x] = (R.neg & 1u) | (((R.neg >> (C - 1)) & 1u) << 1);
+  __syncthreads();
+  const int t = threadIdx.x;
+  const bool lneg = t > 0 && (L.edge_neg[t - 1] & 2u);
+  const unsigned long long lmk = t > 0 ? L.edge_last[t - 1] : KINF;
+  const bool rneg = t + 1 < NT && (L.edge_neg[t + 1] & 1u);
+  const unsigned long long rmk = t + 1 < NT ? L.edge_first[t + 1] : KINF;
+  unsigned opens = 0;
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    if (t * C + i >= cols) break;
+    bool op;
+    if ((R.neg >> i) & 1u) {
+      op = R.mk[i] == R.key[i];
+    } else {
+      const bool ln = i > 0 ? ((R.neg >> (i - 1)) & 1u) != 0 : lneg;
+      const unsigned long long lm = i > 0 ? R.mk[i > 0 ? i - 1 : 0] : lmk;
+      const bool rn = i + 1 < C ? ((R.neg >> (i + 1)) & 1u) != 0 : rneg;
+      const unsigned long long rm = i + 1 < C ? R.mk[i + 1 < C ? i + 1 : C - 1] : rmk;
+      op = (!ln || lm == R.key[i]) && (!rn || rm == R.key[i]);
+    }
+    if (op) opens |= 1u << i;
+  }
+  return opens;
+}
+
+__device__ __forceinline__ int h_bin(float hv) {  // monotone non-decreasing in h
+  const int b = (int)floorf(__fmul_rn(__fadd_rn(canon0(hv), 1.0f), 2048.0f));
+  return b < 0 ? 0 : (b > NBIN - 1 ? NBIN - 1 : b);
+}
+
+template <int C, int NT>
+__global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
+                                               Scal *scal, unsigned *__restrict__ hist) {
+  __shared__ RowLds<C, NT> L;
+  __shared__ unsigned s_hist[NBIN];
+  __shared__ long long s_fix[NT / 64];
+  const int a = blockIdx.x;
+  Scal *sc = scal + blockIdx.y;
+  unsigned *gh = hist + (size_t)blockIdx.y * NBIN;
+  const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
+  const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
+  row_table(L);
+  for (int b = threadIdx.x; b < NBIN; b += NT) s_hist[b] = 0;
+  RowRegs<C, NT> R;
+  row_eval(L, row, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
+  const unsigned opens = row_opens(L, R, cols);
+  long long fix = 0;
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    if (threadIdx.x * C + i < cols) {
+      fix += __double2ll_rn((double)R.h[i] * FIX);
+      if ((opens >> i) & 1u) atomicAdd(&s_hist[h_bin(R.h[i])], 1u);
+    }
   }
   for (int o = 32; o >= 1; o >>= 1) fix += __shfl_xor(fix, o);
   if ((threadIdx.x & 63) == 0) s_fix[threadIdx.x >> 6] = fix;
   __syncthreads();
-  if (threadIdx.x == 0)
-    atomicAdd(reinterpret_cast<unsigned long long *>(&sc->fix_sum), (unsigned long long)(s_fix[0] + s_fix[1] + s_fix[2] + s_fix[3]));
-}
-
-// one block per azimuth; two walks over the row (it stays in L1): count, ONE atomic per block to
-// reserve the block's slice of the key list, then write.  Key order is irrelevant (sorted next).
-__global__ __launch_bounds__(256) void cen_candidates(const float *__restrict__ h, int rows, int cols, Scal *sc,
-                                                      unsigned long long *__restrict__ keys, unsigned *__restrict__ row_count) {
-  __shared__ unsigned s_cnt[4];
-  __shared__ unsigned s_base;
-  const int64_t n = (int64_t)rows * cols;
-  const float mh = mean_h(sc, n);
-  const int a = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *hrow = h + (int64_t)a * cols;
-  unsigned mine = 0;
-  for (int base = wave * 64; base < cols; base += 256) {
-    const int r = base + lane;
-    mine += (unsigned)__popcll(__ballot(r < cols && hrow[r] > mh));
-  }
-  if (lane == 0) s_cnt[wave] = mine;
-  __syncthreads();
+  for (int b = threadIdx.x; b < NBIN; b += NT)
+    if (s_hist[b]) atomicAdd(&gh[b], s_hist[b]);
   if (threadIdx.x == 0) {
-    const unsigned tot = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-    row_count[a] = tot;
-    s_base = tot ? atomicAdd(&sc->n_cand, tot) : 0u;
-  }
-  __syncthreads();
-  unsigned pos = s_base;
-  for (int w = 0; w < wave; w++) pos += s_cnt[w];
-  for (int base = wave * 64; base < cols; base += 256) {
-    const int r = base + lane;
-    const float hv = r < cols ? hrow[r] : 0.0f;
-    const bool is = r < cols && hv > mh;
-    const unsigned long long bal = __ballot(is);
-    if (is)
-      keys[pos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] =
-          ((unsigned long long)(~ord_f32(hv)) << 32) | (unsigned long long)(unsigned)(a * cols + r);
-    pos += (unsigned)__popcll(bal);
+    long long f = 0;
+    for (int w = 0; w < NT / 64; w++) f += s_fix[w];
+    atomicAdd(reinterpret_cast<unsigned long long *>(&sc->fix_sum), (unsigned long long)f);
   }
 }
 
-__global__ __launch_bounds__(256) void cen_rowkeys(const unsigned long long *__restrict__ keys_sorted, const Scal *sc, int cols,
-                                                   unsigned *__restrict__ rowkey, unsigned *__restrict__ rank) {
-  const unsigned m = sc->n_cand;
-  for (unsigned j = blockIdx.x * 256 + threadIdx.x; j < m; j += gridDim.x * 256) {
-    rowkey[j] = (unsigned)(keys_sorted[j] & 0xffffffffull) / (unsigned)cols;
-    rank[j] = j;
+// one block of 256 threads per image: the bin of the max_points-th opener
+__global__ __launch_bounds__(256) void cen_pick(Scal *scal, const unsigned *__restrict__ hist, int max_points) {
+  constexpr int NT = 256;
+  __shared__ unsigned s_cnt[NT / 64];
+  Scal *sc = scal + blockIdx.x;
+  const unsigned *gh = hist + (size_t)blockIdx.x * NBIN;
+  // thread t owns the NBIN / NT bins [NBIN - (t+1) per, NBIN - t per): thread 0 = the highest h
+  constexpr int PER = NBIN / NT;
+  unsigned mine = 0;
+  unsigned hv[PER];
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    hv[j] = gh[NBIN - 1 - (threadIdx.x * PER + j)];
+    mine += hv[j];
+  }
+  unsigned incl = mine;  // inclusive prefix over threads (descending h)
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(incl, d);
+    if ((threadIdx.x & 63) >= d) incl += o;
+  }
+  if ((threadIdx.x & 63) == 63) s_cnt[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  unsigned before = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) before += s_cnt[w];
+  incl += before;
+  const unsigned excl = incl - mine;
+  unsigned total = 0;
+  for (int w = 0; w < NT / 64; w++) total += s_cnt[w];
+  if (max_points <= 0 || total < (unsigned)max_points) {
+    if (threadIdx.x == 0) {
+      sc->bstar = -1;
+      sc->above = total;
+    }
+  } else if (excl < (unsigned)max_points && incl >= (unsigned)max_points) {
+    unsigned c = excl;
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+      if (c + hv[j] >= (unsigned)max_points) {
+        sc->bstar = NBIN - 1 - (threadIdx.x * PER + j);
+        sc->above = c;
+        break;
+      }
+      c += hv[j];
+    }
   }
 }
 
-// exclusive scan of up to 1024 row counts (single block)
-__global__ __launch_bounds__(1024) void cen_row_offsets(const unsigned *__restrict__ row_count, int rows,
-                                                        unsigned *__restrict__ row_off) {
-  __shared__ unsigned s[1024];
-  const int t = threadIdx.x;
-  s[t] = t < rows ? row_count[t] : 0u;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    unsigned v = t >= d ? s[t - d] : 0u;
-    __syncthreads();
-    s[t] += v;
-    __syncthreads();
+template <int C, int NT>
+__global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
+                                                  int off, Scal *scal, unsigned long long *__restrict__ lists, int64_t list_stride) {
+  __shared__ RowLds<C, NT> L;
+  const int a = blockIdx.x;
+  Scal *sc = scal + blockIdx.y;
+  unsigned long long *list = lists + (int64_t)blockIdx.y * list_stride;
+  const int bstar = sc->bstar;
+  if (bstar >= 0) {
+    const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
+    const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
+    row_table(L);
+    RowRegs<C, NT> R;
+    row_eval(L, row, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
+    const unsigned opens = row_opens(L, R, cols);
+    unsigned sel = 0;
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      if (((opens >> i) & 1u) && h_bin(R.h[i]) == bstar) sel |= 1u << i;
+    // one atomic per wavefront
+    const unsigned cnt = (unsigned)__popc(sel);
+    unsigned incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(incl, d);
+      if ((threadIdx.x & 63) >= d) incl += o;
+    }
+    const unsigned wave_total = __shfl(incl, 63);
+    unsigned base = 0;
+    if (wave_total) {
+      if ((threadIdx.x & 63) == 63) base = atomicAdd(&sc->n_list, wave_total);
+      base = __shfl(base, 63);
+      unsigned pos = base + incl - cnt;
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        if ((sel >> i) & 1u) list[pos++] = R.key[i];
+    }
   }
-  if (t < rows) row_off[t + 1] = s[t];
-  if (t == 0) row_off[0] = 0;
 }
 
-// one wavefront per azimuth: replay the azimuth's candidates in global rank order.
-// The sequential method stops when max_points regions have been opened, usually after a few percent
-// of the candidates, so the replay runs in rank WINDOWS [win_lo, win_hi): after each window
-// cen_budget counts the regions opened so far and sets sc->done once the budget is exhausted; later
-// windows return at once.  Between windows the row's marks live in `mark` and its position in the
-// (rank-sorted) candidate list in row_cur.
-__global__ __launch_bounds__(64) void cen_mark(const uint8_t *__restrict__ img, int rows, int cols, int stride, int off,
-                                               const Scal *sc, const unsigned long long *__restrict__ keys_sorted,
-                                               const unsigned *__restrict__ rank_by_row, const unsigned *__restrict__ row_off,
-                                               unsigned win_hi, int first, unsigned *__restrict__ row_cur,
-                                               int *__restrict__ mark, uint8_t *__restrict__ inc) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  int *mk = reinterpret_cast<int *>(lds);                        // [cols] rank of the marking candidate
-  uint8_t *neg = reinterpret_cast<uint8_t *>(lds) + (size_t)cols * 4;  // [cols] s < 0
-  if (sc->done) return;
-  const int a = blockIdx.x, lane = threadIdx.x;
-  const float mean = mean_fft(sc, (int64_t)rows * cols);
-  for (int r = lane; r < cols; r += 64) {
-    mk[r] = first ? 0x7fffffff : mark[(int64_t)a * cols + r];
-    neg[r] = __fsub_rn(px(img, a, r, stride, off), mean) < 0.0f;
-  }
-  __syncthreads();
-  const unsigned t1 = row_off[a + 1];
-  unsigned cur = first ? row_off[a] : row_cur[a];
-  bool more = true;
-  while (more && cur < t1) {
-   // 64 candidates of this azimuth at a time: two dependent global loads per CHUNK, not per candidate
-   const unsigned my_t = cur + lane;
-   const unsigned my_j = my_t < t1 ? rank_by_row[my_t] : 0xffffffffu;
-   const int my_r = my_t < t1 ? (int)((unsigned)(keys_sorted[my_j] & 0xffffffffull) - (unsigned)a * (unsigned)cols) : 0;
-   // the row's list is sorted by rank: the candidates inside the window are a prefix of the chunk
-   const unsigned cnt = (unsigned)__popcll(__ballot(my_t < t1 && my_j < win_hi));
-   more = cnt == 64u;
-   cur += cnt;
-   for (unsigned i = 0; i < cnt; i++) {
-    const unsigned j = __shfl(my_j, (int)i);
-    const int r = __shfl(my_r, (int)i);
-    if (mk[r] != 0x7fffffff) {  // wave-uniform
-      if (lane == 0) inc[j] = 0;
-      continue;
-    }
-    // extend over the adjacent s < 0 pixels, 64 at a time (lane 0 = nearest pixel)
-    int rlow = r, rhigh = r;
-    for (int base = r - 1; base >= 0; base -= 64) {
-      const int p = base - lane;
-      const unsigned long long b = __ballot(p >= 0 && neg[p]);
-      const int run = (~b) ? (__ffsll((long long)~b) - 1) : 64;
-      rlow -= run;
-      if (run < 64) break;
-    }
-    for (int base = r + 1; base < cols; base += 64) {
-      const int p = base + lane;
-      const unsigned long long b = __ballot(p < cols && neg[p]);
-      const int run = (~b) ? (__ffsll((long long)~b) - 1) : 64;
-      rhigh += run;
-      if (run < 64) break;
-    }
-    bool already = false;
-    for (int base = rlow; base <= rhigh; base += 64) {
-      const int p = base + lane;
-      const bool in = p <= rhigh;
-      const bool was = in && mk[p] != 0x7fffffff;
-      if (in && !was) mk[p] = (int)j;
-      already |= __ballot(was) != 0ull;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) inc[j] = already ? 0 : 1;
-   }
-  }
-  __syncthreads();
-  for (int r = lane; r < cols; r += 64) mark[(int64_t)a * cols + r] = mk[r];
-  if (lane == 0) row_cur[a] = cur;
-}
-
-// J* = number of candidates visited by `while (l < max_points && j < M)`: the first rank whose
-// exclusive prefix count of new regions reaches max_points, or M.  inc[] holds 0/1 bytes in rank
-// order; this looks at the window [win_lo, win_hi) (win_lo a multiple of 16) on top of the regions
-// counted in earlier windows; every thread sums a contiguous 16-byte aligned chunk with 16-byte loads.
-__global__ __launch_bounds__(1024) void cen_budget(const uint8_t *__restrict__ inc, Scal *sc, int max_points, unsigned win_lo,
-                                                   unsigned win_hi) {
-  __shared__ unsigned s[1024];
-  if (sc->done) return;
-  const unsigned m = sc->n_cand;
-  const unsigned t = threadIdx.x;
-  if (max_points <= 0) {  // while (0 < 0 ...) never runs
-    if (t == 0) {
-      sc->jstar = 0;
-      sc->done = 1;
-    }
+// one block of 256 threads per image: K* = the max_points-th smallest opener key, and the mark limit
+__global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned long long *__restrict__ lists, int64_t list_stride, int rows,
+                                                   int cols, int max_points) {
+  constexpr int NT = 256;
+  __shared__ unsigned s_h[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ unsigned s_t;
+  Scal *sc = scal + blockIdx.x;
+  const unsigned long long *list = lists + (int64_t)blockIdx.x * list_stride;
+  const int bstar = sc->bstar;
+  const unsigned long long kmean = kmean_of(mean_h_of(sc->fix_sum, (int64_t)rows * cols));
+  if (max_points <= 0) {
+    if (threadIdx.x == 0) sc->klimit = 0ull;  // while (0 < 0 ...) never runs: nothing is marked
     return;
   }
-  const unsigned before = sc->regions;
-  const unsigned w_hi = win_hi < m ? win_hi : m;
-  const unsigned w_lo = win_lo < w_hi ? win_lo : w_hi;
-  const unsigned len = w_hi - w_lo;
-  const unsigned chunk = (((len + 1023) / 1024) + 15u) & ~15u;
-  const unsigned lo = w_lo + (t * chunk < len ? t * chunk : len);
-  const unsigned hi = lo + chunk < w_hi ? lo + chunk : w_hi;
-  unsigned c = 0;
-  unsigned j = lo;
-  for (; j + 16 <= hi; j += 16) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(inc + j);
-    c += __popc(v.x & 0x01010101u) + __popc(v.y & 0x01010101u) + __popc(v.z & 0x01010101u) + __popc(v.w & 0x01010101u);
+  if (bstar < 0) {  // fewer openers than the budget: every candidate is visited
+    if (threadIdx.x == 0) sc->klimit = kmean;
+    return;
   }
-  for (; j < hi; j++) c += inc[j] & 1u;
-  s[t] = c;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    unsigned v = t >= (unsigned)d ? s[t - d] : 0u;
-    __syncthreads();
-    s[t] += v;
-    __syncthreads();
+  const unsigned n = sc->n_list;
+  // MSD radix select (8 x 8 bits) of the t-th smallest key of the list, t 1-based
+  if (threadIdx.x == 0) {
+    s_prefix = 0ull;
+    s_t = (unsigned)max_points - sc->above;
   }
-  const unsigned total = before + s[1023];
-  if (total >= (unsigned)max_points) {
-    const unsigned excl = before + s[t] - c;  // new regions before this chunk
-    if (excl < (unsigned)max_points && excl + c >= (unsigned)max_points) {
-      // the candidate that opens region number max_points is the last one visited
-      unsigned l = excl;
-      for (unsigned jj = lo; jj < hi; jj++) {
-        l += inc[jj] & 1u;
-        if (l >= (unsigned)max_points) {
-          sc->jstar = (long long)jj + 1;
-          sc->done = 1;
-          break;
-        }
+  unsigned long long mask = 0ull;
+  for (int pass = 0; pass < 8; pass++) {
+    const int shift = 56 - 8 * pass;
+    if (threadIdx.x < 256) s_h[threadIdx.x] = 0u;
+    __syncthreads();
+    const unsigned long long prefix = s_prefix;
+    for (unsigned i = threadIdx.x; i < n; i += NT) {
+      const unsigned long long k = list[i];
+      if ((k & mask) == prefix) atomicAdd(&s_h[(unsigned)(k >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {  // lane l owns digits 4l .. 4l+3
+      const unsigned l = threadIdx.x;
+      const unsigned c0 = s_h[4 * l], c1 = s_h[4 * l + 1], c2 = s_h[4 * l + 2], c3 = s_h[4 * l + 3];
+      const unsigned mine = c0 + c1 + c2 + c3;
+      unsigned incl = mine;
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned o = __shfl_up(incl, d);
+        if (l >= (unsigned)d) incl += o;
+      }
+      const unsigned t = s_t, excl = incl - mine;
+      if (excl < t && incl >= t) {
+        unsigned c = excl, dig;
+        if (c + c0 >= t) dig = 0;
+        else if ((c += c0) + c1 >= t) dig = 1;
+        else if ((c += c1) + c2 >= t) dig = 2;
+        else { c += c2; dig = 3; }
+        s_t = t - c;
+        s_prefix = prefix | ((unsigned long long)(4 * l + dig) << shift);
       }
     }
-  } else if (t == 0) {
-    sc->regions = total;
-    if (w_hi >= m) {  // every candidate was visited
-      sc->jstar = (long long)m;
-      sc->done = 1;
-    }
+    mask |= 255ull << shift;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const unsigned long long kstar = s_prefix;  // the key of the candidate that opens region number max_points
+    sc->klimit = (kstar == KINF || kstar + 1ull > kmean) ? kmean : kstar + 1ull;
   }
 }
 
-// one wavefront per azimuth.  LDS: per pixel a flag byte (bit 0: marked by a visited candidate,
-// bit 1: a marked pixel at the same range on the azimuth above or below) and the result slot of a run
-// (indexed by the run's first pixel).  Runs are short, so the lane that owns a run's first pixel walks
-// it; an ordered ballot compaction then restores ascending range order.
-__global__ __launch_bounds__(64) void cen_extract(const float *__restrict__ h, const int *__restrict__ mark, int rows, int cols,
-                                                  const Scal *sc, int min_range, int *__restrict__ row_out,
+template <int C, int NT>
+__global__ __launch_bounds__(NT) void cen_extract(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
+                                                  int off, Scal *scal, int min_range, int row_cap, int *__restrict__ row_out,
                                                   unsigned *__restrict__ row_n) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  int *res = reinterpret_cast<int *>(lds);                             // [cols]
-  uint8_t *flag = reinterpret_cast<uint8_t *>(lds) + (size_t)cols * 4;  // [cols]
-  const int a = blockIdx.x, lane = threadIdx.x;
-  const int js = (int)(sc->jstar > 0x7fffffff ? 0x7fffffff : sc->jstar);
-  const int *mr = mark + (int64_t)a * cols;
-  const int *below = mark + (int64_t)((a - 1 + rows) % rows) * cols;
-  const int *above = mark + (int64_t)((a + 1) % rows) * cols;
-  const float *hr = h + (int64_t)a * cols;
-  for (int r = lane; r < cols; r += 64) {
-    flag[r] = (uint8_t)((mr[r] < js ? 1 : 0) | ((below[r] < js || above[r] < js) ? 2 : 0));
-    res[r] = -1;
+  __shared__ RowLds<C, NT> L;
+  __shared__ uint8_t s_flag[C * NT + 16];  // bit 0: marked on this azimuth, bit 1: marked on the azimuth above or below
+  __shared__ SegMax s_sw[NT / 64];
+  __shared__ unsigned s_cnt[NT / 64];
+  const int a = blockIdx.x, img = blockIdx.y;
+  Scal *sc = scal + img;
+  const uint8_t *base = imgs + (int64_t)img * img_stride + off;
+  const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
+  const unsigned long long klimit = sc->klimit;
+  row_table(L);
+  RowRegs<C, NT> R;
+  const int p0 = threadIdx.x * C;
+  for (int p = threadIdx.x; p < C * NT + 16; p += NT) s_flag[p] = 0;
+  const int nb[2] = {(a - 1 + rows) % rows, (a + 1) % rows};
+  for (int k = 0; k < 2; k++) {
+    row_eval(L, base + (int64_t)nb[k] * stride, cols, (unsigned)nb[k] * (unsigned)cols, mean, maxg, R);
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      if (R.mk[i] < klimit) s_flag[p0 + i] = 2;  // (row_eval's first barrier orders this against the zero fill)
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  const int rmin = min_range < 0 ? 0 : min_range;
-  for (int r = rmin + lane; r < cols; r += 64) {
-    if (!(flag[r] & 1)) continue;
-    if (r > rmin && (flag[r - 1] & 1)) continue;  // not the first pixel of its run (runs are cut at rmin)
-    bool adj = false;
-    int max_r = r;
-    float mx = -INFINITY;
-    int i = r;
-    for (; i < cols && (flag[i] & 1); i++) {
-      adj |= (flag[i] & 2) != 0;
-      const float hv = hr[i];
-      if (hv > mx) {  // first maximum
-        mx = hv;
-        max_r = i;
-      }
+  row_eval(L, base + (int64_t)a * stride, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
+  unsigned marked = 0;
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    if (p0 + i < cols && R.mk[i] < klimit) {
+      marked |= 1u << i;
+      s_flag[p0 + i] |= 1;
     }
+  __syncthreads();
+  // runs of marked pixels at r >= rmin: segmented max-scan; the LAST pixel of a run holds the run's result
+  const int rmin = min_range < 0 ? 0 : min_range;
+  const SegMax ident{0ull, 0u, 0u};
+  SegMax loc = ident;
+  SegMax incl[C];
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const int p = p0 + i;
+    if (((marked >> i) & 1u) && p >= rmin) {
+      const bool start = p == rmin || !(s_flag[p - 1] & 1);
+      SegMax e{((unsigned long long)ord_f32(canon0(R.h[i])) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p), start ? 1u : 0u,
+               (unsigned)((s_flag[p] >> 1) & 1)};
+      loc = seg_max(loc, e);
+    } else {
+      loc = SegMax{0ull, 1u, 0u};
+    }
+    incl[i] = loc;
+  }
+  const SegMax carry = block_excl_scan<NT, false>(loc, ident, seg_max, s_sw);
+  unsigned emit = 0;
+  int res[C];
+  bool seen_head = false;
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const int p = p0 + i;
+    const bool live = ((marked >> i) & 1u) && p >= rmin;
+    SegMax v = incl[i];
+    if (!seen_head && !v.f) v = seg_max(carry, v);  // no head inside the thread's chunk yet: the carry's run continues
+    if (incl[i].f) seen_head = true;
     // a run only counts once an unmarked pixel closes it: a run that reaches the end of the row does not
-    if (i < cols && adj) res[r] = max_r;
+    if (live && p + 1 < cols && !(s_flag[p + 1] & 1) && v.adj) {
+      emit |= 1u << i;
+      res[i] = (int)(0xffffffffu - (unsigned)(v.v & 0xffffffffull));
+    }
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  unsigned cnt = 0;
-  for (int base = 0; base < cols; base += 64) {
-    const int r = base + lane;
-    const int v = r < cols ? res[r] : -1;
-    const unsigned long long bal = __ballot(v >= 0);
-    const unsigned pos = cnt + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-    if (v >= 0 && pos < ROW_CAP) row_out[(int64_t)a * ROW_CAP + pos] = v;
-    cnt += (unsigned)__popcll(bal);
+  // ordered compaction
+  const unsigned cnt = (unsigned)__popc(emit);
+  unsigned inc = cnt;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(inc, d);
+    if ((threadIdx.x & 63) >= d) inc += o;
   }
-  if (lane == 0) row_n[a] = cnt < ROW_CAP ? cnt : ROW_CAP;
+  if ((threadIdx.x & 63) == 63) s_cnt[threadIdx.x >> 6] = inc;
+  __syncthreads();
+  unsigned before = 0, total = 0;
+  for (int w = 0; w < NT / 64; w++) {
+    if (w < (int)(threadIdx.x >> 6)) before += s_cnt[w];
+    total += s_cnt[w];
+  }
+  unsigned pos = before + inc - cnt;
+  int *ro = row_out + ((int64_t)img * rows + a) * row_cap;
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    if ((emit >> i) & 1u) ro[pos++] = res[i];
+  if (threadIdx.x == 0) row_n[(int64_t)img * rows + a] = total;
 }
 
-__global__ __launch_bounds__(256) void cen_compact(const int *__restrict__ row_out, const unsigned *__restrict__ row_n,
-                                                   const unsigned *__restrict__ row_off, int rows, const float *__restrict__ az,
-                                                   float resolution, int max_targets, int *__restrict__ targets,
-                                                   float *__restrict__ xy, Scal *sc) {
-  const int a = blockIdx.x;
-  const unsigned n = row_n[a], o = row_off[a];
-  for (unsigned i = threadIdx.x; i < n; i += 256) {
-    const unsigned d = o + i;
-    if (d >= (unsigned)max_targets) continue;
-    const int r = row_out[(int64_t)a * ROW_CAP + i];
-    targets[2 * d] = a;
-    targets[2 * d + 1] = r;
-    if (xy && az) {
+// one wavefront per (azimuth, image): row-major packing of the rows' keypoints, polar -> Cartesian
+__global__ __launch_bounds__(64) void cen_pack(Scal *scal, int rows, int row_cap, const int *__restrict__ row_out,
+                                               const unsigned *__restrict__ row_n, const float *__restrict__ az, int64_t az_stride,
+                                               float resolution, int max_targets, int *__restrict__ targets, float *__restrict__ xy,
+                                               int *__restrict__ counts) {
+  const int a = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+  const unsigned *rn = row_n + (int64_t)img * rows;
+  unsigned before = 0;
+  for (int r = lane; r < a; r += 64) before += rn[r];
+  for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
+  const unsigned n = rn[a];
+  int *tg = targets + (int64_t)img * max_targets * 2;
+  float *pxy = xy ? xy + (int64_t)img * max_targets * 2 : nullptr;
+  const float *azi = az ? az + (int64_t)img * az_stride : nullptr;
+  const int *ro = row_out + ((int64_t)img * rows + a) * row_cap;
+  for (unsigned i = lane; i < n; i += 64) {
+    const unsigned d = before + i;
+    if (d >= (unsigned)max_targets) break;
+    const int r = ro[i];
+    tg[2 * d] = a;
+    tg[2 * d + 1] = r;
+    if (pxy && azi) {
       const float range = __fmul_rn(__fadd_rn((float)r, 0.5f), resolution);
-      xy[2 * d] = __fmul_rn(range, cosf(az[a]));
-      xy[2 * d + 1] = __fmul_rn(range, sinf(az[a]));
+      pxy[2 * d] = __fmul_rn(range, cosf(azi[a]));
+      pxy[2 * d + 1] = __fmul_rn(range, sinf(azi[a]));
     }
   }
-  if (a == rows - 1 && threadIdx.x == 0) sc->n_targets = o + n;
+  if (a == rows - 1 && lane == 0) {
+    scal[img].n_targets = before + n;
+    if (counts) counts[img] = (int)(before + n);
+  }
 }
 
 }  // namespace
@@ -409,12 +651,64 @@ struct rsx_cen2019 {
   int device = 0, rows = 0, cols = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, h, keys, keys2, rowkey, rowkey2, rank, rank2, inc, mark, scal, row_count, row_off, row_out, row_n, row_off2,
-      targets, xy, az, temp, row_cur;
-  bool attr_set = false;
+  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts;
 };
 
 using rsx::fail;
+
+namespace {
+
+template <int C, int NT>
+void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int nb, int32_t stride, int32_t off, const rsx_cen2019_params &p,
+                  const float *d_az, int64_t az_stride, float resolution, int32_t max_targets, int *d_targets, float *d_xy, int *d_counts,
+                  int row_cap, hipStream_t s) {
+  const int rows = h->rows, cols = h->cols;
+  Scal *sc = h->scal.as<Scal>();
+  const dim3 grid((unsigned)rows, (unsigned)nb);
+  hipLaunchKernelGGL(cen_stats, grid, dim3(256), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
+  hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>());
+  hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
+  hipLaunchKernelGGL((cen_collect<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc,
+                     h->list.as<unsigned long long>(), (int64_t)rows * cols);
+  hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
+                     p.max_points);
+  hipLaunchKernelGGL((cen_extract<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, p.min_range, row_cap,
+                     h->row_out.as<int>(), h->row_n.as<unsigned>());
+  hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
+                     resolution, max_targets, d_targets, d_xy, d_counts);
+}
+
+// d_imgs: nb device images img_stride bytes apart; results stay on the device: d_targets [nb][max_targets][2] int32,
+// d_xy [nb][max_targets][2] float (optional, needs d_az), d_counts [nb] (optional; the counts are also in Scal)
+int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int nb, int32_t stride, int32_t off, const rsx_cen2019_params &p,
+                   const float *d_az, int64_t az_stride, float resolution, int32_t max_targets, int *d_targets, float *d_xy, int *d_counts,
+                   hipStream_t s) {
+  const int rows = h->rows, cols = h->cols;
+  const int row_cap = cols / 2 + 1;  // a row of `cols` bins holds at most ceil(cols / 2) closed runs
+  for (int b0 = 0; b0 < nb; b0 += MAX_SUB_BATCH) {
+    const int n = nb - b0 < MAX_SUB_BATCH ? nb - b0 : MAX_SUB_BATCH;
+    RSX_TRY(h->scal.reserve((size_t)n * sizeof(Scal), s, false));
+    RSX_TRY(h->hist.reserve((size_t)n * NBIN * 4, s, false));
+    RSX_TRY(h->list.reserve((size_t)n * rows * cols * 8, s, false));
+    RSX_TRY(h->row_out.reserve((size_t)n * rows * row_cap * 4, s, false));
+    RSX_TRY(h->row_n.reserve((size_t)n * rows * 4, s, false));
+    RSX_HIP(hipMemsetAsync(h->scal.p, 0, (size_t)n * sizeof(Scal), s));
+    RSX_HIP(hipMemsetAsync(h->hist.p, 0, (size_t)n * NBIN * 4, s));
+    const uint8_t *im = d_imgs + (int64_t)b0 * img_stride;
+    int *tg = d_targets + (int64_t)b0 * max_targets * 2;
+    float *pxy = d_xy ? d_xy + (int64_t)b0 * max_targets * 2 : nullptr;
+    const float *azp = d_az ? d_az + (int64_t)b0 * az_stride : nullptr;
+    int *cn = d_counts ? d_counts + b0 : nullptr;
+    if (cols <= 16 * 256)
+      launch_chain<16, 256>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
+    else
+      launch_chain<16, 1024>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
+    RSX_HIP(hipGetLastError());
+  }
+  return RSX_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
@@ -451,131 +745,92 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (rsx::DevBuf *b : {&h->img, &h->h, &h->keys, &h->keys2, &h->rowkey, &h->rowkey2, &h->rank, &h->rank2, &h->inc, &h->mark,
-                         &h->scal, &h->row_count, &h->row_off, &h->row_out, &h->row_n, &h->row_off2, &h->targets, &h->xy, &h->az,
-                         &h->temp, &h->row_cur})
-    b->release();
+  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
 }
 
-// d_img: device image; results stay on the device (d_targets int32 pairs, d_xy optional); *d_count
-// is the Scal.n_targets word read back by the host wrapper
-static int extract_device(rsx_cen2019 *h, const uint8_t *d_img, int32_t stride, int32_t off, const rsx_cen2019_params &p,
-                          const float *d_az, float resolution, int32_t max_targets, hipStream_t s) {
-  const int rows = h->rows, cols = h->cols;
-  const int64_t n = (int64_t)rows * cols;
-  RSX_TRY(h->h.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->keys.reserve((size_t)n * 8, s, false));
-  RSX_TRY(h->keys2.reserve((size_t)n * 8, s, false));
-  RSX_TRY(h->rowkey.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->rowkey2.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->rank.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->rank2.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->inc.reserve((size_t)n, s, false));
-  RSX_TRY(h->mark.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->scal.reserve(sizeof(Scal), s, false));
-  RSX_TRY(h->row_count.reserve((size_t)rows * 4, s, false));
-  RSX_TRY(h->row_off.reserve((size_t)(rows + 1) * 4, s, false));
-  RSX_TRY(h->row_off2.reserve((size_t)(rows + 1) * 4, s, false));
-  RSX_TRY(h->row_out.reserve((size_t)rows * ROW_CAP * 4, s, false));
-  RSX_TRY(h->row_n.reserve((size_t)rows * 4, s, false));
-  RSX_TRY(h->targets.reserve((size_t)(max_targets > 0 ? max_targets : 1) * 8, s, false));
-  RSX_TRY(h->xy.reserve((size_t)(max_targets > 0 ? max_targets : 1) * 8, s, false));
-  Scal *sc = h->scal.as<Scal>();
-  RSX_HIP(hipMemsetAsync(sc, 0, sizeof(Scal), s));
-  RSX_HIP(hipMemsetAsync(h->row_count.p, 0, (size_t)rows * 4, s));
-  hipLaunchKernelGGL(cen_stats, dim3(rows), dim3(256), 0, s, d_img, rows, cols, stride, off, sc);
-  hipLaunchKernelGGL(cen_h, dim3(rows), dim3(256), 0, s, d_img, rows, cols, stride, off, sc, h->h.as<float>());
-  hipLaunchKernelGGL(cen_candidates, dim3(rows), dim3(256), 0, s, h->h.as<float>(), rows, cols, sc,
-                     h->keys.as<unsigned long long>(), h->row_count.as<unsigned>());
-  RSX_HIP(hipGetLastError());
-  // the candidate count is needed on the host to size the sorts
-  unsigned m = 0;
-  RSX_HIP(hipMemcpyAsync(&m, &sc->n_cand, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  RSX_HIP(hipStreamSynchronize(s));
-  if (m > 0) {
-    size_t tb1 = 0, tb2 = 0;
-    RSX_HIP(rocprim::radix_sort_keys(nullptr, tb1, h->keys.as<unsigned long long>(), h->keys2.as<unsigned long long>(), m, 0, 64, s));
-    RSX_HIP(rocprim::radix_sort_pairs(nullptr, tb2, h->rowkey.as<unsigned>(), h->rowkey2.as<unsigned>(), h->rank.as<unsigned>(),
-                                      h->rank2.as<unsigned>(), m, 0, 10, s));
-    RSX_TRY(h->temp.reserve(tb1 > tb2 ? tb1 : tb2, s, false));
-    RSX_HIP(rocprim::radix_sort_keys(h->temp.p, tb1, h->keys.as<unsigned long long>(), h->keys2.as<unsigned long long>(), m, 0, 64, s));
-    hipLaunchKernelGGL(cen_rowkeys, dim3(1024), dim3(256), 0, s, h->keys2.as<unsigned long long>(), sc, cols,
-                       h->rowkey.as<unsigned>(), h->rank.as<unsigned>());
-    RSX_HIP(rocprim::radix_sort_pairs(h->temp.p, tb2, h->rowkey.as<unsigned>(), h->rowkey2.as<unsigned>(), h->rank.as<unsigned>(),
-                                      h->rank2.as<unsigned>(), m, 0, 10, s));
-  }
-  hipLaunchKernelGGL(cen_row_offsets, dim3(1), dim3(1024), 0, s, h->row_count.as<unsigned>(), rows, h->row_off.as<unsigned>());
-  const size_t lds = (size_t)cols * 5;
-  if (!h->attr_set) {
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cen_mark), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 5));
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&cen_extract), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 5));
-    h->attr_set = true;
-  }
-  // rank windows [0, W), [W, 4W), [4W, 16W) ...: the budget usually runs out in the first one
-  RSX_TRY(h->row_cur.reserve((size_t)rows * 4, s, false));
-  {
-    unsigned w = p.max_points > 0 ? 2u * (unsigned)p.max_points : 16384u;
-    w = (w + 16383u) & ~16383u;
-    unsigned lo = 0;
-    int first = 1;
-    while (true) {
-      const unsigned hi = (m - lo <= w) ? m : lo + w;
-      hipLaunchKernelGGL(cen_mark, dim3(rows), dim3(64), lds, s, d_img, rows, cols, stride, off, sc,
-                         h->keys2.as<unsigned long long>(), h->rank2.as<unsigned>(), h->row_off.as<unsigned>(), hi, first,
-                         h->row_cur.as<unsigned>(), h->mark.as<int>(), h->inc.as<uint8_t>());
-      hipLaunchKernelGGL(cen_budget, dim3(1), dim3(1024), 0, s, h->inc.as<uint8_t>(), sc, p.max_points, lo, hi);
-      first = 0;
-      if (hi >= m) break;
-      lo = hi;
-      w *= 4;
-    }
-  }
-  hipLaunchKernelGGL(cen_extract, dim3(rows), dim3(64), lds, s, h->h.as<float>(), h->mark.as<int>(), rows, cols, sc,
-                     p.min_range, h->row_out.as<int>(), h->row_n.as<unsigned>());
-  hipLaunchKernelGGL(cen_row_offsets, dim3(1), dim3(1024), 0, s, h->row_n.as<unsigned>(), rows, h->row_off2.as<unsigned>());
-  hipLaunchKernelGGL(cen_compact, dim3(rows), dim3(256), 0, s, h->row_out.as<int>(), h->row_n.as<unsigned>(),
-                     h->row_off2.as<unsigned>(), rows, d_az, resolution, max_targets, h->targets.as<int>(),
-                     d_az ? h->xy.as<float>() : nullptr, sc);
-  RSX_HIP(hipGetLastError());
-  return RSX_OK;
+int rsx_cen2019_extract_batch_device(rsx_cen2019 *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
+                                     int32_t col_offset, const rsx_cen2019_params *params, const float *d_azimuths,
+                                     int32_t azimuths_per_image, float resolution, int32_t *d_targets, float *d_xy, int32_t max_targets,
+                                     int32_t *d_counts, void *stream) {
+  if (!h || !d_imgs || !d_targets || n_images < 0 || max_targets < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (col_offset < 0 || row_stride < col_offset + h->cols) return fail(RSX_ERR_BAD_ARG, "row_stride %d too small for offset %d + %d columns", row_stride, col_offset, h->cols);
+  if (image_stride_bytes < (int64_t)h->rows * row_stride && n_images > 1) return fail(RSX_ERR_BAD_ARG, "image_stride_bytes smaller than an image");
+  if (d_xy && !d_azimuths) return fail(RSX_ERR_BAD_ARG, "d_xy needs d_azimuths");
+  if (n_images == 0) return RSX_OK;
+  rsx_cen2019_params p;
+  rsx_cen2019_default_params(&p);
+  if (params) p = *params;
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  return extract_device(h, d_imgs, image_stride_bytes, n_images, row_stride, col_offset, p, d_azimuths, azimuths_per_image ? h->rows : 0,
+                        resolution, max_targets, d_targets, d_xy, d_counts, s);
 }
 
-int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, int32_t col_offset,
-                        const rsx_cen2019_params *params, const float *azimuths, float resolution, int32_t *out_targets,
-                        float *out_xy, int32_t max_targets, int32_t *out_count) {
-  if (!h || !img || !out_targets || !out_count || max_targets < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+int rsx_cen2019_extract_batch(rsx_cen2019 *h, const uint8_t *imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
+                              int32_t col_offset, const rsx_cen2019_params *params, const float *azimuths, int32_t azimuths_per_image,
+                              float resolution, int32_t *out_targets, float *out_xy, int32_t max_targets, int32_t *out_counts) {
+  if (!h || !imgs || !out_targets || !out_counts || n_images < 0 || max_targets < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (col_offset < 0 || row_stride < col_offset + h->cols) return fail(RSX_ERR_BAD_ARG, "row_stride %d too small for offset %d + %d columns", row_stride, col_offset, h->cols);
+  if (n_images > 1 && image_stride_bytes < (int64_t)h->rows * row_stride) return fail(RSX_ERR_BAD_ARG, "image_stride_bytes smaller than an image");
   if (out_xy && !azimuths) return fail(RSX_ERR_BAD_ARG, "out_xy needs azimuths");
+  if (n_images == 0) return RSX_OK;
   rsx_cen2019_params p;
   rsx_cen2019_default_params(&p);
   if (params) p = *params;
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  const size_t bytes = (size_t)h->rows * row_stride;
-  RSX_TRY(h->img.reserve(bytes, s, false));
-  RSX_HIP(hipMemcpyAsync(h->img.p, img, bytes, hipMemcpyHostToDevice, s));
-  const float *d_az = nullptr;
-  if (azimuths) {
-    RSX_TRY(h->az.reserve((size_t)h->rows * 4, s, false));
-    RSX_HIP(hipMemcpyAsync(h->az.p, azimuths, (size_t)h->rows * 4, hipMemcpyHostToDevice, s));
-    d_az = h->az.as<float>();
-  }
-  RSX_TRY(extract_device(h, h->img.as<uint8_t>(), row_stride, col_offset, p, d_az, resolution, max_targets, s));
-  unsigned n = 0;
-  RSX_HIP(hipMemcpyAsync(&n, &h->scal.as<Scal>()->n_targets, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  RSX_HIP(hipStreamSynchronize(s));
-  const unsigned w = n < (unsigned)max_targets ? n : (unsigned)max_targets;
-  if (w) {
-    RSX_HIP(hipMemcpyAsync(out_targets, h->targets.p, (size_t)w * 8, hipMemcpyDeviceToHost, s));
-    if (out_xy) RSX_HIP(hipMemcpyAsync(out_xy, h->xy.p, (size_t)w * 8, hipMemcpyDeviceToHost, s));
+  const size_t ibytes = (size_t)h->rows * row_stride;
+  const int mt = max_targets > 0 ? max_targets : 1;
+  // sub-batches bound the staging memory; each one is a single upload, one launch chain, one download
+  for (int b0 = 0; b0 < n_images; b0 += MAX_SUB_BATCH) {
+    const int n = n_images - b0 < MAX_SUB_BATCH ? n_images - b0 : MAX_SUB_BATCH;
+    RSX_TRY(h->img.reserve(ibytes * n, s, false));
+    RSX_TRY(h->targets.reserve((size_t)n * mt * 8, s, false));
+    RSX_TRY(h->xy.reserve((size_t)n * mt * 8, s, false));
+    RSX_TRY(h->counts.reserve((size_t)n * 4, s, false));
+    if (n == 1 || image_stride_bytes == (int64_t)ibytes) {
+      RSX_HIP(hipMemcpyAsync(h->img.p, imgs + (int64_t)b0 * image_stride_bytes, ibytes * n, hipMemcpyHostToDevice, s));
+    } else {
+      RSX_HIP(hipMemcpy2DAsync(h->img.p, ibytes, imgs + (int64_t)b0 * image_stride_bytes, (size_t)image_stride_bytes, ibytes, (size_t)n,
+                               hipMemcpyHostToDevice, s));
+    }
+    const float *d_az = nullptr;
+    if (azimuths) {
+      const size_t na = (size_t)h->rows * (azimuths_per_image ? n : 1);
+      RSX_TRY(h->az.reserve(na * 4, s, false));
+      RSX_HIP(hipMemcpyAsync(h->az.p, azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0), na * 4, hipMemcpyHostToDevice, s));
+      d_az = h->az.as<float>();
+    }
+    RSX_TRY(extract_device(h, h->img.as<uint8_t>(), (int64_t)ibytes, n, row_stride, col_offset, p, d_az, azimuths_per_image ? h->rows : 0, resolution,
+                           mt, h->targets.as<int>(), d_az ? h->xy.as<float>() : nullptr, h->counts.as<int>(), s));
+    RSX_HIP(hipMemcpyAsync(out_counts + b0, h->counts.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n; i++) {
+      const unsigned cnt = (unsigned)out_counts[b0 + i];
+      const unsigned w = cnt < (unsigned)max_targets ? cnt : (unsigned)max_targets;
+      if (!w) continue;
+      RSX_HIP(hipMemcpyAsync(out_targets + (int64_t)(b0 + i) * max_targets * 2, h->targets.as<int>() + (int64_t)i * mt * 2, (size_t)w * 8,
+                             hipMemcpyDeviceToHost, s));
+      if (out_xy)
+        RSX_HIP(hipMemcpyAsync(out_xy + (int64_t)(b0 + i) * max_targets * 2, h->xy.as<float>() + (int64_t)i * mt * 2, (size_t)w * 8,
+                               hipMemcpyDeviceToHost, s));
+    }
     RSX_HIP(hipStreamSynchronize(s));
   }
-  *out_count = (int32_t)n;
   return RSX_OK;
+}
+
+int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, int32_t col_offset, const rsx_cen2019_params *params,
+                        const float *azimuths, float resolution, int32_t *out_targets, float *out_xy, int32_t max_targets,
+                        int32_t *out_count) {
+  if (!h || !img || !out_targets || !out_count || max_targets < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  return rsx_cen2019_extract_batch(h, img, 1, (int64_t)h->rows * row_stride, row_stride, col_offset, params, azimuths, 0, resolution, out_targets,
+                                   out_xy, max_targets, out_count);
 }
 
 }  // extern "C"

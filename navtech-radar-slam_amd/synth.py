@@ -325,3 +325,107 @@ def trajectory_keyframes(seed_db, n_db, seed_q, n_q, binary_z=True, revisit_frac
     q_pts, q_off = world.observe(rq, qposes, binary_z=binary_z)
     del size
     return db_pts, db_off, q_pts, q_off, src
+
+
+# ---------------------------------------------------------------------------------------------
+# A MOVING sensor: one fixed world of point reflectors seen from a sequence of known poses
+# (SURVEY 8d config 1 / BASELINE configs[0] and [2]: scan pairs with KNOWN motion, end to end).
+# Frame convention = the one the hot path uses (cen2019 step 5, rsx.h rsx_frontend_describe): a keypoint
+# at azimuth phi and range rho sits at (rho cos phi, rho sin phi) in the sensor frame.  A pose (x, y, yaw)
+# places the sensor in the world: p_world = R(yaw) p_sensor + (x, y).
+# ---------------------------------------------------------------------------------------------
+def relative_pose(p_from, p_to):
+    """Pose of sensor `p_to` expressed in the frame of sensor `p_from` (both (x, y, yaw) in the world):
+    p_from_frame = R(yaw_rel) p_to_frame + (x_rel, y_rel) -- what ORORA estimates with src = the scan taken
+    at p_to and dst = the scan taken at p_from."""
+    c, s = np.cos(p_from[2]), np.sin(p_from[2])
+    dx, dy = p_to[0] - p_from[0], p_to[1] - p_from[1]
+    yaw = (p_to[2] - p_from[2] + np.pi) % (2 * np.pi) - np.pi
+    return np.array([c * dx + s * dy, -s * dx + c * dy, yaw])
+
+
+def compose_pose(p, rel):
+    """p o rel: the world pose of a sensor whose pose in the frame of `p` is `rel`."""
+    c, s = np.cos(p[2]), np.sin(p[2])
+    return np.array([p[0] + c * rel[0] - s * rel[1], p[1] + s * rel[0] + c * rel[1], p[2] + rel[2]])
+
+
+def polar_sequence(seed, n_scans, rows=400, cols=3360, n_buildings=260, n_poles=500, world_radius=215.0,
+                   speed=(0.4, 2.6), yaw_rate=0.06, t0=1_560_000_000_000_000_000, period_ns=250_000_000):
+    """n_scans MulRan-shape polar images of ONE world seen from a moving sensor.
+
+    World: rectangular buildings (walls = chains of reflectors ~0.9 m apart at irregular spacing, each with its own fixed strength, so a
+    wall has a texture that survives from scan to scan) and isolated poles, none within 6 m of the driven line.
+    The sensor drives a smooth random curve (per scan: forward step within `speed` m with a slow random walk, a
+    lateral slip of a few cm, yaw increment ~N(0, yaw_rate) rad with memory).  Every reflector within radar range is
+    drawn as a Gaussian blob at its CONTINUOUS (azimuth row, range bin) position -- 1.8 deg beam (sigma ~0.85 rows),
+    1.2-3 range bins -- over an independent speckle floor per scan, so keypoints are unbiased observations of the
+    reflectors up to the polar quantisation.  No occlusion.  -> (images [n, rows, 11+cols] u8, azimuths f32[rows],
+    poses f64[n, 3] world poses with poses[0] = 0, stamps int64[n])."""
+    rng = np.random.default_rng(seed)
+    poses = np.zeros((n_scans, 3))
+    v = rng.uniform(*speed)
+    w = 0.0
+    for i in range(1, n_scans):
+        v = float(np.clip(v + rng.normal(0.0, 0.25), speed[0], speed[1]))
+        w = 0.7 * w + rng.normal(0.0, yaw_rate)
+        poses[i] = compose_pose(poses[i - 1], (v, rng.normal(0.0, 0.03), w))
+    centre = poses[:, :2].mean(axis=0)
+    rad = world_radius + np.abs(poses[:, :2] - centre).max()
+
+    def disc(n):
+        rr, tt = rad * np.sqrt(rng.uniform(0.0, 1.0, n)), rng.uniform(0.0, 2 * np.pi, n)
+        return centre[None, :] + np.stack([rr * np.cos(tt), rr * np.sin(tt)], axis=1)
+
+    pts = [disc(n_poles)]
+    amps = [rng.uniform(150.0, 240.0, n_poles)]
+    for c0 in disc(n_buildings):
+        wx, wy, th = rng.uniform(8.0, 40.0), rng.uniform(8.0, 40.0), rng.uniform(0.0, np.pi)
+        per = []
+        for (ax, ay, bx, by) in ((-wx, -wy, wx, -wy), (wx, -wy, wx, wy), (wx, wy, -wx, wy), (-wx, wy, -wx, -wy)):
+            n = max(2, int(np.hypot(bx - ax, by - ay) / 2 / 0.9))
+            t = np.sort(rng.uniform(0.0, 1.0, n))      # irregular spacing: a periodic wall lets matches slide along it
+            per.append(np.stack([ax + t * (bx - ax), ay + t * (by - ay)], axis=1) / 2)
+        per = np.concatenate(per) + rng.normal(0.0, 0.05, (sum(len(q) for q in per), 2))
+        cs, sn = np.cos(th), np.sin(th)
+        pts.append(c0[None, :] + per @ np.array([[cs, sn], [-sn, cs]]))
+        amps.append(rng.uniform(60.0, 200.0, len(per)))
+    world = np.concatenate(pts)
+    amp = np.concatenate(amps)
+    dmin = np.min(np.hypot(world[:, None, 0] - poses[None, :, 0], world[:, None, 1] - poses[None, :, 1]), axis=1)
+    keep = dmin > 6.0
+    world, amp = world[keep], amp[keep]
+    sig_r = rng.uniform(1.2, 3.0, len(world))
+    sig_a = rng.uniform(0.75, 1.0, len(world))
+    r_idx = np.arange(cols, dtype=np.float32)[None, :]
+    floor = 18.0 + 30.0 * np.exp(-r_idx / 900.0)
+    counts = (np.arange(rows) * (5600 // rows)).astype(np.uint16)
+    az = (counts.astype(np.float64) * 2 * np.pi / 5600.0).astype(np.float32)
+    az_step = 2 * np.pi / rows
+    images = np.zeros((n_scans, rows, OXFORD_META + cols), dtype=np.uint8)
+    stamps = t0 + np.arange(n_scans, dtype=np.int64) * period_ns
+    da, dr = np.arange(-3, 4), np.arange(-9, 10)
+    for i in range(n_scans):
+        power = rng.gamma(2.0, floor / 2.0, size=(rows, cols)).astype(np.float64)
+        c, s = np.cos(poses[i, 2]), np.sin(poses[i, 2])
+        d = world - poses[i, None, :2]
+        px, py = c * d[:, 0] + s * d[:, 1], -s * d[:, 0] + c * d[:, 1]
+        rho = np.hypot(px, py)
+        phi = np.mod(np.arctan2(py, px), 2 * np.pi)
+        rc = rho / RADAR_RESOLUTION - 0.5            # bin r covers [r res, (r+1) res): centre (r + 0.5) res
+        ac = phi / az_step
+        vis = (rc > 62.0) & (rc < cols - 12.0)
+        rc, ac, am, sr, sa = rc[vis], ac[vis], amp[vis], sig_r[vis], sig_a[vis]
+        a0, r0 = np.round(ac).astype(np.int64), np.round(rc).astype(np.int64)
+        aa = a0[:, None] + da[None, :]                                    # [K, 7]
+        rb = r0[:, None] + dr[None, :]                                    # [K, 19]
+        pa = np.exp(-0.5 * ((aa - ac[:, None]) / sa[:, None]) ** 2)
+        pr = np.exp(-0.5 * ((rb - rc[:, None]) / sr[:, None]) ** 2) * am[:, None]
+        flat = ((aa % rows)[:, :, None] * cols + rb[:, None, :]).reshape(-1)
+        power += np.bincount(flat, weights=(pa[:, :, None] * pr[:, None, :]).reshape(-1), minlength=rows * cols).reshape(rows, cols)
+        images[i, :, OXFORD_META:] = np.clip(power, 0, 255).astype(np.uint8)
+        ts = (stamps[i] + np.arange(rows, dtype=np.int64) * 625_000).astype("<i8")
+        images[i, :, 0:8] = ts.view(np.uint8).reshape(rows, 8)
+        images[i, :, 8:10] = counts.astype("<u2").view(np.uint8).reshape(rows, 2)
+        images[i, :, 10] = 255
+    return images, az, poses, stamps

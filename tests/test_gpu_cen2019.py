@@ -58,3 +58,53 @@ def test_rotated_scan_gives_rotated_keypoints(cen):
     a_rot = np.stack([(a[:, 0] + 37) % 400, a[:, 1]], axis=1)
     a_rot = a_rot[np.lexsort((a_rot[:, 1], a_rot[:, 0]))]
     assert np.array_equal(a_rot, b)
+
+
+def test_batch_equals_single_and_oracle(cen, oracle):
+    """rsx_cen2019_extract_batch: several scans in one chain of launches; every image bit-identical to the oracle and to
+    the single-image entry, different images in one batch do not interact (each has its own budget / selection)."""
+    imgs = np.stack([synth.polar_image(20 + i, n_targets=500 + 300 * i)[0] for i in range(5)])
+    az = synth.polar_image(20)[1]
+    ex = cen.Cen2019(400, 3360)
+    for mp in (10000, 700):
+        tg, xy = ex.extract_batch(imgs, max_points=mp, azimuths=az, resolution=synth.RADAR_RESOLUTION)
+        for i in range(len(imgs)):
+            want = oracle.cen2019_extract(imgs[i], max_points=mp)
+            assert np.array_equal(tg[i], want), (mp, i, len(tg[i]), len(want))
+            one, one_xy = ex.extract(imgs[i], max_points=mp, azimuths=az, resolution=synth.RADAR_RESOLUTION)
+            assert np.array_equal(one, want) and np.array_equal(one_xy, xy[i])
+
+
+def test_plateaus_and_ties(cen, oracle):
+    """Saturated plateaus give thousands of region openers with IDENTICAL h: the budget cut then falls inside one
+    histogram bin and is decided by pixel index alone (the radix select over the tie list)."""
+    rng = np.random.default_rng(5)
+    img, _, _ = synth.polar_image(9, n_targets=400)
+    for _ in range(60):
+        a, r = int(rng.integers(0, 398)), int(rng.integers(100, 3300))
+        img[a:a + 3, 11 + r:11 + r + int(rng.integers(5, 60))] = 255
+    ex = cen.Cen2019(400, 3360)
+    for mp in (50, 400, 2000, 10000):
+        got = ex.extract(img, max_points=mp)
+        want, dbg = oracle.cen2019_extract(img, max_points=mp, debug=True)
+        assert np.array_equal(got, want), (mp, len(got), len(want), dbg["jstar"])
+    # two-level images: every pixel is one of two values, h has three distinct values in all
+    two = np.where(rng.uniform(size=(64, 500)) < 0.2, 200, 20).astype(np.uint8)
+    ex2 = cen.Cen2019(64, 500)
+    for mp in (1, 10, 300, 10000):
+        for mr in (0, 7):
+            assert np.array_equal(ex2.extract(two, col_offset=0, max_points=mp, min_range=mr),
+                                  oracle.cen2019_extract(two, col_offset=0, max_points=mp, min_range=mr)), (mp, mr)
+
+
+def test_wide_rows(cen, oracle):
+    """cols > 4096 take the 1024-thread instantiation of the row kernels."""
+    rng = np.random.default_rng(12)
+    img = rng.gamma(2.0, 12.0, size=(12, 9000)).clip(0, 255).astype(np.uint8)
+    for _ in range(40):
+        a, r = int(rng.integers(0, 11)), int(rng.integers(10, 8900))
+        img[a:a + 2, r:r + 4] = rng.integers(150, 255, (2, 4))
+    ex = cen.Cen2019(12, 9000)
+    for mp in (25, 10000):
+        assert np.array_equal(ex.extract(img, col_offset=0, max_points=mp, min_range=3),
+                              oracle.cen2019_extract(img, col_offset=0, max_points=mp, min_range=3)), mp

@@ -17,7 +17,7 @@ def main(root):
             print(f"{calls:7d} {total:14.3f} {avg:12.3f} {pct:7.2f}  {name[:110]}")
         print("\n== per-dispatch durations of the dominant kernel (largest grids first) ==")
         q = ("select name, grid_x*grid_y*grid_z as g, count(*), avg(duration)/1000.0, min(duration)/1000.0, max(duration)/1000.0 "
-             "from kernels where name like '%_kernel%' and name like '%rsx%' group by name, g order by avg(duration) desc limit 8")
+             "from kernels where (name like '%_kernel%' or name like '%cen_%' or name like '%fe_%' or name like '%odo_%') group by name, g order by avg(duration) desc limit 8")
         try:
             for name, grid, n, avg, mn, mx in con.execute(q):
                 print(f"grid={grid:>10} launches={n:4d} avg_us={avg:12.3f} min_us={mn:12.3f} max_us={mx:12.3f}  {name[:60]}")
@@ -30,7 +30,7 @@ def main(root):
              "where grid_size = (select max(grid_size) from counters_collection d where d.kernel_name = c.kernel_name) "
              "group by kernel_name, counter_name order by kernel_name, counter_name")
         for name, cname, n, avg, grid, vgpr, lds in con.execute(q):
-            if "rsx" not in name:
+            if "rsx" not in name and "cen_" not in name and "fe_" not in name and "odo_" not in name:
                 continue
             short = name.split("::")[-1][:40]
             print(f"{short:42s} {cname:24s} dispatches={n:3d} avg_per_dispatch={avg:18.1f} grid={grid} vgpr={vgpr} lds={lds}")
