@@ -393,6 +393,68 @@ int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *
 int rsx_frontend_match(rsx_frontend *h, const uint8_t *q_desc, const uint8_t *q_valid, int32_t nq, const uint8_t *t_desc,
                        const uint8_t *t_valid, int32_t nt, float ratio, int32_t *out_train_idx, int32_t *out_d1, int32_t *out_d2);
 
+/* the batched / device-resident forms of the three calls above (what rsx_odometry chains; usable on their own):
+ * Cartesian images + smoothed copies of n_images scans resident in HBM, kept in the handle's slots 0 .. n_images-1
+ * (azimuths: HOST array, rows floats, the grid of the first image: the pixel map is built on the host once) */
+int rsx_frontend_cartesian_batch_device(rsx_frontend *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
+                                        int32_t col_offset, const float *azimuths, float resolution, void *stream);
+/* descriptors of the keypoints of every image of that batch: d_xy [n_images][max_targets][2] and d_counts [n_images] as
+ * rsx_cen2019_extract_batch_device leaves them -> d_desc [n_images][max_targets][32], d_valid [n_images][max_targets] */
+int rsx_frontend_describe_batch_device(rsx_frontend *h, const float *d_xy, const int32_t *d_counts, int32_t n_images, int32_t max_targets,
+                                       uint8_t *d_desc, uint8_t *d_valid, void *stream);
+/* knnMatch(2) + ratio between CONSECUTIVE keypoint sets of [slot][max_targets] arrays: pair j = (slot first_slot + j,
+ * slot first_slot + j + 1); d_fwd [n_pairs][max_targets]: for every keypoint of the first slot its match in the second
+ * (or -1), d_bwd the reverse direction */
+int rsx_frontend_match_consecutive_device(rsx_frontend *h, const uint8_t *d_desc, const uint8_t *d_valid, const int32_t *d_counts,
+                                          int32_t max_targets, int32_t first_slot, int32_t n_pairs, float ratio, int32_t *d_fwd,
+                                          int32_t *d_bwd, void *stream);
+
+/* ============================== file-based odometry pipeline ============================
+ * The main loop of the upstream file-based `odometry.cpp` entry (reference README.md:26-29,54-60; launched through
+ * $(find orora)/launch/run_orora.launch, launch/navtech_radar_slam_mulran.launch:5-8): polar scan -> cen2019 keypoints ->
+ * Cartesian image + ORB-style descriptors -> knnMatch(2) + ratio + cross check against the previous scan -> ORORA.
+ * The sequence is on disk, so a caller hands over WINDOWS of consecutive scans: every stage runs once per window for all
+ * scans / all consecutive pairs, everything between the image upload and the 48-byte result per scan stays in HBM, and
+ * ORORA registers all pairs of a window in one batch.  The handle remembers the last scan (on the device), so the pair
+ * that straddles two calls is registered too.  Pose composition (sequential, trivial) is the caller's.  Sources of the
+ * upstream entry are absent from the reference checkout (empty submodule) -- parity unpinned. */
+
+typedef struct rsx_odometry rsx_odometry;
+
+typedef struct {
+  rsx_cen2019_params cen;
+  rsx_frontend_params frontend;  /* frontend.ratio = the knnMatch ratio */
+  rsx_orora_params orora;
+  float radar_resolution;        /* metres per range bin (0.0595: Navtech CIR204-H / MulRan) */
+  int32_t col_offset;            /* metadata bytes in front of the power samples of every row (11) */
+  int32_t max_keypoints;         /* keypoints kept per scan (16384 = rsx_orora_max_correspondences(), its upper limit) */
+  int32_t device;
+} rsx_odometry_params;
+
+typedef struct {
+  rsx_orora_result reg;  /* motion between the previous scan and this one: p_previous = R(yaw) p_this + (x, y);
+                            reg.status = 3 for the first scan of a sequence (nothing to register against) */
+  int32_t n_keypoints;   /* cen2019 keypoints of this scan (only the first max_keypoints are used) */
+  int32_t n_matches;     /* cross-checked ratio matches handed to ORORA */
+} rsx_odometry_scan;
+
+int rsx_odometry_default_params(rsx_odometry_params *p);
+int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t cols, rsx_odometry **out);
+int rsx_odometry_destroy(rsx_odometry *h);
+int rsx_odometry_reset(rsx_odometry *h); /* forget the previous scan: the next scan starts a new sequence */
+int rsx_odometry_window(void);           /* scans per internal launch chain (longer calls are cut into such windows) */
+/* n_scans consecutive scans, host images image_stride_bytes apart (rows x row_stride bytes each); azimuths: rows floats
+ * (rad, increasing) shared by all scans or n_scans x rows when azimuths_per_image != 0.  out [n_scans]; out_xy
+ * (optional) [n_scans][max_xy][2]: the scan's keypoints in metres in the sensor frame (/orora/cloud_local).  Synchronous. */
+int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int64_t image_stride_bytes, int32_t row_stride,
+                      const float *azimuths, int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy);
+/* the same with the images already resident in HBM (d_imgs: device pointer; everything else host) */
+int rsx_odometry_push_device(rsx_odometry *h, const uint8_t *d_imgs, int32_t n_scans, int64_t image_stride_bytes, int32_t row_stride,
+                             const float *azimuths, int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy);
+/* page-locked host memory for image windows (decode threads write straight into it: the upload then runs at PCIe speed) */
+int rsx_host_alloc_pinned(size_t bytes, void **out);
+int rsx_host_free_pinned(void *p);
+
 /* ============================== VoxelGrid downsample ===================================
  * pcl::VoxelGrid<pcl::PointXYZI>::filter with setLeafSize(leaf, leaf, leaf): the step right before
  * makeAndSaveScancontextAndKeys in the reference's keyframe path (PGO.cpp:98,482-484; leaf 0.4 set at

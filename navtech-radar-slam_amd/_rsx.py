@@ -73,6 +73,20 @@ class Cen2019Params(C.Structure):
     _fields_ = [("max_points", C.c_int32), ("min_range", C.c_int32)]
 
 
+class OroraResult(C.Structure):
+    _fields_ = [("x", C.c_double), ("y", C.c_double), ("yaw", C.c_double), ("iterations", C.c_int32), ("rot_inliers", C.c_int32),
+                ("trans_inliers", C.c_int32), ("status", C.c_int32)]
+
+
+class OdometryParams(C.Structure):
+    _fields_ = [("cen", Cen2019Params), ("frontend", FrontendParams), ("orora", OroraParams), ("radar_resolution", C.c_float),
+                ("col_offset", C.c_int32), ("max_keypoints", C.c_int32), ("device", C.c_int32)]
+
+
+ODOMETRY_SCAN_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("iterations", "<i4"), ("rot_inliers", "<i4"),
+                                ("trans_inliers", "<i4"), ("status", "<i4"), ("n_keypoints", "<i4"), ("n_matches", "<i4")])
+
+
 ORORA_RESULT_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("iterations", "<i4"),
                                ("rot_inliers", "<i4"), ("trans_inliers", "<i4"), ("status", "<i4")])
 
@@ -102,6 +116,9 @@ SYMBOLS = [
     "rsx_cen2019_extract_batch", "rsx_cen2019_extract_batch_device",
     "rsx_frontend_default_params", "rsx_frontend_create", "rsx_frontend_destroy", "rsx_frontend_cartesian",
     "rsx_frontend_describe", "rsx_frontend_match",
+    "rsx_frontend_cartesian_batch_device", "rsx_frontend_describe_batch_device", "rsx_frontend_match_consecutive_device",
+    "rsx_odometry_default_params", "rsx_odometry_create", "rsx_odometry_destroy", "rsx_odometry_reset", "rsx_odometry_window",
+    "rsx_odometry_push", "rsx_odometry_push_device", "rsx_host_alloc_pinned", "rsx_host_free_pinned",
     "rsx_voxelgrid_create", "rsx_voxelgrid_destroy", "rsx_voxelgrid_filter", "rsx_sc_add_points_downsampled",
     "rsx_icp_default_params", "rsx_icp_create", "rsx_icp_destroy", "rsx_icp_align",
 ]
@@ -200,6 +217,17 @@ def lib():
         L.rsx_frontend_cartesian.argtypes = [vp, vp, i32, i32, vp, C.c_float, vp]
         L.rsx_frontend_describe.argtypes = [vp, vp, i32, vp, vp]
         L.rsx_frontend_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, C.c_float, vp, vp, vp]
+        L.rsx_frontend_cartesian_batch_device.argtypes = [vp, vp, i32, i64, i32, i32, vp, C.c_float, vp]
+        L.rsx_frontend_describe_batch_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+        L.rsx_frontend_match_consecutive_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.c_float, vp, vp, vp]
+        L.rsx_odometry_default_params.argtypes = [C.POINTER(OdometryParams)]
+        L.rsx_odometry_create.argtypes = [C.POINTER(OdometryParams), i32, i32, C.POINTER(vp)]
+        L.rsx_odometry_destroy.argtypes = [vp]
+        L.rsx_odometry_reset.argtypes = [vp]
+        L.rsx_odometry_push.argtypes = [vp, vp, i32, i64, i32, vp, i32, vp, vp, i32]
+        L.rsx_odometry_push_device.argtypes = [vp, vp, i32, i64, i32, vp, i32, vp, vp, i32]
+        L.rsx_host_alloc_pinned.argtypes = [C.c_size_t, C.POINTER(vp)]
+        L.rsx_host_free_pinned.argtypes = [vp]
         L.rsx_voxelgrid_create.argtypes = [C.c_int, C.POINTER(vp)]
         L.rsx_voxelgrid_destroy.argtypes = [vp]
         L.rsx_voxelgrid_filter.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i32, C.c_float, vp, i64, C.POINTER(i64)]

@@ -32,11 +32,14 @@ namespace {
 
 constexpr int HALF_PATCH = 15, NBINS = 30, NPAIRS = 256, BORDER = 19;
 
-__global__ __launch_bounds__(256) void fe_remap(const uint8_t *__restrict__ img, int rows, int cols, int row_stride, int col_offset,
-                                                int W, const float *__restrict__ map_rb, const float *__restrict__ map_ab,
-                                                float *__restrict__ cart) {
+// blockIdx.y = image of a batch (images img_stride bytes apart, Cartesian images W * W floats apart)
+__global__ __launch_bounds__(256) void fe_remap(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int row_stride,
+                                                int col_offset, int W, const float *__restrict__ map_rb, const float *__restrict__ map_ab,
+                                                float *__restrict__ carts) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)W * W) return;
+  const uint8_t *img = imgs + (int64_t)blockIdx.y * img_stride;
+  float *cart = carts + (int64_t)blockIdx.y * W * W;
   const float rb = map_rb[i], ab = map_ab[i];
   const float r0f = floorf(rb), a0f = floorf(ab);
   const float fr = rb - r0f, fa = ab - a0f;
@@ -59,9 +62,11 @@ __global__ __launch_bounds__(256) void fe_remap(const uint8_t *__restrict__ img,
 
 // one pass of the separable Gaussian along x (horizontal = true) or y; BORDER_REFLECT_101
 template <bool HORIZONTAL>
-__global__ __launch_bounds__(256) void fe_blur(const float *__restrict__ in, int W, const float *__restrict__ g, float *__restrict__ out) {
+__global__ __launch_bounds__(256) void fe_blur(const float *__restrict__ ins, int W, const float *__restrict__ g, float *__restrict__ outs) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)W * W) return;
+  const float *in = ins + (int64_t)blockIdx.y * W * W;
+  float *out = outs + (int64_t)blockIdx.y * W * W;
   const int v = (int)(i / W), u = (int)(i - (int64_t)v * W);
   float s = 0.0f;
 #pragma unroll
@@ -74,12 +79,30 @@ __global__ __launch_bounds__(256) void fe_blur(const float *__restrict__ in, int
   out[i] = s;
 }
 
-__global__ __launch_bounds__(64) void fe_describe(const float *__restrict__ cart, const float *__restrict__ blur, int W,
-                                                  const int32_t *__restrict__ uv, int n, const float *__restrict__ dir_cs,
-                                                  const int8_t *__restrict__ pairs, uint32_t *__restrict__ desc,
-                                                  uint8_t *__restrict__ valid) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
+// metric keypoints (x forward, y right) -> nearest Cartesian pixel (u, v), in double like the host form of
+// rsx_frontend_describe: blockIdx.y = image, xy [image][stride][2], counts[image] keypoints each
+__global__ __launch_bounds__(256) void fe_uv(const float *__restrict__ xy, const int32_t *__restrict__ counts, int stride, double cmr,
+                                             double cart_res, int32_t *__restrict__ uv) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  const int n = counts[blockIdx.y] < stride ? counts[blockIdx.y] : stride;
   if (k >= n) return;
+  const int64_t o = ((int64_t)blockIdx.y * stride + k) * 2;
+  uv[o] = (int32_t)round(((double)xy[o + 1] + cmr) / cart_res);
+  uv[o + 1] = (int32_t)round((cmr - (double)xy[o]) / cart_res);
+}
+
+// blockIdx.y = image: keypoint k of image b at uv / desc / valid slot b * stride + k; counts == nullptr: n keypoints
+__global__ __launch_bounds__(64) void fe_describe(const float *__restrict__ carts, const float *__restrict__ blurs, int W,
+                                                  const int32_t *__restrict__ uvs, int n, const int32_t *__restrict__ counts, int stride,
+                                                  const float *__restrict__ dir_cs, const int8_t *__restrict__ pairs,
+                                                  uint32_t *__restrict__ descs, uint8_t *__restrict__ valids) {
+  const int k = blockIdx.x * 64 + threadIdx.x;
+  if (counts) n = counts[blockIdx.y] < stride ? counts[blockIdx.y] : stride;
+  if (k >= n) return;
+  const float *cart = carts + (int64_t)blockIdx.y * W * W, *blur = blurs + (int64_t)blockIdx.y * W * W;
+  const int32_t *uv = uvs + (int64_t)blockIdx.y * stride * 2;
+  uint32_t *desc = descs + (int64_t)blockIdx.y * stride * 8;
+  uint8_t *valid = valids + (int64_t)blockIdx.y * stride;
   const int u = uv[2 * k], v = uv[2 * k + 1];
   uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool ok = !(u < BORDER || v < BORDER || u >= W - BORDER || v >= W - BORDER);
@@ -154,6 +177,53 @@ __global__ __launch_bounds__(256) void fe_match(const uint32_t *__restrict__ q, 
   }
 }
 
+// knnMatch(2) + ratio between CONSECUTIVE scans of a batch: blockIdx.y = pair j (slots first + j and first + j + 1 of the
+// [slot][stride] arrays), blockIdx.z = direction: 0 queries = slot A against train = slot B -> fwd[j][i], 1 the reverse
+// -> bwd[j][i].  Same scan order and tie rule as fe_match.
+__global__ __launch_bounds__(256) void fe_match_consecutive(const uint32_t *__restrict__ descs, const uint8_t *__restrict__ valids,
+                                                            const int32_t *__restrict__ counts, int stride, int first, float ratio,
+                                                            int32_t *__restrict__ fwd, int32_t *__restrict__ bwd) {
+  __shared__ uint32_t st[256 * 8];
+  __shared__ uint8_t sv[256];
+  const int j = blockIdx.y, dir = blockIdx.z;
+  const int qs = first + j + dir, ts = first + j + 1 - dir;
+  const int nq = counts[qs] < stride ? counts[qs] : stride, nt = counts[ts] < stride ? counts[ts] : stride;
+  if ((int)blockIdx.x * 256 >= nq) return;
+  const uint32_t *q = descs + (int64_t)qs * stride * 8, *t = descs + (int64_t)ts * stride * 8;
+  const uint8_t *qv = valids + (int64_t)qs * stride, *tv = valids + (int64_t)ts * stride;
+  int32_t *out_idx = (dir ? bwd : fwd) + (int64_t)j * stride;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t me[8];
+  const bool live = i < nq && qv[i];
+#pragma unroll
+  for (int w = 0; w < 8; w++) me[w] = i < nq ? q[(int64_t)i * 8 + w] : 0u;
+  int d1 = 1 << 30, d2 = 1 << 30, i1 = -1;
+  for (int j0 = 0; j0 < nt; j0 += 256) {
+    __syncthreads();
+    const int jj0 = j0 + threadIdx.x;
+#pragma unroll
+    for (int w = 0; w < 8; w++) st[threadIdx.x * 8 + w] = jj0 < nt ? t[(int64_t)jj0 * 8 + w] : 0u;
+    sv[threadIdx.x] = jj0 < nt ? tv[jj0] : 0;
+    __syncthreads();
+    const int lim = nt - j0 < 256 ? nt - j0 : 256;
+    if (live)
+      for (int jj = 0; jj < lim; jj++) {
+        if (!sv[jj]) continue;
+        int d = 0;
+#pragma unroll
+        for (int w = 0; w < 8; w++) d += __popc(me[w] ^ st[jj * 8 + w]);
+        if (d < d1) {
+          d2 = d1;
+          d1 = d;
+          i1 = j0 + jj;
+        } else if (d < d2) {
+          d2 = d;
+        }
+      }
+  }
+  if (i < nq) out_idx[i] = (i1 >= 0 && d2 < (1 << 30) && (float)d1 < ratio * (float)d2) ? i1 : -1;
+}
+
 }  // namespace
 
 struct rsx_frontend {
@@ -165,6 +235,7 @@ struct rsx_frontend {
   // the map depends on the radar's range resolution and azimuth grid: rebuilt only when they change
   double map_radar_res = -1.0, map_az0 = 0.0, map_az_step = 0.0;
   bool have_image = false;
+  int batch_n = 0;  // Cartesian images held by the last rsx_frontend_cartesian* call
 };
 
 using rsx::fail;
@@ -282,6 +353,58 @@ int rsx_frontend_destroy(rsx_frontend *h) {
   return RSX_OK;
 }
 
+// (re)build the pixel -> (range bin, azimuth row) map when the radar's range resolution or azimuth grid changed
+static int ensure_map(rsx_frontend *h, const float *azimuths, float resolution, hipStream_t s) {
+  const int W = h->W;
+  const size_t npx = (size_t)W * W;
+  const double az0 = (double)azimuths[0], az_step = (double)azimuths[1] - (double)azimuths[0];
+  if (!(az_step > 0.0)) return fail(RSX_ERR_BAD_ARG, "azimuths must increase");
+  if (h->map_radar_res == (double)resolution && h->map_az0 == az0 && h->map_az_step == az_step) return RSX_OK;
+  // in double on the host: forward = azimuth 0, azimuth grows to the right
+  std::vector<float> rb(npx), ab(npx);
+  const double cmr = cart_min_range(W, h->cart_res);
+  for (int v = 0; v < W; v++)
+    for (int u = 0; u < W; u++) {
+      const double fwd = cmr - v * h->cart_res, right = -cmr + u * h->cart_res;
+      const double r = std::sqrt(fwd * fwd + right * right);
+      double th = std::atan2(right, fwd);
+      if (th < 0) th += 2.0 * M_PI;
+      double a = (th - az0) / az_step;
+      a = std::fmod(a, (double)h->rows);
+      if (a < 0) a += h->rows;
+      if (a >= h->rows) a -= h->rows;
+      rb[(size_t)v * W + u] = (float)((r - (double)resolution / 2.0) / (double)resolution);
+      ab[(size_t)v * W + u] = (float)a;
+    }
+  RSX_HIP(hipMemcpyAsync(h->map_rb.p, rb.data(), npx * sizeof(float), hipMemcpyHostToDevice, s));
+  RSX_HIP(hipMemcpyAsync(h->map_ab.p, ab.data(), npx * sizeof(float), hipMemcpyHostToDevice, s));
+  RSX_HIP(hipStreamSynchronize(s));  // rb / ab are locals
+  h->map_radar_res = (double)resolution;
+  h->map_az0 = az0;
+  h->map_az_step = az_step;
+  return RSX_OK;
+}
+
+// n device images -> n Cartesian images + smoothed copies in the handle's slots 0 .. n-1
+static int cartesian_device(rsx_frontend *h, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, int32_t col_offset,
+                            hipStream_t s) {
+  const int W = h->W;
+  const size_t npx = (size_t)W * W;
+  RSX_TRY(h->cart.reserve(npx * sizeof(float) * n, s, false));
+  RSX_TRY(h->tmp.reserve(npx * sizeof(float) * n, s, false));
+  RSX_TRY(h->blur.reserve(npx * sizeof(float) * n, s, false));
+  const dim3 grid((unsigned)((npx + 255) / 256), (unsigned)n);
+  const float *g = reinterpret_cast<const float *>(static_cast<const char *>(h->tables.p) + TAB_GAUSS);
+  hipLaunchKernelGGL(fe_remap, grid, dim3(256), 0, s, d_imgs, img_stride, h->rows, h->cols, row_stride, col_offset, W, h->map_rb.as<float>(),
+                     h->map_ab.as<float>(), h->cart.as<float>());
+  hipLaunchKernelGGL(fe_blur<true>, grid, dim3(256), 0, s, h->cart.as<float>(), W, g, h->tmp.as<float>());
+  hipLaunchKernelGGL(fe_blur<false>, grid, dim3(256), 0, s, h->tmp.as<float>(), W, g, h->blur.as<float>());
+  RSX_HIP(hipGetLastError());
+  h->have_image = true;
+  h->batch_n = n;
+  return RSX_OK;
+}
+
 int rsx_frontend_cartesian(rsx_frontend *h, const uint8_t *img, int32_t row_stride, int32_t col_offset, const float *azimuths,
                            float resolution, float *out_cart) {
   if (!h || !img || !azimuths) return fail(RSX_ERR_BAD_ARG, "null arg");
@@ -289,48 +412,26 @@ int rsx_frontend_cartesian(rsx_frontend *h, const uint8_t *img, int32_t row_stri
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  const int W = h->W;
-  const size_t npx = (size_t)W * W;
-  const double az0 = (double)azimuths[0], az_step = (double)azimuths[1] - (double)azimuths[0];
-  if (!(az_step > 0.0)) return fail(RSX_ERR_BAD_ARG, "azimuths must increase");
-  if (h->map_radar_res != (double)resolution || h->map_az0 != az0 || h->map_az_step != az_step) {
-    // pixel -> (range bin, azimuth row), in double on the host: forward = azimuth 0, azimuth grows to the right
-    std::vector<float> rb(npx), ab(npx);
-    const double cmr = cart_min_range(W, h->cart_res);
-    for (int v = 0; v < W; v++)
-      for (int u = 0; u < W; u++) {
-        const double fwd = cmr - v * h->cart_res, right = -cmr + u * h->cart_res;
-        const double r = std::sqrt(fwd * fwd + right * right);
-        double th = std::atan2(right, fwd);
-        if (th < 0) th += 2.0 * M_PI;
-        double a = (th - az0) / az_step;
-        a = std::fmod(a, (double)h->rows);
-        if (a < 0) a += h->rows;
-        if (a >= h->rows) a -= h->rows;
-        rb[(size_t)v * W + u] = (float)((r - (double)resolution / 2.0) / (double)resolution);
-        ab[(size_t)v * W + u] = (float)a;
-      }
-    RSX_HIP(hipMemcpyAsync(h->map_rb.p, rb.data(), npx * sizeof(float), hipMemcpyHostToDevice, s));
-    RSX_HIP(hipMemcpyAsync(h->map_ab.p, ab.data(), npx * sizeof(float), hipMemcpyHostToDevice, s));
-    RSX_HIP(hipStreamSynchronize(s));  // rb / ab are locals
-    h->map_radar_res = (double)resolution;
-    h->map_az0 = az0;
-    h->map_az_step = az_step;
-  }
+  RSX_TRY(ensure_map(h, azimuths, resolution, s));
   const size_t ibytes = (size_t)h->rows * row_stride;
   RSX_TRY(h->img.reserve(ibytes, s, false));
   RSX_HIP(hipMemcpyAsync(h->img.p, img, ibytes, hipMemcpyHostToDevice, s));
-  const unsigned grid = (unsigned)((npx + 255) / 256);
-  const float *g = reinterpret_cast<const float *>(static_cast<const char *>(h->tables.p) + TAB_GAUSS);
-  hipLaunchKernelGGL(fe_remap, dim3(grid), dim3(256), 0, s, h->img.as<uint8_t>(), h->rows, h->cols, row_stride, col_offset, W,
-                     h->map_rb.as<float>(), h->map_ab.as<float>(), h->cart.as<float>());
-  hipLaunchKernelGGL(fe_blur<true>, dim3(grid), dim3(256), 0, s, h->cart.as<float>(), W, g, h->tmp.as<float>());
-  hipLaunchKernelGGL(fe_blur<false>, dim3(grid), dim3(256), 0, s, h->tmp.as<float>(), W, g, h->blur.as<float>());
-  RSX_HIP(hipGetLastError());
-  if (out_cart) RSX_HIP(hipMemcpyAsync(out_cart, h->cart.p, npx * sizeof(float), hipMemcpyDeviceToHost, s));
+  RSX_TRY(cartesian_device(h, h->img.as<uint8_t>(), 1, (int64_t)ibytes, row_stride, col_offset, s));
+  if (out_cart) RSX_HIP(hipMemcpyAsync(out_cart, h->cart.p, (size_t)h->W * h->W * sizeof(float), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
-  h->have_image = true;
   return RSX_OK;
+}
+
+int rsx_frontend_cartesian_batch_device(rsx_frontend *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
+                                        int32_t col_offset, const float *azimuths, float resolution, void *stream) {
+  if (!h || !d_imgs || !azimuths || n_images < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (row_stride < col_offset + h->cols || col_offset < 0 || !(resolution > 0.0f)) return fail(RSX_ERR_BAD_ARG, "bad image layout");
+  if (n_images > 1 && image_stride_bytes < (int64_t)h->rows * row_stride) return fail(RSX_ERR_BAD_ARG, "image_stride_bytes smaller than an image");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  RSX_TRY(ensure_map(h, azimuths, resolution, s));
+  return cartesian_device(h, d_imgs, n_images, image_stride_bytes, row_stride, col_offset, s);
 }
 
 int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *out_desc, uint8_t *out_valid) {
@@ -353,12 +454,46 @@ int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *
   RSX_HIP(hipMemcpyAsync(h->uv.p, uv.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
   const char *tab = static_cast<const char *>(h->tables.p);
   hipLaunchKernelGGL(fe_describe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, h->cart.as<float>(), h->blur.as<float>(), h->W,
-                     h->uv.as<int32_t>(), n, reinterpret_cast<const float *>(tab + TAB_DIR), reinterpret_cast<const int8_t *>(tab + TAB_PAIRS),
-                     h->desc.as<uint32_t>(), h->valid.as<uint8_t>());
+                     h->uv.as<int32_t>(), n, (const int32_t *)nullptr, n, reinterpret_cast<const float *>(tab + TAB_DIR),
+                     reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), h->desc.as<uint32_t>(), h->valid.as<uint8_t>());
   RSX_HIP(hipGetLastError());
   RSX_HIP(hipMemcpyAsync(out_desc, h->desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipMemcpyAsync(out_valid, h->valid.p, (size_t)n, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));  // also keeps uv alive until the copy is done
+  return RSX_OK;
+}
+
+int rsx_frontend_describe_batch_device(rsx_frontend *h, const float *d_xy, const int32_t *d_counts, int32_t n_images, int32_t max_targets,
+                                       uint8_t *d_desc, uint8_t *d_valid, void *stream) {
+  if (!h || !d_xy || !d_counts || !d_desc || !d_valid || n_images < 1 || max_targets < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->have_image || n_images > h->batch_n) return fail(RSX_ERR_BAD_ARG, "describe_batch: %d images, the last Cartesian batch holds %d", n_images, h->batch_n);
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  RSX_TRY(h->uv.reserve((size_t)n_images * max_targets * 8, s, false));
+  const double cmr = cart_min_range(h->W, h->cart_res);
+  hipLaunchKernelGGL(fe_uv, dim3((unsigned)((max_targets + 255) / 256), (unsigned)n_images), dim3(256), 0, s, d_xy, d_counts, max_targets, cmr,
+                     h->cart_res, h->uv.as<int32_t>());
+  const char *tab = static_cast<const char *>(h->tables.p);
+  hipLaunchKernelGGL(fe_describe, dim3((unsigned)((max_targets + 63) / 64), (unsigned)n_images), dim3(64), 0, s, h->cart.as<float>(),
+                     h->blur.as<float>(), h->W, h->uv.as<int32_t>(), 0, d_counts, max_targets, reinterpret_cast<const float *>(tab + TAB_DIR),
+                     reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), reinterpret_cast<uint32_t *>(d_desc), d_valid);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int rsx_frontend_match_consecutive_device(rsx_frontend *h, const uint8_t *d_desc, const uint8_t *d_valid, const int32_t *d_counts,
+                                          int32_t max_targets, int32_t first_slot, int32_t n_pairs, float ratio, int32_t *d_fwd,
+                                          int32_t *d_bwd, void *stream) {
+  if (!h || !d_desc || !d_valid || !d_counts || !d_fwd || !d_bwd || max_targets < 1 || first_slot < 0 || n_pairs < 0)
+    return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (n_pairs == 0) return RSX_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipLaunchKernelGGL(fe_match_consecutive, dim3((unsigned)((max_targets + 255) / 256), (unsigned)n_pairs, 2), dim3(256), 0, s,
+                     reinterpret_cast<const uint32_t *>(d_desc), d_valid, d_counts, max_targets, first_slot, ratio, d_fwd, d_bwd);
+  RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 

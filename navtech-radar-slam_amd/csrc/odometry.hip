@@ -1,0 +1,337 @@
+// odometry.hip -- the per-sequence pipeline of the upstream file-based odometry.cpp entry, device resident and batched.
+//
+// What the reference runs per scan (its ORORA submodule, an empty directory in the reference checkout: .gitmodules:1-3;
+// README.md:26-29,54-60; launch/navtech_radar_slam_mulran.launch:5-8): polar image -> cen2019 keypoints -> Cartesian image
+// -> ORB descriptors -> BFMatcher knnMatch(2) + ratio against the previous scan -> ORORA (GNC rotation, A-COTE
+// translation) -> pose composition.  The sequence is on disk, so every scan and every consecutive pair is independent
+// until the final composition: a WINDOW of n scans goes through each stage in ONE launch chain --
+//     rsx_cen2019_extract_batch_device          n images   (csrc/cen2019.hip)
+//     rsx_frontend_cartesian_batch_device       n images   (csrc/frontend.hip)
+//     rsx_frontend_describe_batch_device        n keypoint sets
+//     rsx_frontend_match_consecutive_device     all consecutive pairs, both directions
+//     odo_cross / odo_gather                    cross check (the two directions must agree) + correspondence lists
+//     rsx_orora_register_batch_device           all pairs of the window in one call (csrc/orora.hip)
+// -- with every intermediate (keypoints, descriptors, matches, correspondences) in HBM; one upload of the images and one
+// download of 48 bytes per scan (+ the keypoints when the caller wants /orora/cloud_local).  The last scan of a window
+// stays on the device as the "previous scan" of the next one.  Pose composition stays on the host (sequential, trivial).
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "rsx_common.h"
+
+namespace {
+
+constexpr int MAX_WINDOW = 64;  // scans per internal launch chain (workspace: ~26 MB per scan)
+
+// one block per consecutive pair j (slots A = first + j, B = A + 1): keep prev keypoint i when fwd[i] = k >= 0 and
+// bwd[k] = i, in ascending i (the order the host loop of round 2 produced); src = the CURRENT scan's point, dst = the
+// previous scan's point, so that ORORA returns the motion of the sensor expressed in the previous frame.
+__global__ __launch_bounds__(256) void odo_cross(const float *__restrict__ xy, const int32_t *__restrict__ counts, int stride, int first,
+                                                 const int32_t *__restrict__ fwd, const int32_t *__restrict__ bwd,
+                                                 float2 *__restrict__ stage_src, float2 *__restrict__ stage_dst, int32_t *__restrict__ pair_cnt) {
+  __shared__ unsigned s_w[4];
+  const int j = blockIdx.x, A = first + j, B = A + 1;
+  const int nA = counts[A] < stride ? counts[A] : stride, nB = counts[B] < stride ? counts[B] : stride;
+  const int32_t *f = fwd + (int64_t)j * stride, *b = bwd + (int64_t)j * stride;
+  const float2 *pa = reinterpret_cast<const float2 *>(xy) + (int64_t)A * stride, *pb = reinterpret_cast<const float2 *>(xy) + (int64_t)B * stride;
+  float2 *ss = stage_src + (int64_t)j * stride, *sd = stage_dst + (int64_t)j * stride;
+  unsigned run = 0;
+  for (int base = 0; base < nA; base += 256) {
+    const int i = base + threadIdx.x;
+    int k = -1;
+    if (i < nA) {
+      k = f[i];
+      if (k >= nB || (k >= 0 && b[k] != i)) k = -1;
+    }
+    const unsigned long long bal = __ballot(k >= 0);
+    const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) s_w[w] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned before = run, total = 0;
+    for (unsigned ww = 0; ww < 4; ww++) {
+      if (ww < w) before += s_w[ww];
+      total += s_w[ww];
+    }
+    if (k >= 0) {
+      const unsigned pos = before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+      ss[pos] = pb[k];
+      sd[pos] = pa[i];
+    }
+    run += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) pair_cnt[j] = (int32_t)run;
+}
+
+// one block per pair: contiguous correspondence arrays + the offsets rsx_orora_register_batch_device wants
+__global__ __launch_bounds__(256) void odo_gather(const float2 *__restrict__ stage_src, const float2 *__restrict__ stage_dst,
+                                                  const int32_t *__restrict__ pair_cnt, int n_pairs, int stride, float2 *__restrict__ src,
+                                                  float2 *__restrict__ dst, int64_t *__restrict__ offsets) {
+  __shared__ long long s_w[4];
+  const int j = blockIdx.x;
+  long long before = 0;
+  for (int r = threadIdx.x; r < j; r += 256) before += pair_cnt[r];
+  for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
+  if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = before;
+  __syncthreads();
+  before = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+  const int n = pair_cnt[j];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    src[before + i] = stage_src[(int64_t)j * stride + i];
+    dst[before + i] = stage_dst[(int64_t)j * stride + i];
+  }
+  if (threadIdx.x == 0) {
+    offsets[j] = before;
+    if (j == n_pairs - 1) offsets[n_pairs] = before + n;
+  }
+}
+
+}  // namespace
+
+struct rsx_odometry {
+  int device = 0, rows = 0, cols = 0;
+  rsx_odometry_params prm{};
+  std::mutex mu;
+  hipStream_t stream = nullptr;
+  rsx_cen2019 *cen = nullptr;
+  rsx_frontend *fe = nullptr;
+  rsx_orora *reg = nullptr;
+  // slot 0 = the previous scan (carried over between windows), slots 1 .. MAX_WINDOW = the window
+  rsx::DevBuf imgs, az, targets, xy, counts, desc, valid, fwd, bwd, stage_src, stage_dst, pair_cnt, src, dst, offsets, results;
+  void *h_pin = nullptr;  // pinned: counts[MAX_WINDOW + 1], pair_cnt[MAX_WINDOW], results[MAX_WINDOW]
+  bool have_prev = false;
+};
+
+using rsx::fail;
+
+namespace {
+
+constexpr size_t PIN_COUNTS = 0, PIN_PAIRS = 4 * (MAX_WINDOW + 1), PIN_RES = PIN_PAIRS + 4 * MAX_WINDOW + 4,
+                 PIN_BYTES = PIN_RES + sizeof(rsx_orora_result) * MAX_WINDOW;
+
+int reserve_all(rsx_odometry *h, size_t ibytes, hipStream_t s) {
+  const size_t K = (size_t)h->prm.max_keypoints, S = MAX_WINDOW + 1;
+  RSX_TRY(h->imgs.reserve(ibytes * MAX_WINDOW, s, false));
+  RSX_TRY(h->az.reserve((size_t)h->rows * 4 * MAX_WINDOW, s, false));
+  RSX_TRY(h->targets.reserve(S * K * 8, s, false));
+  RSX_TRY(h->xy.reserve(S * K * 8, s, true));
+  RSX_TRY(h->counts.reserve(S * 4, s, true));
+  RSX_TRY(h->desc.reserve(S * K * 32, s, true));
+  RSX_TRY(h->valid.reserve(S * K, s, true));
+  RSX_TRY(h->fwd.reserve((size_t)MAX_WINDOW * K * 4, s, false));
+  RSX_TRY(h->bwd.reserve((size_t)MAX_WINDOW * K * 4, s, false));
+  RSX_TRY(h->stage_src.reserve((size_t)MAX_WINDOW * K * 8, s, false));
+  RSX_TRY(h->stage_dst.reserve((size_t)MAX_WINDOW * K * 8, s, false));
+  RSX_TRY(h->pair_cnt.reserve((size_t)MAX_WINDOW * 4, s, false));
+  RSX_TRY(h->src.reserve((size_t)MAX_WINDOW * K * 8, s, false));
+  RSX_TRY(h->dst.reserve((size_t)MAX_WINDOW * K * 8, s, false));
+  RSX_TRY(h->offsets.reserve((size_t)(MAX_WINDOW + 1) * 8, s, false));
+  RSX_TRY(h->results.reserve((size_t)MAX_WINDOW * sizeof(rsx_orora_result), s, false));
+  return RSX_OK;
+}
+
+// one window of n <= MAX_WINDOW scans whose images are at d_imgs (device); fills out[0..n)
+int run_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, const float *azimuths,
+               int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy, hipStream_t s) {
+  const int K = h->prm.max_keypoints;
+  const size_t slot_xy = (size_t)K * 2;
+  // azimuths: the Cartesian map needs them on the host (first image's grid), cen2019's polar -> Cartesian on the device
+  const size_t na = (size_t)h->rows * (azimuths_per_image ? n : 1);
+  RSX_HIP(hipMemcpyAsync(h->az.p, azimuths, na * 4, hipMemcpyHostToDevice, s));
+  int32_t *d_counts = h->counts.as<int32_t>();
+  RSX_TRY(rsx_cen2019_extract_batch_device(h->cen, d_imgs, n, img_stride, row_stride, h->prm.col_offset, &h->prm.cen, h->az.as<float>(),
+                                           azimuths_per_image, h->prm.radar_resolution, h->targets.as<int32_t>() + slot_xy,
+                                           h->xy.as<float>() + slot_xy, K, d_counts + 1, s));
+  RSX_TRY(rsx_frontend_cartesian_batch_device(h->fe, d_imgs, n, img_stride, row_stride, h->prm.col_offset, azimuths, h->prm.radar_resolution, s));
+  RSX_TRY(rsx_frontend_describe_batch_device(h->fe, h->xy.as<float>() + slot_xy, d_counts + 1, n, K, h->desc.as<uint8_t>() + (size_t)K * 32,
+                                             h->valid.as<uint8_t>() + (size_t)K, s));
+  const int first = h->have_prev ? 0 : 1, n_pairs = n - first;
+  if (n_pairs > 0) {
+    RSX_TRY(rsx_frontend_match_consecutive_device(h->fe, h->desc.as<uint8_t>(), h->valid.as<uint8_t>(), d_counts, K, first, n_pairs,
+                                                  h->prm.frontend.ratio, h->fwd.as<int32_t>(), h->bwd.as<int32_t>(), s));
+    hipLaunchKernelGGL(odo_cross, dim3((unsigned)n_pairs), dim3(256), 0, s, h->xy.as<float>(), d_counts, K, first, h->fwd.as<int32_t>(),
+                       h->bwd.as<int32_t>(), h->stage_src.as<float2>(), h->stage_dst.as<float2>(), h->pair_cnt.as<int32_t>());
+    hipLaunchKernelGGL(odo_gather, dim3((unsigned)n_pairs), dim3(256), 0, s, h->stage_src.as<float2>(), h->stage_dst.as<float2>(),
+                       h->pair_cnt.as<int32_t>(), n_pairs, K, h->src.as<float2>(), h->dst.as<float2>(), h->offsets.as<int64_t>());
+    RSX_HIP(hipGetLastError());
+    RSX_TRY(rsx_orora_register_batch_device(h->reg, h->src.as<float>(), h->dst.as<float>(), h->offsets.as<int64_t>(), n_pairs, &h->prm.orora,
+                                            h->results.as<rsx_orora_result>(), s));
+  }
+  char *pin = static_cast<char *>(h->h_pin);
+  RSX_HIP(hipMemcpyAsync(pin + PIN_COUNTS, d_counts, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, s));
+  if (n_pairs > 0) {
+    RSX_HIP(hipMemcpyAsync(pin + PIN_PAIRS, h->pair_cnt.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipMemcpyAsync(pin + PIN_RES, h->results.p, (size_t)n_pairs * sizeof(rsx_orora_result), hipMemcpyDeviceToHost, s));
+  }
+  RSX_HIP(hipStreamSynchronize(s));
+  const int32_t *hc = reinterpret_cast<const int32_t *>(pin + PIN_COUNTS), *hp = reinterpret_cast<const int32_t *>(pin + PIN_PAIRS);
+  const rsx_orora_result *hr = reinterpret_cast<const rsx_orora_result *>(pin + PIN_RES);
+  for (int i = 0; i < n; i++) {
+    rsx_odometry_scan &o = out[i];
+    std::memset(&o, 0, sizeof(o));
+    o.n_keypoints = hc[1 + i];
+    const int pj = h->have_prev ? i : i - 1;  // index of the pair (scan i-1, scan i) in this window
+    if (pj >= 0) {
+      o.reg = hr[pj];
+      o.n_matches = hp[pj];
+    } else {
+      o.reg.status = 3;  // the first scan of a sequence: there is no previous scan
+    }
+  }
+  if (out_xy && max_xy > 0) {
+    for (int i = 0; i < n; i++) {
+      const int c = hc[1 + i] < K ? hc[1 + i] : K, wn = c < max_xy ? c : max_xy;
+      if (wn > 0)
+        RSX_HIP(hipMemcpyAsync(out_xy + (size_t)i * max_xy * 2, h->xy.as<float>() + (size_t)(1 + i) * slot_xy, (size_t)wn * 8, hipMemcpyDeviceToHost, s));
+    }
+    RSX_HIP(hipStreamSynchronize(s));
+  }
+  // the last scan of the window becomes the previous scan of the next one
+  RSX_HIP(hipMemcpyAsync(h->xy.p, h->xy.as<float>() + (size_t)n * slot_xy, slot_xy * 4, hipMemcpyDeviceToDevice, s));
+  RSX_HIP(hipMemcpyAsync(h->desc.p, h->desc.as<uint8_t>() + (size_t)n * K * 32, (size_t)K * 32, hipMemcpyDeviceToDevice, s));
+  RSX_HIP(hipMemcpyAsync(h->valid.p, h->valid.as<uint8_t>() + (size_t)n * K, (size_t)K, hipMemcpyDeviceToDevice, s));
+  RSX_HIP(hipMemcpyAsync(h->counts.p, d_counts + n, 4, hipMemcpyDeviceToDevice, s));
+  h->have_prev = true;
+  return RSX_OK;
+}
+
+int check_layout(rsx_odometry *h, int32_t n, int64_t image_stride_bytes, int32_t row_stride) {
+  if (row_stride < h->prm.col_offset + h->cols) return fail(RSX_ERR_BAD_ARG, "row_stride %d too small for offset %d + %d columns", row_stride, h->prm.col_offset, h->cols);
+  if (n > 1 && image_stride_bytes < (int64_t)h->rows * row_stride) return fail(RSX_ERR_BAD_ARG, "image_stride_bytes smaller than an image");
+  return RSX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rsx_odometry_default_params(rsx_odometry_params *p) {
+  if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
+  std::memset(p, 0, sizeof(*p));
+  rsx_cen2019_default_params(&p->cen);
+  rsx_frontend_default_params(&p->frontend);
+  rsx_orora_default_params(&p->orora);
+  p->radar_resolution = 0.0595f;  // Navtech CIR204-H range bin [m] (MulRan)
+  p->col_offset = 11;             // metadata bytes in front of every polar_oxford_form row
+  p->max_keypoints = 16384;  // = rsx_orora_max_correspondences(): a pair can never exceed the solver's capacity
+  p->device = 0;
+  return RSX_OK;
+}
+
+int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t cols, rsx_odometry **out) {
+  if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
+  *out = nullptr;
+  rsx_odometry_params p;
+  rsx_odometry_default_params(&p);
+  if (params) p = *params;
+  if (p.max_keypoints < 16 || p.max_keypoints > rsx_orora_max_correspondences())
+    return fail(RSX_ERR_BAD_ARG, "max_keypoints %d outside [16, %d]", p.max_keypoints, rsx_orora_max_correspondences());
+  if (p.col_offset < 0 || !(p.radar_resolution > 0.0f)) return fail(RSX_ERR_BAD_ARG, "bad col_offset / radar_resolution");
+  rsx_odometry *h = new (std::nothrow) rsx_odometry();
+  if (!h) return fail(RSX_ERR_OOM, "host alloc");
+  h->device = p.device;
+  h->rows = rows;
+  h->cols = cols;
+  h->prm = p;
+  int st = rsx_cen2019_create(p.device, rows, cols, &h->cen);
+  if (st == RSX_OK) st = rsx_frontend_create(p.device, rows, cols, &p.frontend, &h->fe);
+  if (st == RSX_OK) st = rsx_orora_create(p.device, &h->reg);
+  if (st == RSX_OK) {
+    hipError_t e = hipSetDevice(p.device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipHostMalloc(&h->h_pin, PIN_BYTES, hipHostMallocDefault);
+    if (e != hipSuccess) st = fail(e == hipErrorOutOfMemory ? RSX_ERR_OOM : RSX_ERR_HIP, "odometry create: %s", hipGetErrorString(e));
+  }
+  if (st != RSX_OK) {
+    rsx_odometry_destroy(h);
+    return st;
+  }
+  *out = h;
+  return RSX_OK;
+}
+
+int rsx_odometry_destroy(rsx_odometry *h) {
+  if (!h) return RSX_OK;
+  (void)hipSetDevice(h->device);
+  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (rsx::DevBuf *b : {&h->imgs, &h->az, &h->targets, &h->xy, &h->counts, &h->desc, &h->valid, &h->fwd, &h->bwd, &h->stage_src, &h->stage_dst,
+                         &h->pair_cnt, &h->src, &h->dst, &h->offsets, &h->results})
+    b->release();
+  if (h->h_pin) (void)hipHostFree(h->h_pin);
+  rsx_cen2019_destroy(h->cen);
+  rsx_frontend_destroy(h->fe);
+  rsx_orora_destroy(h->reg);
+  if (h->stream) (void)hipStreamDestroy(h->stream);
+  delete h;
+  return RSX_OK;
+}
+
+int rsx_odometry_reset(rsx_odometry *h) {
+  if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->have_prev = false;
+  return RSX_OK;
+}
+
+int rsx_odometry_window(void) { return MAX_WINDOW; }
+
+int rsx_odometry_push_device(rsx_odometry *h, const uint8_t *d_imgs, int32_t n_scans, int64_t image_stride_bytes, int32_t row_stride,
+                             const float *azimuths, int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy) {
+  if (!h || !d_imgs || !azimuths || !out || n_scans < 0 || max_xy < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (n_scans == 0) return RSX_OK;
+  RSX_TRY(check_layout(h, n_scans, image_stride_bytes, row_stride));
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  RSX_TRY(reserve_all(h, 0, s));
+  for (int b0 = 0; b0 < n_scans; b0 += MAX_WINDOW) {
+    const int n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
+    RSX_TRY(run_window(h, d_imgs + (int64_t)b0 * image_stride_bytes, n, image_stride_bytes, row_stride,
+                       azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0), azimuths_per_image, out + b0,
+                       out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy, s));
+  }
+  return RSX_OK;
+}
+
+int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int64_t image_stride_bytes, int32_t row_stride,
+                      const float *azimuths, int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy) {
+  if (!h || !imgs || !azimuths || !out || n_scans < 0 || max_xy < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (n_scans == 0) return RSX_OK;
+  RSX_TRY(check_layout(h, n_scans, image_stride_bytes, row_stride));
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t ibytes = (size_t)h->rows * row_stride;
+  RSX_TRY(reserve_all(h, ibytes, s));
+  for (int b0 = 0; b0 < n_scans; b0 += MAX_WINDOW) {
+    const int n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
+    const uint8_t *src = imgs + (int64_t)b0 * image_stride_bytes;
+    if (n == 1 || image_stride_bytes == (int64_t)ibytes) {
+      RSX_HIP(hipMemcpyAsync(h->imgs.p, src, ibytes * n, hipMemcpyHostToDevice, s));
+    } else {
+      RSX_HIP(hipMemcpy2DAsync(h->imgs.p, ibytes, src, (size_t)image_stride_bytes, ibytes, (size_t)n, hipMemcpyHostToDevice, s));
+    }
+    RSX_TRY(run_window(h, h->imgs.as<uint8_t>(), n, (int64_t)ibytes, row_stride, azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0),
+                       azimuths_per_image, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy, s));
+  }
+  return RSX_OK;
+}
+
+int rsx_host_alloc_pinned(size_t bytes, void **out) {
+  if (!out || bytes == 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  *out = nullptr;
+  if (rsx_device_count() <= 0) return fail(RSX_ERR_NO_DEVICE, "no HIP device visible (librsx has no CPU fallback)");
+  RSX_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return RSX_OK;
+}
+
+int rsx_host_free_pinned(void *p) {
+  if (p) RSX_HIP(hipHostFree(p));
+  return RSX_OK;
+}
+
+}  // extern "C"

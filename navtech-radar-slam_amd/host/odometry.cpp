@@ -6,7 +6,12 @@
 // observable surface -- it consumes `<seq_dir>/polar_oxford_form/*.png`, and produces the
 // accumulated pose (/orora/odom) and the current scan's feature points (/orora/cloud_local,
 // sc_pgo.launch:6-7) with identical stamps (PGO.cpp:417-436 pairs them by stamp) -- and calls
-// the GPU hot path through the C-ABI:
+// the GPU hot path through the C-ABI.  Default (round 3): the sequence is on disk, so it is processed in WINDOWS --
+//     rsx_odometry_push         W decoded scans -> cen2019 keypoints, Cartesian images, ORB-style descriptors, knnMatch(2) +
+//                               ratio + cross check of every consecutive pair, ORORA for all pairs of the window in ONE
+//                               batch; everything between the image upload and 48 bytes per scan stays on the GPU
+// while a pool of host threads inflates the PNGs of the next window into page-locked memory.  `--per-scan` keeps the
+// round-2 loop (one scan at a time through the single-call entries, every intermediate through host vectors):
 //     rsx_cen2019_extract       polar image -> keypoints (+ Cartesian points)
 //     rsx_orora_register_batch  matched points -> SE(2) motion
 //     rsx_frontend_*            polar -> Cartesian image, ORB-style descriptors at the keypoints, brute-force Hamming
@@ -24,12 +29,17 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <future>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rosmsg.h"
@@ -160,7 +170,8 @@ void associate(const Scan &prev, const Scan &cur, float gate, std::vector<float>
 int main(int argc, char **argv) {
   try {
     std::string seq_dir, out_path, record_path, matcher = "orb";
-    int max_frames = -1, device = 0;
+    int max_frames = -1, device = 0, window = 0, threads = 0;
+    bool per_scan = false, timing = false;
     double rate_hz = 0.0;
     float gate = 6.0f;
     for (int i = 1; i < argc; i++) {
@@ -170,6 +181,10 @@ int main(int argc, char **argv) {
       else if (a == "--max_frames" && i + 1 < argc) max_frames = std::atoi(argv[++i]);
       else if (a == "--gate" && i + 1 < argc) gate = (float)std::atof(argv[++i]);
       else if (a == "--matcher" && i + 1 < argc) matcher = argv[++i];  // orb (default) | nn
+      else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);    // scans per rsx_odometry_push (default: the library's window)
+      else if (a == "--threads" && i + 1 < argc) threads = std::atoi(argv[++i]);  // PNG decode threads (default: hardware concurrency, <= 64)
+      else if (a == "--per-scan") per_scan = true;                                // the round-2 loop: one scan per call, host vectors in between
+      else if (a == "--timing") timing = true;                                    // decode / pipeline seconds on stderr
       else if (a.rfind("seq_dir:=", 0) == 0) seq_dir = a.substr(9);  // roslaunch-style arg
       else if (a.rfind("do_slam:=", 0) == 0) continue;                // accepted for launch compatibility
       else if (a.rfind("device:=", 0) == 0) device = std::atoi(a.c_str() + 8);    // run_orora.launch
@@ -178,7 +193,8 @@ int main(int argc, char **argv) {
       else seq_dir = a;
     }
     (void)rate_hz;  // only the ROS publishers are paced
-    if (seq_dir.empty()) die("usage: odometry <seq_dir> [--out poses.txt] [--max_frames N] [--gate metres]");
+    if (seq_dir.empty())
+      die("usage: odometry <seq_dir> [--out poses.txt] [--max_frames N] [--matcher orb|nn] [--window W] [--threads T] [--per-scan] [--timing]");
     const std::string dir = seq_dir + "/polar_oxford_form";
     std::vector<std::string> files;
     if (DIR *d = opendir(dir.c_str())) {
@@ -215,15 +231,185 @@ int main(int argc, char **argv) {
     ros::Publisher pub_cloud = nh.advertise<sensor_msgs::PointCloud2>("/orora/cloud_local", 100);
 #endif
 
+    double px = 0, py = 0, pyaw = 0;  // accumulated pose of the sensor in the odom frame
+    // one line per frame, the recording and the publishers: shared by both loops
+    auto emit = [&](size_t fi, int64_t stamp_ns, int n, size_t n_match, const float *pts) {
+      std::fprintf(out, "%lld %.6f %.6f %.6f %d %zu\n", (long long)stamp_ns, px, py, pyaw, n, n_match);
+      if (rec) {  // what the publishers below put on /orora/odom and /orora/cloud_local, as ROS 1 wire bytes
+        rosmsg::Header h;
+        h.seq = (uint32_t)fi;
+        h.fromNSec(stamp_ns);
+        h.frame_id = "odom";
+        const double pos[3] = {px, py, 0.0}, quat[4] = {0.0, 0.0, std::sin(0.5 * pyaw), std::cos(0.5 * pyaw)};
+        record(rosmsg::kOdom, rosmsg::serialize_odometry(h, "radar", pos, quat));
+        h.frame_id = "radar";
+        std::vector<rosmsg::PointXYZI> pc((size_t)n);
+        for (int k = 0; k < n; k++) pc[(size_t)k] = rosmsg::PointXYZI{pts[2 * (size_t)k], pts[2 * (size_t)k + 1], 0.f, 0.f};
+        record(rosmsg::kCloud, rosmsg::serialize_pointcloud2(h, pc));
+      }
+#ifdef RSX_WITH_ROS
+      ros::Time stamp;
+      stamp.fromNSec((uint64_t)stamp_ns);
+      nav_msgs::Odometry od;
+      od.header.stamp = stamp;
+      od.header.frame_id = "odom";
+      od.pose.pose.position.x = px;
+      od.pose.pose.position.y = py;
+      od.pose.pose.orientation = tf::createQuaternionMsgFromYaw(pyaw);
+      pub_odom.publish(od);
+      sensor_msgs::PointCloud2 pc;
+      pc.header = od.header;
+      pc.header.frame_id = "radar";
+      sensor_msgs::PointCloud2Modifier mod(pc);
+      mod.setPointCloud2Fields(4, "x", 1, sensor_msgs::PointField::FLOAT32, "y", 1, sensor_msgs::PointField::FLOAT32, "z", 1,
+                               sensor_msgs::PointField::FLOAT32, "intensity", 1, sensor_msgs::PointField::FLOAT32);
+      mod.resize((size_t)n);
+      sensor_msgs::PointCloud2Iterator<float> ix(pc, "x"), iy(pc, "y"), iz(pc, "z"), ii(pc, "intensity");
+      for (int k = 0; k < n; k++, ++ix, ++iy, ++iz, ++ii) {
+        *ix = pts[2 * (size_t)k];
+        *iy = pts[2 * (size_t)k + 1];
+        *iz = 0.f;
+        *ii = 0.f;
+      }
+      pub_cloud.publish(pc);
+      ros::spinOnce();
+      if (rate_hz > 0.0) ros::Duration(1.0 / rate_hz).sleep();
+#endif
+    };
+    auto compose = [&](const rsx_orora_result &r) {
+      if (r.status != 0) return;
+      const double c = std::cos(pyaw), s = std::sin(pyaw);
+      px += c * r.x - s * r.y;
+      py += s * r.x + c * r.y;
+      pyaw += r.yaw;
+    };
+    if (matcher != "nn" && matcher != "orb") die("--matcher must be orb or nn");
+
+    if (matcher == "orb" && !per_scan) {
+      // ---------------- windows of scans through rsx_odometry_push ----------------
+      using clk = std::chrono::steady_clock;
+      int w0 = 0, h0 = 0;
+      (void)read_png_gray8(dir + "/" + files[0], &w0, &h0);
+      const int rows = h0, cols = w0 - kMeta;
+      if (cols < 2) die(files[0] + ": image too narrow for " + std::to_string(kMeta) + " metadata bytes per row");
+      rsx_odometry_params op;
+      check(rsx_odometry_default_params(&op), "rsx_odometry_default_params");
+      op.device = device;
+      op.radar_resolution = kResolution;
+      op.col_offset = kMeta;
+      rsx_odometry *odo = nullptr;
+      check(rsx_odometry_create(&op, rows, cols, &odo), "rsx_odometry_create");
+      const int W = window > 0 ? std::min(window, 4096) : rsx_odometry_window();
+      const int T = threads > 0 ? threads : (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+      const size_t ibytes = (size_t)rows * w0;
+      struct Win {
+        uint8_t *img = nullptr;
+        std::vector<float> az;
+        std::vector<int64_t> stamp;
+        int n = 0;
+        double decode_cpu_s = 0;
+      } wins[2];
+      for (Win &wn : wins) {
+        void *p = nullptr;
+        check(rsx_host_alloc_pinned(ibytes * (size_t)W, &p), "rsx_host_alloc_pinned");
+        wn.img = static_cast<uint8_t *>(p);
+        wn.az.resize((size_t)W * rows);
+        wn.stamp.resize((size_t)W);
+      }
+      std::string decode_error;
+      auto decode_window = [&](size_t f0, Win *wn) {
+        wn->n = (int)std::min((size_t)W, files.size() - f0);
+        std::atomic<int> next{0};
+        std::atomic<long long> cpu_ns{0};
+        std::mutex err_mu;
+        auto work = [&]() {
+          for (;;) {
+            const int i = next.fetch_add(1);
+            if (i >= wn->n) return;
+            try {
+              const auto t0 = clk::now();
+              int w = 0, h = 0;
+              const std::vector<uint8_t> img = read_png_gray8(dir + "/" + files[f0 + (size_t)i], &w, &h);
+              if (h != rows || w != w0) die(files[f0 + (size_t)i] + ": image shape changed");
+              std::memcpy(wn->img + (size_t)i * ibytes, img.data(), ibytes);
+              int64_t st = 0;
+              std::memcpy(&st, &img[0], 8);  // little-endian int64 at bytes 0-7 of the first row
+              if (st <= 0) st = std::atoll(files[f0 + (size_t)i].c_str());
+              wn->stamp[(size_t)i] = st;
+              for (int a = 0; a < rows; a++) {
+                uint16_t cnt;
+                std::memcpy(&cnt, &img[(size_t)a * w + 8], 2);
+                wn->az[(size_t)i * rows + a] = (float)((double)cnt * 2.0 * M_PI / 5600.0);
+              }
+              cpu_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count();
+            } catch (const std::exception &e) {
+              std::lock_guard<std::mutex> lk(err_mu);
+              if (decode_error.empty()) decode_error = e.what();
+            }
+          }
+        };
+        std::vector<std::thread> pool;
+        const int nt = std::min(T, wn->n);
+        for (int t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+        wn->decode_cpu_s = 1e-9 * (double)cpu_ns.load();
+      };
+#ifdef RSX_WITH_ROS
+      const bool want_xy = true;
+#else
+      const bool want_xy = rec != nullptr;
+#endif
+      const int max_xy = want_xy ? op.max_keypoints : 0;
+      std::vector<float> xy(want_xy ? (size_t)W * max_xy * 2 : 0);
+      std::vector<rsx_odometry_scan> res((size_t)W);
+      double decode_cpu = 0, decode_wait = 0, push_s = 0;
+      const auto t_all = clk::now();
+      std::future<void> fut = std::async(std::launch::async, decode_window, (size_t)0, &wins[0]);
+      size_t fi = 0;
+      for (size_t f0 = 0, wi = 0; f0 < files.size(); f0 += (size_t)W, wi++) {
+        const auto tw = clk::now();
+        fut.get();
+        decode_wait += std::chrono::duration<double>(clk::now() - tw).count();
+        if (!decode_error.empty()) die(decode_error);
+        Win &wn = wins[wi & 1];
+        if (f0 + (size_t)W < files.size()) fut = std::async(std::launch::async, decode_window, f0 + (size_t)W, &wins[(wi + 1) & 1]);
+        decode_cpu += wn.decode_cpu_s;
+        const auto tp = clk::now();
+        check(rsx_odometry_push(odo, wn.img, wn.n, (int64_t)ibytes, w0, wn.az.data(), 1, res.data(), want_xy ? xy.data() : nullptr, max_xy),
+              "rsx_odometry_push");
+        push_s += std::chrono::duration<double>(clk::now() - tp).count();
+        for (int i = 0; i < wn.n; i++, fi++) {
+          compose(res[(size_t)i].reg);
+          const int nk = std::min(res[(size_t)i].n_keypoints, op.max_keypoints);
+          emit(fi, wn.stamp[(size_t)i], nk, (size_t)res[(size_t)i].n_matches, want_xy ? &xy[(size_t)i * max_xy * 2] : nullptr);
+        }
+#ifdef RSX_WITH_ROS
+        if (!ros::ok()) break;
+#endif
+      }
+      const double all_s = std::chrono::duration<double>(clk::now() - t_all).count();
+      if (timing)
+        std::fprintf(stderr,
+                     "timing: scans=%zu window=%d decode_threads=%d decode_cpu_s=%.4f decode_ms_per_scan_per_thread=%.3f decode_wait_s=%.4f "
+                     "pipeline_s=%.4f pipeline_scans_per_s=%.1f total_s=%.4f total_scans_per_s=%.1f\n",
+                     files.size(), W, T, decode_cpu, 1e3 * decode_cpu / (double)files.size(), decode_wait, push_s, (double)files.size() / push_s,
+                     all_s, (double)files.size() / all_s);
+      for (Win &wn : wins) rsx_host_free_pinned(wn.img);
+      rsx_odometry_destroy(odo);
+      if (out != stdout) std::fclose(out);
+      if (rec) std::fclose(rec);
+      return 0;
+    }
+
+    // ---------------- one scan per call (round-2 loop; also the `nn` stand-in matcher) ----------------
     rsx_cen2019 *cen = nullptr;
     rsx_orora *reg = nullptr;
     rsx_frontend *fe = nullptr;
     const bool use_orb = matcher != "nn";
-    if (matcher != "nn" && matcher != "orb") die("--matcher must be orb or nn");
     check(rsx_orora_create(device, &reg), "rsx_orora_create");
     rsx_cen2019_params cp;
     rsx_cen2019_default_params(&cp);
-    double px = 0, py = 0, pyaw = 0;  // accumulated pose of the sensor in the odom frame
     Scan prev;
     int rows = 0, cols = 0;
     std::vector<int32_t> targets(2 * 200000);
@@ -281,7 +467,8 @@ int main(int argc, char **argv) {
         }
         n_match = src.size() / 2;
         const size_t cap = (size_t)rsx_orora_max_correspondences();
-        if (n_match > cap) {  // keep an evenly spread subset
+        if (n_match > cap) {  // keep an evenly spread subset, and say so
+          std::fprintf(stderr, "odometry: frame %zu: %zu matches exceed the solver's %zu, registering an evenly spread subset\n", fi, n_match, cap);
           std::vector<float> s2, d2;
           for (size_t i = 0; i < cap; i++) {
             const size_t k = i * n_match / cap;
@@ -296,53 +483,10 @@ int main(int argc, char **argv) {
         rsx_orora_result r;
         // src = current scan, dst = previous scan: the motion of the sensor expressed in the previous frame
         check(rsx_orora_register_batch(reg, dst.data(), src.data(), offsets, 1, nullptr, &r), "rsx_orora_register_batch");
-        if (r.status == 0) {
-          const double c = std::cos(pyaw), s = std::sin(pyaw);
-          px += c * r.x - s * r.y;
-          py += s * r.x + c * r.y;
-          pyaw += r.yaw;
-        }
+        compose(r);
       }
-      std::fprintf(out, "%lld %.6f %.6f %.6f %d %zu\n", (long long)cur.stamp_ns, px, py, pyaw, n, n_match);
-      if (rec) {  // what the publishers below put on /orora/odom and /orora/cloud_local, as ROS 1 wire bytes
-        rosmsg::Header h;
-        h.seq = (uint32_t)fi;
-        h.fromNSec(cur.stamp_ns);
-        h.frame_id = "odom";
-        const double pos[3] = {px, py, 0.0}, quat[4] = {0.0, 0.0, std::sin(0.5 * pyaw), std::cos(0.5 * pyaw)};
-        record(rosmsg::kOdom, rosmsg::serialize_odometry(h, "radar", pos, quat));
-        h.frame_id = "radar";
-        std::vector<rosmsg::PointXYZI> pc((size_t)n);
-        for (int k = 0; k < n; k++) pc[(size_t)k] = rosmsg::PointXYZI{cur.xy[2 * (size_t)k], cur.xy[2 * (size_t)k + 1], 0.f, 0.f};
-        record(rosmsg::kCloud, rosmsg::serialize_pointcloud2(h, pc));
-      }
+      emit(fi, cur.stamp_ns, n, n_match, cur.xy.data());
 #ifdef RSX_WITH_ROS
-      ros::Time stamp;
-      stamp.fromNSec((uint64_t)cur.stamp_ns);
-      nav_msgs::Odometry od;
-      od.header.stamp = stamp;
-      od.header.frame_id = "odom";
-      od.pose.pose.position.x = px;
-      od.pose.pose.position.y = py;
-      od.pose.pose.orientation = tf::createQuaternionMsgFromYaw(pyaw);
-      pub_odom.publish(od);
-      sensor_msgs::PointCloud2 pc;
-      pc.header = od.header;
-      pc.header.frame_id = "radar";
-      sensor_msgs::PointCloud2Modifier mod(pc);
-      mod.setPointCloud2Fields(4, "x", 1, sensor_msgs::PointField::FLOAT32, "y", 1, sensor_msgs::PointField::FLOAT32, "z", 1,
-                               sensor_msgs::PointField::FLOAT32, "intensity", 1, sensor_msgs::PointField::FLOAT32);
-      mod.resize((size_t)n);
-      sensor_msgs::PointCloud2Iterator<float> ix(pc, "x"), iy(pc, "y"), iz(pc, "z"), ii(pc, "intensity");
-      for (int k = 0; k < n; k++, ++ix, ++iy, ++iz, ++ii) {
-        *ix = cur.xy[2 * (size_t)k];
-        *iy = cur.xy[2 * (size_t)k + 1];
-        *iz = 0.f;
-        *ii = 0.f;
-      }
-      pub_cloud.publish(pc);
-      ros::spinOnce();
-      if (rate_hz > 0.0) ros::Duration(1.0 / rate_hz).sleep();
       if (!ros::ok()) break;
 #endif
       prev = std::move(cur);
