@@ -28,7 +28,9 @@ re-scoring of the survivors) the line carries
   scale_100k        8192 queries vs a 100 000-keyframe DB (the size where DB shards pay), same sharding
   roofline          the dominant kernel (spectral MFMA filter): algorithmic flops / hipEvent time, vs the dense fp16 peak
   cpu_baseline      the CPU oracle (== the reference's Scancontext.cpp, tests/test_oracle_pin.py) on this box's cores
-  latency_q1_n1k_us BASELINE configs[1]; orora / cen2019 / icp: the other parts of the path
+  latency_q1_n1k_us BASELINE configs[1]; orora / cen2019 / icp / frontend: the other parts of the path
+  odometry_e2e      BASELINE configs[0] and [2]: the file-based odometry entry end to end on a moving sensor with known poses
+                    (scans/s resident / from host memory / from PNG files, PNG decode separately, checked against the oracle chain)
 With --gpus G the DB is sharded block-cyclically over G ranks (same DB, same batch => strong scaling); a
 query batch is two stages with one RCCL all-gather of per-rank top-k lists each (sharded.py).
 
@@ -355,11 +357,15 @@ def committed_profile(kernel):
 
 
 def cen2019_leg(device):
-    """Third part of the path: cen2019 keypoint extraction on MulRan-shape polar
-    scans (400 azimuths x 3360 range bins, 11 metadata bytes per row).  rsx_cen2019_extract takes a HOST
-    image (the file-based odometry entry reads PNGs), so this figure includes the 1.35 MB PCIe upload
-    and the keypoint download of every scan."""
-    from navtech_radar_slam_amd import cen2019, synth
+    """Third part of the path: cen2019 keypoint extraction on MulRan-shape polar scans (400 azimuths x
+    3360 range bins, 11 metadata bytes per row).  Three figures: the synchronous single-scan host entry (1.35 MB PCIe upload
+    and keypoint download inside), the batched host entry, and the batched device entry (images resident in HBM, nothing
+    returns to the host).  Roofline: SURVEY 8d prices a scan at 1.344 MB of compulsory bytes; the chain re-reads the
+    L2-resident image six times and is VALU/latency-bound (segmented scans per azimuth), so the HBM fraction is reported
+    for the record, not as the bound."""
+    import ctypes as C
+    import torch
+    from navtech_radar_slam_amd import _rsx, cen2019, synth
     imgs = [synth.polar_image(100 + i)[0] for i in range(4)]
     ex = cen2019.Cen2019(rows=400, cols=3360, device=device)
     n = 0
@@ -370,12 +376,39 @@ def cen2019_leg(device):
     for i in range(reps):
         n = len(ex.extract(imgs[i % 4]))
     dt = (time.perf_counter() - t0) / reps
+    batch = 64
+    stack = np.stack([imgs[i % 4] for i in range(batch)])
+    ex.extract_batch(stack)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ex.extract_batch(stack)
+    dt_b = (time.perf_counter() - t0) / 3 / batch
+    d = torch.from_numpy(stack).cuda()
+    tg = torch.zeros((batch, 20000, 2), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(batch, dtype=torch.int32, device="cuda")
+    p = _rsx.Cen2019Params(10000, 58)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        _rsx.check(_rsx.lib().rsx_cen2019_extract_batch_device(ex._h, d.data_ptr(), batch, stack.strides[0], stack.shape[2], 11, C.byref(p),
+                                                              None, 0, 0.0595, tg.data_ptr(), None, 20000, cnt.data_ptr(), st))
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize()
+    dt_d = (time.perf_counter() - t0) / 10 / batch
     ex.close()
+    alg = 400 * 3360
     return {"scans_per_sec": 1.0 / dt, "ms_per_scan": dt * 1e3, "image": "400x3360 u8 (+11 B/row metadata)",
-            "keypoints_last_scan": int(n), "dtype": "u8/f32", "includes": "H2D image + D2H keypoints (host-buffer entry)",
-            "algorithmic_bytes_per_scan": 400 * 3360,
-            "note": "image passes are L2-resident (1.34 MB); the chain is launch/latency-bound (two rocPRIM sorts of "
-                    "~0.5 M candidates + one host sync for the candidate count), not HBM-bound"}
+            "keypoints_last_scan": int(n), "dtype": "u8/f32/u64 keys", "includes": "H2D image + D2H keypoints (host-buffer entry)",
+            "batched_host_scans_per_sec": 1.0 / dt_b, "batched_device_scans_per_sec": 1.0 / dt_d, "batch": batch,
+            "launches_per_scan_or_batch": 8, "algorithmic_bytes_per_scan": alg,
+            "hbm_algorithmic_GBps_batched_device": alg / dt_d / 1e9, "hbm_frac_batched_device": alg / dt_d / 1e9 / HBM_PEAK_GBS,
+            "note": "round 3: no sort, no host sync -- the greedy region marking in closed form (per-run minima by segmented "
+                    "scans + one radix select); 8 launches per call whatever the batch; kernels re-read the L2-resident image, "
+                    "VALU/latency-bound, not HBM-bound"}
 
 
 def allpairs_leg(device, n=100000, k=10):
@@ -495,6 +528,106 @@ def frontend_leg(device):
             "hamming_pairs_per_scan": int(len(xy0)) * int(len(xy1)),
             "note": "remap + 7x7 blur + describe + knnMatch(2) incl. the PCIe copies of the synchronous host-buffer entry; "
                     "a radar delivers 4 scans/s"}
+
+
+def odometry_e2e_leg(device, skip_cpu, n_unique=24, n_scans=528):
+    """BASELINE configs[0] + configs[2]: the file-based odometry entry end to end on a MOVING sensor with known poses --
+    polar scan -> cen2019 keypoints -> Cartesian image + ORB-style descriptors -> knnMatch(2) + ratio + cross check ->
+    ORORA -> relative motion -- through the device-resident windowed pipeline (rsx_odometry_push: every stage once per
+    window of 64 scans, all pairs of a window in ONE ORORA batch).  Sequence: `n_unique` synthetic MulRan-shape scans
+    of one world along a drive (synth.polar_sequence), driven back and forth to `n_scans` scans (every consecutive pair
+    is a real motion pair with a known answer).  Reported: scans/s with the images resident in HBM, scans/s from host
+    memory (PCIe upload inside), the C++ entry on PNG files (decode threads + pipeline), PNG inflate cost separately."""
+    import shutil
+    import tempfile
+    import torch
+    from navtech_radar_slam_amd import odometry, synth
+    imgs, az, poses, stamps = synth.polar_sequence(11, n_unique)
+    order, i, step = [], 0, 1
+    while len(order) < n_scans:                                   # 0 1 .. n-1 n-2 .. 1 0 1 ..
+        order.append(i)
+        if not 0 <= i + step < n_unique:
+            step = -step
+        i += step
+    order = np.asarray(order)
+    seq = np.ascontiguousarray(imgs[order])
+    od = odometry.Odometry(400, 3360, device=device)
+    od.push(seq[:70], az)                                          # warm-up: workspaces, the Cartesian map
+    od.reset()
+    t0 = time.perf_counter()
+    res = od.push(seq, az)
+    dt_host = time.perf_counter() - t0
+    d = torch.from_numpy(seq).cuda()
+    torch.cuda.synchronize()
+    od.reset()
+    t0 = time.perf_counter()
+    res_dev = od.push(seq, az, device_ptr=d.data_ptr())
+    dt_dev = time.perf_counter() - t0
+    del d
+    worst_t = worst_y = 0.0
+    for i in range(1, n_scans):
+        truth = synth.relative_pose(poses[order[i - 1]], poses[order[i]])
+        worst_t = max(worst_t, float(np.hypot(res["x"][i] - truth[0], res["y"][i] - truth[1])))
+        worst_y = max(worst_y, abs(float(res["yaw"][i] - truth[2])))
+    leg = {"scans": n_scans, "unique_scans": n_unique, "window": 64,
+           "scans_per_sec_resident": n_scans / dt_dev, "scans_per_sec_host_images": n_scans / dt_host,
+           "ms_per_scan_resident": dt_dev / n_scans * 1e3, "ms_per_scan_host_images": dt_host / n_scans * 1e3,
+           "identical_resident_vs_host": bool(res.tobytes() == res_dev.tobytes()),
+           "pairs_registered": int((res["status"] == 0).sum()), "matches_per_pair_min_mean": [int(res["n_matches"][1:].min()), float(res["n_matches"][1:].mean())],
+           "keypoints_per_scan_mean": float(res["n_keypoints"].mean()),
+           "worst_pair_error_vs_truth": {"translation_m": worst_t, "yaw_rad": worst_y},
+           "image": "400x3360 u8 (+11 B/row metadata), 1.35 MB per scan", "dtype": "u8/f32/u32 popcount/f64",
+           "note": "resident: images already in HBM, 48 B per scan come back; host_images: pageable host array, the PCIe upload of "
+                   "every window is inside the time; PNG decode excluded from both (reported under file_entry)"}
+    if not skip_cpu:
+        from oracle import odometry_chain
+        t0 = time.perf_counter()
+        chain = odometry_chain.run(imgs[:8], az, resolution=synth.RADAR_RESOLUTION)
+        cdt = time.perf_counter() - t0
+        diff = max(max(abs(float(res[f][i]) - float(chain[i]["result"][f])) for f in ("x", "y", "yaw")) for i in range(1, 8))
+        same_counts = all(int(res["n_keypoints"][i]) == chain[i]["n_keypoints"] and int(res["n_matches"][i]) == chain[i]["n_matches"] for i in range(8))
+        leg["cpu_baseline"] = {"value": 8 / cdt, "unit": "scans/s", "cores": 1, "kind": "port",
+                               "sample": "the first 8 scans through oracle/odometry_chain.py (cen2019_ref -> frontend_ref -> orora_ref), 1 thread"}
+        leg["oracle_checked_scans"] = 8
+        leg["max_abs_pose_diff_vs_oracle"] = diff
+        leg["counts_identical_to_oracle"] = bool(same_counts)
+    # the C++ entry on PNG files: decode pool + pipeline
+    exe = os.path.join(ROOT, "navtech-radar-slam_amd", "host", "odometry")
+    tmp = tempfile.mkdtemp(prefix="rsx_odo_")
+    try:
+        from PIL import Image
+        dd = os.path.join(tmp, "polar_oxford_form")
+        os.makedirs(dd)
+        uniq = []
+        for i in range(n_unique):
+            pth = os.path.join(tmp, f"u{i}.png")
+            Image.fromarray(imgs[i], mode="L").save(pth)
+            uniq.append(pth)
+        for j, i in enumerate(order):
+            os.link(uniq[i], os.path.join(dd, f"{1560000000000000000 + j * 250000000}.png"))
+        r = subprocess.run([exe, f"seq_dir:={tmp}", f"device:={device}", "--timing", "--out", os.path.join(tmp, "poses.txt")],
+                           capture_output=True, text=True, timeout=600)
+        tl = [ln for ln in r.stderr.splitlines() if ln.startswith("timing:")]
+        if r.returncode == 0 and tl:
+            kv = dict(x.split("=") for x in tl[0].split()[1:])
+            last = open(os.path.join(tmp, "poses.txt")).read().strip().splitlines()[-1].split()
+            acc = np.zeros(3)
+            for i in range(1, n_scans):
+                if res["status"][i] == 0:
+                    acc = synth.compose_pose(acc, (res["x"][i], res["y"][i], res["yaw"][i]))
+            leg["file_entry"] = {"scans": int(kv["scans"]), "decode_threads": int(kv["decode_threads"]),
+                                 "png_decode_ms_per_scan_per_thread": float(kv["decode_ms_per_scan_per_thread"]),
+                                 "pipeline_scans_per_sec": float(kv["pipeline_scans_per_s"]), "total_scans_per_sec": float(kv["total_scans_per_s"]),
+                                 "decode_wait_s": float(kv["decode_wait_s"]),
+                                 "final_pose_equals_python_harness": bool(np.allclose([float(v) for v in last[1:4]], acc, atol=1e-4)),
+                                 "note": "host/odometry seq_dir:=<dir> --timing: PNG inflate on a thread pool into pinned windows "
+                                         "(double buffered) while the GPU runs the previous window; total = wall clock incl. decode"}
+        else:
+            leg["file_entry"] = {"error": (r.stderr or r.stdout)[-400:]}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    od.close()
+    return leg
 
 
 def icp_leg(device):
@@ -744,6 +877,12 @@ def main():
             out["cen2019"] = cen2019_leg(ctx.local_rank)
             out["icp"] = icp_leg(ctx.local_rank)
             out["frontend"] = frontend_leg(ctx.local_rank)
+            out["odometry_e2e"] = odometry_e2e_leg(ctx.local_rank, args.no_cpu_baseline)
+            oe = out["odometry_e2e"]
+            if not oe["identical_resident_vs_host"] or oe.get("counts_identical_to_oracle") is False or oe.get("max_abs_pose_diff_vs_oracle", 0.0) > 1e-4:
+                failures.append("odometry_e2e: pipeline differs from the oracle chain / between its two entries")
+            if oe["worst_pair_error_vs_truth"]["translation_m"] > 0.3 or oe["worst_pair_error_vs_truth"]["yaw_rad"] > 1.5e-2:
+                failures.append("odometry_e2e: a relative pose is off the known motion")
             out["allpairs_100k"] = allpairs_leg(ctx.local_rank)
             if not out["allpairs_100k"]["planted_revisits_recovered"]:
                 failures.append("all-pairs: planted revisits not recovered")
