@@ -4,6 +4,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 
 #include "rsx.h"
@@ -20,6 +21,17 @@ inline int fail(int code, const char *fmt, ...) {
   va_end(ap);
   last_error() = buf;
   return code;
+}
+
+// Experiment / tuning knobs read from the environment exist only in -DRSX_EXPERIMENTS builds (make EXPERIMENTS=1, what
+// tools/prof*.sh and tools/spectral/* build): the product library has no hidden switches.
+inline const char *exp_env(const char *name) {
+#ifdef RSX_EXPERIMENTS
+  return std::getenv(name);
+#else
+  (void)name;
+  return nullptr;
+#endif
 }
 
 #define RSX_HIP(expr)                                                                         \

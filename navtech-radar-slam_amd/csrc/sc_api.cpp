@@ -163,7 +163,7 @@ int prepare_queries(rsx_sc *h, const float *d_q, int32_t nq, hipStream_t s, Quer
 // force it off / on (profiling scripts).  Same precedence as filter_kind_of: explicit params first.
 int filter_mode_of(const rsx_sc *h) {
   static const int env = [] {
-    const char *e = getenv("RSX_SC_FILTER");
+    const char *e = rsx::exp_env("RSX_SC_FILTER");
     if (!e || !*e) return -1;
     return atoi(e) ? 2 : 1;
   }();
@@ -198,7 +198,7 @@ struct ProfScope {
 // RSX_SC_FILTER_KIND=direct|spectral override.
 int filter_kind_of(const rsx_sc *h) {
   static const int env = [] {
-    const char *e = getenv("RSX_SC_FILTER_KIND");
+    const char *e = rsx::exp_env("RSX_SC_FILTER_KIND");
     if (!e || !*e) return -1;
     return (e[0] == 's' || e[0] == '1') ? 1 : 0;
   }();
@@ -299,7 +299,7 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     // queries, ms per step / exact evaluations per query): 64 -> 4.24 / 11.2, 128 -> 4.18 / 10.4; the one-pass scoring of
     // round 1 (RSX_SC_TWO_PHASE=0: first round scored exactly, 96 evaluations per query) 4.0 with 64
     static const int32_t first_target = [] {
-      const char *e = getenv("RSX_SC_FIRST_TARGET");
+      const char *e = rsx::exp_env("RSX_SC_FIRST_TARGET");
       const int v = e ? atoi(e) : 0;
       return (v >= 1 && v <= 128) ? v : 128;
     }();
@@ -309,7 +309,7 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     // the fp32 pruning preview (sc_walk_kernel: identical results, 6.3 instead of 5.6 ms per step on the bench:
     // the per-query chain of ~125 dependent candidates is latency-bound at 2 waves per SIMD)
     static const bool use_walk = [] {
-      const char *e = getenv("RSX_SC_RESCORE");
+      const char *e = rsx::exp_env("RSX_SC_RESCORE");
       return e && e[0] == 'w';
     }();
     if (use_walk) {
@@ -337,18 +337,24 @@ int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible
 }
 
 // the search tree over the ring keys of entries [0, n): built on the host exactly like the reference's nanoflann tree
-// (SC.cpp:348-359 rebuilds it every TREE_MAKING_PERIOD detections on the CPU as well), searched on the device
-int ensure_tree(rsx_sc *h, rsx_sc::KdTreeDev *t, int64_t n) {
-  if (t->n == n) return RSX_OK;
-  hipStream_t s = h->stream;
-  std::vector<float> keys((size_t)n * NR);
-  RSX_HIP(hipMemcpyAsync(keys.data(), h->rkey.p, keys.size() * sizeof(float), hipMemcpyDeviceToHost, s));
-  RSX_HIP(hipStreamSynchronize(s));
+// (SC.cpp:348-359 rebuilds it every TREE_MAKING_PERIOD detections on the CPU as well), searched on the device.
+// The build itself (O(n log n) float work: 6 ms at 10 000 keys, 76 ms at 100 000) touches nothing of the handle, so the
+// detector runs it with the handle UNLOCKED: the writer thread (PGO.cpp:492 process_pg) is not stalled by the reader's
+// (PGO.cpp:561 process_lcd) tree rebuild.  Keys [0, n) are immutable (append-only DB), so the snapshot stays valid.
+struct PreparedTree {
+  int64_t n = 0;
+  std::vector<KdNode16> n16;
+  std::vector<int32_t> vind;
+  float low[KD_DIM], high[KD_DIM];
+  int depth = 0;
+};
+
+int prepare_tree_host(const float *keys, int64_t n, PreparedTree *out) {
   KdTreeHost host;
-  RSX_TRY(kdtree_build_host(keys.data(), n, &host));
-  t->n = 0;
+  RSX_TRY(kdtree_build_host(keys, n, &host));
   // the search kernel's 16-byte nodes (child1 = the next node: the build numbers the nodes in preorder)
-  std::vector<KdNode16> n16(host.nodes.size());
+  std::vector<KdNode16> &n16 = out->n16;
+  n16.resize(host.nodes.size());
   for (size_t i = 0; i < host.nodes.size(); i++) {
     const KdNode &nd = host.nodes[i];
     if (nd.child1 < 0) {
@@ -370,17 +376,49 @@ int ensure_tree(rsx_sc *h, rsx_sc::KdTreeDev *t, int64_t n) {
       }
     }
   }
-  t->n_nodes = (int32_t)n16.size();
-  RSX_TRY(t->nodes.reserve(n16.size() * sizeof(KdNode16), s, false));
-  RSX_TRY(t->vind.reserve(host.vind.size() * sizeof(int32_t), s, false));
-  RSX_HIP(hipMemcpyAsync(t->nodes.p, n16.data(), n16.size() * sizeof(KdNode16), hipMemcpyHostToDevice, s));
-  RSX_HIP(hipMemcpyAsync(t->vind.p, host.vind.data(), host.vind.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
-  RSX_HIP(hipStreamSynchronize(s));  // `host` goes out of scope
-  std::memcpy(t->low, host.low, sizeof(t->low));
-  std::memcpy(t->high, host.high, sizeof(t->high));
-  t->depth = host.depth;
-  t->n = n;
+  out->vind.swap(host.vind);
+  std::memcpy(out->low, host.low, sizeof(out->low));
+  std::memcpy(out->high, host.high, sizeof(out->high));
+  out->depth = host.depth;
+  out->n = n;
   return RSX_OK;
+}
+
+int upload_tree(rsx_sc *h, rsx_sc::KdTreeDev *t, const PreparedTree &p) {
+  hipStream_t s = h->stream;
+  t->n = 0;
+  t->n_nodes = (int32_t)p.n16.size();
+  RSX_TRY(t->nodes.reserve(p.n16.size() * sizeof(KdNode16), s, false));
+  RSX_TRY(t->vind.reserve(p.vind.size() * sizeof(int32_t), s, false));
+  RSX_HIP(hipMemcpyAsync(t->nodes.p, p.n16.data(), p.n16.size() * sizeof(KdNode16), hipMemcpyHostToDevice, s));
+  RSX_HIP(hipMemcpyAsync(t->vind.p, p.vind.data(), p.vind.size() * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  RSX_HIP(hipStreamSynchronize(s));  // the caller's PreparedTree may go out of scope
+  std::memcpy(t->low, p.low, sizeof(t->low));
+  std::memcpy(t->high, p.high, sizeof(t->high));
+  t->depth = p.depth;
+  t->n = p.n;
+  return RSX_OK;
+}
+
+// lk holds h->mu on entry and on return; it is released while the tree is built on the host
+int ensure_tree(rsx_sc *h, rsx_sc::KdTreeDev *t, int64_t n, std::unique_lock<std::mutex> &lk) {
+  if (t->n == n) return RSX_OK;
+  hipStream_t s = h->stream;
+  std::vector<float> keys((size_t)n * NR);
+  RSX_HIP(hipMemcpyAsync(keys.data(), h->rkey.p, keys.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  PreparedTree p;
+  lk.unlock();
+  const int st = prepare_tree_host(keys.data(), n, &p);
+  const std::string err = st == RSX_OK ? std::string() : last_error();
+  lk.lock();
+  if (st != RSX_OK) {
+    last_error() = err;
+    return st;
+  }
+  RSX_TRY(set_device(h));
+  if (t->n == n) return RSX_OK;  // another detector thread built the same tree meanwhile
+  return upload_tree(h, t, p);
 }
 
 // candidate scoring shared by detect_loop_closure / between_session (SC.cpp:362-417)
@@ -397,7 +435,7 @@ int score_candidates_and_finish(rsx_sc *h, const QueryView &qv, const float *d_q
     int32_t *d_found = d_idx + 128;
     if (n_search > 0) {
       // nanoflann's own walk of nanoflann's own tree: the reference's candidates, ties included (sc_kdtree.h)
-      RSX_TRY(ensure_tree(h, tree, n_search));
+      if (tree->n != n_search) return fail(RSX_ERR_INTERNAL, "ring-key tree over %lld keys was not prepared", (long long)n_search);
       // the true k-th smallest distance, by the parallel brute-force pass: lets the walk skip what cannot matter
       int32_t *b_idx = d_idx + 192;
       float *b_kd = reinterpret_cast<float *>(d_idx + 256);
@@ -478,7 +516,13 @@ extern "C" {
 
 const char *rsx_last_error_string(void) { return rsx::last_error().c_str(); }
 
-const char *rsx_version(void) { return "rsx 0.1 (gfx950, HIP; ScanContext + ORORA hot path)"; }
+const char *rsx_version(void) {
+#ifdef RSX_EXPERIMENTS
+  return "rsx 0.3 (gfx950, HIP; ScanContext + ORORA hot path) +experiments";
+#else
+  return "rsx 0.3 (gfx950, HIP; ScanContext + ORORA hot path)";
+#endif
+}
 
 int rsx_device_count(void) {
   int n = 0;
@@ -789,14 +833,32 @@ int rsx_sc_load(rsx_sc *h, const char *path, int64_t *n_loaded) {
   DbFileHeader hd{};
   std::vector<float> buf;
   bool ok = std::fread(&hd, sizeof(hd), 1, f) == 1 && std::memcmp(hd.magic, "RSXSCDB1", 8) == 0 && hd.version == 1 &&
-            hd.num_ring == (uint32_t)NR && hd.num_sector == (uint32_t)NS && hd.dtype == 0 && hd.n_local >= 0 &&
-            hd.n_local <= hd.n_global && hd.shard_world >= 1;
+            hd.num_ring == (uint32_t)NR && hd.num_sector == (uint32_t)NS && hd.dtype == 0 && hd.n_local >= 0 && hd.n_global >= 0 &&
+            hd.n_local <= hd.n_global && hd.shard_world >= 1 && hd.shard_rank >= 0 && hd.shard_rank < hd.shard_world;
+  // the header is not trusted: a shard holds exactly the indices i < n_global with i % world == rank, and the file must
+  // be as long as it says BEFORE anything is allocated from its numbers
   if (ok) {
-    buf.resize((size_t)hd.n_local * DS);
+    const int64_t expect = hd.n_global > hd.shard_rank ? (hd.n_global - hd.shard_rank + hd.shard_world - 1) / hd.shard_world : 0;
+    ok = hd.n_local == expect;
+  }
+  if (ok) {
+    const long here = std::ftell(f);
+    ok = here == (long)sizeof(hd) && std::fseek(f, 0, SEEK_END) == 0;
+    const long end = ok ? std::ftell(f) : -1;
+    ok = ok && end >= 0 && (uint64_t)end == (uint64_t)sizeof(hd) + (uint64_t)hd.n_local * DS * sizeof(float) &&
+         std::fseek(f, here, SEEK_SET) == 0;
+  }
+  if (ok) {
+    try {
+      buf.resize((size_t)hd.n_local * DS);
+    } catch (const std::bad_alloc &) {
+      std::fclose(f);
+      return fail(RSX_ERR_OOM, "%s: %lld descriptors do not fit in host memory", path, (long long)hd.n_local);
+    }
     ok = buf.empty() || std::fread(buf.data(), sizeof(float), buf.size(), f) == buf.size();
   }
   std::fclose(f);
-  if (!ok) return fail(RSX_ERR_BAD_ARG, "%s is not a complete RSXSCDB1 file for 20 x 60 fp32 descriptors", path);
+  if (!ok) return fail(RSX_ERR_BAD_ARG, "%s is not a complete, consistent RSXSCDB1 file for 20 x 60 fp32 descriptors", path);
   std::lock_guard<std::mutex> lk(h->mu);
   // a shard file restores the shard it was saved from; an unsharded file can be loaded into any (sharded) handle,
   // which keeps its own residue class
@@ -825,6 +887,7 @@ static int local_slot_of(rsx_sc *h, int64_t index, int64_t *slot) {
   if (index < 0 || index >= h->n_global) return fail(RSX_ERR_RANGE, "index %lld out of range [0,%lld)", (long long)index, (long long)h->n_global);
   if (!owns(h, index)) return fail(RSX_ERR_RANGE, "index %lld is not stored on shard %d/%d", (long long)index, h->p.shard_rank, h->p.shard_world);
   *slot = index / h->p.shard_world;
+  if (*slot >= h->n_local) return fail(RSX_ERR_INTERNAL, "index %lld maps to slot %lld but the shard holds %lld", (long long)index, (long long)*slot, (long long)h->n_local);
   return RSX_OK;
 }
 
@@ -866,7 +929,7 @@ int rsx_sc_get_sectorkey(rsx_sc *h, int64_t index, double *out60) {
 int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out) {
   if (!h || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (mode != RSX_SC_MODE_CANDIDATE && mode != RSX_SC_MODE_EXHAUSTIVE) return fail(RSX_ERR_BAD_ARG, "bad mode %d", mode);
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::mutex> lk(h->mu);
   if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "detect_loop_closure needs an unsharded handle; use rsx_scs_* or rsx_sc_query_device + merge");
   RSX_TRY(set_device(h));
   const int64_t N = h->n_global;  // snapshot under the lock (the reference races here, PGO.cpp:561)
@@ -876,18 +939,23 @@ int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out) {
   out->nn_idx = 0;
   out->query_idx = (int32_t)(N - 1);
   out->searched = 0;
+  out->reserved = 0;
   out->dist_thres = h->p.dist_thres;
   if (N == 0 || N < h->p.num_exclude_recent + 1) return RSX_OK;  // SC.cpp:341-345
   if (h->tree_counter % h->p.tree_making_period == 0)  // SC.cpp:348-359
     h->tree_size = N - h->p.num_exclude_recent;
   h->tree_counter = h->tree_counter + 1;               // SC.cpp:360
+  const int64_t n_search = h->tree_size;
+  // candidate mode walks the ring-key tree: (re)built here with the handle unlocked; keyframes added meanwhile are not
+  // part of this detection (N was taken above), and the device arrays are addressed only after the lock is back
+  if (mode == RSX_SC_MODE_CANDIDATE && n_search >= 1) RSX_TRY(ensure_tree(h, &h->tree, n_search, lk));
   QueryView qv;
   qv.desc = h->desc.as<float>() + (N - 1) * DS;        // SC.cpp:336
   qv.vkey = h->vkey.as<double>() + (N - 1) * NS;
   qv.norm = h->norm.as<double>() + (N - 1) * NS;
   qv.nq = 1;
   out->searched = 1;
-  return score_candidates_and_finish(h, qv, h->rkey.as<float>() + (N - 1) * NR /* SC.cpp:335 */, h->tree_size, &h->tree, mode,
+  return score_candidates_and_finish(h, qv, h->rkey.as<float>() + (N - 1) * NR /* SC.cpp:335 */, n_search, &h->tree, mode,
                                      &out->loop_id, &out->yaw_diff_rad, &out->min_dist, &out->nn_idx);
 }
 
@@ -972,7 +1040,7 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
     f[i] = (float)curr_desc[i];
     if (!((double)f[i] == curr_desc[i])) return fail(RSX_ERR_NOT_FP32_EXACT, "query descriptor element %d is not fp32-exact", i);
   }
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::mutex> lk(h->mu);
   if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "unsharded handles only");
   if (h->n_global == 0) return fail(RSX_ERR_RANGE, "empty database");  // reference asserts (KDA.h:61)
   RSX_TRY(set_device(h));
@@ -980,6 +1048,7 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
     h->batch_size = h->n_global;
     h->batch_made = true;
   }
+  RSX_TRY(ensure_tree(h, &h->tree_batch, h->batch_size, lk));
   hipStream_t s = h->stream;
   RSX_TRY(h->q_desc.reserve(sizeof(f) + 128, s, false));
   RSX_HIP(hipMemcpyAsync(h->q_desc.p, f, sizeof(f), hipMemcpyHostToDevice, s));
@@ -1047,7 +1116,7 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
     // the exchange, so stage 1 over-samples instead).  Measured per-rank cost of both stages with 8
     // shards of the 10k DB, 8192 queries: 64 -> 3.4 ms, 128 -> 1.9, 192 -> 1.7, 256 -> 1.8.
     static const int stage1_total = [] {
-      const char *e = getenv("RSX_SC_STAGE1_TOTAL");  // tuning knob: lowest bounds scored in stage 1, over all shards
+      const char *e = rsx::exp_env("RSX_SC_STAGE1_TOTAL");  // tuning knob: lowest bounds scored in stage 1, over all shards
       const int v = (e && *e) ? atoi(e) : 0;
       return v > 0 ? v : 160;
     }();
@@ -1234,7 +1303,7 @@ int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exac
   unsigned long long v[16] = {0};
   RSX_HIP(hipMemcpy(v, h->stats.p, 128, hipMemcpyDeviceToHost));
   RSX_HIP(hipMemset(h->stats.p, 0, 128));
-  if (getenv("RSX_RESCORE_PROF") && v[1])  // region cycles of wave 0, averaged per scoring workgroup
+  if (rsx::exp_env("RSX_RESCORE_PROF") && v[1])  // region cycles of wave 0, averaged per scoring workgroup
     fprintf(stderr, "[sc_rescore prof] per query (cycles of wave 0): load %.0f  phaseA %.0f  mergeA %.0f  phaseB %.0f  mergeX %.0f  gather %.0f  total %.0f\n",
             (double)v[4] / v[1], (double)v[5] / v[1], (double)v[6] / v[1], (double)v[7] / v[1], (double)v[8] / v[1], (double)v[9] / v[1],
             (double)v[10] / v[1]);

@@ -711,7 +711,7 @@ __global__ __launch_bounds__(1024) void sc_filter_plan_kernel(Elig el, int32_t n
 double filter_eps() {
   // RSX_SC_FILTER_EPS can only LOOSEN the bound (experiments on how the exact stage grows with eps)
   static const double eps = [] {
-    const char *e = getenv("RSX_SC_FILTER_EPS");
+    const char *e = rsx::exp_env("RSX_SC_FILTER_EPS");
     const double v = e ? atof(e) : 0.0;
     return v > 1.25e-3 ? v : 1.25e-3;
   }();

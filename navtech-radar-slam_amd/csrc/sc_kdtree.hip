@@ -31,7 +31,43 @@
 // not entered -- the candidates' tree positions come from the order pass, one per lane, and "does [lo, hi) hold one" is a
 // compare and a ballot.  The float bound tests on the way to a candidate's leaf are still performed as nanoflann
 // performs them.
+//
+// This file restates algorithms of nanoflann (divideTree / middleSplit_ / planeSplit and the kNN walk of
+// KDTreeSingleIndexAdaptor, nanoflann.hpp 1.3.2 as vendored by the reference) closely enough -- the tie order of the
+// neighbours depends on its exact swap sequence -- that it is a derived work.  nanoflann's licence notice:
+//
+// Software License Agreement (BSD License)
+//
+// Copyright 2008-2009  Marius Muja (mariusm@cs.ubc.ca). All rights reserved.
+// Copyright 2008-2009  David G. Lowe (lowe@cs.ubc.ca). All rights reserved.
+// Copyright 2011-2016  Jose Luis Blanco (joseluisblancoc@gmail.com).
+//   All rights reserved.
+//
+// THE BSD LICENSE
+//
+// Redistribution and use in source and binary forms, with or without
+// modification, are permitted provided that the following conditions
+// are met:
+//
+// 1. Redistributions of source code must retain the above copyright
+//    notice, this list of conditions and the following disclaimer.
+// 2. Redistributions in binary form must reproduce the above copyright
+//    notice, this list of conditions and the following disclaimer in the
+//    documentation and/or other materials provided with the distribution.
+//
+// THIS SOFTWARE IS PROVIDED BY THE AUTHOR ``AS IS'' AND ANY EXPRESS OR
+// IMPLIED WARRANTIES, INCLUDING, BUT NOT LIMITED TO, THE IMPLIED WARRANTIES
+// OF MERCHANTABILITY AND FITNESS FOR A PARTICULAR PURPOSE ARE DISCLAIMED.
+// IN NO EVENT SHALL THE AUTHOR BE LIABLE FOR ANY DIRECT, INDIRECT,
+// INCIDENTAL, SPECIAL, EXEMPLARY, OR CONSEQUENTIAL DAMAGES (INCLUDING, BUT
+// NOT LIMITED TO, PROCUREMENT OF SUBSTITUTE GOODS OR SERVICES; LOSS OF USE,
+// DATA, OR PROFITS; OR BUSINESS INTERRUPTION) HOWEVER CAUSED AND ON ANY
+// THEORY OF LIABILITY, WHETHER IN CONTRACT, STRICT LIABILITY, OR TORT
+// (INCLUDING NEGLIGENCE OR OTHERWISE) ARISING IN ANY WAY OUT OF THE USE OF
+// THIS SOFTWARE, EVEN IF ADVISED OF THE POSSIBILITY OF SUCH DAMAGE.
 #include <hip/hip_runtime.h>
+
+#include <mutex>
 
 #include <cfloat>
 #include <cmath>
@@ -266,13 +302,32 @@ int launch_knn_tree(const KdSearchArgs &a, hipStream_t s) {
   if (a.k < 1 || a.k > KD_KMAX) return fail(RSX_ERR_BAD_ARG, "tree search with k = %d", a.k);
   if (!a.dist_tree) return fail(RSX_ERR_BAD_ARG, "tree search without the distance pass");
   const size_t need = (size_t)a.n_nodes * sizeof(KdNode16) + (size_t)a.n * sizeof(float);
-  const int resident = need <= (size_t)KD_LDS_BUDGET ? 1 : 0;
-  static bool attr_set = false;
-  if (!attr_set) {
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_knn_tree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                KD_LDS_BUDGET));
-    attr_set = true;
+  // the resident form keeps the tree in dynamic LDS: per DEVICE, opt in to what that device can give and fall back to
+  // the walk through global memory when the tree (plus the kernel's static LDS) does not fit
+  int dev = 0;
+  RSX_HIP(hipGetDevice(&dev));
+  static std::mutex mu;
+  static int lds_limit[64];   // 0 = not asked yet, else usable dynamic LDS bytes of device `dev`
+  int limit;
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    if (dev < 0 || dev >= 64) return fail(RSX_ERR_BAD_ARG, "device ordinal %d", dev);
+    if (!lds_limit[dev]) {
+      int max_block = 0;
+      RSX_HIP(hipDeviceGetAttribute(&max_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev));
+      hipFuncAttributes fa;
+      RSX_HIP(hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&sc_knn_tree_kernel)));
+      int dyn = max_block - (int)fa.sharedSizeBytes;
+      if (dyn > KD_LDS_BUDGET) dyn = KD_LDS_BUDGET;
+      if (dyn > 0 && hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_knn_tree_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, dyn) != hipSuccess) {
+        (void)hipGetLastError();
+        dyn = 0;
+      }
+      lds_limit[dev] = dyn > 0 ? dyn : -1;
+    }
+    limit = lds_limit[dev];
   }
+  const int resident = (limit > 0 && need <= (size_t)limit) ? 1 : 0;
   hipLaunchKernelGGL(sc_knn_tree_kernel, dim3(1), dim3(64), resident ? need : 0, s, a, resident);
   RSX_HIP(hipGetLastError());
   return RSX_OK;

@@ -1504,7 +1504,7 @@ struct Variant { int b, w; };
 Variant pair_variant() {
   static Variant v = [] {
     Variant d{2, 4};
-    const char *e = getenv("RSX_SC_PAIR_VARIANT");
+    const char *e = rsx::exp_env("RSX_SC_PAIR_VARIANT");
     int b = 0, w = 0;
     if (e && sscanf(e, "%d,%d", &b, &w) == 2) {
       if ((b == 1 && w == 4) || (b == 2 && (w == 3 || w == 4)) || (b == 4 && w == 2)) d = Variant{b, w};
@@ -1769,7 +1769,7 @@ int launch_walk(const DbView &db, const QueryView &q, const float *lb, int64_t l
   a.seed = nullptr;
   a.eps = eps;
   a.k = k;
-  a.round_begin = getenv("RSX_WALK_NOPREVIEW") ? 1 : 0;  // experiment: disable the pruning preview
+  a.round_begin = rsx::exp_env("RSX_WALK_NOPREVIEW") ? 1 : 0;  // experiment: disable the pruning preview
   a.round_end = RESCORE_ALL_ROUNDS;
   hipLaunchKernelGGL(sc_walk_kernel, dim3(q.nq), dim3(64), WalkLds::SIZE, s, a);
   RSX_HIP(hipGetLastError());
@@ -1801,7 +1801,7 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
   // four 4-wave workgroups per CU keep more queries in flight, so one query's barriers and merge hide behind
   // the others' scoring
   static const int variant = [] {
-    const char *e = getenv("RSX_SC_RESCORE_VARIANT");
+    const char *e = rsx::exp_env("RSX_SC_RESCORE_VARIANT");
     return (e && *e) ? atoi(e) : 0;
   }();
   RescoreArgs a;
@@ -1824,7 +1824,7 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
   a.round_end = round_end;
   a.stats = d_stats;
   static const bool no_two_phase = [] {
-    const char *e = getenv("RSX_SC_TWO_PHASE");  // experiments: 0 = the one-pass scoring of round 1
+    const char *e = rsx::exp_env("RSX_SC_TWO_PHASE");  // experiments: 0 = the one-pass scoring of round 1
     return e && e[0] == '0';
   }();
   a.two_phase = (!no_two_phase && variant == 0 && n_items < (1ll << RS_SLOT_BITS)) ? 1 : 0;

@@ -32,12 +32,34 @@ struct rsx_scs {
   hipEvent_t ev_merged = nullptr;
   int tree_counter = 0;
   int64_t tree_size = 0;
+  bool failed = false;  // an add reached some shards but not all: the shards disagree about the keyframe count
 };
 
 namespace {
 
 int use(const Shard &s) {
   RSX_HIP(hipSetDevice(s.device));
+  return RSX_OK;
+}
+
+int usable(const rsx_scs *h) {
+  if (h->failed)
+    return fail(RSX_ERR_INTERNAL, "this rsx_scs handle is inconsistent (an earlier add failed on one shard after others had taken it): destroy it");
+  return RSX_OK;
+}
+
+// an add must reach every shard or none: a failure after the first shard leaves ownership (i % G) and the eligible
+// prefix different per shard, so the handle is retired instead of answering from a torn database
+template <typename F>
+int add_to_all(rsx_scs *h, F &&add_one) {
+  RSX_TRY(usable(h));
+  for (size_t g = 0; g < h->sh.size(); g++) {
+    const int st = add_one(h->sh[g]);
+    if (st != RSX_OK) {
+      if (g > 0) h->failed = true;
+      return st;
+    }
+  }
   return RSX_OK;
 }
 
@@ -189,7 +211,7 @@ int rsx_scs_add_points(rsx_scs *h, const void *pts, size_t n, size_t stride_byte
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
   int32_t idx = 0;
-  for (Shard &s : h->sh) RSX_TRY(rsx_sc_add_points(s.h, pts, n, stride_bytes, &idx));
+  RSX_TRY(add_to_all(h, [&](Shard &s) { return rsx_sc_add_points(s.h, pts, n, stride_bytes, &idx); }));
   if (out_index) *out_index = idx;
   return RSX_OK;
 }
@@ -197,8 +219,7 @@ int rsx_scs_add_points(rsx_scs *h, const void *pts, size_t n, size_t stride_byte
 int rsx_scs_add_descriptors_f32(rsx_scs *h, const float *descs, int64_t n) {
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
-  for (Shard &s : h->sh) RSX_TRY(rsx_sc_add_descriptors_f32(s.h, descs, n));
-  return RSX_OK;
+  return add_to_all(h, [&](Shard &s) { return rsx_sc_add_descriptors_f32(s.h, descs, n); });
 }
 
 int rsx_scs_get_descriptor(rsx_scs *h, int64_t index, double *out_colmajor) {
@@ -212,6 +233,7 @@ int rsx_scs_query(rsx_scs *h, const float *q_descs, int32_t nq, int32_t k, int64
   if (!h || !q_descs || !out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(usable(h));
   return query_locked(h, q_descs, nq, k, n_eligible, out);
 }
 
@@ -220,6 +242,7 @@ int rsx_scs_query(rsx_scs *h, const float *q_descs, int32_t nq, int32_t k, int64
 int rsx_scs_detect_loop_closure(rsx_scs *h, rsx_sc_detection *out) {
   if (!h || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(usable(h));
   int64_t N = 0;
   RSX_TRY(rsx_sc_size(h->sh[0].h, &N));
   out->loop_id = -1;

@@ -995,7 +995,7 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
   a.ld_lb = ld_lb;
   a.eps_direct = (float)filter_eps();
   {
-    const char *e = getenv("RSX_SPEC_DBG");
+    const char *e = rsx::exp_env("RSX_SPEC_DBG");
     a.dbg = e ? atoi(e) : 0;
   }
   const int64_t ntiles = (n_items + 31) / 32;
@@ -1023,7 +1023,7 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
         best_r = rr;
       }
     }
-    if (const char *e = getenv("RSX_SPEC_R")) {  // experiments: force the number of query ranges
+    if (const char *e = rsx::exp_env("RSX_SPEC_R")) {  // experiments: force the number of query ranges
       const int64_t v = atoll(e);
       if (v >= 1 && v <= nqt) best_r = v;
     }
@@ -1032,7 +1032,7 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
     grid = (unsigned)(rr * ntb);
   }
   static unsigned long long *d_prof = nullptr;
-  static const bool want_prof = getenv("RSX_SPEC_PROF") != nullptr;
+  static const bool want_prof = rsx::exp_env("RSX_SPEC_PROF") != nullptr;
   if (want_prof && !d_prof) RSX_HIP(hipMalloc(&d_prof, 8 * sizeof(unsigned long long)));
   a.prof = want_prof ? d_prof : nullptr;
   hipLaunchKernelGGL(sc_spec_filter_kernel, dim3(grid), dim3(256), lds, s, a);

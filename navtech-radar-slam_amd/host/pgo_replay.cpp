@@ -90,9 +90,9 @@ int main(int argc, char **argv) {
         movementAccumulation = 0.0;
         pts.clear();
         for (const rosmsg::PointXYZI &p : cloud) pts.push_back(Pt32{p.x, p.y, p.z, 1.0f, p.intensity, {0, 0, 0}});
-        // downSizeFilterScancontext.filter + scManager.makeAndSaveScancontextAndKeys (PGO.cpp:482-492), fused on the GPU
-        if (scManager.sharded()) scManager.makeAndSaveScancontextAndKeys(pts.empty() ? nullptr : &pts[0].x, pts.size(), sizeof(Pt32));
-        else scManager.makeAndSaveScancontextAndKeysDownsampled(pts.empty() ? nullptr : &pts[0].x, pts.size(), sizeof(Pt32), 0.4f);
+        // downSizeFilterScancontext.filter + scManager.makeAndSaveScancontextAndKeys (PGO.cpp:482-492) on the GPU, for one
+        // device (fused) and for several (downsample on the first, same cloud to every shard) alike
+        scManager.makeAndSaveScancontextAndKeysDownsampled(pts.empty() ? nullptr : &pts[0].x, pts.size(), sizeof(Pt32), 0.4f);
         n_keyframes++;
         if (n_keyframes < scManager.NUM_EXCLUDE_RECENT) continue;  // PGO.cpp:558
         auto r = scManager.detectLoopClosureID();                   // PGO.cpp:561

@@ -164,6 +164,11 @@ inline Header deserialize_pointcloud2(const uint8_t *data, size_t n, std::vector
   const uint8_t *pd = r.bytes(nbytes);
   (void)r.get<uint8_t>();  // is_dense
   if (off[0] < 0 || off[1] < 0 || off[2] < 0) throw std::runtime_error("rosmsg: cloud without x / y / z");
+  // everything below indexes the data buffer with numbers that came out of the message: check them first
+  for (int k = 0; k < 4; k++)
+    if (off[k] >= 0 && (uint64_t)off[k] + 4 > (uint64_t)point_step) throw std::runtime_error("rosmsg: field offset beyond point_step");
+  if (point_step == 0 || (uint64_t)row_step < (uint64_t)width * point_step) throw std::runtime_error("rosmsg: bad point_step / row_step");
+  if ((uint64_t)height * width > (uint64_t)nbytes / point_step) throw std::runtime_error("rosmsg: point data shorter than height x width");
   out->clear();
   out->reserve((size_t)height * width);
   for (uint32_t row = 0; row < height; row++)

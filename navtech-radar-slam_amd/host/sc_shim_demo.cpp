@@ -78,6 +78,14 @@ static int replay(const char *path, const std::vector<int> &devices, bool exhaus
   auto d = sc.distanceBtnScanContext(a.data(), b.data());
   std::printf("HELPERS %.17g %.17g %d %.17g %d %.17g\n", rk[3], vk1[7], sc.fastAlignUsingVkey(vk1, vk2), d.first, d.second,
               sc.distDirectSC(a.data(), b.data()));
+  // the reference's public data members as views of the GPU database (Scancontext.h:110-115)
+  {
+    const auto &last = sc.polarcontexts_.back();
+    double sum = 0.0;
+    for (int e = 0; e < RSX_SC_DESC_SIZE; e++) sum += last.data()[e];
+    std::printf("MEMBERS %zu %.17g %.9g %.17g %.17g\n", sc.polarcontexts_.size(), sum, (double)sc.polarcontext_invkeys_mat_[(size_t)n_clouds - 1][3],
+                sc.polarcontext_invkeys_[(size_t)n_clouds - 1].data()[3], sc.polarcontext_vkeys_.at((size_t)n_clouds - 1).data()[7]);
+  }
   return 0;
 }
 

@@ -20,8 +20,10 @@
 //     handle is created once under a lock, every call locks the handle inside librsx, and the shim's own
 //     cached values (last log values, recent SCD) are per thread or guarded;
 //   * failures of the GPU library throw std::runtime_error (the reference has no error path);
-//   * the public std::vector members polarcontexts_ etc. are replaced by accessors
-//     (descriptor(i), ringkey(i), sectorkey(i)) that read the HBM-resident database;
+//   * the public std::vector members polarcontexts_, polarcontext_invkeys_, polarcontext_vkeys_ and
+//     polarcontext_invkeys_mat_ (Scancontext.h:110-115) exist as READ-ONLY views of the HBM-resident database with the
+//     std::vector reading interface (size, [], at, front, back, iteration): elements are fetched on first access and
+//     cached; code that writes to them does not compile.  descriptor(i) / ringkey(i) / sectorkey(i) return copies;
 //   * the database stores fp32: saveScancontextAndKeys(MatrixXd) rounds a descriptor that is not
 //     fp32-exact (every descriptor makeScancontext builds is) and remembers the largest rounding error
 //     (lastImportRounding()); setStrictImport(true) makes such a descriptor an error instead;
@@ -32,7 +34,9 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <iostream>
+#include <map>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -57,6 +61,53 @@ using SCPointType = pcl::PointXYZI;  // Scancontext.h:39
 using KeyMat = std::vector<std::vector<float>>;  // Scancontext.h:40
 
 inline void coreImportTest(void);  // Scancontext.h:47
+
+// Read-only view with the reading interface of the std::vector the reference keeps in host memory
+// (Scancontext.h:110-115), over the HBM-resident database: an element is fetched on first access and cached (the
+// database is append-only, so an element never changes); references stay valid for the life of the SCManager.
+template <typename T>
+class RsxMirrorVector {
+ public:
+  using value_type = T;
+  using size_type = std::size_t;
+  RsxMirrorVector(std::function<int64_t()> size, std::function<T(int64_t)> fetch) : size_(std::move(size)), fetch_(std::move(fetch)) {}
+  RsxMirrorVector(const RsxMirrorVector &) = delete;
+  RsxMirrorVector &operator=(const RsxMirrorVector &) = delete;
+  size_type size() const { return (size_type)size_(); }
+  bool empty() const { return size() == 0; }
+  const T &operator[](size_type i) const {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = cache_.find(i);
+    if (it == cache_.end()) it = cache_.emplace(i, fetch_((int64_t)i)).first;
+    return it->second;  // std::map nodes do not move
+  }
+  const T &at(size_type i) const {
+    if (i >= size()) throw std::out_of_range("SCManager database view: index out of range");
+    return (*this)[i];
+  }
+  const T &front() const { return (*this)[0]; }
+  const T &back() const { return (*this)[size() - 1]; }
+  class const_iterator {
+   public:
+    const_iterator(const RsxMirrorVector *v, size_type i) : v_(v), i_(i) {}
+    const T &operator*() const { return (*v_)[i_]; }
+    const T *operator->() const { return &(*v_)[i_]; }
+    const_iterator &operator++() { ++i_; return *this; }
+    bool operator!=(const const_iterator &o) const { return i_ != o.i_; }
+    bool operator==(const const_iterator &o) const { return i_ == o.i_; }
+   private:
+    const RsxMirrorVector *v_;
+    size_type i_;
+  };
+  const_iterator begin() const { return const_iterator(this, 0); }
+  const_iterator end() const { return const_iterator(this, size()); }
+
+ private:
+  std::function<int64_t()> size_;
+  std::function<T(int64_t)> fetch_;
+  mutable std::mutex mu_;
+  mutable std::map<size_type, T> cache_;
+};
 
 class SCManager {
  public:
@@ -87,7 +138,19 @@ class SCManager {
   // (laserPosegraphOptimization.cpp:482-492): the raw keyframe goes in, the VoxelGrid downsample
   // (leaf as set at PGO.cpp:687-688) and the descriptor build both run on the GPU.
   void makeAndSaveScancontextAndKeysDownsampled(const float *xyz, std::size_t n, std::size_t stride_bytes, float leaf = 0.4f) {
-    if (sharded()) throw std::runtime_error("makeAndSaveScancontextAndKeysDownsampled: single-device handles only");
+    if (sharded()) {
+      // several devices: the downsample runs on the first one, the centroids (x, y, z, intensity float4) come back once
+      // and every shard gets the same cloud -- the descriptor is the one a single device would build
+      rsx_scs *hs = shardedHandle();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (!vg_) check(rsx_voxelgrid_create(devices_[0], &vg_), "rsx_voxelgrid_create");
+      ds_.resize(4 * (n ? n : 1));
+      int64_t m = 0;
+      check(rsx_voxelgrid_filter(vg_, xyz, n, stride_bytes, stride_bytes >= 20 ? 16 : -1, leaf, ds_.data(), (int64_t)(n ? n : 1), &m),
+            "rsx_voxelgrid_filter");
+      check(rsx_scs_add_points(hs, ds_.data(), (std::size_t)m, 16, nullptr), "makeAndSaveScancontextAndKeysDownsampled");
+      return;
+    }
     rsx_sc *h = handle();
     {
       std::lock_guard<std::mutex> lk(mu_);
@@ -246,6 +309,22 @@ class SCManager {
   double SC_DIST_THRES = 0.2;
   const int TREE_MAKING_PERIOD_ = 30;
 
+  // ---- the reference's public data members (Scancontext.h:110-115) as read-only views of the GPU database ----
+#ifdef RSX_HAVE_EIGEN
+  using SCMat = Eigen::MatrixXd;  // polarcontexts_[i] is 20 x 60, polarcontext_invkeys_[i] 20 x 1, polarcontext_vkeys_[i] 1 x 60
+#else
+  using SCMat = std::vector<double>;  // the same numbers, column-major
+#endif
+  RsxMirrorVector<SCMat> polarcontexts_{[this] { return size(); }, [this](int64_t i) { return mirrorMat(i, 0); }};
+  RsxMirrorVector<SCMat> polarcontext_invkeys_{[this] { return size(); }, [this](int64_t i) { return mirrorMat(i, 1); }};
+  RsxMirrorVector<SCMat> polarcontext_vkeys_{[this] { return size(); }, [this](int64_t i) { return mirrorMat(i, 2); }};
+  RsxMirrorVector<std::vector<float>> polarcontext_invkeys_mat_{[this] { return size(); }, [this](int64_t i) {
+                                                                   const SCMat k = mirrorMat(i, 1);  // eig2stdvec: double -> float
+                                                                   std::vector<float> f(RSX_SC_NUM_RING);
+                                                                   for (int r = 0; r < RSX_SC_NUM_RING; r++) f[(std::size_t)r] = (float)k.data()[r];
+                                                                   return f;
+                                                                 }};
+
   void setSCdistThres(double new_thres) {  // Scancontext.h:107
     std::lock_guard<std::mutex> lk(mu_);
     SC_DIST_THRES = new_thres;
@@ -357,10 +436,25 @@ class SCManager {
     }
     return h_;
   }
+  // element i of a mirrored member: 0 = the descriptor, 1 = its ring key, 2 = its sector key (keys through the GPU helpers)
+  SCMat mirrorMat(int64_t i, int what) {
+    const std::vector<double> d = descriptor(i);
+    const int rows = what == 2 ? 1 : RSX_SC_NUM_RING, cols = what == 0 ? RSX_SC_NUM_SECTOR : (what == 1 ? 1 : RSX_SC_NUM_SECTOR);
+#ifdef RSX_HAVE_EIGEN
+    SCMat m(rows, cols);
+#else
+    SCMat m((std::size_t)rows * cols);
+#endif
+    if (what == 0) for (int e = 0; e < RSX_SC_DESC_SIZE; e++) m.data()[e] = d[(std::size_t)e];
+    else if (what == 1) makeRingkeyFromScancontext(d.data(), m.data());
+    else makeSectorkeyFromScancontext(d.data(), m.data());
+    return m;
+  }
   std::mutex mu_;  // guards handle creation and the cached values below
   rsx_sc *h_ = nullptr;
   rsx_scs *hs_ = nullptr;
   rsx_voxelgrid *vg_ = nullptr;
+  std::vector<float> ds_;  // downsampled cloud of the multi-device path
   int mode_ = RSX_SC_MODE_CANDIDATE;
   int device_ = 0;
   std::vector<int> devices_;

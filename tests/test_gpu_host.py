@@ -97,7 +97,7 @@ def test_shim_replay_reproduces_reference_stdout(tmp_path, oracle):
     assert got.returncode == 0, got.stdout + got.stderr
     want = subprocess.run([sys.executable, "-c", _REF_REPLAY, root, str(seed), str(n)], capture_output=True, text=True, timeout=300)
     assert want.returncode == 0, want.stderr
-    got_lines = [ln for ln in got.stdout.splitlines() if not ln.startswith("HELPERS")]
+    got_lines = [ln for ln in got.stdout.splitlines() if not ln.startswith(("HELPERS", "MEMBERS"))]
     assert got_lines == want.stdout.splitlines()
     assert sum(ln.startswith("[Loop found]") for ln in got_lines) >= 3 and sum(ln.startswith("[Not loop]") for ln in got_lines) >= 10
     # the public helpers printed at the end, against the oracle
@@ -109,6 +109,10 @@ def test_shim_replay_reproduces_reference_stdout(tmp_path, oracle):
     d, s = oracle.distance(a, b)
     assert (float(h[3]), int(h[4])) == (d, s)
     assert float(h[5]) == oracle.dist_direct(a, b) or (np.isnan(float(h[5])) and np.isnan(oracle.dist_direct(a, b)))
+    # the public data members (polarcontexts_ & co., Scancontext.h:110-115) read through the shim's views
+    m = [ln for ln in got.stdout.splitlines() if ln.startswith("MEMBERS")][0].split()[1:]
+    assert int(m[0]) == n and float(m[1]) == float(a.sum())
+    assert np.float32(float(m[2])) == oracle.ringkey_f32(a)[3] and float(m[3]) == oracle.ringkey(a)[3] and float(m[4]) == oracle.sectorkey(a)[7]
 
 
 def test_shim_multi_device_detector(tmp_path, oracle):

@@ -106,6 +106,31 @@ def test_export_save_load_roundtrip(sc, oracle, tmp_path):
     bad.write_bytes(raw[:1000])
     with pytest.raises(RsxError):
         sc.SCManager().load(str(bad))
+    # the header is not trusted: a shard file whose n_local is not the size of its residue class, a file that
+    # is shorter or longer than its header says, an absurd n_local (must not allocate), a rank outside the world
+    import struct
+    shard0 = bytearray(open(str(tmp_path / "shard0.rsxscdb"), "rb").read())
+    hdr = struct.Struct("<8sIIIIqqii16s")
+    f = list(hdr.unpack_from(shard0))
+    assert f[5] == 301 and f[6] == 151 and (f[7], f[8]) == (0, 2)
+
+    def rejected(fields, payload):
+        pth = tmp_path / "forged.rsxscdb"
+        pth.write_bytes(hdr.pack(*fields) + bytes(payload))
+        with pytest.raises(RsxError):
+            sc.SCManager(shard_rank=0, shard_world=2).load(str(pth))
+
+    body = shard0[64:]
+    rejected(f[:6] + [150] + f[7:], body[:150 * 4800])             # one descriptor short of the residue class
+    rejected(f[:5] + [303, 151] + f[7:], body)                      # n_global says 152 belong to rank 0
+    rejected(f, body[:-4800])                                       # truncated
+    rejected(f, body + b"\0" * 16)                                  # trailing bytes
+    rejected(f[:5] + [2**61, 2**60] + f[7:], body)                  # would be 4.6e18 bytes: rejected before any allocation
+    rejected(f[:7] + [2, 2] + f[9:], body)                          # rank outside the world
+    ok = tmp_path / "forged.rsxscdb"
+    ok.write_bytes(bytes(shard0))
+    s3 = sc.SCManager(shard_rank=0, shard_world=2)
+    assert s3.load(str(ok)) == 151
 
 
 @pytest.mark.parametrize("shards", [2, 5])

@@ -172,6 +172,9 @@ def test_walk_rescoring_matches_rounds():
     import os
     import subprocess
     import sys
+    from navtech_radar_slam_amd import _rsx
+    if "+experiments" not in _rsx.version():
+        pytest.skip("the RSX_SC_RESCORE knob only exists in an experiments build (make -C navtech-radar-slam_amd/csrc EXPERIMENTS=1)")
     code = r'''
 import numpy as np
 from navtech_radar_slam_amd import scancontext as sc, synth, _rsx

@@ -31,7 +31,13 @@ int main() {
   std::vector<float> key(20);
   std::pair<int, float> r2 = scManager.detectLoopClosureIDBetweenSession(key, sc);
   const Eigen::MatrixXd &recent = scManager.getConstRefRecentSCD();
-  return (int)(r.first + r2.first + k + d + dd.first + rk.size() + recent.size());
+  // the public data members (Scancontext.h:110-115), read the way third-party code reads them
+  const Eigen::MatrixXd &last = scManager.polarcontexts_.back();
+  const Eigen::MatrixXd &first_key = scManager.polarcontext_invkeys_[0], &first_vkey = scManager.polarcontext_vkeys_.at(0);
+  std::size_t n_db = scManager.polarcontexts_.size() + scManager.polarcontext_invkeys_mat_.size();
+  float kf = scManager.polarcontext_invkeys_mat_[0][3];
+  for (const auto &m : scManager.polarcontexts_) n_db += (std::size_t)m.size();
+  return (int)(r.first + r2.first + k + d + dd.first + rk.size() + recent.size() + last.size() + first_key.size() + first_vkey.size() + n_db + kf);
 }
 """
 
