@@ -23,8 +23,13 @@ against the CPU oracle on >= 256 queries of the timed batch (`oracle_checked_que
 Besides `value` (that workload through the default path: fp16 MFMA lower-bound filter -> exact fp64
 re-scoring of the survivors) the line carries
   data_dependence   the same batch shape on (a) the round-1 descriptor-level random DB with planted rotated
-                    copies and (b) the exact-all path (filter off: every pair scored in fp64) = the
-                    data-independent floor, each with queries/s and exact evaluations per query
+                    copies, (b) the drive with continuous landmark heights (non-binary descriptors, oracle-checked) and
+                    (c) the exact-all path (filter off: every pair scored in fp64) = the data-independent floor, each with
+                    queries/s and exact evaluations per query
+  host_entry        the same batch through the synchronous host-buffer call (PCIe upload of the queries and download of
+                    the records inside the time)
+  layouts           (N > 1) every query-groups x DB-shards layout of this world, same DB and batch, identical results;
+  layout_emulation  (N = 1) what one rank computes per step in every layout of 2 / 4 / 8 GPUs, emulated on this GPU
   scale_100k        8192 queries vs a 100 000-keyframe DB (the size where DB shards pay), same sharding
   roofline          the dominant kernel (spectral MFMA filter): algorithmic flops / hipEvent time, vs the dense fp16 peak
   cpu_baseline      the CPU oracle (== the reference's Scancontext.cpp, tests/test_oracle_pin.py) on this box's cores
@@ -110,14 +115,14 @@ def random_db_and_queries(n_db, n_q, seed_db=1234, seed_q=4321):
 class Workload:
     """One DB (sharded over the ranks) + one resident query batch + the timed step."""
 
-    def __init__(self, ctx, name, k, capacity, filter_mode=0):
+    def __init__(self, ctx, name, k, capacity, filter_mode=0, query_groups=1):
         from navtech_radar_slam_amd import sharded
         self.ctx, self.name, self.k = ctx, name, k
         if ctx.stub:
-            self.ssc = sharded.ShardedScanContext(local_backend=ctx.stub(ctx.rank, ctx.world))
+            self.ssc = sharded.ShardedScanContext(local_backend=lambda sr, sw: ctx.stub(sr, sw), query_groups=query_groups)
         else:
-            self.ssc = sharded.ShardedScanContext(device=ctx.local_rank, capacity_hint=capacity // ctx.world + 8,
-                                                  filter_mode=filter_mode)
+            self.ssc = sharded.ShardedScanContext(device=ctx.local_rank, capacity_hint=capacity * query_groups // ctx.world + 8,
+                                                  filter_mode=filter_mode, query_groups=query_groups)
         self.mgr = self.ssc.backend
         self.hits = None
 
@@ -152,6 +157,11 @@ class Workload:
         if self.ctx.stub:
             return np.ascontiguousarray(self.hits)
         return self.hits.cpu().numpy().view(scancontext.HIT_DTYPE).reshape(self.nq, self.k)
+
+    def local_pairs(self, n_elig):
+        """(query, entry) pairs ONE launch of this rank's filter scores: its slice of the batch x its shard's eligible entries"""
+        lo, hi, _ = self.ssc._slice(self.nq)
+        return (hi - lo) * len(range(self.ssc.shard_rank, n_elig, self.ssc.shard_world))
 
     def timed(self, steps, warmup, profile=False):
         """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides.
@@ -660,9 +670,70 @@ def icp_leg(device):
                     "(uploads both clouds, one 16-byte read-back per iteration)" % (len(src) * len(tgt))}
 
 
+def layout_emulation_leg(device, db_descs, q_descs, n_elig, k):
+    """What ONE rank computes between the collectives in every layout of 2 / 4 / 8 GPUs, emulated on this one GPU: a handle
+    holding shard 0 of S (the DB descriptors handed over, the handle keeps its residue class) and the first nq / Q queries;
+    S > 1: stage 1 + stage 2 of the two-stage protocol (the stage-1 list of the shard itself as the bound: a looser
+    bound than the merged one, so stage 2 is not under-estimated); S = 1: the single-stage query.  The exchanges
+    (latency-bound all-gathers of 16-byte records, ~0.1 ms each, S > 1 only) and the final all-gather of the slices (Q > 1)
+    are NOT in these numbers; the real curve is the driver's SCALE_r*.json."""
+    import torch
+    from navtech_radar_slam_amd import scancontext
+    nq = len(q_descs)
+    d_q = torch.from_numpy(q_descs).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    out = {}
+    cache = {}
+    for g in (1, 2, 4, 8):
+        row = {}
+        for q in [d for d in range(1, g + 1) if g % d == 0]:
+            s_w = g // q
+            nq_r = -(-nq // q)
+            if (s_w, nq_r) not in cache:
+                h = scancontext.SCManager(device=device, shard_rank=0, shard_world=s_w, capacity_hint=len(db_descs) // s_w + 8)
+                h.add_descriptors_f32(db_descs)
+                a = torch.zeros((nq_r, k, 2), dtype=torch.float64, device="cuda")
+                b = torch.zeros((nq_r, k, 2), dtype=torch.float64, device="cuda")
+
+                def run():
+                    if s_w == 1:
+                        h.query_device(d_q.data_ptr(), nq_r, k, a.data_ptr(), n_eligible=n_elig, stream=st)
+                    else:
+                        h.query_stage1_device(d_q.data_ptr(), nq_r, k, a.data_ptr(), n_eligible=n_elig, stream=st)
+                        h.query_stage2_device(nq_r, k, a.data_ptr(), b.data_ptr(), stream=st)
+                for _ in range(2):
+                    run()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(5):
+                    run()
+                torch.cuda.synchronize()
+                cache[(s_w, nq_r)] = (time.perf_counter() - t0) / 5 * 1e3
+                h.close()
+            row[f"{q}x{s_w}"] = cache[(s_w, nq_r)]
+        out[str(g)] = row
+    base = out["1"]["1x1"]
+    return {"per_rank_ms_per_step": out, "best_layout": {g: min(r, key=r.get) for g, r in out.items()},
+            "compute_speedup_of_best_layout": {g: base / min(r.values()) for g, r in out.items()},
+            "layout_key": "query groups x DB shards",
+            "note": "per-rank compute between the collectives, emulated on ONE GPU (not a multi-GPU measurement); exchanges excluded"}
+
+
+def host_entry_leg(mgr, q_descs, n_elig, k, reps=3):
+    """the same batch through the synchronous HOST-buffer entry (rsx_sc_query): pageable host queries
+    in (nq x 4800 B over PCIe), host records out (nq x k x 16 B), upload and download inside the time."""
+    mgr.query(q_descs, k=k, n_eligible=n_elig)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        mgr.query(q_descs, k=k, n_eligible=n_elig)
+    dt = (time.perf_counter() - t0) / reps
+    return {"ms_per_step": dt * 1e3, "queries_per_sec": len(q_descs) / dt, "h2d_bytes": int(q_descs.nbytes), "d2h_bytes": len(q_descs) * k * 16,
+            "note": "rsx_sc_query: H2D of the queries + filter/select/re-score + D2H of the records, one synchronous call (pageable host memory)"}
+
+
 def roofline_of(wl, launches, kern_ms, n_elig):
     ctx = wl.ctx
-    local_pairs = wl.nq * len(range(ctx.rank, n_elig, ctx.world))  # pairs one launch of this rank scores
+    local_pairs = wl.local_pairs(n_elig)  # pairs one launch of this rank scores
     alg_bytes = local_pairs * ALG_BYTES_PER_PAIR + wl.nq * 4800 + wl.nq * wl.k * 16
     avg_kern_s = (kern_ms / max(launches, 1)) * 1e-3
     kernel = wl.mgr.profiled_kernel_name()
@@ -670,11 +741,13 @@ def roofline_of(wl, launches, kern_ms, n_elig):
         spectral = kernel == "sc_spec_filter_kernel"
         # queries whose 60 columns are all non-empty skip the n_eff mask correlation (3600 MAC per pair): n_eff is then
         # the entry's column count at every shift -- count only what was executed
-        full = float(np.mean((wl.q_host.reshape(wl.nq, 60, 20) != 0).any(axis=2).all(axis=1)))
+        lo_q, hi_q, _ = wl.ssc._slice(wl.nq)
+        full = float(np.mean((wl.q_host[lo_q:hi_q].reshape(hi_q - lo_q, 60, 20) != 0).any(axis=2).all(axis=1)))
         spec_flop = 2 * (9280 + 960 + 3600 * (1.0 - full))
         alg_flop = local_pairs * (spec_flop if spectral else ALG_FLOP_PER_PAIR)
         achieved = alg_flop / avg_kern_s / 1e12 if avg_kern_s > 0 else 0.0
         prof = committed_profile(kernel) if ctx.world == 1 and (wl.nq, n_elig) == (8192, 9970) else None
+        alg_bytes = local_pairs * ALG_BYTES_PER_PAIR + (hi_q - lo_q) * 4800 + (hi_q - lo_q) * wl.k * 16
         return kernel, {
             "bound": "mfma", "achieved": achieved, "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / MFMA_F16_PEAK_TFLOPS, "kernel": kernel, "launches": launches,
@@ -719,6 +792,8 @@ def main():
     ap.add_argument("--data", choices=["trajectory", "random"], default="trajectory",
                     help="headline DB: descriptors built from a synthetic drive (default) or the round-1 random descriptors")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world 1")
+    ap.add_argument("--query-groups", type=int, default=0,
+                    help="layout = query groups x DB shards (sharded.py); 0 = auto (as many query groups as the batch feeds), 1 = pure DB shards")
     args = ap.parse_args()
 
     dry = bool(os.environ.get("RSX_BENCH_LOCAL_BACKEND"))
@@ -741,10 +816,22 @@ def main():
     # ---- headline workload ------------------------------------------------------------------
     t_gen = time.perf_counter()
     db_pts = db_off = None
+    from navtech_radar_slam_amd.sharded import auto_layout
+    qgroups = args.query_groups if args.query_groups > 0 else auto_layout(world, nq)
+    if world % qgroups:
+        raise SystemExit(f"bench.py: --query-groups {qgroups} does not divide --gpus {world}")
+    db_descs = None
     if args.data == "trajectory" and not ctx.stub:
         db_pts, db_off, q_pts, q_off, q_src = synth.trajectory_keyframes(1234, n_db, 4321, nq, binary_z=True)
-        main_wl = Workload(ctx, "trajectory", k, n_db)
-        main_wl.add_clouds(db_pts, db_off)                       # descriptor-BUILD path, keyframe by keyframe
+        # descriptor-BUILD path, keyframe by keyframe, into a full replica on every rank; the (sharded) workloads of every
+        # layout are then filled from its descriptors (a shard keeps its residue class of whatever it is handed)
+        replica = scancontext.SCManager(device=ctx.local_rank, capacity_hint=n_db + 8)
+        for i in range(n_db):
+            replica.makeAndSaveScancontextAndKeys(db_pts[db_off[i]:db_off[i + 1]])
+        db_descs = replica.export_descriptors_f32(0, n_db)
+        replica.close()
+        main_wl = Workload(ctx, "trajectory", k, n_db, query_groups=qgroups)
+        main_wl.add_descriptors(db_descs)
         qb = scancontext.SCManager(device=ctx.local_rank, capacity_hint=nq + 8)
         for i in range(nq):
             qb.makeAndSaveScancontextAndKeys(q_pts[q_off[i]:q_off[i + 1]])
@@ -756,8 +843,10 @@ def main():
                      f"{int((q_src >= 0).sum())} revisits of driven places + {int((q_src < 0).sum())} places never seen")
     else:
         descs, q_descs, r_src, r_rot = random_db_and_queries(n_db, nq)
-        main_wl = Workload(ctx, "random", k, n_db)
+        main_wl = Workload(ctx, "random", k, n_db, query_groups=qgroups)
         main_wl.add_descriptors(descs)
+        if not ctx.stub:
+            db_descs = descs
         data_note = "descriptor-level random binary DB, queries = rotated corrupted copies (planted loops)"
     main_wl.set_queries(q_descs, n_elig)
     gen_s = time.perf_counter() - t_gen
@@ -783,7 +872,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n_db}_{main_wl.name}", "db_keyframes": n_db,
                        "queries_per_step": nq, "topk": k, "rings_x_sectors": "20x60",
-                       "parallelism": f"db_shard{world}" if world > 1 else "single_gpu",
+                       "parallelism": f"query_groups{qgroups}_x_db_shards{world // qgroups}" if world > 1 else "single_gpu",
+                       "layout": main_wl.ssc.layout,
                        "pairs_per_sec": qps * n_elig, "data_note": data_note, "data_generation_s": gen_s},
             "rccl_ranks": ctx.dist.get_world_size() if ctx.distributed else 1,
             "backend": (ctx.dist.get_backend() if ctx.distributed else "none"),
@@ -801,12 +891,34 @@ def main():
             if planted_ok is not None:
                 out["planted_loops_recovered"] = planted_ok
 
+    # ---- every layout of this world (query groups x DB shards), same DB, same batch ------------------
+    if world > 1 and not args.only_main:
+        fill = db_descs if db_descs is not None else descs
+        lay = {}
+        st_l = max(3, args.steps // 4)
+        for qg in [d for d in range(1, world + 1) if world % d == 0]:
+            if qg == qgroups:
+                lay[main_wl.ssc.layout] = {"ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank], "headline": True}
+                continue
+            wl = Workload(ctx, main_wl.name, k, n_db, query_groups=qg)
+            wl.add_descriptors(fill)
+            wl.set_queries(q_descs, n_elig)
+            dtl, prl, _, _ = wl.timed(st_l, 1)
+            same = bool(np.array_equal(wl.results(), res))
+            if not same:
+                failures.append(f"layout {wl.ssc.layout} disagrees with layout {main_wl.ssc.layout}")
+            lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl], "identical_to_headline": same}
+            wl.close()
+        if rank == 0:
+            out["layouts"] = lay
+            out["layouts_key"] = "query groups x DB shards; identical results in every layout"
+
     # ---- data dependence: the random DB and the exact-all floor, same batch shape --------------
     if not ctx.stub and not args.only_main:
         dd = {}
         if args.data == "trajectory":
             descs, rq, r_src, r_rot = random_db_and_queries(n_db, nq)
-            wl = Workload(ctx, "random", k, n_db)
+            wl = Workload(ctx, "random", k, n_db, query_groups=qgroups)
             wl.add_descriptors(descs)
             wl.set_queries(rq, n_elig)
             dtr, _, _, (ev, cd) = wl.timed(max(3, args.steps // 2), 2, profile=True)
@@ -822,18 +934,50 @@ def main():
                                "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n_db}_random (round-1 headline data)"}
             wl.close()
             del descs, rq
+        # the continuous-z family of SURVEY 8d "value distributions": the same drive with every landmark at its own height
+        # (z ~ U(-1, 4): non-binary descriptors, no exact ties), DB and queries through the build path, oracle-checked
+        if args.data == "trajectory":
+            c_pts, c_off, cq_pts, cq_off, _ = synth.trajectory_keyframes(1234, n_db, 4321, nq, binary_z=False)
+            cb = scancontext.SCManager(device=ctx.local_rank, capacity_hint=n_db + nq + 8)
+            for i in range(n_db):
+                cb.makeAndSaveScancontextAndKeys(c_pts[c_off[i]:c_off[i + 1]])
+            for i in range(nq):
+                cb.makeAndSaveScancontextAndKeys(cq_pts[cq_off[i]:cq_off[i + 1]])
+            c_all = cb.export_descriptors_f32(0, n_db + nq)
+            cb.close()
+            wl = Workload(ctx, "trajectory_continuous_z", k, n_db, query_groups=qgroups)
+            wl.add_descriptors(c_all[:n_db])
+            wl.set_queries(np.ascontiguousarray(c_all[n_db:]), n_elig)
+            st_c = max(3, args.steps // 2)
+            dtc, _, _, (evc, cdc) = wl.timed(st_c, 2, profile=True)
+            rc = wl.results()
+            dd["trajectory_continuous_z"] = {"queries_per_sec": nq * st_c / dtc, "ms_per_step": dtc / st_c * 1e3,
+                                             "exact_evals_per_query": evc / (nq * st_c), "previewed_candidates_per_query": cdc / (nq * st_c),
+                                             "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n_db}_trajectory_z_uniform(-1,4)"}
+            if rank == 0 and not args.no_cpu_baseline:
+                from oracle import pyoracle as po
+                om = po.Manager()
+                for i in range(n_db):
+                    om.add_points(c_pts[c_off[i]:c_off[i + 1]])
+                n_chk = 128
+                want = om.exhaustive_batch(c_all[n_db:n_db + n_chk].astype(np.float64), n_eligible=n_elig, k=k, nthreads=os.cpu_count() or 1)
+                ident = int(sum(bool(np.array_equal(rc[i], want[i])) for i in range(n_chk)))
+                dd["trajectory_continuous_z"]["oracle_checked_queries"] = n_chk
+                dd["trajectory_continuous_z"]["oracle_identical_queries"] = ident
+                if ident != n_chk:
+                    failures.append("continuous-z trajectory: GPU top-k differs from the oracle")
+            wl.close()
+            del c_pts, cq_pts, c_all
         # exact-all: filter off, every (query, entry) pair through the fp64 pair kernel
-        wl = Workload(ctx, "exact_all", k, n_db, filter_mode=1)
-        if db_pts is not None:
-            wl.add_clouds(db_pts, db_off)
-        else:
-            wl.add_descriptors(random_db_and_queries(n_db, 1)[0])
+        wl = Workload(ctx, "exact_all", k, n_db, filter_mode=1, query_groups=qgroups)
+        wl.add_descriptors(db_descs)
         wl.set_queries(q_descs, n_elig)
         dte, _, _, _ = wl.timed(3, 1)
         same = bool(np.array_equal(wl.results(), res))
         if not same:
             failures.append("filtered path and exact-all path disagree")
-        dd["exact_all_floor"] = {"queries_per_sec": nq * 3 / dte, "ms_per_step": dte / 3 * 1e3, "exact_evals_per_query": float(len(range(rank, n_elig, world))),
+        dd["exact_all_floor"] = {"queries_per_sec": nq * 3 / dte, "ms_per_step": dte / 3 * 1e3,
+                                 "exact_evals_per_query": float(len(range(wl.ssc.shard_rank, n_elig, wl.ssc.shard_world))),
                                  "identical_to_filtered_path": same,
                                  "note": "filter_mode = 1: every eligible pair scored by the exact fp64 kernel -- what the path "
                                          "costs when the data lets the filter prune nothing"}
@@ -841,7 +985,7 @@ def main():
         # 100k-keyframe DB: where DB shards pay
         n100 = 100000
         d100, q100, s100, r100 = random_db_and_queries(n100, nq, seed_db=2234, seed_q=5321)
-        wl = Workload(ctx, "random100k", k, n100)
+        wl = Workload(ctx, "random100k", k, n100, query_groups=qgroups)
         wl.add_descriptors(d100)
         del d100
         wl.set_queries(q100, n100 - 30)
@@ -857,11 +1001,17 @@ def main():
             out["data_dependence"] = dd
             out["scale_100k"] = {"value": nq * st100 / dt100, "unit": "queries/s", "ms_per_step": dt100 / st100 * 1e3, "steps": st100,
                                  "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n100}_random", "n_gpus": world, "scaling": "strong",
+                                 "layout": f"{qgroups}x{world // qgroups}",
                                  "per_rank_ms_per_step": [t / st100 * 1e3 for t in pr100],
                                  "exact_evals_per_query": ev100 / (nq * st100), "previewed_candidates_per_query": cd100 / (nq * st100),
                                  "planted_loops_recovered": p100}
 
     if rank == 0 and not ctx.stub:
+        if not args.only_main and world == 1:
+            out["host_entry"] = host_entry_leg(main_wl.mgr, q_descs, n_elig, k)
+            if not np.array_equal(main_wl.mgr.query(q_descs[:64], k=k, n_eligible=n_elig), res[:64]):
+                failures.append("host-buffer entry disagrees with the device entry")
+            out["layout_emulation"] = layout_emulation_leg(ctx.local_rank, db_descs, q_descs, n_elig, k)
         if not args.only_main:
             # BASELINE configs[1]: 1 query vs 1k-keyframe DB (latency of the synchronous host call)
             small = scancontext.SCManager(device=ctx.local_rank)

@@ -1,21 +1,28 @@
 """ScanContext database sharded over the ranks of a torch.distributed process group.
 
-Keyframe i lives on rank i % world (block-cyclic, so a growing DB stays balanced).  A query runs
-on every rank against its shard (HIP kernels through librsx.so) in two stages with one all-gather
-each -- RCCL over xGMI when the group's backend is "nccl":
-  stage 1  MFMA filter over the shard + exact scores of the shard's share of the lowest-bound
-           entries; all-gather of the per-rank top-k lists (16-byte rsx_sc_hit records), merge:
-           the k-th distance of the merged list is a GLOBAL upper bound tau of the final k-th best;
-  stage 2  every shard scores only what its filter bounds still admit under tau (instead of under
-           its own, much looser, local k-th best); all-gather + merge of the final per-rank lists.
-The merge is under the total order (dist, global index), which reproduces the sequential
-lowest-index-wins scan of the reference exactly.  Messages are tiny (nq * k * 16 B per rank): the
-exchanges are latency-bound, so queries are batched.
+Layout.  `world` ranks = `query_groups` (Q) x `shard_world` (S).  Rank r belongs to query group r // S and holds DB
+shard r % S: keyframe i lives on the ranks with shard index i % S (block-cyclic, so a growing DB stays balanced), once
+per query group.  A batch of nq queries is cut into Q contiguous slices, one per query group; inside a group the
+slice runs against the group's S shards in two stages with one all-gather each -- RCCL over xGMI when the backend is
+"nccl":
+  stage 1  MFMA filter over the shard + exact scores of the shard's share of the lowest-bound entries; all-gather of
+           the per-rank top-k lists (16-byte rsx_sc_hit records), merge: the k-th distance of the merged list is a
+           GLOBAL upper bound tau of the final k-th best;
+  stage 2  every shard scores only what its filter bounds still admit under tau (instead of under its own, much
+           looser, local k-th best); all-gather + merge of the final per-rank lists;
+and the Q slices are put together by one more all-gather over the ranks with the same shard index.  Q = 1 is the pure
+DB-shard layout of rounds 1-2; S = 1 is pure query parallelism (the DB replicated, no exchange but the final one).
+Why 2-D: per-rank work is  a * nq / Q  (per-query costs: query images, short-list selection, one re-scoring workgroup
+per query)  +  b * nq * N / (Q * S)  (per-pair costs: the filter); the second term only depends on Q * S = world, the
+first shrinks with Q alone -- with S = world a 10 k-keyframe DB scales ~4x on 8 GPUs, with Q > 1 the per-query part
+scales too.  `auto_layout` picks Q from the batch size (a group needs enough queries to fill its GPU).
+The merge is under the total order (dist, global index), which reproduces the sequential lowest-index-wins scan of the
+reference exactly.  Messages are tiny (nq * k * 16 B per rank): the exchanges are latency-bound, so queries are batched.
 
-`local_backend` is a seam for the CPU (gloo) tests, which have no GPU: anything with
-add_descriptors_f32(descs), query_stage1(q, k, n_eligible[, q_elig]) and query_stage2(global_topk), both
--> (nq, k) HIT_DTYPE records.  The default is the GPU SCManager; there is no CPU fallback in the
-product path.
+`local_backend` is a seam for the CPU (gloo) tests, which have no GPU: an object -- or a callable (shard_rank,
+shard_world) -> object -- with add_descriptors_f32(descs), query_stage1(q, k, n_eligible[, q_elig]) and
+query_stage2(global_topk), both -> (nq, k) HIT_DTYPE records.  The default is the GPU SCManager; there is no CPU
+fallback in the product path.
 """
 import numpy as np
 
@@ -23,27 +30,62 @@ from . import scancontext
 from ._rsx import HIT_DTYPE
 
 
+def auto_layout(world, nq, min_queries_per_group=512):
+    """-> query_groups Q (a divisor of world): as many query groups as the batch can feed with >= min_queries_per_group
+    queries each (below that a GPU's 256 CUs are no longer filled by its slice and DB shards are the better use of the
+    ranks: a single query, Q = 1, is the pure DB-shard layout).  The DB is tiny next to 288 GB of HBM (0.83 GB per
+    100 000 keyframes), so replication per query group is never a capacity question."""
+    q = 1
+    for cand in range(1, world + 1):
+        if world % cand == 0 and nq >= cand * min_queries_per_group:
+            q = cand
+    return q
+
+
 class ShardedScanContext:
-    def __init__(self, group=None, device=None, local_backend=None, capacity_hint=1024, filter_mode=0):
+    def __init__(self, group=None, device=None, local_backend=None, capacity_hint=1024, filter_mode=0, query_groups=1):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        q = int(query_groups)
+        if q < 1 or self.world % q:
+            raise ValueError(f"query_groups {q} does not divide the world size {self.world}")
+        self.n_qgroups, self.shard_world = q, self.world // q
+        self.qgroup, self.shard_rank = self.rank // self.shard_world, self.rank % self.shard_world
+        self.shard_group, self.col_group = group, None
+        if q > 1:
+            # torch.distributed: every rank creates every subgroup, in the same order
+            ranks = list(range(self.world)) if group is None else dist.get_process_group_ranks(group)
+            s_w = self.shard_world
+            for g in range(q):
+                grp = dist.new_group(ranks=[ranks[g * s_w + s] for s in range(s_w)]) if s_w > 1 else None
+                if g == self.qgroup:
+                    self.shard_group = grp
+            for s in range(s_w):
+                grp = dist.new_group(ranks=[ranks[g * s_w + s] for g in range(q)])
+                if s == self.shard_rank:
+                    self.col_group = grp
         self.on_gpu = local_backend is None
         if self.on_gpu:
             dev = torch.cuda.current_device() if device is None else device
-            self.backend = scancontext.SCManager(device=dev, shard_rank=self.rank, shard_world=self.world,
+            self.backend = scancontext.SCManager(device=dev, shard_rank=self.shard_rank, shard_world=self.shard_world,
                                                  capacity_hint=capacity_hint, filter_mode=filter_mode)
             self.device = torch.device("cuda", dev)
         else:
-            self.backend = local_backend
+            self.backend = local_backend(self.shard_rank, self.shard_world) if callable(local_backend) else local_backend
             self.device = torch.device("cpu")
         self._bufs = {}
 
+    @property
+    def layout(self):
+        return f"{self.n_qgroups}x{self.shard_world}"
+
     def owner(self, index):
-        return index % self.world
+        """shard index of keyframe `index` (the ranks qgroup * shard_world + owner hold it)"""
+        return index % self.shard_world
 
     def add_descriptors_f32(self, descs):
         """Every rank passes every new keyframe (same order); each keeps its own residue class."""
@@ -59,18 +101,50 @@ class ShardedScanContext:
             self._bufs[name] = t
         return t
 
+    def _slice(self, nq):
+        """this query group's slice [lo, hi) of a batch of nq queries, and the (padded) slice length"""
+        chunk = -(-nq // self.n_qgroups)
+        lo = min(nq, self.qgroup * chunk)
+        return lo, min(nq, lo + chunk), chunk
+
     def _gather_merge(self, local, name, nq, k, stream):
-        parts = self._buf(name + "_parts", (self.world, nq, k, 2))
-        self._dist.all_gather_into_tensor(parts.view(-1), local.view(-1), group=self.group)
+        parts = self._buf(name + "_parts", (self.shard_world, nq, k, 2))
+        self._dist.all_gather_into_tensor(parts.view(-1), local.view(-1), group=self.shard_group)
         out = self._buf(name + "_merged", (nq, k, 2))
-        self.backend.merge_device(parts.data_ptr(), self.world, nq, k, out.data_ptr(), stream=stream)
+        self.backend.merge_device(parts.data_ptr(), self.shard_world, nq, k, out.data_ptr(), stream=stream)
         return out
 
+    def _query_slice_device(self, q_ptr, nq, k, n_eligible, stream, q_elig_ptr, elig_monotone):
+        """nq queries of this group against the group's shards -> device tensor (>= nq, k, 2); nq may be 0 (a group
+        without queries still takes part in the exchanges of its shard group)."""
+        pad = max(nq, 1)
+        local = self._buf("local", (pad, k, 2))
+        if self.shard_world == 1:
+            if nq == 0:
+                return local
+            if not q_elig_ptr:
+                self.backend.query_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream)
+                return local
+            final = self._buf("final", (pad, k, 2))
+            self.backend.query_stage1_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream,
+                                             q_elig_ptr=q_elig_ptr, elig_monotone=elig_monotone)
+            self.backend.query_stage2_device(nq, k, local.data_ptr(), final.data_ptr(), stream=stream)
+            return final
+        # q_elig_ptr: device int64[nq], query i only sees global indices < q_elig[i] (kept alive by the caller)
+        if nq:
+            self.backend.query_stage1_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream,
+                                             q_elig_ptr=q_elig_ptr, elig_monotone=elig_monotone)
+        bound = self._gather_merge(local, "s1", pad, k, stream)
+        final = self._buf("final", (pad, k, 2))
+        if nq:
+            self.backend.query_stage2_device(nq, k, bound.data_ptr(), final.data_ptr(), stream=stream)
+        return self._gather_merge(final, "s2", pad, k, stream)
+
     def query_device(self, q_ptr, nq, k, n_eligible=-1, stream=0, q_elig_ptr=0, elig_monotone=False):
-        """GPU path: device query pointer in, device tensor (nq, k, 2) f64 = rsx_sc_hit records out.
-        `stream` must be the (non-default) torch stream current on this device: the library launches on
-        it and the collectives run on it too.  stream=0 would make librsx use the handle's private
-        stream, unordered with torch's -- then everything runs on an own side stream instead."""
+        """GPU path: device query pointer in, device tensor (nq, k, 2) f64 = rsx_sc_hit records out (the whole batch,
+        identical on every rank).  `stream` must be the (non-default) torch stream current on this device: the library
+        launches on it and the collectives run on it too.  stream=0 would make librsx use the handle's private stream,
+        unordered with torch's -- then everything runs on an own side stream instead."""
         if stream == 0:
             torch = self._torch
             if getattr(self, "_side", None) is None:
@@ -81,28 +155,40 @@ class ShardedScanContext:
                                         elig_monotone=elig_monotone)
             torch.cuda.current_stream(self.device).wait_stream(self._side)
             return out
-        local = self._buf("local", (nq, k, 2))
-        if self.world == 1 and not q_elig_ptr:
-            self.backend.query_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream)
-            return local
-        # q_elig_ptr: device int64[nq], query i only sees global indices < q_elig[i] (kept alive by the caller)
-        self.backend.query_stage1_device(q_ptr, nq, k, local.data_ptr(), n_eligible=n_eligible, stream=stream,
-                                         q_elig_ptr=q_elig_ptr, elig_monotone=elig_monotone)
-        if self.world == 1:
-            final = self._buf("final", (nq, k, 2))
-            self.backend.query_stage2_device(nq, k, local.data_ptr(), final.data_ptr(), stream=stream)
-            return final
-        bound = self._gather_merge(local, "s1", nq, k, stream)
-        final = self._buf("final", (nq, k, 2))
-        self.backend.query_stage2_device(nq, k, bound.data_ptr(), final.data_ptr(), stream=stream)
-        return self._gather_merge(final, "s2", nq, k, stream)
+        if self.n_qgroups == 1:
+            return self._query_slice_device(q_ptr, nq, k, n_eligible, stream, q_elig_ptr, elig_monotone)[:nq]
+        lo, hi, chunk = self._slice(nq)
+        mine = self._buf("slice", (chunk, k, 2))
+        res = self._query_slice_device(q_ptr + lo * 4800, hi - lo, k, n_eligible, stream, q_elig_ptr + lo * 8 if q_elig_ptr else 0,
+                                       elig_monotone)
+        if hi > lo:
+            mine[:hi - lo].copy_(res[:hi - lo])
+        whole = self._buf("whole", (self.n_qgroups * chunk, k, 2))
+        self._dist.all_gather_into_tensor(whole.view(-1), mine.view(-1), group=self.col_group)
+        return whole[:nq]
 
     def _gather_merge_host(self, local, nq, k):
         torch = self._torch
         lt = torch.from_numpy(np.ascontiguousarray(local, dtype=HIT_DTYPE).view(np.float64).reshape(-1).copy())
-        parts = torch.zeros(self.world * lt.numel(), dtype=torch.float64)
-        self._dist.all_gather_into_tensor(parts, lt, group=self.group)
-        return scancontext.merge_topk(parts.numpy().view(HIT_DTYPE).reshape(self.world, nq, k))
+        parts = torch.zeros(self.shard_world * lt.numel(), dtype=torch.float64)
+        self._dist.all_gather_into_tensor(parts, lt, group=self.shard_group)
+        return scancontext.merge_topk(parts.numpy().view(HIT_DTYPE).reshape(self.shard_world, nq, k))
+
+    def _query_slice_host(self, q, k, n_eligible, q_elig):
+        """local_backend path for this group's slice (possibly empty: the collectives still run)"""
+        nq = q.shape[0]
+        pad = max(nq, 1)
+        empty = np.zeros((pad, k), dtype=HIT_DTYPE)
+        if nq:
+            part = self.backend.query_stage1(q, k, n_eligible, q_elig) if q_elig is not None else self.backend.query_stage1(q, k, n_eligible)
+            part = np.ascontiguousarray(part, dtype=HIT_DTYPE)
+        else:
+            part = empty
+        if self.shard_world == 1:
+            return np.ascontiguousarray(self.backend.query_stage2(part), dtype=HIT_DTYPE) if nq else empty[:0]
+        bound = self._gather_merge_host(part, pad, k)
+        final = np.ascontiguousarray(self.backend.query_stage2(bound), dtype=HIT_DTYPE) if nq else empty
+        return self._gather_merge_host(final, pad, k)[:nq]
 
     def query(self, q_descs, k=1, n_eligible=-1, q_elig=None):
         """Host-array convenience form -> (nq, k) HIT_DTYPE, identical on every rank.
@@ -121,12 +207,12 @@ class ShardedScanContext:
                                     elig_monotone=mono)
             torch.cuda.synchronize()
             return out.cpu().numpy().view(HIT_DTYPE).reshape(nq, k)
-        if q_elig is not None:
-            part = np.ascontiguousarray(self.backend.query_stage1(q, k, n_eligible, q_elig), dtype=HIT_DTYPE)
-        else:
-            part = np.ascontiguousarray(self.backend.query_stage1(q, k, n_eligible), dtype=HIT_DTYPE)
-        if self.world == 1:
-            return np.ascontiguousarray(self.backend.query_stage2(part), dtype=HIT_DTYPE)
-        bound = self._gather_merge_host(part, nq, k)
-        final = self.backend.query_stage2(bound)
-        return self._gather_merge_host(final, nq, k)
+        if self.n_qgroups == 1:
+            return self._query_slice_host(q, k, n_eligible, q_elig)
+        lo, hi, chunk = self._slice(nq)
+        mine = np.zeros((chunk, k), dtype=HIT_DTYPE)
+        mine[:hi - lo] = self._query_slice_host(q[lo:hi], k, n_eligible, q_elig[lo:hi] if q_elig is not None else None)
+        lt = torch.from_numpy(mine.view(np.float64).reshape(-1).copy())
+        whole = torch.zeros(self.n_qgroups * lt.numel(), dtype=torch.float64)
+        self._dist.all_gather_into_tensor(whole, lt, group=self.col_group)
+        return whole.numpy().view(HIT_DTYPE).reshape(self.n_qgroups * chunk, k)[:nq].copy()

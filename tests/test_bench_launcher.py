@@ -40,7 +40,26 @@ def test_bench_spawns_its_own_ranks(gpus):
     assert out["ms_per_step"] == pytest.approx(max(out["per_rank_ms_per_step"]))   # MAX over ranks
     assert out["value"] == pytest.approx(4 / (out["ms_per_step"] * 1e-3), rel=1e-6)
     if gpus > 1:
-        assert out["backend"] == "gloo" and out["config"]["parallelism"] == "db_shard2"
+        # 4 queries do not feed two query groups: the automatic layout is the pure DB-shard one; every other layout of
+        # the world is timed too and must return the same records
+        assert out["backend"] == "gloo" and out["config"]["parallelism"] == "query_groups1_x_db_shards2" and out["config"]["layout"] == "1x2"
+        assert set(out["layouts"]) == {"1x2", "2x1"} and out["layouts"]["1x2"]["headline"] is True
+        assert out["layouts"]["2x1"]["identical_to_headline"] is True and len(out["layouts"]["2x1"]["per_rank_ms_per_step"]) == 2
+
+
+def test_bench_query_groups_flag():
+    """--query-groups 2 at world 2: pure query parallelism (DB replicated), same planted loops recovered."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["RSX_BENCH_LOCAL_BACKEND"] = "tests.bench_stub:make"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--db", "150", "--queries", "4",
+           "--topk", "3", "--no-cpu-baseline", "--query-groups", "2", "--only-main"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["layout"] == "2x1" and out["planted_loops_recovered"] is True and out["failures"] == [] and "layouts" not in out
 
 
 def test_bench_refuses_a_world_that_does_not_match():

@@ -62,7 +62,7 @@ class OracleShard:
         return self._search(self._q, self._k, self._ne, tau=kth, q_elig=self._qe)
 
 
-def _worker(rank, world, port, ret):
+def _worker(rank, world, port, ret, query_groups=1):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -74,10 +74,11 @@ def _worker(rank, world, port, ret):
         descs = synth.random_descriptors(1234, n, binary=True)
         queries = np.stack([synth.rotate_descriptor(descs[17 * i + 3], 5 * i) for i in range(nq)])
         queries[-1][:] = 0                                     # a query with no effective column
-        sc = sharded.ShardedScanContext(local_backend=OracleShard(po, rank, world))
+        sc = sharded.ShardedScanContext(local_backend=lambda sr, sw: OracleShard(po, sr, sw), query_groups=query_groups)
+        assert (sc.n_qgroups, sc.shard_world) == (query_groups, world // query_groups) and sc.layout == f"{query_groups}x{world // query_groups}"
         sc.add_descriptors_f32(descs[:200])
         sc.add_descriptors_f32(descs[200:])                    # growing DB keeps the residue classes
-        assert sc.backend.n_global == n and len(sc.backend.m) == len(range(rank, n, world))
+        assert sc.backend.n_global == n and len(sc.backend.m) == len(range(sc.shard_rank, n, sc.shard_world))
         full = po.Manager()
         full.add_descriptors(descs.astype(np.float64))
         for n_elig in (-1, n - 30, 7, 1, 0):
@@ -118,3 +119,28 @@ def test_sharded_query_gloo(world):
         p.join(timeout=300)
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+@pytest.mark.parametrize("world,query_groups", [(4, 2), (4, 4), (2, 2)])
+def test_two_dimensional_layout_gloo(world, query_groups):
+    """query groups x DB shards (4 = 2 x 2, and the pure query-parallel layouts): the batch is cut into slices, each slice
+    runs the two-stage protocol inside its group's shards, the slices are put together by an all-gather over the ranks
+    with the same shard index; 6 queries over 4 groups leaves a group with an EMPTY slice (it still takes part in the
+    collectives).  Results identical to the unsharded oracle on every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, ret, query_groups)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {r: "ok" for r in range(world)}
+
+
+def test_auto_layout():
+    from navtech_radar_slam_amd.sharded import auto_layout
+    assert auto_layout(8, 8192) == 8 and auto_layout(8, 2048) == 4 and auto_layout(8, 1) == 1 and auto_layout(1, 8192) == 1
+    assert auto_layout(4, 1500) == 2 and auto_layout(6, 8192) == 6
