@@ -249,8 +249,22 @@ int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float
  * (several shards on one GPU: used by the tests on one-GPU boxes).  Internally synchronised. */
 typedef struct rsx_scs rsx_scs;
 int rsx_scs_create(const rsx_sc_params *p, const int32_t *devices, int32_t n_devices, rsx_scs **out);
+/* The general form.  Layout: n_devices = query_groups x DB shards; device g belongs to query group g / S and holds DB
+ * shard g % S (S = n_devices / query_groups; keyframe i on the shards i % S, once per group).  A batch is cut into
+ * query_groups contiguous slices, each answered by its group: per-query costs shrink with the number of groups, per-pair
+ * costs with the number of devices (rsx_scs_create = 1 group: every device a shard of ONE database copy).
+ * exchange_kind: how the shards of a group exchange their 16-byte records in the two-stage query --
+ *   RSX_SCS_EXCHANGE_PEER_COPY  hipMemcpyPeerAsync to the group's first device and back (default; no extra library)
+ *   RSX_SCS_EXCHANGE_RCCL       ncclAllGather over the group's communicators, every shard merges for itself; librccl.so is
+ *                               loaded on first use (dlopen); devices inside a group must be distinct
+ * Results are identical in every layout and with either exchange. */
+#define RSX_SCS_EXCHANGE_PEER_COPY 0
+#define RSX_SCS_EXCHANGE_RCCL 1
+int rsx_scs_create_layout(const rsx_sc_params *p, const int32_t *devices, int32_t n_devices, int32_t query_groups, int32_t exchange_kind,
+                          rsx_scs **out);
+int rsx_scs_num_query_groups(rsx_scs *h);
 int rsx_scs_destroy(rsx_scs *h);
-int rsx_scs_num_shards(rsx_scs *h);
+int rsx_scs_num_shards(rsx_scs *h); /* DB shards per query group */
 int rsx_scs_set_dist_thres(rsx_scs *h, double thres);
 int rsx_scs_size(rsx_scs *h, int64_t *n_global);
 int rsx_scs_add_points(rsx_scs *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index);

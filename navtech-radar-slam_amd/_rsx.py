@@ -107,7 +107,7 @@ SYMBOLS = [
     "rsx_sc_pair_distances", "rsx_sc_filter_bounds", "rsx_sc_filter_eps", "rsx_sc_profiled_kernel_name",
     "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
     "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read", "rsx_sc_profile_read_rescoring", "rsx_sc_profile_read_rescoring2",
-    "rsx_scs_create", "rsx_scs_destroy", "rsx_scs_num_shards", "rsx_scs_set_dist_thres", "rsx_scs_size",
+    "rsx_scs_create", "rsx_scs_create_layout", "rsx_scs_num_query_groups", "rsx_scs_destroy", "rsx_scs_num_shards", "rsx_scs_set_dist_thres", "rsx_scs_size",
     "rsx_scs_add_points", "rsx_scs_add_descriptors_f32", "rsx_scs_get_descriptor", "rsx_scs_query",
     "rsx_scs_detect_loop_closure",
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
@@ -189,6 +189,8 @@ def lib():
         L.rsx_sc_profile_read_rescoring2.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
         L.rsx_scs_create.argtypes = [C.POINTER(ScParams), C.POINTER(i32), i32, C.POINTER(vp)]
+        L.rsx_scs_create_layout.argtypes = [C.POINTER(ScParams), C.POINTER(i32), i32, i32, i32, C.POINTER(vp)]
+        L.rsx_scs_num_query_groups.argtypes = [vp]
         L.rsx_scs_destroy.argtypes = [vp]
         L.rsx_scs_num_shards.argtypes = [vp]
         L.rsx_scs_set_dist_thres.argtypes = [vp, dbl]

@@ -344,12 +344,18 @@ class SCManager {
   }
   // shard the database over several GPUs of this node (keyframe i on devices[i % n]); the detector then scores the
   // whole searchable prefix (exhaustive mode) on all of them.  Before first use.
-  void setDevices(const std::vector<int> &devices) {
+  // query_groups: devices.size() = query_groups x DB shards (rsx_scs_create_layout): 1 = every device a shard of one
+  // database copy (the detector's single query is then scored by all devices at once); more groups only pay for
+  // batched queries (query()).  rccl_exchange: ncclAllGather instead of peer copies between the shards of a group.
+  void setDevices(const std::vector<int> &devices, int query_groups = 1, bool rccl_exchange = false) {
     std::lock_guard<std::mutex> lk(mu_);
     if (h_ || hs_) throw std::runtime_error("setDevices after the GPU handle was created");
     if (devices.empty()) throw std::runtime_error("setDevices: empty list");
+    if (query_groups < 1 || devices.size() % (std::size_t)query_groups) throw std::runtime_error("setDevices: query_groups must divide the device count");
     devices_.assign(devices.begin(), devices.end());
     device_ = devices[0];
+    query_groups_ = query_groups;
+    rccl_exchange_ = rccl_exchange;
   }
   bool sharded() const { return devices_.size() > 1; }
   int64_t size() {
@@ -410,7 +416,9 @@ class SCManager {
       rsx_sc_default_params(&p);
       p.dist_thres = SC_DIST_THRES;
       std::vector<int32_t> dev(devices_.begin(), devices_.end());
-      check(rsx_scs_create(&p, dev.data(), (int32_t)dev.size(), &hs_), "SCManager (rsx_scs_create)");
+      check(rsx_scs_create_layout(&p, dev.data(), (int32_t)dev.size(), query_groups_, rccl_exchange_ ? RSX_SCS_EXCHANGE_RCCL : RSX_SCS_EXCHANGE_PEER_COPY,
+                                  &hs_),
+            "SCManager (rsx_scs_create_layout)");
     }
     return hs_;
   }
@@ -458,6 +466,8 @@ class SCManager {
   int mode_ = RSX_SC_MODE_CANDIDATE;
   int device_ = 0;
   std::vector<int> devices_;
+  int query_groups_ = 1;
+  bool rccl_exchange_ = false;
   bool verbose_ = true, strict_import_ = false;
   double last_min_dist_ = 0.0, last_import_rounding_ = 0.0;
   int last_nn_idx_ = 0;

@@ -301,10 +301,11 @@ class SCManager:
 
 
 class ShardedSet:
-    """rsx_scs_*: ONE process, the database sharded over several GPUs (keyframe i on devices[i % n]); the exchanges
-    of the two-stage query are peer copies.  What a single C++ host (alaserPGO) uses instead of torch.distributed."""
+    """rsx_scs_*: ONE process, the database over several GPUs: len(devices) = query_groups x DB shards (keyframe i on the
+    shards i % S of every group); the exchanges of the two-stage query are peer copies or, with exchange="rccl",
+    ncclAllGather.  What a single C++ host (alaserPGO) uses instead of torch.distributed."""
 
-    def __init__(self, devices, sc_dist_thres=0.2, capacity_hint=1024):
+    def __init__(self, devices, sc_dist_thres=0.2, capacity_hint=1024, query_groups=1, exchange="peer"):
         L = lib()
         p = _rsx.ScParams()
         check(L.rsx_sc_default_params(C.byref(p)))
@@ -313,7 +314,7 @@ class ShardedSet:
         dev = (C.c_int32 * len(devices))(*devices)
         self._h = C.c_void_p()
         self._L = L
-        check(L.rsx_scs_create(C.byref(p), dev, len(devices), C.byref(self._h)))
+        check(L.rsx_scs_create_layout(C.byref(p), dev, len(devices), query_groups, {"peer": 0, "rccl": 1}[exchange], C.byref(self._h)))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
@@ -329,6 +330,10 @@ class ShardedSet:
     @property
     def num_shards(self):
         return self._L.rsx_scs_num_shards(self._h)
+
+    @property
+    def num_query_groups(self):
+        return self._L.rsx_scs_num_query_groups(self._h)
 
     def __len__(self):
         n = C.c_int64()

@@ -158,4 +158,35 @@ def test_single_process_multi_device_handle(sc, oracle, shards):
         assert np.array_equal(got[i], o.exhaustive(q[i].astype(np.float64), n_eligible=2570, k=5))
     assert np.array_equal(hs.descriptor(1234), descs[1234].astype(np.float64))
     hs.close()
+    # the same devices as query groups x DB shards: 2 x (shards / 2 ...) -- every layout returns the same records
+    for qg in [g for g in (shards, 1) if shards % g == 0] + ([2] if shards % 2 == 0 and shards > 2 else []):
+        h2 = sc.ShardedSet([0] * shards, query_groups=qg)
+        h2.add_descriptors_f32(descs)
+        assert (h2.num_query_groups, h2.num_shards) == (qg, shards // qg)
+        for k, ne in ((10, 2570), (1, -1)):
+            assert np.array_equal(h2.query(q, k=k, n_eligible=ne), one.query(q, k=k, n_eligible=ne)), (qg, k, ne)
+        assert np.array_equal(h2.query(q[:1], k=4, n_eligible=2570), one.query(q[:1], k=4, n_eligible=2570))   # groups with empty slices
+        h2.close()
+    one.close()
+
+
+def test_rccl_exchange_world_one(sc):
+    """exchange = RCCL (rsx_scs_create_layout, RSX_SCS_EXCHANGE_RCCL): librccl is loaded with dlopen, one communicator per
+    device (ncclCommInitAll), the two stages exchange their records with ncclAllGather inside ncclGroupStart / End and
+    every shard merges for itself.  This box has one GPU: a group of ONE shard still runs both collectives (a 1-rank
+    all-gather), which exercises the binding, the communicator and the stream ordering; a device listed twice in a
+    group is refused (RCCL needs distinct devices).  The multi-GPU form is the same code with S > 1."""
+    from navtech_radar_slam_amd._rsx import RsxError
+    descs = synth.random_descriptors(15, 1500, binary=True)
+    rng = np.random.default_rng(16)
+    q = np.stack([synth.rotate_descriptor(descs[i], int(rng.integers(0, 60))) for i in rng.integers(0, 1400, 24)])
+    one = sc.SCManager()
+    one.add_descriptors_f32(descs)
+    hr = sc.ShardedSet([0], exchange="rccl")
+    hr.add_descriptors_f32(descs)
+    for k, ne in ((10, 1470), (1, -1), (32, 40)):
+        assert np.array_equal(hr.query(q, k=k, n_eligible=ne), one.query(q, k=k, n_eligible=ne)), (k, ne)
+    hr.close()
+    with pytest.raises(RsxError, match="distinct devices"):
+        sc.ShardedSet([0, 0], exchange="rccl")
     one.close()
