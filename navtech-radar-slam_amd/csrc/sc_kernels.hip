@@ -982,6 +982,69 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// sc_pair2_kernel: the exact path in TOP-K form (no out_dist: the filter is off or the problem is small), one entry per
+// wavefront and iteration, in the two phases of the re-scoring kernel: phase A = fp32 fast alignment (exact fp64 fallback
+// when more than one shift survives its error band) + fp32 preview of the 7 window distances; phase B = the exact fp64
+// window evaluation, only when the preview cannot exclude the entry from THIS wave's top-k (an entry that cannot enter the
+// top-k of the wave that scores it cannot enter the merged one).  Every record returned is produced by phase B, i.e. by the
+// same arithmetic as pair_group: results are byte-identical to sc_pair_kernel (tests/test_gpu_sc.py, test_gpu_sc_filter.py
+// compare the two paths).  Per entry ~250 fp32 instructions instead of ~450 fp64 ones.
+// LDS: [query fp64 image, norms, key | 4 x per-wave region | fp32 preview image of the query]
+// ------------------------------------------------------------------------------------------
+constexpr int PAIR2_OFF_QP32 = OFF_WAVES + 4 * ENT_SIZE;
+constexpr int PAIR2_LDS = PAIR2_OFF_QP32 + QP_SIZE;
+
+template <int W>
+__global__ __launch_bounds__(256, W) void sc_pair2_kernel(PairArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  char *wsm = smem + OFF_WAVES + wave * ENT_SIZE;
+  const int qi = blockIdx.y;
+  const int slot = blockIdx.x * 4 + wave;
+  const int nwaves = gridDim.x * 4;
+
+  if (threadIdx.x == 0) *reinterpret_cast<int *>(smem + PAIR2_OFF_QP32 + QP_FLAG) = 1;
+  __syncthreads();
+  load_query_to_lds(a.q, qi, smem, threadIdx.x, 256, PAIR2_OFF_QP32);
+  __syncthreads();
+  const float v1f = lane < NS ? reinterpret_cast<const float *>(smem + PAIR2_OFF_QP32 + QP_V1F)[lane] : 0.0f;
+  const float e1 = wave_sum_f32(v1f * v1f);
+
+  int64_t n_elig = a.n_eligible;
+  if (a.q_elig) {
+    const int64_t e = a.q_elig[qi];
+    n_elig = e < n_elig ? e : n_elig;
+  }
+  double ld = INFINITY;  // per-wave sorted top-k, one record per lane
+  int li = 0x7fffffff, ls = 0;
+  const int32_t *gath = a.gather;
+  EntryRegs cur;
+  for (int64_t g = slot; g < a.n_items; g += nwaves) {
+    const int64_t eslot = gath ? (int64_t)gath[g] : (a.first + g);
+    const int64_t gidx = a.db.idx_base + eslot * a.db.idx_stride;
+    if (gidx >= n_elig) continue;  // (wave-uniform) never a hit
+    if (g + nwaves < a.n_items) touch_entry(a.db, gath ? (int64_t)gath[g + nwaves] : (a.first + g + nwaves), lane);
+    load_entry(a.db, eslot, lane, cur);
+    float pv;
+    const int ks = phase_a(smem, wsm, lane, cur, PAIR2_OFF_QP32, e1, pv);
+    const double kth = __shfl(ld, a.k - 1);  // +inf until the wave holds k hits
+    if ((pv == pv) && (double)pv - (double)kPreviewMargin > kth) continue;  // exact >= pv - margin > the wave's k-th best
+    double bd;
+    int bk;
+    phase_b(smem, wsm, lane, cur, ks, bd, bk);
+    if (bd < kBig) topk_insert(ld, li, ls, lane, a.k, bd, (int)gidx, bk);  // SC.cpp:388: must beat the 1e7 init
+  }
+  if (lane < a.k) {
+    rsx_sc_hit h;
+    h.dist = ld;
+    h.index = li;
+    h.shift = ls;
+    a.partial[((int64_t)qi * a.nslots + slot) * a.k + lane] = h;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // merge: per query, k rounds of "smallest record strictly after the previous pick"
 // records are unique in (dist,index) except the padding {inf, INT_MAX} / {1e7,0,0}
 // ------------------------------------------------------------------------------------------
@@ -1595,7 +1658,12 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   PairProfiler *pp = (g_prof && g_prof->on && g_prof->ev && g_prof->used < PairProfiler::kMax) ? g_prof : nullptr;
   if (pp) RSX_HIP(hipEventRecord(pp->ev[2 * pp->used], s));
   const Variant var = pair_variant();
-  if (var.b == 1) RSX_TRY((launch_pairs_t<1, 4>(a, gx, s)));
+  static const bool one_phase = rsx::exp_env("RSX_SC_PAIR_ONE_PHASE") != nullptr;  // experiments: the round-1/2 kernel for top-k too
+  if (a.partial && !out_dist && !one_phase) {
+    static_assert(PAIR2_LDS <= 48 * 1024, "within the default dynamic LDS limit: no per-device opt-in needed");
+    hipLaunchKernelGGL((sc_pair2_kernel<4>), dim3(gx, q.nq), dim3(256), PAIR2_LDS, s, a);
+    RSX_HIP(hipGetLastError());
+  } else if (var.b == 1) RSX_TRY((launch_pairs_t<1, 4>(a, gx, s)));
   else if (var.b == 2 && var.w == 3) RSX_TRY((launch_pairs_t<2, 3>(a, gx, s)));
   else if (var.b == 2) RSX_TRY((launch_pairs_t<2, 4>(a, gx, s)));
   else RSX_TRY((launch_pairs_t<4, 2>(a, gx, s)));
