@@ -16,16 +16,19 @@
 //   a visited candidate p opens a NEW region  <=>  key(p) is the minimum of every run it touches
 //   the budget ends the walk at K* = the max_points-th smallest key among the region openers
 //   p is marked in the end  <=>  MK(p) <= K*  and  MK(p) is a candidate (h > mean_h)
-// so the chain is four image passes over L2-resident bytes and ONE selection, with no intermediate
-// image in HBM at all (h is recomputed from the bytes where it is needed):
+// so the chain is four image passes over L2-resident bytes and ONE selection; the only intermediate in HBM is 2 bytes
+// per pixel (h is recomputed from the bytes where it is needed):
 //   cen_stats    bytes -> sum(bytes), max |fft(r+1) - fft(r-1)|                     (global: mean, max g)
 //   cen_hist     per azimuth: keys, per-run minima (two segmented min-scans), "opens a region" flags
 //                -> 4096-bin histogram of the openers' h, fixed-point sum of h (mean_h)
 //   cen_pick     (one block per image) the bin B* that holds the max_points-th opener
-//   cen_collect  same evaluation, appends the openers of bin B* (a few dozen keys) to a list
+//                -- and records, per pixel, the range bin of its marker (16 bits) and the opener bits,
+//                so that the scans run once per row
+//   cen_collect  h again (cheap) + the recorded opener bits: appends the openers of bin B* (a few dozen keys)
 //   cen_resolve  (one block per image) radix-selects K* among them
-//   cen_extract  per azimuth: marks of rows a-1, a, a+1 from MK < limit, runs / adjacency / arg-max
-//                by one segmented max-scan, ordered compaction
+//   cen_extract  per azimuth: marks of rows a-1, a, a+1 = key of the recorded marker pixel < limit (h of the
+//                row in LDS, one gather per pixel), runs / adjacency / arg-max by one segmented max-scan,
+//                ordered compaction
 //   cen_pack     row-major packing of the rows' keypoints (+ polar -> Cartesian)
 // One workgroup per (azimuth, image): a launch over a batch of B images is B x rows workgroups, every
 // dependency between passes is a kernel boundary, nothing returns to the host.  (A first version
@@ -74,21 +77,49 @@ __device__ __forceinline__ float mean_h_of(long long fix_sum, int64_t n) { retur
 // candidates are the pixels with h > mean_h  <=>  key < kmean
 __device__ __forceinline__ unsigned long long kmean_of(float mh) { return (unsigned long long)(~ord_f32(canon0(mh))) << 32; }
 
-// one block per (azimuth, image): the row is 3.3 KB and stays in L1
-__global__ __launch_bounds__(256) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
-                                                 int off, Scal *scal) {
-  __shared__ unsigned long long s_sum[4];
-  __shared__ float s_max[4];
+// one block per (azimuth, image): byte sum and largest range gradient of the row, 16 bins per thread from aligned dwords
+// (round 3, first build: one byte per lane and iteration, 0.6 TB/s)
+template <int C, int NT>
+__global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
+                                                int off, Scal *scal) {
+  static_assert(C == 16, "a thread's chunk is four dwords");
+  __shared__ float s_tab[256];
+  __shared__ unsigned long long s_sum[NT / 64];
+  __shared__ float s_max[NT / 64];
   const int a = blockIdx.x;
   Scal *sc = scal + blockIdx.y;
   const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
+  if (threadIdx.x < 256) s_tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
+  __syncthreads();
+  const int p0 = threadIdx.x * C;
+  unsigned w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
+  const unsigned mis = (unsigned)(addr & 3u);
+  const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
+  if (p0 < cols) {
+    if (p0 > 0) w[0] = wp[-1];
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+      if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
+  }
+  unsigned bt[C + 2];
+#pragma unroll
+  for (int i = -1; i <= C; i++) {
+    const int jw = (i + 4) >> 2;
+    const unsigned v = __builtin_amdgcn_alignbyte(w[jw + 1 < 6 ? jw + 1 : 5], w[jw], mis);
+    bt[i + 1] = (v >> (8 * ((i + 4) & 3))) & 0xffu;
+  }
   unsigned long long sb = 0;
   float mg = 0.0f;
-  for (int r = threadIdx.x; r < cols; r += 256) {
-    sb += row[r];
-    if (cols > 1) {
-      const int rp = (r + 1 < cols) ? r + 1 : cols - 2, rm = (r >= 1) ? r - 1 : 1;  // reflect 101
-      mg = fmaxf(mg, fabsf(__fsub_rn(__fdiv_rn((float)row[rp], 255.0f), __fdiv_rn((float)row[rm], 255.0f))));
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const int p = p0 + i;
+    if (p < cols) {
+      sb += bt[i + 1];
+      if (cols > 1) {
+        const unsigned bp = (p + 1 < cols) ? bt[i + 2] : bt[i], bm = (p >= 1) ? bt[i] : bt[i + 2];  // reflect 101
+        mg = fmaxf(mg, fabsf(__fsub_rn(s_tab[bp], s_tab[bm])));
+      }
     }
   }
   for (int o = 32; o >= 1; o >>= 1) {
@@ -101,8 +132,14 @@ __global__ __launch_bounds__(256) void cen_stats(const uint8_t *__restrict__ img
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sc->sum_bytes, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
-    atomicMax(&sc->max_g_bits, __float_as_uint(fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]))));  // non-negative floats order like their bits
+    unsigned long long t = 0;
+    float m = 0.0f;
+    for (int wv = 0; wv < NT / 64; wv++) {
+      t += s_sum[wv];
+      m = fmaxf(m, s_max[wv]);
+    }
+    atomicAdd(&sc->sum_bytes, t);
+    atomicMax(&sc->max_g_bits, __float_as_uint(m));  // non-negative floats order like their bits
   }
 }
 
@@ -198,16 +235,15 @@ __device__ __forceinline__ void row_table(RowLds<C, NT> &L) {
   if (threadIdx.x < 256) L.tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
 }
 
-// the caller has filled L.tab; contains block barriers
+// h and the sign of s for the thread's C pixels of one row, straight from the image bytes: the thread's 16 bytes and their
+// two neighbours come from ALIGNED dwords around row + p0 (an aligned dword that holds one byte of the image cannot cross
+// a page, so the few bytes read beside the row are harmless).  Needs L.tab (visible to the block); no barrier inside.
 template <int C, int NT>
-__device__ __forceinline__ void row_eval(RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, unsigned pix_base, float mean, float maxg,
-                                         RowRegs<C, NT> &R) {
-  __syncthreads();  // previous users of L.sw / L.edge_* are done, L.tab is visible
+__device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg,
+                                           float (&h)[C], unsigned &neg) {
   static_assert(C == 16, "a thread's chunk is four dwords");
   const int p0 = threadIdx.x * C;
-  R.neg = 0;
-  // the thread's 16 bytes and their two neighbours from ALIGNED dwords around row + p0 (an aligned dword that holds
-  // one byte of the image cannot cross a page, so the few bytes read beside the row are harmless)
+  neg = 0;
   unsigned w[6] = {0u, 0u, 0u, 0u, 0u, 0u};  // aligned words [-1 .. 4] relative to (row + p0) & ~3
   const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
   const unsigned mis = (unsigned)(addr & 3u);
@@ -218,21 +254,18 @@ __device__ __forceinline__ void row_eval(RowLds<C, NT> &L, const uint8_t *__rest
     for (int j = 0; j < 5; j++)
       if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
   }
-  unsigned char bt[C + 2];  // pixels p0-1 .. p0+16
+  float ft[C + 2];  // fft of pixels p0-1 .. p0+16
 #pragma unroll
   for (int i = -1; i <= C; i++) {
-    // byte (mis + i) of the stream that starts at word 1
-    const int jw = 1 + ((i + 4) >> 2) - 1;  // word index for offset i when mis = 0: (i >= 0 ? i / 4 : -1) + 1
+    const int jw = (i + 4) >> 2;  // word that holds pixel i when mis = 0 (index into w: word -1 is w[0])
     const unsigned lo = w[jw], hi = w[jw + 1 < 6 ? jw + 1 : 5];
     const unsigned v = __builtin_amdgcn_alignbyte(hi, lo, mis);  // bytes mis .. mis+3 of (hi:lo)
-    bt[i + 1] = (unsigned char)((v >> (8 * ((i + 4) & 3))) & 0xffu);
+    ft[i + 1] = L.tab[(v >> (8 * ((i + 4) & 3))) & 0xffu];
   }
-  float ft[C + 2];
-#pragma unroll
-  for (int i = 0; i < C + 2; i++) ft[i] = L.tab[bt[i]];
 #pragma unroll
   for (int i = 0; i < C; i++) {
     const int p = p0 + i;
+    h[i] = 0.0f;
     if (p < cols) {
       float g = 0.0f;
       if (cols > 1) {
@@ -243,15 +276,25 @@ __device__ __forceinline__ void row_eval(RowLds<C, NT> &L, const uint8_t *__rest
       }
       const float gn = (maxg > 0.0f) ? __fdiv_rn(g, maxg) : 0.0f;
       const float sv = __fsub_rn(ft[i + 1], mean);
-      const float hv = __fmul_rn(sv, __fsub_rn(1.0f, gn));
-      R.h[i] = hv;
-      R.key[i] = ((unsigned long long)(~ord_f32(canon0(hv))) << 32) | (unsigned long long)(pix_base + (unsigned)p);
-      if (sv < 0.0f) R.neg |= 1u << i;
-    } else {  // past the row end: a wall no run crosses
-      R.h[i] = 0.0f;
-      R.key[i] = KINF;
+      h[i] = __fmul_rn(sv, __fsub_rn(1.0f, gn));
+      if (sv < 0.0f) neg |= 1u << i;
     }
   }
+}
+
+__device__ __forceinline__ unsigned long long key_of(float hv, unsigned pixel) {
+  return ((unsigned long long)(~ord_f32(canon0(hv))) << 32) | (unsigned long long)pixel;
+}
+
+// the caller has filled L.tab; contains block barriers
+template <int C, int NT>
+__device__ __forceinline__ void row_eval(RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, unsigned pix_base, float mean, float maxg,
+                                         RowRegs<C, NT> &R) {
+  __syncthreads();  // previous users of L.sw / L.edge_* are done, L.tab is visible
+  const int p0 = threadIdx.x * C;
+  row_load_h(L, row, cols, mean, maxg, R.h, R.neg);
+#pragma unroll
+  for (int i = 0; i < C; i++) R.key[i] = (p0 + i < cols) ? key_of(R.h[i], pix_base + (unsigned)(p0 + i)) : KINF;  // past the row end: a wall
   // forward: X(p) = min key over p's run up to p, including the pixel just left of the run
   const SegMin ident{KINF, 0u};
   unsigned long long x[C];
@@ -337,7 +380,8 @@ __device__ __forceinline__ int h_bin(float hv) {  // monotone non-decreasing in 
 
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
-                                               Scal *scal, unsigned *__restrict__ hist) {
+                                               Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ marker,
+                                               unsigned short *__restrict__ opener) {
   __shared__ RowLds<C, NT> L;
   __shared__ unsigned s_hist[NBIN];
   __shared__ long long s_fix[NT / 64];
@@ -351,6 +395,21 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
   RowRegs<C, NT> R;
   row_eval(L, row, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
   const unsigned opens = row_opens(L, R, cols);
+  {
+    // what the later passes need of this evaluation, so that the segmented scans run ONCE per row: for every pixel the
+    // range bin of the pixel whose key is its mark key (16 bits; rows padded to C * NT), and the opener bits of the thread
+    unsigned mw[C / 2];
+#pragma unroll
+    for (int i = 0; i < C; i += 2) {
+      const unsigned m0 = (threadIdx.x * C + i < cols) ? (unsigned)(R.mk[i] & 0xffffffffull) - (unsigned)a * (unsigned)cols : 0u;
+      const unsigned m1 = (threadIdx.x * C + i + 1 < cols) ? (unsigned)(R.mk[i + 1] & 0xffffffffull) - (unsigned)a * (unsigned)cols : 0u;
+      mw[i / 2] = (m0 & 0xffffu) | (m1 << 16);
+    }
+    uint4 *mdst = reinterpret_cast<uint4 *>(marker + (((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x) * C);
+    mdst[0] = uint4{mw[0], mw[1], mw[2], mw[3]};
+    mdst[1] = uint4{mw[4], mw[5], mw[6], mw[7]};
+    opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
+  }
   long long fix = 0;
 #pragma unroll
   for (int i = 0; i < C; i++) {
@@ -420,40 +479,42 @@ __global__ __launch_bounds__(256) void cen_pick(Scal *scal, const unsigned *__re
 
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
-                                                  int off, Scal *scal, unsigned long long *__restrict__ lists, int64_t list_stride) {
+                                                  int off, Scal *scal, const unsigned short *__restrict__ opener,
+                                                  unsigned long long *__restrict__ lists, int64_t list_stride) {
   __shared__ RowLds<C, NT> L;
   const int a = blockIdx.x;
   Scal *sc = scal + blockIdx.y;
   unsigned long long *list = lists + (int64_t)blockIdx.y * list_stride;
   const int bstar = sc->bstar;
-  if (bstar >= 0) {
-    const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
-    const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
-    row_table(L);
-    RowRegs<C, NT> R;
-    row_eval(L, row, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
-    const unsigned opens = row_opens(L, R, cols);
-    unsigned sel = 0;
+  if (bstar < 0) return;  // fewer openers than the budget: nothing to select
+  const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
+  const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
+  row_table(L);
+  __syncthreads();
+  float h[C];
+  unsigned neg;
+  row_load_h(L, row, cols, mean, maxg, h, neg);
+  const unsigned opens = opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x];  // from cen_hist: no scans here
+  unsigned sel = 0;
+#pragma unroll
+  for (int i = 0; i < C; i++)
+    if (((opens >> i) & 1u) && h_bin(h[i]) == bstar) sel |= 1u << i;
+  // one atomic per wavefront
+  const unsigned cnt = (unsigned)__popc(sel);
+  unsigned incl = cnt;
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned o = __shfl_up(incl, d);
+    if ((threadIdx.x & 63) >= d) incl += o;
+  }
+  const unsigned wave_total = __shfl(incl, 63);
+  unsigned base = 0;
+  if (wave_total) {
+    if ((threadIdx.x & 63) == 63) base = atomicAdd(&sc->n_list, wave_total);
+    base = __shfl(base, 63);
+    unsigned pos = base + incl - cnt;
 #pragma unroll
     for (int i = 0; i < C; i++)
-      if (((opens >> i) & 1u) && h_bin(R.h[i]) == bstar) sel |= 1u << i;
-    // one atomic per wavefront
-    const unsigned cnt = (unsigned)__popc(sel);
-    unsigned incl = cnt;
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned o = __shfl_up(incl, d);
-      if ((threadIdx.x & 63) >= d) incl += o;
-    }
-    const unsigned wave_total = __shfl(incl, 63);
-    unsigned base = 0;
-    if (wave_total) {
-      if ((threadIdx.x & 63) == 63) base = atomicAdd(&sc->n_list, wave_total);
-      base = __shfl(base, 63);
-      unsigned pos = base + incl - cnt;
-#pragma unroll
-      for (int i = 0; i < C; i++)
-        if ((sel >> i) & 1u) list[pos++] = R.key[i];
-    }
+      if ((sel >> i) & 1u) list[pos++] = key_of(h[i], (unsigned)a * (unsigned)cols + (unsigned)(threadIdx.x * C + i));
   }
 }
 
@@ -524,9 +585,10 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
 
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_extract(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
-                                                  int off, Scal *scal, int min_range, int row_cap, int *__restrict__ row_out,
-                                                  unsigned *__restrict__ row_n) {
+                                                  int off, Scal *scal, const unsigned short *__restrict__ marker, int min_range, int row_cap,
+                                                  int *__restrict__ row_out, unsigned *__restrict__ row_n) {
   __shared__ RowLds<C, NT> L;
+  __shared__ float s_h[C * NT];            // h of the row being looked at
   __shared__ uint8_t s_flag[C * NT + 16];  // bit 0: marked on this azimuth, bit 1: marked on the azimuth above or below
   __shared__ SegMax s_sw[NT / 64];
   __shared__ unsigned s_cnt[NT / 64];
@@ -536,25 +598,41 @@ __global__ __launch_bounds__(NT) void cen_extract(const uint8_t *__restrict__ im
   const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
   const unsigned long long klimit = sc->klimit;
   row_table(L);
-  RowRegs<C, NT> R;
   const int p0 = threadIdx.x * C;
   for (int p = threadIdx.x; p < C * NT + 16; p += NT) s_flag[p] = 0;
-  const int nb[2] = {(a - 1 + rows) % rows, (a + 1) % rows};
-  for (int k = 0; k < 2; k++) {
-    row_eval(L, base + (int64_t)nb[k] * stride, cols, (unsigned)nb[k] * (unsigned)cols, mean, maxg, R);
-#pragma unroll
-    for (int i = 0; i < C; i++)
-      if (R.mk[i] < klimit) s_flag[p0 + i] = 2;  // (row_eval's first barrier orders this against the zero fill)
-  }
-  row_eval(L, base + (int64_t)a * stride, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
-  unsigned marked = 0;
-#pragma unroll
-  for (int i = 0; i < C; i++)
-    if (p0 + i < cols && R.mk[i] < klimit) {
-      marked |= 1u << i;
-      s_flag[p0 + i] |= 1;
-    }
   __syncthreads();
+  // marks of the azimuths below / above and of this one: h of the row into LDS, then for every pixel the key of the pixel
+  // cen_hist recorded as its marker (mark key = key of that pixel) against the limit -- no scans
+  const int rws[3] = {(a - 1 + rows) % rows, (a + 1) % rows, a};
+  float h[C];
+  unsigned marked = 0;
+  for (int k = 0; k < 3; k++) {
+    unsigned neg;
+    row_load_h(L, base + (int64_t)rws[k] * stride, cols, mean, maxg, h, neg);
+#pragma unroll
+    for (int i = 0; i < C; i++) s_h[p0 + i] = h[i];
+    const uint4 *msrc = reinterpret_cast<const uint4 *>(marker + (((int64_t)img * rows + rws[k]) * NT + threadIdx.x) * C);
+    const uint4 m0 = msrc[0], m1 = msrc[1];
+    const unsigned mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+    __syncthreads();
+    unsigned bits = 0;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const unsigned rm = (mw[i / 2] >> (16 * (i & 1))) & 0xffffu;
+      if (p0 + i < cols && key_of(s_h[rm], (unsigned)rws[k] * (unsigned)cols + rm) < klimit) bits |= 1u << i;
+    }
+    if (k < 2) {
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        if ((bits >> i) & 1u) s_flag[p0 + i] = 2;
+    } else {
+      marked = bits;
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        if ((bits >> i) & 1u) s_flag[p0 + i] |= 1;
+    }
+    __syncthreads();  // s_h is overwritten by the next row; the flags are complete after the last one
+  }
   // runs of marked pixels at r >= rmin: segmented max-scan; the LAST pixel of a run holds the run's result
   const int rmin = min_range < 0 ? 0 : min_range;
   const SegMax ident{0ull, 0u, 0u};
@@ -565,7 +643,7 @@ __global__ __launch_bounds__(NT) void cen_extract(const uint8_t *__restrict__ im
     const int p = p0 + i;
     if (((marked >> i) & 1u) && p >= rmin) {
       const bool start = p == rmin || !(s_flag[p - 1] & 1);
-      SegMax e{((unsigned long long)ord_f32(canon0(R.h[i])) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p), start ? 1u : 0u,
+      SegMax e{((unsigned long long)ord_f32(canon0(h[i])) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p), start ? 1u : 0u,
                (unsigned)((s_flag[p] >> 1) & 1)};
       loc = seg_max(loc, e);
     } else {
@@ -651,7 +729,7 @@ struct rsx_cen2019 {
   int device = 0, rows = 0, cols = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts;
+  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, marker, opener;
 };
 
 using rsx::fail;
@@ -665,14 +743,16 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   const int rows = h->rows, cols = h->cols;
   Scal *sc = h->scal.as<Scal>();
   const dim3 grid((unsigned)rows, (unsigned)nb);
-  hipLaunchKernelGGL(cen_stats, grid, dim3(256), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
-  hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>());
+  hipLaunchKernelGGL((cen_stats<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
+  hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>(),
+                     h->marker.as<unsigned short>(), h->opener.as<unsigned short>());
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
-  hipLaunchKernelGGL((cen_collect<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc,
+  hipLaunchKernelGGL((cen_collect<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
                      h->list.as<unsigned long long>(), (int64_t)rows * cols);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
-  hipLaunchKernelGGL((cen_extract<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, p.min_range, row_cap,
+  hipLaunchKernelGGL((cen_extract<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->marker.as<unsigned short>(),
+                     p.min_range, row_cap,
                      h->row_out.as<int>(), h->row_n.as<unsigned>());
   hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
                      resolution, max_targets, d_targets, d_xy, d_counts);
@@ -692,6 +772,11 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     RSX_TRY(h->list.reserve((size_t)n * rows * cols * 8, s, false));
     RSX_TRY(h->row_out.reserve((size_t)n * rows * row_cap * 4, s, false));
     RSX_TRY(h->row_n.reserve((size_t)n * rows * 4, s, false));
+    {
+      const size_t nt = cols <= 16 * 256 ? 256 : 1024;  // threads per row block: marker rows are padded to 16 * nt bins
+      RSX_TRY(h->marker.reserve((size_t)n * rows * nt * 16 * 2, s, false));
+      RSX_TRY(h->opener.reserve((size_t)n * rows * nt * 2, s, false));
+    }
     RSX_HIP(hipMemsetAsync(h->scal.p, 0, (size_t)n * sizeof(Scal), s));
     RSX_HIP(hipMemsetAsync(h->hist.p, 0, (size_t)n * NBIN * 4, s));
     const uint8_t *im = d_imgs + (int64_t)b0 * img_stride;
@@ -745,7 +830,7 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts}) b->release();
+  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->marker, &h->opener}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;

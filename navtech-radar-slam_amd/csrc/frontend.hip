@@ -12,8 +12,9 @@
 //   fe_remap      one thread per Cartesian pixel: 4 byte taps of the polar image, bilinear in fp32 (HBM-bound:
 //                 7.4 MB of map + 3.7 MB out per scan)
 //   fe_blur_*     separable 7-tap Gaussian
-//   fe_describe   one thread per keypoint: intensity-centroid orientation (sequential fp32 sums: the oracle's order),
-//                 30-direction quantisation, 256 comparisons on the smoothed image through the rotated pair table
+//   fe_describe   one WAVEFRONT per keypoint: intensity-centroid orientation from order-independent int64 moments
+//                 (I quantised to 2^-24, like OpenCV's integer IC_Angle), 30-direction quantisation, 256 comparisons
+//                 on the smoothed image through the rotated pair table as 4 ballots
 //   fe_match      one thread per query descriptor, train descriptors staged through LDS, 8 x v_bcnt per pair
 // fp32 arithmetic in a fixed order without contraction; every transcendental lives in host-side tables computed
 // in double exactly like the oracle's, so GPU == oracle bit for bit.
@@ -91,49 +92,71 @@ __global__ __launch_bounds__(256) void fe_uv(const float *__restrict__ xy, const
   uv[o + 1] = (int32_t)round((cmr - (double)xy[o]) / cart_res);
 }
 
-// blockIdx.y = image: keypoint k of image b at uv / desc / valid slot b * stride + k; counts == nullptr: n keypoints
-__global__ __launch_bounds__(64) void fe_describe(const float *__restrict__ carts, const float *__restrict__ blurs, int W,
-                                                  const int32_t *__restrict__ uvs, int n, const int32_t *__restrict__ counts, int stride,
-                                                  const float *__restrict__ dir_cs, const int8_t *__restrict__ pairs,
-                                                  uint32_t *__restrict__ descs, uint8_t *__restrict__ valids) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
+// blockIdx.y = image: keypoint k of image b at uv / desc / valid slot b * stride + k; counts == nullptr: n keypoints.
+// ONE WAVEFRONT PER KEYPOINT (round 3; rounds 1-2: one thread per keypoint walking the 709-pixel patch and the 256 pairs
+// alone).  The intensity-centroid moments are defined ORDER-INDEPENDENTLY, like OpenCV's integer IC_Angle on its 8-bit
+// image: I_q = llrint(I * 2^24), m10 = sum dx * I_q, m01 = sum dy * I_q in int64 -- so the 64 lanes take the patch pixels
+// of the 31 x 31 raster in stride and a butterfly adds them; the direction is the first maximum over the 30 bins of
+// (double)m10 * c_b + (double)m01 * s_b (one multiply each, one add: no contraction); the 256 comparisons are 4 ballots.
+// A block of 4 waves walks the keypoints k = 4 * blockIdx.x + wave, + 4 * gridDim.x, ...
+__global__ __launch_bounds__(256) void fe_describe(const float *__restrict__ carts, const float *__restrict__ blurs, int W,
+                                                   const int32_t *__restrict__ uvs, int n, const int32_t *__restrict__ counts, int stride,
+                                                   const float *__restrict__ dir_cs, const int8_t *__restrict__ pairs,
+                                                   uint32_t *__restrict__ descs, uint8_t *__restrict__ valids) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (counts) n = counts[blockIdx.y] < stride ? counts[blockIdx.y] : stride;
-  if (k >= n) return;
   const float *cart = carts + (int64_t)blockIdx.y * W * W, *blur = blurs + (int64_t)blockIdx.y * W * W;
   const int32_t *uv = uvs + (int64_t)blockIdx.y * stride * 2;
   uint32_t *desc = descs + (int64_t)blockIdx.y * stride * 8;
   uint8_t *valid = valids + (int64_t)blockIdx.y * stride;
-  const int u = uv[2 * k], v = uv[2 * k + 1];
-  uint32_t d[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  const bool ok = !(u < BORDER || v < BORDER || u >= W - BORDER || v >= W - BORDER);
-  if (ok) {
-    float m10 = 0.0f, m01 = 0.0f;
-    for (int dy = -HALF_PATCH; dy <= HALF_PATCH; dy++)
-      for (int dx = -HALF_PATCH; dx <= HALF_PATCH; dx++) {
-        if (dx * dx + dy * dy > HALF_PATCH * HALF_PATCH) continue;
-        const float I = cart[(int64_t)(v + dy) * W + (u + dx)];
-        m10 = m10 + (float)dx * I;
-        m01 = m01 + (float)dy * I;
-      }
-    int bin = 0;
-    float best = -INFINITY;
-    for (int b = 0; b < NBINS; b++) {
-      const float dd = m10 * dir_cs[2 * b] + m01 * dir_cs[2 * b + 1];
-      if (dd > best) {
-        best = dd;
-        bin = b;
-      }
+  constexpr int SIDE = 2 * HALF_PATCH + 1;
+  for (int k = blockIdx.x * 4 + wave; k < n; k += gridDim.x * 4) {
+    const int u = uv[2 * k], v = uv[2 * k + 1];
+    const bool ok = !(u < BORDER || v < BORDER || u >= W - BORDER || v >= W - BORDER);  // wave-uniform
+    if (!ok) {
+      if (lane < 8) desc[(int64_t)k * 8 + lane] = 0u;
+      if (lane == 0) valid[k] = 0;
+      continue;
     }
-    const int8_t *pp = pairs + (int64_t)bin * NPAIRS * 4;
-    for (int i = 0; i < NPAIRS; i++) {
-      const float a = blur[(int64_t)(v + pp[4 * i + 1]) * W + (u + pp[4 * i])];
-      const float b = blur[(int64_t)(v + pp[4 * i + 3]) * W + (u + pp[4 * i + 2])];
-      if (a < b) d[i >> 5] |= 1u << (i & 31);  // little-endian words: bit i of byte i / 8
+    long long m10 = 0, m01 = 0;
+    for (int idx = lane; idx < SIDE * SIDE; idx += 64) {
+      const int dy = idx / SIDE - HALF_PATCH, dx = idx - (dy + HALF_PATCH) * SIDE - HALF_PATCH;
+      if (dx * dx + dy * dy > HALF_PATCH * HALF_PATCH) continue;
+      const long long iq = __double2ll_rn((double)cart[(int64_t)(v + dy) * W + (u + dx)] * 16777216.0);
+      m10 += (long long)dx * iq;
+      m01 += (long long)dy * iq;
     }
-  }
 #pragma unroll
-  for (int w = 0; w < 8; w++) desc[(int64_t)k * 8 + w] = d[w];
-  valid[k] = ok ? 1 : 0;
+    for (int o = 32; o >= 1; o >>= 1) {
+      m10 += __shfl_xor(m10, o);
+      m01 += __shfl_xor(m01, o);
+    }
+    const double dm10 = (double)m10, dm01 = (double)m01;
+    double dd = -INFINITY;
+    if (lane < NBINS) {
+      const double a = dm10 * (double)dir_cs[2 * lane], b = dm01 * (double)dir_cs[2 * lane + 1];
+      dd = a + b;
+    }
+    double mx = dd;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    const unsigned long long at = __ballot(lane < NBINS && dd == mx);
+    const int bin = at ? __ffsll((long long)at) - 1 : 0;  // first maximum (NaN cannot occur: finite integers)
+    const int8_t *pp = pairs + (int64_t)bin * NPAIRS * 4;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int i = 64 * j + lane;
+      const char4 p4 = *reinterpret_cast<const char4 *>(pp + 4 * i);
+      const float a = blur[(int64_t)(v + p4.y) * W + (u + p4.x)];
+      const float b = blur[(int64_t)(v + p4.w) * W + (u + p4.z)];
+      const unsigned long long bits = __ballot(a < b);  // bit i of byte i / 8, little-endian words
+      if (lane == 0) {
+        desc[(int64_t)k * 8 + 2 * j] = (uint32_t)bits;
+        desc[(int64_t)k * 8 + 2 * j + 1] = (uint32_t)(bits >> 32);
+      }
+    }
+    if (lane == 0) valid[k] = 1;
+  }
 }
 
 __global__ __launch_bounds__(256) void fe_match(const uint32_t *__restrict__ q, const uint8_t *__restrict__ qv, int nq,
@@ -177,51 +200,87 @@ __global__ __launch_bounds__(256) void fe_match(const uint32_t *__restrict__ q, 
   }
 }
 
+// ordered list of the VALID keypoints of slot (first + blockIdx.x): vidx[blockIdx.x][j] = index of the j-th valid one,
+// vcount[blockIdx.x] = how many (only ~40 % of the keypoints of a 200 m scan fall inside the 250 m Cartesian image)
+__global__ __launch_bounds__(256) void fe_compact_valid(const uint8_t *__restrict__ valids, const int32_t *__restrict__ counts, int stride,
+                                                        int first, int32_t *__restrict__ vidx, int32_t *__restrict__ vcount) {
+  __shared__ int s_w[4];
+  const int slot = first + blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = counts[slot] < stride ? counts[slot] : stride;
+  const uint8_t *v = valids + (int64_t)slot * stride;
+  int32_t *out = vidx + (int64_t)blockIdx.x * stride;
+  int run = 0;
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + threadIdx.x;
+    const bool ok = i < n && v[i];
+    const unsigned long long bal = __ballot(ok);
+    if (lane == 0) s_w[wave] = __popcll(bal);
+    __syncthreads();
+    int before = run, total = 0;
+    for (int w = 0; w < 4; w++) {
+      if (w < wave) before += s_w[w];
+      total += s_w[w];
+    }
+    if (ok) out[before + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+    run += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) vcount[blockIdx.x] = run;
+}
+
 // knnMatch(2) + ratio between CONSECUTIVE scans of a batch: blockIdx.y = pair j (slots first + j and first + j + 1 of the
 // [slot][stride] arrays), blockIdx.z = direction: 0 queries = slot A against train = slot B -> fwd[j][i], 1 the reverse
-// -> bwd[j][i].  Same scan order and tie rule as fe_match.
+// -> bwd[j][i].  Queries and train descriptors are taken from the compacted lists of valid keypoints (ascending index, so
+// "the first minimum wins" is the scan order of fe_match / BFMatcher); invalid queries get -1.
 __global__ __launch_bounds__(256) void fe_match_consecutive(const uint32_t *__restrict__ descs, const uint8_t *__restrict__ valids,
-                                                            const int32_t *__restrict__ counts, int stride, int first, float ratio,
+                                                            const int32_t *__restrict__ counts, int stride, int first,
+                                                            const int32_t *__restrict__ vidx, const int32_t *__restrict__ vcount, float ratio,
                                                             int32_t *__restrict__ fwd, int32_t *__restrict__ bwd) {
   __shared__ uint32_t st[256 * 8];
-  __shared__ uint8_t sv[256];
+  __shared__ int32_t si[256];
   const int j = blockIdx.y, dir = blockIdx.z;
-  const int qs = first + j + dir, ts = first + j + 1 - dir;
-  const int nq = counts[qs] < stride ? counts[qs] : stride, nt = counts[ts] < stride ? counts[ts] : stride;
+  const int qs = j + dir, ts = j + 1 - dir;  // slots relative to `first`
+  const int nq = counts[first + qs] < stride ? counts[first + qs] : stride;
   if ((int)blockIdx.x * 256 >= nq) return;
-  const uint32_t *q = descs + (int64_t)qs * stride * 8, *t = descs + (int64_t)ts * stride * 8;
-  const uint8_t *qv = valids + (int64_t)qs * stride, *tv = valids + (int64_t)ts * stride;
+  const int nqv = vcount[qs], ntv = vcount[ts];
+  const uint32_t *q = descs + (int64_t)(first + qs) * stride * 8, *t = descs + (int64_t)(first + ts) * stride * 8;
+  const int32_t *qi = vidx + (int64_t)qs * stride, *ti = vidx + (int64_t)ts * stride;
   int32_t *out_idx = (dir ? bwd : fwd) + (int64_t)j * stride;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  uint32_t me[8];
-  const bool live = i < nq && qv[i];
-#pragma unroll
-  for (int w = 0; w < 8; w++) me[w] = i < nq ? q[(int64_t)i * 8 + w] : 0u;
-  int d1 = 1 << 30, d2 = 1 << 30, i1 = -1;
-  for (int j0 = 0; j0 < nt; j0 += 256) {
-    __syncthreads();
-    const int jj0 = j0 + threadIdx.x;
-#pragma unroll
-    for (int w = 0; w < 8; w++) st[threadIdx.x * 8 + w] = jj0 < nt ? t[(int64_t)jj0 * 8 + w] : 0u;
-    sv[threadIdx.x] = jj0 < nt ? tv[jj0] : 0;
-    __syncthreads();
-    const int lim = nt - j0 < 256 ? nt - j0 : 256;
-    if (live)
-      for (int jj = 0; jj < lim; jj++) {
-        if (!sv[jj]) continue;
-        int d = 0;
-#pragma unroll
-        for (int w = 0; w < 8; w++) d += __popc(me[w] ^ st[jj * 8 + w]);
-        if (d < d1) {
-          d2 = d1;
-          d1 = d;
-          i1 = j0 + jj;
-        } else if (d < d2) {
-          d2 = d;
-        }
-      }
+  {
+    const int i = blockIdx.x * 256 + threadIdx.x;  // keypoints without a descriptor match nothing
+    if (i < nq && !valids[(int64_t)(first + qs) * stride + i]) out_idx[i] = -1;
   }
-  if (i < nq) out_idx[i] = (i1 >= 0 && d2 < (1 << 30) && (float)d1 < ratio * (float)d2) ? i1 : -1;
+  if ((int)blockIdx.x * 256 >= nqv) return;
+  const int jq = blockIdx.x * 256 + threadIdx.x;
+  const bool live = jq < nqv;
+  const int iq = live ? qi[jq] : 0;
+  uint32_t me[8];
+#pragma unroll
+  for (int w = 0; w < 8; w++) me[w] = live ? q[(int64_t)iq * 8 + w] : 0u;
+  int d1 = 1 << 30, d2 = 1 << 30, i1 = -1;
+  for (int j0 = 0; j0 < ntv; j0 += 256) {
+    __syncthreads();
+    const int jt = j0 + threadIdx.x;
+    const int it = jt < ntv ? ti[jt] : 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++) st[threadIdx.x * 8 + w] = jt < ntv ? t[(int64_t)it * 8 + w] : 0u;
+    si[threadIdx.x] = it;
+    __syncthreads();
+    const int lim = ntv - j0 < 256 ? ntv - j0 : 256;
+    for (int jj = 0; jj < lim; jj++) {  // ascending train index: the first minimum wins, like BFMatcher's scan
+      int d = 0;
+#pragma unroll
+      for (int w = 0; w < 8; w++) d += __popc(me[w] ^ st[jj * 8 + w]);
+      if (d < d1) {
+        d2 = d1;
+        d1 = d;
+        i1 = si[jj];
+      } else if (d < d2) {
+        d2 = d;
+      }
+    }
+  }
+  if (live) out_idx[iq] = (i1 >= 0 && d2 < (1 << 30) && (float)d1 < ratio * (float)d2) ? i1 : -1;
 }
 
 }  // namespace
@@ -231,7 +290,7 @@ struct rsx_frontend {
   double cart_res = 0.0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, map_rb, map_ab, cart, tmp, blur, tables, uv, desc, valid, q, qv, t, tv, m_idx, m_d1, m_d2;
+  rsx::DevBuf img, map_rb, map_ab, cart, tmp, blur, tables, uv, desc, valid, q, qv, t, tv, m_idx, m_d1, m_d2, vidx, vcount;
   // the map depends on the radar's range resolution and azimuth grid: rebuilt only when they change
   double map_radar_res = -1.0, map_az0 = 0.0, map_az_step = 0.0;
   bool have_image = false;
@@ -346,7 +405,7 @@ int rsx_frontend_destroy(rsx_frontend *h) {
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (rsx::DevBuf *b : {&h->img, &h->map_rb, &h->map_ab, &h->cart, &h->tmp, &h->blur, &h->tables, &h->uv, &h->desc, &h->valid, &h->q,
-                         &h->qv, &h->t, &h->tv, &h->m_idx, &h->m_d1, &h->m_d2})
+                         &h->qv, &h->t, &h->tv, &h->m_idx, &h->m_d1, &h->m_d2, &h->vidx, &h->vcount})
     b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -453,7 +512,7 @@ int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *
   RSX_TRY(h->valid.reserve((size_t)n, s, false));
   RSX_HIP(hipMemcpyAsync(h->uv.p, uv.data(), (size_t)n * 8, hipMemcpyHostToDevice, s));
   const char *tab = static_cast<const char *>(h->tables.p);
-  hipLaunchKernelGGL(fe_describe, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, h->cart.as<float>(), h->blur.as<float>(), h->W,
+  hipLaunchKernelGGL(fe_describe, dim3((unsigned)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048)), dim3(256), 0, s, h->cart.as<float>(), h->blur.as<float>(), h->W,
                      h->uv.as<int32_t>(), n, (const int32_t *)nullptr, n, reinterpret_cast<const float *>(tab + TAB_DIR),
                      reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), h->desc.as<uint32_t>(), h->valid.as<uint8_t>());
   RSX_HIP(hipGetLastError());
@@ -475,7 +534,8 @@ int rsx_frontend_describe_batch_device(rsx_frontend *h, const float *d_xy, const
   hipLaunchKernelGGL(fe_uv, dim3((unsigned)((max_targets + 255) / 256), (unsigned)n_images), dim3(256), 0, s, d_xy, d_counts, max_targets, cmr,
                      h->cart_res, h->uv.as<int32_t>());
   const char *tab = static_cast<const char *>(h->tables.p);
-  hipLaunchKernelGGL(fe_describe, dim3((unsigned)((max_targets + 63) / 64), (unsigned)n_images), dim3(64), 0, s, h->cart.as<float>(),
+  // 512 blocks of 4 waves per image walk the image's keypoints (the counts live on the device)
+  hipLaunchKernelGGL(fe_describe, dim3((unsigned)((max_targets + 3) / 4 < 512 ? (max_targets + 3) / 4 : 512), (unsigned)n_images), dim3(256), 0, s, h->cart.as<float>(),
                      h->blur.as<float>(), h->W, h->uv.as<int32_t>(), 0, d_counts, max_targets, reinterpret_cast<const float *>(tab + TAB_DIR),
                      reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), reinterpret_cast<uint32_t *>(d_desc), d_valid);
   RSX_HIP(hipGetLastError());
@@ -491,8 +551,13 @@ int rsx_frontend_match_consecutive_device(rsx_frontend *h, const uint8_t *d_desc
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  RSX_TRY(h->vidx.reserve((size_t)(n_pairs + 1) * max_targets * 4, s, false));
+  RSX_TRY(h->vcount.reserve((size_t)(n_pairs + 1) * 4, s, false));
+  hipLaunchKernelGGL(fe_compact_valid, dim3((unsigned)(n_pairs + 1)), dim3(256), 0, s, d_valid, d_counts, max_targets, first_slot,
+                     h->vidx.as<int32_t>(), h->vcount.as<int32_t>());
   hipLaunchKernelGGL(fe_match_consecutive, dim3((unsigned)((max_targets + 255) / 256), (unsigned)n_pairs, 2), dim3(256), 0, s,
-                     reinterpret_cast<const uint32_t *>(d_desc), d_valid, d_counts, max_targets, first_slot, ratio, d_fwd, d_bwd);
+                     reinterpret_cast<const uint32_t *>(d_desc), d_valid, d_counts, max_targets, first_slot, h->vidx.as<int32_t>(),
+                     h->vcount.as<int32_t>(), ratio, d_fwd, d_bwd);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

@@ -10,7 +10,8 @@
  *   cartesian   yeti's radar_polar_to_cartesian: W x W image centred on the sensor, row 0 = farthest forward,
  *               forward = azimuth 0, azimuth grows clockwise (to the right); pixel -> (range bin, azimuth row) in
  *               double on the host, bilinear taps in fp32, rows wrap around, bins outside the scan read 0.
- *   describe    oriented BRIEF as in ORB: orientation from the intensity centroid of the radius-15 disc, quantised to 30
+ *   describe    oriented BRIEF as in ORB: orientation from the intensity centroid of the radius-15 disc (moments in int64
+ *               over pixels quantised to 2^-24: order independent, like cv::ORB's integer IC_Angle), quantised to 30
  *               directions of 12 deg (the original ORB table form); 256 intensity comparisons on the image smoothed by a
  *               7 x 7 Gaussian (sigma 2).  OpenCV's learned 256-pair pattern table cannot be reproduced offline: the pairs
  *               come from a seeded integer generator (uniform in the disc of radius 13) -- same structure, different
@@ -153,19 +154,21 @@ void feref_describe(const float *cart, const float *blur, int W, double cart_res
     valid[k] = 0;
     if (u < FE_BORDER || v < FE_BORDER || u >= W - FE_BORDER || v >= W - FE_BORDER) continue;
     valid[k] = 1;
-    /* intensity centroid over the disc of radius 15: rows top to bottom, columns left to right */
-    float m10 = 0.0f, m01 = 0.0f;
+    /* intensity centroid over the disc of radius 15, ORDER-INDEPENDENT like OpenCV's integer IC_Angle on its 8-bit
+     * image: every pixel quantised to I_q = llrint(I * 2^24), the moments summed in int64 (exact in any order) */
+    long long m10 = 0, m01 = 0;
     for (int dy = -FE_HALF_PATCH; dy <= FE_HALF_PATCH; dy++)
       for (int dx = -FE_HALF_PATCH; dx <= FE_HALF_PATCH; dx++) {
         if (dx * dx + dy * dy > FE_HALF_PATCH * FE_HALF_PATCH) continue;
-        const float I = cart[(size_t)(v + dy) * W + (u + dx)];
-        m10 = m10 + (float)dx * I;
-        m01 = m01 + (float)dy * I;
+        const long long iq = llrint((double)cart[(size_t)(v + dy) * W + (u + dx)] * 16777216.0);
+        m10 += (long long)dx * iq;
+        m01 += (long long)dy * iq;
       }
     int bin = 0;
-    float best = -INFINITY;
+    double best = -INFINITY;
     for (int b = 0; b < FE_NBINS; b++) {
-      const float d = m10 * dir_cs[2 * b] + m01 * dir_cs[2 * b + 1];
+      const double pa = (double)m10 * (double)dir_cs[2 * b], pb = (double)m01 * (double)dir_cs[2 * b + 1];
+      const double d = pa + pb; /* one multiply each, one add (no contraction): first maximum wins */
       if (d > best) {
         best = d;
         bin = b;
