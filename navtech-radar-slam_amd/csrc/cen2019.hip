@@ -26,9 +26,9 @@
 //                so that the scans run once per row
 //   cen_collect  h again (cheap) + the recorded opener bits: appends the openers of bin B* (a few dozen keys)
 //   cen_resolve  (one block per image) radix-selects K* among them
-//   cen_extract  per azimuth: marks of rows a-1, a, a+1 = key of the recorded marker pixel < limit (h of the
-//                row in LDS, one gather per pixel), runs / adjacency / arg-max by one segmented max-scan,
-//                ordered compaction
+//   cen_runs     per azimuth: marks = key of the recorded marker pixel < limit (h of the row in LDS, one
+//                gather per pixel); closed runs of marks and their arg-max by one segmented max-scan
+//   cen_adjacent per azimuth: keep the runs that meet a mark of the azimuth above or below, ordered compaction
 //   cen_pack     row-major packing of the rows' keypoints (+ polar -> Cartesian)
 // One workgroup per (azimuth, image): a launch over a batch of B images is B x rows workgroups, every
 // dependency between passes is a kernel boundary, nothing returns to the host.  (A first version
@@ -82,7 +82,8 @@ __device__ __forceinline__ unsigned long long kmean_of(float mh) { return (unsig
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
                                                 int off, Scal *scal) {
-  static_assert(C == 16, "a thread's chunk is four dwords");
+  static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
+  constexpr int NWD = C / 4 + 2;
   __shared__ float s_tab[256];
   __shared__ unsigned long long s_sum[NT / 64];
   __shared__ float s_max[NT / 64];
@@ -92,21 +93,23 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
   if (threadIdx.x < 256) s_tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
   __syncthreads();
   const int p0 = threadIdx.x * C;
-  unsigned w[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+  unsigned w[NWD];
+#pragma unroll
+  for (int j = 0; j < NWD; j++) w[j] = 0u;
   const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
   const unsigned mis = (unsigned)(addr & 3u);
   const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
   if (p0 < cols) {
     if (p0 > 0) w[0] = wp[-1];
 #pragma unroll
-    for (int j = 0; j < 5; j++)
+    for (int j = 0; j < NWD - 1; j++)
       if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
   }
   unsigned bt[C + 2];
 #pragma unroll
   for (int i = -1; i <= C; i++) {
     const int jw = (i + 4) >> 2;
-    const unsigned v = __builtin_amdgcn_alignbyte(w[jw + 1 < 6 ? jw + 1 : 5], w[jw], mis);
+    const unsigned v = __builtin_amdgcn_alignbyte(w[jw + 1 < NWD ? jw + 1 : NWD - 1], w[jw], mis);
     bt[i + 1] = (v >> (8 * ((i + 4) & 3))) & 0xffu;
   }
   unsigned long long sb = 0;
@@ -165,6 +168,14 @@ __device__ __forceinline__ SegMax seg_max(SegMax a, SegMax b) {
   SegMax r;
   r.v = b.f ? b.v : (a.v > b.v ? a.v : b.v);
   r.adj = b.f ? b.adj : (a.adj | b.adj);
+  r.f = a.f | b.f;
+  return r;
+}
+// the same with `adj` = a value the segment's head defines (the run's first bin) instead of an OR over the segment
+__device__ __forceinline__ SegMax seg_first(SegMax a, SegMax b) {
+  SegMax r;
+  r.v = b.f ? b.v : (a.v > b.v ? a.v : b.v);
+  r.adj = b.f ? b.adj : a.adj;
   r.f = a.f | b.f;
   return r;
 }
@@ -241,24 +252,27 @@ __device__ __forceinline__ void row_table(RowLds<C, NT> &L) {
 template <int C, int NT>
 __device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg,
                                            float (&h)[C], unsigned &neg) {
-  static_assert(C == 16, "a thread's chunk is four dwords");
+  static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
+  constexpr int NWD = C / 4 + 2;  // aligned words [-1 .. C / 4] relative to (row + p0) & ~3
   const int p0 = threadIdx.x * C;
   neg = 0;
-  unsigned w[6] = {0u, 0u, 0u, 0u, 0u, 0u};  // aligned words [-1 .. 4] relative to (row + p0) & ~3
+  unsigned w[NWD];
+#pragma unroll
+  for (int j = 0; j < NWD; j++) w[j] = 0u;
   const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
   const unsigned mis = (unsigned)(addr & 3u);
   const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
   if (p0 < cols) {
     if (p0 > 0) w[0] = wp[-1];
 #pragma unroll
-    for (int j = 0; j < 5; j++)
+    for (int j = 0; j < NWD - 1; j++)
       if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
   }
-  float ft[C + 2];  // fft of pixels p0-1 .. p0+16
+  float ft[C + 2];  // fft of pixels p0-1 .. p0+C
 #pragma unroll
   for (int i = -1; i <= C; i++) {
     const int jw = (i + 4) >> 2;  // word that holds pixel i when mis = 0 (index into w: word -1 is w[0])
-    const unsigned lo = w[jw], hi = w[jw + 1 < 6 ? jw + 1 : 5];
+    const unsigned lo = w[jw], hi = w[jw + 1 < NWD ? jw + 1 : NWD - 1];
     const unsigned v = __builtin_amdgcn_alignbyte(hi, lo, mis);  // bytes mis .. mis+3 of (hi:lo)
     ft[i + 1] = L.tab[(v >> (8 * ((i + 4) & 3))) & 0xffu];
   }
@@ -406,8 +420,8 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
       mw[i / 2] = (m0 & 0xffffu) | (m1 << 16);
     }
     uint4 *mdst = reinterpret_cast<uint4 *>(marker + (((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x) * C);
-    mdst[0] = uint4{mw[0], mw[1], mw[2], mw[3]};
-    mdst[1] = uint4{mw[4], mw[5], mw[6], mw[7]};
+#pragma unroll
+    for (int j = 0; j < C / 8; j++) mdst[j] = uint4{mw[4 * j], mw[4 * j + 1], mw[4 * j + 2], mw[4 * j + 3]};
     opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
   }
   long long fix = 0;
@@ -583,56 +597,52 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
   }
 }
 
+// runs of marked pixels of ONE azimuth (the part of the extraction that does not look at the neighbours): marks = key of
+// the recorded marker pixel < limit (h of the row in LDS, one gather per pixel; no scans over keys), then one segmented
+// max-scan over the marked runs at r >= min_range: every run that an unmarked pixel closes is recorded as
+// (first bin, last bin, bin of the first maximum of h); the row's mark bits go to HBM for the neighbours' adjacency test.
 template <int C, int NT>
-__global__ __launch_bounds__(NT) void cen_extract(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
-                                                  int off, Scal *scal, const unsigned short *__restrict__ marker, int min_range, int row_cap,
-                                                  int *__restrict__ row_out, unsigned *__restrict__ row_n) {
+__global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
+                                               Scal *scal, const unsigned short *__restrict__ marker, int min_range, int row_cap,
+                                               uint2 *__restrict__ row_runs, unsigned *__restrict__ row_nruns,
+                                               unsigned short *__restrict__ markbits) {
   __shared__ RowLds<C, NT> L;
-  __shared__ float s_h[C * NT];            // h of the row being looked at
-  __shared__ uint8_t s_flag[C * NT + 16];  // bit 0: marked on this azimuth, bit 1: marked on the azimuth above or below
+  __shared__ float s_h[C * NT];           // h of the row
+  __shared__ uint8_t s_flag[C * NT + 16];  // 1: marked
   __shared__ SegMax s_sw[NT / 64];
   __shared__ unsigned s_cnt[NT / 64];
   const int a = blockIdx.x, img = blockIdx.y;
   Scal *sc = scal + img;
-  const uint8_t *base = imgs + (int64_t)img * img_stride + off;
+  const uint8_t *row = imgs + (int64_t)img * img_stride + off + (int64_t)a * stride;
   const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
   const unsigned long long klimit = sc->klimit;
   row_table(L);
   const int p0 = threadIdx.x * C;
-  for (int p = threadIdx.x; p < C * NT + 16; p += NT) s_flag[p] = 0;
+  if (threadIdx.x < 16) s_flag[C * NT + threadIdx.x] = 0;
   __syncthreads();
-  // marks of the azimuths below / above and of this one: h of the row into LDS, then for every pixel the key of the pixel
-  // cen_hist recorded as its marker (mark key = key of that pixel) against the limit -- no scans
-  const int rws[3] = {(a - 1 + rows) % rows, (a + 1) % rows, a};
   float h[C];
-  unsigned marked = 0;
-  for (int k = 0; k < 3; k++) {
-    unsigned neg;
-    row_load_h(L, base + (int64_t)rws[k] * stride, cols, mean, maxg, h, neg);
+  unsigned neg;
+  row_load_h(L, row, cols, mean, maxg, h, neg);
 #pragma unroll
-    for (int i = 0; i < C; i++) s_h[p0 + i] = h[i];
-    const uint4 *msrc = reinterpret_cast<const uint4 *>(marker + (((int64_t)img * rows + rws[k]) * NT + threadIdx.x) * C);
-    const uint4 m0 = msrc[0], m1 = msrc[1];
-    const unsigned mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-    __syncthreads();
-    unsigned bits = 0;
+  for (int i = 0; i < C; i++) s_h[p0 + i] = h[i];
+  const uint4 *msrc = reinterpret_cast<const uint4 *>(marker + (((int64_t)img * rows + a) * NT + threadIdx.x) * C);
+  unsigned mw[C / 2];
 #pragma unroll
-    for (int i = 0; i < C; i++) {
-      const unsigned rm = (mw[i / 2] >> (16 * (i & 1))) & 0xffffu;
-      if (p0 + i < cols && key_of(s_h[rm], (unsigned)rws[k] * (unsigned)cols + rm) < klimit) bits |= 1u << i;
-    }
-    if (k < 2) {
-#pragma unroll
-      for (int i = 0; i < C; i++)
-        if ((bits >> i) & 1u) s_flag[p0 + i] = 2;
-    } else {
-      marked = bits;
-#pragma unroll
-      for (int i = 0; i < C; i++)
-        if ((bits >> i) & 1u) s_flag[p0 + i] |= 1;
-    }
-    __syncthreads();  // s_h is overwritten by the next row; the flags are complete after the last one
+  for (int j = 0; j < C / 8; j++) {
+    const uint4 m = msrc[j];
+    mw[4 * j] = m.x; mw[4 * j + 1] = m.y; mw[4 * j + 2] = m.z; mw[4 * j + 3] = m.w;
   }
+  __syncthreads();
+  unsigned marked = 0;
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const unsigned rm = (mw[i / 2] >> (16 * (i & 1))) & 0xffffu;
+    const bool mk = p0 + i < cols && key_of(s_h[rm], (unsigned)a * (unsigned)cols + rm) < klimit;
+    if (mk) marked |= 1u << i;
+    s_flag[p0 + i] = mk ? 1 : 0;
+  }
+  markbits[((int64_t)img * rows + a) * NT + threadIdx.x] = (unsigned short)marked;
+  __syncthreads();
   // runs of marked pixels at r >= rmin: segmented max-scan; the LAST pixel of a run holds the run's result
   const int rmin = min_range < 0 ? 0 : min_range;
   const SegMax ident{0ull, 0u, 0u};
@@ -642,30 +652,30 @@ __global__ __launch_bounds__(NT) void cen_extract(const uint8_t *__restrict__ im
   for (int i = 0; i < C; i++) {
     const int p = p0 + i;
     if (((marked >> i) & 1u) && p >= rmin) {
-      const bool start = p == rmin || !(s_flag[p - 1] & 1);
-      SegMax e{((unsigned long long)ord_f32(canon0(h[i])) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p), start ? 1u : 0u,
-               (unsigned)((s_flag[p] >> 1) & 1)};
-      loc = seg_max(loc, e);
+      const bool start = p == rmin || !s_flag[p - 1];
+      // adj carries the run's FIRST bin (a head sets it, the rest of the run keeps the head's)
+      SegMax e{((unsigned long long)ord_f32(canon0(h[i])) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p), start ? 1u : 0u, (unsigned)p};
+      loc = start ? e : SegMax{loc.v > e.v ? loc.v : e.v, loc.f, loc.adj};
     } else {
       loc = SegMax{0ull, 1u, 0u};
     }
     incl[i] = loc;
   }
-  const SegMax carry = block_excl_scan<NT, false>(loc, ident, seg_max, s_sw);
+  const SegMax carry = block_excl_scan<NT, false>(loc, ident, seg_first, s_sw);
   unsigned emit = 0;
-  int res[C];
+  uint2 res[C];
   bool seen_head = false;
 #pragma unroll
   for (int i = 0; i < C; i++) {
     const int p = p0 + i;
     const bool live = ((marked >> i) & 1u) && p >= rmin;
     SegMax v = incl[i];
-    if (!seen_head && !v.f) v = seg_max(carry, v);  // no head inside the thread's chunk yet: the carry's run continues
+    if (!seen_head && !v.f) v = seg_first(carry, v);  // no head inside the thread's chunk yet: the carry's run continues
     if (incl[i].f) seen_head = true;
     // a run only counts once an unmarked pixel closes it: a run that reaches the end of the row does not
-    if (live && p + 1 < cols && !(s_flag[p + 1] & 1) && v.adj) {
+    if (live && p + 1 < cols && !s_flag[p + 1]) {
       emit |= 1u << i;
-      res[i] = (int)(0xffffffffu - (unsigned)(v.v & 0xffffffffull));
+      res[i] = uint2{v.adj | ((unsigned)p << 16), 0xffffffffu - (unsigned)(v.v & 0xffffffffull)};  // first | last << 16, arg-max bin
     }
   }
   // ordered compaction
@@ -683,11 +693,58 @@ __global__ __launch_bounds__(NT) void cen_extract(const uint8_t *__restrict__ im
     total += s_cnt[w];
   }
   unsigned pos = before + inc - cnt;
-  int *ro = row_out + ((int64_t)img * rows + a) * row_cap;
+  uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
 #pragma unroll
   for (int i = 0; i < C; i++)
     if ((emit >> i) & 1u) ro[pos++] = res[i];
-  if (threadIdx.x == 0) row_n[(int64_t)img * rows + a] = total;
+  if (threadIdx.x == 0) row_nruns[(int64_t)img * rows + a] = total;
+}
+
+// the adjacency test of the method: a closed run yields a keypoint when the azimuth below or above (wrap-around) has a
+// marked pixel inside the run's range span.  One block per (azimuth, image) over the runs cen_runs recorded and the mark
+// bits of the two neighbours (C bits per 16-bit word); ordered compaction of the survivors' arg-max bins.
+template <int C, int NT>
+__global__ __launch_bounds__(256) void cen_adjacent(int rows, int row_cap, const uint2 *__restrict__ row_runs,
+                                                    const unsigned *__restrict__ row_nruns, const unsigned short *__restrict__ markbits,
+                                                    int *__restrict__ row_out, unsigned *__restrict__ row_n) {
+  __shared__ unsigned short s_nb[NT];  // marks of the two neighbours, OR-ed
+  __shared__ unsigned s_w[4];
+  const int a = blockIdx.x, img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned short *below = markbits + ((int64_t)img * rows + (a - 1 + rows) % rows) * NT;
+  const unsigned short *above = markbits + ((int64_t)img * rows + (a + 1) % rows) * NT;
+  for (int t = threadIdx.x; t < NT; t += 256) s_nb[t] = below[t] | above[t];
+  __syncthreads();
+  const unsigned n = row_nruns[(int64_t)img * rows + a];
+  const uint2 *runs = row_runs + ((int64_t)img * rows + a) * row_cap;
+  int *ro = row_out + ((int64_t)img * rows + a) * row_cap;
+  unsigned done = 0;
+  for (unsigned base = 0; base < n; base += 256) {
+    const unsigned j = base + threadIdx.x;
+    bool keep = false;
+    int arg = 0;
+    if (j < n) {
+      const uint2 r = runs[j];
+      const int first = (int)(r.x & 0xffffu), last = (int)(r.x >> 16);
+      arg = (int)r.y;
+      for (int wd = first / C; wd <= last / C && !keep; wd++) {
+        const int lo = wd == first / C ? first % C : 0, hi = wd == last / C ? last % C : C - 1;
+        const unsigned mask = ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
+        keep = (s_nb[wd] & mask) != 0;
+      }
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (lane == 0) s_w[wave] = (unsigned)__popcll(bal);
+    __syncthreads();
+    unsigned before = done, total = 0;
+    for (int w = 0; w < 4; w++) {
+      if (w < wave) before += s_w[w];
+      total += s_w[w];
+    }
+    if (keep) ro[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = arg;
+    done += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) row_n[(int64_t)img * rows + a] = done;
 }
 
 // one wavefront per (azimuth, image): row-major packing of the rows' keypoints, polar -> Cartesian
@@ -729,7 +786,7 @@ struct rsx_cen2019 {
   int device = 0, rows = 0, cols = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, marker, opener;
+  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, marker, opener, row_runs, row_nruns, markbits;
 };
 
 using rsx::fail;
@@ -751,9 +808,10 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
                      h->list.as<unsigned long long>(), (int64_t)rows * cols);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
-  hipLaunchKernelGGL((cen_extract<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->marker.as<unsigned short>(),
-                     p.min_range, row_cap,
-                     h->row_out.as<int>(), h->row_n.as<unsigned>());
+  hipLaunchKernelGGL((cen_runs<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->marker.as<unsigned short>(),
+                     p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(), h->markbits.as<unsigned short>());
+  hipLaunchKernelGGL((cen_adjacent<C, NT>), grid, dim3(256), 0, s, rows, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
+                     h->markbits.as<unsigned short>(), h->row_out.as<int>(), h->row_n.as<unsigned>());
   hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
                      resolution, max_targets, d_targets, d_xy, d_counts);
 }
@@ -773,9 +831,12 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     RSX_TRY(h->row_out.reserve((size_t)n * rows * row_cap * 4, s, false));
     RSX_TRY(h->row_n.reserve((size_t)n * rows * 4, s, false));
     {
-      const size_t nt = cols <= 16 * 256 ? 256 : 1024;  // threads per row block: marker rows are padded to 16 * nt bins
-      RSX_TRY(h->marker.reserve((size_t)n * rows * nt * 16 * 2, s, false));
+      const size_t nt = cols <= 8 * 512 ? 512 : 1024, cc = cols <= 8 * 512 ? 8 : 16;  // threads per row block x bins per thread: marker rows are padded
+      RSX_TRY(h->marker.reserve((size_t)n * rows * nt * cc * 2, s, false));
       RSX_TRY(h->opener.reserve((size_t)n * rows * nt * 2, s, false));
+      RSX_TRY(h->markbits.reserve((size_t)n * rows * nt * 2, s, false));
+      RSX_TRY(h->row_runs.reserve((size_t)n * rows * row_cap * 8, s, false));
+      RSX_TRY(h->row_nruns.reserve((size_t)n * rows * 4, s, false));
     }
     RSX_HIP(hipMemsetAsync(h->scal.p, 0, (size_t)n * sizeof(Scal), s));
     RSX_HIP(hipMemsetAsync(h->hist.p, 0, (size_t)n * NBIN * 4, s));
@@ -784,8 +845,9 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     float *pxy = d_xy ? d_xy + (int64_t)b0 * max_targets * 2 : nullptr;
     const float *azp = d_az ? d_az + (int64_t)b0 * az_stride : nullptr;
     int *cn = d_counts ? d_counts + b0 : nullptr;
-    if (cols <= 16 * 256)
-      launch_chain<16, 256>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
+    // <= 4096 bins: 512 threads x 8 bins (about 100 VGPRs: four waves per SIMD; 256 x 16 needs 176: two); wider rows: 1024 x 16
+    if (cols <= 8 * 512)
+      launch_chain<8, 512>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     else
       launch_chain<16, 1024>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     RSX_HIP(hipGetLastError());
@@ -830,7 +892,7 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->marker, &h->opener}) b->release();
+  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->marker, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
