@@ -387,8 +387,9 @@ typedef struct {
   int32_t cart_pixel_width; /* W: the Cartesian image is W x W, centred on the sensor (964) */
   float cart_resolution;    /* metres per pixel (0.2592) */
   float ratio;              /* default nearest-neighbour distance ratio of rsx_frontend_match callers (0.8) */
-  int32_t reserved;
+  int32_t flags;            /* RSX_FRONTEND_*; 0 = default */
 } rsx_frontend_params;
+#define RSX_FRONTEND_THREE_PASS 1 /* remap, blur rows, blur columns as three kernels instead of one fused tile kernel (same images) */
 
 int rsx_frontend_default_params(rsx_frontend_params *p);
 /* one handle per polar image shape (rows azimuths x cols range bins) */

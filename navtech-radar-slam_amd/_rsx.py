@@ -66,7 +66,7 @@ class IcpResult(C.Structure):
 
 
 class FrontendParams(C.Structure):
-    _fields_ = [("cart_pixel_width", C.c_int32), ("cart_resolution", C.c_float), ("ratio", C.c_float), ("reserved", C.c_int32)]
+    _fields_ = [("cart_pixel_width", C.c_int32), ("cart_resolution", C.c_float), ("ratio", C.c_float), ("flags", C.c_int32)]
 
 
 class Cen2019Params(C.Structure):

@@ -80,6 +80,74 @@ __global__ __launch_bounds__(256) void fe_blur(const float *__restrict__ ins, in
   out[i] = s;
 }
 
+// fe_remap + both passes of fe_blur in ONE kernel (the batched path): a block produces a 32 x 32 tile of the Cartesian image
+// and of its smoothed copy from a 38 x 38 remapped neighbourhood in LDS (halo 3 = the 7-tap kernel; coordinates outside
+// the image are reflected, BORDER_REFLECT_101, before the remap -- the same pixels the separate passes read).  Same
+// arithmetic per pixel in the same order, so the two images are bit-identical to the three-kernel form; HBM traffic per
+// scan drops from 3 writes + 2 reads of 3.7 MB to 2 writes.
+constexpr int FT = 32, FH = 3, FTS = FT + 2 * FH;
+__global__ __launch_bounds__(256) void fe_cart_fused(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int row_stride,
+                                                     int col_offset, int W, const float *__restrict__ map_rb, const float *__restrict__ map_ab,
+                                                     const float *__restrict__ g, float *__restrict__ carts, float *__restrict__ blurs) {
+  __shared__ float s_c[FTS][FTS + 1];
+  __shared__ float s_t[FTS][FT + 1];
+  const uint8_t *img = imgs + (int64_t)blockIdx.z * img_stride;
+  float *cart = carts + (int64_t)blockIdx.z * W * W, *blur = blurs + (int64_t)blockIdx.z * W * W;
+  const int tu0 = blockIdx.x * FT, tv0 = blockIdx.y * FT;
+  float gk[7];
+#pragma unroll
+  for (int t = 0; t < 7; t++) gk[t] = g[t];
+  for (int idx = threadIdx.x; idx < FTS * FTS; idx += 256) {
+    const int ly = idx / FTS, lx = idx - ly * FTS;
+    int v = tv0 + ly - FH, u = tu0 + lx - FH;
+    const bool inner = ly >= FH && ly < FH + FT && lx >= FH && lx < FH + FT && v < W && u < W;
+    if (v < 0) v = -v;
+    if (v >= W) v = 2 * W - 2 - v;
+    if (u < 0) u = -u;
+    if (u >= W) u = 2 * W - 2 - u;
+    if (v < 0) v = 0;  // (tiles hanging far over the edge of a tiny image: values unused)
+    if (u < 0) u = 0;
+    const int64_t i = (int64_t)v * W + u;
+    const float rb = map_rb[i], ab = map_ab[i];
+    const float r0f = floorf(rb), a0f = floorf(ab);
+    const float fr = rb - r0f, fa = ab - a0f;
+    const int r0 = (int)r0f;
+    int a0 = (int)a0f;
+    if (a0 >= rows) a0 -= rows;
+    const int a1 = (a0 + 1 == rows) ? 0 : a0 + 1;
+    float p[2][2];
+#pragma unroll
+    for (int da = 0; da < 2; da++)
+#pragma unroll
+      for (int dr = 0; dr < 2; dr++) {
+        const int r = r0 + dr, a = da ? a1 : a0;
+        p[da][dr] = (r >= 0 && r < cols) ? __fdiv_rn((float)img[(int64_t)a * row_stride + col_offset + r], 255.0f) : 0.0f;
+      }
+    const float top = p[0][0] + fr * (p[0][1] - p[0][0]);
+    const float bot = p[1][0] + fr * (p[1][1] - p[1][0]);
+    const float c = top + fa * (bot - top);
+    s_c[ly][lx] = c;
+    if (inner) cart[i] = c;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < FTS * FT; idx += 256) {  // rows first (horizontal taps, added left to right)
+    const int ly = idx / FT, lx = idx - ly * FT;
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 7; t++) sum = sum + gk[t] * s_c[ly][lx + t];
+    s_t[ly][lx] = sum;
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < FT * FT; idx += 256) {  // then columns
+    const int ly = idx / FT, lx = idx - ly * FT;
+    const int v = tv0 + ly, u = tu0 + lx;
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 7; t++) sum = sum + gk[t] * s_t[ly + t][lx];
+    if (v < W && u < W) blur[(int64_t)v * W + u] = sum;
+  }
+}
+
 // metric keypoints (x forward, y right) -> nearest Cartesian pixel (u, v), in double like the host form of
 // rsx_frontend_describe: blockIdx.y = image, xy [image][stride][2], counts[image] keypoints each
 __global__ __launch_bounds__(256) void fe_uv(const float *__restrict__ xy, const int32_t *__restrict__ counts, int stride, double cmr,
@@ -232,6 +300,10 @@ __global__ __launch_bounds__(256) void fe_compact_valid(const uint8_t *__restric
 // [slot][stride] arrays), blockIdx.z = direction: 0 queries = slot A against train = slot B -> fwd[j][i], 1 the reverse
 // -> bwd[j][i].  Queries and train descriptors are taken from the compacted lists of valid keypoints (ascending index, so
 // "the first minimum wins" is the scan order of fe_match / BFMatcher); invalid queries get -1.
+// FOUR LANES PER QUERY: a block of 256 threads takes 64 queries, lane part p scans entries p, p + 4, ... of every train
+// tile and the four partial (d1, i1, d2) are merged under the order of the sequential scan (smaller distance, then the
+// smaller train index) -- a lone thread per query scanning 800 descriptors left most of the chip idle.
+constexpr int FM_Q = 64;  // queries per block
 __global__ __launch_bounds__(256) void fe_match_consecutive(const uint32_t *__restrict__ descs, const uint8_t *__restrict__ valids,
                                                             const int32_t *__restrict__ counts, int stride, int first,
                                                             const int32_t *__restrict__ vidx, const int32_t *__restrict__ vcount, float ratio,
@@ -241,46 +313,58 @@ __global__ __launch_bounds__(256) void fe_match_consecutive(const uint32_t *__re
   const int j = blockIdx.y, dir = blockIdx.z;
   const int qs = j + dir, ts = j + 1 - dir;  // slots relative to `first`
   const int nq = counts[first + qs] < stride ? counts[first + qs] : stride;
-  if ((int)blockIdx.x * 256 >= nq) return;
-  const int nqv = vcount[qs], ntv = vcount[ts];
   const uint32_t *q = descs + (int64_t)(first + qs) * stride * 8, *t = descs + (int64_t)(first + ts) * stride * 8;
   const int32_t *qi = vidx + (int64_t)qs * stride, *ti = vidx + (int64_t)ts * stride;
   int32_t *out_idx = (dir ? bwd : fwd) + (int64_t)j * stride;
-  {
-    const int i = blockIdx.x * 256 + threadIdx.x;  // keypoints without a descriptor match nothing
-    if (i < nq && !valids[(int64_t)(first + qs) * stride + i]) out_idx[i] = -1;
-  }
-  if ((int)blockIdx.x * 256 >= nqv) return;
-  const int jq = blockIdx.x * 256 + threadIdx.x;
-  const bool live = jq < nqv;
-  const int iq = live ? qi[jq] : 0;
-  uint32_t me[8];
+  // keypoints without a descriptor match nothing: block b clears the invalid ones among keypoints [256 b, 256 b + 256)
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < nq; i += gridDim.x * 256)
+    if (!valids[(int64_t)(first + qs) * stride + i]) out_idx[i] = -1;
+  const int nqv = vcount[qs], ntv = vcount[ts];
+  for (int q0 = blockIdx.x * FM_Q; q0 < nqv; q0 += gridDim.x * FM_Q) {  // (uniform per block)
+    const int jq = q0 + (threadIdx.x >> 2), part = threadIdx.x & 3;
+    const bool live = jq < nqv;
+    const int iq = live ? qi[jq] : 0;
+    uint32_t me[8];
 #pragma unroll
-  for (int w = 0; w < 8; w++) me[w] = live ? q[(int64_t)iq * 8 + w] : 0u;
-  int d1 = 1 << 30, d2 = 1 << 30, i1 = -1;
-  for (int j0 = 0; j0 < ntv; j0 += 256) {
-    __syncthreads();
-    const int jt = j0 + threadIdx.x;
-    const int it = jt < ntv ? ti[jt] : 0;
+    for (int w = 0; w < 8; w++) me[w] = live ? q[(int64_t)iq * 8 + w] : 0u;
+    int d1 = 1 << 30, d2 = 1 << 30, i1 = 0x7fffffff;
+    for (int j0 = 0; j0 < ntv; j0 += 256) {
+      __syncthreads();
+      const int jt = j0 + threadIdx.x;
+      const int it = jt < ntv ? ti[jt] : 0;
 #pragma unroll
-    for (int w = 0; w < 8; w++) st[threadIdx.x * 8 + w] = jt < ntv ? t[(int64_t)it * 8 + w] : 0u;
-    si[threadIdx.x] = it;
-    __syncthreads();
-    const int lim = ntv - j0 < 256 ? ntv - j0 : 256;
-    for (int jj = 0; jj < lim; jj++) {  // ascending train index: the first minimum wins, like BFMatcher's scan
-      int d = 0;
+      for (int w = 0; w < 8; w++) st[threadIdx.x * 8 + w] = jt < ntv ? t[(int64_t)it * 8 + w] : 0u;
+      si[threadIdx.x] = it;
+      __syncthreads();
+      const int lim = ntv - j0 < 256 ? ntv - j0 : 256;
+      for (int jj = part; jj < lim; jj += 4) {  // ascending train index within this lane's share
+        int d = 0;
 #pragma unroll
-      for (int w = 0; w < 8; w++) d += __popc(me[w] ^ st[jj * 8 + w]);
-      if (d < d1) {
-        d2 = d1;
-        d1 = d;
-        i1 = si[jj];
-      } else if (d < d2) {
-        d2 = d;
+        for (int w = 0; w < 8; w++) d += __popc(me[w] ^ st[jj * 8 + w]);
+        if (d < d1) {
+          d2 = d1;
+          d1 = d;
+          i1 = si[jj];
+        } else if (d < d2) {
+          d2 = d;
+        }
       }
     }
+    // merge the four shares: the sequential scan keeps the smallest distance with the smallest train index (train
+    // indices ascend along the list, each lane saw its share in order) and the second smallest distance overall
+#pragma unroll
+    for (int o = 1; o <= 2; o <<= 1) {
+      const int od1 = __shfl_xor(d1, o), od2 = __shfl_xor(d2, o), oi1 = __shfl_xor(i1, o);
+      const bool mine_first = d1 < od1 || (d1 == od1 && i1 < oi1);
+      const int nd2 = mine_first ? (d2 < od1 ? d2 : od1) : (od2 < d1 ? od2 : d1);
+      if (!mine_first) {
+        d1 = od1;
+        i1 = oi1;
+      }
+      d2 = nd2;
+    }
+    if (live && part == 0) out_idx[iq] = (d1 < (1 << 30) && d2 < (1 << 30) && (float)d1 < ratio * (float)d2) ? i1 : -1;
   }
-  if (live) out_idx[iq] = (i1 >= 0 && d2 < (1 << 30) && (float)d1 < ratio * (float)d2) ? i1 : -1;
 }
 
 }  // namespace
@@ -295,6 +379,7 @@ struct rsx_frontend {
   double map_radar_res = -1.0, map_az0 = 0.0, map_az_step = 0.0;
   bool have_image = false;
   int batch_n = 0;  // Cartesian images held by the last rsx_frontend_cartesian* call
+  bool three_pass = false;  // RSX_FRONTEND_THREE_PASS: remap and the two blur passes as separate kernels
 };
 
 using rsx::fail;
@@ -352,7 +437,7 @@ int rsx_frontend_default_params(rsx_frontend_params *p) {
   p->cart_pixel_width = 964;   // yeti / ORORA defaults for the Navtech CIR204-H (recollection, parameterised)
   p->cart_resolution = 0.2592f;
   p->ratio = 0.8f;
-  p->reserved = 0;
+  p->flags = 0;
   return RSX_OK;
 }
 
@@ -374,6 +459,7 @@ int rsx_frontend_create(int device, int32_t rows, int32_t cols, const rsx_fronte
   h->cols = cols;
   h->W = dp.cart_pixel_width;
   h->cart_res = (double)dp.cart_resolution;
+  h->three_pass = (dp.flags & RSX_FRONTEND_THREE_PASS) != 0;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -450,14 +536,20 @@ static int cartesian_device(rsx_frontend *h, const uint8_t *d_imgs, int n, int64
   const int W = h->W;
   const size_t npx = (size_t)W * W;
   RSX_TRY(h->cart.reserve(npx * sizeof(float) * n, s, false));
-  RSX_TRY(h->tmp.reserve(npx * sizeof(float) * n, s, false));
+  if (h->three_pass) RSX_TRY(h->tmp.reserve(npx * sizeof(float) * n, s, false));
   RSX_TRY(h->blur.reserve(npx * sizeof(float) * n, s, false));
-  const dim3 grid((unsigned)((npx + 255) / 256), (unsigned)n);
   const float *g = reinterpret_cast<const float *>(static_cast<const char *>(h->tables.p) + TAB_GAUSS);
-  hipLaunchKernelGGL(fe_remap, grid, dim3(256), 0, s, d_imgs, img_stride, h->rows, h->cols, row_stride, col_offset, W, h->map_rb.as<float>(),
-                     h->map_ab.as<float>(), h->cart.as<float>());
-  hipLaunchKernelGGL(fe_blur<true>, grid, dim3(256), 0, s, h->cart.as<float>(), W, g, h->tmp.as<float>());
-  hipLaunchKernelGGL(fe_blur<false>, grid, dim3(256), 0, s, h->tmp.as<float>(), W, g, h->blur.as<float>());
+  if (h->three_pass) {  // the round-2 form (kept for the parity test of the fused kernel): remap, blur rows, blur columns
+    const dim3 grid((unsigned)((npx + 255) / 256), (unsigned)n);
+    hipLaunchKernelGGL(fe_remap, grid, dim3(256), 0, s, d_imgs, img_stride, h->rows, h->cols, row_stride, col_offset, W, h->map_rb.as<float>(),
+                       h->map_ab.as<float>(), h->cart.as<float>());
+    hipLaunchKernelGGL(fe_blur<true>, grid, dim3(256), 0, s, h->cart.as<float>(), W, g, h->tmp.as<float>());
+    hipLaunchKernelGGL(fe_blur<false>, grid, dim3(256), 0, s, h->tmp.as<float>(), W, g, h->blur.as<float>());
+  } else {
+    const dim3 grid((unsigned)((W + FT - 1) / FT), (unsigned)((W + FT - 1) / FT), (unsigned)n);
+    hipLaunchKernelGGL(fe_cart_fused, grid, dim3(256), 0, s, d_imgs, img_stride, h->rows, h->cols, row_stride, col_offset, W,
+                       h->map_rb.as<float>(), h->map_ab.as<float>(), g, h->cart.as<float>(), h->blur.as<float>());
+  }
   RSX_HIP(hipGetLastError());
   h->have_image = true;
   h->batch_n = n;
@@ -555,7 +647,7 @@ int rsx_frontend_match_consecutive_device(rsx_frontend *h, const uint8_t *d_desc
   RSX_TRY(h->vcount.reserve((size_t)(n_pairs + 1) * 4, s, false));
   hipLaunchKernelGGL(fe_compact_valid, dim3((unsigned)(n_pairs + 1)), dim3(256), 0, s, d_valid, d_counts, max_targets, first_slot,
                      h->vidx.as<int32_t>(), h->vcount.as<int32_t>());
-  hipLaunchKernelGGL(fe_match_consecutive, dim3((unsigned)((max_targets + 255) / 256), (unsigned)n_pairs, 2), dim3(256), 0, s,
+  hipLaunchKernelGGL(fe_match_consecutive, dim3((unsigned)((max_targets + FM_Q - 1) / FM_Q < 32 ? (max_targets + FM_Q - 1) / FM_Q : 32), (unsigned)n_pairs, 2), dim3(256), 0, s,
                      reinterpret_cast<const uint32_t *>(d_desc), d_valid, d_counts, max_targets, first_slot, h->vidx.as<int32_t>(),
                      h->vcount.as<int32_t>(), ratio, d_fwd, d_bwd);
   RSX_HIP(hipGetLastError());

@@ -16,11 +16,13 @@ def fe():
     return frontend
 
 
-@pytest.mark.parametrize("W,res", [(964, 0.2592), (501, 0.5)])
-def test_frontend_bit_exact(fe, oracle, W, res):
+@pytest.mark.parametrize("W,res,flags", [(964, 0.2592, 0), (501, 0.5, 0), (964, 0.2592, 1), (70, 3.0, 0)])
+def test_frontend_bit_exact(fe, oracle, W, res, flags):
+    """flags = 1 (RSX_FRONTEND_THREE_PASS): remap / blur rows / blur columns as separate kernels; default: the fused tile
+    kernel.  Both must give the oracle's images (W = 70: tiles that hang over the image edge, reflected halos everywhere)."""
     rows, cols = 400, 3360
     p = fe.default_params()
-    p.cart_pixel_width, p.cart_resolution = W, res
+    p.cart_pixel_width, p.cart_resolution, p.flags = W, res, flags
     g = fe.Frontend(rows, cols, params=p)
     o = oracle.FrontendRef(rows, cols, W, res)
     descs = []
