@@ -96,12 +96,13 @@ struct rsx_odometry {
   int device = 0, rows = 0, cols = 0;
   rsx_odometry_params prm{};
   std::mutex mu;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipEvent_t ev_up = nullptr;
   rsx_cen2019 *cen = nullptr;
   rsx_frontend *fe = nullptr;
   rsx_orora *reg = nullptr;
   // slot 0 = the previous scan (carried over between windows), slots 1 .. MAX_WINDOW = the window
-  rsx::DevBuf imgs, az, targets, xy, counts, desc, valid, fwd, bwd, stage_src, stage_dst, pair_cnt, src, dst, offsets, results;
+  rsx::DevBuf imgs, imgs2, az, targets, xy, counts, desc, valid, fwd, bwd, stage_src, stage_dst, pair_cnt, src, dst, offsets, results;
   void *h_pin = nullptr;  // pinned: counts[MAX_WINDOW + 1], pair_cnt[MAX_WINDOW], results[MAX_WINDOW]
   bool have_prev = false;
 };
@@ -134,9 +135,9 @@ int reserve_all(rsx_odometry *h, size_t ibytes, hipStream_t s) {
   return RSX_OK;
 }
 
-// one window of n <= MAX_WINDOW scans whose images are at d_imgs (device); fills out[0..n)
-int run_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, const float *azimuths,
-               int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy, hipStream_t s) {
+// one window of n <= MAX_WINDOW scans whose images are at d_imgs (device): every launch and the result copies, asynchronous
+int enqueue_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, const float *azimuths,
+                   int32_t azimuths_per_image, hipStream_t s) {
   const int K = h->prm.max_keypoints;
   const size_t slot_xy = (size_t)K * 2;
   // azimuths: the Cartesian map needs them on the host (first image's grid), cen2019's polar -> Cartesian on the device
@@ -167,6 +168,15 @@ int run_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_stride
     RSX_HIP(hipMemcpyAsync(pin + PIN_PAIRS, h->pair_cnt.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s));
     RSX_HIP(hipMemcpyAsync(pin + PIN_RES, h->results.p, (size_t)n_pairs * sizeof(rsx_orora_result), hipMemcpyDeviceToHost, s));
   }
+  return RSX_OK;
+}
+
+// wait for the window enqueued last, fill out[0..n) (+ the keypoints), hand the last scan over to the next window
+int finish_window(rsx_odometry *h, int n, rsx_odometry_scan *out, float *out_xy, int32_t max_xy, hipStream_t s) {
+  const int K = h->prm.max_keypoints;
+  const size_t slot_xy = (size_t)K * 2;
+  int32_t *d_counts = h->counts.as<int32_t>();
+  char *pin = static_cast<char *>(h->h_pin);
   RSX_HIP(hipStreamSynchronize(s));
   const int32_t *hc = reinterpret_cast<const int32_t *>(pin + PIN_COUNTS), *hp = reinterpret_cast<const int32_t *>(pin + PIN_PAIRS);
   const rsx_orora_result *hr = reinterpret_cast<const rsx_orora_result *>(pin + PIN_RES);
@@ -197,6 +207,12 @@ int run_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_stride
   RSX_HIP(hipMemcpyAsync(h->counts.p, d_counts + n, 4, hipMemcpyDeviceToDevice, s));
   h->have_prev = true;
   return RSX_OK;
+}
+
+int run_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, const float *azimuths,
+               int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy, hipStream_t s) {
+  RSX_TRY(enqueue_window(h, d_imgs, n, img_stride, row_stride, azimuths, azimuths_per_image, s));
+  return finish_window(h, n, out, out_xy, max_xy, s);
 }
 
 int check_layout(rsx_odometry *h, int32_t n, int64_t image_stride_bytes, int32_t row_stride) {
@@ -243,6 +259,8 @@ int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t
   if (st == RSX_OK) {
     hipError_t e = hipSetDevice(p.device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming);
     if (e == hipSuccess) e = hipHostMalloc(&h->h_pin, PIN_BYTES, hipHostMallocDefault);
     if (e != hipSuccess) st = fail(e == hipErrorOutOfMemory ? RSX_ERR_OOM : RSX_ERR_HIP, "odometry create: %s", hipGetErrorString(e));
   }
@@ -258,13 +276,16 @@ int rsx_odometry_destroy(rsx_odometry *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (rsx::DevBuf *b : {&h->imgs, &h->az, &h->targets, &h->xy, &h->counts, &h->desc, &h->valid, &h->fwd, &h->bwd, &h->stage_src, &h->stage_dst,
+  if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
+  for (rsx::DevBuf *b : {&h->imgs, &h->imgs2, &h->az, &h->targets, &h->xy, &h->counts, &h->desc, &h->valid, &h->fwd, &h->bwd, &h->stage_src, &h->stage_dst,
                          &h->pair_cnt, &h->src, &h->dst, &h->offsets, &h->results})
     b->release();
   if (h->h_pin) (void)hipHostFree(h->h_pin);
   rsx_cen2019_destroy(h->cen);
   rsx_frontend_destroy(h->fe);
   rsx_orora_destroy(h->reg);
+  if (h->ev_up) (void)hipEventDestroy(h->ev_up);
+  if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
@@ -307,16 +328,34 @@ int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int
   hipStream_t s = h->stream;
   const size_t ibytes = (size_t)h->rows * row_stride;
   RSX_TRY(reserve_all(h, ibytes, s));
-  for (int b0 = 0; b0 < n_scans; b0 += MAX_WINDOW) {
-    const int n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
+  // two image buffers: the upload of window w + 1 (copy stream) runs while the kernels of window w do (compute stream)
+  struct CopyDone {  // the caller's host images must not be in flight when this call returns, error or not
+    hipStream_t cs;
+    ~CopyDone() { (void)hipStreamSynchronize(cs); }
+  } copy_done{h->copy_stream};
+  RSX_TRY(h->imgs2.reserve(n_scans > MAX_WINDOW ? ibytes * MAX_WINDOW : 0, s, false));
+  auto upload = [&](int b0, int n, void *dst) -> int {
     const uint8_t *src = imgs + (int64_t)b0 * image_stride_bytes;
     if (n == 1 || image_stride_bytes == (int64_t)ibytes) {
-      RSX_HIP(hipMemcpyAsync(h->imgs.p, src, ibytes * n, hipMemcpyHostToDevice, s));
+      RSX_HIP(hipMemcpyAsync(dst, src, ibytes * n, hipMemcpyHostToDevice, h->copy_stream));
     } else {
-      RSX_HIP(hipMemcpy2DAsync(h->imgs.p, ibytes, src, (size_t)image_stride_bytes, ibytes, (size_t)n, hipMemcpyHostToDevice, s));
+      RSX_HIP(hipMemcpy2DAsync(dst, ibytes, src, (size_t)image_stride_bytes, ibytes, (size_t)n, hipMemcpyHostToDevice, h->copy_stream));
     }
-    RSX_TRY(run_window(h, h->imgs.as<uint8_t>(), n, (int64_t)ibytes, row_stride, azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0),
-                       azimuths_per_image, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy, s));
+    RSX_HIP(hipEventRecord(h->ev_up, h->copy_stream));
+    return RSX_OK;
+  };
+  void *bufs[2] = {h->imgs.p, h->imgs2.p};
+  RSX_TRY(upload(0, n_scans < MAX_WINDOW ? n_scans : MAX_WINDOW, bufs[0]));
+  int w = 0;
+  for (int b0 = 0; b0 < n_scans; b0 += MAX_WINDOW, w++) {
+    const int n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
+    RSX_HIP(hipStreamWaitEvent(s, h->ev_up, 0));
+    RSX_TRY(enqueue_window(h, static_cast<const uint8_t *>(bufs[w & 1]), n, (int64_t)ibytes, row_stride,
+                           azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0), azimuths_per_image, s));
+    const int b1 = b0 + MAX_WINDOW;
+    // (buffer (w + 1) & 1 was read by window w - 1, which finish_window has already waited for)
+    if (b1 < n_scans) RSX_TRY(upload(b1, n_scans - b1 < MAX_WINDOW ? n_scans - b1 : MAX_WINDOW, bufs[(w + 1) & 1]));
+    RSX_TRY(finish_window(h, n, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy, s));
   }
   return RSX_OK;
 }
