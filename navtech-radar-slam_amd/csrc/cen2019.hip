@@ -387,6 +387,18 @@ __device__ __forceinline__ unsigned row_opens(RowLds<C, NT> &L, const RowRegs<C,
   return opens;
 }
 
+// llrint((double)hv * 2^40) for |hv| <= 1 without fp64: x = hv * 2^40 is exact in fp32 (a power-of-two scaling);
+// |x| < 2^31: round to nearest even in fp32 and convert (exact); otherwise x is an integer multiple of 2^8
+// (24-bit significand at magnitude >= 2^31): convert x / 2^8 and shift back
+__device__ __forceinline__ long long fix40(float hv) {
+  const float x = hv * 1099511627776.0f;
+  const float ax = fabsf(x);
+  const long long small = (long long)__float2int_rn(x);
+  const float q = ax * 0.00390625f;  // |hv| = 1 exactly gives q = 2^32: outside uint32
+  const long long big = q >= 4294967296.0f ? (1ll << 40) : (long long)((unsigned long long)__float2uint_rz(q) << 8);
+  return ax < 2147483648.0f ? small : (x < 0.0f ? -big : big);
+}
+
 __device__ __forceinline__ int h_bin(float hv) {  // monotone non-decreasing in h
   const int b = (int)floorf(__fmul_rn(__fadd_rn(canon0(hv), 1.0f), 2048.0f));
   return b < 0 ? 0 : (b > NBIN - 1 ? NBIN - 1 : b);
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
 #pragma unroll
   for (int i = 0; i < C; i++) {
     if (threadIdx.x * C + i < cols) {
-      fix += __double2ll_rn((double)R.h[i] * FIX);
+      fix += fix40(R.h[i]);
       if ((opens >> i) & 1u) atomicAdd(&s_hist[h_bin(R.h[i])], 1u);
     }
   }
@@ -552,6 +564,19 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
     return;
   }
   const unsigned n = sc->n_list;
+  if (n <= 256) {
+    // the usual case (a few dozen openers in the bin): every thread takes one key and counts the smaller ones; the key
+    // of rank t - 1 is K* (keys are distinct).  One global load per thread, n broadcast LDS reads, no passes.
+    __shared__ unsigned long long s_k[256];
+    const unsigned long long mine = threadIdx.x < n ? list[threadIdx.x] : KINF;
+    s_k[threadIdx.x] = mine;
+    __syncthreads();
+    unsigned rank = 0;
+    for (unsigned i = 0; i < n; i++) rank += s_k[i] < mine ? 1u : 0u;
+    const unsigned t = (unsigned)max_points - sc->above;
+    if (threadIdx.x < n && rank == t - 1u) sc->klimit = (mine == KINF || mine + 1ull > kmean) ? kmean : mine + 1ull;
+    return;
+  }
   // MSD radix select (8 x 8 bits) of the t-th smallest key of the list, t 1-based
   if (threadIdx.x == 0) {
     s_prefix = 0ull;

@@ -91,6 +91,9 @@ __global__ __launch_bounds__(256) void fe_cart_fused(const uint8_t *__restrict__
                                                      const float *__restrict__ g, float *__restrict__ carts, float *__restrict__ blurs) {
   __shared__ float s_c[FTS][FTS + 1];
   __shared__ float s_t[FTS][FT + 1];
+  __shared__ float s_tab[256];  // byte -> byte / 255 (correctly rounded once per block instead of four divisions per pixel)
+  s_tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
+  __syncthreads();
   const uint8_t *img = imgs + (int64_t)blockIdx.z * img_stride;
   float *cart = carts + (int64_t)blockIdx.z * W * W, *blur = blurs + (int64_t)blockIdx.z * W * W;
   const int tu0 = blockIdx.x * FT, tv0 = blockIdx.y * FT;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void fe_cart_fused(const uint8_t *__restrict__
 #pragma unroll
       for (int dr = 0; dr < 2; dr++) {
         const int r = r0 + dr, a = da ? a1 : a0;
-        p[da][dr] = (r >= 0 && r < cols) ? __fdiv_rn((float)img[(int64_t)a * row_stride + col_offset + r], 255.0f) : 0.0f;
+        p[da][dr] = (r >= 0 && r < cols) ? s_tab[img[(int64_t)a * row_stride + col_offset + r]] : 0.0f;
       }
     const float top = p[0][0] + fr * (p[0][1] - p[0][0]);
     const float bot = p[1][0] + fr * (p[1][1] - p[1][0]);
