@@ -792,6 +792,8 @@ def main():
     ap.add_argument("--data", choices=["trajectory", "random"], default="trajectory",
                     help="headline DB: descriptors built from a synthetic drive (default) or the round-1 random descriptors")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world 1")
+    ap.add_argument("--all-layouts", action="store_true",
+                    help="N > 1: time the mixed query-groups x DB-shards layouts too (default: the two pure ones and the headline)")
     ap.add_argument("--query-groups", type=int, default=0,
                     help="layout = query groups x DB shards (sharded.py); 0 = auto (as many query groups as the batch feeds), 1 = pure DB shards")
     args = ap.parse_args()
@@ -897,6 +899,8 @@ def main():
         lay = {}
         st_l = max(3, args.steps // 4)
         for qg in [d for d in range(1, world + 1) if world % d == 0]:
+            if qg not in (1, world, qgroups) and not args.all_layouts:
+                continue   # mixed layouts need torch.distributed subgroups: opt-in (--all-layouts); gloo-tested, never run on RCCL
             if qg == qgroups:
                 lay[main_wl.ssc.layout] = {"ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank], "headline": True}
                 continue

@@ -56,7 +56,9 @@ class ShardedScanContext:
         self.n_qgroups, self.shard_world = q, self.world // q
         self.qgroup, self.shard_rank = self.rank // self.shard_world, self.rank % self.shard_world
         self.shard_group, self.col_group = group, None
-        if q > 1:
+        if q > 1 and self.shard_world == 1:
+            self.shard_group, self.col_group = None, group     # pure query parallelism: the only exchange is over everybody
+        elif q > 1:
             # torch.distributed: every rank creates every subgroup, in the same order
             ranks = list(range(self.world)) if group is None else dist.get_process_group_ranks(group)
             s_w = self.shard_world
