@@ -140,3 +140,31 @@ def test_file_entry_on_a_moving_sensor(tmp_path, sequence, chain):
     print("crawl, nn :", nn[-1, 1:4], "matches", nn[1:, 5], "\ncrawl, orb:", orb[-1, 1:4], "matches", orb[1:, 5], "\ntruth     :", slow_poses[-1])
     for est in (nn, orb):
         assert np.hypot(*(est[-1, 1:3] - slow_poses[-1, :2])) < 0.25 and abs(est[-1, 3] - slow_poses[-1, 2]) < 1e-2
+
+
+def test_degenerate_scans(sequence, oracle):
+    """A blank scan in the middle of a sequence (no keypoints, no matches: ORORA reports status 1 for both pairs that
+    touch it and the pose is not advanced), a constant one, and a keypoint cap smaller than the scans' keypoint counts:
+    the pipeline must agree with the oracle chain run under the same cap, and must not read or write out of bounds."""
+    from navtech_radar_slam_amd import odometry
+    from oracle import odometry_chain
+    imgs, az, poses, stamps = sequence
+    seq = imgs[:5].copy()
+    seq[2, :, 11:] = 0
+    seq[3, :, 11:] = 77
+    od = odometry.Odometry(400, 3360)
+    res, xy = od.push(seq, az, want_xy=True)
+    chain = odometry_chain.run(seq, az, resolution=synth.RADAR_RESOLUTION)
+    assert res["n_keypoints"].tolist() == [c["n_keypoints"] for c in chain] and res["n_keypoints"][2] == 0 and res["n_keypoints"][3] == 0
+    assert res["n_matches"].tolist() == [c["n_matches"] for c in chain]
+    assert res["status"].tolist() == [3, 0, 1, 1, 1] and len(xy[2]) == 0
+    p = odometry.default_params()
+    p.max_keypoints = 512
+    small = odometry.Odometry(400, 3360, params=p)
+    r2 = small.push(imgs[:4], az)
+    c2 = odometry_chain.run(imgs[:4], az, resolution=synth.RADAR_RESOLUTION, max_keypoints=512)
+    assert r2["n_keypoints"].tolist() == [c["n_keypoints"] for c in c2] and min(r2["n_keypoints"]) > 512   # the true counts are reported
+    assert r2["n_matches"].tolist() == [c["n_matches"] for c in c2]
+    for i in range(1, 4):
+        w = c2[i]["result"]
+        assert r2["status"][i] == w["status"] and max(abs(r2[f][i] - w[f]) for f in ("x", "y", "yaw")) < 1e-4
