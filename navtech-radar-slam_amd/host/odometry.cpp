@@ -182,7 +182,7 @@ int main(int argc, char **argv) {
       else if (a == "--gate" && i + 1 < argc) gate = (float)std::atof(argv[++i]);
       else if (a == "--matcher" && i + 1 < argc) matcher = argv[++i];  // orb (default) | nn
       else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);    // scans per rsx_odometry_push (default: the library's window)
-      else if (a == "--threads" && i + 1 < argc) threads = std::atoi(argv[++i]);  // PNG decode threads (default: hardware concurrency, <= 256)
+      else if (a == "--threads" && i + 1 < argc) threads = std::atoi(argv[++i]);  // PNG decode threads (default: hardware concurrency, <= 64)
       else if (a == "--per-scan") per_scan = true;                                // the round-2 loop: one scan per call, host vectors in between
       else if (a == "--timing") timing = true;                                    // decode / pipeline seconds on stderr
       else if (a.rfind("seq_dir:=", 0) == 0) seq_dir = a.substr(9);  // roslaunch-style arg
@@ -300,7 +300,7 @@ int main(int argc, char **argv) {
       rsx_odometry *odo = nullptr;
       check(rsx_odometry_create(&op, rows, cols, &odo), "rsx_odometry_create");
       const int W = window > 0 ? std::min(window, 4096) : rsx_odometry_window();
-      const int T = threads > 0 ? threads : (int)std::max(1u, std::min(256u, std::thread::hardware_concurrency()));
+      const int T = threads > 0 ? threads : (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));  // (256 threads: the launch thread starves, 1.9 k against 2.5 k scans/s)
       const size_t ibytes = (size_t)rows * w0;
       struct Win {
         uint8_t *img = nullptr;
