@@ -23,8 +23,12 @@ def _check(got, want):
     for f in ("x", "y", "yaw"):
         assert np.abs(got[f][ok] - want[f][ok]).max() < POSE_TOL, f
     assert np.array_equal(got["iterations"], want["iterations"])
-    assert np.abs(got["rot_inliers"] - want["rot_inliers"]).max() <= 1
-    assert np.abs(got["trans_inliers"] - want["trans_inliers"]).max() <= 1
+    # inlier counts are thresholded quantities (TIM weight >= 0.5; |v - t| <= beta): the GPU sums in another order, poses agree
+    # to ~4e-15, so a count could only differ for a weight / residual within ~1e-14 of its threshold.  The kernels' reduction
+    # orders are fixed, so the outcome on given data is deterministic: on these data sets the counts are EQUAL (rounds 1-2
+    # allowed +-1 here without saying why)
+    assert np.array_equal(got["rot_inliers"], want["rot_inliers"])
+    assert np.array_equal(got["trans_inliers"], want["trans_inliers"])
 
 
 def test_batch_matches_oracle(reg, oracle):
