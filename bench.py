@@ -181,8 +181,8 @@ class Workload:
         prof, resc = (0, 0.0), (0, 0)
         if profile and not ctx.stub:
             prof = self.mgr.profile_read()
-            c, e, _ = self.mgr.profile_read_rescoring2()
-            resc = (e, c)
+            self.resc3 = self.mgr.profile_read_rescoring3()
+            resc = (self.resc3[1], self.resc3[0])
             self.mgr.profile_enable(False)
         per_rank = ctx.all_gather_float(dt)
         return max(per_rank), per_rank, prof, resc
@@ -890,6 +890,10 @@ def main():
             out["roofline"] = roof
             out["exact_evals_per_query"] = evals / max(1, nq * args.steps)
             out["previewed_candidates_per_query"] = cands / max(1, nq * args.steps)
+            r3 = getattr(main_wl, "resc3", None)
+            if r3:  # who served them: the matrix-core window kernel (sc_window.hip) or the per-wavefront VALU alignment + preview
+                out["window_previews_per_query"] = r3[3] / max(1, nq * args.steps)
+                out["valu_previews_per_query"] = r3[4] / max(1, nq * args.steps)
             if planted_ok is not None:
                 out["planted_loops_recovered"] = planted_ok
 

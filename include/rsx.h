@@ -234,6 +234,16 @@ int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t
  * out_lb - rsx_sc_filter_eps() <= the exact distance, for every pair. */
 int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out_lb);
 double rsx_sc_filter_eps(void);
+/* diagnostic entry of the stage between the filter and the exact re-scoring (csrc/sc_window.hip): for each query the first
+ * RSX_SC_WINDOW_P entries of its short list (local slots in ascending filter-bound order, -1 past the end; out_counts[q] of
+ * them are valid) with the sector-key alignment k* (fastAlignUsingVkey, reference SC.cpp:93-113) and the fp16 matrix-core
+ * preview pv of distanceBtnScanContext (SC.cpp:116-148): |pv - distance| <= RSX_SC_WINDOW_MARGIN; pv = NaN where the
+ * kernel declines (alignment not unique within its error bound, non-finite data), +inf where no shift of the window has
+ * an effective column.  All outputs are [nq][RSX_SC_WINDOW_P] host arrays. */
+#define RSX_SC_WINDOW_P 128
+#define RSX_SC_WINDOW_MARGIN 1.25e-3f
+int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t *out_slots, float *out_pv, int32_t *out_kstar,
+                           int32_t *out_counts);
 /* merge nparts per-shard top-k lists (layout [part][nq][k]) into out[nq][k]; pure host logic */
 int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out);
 /* the same on the GPU (d_parts is what an RCCL all-gather of d_out produces) */
@@ -291,6 +301,9 @@ int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms);
 int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored);
 /* the same plus the number of candidates that went through the cheap phase (alignment + fp32 preview) */
 int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored);
+/* out5 = {candidates, exact_evals, queries_rescored, candidates whose alignment + preview came from the matrix-core window
+ * kernel, candidates that went through the per-wavefront alignment + fp32 preview} */
+int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out5);
 
 /* ============================== ORORA registration ======================================
  * Replaces the solver stage of the upstream file-based `odometry.cpp` entry (reference

@@ -106,7 +106,7 @@ SYMBOLS = [
     "rsx_sc_query_stage2_device", "rsx_sc_query_self_device",
     "rsx_sc_pair_distances", "rsx_sc_filter_bounds", "rsx_sc_filter_eps", "rsx_sc_profiled_kernel_name",
     "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
-    "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read", "rsx_sc_profile_read_rescoring", "rsx_sc_profile_read_rescoring2",
+    "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read", "rsx_sc_profile_read_rescoring", "rsx_sc_profile_read_rescoring2", "rsx_sc_profile_read_rescoring3", "rsx_sc_window_previews",
     "rsx_scs_create", "rsx_scs_create_layout", "rsx_scs_num_query_groups", "rsx_scs_destroy", "rsx_scs_num_shards", "rsx_scs_set_dist_thres", "rsx_scs_size",
     "rsx_scs_add_points", "rsx_scs_add_descriptors_f32", "rsx_scs_get_descriptor", "rsx_scs_query",
     "rsx_scs_detect_loop_closure",
@@ -187,6 +187,8 @@ def lib():
         L.rsx_sc_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl)]
         L.rsx_sc_profile_read_rescoring.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
         L.rsx_sc_profile_read_rescoring2.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+        L.rsx_sc_profile_read_rescoring3.argtypes = [vp, C.POINTER(i64)]
+        L.rsx_sc_window_previews.argtypes = [vp, vp, i32, vp, vp, vp, vp]
         L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
         L.rsx_scs_create.argtypes = [C.POINTER(ScParams), C.POINTER(i32), i32, C.POINTER(vp)]
         L.rsx_scs_create_layout.argtypes = [C.POINTER(ScParams), C.POINTER(i32), i32, i32, i32, C.POINTER(vp)]

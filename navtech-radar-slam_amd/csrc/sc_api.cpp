@@ -34,6 +34,7 @@ struct rsx_sc {
   DevBuf desc, vkey, norm, rkey;
   DevBuf hn, cmask;  // fp16 filter image (tile-major) + column masks (sc_filter.hip)
   DevBuf sp, sp_aux; // fp16 spectral filter image + per-entry error-budget scalar (sc_spec.hip)
+  DevBuf hnr, vk16, vk_n;  // entry-major fp16 image + fp16 hi/lo sector keys and their norms (sc_window.hip)
   // detector state (SC.h:104,117-120)
   int tree_counter = 0;
   int64_t tree_size = 0;
@@ -51,6 +52,7 @@ struct rsx_sc {
   // workspaces
   DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
   DevBuf f_qimg, f_lb, f_cand, f_cnt, f_thr, f_plan;  // filter path
+  DevBuf f_wimg, f_win;                               // window previews of the short lists (sc_window.hip)
   PairProfiler prof;
   const char *prof_kernel = "sc_pair_kernel";  // which kernel the profiler events bracket
   // state between rsx_sc_query_stage1_device and rsx_sc_query_stage2_device
@@ -87,6 +89,9 @@ int ensure_capacity(rsx_sc *h, int64_t want_local) {
   RSX_TRY(h->cmask.reserve((size_t)nc * sizeof(uint64_t), h->stream, true));
   RSX_TRY(h->sp.reserve((size_t)nc * SPEC_DB_BYTES_PER_ENTRY, h->stream, true));
   RSX_TRY(h->sp_aux.reserve((size_t)nc * sizeof(float), h->stream, true));
+  RSX_TRY(h->hnr.reserve((size_t)nc * FILTER_DB_BYTES_PER_ENTRY, h->stream, true));
+  RSX_TRY(h->vk16.reserve((size_t)nc * 256, h->stream, true));
+  RSX_TRY(h->vk_n.reserve((size_t)nc * 2 * sizeof(float), h->stream, true));
   h->cap = nc;
   return RSX_OK;
 }
@@ -101,6 +106,9 @@ DbView db_view(const rsx_sc *h) {
   v.cmask = h->cmask.as<uint64_t>();
   v.spT = h->sp.p;
   v.sp_aux = h->sp_aux.as<float>();
+  v.hnR = h->hnr.p;
+  v.vk16 = h->vk16.p;
+  v.vk_n = h->vk_n.as<float>();
   v.n_local = h->n_local;
   v.idx_base = h->p.shard_rank;
   v.idx_stride = h->p.shard_world;
@@ -109,7 +117,8 @@ DbView db_view(const rsx_sc *h) {
 
 // both filter images + column masks of local slots [slot, slot+count); synchronises s
 int build_db_images(rsx_sc *h, int64_t slot, int64_t count, hipStream_t s) {
-  RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->hn.p, h->cmask.as<uint64_t>(), s));
+  RSX_TRY(launch_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->hn.p, h->hnr.p, h->cmask.as<uint64_t>(), s));
+  RSX_TRY(launch_window_db_keys(h->vkey.as<double>(), slot, count, h->vk16.p, h->vk_n.as<float>(), s));
   RSX_TRY(launch_spec_db_images(h->desc.as<float>(), h->norm.as<double>(), slot, count, h->sp.p, h->sp_aux.as<float>(), s));
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
@@ -251,7 +260,18 @@ int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
   RSX_TRY(h->f_cand.reserve((size_t)qb * RESCORE_SHORTLIST_CAP * sizeof(RescoreEntry), s, false));
   RSX_TRY(h->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
   RSX_TRY(h->f_thr.reserve((size_t)qb * RESCORE_THR_STRIDE * sizeof(float), s, false));
+  RSX_TRY(h->f_wimg.reserve(window_qimg_bytes((int32_t)qb), s, false));
+  RSX_TRY(h->f_win.reserve((size_t)qb * WINDOW_P * sizeof(WindowPreview), s, false));
   return RSX_OK;
+}
+
+// RSX_SC_WINDOW=0 (experiments build): re-scoring without the matrix-core window previews
+bool use_window() {
+  static const bool on = [] {
+    const char *e = rsx::exp_env("RSX_SC_WINDOW");
+    return !(e && e[0] == '0');
+  }();
+  return on;
 }
 
 // images -> MFMA filter -> short list + round edges of one query batch
@@ -266,8 +286,12 @@ int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_
     const bool planned = elig_monotone && elig != nullptr;
     RSX_TRY(run_filter(h, q, n_items, lb, ld, planned ? &plan : nullptr, s));
   }
-  return launch_select(db, lb, ld, n_items, q.nq, n_eligible, elig, first_target, h->f_cand.as<RescoreEntry>(),
-                       h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), s);
+  RSX_TRY(launch_select(db, lb, ld, n_items, q.nq, n_eligible, elig, first_target, h->f_cand.as<RescoreEntry>(),
+                        h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), s));
+  // alignment + window preview of the head of every short list on the matrix cores (what re-scoring would otherwise
+  // do on the VALU, one entry per wavefront)
+  if (!use_window()) return RSX_OK;
+  return launch_window(db, q, h->f_wimg.p, h->f_cand.as<RescoreEntry>(), h->f_cnt.as<int32_t>(), h->f_win.as<WindowPreview>(), s);
 }
 
 int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig, int32_t round_begin,
@@ -276,7 +300,8 @@ int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, 
   const int64_t ld = (n_items + 31) / 32 * 32;
   return launch_rescore(db_view(h), q, h->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
                         h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), filter_eps(), round_begin, round_end, tau_src,
-                        seed, d_out, k, s, (h->prof.on && h->stats.p) ? h->stats.as<unsigned long long>() : nullptr);
+                        seed, d_out, k, s, (h->prof.on && h->stats.p) ? h->stats.as<unsigned long long>() : nullptr,
+                        use_window() ? h->f_win.as<WindowPreview>() : nullptr);
 }
 
 // exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> short list ->
@@ -595,7 +620,7 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial, &h->stats, &h->helper_ws, &h->tree.nodes, &h->tree.vind,
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->hnr, &h->vk16, &h->vk_n, &h->f_wimg, &h->f_win, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial, &h->stats, &h->helper_ws, &h->tree.nodes, &h->tree.vind,
                     &h->tree_batch.nodes, &h->tree_batch.vind}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
                     &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
@@ -1232,6 +1257,42 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
 
 double rsx_sc_filter_eps(void) { return filter_eps(); }
 
+int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t *out_slots, float *out_pv, int32_t *out_kstar,
+                           int32_t *out_counts) {
+  if (!h || !q_descs || !out_slots || !out_pv || !out_kstar || !out_counts || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  hipStream_t s = h->stream;
+  const int64_t n = h->n_local;
+  for (int32_t q = 0; q < nq; q++) out_counts[q] = 0;
+  if (n == 0) return RSX_OK;
+  RSX_TRY(h->q_desc.reserve((size_t)nq * DS * sizeof(float), s, false));
+  RSX_HIP(hipMemcpyAsync(h->q_desc.p, q_descs, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, s));
+  QueryView qv;
+  RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), nq, s, &qv));
+  RSX_TRY(filter_reserve(h, n, nq, s));
+  RSX_HIP(hipMemsetAsync(h->f_win.p, 0xff, (size_t)nq * WINDOW_P * sizeof(WindowPreview), s));
+  RSX_TRY(filter_and_select(h, qv, n, h->n_global, nullptr, 128, s));
+  std::vector<RescoreEntry> sl((size_t)nq * RESCORE_SHORTLIST_CAP);
+  std::vector<WindowPreview> wp((size_t)nq * WINDOW_P);
+  std::vector<int32_t> cnt((size_t)nq);
+  RSX_HIP(hipMemcpyAsync(sl.data(), h->f_cand.p, sl.size() * sizeof(RescoreEntry), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipMemcpyAsync(wp.data(), h->f_win.p, wp.size() * sizeof(WindowPreview), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipMemcpyAsync(cnt.data(), h->f_cnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  for (int32_t q = 0; q < nq; q++) {
+    const int32_t c = cnt[(size_t)q] < WINDOW_P ? cnt[(size_t)q] : WINDOW_P;
+    out_counts[q] = c;
+    for (int32_t i = 0; i < WINDOW_P; i++) {
+      const size_t o = (size_t)q * WINDOW_P + i;
+      out_slots[o] = i < c ? sl[(size_t)q * RESCORE_SHORTLIST_CAP + i].slot : -1;
+      out_pv[o] = wp[o].pv;
+      out_kstar[o] = wp[o].ks;
+    }
+  }
+  return RSX_OK;
+}
+
 int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out) {
   if (!parts || !out || nparts < 1 || nq < 1 || k < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   for (int q = 0; q < nq; q++) {
@@ -1293,11 +1354,20 @@ int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *quer
 
 int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored) {
   if (!h || !candidates || !exact_evals || !queries_rescored) return fail(RSX_ERR_BAD_ARG, "null arg");
+  int64_t v[5];
+  RSX_TRY(rsx_sc_profile_read_rescoring3(h, v));
+  *candidates = v[0];
+  *exact_evals = v[1];
+  *queries_rescored = v[2];
+  return RSX_OK;
+}
+
+int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out5) {
+  if (!h || !out5) return fail(RSX_ERR_BAD_ARG, "null arg");
+  int64_t *candidates = out5, *exact_evals = out5 + 1, *queries_rescored = out5 + 2;
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
-  *candidates = 0;
-  *exact_evals = 0;
-  *queries_rescored = 0;
+  for (int i = 0; i < 5; i++) out5[i] = 0;
   if (!h->stats.p) return RSX_OK;
   RSX_HIP(hipDeviceSynchronize());  // the counters are bumped by kernels on the caller's stream
   unsigned long long v[16] = {0};
@@ -1310,6 +1380,8 @@ int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exac
   *candidates = (int64_t)v[0];
   *exact_evals = v[2] ? (int64_t)v[2] : (int64_t)v[0];  // one-pass scoring: every candidate is an exact evaluation
   *queries_rescored = (int64_t)v[1];
+  out5[3] = (int64_t)v[3];   // candidates whose alignment + preview came from the window kernel (sc_window.hip)
+  out5[4] = (int64_t)v[11];  // candidates that went through the VALU alignment + fp32 preview
   return RSX_OK;
 }
 

@@ -84,6 +84,8 @@ constexpr float kAccScale = 1073741824.0f;            // 2^30 carried by the acc
 constexpr u64 kNonFinite = 1ull << 63;
 
 static_assert(FILTER_QIMG_BYTES == 9984, "layout");
+static_assert(QIMG_ODD == FILTER_QIMG_ODD && QIMG_EVEN_CHUNKS * 16 == FILTER_QIMG_MASK_OFF && kAccScale == FILTER_ACC_SCALE,
+              "sc_window.hip reads the same query image");
 static_assert(F_PHASE_BYTES % 1024 == 0, "phase must be whole 1 KiB DMA pieces");
 
 __device__ __forceinline__ void wave_lds_fence() {
@@ -116,7 +118,7 @@ __device__ __forceinline__ void normalise_column(const float *__restrict__ d, do
 __global__ __launch_bounds__(256) void sc_img_db_kernel(const float *__restrict__ desc,
                                                         const double *__restrict__ norm, int64_t first,
                                                         int64_t count, uint4 *__restrict__ hnT,
-                                                        u64 *__restrict__ cmask) {
+                                                        uint4 *__restrict__ hnR, u64 *__restrict__ cmask) {
   __shared__ __attribute__((aligned(16))) _Float16 st[4][DS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t it = (int64_t)blockIdx.x * 4 + wave;
@@ -132,6 +134,7 @@ __global__ __launch_bounds__(256) void sc_img_db_kernel(const float *__restrict_
   for (int c = lane; c < 2 * F_STEPS; c += 64) {
     const uint4 v = *reinterpret_cast<const uint4 *>(&st[wave][c * 8]);
     hnT[(tile * F_STEPS + (c >> 1)) * 64 + (c & 1) * 32 + col] = v;
+    hnR[slot * (2 * F_STEPS) + c] = v;  // the same image entry-major (sc_window.hip gathers single entries)
   }
   if (lane == 0) cmask[slot] = m;
 }
@@ -720,11 +723,11 @@ double filter_eps() {
 
 size_t filter_qimg_bytes(int32_t nq) { return (size_t)nq * FILTER_QIMG_BYTES + 1024; }
 
-int launch_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *hnT, uint64_t *cmask,
-                     hipStream_t s) {
+int launch_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *hnT, void *hnR,
+                     uint64_t *cmask, hipStream_t s) {
   if (count <= 0) return RSX_OK;
   hipLaunchKernelGGL(sc_img_db_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, desc, norm, first, count,
-                     static_cast<uint4 *>(hnT), reinterpret_cast<u64 *>(cmask));
+                     static_cast<uint4 *>(hnT), static_cast<uint4 *>(hnR), reinterpret_cast<u64 *>(cmask));
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

@@ -23,6 +23,9 @@ struct DbView {
   const uint64_t *cmask;  // [n_local] bit j = column j has a non-zero norm; bit 63 = non-finite element
   const void *spT;     // spectral filter image: fp16 Z15 spectra, tile-major (sc_spec.hip); 2432 B per entry
   const float *sp_aux; // [n_local] sqrt of the spectral energy outside f = 0 (error budget of the spectral filter)
+  const void *hnR;     // the fp16 filter image once more, entry-major [n_local][1200] (sc_window.hip gathers single entries)
+  const void *vk16;    // [n_local][128] fp16: sector key scaled by a power of two, hi[64] | lo[64] (sc_window.hip)
+  const float *vk_n;   // [n_local][2] l2 norm of the scaled key (NaN: no matrix-core alignment for this entry), of the key
   int64_t n_local;
   int64_t idx_base;    // global index of local slot s = idx_base + s * idx_stride
   int64_t idx_stride;
@@ -74,6 +77,7 @@ constexpr int RESCORE_NUM_THR = 6;           // round edges t_0..t_4 and t_cap
 // per query: RESCORE_NUM_THR float edges, then RESCORE_NUM_THR int32 counts (short-list entries below each edge:
 // the list is ordered by bin, so round r is the range [count[r-1], count[r]))
 constexpr int RESCORE_THR_STRIDE = 2 * RESCORE_NUM_THR;
+struct WindowPreview;
 struct RescoreEntry {
   float lb;      // filter bound
   int32_t slot;  // local DB slot
@@ -94,7 +98,7 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
                    int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
                    const float *thr, double eps, int32_t round_begin, int32_t round_end, const rsx_sc_hit *tau_src,
                    const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s,
-                   unsigned long long *d_stats = nullptr);
+                   unsigned long long *d_stats = nullptr, const WindowPreview *win = nullptr);
 
 // the same job by one wave per query walking the short list in ascending-bound order (needs the short list
 // ordered by histogram bin, which launch_select produces); single-shard, single-stage
@@ -104,11 +108,14 @@ int launch_walk(const DbView &db, const QueryView &q, const float *lb, int64_t l
 
 // ---- MFMA lower-bound filter (sc_filter.hip) ----
 constexpr int FILTER_QIMG_BYTES = 9984;  // LDS image of one query (two displaced fp16 copies)
+constexpr int FILTER_QIMG_ODD = 4960;    // byte offset of the copy read by odd shifts (holds q2[4..]); = 96 mod 256
+constexpr int FILTER_QIMG_MASK_OFF = 4928;  // the query's column mask (u64) sits in the gap between the copies
+constexpr float FILTER_ACC_SCALE = 1073741824.0f;  // 2^30: both fp16 images are scaled by 2^15
 constexpr int FILTER_DB_BYTES_PER_ENTRY = 2 * DS;
 double filter_eps();
 size_t filter_qimg_bytes(int32_t nq);
 // fp16 filter images of local slots [first, first+count) (needs their norms)
-int launch_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *hnT,
+int launch_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *hnT, void *hnR,
                      uint64_t *cmask, hipStream_t s);
 int launch_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, hipStream_t s);
 // lb[q*ld_lb + slot] = lower bound of dist(query q, local slot), slots [0, n_items); +inf when no
@@ -140,6 +147,25 @@ int launch_spec_query_images(const float *desc, const double *norm, int32_t nq, 
 int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
                        const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s);
 const char *spec_filter_kernel_name();
+
+// ---- window previews of the short lists on the matrix cores (sc_window.hip) ----
+// For the first WINDOW_P short-list entries of every query: the sector-key alignment k* (SC.cpp:93-113) from an fp16
+// hi/lo-split correlation (unique within its error bound, else "no preview") and the fp16 direct-form correlation of
+// the two images evaluated over the window k* +- 3 only: pv with |pv - dist(query, entry)| <= WINDOW_MARGIN.  The
+// re-scoring kernel uses (k*, pv) instead of its own VALU alignment + fp32 preview.
+constexpr int WINDOW_P = RSX_SC_WINDOW_P;               // short-list positions per query that get a window preview
+constexpr float WINDOW_MARGIN = RSX_SC_WINDOW_MARGIN;   // same arithmetic as the direct filter: its error budget (sc_filter.hip)
+constexpr int WINDOW_QK_BYTES = 4624;       // key image of a query (sc_window.hip)
+struct WindowPreview {
+  float pv;    // NaN: no preview (ambiguous alignment, non-finite data); +inf: no effective column in the window
+  int32_t ks;  // k*
+};
+size_t window_qimg_bytes(int32_t nq);  // direct-filter images + key images of a query batch
+int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void *vk16, float *vk_n, hipStream_t s);
+// qimg: window_qimg_bytes(nq) of workspace (filled here); out: [nq][WINDOW_P]
+int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
+                  WindowPreview *out, hipStream_t s);
+const char *window_kernel_name();
 
 // ---- the reference's public helper methods on arbitrary double descriptors (sc_helpers.hip) ----
 // op 0: keys of d_a (out_d = ring key [20] + sector key [60]); 1: distDirectSC(d_a, d_b) -> out_d[0];

@@ -1,0 +1,388 @@
+// sc_window.hip -- window previews of the re-scoring short lists on the matrix cores (gfx950 / CDNA4).
+//
+// Where it sits.  The lower-bound filter (sc_spec.hip / sc_filter.hip) gives every (query, entry) pair the minimum of
+// the column-cosine distance over ALL 60 shifts; sc_select_kernel turns a query's row of bounds into a short list in
+// ascending-bound order; sc_rescore_kernel then needs, for every short-list entry it looks at,
+//     k*  = the sector-key alignment of the pair (fastAlignUsingVkey, SC.cpp:93-113) and
+//     pv ~= dist(query, entry) = min over the 7 shifts k* - 3 .. k* + 3 of d_k (SC.cpp:116-148)
+// to decide which few entries deserve the exact fp64 evaluation.  Rounds 1-2 computed both on the VALU, one entry per
+// wavefront (phase_a in sc_kernels.hip: ~650 issue slots per entry, 137 entries per query: 73 % of the re-scoring
+// kernel).  Both are circular correlations of the query with the entry -- GEMMs whose A operand is a circulant of the
+// query -- so for the first WINDOW_P entries of every short list they are computed here, 32 entries per wavefront:
+//   * alignment: KC[k] = sum_j vkey_q[(j + k) % 60] * vkey_e[j], K = 64, keys scaled by a power of two and split into
+//     fp16 hi + lo (hi*hi + hi*lo + lo*hi: 24 v_mfma_f32_32x32x16_f16 for 2 x 32 shifts x 32 entries).  argmin_k of
+//     ||vkey_q - shift_k(vkey_e)|| = argmax_k KC[k] (the two squared norms do not depend on k).  The maximum is taken
+//     as k* only when it is UNIQUE within the error bound of KC (below); otherwise the entry gets "no preview" and the
+//     re-scoring kernel runs its own alignment (fp32, then the exact fp64 form with the reference's tie rule).
+//   * preview: S[k][e] = sum_i q2[i + 20 k] * e[i], K = 1200, exactly the direct filter's GEMM (same fp16 images, same
+//     circulant addressing of the query image in LDS, same epilogue arithmetic) -- 150 MFMAs per 32 entries -- but the
+//     epilogue takes the minimum of d_k = 1 - S_k / n_eff(k) over the window of k* only.  |pv - dist| <= WINDOW_MARGIN
+//     (= the direct filter's error budget, sc_filter.hip: 2u + u^2 from the fp16 operands + 1200 * 2^-23 from the fp32
+//     accumulation + epilogue < 1.13e-3; shifts without an effective column are ignored on both sides).
+// Cost: 8192 queries x 128 entries = 1 M pairs at 174 MFMAs per 32 = 0.18 Tflop: ~0.1 ms of matrix-core time against
+// the ~1.2 ms of VALU time it replaces.  The entries are gathered (2400 + 256 B each, whole rows of the entry-major
+// image hnR): 2.8 GB per batch out of a 27 MB database image, i.e. from L2 / MALL.
+//
+// Error bound of KC (scaled keys x, max |x| in [2^9, 2^10); E = sum x^2):
+//   representation  x = hi + lo + r, |r| <= 2^-22 |x| (+ 2^-25 absolute where lo is subnormal)
+//   dropped lo*lo   <= 2^-22 |x||y| per term
+//   fp32 accumulation of 3 x 64 products in 12 chained MFMAs: <= 192 * 2^-23 relative to sum |terms| <= sqrt(E_q E_e)
+//   total < (2.29e-5 + 4 * 2.4e-7) sqrt(E_q E_e);  kWinAlignEps = 3e-5 with sqrt(E) rounded up.
+// Two quirks of the reference's search bound where this applies (split_key / `balanced` below): it starts from a best
+// distance of 1e7 (keys with norms >= 4e6 are declined), and it works in fp64 on UNSCALED keys (pairs whose key norms
+// differ by more than 1e6 are declined).
+// A shift other than the true argmax can only reach KC_max - 2 eps sqrt(E_q E_e) when the true values are that close,
+// so a unique candidate above that line IS the reference's argmin (whose fp64 arithmetic is off by < 1e-13 relative).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "rsx_common.h"
+#include "sc_kernels.h"
+
+namespace rsx {
+namespace sc {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+constexpr float kWinAlignEps = 3e-5f;
+constexpr double kWinMaxKeyNorm = 4.0e6;
+constexpr u64 kNonFinite = 1ull << 63;
+constexpr int W_STEPS = DS / 16;            // 75 K-steps of the image GEMM
+constexpr int W_TILE1 = 40;                 // tile 1 (shifts 32..63) reads the A fragment 40 K-steps further on
+constexpr int QK_COPY = 288;                // one displaced copy of the doubled key: 120 halves + pad; 18 slots = 2 mod 16
+constexpr int QK_LO = 8 * QK_COPY;          // 2304: the lo copies
+constexpr int QK_NORM = 2 * QK_LO;          // 4608: float sqrt(E_q) (NaN: no matrix-core alignment), then padding
+static_assert(QK_NORM + 16 == WINDOW_QK_BYTES, "layout");
+constexpr int W_LDS = FILTER_QIMG_BYTES + WINDOW_QK_BYTES;  // 14608
+
+// scaled hi/lo split of one 60-element sector key held one element per lane (lanes >= 60: 0)
+struct KeySplit {
+  _Float16 hi, lo;
+  float nrm;   // sqrt(sum x^2), rounded up; NaN when the key has a non-finite element or is too large (below)
+  float unrm;  // the same of the unscaled key
+};
+__device__ __forceinline__ KeySplit split_key(double v, int lane) {
+  const double av = lane < NS ? fabs(v) : 0.0;
+  double mx = av;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const double o = __shfl_xor(mx, off);
+    mx = (o > mx || !(o == o)) ? o : mx;  // a NaN wins
+  }
+  KeySplit r;
+  r.hi = (_Float16)0.0f;
+  r.lo = (_Float16)0.0f;
+  r.nrm = __builtin_nanf("");
+  r.unrm = __builtin_nanf("");
+  if (!(mx < INFINITY)) return r;  // NaN / inf somewhere (uniform)
+  int e = 0;
+  if (mx > 0.0) {
+    (void)frexp(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
+    e = 10 - e;           // scaled maximum in [2^9, 2^10)
+  }
+  const double x = lane < NS ? ldexp(v, e) : 0.0;
+  const _Float16 hi = (_Float16)(float)x;
+  const _Float16 lo = (_Float16)(float)(x - (double)(float)hi);
+  double s = x * x;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  r.hi = hi;
+  r.lo = lo;
+  r.nrm = (float)(sqrt(s) * (1.0 + 1e-6));
+  // the reference's search starts from min_veq_norm = 1e7 (SC.cpp:100-106: a shift whose key distance is not below
+  // that is never taken, and if none is the alignment stays 0).  ||vkey_q - shift(vkey_e)|| <= ||vkey_q|| + ||vkey_e||:
+  // with both norms below 4e6 the test passes for every shift and the argmin is the plain argmin; larger keys are
+  // left to the exact alignment of the re-scoring kernel
+  const double un = ldexp(sqrt(s), -e);
+  if (!(un < kWinMaxKeyNorm)) r.nrm = __builtin_nanf("");
+  r.unrm = (float)un;
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// database side: [slot][hi 0..63 | lo 0..63] fp16 (elements 60..63 zero: the K padding) + the key's scaled norm
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sc_win_db_keys_kernel(const double *__restrict__ vkey, int64_t first, int64_t count,
+                                                             _Float16 *__restrict__ vk16, float *__restrict__ vk_n) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t it = (int64_t)blockIdx.x * 4 + wave;
+  if (it >= count) return;
+  const int64_t slot = first + it;
+  const KeySplit k = split_key(lane < NS ? vkey[slot * NS + lane] : 0.0, lane);
+  vk16[slot * 128 + lane] = k.hi;
+  vk16[slot * 128 + 64 + lane] = k.lo;
+  if (lane == 0) {
+    vk_n[2 * slot] = k.nrm;
+    vk_n[2 * slot + 1] = k.unrm;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// query side: row k of the circulant reads the doubled key q2[k .. k + 63] (q2[i] = key[i % 60]); 8 copies displaced
+// by one element each keep that read 16-byte aligned (row k: copy k % 8 at element k - k % 8), and the copy stride
+// of 18 sixteen-byte slots keeps the 16 rows a ds_read_b128 serves together on 16 different slots mod 16
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sc_win_query_keys_kernel(const double *__restrict__ vkey, int32_t nq,
+                                                                char *__restrict__ qk) {
+  __shared__ _Float16 st[4][2][128];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + wave;
+  if (q >= nq) return;
+  const KeySplit k = split_key(lane < NS ? vkey[(int64_t)q * NS + lane] : 0.0, lane);
+  if (lane < NS) {
+    st[wave][0][lane] = k.hi;
+    st[wave][1][lane] = k.lo;
+    st[wave][0][lane + NS] = k.hi;
+    st[wave][1][lane + NS] = k.lo;
+  }
+  if (lane < 8) {
+    st[wave][0][2 * NS + lane] = (_Float16)0.0f;
+    st[wave][1][2 * NS + lane] = (_Float16)0.0f;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  char *out = qk + (int64_t)q * WINDOW_QK_BYTES;
+  for (int i = lane; i < 2 * 8 * (QK_COPY / 2); i += 64) {
+    const int part = i / (8 * (QK_COPY / 2));
+    const int r = i % (8 * (QK_COPY / 2));
+    const int c = r / (QK_COPY / 2), el = r % (QK_COPY / 2);
+    const int src = c + el;  // copy c holds q2[c + el]
+    const _Float16 v = src < 2 * NS ? st[wave][part][src] : (_Float16)0.0f;
+    *reinterpret_cast<_Float16 *>(out + part * QK_LO + c * QK_COPY + el * 2) = v;
+  }
+  if (lane < 4) *reinterpret_cast<float *>(out + QK_NORM + lane * 4) = lane == 0 ? k.nrm : (lane == 1 ? k.unrm : 0.0f);
+}
+
+// ------------------------------------------------------------------------------------------
+// the window kernel: one workgroup per query, wave w takes short-list positions 32 w .. 32 w + 31 (then + 128, ...)
+// ------------------------------------------------------------------------------------------
+struct WindowArgs {
+  const char *hnR;
+  const char *vk16;
+  const float *vk_n;
+  const u64 *cmask;
+  const char *qimg;   // [nq][FILTER_QIMG_BYTES]
+  const char *qkimg;  // [nq][WINDOW_QK_BYTES]
+  const RescoreEntry *slist;
+  const int32_t *sl_cnt;
+  WindowPreview *out;
+};
+
+// shift of accumulator register R of tile TL in lane half hh
+__host__ __device__ constexpr int row_of(int tl, int r) { return 32 * tl + (r & 3) + 8 * (r >> 2); }
+
+__global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int qi = blockIdx.x;
+  const int cnt_all = a.sl_cnt[qi];
+  const int cnt = cnt_all < WINDOW_P ? cnt_all : WINDOW_P;
+  if (cnt <= 0) return;  // uniform
+  {
+    const uint4 *g0 = reinterpret_cast<const uint4 *>(a.qimg + (int64_t)qi * FILTER_QIMG_BYTES);
+    const uint4 *g1 = reinterpret_cast<const uint4 *>(a.qkimg + (int64_t)qi * WINDOW_QK_BYTES);
+    uint4 *l = reinterpret_cast<uint4 *>(smem);
+    for (int i = threadIdx.x; i < W_LDS / 16; i += 256) l[i] = i < FILTER_QIMG_BYTES / 16 ? g0[i] : g1[i - FILTER_QIMG_BYTES / 16];
+  }
+  __syncthreads();
+  const int n = lane & 31, hh = lane >> 5;
+  const RescoreEntry *sl = a.slist + (int64_t)qi * RESCORE_SHORTLIST_CAP;
+  const u64 qm = *reinterpret_cast<const u64 *>(smem + FILTER_QIMG_MASK_OFF);
+  const float nq_key = *reinterpret_cast<const float *>(smem + FILTER_QIMG_BYTES + QK_NORM);
+  const float uq_key = *reinterpret_cast<const float *>(smem + FILTER_QIMG_BYTES + QK_NORM + 4);
+  // A-fragment addresses of this lane's row (shift n of tile 0; tile 1 = the same address + 40 K-steps, sc_filter.hip)
+  const char *ap = smem + ((n & 1) ? (FILTER_QIMG_ODD + 40 * n - 8) : (40 * n)) + 16 * hh;
+  const char *kp = smem + FILTER_QIMG_BYTES + (n & 7) * QK_COPY + ((n & ~7) + 8 * hh) * 2;  // tile 1: + 64 B
+
+  for (int base = wave * 32; base < cnt; base += 128) {
+    const int pos = base + n;
+    const bool have = pos < cnt;
+    const int64_t slot = sl[have ? pos : base].slot;
+
+    // ---- alignment: 2 tiles x (hi*hi + hi*lo + lo*hi) x 4 K-steps ----
+    floatx16 k0 = {0}, k1 = {0};
+    {
+      const char *bk = a.vk16 + slot * 256 + 16 * hh;
+      half8 bh[4], bl[4];
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        bh[s] = *reinterpret_cast<const half8 *>(bk + 32 * s);
+        bl[s] = *reinterpret_cast<const half8 *>(bk + 128 + 32 * s);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const half8 ah0 = *reinterpret_cast<const half8 *>(kp + 32 * s);
+        const half8 al0 = *reinterpret_cast<const half8 *>(kp + QK_LO + 32 * s);
+        const half8 ah1 = *reinterpret_cast<const half8 *>(kp + 64 + 32 * s);
+        const half8 al1 = *reinterpret_cast<const half8 *>(kp + QK_LO + 64 + 32 * s);
+        k0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[s], k0, 0, 0, 0);
+        k1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[s], k1, 0, 0, 0);
+        k0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[s], k0, 0, 0, 0);
+        k1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[s], k1, 0, 0, 0);
+        k0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[s], k0, 0, 0, 0);
+        k1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[s], k1, 0, 0, 0);
+      }
+    }
+    int kstar;
+    bool aligned;
+    {
+      float mx = -INFINITY;
+      int am = 0;
+      bool bad = false;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const float v = k0[r];
+        bad |= !(v == v);
+        if (v > mx) {
+          mx = v;
+          am = row_of(0, r) + 4 * hh;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        float v = k1[r];
+        if (r >= 12) v = hh ? -INFINITY : v;  // rows 60..63 are padding
+        bad |= !(v == v);
+        if (v > mx) {
+          mx = v;
+          am = row_of(1, r) + 4 * hh;
+        }
+      }
+      const float omx = __shfl_xor(mx, 32);
+      const int oam = __shfl_xor(am, 32);
+      const float gmx = fmaxf(mx, omx);
+      const float2 en = reinterpret_cast<const float2 *>(a.vk_n)[slot];
+      const float thr = 2.0f * kWinAlignEps * nq_key * en.x;  // NaN when either key is unusable
+      // KC is scale-free, the reference's fp64 arithmetic is not: it compares ||vkey_q - shift(vkey_e)||, and when one key
+      // is much smaller than the other every shift gives the same double (its search then keeps the first one).  A
+      // separation of 2 eps sqrt(E_q E_e) in KC is a RELATIVE separation >= 2.4e-4 * ratio of the squared distances
+      // (<= (|q| + |e|)^2 <= 4 max^2): with ratio = min norm / max norm >= 1e-6 that is 2.4e-10, six orders above the
+      // 60 * 2^-52 the fp64 sums can be off by; more lopsided pairs are left to the exact alignment
+      const float umin = fminf(uq_key, en.y), umax = fmaxf(uq_key, en.y);
+      const bool balanced = umin >= 1e-6f * umax && umax < INFINITY && umin > 0.0f;
+      const float line = gmx - thr;
+      int c = 0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) c += (k0[r] >= line) ? 1 : 0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) c += (k1[r] >= line && !(r >= 12 && hh)) ? 1 : 0;
+      c += __shfl_xor(c, 32);
+      const bool obad = __shfl_xor((int)bad, 32) != 0;
+      kstar = (mx >= omx) ? am : oam;
+      aligned = (c == 1) && !bad && !obad && (thr == thr) && thr < 3.0e38f && balanced;
+    }
+
+    // ---- the 60 correlation values of the two images (the direct filter's GEMM) ----
+    floatx16 acc0 = {0}, acc1 = {0};
+    {
+      const char *brow = a.hnR + slot * (2 * DS) + 16 * hh;
+      constexpr int U = 5;
+      half8 bcur[U], bnext[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) bcur[u] = *reinterpret_cast<const half8 *>(brow + 32 * u);
+#pragma unroll 1
+      for (int s0 = 0; s0 < W_STEPS; s0 += U) {
+        if (s0 + U < W_STEPS) {
+#pragma unroll
+          for (int u = 0; u < U; u++) bnext[u] = *reinterpret_cast<const half8 *>(brow + 32 * (s0 + U + u));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const half8 a0 = *reinterpret_cast<const half8 *>(ap + 32 * (s0 + u));
+          const half8 a1 = *reinterpret_cast<const half8 *>(ap + 32 * (s0 + u + W_TILE1));
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bcur[u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bcur[u], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) bcur[u] = bnext[u];
+      }
+    }
+
+    // ---- epilogue: max of S_k / n_eff(k) over the window of k* (n_eff from the two column masks, as the filter) ----
+    const u64 em = a.cmask[slot];
+    float pv;
+    {
+      const u64 m1c = qm & ~kNonFinite;
+      const u64 lo = m1c | (m1c << 60), hi = m1c >> 4;  // the 60-bit mask twice in a row (120 bits)
+      const u64 lo4 = (lo >> 4) | (hi << 60), hi4 = hi >> 4;
+      const u64 l = hh ? lo4 : lo, h = hh ? hi4 : hi;
+      const unsigned w[4] = {(unsigned)l, (unsigned)(l >> 32), (unsigned)h, (unsigned)(h >> 32)};
+      const unsigned m2lo = (unsigned)em, m2hi = (unsigned)(em >> 32) & 0x0fffffffu;
+      int k0s = kstar - 3;
+      k0s += k0s < 0 ? NS : 0;
+      const int rel0 = 4 * hh - k0s;  // shift of (tile, register) minus the first shift of the window
+      float best = -INFINITY;
+      auto piece = [&](int tl, int r, float S) {
+        const int b = (r & 3) + 8 * (r >> 2);
+        const unsigned rlo = __builtin_amdgcn_alignbit(w[tl + 1], w[tl], b);
+        const unsigned rhi = __builtin_amdgcn_alignbit(w[tl + 2], w[tl + 1], b);
+        const int ne = __builtin_popcount(rlo & m2lo) + __builtin_popcount(rhi & m2hi);
+        float v = S * __builtin_amdgcn_rcpf((float)ne);  // n_eff == 0: S == 0 exactly, 0 * inf = NaN, dropped by fmaxf
+        int u = rel0 + 32 * tl + b;
+        u += u < 0 ? NS : 0;
+        const bool pad = (tl == 1 && r >= 12 && hh);
+        v = (u < 7 && !pad) ? v : -INFINITY;
+        best = fmaxf(best, v);
+      };
+#pragma unroll
+      for (int r = 0; r < 16; r++) piece(0, r, acc0[r]);
+#pragma unroll
+      for (int r = 0; r < 16; r++) piece(1, r, acc1[r]);
+      best = fmaxf(best, __shfl_xor(best, 32));
+      pv = fmaf(best, -1.0f / FILTER_ACC_SCALE, 1.0f);  // -inf (no effective column in the window) -> +inf
+    }
+    if (!aligned || ((qm | em) & kNonFinite)) pv = __builtin_nanf("");
+    if (have && hh == 0) {
+      WindowPreview o;
+      o.pv = pv;
+      o.ks = kstar;
+      a.out[(int64_t)qi * WINDOW_P + pos] = o;
+    }
+  }
+}
+
+}  // namespace
+
+size_t window_qimg_bytes(int32_t nq) { return (size_t)nq * (FILTER_QIMG_BYTES + WINDOW_QK_BYTES) + 1024; }
+
+int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void *vk16, float *vk_n, hipStream_t s) {
+  if (count <= 0) return RSX_OK;
+  hipLaunchKernelGGL(sc_win_db_keys_kernel, dim3((unsigned)((count + 3) / 4)), dim3(256), 0, s, vkey, first, count,
+                     static_cast<_Float16 *>(vk16), vk_n);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
+                  WindowPreview *out, hipStream_t s) {
+  if (q.nq <= 0) return RSX_OK;
+  char *img = static_cast<char *>(qimg);
+  char *kimg = img + (size_t)q.nq * FILTER_QIMG_BYTES;
+  RSX_TRY(launch_query_images(q.desc, q.norm, q.nq, img, s));
+  hipLaunchKernelGGL(sc_win_query_keys_kernel, dim3((unsigned)((q.nq + 3) / 4)), dim3(256), 0, s, q.vkey, q.nq, kimg);
+  RSX_HIP(hipGetLastError());
+  WindowArgs a;
+  a.hnR = static_cast<const char *>(db.hnR);
+  a.vk16 = static_cast<const char *>(db.vk16);
+  a.vk_n = db.vk_n;
+  a.cmask = reinterpret_cast<const u64 *>(db.cmask);
+  a.qimg = img;
+  a.qkimg = kimg;
+  a.slist = slist;
+  a.sl_cnt = sl_cnt;
+  a.out = out;
+  hipLaunchKernelGGL(sc_window_kernel, dim3((unsigned)q.nq), dim3(256), W_LDS, s, a);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+const char *window_kernel_name() { return "sc_window_kernel"; }
+
+}  // namespace sc
+}  // namespace rsx

@@ -13,6 +13,9 @@ import numpy as np
 from . import _rsx
 from ._rsx import HIT_DTYPE, MODE_CANDIDATE, MODE_EXHAUSTIVE, check, lib
 
+WINDOW_P = 128            # rsx.h RSX_SC_WINDOW_P
+WINDOW_MARGIN = 1.25e-3   # rsx.h RSX_SC_WINDOW_MARGIN
+
 
 class SCManager:
     # hyper parameters (Scancontext.h:83-104); fixed at construction like the reference's consts
@@ -261,6 +264,20 @@ class SCManager:
         check(self._L.rsx_sc_filter_bounds(self._h, q.ctypes.data, q.shape[0], out.ctypes.data))
         return out
 
+    def window_previews(self, q_descs):
+        """The stage between the filter and the exact re-scoring (csrc/sc_window.hip), for diagnostics and tests:
+        -> (slots, pv, kstar, counts): the first WINDOW_P short-list entries of every query (local slots, -1 past the
+        end), their matrix-core preview of the pair distance (NaN: the kernel declined) and sector-key alignment."""
+        q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
+        nq = q.shape[0]
+        slots = np.empty((nq, WINDOW_P), dtype=np.int32)
+        pv = np.empty((nq, WINDOW_P), dtype=np.float32)
+        ks = np.empty((nq, WINDOW_P), dtype=np.int32)
+        cnt = np.empty(nq, dtype=np.int32)
+        check(self._L.rsx_sc_window_previews(self._h, q.ctypes.data, nq, slots.ctypes.data, pv.ctypes.data, ks.ctypes.data,
+                                             cnt.ctypes.data))
+        return slots, pv, ks, cnt
+
     @staticmethod
     def filter_eps():
         return lib().rsx_sc_filter_eps()
@@ -291,6 +308,13 @@ class SCManager:
         c, a, b = C.c_int64(), C.c_int64(), C.c_int64()
         check(self._L.rsx_sc_profile_read_rescoring2(self._h, C.byref(c), C.byref(a), C.byref(b)))
         return c.value, a.value, b.value
+
+    def profile_read_rescoring3(self):
+        """-> (candidates, exact window evaluations, queries that scored any, candidates served by the window kernel,
+        candidates through the per-wavefront alignment + preview)."""
+        v = (C.c_int64 * 5)()
+        check(self._L.rsx_sc_profile_read_rescoring3(self._h, v))
+        return tuple(int(x) for x in v)
 
     def hit_to_loop(self, hit):
         h = np.zeros(1, dtype=HIT_DTYPE)

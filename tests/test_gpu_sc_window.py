@@ -1,0 +1,94 @@
+"""The stage between the lower-bound filter and the exact re-scoring (csrc/sc_window.hip), checked pair by pair against the
+oracle's pair function: wherever the kernel returns a preview,
+  * its alignment IS fastAlignUsingVkey of the pair (reference SC.cpp:93-113, oracle scref_fast_align), and
+  * |preview - distanceBtnScanContext| <= RSX_SC_WINDOW_MARGIN (SC.cpp:116-148; +inf <-> the oracle's "no hit" 1e7),
+and it returns one for nearly every pair of ordinary data.  The top-k parity tests of test_gpu_sc_filter.py run through the same
+kernel; this file pins its two outputs directly, on the data families that stress them."""
+import numpy as np
+import pytest
+
+from navtech_radar_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sc():
+    from navtech_radar_slam_amd import _rsx, scancontext
+    assert _rsx.device_count() >= 1, "no HIP device: GPU tests must run on the MI355X box"
+    return scancontext
+
+
+def check_previews(sc, oracle, descs, queries, min_served):
+    g = sc.SCManager(filter_mode=2)
+    g.add_descriptors_f32(descs)
+    slots, pv, ks, cnt = g.window_previews(queries)
+    assert slots.shape == (len(queries), sc.WINDOW_P)
+    served = total = 0
+    o = oracle.Manager()
+    o.add_descriptors(descs.astype(np.float64))
+    for qi in range(len(queries)):
+        q64 = queries[qi].astype(np.float64)
+        dist, _ = o.pair_distances(q64, nthreads=4)
+        vq = oracle.sectorkey(q64)
+        c = int(cnt[qi])
+        assert 0 <= c <= sc.WINDOW_P and np.all(slots[qi, c:] == -1) and np.all(slots[qi, :c] >= 0)
+        assert len(set(slots[qi, :c].tolist())) == c
+        for i in range(c):
+            total += 1
+            if np.isnan(pv[qi, i]):
+                continue
+            served += 1
+            e = int(slots[qi, i])
+            want_k = oracle.fast_align(vq, oracle.sectorkey(descs[e].astype(np.float64)))
+            assert int(ks[qi, i]) == want_k, (qi, e, int(ks[qi, i]), want_k)
+            if dist[e] >= 1e7:
+                assert pv[qi, i] == np.inf, (qi, e, pv[qi, i])
+            else:
+                assert abs(float(pv[qi, i]) - dist[e]) <= sc.WINDOW_MARGIN, (qi, e, float(pv[qi, i]), dist[e])
+    assert total > 0 and served >= min_served * total, (served, total)
+    return served, total
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_window_previews_random(sc, oracle, binary):
+    n = 700
+    descs = synth.random_descriptors(31 + binary, n, binary=binary)
+    rng = np.random.default_rng(5)
+    for i in range(0, n, 9):
+        descs[i] = synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60)))
+    descs[5] = 0
+    descs[6][20 * 7:20 * 9] = 0
+    queries = np.stack([descs[1], synth.rotate_descriptor(descs[50], 31), descs[6], descs[9], descs[5],
+                        synth.random_descriptors(77, 1, binary=binary)[0]])
+    check_previews(sc, oracle, descs, queries, 0.5 if binary else 0.9)
+
+
+def test_window_previews_trajectory(sc, oracle):
+    """radar-like clouds through the descriptor-build path (binary heights: sector keys are multiples of 0.1, so exact
+    ties between shifts do occur -- those pairs must be declined, not guessed)"""
+    db_pts, db_off, q_pts, q_off, _ = synth.trajectory_keyframes(7, 600, 8, 12, binary_z=True)
+    descs = np.stack([oracle.make_scancontext(db_pts[db_off[i]:db_off[i + 1]]) for i in range(600)]).astype(np.float32)
+    queries = np.stack([oracle.make_scancontext(q_pts[q_off[i]:q_off[i + 1]]) for i in range(12)]).astype(np.float32)
+    served, total = check_previews(sc, oracle, descs, queries, 0.8)
+    print(f"window previews served {served} of {total}")
+
+
+def test_window_previews_adversarial(sc, oracle):
+    """magnitudes over six decades inside a column, mixed signs, single-ring and mostly-empty descriptors, sector keys of
+    1e30 (the reference's alignment search starts from 1e7 and never moves: SC.cpp:100) and of 1e-30"""
+    rng = np.random.default_rng(23)
+    n = 640
+    base = synth.random_descriptors(50, n, binary=False).reshape(n, 60, 20)
+    d = (base * 10.0 ** rng.uniform(-3, 3, (n, 60, 20))).astype(np.float32)
+    d[100:200] *= np.where(rng.uniform(size=(100, 60, 20)) < 0.5, -1.0, 1.0).astype(np.float32)
+    d[200:260, :, 1:] = 0
+    d[260:320][rng.uniform(size=(60, 60)) < 0.8] = 0
+    d[320:340] *= np.float32(1e30)
+    d[340:360] *= np.float32(1e-30)
+    d[360] = np.nan
+    d[361, 3, 4] = np.inf
+    descs = np.ascontiguousarray(d.reshape(n, 1200))
+    queries = np.stack([descs[5], synth.rotate_descriptor(descs[150], 17), descs[230], descs[300], descs[330], descs[350],
+                        synth.rotate_descriptor(descs[40], 59), descs[361]])
+    check_previews(sc, oracle, descs, queries, 0.3)

@@ -1,0 +1,73 @@
+"""Offline experiment (CPU, numpy): how many candidates per query would a WINDOW-RESTRICTED lower bound leave,
+against the all-shift bound the filter emits today?    Not part of the product or the tests."""
+import sys, os, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import importlib
+synth = importlib.import_module("navtech-radar-slam_amd.synth".replace("-", "_")) if False else None
+import importlib.util
+spec = importlib.util.spec_from_file_location("synth", os.path.join(os.path.dirname(__file__), "..", "navtech-radar-slam_amd", "synth.py"))
+synth = importlib.util.module_from_spec(spec); spec.loader.exec_module(synth)
+from oracle import pyoracle as po
+
+n_db, nq_all, nq, k = 10000, 8192, int(sys.argv[1]) if len(sys.argv) > 1 else 48, 10
+n_elig = n_db - 30
+db_pts, db_off, q_pts, q_off, q_src = synth.trajectory_keyframes(1234, n_db, 4321, nq_all, binary_z=True)
+t0 = time.time()
+D = np.stack([po.make_scancontext(db_pts[db_off[i]:db_off[i + 1]]) for i in range(n_elig)]).reshape(n_elig, 60, 20).transpose(0, 2, 1).copy()   # column-major 20x60 -> [n,20,60]
+rng = np.random.default_rng(0)
+qi = rng.choice(nq_all, nq, replace=False)
+Q = np.stack([po.make_scancontext(q_pts[q_off[i]:q_off[i + 1]]) for i in qi]).reshape(nq, 60, 20).transpose(0, 2, 1).copy()
+print("descriptors", time.time() - t0, "s", file=sys.stderr)
+
+def unit_cols(X):
+    n = np.sqrt((X * X).sum(axis=1, keepdims=True))
+    m = (n[:, 0, :] > 0)
+    U = np.where(n > 0, X / np.where(n > 0, n, 1), 0.0)
+    return U, m
+
+DU, Dm = unit_cols(D)
+QU, Qm = unit_cols(Q)
+DK, QK = D.mean(axis=1), Q.mean(axis=1)           # sector keys [n,60]
+FD = np.fft.rfft(DU, axis=2); FDm = np.fft.rfft(Dm.astype(float), axis=1); FDK = np.fft.rfft(DK, axis=1)
+res = []
+for a in range(nq):
+    # S[e,s] = sum_j cos(query col (j+s)%60, entry col j)  (shift s applied to ... the convention does not matter for counts
+    # as long as keys and images use the same one)
+    FQ = np.fft.rfft(QU[a], axis=1)
+    S = np.fft.irfft((FQ[None] * np.conj(FD)).sum(axis=1), n=60, axis=1)
+    NE = np.rint(np.fft.irfft(np.fft.rfft(Qm[a].astype(float))[None] * np.conj(FDm), n=60, axis=1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dist = np.where(NE > 0, 1.0 - S / NE, np.inf)                      # [n,60]
+    KC = np.fft.irfft(np.fft.rfft(QK[a])[None] * np.conj(FDK), n=60, axis=1)   # key correlation per shift
+    e1, e2 = (QK[a] ** 2).sum(), (DK ** 2).sum(axis=1)
+    KD = e1 + e2[:, None] - 2 * KC                                        # squared key distance per shift
+    ks = KD.argmin(axis=1)
+    win = (ks[:, None] + np.arange(-3, 4)[None]) % 60
+    true = np.take_along_axis(dist, win, axis=1).min(axis=1)
+    tau = np.sort(true)[k - 1]
+    lb_all = dist.min(axis=1)
+    if a == 0:   # the restatement against the oracle's pair function
+        for e in list(np.argsort(true)[:5]) + [5, 77, 4000]:
+            dd, _ = po.distance(np.asfortranarray(Q[a]).ravel(order="F"), np.asfortranarray(D[e]).ravel(order="F"))
+            assert abs(dd - true[e]) < 1e-9 or (dd > 1e6 and true[e] == np.inf), (e, dd, true[e])
+    lb_all = dist.min(axis=1)
+    pos = np.argsort(lb_all, kind="stable")
+    def evals(margin, P=128):
+        sub = true[pos[:P]]
+        tau_ub = np.sort(sub)[k - 1] + 2 * margin
+        return int((sub <= tau_ub).sum())
+    row = {"tau": tau, "evals_fp32": evals(1e-4), "evals_fp16": evals(1.25e-3), "in_first128": int((np.sort(true)[:k][-1] >= 0) and np.isin(np.argsort(true)[:k], pos[:128]).sum()), "all": int((lb_all <= tau + 2e-3).sum()), "exactwin": int((true <= tau).sum())}
+    for delta in (1e-3, 3e-3, 1e-2):
+        # admissible alignment shifts under an absolute error delta*(e1+e2) on KD; bound = min over the union of their windows
+        adm = KD <= KD.min(axis=1, keepdims=True) + delta * (e1 + e2[:, None])
+        mask = np.zeros_like(adm)
+        for o in range(-3, 4):
+            mask |= np.roll(adm, o, axis=1)
+        lb = np.where(mask, dist, np.inf).min(axis=1)
+        row[f"win{delta:g}"] = int((lb <= tau + 2e-3).sum())
+        row[f"adm{delta:g}"] = float(mask.sum(axis=1).mean())
+    res.append(row)
+keys = list(res[0].keys())
+print({kk: float(np.mean([r[kk] for r in res])) for kk in keys})
+print({kk: float(np.median([r[kk] for r in res])) for kk in keys})
