@@ -237,10 +237,11 @@ double rsx_sc_filter_eps(void);
 /* diagnostic entry of the stage between the filter and the exact re-scoring (csrc/sc_window.hip): for each query the first
  * RSX_SC_WINDOW_P entries of its short list (local slots in ascending filter-bound order, -1 past the end; out_counts[q] of
  * them are valid) with the sector-key alignment k* (fastAlignUsingVkey, reference SC.cpp:93-113) and the fp16 matrix-core
- * preview pv of distanceBtnScanContext (SC.cpp:116-148): |pv - distance| <= RSX_SC_WINDOW_MARGIN; pv = NaN where the
- * kernel declines (alignment not unique within its error bound, non-finite data), +inf where no shift of the window has
- * an effective column.  All outputs are [nq][RSX_SC_WINDOW_P] host arrays. */
-#define RSX_SC_WINDOW_P 128
+ * preview pv of distanceBtnScanContext (SC.cpp:116-148): |pv - distance| <= RSX_SC_WINDOW_MARGIN.  Where the alignment is
+ * not unique within the kernel's error bound, k* = -1 and pv - RSX_SC_WINDOW_MARGIN is a lower bound of the distance only;
+ * pv = NaN for non-finite data, +inf where no shift of the window has an effective column.  All outputs are
+ * [nq][RSX_SC_WINDOW_P] host arrays. */
+#define RSX_SC_WINDOW_P 192
 #define RSX_SC_WINDOW_MARGIN 1.25e-3f
 int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t *out_slots, float *out_pv, int32_t *out_kstar,
                            int32_t *out_counts);

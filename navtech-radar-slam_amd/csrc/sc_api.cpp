@@ -291,7 +291,8 @@ int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_
   // alignment + window preview of the head of every short list on the matrix cores (what re-scoring would otherwise
   // do on the VALU, one entry per wavefront)
   if (!use_window()) return RSX_OK;
-  return launch_window(db, q, h->f_wimg.p, h->f_cand.as<RescoreEntry>(), h->f_cnt.as<int32_t>(), h->f_win.as<WindowPreview>(), s);
+  return launch_window(db, q, h->f_wimg.p, h->f_cand.as<RescoreEntry>(), h->f_cnt.as<int32_t>(), h->f_thr.as<float>(),
+                       h->f_win.as<WindowPreview>(), s);
 }
 
 int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig, int32_t round_begin,
@@ -1275,13 +1276,14 @@ int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t 
   RSX_TRY(filter_and_select(h, qv, n, h->n_global, nullptr, 128, s));
   std::vector<RescoreEntry> sl((size_t)nq * RESCORE_SHORTLIST_CAP);
   std::vector<WindowPreview> wp((size_t)nq * WINDOW_P);
-  std::vector<int32_t> cnt((size_t)nq);
+  std::vector<int32_t> cnt((size_t)nq), thr((size_t)nq * RESCORE_THR_STRIDE);
+  RSX_HIP(hipMemcpyAsync(thr.data(), h->f_thr.p, thr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipMemcpyAsync(sl.data(), h->f_cand.p, sl.size() * sizeof(RescoreEntry), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipMemcpyAsync(wp.data(), h->f_win.p, wp.size() * sizeof(WindowPreview), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipMemcpyAsync(cnt.data(), h->f_cnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   for (int32_t q = 0; q < nq; q++) {
-    const int32_t c = cnt[(size_t)q] < WINDOW_P ? cnt[(size_t)q] : WINDOW_P;
+    const int32_t c = window_count(cnt[(size_t)q], thr[(size_t)q * RESCORE_THR_STRIDE + RESCORE_NUM_THR]);
     out_counts[q] = c;
     for (int32_t i = 0; i < WINDOW_P; i++) {
       const size_t o = (size_t)q * WINDOW_P + i;

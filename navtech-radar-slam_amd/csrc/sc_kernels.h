@@ -157,14 +157,22 @@ constexpr int WINDOW_P = RSX_SC_WINDOW_P;               // short-list positions 
 constexpr float WINDOW_MARGIN = RSX_SC_WINDOW_MARGIN;   // same arithmetic as the direct filter: its error budget (sc_filter.hip)
 constexpr int WINDOW_QK_BYTES = 4624;       // key image of a query (sc_window.hip)
 struct WindowPreview {
-  float pv;    // NaN: no preview (ambiguous alignment, non-finite data); +inf: no effective column in the window
-  int32_t ks;  // k*
+  float pv;    // NaN: no preview (non-finite data); +inf: no effective column in the window(s)
+  int32_t ks;  // k*, or -1: not unique within the error bound -- pv is then a lower bound only (union of the windows)
 };
+// short-list positions of a query that get a record: its whole first re-scoring round (rcnt0 = entries in it), at least
+// 128 and at most WINDOW_P
+__host__ __device__ constexpr int window_count(int sl_cnt, int rcnt0) {
+  int c = (rcnt0 + 31) & ~31;
+  c = c < 128 ? 128 : c;
+  c = c > WINDOW_P ? WINDOW_P : c;
+  return c < sl_cnt ? c : sl_cnt;
+}
 size_t window_qimg_bytes(int32_t nq);  // direct-filter images + key images of a query batch
 int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void *vk16, float *vk_n, hipStream_t s);
 // qimg: window_qimg_bytes(nq) of workspace (filled here); out: [nq][WINDOW_P]
 int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
-                  WindowPreview *out, hipStream_t s);
+                  const float *thr, WindowPreview *out, hipStream_t s);
 const char *window_kernel_name();
 
 // ---- the reference's public helper methods on arbitrary double descriptors (sc_helpers.hip) ----

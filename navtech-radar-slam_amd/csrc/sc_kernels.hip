@@ -594,6 +594,46 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
     bk_out = bk;
 }
 
+// exact stage 1 of pair_group (fastAlignUsingVkey, SC.cpp:93-113) for one entry: v1 = the query's sector key (60 doubles
+// in LDS), ev = the entry's key, one element per lane; uses the key-image part of the wave's LDS region
+__device__ __forceinline__ int align_exact(const double *v1, char *wsm, int lane, double ev) {
+  const int kk = lane < NS ? lane : NS - 1;
+  double *vka = reinterpret_cast<double *>(wsm + ENT_VKEY_A);
+  double *vkb = reinterpret_cast<double *>(wsm + ENT_VKEY_B);
+  if (lane < NS) {
+    vka[lane] = ev;
+    vka[lane + NS] = ev;
+    vkb[lane + 1] = ev;
+    vkb[lane + NS + 1] = ev;
+  }
+  wave_lds_fence();
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  const int eoff = (kk & 1) ? (ENT_VKEY_B + (NS + 1 - kk) * 8) : (ENT_VKEY_A + (NS - kk) * 8);
+  const double2 *v2 = reinterpret_cast<const double2 *>(wsm + eoff);
+  const double2 *v1p = reinterpret_cast<const double2 *>(v1);
+#pragma unroll 1
+  for (int c0 = 0; c0 < NS / 2; c0 += 6) {
+#pragma unroll
+    for (int cc = 0; cc < 6; cc++) {
+      const double2 x = v1p[c0 + cc], y = v2[c0 + cc];
+      const double d0 = x.x - y.x;
+      const double dd0 = d0 * d0;
+      acc[2 * (cc & 1)] = acc[2 * (cc & 1)] + dd0;
+      const double d1 = x.y - y.y;
+      const double dd1 = d1 * d1;
+      acc[2 * (cc & 1) + 1] = acc[2 * (cc & 1) + 1] + dd1;
+    }
+  }
+  const double nrm = sqrt((acc[0] + acc[2]) + (acc[1] + acc[3]));
+  const bool ok = (lane < NS) && (nrm < kBig);
+  double m = ok ? nrm : INFINITY;
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off));
+  const unsigned long long bal = __ballot(ok && nrm == m);
+  wave_lds_fence();
+  return bal ? (__ffsll((long long)bal) - 1) : 0;
+}
+
 // ------------------------------------------------------------------------------------------
 // The same pair function in two phases, one entry per wavefront (sc_rescore_kernel):
 //   phase A  alignment k* (fast fp32 form with exact fallback, see above) + the fp32 preview of the 7 window
@@ -650,42 +690,7 @@ __device__ __forceinline__ int phase_a(const char *smem, char *wsm, int lane, co
     }
     wave_lds_fence();
   }
-  if (need_exact) {  // exact stage 1 of pair_group (SC.cpp:93-113), B = 1
-    double *vka = reinterpret_cast<double *>(wsm + ENT_VKEY_A);
-    double *vkb = reinterpret_cast<double *>(wsm + ENT_VKEY_B);
-    if (lane < NS) {
-      vka[lane] = ev;
-      vka[lane + NS] = ev;
-      vkb[lane + 1] = ev;
-      vkb[lane + NS + 1] = ev;
-    }
-    wave_lds_fence();
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const int eoff = (kk & 1) ? (ENT_VKEY_B + (NS + 1 - kk) * 8) : (ENT_VKEY_A + (NS - kk) * 8);
-    const double2 *v2 = reinterpret_cast<const double2 *>(wsm + eoff);
-    const double2 *v1p = reinterpret_cast<const double2 *>(v1);
-#pragma unroll 1
-    for (int c0 = 0; c0 < NS / 2; c0 += 6) {
-#pragma unroll
-      for (int cc = 0; cc < 6; cc++) {
-        const double2 x = v1p[c0 + cc], y = v2[c0 + cc];
-        const double d0 = x.x - y.x;
-        const double dd0 = d0 * d0;
-        acc[2 * (cc & 1)] = acc[2 * (cc & 1)] + dd0;
-        const double d1 = x.y - y.y;
-        const double dd1 = d1 * d1;
-        acc[2 * (cc & 1) + 1] = acc[2 * (cc & 1) + 1] + dd1;
-      }
-    }
-    const double nrm = sqrt((acc[0] + acc[2]) + (acc[1] + acc[3]));
-    const bool ok = (lane < NS) && (nrm < kBig);
-    double m = ok ? nrm : INFINITY;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) m = fmin(m, __shfl_xor(m, off));
-    const unsigned long long bal = __ballot(ok && nrm == m);
-    kstar = bal ? (__ffsll((long long)bal) - 1) : 0;
-    wave_lds_fence();
-  }
+  if (need_exact) kstar = align_exact(v1, wsm, lane, ev);
   // fp32 preview of the window distances (see PREVIEW above), arranged for few instructions: the query's unit
   // columns are 0 for an empty column and r2 is 0 for an empty entry column, so no per-lane validity select is
   // needed; the effective-column counts come from the two 60-bit column masks on the scalar unit; the seven lane
@@ -1364,6 +1369,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
         double ud = ld;  // this wave's exact hits so far + its candidates' preview upper bounds
         int ui = li, us = ls;
         const WindowPreview *wp = a.win ? a.win + (int64_t)qi * WINDOW_P : nullptr;
+        const int wcnt = window_count(a.sl_cnt[qi], reinterpret_cast<const int32_t *>(a.thr + (int64_t)qi * RESCORE_THR_STRIDE)[RESCORE_NUM_THR]);
         // (requesting the next candidate's registers one candidate ahead was tried: 48 more live registers, one
         // workgroup per CU fewer, 3 % slower -- four waves per SIMD already hide the entry loads)
         EntryRegs cur;
@@ -1380,9 +1386,9 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
             const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
             elig = gidx < n_elig;
             const int pos = posv[g];
-            if (elig && wp && pos >= 0 && pos < WINDOW_P) {
+            if (elig && wp && pos >= 0 && pos < wcnt) {
               const WindowPreview w = wp[pos];
-              if (w.pv == w.pv) {  // NaN: no window preview for this entry
+              if (w.pv == w.pv && w.ks >= 0) {  // NaN: no window preview for this entry
                 windowed = true;
                 wpv = w.pv;
                 pvs[g] = w.pv - WINDOW_MARGIN;  // +inf stays +inf
@@ -1897,6 +1903,382 @@ int launch_walk(const DbView &db, const QueryView &q, const float *lb, int64_t l
   return RSX_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// sc_rescore_wave_kernel: exact re-scoring behind the filter AND the window kernel (sc_window.hip), ONE WAVE per
+// query.  With the alignment k* and a preview of the pair distance already there for the head of the short list, what is
+// left per query is: pick the k-th smallest preview upper bound (an upper bound of the final k-th best distance), and
+// evaluate exactly -- phase B, ~13 entries per query -- the few entries whose preview lower bound does not exceed it, in
+// ascending order of that lower bound so that the exact k-th best takes over as early as possible.  No barriers, no
+// merges between waves, no imbalance between them (the 4-wave workgroup of sc_rescore_kernel spent 64 % of its wave
+// cycles waiting once its phase A was gone), and 9.0 KiB of LDS per query (the query image stays in fp32 and is
+// converted on the fly) instead of 40 KiB: 16 queries per CU in flight instead of 4.
+// Entries without k* (alignment not unique within the window kernel's error bound, or beyond its WINDOW_P positions)
+// get the exact fp64 alignment first; their preview is still a valid LOWER bound (minimum over the union of the candidate
+// windows), so most of them are never touched.  Same stage interface as sc_rescore_kernel (rounds, tau_src, seed).
+// ------------------------------------------------------------------------------------------
+struct WaveLds {
+  static constexpr int OFF_QF32 = 0;                  // the query descriptor as it is: [60][20] fp32, column stride 80 B
+  static constexpr int OFF_QN1 = DS * 4;              // 4800: column norms (fp64)
+  static constexpr int OFF_QV1 = OFF_QN1 + 512;       // 5312: sector key (fp64)
+  static constexpr int OFF_ENT = OFF_QV1 + 512;       // 5824: the wave's entry region (key images / similarity terms)
+  static constexpr int SIZE = OFF_ENT + ENT_SIZE;     // 9232
+};
+constexpr int RW_CH = (WINDOW_P + 63) / 64;  // window records per lane
+
+// phase B on the fp32 query image: the same operations in the same order as phase_b (the conversion float -> double is
+// exact), half the LDS bytes per column
+__device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane, const EntryRegs &er, int ks, double &bd_out,
+                                          int &bk_out) {
+  const int cl = lane < NS ? lane : 0;
+  const double *qn1 = reinterpret_cast<const double *>(smem + WaveLds::OFF_QN1);
+  wave_lds_fence();
+  double e[NR];
+#pragma unroll
+  for (int i = 0; i < 5; i++) {
+    const float4 v = er.ecol[i];
+    e[4 * i + 0] = v.x; e[4 * i + 1] = v.y; e[4 * i + 2] = v.z; e[4 * i + 3] = v.w;
+  }
+  const double n2 = er.n2;
+  double *simp = reinterpret_cast<double *>(wsm + ENT_SIM);
+  int *misc = reinterpret_cast<int *>(wsm + ENT_MISC);
+#pragma unroll
+  for (int t = 0; t < 7; t++) {
+    int k = ks + t - 3;
+    k += (k < 0) ? NS : 0;
+    k -= (k >= NS) ? NS : 0;
+    int c = cl + k;
+    c -= (c >= NS) ? NS : 0;
+    const float4 *qp = reinterpret_cast<const float4 *>(smem + WaveLds::OFF_QF32 + c * (NR * 4));
+    double da[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < 5; i++) {  // element r feeds accumulator r % 4 (Eigen's redux order), as in phase_b
+      const float4 q4 = qp[i];
+      da[0] = fma((double)q4.x, e[4 * i + 0], da[0]);
+      da[1] = fma((double)q4.y, e[4 * i + 1], da[1]);
+      da[2] = fma((double)q4.z, e[4 * i + 2], da[2]);
+      da[3] = fma((double)q4.w, e[4 * i + 3], da[3]);
+    }
+    const double dot = (da[0] + da[2]) + (da[1] + da[3]);
+    const double n1 = qn1[c];
+    const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));
+    const double s = dot / (n1 * n2);
+    if (lane < NS) simp[t * NS + c] = valid ? s : 0.0;
+    const int ne = __popcll(__ballot(valid));
+    if (lane == 0) misc[t] = ne;
+  }
+  wave_lds_fence();
+  const int tt = lane & 7;
+  double bd = INFINITY;
+  int bk = 0x7fffffff;
+  if (lane < 8 && tt < 7) {
+    const double2 *sp = reinterpret_cast<const double2 *>(wsm + ENT_SIM + tt * (NS * 8));
+    double s = 0.0;
+#pragma unroll 1
+    for (int c0 = 0; c0 < NS / 2; c0 += 6) {
+#pragma unroll
+      for (int cc = 0; cc < 6; cc++) {
+        const double2 v = sp[c0 + cc];
+        s = s + v.x;
+        s = s + v.y;
+      }
+    }
+    const int ne = misc[tt];
+    const double d = 1.0 - s / (double)ne;
+    int k = ks + tt - 3;
+    k += (k < 0) ? NS : 0;
+    k -= (k >= NS) ? NS : 0;
+    if (d < kBig) {
+      bd = d;
+      bk = k;
+    }
+  }
+#pragma unroll
+  for (int off = 1; off <= 4; off <<= 1) {
+    const double od = __shfl_xor(bd, off);
+    const int ok = __shfl_xor(bk, off);
+    if (hit_before(od, ok, bd, bk)) {
+      bd = od;
+      bk = ok;
+    }
+  }
+  bd = __shfl(bd, 0);
+  bk = __shfl(bk, 0);
+  if (bd == INFINITY) {
+    bd = kBig;
+    bk = 0;
+  }
+  bd_out = bd;
+  bk_out = bk;
+}
+
+__global__ __launch_bounds__(64, 4) void sc_rescore_wave_kernel(RescoreArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x;
+  const int qi = blockIdx.x;
+  char *wsm = smem + WaveLds::OFF_ENT;
+
+  int64_t n_elig = a.n_eligible;
+  if (a.q_elig) {
+    const int64_t e = a.q_elig[qi];
+    n_elig = e < n_elig ? e : n_elig;
+  }
+  int64_t n_rows = 0;  // local slots [0, n_rows) are the eligible ones
+  if (n_elig > a.db.idx_base) {
+    n_rows = (n_elig - a.db.idx_base + a.db.idx_stride - 1) / a.db.idx_stride;
+    n_rows = n_rows < a.n_items ? n_rows : a.n_items;
+  }
+
+  double ld = INFINITY;  // sorted top-k of exact hits, one record per lane
+  int li = 0x7fffffff, ls = 0;
+  double tau_init = INFINITY;  // (multi-GPU stage 2) the k-th distance of a top-k over more than this shard
+  if (a.tau_src) {
+    const double d = a.tau_src[(int64_t)qi * a.k + (a.k - 1)].dist;
+    if (d < kBig) tau_init = d;
+  }
+  if (a.seed && lane < a.k) {  // this shard's hits of an earlier stage: sorted, padded {1e7,0,0}
+    const rsx_sc_hit h = a.seed[(int64_t)qi * a.k + lane];
+    if (h.dist < kBig) {
+      ld = h.dist; li = h.index; ls = h.shift;
+    }
+  }
+  auto kth_of = [&](double list) {
+    const double t = __shfl(list, a.k - 1);
+    return t < tau_init ? t : tau_init;
+  };
+  double tau = kth_of(ld);
+  bool query_loaded = false;
+  unsigned n_exact = 0, n_looked = 0, n_aligned = 0;  // wave-uniform counters (stats)
+  unsigned nl_lane = 0, n_windowed = 0;               // per-lane counters, summed over the wave at the end
+
+  // score one entry exactly (ks < 0: the alignment is not known yet)
+  auto eval = [&](int64_t slot, int ks, const EntryRegs &er) {
+    if (!query_loaded) {
+      const float4 *src = reinterpret_cast<const float4 *>(a.q.desc + (int64_t)qi * DS);
+      float4 *dst = reinterpret_cast<float4 *>(smem + WaveLds::OFF_QF32);
+      float4 x[5];
+#pragma unroll
+      for (int i = 0; i < 5; i++) x[i] = (lane + 64 * i < DS / 4) ? src[lane + 64 * i] : float4{0.f, 0.f, 0.f, 0.f};
+      const double kn = lane < NS ? a.q.norm[(int64_t)qi * NS + lane] : 0.0;
+      const double kv = lane < NS ? a.q.vkey[(int64_t)qi * NS + lane] : 0.0;
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+        if (lane + 64 * i < DS / 4) dst[lane + 64 * i] = x[i];
+      if (lane < NS) {
+        reinterpret_cast<double *>(smem + WaveLds::OFF_QN1)[lane] = kn;
+        reinterpret_cast<double *>(smem + WaveLds::OFF_QV1)[lane] = kv;
+      }
+      query_loaded = true;
+      wave_lds_fence();
+    }
+    if (ks < 0) {
+      ks = align_exact(reinterpret_cast<const double *>(smem + WaveLds::OFF_QV1), wsm, lane, er.v);
+      n_aligned++;
+    }
+    double bd;
+    int bk;
+    phase_b32(smem, wsm, lane, er, ks, bd, bk);
+    n_exact++;
+    const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
+    if (gidx < n_elig && bd < kBig) {
+      topk_insert(ld, li, ls, lane, a.k, bd, (int)gidx, bk);
+      tau = kth_of(ld);
+    }
+  };
+
+  // ---- this launch's part of the short list: rounds [round_begin, round_end) = positions [i0, i1) ----
+  const int sl_cnt = a.sl_cnt[qi];
+  const RescoreEntry *sl = a.slist + (int64_t)qi * RESCORE_SHORTLIST_CAP;
+  const float *thr = a.thr + (int64_t)qi * RESCORE_THR_STRIDE;
+  const int32_t *rcnt = reinterpret_cast<const int32_t *>(thr) + RESCORE_NUM_THR;
+  const float t_cap = thr[RESCORE_NUM_THR - 1];
+  const int r_end = a.round_end < RESCORE_NUM_THR ? a.round_end : RESCORE_NUM_THR;
+  auto upto = [&](int r) {  // list positions below round edge r - 1
+    if (r <= 0) return 0;
+    const int c = rcnt[r - 1];
+    return c < sl_cnt ? c : sl_cnt;
+  };
+  const int i0 = upto(a.round_begin), i1 = upto(r_end);
+  bool done = false;  // some list entry's bound already exceeds tau: everything after it does too
+
+  // ---- the head of the list: window records (k*, preview) ----
+  int pos_next = i0;
+  if (a.win && i0 < WINDOW_P && i0 < i1) {
+    const WindowPreview *wp = a.win + (int64_t)qi * WINDOW_P;
+    const int wc = window_count(sl_cnt, rcnt[0]);
+    const int pw = i1 < wc ? i1 : wc;
+    float lo[RW_CH], ub[RW_CH];
+    int32_t cslot[RW_CH], cks[RW_CH];
+#pragma unroll
+    for (int j = 0; j < RW_CH; j++) {
+      const int pos = i0 + lane + 64 * j;
+      lo[j] = INFINITY;
+      ub[j] = INFINITY;
+      cslot[j] = 0;
+      cks[j] = -1;
+      if (pos < pw) {
+        const RescoreEntry e = sl[pos];
+        const WindowPreview w = wp[pos];
+        cslot[j] = e.slot;
+        const int64_t gidx = a.db.idx_base + (int64_t)e.slot * a.db.idx_stride;
+        if (gidx < n_elig && !((double)e.lb - a.eps > tau)) {
+          if (!(w.pv == w.pv)) {
+            lo[j] = -INFINITY;  // no preview at all (non-finite data): must be looked at
+          } else {
+            lo[j] = w.pv - WINDOW_MARGIN;  // +inf stays +inf: no effective column in the window, never a hit
+            cks[j] = w.ks;
+            if (w.ks >= 0 && w.pv < 3.0e38f) ub[j] = w.pv + WINDOW_MARGIN;
+          }
+        }
+      }
+    }
+    {
+      unsigned c = 0;
+#pragma unroll
+      for (int j = 0; j < RW_CH; j++) c += (i0 + lane + 64 * j < pw) ? 1u : 0u;
+      nl_lane += c;
+#pragma unroll
+      for (int j = 0; j < RW_CH; j++) n_windowed += (lo[j] > -INFINITY && lo[j] < INFINITY) ? 1u : 0u;
+    }
+    // the k-th smallest of {exact hits so far} u {preview upper bounds}: an upper bound of the final k-th best
+    double ud = ld;
+    int ui = li, us = ls;
+    for (int it = 0; it < a.k; it++) {
+      float m = ub[0];
+#pragma unroll
+      for (int j = 1; j < RW_CH; j++) m = fminf(m, ub[j]);
+      const float wm = wave_min_f32(m);
+      if (!((double)wm < __shfl(ud, a.k - 1))) break;
+      const unsigned long long bal = __ballot(m == wm);
+      const int src = __ffsll((long long)bal) - 1;
+      if (lane == src) {
+        bool gone = false;
+#pragma unroll
+        for (int j = 0; j < RW_CH; j++)
+          if (!gone && ub[j] == wm) {
+            ub[j] = INFINITY;
+            gone = true;
+          }
+      }
+      topk_insert(ud, ui, us, lane, a.k, (double)wm, 0x40000000 + it, 0);  // the index only orders ties
+    }
+    const double tau_ub = kth_of(ud);
+    // survivors in ascending order of their lower bound; the next one's cache lines are requested while the current
+    // one is evaluated
+    auto take_min = [&](int32_t &slot, int &ks) -> float {
+      float m = lo[0];
+#pragma unroll
+      for (int j = 1; j < RW_CH; j++) m = fminf(m, lo[j]);
+      const float wm = wave_min_f32(m);
+      if (wm == INFINITY) return wm;
+      const unsigned long long bal = __ballot(m == wm);
+      const int src = __ffsll((long long)bal) - 1;
+      int32_t s_ = 0;
+      int k_ = -1;
+      if (lane == src) {
+        bool gone = false;
+#pragma unroll
+        for (int j = 0; j < RW_CH; j++)
+          if (!gone && lo[j] == wm) {
+            lo[j] = INFINITY;
+            s_ = cslot[j];
+            k_ = cks[j];
+            gone = true;
+          }
+      }
+      slot = __shfl(s_, src);
+      ks = __shfl(k_, src);
+      return wm;
+    };
+    int32_t cur_slot = 0, nxt_slot = 0;
+    int cur_ks = -1, nxt_ks = -1;
+    float cur_lo = take_min(cur_slot, cur_ks);
+    while (cur_lo < INFINITY) {
+      const double t_eff = tau < tau_ub ? tau : tau_ub;
+      if ((double)cur_lo > t_eff) break;  // exact >= lower bound > an upper bound of the k-th best; the rest is larger still
+      EntryRegs er;
+      load_entry(a.db, cur_slot, lane, er);
+      const float nxt_lo = take_min(nxt_slot, nxt_ks);
+      if (nxt_lo < INFINITY && !((double)nxt_lo > t_eff)) touch_entry(a.db, nxt_slot, lane);
+      eval(cur_slot, cur_ks, er);
+      cur_lo = nxt_lo;
+      cur_slot = nxt_slot;
+      cur_ks = nxt_ks;
+    }
+    pos_next = pw > i0 ? pw : i0;
+  }
+
+  // ---- the rest of this launch's list range, ascending bin order: no preview, exact alignment + phase B ----
+  for (int base = pos_next; base < i1 && !done; base += 64) {
+    const int n_here = (i1 - base < 64) ? (i1 - base) : 64;
+    RescoreEntry mine;
+    mine.lb = INFINITY;
+    mine.slot = 0;
+    if (lane < n_here) mine = sl[base + lane];
+    for (int i = 0; i < n_here; i++) {
+      const float lb = __shfl(mine.lb, i);
+      const int32_t slot = __shfl(mine.slot, i);
+      if ((double)bound_bin_lo(lb) - a.eps > tau) {  // every later entry sits in this bin or a higher one
+        done = true;
+        break;
+      }
+      if ((double)lb - a.eps > tau) continue;  // (NaN / -inf bounds: always scored)
+      const int64_t gidx = a.db.idx_base + (int64_t)slot * a.db.idx_stride;
+      if (!(gidx < n_elig)) continue;
+      EntryRegs er;
+      load_entry(a.db, slot, lane, er);
+      n_looked++;
+      eval(slot, -1, er);
+    }
+  }
+
+  // ---- entries beyond the short list (bound >= t_cap), only while tau admits them ----
+  if (!done && a.round_end > RESCORE_NUM_THR && t_cap < INFINITY && !((double)t_cap - a.eps > tau)) {
+    const float *row = a.lb + (int64_t)qi * a.ld_lb;
+    const bool take_all = (t_cap == -INFINITY);  // empty short list: NaN bounds are here too
+    for (int64_t pos = 0; pos < n_rows; pos += 64) {
+      const int64_t i = pos + lane;
+      const float d = (i < n_rows) ? row[i] : INFINITY;
+      const bool beyond = take_all ? true : (d >= t_cap);
+      unsigned long long bal = __ballot((i < n_rows) && beyond && (d != INFINITY));
+      while (bal) {
+        const int l = __ffsll((long long)bal) - 1;
+        bal &= bal - 1;
+        const float dl = __shfl(d, l);
+        if ((double)dl - a.eps > tau) continue;
+        EntryRegs er;
+        load_entry(a.db, pos + l, lane, er);
+        n_looked++;
+        eval(pos + l, -1, er);
+      }
+    }
+  }
+
+  if (lane < a.k) {
+    rsx_sc_hit h;
+    if (ld == INFINITY) {
+      h.dist = kBig; h.index = 0; h.shift = 0;
+    } else {
+      h.dist = ld; h.index = li; h.shift = ls;
+    }
+    a.out[(int64_t)qi * a.k + lane] = h;
+  }
+  if (a.stats) {
+    unsigned lk = nl_lane, wd = n_windowed;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      lk += __shfl_xor(lk, off);
+      wd += __shfl_xor(wd, off);
+    }
+    if (lane == 0) {
+      atomicAdd(a.stats, (unsigned long long)(lk + n_looked));
+      atomicAdd(a.stats + 3, (unsigned long long)wd);
+      atomicAdd(a.stats + 2, (unsigned long long)n_exact);
+      atomicAdd(a.stats + 11, (unsigned long long)n_aligned);
+      if (n_exact) atomicAdd(a.stats + 1, 1ull);
+    }
+  }
+}
+
 template <int B, int NW, int W, bool TWO = false>
 static int launch_rescore_t(const RescoreArgs &a, hipStream_t s) {
   static bool attr_set = false;
@@ -1951,6 +2333,16 @@ int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_
     return e && e[0] == '0';
   }();
   a.two_phase = (!no_two_phase && variant == 0 && n_items < (1ll << RS_SLOT_BITS)) ? 1 : 0;
+  // with the window records of sc_window.hip: one wave per query (RSX_SC_RESCORE=rounds, experiments: the 4-wave workgroup)
+  static const bool force_rounds = [] {
+    const char *e = rsx::exp_env("RSX_SC_RESCORE");
+    return e && e[0] == 'r';
+  }();
+  if (win && !force_rounds) {
+    hipLaunchKernelGGL(sc_rescore_wave_kernel, dim3(q.nq), dim3(64), WaveLds::SIZE, s, a);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+  }
   switch (variant) {
     case 1: RSX_TRY((launch_rescore_t<1, 16, 4>(a, s))); break;
     case 2: RSX_TRY((launch_rescore_t<2, 12, 3>(a, s))); break;

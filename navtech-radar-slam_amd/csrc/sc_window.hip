@@ -12,8 +12,10 @@
 //   * alignment: KC[k] = sum_j vkey_q[(j + k) % 60] * vkey_e[j], K = 64, keys scaled by a power of two and split into
 //     fp16 hi + lo (hi*hi + hi*lo + lo*hi: 24 v_mfma_f32_32x32x16_f16 for 2 x 32 shifts x 32 entries).  argmin_k of
 //     ||vkey_q - shift_k(vkey_e)|| = argmax_k KC[k] (the two squared norms do not depend on k).  The maximum is taken
-//     as k* only when it is UNIQUE within the error bound of KC (below); otherwise the entry gets "no preview" and the
-//     re-scoring kernel runs its own alignment (fp32, then the exact fp64 form with the reference's tie rule).
+//     as k* only when it is UNIQUE within the error bound of KC (below); otherwise k* = -1 and the preview is taken
+//     over the union of the windows of every shift that could be the reference's choice -- still a valid LOWER bound of
+//     the pair distance, so such an entry is usually pruned as well, and only if it survives does the re-scoring kernel
+//     run the exact fp64 alignment with the reference's tie rule.
 //   * preview: S[k][e] = sum_i q2[i + 20 k] * e[i], K = 1200, exactly the direct filter's GEMM (same fp16 images, same
 //     circulant addressing of the query image in LDS, same epilogue arithmetic) -- 150 MFMAs per 32 entries -- but the
 //     epilogue takes the minimum of d_k = 1 - S_k / n_eff(k) over the window of k* only.  |pv - dist| <= WINDOW_MARGIN
@@ -171,6 +173,7 @@ struct WindowArgs {
   const char *qkimg;  // [nq][WINDOW_QK_BYTES]
   const RescoreEntry *slist;
   const int32_t *sl_cnt;
+  const float *thr;  // round edges + counts of sc_select_kernel
   WindowPreview *out;
 };
 
@@ -181,8 +184,7 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qi = blockIdx.x;
-  const int cnt_all = a.sl_cnt[qi];
-  const int cnt = cnt_all < WINDOW_P ? cnt_all : WINDOW_P;
+  const int cnt = window_count(a.sl_cnt[qi], reinterpret_cast<const int32_t *>(a.thr + (int64_t)qi * RESCORE_THR_STRIDE)[RESCORE_NUM_THR]);
   if (cnt <= 0) return;  // uniform
   {
     const uint4 *g0 = reinterpret_cast<const uint4 *>(a.qimg + (int64_t)qi * FILTER_QIMG_BYTES);
@@ -229,53 +231,56 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
         k1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[s], k1, 0, 0, 0);
       }
     }
-    int kstar;
-    bool aligned;
+    // admissible alignments: every shift whose KC is within the error bound of the maximum (bit m of adm = shift m);
+    // all 60 when the keys cannot be compared here (non-finite, too large, too lopsided: see split_key / `balanced`)
+    u64 win;    // the union of their windows
+    int kstar;  // the alignment when exactly one shift is admissible, else -1
     {
       float mx = -INFINITY;
-      int am = 0;
       bool bad = false;
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        const float v = k0[r];
-        bad |= !(v == v);
-        if (v > mx) {
-          mx = v;
-          am = row_of(0, r) + 4 * hh;
-        }
+        bad |= !(k0[r] == k0[r]);
+        mx = fmaxf(mx, k0[r]);
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        float v = k1[r];
-        if (r >= 12) v = hh ? -INFINITY : v;  // rows 60..63 are padding
-        bad |= !(v == v);
-        if (v > mx) {
-          mx = v;
-          am = row_of(1, r) + 4 * hh;
-        }
+        if (r >= 12 && hh) continue;  // rows 60..63 are padding
+        bad |= !(k1[r] == k1[r]);
+        mx = fmaxf(mx, k1[r]);
       }
-      const float omx = __shfl_xor(mx, 32);
-      const int oam = __shfl_xor(am, 32);
-      const float gmx = fmaxf(mx, omx);
+      const float gmx = fmaxf(mx, __shfl_xor(mx, 32));
       const float2 en = reinterpret_cast<const float2 *>(a.vk_n)[slot];
       const float thr = 2.0f * kWinAlignEps * nq_key * en.x;  // NaN when either key is unusable
       // KC is scale-free, the reference's fp64 arithmetic is not: it compares ||vkey_q - shift(vkey_e)||, and when one key
       // is much smaller than the other every shift gives the same double (its search then keeps the first one).  A
       // separation of 2 eps sqrt(E_q E_e) in KC is a RELATIVE separation >= 2.4e-4 * ratio of the squared distances
       // (<= (|q| + |e|)^2 <= 4 max^2): with ratio = min norm / max norm >= 1e-6 that is 2.4e-10, six orders above the
-      // 60 * 2^-52 the fp64 sums can be off by; more lopsided pairs are left to the exact alignment
+      // 60 * 2^-52 the fp64 sums can be off by; more lopsided pairs count as "cannot be compared"
       const float umin = fminf(uq_key, en.y), umax = fmaxf(uq_key, en.y);
       const bool balanced = umin >= 1e-6f * umax && umax < INFINITY && umin > 0.0f;
       const float line = gmx - thr;
-      int c = 0;
+      unsigned m0 = 0, m1 = 0;
 #pragma unroll
-      for (int r = 0; r < 16; r++) c += (k0[r] >= line) ? 1 : 0;
+      for (int r = 0; r < 16; r++) m0 |= (k0[r] >= line) ? (1u << ((r & 3) + 8 * (r >> 2))) : 0u;
 #pragma unroll
-      for (int r = 0; r < 16; r++) c += (k1[r] >= line && !(r >= 12 && hh)) ? 1 : 0;
-      c += __shfl_xor(c, 32);
+      for (int r = 0; r < 16; r++) m1 |= (k1[r] >= line) ? (1u << ((r & 3) + 8 * (r >> 2))) : 0u;
+      m0 <<= 4 * hh;
+      m1 <<= 4 * hh;
+      m0 |= (unsigned)__shfl_xor((int)m0, 32);
+      m1 |= (unsigned)__shfl_xor((int)m1, 32);
       const bool obad = __shfl_xor((int)bad, 32) != 0;
-      kstar = (mx >= omx) ? am : oam;
-      aligned = (c == 1) && !bad && !obad && (thr == thr) && thr < 3.0e38f && balanced;
+      constexpr u64 M60 = (1ull << NS) - 1ull;
+      u64 adm = (((u64)m1 << 32) | m0) & M60;
+      const bool comparable = !bad && !obad && (thr == thr) && thr < 3.0e38f && balanced && adm != 0;
+      if (!comparable) adm = M60;
+      kstar = (__popcll(adm) == 1) ? (__ffsll((long long)adm) - 1) : -1;
+      win = adm;
+#pragma unroll
+      for (int o = 1; o <= 3; o++) {
+        win |= ((adm << o) | (adm >> (NS - o))) & M60;
+        win |= ((adm >> o) | (adm << (NS - o))) & M60;
+      }
     }
 
     // ---- the 60 correlation values of the two images (the direct filter's GEMM) ----
@@ -314,9 +319,8 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
       const u64 l = hh ? lo4 : lo, h = hh ? hi4 : hi;
       const unsigned w[4] = {(unsigned)l, (unsigned)(l >> 32), (unsigned)h, (unsigned)(h >> 32)};
       const unsigned m2lo = (unsigned)em, m2hi = (unsigned)(em >> 32) & 0x0fffffffu;
-      int k0s = kstar - 3;
-      k0s += k0s < 0 ? NS : 0;
-      const int rel0 = 4 * hh - k0s;  // shift of (tile, register) minus the first shift of the window
+      const u64 winh = win >> (4 * hh);  // bit (32 tl + b) = shift 32 tl + b + 4 hh
+      const unsigned wlo = (unsigned)winh, whi = (unsigned)(winh >> 32);
       float best = -INFINITY;
       auto piece = [&](int tl, int r, float S) {
         const int b = (r & 3) + 8 * (r >> 2);
@@ -324,10 +328,8 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
         const unsigned rhi = __builtin_amdgcn_alignbit(w[tl + 2], w[tl + 1], b);
         const int ne = __builtin_popcount(rlo & m2lo) + __builtin_popcount(rhi & m2hi);
         float v = S * __builtin_amdgcn_rcpf((float)ne);  // n_eff == 0: S == 0 exactly, 0 * inf = NaN, dropped by fmaxf
-        int u = rel0 + 32 * tl + b;
-        u += u < 0 ? NS : 0;
-        const bool pad = (tl == 1 && r >= 12 && hh);
-        v = (u < 7 && !pad) ? v : -INFINITY;
+        const bool inwin = ((tl ? whi : wlo) >> b) & 1u;  // (the padding rows 60..63 are never in the window)
+        v = inwin ? v : -INFINITY;
         best = fmaxf(best, v);
       };
 #pragma unroll
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
       best = fmaxf(best, __shfl_xor(best, 32));
       pv = fmaf(best, -1.0f / FILTER_ACC_SCALE, 1.0f);  // -inf (no effective column in the window) -> +inf
     }
-    if (!aligned || ((qm | em) & kNonFinite)) pv = __builtin_nanf("");
+    if ((qm | em) & kNonFinite) pv = __builtin_nanf("");
     if (have && hh == 0) {
       WindowPreview o;
       o.pv = pv;
@@ -360,7 +362,7 @@ int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void
 }
 
 int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
-                  WindowPreview *out, hipStream_t s) {
+                  const float *thr, WindowPreview *out, hipStream_t s) {
   if (q.nq <= 0) return RSX_OK;
   char *img = static_cast<char *>(qimg);
   char *kimg = img + (size_t)q.nq * FILTER_QIMG_BYTES;
@@ -376,6 +378,7 @@ int launch_window(const DbView &db, const QueryView &q, void *qimg, const Rescor
   a.qkimg = kimg;
   a.slist = slist;
   a.sl_cnt = sl_cnt;
+  a.thr = thr;
   a.out = out;
   hipLaunchKernelGGL(sc_window_kernel, dim3((unsigned)q.nq), dim3(256), W_LDS, s, a);
   RSX_HIP(hipGetLastError());

@@ -13,7 +13,7 @@ import numpy as np
 from . import _rsx
 from ._rsx import HIT_DTYPE, MODE_CANDIDATE, MODE_EXHAUSTIVE, check, lib
 
-WINDOW_P = 128            # rsx.h RSX_SC_WINDOW_P
+WINDOW_P = 192            # rsx.h RSX_SC_WINDOW_P
 WINDOW_MARGIN = 1.25e-3   # rsx.h RSX_SC_WINDOW_MARGIN
 
 

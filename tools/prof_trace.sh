@@ -18,7 +18,7 @@ PY
 python - <<PY >> $OUT/summary.txt
 import json
 try:
-    d = json.loads(open("$OUT/bench_trace.log").read().strip().splitlines()[-1])
+    d = json.loads([l for l in open("$OUT/bench_trace.log") if l.startswith("{")][-1])
     print({k: d.get(k) for k in ("value", "ms_per_step", "exact_evals_per_query", "previewed_candidates_per_query", "window_previews_per_query", "valu_previews_per_query", "failures")})
 except Exception as e:
     print("bench line:", e)
