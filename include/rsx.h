@@ -239,12 +239,13 @@ double rsx_sc_filter_eps(void);
  * them are valid) with the sector-key alignment k* (fastAlignUsingVkey, reference SC.cpp:93-113) and the fp16 matrix-core
  * preview pv of distanceBtnScanContext (SC.cpp:116-148): |pv - distance| <= RSX_SC_WINDOW_MARGIN.  Where the alignment is
  * not unique within the kernel's error bound, k* = -1 and pv - RSX_SC_WINDOW_MARGIN is a lower bound of the distance only;
- * pv = NaN for non-finite data, +inf where no shift of the window has an effective column.  All outputs are
- * [nq][RSX_SC_WINDOW_P] host arrays. */
-#define RSX_SC_WINDOW_P 192
+ * pv = NaN for non-finite data, +inf where no shift of the window has an effective column.  Past the first 128 positions
+ * an entry only gets a record when its filter bound can still reach the top-k (k as in the query call), judged by the
+ * previews of the first 128; the others carry k* = -2, pv = NaN.  All outputs are [nq][RSX_SC_WINDOW_P] host arrays. */
+#define RSX_SC_WINDOW_P 320
 #define RSX_SC_WINDOW_MARGIN 1.25e-3f
-int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t *out_slots, float *out_pv, int32_t *out_kstar,
-                           int32_t *out_counts);
+int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t k, int32_t *out_slots, float *out_pv,
+                           int32_t *out_kstar, int32_t *out_counts);
 /* merge nparts per-shard top-k lists (layout [part][nq][k]) into out[nq][k]; pure host logic */
 int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out);
 /* the same on the GPU (d_parts is what an RCCL all-gather of d_out produces) */

@@ -277,7 +277,7 @@ bool use_window() {
 // images -> MFMA filter -> short list + round edges of one query batch
 // elig_monotone: the per-query limits elig[] do not decrease with the query index (self queries)
 int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig,
-                      int32_t first_target, hipStream_t s, bool elig_monotone = false) {
+                      int32_t first_target, int32_t k, hipStream_t s, bool elig_monotone = false) {
   const DbView db = db_view(h);
   const int64_t ld = (n_items + 31) / 32 * 32;
   float *lb = h->f_lb.as<float>();
@@ -291,7 +291,7 @@ int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_
   // alignment + window preview of the head of every short list on the matrix cores (what re-scoring would otherwise
   // do on the VALU, one entry per wavefront)
   if (!use_window()) return RSX_OK;
-  return launch_window(db, q, h->f_wimg.p, h->f_cand.as<RescoreEntry>(), h->f_cnt.as<int32_t>(), h->f_thr.as<float>(),
+  return launch_window(db, q, h->f_wimg.p, h->f_cand.as<RescoreEntry>(), h->f_cnt.as<int32_t>(), k, filter_eps(),
                        h->f_win.as<WindowPreview>(), s);
 }
 
@@ -329,7 +329,7 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
       const int v = e ? atoi(e) : 0;
       return (v >= 1 && v <= 128) ? v : 128;
     }();
-    RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, first_target, s, elig_monotone));
+    RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, first_target, k, s, elig_monotone));
     // exact re-scoring: the 8-wave workgroup in rounds (sc_rescore_kernel; also what the sharded stages use), or
     // -- RSX_SC_RESCORE=walk, experimental -- one wave per query walking the bound-ordered short list with
     // the fp32 pruning preview (sc_walk_kernel: identical results, 6.3 instead of 5.6 ms per step on the bench:
@@ -1150,7 +1150,7 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
     if (first < 8) first = 8;
     if (first > 128) first = 128;
     RSX_TRY(filter_reserve(h, items, nq, s));
-    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, s, elig_monotone != 0));
+    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, k, s, elig_monotone != 0));
     RSX_TRY(rescore(h, qv, items, n_elig, d_q_elig, 0, 1, nullptr, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));
   } else {
     RSX_TRY(run_topk(h, qv, items, n_elig, d_q_elig, k, h->st_partial.as<rsx_sc_hit>(), s, elig_monotone != 0));  // complete already
@@ -1258,9 +1258,10 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
 
 double rsx_sc_filter_eps(void) { return filter_eps(); }
 
-int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t *out_slots, float *out_pv, int32_t *out_kstar,
-                           int32_t *out_counts) {
+int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t k, int32_t *out_slots, float *out_pv,
+                           int32_t *out_kstar, int32_t *out_counts) {
   if (!h || !q_descs || !out_slots || !out_pv || !out_kstar || !out_counts || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   hipStream_t s = h->stream;
@@ -1273,17 +1274,16 @@ int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t 
   RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), nq, s, &qv));
   RSX_TRY(filter_reserve(h, n, nq, s));
   RSX_HIP(hipMemsetAsync(h->f_win.p, 0xff, (size_t)nq * WINDOW_P * sizeof(WindowPreview), s));
-  RSX_TRY(filter_and_select(h, qv, n, h->n_global, nullptr, 128, s));
+  RSX_TRY(filter_and_select(h, qv, n, h->n_global, nullptr, 128, k, s));
   std::vector<RescoreEntry> sl((size_t)nq * RESCORE_SHORTLIST_CAP);
   std::vector<WindowPreview> wp((size_t)nq * WINDOW_P);
-  std::vector<int32_t> cnt((size_t)nq), thr((size_t)nq * RESCORE_THR_STRIDE);
-  RSX_HIP(hipMemcpyAsync(thr.data(), h->f_thr.p, thr.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  std::vector<int32_t> cnt((size_t)nq);
   RSX_HIP(hipMemcpyAsync(sl.data(), h->f_cand.p, sl.size() * sizeof(RescoreEntry), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipMemcpyAsync(wp.data(), h->f_win.p, wp.size() * sizeof(WindowPreview), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipMemcpyAsync(cnt.data(), h->f_cnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   for (int32_t q = 0; q < nq; q++) {
-    const int32_t c = window_count(cnt[(size_t)q], thr[(size_t)q * RESCORE_THR_STRIDE + RESCORE_NUM_THR]);
+    const int32_t c = cnt[(size_t)q] < WINDOW_P ? cnt[(size_t)q] : WINDOW_P;
     out_counts[q] = c;
     for (int32_t i = 0; i < WINDOW_P; i++) {
       const size_t o = (size_t)q * WINDOW_P + i;

@@ -153,26 +153,23 @@ const char *spec_filter_kernel_name();
 // hi/lo-split correlation (unique within its error bound, else "no preview") and the fp16 direct-form correlation of
 // the two images evaluated over the window k* +- 3 only: pv with |pv - dist(query, entry)| <= WINDOW_MARGIN.  The
 // re-scoring kernel uses (k*, pv) instead of its own VALU alignment + fp32 preview.
-constexpr int WINDOW_P = RSX_SC_WINDOW_P;               // short-list positions per query that get a window preview
-constexpr float WINDOW_MARGIN = RSX_SC_WINDOW_MARGIN;   // same arithmetic as the direct filter: its error budget (sc_filter.hip)
-constexpr int WINDOW_QK_BYTES = 4624;       // key image of a query (sc_window.hip)
+constexpr int WINDOW_P = RSX_SC_WINDOW_P;               // short-list positions per query that can get a record
+constexpr int WINDOW_HEAD = 128;                         // the head of the list: always processed (pass 1)
+constexpr float WINDOW_MARGIN = RSX_SC_WINDOW_MARGIN;    // same arithmetic as the direct filter: its error budget (sc_filter.hip)
+constexpr int WINDOW_QK_BYTES = 4624;                    // key image of a query (sc_window.hip)
+static_assert(WINDOW_P % 64 == 0 && WINDOW_HEAD == 128 && WINDOW_P > WINDOW_HEAD, "layout");
+// Positions WINDOW_HEAD .. WINDOW_P - 1 are processed (pass 2) only when their filter bound does not exceed the k-th
+// smallest upper bound the head yields; the others get the record {NaN, -2} = "none".
 struct WindowPreview {
-  float pv;    // NaN: no preview (non-finite data); +inf: no effective column in the window(s)
-  int32_t ks;  // k*, or -1: not unique within the error bound -- pv is then a lower bound only (union of the windows)
+  float pv;    // NaN: no preview (non-finite data, or no record); +inf: no effective column in the window(s)
+  int32_t ks;  // k*; -1: not unique within the error bound -- pv is then a lower bound only (union of the windows); -2: no record
 };
-// short-list positions of a query that get a record: its whole first re-scoring round (rcnt0 = entries in it), at least
-// 128 and at most WINDOW_P
-__host__ __device__ constexpr int window_count(int sl_cnt, int rcnt0) {
-  int c = (rcnt0 + 31) & ~31;
-  c = c < 128 ? 128 : c;
-  c = c > WINDOW_P ? WINDOW_P : c;
-  return c < sl_cnt ? c : sl_cnt;
-}
 size_t window_qimg_bytes(int32_t nq);  // direct-filter images + key images of a query batch
 int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void *vk16, float *vk_n, hipStream_t s);
 // qimg: window_qimg_bytes(nq) of workspace (filled here); out: [nq][WINDOW_P]
+// k: the top-k the query batch asks for; eps: the filter's error budget (filter_eps())
 int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
-                  const float *thr, WindowPreview *out, hipStream_t s);
+                  int32_t k, double eps, WindowPreview *out, hipStream_t s);
 const char *window_kernel_name();
 
 // ---- the reference's public helper methods on arbitrary double descriptors (sc_helpers.hip) ----

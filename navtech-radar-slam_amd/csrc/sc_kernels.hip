@@ -1369,7 +1369,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
         double ud = ld;  // this wave's exact hits so far + its candidates' preview upper bounds
         int ui = li, us = ls;
         const WindowPreview *wp = a.win ? a.win + (int64_t)qi * WINDOW_P : nullptr;
-        const int wcnt = window_count(a.sl_cnt[qi], reinterpret_cast<const int32_t *>(a.thr + (int64_t)qi * RESCORE_THR_STRIDE)[RESCORE_NUM_THR]);
+        const int wcnt = a.sl_cnt[qi] < WINDOW_P ? a.sl_cnt[qi] : WINDOW_P;
         // (requesting the next candidate's registers one candidate ahead was tried: 48 more live registers, one
         // workgroup per CU fewer, 3 % slower -- four waves per SIMD already hide the entry loads)
         EntryRegs cur;
@@ -2104,25 +2104,26 @@ __global__ __launch_bounds__(64, 4) void sc_rescore_wave_kernel(RescoreArgs a) {
   int pos_next = i0;
   if (a.win && i0 < WINDOW_P && i0 < i1) {
     const WindowPreview *wp = a.win + (int64_t)qi * WINDOW_P;
-    const int wc = window_count(sl_cnt, rcnt[0]);
-    const int pw = i1 < wc ? i1 : wc;
-    float lo[RW_CH], ub[RW_CH];
+    const int pw = i1 < WINDOW_P ? i1 : WINDOW_P;
+    float lo[RW_CH], ub[RW_CH], flb[RW_CH];
     int32_t cslot[RW_CH], cks[RW_CH];
 #pragma unroll
     for (int j = 0; j < RW_CH; j++) {
       const int pos = i0 + lane + 64 * j;
       lo[j] = INFINITY;
       ub[j] = INFINITY;
+      flb[j] = INFINITY;
       cslot[j] = 0;
       cks[j] = -1;
-      if (pos < pw) {
+      if (pos < pw) {  // (chunks past pw cost one compare)
         const RescoreEntry e = sl[pos];
         const WindowPreview w = wp[pos];
         cslot[j] = e.slot;
         const int64_t gidx = a.db.idx_base + (int64_t)e.slot * a.db.idx_stride;
         if (gidx < n_elig && !((double)e.lb - a.eps > tau)) {
+          flb[j] = e.lb;
           if (!(w.pv == w.pv)) {
-            lo[j] = -INFINITY;  // no preview at all (non-finite data): must be looked at
+            lo[j] = -INFINITY;  // no preview (non-finite data, or no record: decided below): must be looked at
           } else {
             lo[j] = w.pv - WINDOW_MARGIN;  // +inf stays +inf: no effective column in the window, never a hit
             cks[j] = w.ks;
@@ -2162,6 +2163,12 @@ __global__ __launch_bounds__(64, 4) void sc_rescore_wave_kernel(RescoreArgs a) {
       topk_insert(ud, ui, us, lane, a.k, (double)wm, 0x40000000 + it, 0);  // the index only orders ties
     }
     const double tau_ub = kth_of(ud);
+    // the filter bound once more, against the bound the previews give: this is what removes the entries the window
+    // kernel left without a record (their bound exceeds ITS k-th smallest upper bound, which is never below this one
+    // when this launch starts at the head of the list)
+#pragma unroll
+    for (int j = 0; j < RW_CH; j++)
+      if ((double)flb[j] - a.eps > tau_ub) lo[j] = INFINITY;  // flb = +inf: nothing here
     // survivors in ascending order of their lower bound; the next one's cache lines are requested while the current
     // one is evaluated
     auto take_min = [&](int32_t &slot, int &ks) -> float {

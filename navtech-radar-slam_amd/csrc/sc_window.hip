@@ -52,6 +52,9 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
+#ifndef WIN_OCC
+#define WIN_OCC 4  // waves per SIMD the register budget is set for
+#endif
 constexpr float kWinAlignEps = 3e-5f;
 constexpr double kWinMaxKeyNorm = 4.0e6;
 constexpr u64 kNonFinite = 1ull << 63;
@@ -173,19 +176,23 @@ struct WindowArgs {
   const char *qkimg;  // [nq][WINDOW_QK_BYTES]
   const RescoreEntry *slist;
   const int32_t *sl_cnt;
-  const float *thr;  // round edges + counts of sc_select_kernel
   WindowPreview *out;
+  double eps;  // the filter's error budget, as the re-scoring kernel applies it to a bound
+  int32_t k;
 };
 
 // shift of accumulator register R of tile TL in lane half hh
 __host__ __device__ constexpr int row_of(int tl, int r) { return 32 * tl + (r & 3) + 8 * (r >> 2); }
 
-__global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
+__global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ float s_ub[WINDOW_HEAD];
+  __shared__ int s_pos[WINDOW_P - WINDOW_HEAD];
+  __shared__ int s_n2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qi = blockIdx.x;
-  const int cnt = window_count(a.sl_cnt[qi], reinterpret_cast<const int32_t *>(a.thr + (int64_t)qi * RESCORE_THR_STRIDE)[RESCORE_NUM_THR]);
-  if (cnt <= 0) return;  // uniform
+  const int sl_cnt = a.sl_cnt[qi];
+  if (sl_cnt <= 0) return;  // uniform
   {
     const uint4 *g0 = reinterpret_cast<const uint4 *>(a.qimg + (int64_t)qi * FILTER_QIMG_BYTES);
     const uint4 *g1 = reinterpret_cast<const uint4 *>(a.qkimg + (int64_t)qi * WINDOW_QK_BYTES);
@@ -202,10 +209,10 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
   const char *ap = smem + ((n & 1) ? (FILTER_QIMG_ODD + 40 * n - 8) : (40 * n)) + 16 * hh;
   const char *kp = smem + FILTER_QIMG_BYTES + (n & 7) * QK_COPY + ((n & ~7) + 8 * hh) * 2;  // tile 1: + 64 B
 
-  for (int base = wave * 32; base < cnt; base += 128) {
-    const int pos = base + n;
-    const bool have = pos < cnt;
-    const int64_t slot = sl[have ? pos : base].slot;
+  // one group of 32 short-list entries (lane n and n + 32: entry at list position `pos`; have = the lane has one, else it
+  // shadows position pos_any): writes the record, returns the upper bound of the pair distance the record implies
+  auto do_group = [&](int pos, bool have, int pos_any) -> float {
+    const int64_t slot = sl[have ? pos : pos_any].slot;
 
     // ---- alignment: 2 tiles x (hi*hi + hi*lo + lo*hi) x 4 K-steps ----
     floatx16 k0 = {0}, k1 = {0};
@@ -245,9 +252,9 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 16; r++) {
-        if (r >= 12 && hh) continue;  // rows 60..63 are padding
-        bad |= !(k1[r] == k1[r]);
-        mx = fmaxf(mx, k1[r]);
+        const float v = (r >= 12 && hh) ? 0.0f : k1[r];  // rows 60..63 are padding (M60 drops their bits below)
+        bad |= !(v == v);
+        mx = fmaxf(mx, (r >= 12 && hh) ? -INFINITY : v);
       }
       const float gmx = fmaxf(mx, __shfl_xor(mx, 32));
       const float2 en = reinterpret_cast<const float2 *>(a.vk_n)[slot];
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
     }
 
     // ---- the 60 correlation values of the two images (the direct filter's GEMM) ----
+    __builtin_amdgcn_sched_barrier(0);  // keep the loads below from being hoisted over the alignment (register pressure)
     floatx16 acc0 = {0}, acc1 = {0};
     {
       const char *brow = a.hnR + slot * (2 * DS) + 16 * hh;
@@ -310,6 +318,7 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
     }
 
     // ---- epilogue: max of S_k / n_eff(k) over the window of k* (n_eff from the two column masks, as the filter) ----
+    __builtin_amdgcn_sched_barrier(0);
     const u64 em = a.cmask[slot];
     float pv;
     {
@@ -346,6 +355,69 @@ __global__ __launch_bounds__(256, 2) void sc_window_kernel(WindowArgs a) {
       o.ks = kstar;
       a.out[(int64_t)qi * WINDOW_P + pos] = o;
     }
+    return (have && kstar >= 0 && pv < 3.0e38f) ? pv + WINDOW_MARGIN : INFINITY;  // NaN fails the compare
+  };
+
+  // ---- pass 1: the head of the list ----
+  const int cnt1 = sl_cnt < WINDOW_HEAD ? sl_cnt : WINDOW_HEAD;
+  float ub = INFINITY;
+  if (wave * 32 < cnt1) ub = do_group(wave * 32 + n, wave * 32 + n < cnt1, wave * 32);
+  if (hh == 0) s_ub[wave * 32 + n] = ub;
+  __syncthreads();
+  if (sl_cnt <= WINDOW_HEAD) return;  // uniform
+
+  // ---- the k-th smallest upper bound of the head: an upper bound of the final k-th best distance.  Only entries whose
+  // filter bound does not exceed it can matter to the re-scoring kernel (whose own bound is at least as tight) ----
+  float tau_ub;
+  {
+    const float v0 = s_ub[lane], v1 = s_ub[lane + 64];
+    int r0 = 0, r1 = 0;
+    const float4 *u4 = reinterpret_cast<const float4 *>(s_ub);
+#pragma unroll 4
+    for (int j = 0; j < WINDOW_HEAD / 4; j++) {
+      const float4 u = u4[j];
+      const float x[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int idx = 4 * j + e;
+        r0 += (x[e] < v0 || (x[e] == v0 && idx < lane)) ? 1 : 0;
+        r1 += (x[e] < v1 || (x[e] == v1 && idx < lane + 64)) ? 1 : 0;
+      }
+    }
+    const int want = a.k - 1;  // 0 <= want < WINDOW_HEAD (k <= RSX_SC_MAX_TOPK)
+    const unsigned long long b0 = __ballot(r0 == want), b1 = __ballot(r1 == want);
+    const float c0 = __shfl(v0, b0 ? __ffsll((long long)b0) - 1 : 0), c1 = __shfl(v1, b1 ? __ffsll((long long)b1) - 1 : 0);
+    tau_ub = b0 ? c0 : c1;  // ranks are a permutation of 0..127: exactly one of the two ballots has a bit
+  }
+
+  // ---- pass 2: list positions WINDOW_HEAD .. WINDOW_P - 1 whose bound can still matter; the others get "no record" ----
+  if (wave == 0) {
+    int n2 = 0;
+    const int lim = sl_cnt < WINDOW_P ? sl_cnt : WINDOW_P;
+    for (int p0 = WINDOW_HEAD; p0 < lim; p0 += 64) {
+      const int pos = p0 + lane;
+      bool pass = false;
+      if (pos < lim) {
+        const float lb = sl[pos].lb;
+        pass = !((double)lb - a.eps > (double)tau_ub);  // NaN / -inf bounds: always
+        if (!pass) {
+          WindowPreview o;
+          o.pv = __builtin_nanf("");
+          o.ks = -2;
+          a.out[(int64_t)qi * WINDOW_P + pos] = o;
+        }
+      }
+      const unsigned long long bal = __ballot(pass);
+      if (pass) s_pos[n2 + __popcll(bal & ((1ull << lane) - 1ull))] = pos;
+      n2 += __popcll(bal);
+    }
+    if (lane == 0) s_n2 = n2;
+  }
+  __syncthreads();
+  const int n2 = s_n2;
+  for (int g = wave; g * 32 < n2; g += 4) {
+    const bool have = g * 32 + n < n2;
+    (void)do_group(s_pos[have ? g * 32 + n : g * 32], have, s_pos[g * 32]);
   }
 }
 
@@ -362,7 +434,7 @@ int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void
 }
 
 int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
-                  const float *thr, WindowPreview *out, hipStream_t s) {
+                  int32_t k, double eps, WindowPreview *out, hipStream_t s) {
   if (q.nq <= 0) return RSX_OK;
   char *img = static_cast<char *>(qimg);
   char *kimg = img + (size_t)q.nq * FILTER_QIMG_BYTES;
@@ -378,8 +450,9 @@ int launch_window(const DbView &db, const QueryView &q, void *qimg, const Rescor
   a.qkimg = kimg;
   a.slist = slist;
   a.sl_cnt = sl_cnt;
-  a.thr = thr;
   a.out = out;
+  a.eps = eps;
+  a.k = k < 1 ? 1 : (k > WINDOW_HEAD ? WINDOW_HEAD : k);
   hipLaunchKernelGGL(sc_window_kernel, dim3((unsigned)q.nq), dim3(256), W_LDS, s, a);
   RSX_HIP(hipGetLastError());
   return RSX_OK;

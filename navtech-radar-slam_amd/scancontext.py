@@ -13,7 +13,7 @@ import numpy as np
 from . import _rsx
 from ._rsx import HIT_DTYPE, MODE_CANDIDATE, MODE_EXHAUSTIVE, check, lib
 
-WINDOW_P = 192            # rsx.h RSX_SC_WINDOW_P
+WINDOW_P = 320            # rsx.h RSX_SC_WINDOW_P
 WINDOW_MARGIN = 1.25e-3   # rsx.h RSX_SC_WINDOW_MARGIN
 
 
@@ -264,17 +264,18 @@ class SCManager:
         check(self._L.rsx_sc_filter_bounds(self._h, q.ctypes.data, q.shape[0], out.ctypes.data))
         return out
 
-    def window_previews(self, q_descs):
+    def window_previews(self, q_descs, k=10):
         """The stage between the filter and the exact re-scoring (csrc/sc_window.hip), for diagnostics and tests:
         -> (slots, pv, kstar, counts): the first WINDOW_P short-list entries of every query (local slots, -1 past the
-        end), their matrix-core preview of the pair distance (NaN: the kernel declined) and sector-key alignment."""
+        end), their matrix-core preview of the pair distance and sector-key alignment (-1: not unique, the preview is a
+        lower bound only; -2 with a NaN preview: no record, the entry's filter bound cannot reach the top-k)."""
         q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
         nq = q.shape[0]
         slots = np.empty((nq, WINDOW_P), dtype=np.int32)
         pv = np.empty((nq, WINDOW_P), dtype=np.float32)
         ks = np.empty((nq, WINDOW_P), dtype=np.int32)
         cnt = np.empty(nq, dtype=np.int32)
-        check(self._L.rsx_sc_window_previews(self._h, q.ctypes.data, nq, slots.ctypes.data, pv.ctypes.data, ks.ctypes.data,
+        check(self._L.rsx_sc_window_previews(self._h, q.ctypes.data, nq, k, slots.ctypes.data, pv.ctypes.data, ks.ctypes.data,
                                              cnt.ctypes.data))
         return slots, pv, ks, cnt
 

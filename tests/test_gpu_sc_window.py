@@ -20,12 +20,13 @@ def sc():
     return scancontext
 
 
-def check_previews(sc, oracle, descs, queries, min_served):
+def check_previews(sc, oracle, descs, queries, min_served, k=10):
     g = sc.SCManager(filter_mode=2)
     g.add_descriptors_f32(descs)
-    slots, pv, ks, cnt = g.window_previews(queries)
+    slots, pv, ks, cnt = g.window_previews(queries, k=k)
     assert slots.shape == (len(queries), sc.WINDOW_P)
     served = total = 0
+    skipped = []
     o = oracle.Manager()
     o.add_descriptors(descs.astype(np.float64))
     for qi in range(len(queries)):
@@ -38,6 +39,10 @@ def check_previews(sc, oracle, descs, queries, min_served):
         for i in range(c):
             total += 1
             e = int(slots[qi, i])
+            if int(ks[qi, i]) == -2:    # no record: past the head of the list and out of reach of the top-k
+                assert i >= 128 and np.isnan(pv[qi, i]), (qi, i)
+                skipped.append((qi, e))
+                continue
             if np.isnan(pv[qi, i]):     # non-finite data only
                 assert not (np.isfinite(descs[e]).all() and np.isfinite(queries[qi]).all()), (qi, e)
                 continue
@@ -52,6 +57,13 @@ def check_previews(sc, oracle, descs, queries, min_served):
                 assert pv[qi, i] == np.inf, (qi, e, pv[qi, i])
             else:
                 assert abs(float(pv[qi, i]) - dist[e]) <= sc.WINDOW_MARGIN, (qi, e, float(pv[qi, i]), dist[e])
+    # an entry without a record cannot be one of the k best
+    topk = {}
+    for qi, e in skipped:
+        if qi not in topk:
+            topk[qi] = set(int(h["index"]) for h in o.exhaustive(queries[qi].astype(np.float64), k=k, nthreads=4) if h["dist"] < 1e7)
+        assert e not in topk[qi] or not np.isfinite(descs[e]).all(), (qi, e)
+    total -= len(skipped)
     assert total > 0 and served >= min_served * total, (served, total)
     return served, total
 

@@ -71,3 +71,5 @@ for a in range(nq):
 keys = list(res[0].keys())
 print({kk: float(np.mean([r[kk] for r in res])) for kk in keys})
 print({kk: float(np.median([r[kk] for r in res])) for kk in keys})
+al = np.array([r["all"] for r in res]); print("all (lb<=tau+2e-3) percentiles 50/90/99/max", np.percentile(al, [50, 90, 99]), al.max(), "frac>160", (al > 160).mean(), "frac>192", (al > 192).mean(), "mean excess over 192", np.maximum(al - 192, 0).mean())
+ev = np.array([r["evals_fp16"] for r in res]); print("evals_fp16 percentiles 50/90/99/max", np.percentile(ev, [50, 90, 99]), ev.max(), "src>=0 mean", ev[q_src[qi] >= 0].mean(), "src<0 mean", ev[q_src[qi] < 0].mean())
