@@ -2011,7 +2011,10 @@ __device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane,
   bk_out = bk;
 }
 
-__global__ __launch_bounds__(64, 4) void sc_rescore_wave_kernel(RescoreArgs a) {
+#ifndef RW_OCC
+#define RW_OCC 3  // waves per SIMD the register budget is set for (161 VGPRs, no spills; 4 = 128 VGPRs with 22 spilled: 0.50 against 0.47 ms)
+#endif
+__global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
@@ -2105,20 +2108,18 @@ __global__ __launch_bounds__(64, 4) void sc_rescore_wave_kernel(RescoreArgs a) {
   if (a.win && i0 < WINDOW_P && i0 < i1) {
     const WindowPreview *wp = a.win + (int64_t)qi * WINDOW_P;
     const int pw = i1 < WINDOW_P ? i1 : WINDOW_P;
+    // per lane RW_CH records (positions i0 + lane + 64 j); only their lower bounds stay in registers -- the slot and k*
+    // of a survivor are read again when its turn comes (one uniform load, a candidate ahead of its use)
     float lo[RW_CH], ub[RW_CH], flb[RW_CH];
-    int32_t cslot[RW_CH], cks[RW_CH];
 #pragma unroll
     for (int j = 0; j < RW_CH; j++) {
       const int pos = i0 + lane + 64 * j;
       lo[j] = INFINITY;
       ub[j] = INFINITY;
       flb[j] = INFINITY;
-      cslot[j] = 0;
-      cks[j] = -1;
       if (pos < pw) {  // (chunks past pw cost one compare)
         const RescoreEntry e = sl[pos];
         const WindowPreview w = wp[pos];
-        cslot[j] = e.slot;
         const int64_t gidx = a.db.idx_base + (int64_t)e.slot * a.db.idx_stride;
         if (gidx < n_elig && !((double)e.lb - a.eps > tau)) {
           flb[j] = e.lb;
@@ -2126,7 +2127,6 @@ __global__ __launch_bounds__(64, 4) void sc_rescore_wave_kernel(RescoreArgs a) {
             lo[j] = -INFINITY;  // no preview (non-finite data, or no record: decided below): must be looked at
           } else {
             lo[j] = w.pv - WINDOW_MARGIN;  // +inf stays +inf: no effective column in the window, never a hit
-            cks[j] = w.ks;
             if (w.ks >= 0 && w.pv < 3.0e38f) ub[j] = w.pv + WINDOW_MARGIN;
           }
         }
@@ -2171,7 +2171,7 @@ __global__ __launch_bounds__(64, 4) void sc_rescore_wave_kernel(RescoreArgs a) {
       if ((double)flb[j] - a.eps > tau_ub) lo[j] = INFINITY;  // flb = +inf: nothing here
     // survivors in ascending order of their lower bound; the next one's cache lines are requested while the current
     // one is evaluated
-    auto take_min = [&](int32_t &slot, int &ks) -> float {
+    auto take_min = [&](int &pos) -> float {
       float m = lo[0];
 #pragma unroll
       for (int j = 1; j < RW_CH; j++) m = fminf(m, lo[j]);
@@ -2179,33 +2179,40 @@ __global__ __launch_bounds__(64, 4) void sc_rescore_wave_kernel(RescoreArgs a) {
       if (wm == INFINITY) return wm;
       const unsigned long long bal = __ballot(m == wm);
       const int src = __ffsll((long long)bal) - 1;
-      int32_t s_ = 0;
-      int k_ = -1;
+      int p_ = 0;
       if (lane == src) {
         bool gone = false;
 #pragma unroll
         for (int j = 0; j < RW_CH; j++)
           if (!gone && lo[j] == wm) {
             lo[j] = INFINITY;
-            s_ = cslot[j];
-            k_ = cks[j];
+            p_ = i0 + lane + 64 * j;
             gone = true;
           }
       }
-      slot = __shfl(s_, src);
-      ks = __shfl(k_, src);
+      pos = __shfl(p_, src);
       return wm;
     };
+    auto record_of = [&](int pos, int32_t &slot, int &ks) {  // uniform address
+      slot = __builtin_amdgcn_readfirstlane(sl[pos].slot);
+      const int k_ = __builtin_amdgcn_readfirstlane(wp[pos].ks);
+      ks = k_ >= 0 ? k_ : -1;
+    };
+    int cur_pos = 0, nxt_pos = 0;
+    float cur_lo = take_min(cur_pos);
     int32_t cur_slot = 0, nxt_slot = 0;
     int cur_ks = -1, nxt_ks = -1;
-    float cur_lo = take_min(cur_slot, cur_ks);
+    if (cur_lo < INFINITY) record_of(cur_pos, cur_slot, cur_ks);
     while (cur_lo < INFINITY) {
       const double t_eff = tau < tau_ub ? tau : tau_ub;
       if ((double)cur_lo > t_eff) break;  // exact >= lower bound > an upper bound of the k-th best; the rest is larger still
       EntryRegs er;
       load_entry(a.db, cur_slot, lane, er);
-      const float nxt_lo = take_min(nxt_slot, nxt_ks);
-      if (nxt_lo < INFINITY && !((double)nxt_lo > t_eff)) touch_entry(a.db, nxt_slot, lane);
+      const float nxt_lo = take_min(nxt_pos);
+      if (nxt_lo < INFINITY) {
+        record_of(nxt_pos, nxt_slot, nxt_ks);
+        if (!((double)nxt_lo > t_eff)) touch_entry(a.db, nxt_slot, lane);
+      }
       eval(cur_slot, cur_ks, er);
       cur_lo = nxt_lo;
       cur_slot = nxt_slot;
