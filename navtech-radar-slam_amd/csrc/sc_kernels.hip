@@ -2132,13 +2132,10 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
         }
       }
     }
-    {
-      unsigned c = 0;
 #pragma unroll
-      for (int j = 0; j < RW_CH; j++) c += (i0 + lane + 64 * j < pw) ? 1u : 0u;
-      nl_lane += c;
-#pragma unroll
-      for (int j = 0; j < RW_CH; j++) n_windowed += (lo[j] > -INFINITY && lo[j] < INFINITY) ? 1u : 0u;
+    for (int j = 0; j < RW_CH; j++) {  // (stats) entries this launch had to consider at all / those with a window record
+      nl_lane += (lo[j] < INFINITY) ? 1u : 0u;
+      n_windowed += (lo[j] > -INFINITY && lo[j] < INFINITY) ? 1u : 0u;
     }
     // the k-th smallest of {exact hits so far} u {preview upper bounds}: an upper bound of the final k-th best
     double ud = ld;
