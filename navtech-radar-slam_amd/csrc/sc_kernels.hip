@@ -2132,11 +2132,6 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
         }
       }
     }
-#pragma unroll
-    for (int j = 0; j < RW_CH; j++) {  // (stats) entries this launch had to consider at all / those with a window record
-      nl_lane += (lo[j] < INFINITY) ? 1u : 0u;
-      n_windowed += (lo[j] > -INFINITY && lo[j] < INFINITY) ? 1u : 0u;
-    }
     // the k-th smallest of {exact hits so far} u {preview upper bounds}: an upper bound of the final k-th best
     double ud = ld;
     int ui = li, us = ls;
@@ -2166,6 +2161,11 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
 #pragma unroll
     for (int j = 0; j < RW_CH; j++)
       if ((double)flb[j] - a.eps > tau_ub) lo[j] = INFINITY;  // flb = +inf: nothing here
+#pragma unroll
+    for (int j = 0; j < RW_CH; j++) {  // (stats) entries whose filter bound still admits them / those with a window record
+      nl_lane += (lo[j] < INFINITY) ? 1u : 0u;
+      n_windowed += (lo[j] > -INFINITY && lo[j] < INFINITY) ? 1u : 0u;
+    }
     // survivors in ascending order of their lower bound; the next one's cache lines are requested while the current
     // one is evaluated
     auto take_min = [&](int &pos) -> float {
