@@ -1224,8 +1224,8 @@ struct RescoreArgs {
   unsigned long long *stats;       // optional (bench instrumentation): [0] += candidates scored (phase A or full), [1] += queries
                                    // that scored any, [2] += exact window evaluations (phase B; two-phase scoring only)
   int32_t two_phase;               // B == 1: alignment + fp32 preview of every candidate first, exact evaluation of the few left
-  const WindowPreview *win;        // optional [nq][WINDOW_P]: (k*, preview) of the first short-list positions (sc_window.hip);
-                                   // stats[3] += candidates that used one
+  const WindowPreview *win;        // [nq][WINDOW_P] records of sc_window.hip (sc_rescore_wave_kernel only); stats[3] += records used,
+                                   // stats[11] += exact alignments
 };
 
 // k-th smallest valid record (by (dist, index)) of the nrec records in xch, by RANK COUNTING on one wave:
@@ -1362,74 +1362,28 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
       {
         // ---- phase A: k* and the fp32 preview pv of every candidate; the k-th smallest (pv + margin) over this
         // round's candidates and the exact hits known so far is an upper bound of the final k-th best distance ----
-        // pvs[g] ends up as a LOWER bound of candidate g's exact distance: preview - its margin (-inf: no preview, phase
-        // B must look at it; +inf: never a hit)
         float *pvs = reinterpret_cast<float *>(smem + L::OFF_PV);
-        const int32_t *posv = reinterpret_cast<const int32_t *>(smem + L::OFF_PV);
         double ud = ld;  // this wave's exact hits so far + its candidates' preview upper bounds
         int ui = li, us = ls;
-        const WindowPreview *wp = a.win ? a.win + (int64_t)qi * WINDOW_P : nullptr;
-        const int wcnt = a.sl_cnt[qi] < WINDOW_P ? a.sl_cnt[qi] : WINDOW_P;
         // (requesting the next candidate's registers one candidate ahead was tried: 48 more live registers, one
         // workgroup per CU fewer, 3 % slower -- four waves per SIMD already hide the entry loads)
         EntryRegs cur;
-        // this wave's candidates are g = wave + RS_WAVES * j; 64 of them at a time, one per lane: the ones with a window
-        // preview (sc_window.hip) are finished right here, the rest go through the VALU alignment + preview one by one
-        for (int g0 = wave; g0 < ncand; g0 += RS_WAVES * 64) {
-          const int g = g0 + RS_WAVES * lane;
-          const bool mine = g < ncand;
-          int64_t slot = 0;
-          bool elig = false, windowed = false;
-          float wpv = INFINITY;
-          if (mine) {
-            slot = cand[g];
-            const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
-            elig = gidx < n_elig;
-            const int pos = posv[g];
-            if (elig && wp && pos >= 0 && pos < wcnt) {
-              const WindowPreview w = wp[pos];
-              if (w.pv == w.pv && w.ks >= 0) {  // NaN: no window preview for this entry
-                windowed = true;
-                wpv = w.pv;
-                pvs[g] = w.pv - WINDOW_MARGIN;  // +inf stays +inf
-                cand[g] = (int32_t)slot | (w.ks << RS_SLOT_BITS);
-                // upper bounds only matter while they can enter the wave's top-k; the inserts themselves are wave-wide
-              }
-            }
-            if (!elig) pvs[g] = INFINITY;  // never scored
-          }
-          {
-            unsigned long long todo = __ballot(windowed);
-            if (a.stats && lane == 0 && todo) atomicAdd(a.stats + 3, (unsigned long long)__popcll(todo));
-            while (todo) {
-              const int src = __ffsll((long long)todo) - 1;
-              todo &= todo - 1;
-              const float pv = __shfl(wpv, src);
-              if (!(fabsf(pv) < 3.0e38f)) continue;  // +inf: never a hit
-              const double ub = (double)pv + (double)WINDOW_MARGIN;
-              const double kth = __shfl(ud, a.k - 1);
-              if (!(ub < kth)) continue;  // cannot lower the k-th smallest upper bound
-              const int64_t sl_ = __shfl((long long)slot, src);
-              topk_insert(ud, ui, us, lane, a.k, ub, (int)(a.db.idx_base + sl_ * a.db.idx_stride), 0);
-            }
-          }
-          unsigned long long rest = __ballot(mine && elig && !windowed);
-          if (a.stats && lane == 0 && rest) atomicAdd(a.stats + 11, (unsigned long long)__popcll(rest));
-          while (rest) {
-            const int src = __ffsll((long long)rest) - 1;
-            rest &= rest - 1;
-            const int gs = g0 + RS_WAVES * src;
-            const int64_t sslot = __shfl((long long)slot, src);
-            const int64_t gidx = a.db.idx_base + sslot * a.db.idx_stride;
-            float pv;
-            load_entry(a.db, sslot, lane, cur);
-            const int ks = phase_a(smem, wsm, lane, cur, L::OFF_QP32, e1, pv);
+        for (int g = wave; g < ncand; g += RS_WAVES) {
+          const int64_t slot = cand[g];
+          const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
+          float pv = INFINITY;  // ineligible: never scored
+          int ks = 0;
+          if (gidx < n_elig) {
+            if (g + RS_WAVES < ncand) touch_entry(a.db, cand[g + RS_WAVES], lane);
+            load_entry(a.db, slot, lane, cur);
+            ks = phase_a(smem, wsm, lane, cur, L::OFF_QP32, e1, pv);
             const bool usable = (pv == pv) && fabsf(pv) < 3.0e38f;  // NaN / -inf: no preview; +inf: never a hit
             if (usable) topk_insert(ud, ui, us, lane, a.k, (double)pv + (double)kPreviewMargin, (int)gidx, 0);
-            if (lane == 0) {
-              pvs[gs] = (pv == pv) ? pv - kPreviewMargin : -INFINITY;  // no preview: phase B must look at it
-              cand[gs] = (int32_t)sslot | (ks << RS_SLOT_BITS);
-            }
+            if (!(pv == pv)) pv = -INFINITY;  // no preview: phase B must look at it
+          }
+          if (lane == 0) {
+            pvs[g] = pv;
+            cand[g] = (int32_t)slot | (ks << RS_SLOT_BITS);
           }
         }
         tick(5);
@@ -1454,7 +1408,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
           // this wave's own k-th exact distance tightens the test as it goes
           const double kth_local = __shfl(ld, a.k - 1);
           const double t_eff = kth_local < tau_ub ? kth_local : tau_ub;
-          if ((double)pv > t_eff) continue;  // exact >= preview - margin > k-th best: not in the top-k
+          if ((double)pv - (double)kPreviewMargin > t_eff) continue;  // exact >= pv - margin > k-th best: not in the top-k
           const int32_t packed = cand[g];
           const int64_t slot = packed & ((1 << RS_SLOT_BITS) - 1);
           load_entry(a.db, slot, lane, cur);
@@ -1513,18 +1467,12 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   };
 
   // block-wide append of this thread's candidate (wave ballot + one LDS atomic per wave)
-  // (two-phase scoring: the candidate's short-list position rides along in the preview array -- phase A reads it to find
-  // the entry's window preview and then overwrites it with the preview's lower bound; -1 = not on the short list)
-  auto append = [&](bool pass, int32_t slot, int32_t pos) {
+  auto append = [&](bool pass, int32_t slot) {
     const unsigned long long bal = __ballot(pass);
     int wbase = 0;
     if (lane == 0 && bal) wbase = atomicAdd(s_ncand, __popcll(bal));
     wbase = __shfl(wbase, 0);
-    if (pass) {
-      const int at = wbase + __popcll(bal & ((1ull << lane) - 1ull));
-      cand[at] = slot;
-      if constexpr (TWO) reinterpret_cast<int32_t *>(smem + L::OFF_PV)[at] = pos;
-    }
+    if (pass) cand[wbase + __popcll(bal & ((1ull << lane) - 1ull))] = slot;
   };
 
   // ---- rounds over the short list ----
@@ -1550,7 +1498,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
       const int c1 = c0 + RS_CAND_CAP < i1 ? c0 + RS_CAND_CAP : i1;
       for (int i = c0 + threadIdx.x; i < c1; i += RS_WAVES * 64) {
         const RescoreEntry e = sl[i];
-        append(!((double)e.lb - a.eps > tau), e.slot, i);
+        append(!((double)e.lb - a.eps > tau), e.slot);
       }
       __syncthreads();
       const int ncand = *s_ncand;
@@ -1579,7 +1527,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
           const bool beyond = take_all ? true : (d >= t_cap);
           pass = beyond && (d != INFINITY) && !((double)d - a.eps > tau);
         }
-        append(pass, (int32_t)i, -1);
+        append(pass, (int32_t)i);
         pos += RS_WAVES * 64;
         __syncthreads();
         ncand = *s_ncand;

@@ -419,6 +419,7 @@ struct SpecLane {
   intx8 Bm;                // this lane's entry: column-mask bytes as fp8 0 / 1 (B operand of the n_eff MFMAs)
   int n_e;
   float sqrt_ne, sqrt_ae;
+  float r_ne;  // rcp(max(n_e, 1)): 1 / n_lo of a query without empty columns
   bool e_bad;
 };
 
@@ -527,12 +528,17 @@ struct Recip {
   unsigned flags;
   float sqrt_nq, sqrt_aq;
 };
-__device__ __forceinline__ Recip recip_setup(const frag4 &tail, const SpecLane &ln) {
+__device__ __forceinline__ Recip recip_header(const frag4 &tail) {  // the query's tail words only
   Recip r;
   r.n_q = (int)tail[0];
   r.flags = tail[1];
   r.sqrt_nq = __uint_as_float(tail[2]);
   r.sqrt_aq = __uint_as_float(tail[3]);
+  return r;
+}
+// the coefficients of u(n) for this lane's entry (queries with an empty column only: three reciprocals and a dozen
+// VALU instructions per query that a query with 60 non-empty columns does not need -- its 1 / n_lo is the lane constant r_ne)
+__device__ __forceinline__ void recip_coeffs(Recip &r, const SpecLane &ln) {
   const int li = (r.n_q + ln.n_e - NS > 1) ? (r.n_q + ln.n_e - NS) : 1;
   const int hmin = r.n_q < ln.n_e ? r.n_q : ln.n_e;
   const float L = (float)li, H = (float)(hmin > li ? hmin : li);
@@ -543,7 +549,6 @@ __device__ __forceinline__ Recip recip_setup(const frag4 &tail, const SpecLane &
   r.B2 = float2v{Bc, Bc};
   r.C2 = float2v{C, C};
   r.rL = __builtin_amdgcn_rcpf(L);
-  return r;
 }
 
 // One (4 queries x 32 entries) tile at LDS byte address `tile_lds`.
@@ -657,7 +662,7 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
     __builtin_amdgcn_sched_barrier(0);
     frag4 tailw = tw;
     asm volatile("" : "+v"(tailw));  // a value of its own: tw is re-loaded for the next query below
-    const Recip r = recip_setup(tailw, ln);
+    Recip r = recip_header(tailw);
     if constexpr (q + 1 < SP_QPT) lds_read_frag(tw, a_tl, (q + 1) * SP_QS);
     dma_issue(dma, wave, lane, SP_DMA_PER_Q * q, SP_DMA_PER_Q);
     // A query whose 60 columns are all non-empty (the usual case for a radar scan) meets every entry with
@@ -682,17 +687,27 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
       }
     }
     if (full_q) {
-#pragma unroll
-      for (int k4 = 0; k4 < 4; k4++) {
-        const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[q * 4 + k4]), z, 0, 0, 0);
+      // two result sets: the MFMA of k4 + 1 is in the pipe while the maxima of k4 are taken (one set: every group of
+      // v_max3 waited out its own MFMA; four sets: 64 live registers, spills -- see below)
+      auto max8 = [&](const floatx16 &dd) {
 #pragma unroll
         for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);  // one v_max3_f32 per pair
-      }
+      };
+      floatx16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[q * 4 + 0]), z, 0, 0, 0);
+      floatx16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[q * 4 + 1]), z, 0, 0, 0);
+      max8(d0);
+      d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[q * 4 + 2]), z, 0, 0, 0);
+      max8(d1);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ln.W, __builtin_bit_cast(half8, P[q * 4 + 3]), z, 0, 0, 0);
+      max8(d0);
+      max8(d1);
       // (issuing the four MFMAs back to back into four result sets and taking the maxima afterwards was tried: the 64
       // live registers push two per-lane address registers to scratch, and their reload at the top of every tile
       // is followed by s_waitcnt vmcnt(0) -- a drain of the DMA in flight)
-      m *= r.rL;  // rcp(n_lo) = rcp(n_e): within 1 ulp of 1 / n_e, covered by the (1 + 4e-6) factor below
+      r.rL = ln.r_ne;  // n_lo = n_hi = n_e: within 1 ulp of 1 / n_e, covered by the (1 + 4e-6) factor below
+      m *= r.rL;
     } else {
+    recip_coeffs(r, ln);
     // u(n) of all 32 n_eff values of the query first (independent of stage 2), then per k4: S * u and the maximum;
     // written stage by stage over 4 independent pairs so that no packed instruction waits for the previous one
     float2v u2[4][4];
@@ -863,6 +878,7 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
     const u64 m2 = n_ok ? a.cmask[n] : 0ull;
     ln.n_e = __popcll(m2 & kMask60);
     ln.sqrt_ne = sqrtf((float)ln.n_e);
+    ln.r_ne = __builtin_amdgcn_rcpf((float)(ln.n_e > 1 ? ln.n_e : 1));
     ln.sqrt_ae = n_ok ? a.aux[n] : 0.0f;
     ln.e_bad = (m2 & kNonFinite) != 0;
     {
