@@ -55,6 +55,9 @@ typedef unsigned long long u64;
 #ifndef WIN_OCC
 #define WIN_OCC 4  // waves per SIMD the register budget is set for
 #endif
+#ifndef WIN_RING
+#define WIN_RING 15  // B fragments of the image GEMM in flight per wave
+#endif
 constexpr float kWinAlignEps = 3e-5f;
 constexpr double kWinMaxKeyNorm = 4.0e6;
 constexpr u64 kNonFinite = 1ull << 63;
@@ -295,25 +298,31 @@ __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
     floatx16 acc0 = {0}, acc1 = {0};
     {
       const char *brow = a.hnR + slot * (2 * DS) + 16 * hh;
-      constexpr int U = 5;
-      half8 bcur[U], bnext[U];
+      // B fragments (16 bytes per lane from 32 different rows) through a ring of WIN_RING registers sets: a slot is
+      // refilled right after its MFMAs, so WIN_RING - 1 gathers per wave are in flight all the time (two buffers of five,
+      // the first version, had 5..10: the kernel is bound by the latency x concurrency of this gather, not by the MFMAs)
+      constexpr int R = WIN_RING;
+      static_assert(W_STEPS % R == 0, "whole ring turns");
+      half8 ring[R];
 #pragma unroll
-      for (int u = 0; u < U; u++) bcur[u] = *reinterpret_cast<const half8 *>(brow + 32 * u);
+      for (int u = 0; u < R; u++) ring[u] = *reinterpret_cast<const half8 *>(brow + 32 * u);
 #pragma unroll 1
-      for (int s0 = 0; s0 < W_STEPS; s0 += U) {
-        if (s0 + U < W_STEPS) {
+      for (int s0 = 0; s0 < W_STEPS - R; s0 += R) {
 #pragma unroll
-          for (int u = 0; u < U; u++) bnext[u] = *reinterpret_cast<const half8 *>(brow + 32 * (s0 + U + u));
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
+        for (int u = 0; u < R; u++) {
           const half8 a0 = *reinterpret_cast<const half8 *>(ap + 32 * (s0 + u));
           const half8 a1 = *reinterpret_cast<const half8 *>(ap + 32 * (s0 + u + W_TILE1));
-          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, bcur[u], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, bcur[u], acc1, 0, 0, 0);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, ring[u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, ring[u], acc1, 0, 0, 0);
+          ring[u] = *reinterpret_cast<const half8 *>(brow + 32 * (s0 + R + u));
         }
+      }
 #pragma unroll
-        for (int u = 0; u < U; u++) bcur[u] = bnext[u];
+      for (int u = 0; u < R; u++) {  // the last turn: nothing left to request
+        const half8 a0 = *reinterpret_cast<const half8 *>(ap + 32 * (W_STEPS - R + u));
+        const half8 a1 = *reinterpret_cast<const half8 *>(ap + 32 * (W_STEPS - R + u + W_TILE1));
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, ring[u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, ring[u], acc1, 0, 0, 0);
       }
     }
 
