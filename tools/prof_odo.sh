@@ -5,7 +5,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/tools/bench_odometry.py 8 256 2 > $OUT/bench_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- python $ROOT/tools/bench_odometry.py 8 256 2 > $OUT/bench_trace.log 2>&1
 python - <<PY > $OUT/summary.txt
 import sqlite3, glob
 db = glob.glob("$OUT/trace/*.db")[0]
