@@ -8,7 +8,7 @@
 // to decide which few entries deserve the exact fp64 evaluation.  Rounds 1-2 computed both on the VALU, one entry per
 // wavefront (phase_a in sc_kernels.hip: ~650 issue slots per entry, 137 entries per query: 73 % of the re-scoring
 // kernel).  Both are circular correlations of the query with the entry -- GEMMs whose A operand is a circulant of the
-// query -- so for the first WINDOW_P entries of every short list they are computed here, 32 entries per wavefront:
+// query -- so for the head of every short list (two passes, see the kernel) they are computed here, 32 entries per wavefront:
 //   * alignment: KC[k] = sum_j vkey_q[(j + k) % 60] * vkey_e[j], K = 64, keys scaled by a power of two and split into
 //     fp16 hi + lo (hi*hi + hi*lo + lo*hi: 24 v_mfma_f32_32x32x16_f16 for 2 x 32 shifts x 32 entries).  argmin_k of
 //     ||vkey_q - shift_k(vkey_e)|| = argmax_k KC[k] (the two squared norms do not depend on k).  The maximum is taken
@@ -21,9 +21,10 @@
 //     epilogue takes the minimum of d_k = 1 - S_k / n_eff(k) over the window of k* only.  |pv - dist| <= WINDOW_MARGIN
 //     (= the direct filter's error budget, sc_filter.hip: 2u + u^2 from the fp16 operands + 1200 * 2^-23 from the fp32
 //     accumulation + epilogue < 1.13e-3; shifts without an effective column are ignored on both sides).
-// Cost: 8192 queries x 128 entries = 1 M pairs at 174 MFMAs per 32 = 0.18 Tflop: ~0.1 ms of matrix-core time against
+// Cost: 8192 queries x ~146 entries = 1.2 M pairs at 174 MFMAs per 32 = 0.21 Tflop: ~0.1 ms of matrix-core time against
 // the ~1.2 ms of VALU time it replaces.  The entries are gathered (2400 + 256 B each, whole rows of the entry-major
-// image hnR): 2.8 GB per batch out of a 27 MB database image, i.e. from L2 / MALL.
+// image hnR): 3.1 GB per batch out of a 27 MB database image, i.e. from L2 / MALL -- which is what bounds the kernel
+// (0.37 ms).
 //
 // Error bound of KC (scaled keys x, max |x| in [2^9, 2^10); E = sum x^2):
 //   representation  x = hi + lo + r, |r| <= 2^-22 |x| (+ 2^-25 absolute where lo is subnormal)
@@ -184,8 +185,6 @@ struct WindowArgs {
   int32_t k;
 };
 
-// shift of accumulator register R of tile TL in lane half hh
-__host__ __device__ constexpr int row_of(int tl, int r) { return 32 * tl + (r & 3) + 8 * (r >> 2); }
 
 __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
