@@ -894,6 +894,7 @@ def main():
             if r3:  # who served them: the matrix-core window kernel (sc_window.hip) or the per-wavefront VALU alignment + preview
                 out["window_previews_per_query"] = r3[3] / max(1, nq * args.steps)
                 out["valu_previews_per_query"] = r3[4] / max(1, nq * args.steps)
+                out["exact_window_shifts_per_evaluation"] = r3[5] / max(1, r3[1])  # <= 7: shifts the previews could not exclude
             if planted_ok is not None:
                 out["planted_loops_recovered"] = planted_ok
 

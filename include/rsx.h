@@ -241,11 +241,13 @@ double rsx_sc_filter_eps(void);
  * not unique within the kernel's error bound, k* = -1 and pv - RSX_SC_WINDOW_MARGIN is a lower bound of the distance only;
  * pv = NaN for non-finite data, +inf where no shift of the window has an effective column.  Past the first 128 positions
  * an entry only gets a record when its filter bound can still reach the top-k (k as in the query call), judged by the
- * previews of the first 128; the others carry k* = -2, pv = NaN.  All outputs are [nq][RSX_SC_WINDOW_P] host arrays. */
+ * previews of the first 128; the others carry k* = -2, pv = NaN.  out_shift_mask (k* >= 0 only): bit t set = the window shift
+ * k* - 3 + t can be the minimum; the exact evaluation skips the others (their preview is more than two margins above the best
+ * one, so they are strictly worse).  All outputs are [nq][RSX_SC_WINDOW_P] host arrays. */
 #define RSX_SC_WINDOW_P 320
 #define RSX_SC_WINDOW_MARGIN 1.25e-3f
 int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t k, int32_t *out_slots, float *out_pv,
-                           int32_t *out_kstar, int32_t *out_counts);
+                           int32_t *out_kstar, int32_t *out_shift_mask, int32_t *out_counts);
 /* merge nparts per-shard top-k lists (layout [part][nq][k]) into out[nq][k]; pure host logic */
 int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out);
 /* the same on the GPU (d_parts is what an RCCL all-gather of d_out produces) */
@@ -303,9 +305,9 @@ int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms);
 int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored);
 /* the same plus the number of candidates that went through the cheap phase (alignment + fp32 preview) */
 int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored);
-/* out5 = {candidates, exact_evals, queries_rescored, candidates whose alignment + preview came from the matrix-core window
- * kernel, candidates that went through the per-wavefront alignment + fp32 preview} */
-int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out5);
+/* out6 = {candidates, exact_evals, queries_rescored, candidates whose alignment + preview came from the matrix-core window
+ * kernel, candidates that needed a per-wavefront alignment, window shifts evaluated exactly (<= 7 per exact evaluation)} */
+int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out6);
 
 /* ============================== ORORA registration ======================================
  * Replaces the solver stage of the upstream file-based `odometry.cpp` entry (reference

@@ -188,7 +188,7 @@ def lib():
         L.rsx_sc_profile_read_rescoring.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
         L.rsx_sc_profile_read_rescoring2.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
         L.rsx_sc_profile_read_rescoring3.argtypes = [vp, C.POINTER(i64)]
-        L.rsx_sc_window_previews.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp]
+        L.rsx_sc_window_previews.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
         L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
         L.rsx_scs_create.argtypes = [C.POINTER(ScParams), C.POINTER(i32), i32, C.POINTER(vp)]
         L.rsx_scs_create_layout.argtypes = [C.POINTER(ScParams), C.POINTER(i32), i32, i32, i32, C.POINTER(vp)]

@@ -65,12 +65,14 @@ struct rsx_sc {
   } st;
   DevBuf st_partial;  // this shard's stage-1 hits
   DevBuf helper_ws;   // staging of the stateless helper calls (Scancontext.h:60-66)
-  DevBuf stats;       // 3 x u64 (profiling only): candidates scored, queries that scored any, exact window evaluations
+  DevBuf stats;       // profiling only: RESCORE_STAT_COPIES blocks of counters (sc_kernels.h), summed by the host when read
   void *pinned = nullptr;  // small pinned host staging (results)
   size_t pinned_bytes = 0;
 };
 
 namespace {
+
+constexpr size_t kStatBytes = (size_t)RESCORE_STAT_COPIES * RESCORE_STAT_WORDS * sizeof(unsigned long long);
 
 int set_device(rsx_sc *h) {
   RSX_HIP(hipSetDevice(h->p.device));
@@ -1259,8 +1261,9 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
 double rsx_sc_filter_eps(void) { return filter_eps(); }
 
 int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t k, int32_t *out_slots, float *out_pv,
-                           int32_t *out_kstar, int32_t *out_counts) {
-  if (!h || !q_descs || !out_slots || !out_pv || !out_kstar || !out_counts || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+                           int32_t *out_kstar, int32_t *out_shift_mask, int32_t *out_counts) {
+  if (!h || !q_descs || !out_slots || !out_pv || !out_kstar || !out_shift_mask || !out_counts || nq < 1)
+    return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
@@ -1289,7 +1292,8 @@ int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t 
       const size_t o = (size_t)q * WINDOW_P + i;
       out_slots[o] = i < c ? sl[(size_t)q * RESCORE_SHORTLIST_CAP + i].slot : -1;
       out_pv[o] = wp[o].pv;
-      out_kstar[o] = wp[o].ks;
+      out_kstar[o] = wp[o].ks >= 0 ? (wp[o].ks & 63) : wp[o].ks;
+      out_shift_mask[o] = wp[o].ks >= 0 ? ((wp[o].ks >> 8) & 0x7f) : 0;
     }
   }
   return RSX_OK;
@@ -1340,8 +1344,8 @@ int rsx_sc_profile_enable(rsx_sc *h, int on) {
     for (int i = 0; i < 2 * PairProfiler::kMax; i++) RSX_HIP(hipEventCreate(&h->prof.ev[i]));
   }
   if (on) {
-    RSX_TRY(h->stats.reserve(128, h->stream, false));
-    RSX_HIP(hipMemsetAsync(h->stats.p, 0, 128, h->stream));
+    RSX_TRY(h->stats.reserve(kStatBytes, h->stream, false));
+    RSX_HIP(hipMemsetAsync(h->stats.p, 0, kStatBytes, h->stream));
     RSX_HIP(hipStreamSynchronize(h->stream));
   }
   h->prof.on = on != 0;
@@ -1356,7 +1360,7 @@ int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *quer
 
 int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored) {
   if (!h || !candidates || !exact_evals || !queries_rescored) return fail(RSX_ERR_BAD_ARG, "null arg");
-  int64_t v[5];
+  int64_t v[6];
   RSX_TRY(rsx_sc_profile_read_rescoring3(h, v));
   *candidates = v[0];
   *exact_evals = v[1];
@@ -1364,26 +1368,35 @@ int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exac
   return RSX_OK;
 }
 
-int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out5) {
-  if (!h || !out5) return fail(RSX_ERR_BAD_ARG, "null arg");
+int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out6) {
+  if (!h || !out6) return fail(RSX_ERR_BAD_ARG, "null arg");
+  int64_t *const out5 = out6;
   int64_t *candidates = out5, *exact_evals = out5 + 1, *queries_rescored = out5 + 2;
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
-  for (int i = 0; i < 5; i++) out5[i] = 0;
+  for (int i = 0; i < 6; i++) out6[i] = 0;
   if (!h->stats.p) return RSX_OK;
   RSX_HIP(hipDeviceSynchronize());  // the counters are bumped by kernels on the caller's stream
-  unsigned long long v[16] = {0};
-  RSX_HIP(hipMemcpy(v, h->stats.p, 128, hipMemcpyDeviceToHost));
-  RSX_HIP(hipMemset(h->stats.p, 0, 128));
+  unsigned long long v[RESCORE_STAT_WORDS] = {0};
+  {
+    std::vector<unsigned long long> all((size_t)RESCORE_STAT_COPIES * RESCORE_STAT_WORDS);
+    RSX_HIP(hipMemcpy(all.data(), h->stats.p, kStatBytes, hipMemcpyDeviceToHost));
+    RSX_HIP(hipMemset(h->stats.p, 0, kStatBytes));
+    for (int c = 0; c < RESCORE_STAT_COPIES; c++)
+      for (int i = 0; i < RESCORE_STAT_WORDS; i++) v[i] += all[(size_t)c * RESCORE_STAT_WORDS + i];
+  }
   if (rsx::exp_env("RSX_RESCORE_PROF") && v[1])  // region cycles of wave 0, averaged per scoring workgroup
     fprintf(stderr, "[sc_rescore prof] per query (cycles of wave 0): load %.0f  phaseA %.0f  mergeA %.0f  phaseB %.0f  mergeX %.0f  gather %.0f  total %.0f\n",
             (double)v[4] / v[1], (double)v[5] / v[1], (double)v[6] / v[1], (double)v[7] / v[1], (double)v[8] / v[1], (double)v[9] / v[1],
             (double)v[10] / v[1]);
+  if (rsx::exp_env("RSX_RESCORE_PROF") && v[1] && v[13])
+    fprintf(stderr, "[sc_rescore prof] wave kernel: header %.0f  records %.0f (then tau_ub = the 'phaseA' figure)\n", (double)v[13] / v[1], (double)v[14] / v[1]);
   *candidates = (int64_t)v[0];
   *exact_evals = v[2] ? (int64_t)v[2] : (int64_t)v[0];  // one-pass scoring: every candidate is an exact evaluation
   *queries_rescored = (int64_t)v[1];
   out5[3] = (int64_t)v[3];   // candidates whose alignment + preview came from the window kernel (sc_window.hip)
-  out5[4] = (int64_t)v[11];  // candidates that went through the VALU alignment + fp32 preview
+  out5[4] = (int64_t)v[11];  // candidates that went through the VALU alignment + fp32 preview / exact alignments (wave kernel)
+  out6[5] = v[12] ? (int64_t)v[12] : 7 * *exact_evals;  // window shifts evaluated exactly (7 per evaluation without a shift mask)
   return RSX_OK;
 }
 

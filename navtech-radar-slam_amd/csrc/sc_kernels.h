@@ -77,6 +77,10 @@ constexpr int RESCORE_NUM_THR = 6;           // round edges t_0..t_4 and t_cap
 // per query: RESCORE_NUM_THR float edges, then RESCORE_NUM_THR int32 counts (short-list entries below each edge:
 // the list is ordered by bin, so round r is the range [count[r-1], count[r]))
 constexpr int RESCORE_THR_STRIDE = 2 * RESCORE_NUM_THR;
+// the re-scoring kernels' bookkeeping (profiling only): RESCORE_STAT_COPIES blocks of RESCORE_STAT_WORDS u64 counters; a query
+// adds to block (query index % copies) -- one shared block made 8192 waves queue up on a single cache line of atomics (measured:
+// +0.15-0.23 ms on a 3.4 ms step); the host sums the blocks
+constexpr int RESCORE_STAT_WORDS = 16, RESCORE_STAT_COPIES = 64;
 struct WindowPreview;
 struct RescoreEntry {
   float lb;      // filter bound
@@ -162,7 +166,9 @@ static_assert(WINDOW_P % 64 == 0 && WINDOW_HEAD == 128 && WINDOW_P > WINDOW_HEAD
 // smallest upper bound the head yields; the others get the record {NaN, -2} = "none".
 struct WindowPreview {
   float pv;    // NaN: no preview (non-finite data, or no record); +inf: no effective column in the window(s)
-  int32_t ks;  // k*; -1: not unique within the error bound -- pv is then a lower bound only (union of the windows); -2: no record
+  int32_t ks;  // >= 0: k* in bits 0..5 and, in bits 8..14, which of the window shifts k* - 3 + t can be the minimum at all
+               // (the others are more than 2 margins above the best preview); -1: not unique within the error bound -- pv is
+               // then a lower bound only (union of the windows); -2: no record
 };
 size_t window_qimg_bytes(int32_t nq);  // direct-filter images + key images of a query batch
 int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void *vk16, float *vk_n, hipStream_t s);

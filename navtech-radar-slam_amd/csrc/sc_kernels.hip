@@ -311,18 +311,27 @@ __device__ __forceinline__ void load_entry(const DbView &db, int64_t slot, int l
   r.n2 = db.norm[slot * NS + cl];
 }
 
-// cache touch of an entry this wave will score one candidate later: one dword per lane and array (60 lanes x 80 B
-// cover every line of the 4800-byte descriptor), results discarded -- brings the lines towards this XCD's L2 without
-// holding registers (requesting the real registers a candidate ahead costs 24 live VGPRs and spills)
-__device__ __forceinline__ void touch_entry(const DbView &db, int64_t slot, int lane) {
+// cache touch of an entry this wave will score later: one dword per lane and array (60 lanes x 80 B cover every line of
+// the 4800-byte descriptor), results discarded -- brings the lines towards this XCD's L2 without holding the entry's 24
+// registers.  The three destination registers belong to the CALLER (struct Touch) and must stay reserved until the loads
+// have landed: the compiler does not know that an asm load is still in flight, and a destination it considered dead
+// would be handed to the next value and overwritten when the load returns.  touch_keep() after the caller's next wait
+// for YOUNGER loads (VMEM returns in order), or touch_wait(), ends the reservation.
+struct Touch {
+  int d0 = 0, d1 = 0, d2 = 0;
+};
+__device__ __forceinline__ void touch_entry(const DbView &db, int64_t slot, int lane, Touch &t) {
   const int cl = lane < NS ? lane : 0;
   const float *pd = db.desc + slot * DS + cl * NR;
   const double *pk = db.vkey + slot * NS + cl, *pn = db.norm + slot * NS + cl;
-  int d0, d1, d2;
   asm volatile("global_load_dword %0, %3, off\n\tglobal_load_dword %1, %4, off\n\tglobal_load_dword %2, %5, off"
-               : "=&v"(d0), "=&v"(d1), "=&v"(d2)
+               : "+v"(t.d0), "+v"(t.d1), "+v"(t.d2)
                : "v"(pd), "v"(pk), "v"(pn)
                : "memory");
+}
+__device__ __forceinline__ void touch_keep(Touch &t) { asm volatile("" : "+v"(t.d0), "+v"(t.d1), "+v"(t.d2)); }
+__device__ __forceinline__ void touch_wait(Touch &t) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(t.d0), "+v"(t.d1), "+v"(t.d2)::"memory");
 }
 
 template <int B, bool PREVIEW = false, bool FAST = false>
@@ -1025,14 +1034,16 @@ __global__ __launch_bounds__(256, W) void sc_pair2_kernel(PairArgs a) {
   int li = 0x7fffffff, ls = 0;
   const int32_t *gath = a.gather;
   EntryRegs cur;
+  Touch tch;
   for (int64_t g = slot; g < a.n_items; g += nwaves) {
     const int64_t eslot = gath ? (int64_t)gath[g] : (a.first + g);
     const int64_t gidx = a.db.idx_base + eslot * a.db.idx_stride;
     if (gidx >= n_elig) continue;  // (wave-uniform) never a hit
-    if (g + nwaves < a.n_items) touch_entry(a.db, gath ? (int64_t)gath[g + nwaves] : (a.first + g + nwaves), lane);
+    if (g + nwaves < a.n_items) touch_entry(a.db, gath ? (int64_t)gath[g + nwaves] : (a.first + g + nwaves), lane, tch);
     load_entry(a.db, eslot, lane, cur);
     float pv;
     const int ks = phase_a(smem, wsm, lane, cur, PAIR2_OFF_QP32, e1, pv);
+    touch_keep(tch);  // phase A has waited for cur's registers, which were requested after the touch
     const double kth = __shfl(ld, a.k - 1);  // +inf until the wave holds k hits
     if ((pv == pv) && (double)pv - (double)kPreviewMargin > kth) continue;  // exact >= pv - margin > the wave's k-th best
     double bd;
@@ -1275,6 +1286,7 @@ __device__ __forceinline__ double wave_select_kth(const rsx_sc_hit *xch, int nre
 template <int B, int RS_WAVES, int W, bool TWO = false>
 __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArgs a) {
   static_assert(!TWO || B == 1, "two-phase scoring handles one entry per wavefront");
+  if (a.stats) a.stats += (blockIdx.x % RESCORE_STAT_COPIES) * RESCORE_STAT_WORDS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = RescoreLds<B, RS_WAVES>;
   const int lane = threadIdx.x & 63;
@@ -1368,15 +1380,17 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
         // (requesting the next candidate's registers one candidate ahead was tried: 48 more live registers, one
         // workgroup per CU fewer, 3 % slower -- four waves per SIMD already hide the entry loads)
         EntryRegs cur;
+        Touch tch;
         for (int g = wave; g < ncand; g += RS_WAVES) {
           const int64_t slot = cand[g];
           const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
           float pv = INFINITY;  // ineligible: never scored
           int ks = 0;
           if (gidx < n_elig) {
-            if (g + RS_WAVES < ncand) touch_entry(a.db, cand[g + RS_WAVES], lane);
+            if (g + RS_WAVES < ncand) touch_entry(a.db, cand[g + RS_WAVES], lane, tch);
             load_entry(a.db, slot, lane, cur);
             ks = phase_a(smem, wsm, lane, cur, L::OFF_QP32, e1, pv);
+            touch_keep(tch);  // phase A has waited for cur's registers, which were requested after the touch
             const bool usable = (pv == pv) && fabsf(pv) < 3.0e38f;  // NaN / -inf: no preview; +inf: never a hit
             if (usable) topk_insert(ud, ui, us, lane, a.k, (double)pv + (double)kPreviewMargin, (int)gidx, 0);
             if (!(pv == pv)) pv = -INFINITY;  // no preview: phase B must look at it
@@ -1875,8 +1889,10 @@ constexpr int RW_CH = (WINDOW_P + 63) / 64;  // window records per lane
 
 // phase B on the fp32 query image: the same operations in the same order as phase_b (the conversion float -> double is
 // exact), half the LDS bytes per column
-__device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane, const EntryRegs &er, int ks, double &bd_out,
-                                          int &bk_out) {
+// tmask: bit t set = window shift ks - 3 + t is evaluated (wave-uniform; the shifts left out are known to be strictly worse
+// than the best one, so the winner under (distance, shift value) is the same)
+__device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane, const EntryRegs &er, int ks, unsigned tmask,
+                                          double &bd_out, int &bk_out) {
   const int cl = lane < NS ? lane : 0;
   const double *qn1 = reinterpret_cast<const double *>(smem + WaveLds::OFF_QN1);
   wave_lds_fence();
@@ -1891,6 +1907,7 @@ __device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane,
   int *misc = reinterpret_cast<int *>(wsm + ENT_MISC);
 #pragma unroll
   for (int t = 0; t < 7; t++) {
+    if (!((tmask >> t) & 1u)) continue;  // scalar branch
     int k = ks + t - 3;
     k += (k < 0) ? NS : 0;
     k -= (k >= NS) ? NS : 0;
@@ -1918,7 +1935,7 @@ __device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane,
   const int tt = lane & 7;
   double bd = INFINITY;
   int bk = 0x7fffffff;
-  if (lane < 8 && tt < 7) {
+  if (lane < 8 && tt < 7 && ((tmask >> tt) & 1u)) {
     const double2 *sp = reinterpret_cast<const double2 *>(wsm + ENT_SIM + tt * (NS * 8));
     double s = 0.0;
 #pragma unroll 1
@@ -1964,6 +1981,7 @@ __device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane,
 #endif
 __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (a.stats) a.stats += (blockIdx.x % RESCORE_STAT_COPIES) * RESCORE_STAT_WORDS;
   const int lane = threadIdx.x;
   const int qi = blockIdx.x;
   char *wsm = smem + WaveLds::OFF_ENT;
@@ -1998,11 +2016,39 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
   };
   double tau = kth_of(ld);
   bool query_loaded = false;
-  unsigned n_exact = 0, n_looked = 0, n_aligned = 0;  // wave-uniform counters (stats)
+  unsigned n_exact = 0, n_looked = 0, n_aligned = 0, n_shifts = 0;  // wave-uniform counters (stats)
   unsigned nl_lane = 0, n_windowed = 0;               // per-lane counters, summed over the wave at the end
 
   // score one entry exactly (ks < 0: the alignment is not known yet)
-  auto eval = [&](int64_t slot, int ks, const EntryRegs &er) {
+  // region cycles for RSX_RESCORE_PROF (experiments builds): [4] query load, [5] records + tau_ub, [6] picking the next
+  // survivor, [7] phase B, [8] exact alignments, [9] waiting for the entry's registers, [10] the whole wave
+#ifdef RSX_EXPERIMENTS
+  const bool timing = a.stats != nullptr;
+#else
+  constexpr bool timing = false;
+#endif
+  long long tacc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  long long t_mark = timing ? clock64() : 0;
+  const long long t_begin = t_mark;
+  auto lap = [&](int slot_) {
+    if (!timing) return;
+    const long long t = clock64();
+    tacc[slot_] += t - t_mark;
+    t_mark = t;
+  };
+  auto eval = [&](int64_t slot, int ksm, const EntryRegs &er) {
+    if (timing) {
+      lap(2);  // [6] since the last lap: picking / requesting
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      lap(5);  // [9]
+    }
+    int ks = ksm;
+    unsigned tmask = 0x7fu;
+    if (ksm >= 0) {  // a window record: k* and the shifts of its window that can be the minimum
+      ks = ksm & 63;
+      const unsigned m7 = ((unsigned)ksm >> 8) & 0x7fu;
+      if (m7) tmask = m7;
+    }
     if (!query_loaded) {
       const float4 *src = reinterpret_cast<const float4 *>(a.q.desc + (int64_t)qi * DS);
       float4 *dst = reinterpret_cast<float4 *>(smem + WaveLds::OFF_QF32);
@@ -2020,15 +2066,22 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
       }
       query_loaded = true;
       wave_lds_fence();
+      lap(0);  // [4]
     }
     if (ks < 0) {
       ks = align_exact(reinterpret_cast<const double *>(smem + WaveLds::OFF_QV1), wsm, lane, er.v);
       n_aligned++;
+      lap(4);  // [8]
     }
     double bd;
     int bk;
-    phase_b32(smem, wsm, lane, er, ks, bd, bk);
+    phase_b32(smem, wsm, lane, er, ks, tmask, bd, bk);
+    if (timing) {
+      asm volatile("" : "+v"(bd));
+      lap(3);  // [7]
+    }
     n_exact++;
+    n_shifts += (unsigned)__builtin_popcount(tmask);
     const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
     if (gidx < n_elig && bd < kBig) {
       topk_insert(ld, li, ls, lane, a.k, bd, (int)gidx, bk);
@@ -2049,6 +2102,11 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
     return c < sl_cnt ? c : sl_cnt;
   };
   const int i0 = upto(a.round_begin), i1 = upto(r_end);
+  if (timing) {
+    int keep = i0 + i1;
+    asm volatile("" : "+s"(keep));
+    lap(7);  // [13] header loads
+  }
   bool done = false;  // some list entry's bound already exceeds tau: everything after it does too
 
   // ---- the head of the list: window records (k*, preview) ----
@@ -2080,6 +2138,10 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
         }
       }
     }
+    if (timing) {
+      asm volatile("" : "+v"(lo[0]), "+v"(ub[0]));
+      lap(8);  // [14] record loads
+    }
     // the k-th smallest of {exact hits so far} u {preview upper bounds}: an upper bound of the final k-th best
     double ud = ld;
     int ui = li, us = ls;
@@ -2103,6 +2165,7 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
       topk_insert(ud, ui, us, lane, a.k, (double)wm, 0x40000000 + it, 0);  // the index only orders ties
     }
     const double tau_ub = kth_of(ud);
+    lap(1);  // [5]
     // the filter bound once more, against the bound the previews give: this is what removes the entries the window
     // kernel left without a record (their bound exceeds ITS k-th smallest upper bound, which is never below this one
     // when this launch starts at the head of the list)
@@ -2114,54 +2177,74 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
       nl_lane += (lo[j] < INFINITY) ? 1u : 0u;
       n_windowed += (lo[j] > -INFINITY && lo[j] < INFINITY) ? 1u : 0u;
     }
-    // survivors in ascending order of their lower bound; the next one's cache lines are requested while the current
-    // one is evaluated
-    auto take_min = [&](int &pos) -> float {
-      float m = lo[0];
-#pragma unroll
-      for (int j = 1; j < RW_CH; j++) m = fminf(m, lo[j]);
-      const float wm = wave_min_f32(m);
-      if (wm == INFINITY) return wm;
-      const unsigned long long bal = __ballot(m == wm);
-      const int src = __ffsll((long long)bal) - 1;
-      int p_ = 0;
-      if (lane == src) {
-        bool gone = false;
-#pragma unroll
-        for (int j = 0; j < RW_CH; j++)
-          if (!gone && lo[j] == wm) {
-            lo[j] = INFINITY;
-            p_ = i0 + lane + 64 * j;
-            gone = true;
-          }
-      }
-      pos = __shfl(p_, src);
-      return wm;
+    // Survivors.  A memory round trip costs this kernel ~10 k cycles (random 4.8-KB rows of a 48 MB array: RSX_RESCORE_PROF
+    // showed 25 k cycles per survivor when each one's records and registers were requested only when its turn came), so the
+    // survivors are first compacted into lanes (64 per round), their slots / k* fetched in ONE parallel round trip, the
+    // cache lines of ALL of them requested at once, and only then are they evaluated -- in ascending order of their lower
+    // bound, the registers of the next one in flight while the current one is evaluated.
+    struct Packed {
+      float lo;
+      int pos;
     };
-    auto record_of = [&](int pos, int32_t &slot, int &ks) {  // uniform address
-      slot = __builtin_amdgcn_readfirstlane(sl[pos].slot);
-      const int k_ = __builtin_amdgcn_readfirstlane(wp[pos].ks);
-      ks = k_ >= 0 ? k_ : -1;
-    };
-    int cur_pos = 0, nxt_pos = 0;
-    float cur_lo = take_min(cur_pos);
-    int32_t cur_slot = 0, nxt_slot = 0;
-    int cur_ks = -1, nxt_ks = -1;
-    if (cur_lo < INFINITY) record_of(cur_pos, cur_slot, cur_ks);
-    while (cur_lo < INFINITY) {
-      const double t_eff = tau < tau_ub ? tau : tau_ub;
-      if ((double)cur_lo > t_eff) break;  // exact >= lower bound > an upper bound of the k-th best; the rest is larger still
-      EntryRegs er;
-      load_entry(a.db, cur_slot, lane, er);
-      const float nxt_lo = take_min(nxt_pos);
-      if (nxt_lo < INFINITY) {
-        record_of(nxt_pos, nxt_slot, nxt_ks);
-        if (!((double)nxt_lo > t_eff)) touch_entry(a.db, nxt_slot, lane);
+    Packed *cbuf = reinterpret_cast<Packed *>(wsm);  // the entry region is free until the first evaluation of a round
+    for (;;) {
+      const double t_now = tau < tau_ub ? tau : tau_ub;
+      int nsurv = 0;
+#pragma unroll
+      for (int j = 0; j < RW_CH; j++) {
+        const bool sv = lo[j] < INFINITY && !((double)lo[j] > t_now);
+        const unsigned long long bal = __ballot(sv);
+        const int rank = nsurv + __popcll(bal & ((1ull << lane) - 1ull));
+        if (sv && rank < 64) {
+          cbuf[rank] = Packed{lo[j], i0 + lane + 64 * j};
+          lo[j] = INFINITY;  // taken
+        }
+        nsurv += __popcll(bal);
       }
-      eval(cur_slot, cur_ks, er);
-      cur_lo = nxt_lo;
-      cur_slot = nxt_slot;
-      cur_ks = nxt_ks;
+      if (nsurv == 0) break;  // (uniform)
+      nsurv = nsurv < 64 ? nsurv : 64;
+      wave_lds_fence();
+      float mylo = INFINITY;
+      int32_t myslot = 0;
+      int myks = -1;
+      if (lane < nsurv) {
+        const Packed c = cbuf[lane];
+        mylo = c.lo;
+        myslot = sl[c.pos].slot;
+        const int k_ = wp[c.pos].ks;
+        myks = k_ >= 0 ? k_ : -1;  // (k* | shift mask << 8) or "alignment unknown"
+      }
+      wave_lds_fence();
+      {
+        Touch tch;
+        for (int i = 0; i < nsurv; i++) touch_entry(a.db, __shfl(myslot, i), lane, tch);
+        touch_wait(tch);  // ONE round trip for all of them (they overlap); from here on the entries come out of the L2
+      }
+      auto pick = [&](int32_t &slot, int &ks) -> float {  // the smallest lower bound left in this round
+        const float wm = wave_min_f32(mylo);
+        if (wm == INFINITY) return wm;
+        const int src = __ffsll((long long)__ballot(mylo == wm)) - 1;
+        slot = __shfl(myslot, src);
+        ks = __shfl(myks, src);
+        if (lane == src) mylo = INFINITY;
+        return wm;
+      };
+      EntryRegs cur, nxt;
+      int32_t cur_slot = 0, nxt_slot = 0;
+      int cur_ks = -1, nxt_ks = -1;
+      float cur_lo = pick(cur_slot, cur_ks);
+      if (cur_lo < INFINITY) load_entry(a.db, cur_slot, lane, cur);
+      while (cur_lo < INFINITY) {
+        const double t_eff = tau < tau_ub ? tau : tau_ub;
+        if ((double)cur_lo > t_eff) break;  // exact >= lower bound > an upper bound of the k-th best; the rest is larger still
+        const float nxt_lo = pick(nxt_slot, nxt_ks);
+        if (nxt_lo < INFINITY && !((double)nxt_lo > t_eff)) load_entry(a.db, nxt_slot, lane, nxt);
+        eval(cur_slot, cur_ks, cur);
+        cur_lo = nxt_lo;
+        cur_slot = nxt_slot;
+        cur_ks = nxt_ks;
+        cur = nxt;
+      }
     }
     pos_next = pw > i0 ? pw : i0;
   }
@@ -2233,6 +2316,13 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
       atomicAdd(a.stats + 3, (unsigned long long)wd);
       atomicAdd(a.stats + 2, (unsigned long long)n_exact);
       atomicAdd(a.stats + 11, (unsigned long long)n_aligned);
+      atomicAdd(a.stats + 12, (unsigned long long)n_shifts);
+      if (timing) {
+        for (int i = 0; i < 6; i++) atomicAdd(a.stats + 4 + i, (unsigned long long)tacc[i]);
+        atomicAdd(a.stats + 13, (unsigned long long)tacc[7]);
+        atomicAdd(a.stats + 14, (unsigned long long)tacc[8]);
+        atomicAdd(a.stats + 10, (unsigned long long)(clock64() - t_begin));
+      }
       if (n_exact) atomicAdd(a.stats + 1, 1ull);
     }
   }

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
       const u64 winh = win >> (4 * hh);  // bit (32 tl + b) = shift 32 tl + b + 4 hh
       const unsigned wlo = (unsigned)winh, whi = (unsigned)(winh >> 32);
       float best = -INFINITY;
-      auto piece = [&](int tl, int r, float S) {
+      auto piece = [&](int tl, int r, float S) -> float {
         const int b = (r & 3) + 8 * (r >> 2);
         const unsigned rlo = __builtin_amdgcn_alignbit(w[tl + 1], w[tl], b);
         const unsigned rhi = __builtin_amdgcn_alignbit(w[tl + 2], w[tl + 1], b);
@@ -348,13 +348,34 @@ __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
         const bool inwin = ((tl ? whi : wlo) >> b) & 1u;  // (the padding rows 60..63 are never in the window)
         v = inwin ? v : -INFINITY;
         best = fmaxf(best, v);
+        return v;
       };
 #pragma unroll
-      for (int r = 0; r < 16; r++) piece(0, r, acc0[r]);
+      for (int r = 0; r < 16; r++) acc0[r] = piece(0, r, acc0[r]);  // S_k -> S_k / n_eff(k) inside the window, -inf outside
 #pragma unroll
-      for (int r = 0; r < 16; r++) piece(1, r, acc1[r]);
+      for (int r = 0; r < 16; r++) acc1[r] = piece(1, r, acc1[r]);
       best = fmaxf(best, __shfl_xor(best, 32));
       pv = fmaf(best, -1.0f / FILTER_ACC_SCALE, 1.0f);  // -inf (no effective column in the window) -> +inf
+      // which of the 7 window shifts can be the minimum at all: d_t >= pv_t - margin and d_min <= pv_min + margin, so a
+      // shift with pv_t > pv_min + 2 margin is STRICTLY worse than the best one and the exact evaluation may skip it
+      // (bit t of the mask = shift k* - 3 + t; only meaningful with a unique alignment)
+      if (kstar >= 0) {
+        const float line = best - 2.0f * WINDOW_MARGIN * FILTER_ACC_SCALE;
+        int k0s = kstar - 3;
+        k0s += k0s < 0 ? NS : 0;
+        unsigned mask7 = 0;
+        auto near = [&](int tl, int r, float v) {
+          int t = 32 * tl + (r & 3) + 8 * (r >> 2) + 4 * hh - k0s;
+          t += t < 0 ? NS : 0;
+          mask7 |= (v >= line && t < 7) ? (1u << t) : 0u;  // v = -inf outside the window, NaN without an effective column
+        };
+#pragma unroll
+        for (int r = 0; r < 16; r++) near(0, r, acc0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; r++) near(1, r, acc1[r]);
+        mask7 |= (unsigned)__shfl_xor((int)mask7, 32);
+        kstar |= (int)(mask7 << 8);
+      }
     }
     if ((qm | em) & kNonFinite) pv = __builtin_nanf("");
     if (have && hh == 0) {

@@ -266,18 +266,20 @@ class SCManager:
 
     def window_previews(self, q_descs, k=10):
         """The stage between the filter and the exact re-scoring (csrc/sc_window.hip), for diagnostics and tests:
-        -> (slots, pv, kstar, counts): the first WINDOW_P short-list entries of every query (local slots, -1 past the
+        -> (slots, pv, kstar, shift_mask, counts): the first WINDOW_P short-list entries of every query (local slots, -1 past the
         end), their matrix-core preview of the pair distance and sector-key alignment (-1: not unique, the preview is a
-        lower bound only; -2 with a NaN preview: no record, the entry's filter bound cannot reach the top-k)."""
+        lower bound only; -2 with a NaN preview: no record, the entry's filter bound cannot reach the top-k); bit t of
+        shift_mask: the window shift kstar - 3 + t can be the minimum (the exact evaluation skips the others)."""
         q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
         nq = q.shape[0]
         slots = np.empty((nq, WINDOW_P), dtype=np.int32)
         pv = np.empty((nq, WINDOW_P), dtype=np.float32)
         ks = np.empty((nq, WINDOW_P), dtype=np.int32)
+        sm = np.empty((nq, WINDOW_P), dtype=np.int32)
         cnt = np.empty(nq, dtype=np.int32)
         check(self._L.rsx_sc_window_previews(self._h, q.ctypes.data, nq, k, slots.ctypes.data, pv.ctypes.data, ks.ctypes.data,
-                                             cnt.ctypes.data))
-        return slots, pv, ks, cnt
+                                             sm.ctypes.data, cnt.ctypes.data))
+        return slots, pv, ks, sm, cnt
 
     @staticmethod
     def filter_eps():
@@ -312,8 +314,8 @@ class SCManager:
 
     def profile_read_rescoring3(self):
         """-> (candidates, exact window evaluations, queries that scored any, candidates served by the window kernel,
-        candidates through the per-wavefront alignment + preview)."""
-        v = (C.c_int64 * 5)()
+        candidates that needed a per-wavefront alignment, window shifts evaluated exactly)."""
+        v = (C.c_int64 * 6)()
         check(self._L.rsx_sc_profile_read_rescoring3(self._h, v))
         return tuple(int(x) for x in v)
 

@@ -23,15 +23,15 @@ def sc():
 def check_previews(sc, oracle, descs, queries, min_served, k=10):
     g = sc.SCManager(filter_mode=2)
     g.add_descriptors_f32(descs)
-    slots, pv, ks, cnt = g.window_previews(queries, k=k)
+    slots, pv, ks, sm, cnt = g.window_previews(queries, k=k)
     assert slots.shape == (len(queries), sc.WINDOW_P)
-    served = total = 0
+    served = total = nbits = nmask = 0
     skipped = []
     o = oracle.Manager()
     o.add_descriptors(descs.astype(np.float64))
     for qi in range(len(queries)):
         q64 = queries[qi].astype(np.float64)
-        dist, _ = o.pair_distances(q64, nthreads=4)
+        dist, shift = o.pair_distances(q64, nthreads=4)
         vq = oracle.sectorkey(q64)
         c = int(cnt[qi])
         assert 0 <= c <= sc.WINDOW_P and np.all(slots[qi, c:] == -1) and np.all(slots[qi, :c] >= 0)
@@ -57,6 +57,11 @@ def check_previews(sc, oracle, descs, queries, min_served, k=10):
                 assert pv[qi, i] == np.inf, (qi, e, pv[qi, i])
             else:
                 assert abs(float(pv[qi, i]) - dist[e]) <= sc.WINDOW_MARGIN, (qi, e, float(pv[qi, i]), dist[e])
+                # the shift the reference ends up with is one the exact evaluation will look at
+                t = (int(shift[e]) - (want_k - 3)) % 60
+                assert t < 7 and (int(sm[qi, i]) >> t) & 1, (qi, e, int(shift[e]), want_k, int(sm[qi, i]))
+                nbits += bin(int(sm[qi, i])).count("1")
+                nmask += 1
     # an entry without a record cannot be one of the k best
     topk = {}
     for qi, e in skipped:
@@ -65,6 +70,7 @@ def check_previews(sc, oracle, descs, queries, min_served, k=10):
         assert e not in topk[qi] or not np.isfinite(descs[e]).all(), (qi, e)
     total -= len(skipped)
     assert total > 0 and served >= min_served * total, (served, total)
+    print(f"window shifts kept per masked entry: {nbits / max(1, nmask):.2f} of 7")
     return served, total
 
 
