@@ -163,20 +163,16 @@ class Workload:
         lo, hi, _ = self.ssc._slice(self.nq)
         return (hi - lo) * len(range(self.ssc.shard_rank, n_elig, self.ssc.shard_world))
 
-    def timed(self, steps, warmup, profile=False, settle_s=0.0):
+    def timed(self, steps, warmup, profile=False, settle_steps=0):
         """W untimed steps, then exactly `steps` steps between barrier + synchronize on both sides.
         -> (max-over-ranks seconds, per-rank seconds, (launches, kernel ms), (exact window evaluations, candidates
-        that went through alignment + preview)).  settle_s: untimed steps for that long BEFORE the W warm-up steps -- the
-        headline leg follows 18 000 tiny build-path kernels, and three 3-ms steps do not always bring the clocks up
-        (one full run of round 3 timed its first leg at 4.1 ms per step and every later leg of the same shape at 3.1)"""
+        that went through alignment + preview)).  settle_steps: that many untimed steps BEFORE the W warm-up steps (a fixed
+        number: every rank must run the same sequence of collectives) -- the headline leg follows 18 000 tiny build-path
+        kernels, and three 3-ms steps do not always bring the clocks up (one full run of round 3 timed its first leg at 4.1 ms
+        per step and every later leg of the same shape at 3.1)"""
         ctx = self.ctx
-        if settle_s > 0 and not ctx.stub:
-            import torch
-            t_s = time.perf_counter()
-            while time.perf_counter() - t_s < settle_s:
-                for _ in range(8):
-                    self.step()
-                torch.cuda.synchronize()
+        for _ in range(0 if ctx.stub else settle_steps):
+            self.step()
         for _ in range(warmup):
             self.step()
         ctx.barrier()
@@ -862,7 +858,7 @@ def main():
     main_wl.set_queries(q_descs, n_elig)
     gen_s = time.perf_counter() - t_gen
 
-    dt, per_rank, (launches, kern_ms), (evals, cands) = main_wl.timed(args.steps, args.warmup, profile=True, settle_s=0.3)
+    dt, per_rank, (launches, kern_ms), (evals, cands) = main_wl.timed(args.steps, args.warmup, profile=True, settle_steps=96)
     res = main_wl.results()
     failures = []
     if args.data != "trajectory" or ctx.stub:
