@@ -1873,7 +1873,7 @@ int launch_walk(const DbView &db, const QueryView &q, const float *lb, int64_t l
 // ascending order of that lower bound so that the exact k-th best takes over as early as possible.  No barriers, no
 // merges between waves, no imbalance between them (the 4-wave workgroup of sc_rescore_kernel spent 64 % of its wave
 // cycles waiting once its phase A was gone), and 9.0 KiB of LDS per query (the query image stays in fp32 and is
-// converted on the fly) instead of 40 KiB: 16 queries per CU in flight instead of 4.
+// converted on the fly) instead of 40 KiB: 12 queries per CU in flight instead of 4.
 // Entries without k* (alignment not unique within the window kernel's error bound, or beyond its WINDOW_P positions)
 // get the exact fp64 alignment first; their preview is still a valid LOWER bound (minimum over the union of the candidate
 // windows), so most of them are never touched.  Same stage interface as sc_rescore_kernel (rounds, tau_src, seed).
@@ -1977,7 +1977,7 @@ __device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane,
 }
 
 #ifndef RW_OCC
-#define RW_OCC 3  // waves per SIMD the register budget is set for (161 VGPRs, no spills; 4 = 128 VGPRs with 22 spilled: 0.50 against 0.47 ms)
+#define RW_OCC 3  // waves per SIMD the register budget is set for (168 VGPRs, 13 spilled; 4 = 128 VGPRs with 98 spilled: 0.42 against 0.24 ms)
 #endif
 __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
