@@ -57,7 +57,12 @@ for a in range(nq):
         sub = true[pos[:P]]
         tau_ub = np.sort(sub)[k - 1] + 2 * margin
         return int((sub <= tau_ub).sum())
-    row = {"tau": tau, "evals_fp32": evals(1e-4), "evals_fp16": evals(1.25e-3), "in_first128": int((np.sort(true)[:k][-1] >= 0) and np.isin(np.argsort(true)[:k], pos[:128]).sum()), "all": int((lb_all <= tau + 2e-3).sum()), "exactwin": int((true <= tau).sum())}
+    def records(H, slack):
+        head = true[pos[:H]]
+        tau_ub = np.sort(head)[k - 1] + slack
+        rest = lb_all[pos[H:320]]
+        return H + int((rest - 2e-3 <= tau_ub).sum())
+    row = {"rec64": records(64, 1.5e-3), "rec96": records(96, 1.5e-3), "rec128": records(128, 1.5e-3), "tau": tau, "evals_fp32": evals(1e-4), "evals_fp16": evals(1.25e-3), "in_first128": int((np.sort(true)[:k][-1] >= 0) and np.isin(np.argsort(true)[:k], pos[:128]).sum()), "all": int((lb_all <= tau + 2e-3).sum()), "exactwin": int((true <= tau).sum())}
     for delta in (1e-3, 3e-3, 1e-2):
         # admissible alignment shifts under an absolute error delta*(e1+e2) on KD; bound = min over the union of their windows
         adm = KD <= KD.min(axis=1, keepdims=True) + delta * (e1 + e2[:, None])
