@@ -350,7 +350,10 @@ def committed_profile(kernel):
     import glob
     import re
     pat, tag = ("r*_sc_filter_v*_rocprofv3.txt", "FilterArgs") if kernel == "sc_filter_kernel" else ("r*_sc_spec_v*_rocprofv3.txt", "SpecArgs")
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+    def order(f):  # (round, version) numerically: r03_..._v10 comes after r03_..._v9
+        m = re.search(r"r(\d+)_.*_v(\d+)_rocprofv3", os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2))) if m else (0, 0)
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)), key=order)
     if not files:
         return None
     fetch = write = avg_us = None
