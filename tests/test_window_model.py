@@ -122,6 +122,7 @@ def test_preview_margin_and_union_lower_bound(oracle, binary):
         descs[:8] = (descs[:8].reshape(8, NS, NR) * 10.0 ** rng.uniform(-3, 3, (8, NS, NR))).reshape(8, 1200).astype(np.float32)
     descs[9][20 * 5:20 * 9] = 0
     worst = 0.0
+    nkept = nmask = 0
     for _ in range(120):
         i, j = rng.integers(0, len(descs), 2)
         q = descs[i] if rng.uniform() < 0.7 else synth.rotate_descriptor(descs[j], int(rng.integers(0, NS)))
@@ -142,8 +143,18 @@ def test_preview_margin_and_union_lower_bound(oracle, binary):
             assert np.isinf(pv[win]).all()
             continue
         worst = max(worst, abs(pv[win].min() - dist))
+        # the shift mask (sc_window.hip): a window shift whose preview is more than two margins above the best one is
+        # strictly worse than the minimum, so the exact evaluation may leave it out -- the reference's final shift never is
+        kept = [k for k in win if pv[k] <= pv[win].min() + 2 * MARGIN]
+        assert shift in kept, (shift, kept)
+        for k in win:
+            if k not in kept and np.isfinite(pv[k]):
+                assert oracle.dist_direct(oracle.circshift(e64, k), q64) > dist
+        nkept += len(kept)
+        nmask += 1
         # whatever set of alignments the kernel keeps, as long as it contains the reference's: the union preview is a lower bound
         others = rng.integers(0, NS, 3).tolist() + [ks]
         union = sorted({(a + o) % NS for a in others for o in range(-3, 4)})
         assert pv[union].min() - MARGIN <= dist
     assert worst <= MARGIN / 2, worst
+    assert nmask > 50 and nkept < 4 * nmask   # the mask does cut: well under 4 of 7 shifts survive on average
