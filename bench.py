@@ -745,8 +745,8 @@ def roofline_of(wl, launches, kern_ms, n_elig):
     alg_bytes = local_pairs * ALG_BYTES_PER_PAIR + wl.nq * 4800 + wl.nq * wl.k * 16
     avg_kern_s = (kern_ms / max(launches, 1)) * 1e-3
     kernel = wl.mgr.profiled_kernel_name()
-    if kernel in ("sc_filter_kernel", "sc_spec_filter_kernel"):
-        spectral = kernel == "sc_spec_filter_kernel"
+    if kernel in ("sc_filter_kernel", "sc_spec_filter_kernel", "sc_spec2_filter_kernel"):
+        spectral = kernel != "sc_filter_kernel"
         # queries whose 60 columns are all non-empty skip the n_eff mask correlation (3600 MAC per pair): n_eff is then
         # the entry's column count at every shift -- count only what was executed
         lo_q, hi_q, _ = wl.ssc._slice(wl.nq)
@@ -799,6 +799,8 @@ def main():
     ap.add_argument("--only-main", action="store_true", help="time only the headline workload (profiling runs)")
     ap.add_argument("--data", choices=["trajectory", "random"], default="trajectory",
                     help="headline DB: descriptors built from a synthetic drive (default) or the round-1 random descriptors")
+    ap.add_argument("--filter-kind", choices=["auto", "direct", "spectral", "spectral2"], default="auto",
+                    help="form of the MFMA lower-bound filter (auto = the library default); A/B runs")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world 1")
     ap.add_argument("--all-layouts", action="store_true",
                     help="N > 1: time the mixed query-groups x DB-shards layouts too (default: the two pure ones and the headline)")
@@ -816,6 +818,9 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    if args.filter_kind != "auto" and not dry:
+        from navtech_radar_slam_amd import _rsx as _r
+        _r.default_filter_kind = {"direct": _r.KIND_DIRECT, "spectral": _r.KIND_SPECTRAL, "spectral2": _r.KIND_SPECTRAL2}[args.filter_kind]
     ctx = Ctx(args)
     from navtech_radar_slam_amd import scancontext, synth
     rank, world = ctx.rank, ctx.world

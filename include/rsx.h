@@ -91,7 +91,8 @@ typedef struct {
    * score every entry exactly, 2 = always filter.  Results are identical in every mode. */
   int32_t filter_mode;
   /* which form of the filter: 0 = default (spectral), 1 = direct (60-shift correlation as one K = 1200
-   * MFMA GEMM per shift), 2 = spectral (Z15 DFT + direct Z4 correlation, ~6x fewer MFMAs).  Both give
+   * MFMA GEMM per shift), 2 = spectral (Z15 DFT + direct Z4 correlation, ~6x fewer MFMAs), 3 = the spectral form
+   * with two waves per SIMD (the entry tile split by frequency over a wave pair; same bounds bit for bit).  All give
    * valid lower bounds of the same quantity; results are identical. */
   int32_t filter_kind;
 } rsx_sc_params;

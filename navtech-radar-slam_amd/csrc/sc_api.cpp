@@ -204,6 +204,8 @@ struct ProfScope {
   }
 };
 
+// 2 = the spectral form with two waves per SIMD (sc_spec2_filter_kernel: same images, same bounds)
+constexpr int kDefaultFilterKind = 1;
 // which form of the lower-bound filter: 0 = direct (sc_filter.hip), 1 = spectral (sc_spec.hip, the default:
 // same bounds up to a slightly larger error budget, ~6x fewer MFMAs).  rsx_sc_params.filter_kind or
 // RSX_SC_FILTER_KIND=direct|spectral override.
@@ -211,10 +213,11 @@ int filter_kind_of(const rsx_sc *h) {
   static const int env = [] {
     const char *e = rsx::exp_env("RSX_SC_FILTER_KIND");
     if (!e || !*e) return -1;
+    if (e[0] == '2' || (e[0] == 's' && std::strstr(e, "2"))) return 2;  // spectral2 / spec2
     return (e[0] == 's' || e[0] == '1') ? 1 : 0;
   }();
   if (h->p.filter_kind) return h->p.filter_kind - 1;
-  return env >= 0 ? env : 1;
+  return env >= 0 ? env : kDefaultFilterKind;
 }
 
 size_t any_qimg_bytes(int32_t nq) {
@@ -227,14 +230,15 @@ int run_filter(rsx_sc *h, const QueryView &q, int64_t n_items, float *lb, int64_
                hipStream_t s) {
   const DbView db = db_view(h);
   if (plan) RSX_TRY(h->f_plan.reserve(filter_plan_bytes(n_items), s, false));
-  if (filter_kind_of(h) == 1) {
-    h->prof_kernel = spec_filter_kernel_name();
+  if (filter_kind_of(h) >= 1) {
+    const bool two_waves = filter_kind_of(h) == 2;
+    h->prof_kernel = two_waves ? spec2_filter_kernel_name() : spec_filter_kernel_name();
     RSX_TRY(launch_spec_query_images(q.desc, q.norm, q.nq, h->f_qimg.p, s));
     const int32_t *qmin = nullptr;
     const int64_t *cum = nullptr;
     if (plan) RSX_TRY(launch_filter_plan(db, *plan, q.nq, n_items, 4, h->f_plan.p, &qmin, &cum, s));
     ProfScope ps(&h->prof, s);
-    RSX_TRY(launch_spec_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, qmin, cum, s));
+    RSX_TRY(launch_spec_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, qmin, cum, s, two_waves));
     ps.stop();
     return RSX_OK;
   }
@@ -598,7 +602,8 @@ int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) {
     return fail(RSX_ERR_BAD_ARG, "kernels are specialised for SEARCH_RADIUS 3 (search_ratio 0.1, SC.h:96)");
   if (d.tree_making_period < 1 || d.num_exclude_recent < 0) return fail(RSX_ERR_BAD_ARG, "bad detector params");
   if (d.filter_mode < 0 || d.filter_mode > 2) return fail(RSX_ERR_BAD_ARG, "filter_mode must be 0 (auto), 1 (off) or 2 (force)");
-  if (d.filter_kind < 0 || d.filter_kind > 2) return fail(RSX_ERR_BAD_ARG, "filter_kind must be 0 (auto), 1 (direct) or 2 (spectral)");
+  if (d.filter_kind < 0 || d.filter_kind > 3)
+    return fail(RSX_ERR_BAD_ARG, "filter_kind must be 0 (auto), 1 (direct), 2 (spectral) or 3 (spectral, two waves per SIMD)");
   int ndev = rsx_device_count();
   if (ndev <= 0) return fail(RSX_ERR_NO_DEVICE, "no HIP device visible (librsx has no CPU fallback)");
   if (d.device < 0 || d.device >= ndev) return fail(RSX_ERR_NO_DEVICE, "device %d out of range (%d visible)", d.device, ndev);

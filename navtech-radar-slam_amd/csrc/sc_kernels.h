@@ -148,9 +148,12 @@ size_t spec_qimg_bytes(int32_t nq);
 int launch_spec_db_images(const float *desc, const double *norm, int64_t first, int64_t count, void *spT, float *aux,
                           hipStream_t s);
 int launch_spec_query_images(const float *desc, const double *norm, int32_t nq, void *qimg, hipStream_t s);
+// two_waves: sc_spec2_filter_kernel (two waves per SIMD, the entry tile split by frequency) instead of sc_spec_filter_kernel;
+// same images, same bounds bit for bit
 int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
-                       const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s);
+                       const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s, bool two_waves);
 const char *spec_filter_kernel_name();
+const char *spec2_filter_kernel_name();
 
 // ---- window previews of the short lists on the matrix cores (sc_window.hip) ----
 // For the first WINDOW_P short-list entries of every query: the sector-key alignment k* (SC.cpp:93-113) from an fp16

@@ -538,9 +538,9 @@ __device__ __forceinline__ Recip recip_header(const frag4 &tail) {  // the query
 }
 // the coefficients of u(n) for this lane's entry (queries with an empty column only: three reciprocals and a dozen
 // VALU instructions per query that a query with 60 non-empty columns does not need -- its 1 / n_lo is the lane constant r_ne)
-__device__ __forceinline__ void recip_coeffs(Recip &r, const SpecLane &ln) {
-  const int li = (r.n_q + ln.n_e - NS > 1) ? (r.n_q + ln.n_e - NS) : 1;
-  const int hmin = r.n_q < ln.n_e ? r.n_q : ln.n_e;
+__device__ __forceinline__ void recip_coeffs(Recip &r, int n_e) {
+  const int li = (r.n_q + n_e - NS > 1) ? (r.n_q + n_e - NS) : 1;
+  const int hmin = r.n_q < n_e ? r.n_q : n_e;
   const float L = (float)li, H = (float)(hmin > li ? hmin : li);
   const float rH = __builtin_amdgcn_rcpf(H), rLH = __builtin_amdgcn_rcpf(L * H);
   const float C = rLH * rH;
@@ -707,7 +707,7 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
       r.rL = ln.r_ne;  // n_lo = n_hi = n_e: within 1 ulp of 1 / n_e, covered by the (1 + 4e-6) factor below
       m *= r.rL;
     } else {
-    recip_coeffs(r, ln);
+    recip_coeffs(r, ln.n_e);
     // u(n) of all 32 n_eff values of the query first (independent of stage 2), then per k4: S * u and the maximum;
     // written stage by stage over 4 independent pairs so that no packed instruction waits for the previous one
     float2v u2[4][4];
@@ -964,6 +964,454 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
   }
 }
 
+
+// ==========================================================================================
+// sc_spec2_filter_kernel -- the same filter with TWO waves per SIMD (round 4)
+// ==========================================================================================
+// sc_spec_filter_kernel keeps the 76 B fragments of a 32-entry tile (304 registers) in ONE wave, so a SIMD holds a
+// single wave and everything a tile needs -- 76 stage-1 MFMAs, their LDS reads, the fp16 packing, 16 stage-2 MFMAs,
+// the maxima, the bound arithmetic, the DMA of the next tile -- issues one after the other on it: the matrix pipe is
+// busy 39 % of the time.  Here the entry tile is split BY FREQUENCY over the two waves w and w + 4 of a
+// 512-thread workgroup (they share SIMD w % 4):
+//   half 0 (waves 0..3): f = 0..3, B fragments 0..35  (144 registers)     half 1 (waves 4..7): f = 4..7, 36..75 (160)
+// Both halves run stage 1 on the SAME (4 queries x 32 entries) tile for their own frequencies (the A fragments of a
+// frequency are read by one wave only, so the LDS traffic per flop is unchanged), pack their C_f to fp16, hand the
+// packed halves of the OTHER wave's two queries over through LDS (16 registers = 4 KiB per wave and tile), and run
+// stage 2 + the bound arithmetic for their own two queries (half h: queries 2h, 2h + 1 of the tile).  Two s_barriers
+// per tile: A after the hand-over is written (it also publishes the LDS-DMA pieces of the next query tile), B once
+// every wave has read its partner's half (the exchange area is single-buffered; B comes ~an LDS round trip after A).
+// With two waves on a SIMD the MFMAs of one fill the VALU / LDS / wait stretches of the other.  Everything a lane
+// needs only in its tail (stage-2 weights, the entry's constants, its mask bytes) lives in LDS, not in registers:
+// at 256 registers per wave the B fragments leave ~110 for the accumulators, the A-fragment ring and the packing.
+#ifndef S2_OPT_PARK0
+#define S2_OPT_PARK0 3   // B fragments of half 0 parked in LDS (read back with the first A fragments of every tile)
+#endif
+#ifndef S2_OPT_PARK1
+#define S2_OPT_PARK1 6   // ... of half 1 (40 fragments: 4 more than half 0)
+#endif
+#ifndef S2_OPT_DEPTH
+#define S2_OPT_DEPTH 5
+#endif
+constexpr int S2_DEPTH = S2_OPT_DEPTH;
+constexpr int S2_NBUF = 3;
+constexpr int S2_XDIR = 8 * 512;                       // one direction of one pair: [8 (query, k4)][g, g + 1][64 lanes] dwords
+constexpr int S2_X_OFF = 0;                            // [4 pairs][2 directions] = 32 KiB
+constexpr int S2_W_OFF = S2_X_OFF + 4 * 2 * S2_XDIR;   // stage-2 weights: 64 lanes x 16 B
+constexpr int S2_EC_OFF = S2_W_OFF + 1024;             // [4 tiles of the block][64 lanes] {n_e | e_bad << 16, sqrt n_e, sqrt a_e, 1 / n_e}
+constexpr int S2_BM_OFF = S2_EC_OFF + 4 * 1024;        // [4 tiles][64 lanes] 32 mask bytes (fp8 0 / 1)
+constexpr int S2_PARK_OFF = S2_BM_OFF + 4 * 2048;
+constexpr int S2_PARK_BYTES = 4 * (S2_OPT_PARK0 + S2_OPT_PARK1) * 1024;
+constexpr int S2_TILES_OFF = S2_PARK_OFF + S2_PARK_BYTES;
+constexpr int S2_LDS_BYTES = S2_TILES_OFF + S2_NBUF * SP_PHASE_BYTES;
+static_assert(S2_LDS_BYTES <= 160 * 1024, "LDS budget");
+static_assert(S2_TILES_OFF >= SP_VS, "wrapped addresses stay non-negative");
+
+template <int HALF>
+struct S2Half {
+  static constexpr int frag0 = HALF == 0 ? 0 : SP_DC_STEPS + 3 * SP_F_STEPS;                    // 0 / 36
+  static constexpr int nfrag = HALF == 0 ? SP_DC_STEPS + 3 * SP_F_STEPS : 4 * SP_F_STEPS;       // 36 / 40
+  static constexpr int npark = HALF == 0 ? S2_OPT_PARK0 : S2_OPT_PARK1;
+  static constexpr int park_off = HALF == 0 ? 0 : 4 * S2_OPT_PARK0 * 1024;                       // inside the park area
+  // slot t -> (frequency, K-step); local frequency lf = f - 4 HALF accumulates into acc[lf % 3]
+  static constexpr int f_of(int t) { return HALF == 0 ? (t < SP_DC_STEPS ? 0 : 1 + (t - SP_DC_STEPS) / SP_F_STEPS) : 4 + t / SP_F_STEPS; }
+  static constexpr int s_of(int t) { return HALF == 0 ? (t < SP_DC_STEPS ? t : (t - SP_DC_STEPS) % SP_F_STEPS) : t % SP_F_STEPS; }
+  static constexpr int first_slot(int lf) { return HALF == 0 ? (lf == 0 ? 0 : SP_DC_STEPS + (lf - 1) * SP_F_STEPS) : lf * SP_F_STEPS; }
+  static constexpr int last_slot(int lf) { return first_slot(lf + 1) - 1; }
+  static constexpr int a_off(int t) { return f_of(t) == 0 ? 32 * s_of(t) : (f_of(t) - 1) * SP_F_BYTES + 32 * s_of(t); }
+};
+
+// LDS reads of stage 1 in issue order: A fragments 0 .. DEPTH-1, parked B fragments 0 .. NP-1, then after the MFMA of slot t
+// the A fragment of slot t + DEPTH.  LDS returns in issue order, so slot t may start once at most
+// (reads issued so far) - 1 - (position of the later of its two reads) are outstanding.
+constexpr int s2_wait_of(int t, int nf, int np) {
+  const int pos_a = t < S2_DEPTH ? t : S2_DEPTH + np + (t - S2_DEPTH);
+  const int pos_b = t < np ? S2_DEPTH + t : -1;
+  int issued = S2_DEPTH + np;            // prologue
+  for (int u = 0; u < t; u++) issued += (u + S2_DEPTH < nf) ? 1 : 0;
+  const int last = pos_a > pos_b ? pos_a : pos_b;
+  return issued - 1 - last;
+}
+
+// per-lane A-fragment addressing of stage 1 (the only lane state that lives in registers across a tile)
+struct S2Lane {
+  unsigned dc_off, f_off, c_dc, c_f;  // as SpecLane
+};
+
+// pieces of a tile over 8 waves: piece c belongs to wave c % 8
+__device__ __forceinline__ void dma_issue8(const TileDma &d, int wave, int lane) {
+  const int wu = __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+  for (int j = 0; j < (SP_STREAM_PIECES + SP_MASK_PIECES + 7) / 8; j++) {
+    const int c = wu + 8 * j;
+    if (c >= SP_STREAM_PIECES + SP_MASK_PIECES) break;
+    const bool is_mask = c >= SP_STREAM_PIECES;
+    const int cc = is_mask ? c - SP_STREAM_PIECES : c;
+    unsigned lo = (unsigned)lane;
+    asm volatile("" : "+v"(lo));
+    const unsigned off = (unsigned)(cc * 1024) + lo * 16u;
+    if ((int)off < (is_mask ? d.nbytes_m : d.nbytes))
+      __builtin_amdgcn_global_load_lds(
+          reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(is_mask ? d.gsrc_m : d.gsrc) + off),
+          (AS3 void *)(d.ldst + c * 1024), 16, 0, 0);
+  }
+}
+
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+// two dwords 256 B x {o0, o1} from addr (the st64 forms count their offsets in units of 64 dwords)
+__device__ __forceinline__ void lds_read2st64(u2v &dst, unsigned addr, int o0, int o1) {
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"(o1));
+}
+__device__ __forceinline__ void lds_write2st64(unsigned addr, unsigned v0, unsigned v1, int o0, int o1) {
+  asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(addr), "v"(v0), "v"(v1), "n"(o0), "n"(o1) : "memory");
+}
+__device__ __forceinline__ void lds_write_b128(unsigned addr, frag4 v, int off) {
+  asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off) : "memory");
+}
+
+// one segment (one tile-block x a range of query tiles) for one half
+template <int HALF>
+__device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, unsigned lds_base, const S2Lane &ln, int wave, int lane,
+                                              int64_t tb, int t0, int t1) {
+  using H = S2Half<HALF>;
+  constexpr int NF = H::nfrag, NP = H::npark;
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u8v __attribute__((ext_vector_type(8)));
+  const int sub = wave & 3;
+  const int col = lane & 31, hh = lane >> 5;
+  const int64_t ntiles = (a.n_items + 31) >> 5;
+  const int q0 = t0 * SP_QPT;
+  const int q1 = (t1 * SP_QPT < a.nq) ? t1 * SP_QPT : a.nq;
+  const int64_t tile = tb * 4 + sub;
+  const bool tile_ok = tile < ntiles;  // wave-uniform, the same for both halves of a pair
+  const int nphase = (q1 - q0 + SP_QPP - 1) / SP_QPP;
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  const unsigned *qflags = reinterpret_cast<const unsigned *>(a.qimg + sp_flags_at(a.nq)) + __builtin_amdgcn_readfirstlane(t0);
+  auto tile_dma = [&](int p, unsigned flagword) {
+    const int qn = q0 + p * SP_QPP;
+    const int nqs = (q1 - qn < SP_QPP) ? (q1 - qn) : SP_QPP;
+    return TileDma{a.qimg + (int64_t)qn * SP_QS, a.qimg + sp_masks_at(a.nq) + (int64_t)qn * SP_MASK_BYTES,
+                   smem + S2_TILES_OFF + (p % S2_NBUF) * SP_PHASE_BYTES, nqs * SP_QS, flagword ? nqs * SP_MASK_BYTES : 0};
+  };
+  dma_issue8(tile_dma(0, scalar_load_u32(qflags)), wave, lane);
+  if (nphase > 1) dma_issue8(tile_dma(1, scalar_load_u32(qflags + 1)), wave, lane);
+
+  half8 B[NF];
+  {
+    const uint4 *src = a.spT + ((tile_ok ? tile : 0) * SP_FRAGS + H::frag0) * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < NF; s++) {
+      const uint4 v = src[s * 64];
+      B[s] = *reinterpret_cast<const half8 *>(&v);
+    }
+    // no AGPR constraint here: a function that never names an AGPR gets its whole budget (256 at two waves per SIMD) as
+    // VGPRs with -amdgpu-mfma-vgpr-form; naming one makes the compiler split the file 128 / 128
+#pragma unroll
+    for (int s = NP; s < NF; s++) asm volatile("" : "+v"(B[s]));
+#pragma unroll
+    for (int s = 0; s < NP; s++)
+      lds_write_b128(lds_base + (unsigned)(S2_PARK_OFF + H::park_off) + (unsigned)(sub * (NP * 1024)) + lane16, __builtin_bit_cast(frag4, B[s]), s * 1024);
+  }
+  if (HALF == 0) {  // the entry constants of the tile, for both halves
+    const int64_t n = tile * 32 + col;
+    const bool n_ok = tile_ok && n < a.n_items;
+    const u64 m2 = n_ok ? a.cmask[n] : 0ull;
+    const int n_e = __popcll(m2 & kMask60);
+    frag4 ec;
+    ec[0] = (unsigned)n_e | (((m2 & kNonFinite) != 0) ? 0x10000u : 0u);
+    ec[1] = __float_as_uint(sqrtf((float)n_e));
+    ec[2] = __float_as_uint(n_ok ? a.aux[n] : 0.0f);
+    ec[3] = __float_as_uint(__builtin_amdgcn_rcpf((float)(n_e > 1 ? n_e : 1)));
+    lds_write_b128(lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + lane16, ec, 0);
+    const unsigned bits = (unsigned)((m2 & kMask60) >> (32 * hh));
+    frag4 bm[2];
+#pragma unroll
+    for (int r = 0; r < 8; r++) bm[r >> 2][r & 3] = ((((bits >> (4 * r)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0x38u;
+    lds_write_b128(lds_base + (unsigned)S2_BM_OFF + (unsigned)(sub * 2048) + 2u * lane16, bm[0], 0);
+    lds_write_b128(lds_base + (unsigned)S2_BM_OFF + (unsigned)(sub * 2048) + 2u * lane16, bm[1], 16);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  const unsigned bpark = lds_base + (unsigned)(S2_PARK_OFF + H::park_off) + (unsigned)(sub * (NP * 1024)) + lane16;
+  for (int p = 0; p < nphase; p++) {
+    const int qp = q0 + p * SP_QPP;
+    const int nq_here = (q1 - qp < SP_QPP) ? (q1 - qp) : SP_QPP;
+    const unsigned tile_lds = lds_base + (unsigned)(S2_TILES_OFF + (p % S2_NBUF) * SP_PHASE_BYTES);
+    unsigned own[2][16];  // own[gl][j]: packed {C_(2g), C_(2g+1)} of (query j / 4, k4 = j % 4), g = 2 HALF + gl
+    if (tile_ok) {
+      // ---------------- stage 1: this half's frequencies, all 4 queries ----------------
+      floatx16 acc[3];
+      floatx16 z;
+#pragma unroll
+      for (int i = 0; i < 16; i++) z[i] = 0.0f;
+      frag4 ring[S2_DEPTH];
+      frag4 bx[NP > 0 ? NP : 1];
+      const unsigned a_dc = tile_lds + ln.dc_off, a_f = tile_lds + ln.f_off;
+      const unsigned a_dcw = a_dc - SP_DC_BYTES, a_fw = a_f - SP_VS;
+      auto a_read = [&](frag4 &dst, auto tc) {
+        constexpr int t = decltype(tc)::value;
+        if constexpr (H::f_of(t) == 0) lds_read_stream<H::s_of(t), SP_DC_BYTES / 16, 10>(dst, a_dc, a_dcw, ln.c_dc, H::a_off(t));
+        else lds_read_stream<H::s_of(t), SP_VS / 16, 16>(dst, a_f, a_fw, ln.c_f, H::a_off(t));
+      };
+      static_for<S2_DEPTH>([&](auto tc) { a_read(ring[decltype(tc)::value], tc); });
+      static_for<NP>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        lds_read_frag(bx[t], bpark, 1024 * t);
+      });
+      static_for<NF>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        constexpr int f = H::f_of(t), lf = f - 4 * HALF;
+        lds_wait_count<s2_wait_of(t, NF, NP)>();
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 af = __builtin_bit_cast(half8, ring[t % S2_DEPTH]);
+        half8 bf;
+        if constexpr (t < NP) bf = __builtin_bit_cast(half8, bx[t]);
+        else bf = B[t];
+        if constexpr (H::s_of(t) == 0) acc[lf % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, z, 0, 0, 0);
+        else acc[lf % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[lf % 3], 0, 0, 0);
+        if constexpr (t + S2_DEPTH < NF) a_read(ring[t % S2_DEPTH], std::integral_constant<int, t + S2_DEPTH>{});
+        if constexpr (HALF == 0) {
+          // C_0 as fp16 hi + lo (see spec_tile): during f = 1, two j per slot
+          constexpr int sb = H::last_slot(0) + 2;
+          if constexpr (t >= sb && t < sb + 8) {
+#pragma unroll
+            for (int j = 2 * (t - sb); j < 2 * (t - sb) + 2; j++) {
+              const float v = acc[0][j];
+              const float hi = __uint_as_float(__float_as_uint(v) & 0xffffe000u);
+              float sp = hh ? v - hi : hi;
+              asm volatile("" : "+v"(sp));
+              acc[0][j] = sp;
+            }
+          }
+        }
+        // first pair (lf 0, 1) -> own[0][*], packed during lf 2 (two j per slot), before lf 3 re-uses acc[0]
+        {
+          constexpr int pb = H::last_slot(1) + 2;
+          static_assert(pb + 8 <= H::first_slot(3), "accumulators are re-used before they are packed");
+          if constexpr (t >= pb && t < pb + 8) {
+#pragma unroll
+            for (int j = 2 * (t - pb); j < 2 * (t - pb) + 2; j++) {
+              unsigned pk = pack2(acc[0][j], acc[1][j]);
+              asm volatile("" : "+v"(pk));
+              own[0][j] = pk;
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      // second pair (lf 2, 3) = acc[2], acc[0]
+#pragma unroll
+      for (int j = 0; j < 16; j++) own[1][j] = pack2(acc[2][j], acc[0][j]);
+      // hand the partner's queries over: (query, k4) = j in [8 (1 - HALF), +8) -> own[0][j] at x_wr + jl * 512, own[1][j] 256 B further
+      unsigned lw = (unsigned)lane;
+      asm volatile("" : "+v"(lw));
+      const unsigned x_wr = lds_base + (unsigned)S2_X_OFF + (unsigned)((sub * 2 + HALF) * S2_XDIR) + lw * 4u;
+#pragma unroll
+      for (int jl = 0; jl < 8; jl++) lds_write2st64(x_wr, own[0][8 * (1 - HALF) + jl], own[1][8 * (1 - HALF) + jl], 2 * jl, 2 * jl + 1);
+    }
+    // barrier A: the exchange is written and the pieces of tile p + 1 this wave issued have landed
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float outv[2] = {0.0f, 0.0f};
+    if (tile_ok) {
+      // ---------------- stage 2 + bounds: this half's two queries ----------------
+      // every lane-dependent address of the tail derives from an opaque copy of the lane id: left visible, the compiler
+      // hoists a dozen of them out of the tile loop and keeps them in registers across stage 1 (spilling B fragments)
+      unsigned lt = (unsigned)lane;
+      asm volatile("" : "+v"(lt));
+      const unsigned lane16 = lt * 16u;
+      const int col = (int)(lt & 31u), hh = (int)(lt >> 5);
+      const unsigned a_tl = tile_lds + SP_TAIL;
+      const unsigned x_rd = lds_base + (unsigned)S2_X_OFF + (unsigned)((sub * 2 + (1 - HALF)) * S2_XDIR) + lt * 4u;
+      frag4 tw[2], wv, ec;
+      u2v rx[8];
+      lds_read_frag(tw[0], a_tl, (2 * HALF) * SP_QS);
+      lds_read_frag(tw[1], a_tl, (2 * HALF + 1) * SP_QS);
+      static_for<8>([&](auto jc) {
+        constexpr int jl = decltype(jc)::value;
+        lds_read2st64(rx[jl], x_rd, 2 * jl, 2 * jl + 1);
+      });
+      lds_read_frag(wv, lds_base + (unsigned)S2_W_OFF + lane16, 0);
+      lds_read_frag(ec, lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + lane16, 0);
+      lds_wait_count<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      // barrier B: every wave holds its partner's half, the exchange area may be written again
+      __builtin_amdgcn_s_barrier();
+      const half8 W = __builtin_bit_cast(half8, wv);
+      const int n_e = (int)(ec[0] & 0xffffu);
+      const bool e_bad = (ec[0] & 0x10000u) != 0;
+      const float sqrt_ne = __uint_as_float(ec[1]), sqrt_ae = __uint_as_float(ec[2]), r_ne = __uint_as_float(ec[3]);
+      floatx16 z;
+#pragma unroll
+      for (int i = 0; i < 16; i++) z[i] = 0.0f;
+      static_for<2>([&](auto qc) {
+        constexpr int ql = decltype(qc)::value;
+        Recip r = recip_header(tw[ql]);
+        auto Pj = [&](int k4) {  // stage-2 B operand of (this query, k4): K = {g0, g1, g2, g3}
+          const int jl = ql * 4 + k4, j = 8 * HALF + jl;
+          u4 t;
+          if constexpr (HALF == 0) t = u4{own[0][j], own[1][j], rx[jl][0], rx[jl][1]};
+          else t = u4{rx[jl][0], rx[jl][1], own[0][j], own[1][j]};
+          return __builtin_bit_cast(half8, t);
+        };
+        const bool full_q = __builtin_amdgcn_readfirstlane(r.n_q) == NS;
+        float m = 0.0f;
+        if (full_q) {
+          auto max8 = [&](const floatx16 &dd) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);
+          };
+          floatx16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(0), z, 0, 0, 0);
+          floatx16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(1), z, 0, 0, 0);
+          max8(d0);
+          d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(2), z, 0, 0, 0);
+          max8(d1);
+          d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(3), z, 0, 0, 0);
+          max8(d0);
+          max8(d1);
+          r.rL = r_ne;
+          m *= r.rL;
+        } else {
+          recip_coeffs(r, n_e);
+          // the entry's mask bytes (B operand of the mask correlation) and the query's mask rows come from LDS; one
+          // M-tile (k4 = 2 mt, 2 mt + 1) at a time: n_eff, u(n_eff), S u, maximum
+          frag4 bm0, bm1;
+          lds_read_frag(bm0, lds_base + (unsigned)S2_BM_OFF + (unsigned)(sub * 2048) + 2u * lane16, 0);
+          lds_read_frag(bm1, lds_base + (unsigned)S2_BM_OFF + (unsigned)(sub * 2048) + 2u * lane16, 16);
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++) {
+            // n_eff rows: row = col <-> (k4 = 2 mt + col / 16, k15 = col % 16), the row order of the stage-2 output
+            const int k4 = 2 * mt + (col >> 4), k15 = (col & 15) == 15 ? 0 : (col & 15);
+            const int k = (45 * k4 + 16 * k15) % NS;  // CRT
+            const unsigned a_m = tile_lds + (unsigned)(SP_MASKREG_OFF + (k & 15) * SP_MASK_COPY + (k & ~15) + hh * 32);
+            frag4 mk0, mk1;
+            lds_read_frag(mk0, a_m, (2 * HALF + ql) * SP_MASK_BYTES);
+            lds_read_frag(mk1, a_m, (2 * HALF + ql) * SP_MASK_BYTES + 16);
+            lds_wait_count<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            const u8v am = {mk0[0], mk0[1], mk0[2], mk0[3], mk1[0], mk1[1], mk1[2], mk1[3]};
+            const u8v bm = {bm0[0], bm0[1], bm0[2], bm0[3], bm1[0], bm1[1], bm1[2], bm1[3]};
+            const floatx16 nacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), __builtin_bit_cast(intx8, bm), z, 0, 0, 0, 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+              float2v u2[4];
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float2v n2 = {nacc[kk * 8 + 2 * e], nacc[kk * 8 + 2 * e + 1]};
+                const float2v t2 = __builtin_elementwise_fma(n2, r.C2, r.B2);
+                u2[e] = __builtin_elementwise_fma(n2, t2, r.A2);
+              }
+              const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(2 * mt + kk), z, 0, 0, 0);
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float2v s2 = {dd[2 * e], dd[2 * e + 1]};
+                const float2v v2 = s2 * u2[e];
+                m = fmaxf(fmaxf(m, v2[0]), v2[1]);
+              }
+            }
+          }
+        }
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        const float err = kE1 * r.sqrt_nq * sqrt_ne + kE2 * r.sqrt_aq * sqrt_ae;
+        float v = (1.0f + a.eps_direct) - fmaf(best, (16.0f / 15.0f) * (1.0f + 4e-6f), err * r.rL);
+        if (r.n_q == 0 || n_e == 0) v = INFINITY;
+        if (r.flags != 0u || e_bad) v = -INFINITY;
+        outv[ql] = v;
+      });
+    } else {
+      __builtin_amdgcn_s_barrier();  // barrier B for the waves without a tile
+    }
+    // lanes 0..31 store query 2 HALF, lanes 32..63 query 2 HALF + 1: one store per wave and tile
+    {
+      unsigned lt = (unsigned)lane;
+      asm volatile("" : "+v"(lt));
+      const int col = (int)(lt & 31u), hh = (int)(lt >> 5);
+      const int64_t n = tile * 32 + col;
+      const int qq = 2 * HALF + hh;
+      const float vv = hh ? outv[1] : outv[0];
+      if (tile_ok && n < a.n_items && qq < nq_here) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = vv;
+    }
+    // the DMA of tile p + 2 into the buffer tile p - 1 was read from (every wave is past barrier A of tile p)
+    if (p + 2 < nphase) dma_issue8(tile_dma(p + 2, scalar_load_u32(qflags + p + 2)), wave, lane);
+  }
+  // segment end: the next segment re-writes the parked fragments, the entry constants and the tile buffers
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(512, 2) void sc_spec2_filter_kernel(SpecArgs a) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int half = wave >> 2;
+  const int col = lane & 31, hh = lane >> 5;
+  const int64_t ntiles = (a.n_items + 31) >> 5;
+  const int64_t ntb = (ntiles + 3) >> 2;
+  const int nqt = (a.nq + SP_QPT - 1) / SP_QPT;
+  const int64_t total = a.tb_cum ? a.tb_cum[ntb] : ntb * (int64_t)nqt;
+  const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+  int64_t L0 = (int64_t)blockIdx.x * per;
+  const int64_t L1 = (L0 + per < total) ? (L0 + per) : total;
+  const unsigned lds_base = (unsigned)(uintptr_t)((AS3 char *)smem);
+  S2Lane ln;
+  {
+    // A-fragment address of this lane inside a tile of 4 query images: row = col = 8 * query + 4 * variant + k4
+    const int rq = col >> 3, rv = (col >> 2) & 1, rk = col & 3;
+    ln.c_dc = rk * 3 + hh;
+    ln.c_f = rk * 5 + hh;
+    ln.dc_off = rq * SP_QS + ln.c_dc * 16;
+    ln.f_off = rq * SP_QS + SP_DC_BYTES + rv * SP_VS + ln.c_f * 16;
+  }
+  if (wave == 0) {
+    // stage-2 A operand (inverse DFT weights, see sc_spec_filter_kernel), once per workgroup, into LDS
+    frag4 wv;
+    half8 W;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      float w = 0.0f;
+      if (col < 15) {
+        if (i == 0) w = 1.0f / 16.0f;
+        else {
+          const int t = (i * col) % 15;
+          w = hh ? (float)(-sinpi(2.0 * t / 15.0) / 8.0) : (float)(cospi(2.0 * t / 15.0) / 8.0);
+        }
+      }
+      W[i] = (_Float16)w;
+    }
+    wv = __builtin_bit_cast(frag4, W);
+    lds_write_b128(lds_base + (unsigned)S2_W_OFF + (unsigned)lane * 16u, wv, 0);
+  }
+  // the younger half of the workgroup loses the VALU arbitration on every segment otherwise (MI355X_MICROARCH: static priority)
+  if (half) __builtin_amdgcn_s_setprio(1);
+
+  int64_t tb = 0;
+  if (a.tb_cum && L0 < L1) {
+    int64_t lo = 0, hi = ntb - 1;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (a.tb_cum[mid] <= L0) lo = mid;
+      else hi = mid - 1;
+    }
+    tb = lo;
+  }
+  while (L0 < L1) {
+    int t0;
+    if (a.tb_cum) {
+      while (a.tb_cum[tb + 1] <= L0) tb++;
+      t0 = a.tb_qmin[tb] + (int)(L0 - a.tb_cum[tb]);
+    } else {
+      tb = L0 / nqt;
+      t0 = (int)(L0 - tb * nqt);
+    }
+    const int t1 = (L1 - L0 < (int64_t)(nqt - t0)) ? (int)(t0 + (L1 - L0)) : nqt;
+    L0 += t1 - t0;
+    if (half == 0) spec2_segment<0>(a, smem, lds_base, ln, wave, lane, tb, t0, t1);
+    else spec2_segment<1>(a, smem, lds_base, ln, wave, lane, tb, t0, t1);
+  }
+}
+
 }  // namespace
 
 size_t spec_qimg_bytes(int32_t nq) { return (size_t)(sp_flags_at(nq) + sp_nq4(nq)) + 1024; }  // + slack: the filter reads flag words up to 3 tiles ahead
@@ -987,8 +1435,10 @@ int launch_spec_query_images(const float *desc, const double *norm, int32_t nq, 
 
 const char *spec_filter_kernel_name() { return "sc_spec_filter_kernel"; }
 
+const char *spec2_filter_kernel_name() { return "sc_spec2_filter_kernel"; }
+
 int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
-                       const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s) {
+                       const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s, bool two_waves) {
   if (nq <= 0 || n_items <= 0) return RSX_OK;
   static int n_cu = 0;
   const int lds = SP_LDS_BYTES;
@@ -1046,6 +1496,19 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
     a.unit_len = (int32_t)((nqt + best_r - 1) / best_r);
     const int64_t rr = (nqt + a.unit_len - 1) / a.unit_len;
     grid = (unsigned)(rr * ntb);
+  }
+  if (two_waves) {
+    // sc_spec2_filter_kernel: 512 threads, the entry tile split by frequency over two waves per SIMD
+    static bool attr2 = false;
+    if (!attr2) {
+      RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_spec2_filter_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS_BYTES));
+      attr2 = true;
+    }
+    a.prof = nullptr;
+    hipLaunchKernelGGL(sc_spec2_filter_kernel, dim3(grid), dim3(512), S2_LDS_BYTES, s, a);
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
   }
   static unsigned long long *d_prof = nullptr;
   static const bool want_prof = rsx::exp_env("RSX_SPEC_PROF") != nullptr;

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 import pytest
 
 
-@pytest.mark.parametrize("kind", ["direct", "spectral"])
+@pytest.mark.parametrize("kind", ["direct", "spectral", "spectral2"])
 def test_no_instruction_touches_inflight_lds_destinations(kind):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_lds_ring.py"), kind], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -17,7 +17,7 @@ from navtech_radar_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 FORCE, OFF = 2, 1
-FILTER_KERNELS = ("sc_filter_kernel", "sc_spec_filter_kernel")
+FILTER_KERNELS = ("sc_filter_kernel", "sc_spec_filter_kernel", "sc_spec2_filter_kernel")
 
 
 @pytest.fixture(scope="module")
@@ -27,11 +27,11 @@ def sc():
     return scancontext
 
 
-@pytest.fixture(autouse=True, params=["direct", "spectral"])
+@pytest.fixture(autouse=True, params=["direct", "spectral", "spectral2"])
 def filter_kind(request):
-    """every test of this module runs with both forms of the filter (sc_filter.hip / sc_spec.hip)"""
+    """every test of this module runs with every form of the filter (sc_filter.hip / sc_spec.hip, one and two waves per SIMD)"""
     from navtech_radar_slam_amd import _rsx
-    _rsx.default_filter_kind = _rsx.KIND_DIRECT if request.param == "direct" else _rsx.KIND_SPECTRAL
+    _rsx.default_filter_kind = {"direct": _rsx.KIND_DIRECT, "spectral": _rsx.KIND_SPECTRAL, "spectral2": _rsx.KIND_SPECTRAL2}[request.param]
     yield request.param
     _rsx.default_filter_kind = _rsx.KIND_AUTO
 
@@ -117,7 +117,7 @@ def test_filtered_query_matches_oracle(sc, oracle, binary, k, filter_kind):
     o = oracle.Manager()
     o.add_descriptors(descs.astype(np.float64))
     got = g.query(queries, k=k, n_eligible=n - 30)
-    assert g.profiled_kernel_name() == ("sc_filter_kernel" if filter_kind == "direct" else "sc_spec_filter_kernel")
+    assert g.profiled_kernel_name() == {"direct": "sc_filter_kernel", "spectral": "sc_spec_filter_kernel", "spectral2": "sc_spec2_filter_kernel"}[filter_kind]
     for qi in range(nq):
         want = o.exhaustive(queries[qi].astype(np.float64), n_eligible=n - 30, k=k, nthreads=4)
         assert np.array_equal(got[qi], want), f"query {qi}"

@@ -33,12 +33,19 @@ def oracle():
     return pyoracle
 
 
+@pytest.fixture(params=["spectral", "spectral2"])
+def spec_kind(request, rsx):
+    """both mappings of the spectral filter: one wave per SIMD (sc_spec_filter_kernel) and the entry tile split by
+    frequency over two waves per SIMD (sc_spec2_filter_kernel)"""
+    return rsx.KIND_SPECTRAL if request.param == "spectral" else rsx.KIND_SPECTRAL2
+
+
 def n_cols(d):
     return (np.sqrt((d.reshape(-1, 60, 20).astype(np.float64) ** 2).sum(2)) > 0).sum(1)
 
 
 @pytest.mark.parametrize("binary", [True, False])
-def test_spectral_bounds(sc, rsx, synth, binary):
+def test_spectral_bounds(sc, rsx, synth, binary, spec_kind):
     n, nq = 1000 + 13, 24                                # ragged last tile, 6 query tiles
     descs = make_db(100 + binary, n, binary)
     rng = np.random.default_rng(9)
@@ -46,7 +53,7 @@ def test_spectral_bounds(sc, rsx, synth, binary):
     queries[::2, rng.integers(0, 1200, 20)] = 0
     queries[1] = 0                                       # empty query
     queries[3].reshape(60, 20)[7:31] = 0                 # 24 empty sectors: wide [n_lo, n_hi]
-    g = sc.SCManager(filter_kind=rsx.KIND_SPECTRAL)
+    g = sc.SCManager(filter_kind=spec_kind)
     g.add_descriptors_f32(descs)
     eps = g.filter_eps()
     lb = g.filter_bounds(queries)
@@ -74,14 +81,14 @@ def test_spectral_bounds(sc, rsx, synth, binary):
 
 
 @pytest.mark.parametrize("k", [1, 10, 32])
-def test_spectral_query_matches_oracle(sc, rsx, synth, oracle, k):
+def test_spectral_query_matches_oracle(sc, rsx, synth, oracle, k, spec_kind):
     n, nq = 2500 + 5, 41
     descs = make_db(7, n, True)
     rng = np.random.default_rng(3)
     queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
     queries[::3, rng.integers(0, 1200, 40)] = 0
     queries[5] = 0
-    g = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+    g = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=spec_kind)
     g.add_descriptors_f32(descs)
     got = g.query(queries, k=k, n_eligible=n - 30)
     o = oracle.Manager()
@@ -97,7 +104,7 @@ def test_spectral_equals_direct_10k(sc, rsx, synth):
     queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
     queries[::4, rng.integers(0, 1200, 60)] = 0
     res = []
-    for kind in (rsx.KIND_DIRECT, rsx.KIND_SPECTRAL):
+    for kind in (rsx.KIND_DIRECT, rsx.KIND_SPECTRAL, rsx.KIND_SPECTRAL2):
         g = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=kind, capacity_hint=n)
         g.add_descriptors_f32(descs)
         res.append(g.query(queries, k=k))
@@ -106,9 +113,10 @@ def test_spectral_equals_direct_10k(sc, rsx, synth):
     want = off.query(queries, k=k)
     assert np.array_equal(res[0], want)
     assert np.array_equal(res[1], want)
+    assert np.array_equal(res[2], want)
 
 
-def test_spectral_self_queries_and_shards(sc, rsx, synth):
+def test_spectral_self_queries_and_shards(sc, rsx, synth, spec_kind):
     """triangular plan in query-tile units + the staged protocol over 3 shard handles"""
     import torch
     n, k, excl = 3017, 10, 30
@@ -122,7 +130,7 @@ def test_spectral_self_queries_and_shards(sc, rsx, synth):
     off.query_self_device(0, n, k, want_d.data_ptr(), exclude_recent=excl, stream=st)
     torch.cuda.synchronize()
     want = want_d.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)
-    g = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+    g = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=spec_kind)
     g.add_descriptors_f32(descs)
     out = torch.zeros((n, k, 2), dtype=torch.float64, device="cuda")
     for first, cnt in ((0, n), (1001, 777)):
@@ -132,7 +140,7 @@ def test_spectral_self_queries_and_shards(sc, rsx, synth):
         got = out.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k)[:cnt]
         assert np.array_equal(got, want[first:first + cnt]), (first, cnt)
     world = 3
-    shards = [sc.SCManager(shard_rank=r, shard_world=world, filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+    shards = [sc.SCManager(shard_rank=r, shard_world=world, filter_mode=rsx.FILTER_FORCE, filter_kind=spec_kind)
               for r in range(world)]
     for s in shards:
         s.add_descriptors_f32(descs)
@@ -150,6 +158,30 @@ def test_spectral_self_queries_and_shards(sc, rsx, synth):
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy().view(sc.HIT_DTYPE).reshape(n, k), want)
     torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_two_wave_mapping_gives_the_same_bounds(sc, rsx, synth, binary):
+    """sc_spec2_filter_kernel splits the entry tile by frequency over two waves; every accumulator still sees its K-steps
+    in the same order, so its bounds equal sc_spec_filter_kernel's BIT FOR BIT -- ragged entry tiles, partial query tiles,
+    queries with and without empty columns, empty and non-finite descriptors"""
+    n, nq = 4096 + 77, 203
+    descs = make_db(300 + binary, n, binary)
+    rng = np.random.default_rng(17)
+    queries = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
+    queries[::2, rng.integers(0, 1200, 20)] = 0
+    queries[1] = 0
+    queries[3].reshape(60, 20)[7:31] = 0
+    queries[8:40] = synth.random_descriptors(5, 32, binary=False) + np.float32(0.5)   # no empty column: the short tail path
+    queries[11, 5] = np.nan
+    descs[12, 100] = np.inf
+    a = sc.SCManager(filter_kind=rsx.KIND_SPECTRAL, capacity_hint=n)
+    b = sc.SCManager(filter_kind=rsx.KIND_SPECTRAL2, capacity_hint=n)
+    a.add_descriptors_f32(descs)
+    b.add_descriptors_f32(descs)
+    la, lb2 = a.filter_bounds(queries), b.filter_bounds(queries)
+    assert b.profiled_kernel_name() == "sc_spec2_filter_kernel" and a.profiled_kernel_name() == "sc_spec_filter_kernel"
+    assert np.array_equal(la.view(np.uint32), lb2.view(np.uint32))
 
 
 def test_default_kind_is_spectral(sc, rsx, synth):
@@ -199,7 +231,7 @@ print("WALK-OK")
     assert "WALK-OK" in r.stdout, r.stdout + r.stderr
 
 
-def test_spectral_random_shapes(sc, rsx, synth):
+def test_spectral_random_shapes(sc, rsx, synth, spec_kind):
     """ragged sizes: 1..70 queries (partial query tiles), 1..1500 entries (partial 32-entry tiles and 128-entry
     tile-blocks, workgroups that straddle tile-blocks), k in {1, 3, 10}, eligibility prefixes -- spectral filter ==
     exact path, record for record"""
@@ -213,7 +245,7 @@ def test_spectral_random_shapes(sc, rsx, synth):
         q = np.stack([synth.rotate_descriptor(descs[int(rng.integers(0, n))], int(rng.integers(0, 60))) for _ in range(nq)])
         q[::3, rng.integers(0, 1200, 30)] = 0
         n_elig = int(rng.integers(0, n + 1)) if trial % 3 == 0 else -1
-        f = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+        f = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=spec_kind)
         o = sc.SCManager(filter_mode=rsx.FILTER_OFF)
         f.add_descriptors_f32(descs)
         o.add_descriptors_f32(descs)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Static check of the filter kernels' hand-issued LDS reads (inline-asm ds_read_b128 + counted
 s_waitcnt): no instruction may touch the destination registers of a read that can still be in
-flight.  Usage: tools/check_lds_ring.py [direct|spectral]  (compiles sc_filter.hip / sc_spec.hip to ISA
+flight.  Usage: tools/check_lds_ring.py [direct|spectral|spectral2]  (compiles sc_filter.hip / sc_spec.hip to ISA
 with hipcc and scans sc_filter_kernel / sc_spec_filter_kernel)."""
 import os
 import re
@@ -22,7 +22,8 @@ def regs(tok):
 
 
 KERNELS = {"direct": ("sc_filter.hip", "sc_filter_kernel", []),
-           "spectral": ("sc_spec.hip", "sc_spec_filter_kernel", ["-mllvm", "-amdgpu-mfma-vgpr-form"])}
+           "spectral": ("sc_spec.hip", "sc_spec_filter_kernel", ["-mllvm", "-amdgpu-mfma-vgpr-form"]),
+           "spectral2": ("sc_spec.hip", "sc_spec2_filter_kernel", ["-mllvm", "-amdgpu-mfma-vgpr-form"])}
 
 
 def main():
@@ -52,9 +53,9 @@ def main():
             continue
         parts = re.split(r"[ ,]+", t)
         op = parts[0]
-        if op == "ds_read_b128":
+        if op.startswith("ds_read"):   # b128 (fragments), b64 / read2st64 (the two-wave kernel's exchange)
             outstanding.append((regs(parts[1]), i))
-            nreads += 1
+            nreads += op == "ds_read_b128"
             continue
         if op == "s_waitcnt":
             m = re.search(r"lgkmcnt\((\d+)\)", t)
