@@ -972,36 +972,40 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
 // single wave and everything a tile needs -- 76 stage-1 MFMAs, their LDS reads, the fp16 packing, 16 stage-2 MFMAs,
 // the maxima, the bound arithmetic, the DMA of the next tile -- issues one after the other on it: the matrix pipe is
 // busy 39 % of the time.  Here the entry tile is split BY FREQUENCY over the two waves w and w + 4 of a
-// 512-thread workgroup (they share SIMD w % 4):
-//   half 0 (waves 0..3): f = 0..3, B fragments 0..35  (144 registers)     half 1 (waves 4..7): f = 4..7, 36..75 (160)
-// Both halves run stage 1 on the SAME (4 queries x 32 entries) tile for their own frequencies (the A fragments of a
-// frequency are read by one wave only, so the LDS traffic per flop is unchanged), pack their C_f to fp16, hand the
-// packed halves of the OTHER wave's two queries over through LDS (16 registers = 4 KiB per wave and tile), and run
-// stage 2 + the bound arithmetic for their own two queries (half h: queries 2h, 2h + 1 of the tile).  Two s_barriers
-// per tile: A after the hand-over is written (it also publishes the LDS-DMA pieces of the next query tile), B once
-// every wave has read its partner's half (the exchange area is single-buffered; B comes ~an LDS round trip after A).
-// With two waves on a SIMD the MFMAs of one fill the VALU / LDS / wait stretches of the other.  Everything a lane
-// needs only in its tail (stage-2 weights, the entry's constants, its mask bytes) lives in LDS, not in registers:
-// at 256 registers per wave the B fragments leave ~110 for the accumulators, the A-fragment ring and the packing.
+// 512-thread workgroup (they share SIMD w % 4), with different roles:
+//   consumer (waves 0..3): f = 0..3 (B fragments 0..35), stage 2 + bounds + stores of all 4 queries of a tile
+//   producer (waves 4..7): f = 4..7 (B fragments 36..75) ONE TILE AHEAD, and every LDS-DMA piece of the query stream
+// In interval k the producer runs stage 1 of query tile k for its frequencies, packs its C_f to fp16 and leaves them
+// in LDS (32 registers = 8 KiB per tile); the consumer runs stage 1 of tile k - 1 for its own frequencies, picks the
+// producer's half of tile k - 1 up and finishes the tile.  The A fragments of a frequency are still read by one wave
+// only, so the LDS traffic per flop is unchanged.  ONE s_barrier per interval (it publishes the producer's packed
+// half and the DMA pieces of tile k + 1); the exchange area is single-buffered, so before overwriting it the producer
+// checks a sequence number the consumer bumps once it has read the previous tile's half (it never has to wait: the
+// consumer reads right after its stage 1, the producer writes after its own, longer one).  The consumer's VALU-heavy
+// tail thus runs beside the producer's MFMAs instead of after them.  The first round-4 build split the TAIL over the
+// two waves as well (two queries each, symmetric roles, two barriers per tile): both waves then sat in their tails
+// at the same time with the matrix pipe idle -- 6.1 k cycles per tile against 7.0 k for the one-wave kernel.
+// Everything a lane needs only in the tail (stage-2 weights, the entry's constants, its mask bytes) lives in LDS, not
+// in registers: at 256 registers per wave the B fragments leave ~110 for accumulators, the A ring and the packing.
 #ifndef S2_OPT_PARK0
-#define S2_OPT_PARK0 3   // B fragments of half 0 parked in LDS (read back with the first A fragments of every tile)
+#define S2_OPT_PARK0 9   // B fragments of the consumer parked in LDS (read back with the first A fragments of every tile)
 #endif
 #ifndef S2_OPT_PARK1
-#define S2_OPT_PARK1 6   // ... of half 1 (40 fragments: 4 more than half 0)
+#define S2_OPT_PARK1 2   // ... of the producer
 #endif
 #ifndef S2_OPT_DEPTH
 #define S2_OPT_DEPTH 5
 #endif
 constexpr int S2_DEPTH = S2_OPT_DEPTH;
 constexpr int S2_NBUF = 3;
-constexpr int S2_XDIR = 8 * 512;                       // one direction of one pair: [8 (query, k4)][g, g + 1][64 lanes] dwords
-constexpr int S2_X_OFF = 0;                            // [4 pairs][2 directions] = 32 KiB
-constexpr int S2_W_OFF = S2_X_OFF + 4 * 2 * S2_XDIR;   // stage-2 weights: 64 lanes x 16 B
-constexpr int S2_EC_OFF = S2_W_OFF + 1024;             // [4 tiles of the block][64 lanes] {n_e | e_bad << 16, sqrt n_e, sqrt a_e, 1 / n_e}
-constexpr int S2_BM_OFF = S2_EC_OFF + 4 * 1024;        // [4 tiles][64 lanes] 32 mask bytes (fp8 0 / 1)
-constexpr int S2_PARK_OFF = S2_BM_OFF + 4 * 2048;
+constexpr int S2_XPAIR = 16 * 512;                     // one wave pair: [16 (query, k4)][g = 2, 3][64 lanes] dwords
+constexpr int S2_X_OFF = 0;                            // [4 pairs] = 32 KiB
+constexpr int S2_W_OFF = S2_X_OFF + 4 * S2_XPAIR;      // stage-2 weights: 64 lanes x 16 B
+constexpr int S2_SEQ_OFF = S2_W_OFF + 1024;            // [4 pairs] "half of tile t - 1 consumed" sequence numbers
+constexpr int S2_EC_OFF = S2_SEQ_OFF + 64;             // [4 tiles of the block][64 lanes] {column mask lo, hi | e_bad << 31, sqrt a_e, sqrt n_e}
+constexpr int S2_PARK_OFF = S2_EC_OFF + 4 * 1024;
 constexpr int S2_PARK_BYTES = 4 * (S2_OPT_PARK0 + S2_OPT_PARK1) * 1024;
-constexpr int S2_TILES_OFF = S2_PARK_OFF + S2_PARK_BYTES;
+constexpr int S2_TILES_OFF = (S2_PARK_OFF + S2_PARK_BYTES + 255) / 256 * 256;
 constexpr int S2_LDS_BYTES = S2_TILES_OFF + S2_NBUF * SP_PHASE_BYTES;
 static_assert(S2_LDS_BYTES <= 160 * 1024, "LDS budget");
 static_assert(S2_TILES_OFF >= SP_VS, "wrapped addresses stay non-negative");
@@ -1037,22 +1041,32 @@ struct S2Lane {
   unsigned dc_off, f_off, c_dc, c_f;  // as SpecLane
 };
 
-// pieces of a tile over 8 waves: piece c belongs to wave c % 8
-__device__ __forceinline__ void dma_issue8(const TileDma &d, int wave, int lane) {
-  const int wu = __builtin_amdgcn_readfirstlane(wave);
+// every piece of a tile, over the 4 producer waves: piece c belongs to producer c % 4.  WHOLE pieces, no lane predicate:
+// what a piece reads beyond the tile's last query is the next query's image or the allocation's slack (sp_nq4 rounds the
+// batch up to whole tiles, spec_qimg_bytes adds 1 KiB) and lands in the unused end of the tile buffer
+__device__ __forceinline__ void dma_issue_all(const TileDma &d, int sub, int lane) {
+  const int wu = __builtin_amdgcn_readfirstlane(sub);
+  unsigned lo = (unsigned)lane;
+  asm volatile("" : "+v"(lo));
+  const unsigned voff = lo * 16u;
+  const char *gs = d.gsrc + wu * 1024;
+  char *ls = d.ldst + wu * 1024;
 #pragma unroll
-  for (int j = 0; j < (SP_STREAM_PIECES + SP_MASK_PIECES + 7) / 8; j++) {
-    const int c = wu + 8 * j;
-    if (c >= SP_STREAM_PIECES + SP_MASK_PIECES) break;
-    const bool is_mask = c >= SP_STREAM_PIECES;
-    const int cc = is_mask ? c - SP_STREAM_PIECES : c;
-    unsigned lo = (unsigned)lane;
-    asm volatile("" : "+v"(lo));
-    const unsigned off = (unsigned)(cc * 1024) + lo * 16u;
-    if ((int)off < (is_mask ? d.nbytes_m : d.nbytes))
-      __builtin_amdgcn_global_load_lds(
-          reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(is_mask ? d.gsrc_m : d.gsrc) + off),
-          (AS3 void *)(d.ldst + c * 1024), 16, 0, 0);
+  for (int j = 0; j < (SP_STREAM_PIECES + 3) / 4; j++) {   // stream pieces wu + 4 j
+    if (wu + 4 * j < SP_STREAM_PIECES)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(gs + j * 4096) + voff),
+                                       (AS3 void *)(ls + j * 4096), 16, 0, 0);
+  }
+  if (d.nbytes_m) {  // the tile's flag word: a query with an empty column
+    const int m0 = (wu - SP_STREAM_PIECES) & 3;  // first mask piece of this wave
+    const char *gm = d.gsrc_m + m0 * 1024;
+    char *lm = d.ldst + (SP_STREAM_PIECES + m0) * 1024;
+#pragma unroll
+    for (int j = 0; j < (SP_MASK_PIECES + 3) / 4; j++) {
+      if (m0 + 4 * j < SP_MASK_PIECES)
+        __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(gm + j * 4096) + voff),
+                                         (AS3 void *)(lm + j * 4096), 16, 0, 0);
+    }
   }
 }
 
@@ -1067,8 +1081,22 @@ __device__ __forceinline__ void lds_write2st64(unsigned addr, unsigned v0, unsig
 __device__ __forceinline__ void lds_write_b128(unsigned addr, frag4 v, int off) {
   asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(off) : "memory");
 }
+__device__ __forceinline__ void lds_write_b32(unsigned addr, unsigned v) {
+  asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// a dword every lane reads from the same LDS address, waited for on the spot
+__device__ __forceinline__ unsigned lds_read_b32_now(unsigned addr) {
+  unsigned v;
+  asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+// a flag word through the scalar cache WITHOUT waiting: the caller reads `dst` only behind a later s_waitcnt lgkmcnt(0)
+// (an SMEM load in flight makes the counted lgkmcnt waits of stage 1 stricter, never laxer)
+__device__ __forceinline__ void scalar_load_u32_async(unsigned &dst, const unsigned *p) {
+  asm volatile("s_load_dword %0, %1, 0x0" : "=s"(dst) : "s"(p) : "memory");
+}
 
-// one segment (one tile-block x a range of query tiles) for one half
+// one segment (one tile-block x a range of query tiles) for one role: HALF 0 = consumer, HALF 1 = producer
 template <int HALF>
 __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, unsigned lds_base, const S2Lane &ln, int wave, int lane,
                                               int64_t tb, int t0, int t1) {
@@ -1077,12 +1105,11 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   typedef unsigned u8v __attribute__((ext_vector_type(8)));
   const int sub = wave & 3;
-  const int col = lane & 31, hh = lane >> 5;
   const int64_t ntiles = (a.n_items + 31) >> 5;
   const int q0 = t0 * SP_QPT;
   const int q1 = (t1 * SP_QPT < a.nq) ? t1 * SP_QPT : a.nq;
   const int64_t tile = tb * 4 + sub;
-  const bool tile_ok = tile < ntiles;  // wave-uniform, the same for both halves of a pair
+  const bool tile_ok = tile < ntiles;  // wave-uniform, the same for both waves of a pair
   const int nphase = (q1 - q0 + SP_QPP - 1) / SP_QPP;
   const unsigned lane16 = (unsigned)lane * 16u;
 
@@ -1093,8 +1120,7 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
     return TileDma{a.qimg + (int64_t)qn * SP_QS, a.qimg + sp_masks_at(a.nq) + (int64_t)qn * SP_MASK_BYTES,
                    smem + S2_TILES_OFF + (p % S2_NBUF) * SP_PHASE_BYTES, nqs * SP_QS, flagword ? nqs * SP_MASK_BYTES : 0};
   };
-  dma_issue8(tile_dma(0, scalar_load_u32(qflags)), wave, lane);
-  if (nphase > 1) dma_issue8(tile_dma(1, scalar_load_u32(qflags + 1)), wave, lane);
+  if (HALF == 1) dma_issue_all(tile_dma(0, scalar_load_u32(qflags)), sub, lane);  // tile 0: overlaps the B loads below
 
   half8 B[NF];
   {
@@ -1112,35 +1138,58 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
     for (int s = 0; s < NP; s++)
       lds_write_b128(lds_base + (unsigned)(S2_PARK_OFF + H::park_off) + (unsigned)(sub * (NP * 1024)) + lane16, __builtin_bit_cast(frag4, B[s]), s * 1024);
   }
-  if (HALF == 0) {  // the entry constants of the tile, for both halves
+  if (HALF == 0) {  // the entry constants of the tile and the pair's sequence number
+    const int col = lane & 31;
     const int64_t n = tile * 32 + col;
     const bool n_ok = tile_ok && n < a.n_items;
     const u64 m2 = n_ok ? a.cmask[n] : 0ull;
     const int n_e = __popcll(m2 & kMask60);
     frag4 ec;
-    ec[0] = (unsigned)n_e | (((m2 & kNonFinite) != 0) ? 0x10000u : 0u);
-    ec[1] = __float_as_uint(sqrtf((float)n_e));
+    ec[0] = (unsigned)(m2 & 0xffffffffull);
+    ec[1] = (unsigned)((m2 & kMask60) >> 32) | (((m2 & kNonFinite) != 0) ? 0x80000000u : 0u);
     ec[2] = __float_as_uint(n_ok ? a.aux[n] : 0.0f);
-    ec[3] = __float_as_uint(__builtin_amdgcn_rcpf((float)(n_e > 1 ? n_e : 1)));
+    ec[3] = __float_as_uint(sqrtf((float)n_e));
     lds_write_b128(lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + lane16, ec, 0);
-    const unsigned bits = (unsigned)((m2 & kMask60) >> (32 * hh));
-    frag4 bm[2];
-#pragma unroll
-    for (int r = 0; r < 8; r++) bm[r >> 2][r & 3] = ((((bits >> (4 * r)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0x38u;
-    lds_write_b128(lds_base + (unsigned)S2_BM_OFF + (unsigned)(sub * 2048) + 2u * lane16, bm[0], 0);
-    lds_write_b128(lds_base + (unsigned)S2_BM_OFF + (unsigned)(sub * 2048) + 2u * lane16, bm[1], 16);
+    lds_write_b32(lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 4), 0u);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   const unsigned bpark = lds_base + (unsigned)(S2_PARK_OFF + H::park_off) + (unsigned)(sub * (NP * 1024)) + lane16;
-  for (int p = 0; p < nphase; p++) {
-    const int qp = q0 + p * SP_QPP;
-    const int nq_here = (q1 - qp < SP_QPP) ? (q1 - qp) : SP_QPP;
-    const unsigned tile_lds = lds_base + (unsigned)(S2_TILES_OFF + (p % S2_NBUF) * SP_PHASE_BYTES);
+  // RSX_SPEC_INSTRUMENT builds: s_memtime sums per region of an interval, for wave 0 (consumer) and wave 4 (producer) of workgroup 0
+  const bool prof = kInstr && a.prof && blockIdx.x == 0 && sub == 0;
+  unsigned long long ps[5] = {0, 0, 0, 0, 0}, pt = 0;
+  auto lap = [&](int region) {
+    if (kInstr && prof) {
+      const unsigned long long now = prof_now();
+      ps[region] += now - pt;
+      pt = now;
+    }
+  };
+  unsigned flag_next = (HALF == 1 && nphase > 1) ? scalar_load_u32(qflags + 1) : 0u;  // producer: flag word of the next tile to stage
+  unsigned long long c_begin = 0, r_begin = 0;
+  if (kInstr && prof) {
+    c_begin = prof_now();
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_begin)::"memory");
+  }
+  // interval k: the producer works on query tile k, the consumer on tile k - 1
+  for (int k = 0; k <= nphase; k++) {
+    if (kInstr && prof) pt = prof_now();
+    const int p = HALF == 1 ? k : k - 1;             // this wave's tile of the interval
+    const bool active = tile_ok && p >= 0 && p < nphase;
+    const unsigned tile_lds = lds_base + (unsigned)(S2_TILES_OFF + ((p + S2_NBUF) % S2_NBUF) * SP_PHASE_BYTES);
+    if (HALF == 1) {
+      // tile k + 1 goes into the buffer tile k - 2 was read from (every wave is past the barrier of interval k - 1); issued
+      // FIRST: a whole interval to land, and the pieces cost least to issue while the SIMD's other wave is busy elsewhere.
+      // Its flag word was requested an interval ago; the one of tile k + 2 is requested now and is DEFINED only behind the
+      // lgkmcnt(0) after stage 1 ("+s" there: no use of it can be scheduled above that wait)
+      if (k + 1 < nphase) dma_issue_all(tile_dma(k + 1, flag_next), sub, lane);
+      if (k + 2 < nphase) scalar_load_u32_async(flag_next, qflags + k + 2);
+    }
     unsigned own[2][16];  // own[gl][j]: packed {C_(2g), C_(2g+1)} of (query j / 4, k4 = j % 4), g = 2 HALF + gl
-    if (tile_ok) {
-      // ---------------- stage 1: this half's frequencies, all 4 queries ----------------
+    if (active) {
+      // ---------------- stage 1: this wave's frequencies, all 4 queries ----------------
+      const int hh = lane >> 5;
       floatx16 acc[3];
       floatx16 z;
 #pragma unroll
@@ -1203,138 +1252,217 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
       // second pair (lf 2, 3) = acc[2], acc[0]
 #pragma unroll
       for (int j = 0; j < 16; j++) own[1][j] = pack2(acc[2][j], acc[0][j]);
-      // hand the partner's queries over: (query, k4) = j in [8 (1 - HALF), +8) -> own[0][j] at x_wr + jl * 512, own[1][j] 256 B further
-      unsigned lw = (unsigned)lane;
-      asm volatile("" : "+v"(lw));
-      const unsigned x_wr = lds_base + (unsigned)S2_X_OFF + (unsigned)((sub * 2 + HALF) * S2_XDIR) + lw * 4u;
-#pragma unroll
-      for (int jl = 0; jl < 8; jl++) lds_write2st64(x_wr, own[0][8 * (1 - HALF) + jl], own[1][8 * (1 - HALF) + jl], 2 * jl, 2 * jl + 1);
     }
-    // barrier A: the exchange is written and the pieces of tile p + 1 this wave issued have landed
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    float outv[2] = {0.0f, 0.0f};
-    if (tile_ok) {
-      // ---------------- stage 2 + bounds: this half's two queries ----------------
+    lap(0);  // stage 1 incl. the last packing
+    if (HALF == 1) {
+      // ---------------- producer: leave the packed half of tile k in LDS, feed the query stream ----------------
+      if (active) {
+        unsigned lw = (unsigned)lane;
+        asm volatile("" : "+v"(lw));
+        // the consumer has picked up the half of tile k - 1 (it did so right after ITS stage 1: no wait in practice)
+        const unsigned seq_at = lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 4);
+        while ((int)__builtin_amdgcn_readfirstlane(lds_read_b32_now(seq_at)) < k) __builtin_amdgcn_s_sleep(1);
+        const unsigned x_wr = lds_base + (unsigned)S2_X_OFF + (unsigned)(sub * S2_XPAIR) + lw * 4u;
+#pragma unroll
+        for (int j = 0; j < 16; j++) lds_write2st64(x_wr, own[0][j], own[1][j], 2 * j, 2 * j + 1);
+      }
+      lap(1);  // sequence check + exchange writes
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(flag_next)::"memory");
+      lap(2);  // wait for the exchange writes
+    } else if (active) {
+      // ---------------- consumer: stage 2 + bounds of tile k - 1, two queries at a time ----------------
       // every lane-dependent address of the tail derives from an opaque copy of the lane id: left visible, the compiler
       // hoists a dozen of them out of the tile loop and keeps them in registers across stage 1 (spilling B fragments)
       unsigned lt = (unsigned)lane;
       asm volatile("" : "+v"(lt));
-      const unsigned lane16 = lt * 16u;
+      const unsigned l16 = lt * 16u;
       const int col = (int)(lt & 31u), hh = (int)(lt >> 5);
       const unsigned a_tl = tile_lds + SP_TAIL;
-      const unsigned x_rd = lds_base + (unsigned)S2_X_OFF + (unsigned)((sub * 2 + (1 - HALF)) * S2_XDIR) + lt * 4u;
-      frag4 tw[2], wv, ec;
-      u2v rx[8];
-      lds_read_frag(tw[0], a_tl, (2 * HALF) * SP_QS);
-      lds_read_frag(tw[1], a_tl, (2 * HALF + 1) * SP_QS);
-      static_for<8>([&](auto jc) {
-        constexpr int jl = decltype(jc)::value;
-        lds_read2st64(rx[jl], x_rd, 2 * jl, 2 * jl + 1);
+      const unsigned x_rd = lds_base + (unsigned)S2_X_OFF + (unsigned)(sub * S2_XPAIR) + lt * 4u;
+      const int qp = q0 + p * SP_QPP;
+      const int nq_here = (q1 - qp < SP_QPP) ? (q1 - qp) : SP_QPP;
+      frag4 wv, ec;
+      u2v rx[16];
+      static_for<16>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        lds_read2st64(rx[j], x_rd, 2 * j, 2 * j + 1);
       });
-      lds_read_frag(wv, lds_base + (unsigned)S2_W_OFF + lane16, 0);
-      lds_read_frag(ec, lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + lane16, 0);
+      lds_read_frag(wv, lds_base + (unsigned)S2_W_OFF + l16, 0);
+      lds_read_frag(ec, lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + l16, 0);
+      lds_wait_count<2>();  // the 16 exchange reads have returned (W and the entry constants are younger)
+      __builtin_amdgcn_sched_barrier(0);
+      // the producer's half of this tile is in registers: the exchange area may be overwritten
+      lds_write_b32(lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 4), (unsigned)k);
       lds_wait_count<0>();
       __builtin_amdgcn_sched_barrier(0);
-      // barrier B: every wave holds its partner's half, the exchange area may be written again
-      __builtin_amdgcn_s_barrier();
-      const half8 W = __builtin_bit_cast(half8, wv);
-      const int n_e = (int)(ec[0] & 0xffffu);
-      const bool e_bad = (ec[0] & 0x10000u) != 0;
-      const float sqrt_ne = __uint_as_float(ec[1]), sqrt_ae = __uint_as_float(ec[2]), r_ne = __uint_as_float(ec[3]);
+      lap(1);  // exchange + constant reads
       floatx16 z;
 #pragma unroll
       for (int i = 0; i < 16; i++) z[i] = 0.0f;
-      static_for<2>([&](auto qc) {
-        constexpr int ql = decltype(qc)::value;
-        Recip r = recip_header(tw[ql]);
-        auto Pj = [&](int k4) {  // stage-2 B operand of (this query, k4): K = {g0, g1, g2, g3}
-          const int jl = ql * 4 + k4, j = 8 * HALF + jl;
-          u4 t;
-          if constexpr (HALF == 0) t = u4{own[0][j], own[1][j], rx[jl][0], rx[jl][1]};
-          else t = u4{rx[jl][0], rx[jl][1], own[0][j], own[1][j]};
-          return __builtin_bit_cast(half8, t);
+      float outv[4];
+      static_for<2>([&](auto hc) {
+        constexpr int qh = decltype(hc)::value;  // queries 2 qh, 2 qh + 1
+        frag4 tw[2];  // {n_q, flags, sqrt n_q, sqrt a_q} of the two queries
+        lds_read_frag(tw[0], a_tl, (2 * qh) * SP_QS);
+        lds_read_frag(tw[1], a_tl, (2 * qh + 1) * SP_QS);
+        lds_wait_count<0>();
+        __builtin_amdgcn_sched_barrier(0);
+        const half8 W = __builtin_bit_cast(half8, wv);
+        const int n_e = __popc(ec[0]) + __popc(ec[1] & 0x0fffffffu);
+        const bool e_bad = (ec[1] & 0x80000000u) != 0;
+        const float sqrt_ne = __uint_as_float(ec[3]), sqrt_ae = __uint_as_float(ec[2]);
+        const float r_ne = __builtin_amdgcn_rcpf((float)(n_e > 1 ? n_e : 1));
+        auto bound_of = [&](float m_scaled, float rL, const Recip &r) {  // m_scaled = 15/16 max_k S_k u(n_k)
+          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m_scaled), __float_as_uint(m_scaled), false, false);
+          const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+          const float err = kE1 * r.sqrt_nq * sqrt_ne + kE2 * r.sqrt_aq * sqrt_ae;
+          float v = (1.0f + a.eps_direct) - fmaf(best, (16.0f / 15.0f) * (1.0f + 4e-6f), err * rL);
+          if (r.n_q == 0 || n_e == 0) v = INFINITY;      // no effective column at any shift: never a hit
+          if (r.flags != 0u || e_bad) v = -INFINITY;     // non-finite input: always re-score exactly
+          return v;
         };
-        const bool full_q = __builtin_amdgcn_readfirstlane(r.n_q) == NS;
-        float m = 0.0f;
-        if (full_q) {
-          auto max8 = [&](const floatx16 &dd) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);
+        const Recip ra = recip_header(tw[0]), rb = recip_header(tw[1]);
+        const bool both_full = __builtin_amdgcn_readfirstlane(ra.n_q) == NS && __builtin_amdgcn_readfirstlane(rb.n_q) == NS;
+        if (both_full) {
+          // The usual case (a radar scan has no empty sector): n_eff(k) = n_e at every shift, so a query is 4 stage-2 MFMAs and
+          // 16 v_max3.  The 8 MFMAs of the pair go through THREE result sets, each consumed two MFMAs after it was issued:
+          // left to the compiler (two sets, maxima right behind their MFMA) the wave idled ~12 wait states per MFMA
+          auto Pq = [&](int q, int k4) {
+            const int j = 4 * q + k4;
+            const u4 t = u4{own[0][j], own[1][j], rx[j][0], rx[j][1]};
+            return __builtin_bit_cast(half8, t);
           };
-          floatx16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(0), z, 0, 0, 0);
-          floatx16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(1), z, 0, 0, 0);
-          max8(d0);
-          d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(2), z, 0, 0, 0);
-          max8(d1);
-          d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(3), z, 0, 0, 0);
-          max8(d0);
-          max8(d1);
-          r.rL = r_ne;
-          m *= r.rL;
-        } else {
-          recip_coeffs(r, n_e);
-          // the entry's mask bytes (B operand of the mask correlation) and the query's mask rows come from LDS; one
-          // M-tile (k4 = 2 mt, 2 mt + 1) at a time: n_eff, u(n_eff), S u, maximum
-          frag4 bm0, bm1;
-          lds_read_frag(bm0, lds_base + (unsigned)S2_BM_OFF + (unsigned)(sub * 2048) + 2u * lane16, 0);
-          lds_read_frag(bm1, lds_base + (unsigned)S2_BM_OFF + (unsigned)(sub * 2048) + 2u * lane16, 16);
+          auto max8 = [&](float m, const floatx16 &dd) {
 #pragma unroll
-          for (int mt = 0; mt < 2; mt++) {
-            // n_eff rows: row = col <-> (k4 = 2 mt + col / 16, k15 = col % 16), the row order of the stage-2 output
-            const int k4 = 2 * mt + (col >> 4), k15 = (col & 15) == 15 ? 0 : (col & 15);
-            const int k = (45 * k4 + 16 * k15) % NS;  // CRT
-            const unsigned a_m = tile_lds + (unsigned)(SP_MASKREG_OFF + (k & 15) * SP_MASK_COPY + (k & ~15) + hh * 32);
-            frag4 mk0, mk1;
-            lds_read_frag(mk0, a_m, (2 * HALF + ql) * SP_MASK_BYTES);
-            lds_read_frag(mk1, a_m, (2 * HALF + ql) * SP_MASK_BYTES + 16);
-            lds_wait_count<0>();
-            __builtin_amdgcn_sched_barrier(0);
-            const u8v am = {mk0[0], mk0[1], mk0[2], mk0[3], mk1[0], mk1[1], mk1[2], mk1[3]};
-            const u8v bm = {bm0[0], bm0[1], bm0[2], bm0[3], bm1[0], bm1[1], bm1[2], bm1[3]};
-            const floatx16 nacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), __builtin_bit_cast(intx8, bm), z, 0, 0, 0, 0, 0, 0);
+            for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);  // one v_max3_f32 per pair
+            return m;
+          };
+          constexpr int qa = 2 * qh, qb = 2 * qh + 1;
+          float ma = 0.0f, mb = 0.0f;
+          floatx16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qa, 0), z, 0, 0, 0);
+          floatx16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qa, 1), z, 0, 0, 0);
+          floatx16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qa, 2), z, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          ma = max8(ma, d0);
+          d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qa, 3), z, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          ma = max8(ma, d1);
+          d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qb, 0), z, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          ma = max8(ma, d2);
+          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qb, 1), z, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          ma = max8(ma, d0);
+          d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qb, 2), z, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          mb = max8(mb, d1);
+          d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qb, 3), z, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          outv[qa] = bound_of(ma * r_ne, r_ne, ra);   // n_lo = n_hi = n_e: 1 / n_lo within 1 ulp of r_ne, covered by the (1 + 4e-6)
+          mb = max8(mb, d2);
+          __builtin_amdgcn_sched_barrier(0);
+          mb = max8(mb, d0);
+          mb = max8(mb, d1);
+          outv[qb] = bound_of(mb * r_ne, r_ne, rb);
+        } else
+        static_for<2>([&](auto qc) {
+          constexpr int ql = decltype(qc)::value;
+          constexpr int q = 2 * qh + ql;
+          Recip r = recip_header(tw[ql]);
+          auto Pj = [&](int k4) {  // stage-2 B operand of (this query, k4): K = {g0, g1, g2, g3}
+            const int j = 4 * q + k4;
+            const u4 t = u4{own[0][j], own[1][j], rx[j][0], rx[j][1]};
+            return __builtin_bit_cast(half8, t);
+          };
+          const bool full_q = __builtin_amdgcn_readfirstlane(r.n_q) == NS;
+          float m = 0.0f;
+          if (full_q) {
+            auto max8 = [&](const floatx16 &dd) {
 #pragma unroll
-            for (int kk = 0; kk < 2; kk++) {
-              float2v u2[4];
+              for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);
+            };
+            floatx16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(0), z, 0, 0, 0);
+            floatx16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(1), z, 0, 0, 0);
+            max8(d0);
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(2), z, 0, 0, 0);
+            max8(d1);
+            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(3), z, 0, 0, 0);
+            max8(d0);
+            max8(d1);
+            r.rL = r_ne;
+            m *= r.rL;
+          } else {
+            recip_coeffs(r, n_e);
+            // the entry's mask bytes (B operand of the mask correlation) and the query's mask rows come from LDS; one
+            // M-tile (k4 = 2 mt, 2 mt + 1) at a time: n_eff, u(n_eff), S u, maximum
+            // this lane's entry: column-mask bits 32 hh .. 32 hh + 31 (the K index of the lane half) as fp8 0.0 / 1.0 bytes
+            const unsigned bits = hh ? (ec[1] & 0x0fffffffu) : ec[0];
+            u8v bm;
 #pragma unroll
-              for (int e = 0; e < 4; e++) {
-                const float2v n2 = {nacc[kk * 8 + 2 * e], nacc[kk * 8 + 2 * e + 1]};
-                const float2v t2 = __builtin_elementwise_fma(n2, r.C2, r.B2);
-                u2[e] = __builtin_elementwise_fma(n2, t2, r.A2);
-              }
-              const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(2 * mt + kk), z, 0, 0, 0);
+            for (int rr = 0; rr < 8; rr++) bm[rr] = ((((bits >> (4 * rr)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0x38u;
 #pragma unroll
-              for (int e = 0; e < 4; e++) {
-                const float2v s2 = {dd[2 * e], dd[2 * e + 1]};
-                const float2v v2 = s2 * u2[e];
-                m = fmaxf(fmaxf(m, v2[0]), v2[1]);
+            for (int mt = 0; mt < 2; mt++) {
+              // n_eff rows: row = col <-> (k4 = 2 mt + col / 16, k15 = col % 16), the row order of the stage-2 output
+              const int k4 = 2 * mt + (col >> 4), k15 = (col & 15) == 15 ? 0 : (col & 15);
+              const int kk0 = (45 * k4 + 16 * k15) % NS;  // CRT
+              const unsigned a_m = tile_lds + (unsigned)(SP_MASKREG_OFF + (kk0 & 15) * SP_MASK_COPY + (kk0 & ~15) + hh * 32);
+              frag4 mk0, mk1;
+              lds_read_frag(mk0, a_m, q * SP_MASK_BYTES);
+              lds_read_frag(mk1, a_m, q * SP_MASK_BYTES + 16);
+              lds_wait_count<0>();
+              __builtin_amdgcn_sched_barrier(0);
+              const u8v am = {mk0[0], mk0[1], mk0[2], mk0[3], mk1[0], mk1[1], mk1[2], mk1[3]};
+              const floatx16 nacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), __builtin_bit_cast(intx8, bm), z, 0, 0, 0, 0, 0, 0);
+#pragma unroll
+              for (int kk = 0; kk < 2; kk++) {
+                float2v u2[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  const float2v n2 = {nacc[kk * 8 + 2 * e], nacc[kk * 8 + 2 * e + 1]};
+                  const float2v t2 = __builtin_elementwise_fma(n2, r.C2, r.B2);
+                  u2[e] = __builtin_elementwise_fma(n2, t2, r.A2);
+                }
+                const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(2 * mt + kk), z, 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                  const float2v s2 = {dd[2 * e], dd[2 * e + 1]};
+                  const float2v v2 = s2 * u2[e];
+                  m = fmaxf(fmaxf(m, v2[0]), v2[1]);
+                }
               }
             }
           }
+          outv[q] = bound_of(m, r.rL, r);
+        });
+        // lanes 0..31 store query 2 qh, lanes 32..63 query 2 qh + 1: one store per query pair
+        {
+          const int64_t n = tile * 32 + col;
+          const int qq = 2 * qh + hh;
+          const float vv = hh ? outv[2 * qh + 1] : outv[2 * qh];
+          if (n < a.n_items && qq < nq_here) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = vv;
         }
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
-        const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-        const float err = kE1 * r.sqrt_nq * sqrt_ne + kE2 * r.sqrt_aq * sqrt_ae;
-        float v = (1.0f + a.eps_direct) - fmaf(best, (16.0f / 15.0f) * (1.0f + 4e-6f), err * r.rL);
-        if (r.n_q == 0 || n_e == 0) v = INFINITY;
-        if (r.flags != 0u || e_bad) v = -INFINITY;
-        outv[ql] = v;
       });
-    } else {
-      __builtin_amdgcn_s_barrier();  // barrier B for the waves without a tile
+      lap(2);  // stage 2 + bounds + stores
     }
-    // lanes 0..31 store query 2 HALF, lanes 32..63 query 2 HALF + 1: one store per wave and tile
-    {
-      unsigned lt = (unsigned)lane;
-      asm volatile("" : "+v"(lt));
-      const int col = (int)(lt & 31u), hh = (int)(lt >> 5);
-      const int64_t n = tile * 32 + col;
-      const int qq = 2 * HALF + hh;
-      const float vv = hh ? outv[1] : outv[0];
-      if (tile_ok && n < a.n_items && qq < nq_here) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = vv;
+    // the producer's pieces of tile k + 1 have landed and its packed half of tile k is written; the consumer's stores
+    // stay in flight (nothing waits for them before the end of the segment)
+    if (HALF == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    lap(3);  // wait for the DMA / the writes
+    __builtin_amdgcn_s_barrier();
+    lap(4);  // barrier
+  }
+  if (kInstr && prof) {
+    unsigned long long r_end;
+    const unsigned long long c_end = prof_now();
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_end)::"memory");
+    if (lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 5; i++) a.prof[HALF * 8 + i] = ps[i];
+      a.prof[HALF * 8 + 5] = (unsigned long long)nphase;
+      a.prof[HALF * 8 + 6] = c_end - c_begin;
+      a.prof[HALF * 8 + 7] = r_end - r_begin;
     }
-    // the DMA of tile p + 2 into the buffer tile p - 1 was read from (every wave is past barrier A of tile p)
-    if (p + 2 < nphase) dma_issue8(tile_dma(p + 2, scalar_load_u32(qflags + p + 2)), wave, lane);
   }
   // segment end: the next segment re-writes the parked fragments, the entry constants and the tile buffers
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1383,8 +1511,14 @@ __global__ __launch_bounds__(512, 2) void sc_spec2_filter_kernel(SpecArgs a) {
     wv = __builtin_bit_cast(frag4, W);
     lds_write_b128(lds_base + (unsigned)S2_W_OFF + (unsigned)lane * 16u, wv, 0);
   }
-  // the younger half of the workgroup loses the VALU arbitration on every segment otherwise (MI355X_MICROARCH: static priority)
-  if (half) __builtin_amdgcn_s_setprio(1);
+  // no static priority: with s_setprio 1 on the consumer (the critical path of an interval) the producer made NO progress
+  // while the consumer sat in its tail -- an s_nop of the prioritised wave wins the issue slot too (measured: 200 cycles
+  // per producer slot there).  RSX_SPEC_DBG bits 1 / 2 of instrumented builds give the consumer / the producer priority
+  if (kInstr && (a.dbg & 1)) {
+    if (half == 0) __builtin_amdgcn_s_setprio(1);
+  } else if (kInstr && (a.dbg & 2)) {
+    if (half == 1) __builtin_amdgcn_s_setprio(1);
+  }
 
   int64_t tb = 0;
   if (a.tb_cum && L0 < L1) {
@@ -1505,9 +1639,25 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
                                   hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS_BYTES));
       attr2 = true;
     }
-    a.prof = nullptr;
+    static unsigned long long *d_prof2 = nullptr;
+    static const bool want_prof2 = kInstr && rsx::exp_env("RSX_SPEC_PROF") != nullptr;
+    if (want_prof2 && !d_prof2) RSX_HIP(hipMalloc(&d_prof2, 16 * sizeof(unsigned long long)));
+    a.prof = want_prof2 ? d_prof2 : nullptr;
     hipLaunchKernelGGL(sc_spec2_filter_kernel, dim3(grid), dim3(512), S2_LDS_BYTES, s, a);
     RSX_HIP(hipGetLastError());
+    if (want_prof2) {  // debugging aid only: synchronises
+      unsigned long long h[16] = {0};
+      RSX_HIP(hipStreamSynchronize(s));
+      RSX_HIP(hipMemcpy(h, d_prof2, sizeof(h), hipMemcpyDeviceToHost));
+      for (int hf = 0; hf < 2; hf++) {
+        const double n = h[hf * 8 + 5] ? (double)h[hf * 8 + 5] : 1.0;
+        fprintf(stderr, "[sc_spec2 prof] %s, %llu tiles of the last segment of workgroup 0: cycles per tile  stage1 %.0f  %s %.0f  %s %.0f"
+                        "  wait %.0f  barrier %.0f | %.0f cycles per tile at %.0f MHz\n",
+                hf ? "producer" : "consumer", h[hf * 8 + 5], h[hf * 8] / n, hf ? "seq+exchange writes" : "const+exchange reads", h[hf * 8 + 1] / n,
+                hf ? "wait for the writes" : "stage2+bounds+stores", h[hf * 8 + 2] / n, h[hf * 8 + 3] / n, h[hf * 8 + 4] / n,
+                h[hf * 8 + 6] / n, h[hf * 8 + 7] ? 100.0 * h[hf * 8 + 6] / h[hf * 8 + 7] : 0.0);
+      }
+    }
     return RSX_OK;
   }
   static unsigned long long *d_prof = nullptr;
