@@ -972,36 +972,41 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
 // single wave and everything a tile needs -- 76 stage-1 MFMAs, their LDS reads, the fp16 packing, 16 stage-2 MFMAs,
 // the maxima, the bound arithmetic, the DMA of the next tile -- issues one after the other on it: the matrix pipe is
 // busy 39 % of the time.  Here the entry tile is split BY FREQUENCY over the two waves w and w + 4 of a
-// 512-thread workgroup (they share SIMD w % 4), with different roles:
-//   consumer (waves 0..3): f = 0..3 (B fragments 0..35), stage 2 + bounds + stores of all 4 queries of a tile
-//   producer (waves 4..7): f = 4..7 (B fragments 36..75) ONE TILE AHEAD, and every LDS-DMA piece of the query stream
-// In interval k the producer runs stage 1 of query tile k for its frequencies, packs its C_f to fp16 and leaves them
-// in LDS (32 registers = 8 KiB per tile); the consumer runs stage 1 of tile k - 1 for its own frequencies, picks the
-// producer's half of tile k - 1 up and finishes the tile.  The A fragments of a frequency are still read by one wave
-// only, so the LDS traffic per flop is unchanged.  ONE s_barrier per interval (it publishes the producer's packed
-// half and the DMA pieces of tile k + 1); the exchange area is single-buffered, so before overwriting it the producer
-// checks a sequence number the consumer bumps once it has read the previous tile's half (it never has to wait: the
-// consumer reads right after its stage 1, the producer writes after its own, longer one).  The consumer's VALU-heavy
-// tail thus runs beside the producer's MFMAs instead of after them.  The first round-4 build split the TAIL over the
-// two waves as well (two queries each, symmetric roles, two barriers per tile): both waves then sat in their tails
-// at the same time with the matrix pipe idle -- 6.1 k cycles per tile against 7.0 k for the one-wave kernel.
+// 512-thread workgroup (they share SIMD w % 4):
+//   "late"  wave (0..3): f = 0..3 (B fragments 0..35),  stage 2 + bounds + store of queries 2, 3 of a tile
+//   "early" wave (4..7): f = 4..7 (B fragments 36..75), stage 2 + bounds + store of queries 0, 1, and every LDS-DMA piece
+// Both run stage 1 on the SAME (4 queries x 32 entries) tile for their own frequencies (the A fragments of a frequency
+// are read by one wave only, so the LDS traffic per flop is unchanged), pack their C_f to fp16 and hand the halves of
+// the partner's two queries over through LDS (16 registers = 4 KiB per wave and tile).  The two waves are HALF A TILE
+// OUT OF PHASE: in interval k the late wave runs [stage 1 of tile k | tail of tile k - 1] and the early wave
+// [tail of tile k - 1 | DMA of tile k + 1 | stage 1 of tile k], so one wave's VALU-heavy tail always runs beside the other's
+// MFMAs.  The late wave carries its own packed halves of its two queries (16 registers) across its next stage 1 -- it
+// has 4 B fragments fewer than the early one, which is exactly that.  ONE s_barrier per interval (it publishes the DMA
+// pieces of the next tile and orders the exchange between intervals); within an interval each single-buffered exchange
+// direction is guarded by a sequence number: the reader bumps it once the half is in its registers, the writer checks
+// it before overwriting (the reads come half an interval before the writes: the check never waits in practice).
+// Round-4 builds before this one, both measured at 1.76-1.80 ms per 8192 x 9970 launch against 2.05 for the one-wave
+// kernel: (i) symmetric, in phase, two barriers per tile -- both waves sat in their tails together, the pipe idle;
+// (ii) producer (f = 4..7 + DMA, one tile ahead) / consumer (f = 0..3 + all four tails) -- during stage 1 the two waves
+// alternated on the matrix pipe at exactly 64 cycles per own MFMA (pipe 100 % busy), but the consumer's serial tail
+// (2.9 k cycles, ~350 issue states) then ran with the pipe idle.  A static s_setprio on either wave starved the other.
 // Everything a lane needs only in the tail (stage-2 weights, the entry's constants, its mask bytes) lives in LDS, not
 // in registers: at 256 registers per wave the B fragments leave ~110 for accumulators, the A ring and the packing.
 #ifndef S2_OPT_PARK0
-#define S2_OPT_PARK0 9   // B fragments of the consumer parked in LDS (read back with the first A fragments of every tile)
+#define S2_OPT_PARK0 5   // B fragments of the consumer parked in LDS (read back with the first A fragments of every tile)
 #endif
 #ifndef S2_OPT_PARK1
-#define S2_OPT_PARK1 2   // ... of the producer
+#define S2_OPT_PARK1 5   // ... of the producer
 #endif
 #ifndef S2_OPT_DEPTH
 #define S2_OPT_DEPTH 5
 #endif
 constexpr int S2_DEPTH = S2_OPT_DEPTH;
 constexpr int S2_NBUF = 3;
-constexpr int S2_XPAIR = 16 * 512;                     // one wave pair: [16 (query, k4)][g = 2, 3][64 lanes] dwords
+constexpr int S2_XPAIR = 16 * 512;                     // one wave pair: two directions x [8 (query, k4)][2 g][64 lanes] dwords
 constexpr int S2_X_OFF = 0;                            // [4 pairs] = 32 KiB
 constexpr int S2_W_OFF = S2_X_OFF + 4 * S2_XPAIR;      // stage-2 weights: 64 lanes x 16 B
-constexpr int S2_SEQ_OFF = S2_W_OFF + 1024;            // [4 pairs] "half of tile t - 1 consumed" sequence numbers
+constexpr int S2_SEQ_OFF = S2_W_OFF + 1024;            // [4 pairs][2 directions] "half of tile t - 1 picked up" sequence numbers
 constexpr int S2_EC_OFF = S2_SEQ_OFF + 64;             // [4 tiles of the block][64 lanes] {column mask lo, hi | e_bad << 31, sqrt a_e, sqrt n_e}
 constexpr int S2_PARK_OFF = S2_EC_OFF + 4 * 1024;
 constexpr int S2_PARK_BYTES = 4 * (S2_OPT_PARK0 + S2_OPT_PARK1) * 1024;
@@ -1096,12 +1101,16 @@ __device__ __forceinline__ void scalar_load_u32_async(unsigned &dst, const unsig
   asm volatile("s_load_dword %0, %1, 0x0" : "=s"(dst) : "s"(p) : "memory");
 }
 
-// one segment (one tile-block x a range of query tiles) for one role: HALF 0 = consumer, HALF 1 = producer
+// one segment (one tile-block x a range of query tiles) for one wave of a pair.
+//   HALF 0 ("late"):  f = 0..3, queries 2, 3 of a tile;  interval k = [stage 1 of tile k | tail of tile k - 1]
+//   HALF 1 ("early"): f = 4..7, queries 0, 1;            interval k = [tail of tile k - 1 | DMA of tile k + 1 | stage 1 of tile k]
 template <int HALF>
 __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, unsigned lds_base, const S2Lane &ln, int wave, int lane,
                                               int64_t tb, int t0, int t1) {
   using H = S2Half<HALF>;
   constexpr int NF = H::nfrag, NP = H::npark;
+  constexpr int QB = HALF == 1 ? 0 : 2;   // this wave's two queries of a tile; (query, k4) = j in [4 QB, 4 QB + 8)
+  constexpr int JB = 4 * QB, JO = 8 - JB; // ... and the partner's
   typedef unsigned u4 __attribute__((ext_vector_type(4)));
   typedef unsigned u8v __attribute__((ext_vector_type(8)));
   const int sub = wave & 3;
@@ -1138,7 +1147,7 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
     for (int s = 0; s < NP; s++)
       lds_write_b128(lds_base + (unsigned)(S2_PARK_OFF + H::park_off) + (unsigned)(sub * (NP * 1024)) + lane16, __builtin_bit_cast(frag4, B[s]), s * 1024);
   }
-  if (HALF == 0) {  // the entry constants of the tile and the pair's sequence number
+  if (HALF == 0) {  // the entry constants of the tile and the pair's sequence numbers
     const int col = lane & 31;
     const int64_t n = tile * 32 + col;
     const bool n_ok = tile_ok && n < a.n_items;
@@ -1150,13 +1159,19 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
     ec[2] = __float_as_uint(n_ok ? a.aux[n] : 0.0f);
     ec[3] = __float_as_uint(sqrtf((float)n_e));
     lds_write_b128(lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + lane16, ec, 0);
-    lds_write_b32(lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 4), 0u);
+    lds_write_b32(lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 8), 0u);
+    lds_write_b32(lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 8 + 4), 0u);
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   const unsigned bpark = lds_base + (unsigned)(S2_PARK_OFF + H::park_off) + (unsigned)(sub * (NP * 1024)) + lane16;
-  // RSX_SPEC_INSTRUMENT builds: s_memtime sums per region of an interval, for wave 0 (consumer) and wave 4 (producer) of workgroup 0
+  // exchange area of the pair: [0, 4 KiB) what the early wave leaves for the late one, [4 KiB, 8 KiB) the other direction;
+  // sequence word s: the half with direction s of tile t - 1 has been picked up (value t)
+  const unsigned x_pair = lds_base + (unsigned)S2_X_OFF + (unsigned)(sub * S2_XPAIR);
+  const unsigned seq_mine = lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 8 + 4 * (1 - HALF));   // bumped by my partner, checked by me
+  const unsigned seq_theirs = lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 8 + 4 * HALF);      // bumped by me
+  // RSX_SPEC_INSTRUMENT builds: s_memtime sums per region of an interval, for waves 0 and 4 of workgroup 0
   const bool prof = kInstr && a.prof && blockIdx.x == 0 && sub == 0;
   unsigned long long ps[5] = {0, 0, 0, 0, 0}, pt = 0;
   auto lap = [&](int region) {
@@ -1166,291 +1181,292 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
       pt = now;
     }
   };
-  unsigned flag_next = (HALF == 1 && nphase > 1) ? scalar_load_u32(qflags + 1) : 0u;  // producer: flag word of the next tile to stage
   unsigned long long c_begin = 0, r_begin = 0;
   if (kInstr && prof) {
     c_begin = prof_now();
     asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_begin)::"memory");
   }
-  // interval k: the producer works on query tile k, the consumer on tile k - 1
+  unsigned flag_next = (HALF == 1 && nphase > 1) ? scalar_load_u32(qflags + 1) : 0u;  // early wave: flag word of the next tile to stage
+  unsigned held[2][8];  // this wave's own packed halves {C_(2g), C_(2g+1)} of ITS two queries of the previous tile
+#pragma unroll
+  for (int i = 0; i < 8; i++) held[0][i] = held[1][i] = 0u;
+
+  // ---------------- stage 1 of tile p: this wave's frequencies, all 4 queries -> own[gl][j] ----------------
+  auto stage1 = [&](int p, unsigned (&own)[2][16]) {
+    const unsigned tile_lds = lds_base + (unsigned)(S2_TILES_OFF + (p % S2_NBUF) * SP_PHASE_BYTES);
+    const int hh = lane >> 5;
+    floatx16 acc[3];
+    floatx16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    frag4 ring[S2_DEPTH];
+    frag4 bx[NP > 0 ? NP : 1];
+    const unsigned a_dc = tile_lds + ln.dc_off, a_f = tile_lds + ln.f_off;
+    const unsigned a_dcw = a_dc - SP_DC_BYTES, a_fw = a_f - SP_VS;
+    auto a_read = [&](frag4 &dst, auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if constexpr (H::f_of(t) == 0) lds_read_stream<H::s_of(t), SP_DC_BYTES / 16, 10>(dst, a_dc, a_dcw, ln.c_dc, H::a_off(t));
+      else lds_read_stream<H::s_of(t), SP_VS / 16, 16>(dst, a_f, a_fw, ln.c_f, H::a_off(t));
+    };
+    static_for<S2_DEPTH>([&](auto tc) { a_read(ring[decltype(tc)::value], tc); });
+    static_for<NP>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      lds_read_frag(bx[t], bpark, 1024 * t);
+    });
+    static_for<NF>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int f = H::f_of(t), lf = f - 4 * HALF;
+      lds_wait_count<s2_wait_of(t, NF, NP)>();
+      __builtin_amdgcn_sched_barrier(0);
+      const half8 af = __builtin_bit_cast(half8, ring[t % S2_DEPTH]);
+      half8 bf;
+      if constexpr (t < NP) bf = __builtin_bit_cast(half8, bx[t]);
+      else bf = B[t];
+      if constexpr (H::s_of(t) == 0) acc[lf % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, z, 0, 0, 0);
+      else acc[lf % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[lf % 3], 0, 0, 0);
+      if constexpr (t + S2_DEPTH < NF) a_read(ring[t % S2_DEPTH], std::integral_constant<int, t + S2_DEPTH>{});
+      if constexpr (HALF == 0) {
+        // C_0 as fp16 hi + lo (see spec_tile): during f = 1, two j per slot
+        constexpr int sb = H::last_slot(0) + 2;
+        if constexpr (t >= sb && t < sb + 8) {
+#pragma unroll
+          for (int j = 2 * (t - sb); j < 2 * (t - sb) + 2; j++) {
+            const float v = acc[0][j];
+            const float hi = __uint_as_float(__float_as_uint(v) & 0xffffe000u);
+            float sp = hh ? v - hi : hi;
+            asm volatile("" : "+v"(sp));
+            acc[0][j] = sp;
+          }
+        }
+      }
+      // first pair (lf 0, 1) -> own[0][*], packed during lf 2 (two j per slot), before lf 3 re-uses acc[0]
+      {
+        constexpr int pb = H::last_slot(1) + 2;
+        static_assert(pb + 8 <= H::first_slot(3), "accumulators are re-used before they are packed");
+        if constexpr (t >= pb && t < pb + 8) {
+#pragma unroll
+          for (int j = 2 * (t - pb); j < 2 * (t - pb) + 2; j++) {
+            unsigned pk = pack2(acc[0][j], acc[1][j]);
+            asm volatile("" : "+v"(pk));
+            own[0][j] = pk;
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // second pair (lf 2, 3) = acc[2], acc[0]
+#pragma unroll
+    for (int j = 0; j < 16; j++) own[1][j] = pack2(acc[2][j], acc[0][j]);
+  };
+
+  // ---------------- hand the partner's two queries of tile p over ----------------
+  auto hand_over = [&](int p, const unsigned (&own)[2][16]) {
+    unsigned lw = (unsigned)lane;
+    asm volatile("" : "+v"(lw));
+    // my partner has picked up what I left for tile p - 1 (it reads long before I write: no wait in practice)
+    while ((int)__builtin_amdgcn_readfirstlane(lds_read_b32_now(seq_mine)) < p) __builtin_amdgcn_s_sleep(1);
+    const unsigned x_wr = x_pair + (unsigned)(HALF == 1 ? 0 : S2_XPAIR / 2) + lw * 4u;
+#pragma unroll
+    for (int jl = 0; jl < 8; jl++) lds_write2st64(x_wr, own[0][JO + jl], own[1][JO + jl], 2 * jl, 2 * jl + 1);
+  };
+
+  // ---------------- stage 2 + bounds + store of this wave's two queries of tile p ----------------
+  auto tail = [&](int p) {
+    const unsigned tile_lds = lds_base + (unsigned)(S2_TILES_OFF + (p % S2_NBUF) * SP_PHASE_BYTES);
+    // every lane-dependent address of the tail derives from an opaque copy of the lane id: left visible, the compiler
+    // hoists a dozen of them out of the tile loop and keeps them in registers across stage 1 (spilling B fragments)
+    unsigned lt = (unsigned)lane;
+    asm volatile("" : "+v"(lt));
+    const unsigned l16 = lt * 16u;
+    const int col = (int)(lt & 31u), hh = (int)(lt >> 5);
+    const unsigned a_tl = tile_lds + SP_TAIL;
+    const unsigned x_rd = x_pair + (unsigned)(HALF == 1 ? S2_XPAIR / 2 : 0) + lt * 4u;
+    const int qp = q0 + p * SP_QPP;
+    const int nq_here = (q1 - qp < SP_QPP) ? (q1 - qp) : SP_QPP;
+    frag4 wv, ec, tw[2];
+    u2v rx[8];
+    static_for<8>([&](auto jc) {
+      constexpr int jl = decltype(jc)::value;
+      lds_read2st64(rx[jl], x_rd, 2 * jl, 2 * jl + 1);
+    });
+    lds_read_frag(wv, lds_base + (unsigned)S2_W_OFF + l16, 0);
+    lds_read_frag(ec, lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + l16, 0);
+    lds_read_frag(tw[0], a_tl, QB * SP_QS);         // {n_q, flags, sqrt n_q, sqrt a_q} of the two queries
+    lds_read_frag(tw[1], a_tl, (QB + 1) * SP_QS);
+    lds_wait_count<4>();  // the 8 exchange reads have returned
+    __builtin_amdgcn_sched_barrier(0);
+    lds_write_b32(seq_theirs, (unsigned)(p + 1));  // my partner's half of tile p is in registers: it may overwrite the area
+    lds_wait_count<0>();
+    __builtin_amdgcn_sched_barrier(0);
+    lap(HALF == 1 ? 0 : 2);  // exchange + constant reads
+    floatx16 z;
+#pragma unroll
+    for (int i = 0; i < 16; i++) z[i] = 0.0f;
+    const half8 W = __builtin_bit_cast(half8, wv);
+    const int n_e = __popc(ec[0]) + __popc(ec[1] & 0x0fffffffu);
+    const bool e_bad = (ec[1] & 0x80000000u) != 0;
+    const float sqrt_ne = __uint_as_float(ec[3]), sqrt_ae = __uint_as_float(ec[2]);
+    const float r_ne = __builtin_amdgcn_rcpf((float)(n_e > 1 ? n_e : 1));
+    auto Pq = [&](int ql, int k4) {  // stage-2 B operand of (query QB + ql, k4): K = {g0, g1, g2, g3}
+      const int jl = 4 * ql + k4;
+      u4 t;
+      if constexpr (HALF == 0) t = u4{held[0][jl], held[1][jl], rx[jl][0], rx[jl][1]};
+      else t = u4{rx[jl][0], rx[jl][1], held[0][jl], held[1][jl]};
+      return __builtin_bit_cast(half8, t);
+    };
+    auto bound_of = [&](float m_scaled, float rL, const Recip &r) {  // m_scaled = 15/16 max_k S_k u(n_k)
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m_scaled), __float_as_uint(m_scaled), false, false);
+      const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      const float err = kE1 * r.sqrt_nq * sqrt_ne + kE2 * r.sqrt_aq * sqrt_ae;
+      float v = (1.0f + a.eps_direct) - fmaf(best, (16.0f / 15.0f) * (1.0f + 4e-6f), err * rL);
+      if (r.n_q == 0 || n_e == 0) v = INFINITY;      // no effective column at any shift: never a hit
+      if (r.flags != 0u || e_bad) v = -INFINITY;     // non-finite input: always re-score exactly
+      return v;
+    };
+    float outv[2];
+    const Recip ra = recip_header(tw[0]), rb = recip_header(tw[1]);
+    const bool both_full = __builtin_amdgcn_readfirstlane(ra.n_q) == NS && __builtin_amdgcn_readfirstlane(rb.n_q) == NS;
+    if (both_full) {
+      // The usual case (a radar scan has no empty sector): n_eff(k) = n_e at every shift, so a query is 4 stage-2 MFMAs and
+      // 16 v_max3.  The 8 MFMAs of the pair go through THREE result sets, each consumed two MFMAs after it was issued
+      auto max8 = [&](float m, const floatx16 &dd) {
+#pragma unroll
+        for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);  // one v_max3_f32 per pair
+        return m;
+      };
+      float ma = 0.0f, mb = 0.0f;
+      floatx16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(0, 0), z, 0, 0, 0);
+      floatx16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(0, 1), z, 0, 0, 0);
+      floatx16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(0, 2), z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ma = max8(ma, d0);
+      d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(0, 3), z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ma = max8(ma, d1);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(1, 0), z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ma = max8(ma, d2);
+      d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(1, 1), z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ma = max8(ma, d0);
+      d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(1, 2), z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      mb = max8(mb, d1);
+      d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(1, 3), z, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      outv[0] = bound_of(ma * r_ne, r_ne, ra);   // n_lo = n_hi = n_e: 1 / n_lo within 1 ulp of r_ne, covered by the (1 + 4e-6)
+      mb = max8(mb, d2);
+      __builtin_amdgcn_sched_barrier(0);
+      mb = max8(mb, d0);
+      mb = max8(mb, d1);
+      outv[1] = bound_of(mb * r_ne, r_ne, rb);
+    } else {
+      static_for<2>([&](auto qc) {
+        constexpr int ql = decltype(qc)::value;
+        Recip r = recip_header(tw[ql]);
+        const bool full_q = __builtin_amdgcn_readfirstlane(r.n_q) == NS;
+        float m = 0.0f;
+        if (full_q) {
+#pragma unroll
+          for (int k4 = 0; k4 < 4; k4++) {
+            const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(ql, k4), z, 0, 0, 0);
+#pragma unroll
+            for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);
+          }
+          r.rL = r_ne;
+          m *= r.rL;
+        } else {
+          recip_coeffs(r, n_e);
+          // this lane's entry: column-mask bits 32 hh .. 32 hh + 31 (the K index of the lane half) as fp8 0.0 / 1.0 bytes;
+          // the query's mask rows come from the tile buffer; one M-tile (k4 = 2 mt, 2 mt + 1) at a time: n_eff, u(n_eff), S u, maximum
+          const unsigned bits = hh ? (ec[1] & 0x0fffffffu) : ec[0];
+          u8v bm;
+#pragma unroll
+          for (int rr = 0; rr < 8; rr++) bm[rr] = ((((bits >> (4 * rr)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0x38u;
+#pragma unroll
+          for (int mt = 0; mt < 2; mt++) {
+            // n_eff rows: row = col <-> (k4 = 2 mt + col / 16, k15 = col % 16), the row order of the stage-2 output
+            const int k4 = 2 * mt + (col >> 4), k15 = (col & 15) == 15 ? 0 : (col & 15);
+            const int kk0 = (45 * k4 + 16 * k15) % NS;  // CRT
+            const unsigned a_m = tile_lds + (unsigned)(SP_MASKREG_OFF + (kk0 & 15) * SP_MASK_COPY + (kk0 & ~15) + hh * 32);
+            frag4 mk0, mk1;
+            lds_read_frag(mk0, a_m, (QB + ql) * SP_MASK_BYTES);
+            lds_read_frag(mk1, a_m, (QB + ql) * SP_MASK_BYTES + 16);
+            lds_wait_count<0>();
+            __builtin_amdgcn_sched_barrier(0);
+            const u8v am = {mk0[0], mk0[1], mk0[2], mk0[3], mk1[0], mk1[1], mk1[2], mk1[3]};
+            const floatx16 nacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), __builtin_bit_cast(intx8, bm), z, 0, 0, 0, 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < 2; kk++) {
+              float2v u2[4];
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float2v n2 = {nacc[kk * 8 + 2 * e], nacc[kk * 8 + 2 * e + 1]};
+                const float2v t2 = __builtin_elementwise_fma(n2, r.C2, r.B2);
+                u2[e] = __builtin_elementwise_fma(n2, t2, r.A2);
+              }
+              const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(ql, 2 * mt + kk), z, 0, 0, 0);
+#pragma unroll
+              for (int e = 0; e < 4; e++) {
+                const float2v s2 = {dd[2 * e], dd[2 * e + 1]};
+                const float2v v2 = s2 * u2[e];
+                m = fmaxf(fmaxf(m, v2[0]), v2[1]);
+              }
+            }
+          }
+        }
+        outv[ql] = bound_of(m, r.rL, r);
+      });
+    }
+    // lanes 0..31 store query QB, lanes 32..63 query QB + 1: one store per wave and tile
+    {
+      const int64_t n = tile * 32 + col;
+      const int qq = QB + hh;
+      const float vv = hh ? outv[1] : outv[0];
+      if (n < a.n_items && qq < nq_here) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = vv;
+    }
+    lap(HALF == 1 ? 1 : 3);  // stage 2 + bounds + store
+  };
+
+  // interval k: stage 1 of query tile k, tails of tile k - 1
   for (int k = 0; k <= nphase; k++) {
     if (kInstr && prof) pt = prof_now();
-    const int p = HALF == 1 ? k : k - 1;             // this wave's tile of the interval
-    const bool active = tile_ok && p >= 0 && p < nphase;
-    const unsigned tile_lds = lds_base + (unsigned)(S2_TILES_OFF + ((p + S2_NBUF) % S2_NBUF) * SP_PHASE_BYTES);
+    const bool do_s1 = tile_ok && k < nphase, do_tail = tile_ok && k >= 1;
+    unsigned own[2][16];  // own[gl][j]: packed {C_(2g), C_(2g+1)} of (query j / 4, k4 = j % 4), g = 2 HALF + gl
     if (HALF == 1) {
-      // tile k + 1 goes into the buffer tile k - 2 was read from (every wave is past the barrier of interval k - 1); issued
-      // FIRST: a whole interval to land, and the pieces cost least to issue while the SIMD's other wave is busy elsewhere.
+      if (do_tail) tail(k - 1);
+      // tile k + 1 goes into the buffer tile k - 2 was read from (every wave is past the barrier of interval k - 1; this
+      // wave's store of the tail above is older, so the vmcnt(0) at the end of the interval waits for nothing young).
       // Its flag word was requested an interval ago; the one of tile k + 2 is requested now and is DEFINED only behind the
       // lgkmcnt(0) after stage 1 ("+s" there: no use of it can be scheduled above that wait)
       if (k + 1 < nphase) dma_issue_all(tile_dma(k + 1, flag_next), sub, lane);
       if (k + 2 < nphase) scalar_load_u32_async(flag_next, qflags + k + 2);
-    }
-    unsigned own[2][16];  // own[gl][j]: packed {C_(2g), C_(2g+1)} of (query j / 4, k4 = j % 4), g = 2 HALF + gl
-    if (active) {
-      // ---------------- stage 1: this wave's frequencies, all 4 queries ----------------
-      const int hh = lane >> 5;
-      floatx16 acc[3];
-      floatx16 z;
+      lap(2);  // DMA issue
+      if (do_s1) {
+        stage1(k, own);
+        lap(3);  // stage 1 incl. the last packing
+        hand_over(k, own);
 #pragma unroll
-      for (int i = 0; i < 16; i++) z[i] = 0.0f;
-      frag4 ring[S2_DEPTH];
-      frag4 bx[NP > 0 ? NP : 1];
-      const unsigned a_dc = tile_lds + ln.dc_off, a_f = tile_lds + ln.f_off;
-      const unsigned a_dcw = a_dc - SP_DC_BYTES, a_fw = a_f - SP_VS;
-      auto a_read = [&](frag4 &dst, auto tc) {
-        constexpr int t = decltype(tc)::value;
-        if constexpr (H::f_of(t) == 0) lds_read_stream<H::s_of(t), SP_DC_BYTES / 16, 10>(dst, a_dc, a_dcw, ln.c_dc, H::a_off(t));
-        else lds_read_stream<H::s_of(t), SP_VS / 16, 16>(dst, a_f, a_fw, ln.c_f, H::a_off(t));
-      };
-      static_for<S2_DEPTH>([&](auto tc) { a_read(ring[decltype(tc)::value], tc); });
-      static_for<NP>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        lds_read_frag(bx[t], bpark, 1024 * t);
-      });
-      static_for<NF>([&](auto tc) {
-        constexpr int t = decltype(tc)::value;
-        constexpr int f = H::f_of(t), lf = f - 4 * HALF;
-        lds_wait_count<s2_wait_of(t, NF, NP)>();
-        __builtin_amdgcn_sched_barrier(0);
-        const half8 af = __builtin_bit_cast(half8, ring[t % S2_DEPTH]);
-        half8 bf;
-        if constexpr (t < NP) bf = __builtin_bit_cast(half8, bx[t]);
-        else bf = B[t];
-        if constexpr (H::s_of(t) == 0) acc[lf % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, z, 0, 0, 0);
-        else acc[lf % 3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[lf % 3], 0, 0, 0);
-        if constexpr (t + S2_DEPTH < NF) a_read(ring[t % S2_DEPTH], std::integral_constant<int, t + S2_DEPTH>{});
-        if constexpr (HALF == 0) {
-          // C_0 as fp16 hi + lo (see spec_tile): during f = 1, two j per slot
-          constexpr int sb = H::last_slot(0) + 2;
-          if constexpr (t >= sb && t < sb + 8) {
-#pragma unroll
-            for (int j = 2 * (t - sb); j < 2 * (t - sb) + 2; j++) {
-              const float v = acc[0][j];
-              const float hi = __uint_as_float(__float_as_uint(v) & 0xffffe000u);
-              float sp = hh ? v - hi : hi;
-              asm volatile("" : "+v"(sp));
-              acc[0][j] = sp;
-            }
-          }
-        }
-        // first pair (lf 0, 1) -> own[0][*], packed during lf 2 (two j per slot), before lf 3 re-uses acc[0]
-        {
-          constexpr int pb = H::last_slot(1) + 2;
-          static_assert(pb + 8 <= H::first_slot(3), "accumulators are re-used before they are packed");
-          if constexpr (t >= pb && t < pb + 8) {
-#pragma unroll
-            for (int j = 2 * (t - pb); j < 2 * (t - pb) + 2; j++) {
-              unsigned pk = pack2(acc[0][j], acc[1][j]);
-              asm volatile("" : "+v"(pk));
-              own[0][j] = pk;
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      });
-      // second pair (lf 2, 3) = acc[2], acc[0]
-#pragma unroll
-      for (int j = 0; j < 16; j++) own[1][j] = pack2(acc[2][j], acc[0][j]);
-    }
-    lap(0);  // stage 1 incl. the last packing
-    if (HALF == 1) {
-      // ---------------- producer: leave the packed half of tile k in LDS, feed the query stream ----------------
-      if (active) {
-        unsigned lw = (unsigned)lane;
-        asm volatile("" : "+v"(lw));
-        // the consumer has picked up the half of tile k - 1 (it did so right after ITS stage 1: no wait in practice)
-        const unsigned seq_at = lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 4);
-        while ((int)__builtin_amdgcn_readfirstlane(lds_read_b32_now(seq_at)) < k) __builtin_amdgcn_s_sleep(1);
-        const unsigned x_wr = lds_base + (unsigned)S2_X_OFF + (unsigned)(sub * S2_XPAIR) + lw * 4u;
-#pragma unroll
-        for (int j = 0; j < 16; j++) lds_write2st64(x_wr, own[0][j], own[1][j], 2 * j, 2 * j + 1);
+        for (int i = 0; i < 8; i++) held[0][i] = own[0][JB + i], held[1][i] = own[1][JB + i];
       }
-      lap(1);  // sequence check + exchange writes
-      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(flag_next)::"memory");
-      lap(2);  // wait for the exchange writes
-    } else if (active) {
-      // ---------------- consumer: stage 2 + bounds of tile k - 1, two queries at a time ----------------
-      // every lane-dependent address of the tail derives from an opaque copy of the lane id: left visible, the compiler
-      // hoists a dozen of them out of the tile loop and keeps them in registers across stage 1 (spilling B fragments)
-      unsigned lt = (unsigned)lane;
-      asm volatile("" : "+v"(lt));
-      const unsigned l16 = lt * 16u;
-      const int col = (int)(lt & 31u), hh = (int)(lt >> 5);
-      const unsigned a_tl = tile_lds + SP_TAIL;
-      const unsigned x_rd = lds_base + (unsigned)S2_X_OFF + (unsigned)(sub * S2_XPAIR) + lt * 4u;
-      const int qp = q0 + p * SP_QPP;
-      const int nq_here = (q1 - qp < SP_QPP) ? (q1 - qp) : SP_QPP;
-      frag4 wv, ec;
-      u2v rx[16];
-      static_for<16>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        lds_read2st64(rx[j], x_rd, 2 * j, 2 * j + 1);
-      });
-      lds_read_frag(wv, lds_base + (unsigned)S2_W_OFF + l16, 0);
-      lds_read_frag(ec, lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + l16, 0);
-      lds_wait_count<2>();  // the 16 exchange reads have returned (W and the entry constants are younger)
-      __builtin_amdgcn_sched_barrier(0);
-      // the producer's half of this tile is in registers: the exchange area may be overwritten
-      lds_write_b32(lds_base + (unsigned)S2_SEQ_OFF + (unsigned)(sub * 4), (unsigned)k);
-      lds_wait_count<0>();
-      __builtin_amdgcn_sched_barrier(0);
-      lap(1);  // exchange + constant reads
-      floatx16 z;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(flag_next)::"memory");
+    } else {
+      if (do_s1) {
+        stage1(k, own);
+        lap(0);  // stage 1 incl. the last packing
+        hand_over(k, own);
+        lap(1);  // sequence check + exchange writes
+      }
+      if (do_tail) tail(k - 1);
+      if (do_s1) {
 #pragma unroll
-      for (int i = 0; i < 16; i++) z[i] = 0.0f;
-      float outv[4];
-      static_for<2>([&](auto hc) {
-        constexpr int qh = decltype(hc)::value;  // queries 2 qh, 2 qh + 1
-        frag4 tw[2];  // {n_q, flags, sqrt n_q, sqrt a_q} of the two queries
-        lds_read_frag(tw[0], a_tl, (2 * qh) * SP_QS);
-        lds_read_frag(tw[1], a_tl, (2 * qh + 1) * SP_QS);
-        lds_wait_count<0>();
-        __builtin_amdgcn_sched_barrier(0);
-        const half8 W = __builtin_bit_cast(half8, wv);
-        const int n_e = __popc(ec[0]) + __popc(ec[1] & 0x0fffffffu);
-        const bool e_bad = (ec[1] & 0x80000000u) != 0;
-        const float sqrt_ne = __uint_as_float(ec[3]), sqrt_ae = __uint_as_float(ec[2]);
-        const float r_ne = __builtin_amdgcn_rcpf((float)(n_e > 1 ? n_e : 1));
-        auto bound_of = [&](float m_scaled, float rL, const Recip &r) {  // m_scaled = 15/16 max_k S_k u(n_k)
-          const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m_scaled), __float_as_uint(m_scaled), false, false);
-          const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-          const float err = kE1 * r.sqrt_nq * sqrt_ne + kE2 * r.sqrt_aq * sqrt_ae;
-          float v = (1.0f + a.eps_direct) - fmaf(best, (16.0f / 15.0f) * (1.0f + 4e-6f), err * rL);
-          if (r.n_q == 0 || n_e == 0) v = INFINITY;      // no effective column at any shift: never a hit
-          if (r.flags != 0u || e_bad) v = -INFINITY;     // non-finite input: always re-score exactly
-          return v;
-        };
-        const Recip ra = recip_header(tw[0]), rb = recip_header(tw[1]);
-        const bool both_full = __builtin_amdgcn_readfirstlane(ra.n_q) == NS && __builtin_amdgcn_readfirstlane(rb.n_q) == NS;
-        if (both_full) {
-          // The usual case (a radar scan has no empty sector): n_eff(k) = n_e at every shift, so a query is 4 stage-2 MFMAs and
-          // 16 v_max3.  The 8 MFMAs of the pair go through THREE result sets, each consumed two MFMAs after it was issued:
-          // left to the compiler (two sets, maxima right behind their MFMA) the wave idled ~12 wait states per MFMA
-          auto Pq = [&](int q, int k4) {
-            const int j = 4 * q + k4;
-            const u4 t = u4{own[0][j], own[1][j], rx[j][0], rx[j][1]};
-            return __builtin_bit_cast(half8, t);
-          };
-          auto max8 = [&](float m, const floatx16 &dd) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);  // one v_max3_f32 per pair
-            return m;
-          };
-          constexpr int qa = 2 * qh, qb = 2 * qh + 1;
-          float ma = 0.0f, mb = 0.0f;
-          floatx16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qa, 0), z, 0, 0, 0);
-          floatx16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qa, 1), z, 0, 0, 0);
-          floatx16 d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qa, 2), z, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          ma = max8(ma, d0);
-          d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qa, 3), z, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          ma = max8(ma, d1);
-          d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qb, 0), z, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          ma = max8(ma, d2);
-          d2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qb, 1), z, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          ma = max8(ma, d0);
-          d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qb, 2), z, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          mb = max8(mb, d1);
-          d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(qb, 3), z, 0, 0, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          outv[qa] = bound_of(ma * r_ne, r_ne, ra);   // n_lo = n_hi = n_e: 1 / n_lo within 1 ulp of r_ne, covered by the (1 + 4e-6)
-          mb = max8(mb, d2);
-          __builtin_amdgcn_sched_barrier(0);
-          mb = max8(mb, d0);
-          mb = max8(mb, d1);
-          outv[qb] = bound_of(mb * r_ne, r_ne, rb);
-        } else
-        static_for<2>([&](auto qc) {
-          constexpr int ql = decltype(qc)::value;
-          constexpr int q = 2 * qh + ql;
-          Recip r = recip_header(tw[ql]);
-          auto Pj = [&](int k4) {  // stage-2 B operand of (this query, k4): K = {g0, g1, g2, g3}
-            const int j = 4 * q + k4;
-            const u4 t = u4{own[0][j], own[1][j], rx[j][0], rx[j][1]};
-            return __builtin_bit_cast(half8, t);
-          };
-          const bool full_q = __builtin_amdgcn_readfirstlane(r.n_q) == NS;
-          float m = 0.0f;
-          if (full_q) {
-            auto max8 = [&](const floatx16 &dd) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) m = fmaxf(fmaxf(m, dd[2 * e]), dd[2 * e + 1]);
-            };
-            floatx16 d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(0), z, 0, 0, 0);
-            floatx16 d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(1), z, 0, 0, 0);
-            max8(d0);
-            d0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(2), z, 0, 0, 0);
-            max8(d1);
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(3), z, 0, 0, 0);
-            max8(d0);
-            max8(d1);
-            r.rL = r_ne;
-            m *= r.rL;
-          } else {
-            recip_coeffs(r, n_e);
-            // the entry's mask bytes (B operand of the mask correlation) and the query's mask rows come from LDS; one
-            // M-tile (k4 = 2 mt, 2 mt + 1) at a time: n_eff, u(n_eff), S u, maximum
-            // this lane's entry: column-mask bits 32 hh .. 32 hh + 31 (the K index of the lane half) as fp8 0.0 / 1.0 bytes
-            const unsigned bits = hh ? (ec[1] & 0x0fffffffu) : ec[0];
-            u8v bm;
-#pragma unroll
-            for (int rr = 0; rr < 8; rr++) bm[rr] = ((((bits >> (4 * rr)) & 0xfu) * 0x00204081u) & 0x01010101u) * 0x38u;
-#pragma unroll
-            for (int mt = 0; mt < 2; mt++) {
-              // n_eff rows: row = col <-> (k4 = 2 mt + col / 16, k15 = col % 16), the row order of the stage-2 output
-              const int k4 = 2 * mt + (col >> 4), k15 = (col & 15) == 15 ? 0 : (col & 15);
-              const int kk0 = (45 * k4 + 16 * k15) % NS;  // CRT
-              const unsigned a_m = tile_lds + (unsigned)(SP_MASKREG_OFF + (kk0 & 15) * SP_MASK_COPY + (kk0 & ~15) + hh * 32);
-              frag4 mk0, mk1;
-              lds_read_frag(mk0, a_m, q * SP_MASK_BYTES);
-              lds_read_frag(mk1, a_m, q * SP_MASK_BYTES + 16);
-              lds_wait_count<0>();
-              __builtin_amdgcn_sched_barrier(0);
-              const u8v am = {mk0[0], mk0[1], mk0[2], mk0[3], mk1[0], mk1[1], mk1[2], mk1[3]};
-              const floatx16 nacc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(__builtin_bit_cast(intx8, am), __builtin_bit_cast(intx8, bm), z, 0, 0, 0, 0, 0, 0);
-#pragma unroll
-              for (int kk = 0; kk < 2; kk++) {
-                float2v u2[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                  const float2v n2 = {nacc[kk * 8 + 2 * e], nacc[kk * 8 + 2 * e + 1]};
-                  const float2v t2 = __builtin_elementwise_fma(n2, r.C2, r.B2);
-                  u2[e] = __builtin_elementwise_fma(n2, t2, r.A2);
-                }
-                const floatx16 dd = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pj(2 * mt + kk), z, 0, 0, 0);
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                  const float2v s2 = {dd[2 * e], dd[2 * e + 1]};
-                  const float2v v2 = s2 * u2[e];
-                  m = fmaxf(fmaxf(m, v2[0]), v2[1]);
-                }
-              }
-            }
-          }
-          outv[q] = bound_of(m, r.rL, r);
-        });
-        // lanes 0..31 store query 2 qh, lanes 32..63 query 2 qh + 1: one store per query pair
-        {
-          const int64_t n = tile * 32 + col;
-          const int qq = 2 * qh + hh;
-          const float vv = hh ? outv[2 * qh + 1] : outv[2 * qh];
-          if (n < a.n_items && qq < nq_here) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = vv;
-        }
-      });
-      lap(2);  // stage 2 + bounds + stores
+        for (int i = 0; i < 8; i++) held[0][i] = own[0][JB + i], held[1][i] = own[1][JB + i];
+      }
+      // this wave issues no DMA; its stores stay in flight (nothing waits for them before the end of the segment)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
-    // the producer's pieces of tile k + 1 have landed and its packed half of tile k is written; the consumer's stores
-    // stay in flight (nothing waits for them before the end of the segment)
-    if (HALF == 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    lap(3);  // wait for the DMA / the writes
+    lap(4);  // exchange writes / end-of-interval wait
     __builtin_amdgcn_s_barrier();
-    lap(4);  // barrier
   }
   if (kInstr && prof) {
     unsigned long long r_end;
@@ -1651,11 +1667,14 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
       RSX_HIP(hipMemcpy(h, d_prof2, sizeof(h), hipMemcpyDeviceToHost));
       for (int hf = 0; hf < 2; hf++) {
         const double n = h[hf * 8 + 5] ? (double)h[hf * 8 + 5] : 1.0;
-        fprintf(stderr, "[sc_spec2 prof] %s, %llu tiles of the last segment of workgroup 0: cycles per tile  stage1 %.0f  %s %.0f  %s %.0f"
-                        "  wait %.0f  barrier %.0f | %.0f cycles per tile at %.0f MHz\n",
-                hf ? "producer" : "consumer", h[hf * 8 + 5], h[hf * 8] / n, hf ? "seq+exchange writes" : "const+exchange reads", h[hf * 8 + 1] / n,
-                hf ? "wait for the writes" : "stage2+bounds+stores", h[hf * 8 + 2] / n, h[hf * 8 + 3] / n, h[hf * 8 + 4] / n,
-                h[hf * 8 + 6] / n, h[hf * 8 + 7] ? 100.0 * h[hf * 8 + 6] / h[hf * 8 + 7] : 0.0);
+        if (hf == 0)
+          fprintf(stderr, "[sc_spec2 prof] late wave, %llu tiles of the last segment of workgroup 0: cycles per tile  stage1 %.0f  seq+exchange writes %.0f"
+                          "  exchange+const reads %.0f  stage2+bounds+store %.0f  wait %.0f | %.0f cycles per tile at %.0f MHz\n",
+                  h[5], h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n, h[6] / n, h[7] ? 100.0 * h[6] / h[7] : 0.0);
+        else
+          fprintf(stderr, "[sc_spec2 prof] early wave, %llu tiles: cycles per tile  exchange+const reads %.0f  stage2+bounds+store %.0f  dma issue %.0f"
+                          "  stage1 %.0f  seq+exchange writes+wait %.0f | %.0f cycles per tile at %.0f MHz\n",
+                  h[13], h[8] / n, h[9] / n, h[10] / n, h[11] / n, h[12] / n, h[14] / n, h[15] ? 100.0 * h[14] / h[15] : 0.0);
       }
     }
     return RSX_OK;
