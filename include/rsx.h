@@ -90,7 +90,7 @@ typedef struct {
    * the entries that can still reach the top-k are scored by the exact fp64 kernel), 1 = always
    * score every entry exactly, 2 = always filter.  Results are identical in every mode. */
   int32_t filter_mode;
-  /* which form of the filter: 0 = default (spectral), 1 = direct (60-shift correlation as one K = 1200
+  /* which form of the filter: 0 = default (3: spectral, two waves per SIMD), 1 = direct (60-shift correlation as one K = 1200
    * MFMA GEMM per shift), 2 = spectral (Z15 DFT + direct Z4 correlation, ~6x fewer MFMAs), 3 = the spectral form
    * with two waves per SIMD (the entry tile split by frequency over a wave pair; same bounds bit for bit).  All give
    * valid lower bounds of the same quantity; results are identical. */

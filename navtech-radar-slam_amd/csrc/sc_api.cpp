@@ -204,8 +204,9 @@ struct ProfScope {
   }
 };
 
-// 2 = the spectral form with two waves per SIMD (sc_spec2_filter_kernel: same images, same bounds)
-constexpr int kDefaultFilterKind = 1;
+// 2 = the spectral form with two waves per SIMD (sc_spec2_filter_kernel: same images, same bounds bit for bit; the default
+// since round 4: 1.76 against 2.05 ms per 8192 x 9970 launch on the same box)
+constexpr int kDefaultFilterKind = 2;
 // which form of the lower-bound filter: 0 = direct (sc_filter.hip), 1 = spectral (sc_spec.hip, the default:
 // same bounds up to a slightly larger error budget, ~6x fewer MFMAs).  rsx_sc_params.filter_kind or
 // RSX_SC_FILTER_KIND=direct|spectral override.

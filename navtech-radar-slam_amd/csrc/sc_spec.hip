@@ -1032,14 +1032,18 @@ struct S2Half {
 // LDS reads of stage 1 in issue order: A fragments 0 .. DEPTH-1, parked B fragments 0 .. NP-1, then after the MFMA of slot t
 // the A fragment of slot t + DEPTH.  LDS returns in issue order, so slot t may start once at most
 // (reads issued so far) - 1 - (position of the later of its two reads) are outstanding.
-constexpr int s2_wait_of(int t, int nf, int np) {
+// s2_wait_of(now, t, ...): the count to wait for at the top of slot `now` so that the reads of slot t >= now have returned.
+// One s_waitcnt serves TWO slots (the even one waits for its own and the next slot's fragments: the next one was issued
+// S2_DEPTH - 1 slots ago, long enough)
+constexpr int s2_wait_of(int now, int t, int nf, int np) {
   const int pos_a = t < S2_DEPTH ? t : S2_DEPTH + np + (t - S2_DEPTH);
   const int pos_b = t < np ? S2_DEPTH + t : -1;
   int issued = S2_DEPTH + np;            // prologue
-  for (int u = 0; u < t; u++) issued += (u + S2_DEPTH < nf) ? 1 : 0;
+  for (int u = 0; u < now; u++) issued += (u + S2_DEPTH < nf) ? 1 : 0;
   const int last = pos_a > pos_b ? pos_a : pos_b;
   return issued - 1 - last;
 }
+static_assert(S2_DEPTH >= 3, "a slot's fragment is requested at least two slots before the wait that covers it");
 
 // per-lane A-fragment addressing of stage 1 (the only lane state that lives in registers across a tile)
 struct S2Lane {
@@ -1216,7 +1220,7 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
     static_for<NF>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       constexpr int f = H::f_of(t), lf = f - 4 * HALF;
-      lds_wait_count<s2_wait_of(t, NF, NP)>();
+      if constexpr (t % 2 == 0) lds_wait_count<s2_wait_of(t, t + 1 < NF ? t + 1 : t, NF, NP)>();
       __builtin_amdgcn_sched_barrier(0);
       const half8 af = __builtin_bit_cast(half8, ring[t % S2_DEPTH]);
       half8 bf;
@@ -1264,7 +1268,8 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
     unsigned lw = (unsigned)lane;
     asm volatile("" : "+v"(lw));
     // my partner has picked up what I left for tile p - 1 (it reads long before I write: no wait in practice)
-    while ((int)__builtin_amdgcn_readfirstlane(lds_read_b32_now(seq_mine)) < p) __builtin_amdgcn_s_sleep(1);
+    if (!(kInstr && (a.dbg & 12)))   // (timing experiments that idle one wave of the pair: nobody bumps the sequence numbers)
+      while ((int)__builtin_amdgcn_readfirstlane(lds_read_b32_now(seq_mine)) < p) __builtin_amdgcn_s_sleep(1);
     const unsigned x_wr = x_pair + (unsigned)(HALF == 1 ? 0 : S2_XPAIR / 2) + lw * 4u;
 #pragma unroll
     for (int jl = 0; jl < 8; jl++) lds_write2st64(x_wr, own[0][JO + jl], own[1][JO + jl], 2 * jl, 2 * jl + 1);
@@ -1293,11 +1298,9 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
     lds_read_frag(ec, lds_base + (unsigned)S2_EC_OFF + (unsigned)(sub * 1024) + l16, 0);
     lds_read_frag(tw[0], a_tl, QB * SP_QS);         // {n_q, flags, sqrt n_q, sqrt a_q} of the two queries
     lds_read_frag(tw[1], a_tl, (QB + 1) * SP_QS);
-    lds_wait_count<4>();  // the 8 exchange reads have returned
-    __builtin_amdgcn_sched_barrier(0);
-    lds_write_b32(seq_theirs, (unsigned)(p + 1));  // my partner's half of tile p is in registers: it may overwrite the area
     lds_wait_count<0>();
     __builtin_amdgcn_sched_barrier(0);
+    lds_write_b32(seq_theirs, (unsigned)(p + 1));  // my partner's half of tile p is in registers: it may overwrite the area
     lap(HALF == 1 ? 0 : 2);  // exchange + constant reads
     floatx16 z;
 #pragma unroll
@@ -1431,7 +1434,10 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
   // interval k: stage 1 of query tile k, tails of tile k - 1
   for (int k = 0; k <= nphase; k++) {
     if (kInstr && prof) pt = prof_now();
-    const bool do_s1 = tile_ok && k < nphase, do_tail = tile_ok && k >= 1;
+    // RSX_SPEC_DBG bits 4 / 8 of instrumented builds idle the early / the late wave (barriers and DMA only): what each wave
+    // costs when it has the SIMD to itself (results are wrong, only the timing means something)
+    const bool idle = kInstr && (a.dbg & (HALF == 1 ? 4 : 8));
+    const bool do_s1 = tile_ok && k < nphase && !idle, do_tail = tile_ok && k >= 1 && !idle;
     unsigned own[2][16];  // own[gl][j]: packed {C_(2g), C_(2g+1)} of (query j / 4, k4 = j % 4), g = 2 HALF + gl
     if (HALF == 1) {
       if (do_tail) tail(k - 1);

@@ -190,7 +190,11 @@ def test_default_kind_is_spectral(sc, rsx, synth):
     g = sc.SCManager(filter_mode=rsx.FILTER_FORCE)
     g.add_descriptors_f32(holes)
     g.query(holes[:16], k=3)
-    assert g.profiled_kernel_name() == "sc_spec_filter_kernel"
+    assert g.profiled_kernel_name() == "sc_spec2_filter_kernel"      # the spectral form, two waves per SIMD
+    g1 = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_SPECTRAL)
+    g1.add_descriptors_f32(holes)
+    g1.query(holes[:16], k=3)
+    assert g1.profiled_kernel_name() == "sc_spec_filter_kernel"
     g2 = sc.SCManager(filter_mode=rsx.FILTER_FORCE, filter_kind=rsx.KIND_DIRECT)
     g2.add_descriptors_f32(holes)
     g2.query(holes[:16], k=3)

@@ -9,7 +9,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --only-main"
 # PMC passes: only the query-path kernels (the 18k build-path dispatches of the data set-up would each be serialised)
-KR="--kernel-include-regex sc_spec_filter_kernel|sc_filter_kernel|sc_rescore_kernel|sc_rescore_wave_kernel|sc_window_kernel|sc_select_kernel|sc_spec_query_kernel|sc_keys_kernel|sc_merge_kernel"
+KR="--kernel-include-regex sc_spec2_filter_kernel|sc_spec_filter_kernel|sc_filter_kernel|sc_rescore_kernel|sc_rescore_wave_kernel|sc_window_kernel|sc_select_kernel|sc_spec_query_kernel|sc_keys_kernel|sc_merge_kernel"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace -- $BENCH > $OUT/bench_trace.log 2>&1
 timeout 300 rocprofv3 $KR --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace -d $OUT/pmc1 -o pmc1 -- $BENCH > $OUT/bench_pmc1.log 2>&1
 timeout 300 rocprofv3 $KR --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_INSTS_SMEM --kernel-trace -d $OUT/pmc2 -o pmc2 -- $BENCH > $OUT/bench_pmc2.log 2>&1
