@@ -678,6 +678,47 @@ def icp_leg(device):
                     "(uploads both clouds, one 16-byte read-back per iteration)" % (len(src) * len(tgt))}
 
 
+def loop_verify_leg(device):
+    """SURVEY 8(f) rank 2 as the survey wrote it: doICPVirtualRelative (PGO.cpp:355-406) on keyframe clouds resident in HBM --
+    submap assembly around the loop keyframe (+-25 keyframes through the root pose, PGO.cpp:329-352), VoxelGrid 0.4 m of both
+    clouds, ICP, the fitness gate -- everything inside the time, one call per loop candidate.  A street driven twice
+    (the second pass closes the loops); the verdict of the first candidate is compared with the oracle chain."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_loopverify import street_drive
+    from navtech_radar_slam_amd import loopverify
+    from oracle import pyoracle as po
+    clouds, pose6 = street_drive(seed=3, n=120, step=2.0, revisit_at=70)
+    kf = loopverify.KeyframeStore(device=device)
+    t0 = time.perf_counter()
+    for c in clouds:
+        kf.add(c)
+    t_add = (time.perf_counter() - t0) / len(clouds)
+    pairs = [(i, 70 + i) for i in range(5, 45, 2)]            # the second pass over keyframes 5..43
+    res = kf.verify(*pairs[0], pose6[pairs[0][0]])
+    t0 = time.perf_counter()
+    acc = 0
+    its = 0
+    for lo, cu in pairs:
+        r = kf.verify(lo, cu, pose6[lo])
+        acc += int(r["accepted"])
+        its += r["iterations"]
+    dt = (time.perf_counter() - t0) / len(pairs)
+    want = po.loop_verify(clouds, pairs[0][0], pairs[0][1], pose6[pairs[0][0]])
+    t0 = time.perf_counter()
+    m = kf.build_map(pose6, skip=2, leaf=0.4)
+    t_map = time.perf_counter() - t0
+    kf.close()
+    return {"ms_per_verification": dt * 1e3, "verifications": len(pairs), "accepted": acc, "mean_icp_iterations": its / len(pairs),
+            "source_points_after_voxelgrid": int(res["n_source"]), "target_points_after_voxelgrid": int(res["n_target"]),
+            "keyframe_points": int(np.mean([len(c) for c in clouds])), "ms_per_keyframe_add": t_add * 1e3,
+            "first_verdict_equals_oracle": bool(res["accepted"] == want["accepted"] and res["n_source"] == want["n_source"] and
+                                                res["n_target"] == want["n_target"] and abs(res["fitness"] - want["fitness"]) < 1e-2 * max(1.0, want["fitness"])),
+            "map": {"points": int(len(m)), "keyframes": len(clouds), "ms": t_map * 1e3},
+            "dtype": "f32 (fp64 moment sums)",
+            "note": "rsx_loop_verify: keyframe clouds in HBM; per candidate: 2 transform kernels + 2 VoxelGrid chains + ICP "
+                    "(brute-force nearest neighbour) + gate; nothing but counts and the convergence flag returns to the host"}
+
+
 def layout_emulation_leg(device, db_descs, q_descs, n_elig, k):
     """What ONE rank computes between the collectives in every layout of 2 / 4 / 8 GPUs, emulated on this one GPU: a handle
     holding shard 0 of S (the DB descriptors handed over, the handle keeps its residue class) and the first nq / Q queries;
@@ -1048,6 +1089,7 @@ def main():
             out["orora"] = orora_leg(ctx.local_rank, args.no_cpu_baseline)
             out["cen2019"] = cen2019_leg(ctx.local_rank)
             out["icp"] = icp_leg(ctx.local_rank)
+            out["loop_verify"] = loop_verify_leg(ctx.local_rank)
             out["frontend"] = frontend_leg(ctx.local_rank)
             out["odometry_e2e"] = odometry_e2e_leg(ctx.local_rank, args.no_cpu_baseline)
             oe = out["odometry_e2e"]

@@ -544,6 +544,69 @@ int rsx_icp_destroy(rsx_icp *h);
 int rsx_icp_align(rsx_icp *h, const void *src, size_t ns, size_t src_stride, const void *tgt, size_t nt, size_t tgt_stride,
                   const rsx_icp_params *params, const float *guess, rsx_icp_result *out);
 
+/* ============================ keyframe clouds: loop verification and the map ==========================
+ * What the pose-graph node does with the keyframe clouds it keeps (keyframeLaserClouds = the 0.4 m VoxelGrid output of
+ * every keyframe, PGO.cpp:482-487), resident in HBM:
+ *   rsx_loop_verify       = doICPVirtualRelative(loop, curr) (PGO.cpp:355-406): source = loopFindNearKeyframesCloud(curr, 0,
+ *                           root = loop), target = loopFindNearKeyframesCloud(loop, 25, root = loop) -- keyframes
+ *                           key - size .. key + size, EACH IN ITS OWN LOCAL FRAME, all moved by the one pose of the root
+ *                           keyframe, concatenated, VoxelGrid 0.4 m (PGO.cpp:329-352) -- then ICP, the gate
+ *                           `converged && fitness <= 0.3` (PGO.cpp:385), pcl::getTranslationAndEulerAngles and
+ *                           poseFrom.between(poseTo) (PGO.cpp:400-407)
+ *   rsx_kfstore_build_map = the cloud pubMap publishes (PGO.cpp:631-655): every SKIP_FRAMES-th keyframe through its own
+ *                           pose, concatenated, VoxelGrid (host/pcd.h writes it to a .pcd file: the "resulting map save
+ *                           function" of the reference's TODO list, README.md:139)
+ * Poses are the reference's Pose6D: double x, y, z, roll, pitch, yaw (PGO.cpp:199-206).  PCL and GTSAM are not part of
+ * the reference checkout; their pieces follow the published sources (oracle/loopverify_ref.c) -- parity unpinned; the
+ * control flow is the reference's own.  Thread safety: one handle = one lock (the reference guards the same data with
+ * mKF, PGO.cpp:339-341,486-495). */
+typedef struct rsx_kfstore rsx_kfstore;
+
+typedef struct {
+  int32_t history_keyframe_search_num; /* 25: the target submap is loop - 25 .. loop + 25 (PGO.cpp:358) */
+  float leaf;                          /* 0.4: downSizeFilterICP (PGO.cpp:687-689) */
+  double fitness_threshold;            /* 0.3: loopFitnessScoreThreshold (PGO.cpp:384) */
+  rsx_icp_params icp;                  /* PGO.cpp:374-378 */
+} rsx_loop_verify_params;
+
+typedef struct {
+  int32_t accepted;    /* !(hasConverged() == false || getFitnessScore() > threshold)  (PGO.cpp:385) */
+  int32_t converged, iterations, state; /* as rsx_icp_result */
+  double fitness;
+  float transform[16]; /* icp.getFinalTransformation(), row-major 4x4 */
+  float x, y, z, roll, pitch, yaw; /* pcl::getTranslationAndEulerAngles of it (PGO.cpp:400-403) */
+  double relative[16]; /* poseFrom.between(poseTo) with poseTo = identity (PGO.cpp:404-407), row-major 4x4: the loop factor */
+  int64_t n_source, n_target; /* points of the two clouds after the VoxelGrid */
+} rsx_loop_verify_result;
+
+int rsx_kfstore_create(int device, rsx_kfstore **out);
+int rsx_kfstore_destroy(rsx_kfstore *h);
+/* keyframeLaserClouds.push_back(cloud) (PGO.cpp:487): n points stride_bytes apart, float x, y, z at byte offsets 0, 4, 8,
+ * float intensity at intensity_offset (16 for pcl::PointXYZI; < 0: none, stored as 0).  The cloud is copied; *out_index =
+ * its keyframe index.  _device: n packed float4 {x, y, z, intensity} already in this device's memory. */
+int rsx_kfstore_add(rsx_kfstore *h, const void *pts, size_t n, size_t stride_bytes, int32_t intensity_offset, int32_t *out_index);
+int rsx_kfstore_add_device(rsx_kfstore *h, const void *d_xyzi, size_t n, int32_t *out_index);
+int rsx_kfstore_size(rsx_kfstore *h, int64_t *n_keyframes, int64_t *n_points);
+/* keyframe `index` as packed float4; *out_count = its size (only the first max_out points are written) */
+int rsx_kfstore_get(rsx_kfstore *h, int32_t index, float *out_xyzi, int64_t max_out, int64_t *out_count);
+int rsx_loop_verify_default_params(rsx_loop_verify_params *p);
+/* loopFindNearKeyframesCloud(out, key, submap_size, root) with root_pose6 = keyframePosesUpdated[root] (PGO.cpp:329-352) */
+int rsx_loop_submap(rsx_kfstore *h, int32_t key, int32_t submap_size, const double *root_pose6, float leaf, float *out_xyzi,
+                    int64_t max_out, int64_t *out_count);
+/* doICPVirtualRelative(loop_idx, curr_idx) with root_pose6 = keyframePosesUpdated[loop_idx] (PGO.cpp:355-406);
+ * params NULL = the reference's constants */
+int rsx_loop_verify(rsx_kfstore *h, int32_t loop_idx, int32_t curr_idx, const double *root_pose6, const rsx_loop_verify_params *params,
+                    rsx_loop_verify_result *out);
+/* pubMap's cloud (PGO.cpp:631-655): keyframes 0, skip, 2 skip, ... < min(n_poses, stored), each through poses6[6 k .. 6 k + 5],
+ * VoxelGrid `leaf`; *out_count = its size (only the first max_out points are written) */
+int rsx_kfstore_build_map(rsx_kfstore *h, const double *poses6, int64_t n_poses, int32_t skip_frames, float leaf, float *out_xyzi,
+                          int64_t max_out, int64_t *out_count);
+/* downSizeFilterScancontext.filter + keyframeLaserClouds.push_back + scManager.makeAndSaveScancontextAndKeys in one call
+ * (PGO.cpp:482-492): the downsampled cloud goes from the VoxelGrid into the keyframe store and the descriptor build
+ * without leaving the GPU.  intensity_offset as above.  All three handles on the same device. */
+int rsx_sc_add_keyframe(rsx_sc *h, rsx_voxelgrid *vg, rsx_kfstore *kf, const void *pts, size_t n, size_t stride_bytes,
+                        int32_t intensity_offset, float leaf, int32_t *out_index);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,17 @@ class IcpResult(C.Structure):
                 ("converged", C.c_int32), ("state", C.c_int32), ("reserved", C.c_int32)]
 
 
+class LoopVerifyParams(C.Structure):
+    _fields_ = [("history_keyframe_search_num", C.c_int32), ("leaf", C.c_float), ("fitness_threshold", C.c_double), ("icp", IcpParams)]
+
+
+class LoopVerifyResult(C.Structure):
+    _fields_ = [("accepted", C.c_int32), ("converged", C.c_int32), ("iterations", C.c_int32), ("state", C.c_int32),
+                ("fitness", C.c_double), ("transform", C.c_float * 16),
+                ("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("roll", C.c_float), ("pitch", C.c_float), ("yaw", C.c_float),
+                ("relative", C.c_double * 16), ("n_source", C.c_int64), ("n_target", C.c_int64)]
+
+
 class FrontendParams(C.Structure):
     _fields_ = [("cart_pixel_width", C.c_int32), ("cart_resolution", C.c_float), ("ratio", C.c_float), ("flags", C.c_int32)]
 
@@ -121,6 +132,8 @@ SYMBOLS = [
     "rsx_odometry_push", "rsx_odometry_push_device", "rsx_host_alloc_pinned", "rsx_host_free_pinned",
     "rsx_voxelgrid_create", "rsx_voxelgrid_destroy", "rsx_voxelgrid_filter", "rsx_sc_add_points_downsampled",
     "rsx_icp_default_params", "rsx_icp_create", "rsx_icp_destroy", "rsx_icp_align",
+    "rsx_kfstore_create", "rsx_kfstore_destroy", "rsx_kfstore_add", "rsx_kfstore_add_device", "rsx_kfstore_size", "rsx_kfstore_get",
+    "rsx_loop_verify_default_params", "rsx_loop_submap", "rsx_loop_verify", "rsx_kfstore_build_map", "rsx_sc_add_keyframe",
 ]
 
 
@@ -241,6 +254,17 @@ def lib():
         L.rsx_icp_destroy.argtypes = [vp]
         L.rsx_icp_align.argtypes = [vp, vp, C.c_size_t, C.c_size_t, vp, C.c_size_t, C.c_size_t, C.POINTER(IcpParams), vp,
                                     C.POINTER(IcpResult)]
+        L.rsx_kfstore_create.argtypes = [i32, C.POINTER(vp)]
+        L.rsx_kfstore_destroy.argtypes = [vp]
+        L.rsx_kfstore_add.argtypes = [vp, vp, C.c_size_t, C.c_size_t, i32, C.POINTER(i32)]
+        L.rsx_kfstore_add_device.argtypes = [vp, vp, C.c_size_t, C.POINTER(i32)]
+        L.rsx_kfstore_size.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
+        L.rsx_kfstore_get.argtypes = [vp, i32, vp, i64, C.POINTER(i64)]
+        L.rsx_loop_verify_default_params.argtypes = [C.POINTER(LoopVerifyParams)]
+        L.rsx_loop_submap.argtypes = [vp, i32, i32, vp, C.c_float, vp, i64, C.POINTER(i64)]
+        L.rsx_loop_verify.argtypes = [vp, i32, i32, vp, C.POINTER(LoopVerifyParams), C.POINTER(LoopVerifyResult)]
+        L.rsx_kfstore_build_map.argtypes = [vp, vp, i64, i32, C.c_float, vp, i64, C.POINTER(i64)]
+        L.rsx_sc_add_keyframe.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_size_t, i32, C.c_float, C.POINTER(i32)]
         _lib = L
     return _lib
 

@@ -28,6 +28,7 @@
 #include <mutex>
 #include <new>
 
+#include "icp.h"
 #include "rsx_common.h"
 
 namespace {
@@ -414,27 +415,46 @@ int rsx_icp_align(rsx_icp *h, const void *src, size_t ns, size_t src_stride, con
   if (!h || !out || (!src && ns) || (!tgt && nt)) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (src_stride < 12 || (src_stride & 3) || tgt_stride < 12 || (tgt_stride & 3)) return fail(RSX_ERR_BAD_ARG, "strides must be >= 12 and multiples of 4");
   if (nt > 0xfffffffeull || ns > 0x7fffffffull) return fail(RSX_ERR_RANGE, "cloud too large");
-  rsx_icp_params p;
-  rsx_icp_default_params(&p);
-  if (params) p = *params;
-  if (p.max_iterations < 1 || !(p.max_corr_dist > 0)) return fail(RSX_ERR_BAD_ARG, "bad ICP params");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
   RSX_TRY(h->src.reserve(ns * src_stride + 16, s, false));
   RSX_TRY(h->tgt.reserve(nt * tgt_stride + 16, s, false));
+  if (ns) RSX_HIP(hipMemcpyAsync(h->src.p, src, ns * src_stride, hipMemcpyHostToDevice, s));
+  if (nt) RSX_HIP(hipMemcpyAsync(h->tgt.p, tgt, nt * tgt_stride, hipMemcpyHostToDevice, s));
+  return rsx::icp::align_device_locked(h, h->src.p, (int64_t)ns, (int64_t)src_stride, h->tgt.p, (int64_t)nt, (int64_t)tgt_stride, params, guess, out);
+}
+
+}  // extern "C"
+
+namespace rsx {
+namespace icp {
+
+std::mutex &mutex_of(rsx_icp *h) { return h->mu; }
+hipStream_t stream_of(rsx_icp *h) { return h->stream; }
+int device_of(rsx_icp *h) { return h->device; }
+
+// the alignment proper on clouds resident in device memory (the caller holds h->mu; whatever produced the clouds has
+// completed or runs on h's stream)
+int align_device_locked(rsx_icp *h, const void *d_src, int64_t n_s, int64_t src_stride, const void *d_tgt, int64_t n_t, int64_t tgt_stride,
+                        const rsx_icp_params *params, const float *guess, rsx_icp_result *out) {
+  rsx_icp_params p;
+  rsx_icp_default_params(&p);
+  if (params) p = *params;
+  if (p.max_iterations < 1 || !(p.max_corr_dist > 0)) return fail(RSX_ERR_BAD_ARG, "bad ICP params");
+  if (n_t > 0xfffffffell || n_s > 0x7fffffffll) return fail(RSX_ERR_RANGE, "cloud too large");
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = h->stream;
+  const size_t ns = (size_t)n_s;
   RSX_TRY(h->cur.reserve(ns * 12 + 16, s, false));
   RSX_TRY(h->best.reserve(ns * 8 + 16, s, false));
   RSX_TRY(h->state.reserve(sizeof(IcpState), s, false));
   RSX_TRY(h->guess.reserve(64, s, false));
-  if (ns) RSX_HIP(hipMemcpyAsync(h->src.p, src, ns * src_stride, hipMemcpyHostToDevice, s));
-  if (nt) RSX_HIP(hipMemcpyAsync(h->tgt.p, tgt, nt * tgt_stride, hipMemcpyHostToDevice, s));
   if (guess) RSX_HIP(hipMemcpyAsync(h->guess.p, guess, 64, hipMemcpyHostToDevice, s));
   IcpState *S = h->state.as<IcpState>();
   float *cur = h->cur.as<float>();
   unsigned long long *best = h->best.as<unsigned long long>();
-  const char *dsrc = static_cast<const char *>(h->src.p), *dtgt = static_cast<const char *>(h->tgt.p);
-  const int64_t n_s = (int64_t)ns, n_t = (int64_t)nt;
+  const char *dsrc = static_cast<const char *>(d_src), *dtgt = static_cast<const char *>(d_tgt);
   const unsigned nb = (unsigned)((n_s + 255) / 256 > 0 ? (n_s + 255) / 256 : 1);
   const unsigned nslices = (unsigned)((n_t + (int64_t)NN_SLICE_TILES * NN_TILE - 1) / ((int64_t)NN_SLICE_TILES * NN_TILE));
   const float max_d2 = (float)(p.max_corr_dist * p.max_corr_dist);
@@ -483,4 +503,5 @@ int rsx_icp_align(rsx_icp *h, const void *src, size_t ns, size_t src_stride, con
   return RSX_OK;
 }
 
-}  // extern "C"
+}  // namespace icp
+}  // namespace rsx

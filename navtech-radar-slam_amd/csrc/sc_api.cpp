@@ -13,6 +13,7 @@
 #include "rsx_common.h"
 #include "sc_kernels.h"
 #include "sc_kdtree.h"
+#include "loopverify.h"
 #include "voxelgrid.h"
 
 namespace rsx {
@@ -727,6 +728,42 @@ int rsx_sc_add_points_downsampled(rsx_sc *h, rsx_voxelgrid *vg, const void *pts,
                          h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
                          h->rkey.as<float>() + slot * NR, h->stream));
     RSX_TRY(build_db_images(h, slot, 1, h->stream));
+    h->n_local = slot + 1;
+  }
+  h->n_global = g + 1;
+  if (out_index) *out_index = (int32_t)g;
+  return RSX_OK;
+}
+
+int rsx_sc_add_keyframe(rsx_sc *h, rsx_voxelgrid *vg, rsx_kfstore *kf, const void *pts, size_t n, size_t stride_bytes,
+                        int32_t intensity_offset, float leaf, int32_t *out_index) {
+  if (!h || !vg || !kf || (!pts && n)) return fail(RSX_ERR_BAD_ARG, "null arg");
+  if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
+  if (intensity_offset >= 0 && ((intensity_offset & 3) || (size_t)intensity_offset + 4 > stride_bytes))
+    return fail(RSX_ERR_BAD_ARG, "intensity_offset outside the point");
+  if (!(leaf > 0.0f)) return fail(RSX_ERR_BAD_ARG, "leaf must be positive");
+  if (rsx::vg::device_of(vg) != h->p.device || rsx::kf::device_of(kf) != h->p.device)
+    return fail(RSX_ERR_BAD_ARG, "voxel grid, keyframe store and ScanContext handles are on different devices");
+  std::lock_guard<std::mutex> lk(h->mu);
+  std::lock_guard<std::mutex> lkv(rsx::vg::mutex_of(vg));
+  std::lock_guard<std::mutex> lkk(rsx::kf::mutex_of(kf));
+  RSX_TRY(set_device(h));
+  const int64_t g = h->n_global;
+  // downSizeFilterScancontext.filter(*thisKeyFrameDS) (PGO.cpp:482-484): every shard keeps the keyframe cloud (the loop
+  // verification runs where the pose graph lives), only the owning shard builds the descriptor
+  const float *d_ds = nullptr;
+  int64_t nds = 0;
+  RSX_TRY(rsx::vg::upload_and_filter(vg, pts, (int64_t)n, (int64_t)stride_bytes, intensity_offset, leaf, (int64_t)(n ? n : 1), &d_ds, &nds));
+  int32_t kf_index = -1;
+  RSX_TRY(rsx::kf::append_device_locked(kf, d_ds, nds, &kf_index));  // keyframeLaserClouds.push_back (PGO.cpp:487)
+  if (owns(h, g)) {
+    const int64_t slot = h->n_local;
+    RSX_TRY(ensure_capacity(h, slot + 1));
+    RSX_TRY(launch_build(d_ds ? static_cast<const void *>(d_ds) : h->desc.p, nds, 16, h->p.lidar_height, h->p.max_radius,
+                         h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
+                         h->rkey.as<float>() + slot * NR, h->stream));  // makeAndSaveScancontextAndKeys (PGO.cpp:492)
+    RSX_TRY(build_db_images(h, slot, 1, h->stream));
+    RSX_HIP(hipStreamSynchronize(h->stream));  // d_ds belongs to vg: it must not be overwritten by vg's next call before the build has read it
     h->n_local = slot + 1;
   }
   h->n_global = g + 1;

@@ -14,6 +14,9 @@ namespace vg {
 // (valid until its next call), *n_out = number of output points.  Synchronises the handle's stream.
 int upload_and_filter(rsx_voxelgrid *h, const void *pts, int64_t n, int64_t stride, int32_t ioff, float leaf, int64_t max_out,
                       const float **d_out, int64_t *n_out);
+// the same on points resident in device memory (complete, or produced on stream s); the caller holds the handle's mutex
+int filter_device(rsx_voxelgrid *h, const void *d_pts, int64_t n, int64_t stride, int32_t ioff, float leaf, int64_t max_out,
+                  const float **d_out, int64_t *n_out, hipStream_t s);
 std::mutex &mutex_of(rsx_voxelgrid *h);
 hipStream_t stream_of(rsx_voxelgrid *h);
 int device_of(rsx_voxelgrid *h);

@@ -5,16 +5,25 @@
 // getOdom, keyframe selection by accumulated translation (keyframe_meter_gap), VoxelGrid(0.4 m) downsample +
 // makeAndSaveScancontextAndKeys -- on the MI355X through the SCManager shim -- and, per keyframe, what
 // performSCLoopClosure does (PGO.cpp:556-571): detectLoopClosureID and the "Loop detected!" line.
-// The pose graph itself (GTSAM / ICP) is out of scope; this is the ScanContext side of the node, replayable offline.
+// --verify-loops adds what process_icp does with every detected pair (PGO.cpp:589-612): doICPVirtualRelative -- submap
+// assembly around the loop keyframe, VoxelGrid, ICP, the fitness gate -- on the keyframe clouds kept in HBM
+// (rsx_kfstore / rsx_loop_verify), printing the reference's "[SC loop] ICP fitness test ..." lines (PGO.cpp:386-389).
+// Without a pose-graph optimiser (GTSAM is not part of this image) keyframePosesUpdated stays the odometry pose of each
+// keyframe, which is what the reference itself uses until the first iSAM2 update (PGO.cpp:489).
+// --save-map <file.pcd> writes the cloud pubMap publishes (PGO.cpp:631-655: every 2nd keyframe through its pose,
+// VoxelGrid of --map_viz_filter_size, default 0.4) as a binary PCD file: the map-saving utility of README.md:139.
 //
 // usage: pgo_replay <recording> [--keyframe_meter_gap 2.0] [--sc_dist_thres 0.45] [--exhaustive] [--devices 0,1,..]
+//                   [--verify-loops] [--save-map map.pcd] [--map_viz_filter_size 0.4]
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <deque>
+#include <iostream>
 #include <string>
 #include <vector>
 
+#include "pcd.h"
 #include "rosmsg.h"
 #include "scancontext/Scancontext.h"
 
@@ -29,13 +38,18 @@ int main(int argc, char **argv) {
       return 1;
     }
     double keyframe_meter_gap = 2.0, sc_dist_thres = 0.2;  // PGO.cpp:676-677 defaults (sc_pgo.launch sets 0.2 / 0.45)
-    bool exhaustive = false;
+    bool exhaustive = false, verify_loops = false;
+    std::string map_path;
+    float map_viz_filter_size = 0.4f;  // PGO.cpp:691 default of mapviz_filter_size
     std::vector<int> devices;
     for (int i = 2; i < argc; i++) {
       const std::string a = argv[i];
       if (a == "--keyframe_meter_gap" && i + 1 < argc) keyframe_meter_gap = std::atof(argv[++i]);
       else if (a == "--sc_dist_thres" && i + 1 < argc) sc_dist_thres = std::atof(argv[++i]);
       else if (a == "--exhaustive") exhaustive = true;
+      else if (a == "--verify-loops") verify_loops = true;
+      else if (a == "--save-map" && i + 1 < argc) map_path = argv[++i];
+      else if (a == "--map_viz_filter_size" && i + 1 < argc) map_viz_filter_size = (float)std::atof(argv[++i]);
       else if (a == "--devices" && i + 1 < argc)
         for (const char *p = argv[++i]; *p;) {
           devices.push_back(std::atoi(p));
@@ -55,6 +69,14 @@ int main(int argc, char **argv) {
     else if (devices.size() == 1) scManager.setDevice(devices[0]);
     scManager.setExhaustive(exhaustive);
     scManager.setVerbose(false);
+    // keyframeLaserClouds / keyframePosesUpdated (PGO.cpp:74-76), the clouds in HBM
+    rsx_kfstore *kf = nullptr;
+    std::vector<double> keyframePosesUpdated;  // 6 doubles per keyframe
+    long n_accepted = 0;
+    if (verify_loops || !map_path.empty()) {
+      if (rsx_kfstore_create(devices.empty() ? 0 : devices[0], &kf) != RSX_OK) throw std::runtime_error(rsx_last_error_string());
+      scManager.attachKeyframeStore(kf);
+    }
 
     // laserOdometryHandler / laserCloudFullResHandler: the two queues (PGO.cpp:124-137)
     struct Msg {
@@ -93,12 +115,25 @@ int main(int argc, char **argv) {
         // downSizeFilterScancontext.filter + scManager.makeAndSaveScancontextAndKeys (PGO.cpp:482-492) on the GPU, for one
         // device (fused) and for several (downsample on the first, same cloud to every shard) alike
         scManager.makeAndSaveScancontextAndKeysDownsampled(pts.empty() ? nullptr : &pts[0].x, pts.size(), sizeof(Pt32), 0.4f);
+        for (double v : {pose_curr.x, pose_curr.y, pose_curr.z, pose_curr.roll, pose_curr.pitch, pose_curr.yaw})
+          keyframePosesUpdated.push_back(v);  // PGO.cpp:488-489
         n_keyframes++;
         if (n_keyframes < scManager.NUM_EXCLUDE_RECENT) continue;  // PGO.cpp:558
         auto r = scManager.detectLoopClosureID();                   // PGO.cpp:561
         if (r.first != -1) {
           std::printf("Loop detected! - between %d and %ld\n", r.first, n_keyframes - 1);  // PGO.cpp:566
           n_loops++;
+          if (verify_loops) {  // process_icp -> doICPVirtualRelative(prev_node_idx, curr_node_idx) (PGO.cpp:596-599)
+            rsx_loop_verify_result v;
+            if (rsx_loop_verify(kf, r.first, (int32_t)(n_keyframes - 1), &keyframePosesUpdated[6 * (size_t)r.first], nullptr, &v) != RSX_OK)
+              throw std::runtime_error(rsx_last_error_string());
+            if (!v.accepted) {  // PGO.cpp:385-389, character for character (std::cout of a double / a float)
+              std::cout << "[SC loop] ICP fitness test failed (" << v.fitness << " > " << 0.3f << "). Reject this SC loop." << std::endl;
+            } else {
+              std::cout << "[SC loop] ICP fitness test passed (" << v.fitness << " < " << 0.3f << "). Add this SC loop." << std::endl;
+              n_accepted++;
+            }
+          }
         }
       }
     };
@@ -118,7 +153,22 @@ int main(int argc, char **argv) {
       process();
     }
     std::fclose(f);
-    std::printf("frames=%ld keyframes=%ld loops=%ld dropped_odom=%ld\n", n_frames, n_keyframes, n_loops, n_dropped);
+    std::fflush(stdout);
+    if (!map_path.empty()) {
+      // pubMap (PGO.cpp:631-655): SKIP_FRAMES = 2, downSizeFilterMapPGO
+      int64_t nk = 0, np = 0, m = 0;
+      if (rsx_kfstore_size(kf, &nk, &np) != RSX_OK) throw std::runtime_error(rsx_last_error_string());
+      std::vector<float> map((size_t)(np > 0 ? np : 1) * 4);
+      if (rsx_kfstore_build_map(kf, keyframePosesUpdated.data(), (int64_t)(keyframePosesUpdated.size() / 6), 2, map_viz_filter_size, map.data(),
+                                np > 0 ? np : 1, &m) != RSX_OK)
+        throw std::runtime_error(rsx_last_error_string());
+      pcd::write_binary_xyzi(map_path, map.data(), m);
+      std::printf("map: %lld points from %lld keyframes -> %s\n", (long long)m, (long long)nk, map_path.c_str());
+    }
+    if (kf) rsx_kfstore_destroy(kf);
+    std::printf("frames=%ld keyframes=%ld loops=%ld dropped_odom=%ld", n_frames, n_keyframes, n_loops, n_dropped);
+    if (verify_loops) std::printf(" loops_accepted=%ld", n_accepted);
+    std::printf("\n");
     return 0;
   } catch (const std::exception &e) {
     std::fprintf(stderr, "pgo_replay: %s\n", e.what());

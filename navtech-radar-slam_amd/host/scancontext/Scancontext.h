@@ -137,7 +137,16 @@ class SCManager {
   // Opt-in fusion of the caller's `downSizeFilterScancontext.filter(*thisKeyFrameDS)` with the build
   // (laserPosegraphOptimization.cpp:482-492): the raw keyframe goes in, the VoxelGrid downsample
   // (leaf as set at PGO.cpp:687-688) and the descriptor build both run on the GPU.
+  // Opt-in: the keyframe-cloud store of the pose-graph node (keyframeLaserClouds, PGO.cpp:487) on the GPU.  Once attached,
+  // makeAndSaveScancontextAndKeysDownsampled also appends the downsampled cloud to it -- what PGO.cpp:482-492 does in three
+  // statements -- so that rsx_loop_verify / rsx_kfstore_build_map (doICPVirtualRelative, pubMap) find every keyframe in
+  // HBM.  The store stays the caller's; it must live on the (first) device of this manager.
+  void attachKeyframeStore(rsx_kfstore *kf) {
+    std::lock_guard<std::mutex> lk(mu_);
+    kf_ = kf;
+  }
   void makeAndSaveScancontextAndKeysDownsampled(const float *xyz, std::size_t n, std::size_t stride_bytes, float leaf = 0.4f) {
+    const int32_t ioff = stride_bytes >= 20 ? 16 : -1;  // pcl::PointXYZI keeps its intensity at byte 16
     if (sharded()) {
       // several devices: the downsample runs on the first one, the centroids (x, y, z, intensity float4) come back once
       // and every shard gets the same cloud -- the descriptor is the one a single device would build
@@ -146,17 +155,20 @@ class SCManager {
       if (!vg_) check(rsx_voxelgrid_create(devices_[0], &vg_), "rsx_voxelgrid_create");
       ds_.resize(4 * (n ? n : 1));
       int64_t m = 0;
-      check(rsx_voxelgrid_filter(vg_, xyz, n, stride_bytes, stride_bytes >= 20 ? 16 : -1, leaf, ds_.data(), (int64_t)(n ? n : 1), &m),
-            "rsx_voxelgrid_filter");
+      check(rsx_voxelgrid_filter(vg_, xyz, n, stride_bytes, ioff, leaf, ds_.data(), (int64_t)(n ? n : 1), &m), "rsx_voxelgrid_filter");
+      if (kf_) check(rsx_kfstore_add(kf_, ds_.data(), (std::size_t)m, 16, 12, nullptr), "rsx_kfstore_add");
       check(rsx_scs_add_points(hs, ds_.data(), (std::size_t)m, 16, nullptr), "makeAndSaveScancontextAndKeysDownsampled");
       return;
     }
     rsx_sc *h = handle();
+    rsx_kfstore *kf = nullptr;
     {
       std::lock_guard<std::mutex> lk(mu_);
       if (!vg_) check(rsx_voxelgrid_create(device_, &vg_), "rsx_voxelgrid_create");
+      kf = kf_;
     }
-    check(rsx_sc_add_points_downsampled(h, vg_, xyz, n, stride_bytes, leaf, nullptr), "makeAndSaveScancontextAndKeysDownsampled");
+    if (kf) check(rsx_sc_add_keyframe(h, vg_, kf, xyz, n, stride_bytes, ioff, leaf, nullptr), "makeAndSaveScancontextAndKeysDownsampled");
+    else check(rsx_sc_add_points_downsampled(h, vg_, xyz, n, stride_bytes, leaf, nullptr), "makeAndSaveScancontextAndKeysDownsampled");
   }
 #ifdef RSX_HAVE_PCL
   void makeAndSaveScancontextAndKeysDownsampled(pcl::PointCloud<SCPointType> &scan, float leaf = 0.4f) {
@@ -462,6 +474,7 @@ class SCManager {
   rsx_sc *h_ = nullptr;
   rsx_scs *hs_ = nullptr;
   rsx_voxelgrid *vg_ = nullptr;
+  rsx_kfstore *kf_ = nullptr;  // not owned (attachKeyframeStore)
   std::vector<float> ds_;  // downsampled cloud of the multi-device path
   int mode_ = RSX_SC_MODE_CANDIDATE;
   int device_ = 0;

@@ -494,6 +494,78 @@ def icp_align(source, target, max_corr_dist=150.0, transformation_epsilon=1e-6, 
             "iterations": r.iterations, "converged": bool(r.converged), "state": r.state}
 
 
+# ---------------------------------------------------------------------------------------------
+# Loop verification chain + map assembly (oracle/loopverify_ref.c): PGO.cpp:199-220, 329-406, 631-655
+# ---------------------------------------------------------------------------------------------
+class LvRefResult(C.Structure):
+    _fields_ = [("accepted", C.c_int32), ("converged", C.c_int32), ("iterations", C.c_int32), ("state", C.c_int32),
+                ("fitness", C.c_double), ("transform", C.c_float * 16),
+                ("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("roll", C.c_float), ("pitch", C.c_float), ("yaw", C.c_float),
+                ("relative", C.c_double * 16), ("n_source", C.c_int64), ("n_target", C.c_int64)]
+
+
+def _kf_pack(clouds):
+    """list of (n_i, 4) float32 keyframe clouds -> (packed (N, 4) float32, offsets int64[nkf + 1])"""
+    off = np.zeros(len(clouds) + 1, dtype=np.int64)
+    for i, c in enumerate(clouds):
+        off[i + 1] = off[i] + len(c)
+    allp = np.ascontiguousarray(np.concatenate([np.asarray(c, dtype=np.float32).reshape(-1, 4) for c in clouds]), dtype=np.float32) \
+        if len(clouds) and off[-1] else np.zeros((1, 4), dtype=np.float32)
+    return allp, off
+
+
+def pose_matrix(pose6):
+    """pcl::getTransformation(x, y, z, roll, pitch, yaw) as the reference calls it (float): (4, 4) float32"""
+    L = lib()
+    p = np.ascontiguousarray(pose6, dtype=np.float64).reshape(6)
+    t = np.zeros(16, dtype=np.float32)
+    L.lvref_pose_matrix.argtypes = [C.c_void_p, C.c_void_p]
+    L.lvref_pose_matrix(p.ctypes.data, t.ctypes.data)
+    return t.reshape(4, 4)
+
+
+def loop_submap(clouds, key, submap_size, root_pose, leaf=0.4):
+    """loopFindNearKeyframesCloud (PGO.cpp:329-352) -> (m, 4) float32"""
+    L = lib()
+    allp, off = _kf_pack(clouds)
+    out = np.zeros((max(int(off[-1]), 1), 4), dtype=np.float32)
+    rp = np.ascontiguousarray(root_pose, dtype=np.float64).reshape(6)
+    L.lvref_submap.restype = C.c_int64
+    L.lvref_submap.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_float, C.c_void_p, C.c_int64]
+    m = L.lvref_submap(allp.ctypes.data, off.ctypes.data, len(clouds), key, submap_size, rp.ctypes.data, leaf, out.ctypes.data, out.shape[0])
+    return out[:m].copy()
+
+
+def loop_verify(clouds, loop_idx, curr_idx, root_pose, history_num=25, leaf=0.4, fitness_threshold=0.3,
+                max_corr_dist=150.0, transformation_epsilon=1e-6, euclidean_fitness_epsilon=1e-6, max_iterations=100):
+    """doICPVirtualRelative (PGO.cpp:355-406) -> dict"""
+    L = lib()
+    allp, off = _kf_pack(clouds)
+    rp = np.ascontiguousarray(root_pose, dtype=np.float64).reshape(6)
+    p = IcpRefParams(max_corr_dist, transformation_epsilon, euclidean_fitness_epsilon, max_iterations, 0)
+    r = LvRefResult()
+    L.lvref_verify.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
+                               C.POINTER(IcpRefParams), C.c_double, C.POINTER(LvRefResult)]
+    L.lvref_verify(allp.ctypes.data, off.ctypes.data, len(clouds), loop_idx, curr_idx, rp.ctypes.data, history_num, leaf, C.byref(p),
+                   fitness_threshold, C.byref(r))
+    return {"accepted": bool(r.accepted), "converged": bool(r.converged), "iterations": r.iterations, "state": r.state,
+            "fitness": r.fitness, "transform": np.array(r.transform, dtype=np.float32).reshape(4, 4),
+            "xyz_rpy": np.array([r.x, r.y, r.z, r.roll, r.pitch, r.yaw], dtype=np.float32),
+            "relative": np.array(r.relative, dtype=np.float64).reshape(4, 4), "n_source": r.n_source, "n_target": r.n_target}
+
+
+def map_build(clouds, poses, skip=2, leaf=0.4):
+    """pubMap's cloud (PGO.cpp:631-655) -> (m, 4) float32"""
+    L = lib()
+    allp, off = _kf_pack(clouds)
+    ps = np.ascontiguousarray(poses, dtype=np.float64).reshape(len(clouds), 6)
+    out = np.zeros((max(int(off[-1]), 1), 4), dtype=np.float32)
+    L.lvref_map.restype = C.c_int64
+    L.lvref_map.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int64]
+    m = L.lvref_map(allp.ctypes.data, off.ctypes.data, len(clouds), ps.ctypes.data, skip, leaf, out.ctypes.data, out.shape[0])
+    return out[:m].copy()
+
+
 # ------------------------------------------------------------------------------------------
 # The reference's own Scancontext.cpp, compiled unmodified against oracle/standin (oracle/ref_sc.cpp)
 # ------------------------------------------------------------------------------------------

@@ -226,3 +226,86 @@ def test_odometry_recording_feeds_the_replay(tmp_path):
     r = subprocess.run([os.path.join(HOST, "pgo_replay"), str(rec), "--keyframe_meter_gap", "-1"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.strip().splitlines()[-1] == "frames=3 keyframes=3 loops=0 dropped_odom=0"
+
+
+def _recording(clouds, xpos, yaw=None):
+    """RSXREPLAY1 bytes of /orora/odom + /orora/cloud_local for clouds[i] seen at (xpos[i], 0, 0) with heading yaw[i]"""
+    import struct
+    import numpy as np
+
+    def st(x):
+        return struct.pack("<I", len(x)) + x.encode()
+
+    def header(seq, t_ns, frame):
+        return struct.pack("<III", seq, t_ns // 10**9, t_ns % 10**9) + st(frame)
+
+    rec = bytearray(b"RSXREPLAY1")
+    t0 = 1_560_000_000_000_000_000
+    for i, c in enumerate(clouds):
+        t = t0 + i * 250_000_000
+        h = 0.0 if yaw is None else float(yaw[i])
+        quat = struct.pack("<4d", 0.0, 0.0, np.sin(h / 2), np.cos(h / 2))
+        od = header(i, t, "odom") + st("radar") + struct.pack("<3d", float(xpos[i]), 0.0, 0.0) + quat + bytes(8 * 78)
+        body = b"".join(struct.pack("<8f", p[0], p[1], p[2], 1.0, p[3], 0, 0, 0) for p in c)
+        pc = header(i, t, "radar") + struct.pack("<II", 1, len(c)) + struct.pack("<I", 4)
+        for name, off in (("x", 0), ("y", 4), ("z", 8), ("intensity", 16)):
+            pc += st(name) + struct.pack("<IBI", off, 7, 1)
+        pc += struct.pack("<BII", 0, 32, 32 * len(c)) + struct.pack("<I", len(body)) + body + struct.pack("<B", 1)
+        rec += struct.pack("<BI", 0, len(od)) + od + struct.pack("<BI", 1, len(pc)) + pc
+    return bytes(rec)
+
+
+def test_replay_verifies_loops_and_saves_the_map(tmp_path, oracle):
+    """pgo_replay --verify-loops --save-map: behind every "Loop detected!" the chain of doICPVirtualRelative (PGO.cpp:355-406)
+    on the keyframe clouds kept in HBM, with the reference's "[SC loop] ICP fitness test ..." lines, and at the end the cloud
+    pubMap builds (PGO.cpp:631-655) as a PCD file.  A street driven twice: the second pass closes loops that the ICP gate
+    accepts.  Verdicts and the map must be the oracle's (VoxelGrid + ScanContext + loop-verification oracles)."""
+    import re
+    import numpy as np
+    from test_oracle_loopverify import street_drive
+    clouds, pose6 = street_drive(seed=3, n=80, step=2.5, revisit_at=48)
+    rec = tmp_path / "loop.rsxreplay"
+    rec.write_bytes(_recording(clouds, pose6[:, 0], pose6[:, 5]))
+    pcdf = tmp_path / "map.pcd"
+    r = subprocess.run([os.path.join(HOST, "pgo_replay"), str(rec), "--keyframe_meter_gap", "2.0", "--sc_dist_thres", "0.45",
+                        "--verify-loops", "--save-map", str(pcdf)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    # the oracle on the same stream: every scan is a keyframe (2.5 m apart; the odometry y is 0 in the recording)
+    m = oracle.Manager(dist_thres=0.45)
+    poses = pose6.copy()
+    poses[:, 1] = 0.0
+    kfs, want = [], []
+    for i, c in enumerate(clouds):
+        ds, _ = oracle.voxelgrid_filter(c, 0.4)
+        kfs.append(ds)
+        m.add_points(ds)
+        if len(m) < 30:
+            continue
+        lid, _, _, _ = m.detect_loop_closure()
+        if lid != -1:
+            v = oracle.loop_verify(kfs, lid, len(m) - 1, poses[lid])
+            want.append((lid, len(m) - 1, v))
+    assert len(want) >= 3 and any(v["accepted"] for _, _, v in want)
+    lines = r.stdout.strip().splitlines()
+    got_loops = [ln for ln in lines if ln.startswith("Loop detected!")]
+    got_icp = [ln for ln in lines if ln.startswith("[SC loop]")]
+    assert got_loops == [f"Loop detected! - between {a} and {b}" for a, b, _ in want]
+    assert len(got_icp) == len(want)
+    for ln, (_, _, v) in zip(got_icp, want):
+        mo = re.match(r"\[SC loop\] ICP fitness test (passed|failed) \(([-+0-9.e]+|inf|nan) ([<>]) 0\.3\)\. (Add|Reject) this SC loop\.", ln)
+        assert mo, ln
+        assert (mo.group(1) == "passed") == (mo.group(3) == "<") == (mo.group(4) == "Add")
+        assert abs(float(mo.group(2)) - v["fitness"]) < 2e-2 * max(1.0, v["fitness"])      # (ICPs may stop an iteration apart)
+        if abs(v["fitness"] - 0.3) > 2e-2:
+            assert (mo.group(1) == "passed") == v["accepted"]
+    n_acc = sum(1 for ln in got_icp if "passed" in ln)
+    assert n_acc >= 3
+    assert lines[-1] == f"frames=80 keyframes=80 loops={len(want)} dropped_odom=0 loops_accepted={n_acc}"
+    # the saved map == the oracle's pubMap cloud, bit for bit
+    raw = pcdf.read_bytes()
+    head, body = raw.split(b"DATA binary\n", 1)
+    assert b"FIELDS x y z intensity" in head and b"VERSION 0.7" in head
+    got_map = np.frombuffer(body, dtype=np.float32).reshape(-1, 4)
+    want_map = oracle.map_build(kfs, poses, skip=2, leaf=0.4)
+    assert f"POINTS {len(want_map)}".encode() in head
+    assert got_map.shape == want_map.shape and np.array_equal(got_map.view(np.uint32), want_map.view(np.uint32))
