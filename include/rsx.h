@@ -102,6 +102,13 @@ typedef enum {
   RSX_SC_MODE_EXHAUSTIVE = 1 /* same pair function against every eligible entry */
 } rsx_sc_mode;
 
+/* Self-test of the exception firewall (every status-returning entry is a function-try-block, rsx_common.h): throws the
+ * named exception INSIDE the library and returns what the firewall makes of it -- 0: a host container asked for an
+ * impossible size (std::length_error) -> RSX_ERR_OOM; 1: std::bad_alloc -> RSX_ERR_OOM; 2: std::runtime_error (what
+ * nanoflann throws through the reference's SCManager, NF.hpp:1228,1324) -> RSX_ERR_INTERNAL; 3: a non-std exception ->
+ * RSX_ERR_INTERNAL.  Needs no device. */
+int rsx_selftest_firewall(int kind);
+
 int rsx_sc_default_params(rsx_sc_params *p);
 int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out);   /* SCManager() */
 int rsx_sc_destroy(rsx_sc *h);

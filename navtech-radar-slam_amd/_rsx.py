@@ -105,7 +105,7 @@ _lib = None
 
 # every symbol include/rsx.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
-    "rsx_last_error_string", "rsx_version", "rsx_device_count",
+    "rsx_last_error_string", "rsx_version", "rsx_device_count", "rsx_selftest_firewall",
     "rsx_sc_default_params", "rsx_sc_create", "rsx_sc_destroy", "rsx_sc_set_dist_thres", "rsx_sc_size",
     "rsx_sc_local_size", "rsx_sc_add_points", "rsx_sc_add_descriptor", "rsx_sc_add_descriptors_f32",
     "rsx_sc_add_descriptors_f32_device", "rsx_sc_add_descriptor_rounded", "rsx_sc_export_descriptors_f32",

@@ -884,14 +884,14 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
 
 extern "C" {
 
-int rsx_cen2019_default_params(rsx_cen2019_params *p) {
+int rsx_cen2019_default_params(rsx_cen2019_params *p) try {
   if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
   p->max_points = 10000;  // yeti_radar_odometry default for cen2019 (recollection)
   p->min_range = 58;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_cen2019_create(int device, int32_t rows, int32_t cols, rsx_cen2019 **out) {
+int rsx_cen2019_create(int device, int32_t rows, int32_t cols, rsx_cen2019 **out) try {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
   *out = nullptr;
   if (rows < 1 || rows > 1024 || cols < 2 || cols > 16384) return fail(RSX_ERR_BAD_ARG, "image shape %d x %d unsupported", rows, cols);
@@ -911,9 +911,9 @@ int rsx_cen2019_create(int device, int32_t rows, int32_t cols, rsx_cen2019 **out
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_cen2019_destroy(rsx_cen2019 *h) {
+int rsx_cen2019_destroy(rsx_cen2019 *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -921,12 +921,12 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_cen2019_extract_batch_device(rsx_cen2019 *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
                                      int32_t col_offset, const rsx_cen2019_params *params, const float *d_azimuths,
                                      int32_t azimuths_per_image, float resolution, int32_t *d_targets, float *d_xy, int32_t max_targets,
-                                     int32_t *d_counts, void *stream) {
+                                     int32_t *d_counts, void *stream) try {
   if (!h || !d_imgs || !d_targets || n_images < 0 || max_targets < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (col_offset < 0 || row_stride < col_offset + h->cols) return fail(RSX_ERR_BAD_ARG, "row_stride %d too small for offset %d + %d columns", row_stride, col_offset, h->cols);
   if (image_stride_bytes < (int64_t)h->rows * row_stride && n_images > 1) return fail(RSX_ERR_BAD_ARG, "image_stride_bytes smaller than an image");
@@ -940,11 +940,11 @@ int rsx_cen2019_extract_batch_device(rsx_cen2019 *h, const uint8_t *d_imgs, int3
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   return extract_device(h, d_imgs, image_stride_bytes, n_images, row_stride, col_offset, p, d_azimuths, azimuths_per_image ? h->rows : 0,
                         resolution, max_targets, d_targets, d_xy, d_counts, s);
-}
+} RSX_CATCH_ALL
 
 int rsx_cen2019_extract_batch(rsx_cen2019 *h, const uint8_t *imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
                               int32_t col_offset, const rsx_cen2019_params *params, const float *azimuths, int32_t azimuths_per_image,
-                              float resolution, int32_t *out_targets, float *out_xy, int32_t max_targets, int32_t *out_counts) {
+                              float resolution, int32_t *out_targets, float *out_xy, int32_t max_targets, int32_t *out_counts) try {
   if (!h || !imgs || !out_targets || !out_counts || n_images < 0 || max_targets < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (col_offset < 0 || row_stride < col_offset + h->cols) return fail(RSX_ERR_BAD_ARG, "row_stride %d too small for offset %d + %d columns", row_stride, col_offset, h->cols);
   if (n_images > 1 && image_stride_bytes < (int64_t)h->rows * row_stride) return fail(RSX_ERR_BAD_ARG, "image_stride_bytes smaller than an image");
@@ -995,14 +995,14 @@ int rsx_cen2019_extract_batch(rsx_cen2019 *h, const uint8_t *imgs, int32_t n_ima
     RSX_HIP(hipStreamSynchronize(s));
   }
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, int32_t col_offset, const rsx_cen2019_params *params,
                         const float *azimuths, float resolution, int32_t *out_targets, float *out_xy, int32_t max_targets,
-                        int32_t *out_count) {
+                        int32_t *out_count) try {
   if (!h || !img || !out_targets || !out_count || max_targets < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   return rsx_cen2019_extract_batch(h, img, 1, (int64_t)h->rows * row_stride, row_stride, col_offset, params, azimuths, 0, resolution, out_targets,
                                    out_xy, max_targets, out_count);
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"

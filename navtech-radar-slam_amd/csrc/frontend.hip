@@ -435,16 +435,16 @@ double cart_min_range(int W, double cart_res) { return (W % 2 == 0) ? (W / 2 - 0
 
 extern "C" {
 
-int rsx_frontend_default_params(rsx_frontend_params *p) {
+int rsx_frontend_default_params(rsx_frontend_params *p) try {
   if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
   p->cart_pixel_width = 964;   // yeti / ORORA defaults for the Navtech CIR204-H (recollection, parameterised)
   p->cart_resolution = 0.2592f;
   p->ratio = 0.8f;
   p->flags = 0;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_frontend_create(int device, int32_t rows, int32_t cols, const rsx_frontend_params *params, rsx_frontend **out) {
+int rsx_frontend_create(int device, int32_t rows, int32_t cols, const rsx_frontend_params *params, rsx_frontend **out) try {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
   *out = nullptr;
   rsx_frontend_params dp;
@@ -487,9 +487,9 @@ int rsx_frontend_create(int device, int32_t rows, int32_t cols, const rsx_fronte
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_frontend_destroy(rsx_frontend *h) {
+int rsx_frontend_destroy(rsx_frontend *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -499,7 +499,7 @@ int rsx_frontend_destroy(rsx_frontend *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 // (re)build the pixel -> (range bin, azimuth row) map when the radar's range resolution or azimuth grid changed
 static int ensure_map(rsx_frontend *h, const float *azimuths, float resolution, hipStream_t s) {
@@ -560,7 +560,7 @@ static int cartesian_device(rsx_frontend *h, const uint8_t *d_imgs, int n, int64
 }
 
 int rsx_frontend_cartesian(rsx_frontend *h, const uint8_t *img, int32_t row_stride, int32_t col_offset, const float *azimuths,
-                           float resolution, float *out_cart) {
+                           float resolution, float *out_cart) try {
   if (!h || !img || !azimuths) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (row_stride < col_offset + h->cols || col_offset < 0 || !(resolution > 0.0f)) return fail(RSX_ERR_BAD_ARG, "bad image layout");
   std::lock_guard<std::mutex> lk(h->mu);
@@ -574,10 +574,10 @@ int rsx_frontend_cartesian(rsx_frontend *h, const uint8_t *img, int32_t row_stri
   if (out_cart) RSX_HIP(hipMemcpyAsync(out_cart, h->cart.p, (size_t)h->W * h->W * sizeof(float), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_frontend_cartesian_batch_device(rsx_frontend *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
-                                        int32_t col_offset, const float *azimuths, float resolution, void *stream) {
+                                        int32_t col_offset, const float *azimuths, float resolution, void *stream) try {
   if (!h || !d_imgs || !azimuths || n_images < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (row_stride < col_offset + h->cols || col_offset < 0 || !(resolution > 0.0f)) return fail(RSX_ERR_BAD_ARG, "bad image layout");
   if (n_images > 1 && image_stride_bytes < (int64_t)h->rows * row_stride) return fail(RSX_ERR_BAD_ARG, "image_stride_bytes smaller than an image");
@@ -586,9 +586,9 @@ int rsx_frontend_cartesian_batch_device(rsx_frontend *h, const uint8_t *d_imgs, 
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   RSX_TRY(ensure_map(h, azimuths, resolution, s));
   return cartesian_device(h, d_imgs, n_images, image_stride_bytes, row_stride, col_offset, s);
-}
+} RSX_CATCH_ALL
 
-int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *out_desc, uint8_t *out_valid) {
+int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *out_desc, uint8_t *out_valid) try {
   if (!h || (!xy && n) || (!out_desc && n) || (!out_valid && n) || n < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n == 0) return RSX_OK;
   std::lock_guard<std::mutex> lk(h->mu);
@@ -615,10 +615,10 @@ int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *
   RSX_HIP(hipMemcpyAsync(out_valid, h->valid.p, (size_t)n, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));  // also keeps uv alive until the copy is done
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_frontend_describe_batch_device(rsx_frontend *h, const float *d_xy, const int32_t *d_counts, int32_t n_images, int32_t max_targets,
-                                       uint8_t *d_desc, uint8_t *d_valid, void *stream) {
+                                       uint8_t *d_desc, uint8_t *d_valid, void *stream) try {
   if (!h || !d_xy || !d_counts || !d_desc || !d_valid || n_images < 1 || max_targets < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   std::lock_guard<std::mutex> lk(h->mu);
   if (!h->have_image || n_images > h->batch_n) return fail(RSX_ERR_BAD_ARG, "describe_batch: %d images, the last Cartesian batch holds %d", n_images, h->batch_n);
@@ -635,11 +635,11 @@ int rsx_frontend_describe_batch_device(rsx_frontend *h, const float *d_xy, const
                      reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), reinterpret_cast<uint32_t *>(d_desc), d_valid);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_frontend_match_consecutive_device(rsx_frontend *h, const uint8_t *d_desc, const uint8_t *d_valid, const int32_t *d_counts,
                                           int32_t max_targets, int32_t first_slot, int32_t n_pairs, float ratio, int32_t *d_fwd,
-                                          int32_t *d_bwd, void *stream) {
+                                          int32_t *d_bwd, void *stream) try {
   if (!h || !d_desc || !d_valid || !d_counts || !d_fwd || !d_bwd || max_targets < 1 || first_slot < 0 || n_pairs < 0)
     return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n_pairs == 0) return RSX_OK;
@@ -655,10 +655,10 @@ int rsx_frontend_match_consecutive_device(rsx_frontend *h, const uint8_t *d_desc
                      h->vcount.as<int32_t>(), ratio, d_fwd, d_bwd);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_frontend_match(rsx_frontend *h, const uint8_t *q_desc, const uint8_t *q_valid, int32_t nq, const uint8_t *t_desc,
-                       const uint8_t *t_valid, int32_t nt, float ratio, int32_t *out_train_idx, int32_t *out_d1, int32_t *out_d2) {
+                       const uint8_t *t_valid, int32_t nt, float ratio, int32_t *out_train_idx, int32_t *out_d1, int32_t *out_d2) try {
   if (!h || nq < 0 || nt < 0 || (nq && (!q_desc || !q_valid || !out_train_idx)) || (nt && (!t_desc || !t_valid)))
     return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (nq == 0) return RSX_OK;
@@ -687,6 +687,6 @@ int rsx_frontend_match(rsx_frontend *h, const uint8_t *q_desc, const uint8_t *q_
   if (out_d2) RSX_HIP(hipMemcpyAsync(out_d2, h->m_d2.p, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"

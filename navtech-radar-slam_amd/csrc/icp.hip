@@ -371,7 +371,7 @@ using rsx::fail;
 
 extern "C" {
 
-int rsx_icp_default_params(rsx_icp_params *p) {
+int rsx_icp_default_params(rsx_icp_params *p) try {
   if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
   p->max_corr_dist = 150.0;             // PGO.cpp:374
   p->transformation_epsilon = 1e-6;     // PGO.cpp:376
@@ -379,9 +379,9 @@ int rsx_icp_default_params(rsx_icp_params *p) {
   p->max_iterations = 100;              // PGO.cpp:375
   p->reserved = 0;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_icp_create(int device, rsx_icp **out) {
+int rsx_icp_create(int device, rsx_icp **out) try {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
   *out = nullptr;
   int ndev = rsx_device_count();
@@ -398,9 +398,9 @@ int rsx_icp_create(int device, rsx_icp **out) {
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_icp_destroy(rsx_icp *h) {
+int rsx_icp_destroy(rsx_icp *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -408,10 +408,10 @@ int rsx_icp_destroy(rsx_icp *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_icp_align(rsx_icp *h, const void *src, size_t ns, size_t src_stride, const void *tgt, size_t nt, size_t tgt_stride,
-                  const rsx_icp_params *params, const float *guess, rsx_icp_result *out) {
+                  const rsx_icp_params *params, const float *guess, rsx_icp_result *out) try {
   if (!h || !out || (!src && ns) || (!tgt && nt)) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (src_stride < 12 || (src_stride & 3) || tgt_stride < 12 || (tgt_stride & 3)) return fail(RSX_ERR_BAD_ARG, "strides must be >= 12 and multiples of 4");
   if (nt > 0xfffffffeull || ns > 0x7fffffffull) return fail(RSX_ERR_RANGE, "cloud too large");
@@ -423,7 +423,7 @@ int rsx_icp_align(rsx_icp *h, const void *src, size_t ns, size_t src_stride, con
   if (ns) RSX_HIP(hipMemcpyAsync(h->src.p, src, ns * src_stride, hipMemcpyHostToDevice, s));
   if (nt) RSX_HIP(hipMemcpyAsync(h->tgt.p, tgt, nt * tgt_stride, hipMemcpyHostToDevice, s));
   return rsx::icp::align_device_locked(h, h->src.p, (int64_t)ns, (int64_t)src_stride, h->tgt.p, (int64_t)nt, (int64_t)tgt_stride, params, guess, out);
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"
 

@@ -194,7 +194,7 @@ int append_device_locked(rsx_kfstore *h, const void *d_xyzi, int64_t n, int32_t 
 
 extern "C" {
 
-int rsx_kfstore_create(int device, rsx_kfstore **out) {
+int rsx_kfstore_create(int device, rsx_kfstore **out) try {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
   *out = nullptr;
   int ndev = rsx_device_count();
@@ -222,9 +222,9 @@ int rsx_kfstore_create(int device, rsx_kfstore **out) {
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_kfstore_destroy(rsx_kfstore *h) {
+int rsx_kfstore_destroy(rsx_kfstore *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -235,7 +235,7 @@ int rsx_kfstore_destroy(rsx_kfstore *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_kfstore_add(rsx_kfstore *h, const void *pts, size_t n, size_t stride_bytes, int32_t intensity_offset, int32_t *out_index) try {
   if (!h || (!pts && n)) return fail(RSX_ERR_BAD_ARG, "null arg");
@@ -264,11 +264,7 @@ int rsx_kfstore_add(rsx_kfstore *h, const void *pts, size_t n, size_t stride_byt
   h->off.push_back(first + (int64_t)n);
   if (out_index) *out_index = (int32_t)kf;
   return RSX_OK;
-} catch (const std::bad_alloc &) {
-  return fail(RSX_ERR_OOM, "host alloc");
-} catch (...) {
-  return fail(RSX_ERR_INTERNAL, "unexpected exception");
-}
+} RSX_CATCH_ALL
 
 int rsx_kfstore_add_device(rsx_kfstore *h, const void *d_xyzi, size_t n, int32_t *out_index) try {
   if (!h || (!d_xyzi && n)) return fail(RSX_ERR_BAD_ARG, "null arg");
@@ -279,21 +275,17 @@ int rsx_kfstore_add_device(rsx_kfstore *h, const void *d_xyzi, size_t n, int32_t
   RSX_TRY(append_device(h, static_cast<const float4 *>(d_xyzi), (int64_t)n, out_index));
   RSX_HIP(hipStreamSynchronize(h->stream));
   return RSX_OK;
-} catch (const std::bad_alloc &) {
-  return fail(RSX_ERR_OOM, "host alloc");
-} catch (...) {
-  return fail(RSX_ERR_INTERNAL, "unexpected exception");
-}
+} RSX_CATCH_ALL
 
-int rsx_kfstore_size(rsx_kfstore *h, int64_t *n_keyframes, int64_t *n_points) {
+int rsx_kfstore_size(rsx_kfstore *h, int64_t *n_keyframes, int64_t *n_points) try {
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
   if (n_keyframes) *n_keyframes = (int64_t)h->off.size() - 1;
   if (n_points) *n_points = h->off.back();
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_kfstore_get(rsx_kfstore *h, int32_t index, float *out_xyzi, int64_t max_out, int64_t *out_count) {
+int rsx_kfstore_get(rsx_kfstore *h, int32_t index, float *out_xyzi, int64_t max_out, int64_t *out_count) try {
   if (!h || !out_count || (!out_xyzi && max_out > 0)) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   if (index < 0 || index >= (int64_t)h->off.size() - 1) return fail(RSX_ERR_RANGE, "keyframe %d out of range", index);
@@ -306,19 +298,19 @@ int rsx_kfstore_get(rsx_kfstore *h, int32_t index, float *out_xyzi, int64_t max_
     RSX_HIP(hipStreamSynchronize(h->stream));
   }
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_loop_verify_default_params(rsx_loop_verify_params *p) {
+int rsx_loop_verify_default_params(rsx_loop_verify_params *p) try {
   if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
   p->history_keyframe_search_num = 25;  // PGO.cpp:358
   p->leaf = 0.4f;                       // PGO.cpp:687-689
   p->fitness_threshold = 0.3;           // PGO.cpp:384
   rsx_icp_default_params(&p->icp);      // PGO.cpp:374-378
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_loop_submap(rsx_kfstore *h, int32_t key, int32_t submap_size, const double *root_pose6, float leaf, float *out_xyzi,
-                    int64_t max_out, int64_t *out_count) {
+                    int64_t max_out, int64_t *out_count) try {
   if (!h || !root_pose6 || !out_count || (!out_xyzi && max_out > 0)) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (submap_size < 0 || !(leaf > 0.0f)) return fail(RSX_ERR_BAD_ARG, "bad submap size / leaf");
   std::lock_guard<std::mutex> lk(h->mu);
@@ -333,10 +325,10 @@ int rsx_loop_submap(rsx_kfstore *h, int32_t key, int32_t submap_size, const doub
     RSX_HIP(hipStreamSynchronize(h->stream));
   }
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_loop_verify(rsx_kfstore *h, int32_t loop_idx, int32_t curr_idx, const double *root_pose6, const rsx_loop_verify_params *params,
-                    rsx_loop_verify_result *out) {
+                    rsx_loop_verify_result *out) try {
   if (!h || !root_pose6 || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
   rsx_loop_verify_params p;
   rsx_loop_verify_default_params(&p);
@@ -387,7 +379,7 @@ int rsx_loop_verify(rsx_kfstore *h, int32_t loop_idx, int32_t curr_idx, const do
   out->relative[12] = out->relative[13] = out->relative[14] = 0.0;
   out->relative[15] = 1.0;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_kfstore_build_map(rsx_kfstore *h, const double *poses6, int64_t n_poses, int32_t skip_frames, float leaf, float *out_xyzi,
                           int64_t max_out, int64_t *out_count) try {
@@ -436,10 +428,6 @@ int rsx_kfstore_build_map(rsx_kfstore *h, const double *poses6, int64_t n_poses,
     }
   }
   return RSX_OK;
-} catch (const std::bad_alloc &) {
-  return fail(RSX_ERR_OOM, "host alloc");
-} catch (...) {
-  return fail(RSX_ERR_INTERNAL, "unexpected exception");
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"

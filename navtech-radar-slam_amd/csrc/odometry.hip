@@ -225,7 +225,7 @@ int check_layout(rsx_odometry *h, int32_t n, int64_t image_stride_bytes, int32_t
 
 extern "C" {
 
-int rsx_odometry_default_params(rsx_odometry_params *p) {
+int rsx_odometry_default_params(rsx_odometry_params *p) try {
   if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
   std::memset(p, 0, sizeof(*p));
   rsx_cen2019_default_params(&p->cen);
@@ -236,9 +236,9 @@ int rsx_odometry_default_params(rsx_odometry_params *p) {
   p->max_keypoints = 16384;  // = rsx_orora_max_correspondences(): a pair can never exceed the solver's capacity
   p->device = 0;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t cols, rsx_odometry **out) {
+int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t cols, rsx_odometry **out) try {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
   *out = nullptr;
   rsx_odometry_params p;
@@ -270,9 +270,9 @@ int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_odometry_destroy(rsx_odometry *h) {
+int rsx_odometry_destroy(rsx_odometry *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -289,19 +289,19 @@ int rsx_odometry_destroy(rsx_odometry *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_odometry_reset(rsx_odometry *h) {
+int rsx_odometry_reset(rsx_odometry *h) try {
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
   h->have_prev = false;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_odometry_window(void) { return MAX_WINDOW; }
 
 int rsx_odometry_push_device(rsx_odometry *h, const uint8_t *d_imgs, int32_t n_scans, int64_t image_stride_bytes, int32_t row_stride,
-                             const float *azimuths, int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy) {
+                             const float *azimuths, int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy) try {
   if (!h || !d_imgs || !azimuths || !out || n_scans < 0 || max_xy < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n_scans == 0) return RSX_OK;
   RSX_TRY(check_layout(h, n_scans, image_stride_bytes, row_stride));
@@ -316,10 +316,10 @@ int rsx_odometry_push_device(rsx_odometry *h, const uint8_t *d_imgs, int32_t n_s
                        out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy, s));
   }
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int64_t image_stride_bytes, int32_t row_stride,
-                      const float *azimuths, int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy) {
+                      const float *azimuths, int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy) try {
   if (!h || !imgs || !azimuths || !out || n_scans < 0 || max_xy < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n_scans == 0) return RSX_OK;
   RSX_TRY(check_layout(h, n_scans, image_stride_bytes, row_stride));
@@ -358,19 +358,19 @@ int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int
     RSX_TRY(finish_window(h, n, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy, s));
   }
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_host_alloc_pinned(size_t bytes, void **out) {
+int rsx_host_alloc_pinned(size_t bytes, void **out) try {
   if (!out || bytes == 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   *out = nullptr;
   if (rsx_device_count() <= 0) return fail(RSX_ERR_NO_DEVICE, "no HIP device visible (librsx has no CPU fallback)");
   RSX_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_host_free_pinned(void *p) {
+int rsx_host_free_pinned(void *p) try {
   if (p) RSX_HIP(hipHostFree(p));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"

@@ -771,7 +771,7 @@ using rsx::fail;
 
 extern "C" {
 
-int rsx_orora_default_params(rsx_orora_params *p) {
+int rsx_orora_default_params(rsx_orora_params *p) try {
   if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
   p->tim_noise_bound = 2.0 * 0.75;
   p->noise_bound_radial = 0.3536;
@@ -781,11 +781,11 @@ int rsx_orora_default_params(rsx_orora_params *p) {
   p->max_iterations = 100;
   p->flags = 0;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_orora_max_correspondences(void) { return MAXK_BIG; }
 
-int rsx_orora_create(int device, rsx_orora **out) {
+int rsx_orora_create(int device, rsx_orora **out) try {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
   *out = nullptr;
   int ndev = rsx_device_count();
@@ -802,9 +802,9 @@ int rsx_orora_create(int device, rsx_orora **out) {
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_orora_destroy(rsx_orora *h) {
+int rsx_orora_destroy(rsx_orora *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -817,10 +817,10 @@ int rsx_orora_destroy(rsx_orora *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_orora_register_batch_device(rsx_orora *h, const float *d_src_xy, const float *d_dst_xy, const int64_t *d_offsets,
-                                    int32_t n_pairs, const rsx_orora_params *params, rsx_orora_result *d_out, void *stream) {
+                                    int32_t n_pairs, const rsx_orora_params *params, rsx_orora_result *d_out, void *stream) try {
   if (!h || !d_src_xy || !d_dst_xy || !d_offsets || !d_out || n_pairs < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n_pairs == 0) return RSX_OK;
   rsx_orora_params dp;
@@ -869,10 +869,10 @@ int rsx_orora_register_batch_device(rsx_orora *h, const float *d_src_xy, const f
   }
 #endif
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_orora_register_batch(rsx_orora *h, const float *src_xy, const float *dst_xy, const int64_t *offsets, int32_t n_pairs,
-                             const rsx_orora_params *params, rsx_orora_result *out) {
+                             const rsx_orora_params *params, rsx_orora_result *out) try {
   if (!h || !src_xy || !dst_xy || !offsets || !out || n_pairs < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n_pairs == 0) return RSX_OK;
   const int64_t m = offsets[n_pairs];
@@ -897,6 +897,6 @@ int rsx_orora_register_batch(rsx_orora *h, const float *src_xy, const float *dst
   RSX_HIP(hipMemcpyAsync(out, h->res.p, (size_t)n_pairs * sizeof(rsx_orora_result), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"

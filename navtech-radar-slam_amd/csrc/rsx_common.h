@@ -5,6 +5,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <new>
+#include <stdexcept>
 #include <string>
 
 #include "rsx.h"
@@ -33,6 +35,36 @@ inline const char *exp_env(const char *name) {
   return nullptr;
 #endif
 }
+
+// Exception firewall of the C-ABI ("no C++ exceptions cross the ABI"; the reference lets nanoflann's
+// std::runtime_error escape, NF.hpp:1228,1324).  EVERY extern "C" entry that returns a status is a function-try-block
+//     int rsx_xxx(...) try { ... } RSX_CATCH_ALL
+// so a std::bad_alloc from a host container (std::vector growth, new), a std::system_error from a mutex or anything else
+// thrown below comes back as a status with rsx_last_error_string() set.
+inline int on_exception() noexcept {
+  int code = RSX_ERR_INTERNAL;
+  try {
+    try {
+      throw;
+    } catch (const std::bad_alloc &) {
+      code = RSX_ERR_OOM;
+      return fail(code, "host allocation failed (std::bad_alloc)");
+    } catch (const std::length_error &e) {
+      code = RSX_ERR_OOM;
+      return fail(code, "host allocation failed (%s)", e.what());
+    } catch (const std::exception &e) {
+      return fail(code, "unexpected exception: %s", e.what());
+    } catch (...) {
+      return fail(code, "unexpected exception");
+    }
+  } catch (...) {  // (recording the message itself failed)
+    return code;
+  }
+}
+#define RSX_CATCH_ALL \
+  catch (...) {       \
+    return rsx::on_exception(); \
+  }
 
 #define RSX_HIP(expr)                                                                         \
   do {                                                                                        \

@@ -558,11 +558,11 @@ const char *rsx_version(void) {
 #endif
 }
 
-int rsx_device_count(void) {
+int rsx_device_count(void) try {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
-}
+} RSX_CATCH_ALL
 
 const char *rsx_sc_dominant_kernel_name(void) { return pair_kernel_name(); }
 
@@ -572,7 +572,7 @@ const char *rsx_sc_profiled_kernel_name(rsx_sc *h) {
   return h->prof_kernel;
 }
 
-int rsx_sc_default_params(rsx_sc_params *p) {
+int rsx_sc_default_params(rsx_sc_params *p) try {
   if (!p) return fail(RSX_ERR_BAD_ARG, "null params");
   p->lidar_height = 2.0;
   p->max_radius = 80.0;
@@ -588,9 +588,9 @@ int rsx_sc_default_params(rsx_sc_params *p) {
   p->filter_mode = 0;
   p->filter_kind = 0;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) {
+int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) try {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
   *out = nullptr;
   rsx_sc_params d;
@@ -624,9 +624,9 @@ int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) {
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_destroy(rsx_sc *h) {
+int rsx_sc_destroy(rsx_sc *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -643,30 +643,30 @@ int rsx_sc_destroy(rsx_sc *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_set_dist_thres(rsx_sc *h, double thres) {
+int rsx_sc_set_dist_thres(rsx_sc *h, double thres) try {
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
   h->p.dist_thres = thres;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_size(rsx_sc *h, int64_t *n) {
+int rsx_sc_size(rsx_sc *h, int64_t *n) try {
   if (!h || !n) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   *n = h->n_global;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_local_size(rsx_sc *h, int64_t *n) {
+int rsx_sc_local_size(rsx_sc *h, int64_t *n) try {
   if (!h || !n) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   *n = h->n_local;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_ringkey_tree_layout(const float *keys20, int64_t n, int32_t *out_vind, int32_t *out_n_nodes, int32_t *out_depth) {
+int rsx_sc_ringkey_tree_layout(const float *keys20, int64_t n, int32_t *out_vind, int32_t *out_n_nodes, int32_t *out_depth) try {
   if (!keys20 || !out_vind || n < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   KdTreeHost host;
   RSX_TRY(kdtree_build_host(keys20, n, &host));
@@ -674,16 +674,16 @@ int rsx_sc_ringkey_tree_layout(const float *keys20, int64_t n, int32_t *out_vind
   if (out_n_nodes) *out_n_nodes = (int32_t)host.nodes.size();
   if (out_depth) *out_depth = host.depth;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_tree_size(rsx_sc *h, int64_t *n) {
+int rsx_sc_tree_size(rsx_sc *h, int64_t *n) try {
   if (!h || !n) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   *n = h->tree_size;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index) {
+int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index) try {
   if (!h || (!pts && n)) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
   std::lock_guard<std::mutex> lk(h->mu);
@@ -704,10 +704,10 @@ int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes,
   h->n_global = g + 1;
   if (out_index) *out_index = (int32_t)g;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_sc_add_points_downsampled(rsx_sc *h, rsx_voxelgrid *vg, const void *pts, size_t n, size_t stride_bytes, float leaf,
-                                  int32_t *out_index) {
+                                  int32_t *out_index) try {
   if (!h || !vg || (!pts && n)) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
   if (!(leaf > 0.0f)) return fail(RSX_ERR_BAD_ARG, "leaf must be positive");
@@ -733,10 +733,10 @@ int rsx_sc_add_points_downsampled(rsx_sc *h, rsx_voxelgrid *vg, const void *pts,
   h->n_global = g + 1;
   if (out_index) *out_index = (int32_t)g;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_sc_add_keyframe(rsx_sc *h, rsx_voxelgrid *vg, rsx_kfstore *kf, const void *pts, size_t n, size_t stride_bytes,
-                        int32_t intensity_offset, float leaf, int32_t *out_index) {
+                        int32_t intensity_offset, float leaf, int32_t *out_index) try {
   if (!h || !vg || !kf || (!pts && n)) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
   if (intensity_offset >= 0 && ((intensity_offset & 3) || (size_t)intensity_offset + 4 > stride_bytes))
@@ -769,7 +769,7 @@ int rsx_sc_add_keyframe(rsx_sc *h, rsx_voxelgrid *vg, rsx_kfstore *kf, const voi
   h->n_global = g + 1;
   if (out_index) *out_index = (int32_t)g;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 static int add_f32_locked(rsx_sc *h, const float *src, int64_t n, bool src_is_device, hipStream_t s) {
   // n consecutive global keyframes starting at h->n_global; copy the owned rows
@@ -815,32 +815,32 @@ static int add_descriptor_f64(rsx_sc *h, const double *desc, bool allow_rounding
   return RSX_OK;
 }
 
-int rsx_sc_add_descriptor(rsx_sc *h, const double *desc, int32_t *out_index) {
+int rsx_sc_add_descriptor(rsx_sc *h, const double *desc, int32_t *out_index) try {
   return add_descriptor_f64(h, desc, false, out_index, nullptr);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_add_descriptor_rounded(rsx_sc *h, const double *desc, int32_t *out_index, double *max_abs_rounding) {
+int rsx_sc_add_descriptor_rounded(rsx_sc *h, const double *desc, int32_t *out_index, double *max_abs_rounding) try {
   return add_descriptor_f64(h, desc, true, out_index, max_abs_rounding);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_add_descriptors_f32(rsx_sc *h, const float *descs, int64_t n) {
+int rsx_sc_add_descriptors_f32(rsx_sc *h, const float *descs, int64_t n) try {
   if (!h || (!descs && n) || n < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n == 0) return RSX_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   return add_f32_locked(h, descs, n, false, h->stream);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_add_descriptors_f32_device(rsx_sc *h, const float *d_descs, int64_t n, void *stream) {
+int rsx_sc_add_descriptors_f32_device(rsx_sc *h, const float *d_descs, int64_t n, void *stream) try {
   if (!h || (!d_descs && n) || n < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n == 0) return RSX_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   return add_f32_locked(h, d_descs, n, true, s);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_export_descriptors_f32(rsx_sc *h, int64_t first_slot, int64_t count, float *out) {
+int rsx_sc_export_descriptors_f32(rsx_sc *h, int64_t first_slot, int64_t count, float *out) try {
   if (!h || (!out && count)) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   if (first_slot < 0 || count < 0 || first_slot + count > h->n_local) return fail(RSX_ERR_RANGE, "slot range out of bounds");
@@ -850,7 +850,7 @@ int rsx_sc_export_descriptors_f32(rsx_sc *h, int64_t first_slot, int64_t count, 
                          h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 // ---- on-disk database.  Little-endian; 64-byte header, then n_local fp32 sector-major
 // descriptors of 4800 B in slot order.  Keys, norms and filter images are derived data: rebuilt on load.
@@ -869,7 +869,7 @@ struct DbFileHeader {
 static_assert(sizeof(DbFileHeader) == 64, "header layout");
 }  // namespace
 
-int rsx_sc_save(rsx_sc *h, const char *path) {
+int rsx_sc_save(rsx_sc *h, const char *path) try {
   if (!h || !path) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
@@ -895,9 +895,9 @@ int rsx_sc_save(rsx_sc *h, const char *path) {
   ok = (std::fclose(f) == 0) && ok;
   if (!ok) return fail(RSX_ERR_INTERNAL, "short write to %s", path);
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_load(rsx_sc *h, const char *path, int64_t *n_loaded) {
+int rsx_sc_load(rsx_sc *h, const char *path, int64_t *n_loaded) try {
   if (!h || !path) return fail(RSX_ERR_BAD_ARG, "null arg");
   FILE *f = std::fopen(path, "rb");
   if (!f) return fail(RSX_ERR_BAD_ARG, "cannot open %s", path);
@@ -952,7 +952,7 @@ int rsx_sc_load(rsx_sc *h, const char *path, int64_t *n_loaded) {
   }
   if (n_loaded) *n_loaded = hd.n_local;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 static int local_slot_of(rsx_sc *h, int64_t index, int64_t *slot) {
   if (index < 0 || index >= h->n_global) return fail(RSX_ERR_RANGE, "index %lld out of range [0,%lld)", (long long)index, (long long)h->n_global);
@@ -962,7 +962,7 @@ static int local_slot_of(rsx_sc *h, int64_t index, int64_t *slot) {
   return RSX_OK;
 }
 
-int rsx_sc_get_descriptor(rsx_sc *h, int64_t index, double *out) {
+int rsx_sc_get_descriptor(rsx_sc *h, int64_t index, double *out) try {
   if (!h || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
@@ -973,9 +973,9 @@ int rsx_sc_get_descriptor(rsx_sc *h, int64_t index, double *out) {
   RSX_HIP(hipStreamSynchronize(h->stream));
   for (int i = 0; i < DS; i++) out[i] = (double)f[i];
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_get_ringkey(rsx_sc *h, int64_t index, float *out20) {
+int rsx_sc_get_ringkey(rsx_sc *h, int64_t index, float *out20) try {
   if (!h || !out20) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
@@ -984,9 +984,9 @@ int rsx_sc_get_ringkey(rsx_sc *h, int64_t index, float *out20) {
   RSX_HIP(hipMemcpyAsync(out20, h->rkey.as<float>() + slot * NR, NR * sizeof(float), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_get_sectorkey(rsx_sc *h, int64_t index, double *out60) {
+int rsx_sc_get_sectorkey(rsx_sc *h, int64_t index, double *out60) try {
   if (!h || !out60) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
@@ -995,9 +995,9 @@ int rsx_sc_get_sectorkey(rsx_sc *h, int64_t index, double *out60) {
   RSX_HIP(hipMemcpyAsync(out60, h->vkey.as<double>() + slot * NS, NS * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out) {
+int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out) try {
   if (!h || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (mode != RSX_SC_MODE_CANDIDATE && mode != RSX_SC_MODE_EXHAUSTIVE) return fail(RSX_ERR_BAD_ARG, "bad mode %d", mode);
   std::unique_lock<std::mutex> lk(h->mu);
@@ -1028,9 +1028,9 @@ int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out) {
   out->searched = 1;
   return score_candidates_and_finish(h, qv, h->rkey.as<float>() + (N - 1) * NR /* SC.cpp:335 */, n_search, &h->tree, mode,
                                      &out->loop_id, &out->yaw_diff_rad, &out->min_dist, &out->nn_idx);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw, double *min_dist, int32_t *nn_idx) {
+int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw, double *min_dist, int32_t *nn_idx) try {
   rsx_sc_detection d;
   RSX_TRY(rsx_sc_detect_loop_closure_ex(h, mode, &d));
   if (loop_id) *loop_id = d.loop_id;
@@ -1038,7 +1038,7 @@ int rsx_sc_detect_loop_closure(rsx_sc *h, int mode, int32_t *loop_id, float *yaw
   if (min_dist) *min_dist = d.min_dist;
   if (nn_idx) *nn_idx = d.nn_idx;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 // ---- Scancontext.h:60-66: the public helper methods, stateless, on arbitrary double descriptors ----
 static int helper_call(rsx_sc *h, int op, const double *a, size_t na, const double *b, size_t nb, double *out_d, size_t nd,
@@ -1058,31 +1058,31 @@ static int helper_call(rsx_sc *h, int op, const double *a, size_t na, const doub
   return RSX_OK;
 }
 
-int rsx_sc_make_keys(rsx_sc *h, const double *desc, double *out_ringkey20, double *out_sectorkey60) {
+int rsx_sc_make_keys(rsx_sc *h, const double *desc, double *out_ringkey20, double *out_sectorkey60) try {
   if (!h || !desc) return fail(RSX_ERR_BAD_ARG, "null arg");
   double o[NR + NS];
   RSX_TRY(helper_call(h, 0, desc, DS, nullptr, 0, o, NR + NS, nullptr));
   if (out_ringkey20) std::memcpy(out_ringkey20, o, NR * sizeof(double));
   if (out_sectorkey60) std::memcpy(out_sectorkey60, o + NR, NS * sizeof(double));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_dist_direct(rsx_sc *h, const double *sc1, const double *sc2, double *out_dist) {
+int rsx_sc_dist_direct(rsx_sc *h, const double *sc1, const double *sc2, double *out_dist) try {
   if (!h || !sc1 || !sc2 || !out_dist) return fail(RSX_ERR_BAD_ARG, "null arg");
   return helper_call(h, 1, sc1, DS, sc2, DS, out_dist, 1, nullptr);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_fast_align(rsx_sc *h, const double *vkey1, const double *vkey2, int32_t *out_shift) {
+int rsx_sc_fast_align(rsx_sc *h, const double *vkey1, const double *vkey2, int32_t *out_shift) try {
   if (!h || !vkey1 || !vkey2 || !out_shift) return fail(RSX_ERR_BAD_ARG, "null arg");
   return helper_call(h, 2, vkey1, NS, vkey2, NS, nullptr, 0, out_shift);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_distance(rsx_sc *h, const double *sc1, const double *sc2, double *out_dist, int32_t *out_shift) {
+int rsx_sc_distance(rsx_sc *h, const double *sc1, const double *sc2, double *out_dist, int32_t *out_shift) try {
   if (!h || !sc1 || !sc2 || !out_dist || !out_shift) return fail(RSX_ERR_BAD_ARG, "null arg");
   return helper_call(h, 3, sc1, DS, sc2, DS, out_dist, 1, out_shift);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_make_scancontext(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, double *out_desc) {
+int rsx_sc_make_scancontext(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, double *out_desc) try {
   if (!h || (!pts && n) || !out_desc) return fail(RSX_ERR_BAD_ARG, "null arg");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
   std::lock_guard<std::mutex> lk(h->mu);
@@ -1101,10 +1101,10 @@ int rsx_sc_make_scancontext(rsx_sc *h, const void *pts, size_t n, size_t stride_
   RSX_HIP(hipStreamSynchronize(s));
   for (int i = 0; i < DS; i++) out_desc[i] = (double)f[i];
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const double *curr_desc, int32_t *loop_id,
-                                  float *yaw, double *min_dist, int32_t *nn_idx) {
+                                  float *yaw, double *min_dist, int32_t *nn_idx) try {
   if (!h || !curr_key20 || !curr_desc) return fail(RSX_ERR_BAD_ARG, "null arg");
   float f[DS];
   for (int i = 0; i < DS; i++) {
@@ -1128,7 +1128,7 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
   QueryView qv;
   RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), 1, s, &qv));
   return score_candidates_and_finish(h, qv, d_key, h->batch_size, &h->tree_batch, RSX_SC_MODE_CANDIDATE, loop_id, yaw, min_dist, nn_idx);
-}
+} RSX_CATCH_ALL
 
 static int query_device_locked(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out,
                                hipStream_t s) {
@@ -1138,15 +1138,15 @@ static int query_device_locked(rsx_sc *h, const float *d_q, int32_t nq, int32_t 
   return run_topk(h, qv, items, n_eligible < 0 ? h->n_global : n_eligible, nullptr, k, d_out, s);
 }
 
-int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out, void *stream) {
+int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out, void *stream) try {
   if (!h || !d_q || !d_out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   return query_device_locked(h, d_q, nq, k, n_eligible, d_out, stream ? static_cast<hipStream_t>(stream) : h->stream);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) {
+int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) try {
   if (!h || !q || !out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   // one lock for staging, query and read-back: two concurrent callers share q_desc / topk
@@ -1159,15 +1159,15 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
   RSX_HIP(hipMemcpyAsync(out, h->topk.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_sc_query_stage1_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible,
-                               rsx_sc_hit *d_partial, void *stream) {
+                               rsx_sc_hit *d_partial, void *stream) try {
   return rsx_sc_query_stage1_elig_device(h, d_q, nq, k, n_eligible, nullptr, 0, d_partial, stream);
-}
+} RSX_CATCH_ALL
 
 int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible,
-                                    const int64_t *d_q_elig, int32_t elig_monotone, rsx_sc_hit *d_partial, void *stream) {
+                                    const int64_t *d_q_elig, int32_t elig_monotone, rsx_sc_hit *d_partial, void *stream) try {
   if (!h || !d_q || !d_partial || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
@@ -1210,10 +1210,10 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
   h->st.q_elig = d_q_elig;
   h->st.qv = qv;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_sc_query_stage2_device(rsx_sc *h, int32_t nq, int32_t k, const rsx_sc_hit *d_global, rsx_sc_hit *d_out,
-                               void *stream) {
+                               void *stream) try {
   if (!h || !d_global || !d_out) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   if (!h->st.valid || h->st.nq != nq || h->st.k != k)
@@ -1226,10 +1226,10 @@ int rsx_sc_query_stage2_device(rsx_sc *h, int32_t nq, int32_t k, const rsx_sc_hi
                    h->st_partial.as<rsx_sc_hit>(), k, d_out, s);
   RSX_HIP(hipMemcpyAsync(d_out, h->st_partial.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToDevice, s));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, int64_t n_eligible, int32_t exclude_recent,
-                             rsx_sc_hit *d_out, void *stream) {
+                             rsx_sc_hit *d_out, void *stream) try {
   if (!h || !d_out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
@@ -1257,9 +1257,9 @@ int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, 
   }
   // the limits q_first + i - exclude_recent grow with i: the filter skips what a query cannot see
   return run_topk(h, qv, local_count_below(h, n_eligible), n_eligible, d_elig, k, d_out, s, /*elig_monotone=*/true);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t count, double *out_dist, int32_t *out_shift) {
+int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t count, double *out_dist, int32_t *out_shift) try {
   if (!h || !q_desc || !out_dist || !out_shift) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   if (first < 0 || count < 0 || first + count > h->n_local) return fail(RSX_ERR_RANGE, "range out of bounds");
@@ -1278,9 +1278,9 @@ int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t
   RSX_HIP(hipMemcpyAsync(out_shift, d_shift, (size_t)count * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out_lb) {
+int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out_lb) try {
   if (!h || !q_descs || !out_lb || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
@@ -1299,12 +1299,12 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
                            (size_t)nq, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 double rsx_sc_filter_eps(void) { return filter_eps(); }
 
 int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t k, int32_t *out_slots, float *out_pv,
-                           int32_t *out_kstar, int32_t *out_shift_mask, int32_t *out_counts) {
+                           int32_t *out_kstar, int32_t *out_shift_mask, int32_t *out_counts) try {
   if (!h || !q_descs || !out_slots || !out_pv || !out_kstar || !out_shift_mask || !out_counts || nq < 1)
     return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
@@ -1340,9 +1340,23 @@ int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t 
     }
   }
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out) {
+int rsx_selftest_firewall(int kind) try {
+  if (kind == 0) {
+    std::vector<double> v;
+    v.reserve(v.max_size() + 1);  // std::length_error
+  } else if (kind == 1) {
+    throw std::bad_alloc();
+  } else if (kind == 2) {
+    throw std::runtime_error("KDTreeSingleIndexAdaptor: selftest");
+  } else if (kind == 3) {
+    throw 42;
+  }
+  return RSX_OK;
+} RSX_CATCH_ALL
+
+int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out) try {
   if (!parts || !out || nparts < 1 || nq < 1 || k < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   for (int q = 0; q < nq; q++) {
     rsx_sc_hit *o = out + (size_t)q * k;
@@ -1366,18 +1380,18 @@ int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32
     }
   }
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_sc_merge_topk_device(rsx_sc *h, const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t k,
-                             rsx_sc_hit *d_out, void *stream) {
+                             rsx_sc_hit *d_out, void *stream) try {
   if (!h || !d_parts || !d_out || nparts < 1 || nq < 1 || k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "bad arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   return launch_merge(d_parts, nparts, nq, k, d_out, s);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_profile_enable(rsx_sc *h, int on) {
+int rsx_sc_profile_enable(rsx_sc *h, int on) try {
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
@@ -1394,14 +1408,14 @@ int rsx_sc_profile_enable(rsx_sc *h, int on) {
   h->prof.on = on != 0;
   h->prof.used = 0;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored) {
+int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored) try {
   int64_t cands = 0;
   return rsx_sc_profile_read_rescoring2(h, &cands, exact_evals, queries_rescored);
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored) {
+int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored) try {
   if (!h || !candidates || !exact_evals || !queries_rescored) return fail(RSX_ERR_BAD_ARG, "null arg");
   int64_t v[6];
   RSX_TRY(rsx_sc_profile_read_rescoring3(h, v));
@@ -1409,9 +1423,9 @@ int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exac
   *exact_evals = v[1];
   *queries_rescored = v[2];
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out6) {
+int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out6) try {
   if (!h || !out6) return fail(RSX_ERR_BAD_ARG, "null arg");
   int64_t *const out5 = out6;
   int64_t *candidates = out5, *exact_evals = out5 + 1, *queries_rescored = out5 + 2;
@@ -1441,9 +1455,9 @@ int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out6) {
   out5[4] = (int64_t)v[11];  // candidates that went through the VALU alignment + fp32 preview / exact alignments (wave kernel)
   out6[5] = v[12] ? (int64_t)v[12] : 7 * *exact_evals;  // window shifts evaluated exactly (7 per evaluation without a shift mask)
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms) {
+int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms) try {
   if (!h || !launches || !total_ms) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
@@ -1458,14 +1472,14 @@ int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms) {
   }
   h->prof.used = 0;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float *yaw) {
+int rsx_sc_hit_to_loop(rsx_sc *h, const rsx_sc_hit *hit, int32_t *loop_id, float *yaw) try {
   if (!h || !hit) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   if (loop_id) *loop_id = (hit->dist < h->p.dist_thres) ? hit->index : -1;  // SC.cpp:401-403
   if (yaw) *yaw = yaw_from_shift(hit->shift);                               // SC.cpp:417
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"

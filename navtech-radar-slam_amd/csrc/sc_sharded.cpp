@@ -247,7 +247,7 @@ int query_locked(rsx_scs *h, const float *q, int32_t nq, int32_t k, int64_t n_el
 extern "C" {
 
 int rsx_scs_create_layout(const rsx_sc_params *p, const int32_t *devices, int32_t n_devices, int32_t query_groups, int32_t exchange_kind,
-                          rsx_scs **out) {
+                          rsx_scs **out) try {
   if (!out || !devices || n_devices < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   *out = nullptr;
   if (query_groups < 1 || n_devices % query_groups) return fail(RSX_ERR_BAD_ARG, "query_groups %d does not divide %d devices", query_groups, n_devices);
@@ -324,13 +324,13 @@ int rsx_scs_create_layout(const rsx_sc_params *p, const int32_t *devices, int32_
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_scs_create(const rsx_sc_params *p, const int32_t *devices, int32_t n_devices, rsx_scs **out) {
+int rsx_scs_create(const rsx_sc_params *p, const int32_t *devices, int32_t n_devices, rsx_scs **out) try {
   return rsx_scs_create_layout(p, devices, n_devices, 1, RSX_SCS_EXCHANGE_PEER_COPY, out);
-}
+} RSX_CATCH_ALL
 
-int rsx_scs_destroy(rsx_scs *h) {
+int rsx_scs_destroy(rsx_scs *h) try {
   if (!h) return RSX_OK;
   for (Shard &s : h->sh) {
     (void)hipSetDevice(s.device);
@@ -349,59 +349,59 @@ int rsx_scs_destroy(rsx_scs *h) {
   }
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_scs_num_shards(rsx_scs *h) { return h ? h->n_shards : 0; }
 int rsx_scs_num_query_groups(rsx_scs *h) { return h ? (int)h->gr.size() : 0; }
 
-int rsx_scs_set_dist_thres(rsx_scs *h, double thres) {
+int rsx_scs_set_dist_thres(rsx_scs *h, double thres) try {
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
   h->p.dist_thres = thres;
   for (Shard &s : h->sh) RSX_TRY(rsx_sc_set_dist_thres(s.h, thres));
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_scs_size(rsx_scs *h, int64_t *n_global) {
+int rsx_scs_size(rsx_scs *h, int64_t *n_global) try {
   if (!h || !n_global) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   return rsx_sc_size(h->sh[0].h, n_global);
-}
+} RSX_CATCH_ALL
 
 // every shard sees every keyframe (the owner builds and stores it, the others advance their count)
-int rsx_scs_add_points(rsx_scs *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index) {
+int rsx_scs_add_points(rsx_scs *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index) try {
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
   int32_t idx = 0;
   RSX_TRY(add_to_all(h, [&](Shard &s) { return rsx_sc_add_points(s.h, pts, n, stride_bytes, &idx); }));
   if (out_index) *out_index = idx;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_scs_add_descriptors_f32(rsx_scs *h, const float *descs, int64_t n) {
+int rsx_scs_add_descriptors_f32(rsx_scs *h, const float *descs, int64_t n) try {
   if (!h) return fail(RSX_ERR_BAD_ARG, "null handle");
   std::lock_guard<std::mutex> lk(h->mu);
   return add_to_all(h, [&](Shard &s) { return rsx_sc_add_descriptors_f32(s.h, descs, n); });
-}
+} RSX_CATCH_ALL
 
-int rsx_scs_get_descriptor(rsx_scs *h, int64_t index, double *out_colmajor) {
+int rsx_scs_get_descriptor(rsx_scs *h, int64_t index, double *out_colmajor) try {
   if (!h || !out_colmajor) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   if (index < 0) return fail(RSX_ERR_RANGE, "index %lld out of range", (long long)index);
   return rsx_sc_get_descriptor(h->sh[(size_t)(index % (int64_t)h->n_shards)].h, index, out_colmajor);  // query group 0's copy
-}
+} RSX_CATCH_ALL
 
-int rsx_scs_query(rsx_scs *h, const float *q_descs, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) {
+int rsx_scs_query(rsx_scs *h, const float *q_descs, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) try {
   if (!h || !q_descs || !out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(usable(h));
   return query_locked(h, q_descs, nq, k, n_eligible, out);
-}
+} RSX_CATCH_ALL
 
 // detectLoopClosureID (SC.cpp:331-422) over the sharded database, exhaustive mode: the frozen
 // searchable prefix and the 30-keyframe exclusion are the reference's; every entry of the prefix is scored.
-int rsx_scs_detect_loop_closure(rsx_scs *h, rsx_sc_detection *out) {
+int rsx_scs_detect_loop_closure(rsx_scs *h, rsx_sc_detection *out) try {
   if (!h || !out) return fail(RSX_ERR_BAD_ARG, "null arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(usable(h));
@@ -432,6 +432,6 @@ int rsx_scs_detect_loop_closure(rsx_scs *h, rsx_sc_detection *out) {
   RSX_TRY(rsx_sc_hit_to_loop(h->sh[0].h, &hit, &out->loop_id, &out->yaw_diff_rad));                  // SC.cpp:401-417
   if (!(hit.dist < 10000000)) out->yaw_diff_rad = 0.0f;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"

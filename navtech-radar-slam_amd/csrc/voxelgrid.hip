@@ -257,7 +257,7 @@ int device_of(rsx_voxelgrid *h) { return h->device; }
 
 extern "C" {
 
-int rsx_voxelgrid_create(int device, rsx_voxelgrid **out) {
+int rsx_voxelgrid_create(int device, rsx_voxelgrid **out) try {
   if (!out) return fail(RSX_ERR_BAD_ARG, "null out");
   *out = nullptr;
   int ndev = rsx_device_count();
@@ -274,9 +274,9 @@ int rsx_voxelgrid_create(int device, rsx_voxelgrid **out) {
   }
   *out = h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
-int rsx_voxelgrid_destroy(rsx_voxelgrid *h) {
+int rsx_voxelgrid_destroy(rsx_voxelgrid *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -285,10 +285,10 @@ int rsx_voxelgrid_destroy(rsx_voxelgrid *h) {
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 int rsx_voxelgrid_filter(rsx_voxelgrid *h, const void *pts, size_t n, size_t stride_bytes, int32_t intensity_offset, float leaf,
-                         float *out_xyzi, int64_t max_out, int64_t *out_count) {
+                         float *out_xyzi, int64_t max_out, int64_t *out_count) try {
   if (!h || (!pts && n) || !out_count || (!out_xyzi && max_out > 0) || max_out < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (stride_bytes < 12 || (stride_bytes & 3)) return fail(RSX_ERR_BAD_ARG, "stride_bytes must be >= 12 and a multiple of 4");
   if (intensity_offset >= 0 && ((intensity_offset & 3) || (size_t)intensity_offset + 4 > stride_bytes))
@@ -305,6 +305,6 @@ int rsx_voxelgrid_filter(rsx_voxelgrid *h, const void *pts, size_t n, size_t str
   }
   *out_count = cnt;
   return RSX_OK;
-}
+} RSX_CATCH_ALL
 
 }  // extern "C"

@@ -123,3 +123,44 @@ def test_ringkey_tree_layout_matches_oracle(rsx, oracle):
             assert np.array_equal(vind.astype(np.int64), want), (n, kind)
             assert sorted(vind.tolist()) == list(range(n)) and nn.value >= 1 and 1 <= depth.value <= 64
     assert L.rsx_sc_ringkey_tree_layout(None, 1, None, None, None) != 0
+
+
+def test_exception_firewall_is_on_every_status_entry():
+    """no C++ exception crosses the C-ABI.  Every `int rsx_*(...)` definition under csrc/ is a function-try-block
+    closed by RSX_CATCH_ALL (rsx_common.h): static check over the sources."""
+    import glob
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "navtech-radar-slam_amd", "csrc")
+    n = 0
+    for f in sorted(glob.glob(os.path.join(csrc, "*.cpp")) + glob.glob(os.path.join(csrc, "*.hip"))):
+        lines = open(f).read().split("\n")
+        for i, line in enumerate(lines):
+            if not re.match(r"^int rsx_\w+\(", line):
+                continue
+            j = i
+            while not lines[j].rstrip().endswith("{") and not lines[j].rstrip().endswith(";"):
+                j += 1
+            if lines[j].rstrip().endswith(";"):
+                continue                        # a declaration
+            assert lines[j].rstrip().endswith("try {"), f"{os.path.basename(f)}:{i + 1}: {line}"
+            k = j + 1
+            while not lines[k].startswith("}"):
+                k += 1
+            assert lines[k].startswith("} RSX_CATCH_ALL"), f"{os.path.basename(f)}:{k + 1}"
+            n += 1
+    assert n >= 100
+
+
+def test_exceptions_thrown_inside_the_library_come_back_as_statuses(rsx):
+    """rsx_selftest_firewall throws inside an extern "C" entry: an impossible std::vector size (std::length_error), a
+    std::bad_alloc, a std::runtime_error (what nanoflann throws through the reference's SCManager, NF.hpp:1228,1324) and a
+    non-std exception.  Each returns a status and a message; the process lives and the library keeps working."""
+    L = rsx.lib()
+    for kind, want, word in ((0, -4, b"allocation"), (1, -4, b"bad_alloc"), (2, -7, b"KDTreeSingleIndexAdaptor"), (3, -7, b"unexpected")):
+        assert L.rsx_selftest_firewall(kind) == want, kind
+        assert word in L.rsx_last_error_string(), (kind, L.rsx_last_error_string())
+    assert L.rsx_selftest_firewall(99) == 0
+    keys = np.zeros((4, 20), dtype=np.float32)
+    vind = np.zeros(4, dtype=np.int32)
+    assert L.rsx_sc_ringkey_tree_layout(keys.ctypes.data, C.c_int64(1 << 61), vind.ctypes.data, None, None) == -1   # refused, not thrown
+    assert L.rsx_sc_ringkey_tree_layout(keys.ctypes.data, C.c_int64(4), vind.ctypes.data, None, None) == 0
+    assert sorted(vind.tolist()) == [0, 1, 2, 3]
