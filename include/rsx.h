@@ -435,9 +435,16 @@ int rsx_frontend_match(rsx_frontend *h, const uint8_t *q_desc, const uint8_t *q_
 
 /* the batched / device-resident forms of the three calls above (what rsx_odometry chains; usable on their own):
  * Cartesian images + smoothed copies of n_images scans resident in HBM, kept in the handle's slots 0 .. n_images-1
- * (azimuths: HOST array, rows floats, the grid of the first image: the pixel map is built on the host once) */
+ * (azimuths: HOST array, rows floats, ONE grid used for every image of the batch; per-image grids: the _az form below) */
 int rsx_frontend_cartesian_batch_device(rsx_frontend *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
                                         int32_t col_offset, const float *azimuths, float resolution, void *stream);
+/* the same with the azimuth grids in DEVICE memory, one per image: image i samples the grid at d_azimuths + i *
+ * azimuth_stride_floats (its first two entries give start and step; 0: one grid for every image).  MulRan scans carry their
+ * own encoder grid; a map built from the first scan's grid would rotate every other scan's Cartesian image against its own
+ * keypoints.  Nothing is read on the host: no synchronisation, whatever the grids do from window to window. */
+int rsx_frontend_cartesian_batch_device_az(rsx_frontend *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes,
+                                           int32_t row_stride, int32_t col_offset, const float *d_azimuths, int64_t azimuth_stride_floats,
+                                           float resolution, void *stream);
 /* descriptors of the keypoints of every image of that batch: d_xy [n_images][max_targets][2] and d_counts [n_images] as
  * rsx_cen2019_extract_batch_device leaves them -> d_desc [n_images][max_targets][32], d_valid [n_images][max_targets] */
 int rsx_frontend_describe_batch_device(rsx_frontend *h, const float *d_xy, const int32_t *d_counts, int32_t n_images, int32_t max_targets,

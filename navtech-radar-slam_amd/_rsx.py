@@ -127,7 +127,7 @@ SYMBOLS = [
     "rsx_cen2019_extract_batch", "rsx_cen2019_extract_batch_device",
     "rsx_frontend_default_params", "rsx_frontend_create", "rsx_frontend_destroy", "rsx_frontend_cartesian",
     "rsx_frontend_describe", "rsx_frontend_match",
-    "rsx_frontend_cartesian_batch_device", "rsx_frontend_describe_batch_device", "rsx_frontend_match_consecutive_device",
+    "rsx_frontend_cartesian_batch_device", "rsx_frontend_cartesian_batch_device_az", "rsx_frontend_describe_batch_device", "rsx_frontend_match_consecutive_device",
     "rsx_odometry_default_params", "rsx_odometry_create", "rsx_odometry_destroy", "rsx_odometry_reset", "rsx_odometry_window",
     "rsx_odometry_push", "rsx_odometry_push_device", "rsx_host_alloc_pinned", "rsx_host_free_pinned",
     "rsx_voxelgrid_create", "rsx_voxelgrid_destroy", "rsx_voxelgrid_filter", "rsx_sc_add_points_downsampled",

@@ -34,14 +34,28 @@ namespace {
 constexpr int HALF_PATCH = 15, NBINS = 30, NPAIRS = 256, BORDER = 19;
 
 // blockIdx.y = image of a batch (images img_stride bytes apart, Cartesian images W * W floats apart)
+// the (fractional) azimuth row a pixel at angle th (radians from "forward", in [0, 2 pi)) samples in an image whose
+// azimuth grid starts at az[0] with step az[1] - az[0]: (th - az0) / step wrapped into [0, rows), in double like the oracle
+// (frontend_ref.c) and like the host-built map of round 3 -- but PER IMAGE: a window of MulRan scans carries one encoder
+// grid per scan, and a map built from the first scan's grid rotates every other scan's Cartesian image against its
+// own keypoints (round-3 advisor finding)
+__device__ __forceinline__ float az_row_of(double th, const float *__restrict__ az, int rows) {
+  const double az0 = (double)az[0], st = (double)az[1] - az0;
+  double a = (th - az0) / st;
+  a = fmod(a, (double)rows);
+  if (a < 0) a += rows;
+  if (a >= rows) a -= rows;
+  return (float)a;
+}
+
 __global__ __launch_bounds__(256) void fe_remap(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int row_stride,
-                                                int col_offset, int W, const float *__restrict__ map_rb, const float *__restrict__ map_ab,
-                                                float *__restrict__ carts) {
+                                                int col_offset, int W, const float *__restrict__ map_rb, const double *__restrict__ map_th,
+                                                const float *__restrict__ az, int64_t az_stride, float *__restrict__ carts) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (int64_t)W * W) return;
   const uint8_t *img = imgs + (int64_t)blockIdx.y * img_stride;
   float *cart = carts + (int64_t)blockIdx.y * W * W;
-  const float rb = map_rb[i], ab = map_ab[i];
+  const float rb = map_rb[i], ab = az_row_of(map_th[i], az + (int64_t)blockIdx.y * az_stride, rows);
   const float r0f = floorf(rb), a0f = floorf(ab);
   const float fr = rb - r0f, fa = ab - a0f;
   const int r0 = (int)r0f;
@@ -87,8 +101,9 @@ __global__ __launch_bounds__(256) void fe_blur(const float *__restrict__ ins, in
 // scan drops from 3 writes + 2 reads of 3.7 MB to 2 writes.
 constexpr int FT = 32, FH = 3, FTS = FT + 2 * FH;
 __global__ __launch_bounds__(256) void fe_cart_fused(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int row_stride,
-                                                     int col_offset, int W, const float *__restrict__ map_rb, const float *__restrict__ map_ab,
-                                                     const float *__restrict__ g, float *__restrict__ carts, float *__restrict__ blurs) {
+                                                     int col_offset, int W, const float *__restrict__ map_rb, const double *__restrict__ map_th,
+                                                     const float *__restrict__ az, int64_t az_stride, const float *__restrict__ g,
+                                                     float *__restrict__ carts, float *__restrict__ blurs) {
   __shared__ float s_c[FTS][FTS + 1];
   __shared__ float s_t[FTS][FT + 1];
   __shared__ float s_tab[256];  // byte -> byte / 255 (correctly rounded once per block instead of four divisions per pixel)
@@ -111,7 +126,7 @@ __global__ __launch_bounds__(256) void fe_cart_fused(const uint8_t *__restrict__
     if (v < 0) v = 0;  // (tiles hanging far over the edge of a tiny image: values unused)
     if (u < 0) u = 0;
     const int64_t i = (int64_t)v * W + u;
-    const float rb = map_rb[i], ab = map_ab[i];
+    const float rb = map_rb[i], ab = az_row_of(map_th[i], az + (int64_t)blockIdx.z * az_stride, rows);
     const float r0f = floorf(rb), a0f = floorf(ab);
     const float fr = rb - r0f, fa = ab - a0f;
     const int r0 = (int)r0f;
@@ -377,9 +392,9 @@ struct rsx_frontend {
   double cart_res = 0.0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, map_rb, map_ab, cart, tmp, blur, tables, uv, desc, valid, q, qv, t, tv, m_idx, m_d1, m_d2, vidx, vcount;
+  rsx::DevBuf img, map_rb, map_th, az1, cart, tmp, blur, tables, uv, desc, valid, q, qv, t, tv, m_idx, m_d1, m_d2, vidx, vcount;
   // the map depends on the radar's range resolution and azimuth grid: rebuilt only when they change
-  double map_radar_res = -1.0, map_az0 = 0.0, map_az_step = 0.0;
+  double map_radar_res = -1.0;
   bool have_image = false;
   int batch_n = 0;  // Cartesian images held by the last rsx_frontend_cartesian* call
   bool three_pass = false;  // RSX_FRONTEND_THREE_PASS: remap and the two blur passes as separate kernels
@@ -471,7 +486,7 @@ int rsx_frontend_create(int device, int32_t rows, int32_t cols, const rsx_fronte
   }
   const size_t npx = (size_t)h->W * h->W;
   int st = RSX_OK;
-  for (rsx::DevBuf *b : {&h->map_rb, &h->map_ab, &h->cart, &h->tmp, &h->blur})
+  for (rsx::DevBuf *b : {&h->map_rb, &h->map_th, &h->cart, &h->tmp, &h->blur})
     if (st == RSX_OK) st = b->reserve(npx * sizeof(float), h->stream, false);
   if (st == RSX_OK) st = h->tables.reserve(TAB_BYTES, h->stream, false);
   if (st == RSX_OK) {
@@ -493,7 +508,7 @@ int rsx_frontend_destroy(rsx_frontend *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (rsx::DevBuf *b : {&h->img, &h->map_rb, &h->map_ab, &h->cart, &h->tmp, &h->blur, &h->tables, &h->uv, &h->desc, &h->valid, &h->q,
+  for (rsx::DevBuf *b : {&h->img, &h->map_rb, &h->map_th, &h->az1, &h->cart, &h->tmp, &h->blur, &h->tables, &h->uv, &h->desc, &h->valid, &h->q,
                          &h->qv, &h->t, &h->tv, &h->m_idx, &h->m_d1, &h->m_d2, &h->vidx, &h->vcount})
     b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -501,41 +516,37 @@ int rsx_frontend_destroy(rsx_frontend *h) try {
   return RSX_OK;
 } RSX_CATCH_ALL
 
-// (re)build the pixel -> (range bin, azimuth row) map when the radar's range resolution or azimuth grid changed
-static int ensure_map(rsx_frontend *h, const float *azimuths, float resolution, hipStream_t s) {
+// (re)build the pixel -> (range bin, angle) map when the radar's range resolution changed (the azimuth grid is applied
+// per image on the device: az_row_of)
+static int ensure_map(rsx_frontend *h, float resolution, hipStream_t s) {
   const int W = h->W;
   const size_t npx = (size_t)W * W;
-  const double az0 = (double)azimuths[0], az_step = (double)azimuths[1] - (double)azimuths[0];
-  if (!(az_step > 0.0)) return fail(RSX_ERR_BAD_ARG, "azimuths must increase");
-  if (h->map_radar_res == (double)resolution && h->map_az0 == az0 && h->map_az_step == az_step) return RSX_OK;
+  if (h->map_radar_res == (double)resolution) return RSX_OK;
   // in double on the host: forward = azimuth 0, azimuth grows to the right
-  std::vector<float> rb(npx), ab(npx);
+  std::vector<float> rb(npx);
+  std::vector<double> th(npx);
   const double cmr = cart_min_range(W, h->cart_res);
   for (int v = 0; v < W; v++)
     for (int u = 0; u < W; u++) {
       const double fwd = cmr - v * h->cart_res, right = -cmr + u * h->cart_res;
       const double r = std::sqrt(fwd * fwd + right * right);
-      double th = std::atan2(right, fwd);
-      if (th < 0) th += 2.0 * M_PI;
-      double a = (th - az0) / az_step;
-      a = std::fmod(a, (double)h->rows);
-      if (a < 0) a += h->rows;
-      if (a >= h->rows) a -= h->rows;
+      double t = std::atan2(right, fwd);
+      if (t < 0) t += 2.0 * M_PI;
       rb[(size_t)v * W + u] = (float)((r - (double)resolution / 2.0) / (double)resolution);
-      ab[(size_t)v * W + u] = (float)a;
+      th[(size_t)v * W + u] = t;
     }
+  RSX_TRY(h->map_th.reserve(npx * sizeof(double), s, false));
   RSX_HIP(hipMemcpyAsync(h->map_rb.p, rb.data(), npx * sizeof(float), hipMemcpyHostToDevice, s));
-  RSX_HIP(hipMemcpyAsync(h->map_ab.p, ab.data(), npx * sizeof(float), hipMemcpyHostToDevice, s));
-  RSX_HIP(hipStreamSynchronize(s));  // rb / ab are locals
+  RSX_HIP(hipMemcpyAsync(h->map_th.p, th.data(), npx * sizeof(double), hipMemcpyHostToDevice, s));
+  RSX_HIP(hipStreamSynchronize(s));  // rb / th are locals
   h->map_radar_res = (double)resolution;
-  h->map_az0 = az0;
-  h->map_az_step = az_step;
   return RSX_OK;
 }
 
 // n device images -> n Cartesian images + smoothed copies in the handle's slots 0 .. n-1
+// d_az: device azimuths, az_stride floats between the grids of consecutive images (0: one grid for all)
 static int cartesian_device(rsx_frontend *h, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, int32_t col_offset,
-                            hipStream_t s) {
+                            const float *d_az, int64_t az_stride, hipStream_t s) {
   const int W = h->W;
   const size_t npx = (size_t)W * W;
   RSX_TRY(h->cart.reserve(npx * sizeof(float) * n, s, false));
@@ -545,13 +556,13 @@ static int cartesian_device(rsx_frontend *h, const uint8_t *d_imgs, int n, int64
   if (h->three_pass) {  // the round-2 form (kept for the parity test of the fused kernel): remap, blur rows, blur columns
     const dim3 grid((unsigned)((npx + 255) / 256), (unsigned)n);
     hipLaunchKernelGGL(fe_remap, grid, dim3(256), 0, s, d_imgs, img_stride, h->rows, h->cols, row_stride, col_offset, W, h->map_rb.as<float>(),
-                       h->map_ab.as<float>(), h->cart.as<float>());
+                       h->map_th.as<double>(), d_az, az_stride, h->cart.as<float>());
     hipLaunchKernelGGL(fe_blur<true>, grid, dim3(256), 0, s, h->cart.as<float>(), W, g, h->tmp.as<float>());
     hipLaunchKernelGGL(fe_blur<false>, grid, dim3(256), 0, s, h->tmp.as<float>(), W, g, h->blur.as<float>());
   } else {
     const dim3 grid((unsigned)((W + FT - 1) / FT), (unsigned)((W + FT - 1) / FT), (unsigned)n);
     hipLaunchKernelGGL(fe_cart_fused, grid, dim3(256), 0, s, d_imgs, img_stride, h->rows, h->cols, row_stride, col_offset, W,
-                       h->map_rb.as<float>(), h->map_ab.as<float>(), g, h->cart.as<float>(), h->blur.as<float>());
+                       h->map_rb.as<float>(), h->map_th.as<double>(), d_az, az_stride, g, h->cart.as<float>(), h->blur.as<float>());
   }
   RSX_HIP(hipGetLastError());
   h->have_image = true;
@@ -566,11 +577,14 @@ int rsx_frontend_cartesian(rsx_frontend *h, const uint8_t *img, int32_t row_stri
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
-  RSX_TRY(ensure_map(h, azimuths, resolution, s));
+  if (!((double)azimuths[1] - (double)azimuths[0] > 0.0)) return fail(RSX_ERR_BAD_ARG, "azimuths must increase");
+  RSX_TRY(ensure_map(h, resolution, s));
   const size_t ibytes = (size_t)h->rows * row_stride;
   RSX_TRY(h->img.reserve(ibytes, s, false));
+  RSX_TRY(h->az1.reserve(8, s, false));
   RSX_HIP(hipMemcpyAsync(h->img.p, img, ibytes, hipMemcpyHostToDevice, s));
-  RSX_TRY(cartesian_device(h, h->img.as<uint8_t>(), 1, (int64_t)ibytes, row_stride, col_offset, s));
+  RSX_HIP(hipMemcpyAsync(h->az1.p, azimuths, 8, hipMemcpyHostToDevice, s));
+  RSX_TRY(cartesian_device(h, h->img.as<uint8_t>(), 1, (int64_t)ibytes, row_stride, col_offset, h->az1.as<float>(), 0, s));
   if (out_cart) RSX_HIP(hipMemcpyAsync(out_cart, h->cart.p, (size_t)h->W * h->W * sizeof(float), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
@@ -584,8 +598,24 @@ int rsx_frontend_cartesian_batch_device(rsx_frontend *h, const uint8_t *d_imgs, 
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
-  RSX_TRY(ensure_map(h, azimuths, resolution, s));
-  return cartesian_device(h, d_imgs, n_images, image_stride_bytes, row_stride, col_offset, s);
+  if (!((double)azimuths[1] - (double)azimuths[0] > 0.0)) return fail(RSX_ERR_BAD_ARG, "azimuths must increase");
+  RSX_TRY(ensure_map(h, resolution, s));
+  RSX_TRY(h->az1.reserve(8, s, false));
+  RSX_HIP(hipMemcpyAsync(h->az1.p, azimuths, 8, hipMemcpyHostToDevice, s));  // (8 bytes of pageable memory: staged before the call returns)
+  return cartesian_device(h, d_imgs, n_images, image_stride_bytes, row_stride, col_offset, h->az1.as<float>(), 0, s);
+} RSX_CATCH_ALL
+
+int rsx_frontend_cartesian_batch_device_az(rsx_frontend *h, const uint8_t *d_imgs, int32_t n_images, int64_t image_stride_bytes, int32_t row_stride,
+                                           int32_t col_offset, const float *d_azimuths, int64_t azimuth_stride_floats, float resolution,
+                                           void *stream) try {
+  if (!h || !d_imgs || !d_azimuths || n_images < 1 || azimuth_stride_floats < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (row_stride < col_offset + h->cols || col_offset < 0 || !(resolution > 0.0f)) return fail(RSX_ERR_BAD_ARG, "bad image layout");
+  if (n_images > 1 && image_stride_bytes < (int64_t)h->rows * row_stride) return fail(RSX_ERR_BAD_ARG, "image_stride_bytes smaller than an image");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  RSX_TRY(ensure_map(h, resolution, s));
+  return cartesian_device(h, d_imgs, n_images, image_stride_bytes, row_stride, col_offset, d_azimuths, azimuth_stride_floats, s);
 } RSX_CATCH_ALL
 
 int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *out_desc, uint8_t *out_valid) try {

@@ -140,14 +140,17 @@ int enqueue_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_st
                    int32_t azimuths_per_image, hipStream_t s) {
   const int K = h->prm.max_keypoints;
   const size_t slot_xy = (size_t)K * 2;
-  // azimuths: the Cartesian map needs them on the host (first image's grid), cen2019's polar -> Cartesian on the device
+  // the azimuth grids go to the device once: cen2019's polar -> Cartesian and the Cartesian image both read them there
   const size_t na = (size_t)h->rows * (azimuths_per_image ? n : 1);
   RSX_HIP(hipMemcpyAsync(h->az.p, azimuths, na * 4, hipMemcpyHostToDevice, s));
   int32_t *d_counts = h->counts.as<int32_t>();
   RSX_TRY(rsx_cen2019_extract_batch_device(h->cen, d_imgs, n, img_stride, row_stride, h->prm.col_offset, &h->prm.cen, h->az.as<float>(),
                                            azimuths_per_image, h->prm.radar_resolution, h->targets.as<int32_t>() + slot_xy,
                                            h->xy.as<float>() + slot_xy, K, d_counts + 1, s));
-  RSX_TRY(rsx_frontend_cartesian_batch_device(h->fe, d_imgs, n, img_stride, row_stride, h->prm.col_offset, azimuths, h->prm.radar_resolution, s));
+  // the Cartesian image of scan i through scan i's OWN azimuth grid (already in HBM for cen2019): results do not depend on
+  // how the sequence is cut into windows, and nothing about the grids is looked at on the host
+  RSX_TRY(rsx_frontend_cartesian_batch_device_az(h->fe, d_imgs, n, img_stride, row_stride, h->prm.col_offset, h->az.as<float>(),
+                                                 azimuths_per_image ? (int64_t)h->rows : 0, h->prm.radar_resolution, s));
   RSX_TRY(rsx_frontend_describe_batch_device(h->fe, h->xy.as<float>() + slot_xy, d_counts + 1, n, K, h->desc.as<uint8_t>() + (size_t)K * 32,
                                              h->valid.as<uint8_t>() + (size_t)K, s));
   const int first = h->have_prev ? 0 : 1, n_pairs = n - first;

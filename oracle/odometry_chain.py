@@ -34,7 +34,7 @@ def run(images, azimuths, resolution=0.0595, col_offset=11, max_points=10000, mi
         nk = len(tg)
         tg = tg[:max_keypoints]
         xy = po.cen2019_to_cartesian(tg, azi, resolution)
-        fe.cartesian(images[i], az[0] if az.ndim == 2 else az, resolution, col_offset=col_offset)
+        fe.cartesian(images[i], azi, resolution, col_offset=col_offset)   # scan i through ITS OWN azimuth grid
         desc, valid = fe.describe(xy)
         rec = {"n_keypoints": nk, "n_matches": 0, "result": None, "xy": xy}
         if prev is not None:

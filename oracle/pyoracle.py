@@ -606,6 +606,7 @@ class RefSC:
         R.ref_sc_fast_align.argtypes = [C.c_void_p, C.c_void_p]
         R.ref_sc_distance.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         R.ref_sc_distances.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+        R.ref_sc_distances_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
         R.ref_sc_circshift.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         R.ref_sc_create.restype = C.c_void_p
         R.ref_sc_destroy.argtypes = [C.c_void_p]
@@ -625,6 +626,16 @@ class RefSC:
 
     def build_info(self):
         return self.R.ref_sc_build_info().decode()
+
+    def distances_batch(self, queries, descs, nthreads=1):
+        """every (query, entry) pair through the reference's distanceBtnScanContext, OpenMP over (query, entry block)
+        -> (dist (nq, n) float64, shift (nq, n) int32)"""
+        q = np.ascontiguousarray(queries, dtype=np.float64).reshape(-1, DS)
+        d = np.ascontiguousarray(descs, dtype=np.float64).reshape(-1, DS)
+        dist = np.empty((q.shape[0], d.shape[0]), dtype=np.float64)
+        shift = np.empty((q.shape[0], d.shape[0]), dtype=np.int32)
+        self.R.ref_sc_distances_batch(q.ctypes.data, q.shape[0], d.ctypes.data, d.shape[0], dist.ctypes.data, shift.ctypes.data, int(nthreads))
+        return dist, shift
 
     def xy2theta(self, x, y):
         return self.R.ref_sc_xy2theta(float(np.float32(x)), float(np.float32(y)))

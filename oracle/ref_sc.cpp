@@ -128,6 +128,27 @@ void ref_sc_distances(const double *query, const double *descs, int64_t n, doubl
   }
 }
 
+/* nq queries x n entries through the reference's own pair function, OpenMP over (query, block of 64 entries): the CPU
+ * baseline bench.py reports beside the GPU number (`cpu_baseline.kind = "reference"`): Scancontext.cpp:116-148 itself, heap
+ * allocations of its circshift / col() temporaries and all, on every host core.  dist, shift: [nq][n]. */
+void ref_sc_distances_batch(const double *queries, int64_t nq, const double *descs, int64_t n, double *dist, int32_t *shift,
+                            int nthreads) {
+  const int64_t nb = (n + 63) / 64;
+#pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(nthreads > 0 ? nthreads : 1)
+  for (int64_t qi = 0; qi < nq; qi++)
+    for (int64_t b = 0; b < nb; b++) {
+      SCManager sc;
+      MatrixXd q = to_mat(queries + qi * 1200, 20, 60);
+      const int64_t i1 = (b + 1) * 64 < n ? (b + 1) * 64 : n;
+      for (int64_t i = b * 64; i < i1; i++) {
+        MatrixXd e = to_mat(descs + i * 1200, 20, 60);
+        std::pair<double, int> r = sc.distanceBtnScanContext(q, e);
+        dist[qi * n + i] = r.first;
+        shift[qi * n + i] = r.second;
+      }
+    }
+}
+
 /* ---- the reference SCManager as a whole (Scancontext.h:57-122) ---- */
 SCManager *ref_sc_create(void) { return new SCManager(); }
 void ref_sc_destroy(SCManager *m) { delete m; }

@@ -95,6 +95,34 @@ def test_window_splits_and_device_images_change_nothing(sequence):
     assert od.push(imgs[3:5], az)["status"].tolist() == [3, 0]
 
 
+def test_every_scan_goes_through_its_own_azimuth_grid(sequence):
+    """MulRan scans carry one encoder grid per scan.  With a different start angle per scan (a fraction of the 0.9 degree
+    step, and once more than a step) the windowed pipeline must (a) not depend on how the sequence is cut into windows --
+    round 3 built ONE pixel map from the first scan of a window and used it for the whole window -- and (b) equal the
+    oracle chain, which remaps every scan through its own grid."""
+    from navtech_radar_slam_amd import odometry
+    from oracle import odometry_chain
+    imgs, az, poses, stamps = sequence
+    imgs = imgs[:7]
+    step = float(az[1] - az[0])
+    shifts = np.array([0.0, 0.31, 0.77, 0.05, 1.42, 0.5, 0.93], dtype=np.float32) * np.float32(step)
+    az_i = (az[None, :] + shifts[:, None]).astype(np.float32)
+    od = odometry.Odometry(400, 3360)
+    whole = od.push(imgs, az_i)
+    od.reset()
+    parts = np.concatenate([od.push(imgs[a:b], az_i[a:b]) for a, b in ((0, 1), (1, 3), (3, 4), (4, 7))])
+    assert parts.tobytes() == whole.tobytes(), "the result depends on the window partition"
+    od.reset()
+    same_grid = od.push(imgs, az)
+    assert same_grid.tobytes() != whole.tobytes(), "the per-scan grids were ignored"
+    chain = odometry_chain.run(imgs, az_i, resolution=synth.RADAR_RESOLUTION)
+    for i in range(len(imgs)):
+        assert whole["n_keypoints"][i] == chain[i]["n_keypoints"] and whole["n_matches"][i] == chain[i]["n_matches"], i
+        if i:
+            w = chain[i]["result"]
+            assert max(abs(whole[f][i] - w[f]) for f in ("x", "y", "yaw")) < 1e-4, (i, whole[i], w)
+
+
 def _write_sequence(tmp_path, imgs, stamps):
     from PIL import Image
     d = tmp_path / "seq" / "polar_oxford_form"
