@@ -855,16 +855,35 @@ def layout_emulation_leg(device, db_descs, q_descs, n_elig, k):
             "note": "per-rank compute between the collectives, emulated on ONE GPU (not a multi-GPU measurement); exchanges excluded"}
 
 
-def host_entry_leg(mgr, q_descs, n_elig, k, reps=3):
-    """the same batch through the synchronous HOST-buffer entry (rsx_sc_query): pageable host queries
-    in (nq x 4800 B over PCIe), host records out (nq x k x 16 B), upload and download inside the time."""
-    mgr.query(q_descs, k=k, n_eligible=n_elig)
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        mgr.query(q_descs, k=k, n_eligible=n_elig)
-    dt = (time.perf_counter() - t0) / reps
-    return {"ms_per_step": dt * 1e3, "queries_per_sec": len(q_descs) / dt, "h2d_bytes": int(q_descs.nbytes), "d2h_bytes": len(q_descs) * k * 16,
-            "note": "rsx_sc_query: H2D of the queries + filter/select/re-score + D2H of the records, one synchronous call (pageable host memory)"}
+def host_entry_leg(mgr, q_descs, n_elig, k, resident_ms, reps=5):
+    """the same batch through the synchronous HOST-buffer entry (rsx_sc_query): host queries in
+    (nq x 4800 B over PCIe), host records out (nq x k x 16 B), upload and download inside the time.  The call cuts the batch
+    into pieces and uploads piece c + 1 while piece c is scored (sc_api.cpp host_pieces); timed from pageable memory (what a
+    caller with a plain malloc'd buffer gets) and from page-locked memory (rsx_host_alloc_pinned)."""
+    from importlib import import_module
+    _rsx = import_module("navtech-radar-slam_amd._rsx")
+
+    def timed(q, out):
+        mgr.query(q, k=k, n_eligible=n_elig, out=out)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            mgr.query(q, k=k, n_eligible=n_elig, out=out)
+        return (time.perf_counter() - t0) / reps
+
+    nq = len(q_descs)
+    dt_pageable = timed(q_descs, None)
+    ref = mgr.query(q_descs, k=k, n_eligible=n_elig)
+    with _rsx.PinnedArray((nq, 1200), np.float32) as pq, _rsx.PinnedArray((nq, k), ref.dtype) as po:
+        pq.a[:] = q_descs.reshape(nq, 1200)
+        dt_pinned = timed(pq.a, po.a)
+        same = bool(np.array_equal(po.a, ref))
+    return {"ms_per_step": dt_pinned * 1e3, "queries_per_sec": nq / dt_pinned, "memory": "pinned (rsx_host_alloc_pinned)",
+            "pageable": {"ms_per_step": dt_pageable * 1e3, "queries_per_sec": nq / dt_pageable},
+            "vs_resident": resident_ms / (dt_pinned * 1e3), "pageable_vs_resident": resident_ms / (dt_pageable * 1e3),
+            "pinned_identical_to_pageable": same,
+            "h2d_bytes": int(q_descs.nbytes), "d2h_bytes": nq * k * 16,
+            "note": "rsx_sc_query: H2D of the queries in pieces, each scored (filter/select/re-score) while the next one goes up, + D2H "
+                    "of the records; one synchronous call.  vs_resident = the headline's ms_per_step (queries already in HBM) / this"}
 
 
 def roofline_of(wl, launches, kern_ms, n_elig):
@@ -1017,6 +1036,8 @@ def main():
                        "queries_per_step": nq, "topk": k, "rings_x_sectors": "20x60",
                        "parallelism": f"query_groups{qgroups}_x_db_shards{world // qgroups}" if world > 1 else "single_gpu",
                        "layout": main_wl.ssc.layout,
+                       "value_is": "device-resident entry (rsx_sc_query_device: queries already in HBM, records left in HBM), "
+                                   "as the bench contract asks; the PCIe-inclusive host-buffer entry is `host_entry` in this line",
                        "pairs_per_sec": qps * n_elig, "data_note": data_note, "data_generation_s": gen_s},
             "rccl_ranks": ctx.dist.get_world_size() if ctx.distributed else 1,
             "backend": (ctx.dist.get_backend() if ctx.distributed else "none"),
@@ -1158,7 +1179,9 @@ def main():
 
     if rank == 0 and not ctx.stub:
         if not args.only_main and world == 1:
-            out["host_entry"] = host_entry_leg(main_wl.mgr, q_descs, n_elig, k)
+            out["host_entry"] = host_entry_leg(main_wl.mgr, q_descs, n_elig, k, out["ms_per_step"])
+            if not out["host_entry"]["pinned_identical_to_pageable"]:
+                failures.append("host-buffer entry: pinned and pageable buffers give different records")
             if not np.array_equal(main_wl.mgr.query(q_descs[:64], k=k, n_eligible=n_elig), res[:64]):
                 failures.append("host-buffer entry disagrees with the device entry")
             out["layout_emulation"] = layout_emulation_leg(ctx.local_rank, db_descs, q_descs, n_elig, k)

@@ -280,3 +280,32 @@ def device_count():
 
 def version():
     return lib().rsx_version().decode()
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory (rsx_host_alloc_pinned): what a caller hands the host-buffer entries
+    (rsx_sc_query, rsx_odometry_push, rsx_cen2019_extract ...) so that their uploads run asynchronously at full PCIe rate.
+    `.a` is the array; close() (or the context manager) frees the memory -- the array must not be used after that."""
+
+    def __init__(self, shape, dtype):
+        import numpy as np
+        self._np = np
+        dt = np.dtype(dtype)
+        n = int(np.prod(shape)) * dt.itemsize
+        self._p = C.c_void_p()
+        check(lib().rsx_host_alloc_pinned(max(n, 1), C.byref(self._p)))
+        buf = (C.c_char * max(n, 1)).from_address(self._p.value)
+        self.a = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.a = None
+            check(lib().rsx_host_free_pinned(self._p))
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False

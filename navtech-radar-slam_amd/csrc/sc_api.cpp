@@ -51,9 +51,16 @@ struct rsx_sc {
     int depth = 0;
   } tree, tree_batch;
   // workspaces
-  DevBuf pts_ws, q_desc, q_vkey, q_norm, q_rkey, partial, topk, knn_ws, small, pair_out, q_elig;
-  DevBuf f_qimg, f_lb, f_cand, f_cnt, f_thr, f_plan;  // filter path
-  DevBuf f_wimg, f_win;                               // window previews of the short lists (sc_window.hip)
+  DevBuf pts_ws, q_desc, topk, knn_ws, small, pair_out, q_elig;
+  // what one query batch in flight owns between its keys and its records.  Two sets: the host-buffer entry scores the
+  // pieces of a large batch alternately on two streams, each with its own set (rsx_sc_query); everything else uses set 0
+  struct QueryWs {
+    DevBuf q_vkey, q_norm, q_rkey, partial;
+    DevBuf f_qimg, f_lb, f_cand, f_cnt, f_thr, f_plan;  // filter path
+    DevBuf f_wimg, f_win;                               // window previews of the short lists (sc_window.hip)
+    DevBuf *all[12] = {&q_vkey, &q_norm, &q_rkey, &partial, &f_qimg, &f_lb, &f_cand, &f_cnt, &f_thr, &f_plan, &f_wimg, &f_win};
+  } ws[2];
+  QueryWs *w = &ws[0];  // the set the calls below work in (guarded by mu like the rest)
   PairProfiler prof;
   const char *prof_kernel = "sc_pair_kernel";  // which kernel the profiler events bracket
   // state between rsx_sc_query_stage1_device and rsx_sc_query_stage2_device
@@ -69,6 +76,11 @@ struct rsx_sc {
   DevBuf stats;       // profiling only: RESCORE_STAT_COPIES blocks of counters (sc_kernels.h), summed by the host when read
   void *pinned = nullptr;  // small pinned host staging (results)
   size_t pinned_bytes = 0;
+  // upload pipeline of the host-buffer entry (rsx_sc_query): pieces of the query batch go up on their own stream while
+  // the pieces before them are scored
+  static constexpr int kMaxPieces = 8;
+  hipStream_t up_stream = nullptr, stream_b = nullptr;
+  hipEvent_t up_ev[kMaxPieces] = {}, lane_ev = nullptr;
 };
 
 namespace {
@@ -160,13 +172,13 @@ int ensure_pinned(rsx_sc *h, size_t bytes) {
 // keys for nq query descriptors already in h->q_desc (or external device pointer)
 int prepare_queries(rsx_sc *h, const float *d_q, int32_t nq, hipStream_t s, QueryView *qv) {
   h->st.valid = false;  // q_vkey / q_norm are about to be overwritten: a pending stage 2 would read the wrong keys
-  RSX_TRY(h->q_vkey.reserve((size_t)nq * NS * sizeof(double), s, false));
-  RSX_TRY(h->q_norm.reserve((size_t)nq * NS * sizeof(double), s, false));
-  RSX_TRY(h->q_rkey.reserve((size_t)nq * NR * sizeof(float), s, false));
-  RSX_TRY(launch_keys(d_q, nq, h->q_vkey.as<double>(), h->q_norm.as<double>(), h->q_rkey.as<float>(), s));
+  RSX_TRY(h->w->q_vkey.reserve((size_t)nq * NS * sizeof(double), s, false));
+  RSX_TRY(h->w->q_norm.reserve((size_t)nq * NS * sizeof(double), s, false));
+  RSX_TRY(h->w->q_rkey.reserve((size_t)nq * NR * sizeof(float), s, false));
+  RSX_TRY(launch_keys(d_q, nq, h->w->q_vkey.as<double>(), h->w->q_norm.as<double>(), h->w->q_rkey.as<float>(), s));
   qv->desc = d_q;
-  qv->vkey = h->q_vkey.as<double>();
-  qv->norm = h->q_norm.as<double>();
+  qv->vkey = h->w->q_vkey.as<double>();
+  qv->norm = h->w->q_norm.as<double>();
   qv->nq = nq;
   return RSX_OK;
 }
@@ -231,23 +243,23 @@ size_t any_qimg_bytes(int32_t nq) {
 int run_filter(rsx_sc *h, const QueryView &q, int64_t n_items, float *lb, int64_t ld, const FilterPlanInput *plan,
                hipStream_t s) {
   const DbView db = db_view(h);
-  if (plan) RSX_TRY(h->f_plan.reserve(filter_plan_bytes(n_items), s, false));
+  if (plan) RSX_TRY(h->w->f_plan.reserve(filter_plan_bytes(n_items), s, false));
   if (filter_kind_of(h) >= 1) {
     const bool two_waves = filter_kind_of(h) == 2;
     h->prof_kernel = two_waves ? spec2_filter_kernel_name() : spec_filter_kernel_name();
-    RSX_TRY(launch_spec_query_images(q.desc, q.norm, q.nq, h->f_qimg.p, s));
+    RSX_TRY(launch_spec_query_images(q.desc, q.norm, q.nq, h->w->f_qimg.p, s));
     const int32_t *qmin = nullptr;
     const int64_t *cum = nullptr;
-    if (plan) RSX_TRY(launch_filter_plan(db, *plan, q.nq, n_items, 4, h->f_plan.p, &qmin, &cum, s));
+    if (plan) RSX_TRY(launch_filter_plan(db, *plan, q.nq, n_items, 4, h->w->f_plan.p, &qmin, &cum, s));
     ProfScope ps(&h->prof, s);
-    RSX_TRY(launch_spec_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, qmin, cum, s, two_waves));
+    RSX_TRY(launch_spec_filter(db, h->w->f_qimg.p, q.nq, n_items, lb, ld, qmin, cum, s, two_waves));
     ps.stop();
     return RSX_OK;
   }
   h->prof_kernel = filter_kernel_name();
-  RSX_TRY(launch_query_images(q.desc, q.norm, q.nq, h->f_qimg.p, s));
+  RSX_TRY(launch_query_images(q.desc, q.norm, q.nq, h->w->f_qimg.p, s));
   ProfScope ps(&h->prof, s);
-  RSX_TRY(launch_filter(db, h->f_qimg.p, q.nq, n_items, lb, ld, plan, plan ? h->f_plan.p : nullptr, s));
+  RSX_TRY(launch_filter(db, h->w->f_qimg.p, q.nq, n_items, lb, ld, plan, plan ? h->w->f_plan.p : nullptr, s));
   ps.stop();
   return RSX_OK;
 }
@@ -263,13 +275,13 @@ int64_t filter_batch(int64_t n_items, int64_t nq) {
 int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
   h->st.valid = false;  // bounds / short lists of a pending stage 2 are about to be overwritten
   const int64_t ld = (n_items + 31) / 32 * 32;
-  RSX_TRY(h->f_qimg.reserve(any_qimg_bytes((int32_t)qb), s, false));
-  RSX_TRY(h->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
-  RSX_TRY(h->f_cand.reserve((size_t)qb * RESCORE_SHORTLIST_CAP * sizeof(RescoreEntry), s, false));
-  RSX_TRY(h->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
-  RSX_TRY(h->f_thr.reserve((size_t)qb * RESCORE_THR_STRIDE * sizeof(float), s, false));
-  RSX_TRY(h->f_wimg.reserve(window_qimg_bytes((int32_t)qb), s, false));
-  RSX_TRY(h->f_win.reserve((size_t)qb * WINDOW_P * sizeof(WindowPreview), s, false));
+  RSX_TRY(h->w->f_qimg.reserve(any_qimg_bytes((int32_t)qb), s, false));
+  RSX_TRY(h->w->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
+  RSX_TRY(h->w->f_cand.reserve((size_t)qb * RESCORE_SHORTLIST_CAP * sizeof(RescoreEntry), s, false));
+  RSX_TRY(h->w->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
+  RSX_TRY(h->w->f_thr.reserve((size_t)qb * RESCORE_THR_STRIDE * sizeof(float), s, false));
+  RSX_TRY(h->w->f_wimg.reserve(window_qimg_bytes((int32_t)qb), s, false));
+  RSX_TRY(h->w->f_win.reserve((size_t)qb * WINDOW_P * sizeof(WindowPreview), s, false));
   return RSX_OK;
 }
 
@@ -288,29 +300,29 @@ int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_
                       int32_t first_target, int32_t k, hipStream_t s, bool elig_monotone = false) {
   const DbView db = db_view(h);
   const int64_t ld = (n_items + 31) / 32 * 32;
-  float *lb = h->f_lb.as<float>();
+  float *lb = h->w->f_lb.as<float>();
   {
     FilterPlanInput plan{n_eligible, elig};
     const bool planned = elig_monotone && elig != nullptr;
     RSX_TRY(run_filter(h, q, n_items, lb, ld, planned ? &plan : nullptr, s));
   }
-  RSX_TRY(launch_select(db, lb, ld, n_items, q.nq, n_eligible, elig, first_target, h->f_cand.as<RescoreEntry>(),
-                        h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), s));
+  RSX_TRY(launch_select(db, lb, ld, n_items, q.nq, n_eligible, elig, first_target, h->w->f_cand.as<RescoreEntry>(),
+                        h->w->f_cnt.as<int32_t>(), h->w->f_thr.as<float>(), s));
   // alignment + window preview of the head of every short list on the matrix cores (what re-scoring would otherwise
   // do on the VALU, one entry per wavefront)
   if (!use_window()) return RSX_OK;
-  return launch_window(db, q, h->f_wimg.p, h->f_cand.as<RescoreEntry>(), h->f_cnt.as<int32_t>(), k, filter_eps(),
-                       h->f_win.as<WindowPreview>(), s);
+  return launch_window(db, q, h->w->f_wimg.p, h->w->f_cand.as<RescoreEntry>(), h->w->f_cnt.as<int32_t>(), k, filter_eps(),
+                       h->w->f_win.as<WindowPreview>(), s);
 }
 
 int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig, int32_t round_begin,
             int32_t round_end, const rsx_sc_hit *tau_src, const rsx_sc_hit *seed, int32_t k, rsx_sc_hit *d_out,
             hipStream_t s) {
   const int64_t ld = (n_items + 31) / 32 * 32;
-  return launch_rescore(db_view(h), q, h->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
-                        h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), filter_eps(), round_begin, round_end, tau_src,
+  return launch_rescore(db_view(h), q, h->w->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->w->f_cand.as<RescoreEntry>(),
+                        h->w->f_cnt.as<int32_t>(), h->w->f_thr.as<float>(), filter_eps(), round_begin, round_end, tau_src,
                         seed, d_out, k, s, (h->prof.on && h->stats.p) ? h->stats.as<unsigned long long>() : nullptr,
-                        use_window() ? h->f_win.as<WindowPreview>() : nullptr);
+                        use_window() ? h->w->f_win.as<WindowPreview>() : nullptr);
 }
 
 // exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> short list ->
@@ -348,8 +360,8 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     }();
     if (use_walk) {
       const int64_t ld = (n_items + 31) / 32 * 32;
-      RSX_TRY(launch_walk(db_view(h), q, h->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->f_cand.as<RescoreEntry>(),
-                          h->f_cnt.as<int32_t>(), h->f_thr.as<float>(), filter_eps(), d_out + b0 * k, k, s));
+      RSX_TRY(launch_walk(db_view(h), q, h->w->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->w->f_cand.as<RescoreEntry>(),
+                          h->w->f_cnt.as<int32_t>(), h->w->f_thr.as<float>(), filter_eps(), d_out + b0 * k, k, s));
     } else {
       RSX_TRY(rescore(h, q, n_items, n_eligible, elig, 0, RESCORE_ALL_ROUNDS, nullptr, nullptr, k, d_out + b0 * k, s));
     }
@@ -361,13 +373,13 @@ int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible
              int32_t k, rsx_sc_hit *d_out, hipStream_t s, bool elig_monotone = false) {
   if (use_filter(h, qv.nq, n_items)) return run_topk_filtered(h, qv, n_items, n_eligible, d_q_elig, k, d_out, s, elig_monotone);
   h->prof_kernel = pair_kernel_name();
-  RSX_TRY(h->partial.reserve(pair_partial_bytes(n_items > 0 ? n_items : 1, qv.nq, k), s, false));
+  RSX_TRY(h->w->partial.reserve(pair_partial_bytes(n_items > 0 ? n_items : 1, qv.nq, k), s, false));
   struct Hook {
     explicit Hook(PairProfiler *p) { set_pair_profiler(p); }
     ~Hook() { set_pair_profiler(nullptr); }
   } hook(&h->prof);
   return launch_pairs(db_view(h), qv, nullptr, 0, n_items, n_eligible, d_q_elig, nullptr, nullptr,
-                      h->partial.as<rsx_sc_hit>(), d_out, k, s);
+                      h->w->partial.as<rsx_sc_hit>(), d_out, k, s);
 }
 
 // the search tree over the ring keys of entries [0, n): built on the host exactly like the reference's nanoflann tree
@@ -630,16 +642,22 @@ int rsx_sc_destroy(rsx_sc *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->hnr, &h->vk16, &h->vk_n, &h->f_wimg, &h->f_win, &h->f_qimg, &h->f_lb, &h->f_cand, &h->f_cnt, &h->f_thr, &h->f_plan, &h->st_partial, &h->stats, &h->helper_ws, &h->tree.nodes, &h->tree.vind,
+  for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->hnr, &h->vk16, &h->vk_n, &h->st_partial, &h->stats, &h->helper_ws, &h->tree.nodes, &h->tree.vind,
                     &h->tree_batch.nodes, &h->tree_batch.vind}) b->release();
-  for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->q_vkey, &h->q_norm,
-                    &h->q_rkey, &h->partial, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
+  for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
+  for (auto &w : h->ws)
+    for (DevBuf *b : w.all) b->release();
   if (h->pinned) (void)hipHostFree(h->pinned);
   if (h->prof.ev) {
     for (int i = 0; i < 2 * PairProfiler::kMax; i++) (void)hipEventDestroy(h->prof.ev[i]);
     delete[] h->prof.ev;
   }
+  for (auto e : h->up_ev)
+    if (e) (void)hipEventDestroy(e);
+  if (h->lane_ev) (void)hipEventDestroy(h->lane_ev);
+  if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
+  if (h->stream_b) (void)hipStreamDestroy(h->stream_b);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
@@ -1146,6 +1164,44 @@ int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int6
   return query_device_locked(h, d_q, nq, k, n_eligible, d_out, stream ? static_cast<hipStream_t>(stream) : h->stream);
 } RSX_CATCH_ALL
 
+// How the host-buffer entry cuts a batch into pieces: the upload of the first piece is the only one nothing hides, every
+// later piece is `growth` times the one before -- a piece is scored ~3x slower than PCIe delivers the next (8192 queries vs
+// 10 000 keyframes on MI355X: 0.33 ms of scoring, 0.09 ms of upload per 1024 queries at the 54 GB/s measured), so the upload
+// of piece c + 1 ends long before the scoring of piece c does, and few large pieces lose less to the per-launch tails than
+// many small ones.  Measured plans (top-10, same box, ms per call / fraction of the resident step's 2.72 ms):
+// whole 3.56 / 0.76, 512:2.5 3.13 / 0.87, 1024:1.0 3.25 / 0.84, 1024:1.5 3.11 / 0.88, 1024:2.5 (1024 + 2560 + 4608)
+// 3.04 / 0.89, 256:4.0 3.01-3.10; on ONE stream 1024:2.5 is 3.20 / 0.85.  Batches below 4 pieces' worth stay whole.
+// RSX_SC_HOST_PIECES=first[:growth_x10] (experiments build) overrides; first = 0 keeps every batch whole.
+int host_pieces(int32_t nq, int32_t *sizes) {
+  static const std::pair<int, int> plan = [] {
+    const char *e = rsx::exp_env("RSX_SC_HOST_PIECES");
+    std::pair<int, int> r{1024, 25};
+    if (e && *e) {
+      r.first = atoi(e);
+      const char *c = strchr(e, ':');
+      if (c) r.second = atoi(c + 1);
+      if (r.second < 10) r.second = 10;
+    }
+    return r;
+  }();
+  if (plan.first <= 0 || nq < 4 * plan.first) {
+    sizes[0] = nq;
+    return 1;
+  }
+  int n = 0;
+  int32_t left = nq;
+  double want = plan.first;
+  while (left > 0) {
+    int32_t take = ((int32_t)want + 63) / 64 * 64;
+    // the last slot takes what is left; a remainder smaller than half a piece joins the piece before it
+    if (n == rsx_sc::kMaxPieces - 1 || left - take < take / 2) take = left;
+    sizes[n++] = take;
+    left -= take;
+    want *= plan.second / 10.0;
+  }
+  return n;
+}
+
 int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) try {
   if (!h || !q || !out || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
@@ -1154,8 +1210,63 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
   RSX_TRY(set_device(h));
   RSX_TRY(h->q_desc.reserve((size_t)nq * DS * sizeof(float), h->stream, false));
   RSX_TRY(h->topk.reserve((size_t)nq * k * sizeof(rsx_sc_hit), h->stream, false));
-  RSX_HIP(hipMemcpyAsync(h->q_desc.p, q, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  RSX_TRY(query_device_locked(h, h->q_desc.as<float>(), nq, k, n_eligible, h->topk.as<rsx_sc_hit>(), h->stream));
+  int32_t sizes[rsx_sc::kMaxPieces];
+  const int np = host_pieces(nq, sizes);
+  static const bool two_lanes = [] {  // RSX_SC_HOST_LANES=1 (experiments build): every piece on the main stream
+    const char *e = rsx::exp_env("RSX_SC_HOST_LANES");
+    return !(e && e[0] == '1');
+  }();
+  if (np == 1) {
+    RSX_HIP(hipMemcpyAsync(h->q_desc.p, q, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    RSX_TRY(query_device_locked(h, h->q_desc.as<float>(), nq, k, n_eligible, h->topk.as<rsx_sc_hit>(), h->stream));
+  } else {
+    // Piece c + 1 goes up on up_stream while piece c is scored.  The order of the calls matters for pageable memory,
+    // where hipMemcpyAsync returns only when the runtime has staged the whole piece: the scoring of piece c is enqueued
+    // BEFORE that call, so the device works while this thread feeds the copy engine.  Pinned memory
+    // (rsx_host_alloc_pinned) makes the copies asynchronous as well and the whole batch is enqueued at once.
+    // Pieces are scored alternately on two streams, each with its own workspace set: a piece ends in short dependent
+    // kernels (select, window previews, re-scoring rounds: latency, not throughput) that the next piece's filter
+    // launch fills in -- in one stream the pieces of the bench batch cost 3.27 ms of kernels against 2.80 ms whole.
+    if (!h->up_stream) {
+      RSX_HIP(hipStreamCreateWithFlags(&h->up_stream, hipStreamNonBlocking));
+      RSX_HIP(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+      for (auto &e : h->up_ev) RSX_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      RSX_HIP(hipEventCreateWithFlags(&h->lane_ev, hipEventDisableTiming));
+    }
+    auto upload = [&](int c, int64_t q0) -> int {
+      RSX_HIP(hipMemcpyAsync(h->q_desc.as<float>() + q0 * DS, q + q0 * DS, (size_t)sizes[c] * DS * sizeof(float),
+                             hipMemcpyHostToDevice, h->up_stream));
+      RSX_HIP(hipEventRecord(h->up_ev[c], h->up_stream));
+      return RSX_OK;
+    };
+    auto all_pieces = [&]() -> int {
+      // lane B starts behind whatever the caller's earlier calls left on the main stream (DB appends ...)
+      RSX_HIP(hipEventRecord(h->lane_ev, h->stream));
+      RSX_HIP(hipStreamWaitEvent(h->stream_b, h->lane_ev, 0));
+      RSX_TRY(upload(0, 0));
+      int64_t q0 = 0;
+      for (int c = 0; c < np; c++) {
+        hipStream_t lane = two_lanes && (c & 1) ? h->stream_b : h->stream;
+        h->w = &h->ws[two_lanes ? (c & 1) : 0];
+        RSX_HIP(hipStreamWaitEvent(lane, h->up_ev[c], 0));
+        RSX_TRY(query_device_locked(h, h->q_desc.as<float>() + q0 * DS, sizes[c], k, n_eligible,
+                                    h->topk.as<rsx_sc_hit>() + q0 * k, lane));
+        q0 += sizes[c];
+        if (c + 1 < np) RSX_TRY(upload(c + 1, q0));
+      }
+      RSX_HIP(hipEventRecord(h->lane_ev, h->stream_b));
+      RSX_HIP(hipStreamWaitEvent(h->stream, h->lane_ev, 0));
+      return RSX_OK;
+    };
+    const int st = all_pieces();
+    h->w = &h->ws[0];
+    if (st != RSX_OK) {  // nothing of this call may still be in flight when the caller gets its buffers back
+      (void)hipStreamSynchronize(h->up_stream);
+      (void)hipStreamSynchronize(h->stream_b);
+      (void)hipStreamSynchronize(h->stream);
+      return st;
+    }
+  }
   RSX_HIP(hipMemcpyAsync(out, h->topk.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
   return RSX_OK;
@@ -1292,10 +1403,10 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
   RSX_HIP(hipMemcpyAsync(h->q_desc.p, q_descs, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, s));
   QueryView qv;
   RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), nq, s, &qv));
-  RSX_TRY(h->f_qimg.reserve(any_qimg_bytes(nq), s, false));
-  RSX_TRY(h->f_lb.reserve((size_t)nq * ld * sizeof(float), s, false));
-  RSX_TRY(run_filter(h, qv, n, h->f_lb.as<float>(), ld, nullptr, s));
-  RSX_HIP(hipMemcpy2DAsync(out_lb, (size_t)n * sizeof(float), h->f_lb.p, (size_t)ld * sizeof(float), (size_t)n * sizeof(float),
+  RSX_TRY(h->w->f_qimg.reserve(any_qimg_bytes(nq), s, false));
+  RSX_TRY(h->w->f_lb.reserve((size_t)nq * ld * sizeof(float), s, false));
+  RSX_TRY(run_filter(h, qv, n, h->w->f_lb.as<float>(), ld, nullptr, s));
+  RSX_HIP(hipMemcpy2DAsync(out_lb, (size_t)n * sizeof(float), h->w->f_lb.p, (size_t)ld * sizeof(float), (size_t)n * sizeof(float),
                            (size_t)nq, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   return RSX_OK;
@@ -1319,14 +1430,14 @@ int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t 
   QueryView qv;
   RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), nq, s, &qv));
   RSX_TRY(filter_reserve(h, n, nq, s));
-  RSX_HIP(hipMemsetAsync(h->f_win.p, 0xff, (size_t)nq * WINDOW_P * sizeof(WindowPreview), s));
+  RSX_HIP(hipMemsetAsync(h->w->f_win.p, 0xff, (size_t)nq * WINDOW_P * sizeof(WindowPreview), s));
   RSX_TRY(filter_and_select(h, qv, n, h->n_global, nullptr, 128, k, s));
   std::vector<RescoreEntry> sl((size_t)nq * RESCORE_SHORTLIST_CAP);
   std::vector<WindowPreview> wp((size_t)nq * WINDOW_P);
   std::vector<int32_t> cnt((size_t)nq);
-  RSX_HIP(hipMemcpyAsync(sl.data(), h->f_cand.p, sl.size() * sizeof(RescoreEntry), hipMemcpyDeviceToHost, s));
-  RSX_HIP(hipMemcpyAsync(wp.data(), h->f_win.p, wp.size() * sizeof(WindowPreview), hipMemcpyDeviceToHost, s));
-  RSX_HIP(hipMemcpyAsync(cnt.data(), h->f_cnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipMemcpyAsync(sl.data(), h->w->f_cand.p, sl.size() * sizeof(RescoreEntry), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipMemcpyAsync(wp.data(), h->w->f_win.p, wp.size() * sizeof(WindowPreview), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipMemcpyAsync(cnt.data(), h->w->f_cnt.p, cnt.size() * sizeof(int32_t), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   for (int32_t q = 0; q < nq; q++) {
     const int32_t c = cnt[(size_t)q] < WINDOW_P ? cnt[(size_t)q] : WINDOW_P;

@@ -225,9 +225,13 @@ class SCManager:
         check(self._L.rsx_sc_load(self._h, os.fsencode(path), C.byref(n)))
         return n.value
 
-    def query(self, q_descs, k=1, n_eligible=-1):
+    def query(self, q_descs, k=1, n_eligible=-1, out=None):
+        """out: optional (nq, k) HIT_DTYPE array to fill (e.g. over pinned memory, _rsx.PinnedArray)"""
         q = np.ascontiguousarray(q_descs, dtype=np.float32).reshape(-1, 1200)
-        out = np.zeros((q.shape[0], k), dtype=HIT_DTYPE)
+        if out is None:
+            out = np.zeros((q.shape[0], k), dtype=HIT_DTYPE)
+        elif out.dtype != HIT_DTYPE or out.shape != (q.shape[0], k) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (nq, k) array of HIT_DTYPE")
         check(self._L.rsx_sc_query(self._h, q.ctypes.data, q.shape[0], k, n_eligible, out.ctypes.data))
         return out
 

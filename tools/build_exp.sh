@@ -1,21 +1,13 @@
 #!/bin/bash
-# librsx with the RSX_* experiment knobs compiled in (make EXPERIMENTS=1), as abtest/librsx_exp.so next to the product build:
-#   RSX_LIB_PATH=abtest/librsx_exp.so RSX_RESCORE_PROF=1 python bench.py ...
+# librsx with the host-side experiment knobs compiled in (sc_api.cpp with -DRSX_EXPERIMENTS: RSX_SC_HOST_PIECES,
+# RSX_SC_FIRST_TARGET, RSX_SC_FILTER ...): abtest/librsx_exp.so.  Kernels are the shipped objects.
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 C=$ROOT/navtech-radar-slam_amd/csrc
-B=/tmp/rsx_exp_build
-mkdir -p $ROOT/abtest $B
-FLAGS="-DRSX_EXPERIMENTS=1 --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -I$ROOT/include -I$C -Wall -Wno-unused-function"
-pids=()
-for f in $C/*.hip $C/*.cpp; do
-  o=$B/$(basename $f).o
-  if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$(find $C $ROOT/include -name '*.h' -newer $o | head -1)" ]; then
-    extra=""; [ "$(basename $f)" = sc_spec.hip ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
-    /opt/rocm/bin/hipcc $FLAGS $extra -x hip -c $f -o $o &
-    pids+=($!)
-  fi
-done
-for p in "${pids[@]}"; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $B/*.o -ldl -o $ROOT/abtest/librsx_exp.so
+make -C $C -j8 > /dev/null
+mkdir -p $ROOT/abtest /tmp/rsx_exp
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt \
+  -I$ROOT/include -I$C -DRSX_EXPERIMENTS=1 -x hip -c $C/sc_api.cpp -o /tmp/rsx_exp/sc_api.cpp.o
+OBJS=$(ls $C/build/*.o | grep -v sc_api.cpp.o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS /tmp/rsx_exp/sc_api.cpp.o -ldl -o $ROOT/abtest/librsx_exp.so
 echo built $ROOT/abtest/librsx_exp.so
