@@ -115,10 +115,12 @@ def random_db_and_queries(n_db, n_q, seed_db=1234, seed_q=4321):
 class Workload:
     """One DB (sharded over the ranks) + one resident query batch + the timed step."""
 
-    def __init__(self, ctx, name, k, capacity, filter_mode=0, query_groups=1):
+    def __init__(self, ctx, name, k, capacity, filter_mode=0, query_groups=1, filter_shards=False):
         from navtech_radar_slam_amd import sharded
         self.ctx, self.name, self.k = ctx, name, k
-        if ctx.stub:
+        if filter_shards:  # replicated DB, the filter cut over the ranks by slot range (one all-to-all of bound rows)
+            self.ssc = sharded.FilterShardedScanContext(device=ctx.local_rank, capacity_hint=capacity + 8, filter_mode=filter_mode)
+        elif ctx.stub:
             self.ssc = sharded.ShardedScanContext(local_backend=lambda sr, sw: ctx.stub(sr, sw), query_groups=query_groups)
         else:
             self.ssc = sharded.ShardedScanContext(device=ctx.local_rank, capacity_hint=capacity * query_groups // ctx.world + 8,
@@ -193,8 +195,7 @@ class Workload:
         return max(per_rank), per_rank, prof, resc
 
     def close(self):
-        if hasattr(self.mgr, "close"):
-            self.mgr.close()
+        self.ssc.close()  # the shard and the sub-communicators of its layout
 
 
 class Ctx:
@@ -806,20 +807,35 @@ def loop_verify_leg(device):
                     "(brute-force nearest neighbour) + gate; nothing but counts and the convergence flag returns to the host"}
 
 
-def layout_emulation_leg(device, db_descs, q_descs, n_elig, k):
-    """What ONE rank computes between the collectives in every layout of 2 / 4 / 8 GPUs, emulated on this one GPU: a handle
-    holding shard 0 of S (the DB descriptors handed over, the handle keeps its residue class) and the first nq / Q queries;
-    S > 1: stage 1 + stage 2 of the two-stage protocol (the stage-1 list of the shard itself as the bound: a looser
-    bound than the merged one, so stage 2 is not under-estimated); S = 1: the single-stage query.  The exchanges
-    (latency-bound all-gathers of 16-byte records, ~0.1 ms each, S > 1 only) and the final all-gather of the slices (Q > 1)
-    are NOT in these numbers; the real curve is the driver's SCALE_r*.json."""
+def layout_emulation_leg(device, db_descs, q_descs, n_elig, k, res=None, reps=5):
+    """What ONE rank computes between the collectives in every layout of 2 / 4 / 8 GPUs, emulated on this one GPU.
+    Q x S (query groups x DB shards): a handle holding shard 0 of S (the DB descriptors handed over, the handle keeps its
+    residue class) and the first nq / Q queries; S > 1: stage 1 + stage 2 of the two-stage protocol (the stage-1 list of
+    the shard itself as the bound: a looser bound than the merged one, so stage 2 is not under-estimated); S = 1: the
+    single-stage query.  `Gf` (filter shards over a replicated DB, sharded.FilterShardedScanContext): the range filter of
+    rank 0 for ALL queries (1 / G of the slots) + the short list / window / re-scoring of the first nq / G queries with the
+    column blocks an all-to-all would have delivered (computed beforehand, untimed); its records are checked against the
+    unsharded result `res`.  The exchanges are NOT in these numbers -- Q x S: latency-bound all-gathers of 16-byte
+    records (~0.1 ms each, S > 1 only) and the final all-gather of the slices; Gf: one all-to-all whose bytes per rank are
+    listed (`filter_shard_exchange`) -- the real curve is the driver's SCALE_r*.json."""
     import torch
-    from navtech_radar_slam_amd import scancontext
+    from navtech_radar_slam_amd import scancontext, sharded
     nq = len(q_descs)
     d_q = torch.from_numpy(q_descs).cuda()
     st = torch.cuda.current_stream().cuda_stream
     out = {}
     cache = {}
+
+    def timed(run):
+        for _ in range(2):
+            run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            run()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3
+
     for g in (1, 2, 4, 8):
         row = {}
         for q in [d for d in range(1, g + 1) if g % d == 0]:
@@ -837,25 +853,53 @@ def layout_emulation_leg(device, db_descs, q_descs, n_elig, k):
                     else:
                         h.query_stage1_device(d_q.data_ptr(), nq_r, k, a.data_ptr(), n_eligible=n_elig, stream=st)
                         h.query_stage2_device(nq_r, k, a.data_ptr(), b.data_ptr(), stream=st)
-                for _ in range(2):
-                    run()
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    run()
-                torch.cuda.synchronize()
-                cache[(s_w, nq_r)] = (time.perf_counter() - t0) / 5 * 1e3
+                cache[(s_w, nq_r)] = timed(run)
                 h.close()
             row[f"{q}x{s_w}"] = cache[(s_w, nq_r)]
         out[str(g)] = row
+    # filter shards over the replicated DB
+    h = scancontext.SCManager(device=device, capacity_hint=len(db_descs) + 8)
+    h.add_descriptors_f32(db_descs)
+    exchange, identical = {}, True
+    for g in (2, 4, 8):
+        lay = sharded.FilterShardedScanContext.__new__(sharded.FilterShardedScanContext)
+        lay.world = g
+        ld_r, rng = lay.ranges(n_elig)
+        chunk = -(-nq // g)
+        send = torch.zeros((g * chunk, ld_r), dtype=torch.float32, device="cuda")
+        recv = torch.zeros((g, chunk, ld_r), dtype=torch.float32, device="cuda")
+        for r, (first, cnt) in enumerate(rng):  # what rank 0 receives: rows [0, chunk) of every rank's matrix
+            h.filter_range_device(d_q.data_ptr(), nq, first, cnt, send.data_ptr(), ld_r, stream=st)
+            torch.cuda.synchronize()  # st is the handle's own stream, not ordered with torch's copy
+            recv[r].copy_(send[:chunk])
+            torch.cuda.synchronize()
+        mine = torch.zeros((chunk, k, 2), dtype=torch.float64, device="cuda")
+
+        def run():
+            h.filter_range_device(d_q.data_ptr(), nq, rng[0][0], rng[0][1], send.data_ptr(), ld_r, stream=st)
+            h.query_bounds_device(d_q.data_ptr(), min(chunk, nq), k, mine.data_ptr(), recv.data_ptr(), g, ld_r, chunk * ld_r,
+                                  n_eligible=n_elig, stream=st)
+        out[str(g)][f"{g}f"] = timed(run)
+        if res is not None:
+            got = mine.cpu().numpy().view(scancontext.HIT_DTYPE).reshape(chunk, k)
+            identical = identical and bool(np.array_equal(got[:min(chunk, nq)], res[:min(chunk, nq)]))
+        exchange[f"{g}f"] = {"all_to_all_bytes_sent_per_rank": int((g - 1) * chunk * ld_r * 4),
+                             "ms_at_50GBps_per_peer_link": (chunk * ld_r * 4) / 50e9 * 1e3}
+        del send, recv
+    h.close()
     base = out["1"]["1x1"]
     return {"per_rank_ms_per_step": out, "best_layout": {g: min(r, key=r.get) for g, r in out.items()},
             "compute_speedup_of_best_layout": {g: base / min(r.values()) for g, r in out.items()},
-            "layout_key": "query groups x DB shards",
-            "note": "per-rank compute between the collectives, emulated on ONE GPU (not a multi-GPU measurement); exchanges excluded"}
+            "compute_speedup_db_shards_only": {g: base / r[f"1x{g}"] for g, r in out.items()},
+            "compute_speedup_filter_shards": {g: base / r[f"{g}f"] for g, r in out.items() if f"{g}f" in r},
+            "filter_shard_exchange": exchange, "filter_shard_records_identical": identical if res is not None else None,
+            "layout_key": "QxS = query groups x DB shards (two-stage protocol inside a group); Gf = filter shards over a "
+                          "replicated DB (one all-to-all of bound rows)",
+            "note": "per-rank compute between the collectives, emulated on ONE GPU (not a multi-GPU measurement); exchanges excluded. "
+                    "ms_at_50GBps_per_peer_link: every peer pair moves its block over its own xGMI link concurrently"}
 
 
-def host_entry_leg(mgr, q_descs, n_elig, k, resident_ms, reps=5):
+def host_entry_leg(mgr, q_descs, n_elig, k, resident_ms, reps=20):
     """the same batch through the synchronous HOST-buffer entry (rsx_sc_query): host queries in
     (nq x 4800 B over PCIe), host records out (nq x k x 16 B), upload and download inside the time.  The call cuts the batch
     into pieces and uploads piece c + 1 while piece c is scored (sc_api.cpp host_pieces); timed from pageable memory (what a
@@ -864,7 +908,8 @@ def host_entry_leg(mgr, q_descs, n_elig, k, resident_ms, reps=5):
     _rsx = import_module("navtech-radar-slam_amd._rsx")
 
     def timed(q, out):
-        mgr.query(q, k=k, n_eligible=n_elig, out=out)
+        for _ in range(15):  # the leg follows host-side set-up with the GPU idle: let the clocks come back up (cf. settle_steps)
+            mgr.query(q, k=k, n_eligible=n_elig, out=out)
         t0 = time.perf_counter()
         for _ in range(reps):
             mgr.query(q, k=k, n_eligible=n_elig, out=out)
@@ -1080,9 +1125,20 @@ def main():
                 failures.append(f"layout {wl.ssc.layout} disagrees with layout {main_wl.ssc.layout}")
             lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl], "identical_to_headline": same}
             wl.close()
+        if not ctx.stub:
+            wl = Workload(ctx, main_wl.name, k, n_db, filter_shards=True)
+            wl.add_descriptors(fill)
+            wl.set_queries(q_descs, n_elig)
+            dtl, prl, _, _ = wl.timed(st_l, 1)
+            same = bool(np.array_equal(wl.results(), res))
+            if not same:
+                failures.append(f"layout {wl.ssc.layout} disagrees with layout {main_wl.ssc.layout}")
+            lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl], "identical_to_headline": same}
+            wl.close()
         if rank == 0:
             out["layouts"] = lay
-            out["layouts_key"] = "query groups x DB shards; identical results in every layout"
+            out["layouts_key"] = ("QxS = query groups x DB shards; Gf = filter shards over a replicated DB (one all-to-all of bound rows); "
+                                  "identical results in every layout")
 
     # ---- data dependence: the random DB and the exact-all floor, same batch shape --------------
     if not ctx.stub and not args.only_main:
@@ -1158,7 +1214,6 @@ def main():
         d100, q100, s100, r100 = random_db_and_queries(n100, nq, seed_db=2234, seed_q=5321)
         wl = Workload(ctx, "random100k", k, n100, query_groups=qgroups)
         wl.add_descriptors(d100)
-        del d100
         wl.set_queries(q100, n100 - 30)
         st100 = max(3, args.steps // 4)
         dt100, pr100, _, (ev100, cd100) = wl.timed(st100, 2, profile=True)
@@ -1168,8 +1223,17 @@ def main():
         if not p100:
             failures.append("100k DB: planted loops not recovered as top-1")
         wl.close()
+        emu100 = None
+        if world == 1 and not ctx.stub:
+            # BASELINE configs[4]: the per-layout figures for the DB size where sharding is supposed to pay
+            emu100 = layout_emulation_leg(ctx.local_rank, d100, q100, n100 - 30, k, res=r, reps=3)
+            if emu100["filter_shard_records_identical"] is False:
+                failures.append("layout emulation (100k): the filter-shard layout's records differ from the unsharded ones")
+        del d100
         if rank == 0:
             out["data_dependence"] = dd
+            if emu100 is not None:
+                out["layout_emulation_100k"] = emu100
             out["scale_100k"] = {"value": nq * st100 / dt100, "unit": "queries/s", "ms_per_step": dt100 / st100 * 1e3, "steps": st100,
                                  "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n100}_random", "n_gpus": world, "scaling": "strong",
                                  "layout": f"{qgroups}x{world // qgroups}",
@@ -1184,7 +1248,9 @@ def main():
                 failures.append("host-buffer entry: pinned and pageable buffers give different records")
             if not np.array_equal(main_wl.mgr.query(q_descs[:64], k=k, n_eligible=n_elig), res[:64]):
                 failures.append("host-buffer entry disagrees with the device entry")
-            out["layout_emulation"] = layout_emulation_leg(ctx.local_rank, db_descs, q_descs, n_elig, k)
+            out["layout_emulation"] = layout_emulation_leg(ctx.local_rank, db_descs, q_descs, n_elig, k, res=res)
+            if out["layout_emulation"]["filter_shard_records_identical"] is False:
+                failures.append("layout emulation: the filter-shard layout's records differ from the unsharded ones")
         if not args.only_main:
             # BASELINE configs[1]: 1 query vs 1k-keyframe DB (latency of the synchronous host call)
             small = scancontext.SCManager(device=ctx.local_rank)

@@ -106,6 +106,7 @@ _lib = None
 # every symbol include/rsx.h declares (tests check the .so exports exactly these)
 SYMBOLS = [
     "rsx_last_error_string", "rsx_version", "rsx_device_count", "rsx_selftest_firewall",
+    "rsx_sc_filter_range_device", "rsx_sc_query_bounds_device",
     "rsx_sc_default_params", "rsx_sc_create", "rsx_sc_destroy", "rsx_sc_set_dist_thres", "rsx_sc_size",
     "rsx_sc_local_size", "rsx_sc_add_points", "rsx_sc_add_descriptor", "rsx_sc_add_descriptors_f32",
     "rsx_sc_add_descriptors_f32_device", "rsx_sc_add_descriptor_rounded", "rsx_sc_export_descriptors_f32",
@@ -190,6 +191,8 @@ def lib():
         L.rsx_sc_query.argtypes = [vp, vp, i32, i32, i64, vp]
         L.rsx_sc_query_device.argtypes = [vp, vp, i32, i32, i64, vp, vp]
         L.rsx_sc_query_stage1_device.argtypes = [vp, vp, i32, i32, i64, vp, vp]
+        L.rsx_sc_filter_range_device.argtypes = [vp, vp, i32, i64, i64, vp, i64, vp]
+        L.rsx_sc_query_bounds_device.argtypes = [vp, vp, i32, i32, i64, vp, i32, i64, i64, vp, vp]
         L.rsx_sc_query_stage1_elig_device.argtypes = [vp, vp, i32, i32, i64, vp, i32, vp, vp]
         L.rsx_sc_query_stage2_device.argtypes = [vp, i32, i32, vp, vp, vp]
         L.rsx_sc_query_self_device.argtypes = [vp, i64, i32, i32, i64, i32, vp, vp]

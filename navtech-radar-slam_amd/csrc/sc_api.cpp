@@ -240,9 +240,16 @@ size_t any_qimg_bytes(int32_t nq) {
 }
 
 // query images + bounds of one batch with the chosen filter form
+// first (a multiple of 32, the images are tile-major): the bounds of local slots [first, first + n_items), lb[q * ld + slot - first]
 int run_filter(rsx_sc *h, const QueryView &q, int64_t n_items, float *lb, int64_t ld, const FilterPlanInput *plan,
-               hipStream_t s) {
-  const DbView db = db_view(h);
+               hipStream_t s, int64_t first = 0) {
+  DbView db = db_view(h);
+  if (first) {
+    db.hnT = static_cast<const char *>(db.hnT) + first * FILTER_DB_BYTES_PER_ENTRY;
+    db.spT = static_cast<const char *>(db.spT) + first * SPEC_DB_BYTES_PER_ENTRY;
+    db.cmask += first;
+    db.sp_aux += first;
+  }
   if (plan) RSX_TRY(h->w->f_plan.reserve(filter_plan_bytes(n_items), s, false));
   if (filter_kind_of(h) >= 1) {
     const bool two_waves = filter_kind_of(h) == 2;
@@ -325,6 +332,15 @@ int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, 
                         use_window() ? h->w->f_win.as<WindowPreview>() : nullptr);
 }
 
+int32_t first_round_target() {
+  static const int32_t v = [] {
+    const char *e = rsx::exp_env("RSX_SC_FIRST_TARGET");
+    const int x = e ? atoi(e) : 0;
+    return (x >= 1 && x <= 128) ? x : 128;
+  }();
+  return v;
+}
+
 // exhaustive top-k through the MFMA lower-bound filter (sc_filter.hip): filter -> short list ->
 // exact re-scoring in rounds of ascending bound.  Everything stays on the stream; no host sync.
 int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
@@ -344,12 +360,7 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     // costs more in barriers than in arithmetic, so the first one is large: measured on MI355X (10k trajectory DB, 8192
     // queries, ms per step / exact evaluations per query): 64 -> 4.24 / 11.2, 128 -> 4.18 / 10.4; the one-pass scoring of
     // round 1 (RSX_SC_TWO_PHASE=0: first round scored exactly, 96 evaluations per query) 4.0 with 64
-    static const int32_t first_target = [] {
-      const char *e = rsx::exp_env("RSX_SC_FIRST_TARGET");
-      const int v = e ? atoi(e) : 0;
-      return (v >= 1 && v <= 128) ? v : 128;
-    }();
-    RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, first_target, k, s, elig_monotone));
+    RSX_TRY(filter_and_select(h, q, n_items, n_eligible, elig, first_round_target(), k, s, elig_monotone));
     // exact re-scoring: the 8-wave workgroup in rounds (sc_rescore_kernel; also what the sharded stages use), or
     // -- RSX_SC_RESCORE=walk, experimental -- one wave per query walking the bound-ordered short list with
     // the fp32 pruning preview (sc_walk_kernel: identical results, 6.3 instead of 5.6 ms per step on the bench:
@@ -1269,6 +1280,61 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
   }
   RSX_HIP(hipMemcpyAsync(out, h->topk.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
+  return RSX_OK;
+} RSX_CATCH_ALL
+
+// ---- filter shards over a replicated database (rsx.h: "filter-shard layout") ----
+int rsx_sc_filter_range_device(rsx_sc *h, const float *d_q, int32_t nq, int64_t first_slot, int64_t n_slots, float *d_lb,
+                               int64_t ld, void *stream) try {
+  if (!h || !d_q || !d_lb || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (first_slot < 0 || first_slot % 32 || n_slots < 0) return fail(RSX_ERR_BAD_ARG, "the range must start at a multiple of 32 slots");
+  if (ld < (n_slots + 31) / 32 * 32 || ld % 4) return fail(RSX_ERR_BAD_ARG, "ld must cover the range rounded up to 32 slots");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  if (first_slot + n_slots > h->n_local) return fail(RSX_ERR_RANGE, "slots [%lld, %lld) of %lld", (long long)first_slot,
+                                                     (long long)(first_slot + n_slots), (long long)h->n_local);
+  if (n_slots == 0) return RSX_OK;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  QueryView qv;
+  RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
+  RSX_TRY(h->w->f_qimg.reserve(any_qimg_bytes(nq), s, false));
+  return run_filter(h, qv, n_slots, d_lb, ld, nullptr, s, first_slot);
+} RSX_CATCH_ALL
+
+int rsx_sc_query_bounds_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, const float *d_lb_blocks,
+                               int32_t n_blocks, int64_t block_ld, int64_t block_stride, rsx_sc_hit *d_out, void *stream) try {
+  if (!h || !d_q || !d_lb_blocks || !d_out || nq < 1 || n_blocks < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_TRY(set_device(h));
+  if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "bounds from filter shards need the whole database in this handle (shard_world 1)");
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  QueryView qv;
+  RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
+  const int64_t n_elig = n_eligible < 0 ? h->n_global : n_eligible;
+  const int64_t n_items = local_count_below(h, n_eligible);
+  if (n_items <= 0) return launch_pairs(db_view(h), qv, nullptr, 0, 0, n_elig, nullptr, nullptr, nullptr, nullptr, d_out, k, s);
+  const int64_t ld = (n_items + 31) / 32 * 32;
+  if (block_ld < 32 || block_ld % 32 || (int64_t)n_blocks * block_ld < ld || block_stride < (int64_t)nq * block_ld)
+    return fail(RSX_ERR_BAD_ARG, "%d blocks of %lld columns do not cover %lld eligible entries", n_blocks, (long long)block_ld,
+                (long long)n_items);
+  const int64_t qb = filter_batch(n_items, nq);
+  RSX_TRY(filter_reserve(h, n_items, qb, s));
+  const DbView db = db_view(h);
+  for (int64_t b0 = 0; b0 < nq; b0 += qb) {
+    QueryView q = qv;
+    q.desc = qv.desc + b0 * DS;
+    q.vkey = qv.vkey + b0 * NS;
+    q.norm = qv.norm + b0 * NS;
+    q.nq = (int32_t)((nq - b0 < qb) ? (nq - b0) : qb);
+    RSX_TRY(launch_gather_bounds(d_lb_blocks, block_ld, block_stride, b0, q.nq, h->w->f_lb.as<float>(), ld, s));
+    RSX_TRY(launch_select(db, h->w->f_lb.as<float>(), ld, n_items, q.nq, n_elig, nullptr, first_round_target(), h->w->f_cand.as<RescoreEntry>(),
+                          h->w->f_cnt.as<int32_t>(), h->w->f_thr.as<float>(), s));
+    if (use_window())
+      RSX_TRY(launch_window(db, q, h->w->f_wimg.p, h->w->f_cand.as<RescoreEntry>(), h->w->f_cnt.as<int32_t>(), k, filter_eps(),
+                            h->w->f_win.as<WindowPreview>(), s));
+    RSX_TRY(rescore(h, q, n_items, n_elig, nullptr, 0, RESCORE_ALL_ROUNDS, nullptr, nullptr, k, d_out + b0 * k, s));
+  }
   return RSX_OK;
 } RSX_CATCH_ALL
 

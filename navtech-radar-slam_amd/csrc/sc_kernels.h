@@ -66,6 +66,11 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
 int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *d_out,
                  hipStream_t s);
 
+// d_lb[q][c] (ld floats per row, nq rows) = d_blocks[c / block_ld][q0 + q][c % block_ld]: the column blocks the filter
+// shards of a replicated DB deliver (block b starts block_stride floats after block b - 1) as one bound matrix
+int launch_gather_bounds(const float *d_blocks, int64_t block_ld, int64_t block_stride, int64_t q0, int32_t nq, float *d_lb,
+                         int64_t ld, hipStream_t s);
+
 // exact k-NN over ring keys [0, n_search) with nanoflann's float L2 (NF.hpp:383-408);
 // d_dist_ws: n_search floats of workspace; out_idx[k] (unfilled = 0), out_found[1]
 int launch_knn(const float *rkeys, int64_t n_search, const float *qkey, int32_t k, float *d_dist_ws,

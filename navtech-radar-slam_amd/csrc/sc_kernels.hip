@@ -1061,6 +1061,20 @@ __global__ __launch_bounds__(256, W) void sc_pair2_kernel(PairArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// bounds delivered as column blocks (one per filter shard, each [rows][block_ld]) -> one row-major matrix
+// lb[q][c] = blocks[c / block_ld][q0 + q][c % block_ld].  block_ld is a multiple of 32: a float4 stays inside one block
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sc_gather_bounds_kernel(const float *__restrict__ blocks, int64_t block_ld,
+                                                               int64_t block_stride, int64_t q0, float *__restrict__ lb,
+                                                               int64_t ld) {
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c >= ld) return;
+  const int64_t q = blockIdx.y, b = c / block_ld, j = c - b * block_ld;
+  const float4 v = *reinterpret_cast<const float4 *>(blocks + b * block_stride + (q0 + q) * block_ld + j);
+  *reinterpret_cast<float4 *>(lb + q * ld + c) = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // merge: per query, k rounds of "smallest record strictly after the previous pick"
 // records are unique in (dist,index) except the padding {inf, INT_MAX} / {1e7,0,0}
 // ------------------------------------------------------------------------------------------
@@ -1643,6 +1657,19 @@ int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t 
   if (nq <= 0) return RSX_OK;
   hipLaunchKernelGGL(sc_merge_kernel, dim3(nq), dim3(64), 0, s, d_parts, nparts, (int64_t)nq * k, (int64_t)k, k, k, d_out);
   RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_gather_bounds(const float *d_blocks, int64_t block_ld, int64_t block_stride, int64_t q0, int32_t nq, float *d_lb,
+                         int64_t ld, hipStream_t s) {
+  if (nq <= 0 || ld <= 0) return RSX_OK;
+  if (block_ld < 32 || block_ld % 32 || ld % 4) return fail(RSX_ERR_BAD_ARG, "bound blocks must be a multiple of 32 columns wide");
+  for (int32_t r0 = 0; r0 < nq; r0 += 65535) {  // gridDim.y
+    const int32_t rows = nq - r0 < 65535 ? nq - r0 : 65535;
+    hipLaunchKernelGGL(sc_gather_bounds_kernel, dim3((unsigned)((ld / 4 + 255) / 256), (unsigned)rows), dim3(256), 0, s, d_blocks,
+                       block_ld, block_stride, q0 + r0, d_lb + (int64_t)r0 * ld, ld);
+    RSX_HIP(hipGetLastError());
+  }
   return RSX_OK;
 }
 

@@ -246,6 +246,15 @@ class SCManager:
         else:
             check(self._L.rsx_sc_query_stage1_device(self._h, q_ptr, nq, k, n_eligible, partial_ptr, stream))
 
+    def filter_range_device(self, q_ptr, nq, first_slot, n_slots, lb_ptr, ld, stream=0):
+        """bounds of nq device queries against slots [first_slot, first_slot + n_slots) -> device float [nq][ld]"""
+        check(self._L.rsx_sc_filter_range_device(self._h, q_ptr, nq, first_slot, n_slots, lb_ptr, ld, stream))
+
+    def query_bounds_device(self, q_ptr, nq, k, out_ptr, lb_blocks_ptr, n_blocks, block_ld, block_stride, n_eligible=-1, stream=0):
+        """rsx_sc_query_device with the bounds supplied as column blocks (what the filter shards of a replicated DB deliver)"""
+        check(self._L.rsx_sc_query_bounds_device(self._h, q_ptr, nq, k, n_eligible, lb_blocks_ptr, n_blocks, block_ld,
+                                                 block_stride, out_ptr, stream))
+
     def query_stage2_device(self, nq, k, global_ptr, out_ptr, stream=0):
         check(self._L.rsx_sc_query_stage2_device(self._h, nq, k, global_ptr, out_ptr, stream))
 

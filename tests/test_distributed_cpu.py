@@ -144,3 +144,96 @@ def test_auto_layout():
     from navtech_radar_slam_amd.sharded import auto_layout
     assert auto_layout(8, 8192) == 8 and auto_layout(8, 2048) == 4 and auto_layout(8, 1) == 1 and auto_layout(1, 8192) == 1
     assert auto_layout(4, 1500) == 2 and auto_layout(6, 8192) == 6
+
+
+class OracleReplica:
+    """Local backend of the filter-shard layout (sharded.FilterShardedScanContext): the whole DB on every rank, searched by
+    the oracle.  Its "filter" returns 0.9 x the exact distance of every pair (a valid lower bound that identifies the pair);
+    the scoring side checks that the bounds it was handed are exactly those -- i.e. that the all-to-all delivered the
+    right rows of the right column blocks -- and prunes with them."""
+
+    def __init__(self, oracle):
+        self.o = oracle
+        self.m = oracle.Manager()
+
+    def __len__(self):
+        return len(self.m)
+
+    def add_descriptors_f32(self, descs):
+        self.m.add_descriptors(np.asarray(descs, dtype=np.float32).reshape(-1, 1200).astype(np.float64))
+
+    def _dists(self, qi, n):
+        r = self.m.exhaustive(qi.astype(np.float64), n_eligible=n, k=max(n, 1))
+        d = np.full(n, np.inf)
+        ok = r["dist"] < 1e7
+        d[r["index"][ok]] = r["dist"][ok]
+        return d
+
+    def filter_range(self, q, first, n):
+        self.calls = getattr(self, "calls", 0) + 1
+        out = np.empty((q.shape[0], n), dtype=np.float32)
+        for i in range(q.shape[0]):
+            out[i] = (0.9 * self._dists(q[i], first + n)[first:]).astype(np.float32)
+        return out
+
+    def query_bounds(self, q, k, n_eligible, lb):
+        n_e = len(self) if n_eligible < 0 else min(n_eligible, len(self))
+        assert lb.shape == (q.shape[0], n_e), (lb.shape, q.shape, n_e)
+        out = np.zeros((q.shape[0], k), dtype=self.o.HIT_DTYPE)
+        for i in range(q.shape[0]):
+            d = self._dists(q[i], n_e)
+            assert np.array_equal(lb[i], (0.9 * d).astype(np.float32)), "bounds of another query / another column block"
+            out[i] = self.m.exhaustive(q[i].astype(np.float64), n_eligible=n_e, k=k)
+            kth = out[i]["dist"][-1]
+            assert not np.any((lb[i] > kth) & np.isin(np.arange(n_e), out[i]["index"][out[i]["dist"] < 1e7]))
+        return out
+
+
+def _worker_filter_shards(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from oracle import pyoracle as po
+    from navtech_radar_slam_amd import sharded, synth
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, nq, k = 171, 7, 4
+        descs = synth.random_descriptors(77, n, binary=True)
+        queries = np.stack([synth.rotate_descriptor(descs[13 * i + 3], 7 * i) for i in range(nq)])
+        queries[-1][:] = 0
+        sc = sharded.FilterShardedScanContext(local_backend=OracleReplica(po))
+        assert sc.layout == f"{world}f"
+        sc.add_descriptors_f32(descs[:100])
+        sc.add_descriptors_f32(descs[100:])
+        assert len(sc.backend) == n                                   # every rank keeps everything
+        ld_r, rng = sc.ranges(n)
+        assert ld_r % 32 == 0 and sum(c for _, c in rng) == n and all(f % 32 == 0 for f, _ in rng)
+        full = po.Manager()
+        full.add_descriptors(descs.astype(np.float64))
+        for n_elig in (-1, n - 30, 33, 1):                            # 33 entries: the last ranks' ranges are empty
+            for qs in (queries, queries[:1]):                         # 1 query over 2-3 ranks: ranks with an empty slice
+                got = sc.query(qs, k=k, n_eligible=n_elig)
+                for i in range(len(qs)):
+                    want = full.exhaustive(qs[i].astype(np.float64), n_eligible=n if n_elig < 0 else n_elig, k=k)
+                    assert np.array_equal(got[i], want), (rank, n_elig, i, got[i], want)
+        ret[rank] = "ok"
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_filter_shard_layout_gloo(world):
+    """Replicated DB, the filter cut over the ranks by slot range, ONE all-to-all of bound-matrix row slices, every rank
+    scores its slice of the batch, all-gather (sharded.FilterShardedScanContext): identical to the unsharded oracle on every
+    rank, including eligibility limits that leave ranks without entries and batches that leave ranks without queries."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_filter_shards, args=(r, world, port, ret)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=300)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert dict(ret) == {r: "ok" for r in range(world)}
