@@ -866,8 +866,8 @@ def layout_emulation_leg(device, db_descs, q_descs, n_elig, k, res=None, reps=5)
         lay.world = g
         ld_r, rng = lay.ranges(n_elig)
         chunk = -(-nq // g)
-        send = torch.zeros((g * chunk, ld_r), dtype=torch.float32, device="cuda")
-        recv = torch.zeros((g, chunk, ld_r), dtype=torch.float32, device="cuda")
+        send = torch.zeros((g * chunk, ld_r), dtype=torch.float16, device="cuda")
+        recv = torch.zeros((g, chunk, ld_r), dtype=torch.float16, device="cuda")
         for r, (first, cnt) in enumerate(rng):  # what rank 0 receives: rows [0, chunk) of every rank's matrix
             h.filter_range_device(d_q.data_ptr(), nq, first, cnt, send.data_ptr(), ld_r, stream=st)
             torch.cuda.synchronize()  # st is the handle's own stream, not ordered with torch's copy
@@ -883,8 +883,8 @@ def layout_emulation_leg(device, db_descs, q_descs, n_elig, k, res=None, reps=5)
         if res is not None:
             got = mine.cpu().numpy().view(scancontext.HIT_DTYPE).reshape(chunk, k)
             identical = identical and bool(np.array_equal(got[:min(chunk, nq)], res[:min(chunk, nq)]))
-        exchange[f"{g}f"] = {"all_to_all_bytes_sent_per_rank": int((g - 1) * chunk * ld_r * 4),
-                             "ms_at_50GBps_per_peer_link": (chunk * ld_r * 4) / 50e9 * 1e3}
+        exchange[f"{g}f"] = {"all_to_all_bytes_sent_per_rank": int((g - 1) * chunk * ld_r * 2),
+                             "ms_at_50GBps_per_peer_link": (chunk * ld_r * 2) / 50e9 * 1e3}
         del send, recv
     h.close()
     base = out["1"]["1x1"]

@@ -219,15 +219,18 @@ int rsx_sc_query_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k
  *   caller         all-gather of d_out
  * The records are those of rsx_sc_query_device on one GPU (the bounds of a pair do not depend on who computed them).
  * first_slot must be a multiple of 32 (the filter images are stored in tiles of 32 entries); d_lb[q * ld + j] is the bound
- * of query q against slot first_slot + j, ld >= n_slots rounded up to 32 (columns past n_slots are unspecified). */
+ * of query q against slot first_slot + j, ld >= n_slots rounded up to 32 (columns past n_slots are unspecified).
+ * Bounds are IEEE binary16 (rsx_f16), rounded toward zero -- the element type of the library's own bound matrix. */
+typedef uint16_t rsx_f16;
 int rsx_sc_filter_range_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int64_t first_slot, int64_t n_slots,
-                               float *d_lb, int64_t ld, void *stream);
-/* d_lb_blocks: n_blocks column blocks, block b = [nq][block_ld] floats starting b * block_stride floats into the buffer,
+                               rsx_f16 *d_lb, int64_t ld, void *stream);
+/* d_lb_blocks: n_blocks column blocks, block b = [nq][block_ld] bounds starting b * block_stride elements (a multiple of 8)
+ * into the buffer,
  * its column j = the bound against slot b * block_ld + j (block_ld a multiple of 32; the blocks together must cover every
  * entry below n_eligible).  Scores nq queries exactly like rsx_sc_query_device, with these bounds in place of its own
  * filter launch. */
 int rsx_sc_query_bounds_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k, int64_t n_eligible,
-                               const float *d_lb_blocks, int32_t n_blocks, int64_t block_ld, int64_t block_stride,
+                               const rsx_f16 *d_lb_blocks, int32_t n_blocks, int64_t block_ld, int64_t block_stride,
                                rsx_sc_hit *d_out, void *stream);
 /* The same query in two stages, for a DB sharded over several GPUs.  With one stage
  * every shard would have to re-score the entries that look promising against ITS OWN k-th best

@@ -241,7 +241,7 @@ size_t any_qimg_bytes(int32_t nq) {
 
 // query images + bounds of one batch with the chosen filter form
 // first (a multiple of 32, the images are tile-major): the bounds of local slots [first, first + n_items), lb[q * ld + slot - first]
-int run_filter(rsx_sc *h, const QueryView &q, int64_t n_items, float *lb, int64_t ld, const FilterPlanInput *plan,
+int run_filter(rsx_sc *h, const QueryView &q, int64_t n_items, lb_t *lb, int64_t ld, const FilterPlanInput *plan,
                hipStream_t s, int64_t first = 0) {
   DbView db = db_view(h);
   if (first) {
@@ -283,7 +283,7 @@ int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
   h->st.valid = false;  // bounds / short lists of a pending stage 2 are about to be overwritten
   const int64_t ld = (n_items + 31) / 32 * 32;
   RSX_TRY(h->w->f_qimg.reserve(any_qimg_bytes((int32_t)qb), s, false));
-  RSX_TRY(h->w->f_lb.reserve((size_t)qb * ld * sizeof(float), s, false));
+  RSX_TRY(h->w->f_lb.reserve((size_t)qb * ld * sizeof(lb_t), s, false));
   RSX_TRY(h->w->f_cand.reserve((size_t)qb * RESCORE_SHORTLIST_CAP * sizeof(RescoreEntry), s, false));
   RSX_TRY(h->w->f_cnt.reserve((size_t)qb * sizeof(int32_t), s, false));
   RSX_TRY(h->w->f_thr.reserve((size_t)qb * RESCORE_THR_STRIDE * sizeof(float), s, false));
@@ -307,7 +307,7 @@ int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_
                       int32_t first_target, int32_t k, hipStream_t s, bool elig_monotone = false) {
   const DbView db = db_view(h);
   const int64_t ld = (n_items + 31) / 32 * 32;
-  float *lb = h->w->f_lb.as<float>();
+  lb_t *lb = h->w->f_lb.as<lb_t>();
   {
     FilterPlanInput plan{n_eligible, elig};
     const bool planned = elig_monotone && elig != nullptr;
@@ -326,7 +326,7 @@ int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, 
             int32_t round_end, const rsx_sc_hit *tau_src, const rsx_sc_hit *seed, int32_t k, rsx_sc_hit *d_out,
             hipStream_t s) {
   const int64_t ld = (n_items + 31) / 32 * 32;
-  return launch_rescore(db_view(h), q, h->w->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->w->f_cand.as<RescoreEntry>(),
+  return launch_rescore(db_view(h), q, h->w->f_lb.as<lb_t>(), ld, n_items, n_eligible, elig, h->w->f_cand.as<RescoreEntry>(),
                         h->w->f_cnt.as<int32_t>(), h->w->f_thr.as<float>(), filter_eps(), round_begin, round_end, tau_src,
                         seed, d_out, k, s, (h->prof.on && h->stats.p) ? h->stats.as<unsigned long long>() : nullptr,
                         use_window() ? h->w->f_win.as<WindowPreview>() : nullptr);
@@ -371,7 +371,7 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
     }();
     if (use_walk) {
       const int64_t ld = (n_items + 31) / 32 * 32;
-      RSX_TRY(launch_walk(db_view(h), q, h->w->f_lb.as<float>(), ld, n_items, n_eligible, elig, h->w->f_cand.as<RescoreEntry>(),
+      RSX_TRY(launch_walk(db_view(h), q, h->w->f_lb.as<lb_t>(), ld, n_items, n_eligible, elig, h->w->f_cand.as<RescoreEntry>(),
                           h->w->f_cnt.as<int32_t>(), h->w->f_thr.as<float>(), filter_eps(), d_out + b0 * k, k, s));
     } else {
       RSX_TRY(rescore(h, q, n_items, n_eligible, elig, 0, RESCORE_ALL_ROUNDS, nullptr, nullptr, k, d_out + b0 * k, s));
@@ -1284,11 +1284,11 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
 } RSX_CATCH_ALL
 
 // ---- filter shards over a replicated database (rsx.h: "filter-shard layout") ----
-int rsx_sc_filter_range_device(rsx_sc *h, const float *d_q, int32_t nq, int64_t first_slot, int64_t n_slots, float *d_lb,
+int rsx_sc_filter_range_device(rsx_sc *h, const float *d_q, int32_t nq, int64_t first_slot, int64_t n_slots, rsx_f16 *d_lb,
                                int64_t ld, void *stream) try {
   if (!h || !d_q || !d_lb || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (first_slot < 0 || first_slot % 32 || n_slots < 0) return fail(RSX_ERR_BAD_ARG, "the range must start at a multiple of 32 slots");
-  if (ld < (n_slots + 31) / 32 * 32 || ld % 4) return fail(RSX_ERR_BAD_ARG, "ld must cover the range rounded up to 32 slots");
+  if (ld < (n_slots + 31) / 32 * 32 || ld % 8) return fail(RSX_ERR_BAD_ARG, "ld must cover the range rounded up to 32 slots");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   if (first_slot + n_slots > h->n_local) return fail(RSX_ERR_RANGE, "slots [%lld, %lld) of %lld", (long long)first_slot,
@@ -1298,10 +1298,10 @@ int rsx_sc_filter_range_device(rsx_sc *h, const float *d_q, int32_t nq, int64_t 
   QueryView qv;
   RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
   RSX_TRY(h->w->f_qimg.reserve(any_qimg_bytes(nq), s, false));
-  return run_filter(h, qv, n_slots, d_lb, ld, nullptr, s, first_slot);
+  return run_filter(h, qv, n_slots, reinterpret_cast<lb_t *>(d_lb), ld, nullptr, s, first_slot);
 } RSX_CATCH_ALL
 
-int rsx_sc_query_bounds_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, const float *d_lb_blocks,
+int rsx_sc_query_bounds_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, const rsx_f16 *d_lb_blocks,
                                int32_t n_blocks, int64_t block_ld, int64_t block_stride, rsx_sc_hit *d_out, void *stream) try {
   if (!h || !d_q || !d_lb_blocks || !d_out || nq < 1 || n_blocks < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
@@ -1315,7 +1315,7 @@ int rsx_sc_query_bounds_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t 
   const int64_t n_items = local_count_below(h, n_eligible);
   if (n_items <= 0) return launch_pairs(db_view(h), qv, nullptr, 0, 0, n_elig, nullptr, nullptr, nullptr, nullptr, d_out, k, s);
   const int64_t ld = (n_items + 31) / 32 * 32;
-  if (block_ld < 32 || block_ld % 32 || (int64_t)n_blocks * block_ld < ld || block_stride < (int64_t)nq * block_ld)
+  if (block_ld < 32 || block_ld % 32 || (int64_t)n_blocks * block_ld < ld || block_stride < (int64_t)nq * block_ld || block_stride % 8)
     return fail(RSX_ERR_BAD_ARG, "%d blocks of %lld columns do not cover %lld eligible entries", n_blocks, (long long)block_ld,
                 (long long)n_items);
   const int64_t qb = filter_batch(n_items, nq);
@@ -1327,8 +1327,8 @@ int rsx_sc_query_bounds_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t 
     q.vkey = qv.vkey + b0 * NS;
     q.norm = qv.norm + b0 * NS;
     q.nq = (int32_t)((nq - b0 < qb) ? (nq - b0) : qb);
-    RSX_TRY(launch_gather_bounds(d_lb_blocks, block_ld, block_stride, b0, q.nq, h->w->f_lb.as<float>(), ld, s));
-    RSX_TRY(launch_select(db, h->w->f_lb.as<float>(), ld, n_items, q.nq, n_elig, nullptr, first_round_target(), h->w->f_cand.as<RescoreEntry>(),
+    RSX_TRY(launch_gather_bounds(reinterpret_cast<const lb_t *>(d_lb_blocks), block_ld, block_stride, b0, q.nq, h->w->f_lb.as<lb_t>(), ld, s));
+    RSX_TRY(launch_select(db, h->w->f_lb.as<lb_t>(), ld, n_items, q.nq, n_elig, nullptr, first_round_target(), h->w->f_cand.as<RescoreEntry>(),
                           h->w->f_cnt.as<int32_t>(), h->w->f_thr.as<float>(), s));
     if (use_window())
       RSX_TRY(launch_window(db, q, h->w->f_wimg.p, h->w->f_cand.as<RescoreEntry>(), h->w->f_cnt.as<int32_t>(), k, filter_eps(),
@@ -1470,11 +1470,14 @@ int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out
   QueryView qv;
   RSX_TRY(prepare_queries(h, h->q_desc.as<float>(), nq, s, &qv));
   RSX_TRY(h->w->f_qimg.reserve(any_qimg_bytes(nq), s, false));
-  RSX_TRY(h->w->f_lb.reserve((size_t)nq * ld * sizeof(float), s, false));
-  RSX_TRY(run_filter(h, qv, n, h->w->f_lb.as<float>(), ld, nullptr, s));
-  RSX_HIP(hipMemcpy2DAsync(out_lb, (size_t)n * sizeof(float), h->w->f_lb.p, (size_t)ld * sizeof(float), (size_t)n * sizeof(float),
+  RSX_TRY(h->w->f_lb.reserve((size_t)nq * ld * sizeof(lb_t), s, false));
+  RSX_TRY(run_filter(h, qv, n, h->w->f_lb.as<lb_t>(), ld, nullptr, s));
+  // the matrix is fp16 on the device (sc_kernels.h lb_t); this diagnostic entry hands out the same values as float
+  std::vector<lb_t> host((size_t)nq * (size_t)n);
+  RSX_HIP(hipMemcpy2DAsync(host.data(), (size_t)n * sizeof(lb_t), h->w->f_lb.p, (size_t)ld * sizeof(lb_t), (size_t)n * sizeof(lb_t),
                            (size_t)nq, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
+  for (size_t i = 0; i < host.size(); i++) out_lb[i] = (float)host[i];
   return RSX_OK;
 } RSX_CATCH_ALL
 

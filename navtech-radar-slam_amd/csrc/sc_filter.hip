@@ -187,7 +187,7 @@ struct FilterArgs {
   int64_t n_items;
   int32_t nq;
   int64_t per_block;  // (tile-block, query) work items per workgroup (no plan)
-  float *lb;
+  lb_t *lb;
   int64_t ld_lb;
   // optional plan (queries whose eligibility grows with the query index, e.g. every keyframe against the
   // keyframes older than itself): tile-block tb only matters to queries >= tb_qmin[tb];
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
     auto fin = [&](const Epi &ep) {
       float best = epi_end(ep);
       if ((prev_mask | m2) & kNonFinite) best = -INFINITY;  // non-finite input: always re-score exactly
-      if (n_ok && hh == 0) a.lb[(int64_t)prev_q * a.ld_lb + n] = best;
+      if (n_ok && hh == 0) a.lb[(int64_t)prev_q * a.ld_lb + n] = lb_pack(best);
     };
     for (int p = 0; p < nphase; p++) {
       const int qp = q0 + p * F_QPP;
@@ -518,7 +518,7 @@ __global__ __launch_bounds__(256, 1) void sc_filter_kernel(FilterArgs a) {
 // x < (b+1)/2048 exactly (power-of-two scaling), so a "bound < edge" test selects whole bins.
 // ------------------------------------------------------------------------------------------
 constexpr int H_BINS = 2048;
-constexpr int SEL_U = 5;  // float4 loads in flight per thread of sc_select_kernel (a 10 016-entry row = 2 pieces)
+constexpr int SEL_U = 5;  // 16-byte loads in flight per thread of sc_select_kernel (a 10 016-entry row of fp16 bounds = 1 piece)
 
 __device__ __forceinline__ int lb_bin(float d) {
   if (!(d > 0.0f)) return 0;  // negative, -inf, NaN
@@ -554,7 +554,7 @@ __device__ __forceinline__ float bin_edge(int b) {  // upper edge of bin b as a 
   return b < 0 ? -INFINITY : (b >= H_BINS - 1 ? INFINITY : (float)(b + 1) / (float)H_BINS);
 }
 
-__global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict__ lb, int64_t ld, int64_t n_items_all,
+__global__ __launch_bounds__(256) void sc_select_kernel(const lb_t *__restrict__ lb, int64_t ld, int64_t n_items_all,
                                                         Elig el, int32_t first_target,
                                                         RescoreEntry *__restrict__ slist,
                                                         int32_t *__restrict__ sl_cnt, float *__restrict__ thr) {
@@ -564,34 +564,35 @@ __global__ __launch_bounds__(256) void sc_select_kernel(const float *__restrict_
   __shared__ int s_total;
   const int q = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float *row = lb + (int64_t)q * ld;
+  const lb_t *row = lb + (int64_t)q * ld;
   const int64_t n_items = n_elig_items(el, q, n_items_all);
   for (int i = threadIdx.x; i < H_BINS; i += 256) hist[i] = 0;
   if (threadIdx.x == 0) s_total = 0;
   __syncthreads();
-  // the row is read in pieces of 256 threads x SEL_U float4: all SEL_U loads of a thread are in flight together (one
-  // 4-byte load per thread and iteration left 8 KB per CU in flight: latency-bound at 1.5 TB/s, 0.22 ms per 8192 rows)
+  // the row is read in pieces of 256 threads x SEL_U 16-byte loads (8 fp16 bounds each): all SEL_U loads of a thread are in
+  // flight together (one 4-byte load per thread and iteration left 8 KB per CU in flight: latency-bound at 1.5 TB/s,
+  // 0.22 ms per 8192 rows)
   auto for_row = [&](auto &&f) {
-    const float4 *row4 = reinterpret_cast<const float4 *>(row);  // ld is a multiple of 32 floats: 128-byte aligned rows
-    const int64_t n4 = n_items >> 2;
-    for (int64_t c0 = 0; c0 < n4; c0 += 256 * SEL_U) {
-      float4 x[SEL_U];
+    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+    const uint4 *row8 = reinterpret_cast<const uint4 *>(row);  // ld is a multiple of 32 elements: 64-byte aligned rows
+    const int64_t n8 = n_items >> 3;
+    for (int64_t c0 = 0; c0 < n8; c0 += 256 * SEL_U) {
+      uint4 x[SEL_U];
 #pragma unroll
       for (int u = 0; u < SEL_U; u++) {
         const int64_t j = c0 + u * 256 + threadIdx.x;
-        x[u] = j < n4 ? row4[j] : float4{INFINITY, INFINITY, INFINITY, INFINITY};
+        x[u] = j < n8 ? row8[j] : uint4{0x7c007c00u, 0x7c007c00u, 0x7c007c00u, 0x7c007c00u};  // +inf
       }
 #pragma unroll
       for (int u = 0; u < SEL_U; u++) {
-        const int64_t i = (c0 + u * 256 + threadIdx.x) << 2;
-        f(x[u].x, i);
-        f(x[u].y, i + 1);
-        f(x[u].z, i + 2);
-        f(x[u].w, i + 3);
+        const int64_t i = (c0 + u * 256 + threadIdx.x) << 3;
+        const half8 h = __builtin_bit_cast(half8, x[u]);
+#pragma unroll
+        for (int e = 0; e < 8; e++) f((float)h[e], i + e);
       }
     }
-    const int64_t i = (n4 << 2) + threadIdx.x;  // the last n_items % 4 entries
-    if (i < n_items) f(row[i], i);
+    const int64_t i = (n8 << 3) + threadIdx.x;  // the last n_items % 8 entries
+    if (i < n_items) f((float)row[i], i);
   };
   for_row([&](float d, int64_t) {
     if (d != INFINITY) atomicAdd(&hist[lb_bin(d)], 1);  // +inf: no effective column at any shift, never a hit
@@ -760,7 +761,7 @@ int launch_filter_plan(const DbView &db, const FilterPlanInput &plan, int32_t nq
   return RSX_OK;
 }
 
-int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
+int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, lb_t *lb, int64_t ld_lb,
                   const FilterPlanInput *plan, void *plan_ws, hipStream_t s) {
   if (nq <= 0 || n_items <= 0) return RSX_OK;
   static int n_cu = 0;
@@ -801,7 +802,7 @@ int launch_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_item
   return RSX_OK;
 }
 
-int launch_select(const DbView &db, const float *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
+int launch_select(const DbView &db, const lb_t *lb, int64_t ld_lb, int64_t n_items, int32_t nq, int64_t n_eligible,
                   const int64_t *q_elig, int32_t first_target, RescoreEntry *slist, int32_t *sl_cnt, float *thr,
                   hipStream_t s) {
   if (nq <= 0) return RSX_OK;

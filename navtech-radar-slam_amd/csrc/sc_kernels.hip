@@ -1062,16 +1062,16 @@ __global__ __launch_bounds__(256, W) void sc_pair2_kernel(PairArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // bounds delivered as column blocks (one per filter shard, each [rows][block_ld]) -> one row-major matrix
-// lb[q][c] = blocks[c / block_ld][q0 + q][c % block_ld].  block_ld is a multiple of 32: a float4 stays inside one block
+// lb[q][c] = blocks[c / block_ld][q0 + q][c % block_ld].  block_ld is a multiple of 32: 8 elements stay inside one block
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sc_gather_bounds_kernel(const float *__restrict__ blocks, int64_t block_ld,
-                                                               int64_t block_stride, int64_t q0, float *__restrict__ lb,
+__global__ __launch_bounds__(256) void sc_gather_bounds_kernel(const lb_t *__restrict__ blocks, int64_t block_ld,
+                                                               int64_t block_stride, int64_t q0, lb_t *__restrict__ lb,
                                                                int64_t ld) {
-  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const int64_t c = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8;
   if (c >= ld) return;
   const int64_t q = blockIdx.y, b = c / block_ld, j = c - b * block_ld;
-  const float4 v = *reinterpret_cast<const float4 *>(blocks + b * block_stride + (q0 + q) * block_ld + j);
-  *reinterpret_cast<float4 *>(lb + q * ld + c) = v;
+  const uint4 v = *reinterpret_cast<const uint4 *>(blocks + b * block_stride + (q0 + q) * block_ld + j);
+  *reinterpret_cast<uint4 *>(lb + q * ld + c) = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1233,7 +1233,7 @@ struct RescoreLds {
 struct RescoreArgs {
   DbView db;
   QueryView q;
-  const float *lb;  // filter bounds [nq][ld_lb] (only read past the short list)
+  const lb_t *lb;  // filter bounds [nq][ld_lb] (only read past the short list)
   int64_t ld_lb, n_items, n_eligible;
   const int64_t *q_elig;
   const RescoreEntry *slist;  // [nq][RS_CAND_CAP]
@@ -1541,7 +1541,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
 
   // ---- entries beyond the short list (bound >= t_cap), only while tau admits them ----
   if (!done && a.round_end > RESCORE_NUM_THR && t_cap < INFINITY && !((double)t_cap - a.eps > tau)) {
-    const float *row = a.lb + (int64_t)qi * a.ld_lb;
+    const lb_t *row = a.lb + (int64_t)qi * a.ld_lb;
     const bool take_all = (t_cap == -INFINITY);  // empty short list: NaN bounds are here too
     int64_t pos = 0;
     while (pos < n_rows) {
@@ -1551,7 +1551,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
         const int64_t i = pos + threadIdx.x;
         bool pass = false;
         if (i < n_rows) {
-          const float d = row[i];
+          const float d = (float)row[i];
           const bool beyond = take_all ? true : (d >= t_cap);
           pass = beyond && (d != INFINITY) && !((double)d - a.eps > tau);
         }
@@ -1660,13 +1660,13 @@ int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t 
   return RSX_OK;
 }
 
-int launch_gather_bounds(const float *d_blocks, int64_t block_ld, int64_t block_stride, int64_t q0, int32_t nq, float *d_lb,
+int launch_gather_bounds(const lb_t *d_blocks, int64_t block_ld, int64_t block_stride, int64_t q0, int32_t nq, lb_t *d_lb,
                          int64_t ld, hipStream_t s) {
   if (nq <= 0 || ld <= 0) return RSX_OK;
-  if (block_ld < 32 || block_ld % 32 || ld % 4) return fail(RSX_ERR_BAD_ARG, "bound blocks must be a multiple of 32 columns wide");
+  if (block_ld < 32 || block_ld % 32 || ld % 8 || block_stride % 8) return fail(RSX_ERR_BAD_ARG, "bound blocks must be a multiple of 32 columns wide");
   for (int32_t r0 = 0; r0 < nq; r0 += 65535) {  // gridDim.y
     const int32_t rows = nq - r0 < 65535 ? nq - r0 : 65535;
-    hipLaunchKernelGGL(sc_gather_bounds_kernel, dim3((unsigned)((ld / 4 + 255) / 256), (unsigned)rows), dim3(256), 0, s, d_blocks,
+    hipLaunchKernelGGL(sc_gather_bounds_kernel, dim3((unsigned)((ld / 8 + 255) / 256), (unsigned)rows), dim3(256), 0, s, d_blocks,
                        block_ld, block_stride, q0 + r0, d_lb + (int64_t)r0 * ld, ld);
     RSX_HIP(hipGetLastError());
   }
@@ -1830,11 +1830,11 @@ __global__ __launch_bounds__(64, 2) void sc_walk_kernel(RescoreArgs a) {
 
   // ---- entries beyond the short list (bound >= t_cap), only while tau admits them ----
   if (!done && t_cap < INFINITY && !((double)t_cap - a.eps > tau)) {
-    const float *row = a.lb + (int64_t)qi * a.ld_lb;
+    const lb_t *row = a.lb + (int64_t)qi * a.ld_lb;
     const bool take_all = (t_cap == -INFINITY);  // empty short list: NaN bounds are here too
     for (int64_t pos = 0; pos < n_rows; pos += 64) {
       const int64_t i = pos + lane;
-      const float d = (i < n_rows) ? row[i] : INFINITY;
+      const float d = (i < n_rows) ? (float)row[i] : INFINITY;
       const bool beyond = take_all ? true : (d >= t_cap);
       unsigned long long bal = __ballot((i < n_rows) && beyond && (d != INFINITY));
       while (bal) {
@@ -1858,7 +1858,7 @@ __global__ __launch_bounds__(64, 2) void sc_walk_kernel(RescoreArgs a) {
   }
 }
 
-int launch_walk(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
+int launch_walk(const DbView &db, const QueryView &q, const lb_t *lb, int64_t ld_lb, int64_t n_items,
                 int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
                 const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s) {
   if (q.nq <= 0) return RSX_OK;
@@ -2302,11 +2302,11 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
 
   // ---- entries beyond the short list (bound >= t_cap), only while tau admits them ----
   if (!done && a.round_end > RESCORE_NUM_THR && t_cap < INFINITY && !((double)t_cap - a.eps > tau)) {
-    const float *row = a.lb + (int64_t)qi * a.ld_lb;
+    const lb_t *row = a.lb + (int64_t)qi * a.ld_lb;
     const bool take_all = (t_cap == -INFINITY);  // empty short list: NaN bounds are here too
     for (int64_t pos = 0; pos < n_rows; pos += 64) {
       const int64_t i = pos + lane;
-      const float d = (i < n_rows) ? row[i] : INFINITY;
+      const float d = (i < n_rows) ? (float)row[i] : INFINITY;
       const bool beyond = take_all ? true : (d >= t_cap);
       unsigned long long bal = __ballot((i < n_rows) && beyond && (d != INFINITY));
       while (bal) {
@@ -2368,7 +2368,7 @@ static int launch_rescore_t(const RescoreArgs &a, hipStream_t s) {
   return RSX_OK;
 }
 
-int launch_rescore(const DbView &db, const QueryView &q, const float *lb, int64_t ld_lb, int64_t n_items,
+int launch_rescore(const DbView &db, const QueryView &q, const lb_t *lb, int64_t ld_lb, int64_t n_items,
                    int64_t n_eligible, const int64_t *q_elig, const RescoreEntry *slist, const int32_t *sl_cnt,
                    const float *thr, double eps, int32_t round_begin, int32_t round_end, const rsx_sc_hit *tau_src,
                    const rsx_sc_hit *seed, rsx_sc_hit *d_out, int32_t k, hipStream_t s, unsigned long long *d_stats,

@@ -317,13 +317,15 @@ struct SpecArgs {
   int64_t n_items;
   int32_t nq;
   int32_t unit_len;   // no plan: workgroup u = (query range u / ntb, tile-block u % ntb), unit_len query tiles per range
-  float *lb;
+  lb_t *lb;
   int64_t ld_lb;
   float eps_direct;
   int32_t dbg;  // timing experiments of RSX_SPEC_INSTRUMENT builds (RSX_SPEC_DBG): 4 = no DMA, 8 = no stores
   unsigned long long *prof;  // RSX_SPEC_PROF: s_memtime sums per region of (workgroup 0, wave 0)
   const int32_t *tb_qmin;  // optional plan, in query-tile units (see sc_filter.hip)
   const int64_t *tb_cum;
+  // sc_spec2_filter_kernel without a plan (xcd_len > 0): query tiles per XCD and per sub-range (see the kernel's work split)
+  int32_t xcd_nqt, xcd_len;
 };
 
 // the DMA of a later tile, issued piecewise from inside the tail of the current one: an LDS-DMA instruction
@@ -340,7 +342,7 @@ struct TileDma {
 // tile loop is followed by s_waitcnt vmcnt(0): a full drain of the DMA pieces and bound stores in flight
 struct TileOut {
   char *rowbase;      // uniform
-  unsigned lane_off;  // (this lane's entry + (lane >= 32 ? ld : 0)) * 4: lanes 32..63 store the odd query of a pair
+  unsigned lane_off;  // (this lane's entry + (lane >= 32 ? ld : 0)) * sizeof(lb_t): lanes 32..63 store the odd query of a pair
   unsigned ld_bytes;  // uniform
   int nq_here;        // valid queries in the tile
   bool n_ok;          // this lane's entry exists
@@ -752,7 +754,7 @@ __device__ __forceinline__ void spec_tile(unsigned tile_lds, const char *tbase, 
       const int qq = (q - 1) + ln.hh;
       const float vv = ln.hh ? out[q] : out[q - 1];
       if (to.n_ok && qq < to.nq_here && !(kInstr && (dbg & 8) && vv != 12345.0f))
-        *reinterpret_cast<float *>(to.rowbase + (size_t)((unsigned)(q - 1) * to.ld_bytes) + to.lane_off) = vv;
+        *reinterpret_cast<lb_t *>(to.rowbase + (size_t)((unsigned)(q - 1) * to.ld_bytes) + to.lane_off) = lb_pack(vv);
     }
   });
 }
@@ -923,8 +925,8 @@ __global__ __launch_bounds__(256, 1) void sc_spec_filter_kernel(SpecArgs a) {
         const char *tbase = smem + SP_TILES_OFF + (p % SP_NBUF) * SP_PHASE_BYTES;
         float out[SP_QPT];
         spec_tile(lds_base + (unsigned)(tbase - smem), tbase, B, ln, a.eps_direct, out, a.dbg, prof ? &t2 : nullptr, dma, wave, lane,
-                  TileOut{reinterpret_cast<char *>(a.lb + (int64_t)qp * a.ld_lb), (unsigned)(n * 4) + (unsigned)hh * (unsigned)(a.ld_lb * 4),
-                          (unsigned)(a.ld_lb * 4), nq_here, n_ok});
+                  TileOut{reinterpret_cast<char *>(a.lb + (int64_t)qp * a.ld_lb), (unsigned)(n * 2) + (unsigned)hh * (unsigned)(a.ld_lb * 2),
+                          (unsigned)(a.ld_lb * 2), nq_here, n_ok});
         if (prof) {
           asm volatile("" : "+v"(out[0]), "+v"(out[1]), "+v"(out[2]), "+v"(out[3]));
           t3 = prof_now();
@@ -1426,7 +1428,7 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
       const int64_t n = tile * 32 + col;
       const int qq = QB + hh;
       const float vv = hh ? outv[1] : outv[0];
-      if (n < a.n_items && qq < nq_here) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = vv;
+      if (n < a.n_items && qq < nq_here) a.lb[(int64_t)(qp + qq) * a.ld_lb + n] = lb_pack(vv);
     }
     lap(HALF == 1 ? 1 : 3);  // stage 2 + bounds + store
   };
@@ -1501,9 +1503,31 @@ __global__ __launch_bounds__(512, 2) void sc_spec2_filter_kernel(SpecArgs a) {
   const int64_t ntb = (ntiles + 3) >> 2;
   const int nqt = (a.nq + SP_QPT - 1) / SP_QPT;
   const int64_t total = a.tb_cum ? a.tb_cum[ntb] : ntb * (int64_t)nqt;
-  const int64_t per = (total + gridDim.x - 1) / gridDim.x;
-  int64_t L0 = (int64_t)blockIdx.x * per;
-  const int64_t L1 = (L0 + per < total) ? (L0 + per) : total;
+  // Work split.  With a plan (or a batch too small to give every XCD its own queries): equal contiguous segments of the
+  // (tile-block, query tile) list, one persistent workgroup per CU.  Otherwise by XCD: workgroup b runs on XCD b % 8 (the
+  // dispatcher deals workgroups round-robin over the XCDs) as the j = b / 8-th of that XCD's sequence; the XCD owns query
+  // tiles [x * xcd_nqt, (x + 1) * xcd_nqt) in sub-ranges of xcd_len tiles, and workgroup j = (sub-range j / ntb, tile-block
+  // j % ntb).  The 32 workgroups resident on an XCD (one per CU) then start on the SAME xcd_len query tiles together and
+  // stay within a few tiles of each other: a query image comes out of HBM / Infinity Cache once per launch and out of the
+  // XCD's L2 for the other 31.  With contiguous segments the 32 streamed 32 different ranges: 1.58 GB of L2 -> fabric
+  // reads per launch for 78 MB of images (profiles/r04_sc_spec_v11).  The price: a 311 KB tile-block load per workgroup
+  // (2 x 78 per XCD instead of 78 + 32) and whole rounds of 32 (4.875 -> 5 on the bench).  A persistent variant (32
+  // workgroups per XCD walking a (chunk, tile-block, tile) list cut evenly) was measured too: its workgroups sit at 32
+  // different tiles of the chunk, the 3.3 MB chunk does not survive in the 4 MB L2 next to the bound stores, and the
+  // traffic went UP to 2.05 GB (1.93-1.96 ms against 1.84-1.86 the same run)
+  int64_t L0, L1;
+  if (a.xcd_len > 0) {
+    const int x = blockIdx.x & 7;
+    const int64_t j = blockIdx.x >> 3, sub = j / ntb, utb = j - sub * ntb;
+    const int64_t qx1 = ((int64_t)(x + 1) * a.xcd_nqt < nqt) ? (int64_t)(x + 1) * a.xcd_nqt : nqt;
+    const int64_t u0 = (int64_t)x * a.xcd_nqt + sub * a.xcd_len, u1 = (u0 + a.xcd_len < qx1) ? (u0 + a.xcd_len) : qx1;
+    L0 = utb * nqt + u0;
+    L1 = u0 < u1 ? utb * nqt + u1 : L0;
+  } else {
+    const int64_t per = (total + gridDim.x - 1) / gridDim.x;
+    L0 = (int64_t)blockIdx.x * per;
+    L1 = (L0 + per < total) ? (L0 + per) : total;
+  }
   const unsigned lds_base = (unsigned)(uintptr_t)((AS3 char *)smem);
   S2Lane ln;
   {
@@ -1593,7 +1617,7 @@ const char *spec_filter_kernel_name() { return "sc_spec_filter_kernel"; }
 
 const char *spec2_filter_kernel_name() { return "sc_spec2_filter_kernel"; }
 
-int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, float *lb, int64_t ld_lb,
+int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n_items, lb_t *lb, int64_t ld_lb,
                        const int32_t *tb_qmin, const int64_t *tb_cum, hipStream_t s, bool two_waves) {
   if (nq <= 0 || n_items <= 0) return RSX_OK;
   static int n_cu = 0;
@@ -1665,6 +1689,44 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
     static const bool want_prof2 = kInstr && rsx::exp_env("RSX_SPEC_PROF") != nullptr;
     if (want_prof2 && !d_prof2) RSX_HIP(hipMalloc(&d_prof2, 16 * sizeof(unsigned long long)));
     a.prof = want_prof2 ? d_prof2 : nullptr;
+    a.xcd_nqt = a.xcd_len = 0;
+    {
+      // XCD-aware split (no plan, every XCD gets >= 16 query tiles of its own).  Sub-ranges per XCD S: whole rounds of the
+      // XCD's workgroup slots (one per CU) filled best, cost = rounds x (tiles per sub-range + 3): a workgroup's start
+      // (311 KB tile-block load, LDS constants, pipeline fill) costs about 3 tiles -- measured on the bench launch: S = 16
+      // (39 full rounds of 16 tiles) 2.05 ms, S = 2 (4.875 -> 5 rounds of 128) 1.83 ms
+      static const bool xcd_on = [] {
+        const char *e = rsx::exp_env("RSX_SPEC_XCD");
+        return !(e && e[0] == '0');
+      }();
+      const int64_t nqt_x = (nqt + 7) / 8;
+      if (xcd_on && !tb_cum && nqt_x >= 16 && n_cu % 8 == 0) {
+        int64_t best_s = 1;
+        double best_cost = 1e300;
+        const int64_t slots = n_cu / 8;
+        for (int64_t S = 1; S <= 64 && (S == 1 || (nqt_x + S - 1) / S >= 16); S++) {
+          const int64_t len = (nqt_x + S - 1) / S, used = (nqt_x + len - 1) / len;
+          const int64_t cost = ((used * ntb + slots - 1) / slots) * (len + 3);
+          if ((double)cost < best_cost * 0.995) {
+            best_cost = (double)cost;
+            best_s = used;
+          }
+        }
+        if (const char *e = rsx::exp_env("RSX_SPEC_XCD_S")) {
+          const int64_t v = atoll(e);
+          if (v >= 1 && v <= nqt_x) best_s = v;
+        }
+        // against the contiguous split (perfectly balanced, one start per workgroup): only where whole rounds cost <= 6 %
+        // -- large batches; a 1024-query batch against 10 000 entries would lose 17 %
+        const double contiguous = (double)(ntb * nqt) / (double)n_cu + 3.0;
+        if (best_cost <= 1.06 * contiguous || rsx::exp_env("RSX_SPEC_XCD_S")) {
+          a.xcd_nqt = (int32_t)nqt_x;
+          a.xcd_len = (int32_t)((nqt_x + best_s - 1) / best_s);
+          const int64_t used = (nqt_x + a.xcd_len - 1) / a.xcd_len;
+          grid = (unsigned)(8 * used * ntb);
+        }
+      }
+    }
     hipLaunchKernelGGL(sc_spec2_filter_kernel, dim3(grid), dim3(512), S2_LDS_BYTES, s, a);
     RSX_HIP(hipGetLastError());
     if (want_prof2) {  // debugging aid only: synchronises

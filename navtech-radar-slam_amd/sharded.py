@@ -270,7 +270,7 @@ class FilterShardedScanContext:
       per query  short list, window previews, exact re-scoring: rank t runs them for ITS nq / world queries against the
                  whole DB, with the bounds the other ranks computed.
     Between the two sits ONE all-to-all (RCCL over xGMI): rank t receives rows [q_t, q_t + nq_t) of every rank's bound
-    matrix, nq * N * 4 / world bytes per rank (41 MB for 8192 queries x 10 000 keyframes on 8 ranks); a last all-gather puts
+    matrix (fp16), nq * N * 2 / world bytes per rank (20 MB for 8192 queries x 10 000 keyframes on 8 ranks); a last all-gather puts
     the slices together (nq * k * 16 B).  Unlike the Q x S layouts there is no second stage and no replicated per-query work
     except the query images of the filter (every rank needs all of them), so both cost terms shrink with the world size.
     The records are those of one GPU: a pair's bound does not depend on who computed it.
@@ -354,15 +354,15 @@ class FilterShardedScanContext:
         first, n = rng[self.rank]
         mine = self._buf("mine", (chunk, k, 2), torch.float64)
         if self.world == 1:
-            send = self._buf("send", (chunk, ld_r), torch.float32)
+            send = self._buf("send", (chunk, ld_r), torch.float16)
             self.backend.filter_range_device(q_ptr, nq, first, n, send.data_ptr(), ld_r, stream=stream)
             self.backend.query_bounds_device(q_ptr, nq, k, mine.data_ptr(), send.data_ptr(), 1, ld_r, chunk * ld_r,
                                              n_eligible=n_eligible, stream=stream)
             return mine[:nq]
-        send = self._buf("send", (self.world * chunk, ld_r), torch.float32)
-        recv = self._buf("recv", (self.world, chunk, ld_r), torch.float32)
+        send = self._buf("send", (self.world * chunk, ld_r), torch.float16)
+        recv = self._buf("recv", (self.world, chunk, ld_r), torch.float16)
         self.backend.filter_range_device(q_ptr, nq, first, n, send.data_ptr(), ld_r, stream=stream)
-        _all_to_all(self._dist, recv.view(-1), send.view(-1), self.group, self._staged)
+        _all_to_all(self._dist, recv.view(-1).view(torch.int16), send.view(-1).view(torch.int16), self.group, self._staged)  # fp16 bit patterns
         if hi > lo:
             self.backend.query_bounds_device(q_ptr + lo * 4800, hi - lo, k, mine.data_ptr(), recv.data_ptr(), self.world, ld_r,
                                              chunk * ld_r, n_eligible=n_eligible, stream=stream)

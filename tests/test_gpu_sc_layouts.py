@@ -51,7 +51,7 @@ def test_filter_shards_emulated_on_one_gpu(world, n_elig):
     torch.cuda.set_stream(side)         # is not ordered with torch's copies below
     s = side.cuda_stream
     # recv[t][r] = what rank t holds after the all-to-all: rows of its slice, one column block per sender r
-    sends = torch.full((world, world * chunk, ld_r), float("nan"), dtype=torch.float32, device="cuda")
+    sends = torch.full((world, world * chunk, ld_r), float("nan"), dtype=torch.float16, device="cuda")
     for r, (first, cnt) in enumerate(rng):
         g.filter_range_device(dq.data_ptr(), nq, first, cnt, sends[r].data_ptr(), ld_r, stream=s)
     got = torch.zeros((world * chunk, k, 2), dtype=torch.float64, device="cuda")
@@ -67,7 +67,7 @@ def test_filter_shards_emulated_on_one_gpu(world, n_elig):
     assert np.array_equal(got[:nq].cpu().numpy().view(sc.HIT_DTYPE).reshape(nq, k), want)
     # and the bounds themselves are the single-GPU filter's, whoever computed them
     lb = g.filter_bounds(queries)
-    mine = torch.cat([sends[r, :nq, :c] for r, (_, c) in enumerate(rng)], dim=1).cpu().numpy()
+    mine = torch.cat([sends[r, :nq, :c] for r, (_, c) in enumerate(rng)], dim=1).float().cpu().numpy()
     assert np.array_equal(mine, lb[:, :n_e], equal_nan=True)
     g.close()
 
