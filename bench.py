@@ -955,6 +955,8 @@ def roofline_of(wl, launches, kern_ms, n_elig):
             "traffic": prof["hbm_bytes_per_launch"] if prof else None, "traffic_unit": "bytes per launch",
             "traffic_source": (prof["source"] + " (committed rocprofv3 PMC passes of this workload; not measured in this run)") if prof else None,
             "committed_profile_avg_launch_ms": prof["kernel_trace_avg_launch_ms"] if prof else None,
+            # the same algorithmic flops over the committed rocprofv3 --kernel-trace average (another box, under the profiler)
+            "frac_at_committed_profile": (alg_flop / (prof["kernel_trace_avg_launch_ms"] * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS) if prof else None,
             "algorithmic_flop_per_launch": alg_flop,
             "algorithmic_flop_per_pair": spec_flop if spectral else ALG_FLOP_PER_PAIR,
             "queries_with_60_nonempty_columns": full,
