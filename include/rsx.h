@@ -121,7 +121,10 @@ int rsx_sc_local_size(rsx_sc *h, int64_t *n_local);
  * (32 for pcl::PointXYZI), float x,y,z at byte offsets 0,4,8.  The descriptor, ring key, sector
  * key and column norms are built on the GPU.  In a sharded handle every rank must call this for
  * every keyframe (same order); ranks that do not own the slot only advance the global count.
- * out_index (optional) = global index of the new keyframe. */
+ * out_index (optional) = global index of the new keyframe.
+ * The call copies the cloud (pts is free again on return) and enqueues ONE kernel; it does not wait for the GPU.  Every
+ * later call on the handle sees the entry (calls that bring their own stream are ordered behind it); a device fault of
+ * the insert is reported by the next call that synchronises. */
 int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes, int32_t *out_index);
 /* saveScancontextAndKeys (SC.cpp:236-246), colmajor double; RSX_ERR_NOT_FP32_EXACT if lossy */
 int rsx_sc_add_descriptor(rsx_sc *h, const double *desc_colmajor, int32_t *out_index);

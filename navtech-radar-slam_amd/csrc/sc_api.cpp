@@ -79,6 +79,18 @@ struct rsx_sc {
   // upload pipeline of the host-buffer entry (rsx_sc_query): pieces of the query batch go up on their own stream while
   // the pieces before them are scored
   static constexpr int kMaxPieces = 8;
+  // staging ring of rsx_sc_add_points: the cloud is copied into pinned memory, goes up asynchronously and one kernel builds
+  // the entry (launch_insert); the host does not wait.  Entries appear in the order of h->stream; a call that brings its own
+  // stream is ordered behind the latest insert (use_stream)
+  static constexpr int kInsSlots = 8;
+  struct InsSlot {
+    void *host = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    bool used = false;
+  } ins[kInsSlots];
+  int ins_next = 0;
+  hipEvent_t last_insert = nullptr;
   hipStream_t up_stream = nullptr, stream_b = nullptr;
   hipEvent_t up_ev[kMaxPieces] = {}, lane_ev = nullptr;
 };
@@ -90,6 +102,20 @@ constexpr size_t kStatBytes = (size_t)RESCORE_STAT_COPIES * RESCORE_STAT_WORDS *
 int set_device(rsx_sc *h) {
   RSX_HIP(hipSetDevice(h->p.device));
   return RSX_OK;
+}
+
+// the stream a device entry works on: the caller's, ordered behind the inserts still in flight on the handle's own
+int use_stream(rsx_sc *h, void *stream, hipStream_t *s) {
+  *s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  if (*s != h->stream && h->last_insert) RSX_HIP(hipStreamWaitEvent(*s, h->last_insert, 0));
+  return RSX_OK;
+}
+
+// one new entry from a cloud in device memory, all of it in one launch
+int insert_cloud(rsx_sc *h, const void *d_pts, int64_t n_pts, int64_t stride, int64_t slot, hipStream_t s) {
+  return launch_insert(d_pts, nullptr, n_pts, 1, stride, h->p.lidar_height, h->p.max_radius, slot, h->desc.as<float>(),
+                       h->vkey.as<double>(), h->norm.as<double>(), h->rkey.as<float>(), h->hn.p, h->hnr.p,
+                       h->cmask.as<uint64_t>(), h->sp.p, h->sp_aux.as<float>(), h->vk16.p, h->vk_n.as<float>(), s);
 }
 
 int ensure_capacity(rsx_sc *h, int64_t want_local) {
@@ -525,19 +551,17 @@ int score_candidates_and_finish(rsx_sc *h, const QueryView &qv, const float *d_q
       RSX_TRY(h->knn_ws.reserve(sizeof(float), s, false));
       RSX_TRY(launch_knn(h->rkey.as<float>(), 0, d_qkey, k, h->knn_ws.as<float>(), d_idx, d_kd, d_found, s));
     }
-    RSX_TRY(h->pair_out.reserve((size_t)k * (sizeof(double) + sizeof(int32_t)), s, false));
-    double *d_dist = h->pair_out.as<double>();
-    int32_t *d_shift = reinterpret_cast<int32_t *>(d_dist + k);
+    // the k distances and shifts next to the indices in `small`: ONE read-back for all three
+    double *d_dist = reinterpret_cast<double *>(h->small.as<char>() + 1024);
+    int32_t *d_shift = reinterpret_cast<int32_t *>(h->small.as<char>() + 2048);
     RSX_TRY(launch_pairs(db_view(h), qv, d_idx, 0, k, -1, nullptr, d_dist, d_shift, nullptr, nullptr, 0, s));
-    RSX_TRY(ensure_pinned(h, 1024));
+    RSX_TRY(ensure_pinned(h, 4096));
     char *hp = static_cast<char *>(h->pinned);
-    RSX_HIP(hipMemcpyAsync(hp, d_idx, k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-    RSX_HIP(hipMemcpyAsync(hp + 256, d_dist, k * sizeof(double), hipMemcpyDeviceToHost, s));
-    RSX_HIP(hipMemcpyAsync(hp + 512, d_shift, k * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipMemcpyAsync(hp, h->small.p, 2048 + 256, hipMemcpyDeviceToHost, s));
     RSX_HIP(hipStreamSynchronize(s));
     const int32_t *ci = reinterpret_cast<const int32_t *>(hp);
-    const double *cd = reinterpret_cast<const double *>(hp + 256);
-    const int32_t *cs = reinterpret_cast<const int32_t *>(hp + 512);
+    const double *cd = reinterpret_cast<const double *>(hp + 1024);
+    const int32_t *cs = reinterpret_cast<const int32_t *>(hp + 2048);
     for (int c = 0; c < k; c++) {  // SC.cpp:380-395: kNN order, strict <
       if (cd[c] < best_d) {
         best_d = cd[c];
@@ -546,10 +570,9 @@ int score_candidates_and_finish(rsx_sc *h, const QueryView &qv, const float *d_q
       }
     }
   } else {
-    RSX_TRY(h->topk.reserve(sizeof(rsx_sc_hit), s, false));
-    RSX_TRY(run_topk(h, qv, n_search, n_search, nullptr, 1, h->topk.as<rsx_sc_hit>(), s));
-    RSX_TRY(ensure_pinned(h, 1024));
-    RSX_HIP(hipMemcpyAsync(h->pinned, h->topk.p, sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, s));
+    // the one record goes straight into pinned host memory (device-visible): no copy to enqueue
+    RSX_TRY(ensure_pinned(h, 4096));
+    RSX_TRY(run_topk(h, qv, n_search, n_search, nullptr, 1, static_cast<rsx_sc_hit *>(h->pinned), s));
     RSX_HIP(hipStreamSynchronize(s));
     const rsx_sc_hit *r = static_cast<const rsx_sc_hit *>(h->pinned);
     if (r->dist < best_d) {
@@ -666,6 +689,10 @@ int rsx_sc_destroy(rsx_sc *h) try {
   }
   for (auto e : h->up_ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto &sl : h->ins) {
+    if (sl.host) (void)hipHostFree(sl.host);
+    if (sl.done) (void)hipEventDestroy(sl.done);
+  }
   if (h->lane_ev) (void)hipEventDestroy(h->lane_ev);
   if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
   if (h->stream_b) (void)hipStreamDestroy(h->stream_b);
@@ -722,12 +749,25 @@ int rsx_sc_add_points(rsx_sc *h, const void *pts, size_t n, size_t stride_bytes,
     const int64_t slot = h->n_local;
     RSX_TRY(ensure_capacity(h, slot + 1));
     const size_t bytes = n * stride_bytes;
-    RSX_TRY(h->pts_ws.reserve(bytes ? bytes : 16, h->stream, false));
-    if (bytes) RSX_HIP(hipMemcpyAsync(h->pts_ws.p, pts, bytes, hipMemcpyHostToDevice, h->stream));
-    RSX_TRY(launch_build(h->pts_ws.p, (int64_t)n, (int64_t)stride_bytes, h->p.lidar_height, h->p.max_radius,
-                         h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS,
-                         h->norm.as<double>() + slot * NS, h->rkey.as<float>() + slot * NR, h->stream));
-    RSX_TRY(build_db_images(h, slot, 1, h->stream));  // synchronises: caller may reuse pts; entry visible to detect()
+    rsx_sc::InsSlot &sl = h->ins[h->ins_next];
+    h->ins_next = (h->ins_next + 1) % rsx_sc::kInsSlots;
+    if (sl.used) RSX_HIP(hipEventSynchronize(sl.done));  // the insert that used this slot 8 calls ago
+    if (bytes > sl.cap) {
+      if (sl.host) (void)hipHostFree(sl.host);
+      sl.host = nullptr;
+      sl.cap = 0;
+      size_t cap = 32768;
+      while (cap < bytes) cap *= 2;
+      RSX_HIP(hipHostMalloc(&sl.host, cap, hipHostMallocDefault));
+      sl.cap = cap;
+    }
+    if (!sl.done) RSX_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+    if (bytes) std::memcpy(sl.host, pts, bytes);  // the caller's buffer is free again when this call returns
+    // the kernel reads the points out of the pinned slot itself (each once, 12 of stride_bytes bytes): no copy to enqueue
+    RSX_TRY(insert_cloud(h, sl.host, (int64_t)n, (int64_t)stride_bytes, slot, h->stream));
+    RSX_HIP(hipEventRecord(sl.done, h->stream));
+    sl.used = true;
+    h->last_insert = sl.done;
     h->n_local = slot + 1;
   }
   h->n_global = g + 1;
@@ -753,10 +793,8 @@ int rsx_sc_add_points_downsampled(rsx_sc *h, rsx_voxelgrid *vg, const void *pts,
     const int64_t slot = h->n_local;
     RSX_TRY(ensure_capacity(h, slot + 1));
     // upload_and_filter synchronised vg's stream: d_ds is complete and stays valid under vg's lock
-    RSX_TRY(launch_build(d_ds ? static_cast<const void *>(d_ds) : h->desc.p, nds, 16, h->p.lidar_height, h->p.max_radius,
-                         h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
-                         h->rkey.as<float>() + slot * NR, h->stream));
-    RSX_TRY(build_db_images(h, slot, 1, h->stream));
+    RSX_TRY(insert_cloud(h, d_ds ? static_cast<const void *>(d_ds) : h->desc.p, nds, 16, slot, h->stream));
+    RSX_HIP(hipStreamSynchronize(h->stream));  // d_ds belongs to vg: its next call must not overwrite it under the kernel
     h->n_local = slot + 1;
   }
   h->n_global = g + 1;
@@ -788,10 +826,7 @@ int rsx_sc_add_keyframe(rsx_sc *h, rsx_voxelgrid *vg, rsx_kfstore *kf, const voi
   if (owns(h, g)) {
     const int64_t slot = h->n_local;
     RSX_TRY(ensure_capacity(h, slot + 1));
-    RSX_TRY(launch_build(d_ds ? static_cast<const void *>(d_ds) : h->desc.p, nds, 16, h->p.lidar_height, h->p.max_radius,
-                         h->desc.as<float>() + slot * DS, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
-                         h->rkey.as<float>() + slot * NR, h->stream));  // makeAndSaveScancontextAndKeys (PGO.cpp:492)
-    RSX_TRY(build_db_images(h, slot, 1, h->stream));
+    RSX_TRY(insert_cloud(h, d_ds ? static_cast<const void *>(d_ds) : h->desc.p, nds, 16, slot, h->stream));  // makeAndSaveScancontextAndKeys (PGO.cpp:492)
     RSX_HIP(hipStreamSynchronize(h->stream));  // d_ds belongs to vg: it must not be overwritten by vg's next call before the build has read it
     h->n_local = slot + 1;
   }
@@ -865,7 +900,8 @@ int rsx_sc_add_descriptors_f32_device(rsx_sc *h, const float *d_descs, int64_t n
   if (n == 0) return RSX_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s;
+  RSX_TRY(use_stream(h, stream, &s));
   return add_f32_locked(h, d_descs, n, true, s);
 } RSX_CATCH_ALL
 
@@ -1172,7 +1208,9 @@ int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int6
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
-  return query_device_locked(h, d_q, nq, k, n_eligible, d_out, stream ? static_cast<hipStream_t>(stream) : h->stream);
+  hipStream_t s;
+  RSX_TRY(use_stream(h, stream, &s));
+  return query_device_locked(h, d_q, nq, k, n_eligible, d_out, s);
 } RSX_CATCH_ALL
 
 // How the host-buffer entry cuts a batch into pieces: the upload of the first piece is the only one nothing hides, every
@@ -1294,7 +1332,8 @@ int rsx_sc_filter_range_device(rsx_sc *h, const float *d_q, int32_t nq, int64_t 
   if (first_slot + n_slots > h->n_local) return fail(RSX_ERR_RANGE, "slots [%lld, %lld) of %lld", (long long)first_slot,
                                                      (long long)(first_slot + n_slots), (long long)h->n_local);
   if (n_slots == 0) return RSX_OK;
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s;
+  RSX_TRY(use_stream(h, stream, &s));
   QueryView qv;
   RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
   RSX_TRY(h->w->f_qimg.reserve(any_qimg_bytes(nq), s, false));
@@ -1308,7 +1347,8 @@ int rsx_sc_query_bounds_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t 
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "bounds from filter shards need the whole database in this handle (shard_world 1)");
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s;
+  RSX_TRY(use_stream(h, stream, &s));
   QueryView qv;
   RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
   const int64_t n_elig = n_eligible < 0 ? h->n_global : n_eligible;
@@ -1349,7 +1389,8 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s;
+  RSX_TRY(use_stream(h, stream, &s));
   h->st.valid = false;
   QueryView qv;
   RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
@@ -1396,7 +1437,8 @@ int rsx_sc_query_stage2_device(rsx_sc *h, int32_t nq, int32_t k, const rsx_sc_hi
   if (!h->st.valid || h->st.nq != nq || h->st.k != k)
     return fail(RSX_ERR_BAD_ARG, "stage 2 without a matching stage 1 (nq=%d k=%d)", nq, k);
   RSX_TRY(set_device(h));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s;
+  RSX_TRY(use_stream(h, stream, &s));
   h->st.valid = false;
   if (h->st.filtered)
     return rescore(h, h->st.qv, h->st.n_items, h->st.n_eligible, h->st.q_elig, 1, RESCORE_ALL_ROUNDS, d_global,
@@ -1413,7 +1455,8 @@ int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, 
   if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "query_self needs an unsharded handle (queries must be local)");
   if (q_first < 0 || q_first + nq > h->n_global) return fail(RSX_ERR_RANGE, "query range out of bounds");
   RSX_TRY(set_device(h));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s;
+  RSX_TRY(use_stream(h, stream, &s));
   QueryView qv;
   qv.desc = h->desc.as<float>() + q_first * DS;
   qv.vkey = h->vkey.as<double>() + q_first * NS;
@@ -1567,7 +1610,8 @@ int rsx_sc_merge_topk_device(rsx_sc *h, const rsx_sc_hit *d_parts, int32_t npart
   if (!h || !d_parts || !d_out || nparts < 1 || nq < 1 || k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "bad arg");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
-  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  hipStream_t s;
+  RSX_TRY(use_stream(h, stream, &s));
   return launch_merge(d_parts, nparts, nq, k, d_out, s);
 } RSX_CATCH_ALL
 

@@ -54,6 +54,7 @@
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
+#include "sc_entry_dev.h"
 
 namespace rsx {
 namespace sc {
@@ -79,7 +80,9 @@ constexpr int F_QPP = 4;          // queries per LDS phase
 constexpr int F_DEPTH = 5;        // A fragments in flight
 constexpr int F_B_VGPR = 44;      // B fragments kept in VGPRs; the rest live in AGPRs
 constexpr int F_PHASE_BYTES = F_QPP * FILTER_QIMG_BYTES;  // 39936 = 39 KiB
-constexpr double kImgScale = 32768.0;                 // 2^15 on both operands
+using dev::kImgScale;  // 2^15 on both operands
+using dev::normalise_column;
+using dev::wave_lds_fence;
 constexpr float kAccScale = 1073741824.0f;            // 2^30 carried by the accumulators
 constexpr u64 kNonFinite = 1ull << 63;
 
@@ -87,30 +90,6 @@ static_assert(FILTER_QIMG_BYTES == 9984, "layout");
 static_assert(QIMG_ODD == FILTER_QIMG_ODD && QIMG_EVEN_CHUNKS * 16 == FILTER_QIMG_MASK_OFF && kAccScale == FILTER_ACC_SCALE,
               "sc_window.hip reads the same query image");
 static_assert(F_PHASE_BYTES % 1024 == 0, "phase must be whole 1 KiB DMA pieces");
-
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// column j of one descriptor -> 20 scaled fp16 values in st[j*20 ..]; returns (nonzero, nonfinite)
-__device__ __forceinline__ void normalise_column(const float *__restrict__ d, double nrm, _Float16 *st,
-                                                 bool &nonzero, bool &bad) {
-  const float4 *p = reinterpret_cast<const float4 *>(d);
-  nonzero = !(nrm == 0.0);  // SC.cpp:78: a column takes part unless its norm == 0
-  bad = false;
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    const float4 v = p[i];
-    const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      double y = nonzero ? ((double)x[e] / nrm) * kImgScale : 0.0;
-      bad |= !(fabs(y) <= kImgScale);  // NaN or inf
-      st[4 * i + e] = (_Float16)(float)y;
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------
 // database image: fp16, tile-major [tile of 32 entries][75 K-steps][64 lanes][8 halves]
@@ -123,20 +102,7 @@ __global__ __launch_bounds__(256) void sc_img_db_kernel(const float *__restrict_
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t it = (int64_t)blockIdx.x * 4 + wave;
   if (it >= count) return;
-  const int64_t slot = first + it;
-  bool nonzero = false, bad = false;
-  if (lane < NS) normalise_column(desc + slot * DS + lane * NR, norm[slot * NS + lane], &st[wave][lane * NR], nonzero, bad);
-  u64 m = __ballot(nonzero && lane < NS);
-  if (__ballot(bad && lane < NS)) m |= kNonFinite;
-  wave_lds_fence();
-  const int64_t tile = slot >> 5;
-  const int col = (int)(slot & 31);
-  for (int c = lane; c < 2 * F_STEPS; c += 64) {
-    const uint4 v = *reinterpret_cast<const uint4 *>(&st[wave][c * 8]);
-    hnT[(tile * F_STEPS + (c >> 1)) * 64 + (c & 1) * 32 + col] = v;
-    hnR[slot * (2 * F_STEPS) + c] = v;  // the same image entry-major (sc_window.hip gathers single entries)
-  }
-  if (lane == 0) cmask[slot] = m;
+  dev::img_db_entry(desc, norm, first + it, st[wave], hnT, hnR, cmask, lane);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -75,6 +75,14 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
                  int32_t *out_shift, rsx_sc_hit *d_partial, rsx_sc_hit *d_topk, int32_t k,
                  hipStream_t s);
 
+// one launch per new keyframe: descriptor + keys from the cloud AND every per-entry image of the query path (sc_spec.hip
+// sc_insert_kernel).  n_clouds clouds: points [d_offs[b], d_offs[b + 1]) of d_pts go to local slot first_slot + b
+// (d_offs = nullptr: one cloud of n_pts points)
+int launch_insert(const void *d_pts, const int64_t *d_offs, int64_t n_pts, int64_t n_clouds, int64_t stride_bytes,
+                  double lidar_height, double max_radius, int64_t first_slot, float *desc, double *vkey, double *norm,
+                  float *rkey, void *hnT, void *hnR, uint64_t *cmask, void *spT, float *aux, void *vk16, float *vk_n,
+                  hipStream_t s);
+
 // merge [nparts][nq][k] -> [nq][k]
 int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *d_out,
                  hipStream_t s);

@@ -40,60 +40,17 @@
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
+#include "sc_entry_dev.h"
 
 namespace rsx {
 namespace sc {
 
 namespace {
 
+using dev::wave_keys;
+using dev::wave_lds_fence;
+
 constexpr double kBig = 10000000.0;  // SC.cpp:96,134,362 "init with something large"
-
-__device__ __forceinline__ void wave_lds_fence() {
-  // LDS operations of one wave execute in order; this only stops the compiler from moving LDS
-  // accesses across the point where lanes exchange data through LDS.
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
-// ------------------------------------------------------------------------------------------
-// keys: one wave per descriptor
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_keys(const float *__restrict__ d, double *__restrict__ vkey,
-                                          double *__restrict__ norm, float *__restrict__ rkey, int lane) {
-  // Eigen 3.3 redux order of the reference build (SSE2, 2-double packets; oracle/sc_ref.c "reductions"):
-  // term i goes to accumulator i % 4 = (packet accumulator i/2 % 2, lane i % 2); result (a0 + a2) + (a1 + a3)
-  if (lane < NS) {
-    const float4 *p = reinterpret_cast<const float4 *>(d + lane * NR);
-    double s0, s1, s2, s3, q0, q1, q2, q3;
-    {
-      float4 v = p[0];
-      double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-      s0 = x0; s1 = x1; s2 = x2; s3 = x3;
-      q0 = x0 * x0; q1 = x1 * x1; q2 = x2 * x2; q3 = x3 * x3;  // exact in fp64
-    }
-#pragma unroll
-    for (int i = 1; i < 5; i++) {
-      float4 v = p[i];
-      double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-      s0 = s0 + x0; q0 = fma(x0, x0, q0);  // x*x exact in fp64 -> fma == mul+add
-      s1 = s1 + x1; q1 = fma(x1, x1, q1);
-      s2 = s2 + x2; q2 = fma(x2, x2, q2);
-      s3 = s3 + x3; q3 = fma(x3, x3, q3);
-    }
-    vkey[lane] = ((s0 + s2) + (s1 + s3)) / (double)NR;  // SC.cpp:224 mean()
-    norm[lane] = sqrt((q0 + q2) + (q1 + q3));           // Eigen norm()
-  }
-  if (lane < NR) {
-    double a[4];
-#pragma unroll
-    for (int c = 0; c < 4; c++) a[c] = (double)d[c * NR + lane];
-    for (int c = 4; c < NS; c += 4) {
-#pragma unroll
-      for (int l = 0; l < 4; l++) a[l] = a[l] + (double)d[(c + l) * NR + lane];
-    }
-    rkey[lane] = (float)(((a[0] + a[2]) + (a[1] + a[3])) / (double)NS);  // SC.cpp:208 mean(), SC.cpp:64 float narrowing
-  }
-}
 
 __global__ __launch_bounds__(256) void sc_keys_kernel(const float *__restrict__ desc, int64_t n,
                                                       double *__restrict__ vkey, double *__restrict__ norm,
@@ -104,38 +61,6 @@ __global__ __launch_bounds__(256) void sc_keys_kernel(const float *__restrict__ 
   wave_keys(desc + i * DS, vkey + i * NS, norm + i * NS, rkey + i * NR, lane);
 }
 
-// ------------------------------------------------------------------------------------------
-// build: one 256-thread block per cloud; LDS max-histogram on order-preserving int encodings
-// ------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned enc_f32(float f) {
-  unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float dec_f32(unsigned u) {
-  u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-  return __uint_as_float(u);
-}
-
-// SC.cpp:23-36; float division, atan in double, result narrowed to float (oracle/sc_ref.c)
-__device__ __forceinline__ float xy2theta_dev(float x, float y) {
-  const double k = 180 / M_PI;
-  if ((x >= 0) & (y >= 0)) return (float)(k * atan((double)__fdiv_rn(y, x)));
-  if ((x < 0) & (y >= 0)) return (float)(180 - (k * atan((double)__fdiv_rn(y, -x))));
-  if ((x < 0) & (y < 0)) return (float)(180 + (k * atan((double)__fdiv_rn(y, x))));
-  if ((x >= 0) & (y < 0)) return (float)(360 - (k * atan((double)__fdiv_rn(-y, x))));
-  return __builtin_nanf("");
-}
-
-__device__ __forceinline__ int ceil_clamp(double v, int hi) {
-  double c = ceil(v);
-  int i;
-  if (!(c == c)) i = 1;  // NaN: x86 cvttsd2si gives INT_MIN, then max(.,1) (SC.cpp:178-179)
-  else if (c >= (double)hi) i = hi;
-  else if (c <= 1.0) i = 1;
-  else i = (int)c;
-  return i;
-}
-
 __global__ __launch_bounds__(256) void sc_build_kernel(const char *__restrict__ pts, int64_t n_pts,
                                                        int64_t stride, double lidar_height,
                                                        double max_radius, float *__restrict__ out_desc,
@@ -143,32 +68,7 @@ __global__ __launch_bounds__(256) void sc_build_kernel(const char *__restrict__ 
                                                        double *__restrict__ out_norm,
                                                        float *__restrict__ out_rkey) {
   __shared__ __attribute__((aligned(16))) unsigned bins[DS];
-  const unsigned no_point = enc_f32(-1000.0f);  // SC.cpp:158-159
-  for (int i = threadIdx.x; i < DS; i += 256) bins[i] = no_point;
-  __syncthreads();
-  for (int64_t i = threadIdx.x; i < n_pts; i += 256) {
-    const float *p = reinterpret_cast<const float *>(pts + i * stride);
-    float x = p[0], y = p[1];
-    float z = (float)((double)p[2] + lidar_height);  // SC.cpp:168
-    if (!(x == x) || !(y == y) || !(z == z)) continue;
-    float ss = __fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y));
-    float azim_range = (float)sqrt((double)ss);  // SC.cpp:171 (== correctly rounded sqrtf)
-    float azim_angle = xy2theta_dev(x, y);       // SC.cpp:172
-    if ((double)azim_range > max_radius) continue;  // SC.cpp:175
-    int ring = ceil_clamp(((double)azim_range / max_radius) * NR, NR);   // SC.cpp:178
-    int sector = ceil_clamp(((double)azim_angle / 360.0) * NS, NS);      // SC.cpp:179
-    atomicMax(&bins[(sector - 1) * NR + (ring - 1)], enc_f32(z));        // SC.cpp:182-183
-  }
-  __syncthreads();
-  float *sd = reinterpret_cast<float *>(bins);
-  for (int i = threadIdx.x; i < DS; i += 256) {
-    unsigned u = bins[i];
-    float v = (u == no_point) ? 0.0f : dec_f32(u);  // SC.cpp:187-190
-    sd[i] = v;
-    out_desc[i] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) wave_keys(sd, out_vkey, out_norm, out_rkey, threadIdx.x);
+  dev::build_block(pts, n_pts, stride, lidar_height, max_radius, bins, out_desc, out_vkey, out_norm, out_rkey);
 }
 
 // ------------------------------------------------------------------------------------------

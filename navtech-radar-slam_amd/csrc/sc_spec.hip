@@ -68,6 +68,7 @@
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
+#include "sc_entry_dev.h"
 
 namespace rsx {
 namespace sc {
@@ -269,6 +270,60 @@ __global__ __launch_bounds__(256) void sc_spec_db_kernel(const float *__restrict
   const int col = (int)(slot & 31);
   for (int c = lane; c < 2 * SP_FRAGS; c += 64)
     spT[(tile * SP_FRAGS + (c >> 1)) * 64 + (c & 1) * 32 + col] = *reinterpret_cast<const uint4 *>(&kv[wave][c * 8]);
+}
+
+// ------------------------------------------------------------------------------------------
+// One new keyframe in ONE launch (the reference's makeAndSaveScancontextAndKeys, SC.cpp:229-247, plus everything the
+// query path keeps per entry): the 256-thread block builds the descriptor and its keys from the cloud (sc_entry_dev.h
+// build_block == sc_build_kernel), then wave 0 writes the spectral image, wave 1 the fp16 image (tile-major and
+// entry-major) and wave 2 the fp16 sector-key image.  Before round 4 these were four dependent launches of one block or one
+// wave each (9 + 4.6 + 10 + 4.5 us of kernels, ~60 us per insert with their gaps and the synchronise).
+// blockIdx.x = cloud: points [offs[b], offs[b + 1]) of pts (offs = nullptr: one cloud of n_pts points), slot first + b.
+// ------------------------------------------------------------------------------------------
+struct InsertArgs {
+  const char *pts;
+  const int64_t *offs;
+  int64_t n_pts, stride;
+  double lidar_height, max_radius;
+  int64_t first;
+  float *desc;
+  double *vkey, *norm;
+  float *rkey;
+  uint4 *hnT, *hnR;
+  u64 *cmask;
+  uint4 *spT;
+  float *aux;
+  _Float16 *vk16;
+  float *vk_n;
+};
+
+__global__ __launch_bounds__(256) void sc_insert_kernel(InsertArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned bins[DS];
+  __shared__ double xn[DS + 32];
+  __shared__ __attribute__((aligned(16))) _Float16 kv[SP_KV];
+  __shared__ __attribute__((aligned(16))) _Float16 st[DS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t slot = a.first + blockIdx.x;
+  const int64_t p0 = a.offs ? a.offs[blockIdx.x] : 0, p1 = a.offs ? a.offs[blockIdx.x + 1] : a.n_pts;
+  dev::build_block(a.pts + p0 * a.stride, p1 - p0, a.stride, a.lidar_height, a.max_radius, bins, a.desc + slot * DS,
+                   a.vkey + slot * NS, a.norm + slot * NS, a.rkey + slot * NR);
+  // the images read the descriptor and its norms back from global memory: written by this block, visible to it after the
+  // barrier (the same L1 / write-through path)
+  __threadfence_block();
+  __syncthreads();
+  if (wave == 0) {
+    float sqrt_a;
+    (void)spectra_of<false>(a.desc + slot * DS, a.norm + slot * NS, xn, kv, lane, sqrt_a);
+    if (lane == 0) a.aux[slot] = sqrt_a;
+    const int64_t tile = slot >> 5;
+    const int col = (int)(slot & 31);
+    for (int c = lane; c < 2 * SP_FRAGS; c += 64)
+      a.spT[(tile * SP_FRAGS + (c >> 1)) * 64 + (c & 1) * 32 + col] = *reinterpret_cast<const uint4 *>(&kv[c * 8]);
+  } else if (wave == 1) {
+    dev::img_db_entry(a.desc, a.norm, slot, st, a.hnT, a.hnR, a.cmask, lane);
+  } else if (wave == 2) {
+    dev::win_db_keys_entry(a.vkey, slot, a.vk16, a.vk_n, lane);
+  }
 }
 
 // query images (see the layout constants): stream image = the LDS layout of the filter kernel
@@ -1609,6 +1664,35 @@ int launch_spec_query_images(const float *desc, const double *norm, int32_t nq, 
   if (nq <= 0) return RSX_OK;
   hipLaunchKernelGGL(sc_spec_query_kernel, dim3((unsigned)((nq + 3) / 4)), dim3(256), 0, s, desc, norm, nq,
                      static_cast<char *>(qimg));
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+int launch_insert(const void *d_pts, const int64_t *d_offs, int64_t n_pts, int64_t n_clouds, int64_t stride_bytes,
+                  double lidar_height, double max_radius, int64_t first_slot, float *desc, double *vkey, double *norm,
+                  float *rkey, void *hnT, void *hnR, uint64_t *cmask, void *spT, float *aux, void *vk16, float *vk_n,
+                  hipStream_t s) {
+  if (n_clouds <= 0) return RSX_OK;
+  InsertArgs a;
+  a.pts = static_cast<const char *>(d_pts);
+  a.offs = d_offs;
+  a.n_pts = n_pts;
+  a.stride = stride_bytes;
+  a.lidar_height = lidar_height;
+  a.max_radius = max_radius;
+  a.first = first_slot;
+  a.desc = desc;
+  a.vkey = vkey;
+  a.norm = norm;
+  a.rkey = rkey;
+  a.hnT = static_cast<uint4 *>(hnT);
+  a.hnR = static_cast<uint4 *>(hnR);
+  a.cmask = reinterpret_cast<u64 *>(cmask);
+  a.spT = static_cast<uint4 *>(spT);
+  a.aux = aux;
+  a.vk16 = static_cast<_Float16 *>(vk16);
+  a.vk_n = vk_n;
+  hipLaunchKernelGGL(sc_insert_kernel, dim3((unsigned)n_clouds), dim3(256), 0, s, a);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

@@ -43,6 +43,7 @@
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
+#include "sc_entry_dev.h"
 
 namespace rsx {
 namespace sc {
@@ -60,7 +61,8 @@ typedef unsigned long long u64;
 #define WIN_RING 15  // B fragments of the image GEMM in flight per wave
 #endif
 constexpr float kWinAlignEps = 3e-5f;
-constexpr double kWinMaxKeyNorm = 4.0e6;
+using dev::KeySplit;
+using dev::split_key;
 constexpr u64 kNonFinite = 1ull << 63;
 constexpr int W_STEPS = DS / 16;            // 75 K-steps of the image GEMM
 constexpr int W_TILE1 = 40;                 // tile 1 (shifts 32..63) reads the A fragment 40 K-steps further on
@@ -70,50 +72,6 @@ constexpr int QK_NORM = 2 * QK_LO;          // 4608: float sqrt(E_q) (NaN: no ma
 static_assert(QK_NORM + 16 == WINDOW_QK_BYTES, "layout");
 constexpr int W_LDS = FILTER_QIMG_BYTES + WINDOW_QK_BYTES;  // 14608
 
-// scaled hi/lo split of one 60-element sector key held one element per lane (lanes >= 60: 0)
-struct KeySplit {
-  _Float16 hi, lo;
-  float nrm;   // sqrt(sum x^2), rounded up; NaN when the key has a non-finite element or is too large (below)
-  float unrm;  // the same of the unscaled key
-};
-__device__ __forceinline__ KeySplit split_key(double v, int lane) {
-  const double av = lane < NS ? fabs(v) : 0.0;
-  double mx = av;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double o = __shfl_xor(mx, off);
-    mx = (o > mx || !(o == o)) ? o : mx;  // a NaN wins
-  }
-  KeySplit r;
-  r.hi = (_Float16)0.0f;
-  r.lo = (_Float16)0.0f;
-  r.nrm = __builtin_nanf("");
-  r.unrm = __builtin_nanf("");
-  if (!(mx < INFINITY)) return r;  // NaN / inf somewhere (uniform)
-  int e = 0;
-  if (mx > 0.0) {
-    (void)frexp(mx, &e);  // mx = f * 2^e, f in [0.5, 1)
-    e = 10 - e;           // scaled maximum in [2^9, 2^10)
-  }
-  const double x = lane < NS ? ldexp(v, e) : 0.0;
-  const _Float16 hi = (_Float16)(float)x;
-  const _Float16 lo = (_Float16)(float)(x - (double)(float)hi);
-  double s = x * x;
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-  r.hi = hi;
-  r.lo = lo;
-  r.nrm = (float)(sqrt(s) * (1.0 + 1e-6));
-  // the reference's search starts from min_veq_norm = 1e7 (SC.cpp:100-106: a shift whose key distance is not below
-  // that is never taken, and if none is the alignment stays 0).  ||vkey_q - shift(vkey_e)|| <= ||vkey_q|| + ||vkey_e||:
-  // with both norms below 4e6 the test passes for every shift and the argmin is the plain argmin; larger keys are
-  // left to the exact alignment of the re-scoring kernel
-  const double un = ldexp(sqrt(s), -e);
-  if (!(un < kWinMaxKeyNorm)) r.nrm = __builtin_nanf("");
-  r.unrm = (float)un;
-  return r;
-}
-
 // ------------------------------------------------------------------------------------------
 // database side: [slot][hi 0..63 | lo 0..63] fp16 (elements 60..63 zero: the K padding) + the key's scaled norm
 // ------------------------------------------------------------------------------------------
@@ -122,14 +80,7 @@ __global__ __launch_bounds__(256) void sc_win_db_keys_kernel(const double *__res
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t it = (int64_t)blockIdx.x * 4 + wave;
   if (it >= count) return;
-  const int64_t slot = first + it;
-  const KeySplit k = split_key(lane < NS ? vkey[slot * NS + lane] : 0.0, lane);
-  vk16[slot * 128 + lane] = k.hi;
-  vk16[slot * 128 + 64 + lane] = k.lo;
-  if (lane == 0) {
-    vk_n[2 * slot] = k.nrm;
-    vk_n[2 * slot + 1] = k.unrm;
-  }
+  dev::win_db_keys_entry(vkey, first + it, vk16, vk_n, lane);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -362,7 +362,7 @@ class FilterShardedScanContext:
         send = self._buf("send", (self.world * chunk, ld_r), torch.float16)
         recv = self._buf("recv", (self.world, chunk, ld_r), torch.float16)
         self.backend.filter_range_device(q_ptr, nq, first, n, send.data_ptr(), ld_r, stream=stream)
-        _all_to_all(self._dist, recv.view(-1).view(torch.int16), send.view(-1).view(torch.int16), self.group, self._staged)  # fp16 bit patterns
+        _all_to_all(self._dist, recv.view(-1).view(torch.uint8), send.view(-1).view(torch.uint8), self.group, self._staged)  # fp16 as bytes (gloo has no half)
         if hi > lo:
             self.backend.query_bounds_device(q_ptr + lo * 4800, hi - lo, k, mine.data_ptr(), recv.data_ptr(), self.world, ld_r,
                                              chunk * ld_r, n_eligible=n_eligible, stream=stream)
