@@ -40,6 +40,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <mutex>
 #include <new>
 
@@ -812,6 +813,9 @@ struct rsx_cen2019 {
   std::mutex mu;
   hipStream_t stream = nullptr;
   rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, marker, opener, row_runs, row_nruns, markbits;
+  rsx::DevBuf one;          // single-scan entry: [count | targets | xy] in one piece, read back with one copy
+  void *one_host = nullptr;  // its pinned mirror
+  size_t one_host_bytes = 0;
 };
 
 using rsx::fail;
@@ -917,6 +921,8 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->one_host) (void)hipHostFree(h->one_host);
+  h->one.release();
   for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->marker, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
@@ -958,6 +964,50 @@ int rsx_cen2019_extract_batch(rsx_cen2019 *h, const uint8_t *imgs, int32_t n_ima
   hipStream_t s = h->stream;
   const size_t ibytes = (size_t)h->rows * row_stride;
   const int mt = max_targets > 0 ? max_targets : 1;
+  if (n_images == 1) {
+    // the live single-scan entry: the image goes up in one copy (asynchronous when the caller's buffer is pinned,
+    // rsx_host_alloc_pinned), the count and every keypoint slot come back in ONE copy into pinned memory, one synchronise
+    // (before round 4: the count first, a synchronise, then the keypoints, a second synchronise)
+    const size_t kp = (size_t)mt * 8, total = 256 + 2 * kp;
+    RSX_TRY(h->img.reserve(ibytes, s, false));
+    RSX_TRY(h->one.reserve(total, s, false));
+    if (total > h->one_host_bytes) {
+      if (h->one_host) (void)hipHostFree(h->one_host);
+      h->one_host = nullptr;
+      h->one_host_bytes = 0;
+      RSX_HIP(hipHostMalloc(&h->one_host, total, hipHostMallocDefault));
+      h->one_host_bytes = total;
+    }
+    RSX_HIP(hipMemcpyAsync(h->img.p, imgs, ibytes, hipMemcpyHostToDevice, s));
+    const float *d_az = nullptr;
+    if (azimuths) {
+      RSX_TRY(h->az.reserve((size_t)h->rows * 4, s, false));
+      RSX_HIP(hipMemcpyAsync(h->az.p, azimuths, (size_t)h->rows * 4, hipMemcpyHostToDevice, s));
+      d_az = h->az.as<float>();
+    }
+    char *d_one = h->one.as<char>();
+    RSX_TRY(extract_device(h, h->img.as<uint8_t>(), (int64_t)ibytes, 1, row_stride, col_offset, p, d_az, 0, resolution, mt,
+                           reinterpret_cast<int *>(d_one + 256), d_az ? reinterpret_cast<float *>(d_one + 256 + kp) : nullptr,
+                           reinterpret_cast<int *>(d_one), s));
+    // the count and the first 16 384 keypoint slots (a scan yields ~3 000) in one copy; a longer list takes a second one
+    const size_t first = mt < 16384 ? (size_t)mt : 16384, fb = first * 8;
+    RSX_HIP(hipMemcpyAsync(h->one_host, d_one, 256 + fb, hipMemcpyDeviceToHost, s));
+    if (out_xy) RSX_HIP(hipMemcpyAsync(static_cast<char *>(h->one_host) + 256 + kp, d_one + 256 + kp, fb, hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipStreamSynchronize(s));
+    const char *hp = static_cast<const char *>(h->one_host);
+    const unsigned cnt = *reinterpret_cast<const unsigned *>(hp);
+    out_counts[0] = (int32_t)cnt;
+    const unsigned w = cnt < (unsigned)max_targets ? cnt : (unsigned)max_targets;
+    if (w > first) {
+      RSX_HIP(hipMemcpyAsync(h->one_host, d_one, out_xy ? total : 256 + kp, hipMemcpyDeviceToHost, s));
+      RSX_HIP(hipStreamSynchronize(s));
+    }
+    if (w) {
+      std::memcpy(out_targets, hp + 256, (size_t)w * 8);
+      if (out_xy) std::memcpy(out_xy, hp + 256 + kp, (size_t)w * 8);
+    }
+    return RSX_OK;
+  }
   // sub-batches bound the staging memory; each one is a single upload, one launch chain, one download
   for (int b0 = 0; b0 < n_images; b0 += MAX_SUB_BATCH) {
     const int n = n_images - b0 < MAX_SUB_BATCH ? n_images - b0 : MAX_SUB_BATCH;
