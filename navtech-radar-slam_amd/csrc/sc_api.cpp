@@ -504,6 +504,7 @@ int ensure_tree(rsx_sc *h, rsx_sc::KdTreeDev *t, int64_t n, std::unique_lock<std
   }
   RSX_TRY(set_device(h));
   if (t->n == n) return RSX_OK;  // another detector thread built the same tree meanwhile
+  if (n > h->n_local) return fail(RSX_ERR_RANGE, "the database shrank while the ring-key tree was being built");
   return upload_tree(h, t, p);
 }
 
@@ -1081,13 +1082,18 @@ int rsx_sc_detect_loop_closure_ex(rsx_sc *h, int mode, rsx_sc_detection *out) tr
   out->reserved = 0;
   out->dist_thres = h->p.dist_thres;
   if (N == 0 || N < h->p.num_exclude_recent + 1) return RSX_OK;  // SC.cpp:341-345
+  int64_t n_search = h->tree_size;
   if (h->tree_counter % h->p.tree_making_period == 0)  // SC.cpp:348-359
-    h->tree_size = N - h->p.num_exclude_recent;
-  h->tree_counter = h->tree_counter + 1;               // SC.cpp:360
-  const int64_t n_search = h->tree_size;
+    n_search = N - h->p.num_exclude_recent;
   // candidate mode walks the ring-key tree: (re)built here with the handle unlocked; keyframes added meanwhile are not
   // part of this detection (N was taken above), and the device arrays are addressed only after the lock is back
   if (mode == RSX_SC_MODE_CANDIDATE && n_search >= 1) RSX_TRY(ensure_tree(h, &h->tree, n_search, lk));
+  // the lock was away during the build: a concurrent rsx_sc_load may have replaced the database
+  if (N > h->n_global || n_search > h->n_global)
+    return fail(RSX_ERR_RANGE, "the database was replaced while the ring-key tree was being built");
+  // the detector's state advances only now that the tree stands (a failed build leaves it where it was)
+  h->tree_size = n_search;
+  h->tree_counter = h->tree_counter + 1;               // SC.cpp:360
   QueryView qv;
   qv.desc = h->desc.as<float>() + (N - 1) * DS;        // SC.cpp:336
   qv.vkey = h->vkey.as<double>() + (N - 1) * NS;
@@ -1183,11 +1189,13 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
   if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "unsharded handles only");
   if (h->n_global == 0) return fail(RSX_ERR_RANGE, "empty database");  // reference asserts (KDA.h:61)
   RSX_TRY(set_device(h));
-  if (!h->batch_made) {  // SC.cpp:275-284
-    h->batch_size = h->n_global;
+  const int64_t batch = h->batch_made ? h->batch_size : h->n_global;  // SC.cpp:275-284
+  RSX_TRY(ensure_tree(h, &h->tree_batch, batch, lk));
+  if (batch > h->n_global) return fail(RSX_ERR_RANGE, "the database was replaced while the ring-key tree was being built");
+  if (!h->batch_made) {  // committed only once the tree stands
+    h->batch_size = batch;
     h->batch_made = true;
   }
-  RSX_TRY(ensure_tree(h, &h->tree_batch, h->batch_size, lk));
   hipStream_t s = h->stream;
   RSX_TRY(h->q_desc.reserve(sizeof(f) + 128, s, false));
   RSX_HIP(hipMemcpyAsync(h->q_desc.p, f, sizeof(f), hipMemcpyHostToDevice, s));

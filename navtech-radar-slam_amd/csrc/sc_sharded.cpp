@@ -142,13 +142,21 @@ int exchange(rsx_scs *h, Group &gr, bool from_out, int32_t nq, int32_t k, bool t
       RSX_TRY(use(s));
       RSX_TRY(s.all.reserve(bytes * S, s.stream, false));
     }
+    // a return between GroupStart and GroupEnd would leave the RCCL group open on this thread and wedge every later
+    // collective of the handle: the first error is kept, the group is always closed, then the error is returned
     RSX_NCCL(h->rccl, h->rccl->GroupStart());
-    for (int g = 0; g < S; g++) {
-      Shard &s = h->sh[(size_t)(gr.first + g)];
-      RSX_TRY(use(s));
-      RSX_NCCL(h->rccl, h->rccl->AllGather(from_out ? s.out.p : s.part.p, s.all.p, bytes, /* ncclChar */ 0, s.comm, s.stream));
-    }
+    auto enqueue = [&]() -> int {
+      for (int g = 0; g < S; g++) {
+        Shard &s = h->sh[(size_t)(gr.first + g)];
+        RSX_TRY(use(s));
+        RSX_NCCL(h->rccl, h->rccl->AllGather(from_out ? s.out.p : s.part.p, s.all.p, bytes, /* ncclChar */ 0, s.comm, s.stream));
+      }
+      return RSX_OK;
+    };
+    const int st_enq = enqueue();
+    const std::string msg_enq = st_enq != RSX_OK ? std::string(rsx_last_error_string()) : std::string();
     RSX_NCCL(h->rccl, h->rccl->GroupEnd());
+    if (st_enq != RSX_OK) return fail(st_enq, "%s", msg_enq.c_str());
     for (int g = 0; g < S; g++) {
       if (!to_bound && g != 0) continue;  // the final merge is only needed where the result is read
       Shard &s = h->sh[(size_t)(gr.first + g)];
@@ -223,23 +231,42 @@ int query_group(rsx_scs *h, Group &gr, const float *q, int32_t nq, int32_t k, in
 int query_locked(rsx_scs *h, const float *q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) {
   const int Q = (int)h->gr.size();
   const int32_t chunk = (nq + Q - 1) / Q;
-  std::vector<Shard *> pend;
-  for (int g = 0; g < Q; g++) {  // every group gets its slice; nothing waits until all groups are launched
+  struct Pending {
+    Shard *lead;
+    const rsx_sc_hit *d_res;
+    int32_t lo, n;
+  };
+  std::vector<Pending> pend;
+  // nothing of this call may be in flight when the caller gets its buffers back, whatever the status
+  auto drain = [&]() {
+    for (const Pending &p : pend)
+      if (use(*p.lead) == RSX_OK) (void)hipStreamSynchronize(p.lead->stream);
+  };
+  // first every group is launched (device work only: the groups run concurrently) ...
+  for (int g = 0; g < Q; g++) {
     const int32_t lo = std::min(nq, g * chunk), n = std::min(nq, lo + chunk) - lo;
     if (n <= 0) continue;
     const rsx_sc_hit *d_res = nullptr;
     Group &gr = h->gr[(size_t)g];
-    RSX_TRY(query_group(h, gr, q + (size_t)lo * RSX_SC_DESC_SIZE, n, k, n_eligible, &d_res));
-    Shard &lead = h->sh[(size_t)gr.first];
-    RSX_TRY(use(lead));
-    RSX_HIP(hipMemcpyAsync(out + (size_t)lo * k, d_res, (size_t)n * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToHost, lead.stream));
-    pend.push_back(&lead);
+    const int st = query_group(h, gr, q + (size_t)lo * RSX_SC_DESC_SIZE, n, k, n_eligible, &d_res);
+    if (st != RSX_OK) {
+      drain();
+      return st;
+    }
+    pend.push_back(Pending{&h->sh[(size_t)gr.first], d_res, lo, n});
   }
-  for (Shard *s : pend) {
-    RSX_TRY(use(*s));
-    RSX_HIP(hipStreamSynchronize(s->stream));
+  // ... then the read-backs: a copy into the caller's (pageable) memory may hold this thread until it has completed, which
+  // between two launches would have run the groups one after the other
+  int st = RSX_OK;
+  for (const Pending &p : pend) {
+    st = use(*p.lead);
+    if (st == RSX_OK && hipMemcpyAsync(out + (size_t)p.lo * k, p.d_res, (size_t)p.n * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToHost,
+                                       p.lead->stream) != hipSuccess)
+      st = fail(RSX_ERR_HIP, "read-back of a query group failed");
+    if (st != RSX_OK) break;
   }
-  return RSX_OK;
+  drain();
+  return st;
 }
 
 }  // namespace
