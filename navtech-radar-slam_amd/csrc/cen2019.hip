@@ -875,7 +875,11 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     const float *azp = d_az ? d_az + (int64_t)b0 * az_stride : nullptr;
     int *cn = d_counts ? d_counts + b0 : nullptr;
     // <= 4096 bins: 512 threads x 8 bins (about 100 VGPRs: four waves per SIMD; 256 x 16 needs 176: two); wider rows: 1024 x 16
-    if (cols <= 8 * 512)
+    // (a Navtech CIR row has 3360 bins = 420 threads: with 448 the eighth wave of the 512-thread block, which would execute
+    // every instruction of the row passes with all lanes off, does not exist)
+    if (cols <= 8 * 448)
+      launch_chain<8, 448>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
+    else if (cols <= 8 * 512)
       launch_chain<8, 512>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     else
       launch_chain<16, 1024>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
