@@ -210,37 +210,54 @@ __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const dou
   }
   wave_lds_fence();
   double dc_energy = 0.0;  // this lane's share of sum |X_0|^2
-  for (int idx = lane; idx < 8 * 80; idx += 64) {
-    const int f = idx / 80, rem = idx - f * 80, a = rem / NR, r = rem - a * NR;
-    double re = 0.0, im = 0.0;
+  // One (a, r) pair per lane and pass (80 pairs: lanes 0..63, then 0..15): the pair's 15 column values are read from LDS once
+  // and serve all 8 frequencies, the twiddles sit in registers.  (Until round 4 a lane took one (f, a, r) output at a time and
+  // read x and two twiddles from LDS for every term: 450 ds_read_b64 per lane instead of 30 + 30.)  Every output is the same
+  // left-to-right sum over b as before, and the f = 0 outputs stay on the same lanes in the same order: the image and
+  // dc_energy are bit-identical.
+  double twc[15], tws[15];
+#pragma unroll
+  for (int t = 0; t < 15; t++) {
+    twc[t] = tw[t];
+    tws[t] = tw[16 + t];
+  }
+#pragma unroll 1
+  for (int idx = lane; idx < 80; idx += 64) {
+    const int a = idx / NR, r = idx - a * NR;
     int c = 45 * a;  // CRT: c = a mod 4, c = b mod 15  ->  c = (45 a + 16 b) mod 60
     c -= (c >= 120) ? 120 : 0;
     c -= (c >= 60) ? 60 : 0;
-    int t = 0;       // (f b) mod 15
+    double x[15];
 #pragma unroll
-    for (int b = 0; b < 15; b++) {
-      const double x = xn[r * NS + c];
-      re += x * tw[t];
-      im -= x * tw[16 + t];
+    for (int bb = 0; bb < 15; bb++) {
+      x[bb] = xn[r * NS + c];
       c += 16;
       c -= (c >= 60) ? 60 : 0;
-      t += f;
-      t -= (t >= 15) ? 15 : 0;
     }
-    if (f == 0) {
-      kv[a * 24 + r] = (_Float16)(float)re;
-      dc_energy += re * re;
-    } else if constexpr (!QIMG) {
-      const int base = 96 + (f - 1) * 160 + a * 40 + r;
-      kv[base] = (_Float16)(float)re;
-      kv[base + 20] = (_Float16)(float)im;
-    } else {
-      const int base = (SP_DC_BYTES + (f - 1) * SP_F_BYTES) / 2 + a * 40 + r;
-      const _Float16 hr = (_Float16)(float)re, hi = (_Float16)(float)im;
-      kv[base] = hr;
-      kv[base + 20] = hi;
-      kv[base + SP_VS / 2] = hi;
-      kv[base + SP_VS / 2 + 20] = -hr;
+#pragma unroll
+    for (int f = 0; f < 8; f++) {
+      double re = 0.0, im = 0.0;
+#pragma unroll
+      for (int bb = 0; bb < 15; bb++) {
+        const int t = (f * bb) % 15;
+        re += x[bb] * twc[t];
+        im -= x[bb] * tws[t];
+      }
+      if (f == 0) {
+        kv[a * 24 + r] = (_Float16)(float)re;
+        dc_energy += re * re;
+      } else if constexpr (!QIMG) {
+        const int base = 96 + (f - 1) * 160 + a * 40 + r;
+        kv[base] = (_Float16)(float)re;
+        kv[base + 20] = (_Float16)(float)im;
+      } else {
+        const int base = (SP_DC_BYTES + (f - 1) * SP_F_BYTES) / 2 + a * 40 + r;
+        const _Float16 hr = (_Float16)(float)re, hi = (_Float16)(float)im;
+        kv[base] = hr;
+        kv[base + 20] = hi;
+        kv[base + SP_VS / 2] = hi;
+        kv[base + SP_VS / 2 + 20] = -hr;
+      }
     }
   }
   if (lane < 16) kv[(lane >> 2) * 24 + 20 + (lane & 3)] = (_Float16)0.0f;  // K padding of f = 0
