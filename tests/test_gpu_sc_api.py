@@ -221,3 +221,55 @@ def test_host_entry_in_pieces_equals_the_device_entry(sc, nq):
         g.query(pq.a[:100], k=k, n_eligible=1400, out=po.a[:100])   # a small batch right after: workspaces reused
         assert np.array_equal(po.a[:100], ref[:100])
     g.close()
+
+
+def test_one_launch_insert_equals_the_bulk_import_path(sc):
+    """rsx_sc_add_points builds descriptor, keys and every per-entry image in ONE kernel (sc_insert_kernel); the bulk import
+    (rsx_sc_add_descriptors_f32) computes keys and images with the batched kernels.  Same descriptors in, so the databases
+    must be indistinguishable: descriptors, keys, filter bounds (= the spectral images) and query records bit for bit."""
+    clouds, _ = synth.keyframe_clouds(9, 70, binary_z=False, loop_frac=0.4, min_gap=2, n_points=800)
+    a = sc.SCManager()
+    for c in clouds:
+        a.makeAndSaveScancontextAndKeys(c)
+    descs = a.export_descriptors_f32(0, len(clouds))
+    b = sc.SCManager()
+    b.add_descriptors_f32(descs)
+    q = np.stack([synth.rotate_descriptor(descs[(7 * i) % len(descs)], 3 * i) for i in range(24)])
+    q[3].reshape(60, 20)[:20] = 0
+    assert np.array_equal(a.filter_bounds(q).view(np.uint32), b.filter_bounds(q).view(np.uint32))
+    for i in (0, 13, len(clouds) - 1):
+        assert np.array_equal(a.descriptor(i), b.descriptor(i))
+        assert np.array_equal(a.ringkey(i), b.ringkey(i)) and np.array_equal(a.sectorkey(i), b.sectorkey(i))
+    fa, fb = sc.SCManager(filter_mode=2), sc.SCManager(filter_mode=2)
+    for c in clouds:
+        fa.makeAndSaveScancontextAndKeys(c)
+    fb.add_descriptors_f32(descs)
+    assert np.array_equal(fa.query(q, k=5), fb.query(q, k=5))          # filter + window previews + exact re-scoring
+    assert np.array_equal(a.query(q, k=5), fa.query(q, k=5))
+
+
+def test_inserts_do_not_wait_and_later_calls_see_them(sc):
+    """rsx_sc_add_points returns without waiting for the GPU: the caller's buffer is free at once (it is overwritten here right
+    after every call), entries appear in order, and a query on the CALLER's stream -- not the handle's -- sees all of them."""
+    import torch
+    clouds, _ = synth.keyframe_clouds(10, 40, binary_z=False, loop_frac=0.3, min_gap=2, n_points=700)
+    ref = sc.SCManager()
+    for c in clouds:
+        ref.makeAndSaveScancontextAndKeys(c)
+    descs = ref.export_descriptors_f32(0, len(clouds))
+    g = sc.SCManager()
+    side = torch.cuda.Stream()
+    d_q = torch.from_numpy(descs[:8].copy()).cuda()
+    out = torch.zeros((8, 1, 2), dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    buf = np.zeros((1000, clouds[0].shape[1]), dtype=np.float32)
+    for i, c in enumerate(clouds):
+        buf[:len(c)] = c
+        g.makeAndSaveScancontextAndKeys(buf[:len(c)])                   # a contiguous view: the library reads THIS memory
+        buf[:] = np.nan                                                # the call copied the cloud: this must not reach the GPU
+        if i % 8 == 7:                                                 # straight after an insert, on a stream of our own
+            g.query_device(d_q.data_ptr(), 8, 1, out.data_ptr(), n_eligible=-1, stream=side.cuda_stream)
+            side.synchronize()
+            got = out.cpu().numpy().view(sc.HIT_DTYPE).reshape(8)
+            assert np.array_equal(got["index"], np.arange(8)) and np.all(got["dist"] < 1e-12), i   # every query finds itself
+    assert np.array_equal(g.export_descriptors_f32(0, len(clouds)), descs)
