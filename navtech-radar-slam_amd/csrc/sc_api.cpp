@@ -1322,6 +1322,10 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
       RSX_HIP(hipStreamWaitEvent(h->stream, h->lane_ev, 0));
       return RSX_OK;
     };
+    struct BackToSetZero {  // also when something below throws (the firewall turns that into a status)
+      rsx_sc *h;
+      ~BackToSetZero() { h->w = &h->ws[0]; }
+    } back{h};
     const int st = all_pieces();
     h->w = &h->ws[0];
     if (st != RSX_OK) {  // nothing of this call may still be in flight when the caller gets its buffers back
