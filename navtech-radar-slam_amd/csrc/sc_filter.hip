@@ -538,29 +538,46 @@ __global__ __launch_bounds__(256) void sc_select_kernel(const lb_t *__restrict__
   // the row is read in pieces of 256 threads x SEL_U 16-byte loads (8 fp16 bounds each): all SEL_U loads of a thread are in
   // flight together (one 4-byte load per thread and iteration left 8 KB per CU in flight: latency-bound at 1.5 TB/s,
   // 0.22 ms per 8192 rows)
-  auto for_row = [&](auto &&f) {
-    typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-    const uint4 *row8 = reinterpret_cast<const uint4 *>(row);  // ld is a multiple of 32 elements: 64-byte aligned rows
-    const int64_t n8 = n_items >> 3;
-    for (int64_t c0 = 0; c0 < n8; c0 += 256 * SEL_U) {
-      uint4 x[SEL_U];
+  // A row that fits one piece (<= 256 x SEL_U x 8 = 10 240 entries: the 10 000-keyframe DB) is read ONCE: the registers of
+  // the histogram pass serve the compaction pass as well.  (Round 3 read it twice, the second time "from the L2" -- 8192 rows
+  // of 20 KB are 0.16 GB, far more than the L2s hold: both readings came over the fabric.)
+  typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+  const uint4 *row8 = reinterpret_cast<const uint4 *>(row);  // ld is a multiple of 32 elements: 64-byte aligned rows
+  const int64_t n8 = n_items >> 3;
+  const bool one_piece = n8 <= 256 * SEL_U;
+  uint4 keep[SEL_U];
+  auto load_piece = [&](int64_t c0, uint4 (&x)[SEL_U]) {
 #pragma unroll
-      for (int u = 0; u < SEL_U; u++) {
-        const int64_t j = c0 + u * 256 + threadIdx.x;
-        x[u] = j < n8 ? row8[j] : uint4{0x7c007c00u, 0x7c007c00u, 0x7c007c00u, 0x7c007c00u};  // +inf
-      }
+    for (int u = 0; u < SEL_U; u++) {
+      const int64_t j = c0 + u * 256 + threadIdx.x;
+      x[u] = j < n8 ? row8[j] : uint4{0x7c007c00u, 0x7c007c00u, 0x7c007c00u, 0x7c007c00u};  // +inf
+    }
+  };
+  auto walk_piece = [&](int64_t c0, const uint4 (&x)[SEL_U], auto &&f) {
 #pragma unroll
-      for (int u = 0; u < SEL_U; u++) {
-        const int64_t i = (c0 + u * 256 + threadIdx.x) << 3;
-        const half8 h = __builtin_bit_cast(half8, x[u]);
+    for (int u = 0; u < SEL_U; u++) {
+      const int64_t i = (c0 + u * 256 + threadIdx.x) << 3;
+      const half8 h = __builtin_bit_cast(half8, x[u]);
 #pragma unroll
-        for (int e = 0; e < 8; e++) f((float)h[e], i + e);
+      for (int e = 0; e < 8; e++) f((float)h[e], i + e);
+    }
+  };
+  // first = true: the pass that loads; a later pass of a one-piece row walks the registers it left behind
+  auto for_row = [&](bool first, auto &&f) {
+    if (one_piece) {
+      if (first) load_piece(0, keep);
+      walk_piece(0, keep, f);
+    } else {
+      for (int64_t c0 = 0; c0 < n8; c0 += 256 * SEL_U) {
+        uint4 x[SEL_U];
+        load_piece(c0, x);
+        walk_piece(c0, x, f);
       }
     }
     const int64_t i = (n8 << 3) + threadIdx.x;  // the last n_items % 8 entries
     if (i < n_items) f((float)row[i], i);
   };
-  for_row([&](float d, int64_t) {
+  for_row(true, [&](float d, int64_t) {
     if (d != INFINITY) atomicAdd(&hist[lb_bin(d)], 1);  // +inf: no effective column at any shift, never a hit
   });
   __syncthreads();
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(256) void sc_select_kernel(const lb_t *__restrict__
   for (int i = threadIdx.x; i < H_BINS; i += 256) fill[i] = i ? hist[i - 1] : 0;  // exclusive prefix = first position
   __syncthreads();
   if (b_cap >= 0) {
-    for_row([&](float d, int64_t i) {  // second reading: from the L2
+    for_row(false, [&](float d, int64_t i) {  // second pass: the kept registers (or, for a long row, a second reading)
       if (d == INFINITY) return;
       const int b = lb_bin(d);
       if (b > b_cap) return;

@@ -192,9 +192,10 @@ __device__ __forceinline__ u64 spectra_of(const float *__restrict__ d, const dou
   if (lane < NS) {
     const double n = nrm[lane];
     nonzero = !(n == 0.0);  // SC.cpp:78: a column takes part unless its norm == 0
+    const double rn = 1.0 / n;  // one division per column (x * (1 / n): 2 ulp of fp64 from x / n, the image is fp16)
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-      const double y = nonzero ? (double)d[lane * NR + r] / n : 0.0;
+      const double y = nonzero ? (double)d[lane * NR + r] * rn : 0.0;
       bad |= !(fabs(y) <= 1.0000001);  // NaN, inf (or a norm that is not the column's)
       xn[r * NS + lane] = y;
     }
