@@ -16,6 +16,8 @@
 //   vg_heads      first point of every voxel -> flag; rocPRIM exclusive scan -> output slot
 //   vg_centroids  the thread of a voxel's first point sums x, y, z, intensity in float, divides by
 //                 the count, writes the packed float4
+// Clouds of <= 4096 points (every keyframe cloud of the reference's pipeline) take vg_small_kernel instead: the same steps in
+// one workgroup and ONE launch, with a bitonic sort in LDS -- no library call on the keyframe path.
 #include <hip/hip_runtime.h>
 
 #include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
@@ -178,6 +180,192 @@ __global__ __launch_bounds__(256) void vg_copy(const char *__restrict__ pts, int
   out[i] = make_float4(p[0], p[1], p[2], ioff >= 0 ? *reinterpret_cast<const float *>(q + ioff) : 0.0f);
 }
 
+// ------------------------------------------------------------------------------------------
+// Clouds of up to VG_SMALL_MAX points (a keyframe cloud is ~10^3): the whole chain in ONE workgroup and one launch --
+// min / max, setup, keys, a bitonic sort of (voxel index << 32 | input index) in LDS (the input index in the low half keeps a
+// voxel's points in input order, as the stable radix sort of the large path does), heads, a block scan for the output slots,
+// centroids.  Same float operations in the same order as the kernels above, so the same bits out.
+// ------------------------------------------------------------------------------------------
+constexpr int VG_SMALL_MAX = 4096;
+constexpr int VG_SMALL_NT = 1024;
+
+__global__ __launch_bounds__(VG_SMALL_NT) void vg_small_kernel(const char *__restrict__ pts, int n, int64_t stride, int ioff, float leaf,
+                                                               float4 *__restrict__ out, int64_t max_out, VgParams *P) {
+  __shared__ unsigned long long sk[VG_SMALL_MAX];
+  __shared__ unsigned s_red[6][VG_SMALL_NT / 64];
+  __shared__ unsigned s_cnt[VG_SMALL_NT / 64];
+  __shared__ unsigned s_pos[VG_SMALL_MAX];
+  __shared__ VgParams sp;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  // ---- min / max / count of the finite points ----
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  unsigned cnt = 0;
+  for (int i = t; i < n; i += VG_SMALL_NT) {
+    const float *p = reinterpret_cast<const float *>(pts + (int64_t)i * stride);
+    if (!finite3(p)) continue;
+    for (int c = 0; c < 3; c++) {
+      mn[c] = fminf(mn[c], p[c]);
+      mx[c] = fmaxf(mx[c], p[c]);
+    }
+    cnt++;
+  }
+  for (int o = 32; o >= 1; o >>= 1) {
+    for (int c = 0; c < 3; c++) {
+      mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+    }
+    cnt += __shfl_xor(cnt, o);
+  }
+  if (lane == 0) {
+    for (int c = 0; c < 3; c++) {
+      s_red[c][w] = enc(mn[c]);
+      s_red[3 + c][w] = enc(mx[c]);
+    }
+    s_cnt[w] = cnt;
+  }
+  __syncthreads();
+  if (t == 0) {  // vg_setup, on the reduced values
+    unsigned long long nv = 0;
+    for (int c = 0; c < 3; c++) {
+      unsigned a = enc(INFINITY), b = enc(-INFINITY);
+      for (int ww = 0; ww < VG_SMALL_NT / 64; ww++) {
+        a = s_red[c][ww] < a ? s_red[c][ww] : a;
+        b = s_red[3 + c][ww] > b ? s_red[3 + c][ww] : b;
+      }
+      sp.mn[c] = a;
+      sp.mx[c] = b;
+    }
+    for (int ww = 0; ww < VG_SMALL_NT / 64; ww++) nv += s_cnt[ww];
+    sp.nvalid = nv;
+    sp.overflow = 0;
+    sp.n_out = 0;
+    if (nv) {
+      const float inv = __fdiv_rn(1.0f, leaf);
+      sp.inv = inv;
+      long long d[3];
+      float fmn[3], fmx[3];
+      for (int c = 0; c < 3; c++) {
+        fmn[c] = dec(sp.mn[c]);
+        fmx[c] = dec(sp.mx[c]);
+        d[c] = (long long)(__fmul_rn(__fsub_rn(fmx[c], fmn[c]), inv)) + 1;
+      }
+      if (d[0] * d[1] * d[2] > 2147483647ll) {  // "Leaf size is too small for the input dataset"
+        sp.overflow = 1;
+        sp.n_out = n;
+      } else {
+        int div_b[3];
+        for (int c = 0; c < 3; c++) {
+          sp.min_b[c] = (int)floorf(__fmul_rn(fmn[c], inv));
+          div_b[c] = (int)floorf(__fmul_rn(fmx[c], inv)) - sp.min_b[c] + 1;
+        }
+        sp.mul[0] = 1;
+        sp.mul[1] = div_b[0];
+        sp.mul[2] = div_b[0] * div_b[1];
+      }
+    }
+  }
+  __syncthreads();
+  if (sp.nvalid == 0 || sp.overflow) {
+    if (sp.overflow)  // output = input (packed), non-finite points included, input order
+      for (int i = t; i < n && i < max_out; i += VG_SMALL_NT) {
+        const char *q = pts + (int64_t)i * stride;
+        const float *p = reinterpret_cast<const float *>(q);
+        out[i] = make_float4(p[0], p[1], p[2], ioff >= 0 ? *reinterpret_cast<const float *>(q + ioff) : 0.0f);
+      }
+    if (t == 0) *P = sp;
+    return;
+  }
+  // ---- keys (a power of two of them: the padding sorts to the end) ----
+  int m = 1;
+  while (m < n) m <<= 1;
+  for (int i = t; i < m; i += VG_SMALL_NT) {
+    unsigned key = 0xffffffffu;
+    if (i < n) {
+      const float *p = reinterpret_cast<const float *>(pts + (int64_t)i * stride);
+      if (finite3(p)) {
+        int idx = 0;
+        for (int c = 0; c < 3; c++) idx += (int)(__fsub_rn(floorf(__fmul_rn(p[c], sp.inv)), (float)sp.min_b[c])) * sp.mul[c];
+        key = (unsigned)idx;
+      }
+    }
+    sk[i] = ((unsigned long long)key << 32) | (unsigned)i;
+  }
+  __syncthreads();
+  // ---- bitonic sort, ascending ----
+  for (int k = 2; k <= m; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = t; i < m; i += VG_SMALL_NT) {
+        const int l = i ^ j;
+        if (l > i) {
+          const unsigned long long a = sk[i], b = sk[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            sk[i] = b;
+            sk[l] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- heads -> output slots (exclusive scan over the sorted positions, VG_SMALL_MAX / VG_SMALL_NT per thread) ----
+  constexpr int PER = VG_SMALL_MAX / VG_SMALL_NT;
+  unsigned flag[PER], run = 0;
+#pragma unroll
+  for (int e = 0; e < PER; e++) {
+    const int i = t * PER + e;
+    unsigned f = 0;
+    if (i < n) {
+      const unsigned k = (unsigned)(sk[i] >> 32);
+      f = (k != 0xffffffffu && (i == 0 || (unsigned)(sk[i - 1] >> 32) != k)) ? 1u : 0u;
+    }
+    flag[e] = f;
+    run += f;
+  }
+  unsigned incl = run;
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned v = __shfl_up(incl, o);
+    if (lane >= o) incl += v;
+  }
+  if (lane == 63) s_cnt[w] = incl;
+  __syncthreads();
+  unsigned base = incl - run;
+  for (int ww = 0; ww < w; ww++) base += s_cnt[ww];
+  unsigned total = 0;
+  for (int ww = 0; ww < VG_SMALL_NT / 64; ww++) total += s_cnt[ww];
+#pragma unroll
+  for (int e = 0; e < PER; e++) {
+    const int i = t * PER + e;
+    if (i < VG_SMALL_MAX) s_pos[i] = base;
+    base += flag[e];
+  }
+  __syncthreads();
+  // ---- centroids: the thread of a voxel's first point sums its points in input order ----
+#pragma unroll
+  for (int e = 0; e < PER; e++) {
+    const int i = t * PER + e;
+    if (!flag[e]) continue;
+    const unsigned k = (unsigned)(sk[i] >> 32);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int j = i;
+    for (; j < n && (unsigned)(sk[j] >> 32) == k; j++) {
+      const char *q = pts + (int64_t)(unsigned)(sk[j] & 0xffffffffu) * stride;
+      const float *p = reinterpret_cast<const float *>(q);
+      s0 = __fadd_rn(s0, p[0]);
+      s1 = __fadd_rn(s1, p[1]);
+      s2 = __fadd_rn(s2, p[2]);
+      if (ioff >= 0) s3 = __fadd_rn(s3, *reinterpret_cast<const float *>(q + ioff));
+    }
+    const float c = (float)(j - i);
+    const unsigned o = s_pos[i];
+    if ((int64_t)o < max_out) out[o] = make_float4(__fdiv_rn(s0, c), __fdiv_rn(s1, c), __fdiv_rn(s2, c), __fdiv_rn(s3, c));
+  }
+  if (t == 0) {
+    sp.n_out = total;
+    *P = sp;
+  }
+}
+
 }  // namespace
 
 struct rsx_voxelgrid {
@@ -208,6 +396,17 @@ int filter_device(rsx_voxelgrid *h, const void *d_pts, int64_t n, int64_t stride
   RSX_TRY(h->out.reserve((size_t)(max_out > 0 ? max_out : 1) * 16, s, false));
   VgParams *P = h->params.as<VgParams>();
   const char *pts = static_cast<const char *>(d_pts);
+  if (n <= VG_SMALL_MAX) {  // a keyframe cloud: one workgroup, one launch (the large path below is 14)
+    hipLaunchKernelGGL(vg_small_kernel, dim3(1), dim3(VG_SMALL_NT), 0, s, pts, (int)n, stride, (int)ioff, leaf, h->out.as<float4>(),
+                       max_out, P);
+    RSX_HIP(hipGetLastError());
+    long long cnt = 0;
+    RSX_HIP(hipMemcpyAsync(&cnt, &P->n_out, sizeof(cnt), hipMemcpyDeviceToHost, s));
+    RSX_HIP(hipStreamSynchronize(s));
+    *d_out = h->out.as<float>();
+    *n_out = cnt;
+    return RSX_OK;
+  }
   const unsigned nb = (unsigned)((n + 255) / 256);
   hipLaunchKernelGGL(vg_init, dim3(1), dim3(64), 0, s, P);
   hipLaunchKernelGGL(vg_minmax, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pts, n, stride, P);
