@@ -408,7 +408,9 @@ __device__ __forceinline__ int h_bin(float hv) {  // monotone non-decreasing in 
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
                                                Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ marker,
-                                               unsigned short *__restrict__ opener) {
+                                               unsigned short *__restrict__ opener, int dbg) {
+  // dbg (experiments builds, tools/ab_cen.py; results are then wrong, only the time means something): 1 = stop after the row
+  // evaluation, 2 = no marker / opener stores, 4 = no histogram and no fixed-point sum
   __shared__ RowLds<C, NT> L;
   __shared__ unsigned s_hist[NBIN];
   __shared__ long long s_fix[NT / 64];
@@ -421,8 +423,9 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
   for (int b = threadIdx.x; b < NBIN; b += NT) s_hist[b] = 0;
   RowRegs<C, NT> R;
   row_eval(L, row, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
+  if (dbg & 1) return;
   const unsigned opens = row_opens(L, R, cols);
-  {
+  if (!(dbg & 2)) {
     // what the later passes need of this evaluation, so that the segmented scans run ONCE per row: for every pixel the
     // range bin of the pixel whose key is its mark key (16 bits; rows padded to C * NT), and the opener bits of the thread
     unsigned mw[C / 2];
@@ -437,6 +440,7 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
     for (int j = 0; j < C / 8; j++) mdst[j] = uint4{mw[4 * j], mw[4 * j + 1], mw[4 * j + 2], mw[4 * j + 3]};
     opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
   }
+  if (dbg & 4) return;
   long long fix = 0;
 #pragma unroll
   for (int i = 0; i < C; i++) {
@@ -825,13 +829,13 @@ namespace {
 template <int C, int NT>
 void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int nb, int32_t stride, int32_t off, const rsx_cen2019_params &p,
                   const float *d_az, int64_t az_stride, float resolution, int32_t max_targets, int *d_targets, float *d_xy, int *d_counts,
-                  int row_cap, hipStream_t s) {
+                  int row_cap, hipStream_t s, int dbg = 0) {
   const int rows = h->rows, cols = h->cols;
   Scal *sc = h->scal.as<Scal>();
   const dim3 grid((unsigned)rows, (unsigned)nb);
   hipLaunchKernelGGL((cen_stats<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
   hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>(),
-                     h->marker.as<unsigned short>(), h->opener.as<unsigned short>());
+                     h->marker.as<unsigned short>(), h->opener.as<unsigned short>(), dbg);
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
   hipLaunchKernelGGL((cen_collect<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
                      h->list.as<unsigned long long>(), (int64_t)rows * cols);
@@ -860,7 +864,7 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     RSX_TRY(h->row_out.reserve((size_t)n * rows * row_cap * 4, s, false));
     RSX_TRY(h->row_n.reserve((size_t)n * rows * 4, s, false));
     {
-      const size_t nt = cols <= 8 * 512 ? 512 : 1024, cc = cols <= 8 * 512 ? 8 : 16;  // threads per row block x bins per thread: marker rows are padded
+      const size_t nt = cols <= 8 * 512 ? 512 : 1024, cc = cols <= 8 * 512 ? 8 : 16;  // threads per row block x bins per thread: marker rows are padded (every configuration of a row width pads to at most nt * cc bins)
       RSX_TRY(h->marker.reserve((size_t)n * rows * nt * cc * 2, s, false));
       RSX_TRY(h->opener.reserve((size_t)n * rows * nt * 2, s, false));
       RSX_TRY(h->markbits.reserve((size_t)n * rows * nt * 2, s, false));
@@ -875,12 +879,16 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     const float *azp = d_az ? d_az + (int64_t)b0 * az_stride : nullptr;
     int *cn = d_counts ? d_counts + b0 : nullptr;
     // <= 4096 bins: 512 threads x 8 bins (about 100 VGPRs: four waves per SIMD; 256 x 16 needs 176: two); wider rows: 1024 x 16
-    // (a Navtech CIR row has 3360 bins = 420 threads: with 448 the eighth wave of the 512-thread block, which would execute
-    // every instruction of the row passes with all lanes off, does not exist)
-    if (cols <= 8 * 448)
+    // (a Navtech CIR row has 3360 bins = 420 threads.  448 threads -- no eighth wave that executes the row passes with all
+    // lanes off -- measured SLOWER: 54.2 k against 57.4 k scans/s batched, seven waves do not spread evenly over four SIMDs;
+    // 256 threads x 16 bins: 43 k.  tools/ab_cen.py, experiments build.)
+    static const int cfg = [] { const char *e = rsx::exp_env("RSX_CEN_CFG"); return e ? atoi(e) : 0; }();
+    if (cfg == 1 && cols <= 16 * 256)
+      launch_chain<16, 256>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
+    else if (cfg == 2 && cols <= 8 * 448)
       launch_chain<8, 448>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     else if (cols <= 8 * 512)
-      launch_chain<8, 512>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
+      launch_chain<8, 512>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s, cfg >> 4);
     else
       launch_chain<16, 1024>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     RSX_HIP(hipGetLastError());
