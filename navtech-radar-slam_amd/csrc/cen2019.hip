@@ -78,21 +78,25 @@ __device__ __forceinline__ float mean_h_of(long long fix_sum, int64_t n) { retur
 // candidates are the pixels with h > mean_h  <=>  key < kmean
 __device__ __forceinline__ unsigned long long kmean_of(float mh) { return (unsigned long long)(~ord_f32(canon0(mh))) << 32; }
 
-// one block per (azimuth, image): byte sum and largest range gradient of the row, 16 bins per thread from aligned dwords
-// (round 3, first build: one byte per lane and iteration, 0.6 TB/s)
+// one block per (azimuth, image): byte sum and largest range gradient of the row, C bins per thread from aligned dwords
+// (round 3, first build: one byte per lane and iteration, 0.6 TB/s).
+// Round 4: the gradient maximum in the INTEGER domain.  g(p) = |t[b(p+1)] - t[b(p-1)]| with t[x] = fl(x / 255): t is increasing
+// with steps of 1/255 +- 2^-24, the subtraction adds at most another 2^-24, so a pair of bytes d apart gives g within 1.8e-7 of
+// d / 255 and a pair with a larger byte difference ALWAYS gives the larger g (1 / 255 = 3.9e-3 apart).  The largest g of the
+// image is therefore reached at a pixel with the largest |b(p+1) - b(p-1)|: every thread keeps the integer maximum of its
+// pixels, a wave agrees on its maximum D, and only the pixels that reach D (a handful per wave) form their float g -- with the
+// same two correctly rounded divisions and the same subtraction the byte -> float table of the other passes holds.  Before:
+// a 256-entry division table per block (and its barrier) and two LDS look-ups, a subtraction and a maximum for EVERY pixel.
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
                                                 int off, Scal *scal) {
   static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
   constexpr int NWD = C / 4 + 2;
-  __shared__ float s_tab[256];
-  __shared__ unsigned long long s_sum[NT / 64];
+  __shared__ unsigned s_sum[NT / 64];
   __shared__ float s_max[NT / 64];
   const int a = blockIdx.x;
   Scal *sc = scal + blockIdx.y;
   const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
-  if (threadIdx.x < 256) s_tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
-  __syncthreads();
   const int p0 = threadIdx.x * C;
   unsigned w[NWD];
 #pragma unroll
@@ -113,23 +117,41 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
     const unsigned v = __builtin_amdgcn_alignbyte(w[jw + 1 < NWD ? jw + 1 : NWD - 1], w[jw], mis);
     bt[i + 1] = (v >> (8 * ((i + 4) & 3))) & 0xffu;
   }
-  unsigned long long sb = 0;
-  float mg = 0.0f;
+  unsigned sb = 0;  // <= C * 255
+  int dmax = -1;
+  int dd[C];
 #pragma unroll
   for (int i = 0; i < C; i++) {
     const int p = p0 + i;
+    dd[i] = -1;
     if (p < cols) {
       sb += bt[i + 1];
       if (cols > 1) {
-        const unsigned bp = (p + 1 < cols) ? bt[i + 2] : bt[i], bm = (p >= 1) ? bt[i] : bt[i + 2];  // reflect 101
-        mg = fmaxf(mg, fabsf(__fsub_rn(s_tab[bp], s_tab[bm])));
+        const int bp = (int)((p + 1 < cols) ? bt[i + 2] : bt[i]), bm = (int)((p >= 1) ? bt[i] : bt[i + 2]);  // reflect 101
+        const int d = bp > bm ? bp - bm : bm - bp;
+        dd[i] = d;
+        dmax = d > dmax ? d : dmax;
       }
     }
   }
+  int dw = dmax;
   for (int o = 32; o >= 1; o >>= 1) {
+    const int v = __shfl_xor(dw, o);
+    dw = v > dw ? v : dw;
     sb += __shfl_xor(sb, o);
-    mg = fmaxf(mg, __shfl_xor(mg, o));
   }
+  float mg = 0.0f;
+  if (dw >= 0 && dmax == dw) {  // (rare lanes)
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      if (dd[i] == dw) {
+        const int p = p0 + i;
+        const unsigned bp = (p + 1 < cols) ? bt[i + 2] : bt[i], bm = (p >= 1) ? bt[i] : bt[i + 2];
+        mg = fmaxf(mg, fabsf(__fsub_rn(__fdiv_rn((float)bp, 255.0f), __fdiv_rn((float)bm, 255.0f))));
+      }
+    }
+  }
+  for (int o = 32; o >= 1; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
   if ((threadIdx.x & 63) == 0) {
     s_sum[threadIdx.x >> 6] = sb;
     s_max[threadIdx.x >> 6] = mg;
@@ -408,9 +430,7 @@ __device__ __forceinline__ int h_bin(float hv) {  // monotone non-decreasing in 
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
                                                Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ marker,
-                                               unsigned short *__restrict__ opener, int dbg) {
-  // dbg (experiments builds, tools/ab_cen.py; results are then wrong, only the time means something): 1 = stop after the row
-  // evaluation, 2 = no marker / opener stores, 4 = no histogram and no fixed-point sum
+                                               unsigned short *__restrict__ opener) {
   __shared__ RowLds<C, NT> L;
   __shared__ unsigned s_hist[NBIN];
   __shared__ long long s_fix[NT / 64];
@@ -423,9 +443,8 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
   for (int b = threadIdx.x; b < NBIN; b += NT) s_hist[b] = 0;
   RowRegs<C, NT> R;
   row_eval(L, row, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
-  if (dbg & 1) return;
   const unsigned opens = row_opens(L, R, cols);
-  if (!(dbg & 2)) {
+  {
     // what the later passes need of this evaluation, so that the segmented scans run ONCE per row: for every pixel the
     // range bin of the pixel whose key is its mark key (16 bits; rows padded to C * NT), and the opener bits of the thread
     unsigned mw[C / 2];
@@ -440,16 +459,25 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
     for (int j = 0; j < C / 8; j++) mdst[j] = uint4{mw[4 * j], mw[4 * j + 1], mw[4 * j + 2], mw[4 * j + 3]};
     opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
   }
-  if (dbg & 4) return;
-  long long fix = 0;
+  // sum of llrint(h * 2^40) over the row without 64-bit conversions: x = h * 2^20 (exact), hi = rint(x), x - hi is exact and at
+  // most 1/2, lo = rint((x - hi) * 2^20); hi * 2^20 is an even integer, so rint(h * 2^40) = hi * 2^20 + lo (== fix40(h), the
+  // emulated 64-bit form this replaces).  A wave's sums of hi and lo stay below 2^29 and 2^28.
+  int fhi = 0, flo = 0;
 #pragma unroll
   for (int i = 0; i < C; i++) {
     if (threadIdx.x * C + i < cols) {
-      fix += fix40(R.h[i]);
+      const float x = R.h[i] * 1048576.0f;
+      const float xr = rintf(x);
+      fhi += (int)xr;
+      flo += __float2int_rn(__fsub_rn(x, xr) * 1048576.0f);
       if ((opens >> i) & 1u) atomicAdd(&s_hist[h_bin(R.h[i])], 1u);
     }
   }
-  for (int o = 32; o >= 1; o >>= 1) fix += __shfl_xor(fix, o);
+  for (int o = 32; o >= 1; o >>= 1) {
+    fhi += __shfl_xor(fhi, o);
+    flo += __shfl_xor(flo, o);
+  }
+  const long long fix = ((long long)fhi << 20) + (long long)flo;
   if ((threadIdx.x & 63) == 0) s_fix[threadIdx.x >> 6] = fix;
   __syncthreads();
   for (int b = threadIdx.x; b < NBIN; b += NT)
@@ -829,13 +857,13 @@ namespace {
 template <int C, int NT>
 void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int nb, int32_t stride, int32_t off, const rsx_cen2019_params &p,
                   const float *d_az, int64_t az_stride, float resolution, int32_t max_targets, int *d_targets, float *d_xy, int *d_counts,
-                  int row_cap, hipStream_t s, int dbg = 0) {
+                  int row_cap, hipStream_t s) {
   const int rows = h->rows, cols = h->cols;
   Scal *sc = h->scal.as<Scal>();
   const dim3 grid((unsigned)rows, (unsigned)nb);
   hipLaunchKernelGGL((cen_stats<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
   hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>(),
-                     h->marker.as<unsigned short>(), h->opener.as<unsigned short>(), dbg);
+                     h->marker.as<unsigned short>(), h->opener.as<unsigned short>());
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
   hipLaunchKernelGGL((cen_collect<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
                      h->list.as<unsigned long long>(), (int64_t)rows * cols);
@@ -881,14 +909,16 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     // <= 4096 bins: 512 threads x 8 bins (about 100 VGPRs: four waves per SIMD; 256 x 16 needs 176: two); wider rows: 1024 x 16
     // (a Navtech CIR row has 3360 bins = 420 threads.  448 threads -- no eighth wave that executes the row passes with all
     // lanes off -- measured SLOWER: 54.2 k against 57.4 k scans/s batched, seven waves do not spread evenly over four SIMDs;
-    // 256 threads x 16 bins: 43 k.  tools/ab_cen.py, experiments build.)
+    // 256 threads x 16 bins: 43 k.  tools/ab_cen.py, experiments build.  The timing exits that took cen_hist apart for DESIGN.md
+    // -- `if (dbg & 1) return;` in front of its barriers -- made the 1024-thread instantiation sum garbage even with dbg = 0
+    // (tests/test_gpu_cen2019.py::test_wide_rows caught it) and are gone again.)
     static const int cfg = [] { const char *e = rsx::exp_env("RSX_CEN_CFG"); return e ? atoi(e) : 0; }();
     if (cfg == 1 && cols <= 16 * 256)
       launch_chain<16, 256>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     else if (cfg == 2 && cols <= 8 * 448)
       launch_chain<8, 448>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     else if (cols <= 8 * 512)
-      launch_chain<8, 512>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s, cfg >> 4);
+      launch_chain<8, 512>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     else
       launch_chain<16, 1024>(h, im, img_stride, n, stride, off, p, azp, az_stride, resolution, max_targets, tg, pxy, cn, row_cap, s);
     RSX_HIP(hipGetLastError());
@@ -1066,5 +1096,15 @@ int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, 
   return rsx_cen2019_extract_batch(h, img, 1, (int64_t)h->rows * row_stride, row_stride, col_offset, params, azimuths, 0, resolution, out_targets,
                                    out_xy, max_targets, out_count);
 } RSX_CATCH_ALL
+
+#ifdef RSX_EXPERIMENTS
+// experiments builds only (tools/): the per-image scalars of the LAST extraction (sum of bytes, largest gradient, ...)
+int rsx_cen2019_debug_scal(rsx_cen2019 *h, void *out64) {
+  if (!h || !out64 || !h->scal.p) return RSX_ERR_BAD_ARG;
+  (void)hipSetDevice(h->device);
+  (void)hipStreamSynchronize(h->stream);
+  return hipMemcpy(out64, h->scal.p, 64, hipMemcpyDeviceToHost) == hipSuccess ? RSX_OK : RSX_ERR_HIP;
+}
+#endif
 
 }  // extern "C"
