@@ -87,6 +87,7 @@ __device__ __forceinline__ unsigned long long kmean_of(float mh) { return (unsig
 // pixels, a wave agrees on its maximum D, and only the pixels that reach D (a handful per wave) form their float g -- with the
 // same two correctly rounded divisions and the same subtraction the byte -> float table of the other passes holds.  Before:
 // a 256-entry division table per block (and its barrier) and two LDS look-ups, a subtraction and a maximum for EVERY pixel.
+constexpr int ST_ROWS = 8;  // azimuths per block of cen_stats
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
                                                 int off, Scal *scal) {
@@ -94,63 +95,67 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
   constexpr int NWD = C / 4 + 2;
   __shared__ unsigned s_sum[NT / 64];
   __shared__ float s_max[NT / 64];
-  const int a = blockIdx.x;
   Scal *sc = scal + blockIdx.y;
-  const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
   const int p0 = threadIdx.x * C;
-  unsigned w[NWD];
-#pragma unroll
-  for (int j = 0; j < NWD; j++) w[j] = 0u;
-  const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
-  const unsigned mis = (unsigned)(addr & 3u);
-  const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
-  if (p0 < cols) {
-    if (p0 > 0) w[0] = wp[-1];
-#pragma unroll
-    for (int j = 0; j < NWD - 1; j++)
-      if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
-  }
-  unsigned bt[C + 2];
-#pragma unroll
-  for (int i = -1; i <= C; i++) {
-    const int jw = (i + 4) >> 2;
-    const unsigned v = __builtin_amdgcn_alignbyte(w[jw + 1 < NWD ? jw + 1 : NWD - 1], w[jw], mis);
-    bt[i + 1] = (v >> (8 * ((i + 4) & 3))) & 0xffu;
-  }
-  unsigned sb = 0;  // <= C * 255
-  int dmax = -1;
-  int dd[C];
-#pragma unroll
-  for (int i = 0; i < C; i++) {
-    const int p = p0 + i;
-    dd[i] = -1;
-    if (p < cols) {
-      sb += bt[i + 1];
-      if (cols > 1) {
-        const int bp = (int)((p + 1 < cols) ? bt[i + 2] : bt[i]), bm = (int)((p >= 1) ? bt[i] : bt[i + 2]);  // reflect 101
-        const int d = bp > bm ? bp - bm : bm - bp;
-        dd[i] = d;
-        dmax = d > dmax ? d : dmax;
-      }
-    }
-  }
-  int dw = dmax;
-  for (int o = 32; o >= 1; o >>= 1) {
-    const int v = __shfl_xor(dw, o);
-    dw = v > dw ? v : dw;
-    sb += __shfl_xor(sb, o);
-  }
+  unsigned sb = 0;  // <= ST_ROWS * C * 255 per thread, a wave's sum stays far below 2^32
   float mg = 0.0f;
-  if (dw >= 0 && dmax == dw) {  // (rare lanes)
+  // ST_ROWS azimuths per block: a row is 3360 bytes, a block per row was mostly block start-up
+  for (int rr = 0; rr < ST_ROWS; rr++) {
+    const int a = blockIdx.x * ST_ROWS + rr;
+    if (a >= rows) break;  // (uniform)
+    const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
+    unsigned w[NWD];
+#pragma unroll
+    for (int j = 0; j < NWD; j++) w[j] = 0u;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
+    const unsigned mis = (unsigned)(addr & 3u);
+    const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
+    if (p0 < cols) {
+      if (p0 > 0) w[0] = wp[-1];
+#pragma unroll
+      for (int j = 0; j < NWD - 1; j++)
+        if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
+    }
+    unsigned bt[C + 2];
+#pragma unroll
+    for (int i = -1; i <= C; i++) {
+      const int jw = (i + 4) >> 2;
+      const unsigned v = __builtin_amdgcn_alignbyte(w[jw + 1 < NWD ? jw + 1 : NWD - 1], w[jw], mis);
+      bt[i + 1] = (v >> (8 * ((i + 4) & 3))) & 0xffu;
+    }
+    int dmax = -1;
+    int dd[C];
 #pragma unroll
     for (int i = 0; i < C; i++) {
-      if (dd[i] == dw) {
-        const int p = p0 + i;
-        const unsigned bp = (p + 1 < cols) ? bt[i + 2] : bt[i], bm = (p >= 1) ? bt[i] : bt[i + 2];
-        mg = fmaxf(mg, fabsf(__fsub_rn(__fdiv_rn((float)bp, 255.0f), __fdiv_rn((float)bm, 255.0f))));
+      const int p = p0 + i;
+      dd[i] = -1;
+      if (p < cols) {
+        sb += bt[i + 1];
+        if (cols > 1) {
+          const int bp = (int)((p + 1 < cols) ? bt[i + 2] : bt[i]), bm = (int)((p >= 1) ? bt[i] : bt[i + 2]);  // reflect 101
+          const int d = bp > bm ? bp - bm : bm - bp;
+          dd[i] = d;
+          dmax = d > dmax ? d : dmax;
+        }
+      }
+    }
+    int dw = dmax;
+    for (int o = 32; o >= 1; o >>= 1) {
+      const int v = __shfl_xor(dw, o);
+      dw = v > dw ? v : dw;
+    }
+    if (dw >= 0 && dmax == dw) {  // (rare lanes)
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        if (dd[i] == dw) {
+          const int p = p0 + i;
+          const unsigned bp = (p + 1 < cols) ? bt[i + 2] : bt[i], bm = (p >= 1) ? bt[i] : bt[i + 2];
+          mg = fmaxf(mg, fabsf(__fsub_rn(__fdiv_rn((float)bp, 255.0f), __fdiv_rn((float)bm, 255.0f))));
+        }
       }
     }
   }
+  for (int o = 32; o >= 1; o >>= 1) sb += __shfl_xor(sb, o);
   for (int o = 32; o >= 1; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
   if ((threadIdx.x & 63) == 0) {
     s_sum[threadIdx.x >> 6] = sb;
@@ -541,39 +546,43 @@ __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ im
                                                   int off, Scal *scal, const unsigned short *__restrict__ opener,
                                                   unsigned long long *__restrict__ lists, int64_t list_stride) {
   __shared__ RowLds<C, NT> L;
-  const int a = blockIdx.x;
   Scal *sc = scal + blockIdx.y;
   unsigned long long *list = lists + (int64_t)blockIdx.y * list_stride;
   const int bstar = sc->bstar;
-  if (bstar < 0) return;  // fewer openers than the budget: nothing to select
-  const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
+  if (bstar < 0) return;  // fewer openers than the budget: nothing to select (uniform, before any barrier)
   const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
   row_table(L);
   __syncthreads();
-  float h[C];
-  unsigned neg;
-  row_load_h(L, row, cols, mean, maxg, h, neg);
-  const unsigned opens = opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x];  // from cen_hist: no scans here
-  unsigned sel = 0;
-#pragma unroll
-  for (int i = 0; i < C; i++)
-    if (((opens >> i) & 1u) && h_bin(h[i]) == bstar) sel |= 1u << i;
-  // one atomic per wavefront
-  const unsigned cnt = (unsigned)__popc(sel);
-  unsigned incl = cnt;
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned o = __shfl_up(incl, d);
-    if ((threadIdx.x & 63) >= d) incl += o;
-  }
-  const unsigned wave_total = __shfl(incl, 63);
-  unsigned base = 0;
-  if (wave_total) {
-    if ((threadIdx.x & 63) == 63) base = atomicAdd(&sc->n_list, wave_total);
-    base = __shfl(base, 63);
-    unsigned pos = base + incl - cnt;
+  // ST_ROWS azimuths per block (no barrier inside a row's work): one table and one block start-up for eight rows
+  for (int rr = 0; rr < ST_ROWS; rr++) {
+    const int a = blockIdx.x * ST_ROWS + rr;
+    if (a >= rows) break;
+    const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
+    float h[C];
+    unsigned neg;
+    row_load_h(L, row, cols, mean, maxg, h, neg);
+    const unsigned opens = opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x];  // from cen_hist: no scans here
+    unsigned sel = 0;
 #pragma unroll
     for (int i = 0; i < C; i++)
-      if ((sel >> i) & 1u) list[pos++] = key_of(h[i], (unsigned)a * (unsigned)cols + (unsigned)(threadIdx.x * C + i));
+      if (((opens >> i) & 1u) && h_bin(h[i]) == bstar) sel |= 1u << i;
+    // one atomic per wavefront
+    const unsigned cnt = (unsigned)__popc(sel);
+    unsigned incl = cnt;
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o = __shfl_up(incl, d);
+      if ((threadIdx.x & 63) >= d) incl += o;
+    }
+    const unsigned wave_total = __shfl(incl, 63);
+    unsigned base = 0;
+    if (wave_total) {
+      if ((threadIdx.x & 63) == 63) base = atomicAdd(&sc->n_list, wave_total);
+      base = __shfl(base, 63);
+      unsigned pos = base + incl - cnt;
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        if ((sel >> i) & 1u) list[pos++] = key_of(h[i], (unsigned)a * (unsigned)cols + (unsigned)(threadIdx.x * C + i));
+    }
   }
 }
 
@@ -861,11 +870,12 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   const int rows = h->rows, cols = h->cols;
   Scal *sc = h->scal.as<Scal>();
   const dim3 grid((unsigned)rows, (unsigned)nb);
-  hipLaunchKernelGGL((cen_stats<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
+  hipLaunchKernelGGL((cen_stats<C, NT>), dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows,
+                     cols, stride, off, sc);
   hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>(),
                      h->marker.as<unsigned short>(), h->opener.as<unsigned short>());
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
-  hipLaunchKernelGGL((cen_collect<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
+  hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
                      h->list.as<unsigned long long>(), (int64_t)rows * cols);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
