@@ -87,10 +87,10 @@ __device__ __forceinline__ unsigned long long kmean_of(float mh) { return (unsig
 // pixels, a wave agrees on its maximum D, and only the pixels that reach D (a handful per wave) form their float g -- with the
 // same two correctly rounded divisions and the same subtraction the byte -> float table of the other passes holds.  Before:
 // a 256-entry division table per block (and its barrier) and two LDS look-ups, a subtraction and a maximum for EVERY pixel.
-constexpr int ST_ROWS = 8;  // azimuths per block of cen_stats
+constexpr int ST_ROWS = 8;  // azimuths per block of cen_stats / cen_collect in a batch (a single scan keeps one per block: 400 blocks fill the chip, 50 would not)
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
-                                                int off, Scal *scal) {
+                                                int off, Scal *scal, int rpb) {
   static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
   constexpr int NWD = C / 4 + 2;
   __shared__ unsigned s_sum[NT / 64];
@@ -99,9 +99,9 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
   const int p0 = threadIdx.x * C;
   unsigned sb = 0;  // <= ST_ROWS * C * 255 per thread, a wave's sum stays far below 2^32
   float mg = 0.0f;
-  // ST_ROWS azimuths per block: a row is 3360 bytes, a block per row was mostly block start-up
-  for (int rr = 0; rr < ST_ROWS; rr++) {
-    const int a = blockIdx.x * ST_ROWS + rr;
+  // rpb azimuths per block: a row is 3360 bytes, a block per row was mostly block start-up
+  for (int rr = 0; rr < rpb; rr++) {
+    const int a = blockIdx.x * rpb + rr;
     if (a >= rows) break;  // (uniform)
     const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
     unsigned w[NWD];
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(256) void cen_pick(Scal *scal, const unsigned *__re
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
                                                   int off, Scal *scal, const unsigned short *__restrict__ opener,
-                                                  unsigned long long *__restrict__ lists, int64_t list_stride) {
+                                                  unsigned long long *__restrict__ lists, int64_t list_stride, int rpb) {
   __shared__ RowLds<C, NT> L;
   Scal *sc = scal + blockIdx.y;
   unsigned long long *list = lists + (int64_t)blockIdx.y * list_stride;
@@ -553,9 +553,9 @@ __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ im
   const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
   row_table(L);
   __syncthreads();
-  // ST_ROWS azimuths per block (no barrier inside a row's work): one table and one block start-up for eight rows
-  for (int rr = 0; rr < ST_ROWS; rr++) {
-    const int a = blockIdx.x * ST_ROWS + rr;
+  // rpb azimuths per block (no barrier inside a row's work): one table and one block start-up for eight rows of a batch
+  for (int rr = 0; rr < rpb; rr++) {
+    const int a = blockIdx.x * rpb + rr;
     if (a >= rows) break;
     const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
     float h[C];
@@ -870,13 +870,14 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   const int rows = h->rows, cols = h->cols;
   Scal *sc = h->scal.as<Scal>();
   const dim3 grid((unsigned)rows, (unsigned)nb);
-  hipLaunchKernelGGL((cen_stats<C, NT>), dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows,
-                     cols, stride, off, sc);
+  const int rpb = (int64_t)rows * nb >= 8192 ? ST_ROWS : 1;
+  hipLaunchKernelGGL((cen_stats<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
+                     stride, off, sc, rpb);
   hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>(),
                      h->marker.as<unsigned short>(), h->opener.as<unsigned short>());
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
-  hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + ST_ROWS - 1) / ST_ROWS), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
-                     h->list.as<unsigned long long>(), (int64_t)rows * cols);
+  hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
+                     h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
   hipLaunchKernelGGL((cen_runs<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->marker.as<unsigned short>(),
