@@ -1110,12 +1110,12 @@ int rsx_cen2019_extract(rsx_cen2019 *h, const uint8_t *img, int32_t row_stride, 
 
 #ifdef RSX_EXPERIMENTS
 // experiments builds only (tools/): the per-image scalars of the LAST extraction (sum of bytes, largest gradient, ...)
-int rsx_cen2019_debug_scal(rsx_cen2019 *h, void *out64) {
+int rsx_cen2019_debug_scal(rsx_cen2019 *h, void *out64) try {
   if (!h || !out64 || !h->scal.p) return RSX_ERR_BAD_ARG;
   (void)hipSetDevice(h->device);
   (void)hipStreamSynchronize(h->stream);
   return hipMemcpy(out64, h->scal.p, 64, hipMemcpyDeviceToHost) == hipSuccess ? RSX_OK : RSX_ERR_HIP;
-}
+} RSX_CATCH_ALL
 #endif
 
 }  // extern "C"
