@@ -210,7 +210,7 @@ def _worker_filter_shards(rank, world, port, ret):
         assert ld_r % 32 == 0 and sum(c for _, c in rng) == n and all(f % 32 == 0 for f, _ in rng)
         full = po.Manager()
         full.add_descriptors(descs.astype(np.float64))
-        for n_elig in (-1, n - 30, 33, 1):                            # 33 entries: the last ranks' ranges are empty
+        for n_elig in (-1, n - 30, 33, 1, 0):                         # 33 entries: the last ranks' ranges are empty; 0: nothing eligible
             for qs in (queries, queries[:1]):                         # 1 query over 2-3 ranks: ranks with an empty slice
                 got = sc.query(qs, k=k, n_eligible=n_elig)
                 for i in range(len(qs)):

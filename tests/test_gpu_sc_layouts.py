@@ -28,7 +28,7 @@ def _workload(n=2003, nq=67):
 
 
 @pytest.mark.parametrize("world", [2, 8])
-@pytest.mark.parametrize("n_elig", [-1, 1973, 40])
+@pytest.mark.parametrize("n_elig", [-1, 1973, 40, 0])
 def test_filter_shards_emulated_on_one_gpu(world, n_elig):
     """what the ranks of sharded.FilterShardedScanContext execute, one after the other on this GPU: rank r's range filter for
     all queries into column block r, then every rank's slice through rsx_sc_query_bounds_device; 40 eligible entries leave
@@ -100,7 +100,7 @@ def _worker(rank, world, port, ret):
             assert lay.on_gpu and lay._staged
             lay.add_descriptors_f32(descs[:1500])
             lay.add_descriptors_f32(descs[1500:])
-            for n_elig in (-1, n - 30, 40):
+            for n_elig in (-1, n - 30, 40, 0):
                 want = full.query(queries, k=k, n_eligible=n_elig)
                 got = lay.query(queries, k=k, n_eligible=n_elig)
                 assert np.array_equal(got, want), (rank, lay.layout, n_elig)
