@@ -1280,6 +1280,17 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
     const char *e = rsx::exp_env("RSX_SC_HOST_LANES");
     return !(e && e[0] == '1');
   }();
+  const size_t out_bytes = (size_t)nq * k * sizeof(rsx_sc_hit);
+  if (np == 1 && out_bytes <= 4096) {
+    // the live detector's size (one query, a few records): the last kernel writes the records straight into pinned host
+    // memory -- no read-back to enqueue, one synchronise
+    RSX_TRY(ensure_pinned(h, 4096));
+    RSX_HIP(hipMemcpyAsync(h->q_desc.p, q, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    RSX_TRY(query_device_locked(h, h->q_desc.as<float>(), nq, k, n_eligible, static_cast<rsx_sc_hit *>(h->pinned), h->stream));
+    RSX_HIP(hipStreamSynchronize(h->stream));
+    std::memcpy(out, h->pinned, out_bytes);
+    return RSX_OK;
+  }
   if (np == 1) {
     RSX_HIP(hipMemcpyAsync(h->q_desc.p, q, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, h->stream));
     RSX_TRY(query_device_locked(h, h->q_desc.as<float>(), nq, k, n_eligible, h->topk.as<rsx_sc_hit>(), h->stream));
