@@ -940,9 +940,9 @@ def host_entry_leg(mgr, q_descs, n_elig, k, resident_ms, reps=20):
         pq.a[:] = q_descs.reshape(nq, 1200)
         dt_pinned = timed(pq.a, po.a)
         same = bool(np.array_equal(po.a, ref))
-    return {"ms_per_step": dt_pinned * 1e3, "queries_per_sec": nq / dt_pinned, "memory": "pinned (rsx_host_alloc_pinned)",
-            "pageable": {"ms_per_step": dt_pageable * 1e3, "queries_per_sec": nq / dt_pageable},
-            "vs_resident": resident_ms / (dt_pinned * 1e3), "pageable_vs_resident": resident_ms / (dt_pageable * 1e3),
+    return {"ms_per_step": dt_pageable * 1e3, "queries_per_sec": nq / dt_pageable, "memory": "pageable (what a caller with a plain buffer gets)",
+            "pinned": {"ms_per_step": dt_pinned * 1e3, "queries_per_sec": nq / dt_pinned, "memory": "rsx_host_alloc_pinned"},
+            "vs_resident": resident_ms / (dt_pageable * 1e3), "pinned_vs_resident": resident_ms / (dt_pinned * 1e3),
             "pinned_identical_to_pageable": same,
             "h2d_bytes": int(q_descs.nbytes), "d2h_bytes": nq * k * 16,
             "note": "rsx_sc_query: H2D of the queries in pieces, each scored (filter/select/re-score) while the next one goes up, + D2H "
