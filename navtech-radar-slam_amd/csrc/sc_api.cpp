@@ -12,6 +12,7 @@
 
 #include "rsx_common.h"
 #include "sc_kernels.h"
+#include "sc_plan.h"
 #include "sc_kdtree.h"
 #include "loopverify.h"
 #include "voxelgrid.h"
@@ -302,15 +303,7 @@ int run_filter(rsx_sc *h, const QueryView &q, int64_t n_items, lb_t *lb, int64_t
 
 // query batch size the filter workspaces are sized for: <= 1 GiB of (fp16) bounds, and the batches of a call equally long
 // (8192 queries against 100 000 entries used to run as 3 x 2684 + 140: the last launch chain at a fraction of the rate)
-int64_t filter_batch(int64_t n_items, int64_t nq) {
-  const int64_t ld = (n_items + 31) / 32 * 32;
-  int64_t qb = (1ll << 29) / ld;
-  if (qb < 64) qb = 64;
-  if (qb >= nq) return nq;
-  const int64_t nb = (nq + qb - 1) / qb;
-  const int64_t even = ((nq + nb - 1) / nb + 63) / 64 * 64;
-  return even < qb ? even : qb;
-}
+int64_t filter_batch(int64_t n_items, int64_t nq) { return plan::filter_batch(n_items, nq); }  // sc_plan.h
 
 int filter_reserve(rsx_sc *h, int64_t n_items, int64_t qb, hipStream_t s) {
   h->st.valid = false;  // bounds / short lists of a pending stage 2 are about to be overwritten
@@ -1237,33 +1230,17 @@ int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int6
 // 3.04 / 0.89, 256:4.0 3.01-3.10; on ONE stream 1024:2.5 is 3.20 / 0.85.  Batches below 4 pieces' worth stay whole.
 // RSX_SC_HOST_PIECES=first[:growth_x10] (experiments build) overrides; first = 0 keeps every batch whole.
 int host_pieces(int32_t nq, int32_t *sizes) {
-  static const std::pair<int, int> plan = [] {
+  static const std::pair<int, int> cfg = [] {
     const char *e = rsx::exp_env("RSX_SC_HOST_PIECES");
     std::pair<int, int> r{1024, 25};
     if (e && *e) {
       r.first = atoi(e);
       const char *c = strchr(e, ':');
       if (c) r.second = atoi(c + 1);
-      if (r.second < 10) r.second = 10;
     }
     return r;
   }();
-  if (plan.first <= 0 || nq < 4 * plan.first) {
-    sizes[0] = nq;
-    return 1;
-  }
-  int n = 0;
-  int32_t left = nq;
-  double want = plan.first;
-  while (left > 0) {
-    int32_t take = ((int32_t)want + 63) / 64 * 64;
-    // the last slot takes what is left; a remainder smaller than half a piece joins the piece before it
-    if (n == rsx_sc::kMaxPieces - 1 || left - take < take / 2) take = left;
-    sizes[n++] = take;
-    left -= take;
-    want *= plan.second / 10.0;
-  }
-  return n;
+  return plan::host_pieces(nq, cfg.first, cfg.second, rsx_sc::kMaxPieces, sizes);  // sc_plan.h
 }
 
 int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *out) try {

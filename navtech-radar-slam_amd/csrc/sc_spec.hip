@@ -69,6 +69,7 @@
 #include "rsx_common.h"
 #include "sc_kernels.h"
 #include "sc_entry_dev.h"
+#include "sc_plan.h"
 
 namespace rsx {
 namespace sc {
@@ -1801,31 +1802,14 @@ int launch_spec_filter(const DbView &db, const void *qimg, int32_t nq, int64_t n
         const char *e = rsx::exp_env("RSX_SPEC_XCD");
         return !(e && e[0] == '0');
       }();
-      const int64_t nqt_x = (nqt + 7) / 8;
-      if (xcd_on && !tb_cum && nqt_x >= 16 && n_cu % 8 == 0) {
-        int64_t best_s = 1;
-        double best_cost = 1e300;
-        const int64_t slots = n_cu / 8;
-        for (int64_t S = 1; S <= 64 && (S == 1 || (nqt_x + S - 1) / S >= 16); S++) {
-          const int64_t len = (nqt_x + S - 1) / S, used = (nqt_x + len - 1) / len;
-          const int64_t cost = ((used * ntb + slots - 1) / slots) * (len + 3);
-          if ((double)cost < best_cost * 0.995) {
-            best_cost = (double)cost;
-            best_s = used;
-          }
-        }
-        if (const char *e = rsx::exp_env("RSX_SPEC_XCD_S")) {
-          const int64_t v = atoll(e);
-          if (v >= 1 && v <= nqt_x) best_s = v;
-        }
-        // against the contiguous split (perfectly balanced, one start per workgroup): only where whole rounds cost <= 6 %
-        // -- large batches; a 1024-query batch against 10 000 entries would lose 17 %
-        const double contiguous = (double)(ntb * nqt) / (double)n_cu + 3.0;
-        if (best_cost <= 1.06 * contiguous || rsx::exp_env("RSX_SPEC_XCD_S")) {
-          a.xcd_nqt = (int32_t)nqt_x;
-          a.xcd_len = (int32_t)((nqt_x + best_s - 1) / best_s);
-          const int64_t used = (nqt_x + a.xcd_len - 1) / a.xcd_len;
-          grid = (unsigned)(8 * used * ntb);
+      if (xcd_on && !tb_cum) {
+        int64_t forced = 0;
+        if (const char *e = rsx::exp_env("RSX_SPEC_XCD_S")) forced = atoll(e);
+        const plan::XcdSplit sp = plan::xcd_split(nqt, ntb, n_cu, forced);  // sc_plan.h
+        if (sp.on) {
+          a.xcd_nqt = sp.nqt_x;
+          a.xcd_len = sp.len;
+          grid = sp.grid;
         }
       }
     }
