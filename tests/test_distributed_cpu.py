@@ -93,6 +93,11 @@ def _worker(rank, world, port, ret, query_groups=1):
         for j, i in enumerate(sub):
             want = full.exhaustive(descs[i].astype(np.float64), n_eligible=int(lim[j]), k=3)
             assert np.array_equal(got[j], want), (rank, i, got[j], want)
+        n_sub = len(sc._subgroups)
+        assert n_sub == (query_groups + world // query_groups if 1 < query_groups < world else 0)
+        sc.close()                                             # collective: destroys the sub-communicators it created
+        assert sc._subgroups == []
+        dist.barrier()                                         # the default group is still alive
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()
