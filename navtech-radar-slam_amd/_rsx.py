@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("RSX_LIB_PATH") or os.path.join(_HERE, "librsx.so")  #
 
 NUM_RING, NUM_SECTOR, DESC_SIZE, MAX_TOPK = 20, 60, 1200, 32
 MODE_CANDIDATE, MODE_EXHAUSTIVE = 0, 1
-FILTER_AUTO, FILTER_OFF, FILTER_FORCE = 0, 1, 2
+FILTER_AUTO, FILTER_OFF, FILTER_FORCE, FILTER_Q1 = 0, 1, 2, 3   # rsx_sc_params.filter_mode
 KIND_AUTO, KIND_DIRECT, KIND_SPECTRAL, KIND_SPECTRAL2 = 0, 1, 2, 3
 default_filter_kind = KIND_AUTO   # what SCManager(filter_kind=KIND_AUTO) passes on (tests flip it to cover both forms)
 

@@ -73,6 +73,10 @@ struct rsx_sc {
     QueryView qv{};
   } st;
   DevBuf st_partial;  // this shard's stage-1 hits
+  // the one-launch single-query path (sc_q1.hip): candidate records / bound lists of the workgroups, and the arrival
+  // counters (never reset: q1_host_ticket[] holds what they read once everything enqueued so far has run)
+  DevBuf q1_ws, q1_ticket;
+  unsigned q1_host_ticket[Q1_MAX_NQ] = {};
   DevBuf helper_ws;   // staging of the stateless helper calls (Scancontext.h:60-66)
   DevBuf stats;       // profiling only: RESCORE_STAT_COPIES blocks of counters (sc_kernels.h), summed by the host when read
   void *pinned = nullptr;  // small pinned host staging (results)
@@ -223,7 +227,7 @@ int filter_mode_of(const rsx_sc *h) {
 }
 
 bool use_filter(const rsx_sc *h, int32_t nq, int64_t n_items) {
-  const int m = filter_mode_of(h);
+  const int m = filter_mode_of(h);  // (3 = the single-query path where it applies: like auto for everything else)
   if (m == 1 || n_items <= 0) return false;
   if (m == 2) return true;
   // the filter amortises a 300-register DB tile load over the queries of a block and costs five
@@ -406,8 +410,39 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
   return RSX_OK;
 }
 
+// a handful of queries (the live detector asks one at a time, PGO.cpp:561,577): ONE launch that streams the fp16 images of
+// every eligible entry once, previews every pair on the matrix cores and scores the few entries the previews cannot exclude
+// exactly (sc_q1.hip) -- instead of the exact-all kernel (one entry per wavefront in fp64) or the six launches of the batched
+// filter chain.  filter_mode 1 / 2 keep those paths; 3 asks for this one wherever it applies.  Records are identical.
+bool use_q1(const rsx_sc *h, int32_t nq) {
+  static const bool off = [] {
+    const char *e = rsx::exp_env("RSX_SC_Q1");
+    return e && e[0] == '0';
+  }();
+  const int m = filter_mode_of(h);
+  return !off && nq >= 1 && nq <= Q1_MAX_NQ && (m == 0 || m == 3);
+}
+
+int run_q1(rsx_sc *h, const float *d_q, int32_t nq, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig, int32_t k,
+           rsx_sc_hit *d_out, hipStream_t s) {
+  if (n_items < 0) n_items = 0;
+  if (!h->q1_ticket.p) {
+    RSX_TRY(h->q1_ticket.reserve(Q1_MAX_NQ * sizeof(unsigned), s, false));
+    RSX_HIP(hipMemsetAsync(h->q1_ticket.p, 0, Q1_MAX_NQ * sizeof(unsigned), s));
+    for (unsigned &t : h->q1_host_ticket) t = 0;
+  }
+  RSX_TRY(h->q1_ws.reserve(q1_workspace_bytes(n_items, nq, k), s, false));
+  h->prof_kernel = q1_kernel_name();
+  ProfScope ps(&h->prof, s);
+  RSX_TRY(launch_q1(db_view(h), d_q, nq, n_items, n_eligible, d_q_elig, k, d_out, h->q1_ws.p, h->q1_ticket.as<unsigned>(),
+                    h->q1_host_ticket, (h->prof.on && h->stats.p) ? h->stats.as<unsigned long long>() : nullptr, s));
+  ps.stop();
+  return RSX_OK;
+}
+
 int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
              int32_t k, rsx_sc_hit *d_out, hipStream_t s, bool elig_monotone = false) {
+  if (use_q1(h, qv.nq)) return run_q1(h, qv.desc, qv.nq, n_items, n_eligible, d_q_elig, k, d_out, s);
   if (use_filter(h, qv.nq, n_items)) return run_topk_filtered(h, qv, n_items, n_eligible, d_q_elig, k, d_out, s, elig_monotone);
   h->prof_kernel = pair_kernel_name();
   RSX_TRY(h->w->partial.reserve(pair_partial_bytes(n_items > 0 ? n_items : 1, qv.nq, k), s, false));
@@ -650,7 +685,7 @@ int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) try {
   if ((int)std::lround(0.5 * d.search_ratio * NS) != 3)
     return fail(RSX_ERR_BAD_ARG, "kernels are specialised for SEARCH_RADIUS 3 (search_ratio 0.1, SC.h:96)");
   if (d.tree_making_period < 1 || d.num_exclude_recent < 0) return fail(RSX_ERR_BAD_ARG, "bad detector params");
-  if (d.filter_mode < 0 || d.filter_mode > 2) return fail(RSX_ERR_BAD_ARG, "filter_mode must be 0 (auto), 1 (off) or 2 (force)");
+  if (d.filter_mode < 0 || d.filter_mode > 3) return fail(RSX_ERR_BAD_ARG, "filter_mode must be 0 (auto), 1 (off), 2 (force) or 3 (single-query path)");
   if (d.filter_kind < 0 || d.filter_kind > 3)
     return fail(RSX_ERR_BAD_ARG, "filter_kind must be 0 (auto), 1 (direct), 2 (spectral) or 3 (spectral, two waves per SIMD)");
   int ndev = rsx_device_count();
@@ -678,7 +713,7 @@ int rsx_sc_destroy(rsx_sc *h) try {
   (void)hipSetDevice(h->p.device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   for (DevBuf *b : {&h->hn, &h->cmask, &h->sp, &h->sp_aux, &h->hnr, &h->vk16, &h->vk_n, &h->st_partial, &h->stats, &h->helper_ws, &h->tree.nodes, &h->tree.vind,
-                    &h->tree_batch.nodes, &h->tree_batch.vind}) b->release();
+                    &h->tree_batch.nodes, &h->tree_batch.vind, &h->q1_ws, &h->q1_ticket}) b->release();
   for (DevBuf *b : {&h->desc, &h->vkey, &h->norm, &h->rkey, &h->pts_ws, &h->q_desc, &h->topk, &h->knn_ws, &h->small, &h->pair_out, &h->q_elig})
     b->release();
   for (auto &w : h->ws)
@@ -1205,9 +1240,11 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
 
 static int query_device_locked(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out,
                                hipStream_t s) {
+  const int64_t items = local_count_below(h, n_eligible);
+  if (use_q1(h, nq))  // builds the query's keys and images itself: no keys launch
+    return run_q1(h, d_q, nq, items, n_eligible < 0 ? h->n_global : n_eligible, nullptr, k, d_out, s);
   QueryView qv;
   RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));
-  const int64_t items = local_count_below(h, n_eligible);
   return run_topk(h, qv, items, n_eligible < 0 ? h->n_global : n_eligible, nullptr, k, d_out, s);
 }
 

@@ -153,6 +153,30 @@ __device__ __forceinline__ void normalise_column(const float *__restrict__ d, do
   }
 }
 
+// query image of the direct filter / the window kernel from the normalised columns in st (DS halves of LDS): two displaced
+// copies of the doubled image + the column mask in the gap between them (layout: sc_filter.hip "query image"), FILTER_QIMG_BYTES
+// at `out` (global memory or LDS).  One wave.
+__device__ __forceinline__ void img_query_image(const _Float16 *st, unsigned long long m, uint4 *out, int lane) {
+  typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+  constexpr int kEven = FILTER_QIMG_MASK_OFF / 16, kGap = (FILTER_QIMG_ODD - FILTER_QIMG_MASK_OFF) / 16;
+  for (int c = lane; c < FILTER_QIMG_BYTES / 16; c += 64) {
+    half8_t v;
+    if (c < kEven) {
+      const int e0 = (8 * c) % DS;  // 1200 is a multiple of 8: no wrap inside a chunk
+      v = *reinterpret_cast<const half8_t *>(&st[e0]);
+    } else if (c < kEven + kGap) {
+      // the gap carries the query's column mask (read by the filter kernel with one ds_read_b64)
+      const uint4 g = {c == kEven ? (unsigned)m : 0u, c == kEven ? (unsigned)(m >> 32) : 0u, 0u, 0u};
+      v = *reinterpret_cast<const half8_t *>(&g);
+    } else {
+      const int e0 = 4 + 8 * (c - kEven - kGap);
+#pragma unroll
+      for (int i = 0; i < 8; i++) v[i] = st[(e0 + i) % DS];
+    }
+    out[c] = *reinterpret_cast<const uint4 *>(&v);
+  }
+}
+
 // database image of one entry (one wave; st: DS halves of LDS): fp16, tile-major [tile of 32 entries][75 K-steps][64 lanes]
 // [8 halves] (hnT, sc_filter.hip) and once more entry-major (hnR, sc_window.hip gathers single entries) + the column mask
 __device__ __forceinline__ void img_db_entry(const float *__restrict__ desc, const double *__restrict__ norm, int64_t slot,

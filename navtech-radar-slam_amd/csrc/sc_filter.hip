@@ -74,8 +74,6 @@ constexpr int F_TILE1 = 40;       // 32 shifts * 20 elements = 640 = 40 K-steps
 constexpr int F_T = F_STEPS + F_TILE1;  // 115 A fragments per query
 constexpr int QIMG_ODD = 4960;    // byte offset of the copy read by odd shifts (holds q2[4..]); = 96 mod 256
 constexpr int QIMG_EVEN_CHUNKS = 308;  // 2464 elements
-constexpr int QIMG_GAP_CHUNKS = 2;
-constexpr int QIMG_CHUNKS = FILTER_QIMG_BYTES / 16;  // 624
 constexpr int F_QPP = 4;          // queries per LDS phase
 constexpr int F_DEPTH = 5;        // A fragments in flight
 constexpr int F_B_VGPR = 44;      // B fragments kept in VGPRs; the rest live in AGPRs
@@ -124,23 +122,7 @@ __global__ __launch_bounds__(256) void sc_img_query_kernel(const float *__restri
   u64 m = __ballot(nonzero && lane < NS);
   if (__ballot(bad && lane < NS)) m |= kNonFinite;
   wave_lds_fence();
-  uint4 *out = reinterpret_cast<uint4 *>(qimg + (int64_t)q * FILTER_QIMG_BYTES);
-  for (int c = lane; c < QIMG_CHUNKS; c += 64) {
-    half8 v;
-    if (c < QIMG_EVEN_CHUNKS) {
-      const int e0 = (8 * c) % DS;  // 1200 is a multiple of 8: no wrap inside a chunk
-      v = *reinterpret_cast<const half8 *>(&st[wave][e0]);
-    } else if (c < QIMG_EVEN_CHUNKS + QIMG_GAP_CHUNKS) {
-      // the gap carries the query's column mask (read by the filter kernel with one ds_read_b64)
-      const uint4 g = {c == QIMG_EVEN_CHUNKS ? (unsigned)m : 0u, c == QIMG_EVEN_CHUNKS ? (unsigned)(m >> 32) : 0u, 0u, 0u};
-      v = *reinterpret_cast<const half8 *>(&g);
-    } else {
-      const int e0 = 4 + 8 * (c - QIMG_EVEN_CHUNKS - QIMG_GAP_CHUNKS);
-#pragma unroll
-      for (int i = 0; i < 8; i++) v[i] = st[wave][(e0 + i) % DS];
-    }
-    out[c] = *reinterpret_cast<const uint4 *>(&v);
-  }
+  dev::img_query_image(st[wave], m, reinterpret_cast<uint4 *>(qimg + (int64_t)q * FILTER_QIMG_BYTES), lane);
 }
 
 // ------------------------------------------------------------------------------------------

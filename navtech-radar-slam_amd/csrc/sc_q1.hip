@@ -1,0 +1,611 @@
+// sc_q1.hip -- ONE exhaustive ScanContext query in ONE launch (gfx950 / CDNA4): the live detector's regime.
+//
+// What it replaces.  The reference's loop detection is one query at 1 Hz (laserPosegraphOptimization.cpp:561,577 ->
+// detectLoopClosureID, Scancontext.cpp:331-422); in exhaustive mode it scores EVERY eligible entry with
+// distanceBtnScanContext (SC.cpp:116-148).  The batched machinery (spectral filter -> select -> window -> re-scoring: six
+// dependent launches) amortises its fixed costs over thousands of queries; run with one query it is all
+// fixed cost (55 us at 10 000 entries, 0.11 of the HBM roofline north_star names for this regime).  A single query cannot
+// re-use anything: every eligible entry has to be streamed out of HBM once, so this kernel is built around that stream.
+//
+// One launch, a grid of <= 512 four-wave workgroups (two per CU), each walking the 32-entry tiles b, b + G, b + 2G, ...:
+//   prep      every workgroup builds the query's images in LDS itself (sector key, column norms, the fp16 image of the
+//             direct filter and the fp16 hi/lo key circulant: the bodies of sc_keys / sc_img_query / sc_win_query_keys),
+//             while the first tile's database fragments are already in flight;
+//   stream    per tile the fp16 image of the 32 entries (tile-major hnT: 75 coalesced 1-KiB fragments, 2400 B per entry)
+//             is cut BY K over the four waves (19 K-steps each: every wave has its whole share in flight at once -- one
+//             memory latency per tile instead of five ring turns), S[k][e] = sum_i q2[i + 20k] e[i] on the matrix cores
+//             exactly as sc_window_kernel computes it; the partial sums of three waves go through LDS to the tile's
+//             epilogue wave (rotating), which also runs the sector-key alignment GEMM (24 MFMAs, fp16 hi/lo keys) and the
+//             window epilogue of sc_window_dev.h: per entry k* (when unique within the error bound) and a preview pv with
+//             |pv - dist| <= WINDOW_MARGIN (a lower bound only when k* is not unique).  2672 B per entry leave HBM.
+//   select    the workgroup keeps its k smallest preview upper bounds; an entry whose lower bound pv - margin can still
+//             reach the workgroup's k-th smallest upper bound becomes a candidate record (16 B, write-through stores);
+//   finish    the workgroup that draws the last arrival ticket (one relaxed agent-scope fetch_add per workgroup, records
+//             published with sc1 stores + vmcnt(0) drain, read with sc1 loads: MI355X_MICROARCH "valid forms") merges the
+//             per-workgroup bounds into the chip-wide k-th smallest upper bound, keeps the candidates that can still reach it
+//             and evaluates those -- a handful -- EXACTLY (align_exact / phase_b32 of sc_exact_dev.h, the same fp64 pair
+//             function in the same order as every other path), four per round, in ascending order of their lower bound with
+//             the exact k-th best tightening the cut.  It writes the k records; no other launch, no host round trip.
+// Results are byte-identical to the exact-all path and to the oracle: every record comes out of the exact pair function, and
+// an entry is skipped only if a proven lower bound of its distance exceeds a proven upper bound of the k-th best.
+//
+// Roofline (HBM): SURVEY 8d prices a pair at 4800 B (one fp32 descriptor); this kernel reads 2672 B per entry (fp16 image
+// 2400 + key image 256 + norms 8 + mask 8).  bench.py latency_q1 reports both the algorithmic and the physical fraction.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+
+#include "rsx_common.h"
+#include "sc_kernels.h"
+#include "sc_entry_dev.h"
+#include "sc_exact_dev.h"
+#include "sc_window_dev.h"
+
+namespace rsx {
+namespace sc {
+
+namespace {
+
+using win::half8;
+using win::floatx16;
+using win::u64;
+using win::kNonFinite;
+using win::W_STEPS;
+using win::W_TILE1;
+using win::QK_COPY;
+using win::QK_LO;
+using win::QK_NORM;
+using win::W_LDS;
+
+constexpr int Q1_KS = 19;  // K-steps of the image GEMM per wave: 75 = 19 + 19 + 19 + 18
+static_assert(4 * Q1_KS >= W_STEPS && 3 * Q1_KS < W_STEPS, "the four waves cover the 75 K-steps");
+// LDS of one workgroup
+constexpr int Q1_OFF_QIMG = 0;                          // the direct filter's query image (two displaced fp16 copies + mask)
+constexpr int Q1_OFF_QK = FILTER_QIMG_BYTES;            // 9984: the key circulant (8 displaced hi copies, 8 lo, norms)
+constexpr int Q1_OFF_Q = W_LDS;                         // 14608: WaveLds's query part: fp32 descriptor | norms | sector key
+constexpr int Q1_OFF_MISC = Q1_OFF_Q + WaveLds::OFF_ENT;  // 20432
+constexpr int Q1_MISC_UB = 0;      // float[32]: the workgroup's k smallest preview upper bounds, ascending
+constexpr int Q1_MISC_CNT = 128;   // int: candidate records written so far
+constexpr int Q1_MISC_LAST = 132;  // int: this workgroup drew the last ticket
+constexpr int Q1_MISC_NSURV = 136; // int: survivors gathered in the current chunk
+constexpr int Q1_MISC_TAU = 144;   // double: the cut of the exact rounds
+constexpr int Q1_MISC_RED = 160;   // u64[2][4]: per-wave minima of the bound merge, double buffered
+constexpr int Q1_MISC_RKEY = 256;  // float[20]: ring key (computed with the other keys, not used)
+constexpr int Q1_MISC_BYTES = 384;
+constexpr int Q1_OFF_SCR = Q1_OFF_MISC + Q1_MISC_BYTES;  // 20816
+static_assert(Q1_OFF_SCR % 16 == 0, "alignment");
+constexpr int Q1_PART_BYTES = 3 * 32 * 64 * 4;           // one buffer of partial sums: 3 waves x 32 accumulators x 64 lanes
+constexpr int Q1_SCR_BYTES = 2 * Q1_PART_BYTES;          // 49152
+constexpr int Q1_LDS = Q1_OFF_SCR + Q1_SCR_BYTES;        // 69968: two workgroups per CU
+// the scratch region during prep ...
+constexpr int Q1_SCR_ST = 0;                             // _Float16[1200]: normalised columns
+constexpr int Q1_SCR_ST2 = 2432;                         // _Float16[2][128]: key staging
+// ... and in the last workgroup
+constexpr int Q1_FIN_ENT = 0;                            // 4 x ENT_SIZE: the waves' exact-evaluation regions
+constexpr int Q1_FIN_RES = 4 * ENT_SIZE;                 // 13632: 4 x {double dist; int idx; int shift} results of a round
+constexpr int Q1_FIN_PREF = Q1_FIN_RES + 64;             // 13696: int[G + 1] prefix sums of the candidate counts
+constexpr int Q1_MAX_G = 512;
+constexpr int Q1_FIN_AB = Q1_FIN_PREF + (Q1_MAX_G + 1) * 4 + 12;  // 15760: bound lists (merge), then the survivors
+static_assert(Q1_FIN_AB % 16 == 0, "alignment");
+constexpr int Q1_FIN_AB_BYTES = Q1_SCR_BYTES - Q1_FIN_AB;  // 33392
+constexpr int Q1_SURV_CAP = 2048;                        // survivors of one chunk: lo[], slot[], ks[]
+static_assert(3 * 4 * Q1_SURV_CAP <= Q1_FIN_AB_BYTES, "survivor arrays fit");
+constexpr int Q1_SORT_MAX = 256;                         // chunks with at most this many survivors are evaluated in ascending lo
+
+struct Q1Args {
+  DbView db;
+  const float *qdesc;      // [nq][1200]
+  int64_t n_items;         // local slots that can be eligible at all
+  int64_t n_eligible;      // global index limit
+  const int64_t *q_elig;   // optional per-query limit
+  rsx_sc_hit *out;         // [nq][k]
+  int32_t k, kp;           // kp = k rounded up to 4: floats of a workgroup's bound list the merge reads
+  int32_t cap_wg;          // candidate records a workgroup may write (= its entries)
+  unsigned *ticket;        // [RSX_Q1_MAX_NQ] arrival counters, never reset
+  unsigned target[8];      // value of ticket[q] once every workgroup of THIS launch has arrived
+  float *ws_ub;            // [nq][G][32]
+  u64 *ws_cnt;             // [nq][G]
+  u64 *ws_cand;            // [nq][G][cap_wg][2]
+  unsigned long long *stats;  // optional (profiling): RESCORE_STAT_WORDS counters
+};
+
+__device__ __forceinline__ void store_sc1(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u64 load_sc1(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ u64 wave_min_u64(u64 v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) {
+    const u64 o = __shfl_xor(v, off);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n = lane & 31, hh = lane >> 5;
+  const int G = (int)gridDim.x, b = (int)blockIdx.x, qi = (int)blockIdx.y;
+  char *misc = smem + Q1_OFF_MISC;
+  char *scr = smem + Q1_OFF_SCR;
+  float *s_ub = reinterpret_cast<float *>(misc + Q1_MISC_UB);
+  int *s_cnt = reinterpret_cast<int *>(misc + Q1_MISC_CNT);
+
+  int64_t n_elig = a.n_eligible;
+  if (a.q_elig) {
+    const int64_t e = a.q_elig[qi];
+    n_elig = e < n_elig ? e : n_elig;
+  }
+  int64_t n_rows = 0;  // local slots [0, n_rows) are the eligible ones
+  if (n_elig > a.db.idx_base) {
+    n_rows = (n_elig - a.db.idx_base + a.db.idx_stride - 1) / a.db.idx_stride;
+    n_rows = n_rows < a.n_items ? n_rows : a.n_items;
+  }
+  const int ntiles = (int)((n_rows + 31) >> 5);
+
+  // ---- database fragments of one tile: this wave's K-steps of the image, and for the tile's epilogue wave the key
+  // fragments (requested first: VMEM returns in order and the alignment runs while the image is still on its way) ----
+  const int ks0 = Q1_KS * wave;
+  const int nst = W_STEPS - ks0 < Q1_KS ? W_STEPS - ks0 : Q1_KS;  // 19, 19, 19, 18
+  half8 frag[Q1_KS];
+  half8 bh[4], bl[4];
+  float2 en = {0.0f, 0.0f};
+  u64 em = 0;
+  auto issue = [&](int t, int it) {
+    if (wave == (it & 3)) {
+      const int64_t slot = (int64_t)t * 32 + n;
+      const char *bk = static_cast<const char *>(a.db.vk16) + slot * 256 + 16 * hh;
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        bh[s] = *reinterpret_cast<const half8 *>(bk + 32 * s);
+        bl[s] = *reinterpret_cast<const half8 *>(bk + 128 + 32 * s);
+      }
+      en = reinterpret_cast<const float2 *>(a.db.vk_n)[slot];
+      em = a.db.cmask[slot];
+    }
+    const half8 *bt = static_cast<const half8 *>(a.db.hnT) + ((int64_t)t * W_STEPS + ks0) * 64 + lane;
+#pragma unroll
+    for (int u = 0; u < Q1_KS; u++)
+      if (u < nst) frag[u] = bt[u * 64];
+  };
+  if (b < ntiles) issue(b, 0);
+
+  // ---- the query's images, built here (what sc_keys / sc_img_query / sc_win_query_keys do for a batch) ----
+  {
+    float4 *qf = reinterpret_cast<float4 *>(smem + Q1_OFF_Q);
+    const float4 *src = reinterpret_cast<const float4 *>(a.qdesc + (int64_t)qi * DS);
+    for (int i = tid; i < DS / 4; i += 256) qf[i] = src[i];
+    if (tid < 32) s_ub[tid] = INFINITY;
+    if (tid == 0) *s_cnt = 0;
+  }
+  __syncthreads();
+  double *qn1 = reinterpret_cast<double *>(smem + Q1_OFF_Q + WaveLds::OFF_QN1);
+  double *qv1 = reinterpret_cast<double *>(smem + Q1_OFF_Q + WaveLds::OFF_QV1);
+  if (wave == 0)
+    dev::wave_keys(reinterpret_cast<const float *>(smem + Q1_OFF_Q), qv1, qn1, reinterpret_cast<float *>(misc + Q1_MISC_RKEY), lane);
+  __syncthreads();
+  if (wave == 0) {
+    _Float16 *st = reinterpret_cast<_Float16 *>(scr + Q1_SCR_ST);
+    bool nonzero = false, bad = false;
+    if (lane < NS)
+      dev::normalise_column(reinterpret_cast<const float *>(smem + Q1_OFF_Q) + lane * NR, qn1[lane], &st[lane * NR], nonzero, bad);
+    u64 m = __ballot(nonzero && lane < NS);
+    if (__ballot(bad && lane < NS)) m |= kNonFinite;
+    wave_lds_fence();
+    dev::img_query_image(st, m, reinterpret_cast<uint4 *>(smem + Q1_OFF_QIMG), lane);
+  } else if (wave == 1) {
+    win::query_keys_image(lane < NS ? qv1[lane] : 0.0, reinterpret_cast<_Float16(*)[128]>(scr + Q1_SCR_ST2), smem + Q1_OFF_QK, lane);
+  }
+  __syncthreads();
+
+  const u64 qm = *reinterpret_cast<const u64 *>(smem + Q1_OFF_QIMG + FILTER_QIMG_MASK_OFF);
+  const float nq_key = *reinterpret_cast<const float *>(smem + Q1_OFF_QK + QK_NORM);
+  const float uq_key = *reinterpret_cast<const float *>(smem + Q1_OFF_QK + QK_NORM + 4);
+  // A-fragment addresses of this lane's row (shift n of tile 0; tile 1 = the same address + 40 K-steps, sc_filter.hip)
+  const char *ap = smem + Q1_OFF_QIMG + ((n & 1) ? (FILTER_QIMG_ODD + 40 * n - 8) : (40 * n)) + 16 * hh + 32 * ks0;
+  const char *kp = smem + Q1_OFF_QK + (n & 7) * QK_COPY + ((n & ~7) + 8 * hh) * 2;  // tile 1: + 64 B
+  u64 *my_cand = a.ws_cand + ((int64_t)qi * G + b) * a.cap_wg * 2;
+
+  int it = 0;
+  for (int t = b; t < ntiles; t += G, it++) {
+    const int ew = it & 3;
+    const bool epi = wave == ew;
+    u64 win = 0;
+    int kstar = -1;
+    if (epi) {
+      // ---- alignment: 2 tiles x (hi*hi + hi*lo + lo*hi) x 4 K-steps (sc_window.hip) ----
+      floatx16 k0 = {0}, k1 = {0};
+#pragma unroll
+      for (int s = 0; s < 4; s++) {
+        const half8 ah0 = *reinterpret_cast<const half8 *>(kp + 32 * s);
+        const half8 al0 = *reinterpret_cast<const half8 *>(kp + QK_LO + 32 * s);
+        const half8 ah1 = *reinterpret_cast<const half8 *>(kp + 64 + 32 * s);
+        const half8 al1 = *reinterpret_cast<const half8 *>(kp + QK_LO + 64 + 32 * s);
+        k0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bh[s], k0, 0, 0, 0);
+        k1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bh[s], k1, 0, 0, 0);
+        k0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, bl[s], k0, 0, 0, 0);
+        k1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, bl[s], k1, 0, 0, 0);
+        k0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[s], k0, 0, 0, 0);
+        k1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[s], k1, 0, 0, 0);
+      }
+      win::alignment_of(k0, k1, nq_key, uq_key, en, hh, win, kstar);
+    }
+    // ---- this wave's K-steps of the 60 correlation values (the direct filter's GEMM) ----
+    floatx16 acc0 = {0}, acc1 = {0};
+#pragma unroll
+    for (int u = 0; u < Q1_KS; u++) {
+      if (u < nst) {
+        const half8 a0 = *reinterpret_cast<const half8 *>(ap + 32 * u);
+        const half8 a1 = *reinterpret_cast<const half8 *>(ap + 32 * (u + W_TILE1));
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, frag[u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, frag[u], acc1, 0, 0, 0);
+      }
+    }
+    const u64 em_t = em;  // (the next tile's epilogue wave is another wave: its loads do not touch this one's mask)
+    if (t + G < ntiles) issue(t + G, it + 1);
+    // ---- partial sums of the other three waves -> LDS (two buffers: one barrier per tile) ----
+    float4 *part = reinterpret_cast<float4 *>(scr + (it & 1) * Q1_PART_BYTES);
+    if (!epi) {
+      const int ps = (wave - ew - 1) & 3;  // 0, 1, 2
+#pragma unroll
+      for (int r4 = 0; r4 < 4; r4++) {
+        part[(ps * 8 + r4) * 64 + lane] = float4{acc0[4 * r4], acc0[4 * r4 + 1], acc0[4 * r4 + 2], acc0[4 * r4 + 3]};
+        part[(ps * 8 + 4 + r4) * 64 + lane] = float4{acc1[4 * r4], acc1[4 * r4 + 1], acc1[4 * r4 + 2], acc1[4 * r4 + 3]};
+      }
+    }
+    __syncthreads();
+    if (epi) {
+#pragma unroll
+      for (int ps = 0; ps < 3; ps++) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4++) {
+          const float4 p0 = part[(ps * 8 + r4) * 64 + lane], p1 = part[(ps * 8 + 4 + r4) * 64 + lane];
+          acc0[4 * r4] += p0.x; acc0[4 * r4 + 1] += p0.y; acc0[4 * r4 + 2] += p0.z; acc0[4 * r4 + 3] += p0.w;
+          acc1[4 * r4] += p1.x; acc1[4 * r4 + 1] += p1.y; acc1[4 * r4 + 2] += p1.z; acc1[4 * r4 + 3] += p1.w;
+        }
+      }
+      const float pv = win::preview_of(acc0, acc1, qm, em_t, win, kstar, hh);
+      // ---- the entry's bounds: lanes 0..31 carry entry t * 32 + n (lanes 32..63 hold the same values) ----
+      const int64_t slot = (int64_t)t * 32 + n;
+      const bool have = hh == 0 && slot < n_rows;
+      const float ub = (have && kstar >= 0 && pv < 3.0e38f) ? pv + WINDOW_MARGIN : INFINITY;  // NaN fails the compare
+      float lo = INFINITY;  // +inf: never a hit (no effective column in the window) or not eligible
+      if (have) lo = (pv == pv) ? pv - WINDOW_MARGIN : -INFINITY;  // NaN: no preview (non-finite data), must be looked at
+      // the workgroup's k smallest upper bounds, ascending, one per lane
+      float lub = s_ub[n];
+      float kth = __shfl(lub, a.k - 1);
+      u64 pend = __ballot(ub < kth);
+      while (pend) {
+        const int l = __ffsll((long long)pend) - 1;
+        pend &= pend - 1;
+        const float v = __shfl(ub, l);
+        if (!(v < kth)) continue;
+        const int pos = __popcll(__ballot(lane < a.k && lub <= v));  // < k: lub[k - 1] = kth > v
+        const float up = __shfl_up(lub, 1);
+        if (lane < a.k) {
+          if (lane > pos) lub = up;
+          else if (lane == pos) lub = v;
+        }
+        kth = __shfl(lub, a.k - 1);
+      }
+      if (lane < 32) s_ub[lane] = lub;
+      // candidates: lower bound not above the workgroup's k-th smallest upper bound (which is never below the chip's)
+      const bool cand = lo < INFINITY && !(lo > kth);
+      const u64 cb = __ballot(cand);
+      if (cb) {
+        const int base = *s_cnt;
+        if (cand) {
+          const int pos = base + __popcll(cb & ((1ull << lane) - 1ull));
+          store_sc1(my_cand + 2 * pos, ((u64)(unsigned)slot << 32) | (u64)__float_as_uint(lo));
+          store_sc1(my_cand + 2 * pos + 1, (u64)(unsigned)kstar);
+        }
+        wave_lds_fence();
+        if (lane == 0) *s_cnt = base + __popcll(cb);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- publish: the bound list and the candidate count of this workgroup, then the arrival ticket ----
+  if (wave == 0) {
+    u64 *ubo = reinterpret_cast<u64 *>(a.ws_ub + ((int64_t)qi * G + b) * 32);
+    if (lane < 16) store_sc1(ubo + lane, reinterpret_cast<const u64 *>(s_ub)[lane]);
+    if (lane == 16) store_sc1(a.ws_cnt + (int64_t)qi * G + b, (u64)(unsigned)*s_cnt);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have left
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned old = __hip_atomic_fetch_add(a.ticket + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *reinterpret_cast<int *>(misc + Q1_MISC_LAST) = (old + 1u == a.target[qi]) ? 1 : 0;
+  }
+  __syncthreads();
+  if (*reinterpret_cast<const int *>(misc + Q1_MISC_LAST) == 0) return;
+
+  // =============================== the last workgroup ===============================
+  int *s_pref = reinterpret_cast<int *>(scr + Q1_FIN_PREF);
+  // ---- the bound lists of every workgroup -> LDS, candidate counts -> prefix sums ----
+  {
+    float *L = reinterpret_cast<float *>(scr + Q1_FIN_AB);
+    const int kp2 = a.kp >> 1;
+    for (int i = tid; i < G * kp2; i += 256) {
+      const int j = i / kp2, c = i - j * kp2;
+      const u64 v = load_sc1(reinterpret_cast<const u64 *>(a.ws_ub + ((int64_t)qi * G + j) * 32) + c);
+      reinterpret_cast<u64 *>(L)[j * kp2 + c] = v;
+    }
+    for (int j = tid; j < G; j += 256) s_pref[j + 1] = (int)load_sc1(a.ws_cnt + (int64_t)qi * G + j);
+    if (tid == 0) s_pref[0] = 0;
+  }
+  __syncthreads();
+  if (wave == 0) {  // inclusive scan of s_pref[1 .. G] (G <= 512: 8 per lane)
+    int v[8], s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int j = lane * 8 + i;
+      v[i] = j < G ? s_pref[j + 1] : 0;
+      s += v[i];
+    }
+    int inc = s;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    int run = inc - s;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int j = lane * 8 + i;
+      run += v[i];
+      if (j < G) s_pref[j + 1] = run;
+    }
+  }
+  // ---- the chip-wide k-th smallest upper bound: k rounds of "smallest head of the sorted lists" ----
+  float tau_ub = INFINITY;
+  {
+    const float *L = reinterpret_cast<const float *>(scr + Q1_FIN_AB);
+    u64 *s_red = reinterpret_cast<u64 *>(misc + Q1_MISC_RED);
+    int p0 = 0, p1 = 0;
+    const int j0 = tid, j1 = tid + 256;
+    for (int r = 0; r < a.k; r++) {
+      u64 key = ~0ull;
+      if (j0 < G && p0 < a.k) key = ((u64)dev::enc_f32(L[j0 * a.kp + p0]) << 32) | (unsigned)j0;
+      if (j1 < G && p1 < a.k) {
+        const u64 k1 = ((u64)dev::enc_f32(L[j1 * a.kp + p1]) << 32) | (unsigned)j1;
+        key = k1 < key ? k1 : key;
+      }
+      key = wave_min_u64(key);
+      if (lane == 0) s_red[(r & 1) * 4 + wave] = key;
+      __syncthreads();
+      u64 g = s_red[(r & 1) * 4];
+#pragma unroll
+      for (int w = 1; w < 4; w++) {
+        const u64 o = s_red[(r & 1) * 4 + w];
+        g = o < g ? o : g;
+      }
+      if (g == ~0ull) {  // fewer than k bounds at all (uniform)
+        tau_ub = INFINITY;
+        break;
+      }
+      tau_ub = dev::dec_f32((unsigned)(g >> 32));
+      const int owner = (int)(unsigned)g;
+      if (owner == j0) p0++;
+      else if (owner == j1) p1++;
+    }
+  }
+  __syncthreads();  // the lists are dead: their space holds the survivors from here on
+
+  // ---- candidates that can still reach the bound, in chunks; exact evaluation four per round ----
+  float *s_lo = reinterpret_cast<float *>(scr + Q1_FIN_AB);
+  int *s_slot = reinterpret_cast<int *>(s_lo + Q1_SURV_CAP);
+  int *s_ks = s_slot + Q1_SURV_CAP;
+  int *s_nsurv = reinterpret_cast<int *>(misc + Q1_MISC_NSURV);
+  double *s_tau = reinterpret_cast<double *>(misc + Q1_MISC_TAU);
+  struct Res {
+    double d;
+    int idx, shift;
+  };
+  Res *s_res = reinterpret_cast<Res *>(scr + Q1_FIN_RES);
+  char *wsm = scr + Q1_FIN_ENT + wave * ENT_SIZE;
+  const char *qsm = smem + Q1_OFF_Q;
+  const int total = s_pref[G];
+  double ld = INFINITY;  // wave 0: the sorted top-k of exact hits, one record per lane
+  int li = 0x7fffffff, ls = 0;
+  double tau = (double)tau_ub;
+  unsigned n_exact = 0, n_aligned = 0, n_shifts = 0, n_surv_all = 0;
+  for (int base = 0; base < total; base += Q1_SURV_CAP) {
+    if (tid == 0) *s_nsurv = 0;
+    __syncthreads();
+    const int lim = total - base < Q1_SURV_CAP ? total - base : Q1_SURV_CAP;
+    for (int e = tid; e < lim; e += 256) {
+      const int ge = base + e;
+      int lo_j = 0, hi_j = G;  // the workgroup j with s_pref[j] <= ge < s_pref[j + 1]
+      while (hi_j - lo_j > 1) {
+        const int mid = (lo_j + hi_j) >> 1;
+        if (s_pref[mid] <= ge) lo_j = mid;
+        else hi_j = mid;
+      }
+      const u64 *rec = a.ws_cand + (((int64_t)qi * G + lo_j) * a.cap_wg + (ge - s_pref[lo_j])) * 2;
+      const u64 ra = load_sc1(rec), rb = load_sc1(rec + 1);
+      const float lo = __uint_as_float((unsigned)ra);
+      if (!((double)lo > tau)) {
+        const int i = atomicAdd(s_nsurv, 1);
+        s_lo[i] = lo;
+        s_slot[i] = (int)(ra >> 32);
+        s_ks[i] = (int)(unsigned)rb;
+      }
+    }
+    __syncthreads();
+    const int ns = *s_nsurv;
+    n_surv_all += (unsigned)ns;
+    if (ns == 0) continue;  // uniform
+    // bring the survivors' descriptors towards this CU while the order is worked out (one memory latency for all of them)
+    {
+      Touch tch;
+      for (int i = wave; i < ns && i < 64; i += 4) touch_entry(a.db, s_slot[i], lane, tch);
+      // ascending (lo, slot) when there are few: the exact k-th best then takes over early and the tail is cut
+      float my_lo = 0.0f;
+      int my_slot = 0, my_ks = 0, rank = 0;
+      const bool sorted = ns <= Q1_SORT_MAX;
+      if (sorted && tid < ns) {
+        my_lo = s_lo[tid];
+        my_slot = s_slot[tid];
+        my_ks = s_ks[tid];
+        for (int j = 0; j < ns; j++) {
+          const float oj = s_lo[j];
+          const int sj = s_slot[j];
+          rank += (oj < my_lo || (oj == my_lo && sj < my_slot)) ? 1 : 0;
+        }
+      }
+      __syncthreads();
+      if (sorted && tid < ns) {
+        s_lo[rank] = my_lo;
+        s_slot[rank] = my_slot;
+        s_ks[rank] = my_ks;
+      }
+      touch_wait(tch);
+      __syncthreads();
+      for (int i0 = 0; i0 < ns; i0 += 4) {
+        if (sorted && (double)s_lo[i0] > tau) break;  // everything after it is larger still (uniform)
+        const int i = i0 + wave;
+        Res r;
+        r.d = INFINITY;
+        r.idx = 0;
+        r.shift = 0;
+        if (i < ns && !((double)s_lo[i] > tau)) {  // (wave-uniform)
+          const int64_t slot = s_slot[i];
+          const int ksm = s_ks[i];
+          EntryRegs er;
+          load_entry(a.db, slot, lane, er);
+          int ks = ksm;
+          unsigned tmask = 0x7fu;
+          if (ksm >= 0) {  // k* and the shifts of its window that can be the minimum (sc_window_dev.h)
+            ks = ksm & 63;
+            const unsigned m7 = ((unsigned)ksm >> 8) & 0x7fu;
+            if (m7) tmask = m7;
+          }
+          if (ks < 0) {
+            ks = align_exact(reinterpret_cast<const double *>(qsm + WaveLds::OFF_QV1), wsm, lane, er.v);
+            n_aligned++;
+          }
+          double bd;
+          int bk;
+          phase_b32(qsm, wsm, lane, er, ks, tmask, bd, bk);
+          n_exact++;
+          n_shifts += (unsigned)__builtin_popcount(tmask);
+          r.d = bd;
+          r.idx = (int)(a.db.idx_base + slot * a.db.idx_stride);
+          r.shift = bk;
+        }
+        if (lane == 0) s_res[wave] = r;
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll 1
+          for (int w = 0; w < 4; w++) {
+            const Res o = s_res[w];
+            if (o.d < kBig) topk_insert(ld, li, ls, lane, a.k, o.d, o.idx, o.shift);
+          }
+          const double kd = __shfl(ld, a.k - 1);
+          if (lane == 0) *s_tau = kd < (double)tau_ub ? kd : (double)tau_ub;
+        }
+        __syncthreads();
+        tau = *s_tau;
+      }
+    }
+    __syncthreads();
+  }
+  if (wave == 0 && lane < a.k) {
+    rsx_sc_hit h;
+    if (ld == INFINITY) {
+      h.dist = kBig; h.index = 0; h.shift = 0;
+    } else {
+      h.dist = ld; h.index = li; h.shift = ls;
+    }
+    a.out[(int64_t)qi * a.k + lane] = h;
+  }
+  if (a.stats) {  // (profiling) same words as sc_rescore_wave_kernel
+    unsigned long long *st = a.stats + (qi % RESCORE_STAT_COPIES) * RESCORE_STAT_WORDS;
+    if (lane == 0) {
+      atomicAdd(st + 2, (unsigned long long)n_exact);
+      atomicAdd(st + 11, (unsigned long long)n_aligned);
+      atomicAdd(st + 12, (unsigned long long)n_shifts);
+    }
+    if (tid == 0) {
+      atomicAdd(st, (unsigned long long)n_surv_all);
+      atomicAdd(st + 3, (unsigned long long)total);
+      atomicAdd(st + 1, 1ull);
+    }
+  }
+}
+
+}  // namespace
+
+// workgroups of one query's launch: as many as there are tiles, at most two per CU (the LDS footprint allows no more); the
+// bound lists of all of them have to fit the last workgroup's LDS
+int q1_grid(int64_t n_items, int32_t k) {
+  const int64_t ntiles = (n_items + 31) / 32;
+  const int kp = (k + 3) & ~3;
+  int gmax = Q1_FIN_AB_BYTES / (kp * 4);
+  if (gmax > Q1_MAX_G) gmax = Q1_MAX_G;
+  if (gmax > 256) gmax = 512;  // whole CUs' worth: 256 or 512
+  else gmax = 256;
+  return (int)(ntiles < 1 ? 1 : (ntiles < gmax ? ntiles : gmax));
+}
+
+size_t q1_workspace_bytes(int64_t n_items, int32_t nq, int32_t k) {
+  const int g = q1_grid(n_items, k);
+  const int64_t ntiles = (n_items + 31) / 32;
+  const int64_t cap_wg = ((ntiles + g - 1) / g) * 32;
+  return (size_t)nq * g * (128 + 8 + (size_t)(cap_wg > 32 ? cap_wg : 32) * 16) + 256;
+}
+
+const char *q1_kernel_name() { return "sc_q1_kernel"; }
+
+int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, int64_t n_eligible, const int64_t *q_elig,
+              int32_t k, rsx_sc_hit *d_out, void *ws, unsigned *d_ticket, unsigned *host_ticket, unsigned long long *d_stats,
+              hipStream_t s) {
+  if (nq <= 0) return RSX_OK;
+  if (nq > Q1_MAX_NQ) return fail(RSX_ERR_BAD_ARG, "the single-query path takes at most %d queries", Q1_MAX_NQ);
+  if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
+  if (n_items < 0) n_items = 0;
+  if (n_items >= (1ll << 31)) return fail(RSX_ERR_RANGE, "the single-query path addresses local slots with 31 bits");
+  {  // 68 KiB of dynamic LDS: opt in once per device
+    static std::atomic<unsigned long long> attr_set{0};
+    int dev = 0;
+    RSX_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
+      RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_q1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Q1_LDS));
+      attr_set.fetch_or(bit, std::memory_order_relaxed);
+    }
+  }
+  const int g = q1_grid(n_items, k);
+  const int64_t ntiles = (n_items + 31) / 32;
+  const int64_t cap_wg = ((ntiles + g - 1) / g) * 32;
+  Q1Args a;
+  a.db = db;
+  a.qdesc = d_q;
+  a.n_items = n_items;
+  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
+  a.q_elig = q_elig;
+  a.out = d_out;
+  a.k = k;
+  a.kp = (k + 3) & ~3;
+  a.cap_wg = (int32_t)(cap_wg > 32 ? cap_wg : 32);
+  a.ticket = d_ticket;
+  for (int q = 0; q < Q1_MAX_NQ; q++) a.target[q] = host_ticket[q] + (q < nq ? (unsigned)g : 0u);
+  char *w = static_cast<char *>(ws);
+  a.ws_ub = reinterpret_cast<float *>(w);
+  w += (size_t)nq * g * 128;
+  a.ws_cnt = reinterpret_cast<u64 *>(w);
+  w += (size_t)nq * g * 8;
+  a.ws_cand = reinterpret_cast<u64 *>(w);
+  a.stats = d_stats;
+  hipLaunchKernelGGL(sc_q1_kernel, dim3((unsigned)g, (unsigned)nq), dim3(256), Q1_LDS, s, a);
+  RSX_HIP(hipGetLastError());
+  for (int q = 0; q < nq; q++) host_ticket[q] += (unsigned)g;  // only once the launch is in the queue
+  return RSX_OK;
+}
+
+}  // namespace sc
+}  // namespace rsx
