@@ -73,10 +73,8 @@ struct rsx_sc {
     QueryView qv{};
   } st;
   DevBuf st_partial;  // this shard's stage-1 hits
-  // the one-launch single-query path (sc_q1.hip): candidate records / bound lists of the workgroups, and the arrival
-  // counters (never reset: q1_host_ticket[] holds what they read once everything enqueued so far has run)
+  // the one-launch single-query path (sc_q1.hip): candidate records / bound lists of the workgroups, and the arrival counters
   DevBuf q1_ws, q1_ticket;
-  unsigned q1_host_ticket[Q1_MAX_NQ] = {};
   DevBuf helper_ws;   // staging of the stateless helper calls (Scancontext.h:60-66)
   DevBuf stats;       // profiling only: RESCORE_STAT_COPIES blocks of counters (sc_kernels.h), summed by the host when read
   void *pinned = nullptr;  // small pinned host staging (results)
@@ -427,15 +425,14 @@ int run_q1(rsx_sc *h, const float *d_q, int32_t nq, int64_t n_items, int64_t n_e
            rsx_sc_hit *d_out, hipStream_t s) {
   if (n_items < 0) n_items = 0;
   if (!h->q1_ticket.p) {
-    RSX_TRY(h->q1_ticket.reserve(Q1_MAX_NQ * sizeof(unsigned), s, false));
-    RSX_HIP(hipMemsetAsync(h->q1_ticket.p, 0, Q1_MAX_NQ * sizeof(unsigned), s));
-    for (unsigned &t : h->q1_host_ticket) t = 0;
+    RSX_TRY(h->q1_ticket.reserve(q1_ticket_bytes(), s, false));
+    RSX_HIP(hipMemsetAsync(h->q1_ticket.p, 0, q1_ticket_bytes(), s));
   }
   RSX_TRY(h->q1_ws.reserve(q1_workspace_bytes(n_items, nq, k), s, false));
   h->prof_kernel = q1_kernel_name();
   ProfScope ps(&h->prof, s);
   RSX_TRY(launch_q1(db_view(h), d_q, nq, n_items, n_eligible, d_q_elig, k, d_out, h->q1_ws.p, h->q1_ticket.as<unsigned>(),
-                    h->q1_host_ticket, (h->prof.on && h->stats.p) ? h->stats.as<unsigned long long>() : nullptr, s));
+                    (h->prof.on && h->stats.p) ? h->stats.as<unsigned long long>() : nullptr, s));
   ps.stop();
   return RSX_OK;
 }

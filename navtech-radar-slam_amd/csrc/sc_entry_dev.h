@@ -22,34 +22,80 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
+// wave-wide reductions on 64-bit values by DPP inside the rows of 16 lanes + four v_readlane (a __shfl_xor butterfly is
+// two ds_bpermute per step: ~1.2 k cycles of dependent LDS-crossbar round trips for one 64-bit reduction)
+template <int CTRL>
+__device__ __forceinline__ unsigned long long dpp_u64(unsigned long long x) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)x, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(x >> 32), CTRL, 0xf, 0xf, false);
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long x, int l) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)x, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(x >> 32), l);
+  return ((unsigned long long)hi << 32) | lo;
+}
+template <bool MAX>
+__device__ __forceinline__ unsigned long long wave_minmax_u64(unsigned long long v) {
+  auto pick = [](unsigned long long a, unsigned long long b) { return MAX ? (a > b ? a : b) : (a < b ? a : b); };
+  v = pick(v, dpp_u64<0xB1>(v));   // quad_perm [1,0,3,2]
+  v = pick(v, dpp_u64<0x4E>(v));   // quad_perm [2,3,0,1]
+  v = pick(v, dpp_u64<0x141>(v));  // row_half_mirror
+  v = pick(v, dpp_u64<0x140>(v));  // row_mirror: every lane = its row's result
+  return pick(pick(readlane_u64(v, 0), readlane_u64(v, 16)), pick(readlane_u64(v, 32), readlane_u64(v, 48)));
+}
+__device__ __forceinline__ double wave_sum_f64(double x) {  // (row sums in butterfly order, then row 0 + 1 + 2 + 3)
+  auto d = [](double a) { return (unsigned long long)__double_as_longlong(a); };
+  auto f = [](unsigned long long a) { return __longlong_as_double((long long)a); };
+  x = x + f(dpp_u64<0xB1>(d(x)));
+  x = x + f(dpp_u64<0x4E>(d(x)));
+  x = x + f(dpp_u64<0x141>(d(x)));
+  x = x + f(dpp_u64<0x140>(d(x)));
+  return ((f(readlane_u64(d(x), 0)) + f(readlane_u64(d(x), 16))) + f(readlane_u64(d(x), 32))) + f(readlane_u64(d(x), 48));
+}
+
 // ------------------------------------------------------------------------------------------
 // keys: one wave per descriptor
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_keys(const float *__restrict__ d, double *__restrict__ vkey,
-                                          double *__restrict__ norm, float *__restrict__ rkey, int lane) {
-  // Eigen 3.3 redux order of the reference build (SSE2, 2-double packets; oracle/sc_ref.c "reductions"):
-  // term i goes to accumulator i % 4 = (packet accumulator i/2 % 2, lane i % 2); result (a0 + a2) + (a1 + a3)
+// sector key + column norm of ONE column held in registers (c[i] = elements 4 i .. 4 i + 3)
+// Eigen 3.3 redux order of the reference build (SSE2, 2-double packets; oracle/sc_ref.c "reductions"):
+// term i goes to accumulator i % 4 = (packet accumulator i/2 % 2, lane i % 2); result (a0 + a2) + (a1 + a3)
+__device__ __forceinline__ void column_keys(const float4 (&c)[5], double &vkey, double &norm) {
+  double s0, s1, s2, s3, q0, q1, q2, q3;
+  {
+    const float4 v = c[0];
+    double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+    s0 = x0; s1 = x1; s2 = x2; s3 = x3;
+    q0 = x0 * x0; q1 = x1 * x1; q2 = x2 * x2; q3 = x3 * x3;  // exact in fp64
+  }
+#pragma unroll
+  for (int i = 1; i < 5; i++) {
+    const float4 v = c[i];
+    double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+    s0 = s0 + x0; q0 = fma(x0, x0, q0);  // x*x exact in fp64 -> fma == mul+add
+    s1 = s1 + x1; q1 = fma(x1, x1, q1);
+    s2 = s2 + x2; q2 = fma(x2, x2, q2);
+    s3 = s3 + x3; q3 = fma(x3, x3, q3);
+  }
+  vkey = ((s0 + s2) + (s1 + s3)) / (double)NR;  // SC.cpp:224 mean()
+  norm = sqrt((q0 + q2) + (q1 + q3));           // Eigen norm()
+}
+
+// sector key + column norm of the lane's column (lanes < 60)
+__device__ __forceinline__ void wave_keys_columns(const float *__restrict__ d, double *__restrict__ vkey,
+                                                  double *__restrict__ norm, int lane) {
   if (lane < NS) {
     const float4 *p = reinterpret_cast<const float4 *>(d + lane * NR);
-    double s0, s1, s2, s3, q0, q1, q2, q3;
-    {
-      float4 v = p[0];
-      double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-      s0 = x0; s1 = x1; s2 = x2; s3 = x3;
-      q0 = x0 * x0; q1 = x1 * x1; q2 = x2 * x2; q3 = x3 * x3;  // exact in fp64
-    }
-#pragma unroll
-    for (int i = 1; i < 5; i++) {
-      float4 v = p[i];
-      double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-      s0 = s0 + x0; q0 = fma(x0, x0, q0);  // x*x exact in fp64 -> fma == mul+add
-      s1 = s1 + x1; q1 = fma(x1, x1, q1);
-      s2 = s2 + x2; q2 = fma(x2, x2, q2);
-      s3 = s3 + x3; q3 = fma(x3, x3, q3);
-    }
-    vkey[lane] = ((s0 + s2) + (s1 + s3)) / (double)NR;  // SC.cpp:224 mean()
-    norm[lane] = sqrt((q0 + q2) + (q1 + q3));           // Eigen norm()
+    const float4 c[5] = {p[0], p[1], p[2], p[3], p[4]};
+    double vk, nr;
+    column_keys(c, vk, nr);
+    vkey[lane] = vk;
+    norm[lane] = nr;
   }
+}
+
+__device__ __forceinline__ void wave_keys(const float *__restrict__ d, double *__restrict__ vkey,
+                                          double *__restrict__ norm, float *__restrict__ rkey, int lane) {
+  wave_keys_columns(d, vkey, norm, lane);
   if (lane < NR) {
     double a[4];
 #pragma unroll
@@ -131,10 +177,8 @@ __device__ __forceinline__ void build_block(const char *__restrict__ pts, int64_
 constexpr double kImgScale = 32768.0;  // 2^15 on both operands of the direct filter's GEMM
 constexpr unsigned long long kEntryNonFinite = 1ull << 63;
 
-// column j of one descriptor -> 20 scaled fp16 values in st[j*20 ..]; returns (nonzero, nonfinite)
-__device__ __forceinline__ void normalise_column(const float *__restrict__ d, double nrm, _Float16 *st,
-                                                 bool &nonzero, bool &bad) {
-  const float4 *p = reinterpret_cast<const float4 *>(d);
+// one column (registers, c[i] = elements 4 i .. 4 i + 3) -> 20 scaled fp16 values in st[0 .. 20); returns (nonzero, nonfinite)
+__device__ __forceinline__ void normalise_column_regs(const float4 (&c)[5], double nrm, _Float16 *st, bool &nonzero, bool &bad) {
   nonzero = !(nrm == 0.0);  // SC.cpp:78: a column takes part unless its norm == 0
   bad = false;
   // one division per column: x * (2^15 / norm) instead of (x / norm) * 2^15 per element -- 2 ulp of fp64 apart, nothing next to
@@ -142,7 +186,7 @@ __device__ __forceinline__ void normalise_column(const float *__restrict__ d, do
   const double scale = kImgScale / nrm;
 #pragma unroll
   for (int i = 0; i < 5; i++) {
-    const float4 v = p[i];
+    const float4 v = c[i];
     const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -152,14 +196,22 @@ __device__ __forceinline__ void normalise_column(const float *__restrict__ d, do
     }
   }
 }
+// column j of one descriptor -> 20 scaled fp16 values in st[j*20 ..]; returns (nonzero, nonfinite)
+__device__ __forceinline__ void normalise_column(const float *__restrict__ d, double nrm, _Float16 *st,
+                                                 bool &nonzero, bool &bad) {
+  const float4 *p = reinterpret_cast<const float4 *>(d);
+  const float4 c[5] = {p[0], p[1], p[2], p[3], p[4]};
+  normalise_column_regs(c, nrm, st, nonzero, bad);
+}
 
 // query image of the direct filter / the window kernel from the normalised columns in st (DS halves of LDS): two displaced
 // copies of the doubled image + the column mask in the gap between them (layout: sc_filter.hip "query image"), FILTER_QIMG_BYTES
-// at `out` (global memory or LDS).  One wave.
-__device__ __forceinline__ void img_query_image(const _Float16 *st, unsigned long long m, uint4 *out, int lane) {
+// at `out` (global memory or LDS).
+// (first, step): chunk c = first, first + step, ... is written by this thread (one wave: lane, 64)
+__device__ __forceinline__ void img_query_image(const _Float16 *st, unsigned long long m, uint4 *out, int first, int step = 64) {
   typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
   constexpr int kEven = FILTER_QIMG_MASK_OFF / 16, kGap = (FILTER_QIMG_ODD - FILTER_QIMG_MASK_OFF) / 16;
-  for (int c = lane; c < FILTER_QIMG_BYTES / 16; c += 64) {
+  for (int c = first; c < FILTER_QIMG_BYTES / 16; c += step) {
     half8_t v;
     if (c < kEven) {
       const int e0 = (8 * c) % DS;  // 1200 is a multiple of 8: no wrap inside a chunk
@@ -206,13 +258,21 @@ struct KeySplit {
   float nrm;   // sqrt(sum x^2), rounded up; NaN when the key has a non-finite element or is too large (below)
   float unrm;  // the same of the unscaled key
 };
+// DPP: the two wave reductions by DPP instead of shuffle butterflies (sc_q1.hip, where they sit on the critical path of every
+// launch): the same maximum (|x| compared as integers: a NaN's bit pattern is above every number's, so it wins as well); the
+// sum of squares is taken in another order, which moves the norms -- error-bound slack, rounded up by 1e-6 -- by an ulp
+template <bool DPP = false>
 __device__ __forceinline__ KeySplit split_key(double v, int lane) {
   const double av = lane < NS ? fabs(v) : 0.0;
   double mx = av;
+  if constexpr (DPP) {
+    mx = __longlong_as_double((long long)wave_minmax_u64<true>((unsigned long long)__double_as_longlong(av)));
+  } else {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const double o = __shfl_xor(mx, off);
-    mx = (o > mx || !(o == o)) ? o : mx;  // a NaN wins
+    for (int off = 32; off >= 1; off >>= 1) {
+      const double o = __shfl_xor(mx, off);
+      mx = (o > mx || !(o == o)) ? o : mx;  // a NaN wins
+    }
   }
   KeySplit r;
   r.hi = (_Float16)0.0f;
@@ -229,8 +289,12 @@ __device__ __forceinline__ KeySplit split_key(double v, int lane) {
   const _Float16 hi = (_Float16)(float)x;
   const _Float16 lo = (_Float16)(float)(x - (double)(float)hi);
   double s = x * x;
+  if constexpr (DPP) {
+    s = wave_sum_f64(s);
+  } else {
 #pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+  }
   r.hi = hi;
   r.lo = lo;
   r.nrm = (float)(sqrt(s) * (1.0 + 1e-6));

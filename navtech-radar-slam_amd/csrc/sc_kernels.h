@@ -211,14 +211,14 @@ const char *window_kernel_name();
 // Streams the fp16 image + key image of every eligible entry once (2672 B per entry), previews every pair on the matrix cores
 // (alignment + window, as sc_window.hip does for the heads of the short lists) and scores the few entries the previews cannot
 // exclude exactly, all inside one launch; records identical to launch_pairs / the filtered path.
-// ws: q1_workspace_bytes() of device memory; d_ticket: Q1_MAX_NQ zero-initialised counters that only this function's
-// launches touch; host_ticket: their values once everything enqueued so far has run (advanced here)
+// ws: q1_workspace_bytes() of device memory; d_ticket: q1_ticket_bytes() of arrival counters, zero before the first launch
+// (every launch leaves them zero again) and touched by nothing else
 constexpr int Q1_MAX_NQ = 8;
 int q1_grid(int64_t n_items, int32_t k);
 size_t q1_workspace_bytes(int64_t n_items, int32_t nq, int32_t k);
+size_t q1_ticket_bytes();
 int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, int64_t n_eligible, const int64_t *q_elig,
-              int32_t k, rsx_sc_hit *d_out, void *ws, unsigned *d_ticket, unsigned *host_ticket, unsigned long long *d_stats,
-              hipStream_t s);
+              int32_t k, rsx_sc_hit *d_out, void *ws, unsigned *d_ticket, unsigned long long *d_stats, hipStream_t s);
 const char *q1_kernel_name();
 
 // ---- the reference's public helper methods on arbitrary double descriptors (sc_helpers.hip) ----

@@ -71,21 +71,21 @@ constexpr int Q1_MISC_CNT = 128;   // int: candidate records written so far
 constexpr int Q1_MISC_LAST = 132;  // int: this workgroup drew the last ticket
 constexpr int Q1_MISC_NSURV = 136; // int: survivors gathered in the current chunk
 constexpr int Q1_MISC_TAU = 144;   // double: the cut of the exact rounds
+constexpr int Q1_MISC_MASK = 152;  // u64: the query's column mask (between the two prep phases)
 constexpr int Q1_MISC_RED = 160;   // u64[2][4]: per-wave minima of the bound merge, double buffered
-constexpr int Q1_MISC_RKEY = 256;  // float[20]: ring key (computed with the other keys, not used)
-constexpr int Q1_MISC_BYTES = 384;
-constexpr int Q1_OFF_SCR = Q1_OFF_MISC + Q1_MISC_BYTES;  // 20816
+constexpr int Q1_MISC_BYTES = 256;
+constexpr int Q1_OFF_SCR = Q1_OFF_MISC + Q1_MISC_BYTES;  // 20688
 static_assert(Q1_OFF_SCR % 16 == 0, "alignment");
 constexpr int Q1_PART_BYTES = 3 * 32 * 64 * 4;           // one buffer of partial sums: 3 waves x 32 accumulators x 64 lanes
 constexpr int Q1_SCR_BYTES = 2 * Q1_PART_BYTES;          // 49152
-constexpr int Q1_LDS = Q1_OFF_SCR + Q1_SCR_BYTES;        // 69968: two workgroups per CU
+constexpr int Q1_LDS = Q1_OFF_SCR + Q1_SCR_BYTES;        // 69840: two workgroups per CU
 // the scratch region during prep ...
 constexpr int Q1_SCR_ST = 0;                             // _Float16[1200]: normalised columns
-constexpr int Q1_SCR_ST2 = 2432;                         // _Float16[2][128]: key staging
+constexpr int Q1_SCR_ST2 = 2432;                         // _Float16[2][128]: doubled hi / lo key
 // ... and in the last workgroup
 constexpr int Q1_FIN_ENT = 0;                            // 4 x ENT_SIZE: the waves' exact-evaluation regions
 constexpr int Q1_FIN_RES = 4 * ENT_SIZE;                 // 13632: 4 x {double dist; int idx; int shift} results of a round
-constexpr int Q1_FIN_PREF = Q1_FIN_RES + 64;             // 13696: int[G + 1] prefix sums of the candidate counts
+constexpr int Q1_FIN_PREF = Q1_FIN_RES + 64;             // 13696: int[G + 1] prefix sums of the candidate counts beyond the eager ones
 constexpr int Q1_MAX_G = 512;
 constexpr int Q1_FIN_AB = Q1_FIN_PREF + (Q1_MAX_G + 1) * 4 + 12;  // 15760: bound lists (merge), then the survivors
 static_assert(Q1_FIN_AB % 16 == 0, "alignment");
@@ -93,6 +93,17 @@ constexpr int Q1_FIN_AB_BYTES = Q1_SCR_BYTES - Q1_FIN_AB;  // 33392
 constexpr int Q1_SURV_CAP = 2048;                        // survivors of one chunk: lo[], slot[], ks[]
 static_assert(3 * 4 * Q1_SURV_CAP <= Q1_FIN_AB_BYTES, "survivor arrays fit");
 constexpr int Q1_SORT_MAX = 256;                         // chunks with at most this many survivors are evaluated in ascending lo
+// what the workgroups publish (global memory, u64 arrays per query; G = workgroups): hdr[G] = candidate count | smallest upper
+// bound << 32; ubs[16][G] = the bound list in pairs; rec[2 * Q1_EAGER][G] = the first candidate records {slot << 32 | lo bits,
+// k* | shift mask} -- all indexed by workgroup LAST, so that the last workgroup's thread j reads workgroup j and a wavefront's
+// load touches 4 cache lines instead of 64 (the first build kept one block per workgroup: 3 400 eight-byte requests out of one
+// CU for 313 workgroups, 4.4 us) -- and blk[G][...] the records beyond the eager ones
+constexpr int Q1_EAGER = 4;  // candidate records per workgroup the last workgroup requests together with the header
+static_assert(2 * Q1_EAGER * 256 <= Q1_SURV_CAP, "the eager records of 512 workgroups fit one chunk");
+// arrival counters: per query 8 group counters (workgroup b arrives at group b % 8: ~13 ns per atomic on ONE word is 4 us
+// for 313 workgroups arriving together, MI355X_MICROARCH "fanin") + one for the groups, each on its own 128-byte line
+constexpr int Q1_TICKET_STRIDE = 32;  // unsigned per counter
+constexpr int Q1_TICKETS_PER_Q = 9;
 
 struct Q1Args {
   DbView db;
@@ -102,30 +113,33 @@ struct Q1Args {
   const int64_t *q_elig;   // optional per-query limit
   rsx_sc_hit *out;         // [nq][k]
   int32_t k, kp;           // kp = k rounded up to 4: floats of a workgroup's bound list the merge reads
-  int32_t cap_wg;          // candidate records a workgroup may write (= its entries)
-  unsigned *ticket;        // [RSX_Q1_MAX_NQ] arrival counters, never reset
-  unsigned target[8];      // value of ticket[q] once every workgroup of THIS launch has arrived
-  float *ws_ub;            // [nq][G][32]
-  u64 *ws_cnt;             // [nq][G]
-  u64 *ws_cand;            // [nq][G][cap_wg][2]
+  int32_t blk;             // u64 per workgroup in ws_blk: 2 x (its entries beyond the eager records)
+  unsigned *ticket;        // [nq][Q1_TICKETS_PER_Q][Q1_TICKET_STRIDE]: zero between launches (the last workgroup resets them)
+  u64 *ws_hdr, *ws_ubs, *ws_rec, *ws_blk;  // [nq][G], [nq][16][G], [nq][2 * Q1_EAGER][G], [nq][G][blk]
   unsigned long long *stats;  // optional (profiling): RESCORE_STAT_WORDS counters
 };
 
 __device__ __forceinline__ void store_sc1(u64 *p, u64 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ u64 load_sc1(const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ u64 wave_min_u64(u64 v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) {
-    const u64 o = __shfl_xor(v, off);
-    v = o < v ? o : v;
-  }
-  return v;
-}
+__device__ __forceinline__ u64 wave_min_u64(u64 v) { return dev::wave_minmax_u64<false>(v); }
+
+// RSX_EXPERIMENTS builds with profiling on: the last workgroup adds the length of its phases (10-ns ticks of the constant
+// clock) to stats words 4..10, 13, 14: prep | tiles | publish | ticket | header loads | bound merge | total | eager rounds | rest
+#ifdef RSX_EXPERIMENTS
+#define Q1_MARK(i) do { if (a.stats) tmark[i] = wall_clock64(); } while (0)
+#else
+#define Q1_MARK(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef RSX_EXPERIMENTS
+  unsigned long long tmark[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  Q1_MARK(0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // in an SGPR: everything decided per wave is a scalar branch
   const int n = lane & 31, hh = lane >> 5;
   const int G = (int)gridDim.x, b = (int)blockIdx.x, qi = (int)blockIdx.y;
   char *misc = smem + Q1_OFF_MISC;
@@ -145,10 +159,18 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   }
   const int ntiles = (int)((n_rows + 31) >> 5);
 
+  // ---- the query's column of this lane, requested FIRST (a wave's loads return in order: behind the tile's fragments the
+  // 4.8 KB of the query would wait for 27 KB per wave; waves 0 and 1 each keep a copy) ----
+  float4 qcol[5] = {};
+  if (wave < 2 && lane < NS) {
+    const float4 *src = reinterpret_cast<const float4 *>(a.qdesc + (int64_t)qi * DS + lane * NR);
+#pragma unroll
+    for (int i = 0; i < 5; i++) qcol[i] = src[i];
+  }
   // ---- database fragments of one tile: this wave's K-steps of the image, and for the tile's epilogue wave the key
   // fragments (requested first: VMEM returns in order and the alignment runs while the image is still on its way) ----
   const int ks0 = Q1_KS * wave;
-  const int nst = W_STEPS - ks0 < Q1_KS ? W_STEPS - ks0 : Q1_KS;  // 19, 19, 19, 18
+  const bool full = wave != 3;  // K-steps of this wave: 19, 19, 19, 18
   half8 frag[Q1_KS];
   half8 bh[4], bl[4];
   float2 en = {0.0f, 0.0f};
@@ -167,46 +189,54 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
     }
     const half8 *bt = static_cast<const half8 *>(a.db.hnT) + ((int64_t)t * W_STEPS + ks0) * 64 + lane;
 #pragma unroll
-    for (int u = 0; u < Q1_KS; u++)
-      if (u < nst) frag[u] = bt[u * 64];
+    for (int u = 0; u < Q1_KS - 1; u++) frag[u] = bt[u * 64];
+    if (full) frag[Q1_KS - 1] = bt[(Q1_KS - 1) * 64];
   };
   if (b < ntiles) issue(b, 0);
 
-  // ---- the query's images, built here (what sc_keys / sc_img_query / sc_win_query_keys do for a batch) ----
-  {
-    float4 *qf = reinterpret_cast<float4 *>(smem + Q1_OFF_Q);
-    const float4 *src = reinterpret_cast<const float4 *>(a.qdesc + (int64_t)qi * DS);
-    for (int i = tid; i < DS / 4; i += 256) qf[i] = src[i];
-    if (tid < 32) s_ub[tid] = INFINITY;
-    if (tid == 0) *s_cnt = 0;
-  }
-  __syncthreads();
-  double *qn1 = reinterpret_cast<double *>(smem + Q1_OFF_Q + WaveLds::OFF_QN1);
-  double *qv1 = reinterpret_cast<double *>(smem + Q1_OFF_Q + WaveLds::OFF_QV1);
-  if (wave == 0)
-    dev::wave_keys(reinterpret_cast<const float *>(smem + Q1_OFF_Q), qv1, qn1, reinterpret_cast<float *>(misc + Q1_MISC_RKEY), lane);
-  __syncthreads();
+  // ---- the query's images, built here (what sc_keys / sc_img_query / sc_win_query_keys do for a batch): wave 0 the column
+  // norms + normalised columns (and the fp32 copy the exact evaluation reads), wave 1 the doubled hi / lo key, then every
+  // thread a share of the two displaced image copies and the 16 displaced key copies ----
+  if (tid < 32) s_ub[tid] = INFINITY;
+  if (tid == 0) *s_cnt = 0;
+  _Float16 *st = reinterpret_cast<_Float16 *>(scr + Q1_SCR_ST);
+  _Float16(*st2)[128] = reinterpret_cast<_Float16(*)[128]>(scr + Q1_SCR_ST2);
+  dev::KeySplit ksplit{};
   if (wave == 0) {
-    _Float16 *st = reinterpret_cast<_Float16 *>(scr + Q1_SCR_ST);
+    double vk = 0.0, nr = 0.0;
+    dev::column_keys(qcol, vk, nr);
     bool nonzero = false, bad = false;
-    if (lane < NS)
-      dev::normalise_column(reinterpret_cast<const float *>(smem + Q1_OFF_Q) + lane * NR, qn1[lane], &st[lane * NR], nonzero, bad);
+    if (lane < NS) {
+      float4 *qf = reinterpret_cast<float4 *>(smem + Q1_OFF_Q) + lane * (NR / 4);
+#pragma unroll
+      for (int i = 0; i < 5; i++) qf[i] = qcol[i];
+      reinterpret_cast<double *>(smem + Q1_OFF_Q + WaveLds::OFF_QN1)[lane] = nr;
+      reinterpret_cast<double *>(smem + Q1_OFF_Q + WaveLds::OFF_QV1)[lane] = vk;
+      dev::normalise_column_regs(qcol, nr, &st[lane * NR], nonzero, bad);
+    }
     u64 m = __ballot(nonzero && lane < NS);
     if (__ballot(bad && lane < NS)) m |= kNonFinite;
-    wave_lds_fence();
-    dev::img_query_image(st, m, reinterpret_cast<uint4 *>(smem + Q1_OFF_QIMG), lane);
+    if (lane == 0) *reinterpret_cast<u64 *>(misc + Q1_MISC_MASK) = m;
   } else if (wave == 1) {
-    win::query_keys_image(lane < NS ? qv1[lane] : 0.0, reinterpret_cast<_Float16(*)[128]>(scr + Q1_SCR_ST2), smem + Q1_OFF_QK, lane);
+    double vk = 0.0, nr = 0.0;
+    dev::column_keys(qcol, vk, nr);
+    ksplit = win::query_keys_stage<true>(lane < NS ? vk : 0.0, st2, lane);
   }
   __syncthreads();
+  dev::img_query_image(st, *reinterpret_cast<const u64 *>(misc + Q1_MISC_MASK), reinterpret_cast<uint4 *>(smem + Q1_OFF_QIMG), tid, 256);
+  win::query_keys_copies(st2, smem + Q1_OFF_QK, tid, 256);
+  if (wave == 1) win::query_keys_norms(ksplit, smem + Q1_OFF_QK, lane);
+  __syncthreads();
 
+  Q1_MARK(1);
   const u64 qm = *reinterpret_cast<const u64 *>(smem + Q1_OFF_QIMG + FILTER_QIMG_MASK_OFF);
   const float nq_key = *reinterpret_cast<const float *>(smem + Q1_OFF_QK + QK_NORM);
   const float uq_key = *reinterpret_cast<const float *>(smem + Q1_OFF_QK + QK_NORM + 4);
   // A-fragment addresses of this lane's row (shift n of tile 0; tile 1 = the same address + 40 K-steps, sc_filter.hip)
   const char *ap = smem + Q1_OFF_QIMG + ((n & 1) ? (FILTER_QIMG_ODD + 40 * n - 8) : (40 * n)) + 16 * hh + 32 * ks0;
   const char *kp = smem + Q1_OFF_QK + (n & 7) * QK_COPY + ((n & ~7) + 8 * hh) * 2;  // tile 1: + 64 B
-  u64 *my_cand = a.ws_cand + ((int64_t)qi * G + b) * a.cap_wg * 2;
+  u64 *my_rec = a.ws_rec + (int64_t)qi * (2 * Q1_EAGER) * G + b;   // eager record e: [2 e] and [2 e + 1], stride G
+  u64 *my_blk = a.ws_blk + ((int64_t)qi * G + b) * a.blk;
 
   int it = 0;
   for (int t = b; t < ntiles; t += G, it++) {
@@ -230,13 +260,13 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
         k0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, bh[s], k0, 0, 0, 0);
         k1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, bh[s], k1, 0, 0, 0);
       }
-      win::alignment_of(k0, k1, nq_key, uq_key, en, hh, win, kstar);
+      win::alignment_of<true>(k0, k1, nq_key, uq_key, en, hh, win, kstar);
     }
     // ---- this wave's K-steps of the 60 correlation values (the direct filter's GEMM) ----
     floatx16 acc0 = {0}, acc1 = {0};
 #pragma unroll
     for (int u = 0; u < Q1_KS; u++) {
-      if (u < nst) {
+      if (u < Q1_KS - 1 || full) {
         const half8 a0 = *reinterpret_cast<const half8 *>(ap + 32 * u);
         const half8 a1 = *reinterpret_cast<const half8 *>(ap + 32 * (u + W_TILE1));
         acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, frag[u], acc0, 0, 0, 0);
@@ -266,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
           acc1[4 * r4] += p1.x; acc1[4 * r4 + 1] += p1.y; acc1[4 * r4 + 2] += p1.z; acc1[4 * r4 + 3] += p1.w;
         }
       }
-      const float pv = win::preview_of(acc0, acc1, qm, em_t, win, kstar, hh);
+      const float pv = win::preview_of<true>(acc0, acc1, qm, em_t, win, kstar, hh);
       // ---- the entry's bounds: lanes 0..31 carry entry t * 32 + n (lanes 32..63 hold the same values) ----
       const int64_t slot = (int64_t)t * 32 + n;
       const bool have = hh == 0 && slot < n_rows;
@@ -275,12 +305,17 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
       if (have) lo = (pv == pv) ? pv - WINDOW_MARGIN : -INFINITY;  // NaN: no preview (non-finite data), must be looked at
       // the workgroup's k smallest upper bounds, ascending, one per lane
       float lub = s_ub[n];
-      float kth = __shfl(lub, a.k - 1);
-      u64 pend = __ballot(ub < kth);
+      auto lane_of = [](float x, int l) { return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(x), l)); };
+      float kth = lane_of(lub, a.k - 1);
+      if (a.k == 1) {  // (the detector's case: the list is one value)
+        kth = fminf(kth, wave_min_f32(ub));
+        lub = lane == 0 ? kth : lub;
+      }
+      u64 pend = a.k == 1 ? 0ull : __ballot(ub < kth);
       while (pend) {
         const int l = __ffsll((long long)pend) - 1;
         pend &= pend - 1;
-        const float v = __shfl(ub, l);
+        const float v = lane_of(ub, l);
         if (!(v < kth)) continue;
         const int pos = __popcll(__ballot(lane < a.k && lub <= v));  // < k: lub[k - 1] = kth > v
         const float up = __shfl_up(lub, 1);
@@ -288,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
           if (lane > pos) lub = up;
           else if (lane == pos) lub = v;
         }
-        kth = __shfl(lub, a.k - 1);
+        kth = lane_of(lub, a.k - 1);
       }
       if (lane < 32) s_ub[lane] = lub;
       // candidates: lower bound not above the workgroup's k-th smallest upper bound (which is never below the chip's)
@@ -298,8 +333,10 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
         const int base = *s_cnt;
         if (cand) {
           const int pos = base + __popcll(cb & ((1ull << lane) - 1ull));
-          store_sc1(my_cand + 2 * pos, ((u64)(unsigned)slot << 32) | (u64)__float_as_uint(lo));
-          store_sc1(my_cand + 2 * pos + 1, (u64)(unsigned)kstar);
+          u64 *r0 = pos < Q1_EAGER ? my_rec + (int64_t)(2 * pos) * G : my_blk + 2 * (pos - Q1_EAGER);
+          u64 *r1 = pos < Q1_EAGER ? r0 + G : r0 + 1;
+          store_sc1(r0, ((u64)(unsigned)slot << 32) | (u64)__float_as_uint(lo));
+          store_sc1(r1, (u64)(unsigned)kstar);
         }
         wave_lds_fence();
         if (lane == 0) *s_cnt = base + __popcll(cb);
@@ -307,52 +344,96 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
     }
   }
   __syncthreads();
+  Q1_MARK(2);
 
   // ---- publish: the bound list and the candidate count of this workgroup, then the arrival ticket ----
   if (wave == 0) {
-    u64 *ubo = reinterpret_cast<u64 *>(a.ws_ub + ((int64_t)qi * G + b) * 32);
-    if (lane < 16) store_sc1(ubo + lane, reinterpret_cast<const u64 *>(s_ub)[lane]);
-    if (lane == 16) store_sc1(a.ws_cnt + (int64_t)qi * G + b, (u64)(unsigned)*s_cnt);
+    if (a.k > 1 && lane < (a.kp >> 1))
+      store_sc1(a.ws_ubs + ((int64_t)qi * 16 + lane) * G + b, reinterpret_cast<const u64 *>(s_ub)[lane]);
+    if (lane == 16) store_sc1(a.ws_hdr + (int64_t)qi * G + b, (u64)(unsigned)*s_cnt | ((u64)__float_as_uint(s_ub[0]) << 32));
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its write-through stores have left
   __syncthreads();
+  Q1_MARK(3);
+  unsigned *tk = a.ticket + (size_t)qi * Q1_TICKETS_PER_Q * Q1_TICKET_STRIDE;
   if (tid == 0) {
-    const unsigned old = __hip_atomic_fetch_add(a.ticket + qi, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    *reinterpret_cast<int *>(misc + Q1_MISC_LAST) = (old + 1u == a.target[qi]) ? 1 : 0;
+    const int grp = b & 7;
+    const unsigned members = (unsigned)((G - grp + 7) >> 3), groups = (unsigned)(G < 8 ? G : 8);
+    int last = 0;
+    const unsigned old = __hip_atomic_fetch_add(tk + grp * Q1_TICKET_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == members) {
+      const unsigned old2 = __hip_atomic_fetch_add(tk + 8 * Q1_TICKET_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (old2 + 1u == groups) ? 1 : 0;
+    }
+    *reinterpret_cast<int *>(misc + Q1_MISC_LAST) = last;
   }
   __syncthreads();
   if (*reinterpret_cast<const int *>(misc + Q1_MISC_LAST) == 0) return;
+  Q1_MARK(4);
 
   // =============================== the last workgroup ===============================
+  if (tid < Q1_TICKETS_PER_Q)  // the counters of this query are zero again when the next launch arrives
+    __hip_atomic_store(tk + tid * Q1_TICKET_STRIDE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int *s_pref = reinterpret_cast<int *>(scr + Q1_FIN_PREF);
-  // ---- the bound lists of every workgroup -> LDS, candidate counts -> prefix sums ----
+  // ---- ONE memory round trip: of every workgroup (two per thread) the candidate count + smallest bound, the first
+  // Q1_EAGER candidate records and (k > 1) the bound list (straight-line write-through loads: the compiler batches them; in
+  // a loop each would wait for the one before) ----
+  u64 hdr_r[2], rec[2][2 * Q1_EAGER], lst[2][16];
+  const int kp2 = a.k > 1 ? (a.kp >> 1) : 0;
+#pragma unroll
+  for (int o = 0; o < 2; o++) {
+    const int j = tid + 256 * o;
+    const bool own = j < G;
+    const int jj = own ? j : 0;
+    hdr_r[o] = own ? load_sc1(a.ws_hdr + (int64_t)qi * G + jj) : 0;
+#pragma unroll
+    for (int c = 0; c < 2 * Q1_EAGER; c++) rec[o][c] = own ? load_sc1(a.ws_rec + ((int64_t)qi * (2 * Q1_EAGER) + c) * G + jj) : 0;
+#pragma unroll
+    for (int c = 0; c < 16; c++) lst[o][c] = (own && c < kp2) ? load_sc1(a.ws_ubs + ((int64_t)qi * 16 + c) * G + jj) : 0;
+  }
+  int *s_total = reinterpret_cast<int *>(misc + Q1_MISC_NSURV);  // (free until the survivors are gathered)
+  if (tid == 0) *s_total = 0;
+  __syncthreads();
   {
-    float *L = reinterpret_cast<float *>(scr + Q1_FIN_AB);
-    const int kp2 = a.kp >> 1;
-    for (int i = tid; i < G * kp2; i += 256) {
-      const int j = i / kp2, c = i - j * kp2;
-      const u64 v = load_sc1(reinterpret_cast<const u64 *>(a.ws_ub + ((int64_t)qi * G + j) * 32) + c);
-      reinterpret_cast<u64 *>(L)[j * kp2 + c] = v;
+    u64 *L = reinterpret_cast<u64 *>(scr + Q1_FIN_AB);
+    int extra_mine = 0;
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+      const int j = tid + 256 * o;
+      if (j < G) {
+        if (a.k > 1) {
+#pragma unroll
+          for (int c = 0; c < 16; c++)
+            if (c < kp2) L[j * kp2 + c] = lst[o][c];
+        } else {
+          reinterpret_cast<float *>(L)[j * a.kp] = __uint_as_float((unsigned)(hdr_r[o] >> 32));
+        }
+        const int extra = (int)(unsigned)hdr_r[o] - Q1_EAGER;
+        s_pref[j + 1] = extra > 0 ? extra : 0;
+        extra_mine += extra > 0 ? extra : 0;
+      }
     }
-    for (int j = tid; j < G; j += 256) s_pref[j + 1] = (int)load_sc1(a.ws_cnt + (int64_t)qi * G + j);
     if (tid == 0) s_pref[0] = 0;
+    if (extra_mine) atomicAdd(s_total, extra_mine);
   }
   __syncthreads();
-  if (wave == 0) {  // inclusive scan of s_pref[1 .. G] (G <= 512: 8 per lane)
-    int v[8], s = 0;
+  Q1_MARK(5);
+  const int total = *s_total;  // candidate records beyond the eager ones
+  if (total > 0 && wave == 0) {  // inclusive scan of s_pref[1 .. G] (G <= 512: 8 per lane); read after later barriers only
+    int v[8], sum = 0;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const int j = lane * 8 + i;
       v[i] = j < G ? s_pref[j + 1] : 0;
-      s += v[i];
+      sum += v[i];
     }
-    int inc = s;
+    int inc = sum;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
       const int o = __shfl_up(inc, off);
       if (lane >= off) inc += o;
     }
-    int run = inc - s;
+    int run = inc - sum;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const int j = lane * 8 + i;
@@ -394,8 +475,10 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
     }
   }
   __syncthreads();  // the lists are dead: their space holds the survivors from here on
+  Q1_MARK(6);
 
-  // ---- candidates that can still reach the bound, in chunks; exact evaluation four per round ----
+  // ---- candidates that can still reach the bound (first the eager records, then the rest in chunks); exact evaluation four
+  // per round, the next round's entries requested before the current ones are evaluated ----
   float *s_lo = reinterpret_cast<float *>(scr + Q1_FIN_AB);
   int *s_slot = reinterpret_cast<int *>(s_lo + Q1_SURV_CAP);
   int *s_ks = s_slot + Q1_SURV_CAP;
@@ -408,46 +491,30 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   Res *s_res = reinterpret_cast<Res *>(scr + Q1_FIN_RES);
   char *wsm = scr + Q1_FIN_ENT + wave * ENT_SIZE;
   const char *qsm = smem + Q1_OFF_Q;
-  const int total = s_pref[G];
   double ld = INFINITY;  // wave 0: the sorted top-k of exact hits, one record per lane
   int li = 0x7fffffff, ls = 0;
   double tau = (double)tau_ub;
-  unsigned n_exact = 0, n_aligned = 0, n_shifts = 0, n_surv_all = 0;
-  for (int base = 0; base < total; base += Q1_SURV_CAP) {
-    if (tid == 0) *s_nsurv = 0;
-    __syncthreads();
-    const int lim = total - base < Q1_SURV_CAP ? total - base : Q1_SURV_CAP;
-    for (int e = tid; e < lim; e += 256) {
-      const int ge = base + e;
-      int lo_j = 0, hi_j = G;  // the workgroup j with s_pref[j] <= ge < s_pref[j + 1]
-      while (hi_j - lo_j > 1) {
-        const int mid = (lo_j + hi_j) >> 1;
-        if (s_pref[mid] <= ge) lo_j = mid;
-        else hi_j = mid;
-      }
-      const u64 *rec = a.ws_cand + (((int64_t)qi * G + lo_j) * a.cap_wg + (ge - s_pref[lo_j])) * 2;
-      const u64 ra = load_sc1(rec), rb = load_sc1(rec + 1);
-      const float lo = __uint_as_float((unsigned)ra);
-      if (!((double)lo > tau)) {
-        const int i = atomicAdd(s_nsurv, 1);
-        s_lo[i] = lo;
-        s_slot[i] = (int)(ra >> 32);
-        s_ks[i] = (int)(unsigned)rb;
-      }
+  unsigned n_exact = 0, n_aligned = 0, n_shifts = 0, n_surv_all = 0, n_cand_all = 0;
+
+  auto keep = [&](u64 ra, u64 rb) {  // a candidate record whose lower bound can still reach the cut -> survivor list
+    const float lo = __uint_as_float((unsigned)ra);
+    if (!((double)lo > tau)) {
+      const int i = atomicAdd(s_nsurv, 1);
+      s_lo[i] = lo;
+      s_slot[i] = (int)(ra >> 32);
+      s_ks[i] = (int)(unsigned)rb;
     }
-    __syncthreads();
+  };
+  auto rounds = [&]() {  // the survivors in s_lo / s_slot / s_ks [0, *s_nsurv): exact evaluation (all threads call this)
     const int ns = *s_nsurv;
     n_surv_all += (unsigned)ns;
-    if (ns == 0) continue;  // uniform
-    // bring the survivors' descriptors towards this CU while the order is worked out (one memory latency for all of them)
-    {
-      Touch tch;
-      for (int i = wave; i < ns && i < 64; i += 4) touch_entry(a.db, s_slot[i], lane, tch);
-      // ascending (lo, slot) when there are few: the exact k-th best then takes over early and the tail is cut
+    if (ns == 0) return;  // uniform
+    // ascending (lo, slot) when there are few: the exact k-th best then takes over early and the tail is cut
+    const bool sorted = ns <= Q1_SORT_MAX;
+    if (sorted && ns > 1) {
       float my_lo = 0.0f;
       int my_slot = 0, my_ks = 0, rank = 0;
-      const bool sorted = ns <= Q1_SORT_MAX;
-      if (sorted && tid < ns) {
+      if (tid < ns) {
         my_lo = s_lo[tid];
         my_slot = s_slot[tid];
         my_ks = s_ks[tid];
@@ -458,61 +525,108 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
         }
       }
       __syncthreads();
-      if (sorted && tid < ns) {
+      if (tid < ns) {
         s_lo[rank] = my_lo;
         s_slot[rank] = my_slot;
         s_ks[rank] = my_ks;
       }
-      touch_wait(tch);
       __syncthreads();
-      for (int i0 = 0; i0 < ns; i0 += 4) {
-        if (sorted && (double)s_lo[i0] > tau) break;  // everything after it is larger still (uniform)
-        const int i = i0 + wave;
-        Res r;
-        r.d = INFINITY;
-        r.idx = 0;
-        r.shift = 0;
-        if (i < ns && !((double)s_lo[i] > tau)) {  // (wave-uniform)
-          const int64_t slot = s_slot[i];
-          const int ksm = s_ks[i];
-          EntryRegs er;
-          load_entry(a.db, slot, lane, er);
-          int ks = ksm;
-          unsigned tmask = 0x7fu;
-          if (ksm >= 0) {  // k* and the shifts of its window that can be the minimum (sc_window_dev.h)
-            ks = ksm & 63;
-            const unsigned m7 = ((unsigned)ksm >> 8) & 0x7fu;
-            if (m7) tmask = m7;
-          }
-          if (ks < 0) {
-            ks = align_exact(reinterpret_cast<const double *>(qsm + WaveLds::OFF_QV1), wsm, lane, er.v);
-            n_aligned++;
-          }
-          double bd;
-          int bk;
-          phase_b32(qsm, wsm, lane, er, ks, tmask, bd, bk);
-          n_exact++;
-          n_shifts += (unsigned)__builtin_popcount(tmask);
-          r.d = bd;
-          r.idx = (int)(a.db.idx_base + slot * a.db.idx_stride);
-          r.shift = bk;
+    }
+    EntryRegs cur, nxt;
+    if (wave < ns && !((double)s_lo[wave] > tau)) load_entry(a.db, s_slot[wave], lane, cur);
+    for (int i0 = 0; i0 < ns; i0 += 4) {
+      if (sorted && (double)s_lo[i0] > tau) break;  // everything after it is larger still (uniform)
+      const int i = i0 + wave;
+      // (tau only decreases: an entry that is evaluated below passed this test when its registers were requested)
+      if (i + 4 < ns && !((double)s_lo[i + 4] > tau)) load_entry(a.db, s_slot[i + 4], lane, nxt);
+      Res r;
+      r.d = INFINITY;
+      r.idx = 0;
+      r.shift = 0;
+      if (i < ns && !((double)s_lo[i] > tau)) {  // (wave-uniform)
+        const int64_t slot = s_slot[i];
+        const int ksm = s_ks[i];
+        int ks = ksm;
+        unsigned tmask = 0x7fu;
+        if (ksm >= 0) {  // k* and the shifts of its window that can be the minimum (sc_window_dev.h)
+          ks = ksm & 63;
+          const unsigned m7 = ((unsigned)ksm >> 8) & 0x7fu;
+          if (m7) tmask = m7;
         }
-        if (lane == 0) s_res[wave] = r;
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll 1
-          for (int w = 0; w < 4; w++) {
-            const Res o = s_res[w];
-            if (o.d < kBig) topk_insert(ld, li, ls, lane, a.k, o.d, o.idx, o.shift);
-          }
-          const double kd = __shfl(ld, a.k - 1);
-          if (lane == 0) *s_tau = kd < (double)tau_ub ? kd : (double)tau_ub;
+        if (ks < 0) {
+          ks = align_exact(reinterpret_cast<const double *>(qsm + WaveLds::OFF_QV1), wsm, lane, cur.v);
+          n_aligned++;
         }
-        __syncthreads();
-        tau = *s_tau;
+        double bd;
+        int bk;
+        phase_b32(qsm, wsm, lane, cur, ks, tmask, bd, bk);
+        n_exact++;
+        n_shifts += (unsigned)__builtin_popcount(tmask);
+        r.d = bd;
+        r.idx = (int)(a.db.idx_base + slot * a.db.idx_stride);
+        r.shift = bk;
       }
+      if (lane == 0) s_res[wave] = r;
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll 1
+        for (int w = 0; w < 4; w++) {
+          const Res o = s_res[w];
+          if (o.d < kBig) topk_insert(ld, li, ls, lane, a.k, o.d, o.idx, o.shift);
+        }
+        const double kd = __shfl(ld, a.k - 1);
+        if (lane == 0) *s_tau = kd < (double)tau_ub ? kd : (double)tau_ub;
+      }
+      __syncthreads();
+      tau = *s_tau;
+      cur = nxt;
+    }
+  };
+
+  if (tid == 0) *s_nsurv = 0;
+  __syncthreads();
+#pragma unroll
+  for (int o = 0; o < 2; o++) {
+    const int cnt = (int)(unsigned)hdr_r[o];
+    n_cand_all += (unsigned)cnt;
+#pragma unroll
+    for (int c = 0; c < Q1_EAGER; c++)
+      if (c < cnt) keep(rec[o][2 * c], rec[o][2 * c + 1]);
+  }
+  __syncthreads();
+  rounds();
+  Q1_MARK(7);
+  for (int base = 0; base < total; base += Q1_SURV_CAP) {
+    __syncthreads();
+    if (tid == 0) *s_nsurv = 0;
+    __syncthreads();
+    const int lim = total - base < Q1_SURV_CAP ? total - base : Q1_SURV_CAP;
+    for (int e0 = 0; e0 < lim; e0 += 4 * 256) {  // four records per thread in flight
+      u64 ra[4], rb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int e = e0 + tid + 256 * u;
+        ra[u] = 0;
+        rb[u] = 0;
+        if (e < lim) {
+          const int ge = base + e;
+          int lo_j = 0, hi_j = G;  // the workgroup j with s_pref[j] <= ge < s_pref[j + 1]
+          while (hi_j - lo_j > 1) {
+            const int mid = (lo_j + hi_j) >> 1;
+            if (s_pref[mid] <= ge) lo_j = mid;
+            else hi_j = mid;
+          }
+          const u64 *r = a.ws_blk + ((int64_t)qi * G + lo_j) * a.blk + 2 * (ge - s_pref[lo_j]);
+          ra[u] = load_sc1(r);
+          rb[u] = load_sc1(r + 1);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+        if (e0 + tid + 256 * u < lim) keep(ra[u], rb[u]);
     }
     __syncthreads();
+    rounds();
   }
   if (wave == 0 && lane < a.k) {
     rsx_sc_hit h;
@@ -530,10 +644,17 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
       atomicAdd(st + 11, (unsigned long long)n_aligned);
       atomicAdd(st + 12, (unsigned long long)n_shifts);
     }
+    atomicAdd(st + 3, (unsigned long long)n_cand_all);
     if (tid == 0) {
       atomicAdd(st, (unsigned long long)n_surv_all);
-      atomicAdd(st + 3, (unsigned long long)total);
       atomicAdd(st + 1, 1ull);
+#ifdef RSX_EXPERIMENTS
+      Q1_MARK(8);
+      for (int i = 0; i < 6; i++) atomicAdd(st + 4 + i, tmark[i + 1] - tmark[i]);
+      atomicAdd(st + 10, tmark[8] - tmark[0]);
+      atomicAdd(st + 13, tmark[7] - tmark[6]);
+      atomicAdd(st + 14, tmark[8] - tmark[7]);
+#endif
     }
   }
 }
@@ -545,25 +666,27 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
 int q1_grid(int64_t n_items, int32_t k) {
   const int64_t ntiles = (n_items + 31) / 32;
   const int kp = (k + 3) & ~3;
-  int gmax = Q1_FIN_AB_BYTES / (kp * 4);
-  if (gmax > Q1_MAX_G) gmax = Q1_MAX_G;
-  if (gmax > 256) gmax = 512;  // whole CUs' worth: 256 or 512
-  else gmax = 256;
+  const int gmax = (Q1_FIN_AB_BYTES / (kp * 4) >= Q1_MAX_G) ? Q1_MAX_G : 256;  // whole CUs' worth: 512 up to k = 16, else 256
   return (int)(ntiles < 1 ? 1 : (ntiles < gmax ? ntiles : gmax));
+}
+
+static int64_t q1_block_u64(int64_t n_items, int g) {
+  const int64_t ntiles = (n_items + 31) / 32;
+  const int64_t ent = ((ntiles + g - 1) / g) * 32;  // entries of one workgroup = candidate records it may write
+  return 2 * (ent > Q1_EAGER ? ent - Q1_EAGER : 1);
 }
 
 size_t q1_workspace_bytes(int64_t n_items, int32_t nq, int32_t k) {
   const int g = q1_grid(n_items, k);
-  const int64_t ntiles = (n_items + 31) / 32;
-  const int64_t cap_wg = ((ntiles + g - 1) / g) * 32;
-  return (size_t)nq * g * (128 + 8 + (size_t)(cap_wg > 32 ? cap_wg : 32) * 16) + 256;
+  return (size_t)nq * g * (1 + 16 + 2 * Q1_EAGER + q1_block_u64(n_items, g)) * 8 + 256;
 }
+
+size_t q1_ticket_bytes() { return (size_t)Q1_MAX_NQ * Q1_TICKETS_PER_Q * Q1_TICKET_STRIDE * sizeof(unsigned); }
 
 const char *q1_kernel_name() { return "sc_q1_kernel"; }
 
 int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, int64_t n_eligible, const int64_t *q_elig,
-              int32_t k, rsx_sc_hit *d_out, void *ws, unsigned *d_ticket, unsigned *host_ticket, unsigned long long *d_stats,
-              hipStream_t s) {
+              int32_t k, rsx_sc_hit *d_out, void *ws, unsigned *d_ticket, unsigned long long *d_stats, hipStream_t s) {
   if (nq <= 0) return RSX_OK;
   if (nq > Q1_MAX_NQ) return fail(RSX_ERR_BAD_ARG, "the single-query path takes at most %d queries", Q1_MAX_NQ);
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
@@ -580,8 +703,6 @@ int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, i
     }
   }
   const int g = q1_grid(n_items, k);
-  const int64_t ntiles = (n_items + 31) / 32;
-  const int64_t cap_wg = ((ntiles + g - 1) / g) * 32;
   Q1Args a;
   a.db = db;
   a.qdesc = d_q;
@@ -591,19 +712,15 @@ int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, i
   a.out = d_out;
   a.k = k;
   a.kp = (k + 3) & ~3;
-  a.cap_wg = (int32_t)(cap_wg > 32 ? cap_wg : 32);
+  a.blk = (int32_t)q1_block_u64(n_items, g);
   a.ticket = d_ticket;
-  for (int q = 0; q < Q1_MAX_NQ; q++) a.target[q] = host_ticket[q] + (q < nq ? (unsigned)g : 0u);
-  char *w = static_cast<char *>(ws);
-  a.ws_ub = reinterpret_cast<float *>(w);
-  w += (size_t)nq * g * 128;
-  a.ws_cnt = reinterpret_cast<u64 *>(w);
-  w += (size_t)nq * g * 8;
-  a.ws_cand = reinterpret_cast<u64 *>(w);
+  a.ws_hdr = static_cast<u64 *>(ws);
+  a.ws_ubs = a.ws_hdr + (size_t)nq * g;
+  a.ws_rec = a.ws_ubs + (size_t)nq * 16 * g;
+  a.ws_blk = a.ws_rec + (size_t)nq * 2 * Q1_EAGER * g;
   a.stats = d_stats;
   hipLaunchKernelGGL(sc_q1_kernel, dim3((unsigned)g, (unsigned)nq), dim3(256), Q1_LDS, s, a);
   RSX_HIP(hipGetLastError());
-  for (int q = 0; q < nq; q++) host_ticket[q] += (unsigned)g;  // only once the launch is in the queue
   return RSX_OK;
 }
 

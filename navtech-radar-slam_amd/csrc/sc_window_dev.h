@@ -33,10 +33,10 @@ constexpr int W_LDS = FILTER_QIMG_BYTES + WINDOW_QK_BYTES;  // 14608
 // query side of the alignment: row k of the circulant reads the doubled key q2[k .. k + 63] (q2[i] = key[i % 60]); 8 copies
 // displaced by one element each keep that read 16-byte aligned (row k: copy k % 8 at element k - k % 8), and the copy stride
 // of 18 sixteen-byte slots keeps the 16 rows a ds_read_b128 serves together on 16 different slots mod 16.
-// One wave; v = the query's sector key, one element per lane; st = 2 x 128 halves of LDS staging; out = WINDOW_QK_BYTES
-// (global memory or LDS)
-__device__ __forceinline__ void query_keys_image(double v, _Float16 (*st)[128], char *out, int lane) {
-  const dev::KeySplit k = dev::split_key(lane < NS ? v : 0.0, lane);
+// Stage (one wave; v = the query's sector key, one element per lane): the doubled hi / lo keys into st (2 x 128 halves of LDS)
+template <bool DPP = false>
+__device__ __forceinline__ dev::KeySplit query_keys_stage(double v, _Float16 (*st)[128], int lane) {
+  const dev::KeySplit k = dev::split_key<DPP>(lane < NS ? v : 0.0, lane);
   if (lane < NS) {
     st[0][lane] = k.hi;
     st[1][lane] = k.lo;
@@ -47,9 +47,11 @@ __device__ __forceinline__ void query_keys_image(double v, _Float16 (*st)[128], 
     st[0][2 * NS + lane] = (_Float16)0.0f;
     st[1][2 * NS + lane] = (_Float16)0.0f;
   }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < 2 * 8 * (QK_COPY / 2); i += 64) {
+  return k;
+}
+// the 2 x 8 displaced copies from st: element i = first, first + step, ... by this thread; out = WINDOW_QK_BYTES (global or LDS)
+__device__ __forceinline__ void query_keys_copies(const _Float16 (*st)[128], char *out, int first, int step) {
+  for (int i = first; i < 2 * 8 * (QK_COPY / 2); i += step) {
     const int part = i / (8 * (QK_COPY / 2));
     const int r = i % (8 * (QK_COPY / 2));
     const int c = r / (QK_COPY / 2), el = r % (QK_COPY / 2);
@@ -57,13 +59,25 @@ __device__ __forceinline__ void query_keys_image(double v, _Float16 (*st)[128], 
     const _Float16 v16 = src < 2 * NS ? st[part][src] : (_Float16)0.0f;
     *reinterpret_cast<_Float16 *>(out + part * QK_LO + c * QK_COPY + el * 2) = v16;
   }
+}
+__device__ __forceinline__ void query_keys_norms(const dev::KeySplit &k, char *out, int lane) {
   if (lane < 4) *reinterpret_cast<float *>(out + QK_NORM + lane * 4) = lane == 0 ? k.nrm : (lane == 1 ? k.unrm : 0.0f);
+}
+// all of it by one wave
+__device__ __forceinline__ void query_keys_image(double v, _Float16 (*st)[128], char *out, int lane) {
+  const dev::KeySplit k = query_keys_stage(v, st, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  query_keys_copies(st, out, lane, 64);
+  query_keys_norms(k, out, lane);
 }
 
 // admissible alignments of the lane's entry (lane n and n + 32 hold the two halves of entry n's 64 shift rows): every shift
 // whose KC is within the error bound of the maximum (bit m of adm = shift m); all 60 when the keys cannot be compared here
 // (non-finite, too large, too lopsided: see split_key / `balanced`).  win = the union of their windows; kstar = the alignment
 // when exactly one shift is admissible, else -1
+// LEAN (sc_q1.hip): the lane halves are joined with v_permlane32_swap instead of four ds_bpermute round trips
+template <bool LEAN = false>
 __device__ __forceinline__ void alignment_of(const floatx16 &k0, const floatx16 &k1, float nq_key, float uq_key, float2 en,
                                              int hh, u64 &win, int &kstar) {
   float mx = -INFINITY;
@@ -79,7 +93,13 @@ __device__ __forceinline__ void alignment_of(const floatx16 &k0, const floatx16 
     bad |= !(v == v);
     mx = fmaxf(mx, (r >= 12 && hh) ? -INFINITY : v);
   }
-  const float gmx = fmaxf(mx, __shfl_xor(mx, 32));
+  float gmx;
+  if constexpr (LEAN) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+    gmx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  } else {
+    gmx = fmaxf(mx, __shfl_xor(mx, 32));
+  }
   const float thr = 2.0f * kWinAlignEps * nq_key * en.x;  // NaN when either key is unusable
   // KC is scale-free, the reference's fp64 arithmetic is not: it compares ||vkey_q - shift(vkey_e)||, and when one key
   // is much smaller than the other every shift gives the same double (its search then keeps the first one).  A
@@ -96,9 +116,19 @@ __device__ __forceinline__ void alignment_of(const floatx16 &k0, const floatx16 
   for (int r = 0; r < 16; r++) m1 |= (k1[r] >= line) ? (1u << ((r & 3) + 8 * (r >> 2))) : 0u;
   m0 <<= 4 * hh;
   m1 <<= 4 * hh;
-  m0 |= (unsigned)__shfl_xor((int)m0, 32);
-  m1 |= (unsigned)__shfl_xor((int)m1, 32);
-  const bool obad = __shfl_xor((int)bad, 32) != 0;
+  bool obad;
+  if constexpr (LEAN) {
+    const auto s0 = __builtin_amdgcn_permlane32_swap(m0, m0, false, false);
+    const auto s1 = __builtin_amdgcn_permlane32_swap(m1, m1, false, false);
+    const auto sb = __builtin_amdgcn_permlane32_swap((unsigned)bad, (unsigned)bad, false, false);
+    m0 = s0[0] | s0[1];
+    m1 = s1[0] | s1[1];
+    obad = (sb[0] | sb[1]) != 0;
+  } else {
+    m0 |= (unsigned)__shfl_xor((int)m0, 32);
+    m1 |= (unsigned)__shfl_xor((int)m1, 32);
+    obad = __shfl_xor((int)bad, 32) != 0;
+  }
   constexpr u64 M60 = (1ull << NS) - 1ull;
   u64 adm = (((u64)m1 << 32) | m0) & M60;
   const bool comparable = !bad && !obad && (thr == thr) && thr < 3.0e38f && balanced && adm != 0;
@@ -115,9 +145,76 @@ __device__ __forceinline__ void alignment_of(const floatx16 &k0, const floatx16 
 // epilogue of the image GEMM: max of S_k / n_eff(k) over the window(s) (n_eff from the two column masks, as the filter);
 // returns the preview pv (NaN: non-finite data; +inf: no effective column in the window) and, for a unique alignment, ORs
 // into kstar (bits 8..14) which of the 7 window shifts can be the minimum at all.  acc0 / acc1 are overwritten.
+// LEAN (sc_q1.hip, whose epilogue sits on the critical path of every tile): the same values with fewer instructions -- a query
+// without an empty column meets every entry with n_eff(k) = the entry's column count at every shift (one reciprocal per
+// entry instead of two funnel shifts and two popcounts per value), and the shift mask comes from ONE 60-bit mask of the
+// values above the line, rotated by the window start, instead of a window position per value
+template <bool LEAN = false>
 __device__ __forceinline__ float preview_of(floatx16 &acc0, floatx16 &acc1, u64 qm, u64 em, u64 win, int &kstar, int hh) {
   float pv;
-  {
+  if constexpr (LEAN) {
+    constexpr u64 M60 = (1ull << NS) - 1ull;
+    const u64 winh = win >> (4 * hh);  // bit (32 tl + b) = shift 32 tl + b + 4 hh
+    const unsigned wlo = (unsigned)winh, whi = (unsigned)(winh >> 32);
+    float best = -INFINITY;
+    if ((qm & M60) == M60) {  // (the query's mask: wave-uniform)
+      const float rn = __builtin_amdgcn_rcpf((float)__popcll(em & M60));  // no column at all: S == 0 exactly, 0 * inf = NaN, dropped by fmaxf
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int b = (r & 3) + 8 * (r >> 2);
+        const float v0 = (wlo & (1u << b)) ? acc0[r] * rn : -INFINITY, v1 = (whi & (1u << b)) ? acc1[r] * rn : -INFINITY;
+        acc0[r] = v0;
+        acc1[r] = v1;
+        best = fmaxf(best, fmaxf(v0, v1));
+      }
+    } else {
+      const u64 m1c = qm & ~kNonFinite;
+      const u64 lo = m1c | (m1c << 60), hi = m1c >> 4;  // the 60-bit mask twice in a row (120 bits)
+      const u64 lo4 = (lo >> 4) | (hi << 60), hi4 = hi >> 4;
+      const u64 l = hh ? lo4 : lo, h = hh ? hi4 : hi;
+      const unsigned w[4] = {(unsigned)l, (unsigned)(l >> 32), (unsigned)h, (unsigned)(h >> 32)};
+      const unsigned m2lo = (unsigned)em, m2hi = (unsigned)(em >> 32) & 0x0fffffffu;
+      auto piece = [&](int tl, int r, float S) -> float {
+        const int b = (r & 3) + 8 * (r >> 2);
+        const unsigned rlo = __builtin_amdgcn_alignbit(w[tl + 1], w[tl], b);
+        const unsigned rhi = __builtin_amdgcn_alignbit(w[tl + 2], w[tl + 1], b);
+        const int ne = __builtin_popcount(rlo & m2lo) + __builtin_popcount(rhi & m2hi);
+        float v = S * __builtin_amdgcn_rcpf((float)ne);
+        v = (((tl ? whi : wlo) >> b) & 1u) ? v : -INFINITY;
+        best = fmaxf(best, v);
+        return v;
+      };
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc0[r] = piece(0, r, acc0[r]);
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc1[r] = piece(1, r, acc1[r]);
+    }
+    {
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+      best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    pv = fmaf(best, -1.0f / FILTER_ACC_SCALE, 1.0f);  // -inf (no effective column in the window) -> +inf
+    if (kstar >= 0) {  // the shift mask (see below): bit t = shift k* - 3 + t is within 2 margins of the best one
+      const float line = best - 2.0f * WINDOW_MARGIN * FILTER_ACC_SCALE;
+      unsigned g0 = 0, g1 = 0;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int b = (r & 3) + 8 * (r >> 2);
+        g0 |= (acc0[r] >= line) ? (1u << b) : 0u;  // -inf outside the window, NaN without an effective column: no bit
+        g1 |= (acc1[r] >= line) ? (1u << b) : 0u;
+      }
+      u64 ge = (((u64)g1 << 32) | g0) << (4 * hh);
+      {
+        const auto sl = __builtin_amdgcn_permlane32_swap((unsigned)ge, (unsigned)ge, false, false);
+        const auto sh = __builtin_amdgcn_permlane32_swap((unsigned)(ge >> 32), (unsigned)(ge >> 32), false, false);
+        ge = ((u64)(sh[0] | sh[1]) << 32) | (sl[0] | sl[1]);
+      }
+      int k0s = kstar - 3;
+      k0s += k0s < 0 ? NS : 0;
+      const unsigned mask7 = (unsigned)((ge >> k0s) | (ge << (NS - k0s))) & 0x7fu;
+      kstar |= (int)(mask7 << 8);
+    }
+  } else {
     const u64 m1c = qm & ~kNonFinite;
     const u64 lo = m1c | (m1c << 60), hi = m1c >> 4;  // the 60-bit mask twice in a row (120 bits)
     const u64 lo4 = (lo >> 4) | (hi << 60), hi4 = hi >> 4;
