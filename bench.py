@@ -721,66 +721,81 @@ def icp_leg(device):
 def q1_latency_leg(device, q_descs):
     """ONE exhaustive query against N keyframes, N = 1 k / 10 k / 100 k: the regime of the live 1 Hz detector
     (PGO.cpp:561,577) and the only one where north_star's HBM roofline applies -- a single query cannot re-use anything, so
-    every eligible entry is streamed out of HBM once.  The small-problem path (no MFMA filter: sc_pair2_kernel, one entry
-    per wavefront, exact fp64) with the query and the result resident in HBM; time per call from the device's point of view
-    (back-to-back calls on one stream, host launch overhead amortised) and as one synchronous host call.  `hbm_frac` =
-    SURVEY 8d's algorithmic bytes (N x 4800 B, one fp32 descriptor per pair) / time / 8 TB/s; `hbm_frac_read` counts what the
-    kernel actually reads per entry (descriptor + sector key + column norms = 5760 B)."""
+    every eligible entry is streamed out of HBM once.  Default path since round 5: ONE launch (sc_q1_kernel, csrc/sc_q1.hip)
+    that streams the fp16 image + key image of every eligible entry (2672 B), previews every pair on the matrix cores and
+    scores the few survivors exactly.  Time per call from the device's point of view (back-to-back calls on one stream over
+    a pool of 16 different queries, query and result resident in HBM) and as one synchronous host call.  `hbm_frac` =
+    SURVEY 8d's algorithmic bytes (N x 4800 B, one fp32 descriptor per pair) / time / 8 TB/s; `hbm_frac_read` = the bytes the
+    kernel actually requests per entry (2672 B).  `floor_us` = the same call against a 32-keyframe DB: what one launch of
+    this path costs before the first byte of a database is streamed (host call, kernel start, the query's images, the
+    hand-off to the last workgroup, one exact evaluation).  The two older paths are timed beside it with the mode forced
+    (exact-all: sc_pair2_kernel, every entry in fp64; filter: the batched chain of six launches) and must return the same
+    records, as must 2..8 queries per call."""
     import torch
     from navtech_radar_slam_amd import scancontext, synth
     out = {}
     st = torch.cuda.current_stream().cuda_stream
-    d_q = torch.from_numpy(np.ascontiguousarray(q_descs[:1])).cuda()
-    d_out = torch.zeros((1, 1, 2), dtype=torch.float64, device="cuda")
-    for n in (1000, 10000, 100000):
+    pool = np.ascontiguousarray(q_descs[:16])
+    d_q = torch.from_numpy(pool).cuda()
+
+    def stream_us(h, k, nq=1, reps=100):
+        o = torch.zeros((16, k, 2), dtype=torch.float64, device="cuda")
+        for i in range(8):
+            h.query_device(d_q[i % (17 - nq):].data_ptr(), nq, k, o[i % (17 - nq):].data_ptr(), n_eligible=n_elig, stream=st)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            q0 = i % (17 - nq)
+            h.query_device(d_q[q0:].data_ptr(), nq, k, o[q0:].data_ptr(), n_eligible=n_elig, stream=st)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+
+    def all_records(h, k, nq):
+        o = torch.zeros((16, k, 2), dtype=torch.float64, device="cuda")
+        for q0 in range(0, 16, nq):
+            h.query_device(d_q[q0:].data_ptr(), min(nq, 16 - q0), k, o[q0:].data_ptr(), n_eligible=n_elig, stream=st)
+        torch.cuda.synchronize()
+        return o
+
+    for n in (32, 1000, 10000, 100000):
         descs = synth.random_descriptors(77, n, binary=True)
         h = scancontext.SCManager(device=device, capacity_hint=n + 8)
         h.add_descriptors_f32(descs)
-        n_elig = n - 30
-
-        def run():
-            h.query_device(d_q.data_ptr(), 1, 1, d_out.data_ptr(), n_eligible=n_elig, stream=st)
-        for _ in range(5):
-            run()
-        torch.cuda.synchronize()
-        reps = 50
+        n_elig = n - 30 if n > 100 else n
+        dev_us = stream_us(h, 1)
+        if n == 32:
+            out["floor_us"] = dev_us
+            out["floor_kernel"] = h.profiled_kernel_name()
+            h.close()
+            continue
+        dev_us_k10 = stream_us(h, 10)
         t0 = time.perf_counter()
-        for _ in range(reps):
-            run()
-        torch.cuda.synchronize()
-        dev_us = (time.perf_counter() - t0) / reps * 1e6
-        t0 = time.perf_counter()
-        for _ in range(20):
-            h.query(q_descs[:1], k=1, n_eligible=n_elig)
+        for i in range(20):
+            h.query(pool[i % 16:i % 16 + 1], k=1, n_eligible=n_elig)
         host_us = (time.perf_counter() - t0) / 20 * 1e6
-        # the same query with the path forced: exact-all (filter_mode = 1: sc_pair kernel, every entry scored in fp64) and the
-        # MFMA filter (filter_mode = 2: the spectral fp16 image streamed instead, 2432 B per entry, then a few exact scores)
+        want = all_records(h, 1, 1)
+        same_q = all(bool(torch.equal(all_records(h, 1, nq), want)) for nq in (2, 3, 5, 8))
         forced = {}
         for name, mode in (("exact_all", 1), ("filter", 2)):
             hf = scancontext.SCManager(device=device, capacity_hint=n + 8, filter_mode=mode)
             hf.add_descriptors_f32(descs)
-            d_out2 = torch.zeros((1, 1, 2), dtype=torch.float64, device="cuda")
-            for _ in range(5):
-                hf.query_device(d_q.data_ptr(), 1, 1, d_out2.data_ptr(), n_eligible=n_elig, stream=st)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                hf.query_device(d_q.data_ptr(), 1, 1, d_out2.data_ptr(), n_eligible=n_elig, stream=st)
-            torch.cuda.synchronize()
-            forced[name] = ((time.perf_counter() - t0) / reps * 1e6, bool(torch.equal(d_out, d_out2)))
+            forced[name] = (stream_us(hf, 1, reps=50 if name == "filter" or n <= 10000 else 10), bool(torch.equal(all_records(hf, 1, 1), want)))
             hf.close()
-        exact_us = forced["exact_all"][0]
         out[f"n{n}"] = {"us_per_query_stream": dev_us, "us_per_query_host_call": host_us, "queries_per_sec_stream": 1e6 / dev_us,
+                        "us_per_query_stream_top10": dev_us_k10,
                         "default_path_kernel": h.profiled_kernel_name(),
-                        "us_per_query_stream_exact_all": exact_us, "us_per_query_stream_filter_forced": forced["filter"][0],
+                        "us_per_query_stream_exact_all": forced["exact_all"][0], "us_per_query_stream_filter_forced": forced["filter"][0],
                         "forced_paths_identical": forced["exact_all"][1] and forced["filter"][1],
-                        "algorithmic_bytes": n_elig * ALG_BYTES_PER_PAIR,
-                        "hbm_frac": n_elig * ALG_BYTES_PER_PAIR / (exact_us * 1e-6) / (HBM_PEAK_GBS * 1e9),
-                        "hbm_frac_read": n_elig * 5760 / (exact_us * 1e-6) / (HBM_PEAK_GBS * 1e9)}
+                        "records_identical_2_to_8_queries_per_call": same_q,
+                        "algorithmic_bytes": n_elig * ALG_BYTES_PER_PAIR, "bytes_requested": n_elig * 2672,
+                        "hbm_frac": n_elig * ALG_BYTES_PER_PAIR / (dev_us * 1e-6) / (HBM_PEAK_GBS * 1e9),
+                        "hbm_frac_read": n_elig * 2672 / (dev_us * 1e-6) / (HBM_PEAK_GBS * 1e9),
+                        "hbm_frac_exact_all": n_elig * ALG_BYTES_PER_PAIR / (forced["exact_all"][0] * 1e-6) / (HBM_PEAK_GBS * 1e9)}
         h.close()
-    out["note"] = ("one query, top-1; us_per_query_stream = the default path (exact-all below 50 000 keyframes, the MFMA filter from "
-                   "there on: default_path_kernel), back-to-back device-resident calls; host_call = rsx_sc_query (H2D 4.8 KB, D2H 16 B, "
-                   "one synchronise); hbm_frac / hbm_frac_read = the exact-all path (every eligible entry streamed once) against 8 TB/s")
+    out["note"] = ("one query, top-1, a pool of 16 queries in turn; us_per_query_stream = the default path (default_path_kernel: one "
+                   "launch), back-to-back device-resident calls; host_call = rsx_sc_query (H2D 4.8 KB, D2H 16 B, one synchronise); "
+                   "hbm_frac = N x 4800 B / time / 8 TB/s on the default path, hbm_frac_read = the 2672 B per entry it requests; "
+                   "floor_us = the same call against 32 keyframes")
     return out
 
 
@@ -1288,6 +1303,10 @@ def main():
             out["latency_q1_n1k_us"] = (time.perf_counter() - t0) / 50 * 1e6
             small.close()
             out["latency_q1"] = q1_latency_leg(ctx.local_rank, q_descs)
+            for nm in ("n1000", "n10000", "n100000"):
+                lq = out["latency_q1"][nm]
+                if not (lq["forced_paths_identical"] and lq["records_identical_2_to_8_queries_per_call"]):
+                    failures.append(f"latency_q1 {nm}: the single-query path, the exact-all path and the filter chain disagree")
             out["orora"] = orora_leg(ctx.local_rank, args.no_cpu_baseline)
             out["cen2019"] = cen2019_leg(ctx.local_rank)
             out["icp"] = icp_leg(ctx.local_rank)

@@ -232,8 +232,9 @@ bool use_filter(const rsx_sc *h, int32_t nq, int64_t n_items) {
   // extra launches: worth it for batched queries against a sizeable DB -- and for ANY number of queries once the DB is
   // so large that scoring every entry exactly costs more than the launches (one query, MI355X, us per query
   // exact-all / filtered: 1 000 keyframes 22 / 85, 10 000: 55 / 94, 100 000: 232 / 178)
+  // (a handful of queries never gets here in auto mode unless the single-query path declined them: use_q1)
   if (n_items >= 50000) return true;
-  return nq >= 8 && (int64_t)nq * n_items >= (1ll << 20);
+  return (int64_t)nq * n_items >= (1ll << 17);  // exact-all scores ~1 G pairs/s, the chain's fixed cost is ~85 us
 }
 
 struct ProfScope {
@@ -412,13 +413,17 @@ int run_topk_filtered(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n
 // every eligible entry once, previews every pair on the matrix cores and scores the few entries the previews cannot exclude
 // exactly (sc_q1.hip) -- instead of the exact-all kernel (one entry per wavefront in fp64) or the six launches of the batched
 // filter chain.  filter_mode 1 / 2 keep those paths; 3 asks for this one wherever it applies.  Records are identical.
-bool use_q1(const rsx_sc *h, int32_t nq) {
+bool use_q1(const rsx_sc *h, int32_t nq, int64_t n_items) {
   static const bool off = [] {
     const char *e = rsx::exp_env("RSX_SC_Q1");
     return e && e[0] == '0';
   }();
   const int m = filter_mode_of(h);
-  return !off && nq >= 1 && nq <= Q1_MAX_NQ && (m == 0 || m == 3);
+  if (off || nq < 1 || nq > Q1_MAX_NQ || !(m == 0 || m == 3)) return false;
+  // every query streams the whole database again, so with several queries against a large database the batched chain (one
+  // pass of the spectral filter for all of them) takes over: MI355X, top-1, us per call single-query path / filter chain:
+  // 8 queries x 10 000 keyframes 55 / 88, 8 x 100 000: 305 / 190; one query: 17 / 90 and 54 / 172
+  return m == 3 || nq == 1 || (int64_t)nq * n_items <= 320000;
 }
 
 int run_q1(rsx_sc *h, const float *d_q, int32_t nq, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig, int32_t k,
@@ -439,7 +444,7 @@ int run_q1(rsx_sc *h, const float *d_q, int32_t nq, int64_t n_items, int64_t n_e
 
 int run_topk(rsx_sc *h, const QueryView &qv, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig,
              int32_t k, rsx_sc_hit *d_out, hipStream_t s, bool elig_monotone = false) {
-  if (use_q1(h, qv.nq)) return run_q1(h, qv.desc, qv.nq, n_items, n_eligible, d_q_elig, k, d_out, s);
+  if (use_q1(h, qv.nq, n_items)) return run_q1(h, qv.desc, qv.nq, n_items, n_eligible, d_q_elig, k, d_out, s);
   if (use_filter(h, qv.nq, n_items)) return run_topk_filtered(h, qv, n_items, n_eligible, d_q_elig, k, d_out, s, elig_monotone);
   h->prof_kernel = pair_kernel_name();
   RSX_TRY(h->w->partial.reserve(pair_partial_bytes(n_items > 0 ? n_items : 1, qv.nq, k), s, false));
@@ -1238,7 +1243,7 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
 static int query_device_locked(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int64_t n_eligible, rsx_sc_hit *d_out,
                                hipStream_t s) {
   const int64_t items = local_count_below(h, n_eligible);
-  if (use_q1(h, nq))  // builds the query's keys and images itself: no keys launch
+  if (use_q1(h, nq, items))  // builds the query's keys and images itself: no keys launch
     return run_q1(h, d_q, nq, items, n_eligible < 0 ? h->n_global : n_eligible, nullptr, k, d_out, s);
   QueryView qv;
   RSX_TRY(prepare_queries(h, d_q, nq, s, &qv));

@@ -159,6 +159,24 @@ __device__ __forceinline__ void topk_insert(double &ld, int &li, int &ls, int la
   }
 }
 
+// the same insertion with the shift-up by one lane as DPP wave_shr:1 (four v_mov_b32_dpp) instead of four ds_bpermute round
+// trips: sc_q1.hip, where the insertions of a round sit on the critical path of the last workgroup
+__device__ __forceinline__ void topk_insert_dpp(double &ld, int &li, int &ls, int lane, int k, double dist, int idx, int shift) {
+  const bool before = (lane < k) && hit_before(ld, li, dist, idx);
+  const int pos = __popcll(__ballot(before));
+  if (pos < k) {
+    auto shr1 = [](int x) { return __builtin_amdgcn_update_dpp(x, x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); };
+    const long long lb = __double_as_longlong(ld);
+    const long long ub = ((long long)shr1((int)(lb >> 32)) << 32) | (unsigned)shr1((int)lb);
+    const int ui = shr1(li), us = shr1(ls);
+    if (lane > pos) {
+      ld = __longlong_as_double(ub); li = ui; ls = us;
+    } else if (lane == pos) {
+      ld = dist; li = idx; ls = shift;
+    }
+  }
+}
+
 struct WaveLds {
   static constexpr int OFF_QF32 = 0;                  // the query descriptor as it is: [60][20] fp32, column stride 80 B
   static constexpr int OFF_QN1 = DS * 4;              // 4800: column norms (fp64)

@@ -69,10 +69,11 @@ constexpr int Q1_OFF_MISC = Q1_OFF_Q + WaveLds::OFF_ENT;  // 20432
 constexpr int Q1_MISC_UB = 0;      // float[32]: the workgroup's k smallest preview upper bounds, ascending
 constexpr int Q1_MISC_CNT = 128;   // int: candidate records written so far
 constexpr int Q1_MISC_LAST = 132;  // int: this workgroup drew the last ticket
-constexpr int Q1_MISC_NSURV = 136; // int: survivors gathered in the current chunk
+constexpr int Q1_MISC_NSURV = 136; // int: survivors gathered so far
+constexpr int Q1_MISC_TOTAL = 224, Q1_MISC_MORE = 228;  // ints of the last workgroup
 constexpr int Q1_MISC_TAU = 144;   // double: the cut of the exact rounds
 constexpr int Q1_MISC_MASK = 152;  // u64: the query's column mask (between the two prep phases)
-constexpr int Q1_MISC_RED = 160;   // u64[2][4]: per-wave minima of the bound merge, double buffered
+constexpr int Q1_MISC_RED = 160;   // float[8]: per-wave minima of the bound merge, its result
 constexpr int Q1_MISC_BYTES = 256;
 constexpr int Q1_OFF_SCR = Q1_OFF_MISC + Q1_MISC_BYTES;  // 20688
 static_assert(Q1_OFF_SCR % 16 == 0, "alignment");
@@ -90,16 +91,17 @@ constexpr int Q1_MAX_G = 512;
 constexpr int Q1_FIN_AB = Q1_FIN_PREF + (Q1_MAX_G + 1) * 4 + 12;  // 15760: bound lists (merge), then the survivors
 static_assert(Q1_FIN_AB % 16 == 0, "alignment");
 constexpr int Q1_FIN_AB_BYTES = Q1_SCR_BYTES - Q1_FIN_AB;  // 33392
-constexpr int Q1_SURV_CAP = 2048;                        // survivors of one chunk: lo[], slot[], ks[]
+constexpr int Q1_SURV_CAP = 2560;                        // survivors gathered before they are evaluated: lo[], slot[], ks[]
 static_assert(3 * 4 * Q1_SURV_CAP <= Q1_FIN_AB_BYTES, "survivor arrays fit");
 constexpr int Q1_SORT_MAX = 256;                         // chunks with at most this many survivors are evaluated in ascending lo
 // what the workgroups publish (global memory, u64 arrays per query; G = workgroups): hdr[G] = candidate count | smallest upper
-// bound << 32; ubs[16][G] = the bound list in pairs; rec[2 * Q1_EAGER][G] = the first candidate records {slot << 32 | lo bits,
+// bound << 32; ubs[16][G] = the bound list in pairs; rec[2 * Q1_SOA][G] = the first candidate records {slot << 32 | lo bits,
 // k* | shift mask} -- all indexed by workgroup LAST, so that the last workgroup's thread j reads workgroup j and a wavefront's
 // load touches 4 cache lines instead of 64 (the first build kept one block per workgroup: 3 400 eight-byte requests out of one
 // CU for 313 workgroups, 4.4 us) -- and blk[G][...] the records beyond the eager ones
 constexpr int Q1_EAGER = 4;  // candidate records per workgroup the last workgroup requests together with the header
-static_assert(2 * Q1_EAGER * 256 <= Q1_SURV_CAP, "the eager records of 512 workgroups fit one chunk");
+constexpr int Q1_SOA = 16;   // candidate records per workgroup in the workgroup-last arrays (the rest: one block per workgroup)
+static_assert(2 * Q1_EAGER * 256 <= Q1_SURV_CAP && Q1_SOA % Q1_EAGER == 0, "a step's records of 512 workgroups fit the survivor list");
 // arrival counters: per query 8 group counters (workgroup b arrives at group b % 8: ~13 ns per atomic on ONE word is 4 us
 // for 313 workgroups arriving together, MI355X_MICROARCH "fanin") + one for the groups, each on its own 128-byte line
 constexpr int Q1_TICKET_STRIDE = 32;  // unsigned per counter
@@ -115,7 +117,7 @@ struct Q1Args {
   int32_t k, kp;           // kp = k rounded up to 4: floats of a workgroup's bound list the merge reads
   int32_t blk;             // u64 per workgroup in ws_blk: 2 x (its entries beyond the eager records)
   unsigned *ticket;        // [nq][Q1_TICKETS_PER_Q][Q1_TICKET_STRIDE]: zero between launches (the last workgroup resets them)
-  u64 *ws_hdr, *ws_ubs, *ws_rec, *ws_blk;  // [nq][G], [nq][16][G], [nq][2 * Q1_EAGER][G], [nq][G][blk]
+  u64 *ws_hdr, *ws_ubs, *ws_rec, *ws_blk;  // [nq][G], [nq][16][G], [nq][2 * Q1_SOA][G], [nq][G][blk]
   unsigned long long *stats;  // optional (profiling): RESCORE_STAT_WORDS counters
 };
 
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   half8 bh[4], bl[4];
   float2 en = {0.0f, 0.0f};
   u64 em = 0;
-  auto issue = [&](int t, int it) {
+  auto issue = [&](int t, int it) __attribute__((always_inline)) {
     if (wave == (it & 3)) {
       const int64_t slot = (int64_t)t * 32 + n;
       const char *bk = static_cast<const char *>(a.db.vk16) + slot * 256 + 16 * hh;
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   // A-fragment addresses of this lane's row (shift n of tile 0; tile 1 = the same address + 40 K-steps, sc_filter.hip)
   const char *ap = smem + Q1_OFF_QIMG + ((n & 1) ? (FILTER_QIMG_ODD + 40 * n - 8) : (40 * n)) + 16 * hh + 32 * ks0;
   const char *kp = smem + Q1_OFF_QK + (n & 7) * QK_COPY + ((n & ~7) + 8 * hh) * 2;  // tile 1: + 64 B
-  u64 *my_rec = a.ws_rec + (int64_t)qi * (2 * Q1_EAGER) * G + b;   // eager record e: [2 e] and [2 e + 1], stride G
+  u64 *my_rec = a.ws_rec + (int64_t)qi * (2 * Q1_SOA) * G + b;   // record e < Q1_SOA: [2 e] and [2 e + 1], stride G
   u64 *my_blk = a.ws_blk + ((int64_t)qi * G + b) * a.blk;
 
   int it = 0;
@@ -333,8 +335,8 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
         const int base = *s_cnt;
         if (cand) {
           const int pos = base + __popcll(cb & ((1ull << lane) - 1ull));
-          u64 *r0 = pos < Q1_EAGER ? my_rec + (int64_t)(2 * pos) * G : my_blk + 2 * (pos - Q1_EAGER);
-          u64 *r1 = pos < Q1_EAGER ? r0 + G : r0 + 1;
+          u64 *r0 = pos < Q1_SOA ? my_rec + (int64_t)(2 * pos) * G : my_blk + 2 * (pos - Q1_SOA);
+          u64 *r1 = pos < Q1_SOA ? r0 + G : r0 + 1;
           store_sc1(r0, ((u64)(unsigned)slot << 32) | (u64)__float_as_uint(lo));
           store_sc1(r1, (u64)(unsigned)kstar);
         }
@@ -380,23 +382,32 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   // a loop each would wait for the one before) ----
   u64 hdr_r[2], rec[2][2 * Q1_EAGER], lst[2][16];
   const int kp2 = a.k > 1 ? (a.kp >> 1) : 0;
+  const u64 *rec_q = a.ws_rec + (int64_t)qi * (2 * Q1_SOA) * G;
+  int jj[2];
+#pragma unroll
+  for (int o = 0; o < 2; o++) jj[o] = tid + 256 * o < G ? tid + 256 * o : 0;
 #pragma unroll
   for (int o = 0; o < 2; o++) {
-    const int j = tid + 256 * o;
-    const bool own = j < G;
-    const int jj = own ? j : 0;
-    hdr_r[o] = own ? load_sc1(a.ws_hdr + (int64_t)qi * G + jj) : 0;
+    const bool own = tid + 256 * o < G;
+    hdr_r[o] = own ? load_sc1(a.ws_hdr + (int64_t)qi * G + jj[o]) : 0;
 #pragma unroll
-    for (int c = 0; c < 2 * Q1_EAGER; c++) rec[o][c] = own ? load_sc1(a.ws_rec + ((int64_t)qi * (2 * Q1_EAGER) + c) * G + jj) : 0;
+    for (int c = 0; c < 2 * Q1_EAGER; c++) rec[o][c] = own ? load_sc1(rec_q + (int64_t)c * G + jj[o]) : 0;
 #pragma unroll
-    for (int c = 0; c < 16; c++) lst[o][c] = (own && c < kp2) ? load_sc1(a.ws_ubs + ((int64_t)qi * 16 + c) * G + jj) : 0;
+    for (int c = 0; c < 16; c++) lst[o][c] = (own && c < kp2) ? load_sc1(a.ws_ubs + ((int64_t)qi * 16 + c) * G + jj[o]) : 0;
   }
-  int *s_total = reinterpret_cast<int *>(misc + Q1_MISC_NSURV);  // (free until the survivors are gathered)
-  if (tid == 0) *s_total = 0;
+  int *s_nsurv = reinterpret_cast<int *>(misc + Q1_MISC_NSURV);
+  int *s_total = reinterpret_cast<int *>(misc + Q1_MISC_TOTAL);  // candidate records beyond the Q1_SOA per workgroup
+  int *s_more = reinterpret_cast<int *>(misc + Q1_MISC_MORE);    // some workgroup has more than Q1_EAGER
+  if (tid == 0) {
+    *s_total = 0;
+    *s_more = 0;
+    *s_nsurv = 0;
+  }
   __syncthreads();
+  float t0 = INFINITY;  // smallest k-th bound of the lists this thread holds
   {
     u64 *L = reinterpret_cast<u64 *>(scr + Q1_FIN_AB);
-    int extra_mine = 0;
+    int extra_mine = 0, more_mine = 0;
 #pragma unroll
     for (int o = 0; o < 2; o++) {
       const int j = tid + 256 * o;
@@ -406,19 +417,23 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
           for (int c = 0; c < 16; c++)
             if (c < kp2) L[j * kp2 + c] = lst[o][c];
         } else {
-          reinterpret_cast<float *>(L)[j * a.kp] = __uint_as_float((unsigned)(hdr_r[o] >> 32));
+          t0 = fminf(t0, __uint_as_float((unsigned)(hdr_r[o] >> 32)));
         }
-        const int extra = (int)(unsigned)hdr_r[o] - Q1_EAGER;
+        const int cnt = (int)(unsigned)hdr_r[o];
+        const int extra = cnt - Q1_SOA;
         s_pref[j + 1] = extra > 0 ? extra : 0;
         extra_mine += extra > 0 ? extra : 0;
+        more_mine |= cnt > Q1_EAGER ? 1 : 0;
       }
     }
     if (tid == 0) s_pref[0] = 0;
     if (extra_mine) atomicAdd(s_total, extra_mine);
+    if (more_mine) atomicOr(s_more, 1);
   }
   __syncthreads();
   Q1_MARK(5);
-  const int total = *s_total;  // candidate records beyond the eager ones
+  const int total = *s_total;
+  const bool more = *s_more != 0;
   if (total > 0 && wave == 0) {  // inclusive scan of s_pref[1 .. G] (G <= 512: 8 per lane); read after later barriers only
     int v[8], sum = 0;
 #pragma unroll
@@ -441,48 +456,64 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
       if (j < G) s_pref[j + 1] = run;
     }
   }
-  // ---- the chip-wide k-th smallest upper bound: k rounds of "smallest head of the sorted lists" ----
-  float tau_ub = INFINITY;
+  // ---- the chip-wide k-th smallest upper bound.  k = 1: the smallest of the workgroups' bounds.  k > 1: the sorted lists
+  // are merged by ONE wavefront, k rounds of "smallest head" (a lane owns 8 lists and keeps their heads in registers; a
+  // round is a lane-local minimum, one DPP reduction and one LDS read by the owner: no barrier) ----
+  float tau_ub;
   {
     const float *L = reinterpret_cast<const float *>(scr + Q1_FIN_AB);
-    u64 *s_red = reinterpret_cast<u64 *>(misc + Q1_MISC_RED);
-    int p0 = 0, p1 = 0;
-    const int j0 = tid, j1 = tid + 256;
-    for (int r = 0; r < a.k; r++) {
-      u64 key = ~0ull;
-      if (j0 < G && p0 < a.k) key = ((u64)dev::enc_f32(L[j0 * a.kp + p0]) << 32) | (unsigned)j0;
-      if (j1 < G && p1 < a.k) {
-        const u64 k1 = ((u64)dev::enc_f32(L[j1 * a.kp + p1]) << 32) | (unsigned)j1;
-        key = k1 < key ? k1 : key;
-      }
-      key = wave_min_u64(key);
-      if (lane == 0) s_red[(r & 1) * 4 + wave] = key;
+    float *s_redf = reinterpret_cast<float *>(misc + Q1_MISC_RED);
+    if (a.k == 1) {
+      t0 = wave_min_f32(t0);
+      if (lane == 0) s_redf[wave] = t0;
       __syncthreads();
-      u64 g = s_red[(r & 1) * 4];
+      tau_ub = fminf(fminf(s_redf[0], s_redf[1]), fminf(s_redf[2], s_redf[3]));
+    } else {
+      if (wave == 0) {
+        u64 head[8];
+        int ptr[8];
 #pragma unroll
-      for (int w = 1; w < 4; w++) {
-        const u64 o = s_red[(r & 1) * 4 + w];
-        g = o < g ? o : g;
+        for (int i = 0; i < 8; i++) {
+          const int j = lane + 64 * i;
+          ptr[i] = 0;
+          head[i] = j < G ? (((u64)dev::enc_f32(L[j * a.kp]) << 32) | (unsigned)j) : ~0ull;
+        }
+        float kth = INFINITY;
+        for (int r = 0; r < a.k; r++) {
+          u64 m = head[0];
+#pragma unroll
+          for (int i = 1; i < 8; i++) m = head[i] < m ? head[i] : m;
+          const u64 g = wave_min_u64(m);
+          if (g == ~0ull) {  // fewer than k bounds at all
+            kth = INFINITY;
+            break;
+          }
+          kth = dev::dec_f32((unsigned)(g >> 32));
+          const int owner = (int)(unsigned)g;
+          if ((owner & 63) == lane) {  // the owner moves on in that list
+            const int oi = owner >> 6;
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+              if (i == oi) {
+                ptr[i]++;
+                head[i] = ptr[i] < a.k ? (((u64)dev::enc_f32(L[owner * a.kp + ptr[i]]) << 32) | (unsigned)owner) : ~0ull;
+              }
+          }
+        }
+        if (lane == 0) s_redf[4] = kth;
       }
-      if (g == ~0ull) {  // fewer than k bounds at all (uniform)
-        tau_ub = INFINITY;
-        break;
-      }
-      tau_ub = dev::dec_f32((unsigned)(g >> 32));
-      const int owner = (int)(unsigned)g;
-      if (owner == j0) p0++;
-      else if (owner == j1) p1++;
+      __syncthreads();
+      tau_ub = s_redf[4];
     }
   }
   __syncthreads();  // the lists are dead: their space holds the survivors from here on
   Q1_MARK(6);
 
-  // ---- candidates that can still reach the bound (first the eager records, then the rest in chunks); exact evaluation four
-  // per round, the next round's entries requested before the current ones are evaluated ----
+  // ---- candidates that can still reach the bound; exact evaluation four per round, the next round's entries requested
+  // before the current ones are evaluated ----
   float *s_lo = reinterpret_cast<float *>(scr + Q1_FIN_AB);
   int *s_slot = reinterpret_cast<int *>(s_lo + Q1_SURV_CAP);
   int *s_ks = s_slot + Q1_SURV_CAP;
-  int *s_nsurv = reinterpret_cast<int *>(misc + Q1_MISC_NSURV);
   double *s_tau = reinterpret_cast<double *>(misc + Q1_MISC_TAU);
   struct Res {
     double d;
@@ -496,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   double tau = (double)tau_ub;
   unsigned n_exact = 0, n_aligned = 0, n_shifts = 0, n_surv_all = 0, n_cand_all = 0;
 
-  auto keep = [&](u64 ra, u64 rb) {  // a candidate record whose lower bound can still reach the cut -> survivor list
+  auto keep = [&](u64 ra, u64 rb) __attribute__((always_inline)) {  // a candidate record whose lower bound can still reach the cut -> survivor list
     const float lo = __uint_as_float((unsigned)ra);
     if (!((double)lo > tau)) {
       const int i = atomicAdd(s_nsurv, 1);
@@ -505,7 +536,8 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
       s_ks[i] = (int)(unsigned)rb;
     }
   };
-  auto rounds = [&]() {  // the survivors in s_lo / s_slot / s_ks [0, *s_nsurv): exact evaluation (all threads call this)
+  // the survivors gathered so far: exact evaluation, then the list is empty again (all threads call this, behind a barrier)
+  auto rounds = [&]() __attribute__((always_inline)) {
     const int ns = *s_nsurv;
     n_surv_all += (unsigned)ns;
     if (ns == 0) return;  // uniform
@@ -572,19 +604,20 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
 #pragma unroll 1
         for (int w = 0; w < 4; w++) {
           const Res o = s_res[w];
-          if (o.d < kBig) topk_insert(ld, li, ls, lane, a.k, o.d, o.idx, o.shift);
+          if (o.d < kBig) topk_insert_dpp(ld, li, ls, lane, a.k, o.d, o.idx, o.shift);
         }
-        const double kd = __shfl(ld, a.k - 1);
+        const double kd = __longlong_as_double((long long)dev::readlane_u64((u64)__double_as_longlong(ld), a.k - 1));
         if (lane == 0) *s_tau = kd < (double)tau_ub ? kd : (double)tau_ub;
       }
       __syncthreads();
       tau = *s_tau;
       cur = nxt;
     }
+    __syncthreads();
+    if (tid == 0) *s_nsurv = 0;
+    __syncthreads();
   };
-
-  if (tid == 0) *s_nsurv = 0;
-  __syncthreads();
+  // (1) the eager records
 #pragma unroll
   for (int o = 0; o < 2; o++) {
     const int cnt = (int)(unsigned)hdr_r[o];
@@ -594,39 +627,61 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
       if (c < cnt) keep(rec[o][2 * c], rec[o][2 * c + 1]);
   }
   __syncthreads();
-  rounds();
   Q1_MARK(7);
-  for (int base = 0; base < total; base += Q1_SURV_CAP) {
-    __syncthreads();
-    if (tid == 0) *s_nsurv = 0;
-    __syncthreads();
-    const int lim = total - base < Q1_SURV_CAP ? total - base : Q1_SURV_CAP;
-    for (int e0 = 0; e0 < lim; e0 += 4 * 256) {  // four records per thread in flight
-      u64 ra[4], rb[4];
+  // (2) the other records in pieces -- first records Q1_EAGER .. Q1_SOA - 1 of every workgroup, four at a time (one batched
+  // round trip each), then what lies beyond (a workgroup with more than Q1_SOA candidates: duplicates, k near the tile
+  // size) -- and ONE call site of the exact rounds: whenever the next piece might not fit the survivor list, and at the end
+  const int nsoa = more ? Q1_SOA / Q1_EAGER - 1 : 0, npieces = nsoa + (total + 4 * 256 - 1) / (4 * 256);
+  for (int pc = 0;;) {
+    const int need = pc < nsoa ? 2 * Q1_EAGER * 256 : 4 * 256;
+    if (pc < npieces && *s_nsurv + need <= Q1_SURV_CAP) {  // (uniform)
+      if (pc < nsoa) {
+        const int c0 = Q1_EAGER * (pc + 1);
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int e = e0 + tid + 256 * u;
-        ra[u] = 0;
-        rb[u] = 0;
-        if (e < lim) {
-          const int ge = base + e;
-          int lo_j = 0, hi_j = G;  // the workgroup j with s_pref[j] <= ge < s_pref[j + 1]
-          while (hi_j - lo_j > 1) {
-            const int mid = (lo_j + hi_j) >> 1;
-            if (s_pref[mid] <= ge) lo_j = mid;
-            else hi_j = mid;
-          }
-          const u64 *r = a.ws_blk + ((int64_t)qi * G + lo_j) * a.blk + 2 * (ge - s_pref[lo_j]);
-          ra[u] = load_sc1(r);
-          rb[u] = load_sc1(r + 1);
+        for (int o = 0; o < 2; o++) {
+          const int cnt = (int)(unsigned)hdr_r[o];
+#pragma unroll
+          for (int c = 0; c < 2 * Q1_EAGER; c++) rec[o][c] = cnt > c0 ? load_sc1(rec_q + (int64_t)(2 * c0 + c) * G + jj[o]) : 0;
         }
-      }
 #pragma unroll
-      for (int u = 0; u < 4; u++)
-        if (e0 + tid + 256 * u < lim) keep(ra[u], rb[u]);
+        for (int o = 0; o < 2; o++) {
+          const int cnt = (int)(unsigned)hdr_r[o];
+#pragma unroll
+          for (int c = 0; c < Q1_EAGER; c++)
+            if (c0 + c < cnt) keep(rec[o][2 * c], rec[o][2 * c + 1]);
+        }
+      } else {
+        const int base = (pc - nsoa) * 4 * 256;
+        const int lim = total - base < 4 * 256 ? total - base : 4 * 256;
+        u64 ra[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {  // four records per thread in flight
+          const int e = tid + 256 * u;
+          ra[u] = 0;
+          rb[u] = 0;
+          if (e < lim) {
+            const int ge = base + e;
+            int lo_j = 0, hi_j = G;  // the workgroup j with s_pref[j] <= ge < s_pref[j + 1]
+            while (hi_j - lo_j > 1) {
+              const int mid = (lo_j + hi_j) >> 1;
+              if (s_pref[mid] <= ge) lo_j = mid;
+              else hi_j = mid;
+            }
+            const u64 *r = a.ws_blk + ((int64_t)qi * G + lo_j) * a.blk + 2 * (ge - s_pref[lo_j]);
+            ra[u] = load_sc1(r);
+            rb[u] = load_sc1(r + 1);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+          if (tid + 256 * u < lim) keep(ra[u], rb[u]);
+      }
+      pc++;
+      __syncthreads();
+      continue;
     }
-    __syncthreads();
     rounds();
+    if (pc >= npieces) break;
   }
   if (wave == 0 && lane < a.k) {
     rsx_sc_hit h;
@@ -673,12 +728,12 @@ int q1_grid(int64_t n_items, int32_t k) {
 static int64_t q1_block_u64(int64_t n_items, int g) {
   const int64_t ntiles = (n_items + 31) / 32;
   const int64_t ent = ((ntiles + g - 1) / g) * 32;  // entries of one workgroup = candidate records it may write
-  return 2 * (ent > Q1_EAGER ? ent - Q1_EAGER : 1);
+  return 2 * (ent > Q1_SOA ? ent - Q1_SOA : 1);
 }
 
 size_t q1_workspace_bytes(int64_t n_items, int32_t nq, int32_t k) {
   const int g = q1_grid(n_items, k);
-  return (size_t)nq * g * (1 + 16 + 2 * Q1_EAGER + q1_block_u64(n_items, g)) * 8 + 256;
+  return (size_t)nq * g * (1 + 16 + 2 * Q1_SOA + q1_block_u64(n_items, g)) * 8 + 256;
 }
 
 size_t q1_ticket_bytes() { return (size_t)Q1_MAX_NQ * Q1_TICKETS_PER_Q * Q1_TICKET_STRIDE * sizeof(unsigned); }
@@ -717,7 +772,7 @@ int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, i
   a.ws_hdr = static_cast<u64 *>(ws);
   a.ws_ubs = a.ws_hdr + (size_t)nq * g;
   a.ws_rec = a.ws_ubs + (size_t)nq * 16 * g;
-  a.ws_blk = a.ws_rec + (size_t)nq * 2 * Q1_EAGER * g;
+  a.ws_blk = a.ws_rec + (size_t)nq * 2 * Q1_SOA * g;
   a.stats = d_stats;
   hipLaunchKernelGGL(sc_q1_kernel, dim3((unsigned)g, (unsigned)nq), dim3(256), Q1_LDS, s, a);
   RSX_HIP(hipGetLastError());
