@@ -763,9 +763,10 @@ def q1_latency_leg(device, q_descs):
         h.add_descriptors_f32(descs)
         n_elig = n - 30 if n > 100 else n
         dev_us = stream_us(h, 1)
+        default_kernel = h.profiled_kernel_name()
         if n == 32:
             out["floor_us"] = dev_us
-            out["floor_kernel"] = h.profiled_kernel_name()
+            out["floor_kernel"] = default_kernel
             h.close()
             continue
         dev_us_k10 = stream_us(h, 10)
@@ -783,7 +784,7 @@ def q1_latency_leg(device, q_descs):
             hf.close()
         out[f"n{n}"] = {"us_per_query_stream": dev_us, "us_per_query_host_call": host_us, "queries_per_sec_stream": 1e6 / dev_us,
                         "us_per_query_stream_top10": dev_us_k10,
-                        "default_path_kernel": h.profiled_kernel_name(),
+                        "default_path_kernel": default_kernel,
                         "us_per_query_stream_exact_all": forced["exact_all"][0], "us_per_query_stream_filter_forced": forced["filter"][0],
                         "forced_paths_identical": forced["exact_all"][1] and forced["filter"][1],
                         "records_identical_2_to_8_queries_per_call": same_q,
