@@ -225,7 +225,9 @@ int rsx_sc_query_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int32_t k
  * The records are those of rsx_sc_query_device on one GPU (the bounds of a pair do not depend on who computed them).
  * first_slot must be a multiple of 32 (the filter images are stored in tiles of 32 entries); d_lb[q * ld + j] is the bound
  * of query q against slot first_slot + j, ld >= n_slots rounded up to 32 (columns past n_slots are unspecified).
- * Bounds are IEEE binary16 (rsx_f16), rounded toward zero -- the element type of the library's own bound matrix. */
+ * Bounds are IEEE binary16 (rsx_f16), rounded toward zero -- the element type of the library's own bound matrix.
+ * d_lb and d_lb_blocks must be 16-byte aligned (RSX_ERR_BAD_ARG otherwise: they are written / read with 16-byte accesses).
+ * n_slots == 0 is a no-op whatever first_slot says (a rank whose range lies beyond the entries of a small database). */
 typedef uint16_t rsx_f16;
 int rsx_sc_filter_range_device(rsx_sc *h, const float *d_q_descs, int32_t nq, int64_t first_slot, int64_t n_slots,
                                rsx_f16 *d_lb, int64_t ld, void *stream);

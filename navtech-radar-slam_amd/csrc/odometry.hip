@@ -224,6 +224,18 @@ int check_layout(rsx_odometry *h, int32_t n, int64_t image_stride_bytes, int32_t
   return RSX_OK;
 }
 
+// the azimuth grids are host arrays here: every grid must ascend (the Cartesian remap divides by az[1] - az[0] on the
+// device, frontend.hip az_row_of: a zero or negative step would give NaN row indices and NaN images instead of a status)
+int check_azimuths(const rsx_odometry *h, const float *azimuths, int32_t per_image, int32_t n_scans) {
+  if (h->rows < 2) return RSX_OK;
+  const int grids = per_image ? n_scans : 1;
+  for (int g = 0; g < grids; g++) {
+    const float *az = azimuths + (size_t)g * h->rows;
+    if (!((double)az[1] - (double)az[0] > 0.0)) return fail(RSX_ERR_BAD_ARG, "azimuths must increase (scan %d)", g);
+  }
+  return RSX_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -308,6 +320,7 @@ int rsx_odometry_push_device(rsx_odometry *h, const uint8_t *d_imgs, int32_t n_s
   if (!h || !d_imgs || !azimuths || !out || n_scans < 0 || max_xy < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n_scans == 0) return RSX_OK;
   RSX_TRY(check_layout(h, n_scans, image_stride_bytes, row_stride));
+  RSX_TRY(check_azimuths(h, azimuths, azimuths_per_image, n_scans));
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;
@@ -326,6 +339,7 @@ int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int
   if (!h || !imgs || !azimuths || !out || n_scans < 0 || max_xy < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (n_scans == 0) return RSX_OK;
   RSX_TRY(check_layout(h, n_scans, image_stride_bytes, row_stride));
+  RSX_TRY(check_azimuths(h, azimuths, azimuths_per_image, n_scans));
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
   hipStream_t s = h->stream;

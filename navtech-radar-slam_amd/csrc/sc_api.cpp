@@ -859,15 +859,18 @@ int rsx_sc_add_keyframe(rsx_sc *h, rsx_voxelgrid *vg, rsx_kfstore *kf, const voi
   const float *d_ds = nullptr;
   int64_t nds = 0;
   RSX_TRY(rsx::vg::upload_and_filter(vg, pts, (int64_t)n, (int64_t)stride_bytes, intensity_offset, leaf, (int64_t)(n ? n : 1), &d_ds, &nds));
-  int32_t kf_index = -1;
-  RSX_TRY(rsx::kf::append_device_locked(kf, d_ds, nds, &kf_index));  // keyframeLaserClouds.push_back (PGO.cpp:487)
-  if (owns(h, g)) {
+  // the descriptor first, the store last, the counters only when both stand: a failure in either leaves database and store
+  // with the same number of keyframes (the slot written here is simply written again by the next call)
+  const bool mine = owns(h, g);
+  if (mine) {
     const int64_t slot = h->n_local;
     RSX_TRY(ensure_capacity(h, slot + 1));
     RSX_TRY(insert_cloud(h, d_ds ? static_cast<const void *>(d_ds) : h->desc.p, nds, 16, slot, h->stream));  // makeAndSaveScancontextAndKeys (PGO.cpp:492)
     RSX_HIP(hipStreamSynchronize(h->stream));  // d_ds belongs to vg: it must not be overwritten by vg's next call before the build has read it
-    h->n_local = slot + 1;
   }
+  int32_t kf_index = -1;
+  RSX_TRY(rsx::kf::append_device_locked(kf, d_ds, nds, &kf_index));  // keyframeLaserClouds.push_back (PGO.cpp:487)
+  if (mine) h->n_local = h->n_local + 1;
   h->n_global = g + 1;
   if (out_index) *out_index = (int32_t)g;
   return RSX_OK;
@@ -1373,11 +1376,12 @@ int rsx_sc_filter_range_device(rsx_sc *h, const float *d_q, int32_t nq, int64_t 
   if (!h || !d_q || !d_lb || nq < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (first_slot < 0 || first_slot % 32 || n_slots < 0) return fail(RSX_ERR_BAD_ARG, "the range must start at a multiple of 32 slots");
   if (ld < (n_slots + 31) / 32 * 32 || ld % 8) return fail(RSX_ERR_BAD_ARG, "ld must cover the range rounded up to 32 slots");
+  if ((reinterpret_cast<uintptr_t>(d_lb) & 15u) != 0) return fail(RSX_ERR_BAD_ARG, "d_lb must be 16-byte aligned");
+  if (n_slots == 0) return RSX_OK;  // an empty range (a rank beyond the entries of a small database) names no slot
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   if (first_slot + n_slots > h->n_local) return fail(RSX_ERR_RANGE, "slots [%lld, %lld) of %lld", (long long)first_slot,
                                                      (long long)(first_slot + n_slots), (long long)h->n_local);
-  if (n_slots == 0) return RSX_OK;
   hipStream_t s;
   RSX_TRY(use_stream(h, stream, &s));
   QueryView qv;
@@ -1390,6 +1394,8 @@ int rsx_sc_query_bounds_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t 
                                int32_t n_blocks, int64_t block_ld, int64_t block_stride, rsx_sc_hit *d_out, void *stream) try {
   if (!h || !d_q || !d_lb_blocks || !d_out || nq < 1 || n_blocks < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k must be in [1,%d]", RSX_SC_MAX_TOPK);
+  if ((reinterpret_cast<uintptr_t>(d_lb_blocks) & 15u) != 0)  // the blocks are read with 16-byte loads
+    return fail(RSX_ERR_BAD_ARG, "d_lb_blocks must be 16-byte aligned");
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   if (h->p.shard_world != 1) return fail(RSX_ERR_BAD_ARG, "bounds from filter shards need the whole database in this handle (shard_world 1)");

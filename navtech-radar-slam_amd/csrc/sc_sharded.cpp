@@ -242,6 +242,12 @@ int query_locked(rsx_scs *h, const float *q, int32_t nq, int32_t k, int64_t n_el
     for (const Pending &p : pend)
       if (use(*p.lead) == RSX_OK) (void)hipStreamSynchronize(p.lead->stream);
   };
+  // after a failure: EVERY shard stream of EVERY group (the group that failed part-way is not in `pend`, and the non-lead
+  // shards of the others may still hold uploads from the caller's query buffer or exchanges in flight)
+  auto drain_all = [&]() {
+    for (Shard &sh : h->sh)
+      if (sh.stream && use(sh) == RSX_OK) (void)hipStreamSynchronize(sh.stream);
+  };
   // first every group is launched (device work only: the groups run concurrently) ...
   for (int g = 0; g < Q; g++) {
     const int32_t lo = std::min(nq, g * chunk), n = std::min(nq, lo + chunk) - lo;
@@ -250,7 +256,7 @@ int query_locked(rsx_scs *h, const float *q, int32_t nq, int32_t k, int64_t n_el
     Group &gr = h->gr[(size_t)g];
     const int st = query_group(h, gr, q + (size_t)lo * RSX_SC_DESC_SIZE, n, k, n_eligible, &d_res);
     if (st != RSX_OK) {
-      drain();
+      drain_all();
       return st;
     }
     pend.push_back(Pending{&h->sh[(size_t)gr.first], d_res, lo, n});
@@ -265,7 +271,8 @@ int query_locked(rsx_scs *h, const float *q, int32_t nq, int32_t k, int64_t n_el
       st = fail(RSX_ERR_HIP, "read-back of a query group failed");
     if (st != RSX_OK) break;
   }
-  drain();
+  if (st != RSX_OK) drain_all();
+  else drain();
   return st;
 }
 

@@ -328,7 +328,10 @@ class FilterShardedScanContext:
         out = []
         for r in range(self.world):
             first = min(n_entries, r * ld_r)
-            out.append((r * ld_r, min(n_entries, first + ld_r) - first))
+            cnt = min(n_entries, first + ld_r) - first
+            # an empty range starts at the last tile boundary inside the database (a rank beyond the entries -- a small or
+            # growing DB on many ranks -- must not name slots that do not exist; its column block is never read)
+            out.append((r * ld_r if cnt else n_entries // 32 * 32, cnt))
         return ld_r, out
 
     def _n_entries(self, n_eligible):
@@ -355,13 +358,15 @@ class FilterShardedScanContext:
         mine = self._buf("mine", (chunk, k, 2), torch.float64)
         if self.world == 1:
             send = self._buf("send", (chunk, ld_r), torch.float16)
-            self.backend.filter_range_device(q_ptr, nq, first, n, send.data_ptr(), ld_r, stream=stream)
+            if n:
+                self.backend.filter_range_device(q_ptr, nq, first, n, send.data_ptr(), ld_r, stream=stream)
             self.backend.query_bounds_device(q_ptr, nq, k, mine.data_ptr(), send.data_ptr(), 1, ld_r, chunk * ld_r,
                                              n_eligible=n_eligible, stream=stream)
             return mine[:nq]
         send = self._buf("send", (self.world * chunk, ld_r), torch.float16)
         recv = self._buf("recv", (self.world, chunk, ld_r), torch.float16)
-        self.backend.filter_range_device(q_ptr, nq, first, n, send.data_ptr(), ld_r, stream=stream)
+        if n:  # (a rank without entries still takes part in the exchange: the others are already waiting in it)
+            self.backend.filter_range_device(q_ptr, nq, first, n, send.data_ptr(), ld_r, stream=stream)
         _all_to_all(self._dist, recv.view(-1).view(torch.uint8), send.view(-1).view(torch.uint8), self.group, self._staged)  # fp16 as bytes (gloo has no half)
         if hi > lo:
             self.backend.query_bounds_device(q_ptr + lo * 4800, hi - lo, k, mine.data_ptr(), recv.data_ptr(), self.world, ld_r,

@@ -221,6 +221,20 @@ def _worker_filter_shards(rank, world, port, ret):
                 for i in range(len(qs)):
                     want = full.exhaustive(qs[i].astype(np.float64), n_eligible=n if n_elig < 0 else n_elig, k=k)
                     assert np.array_equal(got[i], want), (rank, n_elig, i, got[i], want)
+        # a database smaller than the ranks' tiles (the live, growing DB): trailing ranks have an empty range that must not
+        # name slots beyond the entries, and still take part in the exchange
+        for n_small in (0, 5, 40, 100):
+            small = sharded.FilterShardedScanContext(local_backend=OracleReplica(po))
+            if n_small:
+                small.add_descriptors_f32(descs[:n_small])
+            ld_s, rng_s = small.ranges(n_small)
+            assert all(f + c <= n_small and f % 32 == 0 for f, c in rng_s) and sum(c for _, c in rng_s) == n_small, rng_s
+            ref = po.Manager()
+            if n_small:
+                ref.add_descriptors(descs[:n_small].astype(np.float64))
+            got = small.query(queries, k=k)
+            for i in range(nq):
+                assert np.array_equal(got[i], ref.exhaustive(queries[i].astype(np.float64), n_eligible=n_small, k=k)), (rank, n_small, i)
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

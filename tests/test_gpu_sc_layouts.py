@@ -27,6 +27,37 @@ def _workload(n=2003, nq=67):
     return descs, queries
 
 
+@pytest.mark.parametrize("n_db", [100, 1025])
+def test_filter_shards_of_a_small_database_on_8_ranks(n_db):
+    """100 or 1025 keyframes on 8 ranks (round-4 advisor finding): the trailing ranks' ranges are empty and start INSIDE the
+    database -- rsx_sc_filter_range_device used to refuse them with RSX_ERR_RANGE while the other ranks were already waiting
+    in the all-to-all -- and an empty range is a no-op whatever its first slot is"""
+    import torch
+    from navtech_radar_slam_amd import scancontext as sc, sharded
+    descs, queries = _workload(n=n_db, nq=9)
+    g = sc.SCManager(filter_mode=2)
+    g.add_descriptors_f32(descs)
+    lay = sharded.FilterShardedScanContext.__new__(sharded.FilterShardedScanContext)
+    lay.world = 8
+    ld_r, rng = sharded.FilterShardedScanContext.ranges(lay, n_db)
+    assert sum(c for _, c in rng) == n_db and all(f % 32 == 0 and f + c <= n_db for f, c in rng), rng
+    assert any(c == 0 for _, c in rng)
+    dq = torch.from_numpy(queries).cuda()
+    side = torch.cuda.Stream()
+    torch.cuda.set_stream(side)
+    s = side.cuda_stream
+    sends = torch.full((8, len(queries), ld_r), float("nan"), dtype=torch.float16, device="cuda")
+    for r, (first, cnt) in enumerate(rng):
+        g.filter_range_device(dq.data_ptr(), len(queries), first, cnt, sends[r].data_ptr(), ld_r, stream=s)
+    g.filter_range_device(dq.data_ptr(), len(queries), 7 * ld_r, 0, sends[7].data_ptr(), ld_r, stream=s)   # the old, unclamped start
+    got = torch.zeros((len(queries), 5, 2), dtype=torch.float64, device="cuda")
+    g.query_bounds_device(dq.data_ptr(), len(queries), 5, got.data_ptr(), sends.data_ptr(), 8, ld_r, len(queries) * ld_r, stream=s)
+    torch.cuda.synchronize()
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    assert np.array_equal(got.cpu().numpy().view(sc.HIT_DTYPE).reshape(len(queries), 5), g.query(queries, k=5))
+    g.close()
+
+
 @pytest.mark.parametrize("world", [2, 8])
 @pytest.mark.parametrize("n_elig", [-1, 1973, 40, 0])
 def test_filter_shards_emulated_on_one_gpu(world, n_elig):
