@@ -97,7 +97,15 @@ typedef struct {
    * with two waves per SIMD (the entry tile split by frequency over a wave pair; same bounds bit for bit).  All give
    * valid lower bounds of the same quantity; results are identical. */
   int32_t filter_kind;
+  /* summation order of the sums the reference takes through Eigen (mean, norm, dot): a property of how the REFERENCE was
+   * built, which the bit-exact contract follows.  RSX_SC_SUM_EIGEN_SSE2 (0, default) = the reference as its CMakeLists.txt
+   * builds it (x86-64, -O3, 2-double packets); RSX_SC_SUM_SEQ = Eigen without vectorisation; RSX_SC_SUM_EIGEN_AVX_FMA = a
+   * workspace compiled with -march=native (4-double packets, fused multiply-adds).  csrc/sc_redux_dev.h. */
+  int32_t sum_order;
 } rsx_sc_params;
+#define RSX_SC_SUM_EIGEN_SSE2 0
+#define RSX_SC_SUM_SEQ 1
+#define RSX_SC_SUM_EIGEN_AVX_FMA 2
 
 typedef enum {
   RSX_SC_MODE_CANDIDATE = 0, /* reference semantics: ring-key 3-NN then 3 pair distances (SC.cpp:331-422) */

@@ -118,7 +118,7 @@ int use_stream(rsx_sc *h, void *stream, hipStream_t *s) {
 int insert_cloud(rsx_sc *h, const void *d_pts, int64_t n_pts, int64_t stride, int64_t slot, hipStream_t s) {
   return launch_insert(d_pts, nullptr, n_pts, 1, stride, h->p.lidar_height, h->p.max_radius, slot, h->desc.as<float>(),
                        h->vkey.as<double>(), h->norm.as<double>(), h->rkey.as<float>(), h->hn.p, h->hnr.p,
-                       h->cmask.as<uint64_t>(), h->sp.p, h->sp_aux.as<float>(), h->vk16.p, h->vk_n.as<float>(), s);
+                       h->cmask.as<uint64_t>(), h->sp.p, h->sp_aux.as<float>(), h->vk16.p, h->vk_n.as<float>(), s, h->p.sum_order);
 }
 
 int ensure_capacity(rsx_sc *h, int64_t want_local) {
@@ -156,6 +156,7 @@ DbView db_view(const rsx_sc *h) {
   v.n_local = h->n_local;
   v.idx_base = h->p.shard_rank;
   v.idx_stride = h->p.shard_world;
+  v.sum_order = h->p.sum_order;
   return v;
 }
 
@@ -204,7 +205,7 @@ int prepare_queries(rsx_sc *h, const float *d_q, int32_t nq, hipStream_t s, Quer
   RSX_TRY(h->w->q_vkey.reserve((size_t)nq * NS * sizeof(double), s, false));
   RSX_TRY(h->w->q_norm.reserve((size_t)nq * NS * sizeof(double), s, false));
   RSX_TRY(h->w->q_rkey.reserve((size_t)nq * NR * sizeof(float), s, false));
-  RSX_TRY(launch_keys(d_q, nq, h->w->q_vkey.as<double>(), h->w->q_norm.as<double>(), h->w->q_rkey.as<float>(), s));
+  RSX_TRY(launch_keys(d_q, nq, h->w->q_vkey.as<double>(), h->w->q_norm.as<double>(), h->w->q_rkey.as<float>(), s, h->p.sum_order));
   qv->desc = d_q;
   qv->vkey = h->w->q_vkey.as<double>();
   qv->norm = h->w->q_norm.as<double>();
@@ -671,6 +672,7 @@ int rsx_sc_default_params(rsx_sc_params *p) try {
   p->capacity_hint = 1024;
   p->filter_mode = 0;
   p->filter_kind = 0;
+  p->sum_order = RSX_SC_SUM_EIGEN_SSE2;
   return RSX_OK;
 } RSX_CATCH_ALL
 
@@ -688,6 +690,7 @@ int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) try {
     return fail(RSX_ERR_BAD_ARG, "kernels are specialised for SEARCH_RADIUS 3 (search_ratio 0.1, SC.h:96)");
   if (d.tree_making_period < 1 || d.num_exclude_recent < 0) return fail(RSX_ERR_BAD_ARG, "bad detector params");
   if (d.filter_mode < 0 || d.filter_mode > 3) return fail(RSX_ERR_BAD_ARG, "filter_mode must be 0 (auto), 1 (off), 2 (force) or 3 (single-query path)");
+  if (d.sum_order < 0 || d.sum_order > RSX_SC_SUM_EIGEN_AVX_FMA) return fail(RSX_ERR_BAD_ARG, "sum_order must be RSX_SC_SUM_EIGEN_SSE2, _SEQ or _EIGEN_AVX_FMA");
   if (d.filter_kind < 0 || d.filter_kind > 3)
     return fail(RSX_ERR_BAD_ARG, "filter_kind must be 0 (auto), 1 (direct), 2 (spectral) or 3 (spectral, two waves per SIMD)");
   int ndev = rsx_device_count();
@@ -890,7 +893,7 @@ static int add_f32_locked(rsx_sc *h, const float *src, int64_t n, bool src_is_de
                              DS * sizeof(float), (size_t)count,
                              src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s));
     RSX_TRY(launch_keys(dst, count, h->vkey.as<double>() + slot * NS, h->norm.as<double>() + slot * NS,
-                        h->rkey.as<float>() + slot * NR, s));
+                        h->rkey.as<float>() + slot * NR, s, h->p.sum_order));
     RSX_TRY(build_db_images(h, slot, count, s));
     h->n_local = slot + count;
   }
@@ -1047,7 +1050,7 @@ int rsx_sc_load(rsx_sc *h, const char *path, int64_t *n_loaded) try {
     if (hd.n_local) {
       RSX_TRY(ensure_capacity(h, hd.n_local));
       RSX_HIP(hipMemcpyAsync(h->desc.p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
-      RSX_TRY(launch_keys(h->desc.as<float>(), hd.n_local, h->vkey.as<double>(), h->norm.as<double>(), h->rkey.as<float>(), h->stream));
+      RSX_TRY(launch_keys(h->desc.as<float>(), hd.n_local, h->vkey.as<double>(), h->norm.as<double>(), h->rkey.as<float>(), h->stream, h->p.sum_order));
       RSX_TRY(build_db_images(h, 0, hd.n_local, h->stream));
     }
     h->n_local = hd.n_local;
@@ -1162,7 +1165,7 @@ static int helper_call(rsx_sc *h, int op, const double *a, size_t na, const doub
   int32_t *d_i = reinterpret_cast<int32_t *>(d_o + 96);
   RSX_HIP(hipMemcpyAsync(d_a, a, na * sizeof(double), hipMemcpyHostToDevice, s));
   if (b) RSX_HIP(hipMemcpyAsync(d_b, b, nb * sizeof(double), hipMemcpyHostToDevice, s));
-  RSX_TRY(launch_helper(op, d_a, b ? d_b : nullptr, d_o, d_i, s));
+  RSX_TRY(launch_helper(op, d_a, b ? d_b : nullptr, d_o, d_i, s, h->p.sum_order));
   if (out_d) RSX_HIP(hipMemcpyAsync(out_d, d_o, nd * sizeof(double), hipMemcpyDeviceToHost, s));
   if (out_i) RSX_HIP(hipMemcpyAsync(out_i, d_i, sizeof(int32_t), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
@@ -1206,7 +1209,7 @@ int rsx_sc_make_scancontext(rsx_sc *h, const void *pts, size_t n, size_t stride_
   float *d_desc = h->helper_ws.as<float>();                        // 1200 floats
   double *d_vk = reinterpret_cast<double *>(d_desc + DS);          // + keys (discarded)
   RSX_TRY(launch_build(h->pts_ws.p, (int64_t)n, (int64_t)stride_bytes, h->p.lidar_height, h->p.max_radius, d_desc, d_vk,
-                       d_vk + NS, reinterpret_cast<float *>(d_vk + 2 * NS), s));
+                       d_vk + NS, reinterpret_cast<float *>(d_vk + 2 * NS), s, h->p.sum_order));
   float f[DS];
   RSX_HIP(hipMemcpyAsync(f, d_desc, sizeof(f), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));

@@ -10,6 +10,7 @@
 #include <cstdint>
 
 #include "sc_kernels.h"
+#include "sc_redux_dev.h"
 
 namespace rsx {
 namespace sc {
@@ -59,7 +60,19 @@ __device__ __forceinline__ double wave_sum_f64(double x) {  // (row sums in butt
 // sector key + column norm of ONE column held in registers (c[i] = elements 4 i .. 4 i + 3)
 // Eigen 3.3 redux order of the reference build (SSE2, 2-double packets; oracle/sc_ref.c "reductions"):
 // term i goes to accumulator i % 4 = (packet accumulator i/2 % 2, lane i % 2); result (a0 + a2) + (a1 + a3)
+template <int SO = SO_SSE2>
 __device__ __forceinline__ void column_keys(const float4 (&c)[5], double &vkey, double &norm) {
+  if constexpr (SO != SO_SSE2) {  // the reference built with another packet size (sc_redux_dev.h)
+    double x[NR];
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      x[4 * i] = c[i].x; x[4 * i + 1] = c[i].y; x[4 * i + 2] = c[i].z; x[4 * i + 3] = c[i].w;
+    }
+    auto at = [&](int i) { return x[i]; };
+    vkey = redux_sum<SO, NR>(at) / (double)NR;
+    norm = sqrt(redux_prod<SO, NR>(at, at));
+    return;
+  }
   double s0, s1, s2, s3, q0, q1, q2, q3;
   {
     const float4 v = c[0];
@@ -81,21 +94,27 @@ __device__ __forceinline__ void column_keys(const float4 (&c)[5], double &vkey, 
 }
 
 // sector key + column norm of the lane's column (lanes < 60)
+template <int SO = SO_SSE2>
 __device__ __forceinline__ void wave_keys_columns(const float *__restrict__ d, double *__restrict__ vkey,
                                                   double *__restrict__ norm, int lane) {
   if (lane < NS) {
     const float4 *p = reinterpret_cast<const float4 *>(d + lane * NR);
     const float4 c[5] = {p[0], p[1], p[2], p[3], p[4]};
     double vk, nr;
-    column_keys(c, vk, nr);
+    column_keys<SO>(c, vk, nr);
     vkey[lane] = vk;
     norm[lane] = nr;
   }
 }
 
+template <int SO = SO_SSE2>
 __device__ __forceinline__ void wave_keys(const float *__restrict__ d, double *__restrict__ vkey,
                                           double *__restrict__ norm, float *__restrict__ rkey, int lane) {
-  wave_keys_columns(d, vkey, norm, lane);
+  wave_keys_columns<SO>(d, vkey, norm, lane);
+  if constexpr (SO != SO_SSE2) {
+    if (lane < NR) rkey[lane] = (float)(redux_sum<SO, NS>([&](int c) { return (double)d[c * NR + lane]; }) / (double)NS);
+    return;
+  }
   if (lane < NR) {
     double a[4];
 #pragma unroll
@@ -142,6 +161,7 @@ __device__ __forceinline__ int ceil_clamp(double v, int hi) {
 
 // makeScancontext + the three key builders for one cloud, by one 256-thread block (SC.cpp:151-227); bins: DS words of LDS,
 // which hold the descriptor as floats when the function returns (after a __syncthreads the caller adds if other waves read it)
+template <int SO = SO_SSE2>
 __device__ __forceinline__ void build_block(const char *__restrict__ pts, int64_t n_pts, int64_t stride, double lidar_height,
                                             double max_radius, unsigned *bins, float *__restrict__ out_desc,
                                             double *__restrict__ out_vkey, double *__restrict__ out_norm,
@@ -171,7 +191,7 @@ __device__ __forceinline__ void build_block(const char *__restrict__ pts, int64_
     out_desc[i] = v;
   }
   __syncthreads();
-  if (threadIdx.x < 64) wave_keys(sd, out_vkey, out_norm, out_rkey, threadIdx.x);
+  if (threadIdx.x < 64) wave_keys<SO>(sd, out_vkey, out_norm, out_rkey, threadIdx.x);
 }
 
 constexpr double kImgScale = 32768.0;  // 2^15 on both operands of the direct filter's GEMM

@@ -105,6 +105,7 @@ __device__ __forceinline__ void touch_wait(Touch &t) {
 
 // exact stage 1 of pair_group (fastAlignUsingVkey, SC.cpp:93-113) for one entry: v1 = the query's sector key (60 doubles
 // in LDS), ev = the entry's key, one element per lane; uses the key-image part of the wave's LDS region
+template <int SO = dev::SO_SSE2>
 __device__ __forceinline__ int align_exact(const double *v1, char *wsm, int lane, double ev) {
   const int kk = lane < NS ? lane : NS - 1;
   double *vka = reinterpret_cast<double *>(wsm + ENT_VKEY_A);
@@ -133,7 +134,12 @@ __device__ __forceinline__ int align_exact(const double *v1, char *wsm, int lane
       acc[2 * (cc & 1) + 1] = acc[2 * (cc & 1) + 1] + dd1;
     }
   }
-  const double nrm = sqrt((acc[0] + acc[2]) + (acc[1] + acc[3]));
+  double nrm = sqrt((acc[0] + acc[2]) + (acc[1] + acc[3]));
+  if constexpr (SO != dev::SO_SSE2) {  // the reference built with another packet size: the same 60 terms, its order
+    const double *v1d = v1, *v2d = reinterpret_cast<const double *>(wsm + eoff);
+    auto d = [&](int c) { return v1d[c] - v2d[c]; };
+    nrm = sqrt(dev::redux_prod<SO, NS>(d, d));
+  }
   const bool ok = (lane < NS) && (nrm < kBig);
   double m = ok ? nrm : INFINITY;
 #pragma unroll
@@ -189,6 +195,7 @@ struct WaveLds {
 // exact), half the LDS bytes per column
 // tmask: bit t set = window shift ks - 3 + t is evaluated (wave-uniform; the shifts left out are known to be strictly worse
 // than the best one, so the winner under (distance, shift value) is the same)
+template <int SO = dev::SO_SSE2>
 __device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane, const EntryRegs &er, int ks, unsigned tmask,
                                           double &bd_out, int &bk_out) {
   const int cl = lane < NS ? lane : 0;
@@ -221,7 +228,11 @@ __device__ __forceinline__ void phase_b32(const char *smem, char *wsm, int lane,
       da[2] = fma((double)q4.z, e[4 * i + 2], da[2]);
       da[3] = fma((double)q4.w, e[4 * i + 3], da[3]);
     }
-    const double dot = (da[0] + da[2]) + (da[1] + da[3]);
+    double dot = (da[0] + da[2]) + (da[1] + da[3]);
+    if constexpr (SO != dev::SO_SSE2) {  // (products of two fp32 values are exact in fp64: fused or not is the same number)
+      const float *qf = reinterpret_cast<const float *>(qp);
+      dot = dev::redux_prod<SO, NR>([&](int r) { return (double)qf[r]; }, [&](int r) { return e[r]; });
+    }
     const double n1 = qn1[c];
     const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));
     const double s = dot / (n1 * n2);

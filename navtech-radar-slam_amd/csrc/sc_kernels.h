@@ -29,6 +29,7 @@ struct DbView {
   int64_t n_local;
   int64_t idx_base;    // global index of local slot s = idx_base + s * idx_stride
   int64_t idx_stride;
+  int32_t sum_order;   // RSX_SC_SUM_*: the order of the sums the reference takes through Eigen (sc_redux_dev.h)
 };
 
 // Element of the bound matrix the filter hands to the short-list selection and the re-scoring: fp16, converted with
@@ -52,13 +53,13 @@ struct QueryView {
 };
 
 // keys for n descriptors (device pointers)
-int launch_keys(const float *desc, int64_t n, double *vkey, double *norm, float *rkey, hipStream_t s);
+int launch_keys(const float *desc, int64_t n, double *vkey, double *norm, float *rkey, hipStream_t s, int sum_order);
 
 // descriptor from one point cloud resident in device memory, written to out_desc (1200 floats)
 // followed by its keys
 int launch_build(const void *d_pts, int64_t n_pts, int64_t stride_bytes, double lidar_height,
                  double max_radius, float *out_desc, double *out_vkey, double *out_norm,
-                 float *out_rkey, hipStream_t s);
+                 float *out_rkey, hipStream_t s, int sum_order);
 
 // number of partial top-k slots per query the pair kernel will produce for this problem
 int pair_num_slots(int64_t n_items, int32_t nq);
@@ -81,7 +82,7 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
 int launch_insert(const void *d_pts, const int64_t *d_offs, int64_t n_pts, int64_t n_clouds, int64_t stride_bytes,
                   double lidar_height, double max_radius, int64_t first_slot, float *desc, double *vkey, double *norm,
                   float *rkey, void *hnT, void *hnR, uint64_t *cmask, void *spT, float *aux, void *vk16, float *vk_n,
-                  hipStream_t s);
+                  hipStream_t s, int sum_order);
 
 // merge [nparts][nq][k] -> [nq][k]
 int launch_merge(const rsx_sc_hit *d_parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *d_out,
@@ -224,7 +225,7 @@ const char *q1_kernel_name();
 // ---- the reference's public helper methods on arbitrary double descriptors (sc_helpers.hip) ----
 // op 0: keys of d_a (out_d = ring key [20] + sector key [60]); 1: distDirectSC(d_a, d_b) -> out_d[0];
 // 2: fastAlignUsingVkey(d_a, d_b) (60-element keys) -> out_i[0]; 3: distanceBtnScanContext -> out_d[0], out_i[0]
-int launch_helper(int op, const double *d_a, const double *d_b, double *d_out_d, int32_t *d_out_i, hipStream_t s);
+int launch_helper(int op, const double *d_a, const double *d_b, double *d_out_d, int32_t *d_out_i, hipStream_t s, int sum_order);
 
 // optional hipEvent bracket around the dominant (pair) kernel
 struct PairProfiler {

@@ -51,15 +51,17 @@ namespace {
 using dev::wave_keys;
 
 
+template <int SO>
 __global__ __launch_bounds__(256) void sc_keys_kernel(const float *__restrict__ desc, int64_t n,
                                                       double *__restrict__ vkey, double *__restrict__ norm,
                                                       float *__restrict__ rkey) {
   const int lane = threadIdx.x & 63;
   int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  wave_keys(desc + i * DS, vkey + i * NS, norm + i * NS, rkey + i * NR, lane);
+  wave_keys<SO>(desc + i * DS, vkey + i * NS, norm + i * NS, rkey + i * NR, lane);
 }
 
+template <int SO>
 __global__ __launch_bounds__(256) void sc_build_kernel(const char *__restrict__ pts, int64_t n_pts,
                                                        int64_t stride, double lidar_height,
                                                        double max_radius, float *__restrict__ out_desc,
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void sc_build_kernel(const char *__restrict__ 
                                                        double *__restrict__ out_norm,
                                                        float *__restrict__ out_rkey) {
   __shared__ __attribute__((aligned(16))) unsigned bins[DS];
-  dev::build_block(pts, n_pts, stride, lidar_height, max_radius, bins, out_desc, out_vkey, out_norm, out_rkey);
+  dev::build_block<SO>(pts, n_pts, stride, lidar_height, max_radius, bins, out_desc, out_vkey, out_norm, out_rkey);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -154,7 +156,7 @@ typedef float float2p __attribute__((ext_vector_type(2)));
 constexpr float kPreviewMargin = 1e-4f;
 
 
-template <int B, bool PREVIEW = false, bool FAST = false>
+template <int B, bool PREVIEW = false, bool FAST = false, int SO = dev::SO_SSE2>
 __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, char *wsm, int lane,
                                            const int64_t (&eslot)[B], double &bd_out, int &bk_out,
                                            double tau_prune = INFINITY, int off_preview = 0,
@@ -275,6 +277,12 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
 #pragma unroll
     for (int b = 0; b < B; b++) {
       double nrm = sqrt((acc[b][0] + acc[b][2]) + (acc[b][1] + acc[b][3]));  // SC.cpp:105 norm()
+      if constexpr (SO != dev::SO_SSE2) {  // the reference built with another packet size: the same 60 terms in its order
+        const int eoff = (kk & 1) ? (ENT_VKEY_B + (NS + 1 - kk) * 8) : (ENT_VKEY_A + (NS - kk) * 8);
+        const double *v2d = reinterpret_cast<const double *>(wsm + b * ENT_SIZE + eoff);
+        auto d = [&](int c) { return v1[c] - v2d[c]; };
+        nrm = sqrt(dev::redux_prod<SO, NS>(d, d));
+      }
       bool ok = (lane < NS) && (nrm < kBig);     // SC.cpp:96,104 (NaN never passes `<`)
       double m = ok ? nrm : INFINITY;
 #pragma unroll
@@ -364,7 +372,11 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
           da[2 * (i & 1)] = fma(q2.x, e[2 * i + 0], da[2 * (i & 1)]);  // fp32 x fp32 exact in fp64: fma == mul + add
           da[2 * (i & 1) + 1] = fma(q2.y, e[2 * i + 1], da[2 * (i & 1) + 1]);
         }
-        const double dot = (da[0] + da[2]) + (da[1] + da[3]);
+        double dot = (da[0] + da[2]) + (da[1] + da[3]);
+        if constexpr (SO != dev::SO_SSE2) {  // (fp32 x fp32 products are exact in fp64: fused or not is the same number)
+          const double *qd = reinterpret_cast<const double *>(qp);
+          dot = dev::redux_prod<SO, NR>([&](int r) { return qd[r]; }, [&](int r) { return e[r]; });
+        }
         const double n1 = qn1[c];
         const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));  // SC.cpp:78
         const double s = dot / (n1 * n2);                                  // SC.cpp:81
@@ -434,6 +446,7 @@ __device__ __forceinline__ void pair_group(const DbView &db, const char *smem, c
 // phase_a returns k*; pv = +inf when no shift of the window has an effective column (never a hit), NaN when no
 // preview is possible (norms outside [1e-15, 1e15], non-finite data): such an entry must go through phase B.
 // ------------------------------------------------------------------------------------------
+template <int SO = dev::SO_SSE2>
 __device__ __forceinline__ int phase_a(const char *smem, char *wsm, int lane, const EntryRegs &er, int off_preview,
                                        float e1, float &pv) {
   const int cl = lane < NS ? lane : 0;
@@ -480,7 +493,7 @@ __device__ __forceinline__ int phase_a(const char *smem, char *wsm, int lane, co
     }
     wave_lds_fence();
   }
-  if (need_exact) kstar = align_exact(v1, wsm, lane, ev);
+  if (need_exact) kstar = align_exact<SO>(v1, wsm, lane, ev);
   // fp32 preview of the window distances (see PREVIEW above), arranged for few instructions: the query's unit
   // columns are 0 for an empty column and r2 is 0 for an empty entry column, so no per-lane validity select is
   // needed; the effective-column counts come from the two 60-bit column masks on the scalar unit; the seven lane
@@ -559,6 +572,7 @@ __device__ __forceinline__ int phase_a(const char *smem, char *wsm, int lane, co
 
 // phase B: distDirectSC over the window of a known k* (stages 2 and 3 of pair_group, B = 1).  Every lane returns
 // (bd, bk) = (distance, shift), {1e7, 0} when no shift of the window has an effective column.
+template <int SO = dev::SO_SSE2>
 __device__ __forceinline__ void phase_b(const char *smem, char *wsm, int lane, const EntryRegs &er, int ks, double &bd_out,
                                         int &bk_out) {
   const int cl = lane < NS ? lane : 0;
@@ -588,7 +602,11 @@ __device__ __forceinline__ void phase_b(const char *smem, char *wsm, int lane, c
       da[2 * (i & 1)] = fma(q2.x, e[2 * i + 0], da[2 * (i & 1)]);
       da[2 * (i & 1) + 1] = fma(q2.y, e[2 * i + 1], da[2 * (i & 1) + 1]);
     }
-    const double dot = (da[0] + da[2]) + (da[1] + da[3]);
+    double dot = (da[0] + da[2]) + (da[1] + da[3]);
+    if constexpr (SO != dev::SO_SSE2) {
+      const double *qd = reinterpret_cast<const double *>(qp);
+      dot = dev::redux_prod<SO, NR>([&](int r) { return qd[r]; }, [&](int r) { return e[r]; });
+    }
     const double n1 = qn1[c];
     const bool valid = (lane < NS) && !((n1 == 0.0) | (n2 == 0.0));
     const double s = dot / (n1 * n2);
@@ -690,7 +708,7 @@ __device__ __forceinline__ void load_query_to_lds(const QueryView &q, int qi, ch
 
 
 // W = waves per SIMD the register allocator must leave room for (<= what the LDS footprint allows)
-template <int B, int W>
+template <int B, int W, int SO>
 __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -730,7 +748,7 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
     }
     double bd;
     int bk;
-    pair_group<B>(a.db, smem, wsm, lane, eslot, bd, bk);
+    pair_group<B, false, false, SO>(a.db, smem, wsm, lane, eslot, bd, bk);
 
     // ---- outputs ----
 #pragma unroll
@@ -774,7 +792,7 @@ __global__ __launch_bounds__(256, W) void sc_pair_kernel(PairArgs a) {
 constexpr int PAIR2_OFF_QP32 = OFF_WAVES + 4 * ENT_SIZE;
 constexpr int PAIR2_LDS = PAIR2_OFF_QP32 + QP_SIZE;
 
-template <int W>
+template <int W, int SO>
 __global__ __launch_bounds__(256, W) void sc_pair2_kernel(PairArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x & 63;
@@ -808,13 +826,13 @@ __global__ __launch_bounds__(256, W) void sc_pair2_kernel(PairArgs a) {
     if (g + nwaves < a.n_items) touch_entry(a.db, gath ? (int64_t)gath[g + nwaves] : (a.first + g + nwaves), lane, tch);
     load_entry(a.db, eslot, lane, cur);
     float pv;
-    const int ks = phase_a(smem, wsm, lane, cur, PAIR2_OFF_QP32, e1, pv);
+    const int ks = phase_a<SO>(smem, wsm, lane, cur, PAIR2_OFF_QP32, e1, pv);
     touch_keep(tch);  // phase A has waited for cur's registers, which were requested after the touch
     const double kth = __shfl(ld, a.k - 1);  // +inf until the wave holds k hits
     if ((pv == pv) && (double)pv - (double)kPreviewMargin > kth) continue;  // exact >= pv - margin > the wave's k-th best
     double bd;
     int bk;
-    phase_b(smem, wsm, lane, cur, ks, bd, bk);
+    phase_b<SO>(smem, wsm, lane, cur, ks, bd, bk);
     if (bd < kBig) topk_insert(ld, li, ls, lane, a.k, bd, (int)gidx, bk);  // SC.cpp:388: must beat the 1e7 init
   }
   if (lane < a.k) {
@@ -1063,7 +1081,7 @@ __device__ __forceinline__ double wave_select_kth(const rsx_sc_hit *xch, int nre
 
 // RS_WAVES waves per workgroup, W = waves per SIMD the register allocator leaves room for (several
 // workgroups share a CU so that one query's barriers / merges hide behind another's scoring)
-template <int B, int RS_WAVES, int W, bool TWO = false>
+template <int B, int RS_WAVES, int W, bool TWO, int SO>
 __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArgs a) {
   static_assert(!TWO || B == 1, "two-phase scoring handles one entry per wavefront");
   if (a.stats) a.stats += (blockIdx.x % RESCORE_STAT_COPIES) * RESCORE_STAT_WORDS;
@@ -1169,7 +1187,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
           if (gidx < n_elig) {
             if (g + RS_WAVES < ncand) touch_entry(a.db, cand[g + RS_WAVES], lane, tch);
             load_entry(a.db, slot, lane, cur);
-            ks = phase_a(smem, wsm, lane, cur, L::OFF_QP32, e1, pv);
+            ks = phase_a<SO>(smem, wsm, lane, cur, L::OFF_QP32, e1, pv);
             touch_keep(tch);  // phase A has waited for cur's registers, which were requested after the touch
             const bool usable = (pv == pv) && fabsf(pv) < 3.0e38f;  // NaN / -inf: no preview; +inf: never a hit
             if (usable) topk_insert(ud, ui, us, lane, a.k, (double)pv + (double)kPreviewMargin, (int)gidx, 0);
@@ -1208,7 +1226,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
           load_entry(a.db, slot, lane, cur);
           double bd;
           int bk;
-          phase_b(smem, wsm, lane, cur, (packed >> RS_SLOT_BITS) & 63, bd, bk);
+          phase_b<SO>(smem, wsm, lane, cur, (packed >> RS_SLOT_BITS) & 63, bd, bk);
           if (a.stats && lane == 0) atomicAdd(a.stats + 2, 1ull);
           const int64_t gidx = a.db.idx_base + slot * a.db.idx_stride;
           if (bd < kBig) topk_insert(ld, li, ls, lane, a.k, bd, (int)gidx, bk);
@@ -1231,7 +1249,7 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
       int bk;
       // tau is finite from the second round on: candidates then leave after the alignment + fp32 preview unless
       // they can still reach the top-k
-      pair_group<B, kRescorePreview, B == 1>(a.db, smem, wsm, lane, eslot, bd, bk, tau, L::OFF_QP32, nullptr, e1);
+      pair_group<B, kRescorePreview, B == 1, SO>(a.db, smem, wsm, lane, eslot, bd, bk, tau, L::OFF_QP32, nullptr, e1);
 #pragma unroll
       for (int b = 0; b < B; b++) {
         const double dist = __shfl(bd, b * 8);
@@ -1346,18 +1364,18 @@ __global__ __launch_bounds__(RS_WAVES * 64, W) void sc_rescore_kernel(RescoreArg
   if (timing && lane == 0) atomicAdd(a.stats + 10, (unsigned long long)(clock64() - t_begin));
 }
 
-template <int B, int W>
+template <int B, int W, int SO>
 int launch_pairs_t(const PairArgs &a, int gx, hipStream_t s) {
   static_assert(W <= pair_waves_per_simd<B>(), "LDS footprint does not allow this occupancy");
   static bool attr_set = false;
   const int lds = PairLds<B>::SIZE;
   if (!attr_set) {
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_pair_kernel<B, W>),
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_pair_kernel<B, W, SO>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
   dim3 grid(gx, a.q.nq);
-  hipLaunchKernelGGL((sc_pair_kernel<B, W>), grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL((sc_pair_kernel<B, W, SO>), grid, dim3(256), lds, s, a);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
@@ -1402,18 +1420,18 @@ size_t pair_partial_bytes(int64_t n_items, int32_t nq, int32_t k) {
   return (size_t)pair_num_slots(n_items, nq) * (size_t)nq * (size_t)k * sizeof(rsx_sc_hit);
 }
 
-int launch_keys(const float *desc, int64_t n, double *vkey, double *norm, float *rkey, hipStream_t s) {
+int launch_keys(const float *desc, int64_t n, double *vkey, double *norm, float *rkey, hipStream_t s, int sum_order) {
   if (n <= 0) return RSX_OK;
-  hipLaunchKernelGGL(sc_keys_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, desc, n, vkey, norm, rkey);
+  RSX_SO_DISPATCH(sum_order, hipLaunchKernelGGL(sc_keys_kernel<SO>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, desc, n, vkey, norm, rkey));
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
 
 int launch_build(const void *d_pts, int64_t n_pts, int64_t stride_bytes, double lidar_height,
                  double max_radius, float *out_desc, double *out_vkey, double *out_norm,
-                 float *out_rkey, hipStream_t s) {
-  hipLaunchKernelGGL(sc_build_kernel, dim3(1), dim3(256), 0, s, static_cast<const char *>(d_pts), n_pts,
-                     stride_bytes, lidar_height, max_radius, out_desc, out_vkey, out_norm, out_rkey);
+                 float *out_rkey, hipStream_t s, int sum_order) {
+  RSX_SO_DISPATCH(sum_order, hipLaunchKernelGGL(sc_build_kernel<SO>, dim3(1), dim3(256), 0, s, static_cast<const char *>(d_pts), n_pts,
+                                                stride_bytes, lidar_height, max_radius, out_desc, out_vkey, out_norm, out_rkey));
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
@@ -1475,12 +1493,17 @@ int launch_pairs(const DbView &db, const QueryView &q, const int32_t *gather, in
   static const bool one_phase = rsx::exp_env("RSX_SC_PAIR_ONE_PHASE") != nullptr;  // experiments: the round-1/2 kernel for top-k too
   if (a.partial && !out_dist && !one_phase) {
     static_assert(PAIR2_LDS <= 48 * 1024, "within the default dynamic LDS limit: no per-device opt-in needed");
-    hipLaunchKernelGGL((sc_pair2_kernel<4>), dim3(gx, q.nq), dim3(256), PAIR2_LDS, s, a);
+    RSX_SO_DISPATCH(db.sum_order, hipLaunchKernelGGL((sc_pair2_kernel<4, SO>), dim3(gx, q.nq), dim3(256), PAIR2_LDS, s, a));
     RSX_HIP(hipGetLastError());
-  } else if (var.b == 1) RSX_TRY((launch_pairs_t<1, 4>(a, gx, s)));
-  else if (var.b == 2 && var.w == 3) RSX_TRY((launch_pairs_t<2, 3>(a, gx, s)));
-  else if (var.b == 2) RSX_TRY((launch_pairs_t<2, 4>(a, gx, s)));
-  else RSX_TRY((launch_pairs_t<4, 2>(a, gx, s)));
+  } else if (db.sum_order != dev::SO_SSE2) {  // (the other shapes are tuning experiments of the default order)
+    int st = RSX_OK;
+    if (var.b != 2) return fail(RSX_ERR_BAD_ARG, "RSX_SC_PAIR_VARIANT applies to the default summation order only");
+    RSX_SO_DISPATCH(db.sum_order, st = (launch_pairs_t<2, 4, SO>(a, gx, s)));
+    RSX_TRY(st);
+  } else if (var.b == 1) RSX_TRY((launch_pairs_t<1, 4, dev::SO_SSE2>(a, gx, s)));
+  else if (var.b == 2 && var.w == 3) RSX_TRY((launch_pairs_t<2, 3, dev::SO_SSE2>(a, gx, s)));
+  else if (var.b == 2) RSX_TRY((launch_pairs_t<2, 4, dev::SO_SSE2>(a, gx, s)));
+  else RSX_TRY((launch_pairs_t<4, 2, dev::SO_SSE2>(a, gx, s)));
   if (pp) {
     RSX_HIP(hipEventRecord(pp->ev[2 * pp->used + 1], s));
     pp->used++;
@@ -1516,6 +1539,7 @@ __device__ __forceinline__ float bound_bin_lo(float lb) {  // lower edge of the 
   return x >= 2047.0f ? 2047.0f / 2048.0f : floorf(x) / 2048.0f;
 }
 
+template <int SO>
 __global__ __launch_bounds__(64, 2) void sc_walk_kernel(RescoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int lane = threadIdx.x;
@@ -1551,7 +1575,7 @@ __global__ __launch_bounds__(64, 2) void sc_walk_kernel(RescoreArgs a) {
     const int64_t eslot[1] = {slot};
     double bd;
     int bk;
-    pair_group<1, true>(a.db, smem, wsm, lane, eslot, bd, bk, a.round_begin ? INFINITY : tau, WalkLds::OFF_QP32, &er);
+    pair_group<1, true, false, SO>(a.db, smem, wsm, lane, eslot, bd, bk, a.round_begin ? INFINITY : tau, WalkLds::OFF_QP32, &er);
     const double dist = __shfl(bd, 0);
     const int shift = __shfl(bk, 0);
     const int64_t gidx = a.db.idx_base + (int64_t)slot * a.db.idx_stride;
@@ -1629,9 +1653,10 @@ int launch_walk(const DbView &db, const QueryView &q, const lb_t *lb, int64_t ld
                 const float *thr, double eps, rsx_sc_hit *d_out, int32_t k, hipStream_t s) {
   if (q.nq <= 0) return RSX_OK;
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
+  if (db.sum_order != dev::SO_SSE2) return fail(RSX_ERR_BAD_ARG, "the walk kernel (an experiment) exists for the default summation order only");
   static bool attr_set = false;
   if (!attr_set) {
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_walk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_walk_kernel<dev::SO_SSE2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 WalkLds::SIZE));
     attr_set = true;
   }
@@ -1653,7 +1678,7 @@ int launch_walk(const DbView &db, const QueryView &q, const lb_t *lb, int64_t ld
   a.k = k;
   a.round_begin = rsx::exp_env("RSX_WALK_NOPREVIEW") ? 1 : 0;  // experiment: disable the pruning preview
   a.round_end = RESCORE_ALL_ROUNDS;
-  hipLaunchKernelGGL(sc_walk_kernel, dim3(q.nq), dim3(64), WalkLds::SIZE, s, a);
+  hipLaunchKernelGGL(sc_walk_kernel<dev::SO_SSE2>, dim3(q.nq), dim3(64), WalkLds::SIZE, s, a);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
@@ -1677,6 +1702,7 @@ constexpr int RW_CH = (WINDOW_P + 63) / 64;  // window records per lane
 #ifndef RW_OCC
 #define RW_OCC 3  // waves per SIMD the register budget is set for (168 VGPRs, 13 spilled; 4 = 128 VGPRs with 98 spilled: 0.42 against 0.24 ms)
 #endif
+template <int SO>
 __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (a.stats) a.stats += (blockIdx.x % RESCORE_STAT_COPIES) * RESCORE_STAT_WORDS;
@@ -1767,13 +1793,13 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
       lap(0);  // [4]
     }
     if (ks < 0) {
-      ks = align_exact(reinterpret_cast<const double *>(smem + WaveLds::OFF_QV1), wsm, lane, er.v);
+      ks = align_exact<SO>(reinterpret_cast<const double *>(smem + WaveLds::OFF_QV1), wsm, lane, er.v);
       n_aligned++;
       lap(4);  // [8]
     }
     double bd;
     int bk;
-    phase_b32(smem, wsm, lane, er, ks, tmask, bd, bk);
+    phase_b32<SO>(smem, wsm, lane, er, ks, tmask, bd, bk);
     if (timing) {
       asm volatile("" : "+v"(bd));
       lap(3);  // [7]
@@ -2026,16 +2052,16 @@ __global__ __launch_bounds__(64, RW_OCC) void sc_rescore_wave_kernel(RescoreArgs
   }
 }
 
-template <int B, int NW, int W, bool TWO = false>
+template <int B, int NW, int W, bool TWO = false, int SO = dev::SO_SSE2>
 static int launch_rescore_t(const RescoreArgs &a, hipStream_t s) {
   static bool attr_set = false;
   constexpr int lds = RescoreLds<B, NW>::SIZE;
   if (!attr_set) {
-    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<B, NW, W, TWO>),
+    RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_rescore_kernel<B, NW, W, TWO, SO>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((sc_rescore_kernel<B, NW, W, TWO>), dim3(a.q.nq), dim3(NW * 64), lds, s, a);
+  hipLaunchKernelGGL((sc_rescore_kernel<B, NW, W, TWO, SO>), dim3(a.q.nq), dim3(NW * 64), lds, s, a);
   return RSX_OK;
 }
 
@@ -2086,7 +2112,15 @@ int launch_rescore(const DbView &db, const QueryView &q, const lb_t *lb, int64_t
     return e && e[0] == 'r';
   }();
   if (win && !force_rounds) {
-    hipLaunchKernelGGL(sc_rescore_wave_kernel, dim3(q.nq), dim3(64), WaveLds::SIZE, s, a);
+    RSX_SO_DISPATCH(db.sum_order, hipLaunchKernelGGL(sc_rescore_wave_kernel<SO>, dim3(q.nq), dim3(64), WaveLds::SIZE, s, a));
+    RSX_HIP(hipGetLastError());
+    return RSX_OK;
+  }
+  if (db.sum_order != dev::SO_SSE2) {  // (the other workgroup shapes are tuning experiments of the default order)
+    int st = RSX_OK;
+    if (a.two_phase) RSX_SO_DISPATCH(db.sum_order, st = (launch_rescore_t<1, 4, 4, true, SO>(a, s)));
+    else RSX_SO_DISPATCH(db.sum_order, st = (launch_rescore_t<1, 4, 4, false, SO>(a, s)));
+    RSX_TRY(st);
     RSX_HIP(hipGetLastError());
     return RSX_OK;
   }

@@ -134,6 +134,7 @@ __device__ __forceinline__ u64 wave_min_u64(u64 v) { return dev::wave_minmax_u64
 #define Q1_MARK(i) do { } while (0)
 #endif
 
+template <int SO>
 __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef RSX_EXPERIMENTS
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
   dev::KeySplit ksplit{};
   if (wave == 0) {
     double vk = 0.0, nr = 0.0;
-    dev::column_keys(qcol, vk, nr);
+    dev::column_keys<SO>(qcol, vk, nr);
     bool nonzero = false, bad = false;
     if (lane < NS) {
       float4 *qf = reinterpret_cast<float4 *>(smem + Q1_OFF_Q) + lane * (NR / 4);
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
     if (lane == 0) *reinterpret_cast<u64 *>(misc + Q1_MISC_MASK) = m;
   } else if (wave == 1) {
     double vk = 0.0, nr = 0.0;
-    dev::column_keys(qcol, vk, nr);
+    dev::column_keys<SO>(qcol, vk, nr);
     ksplit = win::query_keys_stage<true>(lane < NS ? vk : 0.0, st2, lane);
   }
   __syncthreads();
@@ -586,12 +587,12 @@ __global__ __launch_bounds__(256, 2) void sc_q1_kernel(Q1Args a) {
           if (m7) tmask = m7;
         }
         if (ks < 0) {
-          ks = align_exact(reinterpret_cast<const double *>(qsm + WaveLds::OFF_QV1), wsm, lane, cur.v);
+          ks = align_exact<SO>(reinterpret_cast<const double *>(qsm + WaveLds::OFF_QV1), wsm, lane, cur.v);
           n_aligned++;
         }
         double bd;
         int bk;
-        phase_b32(qsm, wsm, lane, cur, ks, tmask, bd, bk);
+        phase_b32<SO>(qsm, wsm, lane, cur, ks, tmask, bd, bk);
         n_exact++;
         n_shifts += (unsigned)__builtin_popcount(tmask);
         r.d = bd;
@@ -747,14 +748,17 @@ int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, i
   if (k < 1 || k > RSX_SC_MAX_TOPK) return fail(RSX_ERR_BAD_ARG, "k=%d out of range [1,%d]", k, RSX_SC_MAX_TOPK);
   if (n_items < 0) n_items = 0;
   if (n_items >= (1ll << 31)) return fail(RSX_ERR_RANGE, "the single-query path addresses local slots with 31 bits");
-  {  // 68 KiB of dynamic LDS: opt in once per device
-    static std::atomic<unsigned long long> attr_set{0};
+  {  // 68 KiB of dynamic LDS: opt in once per device (and summation order: each is a kernel of its own)
+    static std::atomic<unsigned long long> attr_set[3] = {};
     int dev = 0;
     RSX_HIP(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
-    if (!(attr_set.load(std::memory_order_relaxed) & bit)) {
-      RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_q1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, Q1_LDS));
-      attr_set.fetch_or(bit, std::memory_order_relaxed);
+    const int so = (db.sum_order >= 0 && db.sum_order <= 2) ? db.sum_order : 0;
+    if (!(attr_set[so].load(std::memory_order_relaxed) & bit)) {
+      hipError_t e = hipSuccess;
+      RSX_SO_DISPATCH(so, e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_q1_kernel<SO>), hipFuncAttributeMaxDynamicSharedMemorySize, Q1_LDS));
+      RSX_HIP(e);
+      attr_set[so].fetch_or(bit, std::memory_order_relaxed);
     }
   }
   const int g = q1_grid(n_items, k);
@@ -774,7 +778,7 @@ int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, i
   a.ws_rec = a.ws_ubs + (size_t)nq * 16 * g;
   a.ws_blk = a.ws_rec + (size_t)nq * 2 * Q1_SOA * g;
   a.stats = d_stats;
-  hipLaunchKernelGGL(sc_q1_kernel, dim3((unsigned)g, (unsigned)nq), dim3(256), Q1_LDS, s, a);
+  RSX_SO_DISPATCH(db.sum_order, hipLaunchKernelGGL(sc_q1_kernel<SO>, dim3((unsigned)g, (unsigned)nq), dim3(256), Q1_LDS, s, a));
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

@@ -316,6 +316,7 @@ struct InsertArgs {
   float *vk_n;
 };
 
+template <int SO>
 __global__ __launch_bounds__(256) void sc_insert_kernel(InsertArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned bins[DS];
   __shared__ double xn[DS + 32];
@@ -324,7 +325,7 @@ __global__ __launch_bounds__(256) void sc_insert_kernel(InsertArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t slot = a.first + blockIdx.x;
   const int64_t p0 = a.offs ? a.offs[blockIdx.x] : 0, p1 = a.offs ? a.offs[blockIdx.x + 1] : a.n_pts;
-  dev::build_block(a.pts + p0 * a.stride, p1 - p0, a.stride, a.lidar_height, a.max_radius, bins, a.desc + slot * DS,
+  dev::build_block<SO>(a.pts + p0 * a.stride, p1 - p0, a.stride, a.lidar_height, a.max_radius, bins, a.desc + slot * DS,
                    a.vkey + slot * NS, a.norm + slot * NS, a.rkey + slot * NR);
   // the images read the descriptor and its norms back from global memory: written by this block, visible to it after the
   // barrier (the same L1 / write-through path)
@@ -1690,7 +1691,7 @@ int launch_spec_query_images(const float *desc, const double *norm, int32_t nq, 
 int launch_insert(const void *d_pts, const int64_t *d_offs, int64_t n_pts, int64_t n_clouds, int64_t stride_bytes,
                   double lidar_height, double max_radius, int64_t first_slot, float *desc, double *vkey, double *norm,
                   float *rkey, void *hnT, void *hnR, uint64_t *cmask, void *spT, float *aux, void *vk16, float *vk_n,
-                  hipStream_t s) {
+                  hipStream_t s, int sum_order) {
   if (n_clouds <= 0) return RSX_OK;
   InsertArgs a;
   a.pts = static_cast<const char *>(d_pts);
@@ -1711,7 +1712,7 @@ int launch_insert(const void *d_pts, const int64_t *d_offs, int64_t n_pts, int64
   a.aux = aux;
   a.vk16 = static_cast<_Float16 *>(vk16);
   a.vk_n = vk_n;
-  hipLaunchKernelGGL(sc_insert_kernel, dim3((unsigned)n_clouds), dim3(256), 0, s, a);
+  RSX_SO_DISPATCH(sum_order, hipLaunchKernelGGL(sc_insert_kernel<SO>, dim3((unsigned)n_clouds), dim3(256), 0, s, a));
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }

@@ -349,6 +349,15 @@ class SCManager {
   void setExhaustive(bool on) { mode_ = on ? RSX_SC_MODE_EXHAUSTIVE : RSX_SC_MODE_CANDIDATE; }
   void setVerbose(bool on) { verbose_ = on; }
   void setStrictImport(bool on) { strict_import_ = on; }
+  // how the reference this shim replaces was BUILT: the order of the sums it takes through Eigen (rsx.h RSX_SC_SUM_*).  The
+  // default is the reference's own CMakeLists.txt (x86-64, SSE2); a catkin workspace compiled with -march=native wants
+  // RSX_SC_SUM_EIGEN_AVX_FMA for bit-identical loop decisions.  Before first use.
+  void setSumOrder(int order) {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (h_ || hs_) throw std::runtime_error("setSumOrder after the GPU handle was created");
+    if (order < RSX_SC_SUM_EIGEN_SSE2 || order > RSX_SC_SUM_EIGEN_AVX_FMA) throw std::runtime_error("setSumOrder: unknown order");
+    sum_order_ = order;
+  }
   void setDevice(int device) {  // before first use
     std::lock_guard<std::mutex> lk(mu_);
     if (h_ || hs_) throw std::runtime_error("setDevice after the GPU handle was created");
@@ -417,6 +426,7 @@ class SCManager {
       rsx_sc_default_params(&p);
       p.dist_thres = SC_DIST_THRES;
       p.device = device_;
+      p.sum_order = sum_order_;
       check(rsx_sc_create(&p, &h_), "SCManager (rsx_sc_create)");
     }
     return h_;
@@ -427,6 +437,7 @@ class SCManager {
       rsx_sc_params p;
       rsx_sc_default_params(&p);
       p.dist_thres = SC_DIST_THRES;
+      p.sum_order = sum_order_;
       std::vector<int32_t> dev(devices_.begin(), devices_.end());
       check(rsx_scs_create_layout(&p, dev.data(), (int32_t)dev.size(), query_groups_, rccl_exchange_ ? RSX_SCS_EXCHANGE_RCCL : RSX_SCS_EXCHANGE_PEER_COPY,
                                   &hs_),
@@ -451,6 +462,7 @@ class SCManager {
       rsx_sc_params p;
       rsx_sc_default_params(&p);
       p.device = device_;
+      p.sum_order = sum_order_;
       p.capacity_hint = 32;
       check(rsx_sc_create(&p, &h_), "SCManager (helper handle)");
     }
@@ -478,6 +490,7 @@ class SCManager {
   std::vector<float> ds_;  // downsampled cloud of the multi-device path
   int mode_ = RSX_SC_MODE_CANDIDATE;
   int device_ = 0;
+  int sum_order_ = RSX_SC_SUM_EIGEN_SSE2;
   std::vector<int> devices_;
   int query_groups_ = 1;
   bool rccl_exchange_ = false;

@@ -30,7 +30,7 @@ class SCManager:
 
     def __init__(self, device=0, shard_rank=0, shard_world=1, capacity_hint=1024, sc_dist_thres=0.2,
                  lidar_height=None, num_exclude_recent=None, num_candidates=None, tree_making_period=None,
-                 filter_mode=_rsx.FILTER_AUTO, filter_kind=_rsx.KIND_AUTO):
+                 filter_mode=_rsx.FILTER_AUTO, filter_kind=_rsx.KIND_AUTO, sum_order=_rsx.SUM_EIGEN_SSE2):
         L = lib()
         p = _rsx.ScParams()
         check(L.rsx_sc_default_params(C.byref(p)))
@@ -39,6 +39,7 @@ class SCManager:
         p.dist_thres = sc_dist_thres
         p.filter_mode = filter_mode
         p.filter_kind = filter_kind or _rsx.default_filter_kind
+        p.sum_order = sum_order
         if lidar_height is not None:
             p.lidar_height = lidar_height
         if num_exclude_recent is not None:

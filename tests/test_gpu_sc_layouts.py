@@ -34,7 +34,7 @@ def test_filter_shards_of_a_small_database_on_8_ranks(n_db):
     in the all-to-all -- and an empty range is a no-op whatever its first slot is"""
     import torch
     from navtech_radar_slam_amd import scancontext as sc, sharded
-    descs, queries = _workload(n=n_db, nq=9)
+    descs, queries = _workload(n=n_db, nq=12)
     g = sc.SCManager(filter_mode=2)
     g.add_descriptors_f32(descs)
     lay = sharded.FilterShardedScanContext.__new__(sharded.FilterShardedScanContext)
