@@ -177,6 +177,8 @@ class Workload:
             self.step()
         for _ in range(warmup):
             self.step()
+        self.ssc.time_exchanges = ctx.world > 1 and not ctx.stub   # two events per collective (sharded._ExchangeTimer)
+        self.ssc.exchange_ms()
         ctx.barrier()
         if profile and not ctx.stub:
             self.mgr.profile_enable(True)
@@ -185,6 +187,8 @@ class Workload:
             self.step()
         ctx.barrier()
         dt = time.perf_counter() - t0
+        self.exchange_ms_per_step = self.ssc.exchange_ms() / max(1, steps)   # this rank: inside collectives, waiting for peers included
+        self.ssc.time_exchanges = False
         prof, resc = (0, 0.0), (0, 0)
         if profile and not ctx.stub:
             prof = self.mgr.profile_read()
@@ -1032,8 +1036,9 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even at world 1")
     ap.add_argument("--all-layouts", action="store_true",
                     help="N > 1: time the mixed query-groups x DB-shards layouts too (default: the two pure ones and the headline)")
-    ap.add_argument("--query-groups", type=int, default=0,
-                    help="layout = query groups x DB shards (sharded.py); 0 = auto (as many query groups as the batch feeds), 1 = pure DB shards")
+    ap.add_argument("--query-groups", type=int, default=1,
+                    help="headline layout = query groups x DB shards (sharded.py); 1 (default) = pure DB shards, what north_star names "
+                         "(the DB sharded over the GPUs, RCCL all-gather of the top-k); 0 = auto (as many query groups as the batch feeds)")
     args = ap.parse_args()
 
     dry = bool(os.environ.get("RSX_BENCH_LOCAL_BACKEND"))
@@ -1061,6 +1066,7 @@ def main():
     db_pts = db_off = None
     from navtech_radar_slam_amd.sharded import auto_layout
     qgroups = args.query_groups if args.query_groups > 0 else auto_layout(world, nq)
+    auto_qg = auto_layout(world, nq)
     if world % qgroups:
         raise SystemExit(f"bench.py: --query-groups {qgroups} does not divide --gpus {world}")
     db_descs = None
@@ -1147,10 +1153,11 @@ def main():
         lay = {}
         st_l = max(3, args.steps // 4)
         for qg in [d for d in range(1, world + 1) if world % d == 0]:
-            if qg not in (1, world, qgroups) and not args.all_layouts:
+            if qg not in (1, world, qgroups, auto_qg) and not args.all_layouts:
                 continue   # mixed layouts need torch.distributed subgroups: opt-in (--all-layouts); gloo-tested, never run on RCCL
             if qg == qgroups:
-                lay[main_wl.ssc.layout] = {"ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank], "headline": True}
+                lay[main_wl.ssc.layout] = {"ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+                                           "exchange_ms_per_step_per_rank": ctx.all_gather_float(main_wl.exchange_ms_per_step), "headline": True}
                 continue
             wl = Workload(ctx, main_wl.name, k, n_db, query_groups=qg)
             wl.add_descriptors(fill)
@@ -1159,7 +1166,9 @@ def main():
             same = bool(np.array_equal(wl.results(), res))
             if not same:
                 failures.append(f"layout {wl.ssc.layout} disagrees with layout {main_wl.ssc.layout}")
-            lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl], "identical_to_headline": same}
+            lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl],
+                                  "exchange_ms_per_step_per_rank": ctx.all_gather_float(wl.exchange_ms_per_step), "identical_to_headline": same,
+                                  "auto_layout": qg == auto_qg}
             wl.close()
         if not ctx.stub:
             # filter shards over a replicated DB: has run in two processes on one GPU over gloo (tests/test_gpu_sc_layouts.py),
@@ -1172,14 +1181,20 @@ def main():
                 same = bool(np.array_equal(wl.results(), res))
                 if not same:
                     failures.append(f"layout {wl.ssc.layout} disagrees with layout {main_wl.ssc.layout}")
-                lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl], "identical_to_headline": same}
+                lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl],
+                                      "exchange_ms_per_step_per_rank": ctx.all_gather_float(wl.exchange_ms_per_step), "identical_to_headline": same}
                 wl.close()
             except Exception as e:  # noqa: BLE001
                 lay[f"{world}f"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if rank == 0:
             out["layouts"] = lay
+            timed_l = {n: v["ms_per_step"] for n, v in lay.items() if "ms_per_step" in v}
+            out["best_layout"] = min(timed_l, key=timed_l.get)
+            out["best_layout_queries_per_sec"] = nq / (timed_l[out["best_layout"]] * 1e-3)
             out["layouts_key"] = ("QxS = query groups x DB shards; Gf = filter shards over a replicated DB (one all-to-all of bound rows); "
-                                  "identical results in every layout")
+                                  "identical results in every layout.  `value` is the headline layout (default 1xN: the DB sharded over "
+                                  "the GPUs, RCCL all-gather of the top-k, as north_star names it); best_layout is printed beside it; "
+                                  "exchange_ms_per_step_per_rank = device time inside the collectives (waiting for the slowest peer included)")
 
     # ---- data dependence: the random DB and the exact-all floor, same batch shape --------------
     if not ctx.stub and not args.only_main:

@@ -334,7 +334,7 @@ bool use_window() {
 // images -> MFMA filter -> short list + round edges of one query batch
 // elig_monotone: the per-query limits elig[] do not decrease with the query index (self queries)
 int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig,
-                      int32_t first_target, int32_t k, hipStream_t s, bool elig_monotone = false) {
+                      int32_t first_target, int32_t k, hipStream_t s, bool elig_monotone = false, int32_t window_head_only = 0) {
   const DbView db = db_view(h);
   const int64_t ld = (n_items + 31) / 32 * 32;
   lb_t *lb = h->w->f_lb.as<lb_t>();
@@ -349,7 +349,7 @@ int filter_and_select(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_
   // do on the VALU, one entry per wavefront)
   if (!use_window()) return RSX_OK;
   return launch_window(db, q, h->w->f_wimg.p, h->w->f_cand.as<RescoreEntry>(), h->w->f_cnt.as<int32_t>(), k, filter_eps(),
-                       h->w->f_win.as<WindowPreview>(), s);
+                       h->w->f_win.as<WindowPreview>(), s, window_head_only);
 }
 
 int rescore(rsx_sc *h, const QueryView &q, int64_t n_items, int64_t n_eligible, const int64_t *elig, int32_t round_begin,
@@ -1468,7 +1468,9 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
     if (first < 8) first = 8;
     if (first > 128) first = 128;
     RSX_TRY(filter_reserve(h, items, nq, s));
-    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, k, s, elig_monotone != 0));
+    // (the window previews stop at this shard's round-0 share as well: S shards previewing 128 list positions each is S
+    // times one GPU's window kernel -- the largest part of a shard's time that did not shrink with S)
+    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, k, s, elig_monotone != 0, h->p.shard_world > 1 ? first : 0));
     RSX_TRY(rescore(h, qv, items, n_elig, d_q_elig, 0, 1, nullptr, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));
   } else {
     RSX_TRY(run_topk(h, qv, items, n_elig, d_q_elig, k, h->st_partial.as<rsx_sc_hit>(), s, elig_monotone != 0));  // complete already

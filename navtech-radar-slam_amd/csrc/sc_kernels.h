@@ -204,8 +204,10 @@ size_t window_qimg_bytes(int32_t nq);  // direct-filter images + key images of a
 int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void *vk16, float *vk_n, hipStream_t s);
 // qimg: window_qimg_bytes(nq) of workspace (filled here); out: [nq][WINDOW_P]
 // k: the top-k the query batch asks for; eps: the filter's error budget (filter_eps())
+// head_only > 0: records for the first head_only list positions (rounded up to 32) only, "no record" behind them -- stage 1
+// of a DB shard scores only that many entries per query, and S shards previewing 128 each is S times the work of one GPU
 int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
-                  int32_t k, double eps, WindowPreview *out, hipStream_t s);
+                  int32_t k, double eps, WindowPreview *out, hipStream_t s, int32_t head_only = 0);
 const char *window_kernel_name();
 
 // ---- one query in one launch (sc_q1.hip): the live detector's regime, nq <= Q1_MAX_NQ ----

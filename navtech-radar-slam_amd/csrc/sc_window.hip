@@ -108,13 +108,15 @@ struct WindowArgs {
   WindowPreview *out;
   double eps;  // the filter's error budget, as the re-scoring kernel applies it to a bound
   int32_t k;
+  int32_t head;   // |head| = list positions pass 1 always processes (a multiple of 32, <= WINDOW_HEAD); negative: the
+                  // positions behind them get "no record" (stage 1 of a DB shard: it scores the head only)
 };
 
 
 __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float s_ub[WINDOW_HEAD];
-  __shared__ int s_pos[WINDOW_P - WINDOW_HEAD];
+  __shared__ int s_pos[WINDOW_P];
   __shared__ int s_n2;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int qi = blockIdx.x;
@@ -216,12 +218,23 @@ __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
   };
 
   // ---- pass 1: the head of the list ----
-  const int cnt1 = sl_cnt < WINDOW_HEAD ? sl_cnt : WINDOW_HEAD;
+  const int head = a.head < 0 ? -a.head : a.head;
+  const int cnt1 = sl_cnt < head ? sl_cnt : head;
   float ub = INFINITY;
   if (wave * 32 < cnt1) ub = do_group(wave * 32 + n, wave * 32 + n < cnt1, wave * 32);
   if (hh == 0) s_ub[wave * 32 + n] = ub;
   __syncthreads();
-  if (sl_cnt <= WINDOW_HEAD) return;  // uniform
+  if (sl_cnt <= head) return;  // uniform
+  if (a.head < 0) {  // (uniform) the rest of the list: no record
+    const int lim = sl_cnt < WINDOW_P ? sl_cnt : WINDOW_P;
+    for (int pos = head + (int)threadIdx.x; pos < lim; pos += 256) {
+      WindowPreview o;
+      o.pv = __builtin_nanf("");
+      o.ks = -2;
+      a.out[(int64_t)qi * WINDOW_P + pos] = o;
+    }
+    return;
+  }
 
   // ---- the k-th smallest upper bound of the head: an upper bound of the final k-th best distance.  Only entries whose
   // filter bound does not exceed it can matter to the re-scoring kernel (whose own bound is at least as tight) ----
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
   if (wave == 0) {
     int n2 = 0;
     const int lim = sl_cnt < WINDOW_P ? sl_cnt : WINDOW_P;
-    for (int p0 = WINDOW_HEAD; p0 < lim; p0 += 64) {
+    for (int p0 = head; p0 < lim; p0 += 64) {
       const int pos = p0 + lane;
       bool pass = false;
       if (pos < lim) {
@@ -291,7 +304,7 @@ int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void
 }
 
 int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
-                  int32_t k, double eps, WindowPreview *out, hipStream_t s) {
+                  int32_t k, double eps, WindowPreview *out, hipStream_t s, int32_t head_only) {
   if (q.nq <= 0) return RSX_OK;
   char *img = static_cast<char *>(qimg);
   char *kimg = img + (size_t)q.nq * FILTER_QIMG_BYTES;
@@ -310,6 +323,12 @@ int launch_window(const DbView &db, const QueryView &q, void *qimg, const Rescor
   a.out = out;
   a.eps = eps;
   a.k = k < 1 ? 1 : (k > WINDOW_HEAD ? WINDOW_HEAD : k);
+  a.head = WINDOW_HEAD;
+  if (head_only > 0) {  // a DB shard's stage 1 scores only its first `head_only` list positions
+    int32_t hd = (head_only + 31) / 32 * 32;
+    if (hd > WINDOW_HEAD) hd = WINDOW_HEAD;
+    a.head = -hd;
+  }
   hipLaunchKernelGGL(sc_window_kernel, dim3((unsigned)q.nq), dim3(256), W_LDS, s, a);
   RSX_HIP(hipGetLastError());
   return RSX_OK;

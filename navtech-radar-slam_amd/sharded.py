@@ -66,7 +66,31 @@ def _all_to_all(dist, out, inp, group, staged):
     out.copy_(h)
 
 
-class ShardedScanContext:
+class _ExchangeTimer:
+    """Opt-in (bench.py): device time between the start and the end of every collective on the stream it runs on, the wait
+    for the slowest peer included (two events per exchange; off by default)."""
+    time_exchanges = False
+
+    def _timed_exchange(self, fn):
+        if not self.time_exchanges or not getattr(self, "on_gpu", False):
+            return fn()
+        torch = self._torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = fn()
+        e1.record()
+        self.__dict__.setdefault("_ex_events", []).append((e0, e1))
+        return out
+
+    def exchange_ms(self):
+        """sum over the exchanges recorded since the last call (synchronises)"""
+        ev = self.__dict__.pop("_ex_events", [])
+        if ev:
+            self._torch.cuda.synchronize()
+        return float(sum(a.elapsed_time(b) for a, b in ev))
+
+
+class ShardedScanContext(_ExchangeTimer):
     def __init__(self, group=None, device=None, local_backend=None, capacity_hint=1024, filter_mode=0, query_groups=1):
         import torch
         import torch.distributed as dist
@@ -143,7 +167,7 @@ class ShardedScanContext:
 
     def _gather_merge(self, local, name, nq, k, stream):
         parts = self._buf(name + "_parts", (self.shard_world, nq, k, 2))
-        _all_gather(self._dist, parts.view(-1), local.view(-1), self.shard_group, self._staged)
+        self._timed_exchange(lambda: _all_gather(self._dist, parts.view(-1), local.view(-1), self.shard_group, self._staged))
         out = self._buf(name + "_merged", (nq, k, 2))
         self.backend.merge_device(parts.data_ptr(), self.shard_world, nq, k, out.data_ptr(), stream=stream)
         return out
@@ -198,7 +222,7 @@ class ShardedScanContext:
         if hi > lo:
             mine[:hi - lo].copy_(res[:hi - lo])
         whole = self._buf("whole", (self.n_qgroups * chunk, k, 2))
-        _all_gather(self._dist, whole.view(-1), mine.view(-1), self.col_group, self._staged)
+        self._timed_exchange(lambda: _all_gather(self._dist, whole.view(-1), mine.view(-1), self.col_group, self._staged))
         return whole[:nq]
 
     def _gather_merge_host(self, local, nq, k):
@@ -261,7 +285,7 @@ class ShardedScanContext:
         self._subgroups = []
 
 
-class FilterShardedScanContext:
+class FilterShardedScanContext(_ExchangeTimer):
     """Filter shards over a REPLICATED database (rsx.h: rsx_sc_filter_range_device / rsx_sc_query_bounds_device).
 
     Every rank holds every keyframe -- the DB is small next to HBM (0.83 GB per 100 000 keyframes) -- and a batch costs
@@ -367,12 +391,13 @@ class FilterShardedScanContext:
         recv = self._buf("recv", (self.world, chunk, ld_r), torch.float16)
         if n:  # (a rank without entries still takes part in the exchange: the others are already waiting in it)
             self.backend.filter_range_device(q_ptr, nq, first, n, send.data_ptr(), ld_r, stream=stream)
-        _all_to_all(self._dist, recv.view(-1).view(torch.uint8), send.view(-1).view(torch.uint8), self.group, self._staged)  # fp16 as bytes (gloo has no half)
+        self._timed_exchange(lambda: _all_to_all(self._dist, recv.view(-1).view(torch.uint8), send.view(-1).view(torch.uint8), self.group,
+                                                 self._staged))  # fp16 as bytes (gloo has no half)
         if hi > lo:
             self.backend.query_bounds_device(q_ptr + lo * 4800, hi - lo, k, mine.data_ptr(), recv.data_ptr(), self.world, ld_r,
                                              chunk * ld_r, n_eligible=n_eligible, stream=stream)
         whole = self._buf("whole", (self.world * chunk, k, 2), torch.float64)
-        _all_gather(self._dist, whole.view(-1), mine.view(-1), self.group, self._staged)
+        self._timed_exchange(lambda: _all_gather(self._dist, whole.view(-1), mine.view(-1), self.group, self._staged))
         return whole[:nq]
 
     def query(self, q_descs, k=1, n_eligible=-1):

@@ -40,11 +40,30 @@ def test_bench_spawns_its_own_ranks(gpus):
     assert out["ms_per_step"] == pytest.approx(max(out["per_rank_ms_per_step"]))   # MAX over ranks
     assert out["value"] == pytest.approx(4 / (out["ms_per_step"] * 1e-3), rel=1e-6)
     if gpus > 1:
-        # 4 queries do not feed two query groups: the automatic layout is the pure DB-shard one; every other layout of
-        # the world is timed too and must return the same records
+        # the headline at N > 1 is the layout north_star names -- the DB sharded over the GPUs, all-gather of the top-k (1xN) --
+        # whatever the batch size; every other layout of the world is timed beside it and must return the same records
         assert out["backend"] == "gloo" and out["config"]["parallelism"] == "query_groups1_x_db_shards2" and out["config"]["layout"] == "1x2"
         assert set(out["layouts"]) == {"1x2", "2x1"} and out["layouts"]["1x2"]["headline"] is True
         assert out["layouts"]["2x1"]["identical_to_headline"] is True and len(out["layouts"]["2x1"]["per_rank_ms_per_step"]) == 2
+        assert out["best_layout"] in out["layouts"] and out["best_layout_queries_per_sec"] > 0
+        assert all(len(v["exchange_ms_per_step_per_rank"]) == 2 for v in out["layouts"].values())
+
+
+def test_headline_is_the_db_shard_layout_for_a_large_batch_too():
+    """1024 queries at world 2 would feed two query groups (the automatic layout: DB replicated, pure query parallelism);
+    the headline stays 1x2, the automatic layout is timed beside it and marked"""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["RSX_BENCH_LOCAL_BACKEND"] = "tests.bench_stub:make"
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--db", "80", "--queries", "1024",
+           "--topk", "2", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["config"]["layout"] == "1x2" and out["layouts"]["1x2"]["headline"] is True and out["failures"] == []
+    assert out["layouts"]["2x1"]["auto_layout"] is True and out["layouts"]["2x1"]["identical_to_headline"] is True
 
 
 def test_bench_query_groups_flag():
