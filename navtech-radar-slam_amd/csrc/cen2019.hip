@@ -43,6 +43,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <type_traits>
 
 #include "rsx_common.h"
 
@@ -67,6 +68,21 @@ struct Scal {  // per image
 };
 static_assert(sizeof(Scal) == 64, "Scal layout");
 
+__device__ __forceinline__ int wave_sum_i32(int x) {  // every lane: the sum over the 64 lanes
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);  // row_mirror: every lane = its row's sum
+  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+}
+__device__ __forceinline__ int wave_max_i32(int x) {  // every lane: the maximum over the 64 lanes
+  auto mx = [](int a, int b) { return a > b ? a : b; };
+  x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false));
+  x = mx(x, __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false));
+  return mx(mx(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), mx(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
+}
 __device__ __forceinline__ unsigned ord_f32(float f) {
   unsigned u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
@@ -139,11 +155,7 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
         }
       }
     }
-    int dw = dmax;
-    for (int o = 32; o >= 1; o >>= 1) {
-      const int v = __shfl_xor(dw, o);
-      dw = v > dw ? v : dw;
-    }
+    const int dw = wave_max_i32(dmax);
     if (dw >= 0 && dmax == dw) {  // (rare lanes)
 #pragma unroll
       for (int i = 0; i < C; i++) {
@@ -155,8 +167,8 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
       }
     }
   }
-  for (int o = 32; o >= 1; o >>= 1) sb += __shfl_xor(sb, o);
-  for (int o = 32; o >= 1; o >>= 1) mg = fmaxf(mg, __shfl_xor(mg, o));
+  sb = (unsigned)wave_sum_i32((int)sb);
+  mg = __int_as_float(wave_max_i32(__float_as_int(mg)));  // non-negative floats order like their bits
   if ((threadIdx.x & 63) == 0) {
     s_sum[threadIdx.x >> 6] = sb;
     s_max[threadIdx.x >> 6] = mg;
@@ -175,98 +187,15 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// segmented scans over the NT threads of a block.  An element is (value, head flag); "a then b" combines to
-// (b.head ? b.value : op(a.value, b.value), a.head | b.head): a head starts a new segment.
-// ---------------------------------------------------------------------------------------------------------------
-struct SegMin {
-  unsigned long long v;
-  unsigned f;
-};
-__device__ __forceinline__ SegMin seg_min(SegMin a, SegMin b) {
-  SegMin r;
-  r.v = b.f ? b.v : (a.v < b.v ? a.v : b.v);
-  r.f = a.f | b.f;
-  return r;
-}
-struct SegMax {  // value = (ord(h) << 32 | ~range bin): max = largest h, first bin among equals; adj = OR over the segment
-  unsigned long long v;
-  unsigned f, adj;
-};
-__device__ __forceinline__ SegMax seg_max(SegMax a, SegMax b) {
-  SegMax r;
-  r.v = b.f ? b.v : (a.v > b.v ? a.v : b.v);
-  r.adj = b.f ? b.adj : (a.adj | b.adj);
-  r.f = a.f | b.f;
-  return r;
-}
-// the same with `adj` = a value the segment's head defines (the run's first bin) instead of an OR over the segment
-__device__ __forceinline__ SegMax seg_first(SegMax a, SegMax b) {
-  SegMax r;
-  r.v = b.f ? b.v : (a.v > b.v ? a.v : b.v);
-  r.adj = b.f ? b.adj : a.adj;
-  r.f = a.f | b.f;
-  return r;
-}
-__device__ __forceinline__ SegMin shfl_up_seg(SegMin x, int d) { return SegMin{__shfl_up(x.v, d), (unsigned)__shfl_up((int)x.f, d)}; }
-__device__ __forceinline__ SegMin shfl_down_seg(SegMin x, int d) { return SegMin{__shfl_down(x.v, d), (unsigned)__shfl_down((int)x.f, d)}; }
-__device__ __forceinline__ SegMax shfl_up_seg(SegMax x, int d) {
-  return SegMax{__shfl_up(x.v, d), (unsigned)__shfl_up((int)x.f, d), (unsigned)__shfl_up((int)x.adj, d)};
-}
-
-// exclusive scan of one aggregate per thread, in thread order (REV: from the last thread down); `ident` = the
-// element that changes nothing.  s_w: NT/64 elements of LDS scratch.  Two block barriers.
-template <int NT, bool REV, typename E, typename OP>
-__device__ __forceinline__ E block_excl_scan(E x, E ident, OP op, E *s_w) {
-  constexpr int NW = NT / 64;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    if constexpr (!REV) {
-      const E o = shfl_up_seg(x, d);
-      if (lane >= d) x = op(o, x);
-    } else {
-      const E o = shfl_down_seg(x, d);
-      if (lane + d < 64) x = op(o, x);
-    }
-  }
-  E e;
-  if constexpr (!REV) {
-    e = shfl_up_seg(x, 1);
-    if (lane == 0) e = ident;
-    if (lane == 63) s_w[w] = x;
-  } else {
-    e = shfl_down_seg(x, 1);
-    if (lane == 63) e = ident;
-    if (lane == 0) s_w[w] = x;
-  }
-  __syncthreads();
-  E acc = ident;
-  if constexpr (!REV) {
-    for (int ww = 0; ww < w; ww++) acc = op(acc, s_w[ww]);
-  } else {
-    for (int ww = NW - 1; ww > w; ww--) acc = op(acc, s_w[ww]);
-  }
-  __syncthreads();
-  return op(acc, e);
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Evaluation of one azimuth row by a block of NT threads, C consecutive range bins per thread (NT * C >= cols):
-// per pixel the key, the mark key MK, h and neg.  LDS scratch: row bytes, the 256-entry byte -> fft table.
+// Evaluation of one azimuth row by a block of NT threads, C consecutive range bins per thread (NT * C >= cols).
+// LDS scratch: the 256-entry byte -> fft table and what the threads hand to each other across wavefronts.
 // ---------------------------------------------------------------------------------------------------------------
 template <int C, int NT>
 struct RowLds {
   float tab[256];
-  SegMin sw[NT / 64];
-  unsigned long long edge_first[NT], edge_last[NT];  // MK of a thread's first / last pixel
-  unsigned edge_neg[NT];                             // bit 0: first pixel neg, bit 1: last pixel neg
-};
-
-template <int C, int NT>
-struct RowRegs {
-  unsigned long long key[C], mk[C];
-  float h[C];
-  unsigned neg;  // bit i: s < 0
+  double fwd[NT / 64], bwd[NT / 64];  // a wavefront's forward / backward scan total (sc_max keys, below)
+  unsigned nn_cnt[NT / 64];           // non-neg pixels of a wavefront
+  unsigned edge[NT / 64];             // bit 0: the wavefront's first pixel is neg, bit 1: its last pixel is neg
 };
 
 template <int C, int NT>
@@ -305,26 +234,31 @@ __device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t
     const unsigned v = __builtin_amdgcn_alignbyte(hi, lo, mis);  // bytes mis .. mis+3 of (hi:lo)
     ft[i + 1] = L.tab[(v >> (8 * ((i + 4) & 3))) & 0xffu];
   }
+  // g / maxg, correctly rounded, without the ~10-instruction IEEE sequence per pixel: with y = RN(1 / maxg) (one division per
+  // thread) q = RN(g y), r = fma(-maxg, q, g), q' = fma(r, y, q) IS RN(g / maxg) for every pair of range gradients bytes can
+  // produce -- 598 values, all 179 100 pairs with g <= maxg checked (tools/prove_cen_division.py, tests/test_cen2019_arith.py)
+  auto pixel = [&](int i, float fp, float fm) {
+    const float g = fabsf(__fsub_rn(fp, fm));
+    const float q0 = __fmul_rn(g, rcp_maxg);
+    const float gn = (maxg > 0.0f) ? __fmaf_rn(__fmaf_rn(-maxg, q0, g), rcp_maxg, q0) : 0.0f;
+    const float sv = __fsub_rn(ft[i + 1], mean);
+    h[i] = __fmul_rn(sv, __fsub_rn(1.0f, gn));
+    if (sv < 0.0f) neg |= 1u << i;
+  };
+  if (p0 >= 1 && p0 + C < cols) {  // the chunk and both neighbours lie inside the row (every thread but the first and the last few)
 #pragma unroll
-  for (int i = 0; i < C; i++) {
-    const int p = p0 + i;
-    h[i] = 0.0f;
-    if (p < cols) {
-      float g = 0.0f;
-      if (cols > 1) {
+    for (int i = 0; i < C; i++) pixel(i, ft[i + 2], ft[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const int p = p0 + i;
+      h[i] = 0.0f;
+      if (p < cols) {
         // reflect 101: the neighbour of bin 0 on the left is bin 1, of the last bin on the right the one before it
-        const float fp = (p + 1 < cols) ? ft[i + 2] : ft[i];
-        const float fm = (p >= 1) ? ft[i] : ft[i + 2];
-        g = fabsf(__fsub_rn(fp, fm));
+        const float fp = cols > 1 ? ((p + 1 < cols) ? ft[i + 2] : ft[i]) : 0.0f;
+        const float fm = cols > 1 ? ((p >= 1) ? ft[i] : ft[i + 2]) : 0.0f;
+        pixel(i, fp, fm);
       }
-      // g / maxg, correctly rounded, without the ~10-instruction IEEE sequence per pixel: with y = RN(1 / maxg) (one division per
-      // thread) q = RN(g y), r = fma(-maxg, q, g), q' = fma(r, y, q) IS RN(g / maxg) for every pair of range gradients bytes can
-      // produce -- 598 values, all 179 100 pairs with g <= maxg checked (tools/prove_cen_division.py, tests/test_cen2019_arith.py)
-      const float q0 = __fmul_rn(g, rcp_maxg);
-      const float gn = (maxg > 0.0f) ? __fmaf_rn(__fmaf_rn(-maxg, q0, g), rcp_maxg, q0) : 0.0f;
-      const float sv = __fsub_rn(ft[i + 1], mean);
-      h[i] = __fmul_rn(sv, __fsub_rn(1.0f, gn));
-      if (sv < 0.0f) neg |= 1u << i;
     }
   }
 }
@@ -333,91 +267,175 @@ __device__ __forceinline__ unsigned long long key_of(float hv, unsigned pixel) {
   return ((unsigned long long)(~ord_f32(canon0(hv))) << 32) | (unsigned long long)pixel;
 }
 
-// the caller has filled L.tab; contains block barriers
-template <int C, int NT>
-__device__ __forceinline__ void row_eval(RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, unsigned pix_base, float mean, float maxg,
-                                         RowRegs<C, NT> &R) {
-  __syncthreads();  // previous users of L.sw / L.edge_* are done, L.tab is visible
-  const int p0 = threadIdx.x * C;
-  row_load_h(L, row, cols, mean, maxg, R.h, R.neg);
-#pragma unroll
-  for (int i = 0; i < C; i++) R.key[i] = (p0 + i < cols) ? key_of(R.h[i], pix_base + (unsigned)(p0 + i)) : KINF;  // past the row end: a wall
-  // forward: X(p) = min key over p's run up to p, including the pixel just left of the run
-  const SegMin ident{KINF, 0u};
-  unsigned long long x[C];
-  {
-    SegMin loc = ident;
-#pragma unroll
-    for (int i = 0; i < C; i++) {
-      if ((R.neg >> i) & 1u) {
-        loc.v = loc.v < R.key[i] ? loc.v : R.key[i];
-      } else {
-        loc.v = R.key[i];
-        loc.f = 1u;
-      }
-      x[i] = loc.v;
-    }
-    const SegMin carry = block_excl_scan<NT, false>(loc, ident, seg_min, L.sw);
-    const int first_head = __builtin_ctz(~R.neg | (1u << C));  // pixels before the thread's first non-neg pixel continue the carry
-#pragma unroll
-    for (int i = 0; i < C; i++)
-      if (i < first_head) x[i] = x[i] < carry.v ? x[i] : carry.v;
-  }
-  // backward: Y(p) likewise from the right; MK = min(X, Y) on neg pixels
-  {
-    SegMin loc = ident;
-    unsigned long long y[C];
-#pragma unroll
-    for (int i = C - 1; i >= 0; i--) {
-      if ((R.neg >> i) & 1u) {
-        loc.v = loc.v < R.key[i] ? loc.v : R.key[i];
-      } else {
-        loc.v = R.key[i];
-        loc.f = 1u;
-      }
-      y[i] = loc.v;
-    }
-    const SegMin carry = block_excl_scan<NT, true>(loc, ident, seg_min, L.sw);
-    const unsigned nn = ~R.neg & ((C == 32) ? 0xffffffffu : ((1u << C) - 1u));
-    const int last_head = nn ? 31 - __builtin_clz(nn) : -1;
-#pragma unroll
-    for (int i = 0; i < C; i++) {
-      unsigned long long yy = y[i];
-      if (i > last_head) yy = yy < carry.v ? yy : carry.v;
-      R.mk[i] = ((R.neg >> i) & 1u) ? (x[i] < yy ? x[i] : yy) : R.key[i];
-    }
+// ---------------------------------------------------------------------------------------------------------------
+// Round 5: the per-run minima WITHOUT 64-bit keys, markers or selects.
+//
+// What the walk needs of a row (file header): which pixels OPEN a region -- the pixel with the smallest key of every run it
+// touches.  Keys order by (h descending, pixel ascending), so inside ONE row "smallest key" is "largest h, leftmost among
+// equals", and with E(p) = the maximal run of neg pixels around p plus the non-neg pixel on either side:
+//     F(p) = max h over E ∩ [.., p]   (forward, restarting at every non-neg pixel)
+//     G(p) = max h over E ∩ [p, ..]   (backward, likewise)
+//     p opens  <=>  (p has nothing to its left in E  or  h(p) >  F(p - 1))     (a tie goes to the pixel on the left)
+//              and  (p has nothing to its right in E or  h(p) >= G(p + 1))
+// where "nothing to its left" = p is the row's first pixel, or p and p - 1 are both non-neg (then p touches no run there).
+// F and G are SEGMENTED max-scans; they become PLAIN max-scans of one 64-bit number per pixel when the segment number is put
+// in front of the value: key = (number of non-neg pixels up to p) << 32 | ord(h(p)) -- a later segment beats everything
+// before it, inside a segment the larger h wins.  With 0x40000000 added to the high word the 64 bits are a positive normal
+// double whose order is the integers' order: one v_max_f64 per step, no compare-and-select pairs, no head flags, and the
+// wave-level scan is DPP (row_shr / row_shl inside the rows of 16 lanes, three v_readlane across them) instead of twelve
+// ds_bpermute round trips per direction.  (Rounds 3-4: two segmented min-scans over (~ord(h) << 32 | pixel) with head flags:
+// 1311 VALU + 1203 scalar instructions per 8 pixels, and a 2-byte marker per pixel written for the later passes -- which
+// now ask a different, cheaper question, see cen_runs.)
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sc_key(unsigned seg, unsigned ordh) {
+  return __longlong_as_double((long long)(((unsigned long long)(0x40000000u + seg) << 32) | ordh));
+}
+// v_max_f64 itself: llvm.maxnum in IEEE mode first canonicalises every operand that might be a signalling NaN (a second
+// v_max_f64 x, x per operand: 126 of them in the first build of cen_hist); the keys are never NaNs
+__device__ __forceinline__ double kmax(double a, double b) {
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned sc_lo(double k) { return (unsigned)(unsigned long long)__double_as_longlong(k); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {  // lanes without a source: 0.0 (below every key)
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+// inclusive max-scan over the 64 lanes (REV: from lane 63 down): Hillis-Steele inside each row of 16 by DPP, the rows' totals by
+// v_readlane
+template <bool REV>
+__device__ __forceinline__ double wave_incl_max(double x, int lane) {
+  if constexpr (!REV) {
+    x = kmax(x, dpp_f64<0x111>(x));  // row_shr:1
+    x = kmax(x, dpp_f64<0x112>(x));  // row_shr:2
+    x = kmax(x, dpp_f64<0x114>(x));  // row_shr:4
+    x = kmax(x, dpp_f64<0x118>(x));  // row_shr:8
+    const double t0 = readlane_f64(x, 15), t1 = kmax(t0, readlane_f64(x, 31)), t2 = kmax(t1, readlane_f64(x, 47));
+    const double pre = lane < 16 ? 0.0 : (lane < 32 ? t0 : (lane < 48 ? t1 : t2));
+    return kmax(x, pre);
+  } else {
+    x = kmax(x, dpp_f64<0x101>(x));  // row_shl:1
+    x = kmax(x, dpp_f64<0x102>(x));
+    x = kmax(x, dpp_f64<0x104>(x));
+    x = kmax(x, dpp_f64<0x108>(x));
+    const double t3 = readlane_f64(x, 48), t2 = kmax(t3, readlane_f64(x, 32)), t1 = kmax(t2, readlane_f64(x, 16));
+    const double suf = lane >= 48 ? 0.0 : (lane >= 32 ? t3 : (lane >= 16 ? t2 : t1));
+    return kmax(x, suf);
   }
 }
+__device__ __forceinline__ unsigned wave_incl_add(unsigned x, int lane) {
+  auto d = [](unsigned v, auto ctrl) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, false); };
+  x += d(x, std::integral_constant<int, 0x111>{});
+  x += d(x, std::integral_constant<int, 0x112>{});
+  x += d(x, std::integral_constant<int, 0x114>{});
+  x += d(x, std::integral_constant<int, 0x118>{});
+  const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)x, 15), t1 = t0 + (unsigned)__builtin_amdgcn_readlane((int)x, 31),
+                 t2 = t1 + (unsigned)__builtin_amdgcn_readlane((int)x, 47);
+  return x + (lane < 16 ? 0u : (lane < 32 ? t0 : (lane < 48 ? t1 : t2)));
+}
 
-// bit i: pixel i of the thread's chunk, when visited, opens a new region (see the file header)
+// facts of the thread's C pixels of one row; pixels past the row end are walls: non-neg, below every h
+template <int C>
+struct RowChunk {
+  float h[C];
+  unsigned ordh[C];  // ord_f32(canon0(h)): order-preserving, +-0 alike
+  unsigned neg;      // bit i: s < 0
+  unsigned excl_nn;  // non-neg pixels of the row before the thread's first pixel
+  unsigned total_nn; // ... of the whole (padded) row
+};
+
+// h, neg and the non-neg prefix counts of the row.  The caller has filled L.tab; contains two block barriers.
 template <int C, int NT>
-__device__ __forceinline__ unsigned row_opens(RowLds<C, NT> &L, const RowRegs<C, NT> &R, int cols) {
-  L.edge_first[threadIdx.x] = R.mk[0];
-  L.edge_last[threadIdx.x] = R.mk[C - 1];
-  L.edge_neg[threadIdx.x] = (R.neg & 1u) | (((R.neg >> (C - 1)) & 1u) << 1);
+__device__ __forceinline__ void row_chunk(RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg, RowChunk<C> &R) {
+  constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();  // previous users of L are done, L.tab is visible
+  row_load_h(L, row, cols, mean, maxg, R.h, R.neg);
+#pragma unroll
+  for (int i = 0; i < C; i++) R.ordh[i] = (threadIdx.x * C + i < cols) ? ord_f32(R.h[i] + 0.0f) : 0u;  // (-0.0) + 0.0 = +0.0
+  const unsigned cnt = (unsigned)__popc(~R.neg & FULL);
+  const unsigned incl = wave_incl_add(cnt, lane);
+  if (lane == 63) L.nn_cnt[w] = incl;
   __syncthreads();
-  const int t = threadIdx.x;
-  const bool lneg = t > 0 && (L.edge_neg[t - 1] & 2u);
-  const unsigned long long lmk = t > 0 ? L.edge_last[t - 1] : KINF;
-  const bool rneg = t + 1 < NT && (L.edge_neg[t + 1] & 1u);
-  const unsigned long long rmk = t + 1 < NT ? L.edge_first[t + 1] : KINF;
-  unsigned opens = 0;
+  unsigned before = 0, total = 0;
+#pragma unroll
+  for (int ww = 0; ww < NT / 64; ww++) {
+    const unsigned c = L.nn_cnt[ww];
+    before += ww < w ? c : 0u;
+    total += c;
+  }
+  R.excl_nn = before + incl - cnt;
+  R.total_nn = total;
+}
+
+// bit i: pixel i of the thread's chunk, when visited, opens a new region.  Contains one block barrier.
+template <int C, int NT>
+__device__ __forceinline__ unsigned row_opens(RowLds<C, NT> &L, const RowChunk<C> &R, int cols) {
+  constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned nn = ~R.neg & FULL;
+  // thread-local runs: fl[i] = forward key maximum over the chunk's pixels before i, bl[i] = backward over those after i
+  double fl[C], bl[C];
+  double run = 0.0;
 #pragma unroll
   for (int i = 0; i < C; i++) {
-    if (t * C + i >= cols) break;
-    bool op;
-    if ((R.neg >> i) & 1u) {
-      op = R.mk[i] == R.key[i];
-    } else {
-      const bool ln = i > 0 ? ((R.neg >> (i - 1)) & 1u) != 0 : lneg;
-      const unsigned long long lm = i > 0 ? R.mk[i > 0 ? i - 1 : 0] : lmk;
-      const bool rn = i + 1 < C ? ((R.neg >> (i + 1)) & 1u) != 0 : rneg;
-      const unsigned long long rm = i + 1 < C ? R.mk[i + 1 < C ? i + 1 : C - 1] : rmk;
-      op = (!ln || lm == R.key[i]) && (!rn || rm == R.key[i]);
-    }
-    if (op) opens |= 1u << i;
+    fl[i] = run;
+    const unsigned seg = R.excl_nn + (unsigned)__popc(nn & ((2u << i) - 1u));  // non-neg pixels in [0, p]
+    run = kmax(run, sc_key(seg, R.ordh[i]));
   }
-  return opens;
+  const double ftot = run;
+  run = 0.0;
+#pragma unroll
+  for (int i = C - 1; i >= 0; i--) {
+    bl[i] = run;
+    const unsigned seg = R.total_nn - R.excl_nn - (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels in [p, end]
+    run = kmax(run, sc_key(seg, R.ordh[i]));
+  }
+  const double btot = run;
+  // across the threads of the wavefront (exclusive: shifted by one lane), then across the wavefronts through LDS
+  const double fi = wave_incl_max<false>(ftot, lane), bi = wave_incl_max<true>(btot, lane);
+  double fx = dpp_f64<0x138>(fi), bx = dpp_f64<0x130>(bi);  // wave_shr:1 / wave_shl:1 (lane 0 / 63: 0.0)
+  unsigned eprev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)((R.neg >> (C - 1)) & 1u), 0x138, 0xf, 0xf, false);  // previous thread's last pixel neg
+  unsigned enext = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(R.neg & 1u), 0x130, 0xf, 0xf, false);               // next thread's first pixel neg
+  if (lane == 63) L.fwd[w] = fi;
+  if (lane == 0) L.bwd[w] = bi;
+  const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)(R.neg & 1u), 0), e1 = (unsigned)__builtin_amdgcn_readlane((int)((R.neg >> (C - 1)) & 1u), 63);
+  if (lane == 0) L.edge[w] = e0 | (e1 << 1);
+  __syncthreads();
+  double fc = 0.0, bc = 0.0;
+#pragma unroll
+  for (int ww = 0; ww < NT / 64; ww++) {
+    fc = kmax(fc, ww < w ? L.fwd[ww] : 0.0);
+    bc = kmax(bc, ww > w ? L.bwd[ww] : 0.0);
+  }
+  fx = kmax(fx, fc);
+  bx = kmax(bx, bc);
+  if (lane == 0) eprev = w > 0 ? (L.edge[w > 0 ? w - 1 : 0] >> 1) & 1u : 0u;
+  if (lane == 63) enext = w + 1 < NT / 64 ? L.edge[w + 1 < NT / 64 ? w + 1 : 0] & 1u : 0u;
+  // the comparisons
+  unsigned cl = 0, cr = 0;
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    cl |= (R.ordh[i] > sc_lo(kmax(fx, fl[i]))) ? (1u << i) : 0u;   // h(p) >  F(p - 1)
+    cr |= (R.ordh[i] >= sc_lo(kmax(bx, bl[i]))) ? (1u << i) : 0u;  // h(p) >= G(p + 1)
+  }
+  const int p0 = threadIdx.x * C;
+  const unsigned nn_left = ((nn << 1) | (eprev ? 0u : 1u)) & FULL;               // bit i: pixel p - 1 is non-neg (the row's first pixel: no neighbour, handled below)
+  const unsigned nn_right = (nn >> 1) | ((enext ? 0u : 1u) << (C - 1));          // bit i: pixel p + 1 is non-neg (past the row end: walls)
+  const unsigned first = p0 == 0 ? 1u : 0u;
+  const unsigned left_ok = first | (nn & nn_left) | cl;
+  const unsigned right_ok = (nn & nn_right) | cr;
+  const unsigned valid = p0 >= cols ? 0u : (p0 + C <= cols ? FULL : ((1u << (cols - p0)) - 1u));
+  return left_ok & right_ok & valid;
 }
 
 // llrint((double)hv * 2^40) for |hv| <= 1 without fp64: x = hv * 2^40 is exact in fp32 (a power-of-two scaling);
@@ -439,8 +457,7 @@ __device__ __forceinline__ int h_bin(float hv) {  // monotone non-decreasing in 
 
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
-                                               Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ marker,
-                                               unsigned short *__restrict__ opener) {
+                                               Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ opener) {
   __shared__ RowLds<C, NT> L;
   __shared__ unsigned s_hist[NBIN];
   __shared__ long long s_fix[NT / 64];
@@ -451,42 +468,25 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
   const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
   row_table(L);
   for (int b = threadIdx.x; b < NBIN; b += NT) s_hist[b] = 0;
-  RowRegs<C, NT> R;
-  row_eval(L, row, cols, (unsigned)a * (unsigned)cols, mean, maxg, R);
+  RowChunk<C> R;
+  row_chunk(L, row, cols, mean, maxg, R);
   const unsigned opens = row_opens(L, R, cols);
-  {
-    // what the later passes need of this evaluation, so that the segmented scans run ONCE per row: for every pixel the
-    // range bin of the pixel whose key is its mark key (16 bits; rows padded to C * NT), and the opener bits of the thread
-    unsigned mw[C / 2];
-#pragma unroll
-    for (int i = 0; i < C; i += 2) {
-      const unsigned m0 = (threadIdx.x * C + i < cols) ? (unsigned)(R.mk[i] & 0xffffffffull) - (unsigned)a * (unsigned)cols : 0u;
-      const unsigned m1 = (threadIdx.x * C + i + 1 < cols) ? (unsigned)(R.mk[i + 1] & 0xffffffffull) - (unsigned)a * (unsigned)cols : 0u;
-      mw[i / 2] = (m0 & 0xffffu) | (m1 << 16);
-    }
-    uint4 *mdst = reinterpret_cast<uint4 *>(marker + (((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x) * C);
-#pragma unroll
-    for (int j = 0; j < C / 8; j++) mdst[j] = uint4{mw[4 * j], mw[4 * j + 1], mw[4 * j + 2], mw[4 * j + 3]};
-    opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
-  }
+  // the opener bits of the thread are all the later passes need of this evaluation (cen_collect); 2 bytes per C pixels
+  opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
   // sum of llrint(h * 2^40) over the row without 64-bit conversions: x = h * 2^20 (exact), hi = rint(x), x - hi is exact and at
   // most 1/2, lo = rint((x - hi) * 2^20); hi * 2^20 is an even integer, so rint(h * 2^40) = hi * 2^20 + lo (== fix40(h), the
   // emulated 64-bit form this replaces).  A wave's sums of hi and lo stay below 2^29 and 2^28.
   int fhi = 0, flo = 0;
 #pragma unroll
-  for (int i = 0; i < C; i++) {
-    if (threadIdx.x * C + i < cols) {
-      const float x = R.h[i] * 1048576.0f;
-      const float xr = rintf(x);
-      fhi += (int)xr;
-      flo += __float2int_rn(__fsub_rn(x, xr) * 1048576.0f);
-      if ((opens >> i) & 1u) atomicAdd(&s_hist[h_bin(R.h[i])], 1u);
-    }
+  for (int i = 0; i < C; i++) {  // (past the row end h = 0 and no opener bit is set)
+    const float x = R.h[i] * 1048576.0f;
+    const float xr = rintf(x);
+    fhi += (int)xr;
+    flo += __float2int_rn(__fsub_rn(x, xr) * 1048576.0f);
+    if ((opens >> i) & 1u) atomicAdd(&s_hist[h_bin(R.h[i])], 1u);
   }
-  for (int o = 32; o >= 1; o >>= 1) {
-    fhi += __shfl_xor(fhi, o);
-    flo += __shfl_xor(flo, o);
-  }
+  fhi = wave_sum_i32(fhi);  // (DPP + v_readlane: the xor butterfly was twelve ds_bpermute round trips)
+  flo = wave_sum_i32(flo);
   const long long fix = ((long long)fhi << 20) + (long long)flo;
   if ((threadIdx.x & 63) == 0) s_fix[threadIdx.x >> 6] = fix;
   __syncthreads();
@@ -573,16 +573,12 @@ __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ im
       if (((opens >> i) & 1u) && h_bin(h[i]) == bstar) sel |= 1u << i;
     // one atomic per wavefront
     const unsigned cnt = (unsigned)__popc(sel);
-    unsigned incl = cnt;
-    for (int d = 1; d < 64; d <<= 1) {
-      const unsigned o = __shfl_up(incl, d);
-      if ((threadIdx.x & 63) >= d) incl += o;
-    }
-    const unsigned wave_total = __shfl(incl, 63);
+    const unsigned incl = wave_incl_add(cnt, (int)(threadIdx.x & 63));
+    const unsigned wave_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
     unsigned base = 0;
     if (wave_total) {
       if ((threadIdx.x & 63) == 63) base = atomicAdd(&sc->n_list, wave_total);
-      base = __shfl(base, 63);
+      base = (unsigned)__builtin_amdgcn_readlane((int)base, 63);
       unsigned pos = base + incl - cnt;
 #pragma unroll
       for (int i = 0; i < C; i++)
@@ -669,20 +665,23 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
   }
 }
 
-// runs of marked pixels of ONE azimuth (the part of the extraction that does not look at the neighbours): marks = key of
-// the recorded marker pixel < limit (h of the row in LDS, one gather per pixel; no scans over keys), then one segmented
-// max-scan over the marked runs at r >= min_range: every run that an unmarked pixel closes is recorded as
+// runs of marked pixels of ONE azimuth (the part of the extraction that does not look at the neighbours).  Marks (round 5): a
+// pixel is marked in the end iff its mark key MK(p) -- its own key, or for a neg pixel the smallest key of its run and the
+// two pixels beside it -- is below the limit.  With the limit KNOWN that is no minimum any more but an OR: with
+// hit(q) = key(q) < limit, a non-neg pixel is marked iff it is a hit, a neg pixel iff ANY pixel of its run or one of the two
+// neighbours is.  Runs are numbered by the non-neg pixels before them (one integer prefix sum per row), a hit sets the flag
+// byte of the run(s) it touches, a neg pixel reads its run's flag: no keys of other pixels, no marker read, no gather.
+// Then one segmented max-scan over the marked runs at r >= min_range: every run that an unmarked pixel closes is recorded as
 // (first bin, last bin, bin of the first maximum of h); the row's mark bits go to HBM for the neighbours' adjacency test.
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
-                                               Scal *scal, const unsigned short *__restrict__ marker, int min_range, int row_cap,
-                                               uint2 *__restrict__ row_runs, unsigned *__restrict__ row_nruns,
-                                               unsigned short *__restrict__ markbits) {
+                                               Scal *scal, int min_range, int row_cap, uint2 *__restrict__ row_runs,
+                                               unsigned *__restrict__ row_nruns, unsigned short *__restrict__ markbits) {
+  constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
   __shared__ RowLds<C, NT> L;
-  __shared__ float s_h[C * NT];           // h of the row
-  __shared__ uint8_t s_flag[C * NT + 16];  // 1: marked
-  __shared__ SegMax s_sw[NT / 64];
-  __shared__ unsigned s_cnt[NT / 64];
+  __shared__ __attribute__((aligned(16))) uint8_t s_run[C * NT + 16];  // flag of neg run number k: some toucher is a hit
+  __shared__ double s_k[NT / 64];
+  __shared__ unsigned s_cnt[NT / 64], s_cnt2[NT / 64];
   const int a = blockIdx.x, img = blockIdx.y;
   Scal *sc = scal + img;
   const uint8_t *row = imgs + (int64_t)img * img_stride + off + (int64_t)a * stride;
@@ -690,85 +689,118 @@ __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs,
   const unsigned long long klimit = sc->klimit;
   row_table(L);
   const int p0 = threadIdx.x * C;
-  if (threadIdx.x < 16) s_flag[C * NT + threadIdx.x] = 0;
-  __syncthreads();
-  float h[C];
-  unsigned neg;
-  row_load_h(L, row, cols, mean, maxg, h, neg);
+  {
+    uint4 *z = reinterpret_cast<uint4 *>(s_run);
+    for (int i = threadIdx.x; i < (C * NT + 16) / 16; i += NT) z[i] = uint4{0u, 0u, 0u, 0u};
+  }
+  RowChunk<C> R;
+  row_chunk(L, row, cols, mean, maxg, R);  // (its barriers also publish the zeroed flags)
+  float (&h)[C] = R.h;
+  const unsigned nn = ~R.neg & FULL;
+  unsigned hit = 0;
 #pragma unroll
-  for (int i = 0; i < C; i++) s_h[p0 + i] = h[i];
-  const uint4 *msrc = reinterpret_cast<const uint4 *>(marker + (((int64_t)img * rows + a) * NT + threadIdx.x) * C);
-  unsigned mw[C / 2];
-#pragma unroll
-  for (int j = 0; j < C / 8; j++) {
-    const uint4 m = msrc[j];
-    mw[4 * j] = m.x; mw[4 * j + 1] = m.y; mw[4 * j + 2] = m.z; mw[4 * j + 3] = m.w;
+  for (int i = 0; i < C; i++) {
+    const bool hh = p0 + i < cols && key_of(h[i], (unsigned)a * (unsigned)cols + (unsigned)(p0 + i)) < klimit;
+    if (hh) {
+      hit |= 1u << i;
+      const unsigned c = R.excl_nn + (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels before p = the number of the run p is in / that ends at p
+      s_run[c] = 1;                                // a neg pixel: its own run; a non-neg pixel: the run on its left ...
+      if ((nn >> i) & 1u) s_run[c + 1] = 1;        // ... and the run on its right
+    }
   }
   __syncthreads();
   unsigned marked = 0;
 #pragma unroll
   for (int i = 0; i < C; i++) {
-    const unsigned rm = (mw[i / 2] >> (16 * (i & 1))) & 0xffffu;
-    const bool mk = p0 + i < cols && key_of(s_h[rm], (unsigned)a * (unsigned)cols + rm) < klimit;
+    const unsigned c = R.excl_nn + (unsigned)__popc(nn & ((1u << i) - 1u));
+    const bool mk = p0 + i < cols && (((nn >> i) & 1u) ? ((hit >> i) & 1u) != 0 : s_run[c] != 0);
     if (mk) marked |= 1u << i;
-    s_flag[p0 + i] = mk ? 1 : 0;
   }
   markbits[((int64_t)img * rows + a) * NT + threadIdx.x] = (unsigned short)marked;
-  __syncthreads();
-  // runs of marked pixels at r >= rmin: segmented max-scan; the LAST pixel of a run holds the run's result
+  // ---- closed runs of marked pixels at r >= rmin: (first bin, last bin, bin of the first maximum of h).  live = marked and
+  // r >= rmin; a run starts where the pixel before is not live, and counts once an UNMARKED pixel closes it (a run that
+  // reaches the end of the row does not).  Two plain max-scans (sc_key's trick): S(p) = 1 + the bin of the latest start
+  // at or before p, then K(p) = S(p) | ord(h) | ~bin in one positive double -- the latest run beats everything before it,
+  // inside it the largest h wins and among equals the lowest bin -- so the value at a run's last pixel is the run's result.
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int rmin = min_range < 0 ? 0 : min_range;
-  const SegMax ident{0ull, 0u, 0u};
-  SegMax loc = ident;
-  SegMax incl[C];
+  const unsigned ge = p0 >= rmin ? FULL : (p0 + C <= rmin ? 0u : (FULL & ~((1u << (rmin - p0)) - 1u)));  // bit i: p >= rmin
+  const unsigned live = marked & ge;
+  unsigned lprev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)((live >> (C - 1)) & 1u), 0x138, 0xf, 0xf, false);   // previous thread's last pixel live
+  unsigned mnext = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(marked & 1u), 0x130, 0xf, 0xf, false);               // next thread's first pixel marked
+  {
+    const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)(marked & 1u), 0), e1 = (unsigned)__builtin_amdgcn_readlane((int)((live >> (C - 1)) & 1u), 63);
+    if (lane == 0) L.edge[w] = e0 | (e1 << 1);
+  }
+  __syncthreads();
+  if (lane == 0) lprev = w > 0 ? (L.edge[w > 0 ? w - 1 : 0] >> 1) & 1u : 0u;
+  if (lane == 63) mnext = w + 1 < NT / 64 ? L.edge[w + 1 < NT / 64 ? w + 1 : 0] & 1u : 0u;
+  const unsigned start = live & ~(((live << 1) | lprev) & FULL);
+  const unsigned in_row = p0 + C < cols ? FULL : (p0 + 1 >= cols ? 0u : ((1u << (cols - 1 - p0)) - 1u));  // bit i: p + 1 < cols
+  const unsigned close = live & ~((marked >> 1) | (mnext << (C - 1))) & in_row;
+  // S: 1 + bin of the latest start (0: none yet)
+  const unsigned sloc = start ? (unsigned)(p0 + (31 - __builtin_clz(start)) + 1) : 0u;
+  unsigned sin;
+  {
+    auto dmax = [](unsigned v, auto ctrl) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, false); return o > v ? o : v; };
+    unsigned x = sloc;
+    x = dmax(x, std::integral_constant<int, 0x111>{});
+    x = dmax(x, std::integral_constant<int, 0x112>{});
+    x = dmax(x, std::integral_constant<int, 0x114>{});
+    x = dmax(x, std::integral_constant<int, 0x118>{});
+    const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)x, 15), t1 = (unsigned)__builtin_amdgcn_readlane((int)x, 31),
+                   t2 = (unsigned)__builtin_amdgcn_readlane((int)x, 47);
+    const unsigned m1 = t0 > t1 ? t0 : t1, m2 = m1 > t2 ? m1 : t2;
+    const unsigned pre = lane < 16 ? 0u : (lane < 32 ? t0 : (lane < 48 ? m1 : m2));
+    x = x > pre ? x : pre;  // inclusive over the wavefront (positions only grow, so max = latest)
+    if (lane == 63) s_cnt[w] = x;
+    sin = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);  // exclusive
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ww = 0; ww < NT / 64; ww++) {
+    const unsigned v = ww < w ? s_cnt[ww] : 0u;
+    sin = v > sin ? v : sin;
+  }
+  // K
+  double kin[C];
+  double run = 0.0;
 #pragma unroll
   for (int i = 0; i < C; i++) {
-    const int p = p0 + i;
-    if (((marked >> i) & 1u) && p >= rmin) {
-      const bool start = p == rmin || !s_flag[p - 1];
-      // adj carries the run's FIRST bin (a head sets it, the rest of the run keeps the head's)
-      SegMax e{((unsigned long long)ord_f32(canon0(h[i])) << 32) | (unsigned long long)(0xffffffffu - (unsigned)p), start ? 1u : 0u, (unsigned)p};
-      loc = start ? e : SegMax{loc.v > e.v ? loc.v : e.v, loc.f, loc.adj};
-    } else {
-      loc = SegMax{0ull, 1u, 0u};
-    }
-    incl[i] = loc;
+    const unsigned below = start & ((2u << i) - 1u);  // starts of the chunk at or before i
+    const unsigned sp = below ? (unsigned)(p0 + (31 - __builtin_clz(below)) + 1) : sin;
+    const unsigned long long k = (1ull << 62) | ((unsigned long long)sp << 46) | ((unsigned long long)R.ordh[i] << 14) |
+                                 (unsigned long long)(0x3fffu - (unsigned)((p0 + i) & 0x3fff));
+    const double kd = ((live >> i) & 1u) ? __longlong_as_double((long long)k) : 0.0;
+    run = kmax(run, kd);
+    kin[i] = run;
   }
-  const SegMax carry = block_excl_scan<NT, false>(loc, ident, seg_first, s_sw);
-  unsigned emit = 0;
-  uint2 res[C];
-  bool seen_head = false;
-#pragma unroll
-  for (int i = 0; i < C; i++) {
-    const int p = p0 + i;
-    const bool live = ((marked >> i) & 1u) && p >= rmin;
-    SegMax v = incl[i];
-    if (!seen_head && !v.f) v = seg_first(carry, v);  // no head inside the thread's chunk yet: the carry's run continues
-    if (incl[i].f) seen_head = true;
-    // a run only counts once an unmarked pixel closes it: a run that reaches the end of the row does not
-    if (live && p + 1 < cols && !s_flag[p + 1]) {
-      emit |= 1u << i;
-      res[i] = uint2{v.adj | ((unsigned)p << 16), 0xffffffffu - (unsigned)(v.v & 0xffffffffull)};  // first | last << 16, arg-max bin
-    }
-  }
-  // ordered compaction
-  const unsigned cnt = (unsigned)__popc(emit);
-  unsigned inc = cnt;
-  for (int d = 1; d < 64; d <<= 1) {
-    const unsigned o = __shfl_up(inc, d);
-    if ((threadIdx.x & 63) >= d) inc += o;
-  }
-  if ((threadIdx.x & 63) == 63) s_cnt[threadIdx.x >> 6] = inc;
+  const double ki = wave_incl_max<false>(run, lane);
+  double kx = dpp_f64<0x138>(ki);
+  if (lane == 63) s_k[w] = ki;
+  // (the compaction's counts travel with the same barrier)
+  const unsigned cnt = (unsigned)__popc(close);
+  const unsigned inc = wave_incl_add(cnt, lane);
+  if (lane == 63) s_cnt2[w] = inc;
   __syncthreads();
   unsigned before = 0, total = 0;
-  for (int w = 0; w < NT / 64; w++) {
-    if (w < (int)(threadIdx.x >> 6)) before += s_cnt[w];
-    total += s_cnt[w];
+#pragma unroll
+  for (int ww = 0; ww < NT / 64; ww++) {
+    kx = kmax(kx, ww < w ? s_k[ww] : 0.0);
+    const unsigned c = s_cnt2[ww];
+    before += ww < w ? c : 0u;
+    total += c;
   }
   unsigned pos = before + inc - cnt;
   uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
 #pragma unroll
-  for (int i = 0; i < C; i++)
-    if ((emit >> i) & 1u) ro[pos++] = res[i];
+  for (int i = 0; i < C; i++) {
+    if ((close >> i) & 1u) {
+      const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
+      const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
+      ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
+    }
+  }
   if (threadIdx.x == 0) row_nruns[(int64_t)img * rows + a] = total;
 }
 
@@ -858,7 +890,7 @@ struct rsx_cen2019 {
   int device = 0, rows = 0, cols = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, marker, opener, row_runs, row_nruns, markbits;
+  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, row_runs, row_nruns, markbits;
   rsx::DevBuf one;          // single-scan entry: [count | targets | xy] in one piece, read back with one copy
   void *one_host = nullptr;  // its pinned mirror
   size_t one_host_bytes = 0;
@@ -879,14 +911,14 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   hipLaunchKernelGGL((cen_stats<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
                      stride, off, sc, rpb);
   hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>(),
-                     h->marker.as<unsigned short>(), h->opener.as<unsigned short>());
+                     h->opener.as<unsigned short>());
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
   hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
                      h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
-  hipLaunchKernelGGL((cen_runs<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->marker.as<unsigned short>(),
-                     p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(), h->markbits.as<unsigned short>());
+  hipLaunchKernelGGL((cen_runs<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, p.min_range, row_cap,
+                     h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(), h->markbits.as<unsigned short>());
   hipLaunchKernelGGL((cen_adjacent<C, NT>), grid, dim3(256), 0, s, rows, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
                      h->markbits.as<unsigned short>(), h->row_out.as<int>(), h->row_n.as<unsigned>());
   hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
@@ -908,8 +940,7 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     RSX_TRY(h->row_out.reserve((size_t)n * rows * row_cap * 4, s, false));
     RSX_TRY(h->row_n.reserve((size_t)n * rows * 4, s, false));
     {
-      const size_t nt = cols <= 8 * 512 ? 512 : 1024, cc = cols <= 8 * 512 ? 8 : 16;  // threads per row block x bins per thread: marker rows are padded (every configuration of a row width pads to at most nt * cc bins)
-      RSX_TRY(h->marker.reserve((size_t)n * rows * nt * cc * 2, s, false));
+      const size_t nt = cols <= 8 * 512 ? 512 : 1024;  // threads per row block: one 16-bit word of opener / mark bits per thread
       RSX_TRY(h->opener.reserve((size_t)n * rows * nt * 2, s, false));
       RSX_TRY(h->markbits.reserve((size_t)n * rows * nt * 2, s, false));
       RSX_TRY(h->row_runs.reserve((size_t)n * rows * row_cap * 8, s, false));
@@ -981,7 +1012,7 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) try {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->one_host) (void)hipHostFree(h->one_host);
   h->one.release();
-  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->marker, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
+  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
