@@ -240,10 +240,10 @@ __device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t
   auto pixel = [&](int i, float fp, float fm) {
     const float g = fabsf(__fsub_rn(fp, fm));
     const float q0 = __fmul_rn(g, rcp_maxg);
-    const float gn = (maxg > 0.0f) ? __fmaf_rn(__fmaf_rn(-maxg, q0, g), rcp_maxg, q0) : 0.0f;
+    const float gn = __fmaf_rn(__fmaf_rn(-maxg, q0, g), rcp_maxg, q0);  // (maxg = 0: every g is 0 and rcp_maxg is 0: gn = 0)
     const float sv = __fsub_rn(ft[i + 1], mean);
     h[i] = __fmul_rn(sv, __fsub_rn(1.0f, gn));
-    if (sv < 0.0f) neg |= 1u << i;
+    neg |= (__float_as_uint(sv) >> 31) << i;  // sv < 0 (a difference is never -0.0)
   };
   if (p0 >= 1 && p0 + C < cols) {  // the chunk and both neighbours lie inside the row (every thread but the first and the last few)
 #pragma unroll
@@ -457,7 +457,8 @@ __device__ __forceinline__ int h_bin(float hv) {  // monotone non-decreasing in 
 
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
-                                               Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ opener) {
+                                               Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ opener,
+                                               unsigned short *__restrict__ topbin) {
   __shared__ RowLds<C, NT> L;
   __shared__ unsigned s_hist[NBIN];
   __shared__ long long s_fix[NT / 64];
@@ -477,14 +478,21 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
   // most 1/2, lo = rint((x - hi) * 2^20); hi * 2^20 is an even integer, so rint(h * 2^40) = hi * 2^20 + lo (== fix40(h), the
   // emulated 64-bit form this replaces).  A wave's sums of hi and lo stay below 2^29 and 2^28.
   int fhi = 0, flo = 0;
+  int top = 0;  // 1 + the highest histogram bin an opener of this thread fell into (0: the thread has no opener)
 #pragma unroll
   for (int i = 0; i < C; i++) {  // (past the row end h = 0 and no opener bit is set)
     const float x = R.h[i] * 1048576.0f;
     const float xr = rintf(x);
     fhi += (int)xr;
     flo += __float2int_rn(__fsub_rn(x, xr) * 1048576.0f);
-    if ((opens >> i) & 1u) atomicAdd(&s_hist[h_bin(R.h[i])], 1u);
+    if ((opens >> i) & 1u) {
+      const int b = h_bin(R.h[i]);
+      atomicAdd(&s_hist[b], 1u);
+      top = b + 1 > top ? b + 1 : top;
+    }
   }
+  // what cen_collect needs of this evaluation: it looks only at threads that can hold an opener of the selected bin
+  topbin[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)top;
   fhi = wave_sum_i32(fhi);  // (DPP + v_readlane: the xor butterfly was twelve ds_bpermute round trips)
   flo = wave_sum_i32(flo);
   const long long fix = ((long long)fhi << 20) + (long long)flo;
@@ -546,43 +554,54 @@ __global__ __launch_bounds__(256) void cen_pick(Scal *scal, const unsigned *__re
   }
 }
 
+// h of ONE pixel straight from the bytes (the same operations in the same order as row_load_h: the same float)
+__device__ __forceinline__ float pixel_h(const uint8_t *__restrict__ row, int cols, int p, float mean, float maxg) {
+  const float f0 = __fdiv_rn((float)row[p], 255.0f);
+  float g = 0.0f;
+  if (cols > 1) {  // reflect 101
+    const float fp = __fdiv_rn((float)row[p + 1 < cols ? p + 1 : p - 1], 255.0f), fm = __fdiv_rn((float)row[p >= 1 ? p - 1 : p + 1], 255.0f);
+    g = fabsf(__fsub_rn(fp, fm));
+  }
+  const float rcp_maxg = (maxg > 0.0f) ? __fdiv_rn(1.0f, maxg) : 0.0f;
+  const float q0 = __fmul_rn(g, rcp_maxg);
+  const float gn = (maxg > 0.0f) ? __fmaf_rn(__fmaf_rn(-maxg, q0, g), rcp_maxg, q0) : 0.0f;
+  return __fmul_rn(__fsub_rn(f0, mean), __fsub_rn(1.0f, gn));
+}
+
+// the openers of histogram bin B* (a few dozen keys per image) -> list.  Round 5: cen_hist left, per thread, the highest bin
+// an opener of the thread fell into; only the threads that reach B* are looked at (one in twelve on the bench images), their
+// opener pixels are queued in LDS and evaluated one pixel per lane, straight from the bytes.  Before: h of EVERY pixel again
+// (1807 VALU instructions per wavefront for eight rows, 80 us per 64 images).
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
                                                   int off, Scal *scal, const unsigned short *__restrict__ opener,
-                                                  unsigned long long *__restrict__ lists, int64_t list_stride, int rpb) {
-  __shared__ RowLds<C, NT> L;
+                                                  const unsigned short *__restrict__ topbin, unsigned long long *__restrict__ lists,
+                                                  int64_t list_stride, int rpb) {
+  __shared__ unsigned short s_q[C * NT];
+  __shared__ unsigned s_n;
   Scal *sc = scal + blockIdx.y;
   unsigned long long *list = lists + (int64_t)blockIdx.y * list_stride;
   const int bstar = sc->bstar;
   if (bstar < 0) return;  // fewer openers than the budget: nothing to select (uniform, before any barrier)
   const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
-  row_table(L);
-  __syncthreads();
-  // rpb azimuths per block (no barrier inside a row's work): one table and one block start-up for eight rows of a batch
   for (int rr = 0; rr < rpb; rr++) {
     const int a = blockIdx.x * rpb + rr;
-    if (a >= rows) break;
+    if (a >= rows) break;  // (uniform)
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int64_t slot = ((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x;
+    if ((int)topbin[slot] > bstar) {  // 1 + highest opener bin >= B* + 1
+      unsigned op = opener[slot];
+      const unsigned at = atomicAdd(&s_n, (unsigned)__popc(op));
+      for (unsigned j = at; op; op &= op - 1, j++) s_q[j] = (unsigned short)(threadIdx.x * C + __builtin_ctz(op));
+    }
+    __syncthreads();
+    const unsigned n = s_n;
     const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
-    float h[C];
-    unsigned neg;
-    row_load_h(L, row, cols, mean, maxg, h, neg);
-    const unsigned opens = opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x];  // from cen_hist: no scans here
-    unsigned sel = 0;
-#pragma unroll
-    for (int i = 0; i < C; i++)
-      if (((opens >> i) & 1u) && h_bin(h[i]) == bstar) sel |= 1u << i;
-    // one atomic per wavefront
-    const unsigned cnt = (unsigned)__popc(sel);
-    const unsigned incl = wave_incl_add(cnt, (int)(threadIdx.x & 63));
-    const unsigned wave_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-    unsigned base = 0;
-    if (wave_total) {
-      if ((threadIdx.x & 63) == 63) base = atomicAdd(&sc->n_list, wave_total);
-      base = (unsigned)__builtin_amdgcn_readlane((int)base, 63);
-      unsigned pos = base + incl - cnt;
-#pragma unroll
-      for (int i = 0; i < C; i++)
-        if ((sel >> i) & 1u) list[pos++] = key_of(h[i], (unsigned)a * (unsigned)cols + (unsigned)(threadIdx.x * C + i));
+    for (unsigned j = threadIdx.x; j < n; j += NT) {
+      const int p = s_q[j];
+      const float hv = pixel_h(row, cols, p, mean, maxg);
+      if (h_bin(hv) == bstar) list[atomicAdd(&sc->n_list, 1u)] = key_of(hv, (unsigned)a * (unsigned)cols + (unsigned)p);
     }
   }
 }
@@ -890,7 +909,7 @@ struct rsx_cen2019 {
   int device = 0, rows = 0, cols = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, row_runs, row_nruns, markbits;
+  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, topbin, row_runs, row_nruns, markbits;
   rsx::DevBuf one;          // single-scan entry: [count | targets | xy] in one piece, read back with one copy
   void *one_host = nullptr;  // its pinned mirror
   size_t one_host_bytes = 0;
@@ -911,10 +930,10 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   hipLaunchKernelGGL((cen_stats<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
                      stride, off, sc, rpb);
   hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>(),
-                     h->opener.as<unsigned short>());
+                     h->opener.as<unsigned short>(), h->topbin.as<unsigned short>());
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
   hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
-                     h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
+                     h->topbin.as<unsigned short>(), h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
   hipLaunchKernelGGL((cen_runs<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, p.min_range, row_cap,
@@ -942,6 +961,7 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     {
       const size_t nt = cols <= 8 * 512 ? 512 : 1024;  // threads per row block: one 16-bit word of opener / mark bits per thread
       RSX_TRY(h->opener.reserve((size_t)n * rows * nt * 2, s, false));
+      RSX_TRY(h->topbin.reserve((size_t)n * rows * nt * 2, s, false));
       RSX_TRY(h->markbits.reserve((size_t)n * rows * nt * 2, s, false));
       RSX_TRY(h->row_runs.reserve((size_t)n * rows * row_cap * 8, s, false));
       RSX_TRY(h->row_nruns.reserve((size_t)n * rows * 4, s, false));
@@ -1012,7 +1032,7 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) try {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->one_host) (void)hipHostFree(h->one_host);
   h->one.release();
-  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
+  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->topbin, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
