@@ -59,7 +59,9 @@ struct Scal {  // per image
   long long fix_sum;
   unsigned long long klimit;  // a pixel is marked in the end iff MK(p) < klimit
   unsigned int max_g_bits;
-  unsigned int pad0[3];
+  float mean;      // mean of fft = byte / 255 over the image   } cen_scalars, once per image: every thread of every row block
+  float rcp_maxg;  // RN(1 / max g), 0 when max g = 0             } used to redo these divisions (45 fp64 instructions)
+  unsigned int pad0;
   int bstar;               // histogram bin of the max_points-th region opener (-1: there are fewer openers)
   unsigned int above;      // openers in the bins above bstar
   unsigned int n_list;     // openers of bin bstar collected so far
@@ -69,10 +71,10 @@ struct Scal {  // per image
 static_assert(sizeof(Scal) == 64, "Scal layout");
 
 __device__ __forceinline__ int wave_sum_i32(int x) {  // every lane: the sum over the 64 lanes
-  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, false);  // row_half_mirror
-  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, false);  // row_mirror: every lane = its row's sum
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);  // row_mirror: every lane = its row's sum
   return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 }
 __device__ __forceinline__ int wave_max_i32(int x) {  // every lane: the maximum over the 64 lanes
@@ -84,8 +86,8 @@ __device__ __forceinline__ int wave_max_i32(int x) {  // every lane: the maximum
   return mx(mx(__builtin_amdgcn_readlane(x, 0), __builtin_amdgcn_readlane(x, 16)), mx(__builtin_amdgcn_readlane(x, 32), __builtin_amdgcn_readlane(x, 48)));
 }
 __device__ __forceinline__ unsigned ord_f32(float f) {
-  unsigned u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  const unsigned u = __float_as_uint(f);
+  return u ^ ((unsigned)((int)u >> 31) | 0x80000000u);  // negative: ~u, otherwise u | sign bit
 }
 __device__ __forceinline__ float canon0(float f) { return f == 0.0f ? 0.0f : f; }  // -0.0 sorts like +0.0 (oracle: h compares)
 
@@ -186,29 +188,58 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
   }
 }
 
+// the two divisions every later pass needs, once per image (a thread per image)
+__global__ __launch_bounds__(64) void cen_scalars(Scal *scal, int nb, int64_t n_pixels) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nb) return;
+  Scal *sc = scal + i;
+  const float maxg = __uint_as_float(sc->max_g_bits);
+  sc->mean = mean_fft(sc, n_pixels);
+  sc->rcp_maxg = (maxg > 0.0f) ? __fdiv_rn(1.0f, maxg) : 0.0f;
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Evaluation of one azimuth row by a block of NT threads, C consecutive range bins per thread (NT * C >= cols).
 // LDS scratch: the 256-entry byte -> fft table and what the threads hand to each other across wavefronts.
 // ---------------------------------------------------------------------------------------------------------------
 template <int C, int NT>
 struct RowLds {
+  static constexpr int NW = NT / 64;
   float tab[256];
-  double fwd[NT / 64], bwd[NT / 64];  // a wavefront's forward / backward scan total (sc_max keys, below)
-  unsigned nn_cnt[NT / 64];           // non-neg pixels of a wavefront
-  unsigned edge[NT / 64];             // bit 0: the wavefront's first pixel is neg, bit 1: its last pixel is neg
+  // what a wavefront hands to the others.  Each array has a second half of NW zeros (written once, row_table): wavefront w
+  // reads the NW slots before (after) its own, whatever w is -- the slots outside the block are zeros, the identity of max
+  // and +.  (Rounds 3-5a: `ww < w ? x[ww] : 0`, two v_cndmask per slot and direction, 48 an evaluation.)
+  double fwd[2 * NW];        // [NW + w]: forward scan total (sc_key keys, below); [0, NW): zeros
+  double bwd[2 * NW];        // [w]: backward scan total; [NW, 2 NW): zeros
+  unsigned nn_cnt[2 * NW];   // [NW + w]: non-neg pixels of the wavefront; [0, NW): zeros
+  unsigned edge[NW];         // bit 0: the wavefront's first pixel is neg, bit 1: its last pixel is neg
 };
 
 template <int C, int NT>
 __device__ __forceinline__ void row_table(RowLds<C, NT> &L) {
+  constexpr int NW = NT / 64;
   if (threadIdx.x < 256) L.tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
+  if (threadIdx.x < NW) {
+    L.fwd[threadIdx.x] = 0.0;
+    L.bwd[NW + threadIdx.x] = 0.0;
+    L.nn_cnt[threadIdx.x] = 0u;
+  }
 }
 
 // h and the sign of s for the thread's C pixels of one row, straight from the image bytes: the thread's 16 bytes and their
 // two neighbours come from ALIGNED dwords around row + p0 (an aligned dword that holds one byte of the image cannot cross
 // a page, so the few bytes read beside the row are harmless).  Needs L.tab (visible to the block); no barrier inside.
+// the chunks of a wavefront that holds the row's first pixel or reaches its end need the border rules; the others
+// (wavefront-uniform: a scalar branch) do not
+template <int C>
+__device__ __forceinline__ bool edge_wave(int cols) {
+  const int wp0 = (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u)) * C;
+  return wp0 == 0 || wp0 + 64 * C >= cols;
+}
+
 template <int C, int NT>
 __device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg,
-                                           float (&h)[C], unsigned &neg) {
+                                           float rcp_maxg, float (&h)[C], unsigned &neg) {
   static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
   constexpr int NWD = C / 4 + 2;  // aligned words [-1 .. C / 4] relative to (row + p0) & ~3
   const int p0 = threadIdx.x * C;
@@ -225,7 +256,6 @@ __device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t
     for (int j = 0; j < NWD - 1; j++)
       if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
   }
-  const float rcp_maxg = (maxg > 0.0f) ? __fdiv_rn(1.0f, maxg) : 0.0f;
   float ft[C + 2];  // fft of pixels p0-1 .. p0+C
 #pragma unroll
   for (int i = -1; i <= C; i++) {
@@ -234,32 +264,35 @@ __device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t
     const unsigned v = __builtin_amdgcn_alignbyte(hi, lo, mis);  // bytes mis .. mis+3 of (hi:lo)
     ft[i + 1] = L.tab[(v >> (8 * ((i + 4) & 3))) & 0xffu];
   }
+  // reflect 101 at the two ends of the row: the neighbour of bin 0 on the left is bin 1, of the last bin on the right the one
+  // before it -- written into the neighbour slots, so that every pixel of every thread runs the SAME code below (rounds 3-4: a
+  // second, branchy copy of the pixel code for the first and the last threads, executed by the whole wavefront around them)
+  const bool edge = edge_wave<C>(cols);
+  if (edge) {
+    if (p0 == 0) ft[0] = ft[2];
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      if (p0 + i == cols - 1) ft[i + 2] = ft[i];
+  }
   // g / maxg, correctly rounded, without the ~10-instruction IEEE sequence per pixel: with y = RN(1 / maxg) (one division per
-  // thread) q = RN(g y), r = fma(-maxg, q, g), q' = fma(r, y, q) IS RN(g / maxg) for every pair of range gradients bytes can
+  // image) q = RN(g y), r = fma(-maxg, q, g), q' = fma(r, y, q) IS RN(g / maxg) for every pair of range gradients bytes can
   // produce -- 598 values, all 179 100 pairs with g <= maxg checked (tools/prove_cen_division.py, tests/test_cen2019_arith.py)
-  auto pixel = [&](int i, float fp, float fm) {
-    const float g = fabsf(__fsub_rn(fp, fm));
+#pragma unroll
+  for (int i = 0; i < C; i++) {
+    const float g = fabsf(__fsub_rn(ft[i + 2], ft[i]));
     const float q0 = __fmul_rn(g, rcp_maxg);
     const float gn = __fmaf_rn(__fmaf_rn(-maxg, q0, g), rcp_maxg, q0);  // (maxg = 0: every g is 0 and rcp_maxg is 0: gn = 0)
     const float sv = __fsub_rn(ft[i + 1], mean);
     h[i] = __fmul_rn(sv, __fsub_rn(1.0f, gn));
     neg |= (__float_as_uint(sv) >> 31) << i;  // sv < 0 (a difference is never -0.0)
-  };
-  if (p0 >= 1 && p0 + C < cols) {  // the chunk and both neighbours lie inside the row (every thread but the first and the last few)
+  }
+  if (edge) {  // pixels past the end of the row: h = 0, not neg
 #pragma unroll
-    for (int i = 0; i < C; i++) pixel(i, ft[i + 2], ft[i]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < C; i++) {
-      const int p = p0 + i;
-      h[i] = 0.0f;
-      if (p < cols) {
-        // reflect 101: the neighbour of bin 0 on the left is bin 1, of the last bin on the right the one before it
-        const float fp = cols > 1 ? ((p + 1 < cols) ? ft[i + 2] : ft[i]) : 0.0f;
-        const float fm = cols > 1 ? ((p >= 1) ? ft[i] : ft[i + 2]) : 0.0f;
-        pixel(i, fp, fm);
+    for (int i = 0; i < C; i++)
+      if (p0 + i >= cols) {
+        h[i] = 0.0f;
+        neg &= ~(1u << i);
       }
-    }
   }
 }
 
@@ -298,20 +331,26 @@ __device__ __forceinline__ double kmax(double a, double b) {
   return r;
 }
 __device__ __forceinline__ unsigned sc_lo(double k) { return (unsigned)(unsigned long long)__double_as_longlong(k); }
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double x) {  // lanes without a source: 0.0 (below every key)
+// (bound_ctrl: a lane without a source reads 0 -- no register to clear in front of every DPP move)
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ double dpp_f64(double x) {  // lanes without a source (and rows outside ROWS): 0.0, below every key
   const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
-  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, ROWS, 0xf, ROWS == 0xf);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, ROWS, 0xf, ROWS == 0xf);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <int CTRL, int ROWS = 0xf>
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWS, 0xf, ROWS == 0xf);
 }
 __device__ __forceinline__ double readlane_f64(double x, int l) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(x);
   const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), l);
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
-// inclusive max-scan over the 64 lanes (REV: from lane 63 down): Hillis-Steele inside each row of 16 by DPP, the rows' totals by
-// v_readlane
+// inclusive max-scan over the 64 lanes (REV: from lane 63 down): Hillis-Steele inside each row of 16 by DPP; across the rows
+// forward by the two row broadcasts of the ISA (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3), backward --
+// there is no broadcast of a row's FIRST lane -- by three v_readlane
 template <bool REV>
 __device__ __forceinline__ double wave_incl_max(double x, int lane) {
   if constexpr (!REV) {
@@ -319,9 +358,9 @@ __device__ __forceinline__ double wave_incl_max(double x, int lane) {
     x = kmax(x, dpp_f64<0x112>(x));  // row_shr:2
     x = kmax(x, dpp_f64<0x114>(x));  // row_shr:4
     x = kmax(x, dpp_f64<0x118>(x));  // row_shr:8
-    const double t0 = readlane_f64(x, 15), t1 = kmax(t0, readlane_f64(x, 31)), t2 = kmax(t1, readlane_f64(x, 47));
-    const double pre = lane < 16 ? 0.0 : (lane < 32 ? t0 : (lane < 48 ? t1 : t2));
-    return kmax(x, pre);
+    x = kmax(x, dpp_f64<0x142, 0xa>(x));  // row_bcast:15
+    x = kmax(x, dpp_f64<0x143, 0xc>(x));  // row_bcast:31
+    return x;
   } else {
     x = kmax(x, dpp_f64<0x101>(x));  // row_shl:1
     x = kmax(x, dpp_f64<0x102>(x));
@@ -332,15 +371,24 @@ __device__ __forceinline__ double wave_incl_max(double x, int lane) {
     return kmax(x, suf);
   }
 }
-__device__ __forceinline__ unsigned wave_incl_add(unsigned x, int lane) {
-  auto d = [](unsigned v, auto ctrl) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, false); };
-  x += d(x, std::integral_constant<int, 0x111>{});
-  x += d(x, std::integral_constant<int, 0x112>{});
-  x += d(x, std::integral_constant<int, 0x114>{});
-  x += d(x, std::integral_constant<int, 0x118>{});
-  const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)x, 15), t1 = t0 + (unsigned)__builtin_amdgcn_readlane((int)x, 31),
-                 t2 = t1 + (unsigned)__builtin_amdgcn_readlane((int)x, 47);
-  return x + (lane < 16 ? 0u : (lane < 32 ? t0 : (lane < 48 ? t1 : t2)));
+__device__ __forceinline__ unsigned wave_incl_add(unsigned x, int) {
+  x += dpp_u32<0x111>(x);
+  x += dpp_u32<0x112>(x);
+  x += dpp_u32<0x114>(x);
+  x += dpp_u32<0x118>(x);
+  x += dpp_u32<0x142, 0xa>(x);
+  x += dpp_u32<0x143, 0xc>(x);
+  return x;
+}
+__device__ __forceinline__ unsigned wave_incl_max_u32(unsigned x) {
+  auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+  x = mx(x, dpp_u32<0x111>(x));
+  x = mx(x, dpp_u32<0x112>(x));
+  x = mx(x, dpp_u32<0x114>(x));
+  x = mx(x, dpp_u32<0x118>(x));
+  x = mx(x, dpp_u32<0x142, 0xa>(x));
+  x = mx(x, dpp_u32<0x143, 0xc>(x));
+  return x;
 }
 
 // facts of the thread's C pixels of one row; pixels past the row end are walls: non-neg, below every h
@@ -350,38 +398,40 @@ struct RowChunk {
   unsigned ordh[C];  // ord_f32(canon0(h)): order-preserving, +-0 alike
   unsigned neg;      // bit i: s < 0
   unsigned excl_nn;  // non-neg pixels of the row before the thread's first pixel
-  unsigned total_nn; // ... of the whole (padded) row
 };
 
 // h, neg and the non-neg prefix counts of the row.  The caller has filled L.tab; contains two block barriers.
 template <int C, int NT>
-__device__ __forceinline__ void row_chunk(RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg, RowChunk<C> &R) {
+__device__ __forceinline__ void row_chunk(RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg, float rcp_maxg,
+                                          RowChunk<C> &R) {
   constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   __syncthreads();  // previous users of L are done, L.tab is visible
-  row_load_h(L, row, cols, mean, maxg, R.h, R.neg);
+  row_load_h(L, row, cols, mean, maxg, rcp_maxg, R.h, R.neg);
 #pragma unroll
-  for (int i = 0; i < C; i++) R.ordh[i] = (threadIdx.x * C + i < cols) ? ord_f32(R.h[i] + 0.0f) : 0u;  // (-0.0) + 0.0 = +0.0
+  for (int i = 0; i < C; i++) R.ordh[i] = ord_f32(R.h[i] + 0.0f);  // (-0.0) + 0.0 = +0.0
+  if (edge_wave<C>(cols)) {
+#pragma unroll
+    for (int i = 0; i < C; i++)
+      if ((int)threadIdx.x * C + i >= cols) R.ordh[i] = 0u;  // walls
+  }
   const unsigned cnt = (unsigned)__popc(~R.neg & FULL);
   const unsigned incl = wave_incl_add(cnt, lane);
-  if (lane == 63) L.nn_cnt[w] = incl;
+  if (lane == 63) L.nn_cnt[NW + w] = incl;
   __syncthreads();
-  unsigned before = 0, total = 0;
+  unsigned before = 0;
 #pragma unroll
-  for (int ww = 0; ww < NT / 64; ww++) {
-    const unsigned c = L.nn_cnt[ww];
-    before += ww < w ? c : 0u;
-    total += c;
-  }
+  for (int k = 0; k < NW; k++) before += L.nn_cnt[NW + w - 1 - k];
   R.excl_nn = before + incl - cnt;
-  R.total_nn = total;
 }
 
 // bit i: pixel i of the thread's chunk, when visited, opens a new region.  Contains one block barrier.
 template <int C, int NT>
 __device__ __forceinline__ unsigned row_opens(RowLds<C, NT> &L, const RowChunk<C> &R, int cols) {
   constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  constexpr int NW = NT / 64;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const unsigned nn = ~R.neg & FULL;
   // thread-local runs: fl[i] = forward key maximum over the chunk's pixels before i, bl[i] = backward over those after i
   double fl[C], bl[C];
@@ -397,36 +447,36 @@ __device__ __forceinline__ unsigned row_opens(RowLds<C, NT> &L, const RowChunk<C
 #pragma unroll
   for (int i = C - 1; i >= 0; i--) {
     bl[i] = run;
-    const unsigned seg = R.total_nn - R.excl_nn - (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels in [p, end]
+    const unsigned seg = (unsigned)(NT * C) - R.excl_nn - (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels in [p, end] + those of the padding (any constant)
     run = kmax(run, sc_key(seg, R.ordh[i]));
   }
   const double btot = run;
   // across the threads of the wavefront (exclusive: shifted by one lane), then across the wavefronts through LDS
   const double fi = wave_incl_max<false>(ftot, lane), bi = wave_incl_max<true>(btot, lane);
   double fx = dpp_f64<0x138>(fi), bx = dpp_f64<0x130>(bi);  // wave_shr:1 / wave_shl:1 (lane 0 / 63: 0.0)
-  unsigned eprev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)((R.neg >> (C - 1)) & 1u), 0x138, 0xf, 0xf, false);  // previous thread's last pixel neg
-  unsigned enext = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(R.neg & 1u), 0x130, 0xf, 0xf, false);               // next thread's first pixel neg
-  if (lane == 63) L.fwd[w] = fi;
+  unsigned eprev = dpp_u32<0x138>((R.neg >> (C - 1)) & 1u);  // previous thread's last pixel neg
+  unsigned enext = dpp_u32<0x130>(R.neg & 1u);               // next thread's first pixel neg
+  if (lane == 63) L.fwd[NW + w] = fi;
   if (lane == 0) L.bwd[w] = bi;
   const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)(R.neg & 1u), 0), e1 = (unsigned)__builtin_amdgcn_readlane((int)((R.neg >> (C - 1)) & 1u), 63);
   if (lane == 0) L.edge[w] = e0 | (e1 << 1);
   __syncthreads();
-  double fc = 0.0, bc = 0.0;
 #pragma unroll
-  for (int ww = 0; ww < NT / 64; ww++) {
-    fc = kmax(fc, ww < w ? L.fwd[ww] : 0.0);
-    bc = kmax(bc, ww > w ? L.bwd[ww] : 0.0);
+  for (int k = 0; k < NW; k++) {
+    fx = kmax(fx, L.fwd[NW + w - 1 - k]);
+    bx = kmax(bx, L.bwd[w + 1 + k]);
   }
-  fx = kmax(fx, fc);
-  bx = kmax(bx, bc);
   if (lane == 0) eprev = w > 0 ? (L.edge[w > 0 ? w - 1 : 0] >> 1) & 1u : 0u;
   if (lane == 63) enext = w + 1 < NT / 64 ? L.edge[w + 1 < NT / 64 ? w + 1 : 0] & 1u : 0u;
   // the comparisons
+  // the comparisons, from the last pixel down: x = x + x + (a > b), a compare into vcc and an add-with-carry per pixel (the
+  // compiler's form of `x |= (a > b) << i` is compare, select, or)
   unsigned cl = 0, cr = 0;
 #pragma unroll
-  for (int i = 0; i < C; i++) {
-    cl |= (R.ordh[i] > sc_lo(kmax(fx, fl[i]))) ? (1u << i) : 0u;   // h(p) >  F(p - 1)
-    cr |= (R.ordh[i] >= sc_lo(kmax(bx, bl[i]))) ? (1u << i) : 0u;  // h(p) >= G(p + 1)
+  for (int i = C - 1; i >= 0; i--) {
+    const unsigned f = sc_lo(kmax(fx, fl[i])), b = sc_lo(kmax(bx, bl[i]));
+    asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cl) : "v"(R.ordh[i]), "v"(f) : "vcc");  // h(p) >  F(p - 1)
+    asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cr) : "v"(R.ordh[i]), "v"(b) : "vcc");  // h(p) >= G(p + 1)
   }
   const int p0 = threadIdx.x * C;
   const unsigned nn_left = ((nn << 1) | (eprev ? 0u : 1u)) & FULL;               // bit i: pixel p - 1 is non-neg (the row's first pixel: no neighbour, handled below)
@@ -450,54 +500,69 @@ __device__ __forceinline__ long long fix40(float hv) {
   return ax < 2147483648.0f ? small : (x < 0.0f ? -big : big);
 }
 
-__device__ __forceinline__ int h_bin(float hv) {  // monotone non-decreasing in h
-  const int b = (int)floorf(__fmul_rn(__fadd_rn(canon0(hv), 1.0f), 2048.0f));
-  return b < 0 ? 0 : (b > NBIN - 1 ? NBIN - 1 : b);
+// bin of h in the selection histogram: monotone non-decreasing in h, which is all the selection needs.  |h| <= 1, so
+// (h + 1) * 2048 lies in [0, 4096]: the conversion truncates (= floor, the value is not negative; -0.0 + 1 = 1 like +0.0)
+__device__ __forceinline__ int h_bin(float hv) {
+  const unsigned b = __float2uint_rz(__fmul_rn(__fadd_rn(hv, 1.0f), 2048.0f));  // (saturating: a negative value gives 0)
+  return (int)(b > (unsigned)(NBIN - 1) ? (unsigned)(NBIN - 1) : b);
 }
 
+constexpr int HIST_ROWS = 4;  // azimuths per block of cen_hist in a batch: the table, the zeroed block histogram and its flush (atomics into the image's 4096 bins: a quarter of the kernel at one row per block) once for all of them
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
                                                Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ opener,
-                                               unsigned short *__restrict__ topbin) {
+                                               unsigned short *__restrict__ topbin, int rpb) {
   __shared__ RowLds<C, NT> L;
-  __shared__ unsigned s_hist[NBIN];
+  __shared__ __attribute__((aligned(16))) unsigned s_hist[NBIN];
   __shared__ long long s_fix[NT / 64];
-  const int a = blockIdx.x;
   Scal *sc = scal + blockIdx.y;
   unsigned *gh = hist + (size_t)blockIdx.y * NBIN;
-  const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
-  const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
+  const float mean = sc->mean, maxg = __uint_as_float(sc->max_g_bits), rcp_maxg = sc->rcp_maxg;
   row_table(L);
-  for (int b = threadIdx.x; b < NBIN; b += NT) s_hist[b] = 0;
-  RowChunk<C> R;
-  row_chunk(L, row, cols, mean, maxg, R);
-  const unsigned opens = row_opens(L, R, cols);
-  // the opener bits of the thread are all the later passes need of this evaluation (cen_collect); 2 bytes per C pixels
-  opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
-  // sum of llrint(h * 2^40) over the row without 64-bit conversions: x = h * 2^20 (exact), hi = rint(x), x - hi is exact and at
+  for (int b = threadIdx.x; b < NBIN / 4; b += NT) reinterpret_cast<uint4 *>(s_hist)[b] = uint4{0u, 0u, 0u, 0u};
+  // sum of llrint(h * 2^40) over the rows without 64-bit conversions: x = h * 2^20 (exact), hi = rint(x), x - hi is exact and at
   // most 1/2, lo = rint((x - hi) * 2^20); hi * 2^20 is an even integer, so rint(h * 2^40) = hi * 2^20 + lo (== fix40(h), the
-  // emulated 64-bit form this replaces).  A wave's sums of hi and lo stay below 2^29 and 2^28.
-  int fhi = 0, flo = 0;
-  int top = 0;  // 1 + the highest histogram bin an opener of this thread fell into (0: the thread has no opener)
+  // emulated 64-bit form this replaces).  A wave's sums of hi and lo stay below 2^29 and 2^28 per row (summed over the wavefront after every second row).
+  // rint by the 1.5 * 2^23 trick (|x| <= 2^20): fl(x + M) = M + rint(x) with ties to even, and ITS BITS are bits(M) + rint(x)
+  // -- the bits are summed as they are, the bits(M) come off at the end (mod 2^32): six instructions a pixel, not nine
+  constexpr float M = 12582912.0f, S = 1048576.0f;
+  unsigned ahi = 0, alo = 0;
+  long long fix = 0;
+  for (int rr = 0; rr < rpb; rr++) {
+    const int a = blockIdx.x * rpb + rr;
+    if (a >= rows) break;  // (uniform)
+    const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
+    RowChunk<C> R;
+    row_chunk(L, row, cols, mean, maxg, rcp_maxg, R);
+    const unsigned opens = row_opens(L, R, cols);
+    // the opener bits of the thread are all the later passes need of this evaluation (cen_collect); 2 bytes per C pixels
+    opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
+    int top = 0;  // 1 + the highest histogram bin an opener of this thread fell into (0: the thread has no opener)
 #pragma unroll
-  for (int i = 0; i < C; i++) {  // (past the row end h = 0 and no opener bit is set)
-    const float x = R.h[i] * 1048576.0f;
-    const float xr = rintf(x);
-    fhi += (int)xr;
-    flo += __float2int_rn(__fsub_rn(x, xr) * 1048576.0f);
-    if ((opens >> i) & 1u) {
-      const int b = h_bin(R.h[i]);
-      atomicAdd(&s_hist[b], 1u);
-      top = b + 1 > top ? b + 1 : top;
+    for (int i = 0; i < C; i++) {  // (past the row end h = 0 and no opener bit is set)
+      const float t = __fmaf_rn(R.h[i], S, M);
+      ahi += __float_as_uint(t) - 0x4B400000u;
+      const float r = __fmaf_rn(R.h[i], S, -__fsub_rn(t, M));  // x - rint(x), exact
+      alo += __float_as_uint(__fmaf_rn(r, S, M)) - 0x4B400000u;
+      if ((opens >> i) & 1u) {
+        const int b = h_bin(R.h[i]);
+        atomicAdd(&s_hist[b], 1u);
+        top = b + 1 > top ? b + 1 : top;
+      }
+    }
+    // what cen_collect needs of this evaluation: it looks only at threads that can hold an opener of the selected bin
+    topbin[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)top;
+    if ((rr & 1) || rr + 1 == rpb || a + 1 >= rows) {  // (uniform)
+      const int fhi = wave_sum_i32((int)ahi);  // (DPP + v_readlane: the xor butterfly was twelve ds_bpermute round trips)
+      const int flo = wave_sum_i32((int)alo);
+      fix += ((long long)fhi << 20) + (long long)flo;
+      ahi = alo = 0;
     }
   }
-  // what cen_collect needs of this evaluation: it looks only at threads that can hold an opener of the selected bin
-  topbin[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)top;
-  fhi = wave_sum_i32(fhi);  // (DPP + v_readlane: the xor butterfly was twelve ds_bpermute round trips)
-  flo = wave_sum_i32(flo);
-  const long long fix = ((long long)fhi << 20) + (long long)flo;
   if ((threadIdx.x & 63) == 0) s_fix[threadIdx.x >> 6] = fix;
   __syncthreads();
+  // (one bin per lane: a wavefront's atomics fall into two cache lines.  Four consecutive bins per lane -- one ds_read_b128 --
+  // spread every atomic instruction over eight lines and made the kernel three times slower.)
   for (int b = threadIdx.x; b < NBIN; b += NT)
     if (s_hist[b]) atomicAdd(&gh[b], s_hist[b]);
   if (threadIdx.x == 0) {
@@ -555,14 +620,13 @@ __global__ __launch_bounds__(256) void cen_pick(Scal *scal, const unsigned *__re
 }
 
 // h of ONE pixel straight from the bytes (the same operations in the same order as row_load_h: the same float)
-__device__ __forceinline__ float pixel_h(const uint8_t *__restrict__ row, int cols, int p, float mean, float maxg) {
+__device__ __forceinline__ float pixel_h(const uint8_t *__restrict__ row, int cols, int p, float mean, float maxg, float rcp_maxg) {
   const float f0 = __fdiv_rn((float)row[p], 255.0f);
   float g = 0.0f;
   if (cols > 1) {  // reflect 101
     const float fp = __fdiv_rn((float)row[p + 1 < cols ? p + 1 : p - 1], 255.0f), fm = __fdiv_rn((float)row[p >= 1 ? p - 1 : p + 1], 255.0f);
     g = fabsf(__fsub_rn(fp, fm));
   }
-  const float rcp_maxg = (maxg > 0.0f) ? __fdiv_rn(1.0f, maxg) : 0.0f;
   const float q0 = __fmul_rn(g, rcp_maxg);
   const float gn = (maxg > 0.0f) ? __fmaf_rn(__fmaf_rn(-maxg, q0, g), rcp_maxg, q0) : 0.0f;
   return __fmul_rn(__fsub_rn(f0, mean), __fsub_rn(1.0f, gn));
@@ -583,7 +647,7 @@ __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ im
   unsigned long long *list = lists + (int64_t)blockIdx.y * list_stride;
   const int bstar = sc->bstar;
   if (bstar < 0) return;  // fewer openers than the budget: nothing to select (uniform, before any barrier)
-  const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
+  const float mean = sc->mean, maxg = __uint_as_float(sc->max_g_bits), rcp_maxg = sc->rcp_maxg;
   for (int rr = 0; rr < rpb; rr++) {
     const int a = blockIdx.x * rpb + rr;
     if (a >= rows) break;  // (uniform)
@@ -600,7 +664,7 @@ __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ im
     const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
     for (unsigned j = threadIdx.x; j < n; j += NT) {
       const int p = s_q[j];
-      const float hv = pixel_h(row, cols, p, mean, maxg);
+      const float hv = pixel_h(row, cols, p, mean, maxg, rcp_maxg);
       if (h_bin(hv) == bstar) list[atomicAdd(&sc->n_list, 1u)] = key_of(hv, (unsigned)a * (unsigned)cols + (unsigned)p);
     }
   }
@@ -692,135 +756,139 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
 // byte of the run(s) it touches, a neg pixel reads its run's flag: no keys of other pixels, no marker read, no gather.
 // Then one segmented max-scan over the marked runs at r >= min_range: every run that an unmarked pixel closes is recorded as
 // (first bin, last bin, bin of the first maximum of h); the row's mark bits go to HBM for the neighbours' adjacency test.
+constexpr int RUNS_ROWS = 1;  // azimuths per block of cen_runs in a batch (2: 175 us per 64 scans against 169 -- its flags are zeroed per azimuth, only the table is shared)
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
                                                Scal *scal, int min_range, int row_cap, uint2 *__restrict__ row_runs,
-                                               unsigned *__restrict__ row_nruns, unsigned short *__restrict__ markbits) {
+                                               unsigned *__restrict__ row_nruns, unsigned short *__restrict__ markbits, int rpb) {
   constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
   __shared__ RowLds<C, NT> L;
   __shared__ __attribute__((aligned(16))) uint8_t s_run[C * NT + 16];  // flag of neg run number k: some toucher is a hit
-  __shared__ double s_k[NT / 64];
-  __shared__ unsigned s_cnt[NT / 64], s_cnt2[NT / 64];
-  const int a = blockIdx.x, img = blockIdx.y;
+  constexpr int NW = NT / 64;
+  __shared__ double s_k[2 * NW];                    // [NW + w]; [0, NW): zeros (RowLds: no selects on the reading side)
+  __shared__ unsigned s_cnt[2 * NW], s_cnt2[2 * NW];
+  const int img = blockIdx.y;
   Scal *sc = scal + img;
-  const uint8_t *row = imgs + (int64_t)img * img_stride + off + (int64_t)a * stride;
-  const float mean = mean_fft(sc, (int64_t)rows * cols), maxg = __uint_as_float(sc->max_g_bits);
+  const float mean = sc->mean, maxg = __uint_as_float(sc->max_g_bits), rcp_maxg = sc->rcp_maxg;
   const unsigned long long klimit = sc->klimit;
   row_table(L);
   const int p0 = threadIdx.x * C;
-  {
-    uint4 *z = reinterpret_cast<uint4 *>(s_run);
-    for (int i = threadIdx.x; i < (C * NT + 16) / 16; i += NT) z[i] = uint4{0u, 0u, 0u, 0u};
+  if (threadIdx.x < NW) {
+    s_k[threadIdx.x] = 0.0;
+    s_cnt[threadIdx.x] = 0u;
+    s_cnt2[threadIdx.x] = 0u;
   }
-  RowChunk<C> R;
-  row_chunk(L, row, cols, mean, maxg, R);  // (its barriers also publish the zeroed flags)
-  float (&h)[C] = R.h;
-  const unsigned nn = ~R.neg & FULL;
-  unsigned hit = 0;
-#pragma unroll
-  for (int i = 0; i < C; i++) {
-    const bool hh = p0 + i < cols && key_of(h[i], (unsigned)a * (unsigned)cols + (unsigned)(p0 + i)) < klimit;
-    if (hh) {
-      hit |= 1u << i;
-      const unsigned c = R.excl_nn + (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels before p = the number of the run p is in / that ends at p
-      s_run[c] = 1;                                // a neg pixel: its own run; a non-neg pixel: the run on its left ...
-      if ((nn >> i) & 1u) s_run[c + 1] = 1;        // ... and the run on its right
+  for (int rr = 0; rr < rpb; rr++) {  // (rpb azimuths per block in a batch: the table and the block's start-up once)
+    const int a = blockIdx.x * rpb + rr;
+    if (a >= rows) break;  // (uniform)
+    const uint8_t *row = imgs + (int64_t)img * img_stride + off + (int64_t)a * stride;
+    {  // (the readers of the previous azimuth's flags are three barriers behind)
+      uint4 *z = reinterpret_cast<uint4 *>(s_run);
+      for (int i = threadIdx.x; i < (C * NT + 16) / 16; i += NT) z[i] = uint4{0u, 0u, 0u, 0u};
     }
-  }
-  __syncthreads();
-  unsigned marked = 0;
+    RowChunk<C> R;
+    row_chunk(L, row, cols, mean, maxg, rcp_maxg, R);  // (its barriers also publish the zeroed flags)
+    const unsigned nn = ~R.neg & FULL;
+    // hit(p) = key(p) < limit, key = ~ord(h) << 32 | pixel: straight from the chunk's ord(h) (a wall's is 0: the largest key
+    // there is, never a hit -- no test against the row's end)
+    unsigned hit = 0;
+    const unsigned pix0 = (unsigned)a * (unsigned)cols + (unsigned)p0;
 #pragma unroll
-  for (int i = 0; i < C; i++) {
-    const unsigned c = R.excl_nn + (unsigned)__popc(nn & ((1u << i) - 1u));
-    const bool mk = p0 + i < cols && (((nn >> i) & 1u) ? ((hit >> i) & 1u) != 0 : s_run[c] != 0);
-    if (mk) marked |= 1u << i;
-  }
-  markbits[((int64_t)img * rows + a) * NT + threadIdx.x] = (unsigned short)marked;
-  // ---- closed runs of marked pixels at r >= rmin: (first bin, last bin, bin of the first maximum of h).  live = marked and
-  // r >= rmin; a run starts where the pixel before is not live, and counts once an UNMARKED pixel closes it (a run that
-  // reaches the end of the row does not).  Two plain max-scans (sc_key's trick): S(p) = 1 + the bin of the latest start
-  // at or before p, then K(p) = S(p) | ord(h) | ~bin in one positive double -- the latest run beats everything before it,
-  // inside it the largest h wins and among equals the lowest bin -- so the value at a run's last pixel is the run's result.
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int rmin = min_range < 0 ? 0 : min_range;
-  const unsigned ge = p0 >= rmin ? FULL : (p0 + C <= rmin ? 0u : (FULL & ~((1u << (rmin - p0)) - 1u)));  // bit i: p >= rmin
-  const unsigned live = marked & ge;
-  unsigned lprev = (unsigned)__builtin_amdgcn_update_dpp(0, (int)((live >> (C - 1)) & 1u), 0x138, 0xf, 0xf, false);   // previous thread's last pixel live
-  unsigned mnext = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(marked & 1u), 0x130, 0xf, 0xf, false);               // next thread's first pixel marked
-  {
-    const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)(marked & 1u), 0), e1 = (unsigned)__builtin_amdgcn_readlane((int)((live >> (C - 1)) & 1u), 63);
-    if (lane == 0) L.edge[w] = e0 | (e1 << 1);
-  }
-  __syncthreads();
-  if (lane == 0) lprev = w > 0 ? (L.edge[w > 0 ? w - 1 : 0] >> 1) & 1u : 0u;
-  if (lane == 63) mnext = w + 1 < NT / 64 ? L.edge[w + 1 < NT / 64 ? w + 1 : 0] & 1u : 0u;
-  const unsigned start = live & ~(((live << 1) | lprev) & FULL);
-  const unsigned in_row = p0 + C < cols ? FULL : (p0 + 1 >= cols ? 0u : ((1u << (cols - 1 - p0)) - 1u));  // bit i: p + 1 < cols
-  const unsigned close = live & ~((marked >> 1) | (mnext << (C - 1))) & in_row;
-  // S: 1 + bin of the latest start (0: none yet)
-  const unsigned sloc = start ? (unsigned)(p0 + (31 - __builtin_clz(start)) + 1) : 0u;
-  unsigned sin;
-  {
-    auto dmax = [](unsigned v, auto ctrl) { const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, decltype(ctrl)::value, 0xf, 0xf, false); return o > v ? o : v; };
-    unsigned x = sloc;
-    x = dmax(x, std::integral_constant<int, 0x111>{});
-    x = dmax(x, std::integral_constant<int, 0x112>{});
-    x = dmax(x, std::integral_constant<int, 0x114>{});
-    x = dmax(x, std::integral_constant<int, 0x118>{});
-    const unsigned t0 = (unsigned)__builtin_amdgcn_readlane((int)x, 15), t1 = (unsigned)__builtin_amdgcn_readlane((int)x, 31),
-                   t2 = (unsigned)__builtin_amdgcn_readlane((int)x, 47);
-    const unsigned m1 = t0 > t1 ? t0 : t1, m2 = m1 > t2 ? m1 : t2;
-    const unsigned pre = lane < 16 ? 0u : (lane < 32 ? t0 : (lane < 48 ? m1 : m2));
-    x = x > pre ? x : pre;  // inclusive over the wavefront (positions only grow, so max = latest)
-    if (lane == 63) s_cnt[w] = x;
-    sin = (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);  // exclusive
-  }
-  __syncthreads();
-#pragma unroll
-  for (int ww = 0; ww < NT / 64; ww++) {
-    const unsigned v = ww < w ? s_cnt[ww] : 0u;
-    sin = v > sin ? v : sin;
-  }
-  // K
-  double kin[C];
-  double run = 0.0;
-#pragma unroll
-  for (int i = 0; i < C; i++) {
-    const unsigned below = start & ((2u << i) - 1u);  // starts of the chunk at or before i
-    const unsigned sp = below ? (unsigned)(p0 + (31 - __builtin_clz(below)) + 1) : sin;
-    const unsigned long long k = (1ull << 62) | ((unsigned long long)sp << 46) | ((unsigned long long)R.ordh[i] << 14) |
-                                 (unsigned long long)(0x3fffu - (unsigned)((p0 + i) & 0x3fff));
-    const double kd = ((live >> i) & 1u) ? __longlong_as_double((long long)k) : 0.0;
-    run = kmax(run, kd);
-    kin[i] = run;
-  }
-  const double ki = wave_incl_max<false>(run, lane);
-  double kx = dpp_f64<0x138>(ki);
-  if (lane == 63) s_k[w] = ki;
-  // (the compaction's counts travel with the same barrier)
-  const unsigned cnt = (unsigned)__popc(close);
-  const unsigned inc = wave_incl_add(cnt, lane);
-  if (lane == 63) s_cnt2[w] = inc;
-  __syncthreads();
-  unsigned before = 0, total = 0;
-#pragma unroll
-  for (int ww = 0; ww < NT / 64; ww++) {
-    kx = kmax(kx, ww < w ? s_k[ww] : 0.0);
-    const unsigned c = s_cnt2[ww];
-    before += ww < w ? c : 0u;
-    total += c;
-  }
-  unsigned pos = before + inc - cnt;
-  uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
-#pragma unroll
-  for (int i = 0; i < C; i++) {
-    if ((close >> i) & 1u) {
-      const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
-      const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
-      ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
+    for (int i = 0; i < C; i++) {
+      const unsigned long long key = ((unsigned long long)(~R.ordh[i]) << 32) | (unsigned long long)(pix0 + (unsigned)i);
+      if (key < klimit) {
+        hit |= 1u << i;
+        const unsigned c = R.excl_nn + (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels before p = the number of the run p is in / that ends at p
+        s_run[c] = 1;                                // a neg pixel: its own run; a non-neg pixel: the run on its left ...
+        if ((nn >> i) & 1u) s_run[c + 1] = 1;        // ... and the run on its right
+      }
     }
+    __syncthreads();
+    // marks: a non-neg pixel iff it is a hit, a neg pixel iff its run's flag is set (walls are non-neg and no hits)
+    unsigned flags = 0;
+#pragma unroll
+    for (int i = C - 1; i >= 0; i--) {
+      const unsigned f = s_run[R.excl_nn + (unsigned)__popc(nn & ((1u << i) - 1u))];
+      asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(flags) : "v"(f) : "vcc");
+    }
+    const unsigned marked = (nn & hit) | (R.neg & flags);
+    markbits[((int64_t)img * rows + a) * NT + threadIdx.x] = (unsigned short)marked;
+    // ---- closed runs of marked pixels at r >= rmin: (first bin, last bin, bin of the first maximum of h).  live = marked and
+    // r >= rmin; a run starts where the pixel before is not live, and counts once an UNMARKED pixel closes it (a run that
+    // reaches the end of the row does not).  Two plain max-scans (sc_key's trick): S(p) = 1 + the bin of the latest start
+    // at or before p, then K(p) = S(p) | ord(h) | ~bin in one positive double -- the latest run beats everything before it,
+    // inside it the largest h wins and among equals the lowest bin -- so the value at a run's last pixel is the run's result.
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int rmin = min_range < 0 ? 0 : min_range;
+    const unsigned ge = p0 >= rmin ? FULL : (p0 + C <= rmin ? 0u : (FULL & ~((1u << (rmin - p0)) - 1u)));  // bit i: p >= rmin
+    const unsigned live = marked & ge;
+    unsigned lprev = dpp_u32<0x138>((live >> (C - 1)) & 1u);   // previous thread's last pixel live
+    unsigned mnext = dpp_u32<0x130>(marked & 1u);               // next thread's first pixel marked
+    {
+      const unsigned e0 = (unsigned)__builtin_amdgcn_readlane((int)(marked & 1u), 0), e1 = (unsigned)__builtin_amdgcn_readlane((int)((live >> (C - 1)) & 1u), 63);
+      if (lane == 0) L.edge[w] = e0 | (e1 << 1);
+    }
+    __syncthreads();
+    if (lane == 0) lprev = w > 0 ? (L.edge[w > 0 ? w - 1 : 0] >> 1) & 1u : 0u;
+    if (lane == 63) mnext = w + 1 < NT / 64 ? L.edge[w + 1 < NT / 64 ? w + 1 : 0] & 1u : 0u;
+    const unsigned start = live & ~(((live << 1) | lprev) & FULL);
+    const unsigned in_row = p0 + C < cols ? FULL : (p0 + 1 >= cols ? 0u : ((1u << (cols - 1 - p0)) - 1u));  // bit i: p + 1 < cols
+    const unsigned close = live & ~((marked >> 1) | (mnext << (C - 1))) & in_row;
+    // S: 1 + bin of the latest start (0: none yet)
+    const unsigned sloc = start ? (unsigned)(p0 + (31 - __builtin_clz(start)) + 1) : 0u;
+    unsigned sin;
+    {
+      const unsigned x = wave_incl_max_u32(sloc);  // inclusive over the wavefront (positions only grow, so max = latest)
+      if (lane == 63) s_cnt[NW + w] = x;
+      sin = dpp_u32<0x138>(x);  // exclusive
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      const unsigned v = s_cnt[NW + w - 1 - k];
+      sin = v > sin ? v : sin;
+    }
+    // K = 1 << 62 | S << 46 | ord(h) << 14 | ~bin: the high word is one v_alignbit of (S | 1 << 16, ord(h)), the low word one
+    // v_lshl_or; a pixel that is not live gets a high word of 0 (a tiny positive double below every key, whatever the low word)
+    double kin[C];
+    double run = 0.0;
+    const unsigned sinx = sin | 0x10000u, pbx = (unsigned)p0 + 32u + 0x10000u, c0 = 0x3fffu - ((unsigned)p0 & 0x3fffu);  // (p0 is a multiple of C: no carry into the next 16384)
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const unsigned below = start & ((2u << i) - 1u);  // starts of the chunk at or before i
+      const unsigned spx = below ? pbx - (unsigned)__builtin_clz(below) : sinx;
+      const unsigned hi = __builtin_amdgcn_alignbit(spx, R.ordh[i], 18);
+      const unsigned lo = (R.ordh[i] << 14) | (c0 - (unsigned)i);
+      const double kd = __hiloint2double((int)(((live >> i) & 1u) ? hi : 0u), (int)lo);
+      run = kmax(run, kd);
+      kin[i] = run;
+    }
+    const double ki = wave_incl_max<false>(run, lane);
+    double kx = dpp_f64<0x138>(ki);
+    if (lane == 63) s_k[NW + w] = ki;
+    // (the compaction's counts travel with the same barrier)
+    const unsigned cnt = (unsigned)__popc(close);
+    const unsigned inc = wave_incl_add(cnt, lane);
+    if (lane == 63) s_cnt2[NW + w] = inc;
+    __syncthreads();
+    unsigned before = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      kx = kmax(kx, s_k[NW + w - 1 - k]);
+      before += s_cnt2[NW + w - 1 - k];
+    }
+    unsigned pos = before + inc - cnt;
+    uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      if ((close >> i) & 1u) {
+        const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
+        const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
+        ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
+      }
+    }
+    if (threadIdx.x == NT - 1) row_nruns[(int64_t)img * rows + a] = before + inc;  // the last thread's inclusive count
   }
-  if (threadIdx.x == 0) row_nruns[(int64_t)img * rows + a] = total;
 }
 
 // the adjacency test of the method: a closed run yields a keypoint when the azimuth below or above (wrap-around) has a
@@ -929,15 +997,19 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   const int rpb = (int64_t)rows * nb >= 8192 ? ST_ROWS : 1;
   hipLaunchKernelGGL((cen_stats<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
                      stride, off, sc, rpb);
-  hipLaunchKernelGGL((cen_hist<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>(),
-                     h->opener.as<unsigned short>(), h->topbin.as<unsigned short>());
+  hipLaunchKernelGGL(cen_scalars, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, sc, nb, (int64_t)rows * cols);
+  const int hrpb = rpb > 1 ? HIST_ROWS : 1;
+  hipLaunchKernelGGL((cen_hist<C, NT>), dim3((unsigned)((rows + hrpb - 1) / hrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
+                     stride, off, sc, h->hist.as<unsigned>(), h->opener.as<unsigned short>(), h->topbin.as<unsigned short>(), hrpb);
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
   hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
                      h->topbin.as<unsigned short>(), h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
-  hipLaunchKernelGGL((cen_runs<C, NT>), grid, dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, p.min_range, row_cap,
-                     h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(), h->markbits.as<unsigned short>());
+  const int rrpb = rpb > 1 ? RUNS_ROWS : 1;
+  hipLaunchKernelGGL((cen_runs<C, NT>), dim3((unsigned)((rows + rrpb - 1) / rrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
+                     stride, off, sc, p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
+                     h->markbits.as<unsigned short>(), rrpb);
   hipLaunchKernelGGL((cen_adjacent<C, NT>), grid, dim3(256), 0, s, rows, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
                      h->markbits.as<unsigned short>(), h->row_out.as<int>(), h->row_n.as<unsigned>());
   hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,

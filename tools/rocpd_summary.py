@@ -34,7 +34,7 @@ def main(root, all_grids=False):
         for name, cname, n, avg, grid, vgpr, lds in con.execute(q):
             if not any(t in name for t in ("rsx", "cen_", "fe_", "odo_", "icp_", "vg_", "lv_")):
                 continue
-            short = name.split("::")[-1][:40]
+            short = name.replace("void ", "").replace("(anonymous namespace)::", "")[:40]  # (split("::")[-1] cut kernels with a namespaced ARGUMENT type down to the argument list)
             print(f"{short:42s} {cname:24s} dispatches={n:3d} avg_per_dispatch={avg:18.1f} grid={grid} vgpr={vgpr} lds={lds}")
 
 
