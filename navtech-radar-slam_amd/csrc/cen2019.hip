@@ -16,18 +16,17 @@
 //   a visited candidate p opens a NEW region  <=>  key(p) is the minimum of every run it touches
 //   the budget ends the walk at K* = the max_points-th smallest key among the region openers
 //   p is marked in the end  <=>  MK(p) <= K*  and  MK(p) is a candidate (h > mean_h)
-// so the chain is four image passes over L2-resident bytes and ONE selection; the only intermediate in HBM is 2 bytes
-// per pixel (h is recomputed from the bytes where it is needed):
+// so the chain is three passes over the image bytes and ONE selection; the intermediates in HBM are 2 bytes per 8 pixels
+// (opener bits + how high the thread's openers reach) and 1 byte per 8 pixels (mark bits) -- h is recomputed from the bytes:
 //   cen_stats    bytes -> sum(bytes), max |fft(r+1) - fft(r-1)|                     (global: mean, max g)
-//   cen_hist     per azimuth: keys, per-run minima (two segmented min-scans), "opens a region" flags
-//                -> 4096-bin histogram of the openers' h, fixed-point sum of h (mean_h)
+//   cen_scalars  (a thread per image) mean and 1 / max g, once
+//   cen_hist     per azimuth: which pixels OPEN a region -- per-run maxima of h as plain max-scans of (segment | ord(h))
+//                keys, see row_opens -- -> 4096-bin histogram of the openers' h, fixed-point sum of h (mean_h), opener bits
 //   cen_pick     (one block per image) the bin B* that holds the max_points-th opener
-//                -- and records, per pixel, the range bin of its marker (16 bits) and the opener bits,
-//                so that the scans run once per row
-//   cen_collect  h again (cheap) + the recorded opener bits: appends the openers of bin B* (a few dozen keys)
-//   cen_resolve  (one block per image) radix-selects K* among them
-//   cen_runs     per azimuth: marks = key of the recorded marker pixel < limit (h of the row in LDS, one
-//                gather per pixel); closed runs of marks and their arg-max by one segmented max-scan
+//   cen_collect  the recorded opener bits of the threads that reach B*: appends the openers of bin B* (a few dozen keys)
+//   cen_resolve  (one block per image) selects K* among them
+//   cen_runs     per azimuth: marks = OR over run flags (a hit sets the flag of the run(s) it touches); closed runs of marks
+//                and their arg-max by two plain max-scans; mark bits
 //   cen_adjacent per azimuth: keep the runs that meet a mark of the azimuth above or below, ordered compaction
 //   cen_pack     row-major packing of the rows' keypoints (+ polar -> Cartesian)
 // One workgroup per (azimuth, image): a launch over a batch of B images is B x rows workgroups, every
@@ -507,11 +506,16 @@ __device__ __forceinline__ int h_bin(float hv) {
   return (int)(b > (unsigned)(NBIN - 1) ? (unsigned)(NBIN - 1) : b);
 }
 
+// what cen_hist leaves per thread for cen_collect: the opener bits of its C pixels | topq << (8 or 16), topq = ceil((1 + the
+// highest histogram bin an opener of the thread fell into) / 32) (0: no opener) -- 2 bytes per 8 pixels; cen_runs leaves the C
+// mark bits (1 byte per 8 pixels).  Threads past the end of the row write nothing.
+template <int C> using OpRec = std::conditional_t<(C <= 8), unsigned short, unsigned>;
+template <int C> using MarkT = std::conditional_t<(C <= 8), uint8_t, unsigned short>;
+template <int C> constexpr int kTopShift = C <= 8 ? 8 : 16;
 constexpr int HIST_ROWS = 4;  // azimuths per block of cen_hist in a batch: the table, the zeroed block histogram and its flush (atomics into the image's 4096 bins: a quarter of the kernel at one row per block) once for all of them
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
-                                               Scal *scal, unsigned *__restrict__ hist, unsigned short *__restrict__ opener,
-                                               unsigned short *__restrict__ topbin, int rpb) {
+                                               Scal *scal, unsigned *__restrict__ hist, OpRec<C> *__restrict__ opener, int rpb) {
   __shared__ RowLds<C, NT> L;
   __shared__ __attribute__((aligned(16))) unsigned s_hist[NBIN];
   __shared__ long long s_fix[NT / 64];
@@ -535,8 +539,6 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
     RowChunk<C> R;
     row_chunk(L, row, cols, mean, maxg, rcp_maxg, R);
     const unsigned opens = row_opens(L, R, cols);
-    // the opener bits of the thread are all the later passes need of this evaluation (cen_collect); 2 bytes per C pixels
-    opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)opens;
     int top = 0;  // 1 + the highest histogram bin an opener of this thread fell into (0: the thread has no opener)
 #pragma unroll
     for (int i = 0; i < C; i++) {  // (past the row end h = 0 and no opener bit is set)
@@ -550,8 +552,10 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
         top = b + 1 > top ? b + 1 : top;
       }
     }
-    // what cen_collect needs of this evaluation: it looks only at threads that can hold an opener of the selected bin
-    topbin[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (unsigned short)top;
+    // all the later passes need of this evaluation: the opener bits, and (cen_collect looks only at threads that can hold an
+    // opener of the selected bin) how high the thread's openers reach
+    if ((int)threadIdx.x * C < cols)
+      opener[((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x] = (OpRec<C>)(opens | ((unsigned)((top + 31) >> 5) << kTopShift<C>));
     if ((rr & 1) || rr + 1 == rpb || a + 1 >= rows) {  // (uniform)
       const int fhi = wave_sum_i32((int)ahi);  // (DPP + v_readlane: the xor butterfly was twelve ds_bpermute round trips)
       const int flo = wave_sum_i32((int)alo);
@@ -638,8 +642,7 @@ __device__ __forceinline__ float pixel_h(const uint8_t *__restrict__ row, int co
 // (1807 VALU instructions per wavefront for eight rows, 80 us per 64 images).
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
-                                                  int off, Scal *scal, const unsigned short *__restrict__ opener,
-                                                  const unsigned short *__restrict__ topbin, unsigned long long *__restrict__ lists,
+                                                  int off, Scal *scal, const OpRec<C> *__restrict__ opener, unsigned long long *__restrict__ lists,
                                                   int64_t list_stride, int rpb) {
   __shared__ unsigned short s_q[C * NT];
   __shared__ unsigned s_n;
@@ -654,8 +657,9 @@ __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ im
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     const int64_t slot = ((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x;
-    if ((int)topbin[slot] > bstar) {  // 1 + highest opener bin >= B* + 1
-      unsigned op = opener[slot];
+    const unsigned rec = (int)threadIdx.x * C < cols ? (unsigned)opener[slot] : 0u;
+    if ((int)((rec >> kTopShift<C>) << 5) > bstar) {  // 1 + highest opener bin (rounded up to 32) >= B* + 1
+      unsigned op = rec & ((1u << kTopShift<C>) - 1u);
       const unsigned at = atomicAdd(&s_n, (unsigned)__popc(op));
       for (unsigned j = at; op; op &= op - 1, j++) s_q[j] = (unsigned short)(threadIdx.x * C + __builtin_ctz(op));
     }
@@ -756,11 +760,11 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
 // byte of the run(s) it touches, a neg pixel reads its run's flag: no keys of other pixels, no marker read, no gather.
 // Then one segmented max-scan over the marked runs at r >= min_range: every run that an unmarked pixel closes is recorded as
 // (first bin, last bin, bin of the first maximum of h); the row's mark bits go to HBM for the neighbours' adjacency test.
-constexpr int RUNS_ROWS = 1;  // azimuths per block of cen_runs in a batch (2: 175 us per 64 scans against 169 -- its flags are zeroed per azimuth, only the table is shared)
+constexpr int RUNS_ROWS = 2;  // azimuths per block of cen_runs in a batch
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
                                                Scal *scal, int min_range, int row_cap, uint2 *__restrict__ row_runs,
-                                               unsigned *__restrict__ row_nruns, unsigned short *__restrict__ markbits, int rpb) {
+                                               unsigned *__restrict__ row_nruns, MarkT<C> *__restrict__ markbits, int rpb) {
   constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
   __shared__ RowLds<C, NT> L;
   __shared__ __attribute__((aligned(16))) uint8_t s_run[C * NT + 16];  // flag of neg run number k: some toucher is a hit
@@ -812,7 +816,7 @@ __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs,
       asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(flags) : "v"(f) : "vcc");
     }
     const unsigned marked = (nn & hit) | (R.neg & flags);
-    markbits[((int64_t)img * rows + a) * NT + threadIdx.x] = (unsigned short)marked;
+    if (p0 < cols) markbits[((int64_t)img * rows + a) * NT + threadIdx.x] = (MarkT<C>)marked;
     // ---- closed runs of marked pixels at r >= rmin: (first bin, last bin, bin of the first maximum of h).  live = marked and
     // r >= rmin; a run starts where the pixel before is not live, and counts once an UNMARKED pixel closes it (a run that
     // reaches the end of the row does not).  Two plain max-scans (sc_key's trick): S(p) = 1 + the bin of the latest start
@@ -893,17 +897,17 @@ __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs,
 
 // the adjacency test of the method: a closed run yields a keypoint when the azimuth below or above (wrap-around) has a
 // marked pixel inside the run's range span.  One block per (azimuth, image) over the runs cen_runs recorded and the mark
-// bits of the two neighbours (C bits per 16-bit word); ordered compaction of the survivors' arg-max bins.
+// bits of the two neighbours (C bits per chunk); ordered compaction of the survivors' arg-max bins.
 template <int C, int NT>
-__global__ __launch_bounds__(256) void cen_adjacent(int rows, int row_cap, const uint2 *__restrict__ row_runs,
-                                                    const unsigned *__restrict__ row_nruns, const unsigned short *__restrict__ markbits,
+__global__ __launch_bounds__(256) void cen_adjacent(int rows, int cols, int row_cap, const uint2 *__restrict__ row_runs,
+                                                    const unsigned *__restrict__ row_nruns, const MarkT<C> *__restrict__ markbits,
                                                     int *__restrict__ row_out, unsigned *__restrict__ row_n) {
   __shared__ unsigned short s_nb[NT];  // marks of the two neighbours, OR-ed
   __shared__ unsigned s_w[4];
   const int a = blockIdx.x, img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const unsigned short *below = markbits + ((int64_t)img * rows + (a - 1 + rows) % rows) * NT;
-  const unsigned short *above = markbits + ((int64_t)img * rows + (a + 1) % rows) * NT;
-  for (int t = threadIdx.x; t < NT; t += 256) s_nb[t] = below[t] | above[t];
+  const MarkT<C> *below = markbits + ((int64_t)img * rows + (a - 1 + rows) % rows) * NT;
+  const MarkT<C> *above = markbits + ((int64_t)img * rows + (a + 1) % rows) * NT;
+  for (int t = threadIdx.x; t < NT; t += 256) s_nb[t] = t * C < cols ? (unsigned short)(below[t] | above[t]) : (unsigned short)0;  // (chunks past the row's end were not written)
   __syncthreads();
   const unsigned n = row_nruns[(int64_t)img * rows + a];
   const uint2 *runs = row_runs + ((int64_t)img * rows + a) * row_cap;
@@ -977,7 +981,7 @@ struct rsx_cen2019 {
   int device = 0, rows = 0, cols = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, topbin, row_runs, row_nruns, markbits;
+  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, row_runs, row_nruns, markbits;
   rsx::DevBuf one;          // single-scan entry: [count | targets | xy] in one piece, read back with one copy
   void *one_host = nullptr;  // its pinned mirror
   size_t one_host_bytes = 0;
@@ -1000,18 +1004,18 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   hipLaunchKernelGGL(cen_scalars, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, sc, nb, (int64_t)rows * cols);
   const int hrpb = rpb > 1 ? HIST_ROWS : 1;
   hipLaunchKernelGGL((cen_hist<C, NT>), dim3((unsigned)((rows + hrpb - 1) / hrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
-                     stride, off, sc, h->hist.as<unsigned>(), h->opener.as<unsigned short>(), h->topbin.as<unsigned short>(), hrpb);
+                     stride, off, sc, h->hist.as<unsigned>(), h->opener.as<OpRec<C>>(), hrpb);
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
-  hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<unsigned short>(),
-                     h->topbin.as<unsigned short>(), h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
+  hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<OpRec<C>>(),
+                     h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
   const int rrpb = rpb > 1 ? RUNS_ROWS : 1;
   hipLaunchKernelGGL((cen_runs<C, NT>), dim3((unsigned)((rows + rrpb - 1) / rrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
                      stride, off, sc, p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
-                     h->markbits.as<unsigned short>(), rrpb);
-  hipLaunchKernelGGL((cen_adjacent<C, NT>), grid, dim3(256), 0, s, rows, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
-                     h->markbits.as<unsigned short>(), h->row_out.as<int>(), h->row_n.as<unsigned>());
+                     h->markbits.as<MarkT<C>>(), rrpb);
+  hipLaunchKernelGGL((cen_adjacent<C, NT>), grid, dim3(256), 0, s, rows, cols, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
+                     h->markbits.as<MarkT<C>>(), h->row_out.as<int>(), h->row_n.as<unsigned>());
   hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
                      resolution, max_targets, d_targets, d_xy, d_counts);
 }
@@ -1031,10 +1035,9 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
     RSX_TRY(h->row_out.reserve((size_t)n * rows * row_cap * 4, s, false));
     RSX_TRY(h->row_n.reserve((size_t)n * rows * 4, s, false));
     {
-      const size_t nt = cols <= 8 * 512 ? 512 : 1024;  // threads per row block: one 16-bit word of opener / mark bits per thread
-      RSX_TRY(h->opener.reserve((size_t)n * rows * nt * 2, s, false));
-      RSX_TRY(h->topbin.reserve((size_t)n * rows * nt * 2, s, false));
-      RSX_TRY(h->markbits.reserve((size_t)n * rows * nt * 2, s, false));
+      const size_t nt = cols <= 8 * 512 ? 512 : 1024;  // threads per row block: an OpRec and a MarkT per thread
+      RSX_TRY(h->opener.reserve((size_t)n * rows * nt * (cols <= 8 * 512 ? 2 : 4), s, false));
+      RSX_TRY(h->markbits.reserve((size_t)n * rows * nt * (cols <= 8 * 512 ? 1 : 2), s, false));
       RSX_TRY(h->row_runs.reserve((size_t)n * rows * row_cap * 8, s, false));
       RSX_TRY(h->row_nruns.reserve((size_t)n * rows * 4, s, false));
     }
@@ -1104,7 +1107,7 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) try {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->one_host) (void)hipHostFree(h->one_host);
   h->one.release();
-  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->topbin, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
+  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
