@@ -718,8 +718,8 @@ def icp_leg(device):
     return {"ms_per_align": dt * 1e3, "source_points": len(src), "target_points": len(tgt), "iterations": res["iterations"],
             "converged": res["converged"], "fitness": res["fitness"], "accepted": bool(res["converged"] and res["fitness"] <= 0.3),
             "dtype": "f32 (fp64 moment sums)",
-            "note": "brute-force nearest neighbour, %.1e distance evaluations per iteration; host-buffer entry "
-                    "(uploads both clouds, one 16-byte read-back per iteration)" % (len(src) * len(tgt))}
+            "note": "one persistent launch per alignment (grid barrier per iteration); brute-force nearest neighbour, %.1e distance "
+                    "evaluations per iteration; host-buffer entry (uploads both clouds, one read-back)" % (len(src) * len(tgt))}
 
 
 def q1_latency_leg(device, q_descs):
@@ -829,7 +829,7 @@ def loop_verify_leg(device):
         acc += int(r["accepted"])
         its += r["iterations"]
     dt = (time.perf_counter() - t0) / len(pairs)
-    want = po.loop_verify(clouds, pairs[0][0], pairs[0][1], pose6[pairs[0][0]])
+    want = po.loop_verify(clouds, pairs[0][0], pairs[0][1], pose6[pairs[0][0]], sum_order=po.ICP_SUM_TREE)
     t0 = time.perf_counter()
     m = kf.build_map(pose6, skip=2, leaf=0.4)
     t_map = time.perf_counter() - t0
@@ -838,11 +838,14 @@ def loop_verify_leg(device):
             "source_points_after_voxelgrid": int(res["n_source"]), "target_points_after_voxelgrid": int(res["n_target"]),
             "keyframe_points": int(np.mean([len(c) for c in clouds])), "ms_per_keyframe_add": t_add * 1e3,
             "first_verdict_equals_oracle": bool(res["accepted"] == want["accepted"] and res["n_source"] == want["n_source"] and
-                                                res["n_target"] == want["n_target"] and abs(res["fitness"] - want["fitness"]) < 1e-2 * max(1.0, want["fitness"])),
+                                                res["n_target"] == want["n_target"] and abs(res["fitness"] - want["fitness"]) < 1e-4 * max(1.0, want["fitness"]) and
+                                                res["iterations"] == want["iterations"]),
             "map": {"points": int(len(m)), "keyframes": len(clouds), "ms": t_map * 1e3},
             "dtype": "f32 (fp64 moment sums)",
-            "note": "rsx_loop_verify: keyframe clouds in HBM; per candidate: 2 transform kernels + 2 VoxelGrid chains + ICP "
-                    "(brute-force nearest neighbour) + gate; nothing but counts and the convergence flag returns to the host"}
+            "launches_per_verification": 2,
+            "note": "rsx_loop_verify: keyframe clouds in HBM; per candidate TWO launches -- both submaps transformed + VoxelGrid-"
+                    "filtered by one cooperative kernel, the persistent ICP kernel (brute-force nearest neighbour, one grid barrier "
+                    "per iteration) + gate -- and one read-back; the cloud sizes stay on the device in between"}
 
 
 def layout_emulation_leg(device, db_descs, q_descs, n_elig, k, res=None, reps=5):

@@ -43,9 +43,7 @@
 
 namespace {
 
-struct Mat34 {
-  float m[12];  // row-major 3 x 4
-};
+using rsx::vg::Mat34;  // row-major 3 x 4
 
 // pcl::getTransformation(float x, float y, float z, float roll, float pitch, float yaw): the Affine3f overload the
 // reference reaches from local2global (PGO.cpp:206; its Pose6D doubles are narrowed at the call), computed on the host
@@ -68,20 +66,6 @@ __global__ __launch_bounds__(256) void lv_pack(const char *__restrict__ pts, int
   if (i >= n) return;
   const float *p = reinterpret_cast<const float *>(pts + i * stride);
   out[i] = float4{p[0], p[1], p[2], ioff >= 0 ? *reinterpret_cast<const float *>(pts + i * stride + ioff) : 0.0f};
-}
-
-// local2global (PGO.cpp:210-217) over a contiguous slice: out = T * p, every product and sum in float, left to right
-// (compiled with -ffp-contract=off: no fused multiply-add, like the reference's x86-64 build); intensity copied
-__global__ __launch_bounds__(256) void lv_transform(const float4 *__restrict__ in, int64_t n, Mat34 T, float4 *__restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = in[i];
-  float4 o;
-  o.x = T.m[0] * p.x + T.m[1] * p.y + T.m[2] * p.z + T.m[3];
-  o.y = T.m[4] * p.x + T.m[5] * p.y + T.m[6] * p.z + T.m[7];
-  o.z = T.m[8] * p.x + T.m[9] * p.y + T.m[10] * p.z + T.m[11];
-  o.w = p.w;
-  out[i] = o;
 }
 
 // pubMap (PGO.cpp:640-645): every point of a KEPT keyframe through the pose of its keyframe, kept keyframes back to back in
@@ -149,25 +133,39 @@ int append_device(rsx_kfstore *h, const float4 *d_pts, int64_t n, int32_t *out_i
   return RSX_OK;
 }
 
-// loopFindNearKeyframesCloud (PGO.cpp:329-352) on the device: -> *d_out (owned by vg, valid until its next call), *n_out
-int submap_device(rsx_kfstore *h, rsx_voxelgrid *vg, rsx::DevBuf &work, int64_t key, int64_t size, const Mat34 &T, float leaf,
-                  const float **d_out, int64_t *n_out) {
-  *d_out = nullptr;
-  *n_out = 0;
+// the slice of the store loopFindNearKeyframesCloud (PGO.cpp:329-352) concatenates: keyframes key - size .. key + size
+void submap_slice(const rsx_kfstore *h, int64_t key, int64_t size, int64_t *first, int64_t *n) {
   const int64_t nkf = (int64_t)h->off.size() - 1;
   int64_t lo = key - size, hi = key + size;
   if (lo < 0) lo = 0;
   if (hi > nkf - 1) hi = nkf - 1;
-  if (lo > hi) return RSX_OK;
-  const int64_t first = h->off[lo], n = h->off[hi + 1] - first;
+  *first = 0;
+  *n = 0;
+  if (lo > hi) return;
+  *first = h->off[lo];
+  *n = h->off[hi + 1] - *first;
+}
+
+// loopFindNearKeyframesCloud on the device: transform (local2global by the root pose) and VoxelGrid in ONE launch
+// -> *d_out (owned by vg, valid until its next call), *n_out
+int submap_device(rsx_kfstore *h, rsx_voxelgrid *vg, int64_t key, int64_t size, const Mat34 &T, float leaf, const float **d_out,
+                  int64_t *n_out) {
+  *d_out = nullptr;
+  *n_out = 0;
+  int64_t first = 0, n = 0;
+  submap_slice(h, key, size, &first, &n);
   if (n <= 0) return RSX_OK;  // nearKeyframes->empty()
   hipStream_t s = h->stream;
-  RSX_TRY(work.reserve((size_t)n * 16, s, false));
-  hipLaunchKernelGGL(lv_transform, dim3(blocks_of(n)), dim3(256), 0, s, h->clouds.as<float4>() + first, n, T, work.as<float4>());
-  RSX_HIP(hipGetLastError());
-  // the VoxelGrid chain runs on the store's stream behind the transform and synchronises it for its count
   std::lock_guard<std::mutex> lk(rsx::vg::mutex_of(vg));
-  return rsx::vg::filter_device(vg, work.p, n, 16, 12, leaf, n, d_out, n_out, s);
+  rsx::vg::JobIn in{vg, h->clouds.as<float4>() + first, n, 16, 12, &T, leaf, n};
+  rsx::vg::DeviceCloud dc;
+  RSX_TRY(rsx::vg::enqueue(&in, 1, s, &dc));
+  long long cnt = 0;
+  RSX_HIP(hipMemcpyAsync(&cnt, dc.d_count, sizeof(cnt), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipStreamSynchronize(s));
+  *d_out = dc.d_out;
+  *n_out = cnt;
+  return RSX_OK;
 }
 
 }  // namespace
@@ -317,7 +315,7 @@ int rsx_loop_submap(rsx_kfstore *h, int32_t key, int32_t submap_size, const doub
   RSX_HIP(hipSetDevice(h->device));
   const float *d = nullptr;
   int64_t n = 0;
-  RSX_TRY(submap_device(h, h->vg_t, h->work_t, key, submap_size, pose_matrix(root_pose6), leaf, &d, &n));
+  RSX_TRY(submap_device(h, h->vg_t, key, submap_size, pose_matrix(root_pose6), leaf, &d, &n));
   *out_count = n;
   const int64_t w = n < max_out ? n : max_out;
   if (w > 0) {
@@ -340,18 +338,40 @@ int rsx_loop_verify(rsx_kfstore *h, int32_t loop_idx, int32_t curr_idx, const do
   const int64_t nkf = (int64_t)h->off.size() - 1;
   if (loop_idx < 0 || loop_idx >= nkf || curr_idx < 0 || curr_idx >= nkf) return fail(RSX_ERR_RANGE, "keyframe index out of range (%lld stored)", (long long)nkf);
   const Mat34 T = pose_matrix(root_pose6);  // the ONE root pose both clouds are moved by (PGO.cpp:340,361-362)
-  const float *d_src = nullptr, *d_tgt = nullptr;
+  // two launches and one read-back: (1) both submaps -- source = keyframe curr alone (PGO.cpp:361), target = loop +- 25
+  // (PGO.cpp:362) -- transformed by the root pose and VoxelGrid-filtered by ONE cooperative kernel, their sizes left in device
+  // memory; (2) the persistent ICP kernel, which reads the sizes there.  All on the ICP handle's stream.
+  int64_t first[2], np[2];
+  submap_slice(h, curr_idx, 0, &first[0], &np[0]);
+  submap_slice(h, loop_idx, p.history_keyframe_search_num, &first[1], &np[1]);
+  rsx_voxelgrid *vgs[2] = {h->vg_s, h->vg_t};
+  rsx_icp_result ir;
   int64_t ns = 0, nt = 0;
-  RSX_TRY(submap_device(h, h->vg_s, h->work_s, curr_idx, 0, T, p.leaf, &d_src, &ns));                              // PGO.cpp:361
-  RSX_TRY(submap_device(h, h->vg_t, h->work_t, loop_idx, p.history_keyframe_search_num, T, p.leaf, &d_tgt, &nt));  // PGO.cpp:362
+  {
+    std::lock_guard<std::mutex> lks(rsx::vg::mutex_of(h->vg_s));
+    std::lock_guard<std::mutex> lkt(rsx::vg::mutex_of(h->vg_t));
+    std::lock_guard<std::mutex> lki(rsx::icp::mutex_of(h->icp));
+    hipStream_t s = rsx::icp::stream_of(h->icp);
+    rsx::vg::JobIn jobs[2];
+    rsx::vg::DeviceCloud dc[2];
+    int which[2], nj = 0;
+    for (int c = 0; c < 2; c++)
+      if (np[c] > 0) {
+        jobs[nj] = rsx::vg::JobIn{vgs[c], h->clouds.as<float4>() + first[c], np[c], 16, 12, &T, p.leaf, np[c]};
+        which[nj++] = c;
+      }
+    if (nj) RSX_TRY(rsx::vg::enqueue(jobs, nj, s, dc));
+    const float *d_cloud[2] = {nullptr, nullptr};
+    const long long *d_cnt[2] = {nullptr, nullptr};
+    for (int j = 0; j < nj; j++) {
+      d_cloud[which[j]] = dc[j].d_out;
+      d_cnt[which[j]] = dc[j].d_count;
+    }
+    RSX_TRY(rsx::icp::align_device_counts_locked(h->icp, d_cloud[0], np[0], d_cnt[0], 16, d_cloud[1], np[1], d_cnt[1], 16, &p.icp, nullptr, &ir,
+                                                 &ns, &nt));
+  }
   out->n_source = ns;
   out->n_target = nt;
-  rsx_icp_result ir;
-  {
-    // both VoxelGrid calls synchronised the store's stream: the clouds are complete.  The ICP runs on its own stream.
-    std::lock_guard<std::mutex> lki(rsx::icp::mutex_of(h->icp));
-    RSX_TRY(rsx::icp::align_device_locked(h->icp, d_src, ns, 16, d_tgt, nt, 16, &p.icp, nullptr, &ir));
-  }
   out->converged = ir.converged;
   out->iterations = ir.iterations;
   out->state = ir.state;

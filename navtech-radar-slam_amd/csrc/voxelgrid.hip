@@ -7,29 +7,32 @@
 // float additions inside a voxel run in ascending input order, which PCL's unstable std::sort leaves
 // open).
 //
-// Kernel chain (keyframe clouds are 10^3..10^5 points: latency-bound, everything is L2-resident):
-//   vg_minmax     finite points -> min / max per axis (order-preserving integer atomics), count
-//   vg_setup      one thread: inverse leaf, overflow test, min_b, divb_mul          (float ops as PCL)
-//   vg_keys       voxel index per point (0xffffffff for non-finite points), value = input index
-//   rocPRIM radix sort of (voxel index, input index) pairs -- stable, so a voxel's points stay in
-//   input order
-//   vg_heads      first point of every voxel -> flag; rocPRIM exclusive scan -> output slot
-//   vg_centroids  the thread of a voxel's first point sums x, y, z, intensity in float, divides by
-//                 the count, writes the packed float4
-// Clouds of <= 4096 points (every keyframe cloud of the reference's pipeline) take vg_small_kernel instead: the same steps in
-// one workgroup and ONE launch, with a bitonic sort in LDS -- no library call on the keyframe path.
+// Two kernels, each ONE launch per cloud:
+//   vg_small_kernel  clouds of <= 4096 points (every keyframe cloud of the reference's pipeline): one workgroup -- min / max,
+//                    setup, voxel keys, a bitonic sort of (voxel index << 32 | input index) in LDS, heads, scan, centroids;
+//   vg_coop_kernel   anything larger (the 51-keyframe submaps of loop verification, the map cloud), and up to TWO clouds per
+//                    launch: a persistent kernel of <= 128 workgroups per cloud that meet at grid barriers
+//                    (rsx_grid_dev.h).  An optional rigid transform (local2global, PGO.cpp:199-220) is applied to every
+//                    point as it is read, so "transform the submap, then VoxelGrid it" is one pass over the store:
+//        min / max / count of the finite points (per-workgroup partials, every workgroup reduces them: deterministic)
+//        setup (float ops as PCL; every workgroup computes it for itself)
+//        LSD radix sort of (voxel index, input index), 8 bits a pass, only as many passes as the grid's volume has bits:
+//        per-workgroup digit counts -> barrier -> every workgroup scans the counts it needs -> stable scatter (wavefronts
+//        walk their sub-tiles in order; ranks inside a 64-element chunk by eight ballots) -> barrier.  Stable, so a voxel's
+//        points stay in input order -- the order their floats are added in.
+//        heads -> per-workgroup counts -> barrier -> output slots; the thread of a voxel's first point sums its points
+//   Rounds 1-4 ran this as 14 launches around two rocPRIM calls (radix_sort_pairs, exclusive_scan) and a host
+//   synchronisation for the count; the count now stays on the device for whoever runs next (icp.hip).
 #include <hip/hip_runtime.h>
-
-#include <cstring>  // rocprim's texture_cache_iterator.hpp uses memset without including it
-
-#include <rocprim/rocprim.hpp>
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <mutex>
 #include <new>
 
 #include "rsx_common.h"
+#include "rsx_grid_dev.h"
 #include "voxelgrid.h"
 
 namespace {
@@ -53,132 +56,6 @@ __device__ __forceinline__ float dec(unsigned u) {
   return __uint_as_float(u);
 }
 __device__ __forceinline__ bool finite3(const float *p) { return isfinite(p[0]) && isfinite(p[1]) && isfinite(p[2]); }
-
-__global__ __launch_bounds__(256) void vg_init(VgParams *P) {
-  if (threadIdx.x == 0) {
-    for (int c = 0; c < 3; c++) {
-      P->mn[c] = enc(INFINITY);
-      P->mx[c] = enc(-INFINITY);
-    }
-    P->nvalid = 0;
-    P->overflow = 0;
-    P->n_out = 0;
-  }
-}
-
-__global__ __launch_bounds__(256) void vg_minmax(const char *__restrict__ pts, int64_t n, int64_t stride, VgParams *P) {
-  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-  unsigned long long cnt = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const float *p = reinterpret_cast<const float *>(pts + i * stride);
-    if (!finite3(p)) continue;
-    for (int c = 0; c < 3; c++) {
-      mn[c] = fminf(mn[c], p[c]);
-      mx[c] = fmaxf(mx[c], p[c]);
-    }
-    cnt++;
-  }
-  for (int o = 32; o >= 1; o >>= 1) {
-    for (int c = 0; c < 3; c++) {
-      mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
-      mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
-    }
-    cnt += __shfl_xor(cnt, o);
-  }
-  if ((threadIdx.x & 63) == 0 && cnt) {
-    for (int c = 0; c < 3; c++) {
-      atomicMin(&P->mn[c], enc(mn[c]));
-      atomicMax(&P->mx[c], enc(mx[c]));
-    }
-    atomicAdd(&P->nvalid, cnt);
-  }
-}
-
-__global__ void vg_setup(VgParams *P, float leaf, int64_t n) {
-  if (threadIdx.x || blockIdx.x) return;
-  if (P->nvalid == 0) {
-    P->n_out = 0;
-    return;
-  }
-  const float inv = __fdiv_rn(1.0f, leaf);
-  P->inv = inv;
-  long long d[3];
-  float mn[3], mx[3];
-  for (int c = 0; c < 3; c++) {
-    mn[c] = dec(P->mn[c]);
-    mx[c] = dec(P->mx[c]);
-    d[c] = (long long)(__fmul_rn(__fsub_rn(mx[c], mn[c]), inv)) + 1;
-  }
-  if (d[0] * d[1] * d[2] > 2147483647ll) {  // "Leaf size is too small for the input dataset"
-    P->overflow = 1;
-    P->n_out = n;
-    return;
-  }
-  int div_b[3];
-  for (int c = 0; c < 3; c++) {
-    P->min_b[c] = (int)floorf(__fmul_rn(mn[c], inv));
-    div_b[c] = (int)floorf(__fmul_rn(mx[c], inv)) - P->min_b[c] + 1;
-  }
-  P->mul[0] = 1;
-  P->mul[1] = div_b[0];
-  P->mul[2] = div_b[0] * div_b[1];
-}
-
-__global__ __launch_bounds__(256) void vg_keys(const char *__restrict__ pts, int64_t n, int64_t stride, const VgParams *P,
-                                               unsigned *__restrict__ keys, unsigned *__restrict__ vals) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const float *p = reinterpret_cast<const float *>(pts + i * stride);
-  unsigned key = 0xffffffffu;
-  if (finite3(p) && !P->overflow) {
-    int idx = 0;
-    for (int c = 0; c < 3; c++) idx += (int)(__fsub_rn(floorf(__fmul_rn(p[c], P->inv)), (float)P->min_b[c])) * P->mul[c];
-    key = (unsigned)idx;
-  }
-  keys[i] = key;
-  vals[i] = (unsigned)i;
-}
-
-__global__ __launch_bounds__(256) void vg_heads(const unsigned *__restrict__ keys, int64_t n, unsigned *__restrict__ flags) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const unsigned k = keys[i];
-  flags[i] = (k != 0xffffffffu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
-}
-
-__global__ __launch_bounds__(256) void vg_centroids(const char *__restrict__ pts, int64_t n, int64_t stride, int ioff,
-                                                    const unsigned *__restrict__ keys, const unsigned *__restrict__ vals,
-                                                    const unsigned *__restrict__ flags, const unsigned *__restrict__ pos,
-                                                    float4 *__restrict__ out, int64_t max_out, VgParams *P) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  if (i == n - 1 && !P->overflow) P->n_out = (long long)pos[i] + flags[i];
-  if (!flags[i]) return;
-  const unsigned k = keys[i];
-  float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-  int64_t j = i;
-  for (; j < n && keys[j] == k; j++) {
-    const char *q = pts + (int64_t)vals[j] * stride;
-    const float *p = reinterpret_cast<const float *>(q);
-    s0 = __fadd_rn(s0, p[0]);
-    s1 = __fadd_rn(s1, p[1]);
-    s2 = __fadd_rn(s2, p[2]);
-    if (ioff >= 0) s3 = __fadd_rn(s3, *reinterpret_cast<const float *>(q + ioff));
-  }
-  const float cnt = (float)(j - i);
-  const unsigned o = pos[i];
-  if ((int64_t)o < max_out) out[o] = make_float4(__fdiv_rn(s0, cnt), __fdiv_rn(s1, cnt), __fdiv_rn(s2, cnt), __fdiv_rn(s3, cnt));
-}
-
-// overflow path: output = input (packed), non-finite points included, input order
-__global__ __launch_bounds__(256) void vg_copy(const char *__restrict__ pts, int64_t n, int64_t stride, int ioff,
-                                               const VgParams *P, float4 *__restrict__ out, int64_t max_out) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || i >= max_out || !P->overflow) return;
-  const char *q = pts + i * stride;
-  const float *p = reinterpret_cast<const float *>(q);
-  out[i] = make_float4(p[0], p[1], p[2], ioff >= 0 ? *reinterpret_cast<const float *>(q + ioff) : 0.0f);
-}
 
 // ------------------------------------------------------------------------------------------
 // Clouds of up to VG_SMALL_MAX points (a keyframe cloud is ~10^3): the whole chain in ONE workgroup and one launch --
@@ -366,13 +243,382 @@ __global__ __launch_bounds__(VG_SMALL_NT) void vg_small_kernel(const char *__res
   }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// vg_coop_kernel: one or two clouds, any size, one launch (file header).
+// ------------------------------------------------------------------------------------------
+constexpr int CO_NT = 256;   // threads per workgroup: four wavefronts, each walks a quarter of the workgroup's tile in order
+constexpr int CO_MAX_W = 128;  // workgroups per cloud
+
+struct CoJob {
+  const char *pts;  // float x, y, z at byte offsets 0, 4, 8 of each stride, intensity at ioff (< 0: none)
+  long long n, stride;
+  int ioff, has_T;
+  rsx::vg::Mat34 T;  // applied to every point as it is read (has_T)
+  float leaf;
+  long long max_out;
+  float4 *out;
+  VgParams *P;
+  unsigned *keys0, *keys1, *vals0, *vals1;  // n each: the sort's two buffers
+  unsigned *hist;                            // [256][W] digit counts of the workgroups
+  unsigned *part;                            // [W][8]: min x y z, max x y z (encoded), finite points, heads
+  unsigned *bar;                             // grid barrier counters of this cloud (rsx_grid_dev.h)
+  int wg_first, W;
+};
+
+struct CoShared {
+  VgParams sp;
+  unsigned invalid_key;  // key of a non-finite point: above every voxel index
+  int passes;
+};
+
+__device__ __forceinline__ float4 co_point(const CoJob &J, long long i) {
+  const char *q = J.pts + i * J.stride;
+  const float *p = reinterpret_cast<const float *>(q);
+  const float4 v = make_float4(p[0], p[1], p[2], J.ioff >= 0 ? *reinterpret_cast<const float *>(q + J.ioff) : 0.0f);
+  if (!J.has_T) return v;
+  // local2global (PGO.cpp:210-217): every product and sum in float, left to right, no contraction
+  const float *m = J.T.m;
+  float4 o;
+  o.x = m[0] * v.x + m[1] * v.y + m[2] * v.z + m[3];
+  o.y = m[4] * v.x + m[5] * v.y + m[6] * v.z + m[7];
+  o.z = m[8] * v.x + m[9] * v.y + m[10] * v.z + m[11];
+  o.w = v.w;
+  return o;
+}
+__device__ __forceinline__ bool co_finite(const float4 &p) { return isfinite(p.x) && isfinite(p.y) && isfinite(p.z); }
+__device__ __forceinline__ unsigned co_key(const CoShared &S, const float4 &p) {
+  if (!co_finite(p)) return S.invalid_key;
+  const VgParams &sp = S.sp;
+  int idx = (int)(__fsub_rn(floorf(__fmul_rn(p.x, sp.inv)), (float)sp.min_b[0])) * sp.mul[0];
+  idx += (int)(__fsub_rn(floorf(__fmul_rn(p.y, sp.inv)), (float)sp.min_b[1])) * sp.mul[1];
+  idx += (int)(__fsub_rn(floorf(__fmul_rn(p.z, sp.inv)), (float)sp.min_b[2])) * sp.mul[2];
+  return (unsigned)idx;
+}
+
+__device__ void co_run(const CoJob &J, unsigned wg) {
+  using namespace rsx;
+  __shared__ CoShared S;
+  __shared__ unsigned s_wh[4][256];  // digit counts of the four wavefronts, then their running output positions
+  __shared__ unsigned s_red[8][4];
+  __shared__ unsigned s_w4[4];
+  __shared__ unsigned s_tmp[CO_MAX_W];
+  __shared__ unsigned s_base, s_total;
+  grid::Member m{J.bar, wg, (unsigned)J.W, 0u};
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const long long n = J.n;
+  const long long per = ((n + J.W - 1) / J.W + CO_NT - 1) / CO_NT * CO_NT;  // the workgroup's tile, a multiple of 256
+  const long long lo = (long long)wg * per < n ? (long long)wg * per : n, hi = lo + per < n ? lo + per : n;
+  const long long sub = per / 4;                                          // a wavefront's share, a multiple of 64
+  const long long wlo = lo + w * sub < hi ? lo + w * sub : hi, whi = wlo + sub < hi ? wlo + sub : hi;
+  // ---- min / max / count of the finite points: per-workgroup partials ----
+  {
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    unsigned cnt = 0;
+    for (long long i = lo + t; i < hi; i += CO_NT) {
+      const float4 p = co_point(J, i);
+      if (!co_finite(p)) continue;
+      mn[0] = fminf(mn[0], p.x);
+      mn[1] = fminf(mn[1], p.y);
+      mn[2] = fminf(mn[2], p.z);
+      mx[0] = fmaxf(mx[0], p.x);
+      mx[1] = fmaxf(mx[1], p.y);
+      mx[2] = fmaxf(mx[2], p.z);
+      cnt++;
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+      for (int c = 0; c < 3; c++) {
+        mn[c] = fminf(mn[c], __shfl_xor(mn[c], o));
+        mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o));
+      }
+      cnt += __shfl_xor(cnt, o);
+    }
+    if (lane == 0) {
+      for (int c = 0; c < 3; c++) {
+        s_red[c][w] = enc(mn[c]);
+        s_red[3 + c][w] = enc(mx[c]);
+      }
+      s_red[6][w] = cnt;
+    }
+    __syncthreads();
+    if (t < 7) {
+      unsigned v = s_red[t][0];
+      for (int ww = 1; ww < 4; ww++) v = t < 3 ? (s_red[t][ww] < v ? s_red[t][ww] : v) : (t < 6 ? (s_red[t][ww] > v ? s_red[t][ww] : v) : v + s_red[t][ww]);
+      grid::st(J.part + (size_t)wg * 8 + t, v);
+    }
+  }
+  grid::sync(m);
+  // ---- setup: every workgroup reduces the partials and computes the grid for itself (vg_setup's float operations) ----
+  if (t == 0) {
+    VgParams sp;
+    unsigned long long nv = 0;
+    for (int c = 0; c < 3; c++) {
+      sp.mn[c] = enc(INFINITY);
+      sp.mx[c] = enc(-INFINITY);
+    }
+    for (int g = 0; g < J.W; g++) {
+      for (int c = 0; c < 3; c++) {
+        const unsigned a = grid::ld(J.part + (size_t)g * 8 + c), b = grid::ld(J.part + (size_t)g * 8 + 3 + c);
+        sp.mn[c] = a < sp.mn[c] ? a : sp.mn[c];
+        sp.mx[c] = b > sp.mx[c] ? b : sp.mx[c];
+      }
+      nv += grid::ld(J.part + (size_t)g * 8 + 6);
+    }
+    sp.nvalid = nv;
+    sp.overflow = 0;
+    sp.n_out = 0;
+    sp.inv = 0.0f;
+    for (int c = 0; c < 3; c++) sp.min_b[c] = sp.mul[c] = 0;
+    unsigned invalid = 1u;
+    int passes = 1;
+    if (nv) {
+      const float inv = __fdiv_rn(1.0f, J.leaf);
+      sp.inv = inv;
+      long long d[3];
+      float fmn[3], fmx[3];
+      for (int c = 0; c < 3; c++) {
+        fmn[c] = dec(sp.mn[c]);
+        fmx[c] = dec(sp.mx[c]);
+        d[c] = (long long)(__fmul_rn(__fsub_rn(fmx[c], fmn[c]), inv)) + 1;
+      }
+      if (d[0] * d[1] * d[2] > 2147483647ll) {  // "Leaf size is too small for the input dataset"
+        sp.overflow = 1;
+        sp.n_out = n;
+      } else {
+        long long div_b[3];
+        for (int c = 0; c < 3; c++) {
+          sp.min_b[c] = (int)floorf(__fmul_rn(fmn[c], inv));
+          div_b[c] = (long long)((int)floorf(__fmul_rn(fmx[c], inv)) - sp.min_b[c] + 1);
+        }
+        sp.mul[0] = 1;
+        sp.mul[1] = (int)div_b[0];
+        sp.mul[2] = (int)(div_b[0] * div_b[1]);
+        long long vol = div_b[0] * div_b[1] * div_b[2];  // voxel indices are < vol
+        if (vol < 1) vol = 1;
+        int nbits = 0;
+        while (nbits < 31 && ((long long)1 << nbits) < vol) nbits++;
+        invalid = 1u << nbits;  // >= vol: above every voxel index
+        passes = (nbits + 1 + 7) / 8;
+      }
+    }
+    S.sp = sp;
+    S.invalid_key = invalid;
+    S.passes = passes;
+  }
+  __syncthreads();
+  if (S.sp.nvalid == 0 || S.sp.overflow) {
+    if (S.sp.overflow)  // output = input (packed), non-finite points included, input order
+      for (long long i = lo + t; i < hi && i < J.max_out; i += CO_NT) J.out[i] = co_point(J, i);
+    if (wg == 0 && t == 0) *J.P = S.sp;
+    grid::exit(m);
+    return;
+  }
+  // ---- LSD radix sort of (voxel index, input index), 8 bits a pass ----
+  // A wavefront's share of up to CO_CH chunks of 64 elements (clouds of up to ~260 000 points) is read ONCE per pass, all
+  // loads in flight together, and kept in registers for the count and the scatter; larger shares are read chunk by chunk,
+  // twice.  (First build: chunk by chunk for everyone -- a memory round trip per chunk and phase, 30 us a pass.)
+  constexpr int CO_CH = 8;
+  const bool cached = sub <= (long long)CO_CH * 64;  // (the same for every workgroup of the cloud)
+  const int passes = S.passes;
+  for (int p = 0; p < passes; p++) {
+    const int shift = 8 * p;
+    const unsigned *kin = (p & 1) ? J.keys0 : J.keys1, *vin = (p & 1) ? J.vals0 : J.vals1;  // pass p reads what pass p - 1 wrote
+    unsigned *kout = (p & 1) ? J.keys1 : J.keys0, *vout = (p & 1) ? J.vals1 : J.vals0;
+    auto fetch = [&](long long e, unsigned &key, unsigned &val) {
+      key = p == 0 ? co_key(S, co_point(J, e)) : grid::ld(kin + e);
+      val = p == 0 ? (unsigned)e : grid::ld(vin + e);
+    };
+    unsigned rk[CO_CH], rv[CO_CH];
+    for (int i = t; i < 4 * 256; i += CO_NT) (&s_wh[0][0])[i] = 0u;
+    if (cached) {
+#pragma unroll
+      for (int c = 0; c < CO_CH; c++) {
+        const long long e = wlo + c * 64 + lane;
+        rk[c] = rv[c] = 0u;
+        if (e < whi) fetch(e, rk[c], rv[c]);
+      }
+    }
+    __syncthreads();
+    if (cached) {
+#pragma unroll
+      for (int c = 0; c < CO_CH; c++)
+        if (wlo + c * 64 + lane < whi) atomicAdd(&s_wh[w][(rk[c] >> shift) & 255u], 1u);
+    } else {
+      for (long long e0 = wlo; e0 < whi; e0 += 64) {
+        const long long e = e0 + lane;
+        if (e < whi) {
+          unsigned key, val;
+          fetch(e, key, val);
+          atomicAdd(&s_wh[w][(key >> shift) & 255u], 1u);
+        }
+      }
+    }
+    __syncthreads();
+    grid::st(J.hist + (size_t)t * J.W + wg, s_wh[0][t] + s_wh[1][t] + s_wh[2][t] + s_wh[3][t]);
+    grid::sync(m);
+    {  // where digit t of this workgroup starts: all smaller digits of everyone, digit t of the workgroups before
+      unsigned before = 0, total = 0;
+      for (int g = 0; g < J.W; g++) {
+        const unsigned v = grid::ld(J.hist + (size_t)t * J.W + g);
+        total += v;
+        before += g < (int)wg ? v : 0u;
+      }
+      unsigned incl = total;
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      if (lane == 63) s_w4[w] = incl;
+      __syncthreads();
+      unsigned base = incl - total + before;
+      for (int ww = 0; ww < w; ww++) base += s_w4[ww];
+      for (int ww = 0; ww < 4; ww++) {
+        const unsigned c = s_wh[ww][t];
+        s_wh[ww][t] = base;
+        base += c;
+      }
+    }
+    __syncthreads();
+    // the wavefront's elements in order, 64 at a time: ranks inside a chunk by eight ballots, the chunk's first element of a
+    // digit moves that digit's position on
+    auto scatter = [&](bool active, unsigned key, unsigned val) {
+      const unsigned digit = (key >> shift) & 255u;
+      unsigned long long peers = __ballot(active);
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        const bool one = (digit >> bit) & 1u;
+        const unsigned long long bal = __ballot(active && one);
+        peers &= one ? bal : ~bal;
+      }
+      unsigned base = 0;
+      if (active) base = s_wh[w][digit];
+      __builtin_amdgcn_wave_barrier();
+      const unsigned long long below = peers & ((1ull << lane) - 1ull);
+      if (active && below == 0ull) s_wh[w][digit] = base + (unsigned)__popcll(peers);
+      __builtin_amdgcn_wave_barrier();
+      if (active) {
+        const unsigned dst = base + (unsigned)__popcll(below);
+        grid::st(kout + dst, key);
+        grid::st(vout + dst, val);
+      }
+    };
+    if (cached) {
+#pragma unroll
+      for (int c = 0; c < CO_CH; c++)
+        if (wlo + c * 64 < whi) scatter(wlo + c * 64 + lane < whi, rk[c], rv[c]);  // (uniform)
+    } else {
+      for (long long e0 = wlo; e0 < whi; e0 += 64) {
+        const long long e = e0 + lane;
+        unsigned key = 0, val = 0;
+        if (e < whi) fetch(e, key, val);
+        scatter(e < whi, key, val);
+      }
+    }
+    grid::sync(m);
+  }
+  const unsigned *K = ((passes - 1) & 1) ? J.keys1 : J.keys0, *V = ((passes - 1) & 1) ? J.vals1 : J.vals0;
+  // ---- heads: the first point of every voxel; their number per workgroup -> output slots ----
+  auto head_of = [&](long long e) -> bool {
+    const unsigned k = grid::ld(K + e);
+    return k != S.invalid_key && (e == 0 || grid::ld(K + e - 1) != k);
+  };
+  unsigned long long hb[CO_CH];  // (cached) the chunks' head masks
+  {
+    unsigned cnt = 0;
+    if (cached) {
+      unsigned k0[CO_CH], k1[CO_CH];
+#pragma unroll
+      for (int c = 0; c < CO_CH; c++) {
+        const long long e = wlo + c * 64 + lane;
+        k0[c] = k1[c] = S.invalid_key;
+        if (e < whi) {
+          k0[c] = grid::ld(K + e);
+          if (e > 0) k1[c] = grid::ld(K + e - 1);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < CO_CH; c++) {
+        const long long e = wlo + c * 64 + lane;
+        hb[c] = __ballot(e < whi && k0[c] != S.invalid_key && (e == 0 || k1[c] != k0[c]));
+        cnt += (unsigned)__popcll(hb[c]);
+      }
+    } else {
+      for (long long e0 = wlo; e0 < whi; e0 += 64) {
+        const long long e = e0 + lane;
+        cnt += (unsigned)__popcll(__ballot(e < whi && head_of(e)));
+      }
+    }
+    if (lane == 0) s_w4[w] = cnt;
+    __syncthreads();
+    if (t == 0) grid::st(J.part + (size_t)wg * 8 + 7, s_w4[0] + s_w4[1] + s_w4[2] + s_w4[3]);
+  }
+  grid::sync(m);
+  if (t < J.W) s_tmp[t] = grid::ld(J.part + (size_t)t * 8 + 7);
+  __syncthreads();
+  if (t == 0) {
+    unsigned b = 0, tot = 0;
+    for (int g = 0; g < J.W; g++) {
+      if (g == (int)wg) b = tot;
+      tot += s_tmp[g];
+    }
+    s_base = b;
+    s_total = tot;
+  }
+  __syncthreads();
+  {
+    unsigned pos = s_base;
+    for (int ww = 0; ww < w; ww++) pos += s_w4[ww];
+    auto centroid = [&](long long e, bool head, unsigned long long bal) {  // the thread of a voxel's first point sums its points in input order
+      if (head) {
+        const unsigned o = pos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        const unsigned k = grid::ld(K + e);
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        long long j = e;
+        for (; j < n && grid::ld(K + j) == k; j++) {
+          const float4 q = co_point(J, (long long)grid::ld(V + j));
+          s0 = __fadd_rn(s0, q.x);
+          s1 = __fadd_rn(s1, q.y);
+          s2 = __fadd_rn(s2, q.z);
+          if (J.ioff >= 0) s3 = __fadd_rn(s3, q.w);
+        }
+        const float c = (float)(j - e);
+        if ((long long)o < J.max_out) J.out[o] = make_float4(__fdiv_rn(s0, c), __fdiv_rn(s1, c), __fdiv_rn(s2, c), __fdiv_rn(s3, c));
+      }
+      pos += (unsigned)__popcll(bal);
+    };
+    if (cached) {
+#pragma unroll
+      for (int c = 0; c < CO_CH; c++)
+        if (wlo + c * 64 < whi) centroid(wlo + c * 64 + lane, (hb[c] >> lane) & 1ull, hb[c]);
+    } else {
+      for (long long e0 = wlo; e0 < whi; e0 += 64) {
+        const long long e = e0 + lane;
+        const bool head = e < whi && head_of(e);
+        centroid(e, head, __ballot(head));
+      }
+    }
+  }
+  if (wg == 0 && t == 0) {
+    S.sp.n_out = (long long)s_total;
+    *J.P = S.sp;
+  }
+  grid::exit(m);
+}
+
+__global__ __launch_bounds__(CO_NT) void vg_coop_kernel(CoJob a, CoJob b) {
+  if ((int)blockIdx.x < a.W)
+    co_run(a, blockIdx.x);
+  else
+    co_run(b, blockIdx.x - (unsigned)a.W);
+}
+
 }  // namespace
 
 struct rsx_voxelgrid {
   int device = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf pts, keys, keys2, vals, vals2, flags, pos, out, params, temp;
+  rsx::DevBuf pts, keys, keys2, vals, vals2, hist, part, bar, out, params;
 };
 
 using rsx::fail;
@@ -380,56 +626,92 @@ using rsx::fail;
 namespace rsx {
 namespace vg {
 
+namespace {
+
+int workgroups_for(int64_t n) {
+  const int64_t w = (n + 1023) / 1024;
+  return (int)(w < 1 ? 1 : (w > CO_MAX_W ? CO_MAX_W : w));
+}
+
+// buffers of one cloud's job; the barrier counters are zeroed when the buffer is first allocated (the kernel leaves them zero)
+int prepare_job(rsx_voxelgrid *h, const void *d_pts, int64_t n, int64_t stride, int32_t ioff, const Mat34 *T, float leaf, int64_t max_out,
+                hipStream_t s, CoJob *J) {
+  if (n > 0x7fffffff) return fail(RSX_ERR_RANGE, "more than 2^31-1 points");
+  const int W = workgroups_for(n);
+  RSX_TRY(h->params.reserve(sizeof(VgParams), s, false));
+  RSX_TRY(h->keys.reserve((size_t)n * 4 + 16, s, false));
+  RSX_TRY(h->keys2.reserve((size_t)n * 4 + 16, s, false));
+  RSX_TRY(h->vals.reserve((size_t)n * 4 + 16, s, false));
+  RSX_TRY(h->vals2.reserve((size_t)n * 4 + 16, s, false));
+  RSX_TRY(h->hist.reserve((size_t)256 * CO_MAX_W * 4, s, false));
+  RSX_TRY(h->part.reserve((size_t)CO_MAX_W * 8 * 4, s, false));
+  RSX_TRY(h->out.reserve((size_t)(max_out > 0 ? max_out : 1) * 16, s, false));
+  if (!h->bar.p) {
+    RSX_TRY(h->bar.reserve(rsx::grid::BYTES, s, false));
+    RSX_HIP(hipMemsetAsync(h->bar.p, 0, rsx::grid::BYTES, s));
+  }
+  J->pts = static_cast<const char *>(d_pts);
+  J->n = n;
+  J->stride = stride;
+  J->ioff = (int)ioff;
+  J->has_T = T ? 1 : 0;
+  if (T) J->T = *T;
+  else std::memset(&J->T, 0, sizeof(J->T));
+  J->leaf = leaf;
+  J->max_out = max_out;
+  J->out = h->out.as<float4>();
+  J->P = h->params.as<VgParams>();
+  J->keys0 = h->keys.as<unsigned>();
+  J->keys1 = h->keys2.as<unsigned>();
+  J->vals0 = h->vals.as<unsigned>();
+  J->vals1 = h->vals2.as<unsigned>();
+  J->hist = h->hist.as<unsigned>();
+  J->part = h->part.as<unsigned>();
+  J->bar = h->bar.as<unsigned>();
+  J->wg_first = 0;
+  J->W = W;
+  return RSX_OK;
+}
+
+}  // namespace
+
+int enqueue(const JobIn *jobs, int njobs, hipStream_t s, DeviceCloud *out) {
+  if (njobs < 1 || njobs > 2) return fail(RSX_ERR_BAD_ARG, "one or two clouds per launch");
+  CoJob J[2];
+  std::memset(J, 0, sizeof(J));
+  for (int k = 0; k < njobs; k++) {
+    const JobIn &in = jobs[k];
+    if (in.n <= 0) return fail(RSX_ERR_BAD_ARG, "empty cloud");
+    RSX_TRY(prepare_job(in.h, in.d_pts, in.n, in.stride, in.ioff, in.T, in.leaf, in.max_out, s, &J[k]));
+    out[k].d_out = in.h->out.as<float>();
+    out[k].d_count = &in.h->params.as<VgParams>()->n_out;
+  }
+  if (njobs == 2) J[1].wg_first = J[0].W;
+  hipLaunchKernelGGL(vg_coop_kernel, dim3((unsigned)(J[0].W + J[1].W)), dim3(CO_NT), 0, s, J[0], J[1]);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
 int filter_device(rsx_voxelgrid *h, const void *d_pts, int64_t n, int64_t stride, int32_t ioff, float leaf, int64_t max_out,
                   const float **d_out, int64_t *n_out, hipStream_t s) {
   *d_out = nullptr;
   *n_out = 0;
   if (n <= 0) return RSX_OK;
   if (n > 0x7fffffff) return fail(RSX_ERR_RANGE, "more than 2^31-1 points");
-  RSX_TRY(h->params.reserve(sizeof(VgParams), s, false));
-  RSX_TRY(h->keys.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->keys2.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->vals.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->vals2.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->flags.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->pos.reserve((size_t)n * 4, s, false));
-  RSX_TRY(h->out.reserve((size_t)(max_out > 0 ? max_out : 1) * 16, s, false));
-  VgParams *P = h->params.as<VgParams>();
   const char *pts = static_cast<const char *>(d_pts);
-  if (n <= VG_SMALL_MAX) {  // a keyframe cloud: one workgroup, one launch (the large path below is 14)
+  if (n <= VG_SMALL_MAX) {  // a keyframe cloud: one workgroup
+    RSX_TRY(h->params.reserve(sizeof(VgParams), s, false));
+    RSX_TRY(h->out.reserve((size_t)(max_out > 0 ? max_out : 1) * 16, s, false));
     hipLaunchKernelGGL(vg_small_kernel, dim3(1), dim3(VG_SMALL_NT), 0, s, pts, (int)n, stride, (int)ioff, leaf, h->out.as<float4>(),
-                       max_out, P);
+                       max_out, h->params.as<VgParams>());
     RSX_HIP(hipGetLastError());
-    long long cnt = 0;
-    RSX_HIP(hipMemcpyAsync(&cnt, &P->n_out, sizeof(cnt), hipMemcpyDeviceToHost, s));
-    RSX_HIP(hipStreamSynchronize(s));
-    *d_out = h->out.as<float>();
-    *n_out = cnt;
-    return RSX_OK;
+  } else {
+    JobIn in{h, d_pts, n, stride, ioff, nullptr, leaf, max_out};
+    DeviceCloud dc;
+    RSX_TRY(enqueue(&in, 1, s, &dc));
   }
-  const unsigned nb = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(vg_init, dim3(1), dim3(64), 0, s, P);
-  hipLaunchKernelGGL(vg_minmax, dim3(nb < 1024 ? nb : 1024), dim3(256), 0, s, pts, n, stride, P);
-  hipLaunchKernelGGL(vg_setup, dim3(1), dim3(64), 0, s, P, leaf, n);
-  hipLaunchKernelGGL(vg_keys, dim3(nb), dim3(256), 0, s, pts, n, stride, P, h->keys.as<unsigned>(), h->vals.as<unsigned>());
-  RSX_HIP(hipGetLastError());
-  size_t tb1 = 0, tb2 = 0;
-  RSX_HIP(rocprim::radix_sort_pairs(nullptr, tb1, h->keys.as<unsigned>(), h->keys2.as<unsigned>(), h->vals.as<unsigned>(),
-                                    h->vals2.as<unsigned>(), (size_t)n, 0, 32, s));
-  RSX_HIP(rocprim::exclusive_scan(nullptr, tb2, h->flags.as<unsigned>(), h->pos.as<unsigned>(), 0u, (size_t)n,
-                                  rocprim::plus<unsigned>(), s));
-  RSX_TRY(h->temp.reserve(tb1 > tb2 ? tb1 : tb2, s, false));
-  RSX_HIP(rocprim::radix_sort_pairs(h->temp.p, tb1, h->keys.as<unsigned>(), h->keys2.as<unsigned>(), h->vals.as<unsigned>(),
-                                    h->vals2.as<unsigned>(), (size_t)n, 0, 32, s));
-  hipLaunchKernelGGL(vg_heads, dim3(nb), dim3(256), 0, s, h->keys2.as<unsigned>(), n, h->flags.as<unsigned>());
-  RSX_HIP(rocprim::exclusive_scan(h->temp.p, tb2, h->flags.as<unsigned>(), h->pos.as<unsigned>(), 0u, (size_t)n,
-                                  rocprim::plus<unsigned>(), s));
-  hipLaunchKernelGGL(vg_centroids, dim3(nb), dim3(256), 0, s, pts, n, stride, (int)ioff, h->keys2.as<unsigned>(),
-                     h->vals2.as<unsigned>(), h->flags.as<unsigned>(), h->pos.as<unsigned>(), h->out.as<float4>(), max_out, P);
-  hipLaunchKernelGGL(vg_copy, dim3(nb), dim3(256), 0, s, pts, n, stride, (int)ioff, P, h->out.as<float4>(), max_out);
-  RSX_HIP(hipGetLastError());
   long long cnt = 0;
-  RSX_HIP(hipMemcpyAsync(&cnt, &P->n_out, sizeof(cnt), hipMemcpyDeviceToHost, s));
+  RSX_HIP(hipMemcpyAsync(&cnt, &h->params.as<VgParams>()->n_out, sizeof(cnt), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
   *d_out = h->out.as<float>();
   *n_out = cnt;
@@ -479,7 +761,7 @@ int rsx_voxelgrid_destroy(rsx_voxelgrid *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (rsx::DevBuf *b : {&h->pts, &h->keys, &h->keys2, &h->vals, &h->vals2, &h->flags, &h->pos, &h->out, &h->params, &h->temp})
+  for (rsx::DevBuf *b : {&h->pts, &h->keys, &h->keys2, &h->vals, &h->vals2, &h->hist, &h->part, &h->bar, &h->out, &h->params})
     b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;

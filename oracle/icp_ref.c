@@ -27,6 +27,14 @@
  * kd-tree, also exact) with ties broken by the lower target index; sums run in ascending index order
  * in float; the 3x3 SVD is a cyclic Jacobi eigen-decomposition of H^T H in double (PCL: Eigen
  * JacobiSVD in float).  Poses therefore agree with PCL to float round-off, not bit for bit.
+ *
+ * sum_order = ICPREF_SUM_TREE restates the ORDER in which the device kernel (csrc/icp.hip, round 5) adds: the moments
+ * in double, correspondence i into partial sum i mod 1024 in ascending i, the partial sums l, l + 64, ... one after the other,
+ * the 64 results as a balanced tree (neighbours first); means = (float)(sum / n), covariance terms = the float product of the float differences, added in
+ * double in the same order, H = (double)(float)sum / n.  Neither order is PCL's (Eigen's vectorised float sums); the +-25
+ * submap of the reference is full of nearly tied nearest neighbours, a last-bit difference in a step flips one of them, and
+ * two descents that add in different orders settle a centimetre apart.  With the same order the device and this file agree
+ * to 1e-4 there too (tests/test_gpu_loopverify.py).
  */
 #include <math.h>
 #include <stdint.h>
@@ -64,7 +72,7 @@ void icpref_rotation_from_covariance(const double H[9], double R[9]) {
     }
   for (int sweep = 0; sweep < 60; sweep++) {
     const double off = fabs(A[1]) + fabs(A[2]) + fabs(A[5]);
-    if (off < 1e-300) break;
+    if (off <= 1e-22 * (fabs(A[0]) + fabs(A[4]) + fabs(A[8]))) break; /* below 2^-53 of the diagonal a rotation changes nothing */
     for (int p = 0; p < 2; p++)
       for (int q = p + 1; q < 3; q++) {
         const double apq = A[3 * p + q];
@@ -156,6 +164,17 @@ static void nearest(const float *p, const float *tgt, int64_t nt, float *d2, int
   *idx = bi;
 }
 
+/* the sum of the 1024 partial sums as the device adds them: lane l the sixteen partial sums l, l + 64, ... one after the
+ * other, then the 64 lanes as a balanced tree, neighbours first */
+#define TREE_LANES 1024
+static double tree_sum(double *p) {
+  for (int l = 0; l < 64; l++)
+    for (int j = 1; j < TREE_LANES / 64; j++) p[l] += p[l + 64 * j];
+  for (int s = 1; s < 64; s <<= 1)
+    for (int j = 0; j < 64; j += 2 * s) p[j] += p[j + s];
+  return p[0];
+}
+
 /* src, tgt: packed xyz float triples.  guess: optional row-major 4x4 (NULL = identity). */
 void icpref_align(const float *src, int64_t ns, const float *tgt, int64_t nt, const icpref_params *prm, const float *guess,
                   icpref_result *out) {
@@ -183,27 +202,61 @@ void icpref_align(const float *src, int64_t ns, const float *tgt, int64_t nt, co
       break;
     }
     float ms[3] = {0, 0, 0}, md[3] = {0, 0, 0};
-    for (int64_t i = 0; i < ns; i++)
-      if (ci[i] >= 0)
-        for (int r = 0; r < 3; r++) {
-          ms[r] += cur[3 * i + r];
-          md[r] += tgt[3 * ci[i] + r];
-        }
-    for (int r = 0; r < 3; r++) {
-      ms[r] /= (float)cnt;
-      md[r] /= (float)cnt;
-    }
-    float Hf[9] = {0};
     double mse = 0.0;
-    for (int64_t i = 0; i < ns; i++)
-      if (ci[i] >= 0) {
-        for (int a = 0; a < 3; a++)
-          for (int b = 0; b < 3; b++) Hf[3 * a + b] += (tgt[3 * ci[i] + a] - md[a]) * (cur[3 * i + b] - ms[b]);
-        mse += (double)cd[i];
-      }
-    mse /= (double)cnt;
     double H[9], R[9];
-    for (int i = 0; i < 9; i++) H[i] = (double)Hf[i] / (double)cnt;
+    if (prm->sum_order == ICPREF_SUM_TREE) {
+      static double part[9][TREE_LANES];
+      memset(part, 0, sizeof(part));
+      for (int64_t i = 0; i < ns; i++)
+        if (ci[i] >= 0) {
+          const int l = (int)(i % TREE_LANES);
+          part[0][l] += 1.0;
+          for (int r = 0; r < 3; r++) {
+            part[1 + r][l] += cur[3 * i + r];
+            part[4 + r][l] += tgt[3 * ci[i] + r];
+          }
+          part[7][l] += (double)cd[i];
+        }
+      double sums[8];
+      for (int c = 0; c < 8; c++) sums[c] = tree_sum(part[c]);
+      const double n = sums[0];
+      for (int r = 0; r < 3; r++) {
+        ms[r] = (float)(sums[1 + r] / n);
+        md[r] = (float)(sums[4 + r] / n);
+      }
+      mse = sums[7] / n;
+      memset(part, 0, sizeof(part));
+      for (int64_t i = 0; i < ns; i++)
+        if (ci[i] >= 0) {
+          const int l = (int)(i % TREE_LANES);
+          for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) {
+              const float prod = (tgt[3 * ci[i] + a] - md[a]) * (cur[3 * i + b] - ms[b]);
+              part[3 * a + b][l] += (double)prod;
+            }
+        }
+      for (int c = 0; c < 9; c++) H[c] = (double)(float)tree_sum(part[c]) / n;
+    } else {
+      for (int64_t i = 0; i < ns; i++)
+        if (ci[i] >= 0)
+          for (int r = 0; r < 3; r++) {
+            ms[r] += cur[3 * i + r];
+            md[r] += tgt[3 * ci[i] + r];
+          }
+      for (int r = 0; r < 3; r++) {
+        ms[r] /= (float)cnt;
+        md[r] /= (float)cnt;
+      }
+      float Hf[9] = {0};
+      for (int64_t i = 0; i < ns; i++)
+        if (ci[i] >= 0) {
+          for (int a = 0; a < 3; a++)
+            for (int b = 0; b < 3; b++) Hf[3 * a + b] += (tgt[3 * ci[i] + a] - md[a]) * (cur[3 * i + b] - ms[b]);
+          mse += (double)cd[i];
+        }
+      mse /= (double)cnt;
+      for (int i = 0; i < 9; i++) H[i] = (double)Hf[i] / (double)cnt;
+    }
     icpref_rotation_from_covariance(H, R);
     mat4_identity(step);
     for (int a = 0; a < 3; a++) {
@@ -244,6 +297,8 @@ void icpref_align(const float *src, int64_t ns, const float *tgt, int64_t nt, co
   /* getFitnessScore(): mean squared distance of the finally transformed source to its nearest target */
   double fit = 0.0;
   int64_t nr = 0;
+  static double fpart[TREE_LANES];
+  memset(fpart, 0, sizeof(fpart));
   for (int64_t i = 0; i < ns; i++) {
     float p[3], d2;
     int64_t j;
@@ -252,9 +307,11 @@ void icpref_align(const float *src, int64_t ns, const float *tgt, int64_t nt, co
     nearest(p, tgt, nt, &d2, &j);
     if (j >= 0) {
       fit += (double)d2;
+      fpart[i % TREE_LANES] += (double)d2;
       nr++;
     }
   }
+  if (prm->sum_order == ICPREF_SUM_TREE) fit = tree_sum(fpart);
   memcpy(out->transform, final, sizeof(final));
   out->fitness = nr > 0 ? fit / (double)nr : 1.7976931348623157e308;
   out->iterations = iters;

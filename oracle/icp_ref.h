@@ -11,8 +11,10 @@ typedef struct {
   double transformation_epsilon;    /* setTransformationEpsilon(1e-6), PGO.cpp:376 */
   double euclidean_fitness_epsilon; /* setEuclideanFitnessEpsilon(1e-6), PGO.cpp:377 */
   int32_t max_iterations;           /* setMaximumIterations(100), PGO.cpp:375 */
-  int32_t reserved;
+  int32_t sum_order;                /* 0: sums in ascending index order in float (the restatement of PCL's float sums);
+                                       1: ICPREF_SUM_TREE, the order of the device kernel (icp_ref.c) */
 } icpref_params;
+enum { ICPREF_SUM_SEQUENTIAL_FLOAT = 0, ICPREF_SUM_TREE = 1 };
 
 typedef struct {
   float transform[16]; /* row-major 4x4: target <- source */

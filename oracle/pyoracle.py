@@ -369,7 +369,7 @@ class RefKdTree:
 class OroraParams(C.Structure):
     _fields_ = [("tim_noise_bound", C.c_double), ("noise_bound_radial", C.c_double),
                 ("noise_bound_tangential", C.c_double), ("gnc_factor", C.c_double),
-                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("flags", C.c_int32)]
+                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("sum_order", C.c_int32)]
 
 
 ORORA_RESULT_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("iterations", "<i4"),
@@ -462,9 +462,12 @@ def voxelgrid_filter(pts, leaf=0.4, intensity_col=3):
 # ---------------------------------------------------------------------------------------------
 # ICP loop verification (oracle/icp_ref.c) -- PARITY UNPINNED, see the header of that file
 # ---------------------------------------------------------------------------------------------
+ICP_SUM_SEQUENTIAL_FLOAT, ICP_SUM_TREE = 0, 1
+
+
 class IcpRefParams(C.Structure):
     _fields_ = [("max_corr_dist", C.c_double), ("transformation_epsilon", C.c_double),
-                ("euclidean_fitness_epsilon", C.c_double), ("max_iterations", C.c_int32), ("flags", C.c_int32)]
+                ("euclidean_fitness_epsilon", C.c_double), ("max_iterations", C.c_int32), ("sum_order", C.c_int32)]
 
 
 class IcpRefResult(C.Structure):
@@ -481,11 +484,12 @@ def icp_rotation_from_covariance(H):
 
 
 def icp_align(source, target, max_corr_dist=150.0, transformation_epsilon=1e-6, euclidean_fitness_epsilon=1e-6,
-              max_iterations=100, guess=None):
+              max_iterations=100, guess=None, sum_order=0):
+    """sum_order: ICP_SUM_SEQUENTIAL_FLOAT (0) or ICP_SUM_TREE (1, the order the device kernel adds in: icp_ref.c)"""
     L = lib()
     s = np.ascontiguousarray(np.asarray(source, dtype=np.float32)[:, :3])
     t = np.ascontiguousarray(np.asarray(target, dtype=np.float32)[:, :3])
-    p = IcpRefParams(max_corr_dist, transformation_epsilon, euclidean_fitness_epsilon, max_iterations, 0)
+    p = IcpRefParams(max_corr_dist, transformation_epsilon, euclidean_fitness_epsilon, max_iterations, sum_order)
     g = np.ascontiguousarray(guess, dtype=np.float32).reshape(16) if guess is not None else None
     r = IcpRefResult()
     L.icpref_align.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(IcpRefParams), C.c_void_p, C.POINTER(IcpRefResult)]
@@ -537,12 +541,12 @@ def loop_submap(clouds, key, submap_size, root_pose, leaf=0.4):
 
 
 def loop_verify(clouds, loop_idx, curr_idx, root_pose, history_num=25, leaf=0.4, fitness_threshold=0.3,
-                max_corr_dist=150.0, transformation_epsilon=1e-6, euclidean_fitness_epsilon=1e-6, max_iterations=100):
+                max_corr_dist=150.0, transformation_epsilon=1e-6, euclidean_fitness_epsilon=1e-6, max_iterations=100, sum_order=0):
     """doICPVirtualRelative (PGO.cpp:355-406) -> dict"""
     L = lib()
     allp, off = _kf_pack(clouds)
     rp = np.ascontiguousarray(root_pose, dtype=np.float64).reshape(6)
-    p = IcpRefParams(max_corr_dist, transformation_epsilon, euclidean_fitness_epsilon, max_iterations, 0)
+    p = IcpRefParams(max_corr_dist, transformation_epsilon, euclidean_fitness_epsilon, max_iterations, sum_order)
     r = LvRefResult()
     L.lvref_verify.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_float,
                                C.POINTER(IcpRefParams), C.c_double, C.POINTER(LvRefResult)]

@@ -72,3 +72,24 @@ def test_convergence_states(oracle):
     g[:3, 3] = [-2.0, -1.0, 0.0]
     rg = oracle.icp_align(src, tgt, guess=g)                                    # a perfect guess: converges at once
     assert rg["converged"] and rg["iterations"] <= 3 and rg["fitness"] < 1e-9
+
+
+def test_the_two_orders_of_addition(oracle):
+    """ICPREF_SUM_TREE (what the device kernel does: fp64, correspondence i into partial sum i mod 1024, a balanced tree
+    over the partial sums) against the sequential float sums: the same algorithm, so on a well-conditioned problem the same
+    pose to 1e-4 and the same verdicts -- and not the same bits, which is why the device is compared with its own order"""
+    tgt = scene(2, 6000)
+    R, t = rot(0.1, 0.01, -0.01), np.array([0.5, -0.6, 0.04])
+    rng = np.random.default_rng(2)
+    sub = tgt[rng.choice(len(tgt), 2000, replace=False)] + rng.normal(0, 0.02, (2000, 3))
+    src = ((sub - t) @ R).astype(np.float32)
+    a = oracle.icp_align(src, tgt)
+    b = oracle.icp_align(src, tgt, sum_order=oracle.ICP_SUM_TREE)
+    assert a["converged"] and b["converged"] and abs(a["iterations"] - b["iterations"]) <= 2
+    assert np.abs(a["transform"] - b["transform"]).max() < 1e-4 and abs(a["fitness"] - b["fitness"]) < 1e-4 * max(1.0, a["fitness"])
+    # fewer than 1024 correspondences, and fewer than 3: the tree has empty leaves
+    few = oracle.icp_align(src[:100], tgt, sum_order=oracle.ICP_SUM_TREE)
+    ref = oracle.icp_align(src[:100], tgt)
+    assert few["converged"] == ref["converged"] and np.abs(few["transform"] - ref["transform"]).max() < 1e-3
+    none = oracle.icp_align(src[:2], tgt, sum_order=oracle.ICP_SUM_TREE)
+    assert not none["converged"] and none["state"] == 5 and none["iterations"] == 0
