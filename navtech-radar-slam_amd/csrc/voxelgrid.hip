@@ -260,7 +260,7 @@ struct CoJob {
   float4 *out;
   VgParams *P;
   unsigned *keys0, *keys1, *vals0, *vals1;  // n each: the sort's two buffers
-  unsigned *hist;                            // [256][W] digit counts of the workgroups
+  unsigned *hist;                            // [W][256] digit counts of the workgroups (digit-minor: a wavefront's load is 256 contiguous bytes)
   unsigned *part;                            // [W][8]: min x y z, max x y z (encoded), finite points, heads
   unsigned *bar;                             // grid barrier counters of this cloud (rsx_grid_dev.h)
   int wg_first, W;
@@ -306,6 +306,18 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
   __shared__ unsigned s_base, s_total;
   grid::Member m{J.bar, wg, (unsigned)J.W, 0u};
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+#ifdef RSX_VG_TIMING
+  unsigned long long tmk[18] = {0}, tlast = wall_clock64();
+  int tmi = 0;
+#define VG_MARK()                                 \
+  {                                               \
+    const unsigned long long n_ = wall_clock64(); \
+    if (tmi < 18) tmk[tmi++] = n_ - tlast;        \
+    tlast = n_;                                   \
+  }
+#else
+#define VG_MARK()
+#endif
   const long long n = J.n;
   const long long per = ((n + J.W - 1) / J.W + CO_NT - 1) / CO_NT * CO_NT;  // the workgroup's tile, a multiple of 256
   const long long lo = (long long)wg * per < n ? (long long)wg * per : n, hi = lo + per < n ? lo + per : n;
@@ -347,22 +359,34 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
       grid::st(J.part + (size_t)wg * 8 + t, v);
     }
   }
+  VG_MARK()
   grid::sync(m);
+  VG_MARK()
   // ---- setup: every workgroup reduces the partials and computes the grid for itself (vg_setup's float operations) ----
+  // (the partials are read by W threads at once, seven loads in flight each)
+  {
+    unsigned pv[7];
+#pragma unroll
+    for (int c = 0; c < 7; c++) pv[c] = t < J.W ? grid::ld(J.part + (size_t)t * 8 + c) : (c < 3 ? enc(INFINITY) : (c < 6 ? enc(-INFINITY) : 0u));
+    if (t < 128) {  // (W <= 128: two wavefronts)
+      for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int c = 0; c < 7; c++) {
+          const unsigned x = __shfl_xor(pv[c], o);
+          pv[c] = c < 3 ? (x < pv[c] ? x : pv[c]) : (c < 6 ? (x > pv[c] ? x : pv[c]) : pv[c] + x);
+        }
+      if (lane == 0)
+#pragma unroll
+        for (int c = 0; c < 7; c++) s_red[c][w] = pv[c];
+    }
+  }
+  __syncthreads();
   if (t == 0) {
     VgParams sp;
-    unsigned long long nv = 0;
+    const unsigned long long nv = (unsigned long long)s_red[6][0] + s_red[6][1];
     for (int c = 0; c < 3; c++) {
-      sp.mn[c] = enc(INFINITY);
-      sp.mx[c] = enc(-INFINITY);
-    }
-    for (int g = 0; g < J.W; g++) {
-      for (int c = 0; c < 3; c++) {
-        const unsigned a = grid::ld(J.part + (size_t)g * 8 + c), b = grid::ld(J.part + (size_t)g * 8 + 3 + c);
-        sp.mn[c] = a < sp.mn[c] ? a : sp.mn[c];
-        sp.mx[c] = b > sp.mx[c] ? b : sp.mx[c];
-      }
-      nv += grid::ld(J.part + (size_t)g * 8 + 6);
+      sp.mn[c] = s_red[c][0] < s_red[c][1] ? s_red[c][0] : s_red[c][1];
+      sp.mx[c] = s_red[3 + c][0] > s_red[3 + c][1] ? s_red[3 + c][0] : s_red[3 + c][1];
     }
     sp.nvalid = nv;
     sp.overflow = 0;
@@ -413,6 +437,7 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
     grid::exit(m);
     return;
   }
+  VG_MARK()
   // ---- LSD radix sort of (voxel index, input index), 8 bits a pass ----
   // A wavefront's share of up to CO_CH chunks of 64 elements (clouds of up to ~260 000 points) is read ONCE per pass, all
   // loads in flight together, and kept in registers for the count and the scatter; larger shares are read chunk by chunk,
@@ -454,14 +479,22 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
       }
     }
     __syncthreads();
-    grid::st(J.hist + (size_t)t * J.W + wg, s_wh[0][t] + s_wh[1][t] + s_wh[2][t] + s_wh[3][t]);
+    grid::st(J.hist + (size_t)wg * 256 + t, s_wh[0][t] + s_wh[1][t] + s_wh[2][t] + s_wh[3][t]);
+    VG_MARK()
     grid::sync(m);
+    VG_MARK()
     {  // where digit t of this workgroup starts: all smaller digits of everyone, digit t of the workgroups before
+      // (32 loads in flight at a time: a coherent load is ~2 us, one after the other they were 17 us a pass)
       unsigned before = 0, total = 0;
-      for (int g = 0; g < J.W; g++) {
-        const unsigned v = grid::ld(J.hist + (size_t)t * J.W + g);
-        total += v;
-        before += g < (int)wg ? v : 0u;
+      for (int g0 = 0; g0 < J.W; g0 += 32) {
+        unsigned v[32];
+#pragma unroll
+        for (int u = 0; u < 32; u++) v[u] = g0 + u < J.W ? grid::ld(J.hist + (size_t)(g0 + u) * 256 + t) : 0u;
+#pragma unroll
+        for (int u = 0; u < 32; u++) {
+          total += v[u];
+          before += g0 + u < (int)wg ? v[u] : 0u;
+        }
       }
       unsigned incl = total;
       for (int o = 1; o < 64; o <<= 1) {
@@ -514,6 +547,7 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
         scatter(e < whi, key, val);
       }
     }
+    VG_MARK()
     grid::sync(m);
   }
   const unsigned *K = ((passes - 1) & 1) ? J.keys1 : J.keys0, *V = ((passes - 1) & 1) ? J.vals1 : J.vals0;
@@ -552,7 +586,9 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
     __syncthreads();
     if (t == 0) grid::st(J.part + (size_t)wg * 8 + 7, s_w4[0] + s_w4[1] + s_w4[2] + s_w4[3]);
   }
+  VG_MARK()
   grid::sync(m);
+  VG_MARK()
   if (t < J.W) s_tmp[t] = grid::ld(J.part + (size_t)t * 8 + 7);
   __syncthreads();
   if (t == 0) {
@@ -571,15 +607,35 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
     auto centroid = [&](long long e, bool head, unsigned long long bal) {  // the thread of a voxel's first point sums its points in input order
       if (head) {
         const unsigned o = pos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        // the voxel's points four at a time: the next four (key, index) pairs are requested together -- a coherent load is
+        // ~2 us, and a voxel of the 51-keyframe submap holds 2.3 points on average (one pair per round trip: 40 us of tail)
         const unsigned k = grid::ld(K + e);
         float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
         long long j = e;
-        for (; j < n && grid::ld(K + j) == k; j++) {
-          const float4 q = co_point(J, (long long)grid::ld(V + j));
-          s0 = __fadd_rn(s0, q.x);
-          s1 = __fadd_rn(s1, q.y);
-          s2 = __fadd_rn(s2, q.z);
-          if (J.ioff >= 0) s3 = __fadd_rn(s3, q.w);
+        bool more = true;
+        while (more) {
+          unsigned kk[4], vv[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const long long jj = j + u < n ? j + u : n - 1;
+            kk[u] = grid::ld(K + jj);
+            vv[u] = grid::ld(V + jj);
+          }
+          float4 q[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) q[u] = co_point(J, (long long)vv[u]);
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (more && j < n && kk[u] == k) {
+              s0 = __fadd_rn(s0, q[u].x);
+              s1 = __fadd_rn(s1, q[u].y);
+              s2 = __fadd_rn(s2, q[u].z);
+              if (J.ioff >= 0) s3 = __fadd_rn(s3, q[u].w);
+              j++;
+            } else {
+              more = false;
+            }
+          }
         }
         const float c = (float)(j - e);
         if ((long long)o < J.max_out) J.out[o] = make_float4(__fdiv_rn(s0, c), __fdiv_rn(s1, c), __fdiv_rn(s2, c), __fdiv_rn(s3, c));
@@ -598,6 +654,12 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
       }
     }
   }
+#ifdef RSX_VG_TIMING
+  VG_MARK()
+  if (wg == 0 && t == 0 && J.n > 20000)
+    printf("vg timing (10 ns): %llu %llu %llu | %llu %llu %llu %llu | %llu %llu %llu %llu | %llu %llu %llu %llu | heads %llu %llu %llu  W %d passes %d\n", tmk[0], tmk[1], tmk[2], tmk[3], tmk[4], tmk[5],
+           tmk[6], tmk[7], tmk[8], tmk[9], tmk[10], tmk[11], tmk[12], tmk[13], tmk[14], tmk[15], tmk[16], tmk[17], J.W, passes);
+#endif
   if (wg == 0 && t == 0) {
     S.sp.n_out = (long long)s_total;
     *J.P = S.sp;
