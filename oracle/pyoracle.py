@@ -369,7 +369,7 @@ class RefKdTree:
 class OroraParams(C.Structure):
     _fields_ = [("tim_noise_bound", C.c_double), ("noise_bound_radial", C.c_double),
                 ("noise_bound_tangential", C.c_double), ("gnc_factor", C.c_double),
-                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("sum_order", C.c_int32)]
+                ("cost_threshold", C.c_double), ("max_iterations", C.c_int32), ("flags", C.c_int32)]
 
 
 ORORA_RESULT_DTYPE = np.dtype([("x", "<f8"), ("y", "<f8"), ("yaw", "<f8"), ("iterations", "<i4"),
