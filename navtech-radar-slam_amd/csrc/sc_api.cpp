@@ -1468,9 +1468,15 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
     if (first < 8) first = 8;
     if (first > 128) first = 128;
     RSX_TRY(filter_reserve(h, items, nq, s));
-    // (the window previews stop at this shard's round-0 share as well: S shards previewing 128 list positions each is S
-    // times one GPU's window kernel -- the largest part of a shard's time that did not shrink with S)
-    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, k, s, elig_monotone != 0, h->p.shard_world > 1 ? first : 0));
+    // (Round 5 tried to stop the window previews at this shard's round-0 share -- S shards previewing 128 list positions each
+    // is S times one GPU's window kernel.  Stage 1 got faster and the step three times SLOWER: stage 2 re-scores candidates
+    // beyond the share, and without a window preview each of them costs a VALU preview, one entry per wavefront: emulated
+    // per-rank compute 1 x 8 on the 10 k DB 1.03 -> 5.95 ms.  RSX_SC_WINDOW_HEAD=1 (experiments build) brings it back.)
+    static const bool head_only = [] {
+      const char *e = rsx::exp_env("RSX_SC_WINDOW_HEAD");
+      return e && e[0] == '1';
+    }();
+    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, k, s, elig_monotone != 0, (head_only && h->p.shard_world > 1) ? first : 0));
     RSX_TRY(rescore(h, qv, items, n_elig, d_q_elig, 0, 1, nullptr, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));
   } else {
     RSX_TRY(run_topk(h, qv, items, n_elig, d_q_elig, k, h->st_partial.as<rsx_sc_hit>(), s, elig_monotone != 0));  // complete already
