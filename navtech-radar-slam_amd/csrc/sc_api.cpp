@@ -1306,8 +1306,17 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
   if (np == 1 && out_bytes <= 4096) {
     // the live detector's size (one query, a few records): the last kernel writes the records straight into pinned host
     // memory -- no read-back to enqueue, one synchronise
-    RSX_TRY(ensure_pinned(h, 4096));
-    RSX_HIP(hipMemcpyAsync(h->q_desc.p, q, (size_t)nq * DS * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    // ... and the query goes up from the handle's own pinned buffer (a memcpy of 4.8 KB per query, then ONE asynchronous DMA):
+    // from the caller's pageable buffer the runtime stages the copy itself, 5 us more per call
+    const size_t q_bytes = (size_t)nq * DS * sizeof(float);
+    const bool small_q = q_bytes <= 8 * DS * sizeof(float);
+    RSX_TRY(ensure_pinned(h, 4096 + (small_q ? q_bytes : 0)));
+    const void *src = q;
+    if (small_q) {
+      std::memcpy(static_cast<char *>(h->pinned) + 4096, q, q_bytes);
+      src = static_cast<char *>(h->pinned) + 4096;
+    }
+    RSX_HIP(hipMemcpyAsync(h->q_desc.p, src, q_bytes, hipMemcpyHostToDevice, h->stream));
     RSX_TRY(query_device_locked(h, h->q_desc.as<float>(), nq, k, n_eligible, static_cast<rsx_sc_hit *>(h->pinned), h->stream));
     RSX_HIP(hipStreamSynchronize(h->stream));
     std::memcpy(out, h->pinned, out_bytes);
