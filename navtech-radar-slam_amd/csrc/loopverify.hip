@@ -15,12 +15,11 @@
 //                                                        concatenated, VoxelGrid
 //
 // MI355X mapping: the keyframe clouds live back to back in ONE HBM array of float4 {x, y, z, intensity} (append-only, like
-// the reference's vector), so the +-25-keyframe submap of a loop candidate is one contiguous slice: one transform kernel
-// over the slice (coalesced 16-byte loads / stores), the VoxelGrid chain of voxelgrid.hip on the result, and the ICP of
-// icp.hip on the two downsampled clouds -- nothing returns to the host between the candidate and the verdict except the
-// VoxelGrid counts and the ICP's convergence flag.  A radar keyframe is ~10^3 points, a submap <= 51 of them: the chain is
-// launch- and latency-bound (~35 launches), no roofline applies; what matters is that the 1 Hz detector's candidate is
-// verified without a 76 k-point round trip over PCIe.
+// the reference's vector), so the +-25-keyframe submap of a loop candidate is one contiguous slice.  A verification is TWO
+// launches and one read-back (round 5): vg_coop_kernel transforms both slices by the root pose as it reads them and
+// VoxelGrid-filters them (voxelgrid.hip; the sizes stay in device memory), icp_persistent_kernel aligns them (icp.hip).
+// A radar keyframe is ~10^3 points, a submap <= 51 of them: the chain is latency-bound (grid barriers, coherent loads) and
+// the nearest-neighbour scan VALU-bound; no HBM roofline applies.  Rounds 1-4: ~180 launches and 26 host synchronisations.
 //
 // Parity: the transform is bit-exact float (mul / add in the reference's order, no contraction), the VoxelGrid is
 // bit-identical to oracle/voxelgrid_ref.c, the ICP within 1e-4 of oracle/icp_ref.c -- the chain is checked against
