@@ -674,10 +674,10 @@ __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ im
   }
 }
 
-// one block of 256 threads per image: K* = the max_points-th smallest opener key, and the mark limit
-__global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned long long *__restrict__ lists, int64_t list_stride, int rows,
+// one block of 1024 threads per image: K* = the max_points-th smallest opener key, and the mark limit
+__global__ __launch_bounds__(1024) void cen_resolve(Scal *scal, const unsigned long long *__restrict__ lists, int64_t list_stride, int rows,
                                                    int cols, int max_points) {
-  constexpr int NT = 256;
+  constexpr int NT = 1024;
   __shared__ unsigned s_h[256];
   __shared__ unsigned long long s_prefix;
   __shared__ unsigned s_t;
@@ -694,12 +694,15 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
     return;
   }
   const unsigned n = sc->n_list;
+#ifdef RSX_CEN_DEBUG
+  if (threadIdx.x == 0 && blockIdx.x < 4) printf("cen_resolve image %d: n_list %u bstar %d above %u\n", (int)blockIdx.x, n, bstar, sc->above);
+#endif
   if (n <= 256) {
     // the usual case (a few dozen openers in the bin): every thread takes one key and counts the smaller ones; the key
     // of rank t - 1 is K* (keys are distinct).  One global load per thread, n broadcast LDS reads, no passes.
     __shared__ unsigned long long s_k[256];
     const unsigned long long mine = threadIdx.x < n ? list[threadIdx.x] : KINF;
-    s_k[threadIdx.x] = mine;
+    if (threadIdx.x < 256) s_k[threadIdx.x] = mine;
     __syncthreads();
     unsigned rank = 0;
     for (unsigned i = 0; i < n; i++) rank += s_k[i] < mine ? 1u : 0u;
@@ -712,15 +715,97 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
     s_prefix = 0ull;
     s_t = (unsigned)max_points - sc->above;
   }
+  // (lists of up to 32 keys per thread -- the odometry drive's images put a few thousand tied openers into the selected bin --
+  // are read ONCE and kept in registers for the eight passes: re-reading them pass by pass was 100 us per 64-scan window)
+  constexpr int RK = 32;
+  const bool in_regs = n <= (unsigned)(RK * NT);
+  unsigned long long rk[RK];
+  if (in_regs) {
+#pragma unroll
+    for (int e = 0; e < RK; e++) {
+      const unsigned i = threadIdx.x + (unsigned)e * NT;
+      rk[e] = i < n ? list[i] : KINF;
+    }
+  }
+#ifdef RSX_CEN_DEBUG
+  const unsigned long long dbg_t0 = wall_clock64();
+  unsigned long long dbg_tp[8];
+#endif
+  // bytes that ALL keys share need no counting pass (tied openers: the four bytes of h and the top byte of the pixel index --
+  // five of the eight passes, 11 us each with 15 000 keys)
+  __shared__ unsigned long long s_and[NT / 64], s_or[NT / 64];
+  unsigned long long differ;
+  {
+    unsigned long long va = ~0ull, vo = 0ull;
+    if (in_regs) {
+#pragma unroll
+      for (int e = 0; e < RK; e++)
+        if (threadIdx.x + (unsigned)e * NT < n) {
+          va &= rk[e];
+          vo |= rk[e];
+        }
+    } else {
+      for (unsigned i = threadIdx.x; i < n; i += NT) {
+        const unsigned long long k = list[i];
+        va &= k;
+        vo |= k;
+      }
+    }
+    for (int o = 32; o >= 1; o >>= 1) {
+      va &= __shfl_xor(va, o);
+      vo |= __shfl_xor(vo, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      s_and[threadIdx.x >> 6] = va;
+      s_or[threadIdx.x >> 6] = vo;
+    }
+    __syncthreads();
+    va = ~0ull;
+    vo = 0ull;
+    for (int w = 0; w < NT / 64; w++) {
+      va &= s_and[w];
+      vo |= s_or[w];
+    }
+    differ = va ^ vo;
+    if (threadIdx.x == 0) s_prefix = va & ~differ;  // (the shared bytes are the prefix's; the passes below fill in the others)
+    __syncthreads();
+  }
   unsigned long long mask = 0ull;
   for (int pass = 0; pass < 8; pass++) {
     const int shift = 56 - 8 * pass;
+    if (((differ >> shift) & 255ull) == 0ull) {  // every key has this byte (uniform)
+      mask |= 255ull << shift;
+      continue;
+    }
+#ifdef RSX_CEN_DEBUG
+    dbg_tp[pass] = wall_clock64() - dbg_t0;
+#endif
     if (threadIdx.x < 256) s_h[threadIdx.x] = 0u;
     __syncthreads();
-    const unsigned long long prefix = s_prefix;
-    for (unsigned i = threadIdx.x; i < n; i += NT) {
-      const unsigned long long k = list[i];
-      if ((k & mask) == prefix) atomicAdd(&s_h[(unsigned)(k >> shift) & 255u], 1u);
+    const unsigned long long prefix = s_prefix & mask;  // (s_prefix already holds the shared bytes further down)
+    // (tied openers share their h: in the four passes over h's bytes every key falls into the SAME bin, and thousands of LDS
+    // atomics on one address are served one after the other -- 80 us.  A wavefront adds once per distinct digit.)
+    auto count = [&](bool on, unsigned long long key) {
+      const unsigned digit = (unsigned)(key >> shift) & 255u;
+      unsigned long long peers = __ballot(on);
+      if (peers == 0ull) return;  // (uniform)
+#pragma unroll
+      for (int bit = 0; bit < 8; bit++) {
+        const bool one = (digit >> bit) & 1u;
+        const unsigned long long bal = __ballot(on && one);
+        peers &= one ? bal : ~bal;
+      }
+      if (on && (peers & ((1ull << (threadIdx.x & 63)) - 1ull)) == 0ull) atomicAdd(&s_h[digit], (unsigned)__popcll(peers));
+    };
+    if (in_regs) {
+#pragma unroll
+      for (int e = 0; e < RK; e++) count(threadIdx.x + (unsigned)e * NT < n && (rk[e] & mask) == prefix, rk[e]);
+    } else {
+      for (unsigned i0 = 0; i0 < n; i0 += NT) {  // (whole wavefronts: the ballots need every lane)
+        const unsigned i = i0 + threadIdx.x;
+        const unsigned long long k = i < n ? list[i] : KINF;
+        count(i < n && (k & mask) == prefix, k);
+      }
     }
     __syncthreads();
     if (threadIdx.x < 64) {  // lane l owns digits 4l .. 4l+3
@@ -740,12 +825,16 @@ __global__ __launch_bounds__(256) void cen_resolve(Scal *scal, const unsigned lo
         else if ((c += c1) + c2 >= t) dig = 2;
         else { c += c2; dig = 3; }
         s_t = t - c;
-        s_prefix = prefix | ((unsigned long long)(4 * l + dig) << shift);
+        s_prefix |= (unsigned long long)(4 * l + dig) << shift;
       }
     }
     mask |= 255ull << shift;
     __syncthreads();
   }
+#ifdef RSX_CEN_DEBUG
+  if (threadIdx.x == 0 && blockIdx.x == 0)
+    printf("passes at %llu %llu %llu %llu %llu %llu %llu %llu end %llu (10 ns)\n", dbg_tp[0], dbg_tp[1], dbg_tp[2], dbg_tp[3], dbg_tp[4], dbg_tp[5], dbg_tp[6], dbg_tp[7], wall_clock64() - dbg_t0);
+#endif
   if (threadIdx.x == 0) {
     const unsigned long long kstar = s_prefix;  // the key of the candidate that opens region number max_points
     sc->klimit = (kstar == KINF || kstar + 1ull > kmean) ? kmean : kstar + 1ull;
@@ -1008,7 +1097,7 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
   hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<OpRec<C>>(),
                      h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
-  hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(256), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
+  hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(1024), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
   const int rrpb = rpb > 1 ? RUNS_ROWS : 1;
   hipLaunchKernelGGL((cen_runs<C, NT>), dim3((unsigned)((rows + rrpb - 1) / rrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
