@@ -1434,12 +1434,26 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
       mb = max8(mb, d1);
       d1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(W, Pq(1, 3), z, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
-      outv[0] = bound_of(ma * r_ne, r_ne, ra);   // n_lo = n_hi = n_e: 1 / n_lo within 1 ulp of r_ne, covered by the (1 + 4e-6)
       mb = max8(mb, d2);
       __builtin_amdgcn_sched_barrier(0);
       mb = max8(mb, d0);
       mb = max8(mb, d1);
-      outv[1] = bound_of(mb * r_ne, r_ne, rb);
+      // ONE bound per lane (round 5).  Lanes 0..31 store query QB, lanes 32..63 query QB + 1, and every lane holds the maxima
+      // of its half of the rows for BOTH queries: v_permlane32_swap of (ma, mb) hands the lower half query A's two partial
+      // maxima and the upper half query B's, so one swap + one maximum replace two, and the bound arithmetic runs once per
+      // lane with its own query's constants instead of twice with half of it thrown away.  (n_q = 60 for both: sqrt n_q is
+      // the same number; n_lo = n_hi = n_e: 1 / n_lo within 1 ulp of r_ne, covered by the (1 + 4e-6).)
+      {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ma * r_ne), __float_as_uint(mb * r_ne), false, false);
+        const float best = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        const float sqrt_aq = hh ? rb.sqrt_aq : ra.sqrt_aq;
+        const unsigned flags = hh ? rb.flags : ra.flags;
+        const float err = kE1 * ra.sqrt_nq * sqrt_ne + kE2 * sqrt_aq * sqrt_ae;
+        float v = (1.0f + a.eps_direct) - fmaf(best, (16.0f / 15.0f) * (1.0f + 4e-6f), err * r_ne);
+        if (n_e == 0) v = INFINITY;                 // no effective column at any shift: never a hit
+        if (flags != 0u || e_bad) v = -INFINITY;    // non-finite input: always re-score exactly
+        outv[0] = outv[1] = v;
+      }
     } else {
       static_for<2>([&](auto qc) {
         constexpr int ql = decltype(qc)::value;
