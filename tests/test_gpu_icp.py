@@ -66,3 +66,33 @@ def test_states_and_rejection(icpmod, oracle):
     wrong = ic.align(src, scene(9))
     assert not ic.accepts(wrong)                                       # a different place: fitness > 0.3
     assert abs(wrong["fitness"] - oracle.icp_align(src, scene(9))["fitness"]) < 1e-3 * wrong["fitness"]
+
+
+@pytest.mark.parametrize("ns,nt", [(40000, 3000), (300, 70000), (1500, 200000), (129, 40), (3, 1), (5000, 5000)])
+def test_shapes_of_the_persistent_kernel(icpmod, oracle, ns, nt):
+    """what the (source block) x (target slice) grid has to cope with: more source blocks than workgroups (several blocks per
+    workgroup, points re-read instead of kept in registers), a few source points against many targets, target slices that
+    do not fit the LDS tile (re-loaded every iteration), slices of a single point, three points against one.  Compared with
+    the oracle adding in the device's order: same iteration count, pose to 1e-6 (capped iterations keep the oracle quick)."""
+    rng = np.random.default_rng(ns + nt)
+    tgt = scene(7, max(nt, 40))
+    tgt = tgt[rng.choice(len(tgt), nt, replace=len(tgt) < nt)]
+    R, t = rot(0.03, 0.005, -0.004), np.array([0.4, -0.2, 0.02])
+    sub = tgt[rng.choice(nt, ns, replace=True)] + rng.normal(0, 0.05, (ns, 3))
+    src = ((sub - t) @ R).astype(np.float32)
+    ic = icpmod.Icp()
+    ic.params.max_iterations = 6
+    got = ic.align(src, tgt)
+    want = oracle.icp_align(src, tgt, max_iterations=6, sum_order=oracle.ICP_SUM_TREE)
+    assert got["iterations"] == want["iterations"] and got["state"] == want["state"] and got["converged"] == want["converged"]
+    assert np.abs(got["transform"] - want["transform"]).max() < 1e-6
+    assert abs(got["fitness"] - want["fitness"]) < 1e-6 * max(1.0, want["fitness"])
+
+
+def test_empty_clouds(icpmod):
+    ic = icpmod.Icp()
+    pts = scene(3, 200)
+    for src, tgt in ((pts[:0], pts), (pts, pts[:0]), (pts[:2], pts)):
+        r = ic.align(src, tgt)
+        assert not r["converged"] and r["state"] == 5 and r["iterations"] == 0
+        assert np.array_equal(r["transform"], np.eye(4, dtype=np.float32))

@@ -173,3 +173,25 @@ def test_bad_arguments(lv, drive):
     with pytest.raises(Exception):
         kf.verify(-1, 1, pose6[0])
     assert len(kf.build_map(pose6[:0])) == 0
+
+
+def test_empty_and_tiny_keyframes(lv, oracle, drive):
+    """an empty current keyframe (nearKeyframes->empty(), PGO.cpp:343-346) and one of two points: not converged, rejected,
+    identity -- one of the two clouds of the cooperative VoxelGrid launch is then missing / a single workgroup"""
+    clouds, pose6 = drive
+    cl = [c.copy() for c in clouds[:20]]
+    cl[15] = cl[15][:0]
+    cl[16] = cl[16][:2]
+    kf = lv.KeyframeStore()
+    for c in cl:
+        kf.add(c)
+    kf.params.history_keyframe_search_num = 3
+    for curr in (15, 16):
+        got = kf.verify(2, curr, pose6[2])
+        want = oracle.loop_verify(cl, 2, curr, pose6[2], history_num=3, sum_order=oracle.ICP_SUM_TREE)
+        assert (got["n_source"], got["n_target"]) == (want["n_source"], want["n_target"])
+        assert not got["converged"] and not got["accepted"] and got["converged"] == want["converged"] and got["iterations"] == want["iterations"]
+        assert np.array_equal(got["transform"], np.eye(4, dtype=np.float32))
+    good = kf.verify(2, 14, pose6[2])          # and the store still answers an ordinary candidate afterwards
+    ref = oracle.loop_verify(cl, 2, 14, pose6[2], history_num=3, sum_order=oracle.ICP_SUM_TREE)
+    assert good["iterations"] == ref["iterations"] and np.abs(good["transform"] - ref["transform"]).max() < TOL
