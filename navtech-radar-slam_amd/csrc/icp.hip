@@ -43,7 +43,7 @@ namespace {
 
 constexpr int PI_NT = 1024;   // threads per workgroup
 constexpr int PI_SRC = 128;   // source points per block
-constexpr int PI_SP = 4;      // ... four per thread: a thread reads a target point ONCE (one 16-byte LDS read) for four distances,
+constexpr int PI_SP = 4;      // ... four per thread: a thread reads a target point ONCE (one 16-byte LDS read) for four distances (eight: spills and twice the LDS atomics, 795 us against 670),
                               // two at a time with packed fp32 arithmetic.  (First build: one source point per thread and three
                               // 4-byte LDS reads per distance -- the LDS pipe, not the VALU, set the pace: 45 us per iteration.)
 constexpr int PI_GROUPS = PI_SRC / PI_SP;  // 32 threads cover a block's source points ...
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(PI_NT) void icp_persistent_kernel(IcpArgs A) {
   // a workgroup with ONE source block (the usual case: a scan of ~10^3 points is ~10 blocks, the grid 256 workgroups)
   // keeps its four points per thread in registers from iteration to iteration; otherwise they are read back
   const bool one_block = nblk <= (long long)Gs;
-  float hx[PI_SP] = {0, 0, 0, 0}, hy[PI_SP] = {0, 0, 0, 0}, hz[PI_SP] = {0, 0, 0, 0};
+  float hx[PI_SP] = {}, hy[PI_SP] = {}, hz[PI_SP] = {};
   auto nn_pass = [&](int mode, const float4 *prev, float4 *store, unsigned long long *rec, unsigned long long *clr) {
     if (!working) return;
     for (long long blk = gs; blk < nblk; blk += Gs) {
@@ -369,7 +369,13 @@ __global__ __launch_bounds__(PI_NT) void icp_persistent_kernel(IcpArgs A) {
         bd[e] = INFINITY;
         bi[e] = 0xffffffffu;
       }
-      const f2 x01 = {px[0], px[1]}, x23 = {px[2], px[3]}, y01 = {py[0], py[1]}, y23 = {py[2], py[3]}, z01 = {pz[0], pz[1]}, z23 = {pz[2], pz[3]};
+      f2 xx[PI_SP / 2], yy[PI_SP / 2], zz[PI_SP / 2];
+#pragma unroll
+      for (int h2 = 0; h2 < PI_SP / 2; h2++) {
+        xx[h2] = f2{px[2 * h2], px[2 * h2 + 1]};
+        yy[h2] = f2{py[2 * h2], py[2 * h2 + 1]};
+        zz[h2] = f2{pz[2 * h2], pz[2 * h2 + 1]};
+      }
       for (long long base = t_lo; base < t_hi; base += PI_TILE) {
         const int cnt = (int)(t_hi - base < PI_TILE ? t_hi - base : PI_TILE);
         if (!resident) {
@@ -384,15 +390,19 @@ __global__ __launch_bounds__(PI_NT) void icp_persistent_kernel(IcpArgs A) {
           // (x - tx)^2 + (y - ty)^2 + (z - tz)^2, every operation rounded on its own (no contraction), two source points per
           // packed instruction -- the oracle's float expression
           const f2 tx = {T.x, T.x}, ty = {T.y, T.y}, tz = {T.z, T.z};
-          const f2 dxa = x01 - tx, dya = y01 - ty, dza = z01 - tz, dxb = x23 - tx, dyb = y23 - ty, dzb = z23 - tz;
-          const f2 da = (dxa * dxa + dya * dya) + dza * dza, db = (dxb * dxb + dyb * dyb) + dzb * dzb;
-          const float d[PI_SP] = {da.x, da.y, db.x, db.y};
 #pragma unroll
-          for (int e = 0; e < PI_SP; e++)
-            if (d[e] < bd[e]) {  // ascending scan, strict <: the lower index wins ties
-              bd[e] = d[e];
-              bi[e] = idx;
+          for (int h2 = 0; h2 < PI_SP / 2; h2++) {
+            const f2 dx = xx[h2] - tx, dy = yy[h2] - ty, dz = zz[h2] - tz;
+            const f2 d = (dx * dx + dy * dy) + dz * dz;
+            if (d.x < bd[2 * h2]) {  // ascending scan, strict <: the lower index wins ties
+              bd[2 * h2] = d.x;
+              bi[2 * h2] = idx;
             }
+            if (d.y < bd[2 * h2 + 1]) {
+              bd[2 * h2 + 1] = d.y;
+              bi[2 * h2 + 1] = idx;
+            }
+          }
         }
       }
       ICP_MARK(7)
@@ -616,7 +626,8 @@ struct rsx_icp {
   int device = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf src, tgt, cur, best, state, guess, bar;
+  rsx::DevBuf src, tgt, cur, best, guess, bar;
+  void *state_host = nullptr;  // pinned, device-visible: the kernel writes the result there (no read-back to enqueue)
   int n_wg = 0;  // workgroups of the persistent kernel: one per CU, at most PI_MAX_G
 };
 
@@ -657,7 +668,8 @@ int rsx_icp_destroy(rsx_icp *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  for (rsx::DevBuf *b : {&h->src, &h->tgt, &h->cur, &h->best, &h->state, &h->guess, &h->bar}) b->release();
+  for (rsx::DevBuf *b : {&h->src, &h->tgt, &h->cur, &h->best, &h->guess, &h->bar}) b->release();
+  if (h->state_host) (void)hipHostFree(h->state_host);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
@@ -709,7 +721,7 @@ int align_device_counts_locked(rsx_icp *h, const void *d_src, int64_t n_s, const
   const size_t cap = (size_t)(n_s > 0 ? n_s : 1);
   RSX_TRY(h->cur.reserve(2 * cap * 16, s, false));
   RSX_TRY(h->best.reserve(3 * cap * 8, s, false));
-  RSX_TRY(h->state.reserve(sizeof(IcpState), s, false));
+  if (!h->state_host) RSX_HIP(hipHostMalloc(&h->state_host, sizeof(IcpState), hipHostMallocDefault));
   RSX_TRY(h->guess.reserve(64, s, false));
   if (!h->bar.p) {
     RSX_TRY(h->bar.reserve(rsx::grid::BYTES, s, false));
@@ -729,7 +741,7 @@ int align_device_counts_locked(rsx_icp *h, const void *d_src, int64_t n_s, const
   A.guess = guess ? h->guess.as<float>() : nullptr;
   A.cur = h->cur.as<float4>();
   A.best = h->best.as<unsigned long long>();
-  A.S = h->state.as<IcpState>();
+  A.S = static_cast<IcpState *>(h->state_host);
   A.bar = h->bar.as<unsigned>();
   A.max_d2 = (float)(p.max_corr_dist * p.max_corr_dist);
   A.max_iterations = p.max_iterations;
@@ -737,9 +749,8 @@ int align_device_counts_locked(rsx_icp *h, const void *d_src, int64_t n_s, const
   A.feps = p.euclidean_fitness_epsilon;
   hipLaunchKernelGGL(icp_persistent_kernel, dim3((unsigned)h->n_wg), dim3(PI_NT), PI_DYN_LDS, s, A);
   RSX_HIP(hipGetLastError());
-  IcpState hstate;
-  RSX_HIP(hipMemcpyAsync(&hstate, A.S, sizeof(hstate), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
+  const IcpState hstate = *static_cast<const IcpState *>(h->state_host);
   std::memcpy(out->transform, hstate.final_t, sizeof(out->transform));
   out->fitness = hstate.fit_cnt ? hstate.fit_sum / (double)hstate.fit_cnt : 1.7976931348623157e308;
   out->iterations = hstate.iterations;
