@@ -593,7 +593,9 @@ int rsx_icp_create(int device, rsx_icp **out);
 int rsx_icp_destroy(rsx_icp *h);
 /* icp.setInputSource(src); icp.setInputTarget(tgt); icp.align(unused, guess).  Points: float x,y,z at
  * byte offsets 0,4,8 of each stride; guess: optional row-major 4x4 (NULL = identity).  The caller
- * applies the acceptance test of PGO.cpp:385-387 (converged && fitness <= 0.3). */
+ * applies the acceptance test of PGO.cpp:385-387 (converged && fitness <= 0.3).  One launch: a persistent kernel that
+ * occupies the whole device for the duration of the alignment (~0.5 ms); calls from several handles of one process are
+ * serialised, two processes must not align on the same device at the same time. */
 int rsx_icp_align(rsx_icp *h, const void *src, size_t ns, size_t src_stride, const void *tgt, size_t nt, size_t tgt_stride,
                   const rsx_icp_params *params, const float *guess, rsx_icp_result *out);
 

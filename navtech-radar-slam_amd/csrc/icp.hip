@@ -747,9 +747,17 @@ int align_device_counts_locked(rsx_icp *h, const void *d_src, int64_t n_s, const
   A.max_iterations = p.max_iterations;
   A.teps = p.transformation_epsilon;
   A.feps = p.euclidean_fitness_epsilon;
-  hipLaunchKernelGGL(icp_persistent_kernel, dim3((unsigned)h->n_wg), dim3(PI_NT), PI_DYN_LDS, s, A);
-  RSX_HIP(hipGetLastError());
-  RSX_HIP(hipStreamSynchronize(s));
+  {
+    // One persistent ICP kernel at a time per process: its workgroups fill every CU (16 wavefronts at 128 VGPRs) and wait for
+    // each other at grid barriers, so two of them launched together from different handles could each hold a part of the chip
+    // and wait for the rest for ever.  (Other kernels beside it are harmless: they only delay it.  Two PROCESSES aligning on one
+    // GPU at the same moment are not covered -- one process per GPU is the deployment this library is written for.)
+    static std::mutex persistent_mu;
+    std::lock_guard<std::mutex> lkp(persistent_mu);
+    hipLaunchKernelGGL(icp_persistent_kernel, dim3((unsigned)h->n_wg), dim3(PI_NT), PI_DYN_LDS, s, A);
+    RSX_HIP(hipGetLastError());
+    RSX_HIP(hipStreamSynchronize(s));
+  }
   const IcpState hstate = *static_cast<const IcpState *>(h->state_host);
   std::memcpy(out->transform, hstate.final_t, sizeof(out->transform));
   out->fitness = hstate.fit_cnt ? hstate.fit_sum / (double)hstate.fit_cnt : 1.7976931348623157e308;
