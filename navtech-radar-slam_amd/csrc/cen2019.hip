@@ -639,38 +639,48 @@ __device__ __forceinline__ float pixel_h(const uint8_t *__restrict__ row, int co
 // the openers of histogram bin B* (a few dozen keys per image) -> list.  Round 5: cen_hist left, per thread, the highest bin
 // an opener of the thread fell into; only the threads that reach B* are looked at (one in twelve on the bench images), their
 // opener pixels are queued in LDS and evaluated one pixel per lane, straight from the bytes.  Before: h of EVERY pixel again
-// (1807 VALU instructions per wavefront for eight rows, 80 us per 64 images).
+// (1807 VALU instructions per wavefront for eight rows, 80 us per 64 images).  A WAVEFRONT per azimuth, no workgroup barrier:
+// the wavefront walks the row's records 64 at a time, queues the opener pixels of the threads that qualify (positions by a
+// DPP prefix sum) in its own LDS segment and evaluates them; the first build took a workgroup per azimuth and two barriers.
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_collect(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
                                                   int off, Scal *scal, const OpRec<C> *__restrict__ opener, unsigned long long *__restrict__ lists,
                                                   int64_t list_stride, int rpb) {
-  __shared__ unsigned short s_q[C * NT];
-  __shared__ unsigned s_n;
+  constexpr int NW = NT / 64, QCAP = 2 * 64 * C;  // (a step of 64 records adds at most 64 C pixels)
+  __shared__ unsigned short s_q[NW][QCAP];
   Scal *sc = scal + blockIdx.y;
   unsigned long long *list = lists + (int64_t)blockIdx.y * list_stride;
   const int bstar = sc->bstar;
-  if (bstar < 0) return;  // fewer openers than the budget: nothing to select (uniform, before any barrier)
+  if (bstar < 0) return;  // fewer openers than the budget: nothing to select
   const float mean = sc->mean, maxg = __uint_as_float(sc->max_g_bits), rcp_maxg = sc->rcp_maxg;
-  for (int rr = 0; rr < rpb; rr++) {
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  for (int rr = w; rr < rpb; rr += NW) {
     const int a = blockIdx.x * rpb + rr;
-    if (a >= rows) break;  // (uniform)
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const int64_t slot = ((int64_t)blockIdx.y * rows + a) * NT + threadIdx.x;
-    const unsigned rec = (int)threadIdx.x * C < cols ? (unsigned)opener[slot] : 0u;
-    if ((int)((rec >> kTopShift<C>) << 5) > bstar) {  // 1 + highest opener bin (rounded up to 32) >= B* + 1
-      unsigned op = rec & ((1u << kTopShift<C>) - 1u);
-      const unsigned at = atomicAdd(&s_n, (unsigned)__popc(op));
-      for (unsigned j = at; op; op &= op - 1, j++) s_q[j] = (unsigned short)(threadIdx.x * C + __builtin_ctz(op));
-    }
-    __syncthreads();
-    const unsigned n = s_n;
+    if (a >= rows) break;  // (uniform in the wavefront)
     const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
-    for (unsigned j = threadIdx.x; j < n; j += NT) {
-      const int p = s_q[j];
-      const float hv = pixel_h(row, cols, p, mean, maxg, rcp_maxg);
-      if (h_bin(hv) == bstar) list[atomicAdd(&sc->n_list, 1u)] = key_of(hv, (unsigned)a * (unsigned)cols + (unsigned)p);
+    unsigned n = 0;
+    auto drain = [&]() {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      for (unsigned j = lane; j < n; j += 64) {
+        const int p = s_q[w][j];
+        const float hv = pixel_h(row, cols, p, mean, maxg, rcp_maxg);
+        if (h_bin(hv) == bstar) list[atomicAdd(&sc->n_list, 1u)] = key_of(hv, (unsigned)a * (unsigned)cols + (unsigned)p);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      n = 0;
+    };
+    for (int t0 = 0; t0 * C < cols; t0 += 64) {
+      const int t = t0 + lane;
+      const unsigned rec = t * C < cols ? (unsigned)opener[((int64_t)blockIdx.y * rows + a) * NT + t] : 0u;
+      unsigned op = ((int)((rec >> kTopShift<C>) << 5) > bstar) ? rec & ((1u << kTopShift<C>) - 1u) : 0u;  // 1 + highest opener bin (rounded up to 32) >= B* + 1
+      const unsigned cnt = (unsigned)__popc(op), incl = wave_incl_add(cnt, lane);
+      const unsigned total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+      if (total == 0) continue;              // (uniform)
+      if (n + total > (unsigned)QCAP) drain();  // (uniform)
+      for (unsigned j = n + incl - cnt; op; op &= op - 1, j++) s_q[w][j] = (unsigned short)(t * C + __builtin_ctz(op));
+      n += total;
     }
+    drain();
   }
 }
 
