@@ -604,39 +604,87 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
   {
     unsigned pos = s_base;
     for (int ww = 0; ww < w; ww++) pos += s_w4[ww];
-    auto centroid = [&](long long e, bool head, unsigned long long bal) {  // the thread of a voxel's first point sums its points in input order
-      if (head) {
-        const unsigned o = pos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
-        // the voxel's points four at a time: the next four (key, index) pairs are requested together -- a coherent load is
-        // ~2 us, and a voxel of the 51-keyframe submap holds 2.3 points on average (one pair per round trip: 40 us of tail)
-        const unsigned k = grid::ld(K + e);
-        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-        long long j = e;
-        bool more = true;
-        while (more) {
-          unsigned kk[4], vv[4];
+    // the rest of a voxel from sorted position j on (the voxel has `have` points so far), four (key, index) pairs per round trip
+    auto finish = [&](unsigned k, long long j, float &s0, float &s1, float &s2, float &s3) -> long long {
+      bool more = true;
+      while (more) {
+        unsigned kk[4], vv[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const long long jj = j + u < n ? j + u : n - 1;
-            kk[u] = grid::ld(K + jj);
-            vv[u] = grid::ld(V + jj);
-          }
-          float4 q[4];
+        for (int u = 0; u < 4; u++) {
+          const long long jj = j + u < n ? j + u : n - 1;
+          kk[u] = grid::ld(K + jj);
+          vv[u] = grid::ld(V + jj);
+        }
+        float4 q[4];
 #pragma unroll
-          for (int u = 0; u < 4; u++) q[u] = co_point(J, (long long)vv[u]);
+        for (int u = 0; u < 4; u++) q[u] = co_point(J, (long long)vv[u]);
 #pragma unroll
-          for (int u = 0; u < 4; u++) {
-            if (more && j < n && kk[u] == k) {
-              s0 = __fadd_rn(s0, q[u].x);
-              s1 = __fadd_rn(s1, q[u].y);
-              s2 = __fadd_rn(s2, q[u].z);
-              if (J.ioff >= 0) s3 = __fadd_rn(s3, q[u].w);
-              j++;
-            } else {
-              more = false;
-            }
+        for (int u = 0; u < 4; u++) {
+          if (more && j < n && kk[u] == k) {
+            s0 = __fadd_rn(s0, q[u].x);
+            s1 = __fadd_rn(s1, q[u].y);
+            s2 = __fadd_rn(s2, q[u].z);
+            if (J.ioff >= 0) s3 = __fadd_rn(s3, q[u].w);
+            j++;
+          } else {
+            more = false;
           }
         }
+      }
+      return j;
+    };
+    // one chunk of 64 sorted positions: EVERY lane fetches its own (key, index, point) -- one round trip for the whole chunk --
+    // and the lane of a voxel's first point adds the points of the lanes after it, in order, through the wavefront (a voxel
+    // with 40 points was ten round trips of one thread: the kernel's tail).  A voxel that runs past the chunk goes on as before.
+    auto centroid_chunk = [&](long long e, unsigned long long heads) {
+      const bool in = e < whi;
+      unsigned k = S.invalid_key, v = 0;
+      if (in) {
+        k = grid::ld(K + e);
+        v = grid::ld(V + e);
+      }
+      const bool valid = in && k != S.invalid_key;
+      float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (valid) q = co_point(J, (long long)v);
+      const bool head = (heads >> lane) & 1ull;
+      // the points of this lane's voxel inside the chunk: up to the next head or the first non-finite point (the voxel ends
+      // there), or up to the end of the wavefront's share / of the chunk (the voxel may go on: `finish` looks)
+      const unsigned long long above = ~((2ull << lane) - 1ull);  // (lane 63: empty)
+      const unsigned long long ends = (heads | __ballot(in && !valid)) & above, outside = ~__ballot(in) & above;
+      const int p_end = ends ? __builtin_ctzll(ends) : 64, p_out = outside ? __builtin_ctzll(outside) : 64;
+      const int seglen = (p_end < p_out ? p_end : p_out) - lane;
+      const bool open_end = p_out <= p_end;  // nothing inside the chunk closed the voxel
+      float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+      int longest = head ? seglen : 0;
+      for (int o = 32; o >= 1; o >>= 1) {
+        const int x = __shfl_xor(longest, o);
+        longest = x > longest ? x : longest;
+      }
+      for (int d = 0; d < longest; d++) {  // (uniform)
+        const int srcl = lane + d < 64 ? lane + d : 63;
+        const float x = __shfl(q.x, srcl), y = __shfl(q.y, srcl), z = __shfl(q.z, srcl), wv = __shfl(q.w, srcl);
+        if (head && d < seglen) {
+          s0 = __fadd_rn(s0, x);
+          s1 = __fadd_rn(s1, y);
+          s2 = __fadd_rn(s2, z);
+          if (J.ioff >= 0) s3 = __fadd_rn(s3, wv);
+        }
+      }
+      if (head) {
+        const unsigned o = pos + (unsigned)__popcll(heads & ((1ull << lane) - 1ull));
+        long long j = e + seglen;
+        if (open_end && j < n) j = finish(k, j, s0, s1, s2, s3);  // the voxel may go on in the next chunk / share / tile
+        const float c = (float)(j - e);
+        if ((long long)o < J.max_out) J.out[o] = make_float4(__fdiv_rn(s0, c), __fdiv_rn(s1, c), __fdiv_rn(s2, c), __fdiv_rn(s3, c));
+      }
+      pos += (unsigned)__popcll(heads);
+    };
+    auto centroid = [&](long long e, bool head, unsigned long long bal) {  // (shares too large for the register path: one thread per voxel)
+      if (head) {
+        const unsigned o = pos + (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+        const unsigned k = grid::ld(K + e);
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        const long long j = finish(k, e, s0, s1, s2, s3);
         const float c = (float)(j - e);
         if ((long long)o < J.max_out) J.out[o] = make_float4(__fdiv_rn(s0, c), __fdiv_rn(s1, c), __fdiv_rn(s2, c), __fdiv_rn(s3, c));
       }
@@ -645,7 +693,7 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
     if (cached) {
 #pragma unroll
       for (int c = 0; c < CO_CH; c++)
-        if (wlo + c * 64 < whi) centroid(wlo + c * 64 + lane, (hb[c] >> lane) & 1ull, hb[c]);
+        if (wlo + c * 64 < whi) centroid_chunk(wlo + c * 64 + lane, hb[c]);
     } else {
       for (long long e0 = wlo; e0 < whi; e0 += 64) {
         const long long e = e0 + lane;
