@@ -704,9 +704,6 @@ __global__ __launch_bounds__(1024) void cen_resolve(Scal *scal, const unsigned l
     return;
   }
   const unsigned n = sc->n_list;
-#ifdef RSX_CEN_DEBUG
-  if (threadIdx.x == 0 && blockIdx.x < 4) printf("cen_resolve image %d: n_list %u bstar %d above %u\n", (int)blockIdx.x, n, bstar, sc->above);
-#endif
   if (n <= 256) {
     // the usual case (a few dozen openers in the bin): every thread takes one key and counts the smaller ones; the key
     // of rank t - 1 is K* (keys are distinct).  One global load per thread, n broadcast LDS reads, no passes.
@@ -737,10 +734,6 @@ __global__ __launch_bounds__(1024) void cen_resolve(Scal *scal, const unsigned l
       rk[e] = i < n ? list[i] : KINF;
     }
   }
-#ifdef RSX_CEN_DEBUG
-  const unsigned long long dbg_t0 = wall_clock64();
-  unsigned long long dbg_tp[8];
-#endif
   // bytes that ALL keys share need no counting pass (tied openers: the four bytes of h and the top byte of the pixel index --
   // five of the eight passes, 11 us each with 15 000 keys)
   __shared__ unsigned long long s_and[NT / 64], s_or[NT / 64];
@@ -787,9 +780,6 @@ __global__ __launch_bounds__(1024) void cen_resolve(Scal *scal, const unsigned l
       mask |= 255ull << shift;
       continue;
     }
-#ifdef RSX_CEN_DEBUG
-    dbg_tp[pass] = wall_clock64() - dbg_t0;
-#endif
     if (threadIdx.x < 256) s_h[threadIdx.x] = 0u;
     __syncthreads();
     const unsigned long long prefix = s_prefix & mask;  // (s_prefix already holds the shared bytes further down)
@@ -841,10 +831,6 @@ __global__ __launch_bounds__(1024) void cen_resolve(Scal *scal, const unsigned l
     mask |= 255ull << shift;
     __syncthreads();
   }
-#ifdef RSX_CEN_DEBUG
-  if (threadIdx.x == 0 && blockIdx.x == 0)
-    printf("passes at %llu %llu %llu %llu %llu %llu %llu %llu end %llu (10 ns)\n", dbg_tp[0], dbg_tp[1], dbg_tp[2], dbg_tp[3], dbg_tp[4], dbg_tp[5], dbg_tp[6], dbg_tp[7], wall_clock64() - dbg_t0);
-#endif
   if (threadIdx.x == 0) {
     const unsigned long long kstar = s_prefix;  // the key of the candidate that opens region number max_points
     sc->klimit = (kstar == KINF || kstar + 1ull > kmean) ? kmean : kstar + 1ull;
