@@ -31,6 +31,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,7 +65,7 @@ struct IcpState {
 #endif
 };
 
-enum { ST_NOT = 0, ST_ITER = 1, ST_TRANSFORM = 2, ST_ABS_MSE = 3, ST_REL_MSE = 4, ST_NO_CORR = 5 };
+enum { ST_NOT = 0, ST_ITER = 1, ST_TRANSFORM = 2, ST_ABS_MSE = 3, ST_REL_MSE = 4, ST_NO_CORR = 5, ST_GAVE_UP = 99 };
 
 struct IcpArgs {
   const char *src, *tgt;  // float x, y, z at byte offsets 0, 4, 8 of each stride
@@ -277,8 +278,22 @@ __global__ __launch_bounds__(PI_NT) void icp_persistent_kernel(IcpArgs A) {
   __shared__ int s_conv, s_state, s_iter;
   const int t = threadIdx.x;
   const unsigned G = gridDim.x, b = blockIdx.x;
-  grid::Member m{A.bar, b, G, 0u};
+  grid::Member m{A.bar, b, G, 0u, false};
+  // (a barrier that gives up -- rsx_grid_dev.h -- ends the alignment with state ST_GAVE_UP: the host reports it)
+  auto gave_up = [&]() {
+    if (b == 0 && threadIdx.x == 0) {
+      A.S->state = ST_GAVE_UP;
+      A.S->converged = 0;
+      A.S->iterations = 0;
+      A.S->fit_cnt = 0;
+    }
+    grid::exit(m);
+  };
   const long long ns = A.ns_ptr ? *A.ns_ptr : A.ns_imm, nt = A.nt_ptr ? *A.nt_ptr : A.nt_imm;
+  if (ns < 0 || nt < 0) {  // the launch that was to leave the sizes gave up (uniform: no barrier has been entered)
+    gave_up();
+    return;
+  }
   // the workgroups as (source block) x (target slice)
   const long long nblk = (ns + PI_SRC - 1) / PI_SRC;
   const unsigned Gs = (unsigned)(nblk < 1 ? 1 : (nblk < (long long)G ? nblk : (long long)G)), Gt = G / Gs;
@@ -312,7 +327,10 @@ __global__ __launch_bounds__(PI_NT) void icp_persistent_kernel(IcpArgs A) {
       const long long i = blk * PI_SRC + t;
       if (i < ns) grid::st(best0 + i, ~0ull);
     }
-  grid::sync(m);
+  if (!grid::sync(m)) {
+    gave_up();
+    return;
+  }
   // the nearest neighbours of this workgroup's source blocks in its target slice -> rec (min over the slices).  The points:
   // mode 0 = guess * source, 1 = step * (points of the iteration before), 2 = final * source; the owner stores them / clears `clr`
 #ifdef RSX_ICP_TIMING
@@ -422,7 +440,10 @@ __global__ __launch_bounds__(PI_NT) void icp_persistent_kernel(IcpArgs A) {
     const float4 *curk = A.cur + (size_t)(k & 1) * A.ns_cap;
     nn_pass(k == 0 ? 0 : 1, A.cur + (size_t)((k + 1) & 1) * A.ns_cap, A.cur + (size_t)(k & 1) * A.ns_cap, rec, best_of(k + 1));
     ICP_MARK(0)
-    grid::sync(m);
+    if (!grid::sync(m)) {
+      gave_up();
+      return;
+    }
     ICP_MARK(1)
     // ---- moments over all correspondences, by every workgroup ----
     // (a source cloud of up to KEEP * PI_MOM points -- a keyframe scan -- keeps its correspondences in registers between the two passes)
@@ -588,7 +609,10 @@ __global__ __launch_bounds__(PI_NT) void icp_persistent_kernel(IcpArgs A) {
   // ---- getFitnessScore(): nearest-neighbour distances of final * source (the record buffer iteration k cleared) ----
   unsigned long long *rec = best_of(k + 1);
   nn_pass(2, nullptr, nullptr, rec, nullptr);
-  grid::sync(m);
+  if (!grid::sync(m)) {
+    gave_up();
+    return;
+  }
   if (b == 0) {
     double fs = 0.0, fc = 0.0;
     for (long long i = t; i < ns && t < PI_MOM; i += PI_MOM) {
@@ -716,6 +740,7 @@ int align_device_counts_locked(rsx_icp *h, const void *d_src, int64_t n_s, const
     int cus = 0;
     RSX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
     h->n_wg = cus < 1 ? 1 : (cus > PI_MAX_G ? PI_MAX_G : cus);
+    if (const char *e = rsx::exp_env("RSX_ICP_WGS")) h->n_wg = atoi(e);  // (experiments build: tools/test_watchdog.sh oversubscribes the device)
     RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icp_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PI_DYN_LDS));
   }
   const size_t cap = (size_t)(n_s > 0 ? n_s : 1);
@@ -759,6 +784,8 @@ int align_device_counts_locked(rsx_icp *h, const void *d_src, int64_t n_s, const
     RSX_HIP(hipStreamSynchronize(s));
   }
   const IcpState hstate = *static_cast<const IcpState *>(h->state_host);
+  if (hstate.state == ST_GAVE_UP)
+    return fail(RSX_ERR_HIP, "a grid barrier of the persistent kernel gave up after 5 s: its workgroups were not all resident (CUs masked, or another process holds a part of the device)");
   std::memcpy(out->transform, hstate.final_t, sizeof(out->transform));
   out->fitness = hstate.fit_cnt ? hstate.fit_sum / (double)hstate.fit_cnt : 1.7976931348623157e308;
   out->iterations = hstate.iterations;

@@ -162,6 +162,7 @@ int submap_device(rsx_kfstore *h, rsx_voxelgrid *vg, int64_t key, int64_t size, 
   long long cnt = 0;
   RSX_HIP(hipMemcpyAsync(&cnt, dc.d_count, sizeof(cnt), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
+  if (cnt < 0) return fail(RSX_ERR_HIP, "a grid barrier of the cooperative VoxelGrid kernel gave up after 5 s: its workgroups were not all resident");
   *d_out = dc.d_out;
   *n_out = cnt;
   return RSX_OK;

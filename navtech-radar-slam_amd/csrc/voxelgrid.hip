@@ -304,7 +304,15 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
   __shared__ unsigned s_w4[4];
   __shared__ unsigned s_tmp[CO_MAX_W];
   __shared__ unsigned s_base, s_total;
-  grid::Member m{J.bar, wg, (unsigned)J.W, 0u};
+  grid::Member m{J.bar, wg, (unsigned)J.W, 0u, false};
+  // (a barrier that gives up -- rsx_grid_dev.h -- ends the cloud with n_out = -1: the host reports it)
+  auto gave_up = [&]() {
+    if (wg == 0 && threadIdx.x == 0) {
+      S.sp.n_out = -1;
+      *J.P = S.sp;
+    }
+    grid::exit(m);
+  };
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
 #ifdef RSX_VG_TIMING
   unsigned long long tmk[18] = {0}, tlast = wall_clock64();
@@ -360,7 +368,10 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
     }
   }
   VG_MARK()
-  grid::sync(m);
+  if (!grid::sync(m)) {
+    gave_up();
+    return;
+  }
   VG_MARK()
   // ---- setup: every workgroup reduces the partials and computes the grid for itself (vg_setup's float operations) ----
   // (the partials are read by W threads at once, seven loads in flight each)
@@ -481,7 +492,10 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
     __syncthreads();
     grid::st(J.hist + (size_t)wg * 256 + t, s_wh[0][t] + s_wh[1][t] + s_wh[2][t] + s_wh[3][t]);
     VG_MARK()
-    grid::sync(m);
+    if (!grid::sync(m)) {
+      gave_up();
+      return;
+    }
     VG_MARK()
     {  // where digit t of this workgroup starts: all smaller digits of everyone, digit t of the workgroups before
       // (32 loads in flight at a time: a coherent load is ~2 us, one after the other they were 17 us a pass)
@@ -548,7 +562,10 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
       }
     }
     VG_MARK()
-    grid::sync(m);
+    if (!grid::sync(m)) {
+      gave_up();
+      return;
+    }
   }
   const unsigned *K = ((passes - 1) & 1) ? J.keys1 : J.keys0, *V = ((passes - 1) & 1) ? J.vals1 : J.vals0;
   // ---- heads: the first point of every voxel; their number per workgroup -> output slots ----
@@ -587,7 +604,10 @@ __device__ void co_run(const CoJob &J, unsigned wg) {
     if (t == 0) grid::st(J.part + (size_t)wg * 8 + 7, s_w4[0] + s_w4[1] + s_w4[2] + s_w4[3]);
   }
   VG_MARK()
-  grid::sync(m);
+  if (!grid::sync(m)) {
+    gave_up();
+    return;
+  }
   VG_MARK()
   if (t < J.W) s_tmp[t] = grid::ld(J.part + (size_t)t * 8 + 7);
   __syncthreads();
@@ -823,6 +843,7 @@ int filter_device(rsx_voxelgrid *h, const void *d_pts, int64_t n, int64_t stride
   long long cnt = 0;
   RSX_HIP(hipMemcpyAsync(&cnt, &h->params.as<VgParams>()->n_out, sizeof(cnt), hipMemcpyDeviceToHost, s));
   RSX_HIP(hipStreamSynchronize(s));
+  if (cnt < 0) return fail(RSX_ERR_HIP, "a grid barrier of the cooperative VoxelGrid kernel gave up after 5 s: its workgroups were not all resident");
   *d_out = h->out.as<float>();
   *n_out = cnt;
   return RSX_OK;
