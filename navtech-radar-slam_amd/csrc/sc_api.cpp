@@ -68,6 +68,7 @@ struct rsx_sc {
   struct {
     bool valid = false, filtered = false;
     int32_t nq = 0, k = 0;
+    int32_t window_head = 0;  // > 0: stage 1 left window records for this many list positions only; stage 2 adds the rest on demand
     int64_t n_items = 0, n_eligible = 0;
     const int64_t *q_elig = nullptr;
     QueryView qv{};
@@ -1462,6 +1463,7 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
   const int64_t n_elig = n_eligible < 0 ? h->n_global : n_eligible;
   RSX_TRY(h->st_partial.reserve((size_t)nq * k * sizeof(rsx_sc_hit), s, false));
   const bool filtered = use_filter(h, nq, items) && filter_batch(items, nq) >= nq;
+  int32_t window_head = 0;
   if (filtered) {
     // round 0 only: this shard's share of the ~160 lowest bounds per query -- enough for the merged
     // k-th distance to be the final one for almost every query (a single GPU needs ~120 exact scores
@@ -1477,15 +1479,19 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
     if (first < 8) first = 8;
     if (first > 128) first = 128;
     RSX_TRY(filter_reserve(h, items, nq, s));
-    // (Round 5 tried to stop the window previews at this shard's round-0 share -- S shards previewing 128 list positions each
-    // is S times one GPU's window kernel.  Stage 1 got faster and the step three times SLOWER: stage 2 re-scores candidates
-    // beyond the share, and without a window preview each of them costs a VALU preview, one entry per wavefront: emulated
-    // per-rank compute 1 x 8 on the 10 k DB 1.03 -> 5.95 ms.  RSX_SC_WINDOW_HEAD=1 (experiments build) brings it back.)
+    // Round 5 experiment, OFF by default (RSX_SC_WINDOW_HEAD=1 in the experiments build): a DB shard's window kernel scores only
+    // the head of the list that round 0 re-scores -- S shards previewing 128 list positions each are S times one GPU's window
+    // kernel -- and stage 2 makes the records behind the head ON DEMAND, for the positions whose bound can still reach the k-th
+    // best distance of the merged lists (sc_window_tail_kernel).  Emulated per-rank compute, 1 x 8, 8192 queries against a
+    // 10 000-entry random DB (tools/bench_layouts.py): the whole head in stage 1 1.20 ms; head only and NO tail (stage 2 pays a
+    // VALU preview, one entry per wavefront, per candidate) 6.87 ms; head only + tail on demand 1.52 ms -- a second launch of a
+    // workgroup per query that stages the query's images again costs more than the previews it saves.
     static const bool head_only = [] {
       const char *e = rsx::exp_env("RSX_SC_WINDOW_HEAD");
       return e && e[0] == '1';
     }();
-    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, k, s, elig_monotone != 0, (head_only && h->p.shard_world > 1) ? first : 0));
+    window_head = (head_only && h->p.shard_world > 1 && use_window()) ? first : 0;
+    RSX_TRY(filter_and_select(h, qv, items, n_elig, d_q_elig, first, k, s, elig_monotone != 0, window_head));
     RSX_TRY(rescore(h, qv, items, n_elig, d_q_elig, 0, 1, nullptr, nullptr, k, h->st_partial.as<rsx_sc_hit>(), s));
   } else {
     RSX_TRY(run_topk(h, qv, items, n_elig, d_q_elig, k, h->st_partial.as<rsx_sc_hit>(), s, elig_monotone != 0));  // complete already
@@ -1493,6 +1499,7 @@ int rsx_sc_query_stage1_elig_device(rsx_sc *h, const float *d_q, int32_t nq, int
   RSX_HIP(hipMemcpyAsync(d_partial, h->st_partial.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToDevice, s));
   h->st.valid = true;
   h->st.filtered = filtered;
+  h->st.window_head = window_head;
   h->st.nq = nq;
   h->st.k = k;
   h->st.n_items = items;
@@ -1512,9 +1519,13 @@ int rsx_sc_query_stage2_device(rsx_sc *h, int32_t nq, int32_t k, const rsx_sc_hi
   hipStream_t s;
   RSX_TRY(use_stream(h, stream, &s));
   h->st.valid = false;
-  if (h->st.filtered)
+  if (h->st.filtered) {
+    if (h->st.window_head > 0)
+      RSX_TRY(launch_window_tail(db_view(h), nq, h->w->f_wimg.p, h->w->f_cand.as<RescoreEntry>(), h->w->f_cnt.as<int32_t>(), k, filter_eps(),
+                                 h->w->f_win.as<WindowPreview>(), h->st.window_head, d_global, s));
     return rescore(h, h->st.qv, h->st.n_items, h->st.n_eligible, h->st.q_elig, 1, RESCORE_ALL_ROUNDS, d_global,
                    h->st_partial.as<rsx_sc_hit>(), k, d_out, s);
+  }
   RSX_HIP(hipMemcpyAsync(d_out, h->st_partial.p, (size_t)nq * k * sizeof(rsx_sc_hit), hipMemcpyDeviceToDevice, s));
   return RSX_OK;
 } RSX_CATCH_ALL

@@ -208,6 +208,10 @@ int launch_window_db_keys(const double *vkey, int64_t first, int64_t count, void
 // of a DB shard scores only that many entries per query, and S shards previewing 128 each is S times the work of one GPU
 int launch_window(const DbView &db, const QueryView &q, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt,
                   int32_t k, double eps, WindowPreview *out, hipStream_t s, int32_t head_only = 0);
+// stage 2 of a DB shard after a head-only stage 1: records for the list positions behind the head whose bound can still reach
+// the k-th best distance of d_global [nq][k] (the merged stage-1 lists); qimg still holds stage 1's query images
+int launch_window_tail(const DbView &db, int32_t nq, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt, int32_t k, double eps,
+                       WindowPreview *out, int32_t head, const rsx_sc_hit *d_global, hipStream_t s);
 const char *window_kernel_name();
 
 // ---- one query in one launch (sc_q1.hip): the live detector's regime, nq <= Q1_MAX_NQ ----

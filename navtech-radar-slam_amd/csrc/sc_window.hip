@@ -113,7 +113,10 @@ struct WindowArgs {
 };
 
 
-__global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
+// TAIL (stage 2 of a DB shard whose stage 1 scored the head only): no pass 1; the positions behind the head whose bound can
+// still reach `tau` -- the k-th best distance of the merged stage-1 lists, known only after the exchange -- get their records now
+template <bool TAIL>
+__device__ __forceinline__ void window_body(const WindowArgs &a, const rsx_sc_hit *__restrict__ global) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ float s_ub[WINDOW_HEAD];
   __shared__ int s_pos[WINDOW_P];
@@ -217,49 +220,55 @@ __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
     return (have && kstar >= 0 && pv < 3.0e38f) ? pv + WINDOW_MARGIN : INFINITY;  // NaN fails the compare
   };
 
-  // ---- pass 1: the head of the list ----
   const int head = a.head < 0 ? -a.head : a.head;
-  const int cnt1 = sl_cnt < head ? sl_cnt : head;
-  float ub = INFINITY;
-  if (wave * 32 < cnt1) ub = do_group(wave * 32 + n, wave * 32 + n < cnt1, wave * 32);
-  if (hh == 0) s_ub[wave * 32 + n] = ub;
-  __syncthreads();
-  if (sl_cnt <= head) return;  // uniform
-  if (a.head < 0) {  // (uniform) the rest of the list: no record
-    const int lim = sl_cnt < WINDOW_P ? sl_cnt : WINDOW_P;
-    for (int pos = head + (int)threadIdx.x; pos < lim; pos += 256) {
-      WindowPreview o;
-      o.pv = __builtin_nanf("");
-      o.ks = -2;
-      a.out[(int64_t)qi * WINDOW_P + pos] = o;
-    }
-    return;
-  }
-
-  // ---- the k-th smallest upper bound of the head: an upper bound of the final k-th best distance.  Only entries whose
-  // filter bound does not exceed it can matter to the re-scoring kernel (whose own bound is at least as tight) ----
   float tau_ub;
-  {
-    const float v0 = s_ub[lane], v1 = s_ub[lane + 64];
-    int r0 = 0, r1 = 0;
-    const float4 *u4 = reinterpret_cast<const float4 *>(s_ub);
-#pragma unroll 4
-    for (int j = 0; j < WINDOW_HEAD / 4; j++) {
-      const float4 u = u4[j];
-      const float x[4] = {u.x, u.y, u.z, u.w};
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int idx = 4 * j + e;
-        r0 += (x[e] < v0 || (x[e] == v0 && idx < lane)) ? 1 : 0;
-        r1 += (x[e] < v1 || (x[e] == v1 && idx < lane + 64)) ? 1 : 0;
+  if constexpr (TAIL) {
+    if (sl_cnt <= head) return;  // uniform
+    const double t = global[(int64_t)qi * a.k + (a.k - 1)].dist;  // (1e7 while fewer than k entries are known: everything passes)
+    tau_ub = __double2float_ru(t);
+  } else {
+    // ---- pass 1: the head of the list ----
+    const int cnt1 = sl_cnt < head ? sl_cnt : head;
+    float ub = INFINITY;
+    if (wave * 32 < cnt1) ub = do_group(wave * 32 + n, wave * 32 + n < cnt1, wave * 32);
+    if (hh == 0) s_ub[wave * 32 + n] = ub;
+    __syncthreads();
+    if (sl_cnt <= head) return;  // uniform
+    if (a.head < 0) {  // (uniform) the rest of the list: no record
+      const int lim = sl_cnt < WINDOW_P ? sl_cnt : WINDOW_P;
+      for (int pos = head + (int)threadIdx.x; pos < lim; pos += 256) {
+        WindowPreview o;
+        o.pv = __builtin_nanf("");
+        o.ks = -2;
+        a.out[(int64_t)qi * WINDOW_P + pos] = o;
       }
+      return;
     }
-    const int want = a.k - 1;  // 0 <= want < WINDOW_HEAD (k <= RSX_SC_MAX_TOPK)
-    const unsigned long long b0 = __ballot(r0 == want), b1 = __ballot(r1 == want);
-    const float c0 = __shfl(v0, b0 ? __ffsll((long long)b0) - 1 : 0), c1 = __shfl(v1, b1 ? __ffsll((long long)b1) - 1 : 0);
-    tau_ub = b0 ? c0 : c1;  // ranks are a permutation of 0..127: exactly one of the two ballots has a bit
-  }
 
+    // ---- the k-th smallest upper bound of the head: an upper bound of the final k-th best distance.  Only entries whose
+    // filter bound does not exceed it can matter to the re-scoring kernel (whose own bound is at least as tight) ----
+    {
+      const float v0 = s_ub[lane], v1 = s_ub[lane + 64];
+      int r0 = 0, r1 = 0;
+      const float4 *u4 = reinterpret_cast<const float4 *>(s_ub);
+#pragma unroll 4
+      for (int j = 0; j < WINDOW_HEAD / 4; j++) {
+        const float4 u = u4[j];
+        const float x[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const int idx = 4 * j + e;
+          r0 += (x[e] < v0 || (x[e] == v0 && idx < lane)) ? 1 : 0;
+          r1 += (x[e] < v1 || (x[e] == v1 && idx < lane + 64)) ? 1 : 0;
+        }
+      }
+      const int want = a.k - 1;  // 0 <= want < WINDOW_HEAD (k <= RSX_SC_MAX_TOPK)
+      const unsigned long long b0 = __ballot(r0 == want), b1 = __ballot(r1 == want);
+      const float c0 = __shfl(v0, b0 ? __ffsll((long long)b0) - 1 : 0), c1 = __shfl(v1, b1 ? __ffsll((long long)b1) - 1 : 0);
+      tau_ub = b0 ? c0 : c1;  // ranks are a permutation of 0..127: exactly one of the two ballots has a bit
+    }
+
+  }
   // ---- pass 2: list positions WINDOW_HEAD .. WINDOW_P - 1 whose bound can still matter; the others get "no record" ----
   if (wave == 0) {
     int n2 = 0;
@@ -290,6 +299,9 @@ __global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) {
     (void)do_group(s_pos[have ? g * 32 + n : g * 32], have, s_pos[g * 32]);
   }
 }
+
+__global__ __launch_bounds__(256, WIN_OCC) void sc_window_kernel(WindowArgs a) { window_body<false>(a, nullptr); }
+__global__ __launch_bounds__(256, WIN_OCC) void sc_window_tail_kernel(WindowArgs a, const rsx_sc_hit *__restrict__ global) { window_body<true>(a, global); }
 
 }  // namespace
 
@@ -330,6 +342,31 @@ int launch_window(const DbView &db, const QueryView &q, void *qimg, const Rescor
     a.head = -hd;
   }
   hipLaunchKernelGGL(sc_window_kernel, dim3((unsigned)q.nq), dim3(256), W_LDS, s, a);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+// stage 2 of a DB shard: the records behind the head that stage 1 left out, for the list positions whose bound can still reach
+// the k-th best distance of the merged stage-1 lists (d_global [nq][k]).  The query images of stage 1 are still in qimg.
+int launch_window_tail(const DbView &db, int32_t nq, void *qimg, const RescoreEntry *slist, const int32_t *sl_cnt, int32_t k, double eps,
+                       WindowPreview *out, int32_t head, const rsx_sc_hit *d_global, hipStream_t s) {
+  if (nq <= 0) return RSX_OK;
+  char *img = static_cast<char *>(qimg);
+  WindowArgs a;
+  a.hnR = static_cast<const char *>(db.hnR);
+  a.vk16 = static_cast<const char *>(db.vk16);
+  a.vk_n = db.vk_n;
+  a.cmask = reinterpret_cast<const u64 *>(db.cmask);
+  a.qimg = img;
+  a.qkimg = img + (size_t)nq * FILTER_QIMG_BYTES;
+  a.slist = slist;
+  a.sl_cnt = sl_cnt;
+  a.out = out;
+  a.eps = eps;
+  a.k = k < 1 ? 1 : (k > WINDOW_HEAD ? WINDOW_HEAD : k);
+  int32_t hd = (head + 31) / 32 * 32;
+  a.head = hd > WINDOW_HEAD ? WINDOW_HEAD : hd;
+  hipLaunchKernelGGL(sc_window_tail_kernel, dim3((unsigned)nq), dim3(256), W_LDS, s, a, d_global);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
