@@ -15,6 +15,8 @@
  *     handle's GPU and are used asynchronously on the given hipStream_t (passed as void*).
  *     A NULL stream selects the handle's own private (non-blocking) stream, NOT the legacy default
  *     stream: callers that mix several handles or other GPU work must pass one explicit stream.
+ *     Calls on ONE handle that pass different streams are ordered by the library (the handle's workspaces are shared: a call
+ *     arriving on another stream than the previous call makes its stream wait for everything enqueued on the old one).
  *   - a handle is internally synchronised: every entry point holds the handle's mutex for its whole
  *     duration, so any number of threads may call concurrently (the reference itself races between its
  *     writer, PGO.cpp:492 process_pg, and its reader, PGO.cpp:561 process_lcd).  The one multi-call
@@ -112,12 +114,6 @@ typedef enum {
   RSX_SC_MODE_EXHAUSTIVE = 1 /* same pair function against every eligible entry */
 } rsx_sc_mode;
 
-/* Self-test of the exception firewall (every status-returning entry is a function-try-block, rsx_common.h): throws the
- * named exception INSIDE the library and returns what the firewall makes of it -- 0: a host container asked for an
- * impossible size (std::length_error) -> RSX_ERR_OOM; 1: std::bad_alloc -> RSX_ERR_OOM; 2: std::runtime_error (what
- * nanoflann throws through the reference's SCManager, NF.hpp:1228,1324) -> RSX_ERR_INTERNAL; 3: a non-std exception ->
- * RSX_ERR_INTERNAL.  Needs no device. */
-int rsx_selftest_firewall(int kind);
 
 int rsx_sc_default_params(rsx_sc_params *p);
 int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out);   /* SCManager() */
@@ -190,11 +186,6 @@ int rsx_sc_detect_between_session(rsx_sc *h, const float *curr_key20, const doub
                                   int32_t *nn_idx);
 /* current frozen searchable prefix length ("tree" size, SC.cpp:352-353) */
 int rsx_sc_tree_size(rsx_sc *h, int64_t *n);
-/* Introspection of the candidate stage (host only, no device needed): the ring-key search tree the detector would build
- * over `n` keys of 20 floats -- nanoflann's tree (KDTreeVectorOfVectorsAdaptor.h:49-117, leaf size 10, Scancontext.cpp:284,356)
- * rebuilt node for node, because the order in which tied neighbours come back is the order of its leaves.  out_vind[n] =
- * the permutation of the keys as planeSplit leaves it (nanoflann.hpp:968-1004); optional out_n_nodes / out_depth. */
-int rsx_sc_ringkey_tree_layout(const float *keys20, int64_t n, int32_t *out_vind, int32_t *out_n_nodes, int32_t *out_depth);
 
 /* The reference's public helper methods (SC.h:60-66), stateless: the handle only lends its device, stream and
  * staging memory.  They run on the GPU in fp64 on the doubles as given (no fp32 storage involved, any MatrixXd
@@ -276,25 +267,6 @@ int rsx_sc_query_self_device(rsx_sc *h, int64_t q_first, int32_t nq, int32_t k, 
 /* parity helper: dist/shift of ONE query against local entries [first, first+count) (host out) */
 int rsx_sc_pair_distances(rsx_sc *h, const float *q_desc, int64_t first, int64_t count,
                           double *out_dist, int32_t *out_shift);
-/* parity helper for the MFMA filter: out_lb[q * n_local + slot] = the filter's lower bound of
- * dist(query q, local slot) for every local entry (host out).  Contract checked by the tests:
- * out_lb - rsx_sc_filter_eps() <= the exact distance, for every pair. */
-int rsx_sc_filter_bounds(rsx_sc *h, const float *q_descs, int32_t nq, float *out_lb);
-double rsx_sc_filter_eps(void);
-/* diagnostic entry of the stage between the filter and the exact re-scoring (csrc/sc_window.hip): for each query the first
- * RSX_SC_WINDOW_P entries of its short list (local slots in ascending filter-bound order, -1 past the end; out_counts[q] of
- * them are valid) with the sector-key alignment k* (fastAlignUsingVkey, reference SC.cpp:93-113) and the fp16 matrix-core
- * preview pv of distanceBtnScanContext (SC.cpp:116-148): |pv - distance| <= RSX_SC_WINDOW_MARGIN.  Where the alignment is
- * not unique within the kernel's error bound, k* = -1 and pv - RSX_SC_WINDOW_MARGIN is a lower bound of the distance only;
- * pv = NaN for non-finite data, +inf where no shift of the window has an effective column.  Past the first 128 positions
- * an entry only gets a record when its filter bound can still reach the top-k (k as in the query call), judged by the
- * previews of the first 128; the others carry k* = -2, pv = NaN.  out_shift_mask (k* >= 0 only): bit t set = the window shift
- * k* - 3 + t can be the minimum; the exact evaluation skips the others (their preview is more than two margins above the best
- * one, so they are strictly worse).  All outputs are [nq][RSX_SC_WINDOW_P] host arrays. */
-#define RSX_SC_WINDOW_P 320
-#define RSX_SC_WINDOW_MARGIN 1.25e-3f
-int rsx_sc_window_previews(rsx_sc *h, const float *q_descs, int32_t nq, int32_t k, int32_t *out_slots, float *out_pv,
-                           int32_t *out_kstar, int32_t *out_shift_mask, int32_t *out_counts);
 /* merge nparts per-shard top-k lists (layout [part][nq][k]) into out[nq][k]; pure host logic */
 int rsx_sc_merge_topk(const rsx_sc_hit *parts, int32_t nparts, int32_t nq, int32_t k, rsx_sc_hit *out);
 /* the same on the GPU (d_parts is what an RCCL all-gather of d_out produces) */
@@ -337,24 +309,6 @@ int rsx_scs_query(rsx_scs *h, const float *q_descs, int32_t nq, int32_t k, int64
  * as the reference; every entry of the prefix scored) */
 int rsx_scs_detect_loop_closure(rsx_scs *h, rsx_sc_detection *out);
 
-/* instrumentation for bench.py: name of the dominant kernel (as rocprofv3 reports it) and, when
- * enabled, hipEvent pairs recorded around every launch of it on the stream it runs on.
- * rsx_sc_profile_read synchronises, returns launches and summed milliseconds since the last read,
- * and resets the counters. */
-const char *rsx_sc_dominant_kernel_name(void);
-/* name of the kernel the profiler events of this handle bracketed in its last exhaustive query:
- * "sc_filter_kernel" when the query went through the filter, else "sc_pair_kernel" */
-const char *rsx_sc_profiled_kernel_name(rsx_sc *h);
-int rsx_sc_profile_enable(rsx_sc *h, int on);
-int rsx_sc_profile_read(rsx_sc *h, int64_t *launches, double *total_ms);
-/* while profiling is enabled the exact re-scoring kernel also counts its work: exact (fp64) pair evaluations and
- * (query, launch) pairs that scored at least one candidate, since the last read (device-synchronising) */
-int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored);
-/* the same plus the number of candidates that went through the cheap phase (alignment + fp32 preview) */
-int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored);
-/* out6 = {candidates, exact_evals, queries_rescored, candidates whose alignment + preview came from the matrix-core window
- * kernel, candidates that needed a per-wavefront alignment, window shifts evaluated exactly (<= 7 per exact evaluation)} */
-int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out6);
 
 /* ============================== ORORA registration ======================================
  * Replaces the solver stage of the upstream file-based `odometry.cpp` entry (reference
@@ -594,8 +548,11 @@ int rsx_icp_destroy(rsx_icp *h);
 /* icp.setInputSource(src); icp.setInputTarget(tgt); icp.align(unused, guess).  Points: float x,y,z at
  * byte offsets 0,4,8 of each stride; guess: optional row-major 4x4 (NULL = identity).  The caller
  * applies the acceptance test of PGO.cpp:385-387 (converged && fitness <= 0.3).  One launch: a persistent kernel that
- * occupies the whole device for the duration of the alignment (~0.5 ms); calls from several handles of one process are
- * serialised, two processes must not align on the same device at the same time. */
+ * occupies the whole device for the duration of the alignment (~0.5 ms).  Every kernel of this library that waits at a grid
+ * barrier (this one and the cooperative VoxelGrid kernel behind rsx_voxelgrid_filter / rsx_loop_submap / rsx_loop_verify /
+ * rsx_sc_add_keyframe) is ordered against the others ON THE DEVICE, across handles, streams and threads of one process
+ * (csrc/rsx_persistent.h), and sizes its grid from the runtime's occupancy answer; two PROCESSES must not run such calls on
+ * the same device at the same time (the barrier's 5 s watchdog turns that into RSX_ERR_HIP instead of a hang). */
 int rsx_icp_align(rsx_icp *h, const void *src, size_t ns, size_t src_stride, const void *tgt, size_t nt, size_t tgt_stride,
                   const rsx_icp_params *params, const float *guess, rsx_icp_result *out);
 

@@ -46,6 +46,12 @@ class ScParams(C.Structure):
     ]
 
 
+class RescoringStats(C.Structure):  # rsx_sc_rescoring_stats (include/rsx_diag.h)
+    _fields_ = [("struct_size", C.c_uint32), ("reserved", C.c_uint32), ("candidates", C.c_int64), ("exact_evals", C.c_int64),
+                ("queries_rescored", C.c_int64), ("window_previews", C.c_int64), ("valu_previews", C.c_int64),
+                ("exact_window_shifts", C.c_int64)]
+
+
 class ScDetection(C.Structure):
     _fields_ = [("loop_id", C.c_int32), ("yaw_diff_rad", C.c_float), ("min_dist", C.c_double), ("nn_idx", C.c_int32),
                 ("query_idx", C.c_int32), ("searched", C.c_int32), ("reserved", C.c_int32), ("dist_thres", C.c_double)]
@@ -120,7 +126,7 @@ SYMBOLS = [
     "rsx_sc_query_stage2_device", "rsx_sc_query_self_device",
     "rsx_sc_pair_distances", "rsx_sc_filter_bounds", "rsx_sc_filter_eps", "rsx_sc_profiled_kernel_name",
     "rsx_sc_merge_topk", "rsx_sc_merge_topk_device", "rsx_sc_hit_to_loop",
-    "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read", "rsx_sc_profile_read_rescoring", "rsx_sc_profile_read_rescoring2", "rsx_sc_profile_read_rescoring3", "rsx_sc_window_previews",
+    "rsx_sc_dominant_kernel_name", "rsx_sc_profile_enable", "rsx_sc_profile_read", "rsx_sc_profile_read_rescoring", "rsx_sc_window_previews",
     "rsx_scs_create", "rsx_scs_create_layout", "rsx_scs_num_query_groups", "rsx_scs_destroy", "rsx_scs_num_shards", "rsx_scs_set_dist_thres", "rsx_scs_size",
     "rsx_scs_add_points", "rsx_scs_add_descriptors_f32", "rsx_scs_get_descriptor", "rsx_scs_query",
     "rsx_scs_detect_loop_closure",
@@ -203,9 +209,7 @@ def lib():
         L.rsx_sc_merge_topk_device.argtypes = [vp, vp, i32, i32, i32, vp, vp]
         L.rsx_sc_profile_enable.argtypes = [vp, C.c_int]
         L.rsx_sc_profile_read.argtypes = [vp, C.POINTER(i64), C.POINTER(dbl)]
-        L.rsx_sc_profile_read_rescoring.argtypes = [vp, C.POINTER(i64), C.POINTER(i64)]
-        L.rsx_sc_profile_read_rescoring2.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
-        L.rsx_sc_profile_read_rescoring3.argtypes = [vp, C.POINTER(i64)]
+        L.rsx_sc_profile_read_rescoring.argtypes = [vp, C.POINTER(RescoringStats)]
         L.rsx_sc_window_previews.argtypes = [vp, vp, i32, i32, vp, vp, vp, vp, vp]
         L.rsx_sc_hit_to_loop.argtypes = [vp, vp, C.POINTER(i32), C.POINTER(C.c_float)]
         L.rsx_scs_create.argtypes = [C.POINTER(ScParams), C.POINTER(i32), i32, C.POINTER(vp)]

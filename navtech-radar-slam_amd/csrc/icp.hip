@@ -39,6 +39,7 @@
 #include "icp.h"
 #include "rsx_common.h"
 #include "rsx_grid_dev.h"
+#include "rsx_persistent.h"
 
 namespace {
 
@@ -739,9 +740,13 @@ int align_device_counts_locked(rsx_icp *h, const void *d_src, int64_t n_s, const
   if (!h->n_wg) {
     int cus = 0;
     RSX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-    h->n_wg = cus < 1 ? 1 : (cus > PI_MAX_G ? PI_MAX_G : cus);
-    if (const char *e = rsx::exp_env("RSX_ICP_WGS")) h->n_wg = atoi(e);  // (experiments build: tools/test_watchdog.sh oversubscribes the device)
     RSX_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&icp_persistent_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PI_DYN_LDS));
+    // one workgroup per CU, and never more than the runtime says the device keeps resident (a CU-masked / partitioned device)
+    const int limit = rsx::persistent::resident_limit(reinterpret_cast<const void *>(&icp_persistent_kernel), PI_NT, PI_DYN_LDS, h->device);
+    if (limit < 1) return fail(RSX_ERR_HIP, "occupancy query of the persistent ICP kernel failed");
+    h->n_wg = cus < 1 ? 1 : (cus > PI_MAX_G ? PI_MAX_G : cus);
+    if (h->n_wg > limit) h->n_wg = limit;
+    if (const char *e = rsx::exp_env("RSX_ICP_WGS")) h->n_wg = atoi(e);  // (experiments build: tools/watchdog_check.py oversubscribes the device)
   }
   const size_t cap = (size_t)(n_s > 0 ? n_s : 1);
   RSX_TRY(h->cur.reserve(2 * cap * 16, s, false));
@@ -773,16 +778,16 @@ int align_device_counts_locked(rsx_icp *h, const void *d_src, int64_t n_s, const
   A.teps = p.transformation_epsilon;
   A.feps = p.euclidean_fitness_epsilon;
   {
-    // One persistent ICP kernel at a time per process: its workgroups fill every CU (16 wavefronts at 128 VGPRs) and wait for
-    // each other at grid barriers, so two of them launched together from different handles could each hold a part of the chip
-    // and wait for the rest for ever.  (Other kernels beside it are harmless: they only delay it.  Two PROCESSES aligning on one
-    // GPU at the same moment are not covered -- one process per GPU is the deployment this library is written for.)
-    static std::mutex persistent_mu;
-    std::lock_guard<std::mutex> lkp(persistent_mu);
+    // One grid-barrier kernel at a time per device (rsx_persistent.h): this kernel's workgroups fill every CU (16 wavefronts at
+    // 128 VGPRs) and wait for each other at grid barriers, and so do vg_coop_kernel's (voxelgrid.hip) -- two of them dispatched
+    // side by side, from other handles, streams or threads, could each hold a part of the chip and wait for the rest until
+    // the watchdog.  The gate orders them on the device; kernels without grid barriers beside it only delay it.
+    rsx::persistent::Gate gate(h->device, s);
+    RSX_TRY(gate.status());
     hipLaunchKernelGGL(icp_persistent_kernel, dim3((unsigned)h->n_wg), dim3(PI_NT), PI_DYN_LDS, s, A);
     RSX_HIP(hipGetLastError());
-    RSX_HIP(hipStreamSynchronize(s));
   }
+  RSX_HIP(hipStreamSynchronize(s));
   const IcpState hstate = *static_cast<const IcpState *>(h->state_host);
   if (hstate.state == ST_GAVE_UP)
     return fail(RSX_ERR_HIP, "a grid barrier of the persistent kernel gave up after 5 s: its workgroups were not all resident (CUs masked, or another process holds a part of the device)");

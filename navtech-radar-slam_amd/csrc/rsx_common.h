@@ -10,6 +10,7 @@
 #include <string>
 
 #include "rsx.h"
+#include "rsx_diag.h"
 
 namespace rsx {
 

@@ -95,6 +95,10 @@ struct rsx_sc {
   } ins[kInsSlots];
   int ins_next = 0;
   hipEvent_t last_insert = nullptr;
+  // the handle's workspaces (and the single-query path's arrival tickets, which must be zero between launches) are shared by
+  // every call: when a call arrives on another stream than the previous one, the new stream is ordered behind the old
+  hipStream_t last_user_stream = nullptr;
+  hipEvent_t stream_switch = nullptr;
   hipStream_t up_stream = nullptr, stream_b = nullptr;
   hipEvent_t up_ev[kMaxPieces] = {}, lane_ev = nullptr;
 };
@@ -112,6 +116,13 @@ int set_device(rsx_sc *h) {
 int use_stream(rsx_sc *h, void *stream, hipStream_t *s) {
   *s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   if (*s != h->stream && h->last_insert) RSX_HIP(hipStreamWaitEvent(*s, h->last_insert, 0));
+  if (h->last_user_stream && h->last_user_stream != *s) {
+    if (!h->stream_switch) RSX_HIP(hipEventCreateWithFlags(&h->stream_switch, hipEventDisableTiming));
+    // (a previous stream the caller has destroyed in the meantime has drained: nothing to wait for)
+    if (hipEventRecord(h->stream_switch, h->last_user_stream) == hipSuccess) RSX_HIP(hipStreamWaitEvent(*s, h->stream_switch, 0));
+    else (void)hipGetLastError();
+  }
+  h->last_user_stream = *s;
   return RSX_OK;
 }
 
@@ -736,6 +747,7 @@ int rsx_sc_destroy(rsx_sc *h) try {
     if (sl.done) (void)hipEventDestroy(sl.done);
   }
   if (h->lane_ev) (void)hipEventDestroy(h->lane_ev);
+  if (h->stream_switch) (void)hipEventDestroy(h->stream_switch);
   if (h->up_stream) (void)hipStreamDestroy(h->up_stream);
   if (h->stream_b) (void)hipStreamDestroy(h->stream_b);
   if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1717,25 +1729,21 @@ int rsx_sc_profile_enable(rsx_sc *h, int on) try {
   return RSX_OK;
 } RSX_CATCH_ALL
 
-int rsx_sc_profile_read_rescoring(rsx_sc *h, int64_t *exact_evals, int64_t *queries_rescored) try {
-  int64_t cands = 0;
-  return rsx_sc_profile_read_rescoring2(h, &cands, exact_evals, queries_rescored);
-} RSX_CATCH_ALL
-
-int rsx_sc_profile_read_rescoring2(rsx_sc *h, int64_t *candidates, int64_t *exact_evals, int64_t *queries_rescored) try {
-  if (!h || !candidates || !exact_evals || !queries_rescored) return fail(RSX_ERR_BAD_ARG, "null arg");
-  int64_t v[6];
-  RSX_TRY(rsx_sc_profile_read_rescoring3(h, v));
-  *candidates = v[0];
-  *exact_evals = v[1];
-  *queries_rescored = v[2];
-  return RSX_OK;
-} RSX_CATCH_ALL
-
-int rsx_sc_profile_read_rescoring3(rsx_sc *h, int64_t *out6) try {
-  if (!h || !out6) return fail(RSX_ERR_BAD_ARG, "null arg");
+int rsx_sc_profile_read_rescoring(rsx_sc *h, rsx_sc_rescoring_stats *out) try {
+  if (!h || !out || out->struct_size < offsetof(rsx_sc_rescoring_stats, candidates)) return fail(RSX_ERR_BAD_ARG, "null arg / struct_size not set");
+  int64_t out6[6];
   int64_t *const out5 = out6;
   int64_t *candidates = out5, *exact_evals = out5 + 1, *queries_rescored = out5 + 2;
+  // copies the fields that fit into the caller's struct_size on every return path
+  struct Publish {
+    rsx_sc_rescoring_stats *o;
+    const int64_t *v;
+    ~Publish() {
+      int64_t *dst = &o->candidates;
+      const size_t n = (o->struct_size - offsetof(rsx_sc_rescoring_stats, candidates)) / sizeof(int64_t);
+      for (size_t i = 0; i < n && i < 6; i++) dst[i] = v[i];
+    }
+  } publish{out, out6};
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_TRY(set_device(h));
   for (int i = 0; i < 6; i++) out6[i] = 0;

@@ -5,6 +5,7 @@
 #include <cstdint>
 
 #include "rsx.h"
+#include "rsx_diag.h"
 
 namespace rsx {
 namespace sc {

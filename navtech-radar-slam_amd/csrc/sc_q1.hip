@@ -766,7 +766,12 @@ int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, i
   a.db = db;
   a.qdesc = d_q;
   a.n_items = n_items;
-  a.n_eligible = n_eligible < 0 ? INT64_MAX : n_eligible;
+  {  // "every entry" (< 0) or anything past the end: the first global index no local slot reaches -- never INT64_MAX, the
+     // kernel's (n_eligible - idx_base + idx_stride - 1) / idx_stride would overflow on a sharded handle (idx_stride > 1)
+    const int64_t stride = db.idx_stride > 0 ? db.idx_stride : 1;
+    const int64_t past_end = db.idx_base + n_items * stride;
+    a.n_eligible = (n_eligible < 0 || n_eligible > past_end) ? past_end : n_eligible;
+  }
   a.q_elig = q_elig;
   a.out = d_out;
   a.k = k;

@@ -33,6 +33,7 @@
 
 #include "rsx_common.h"
 #include "rsx_grid_dev.h"
+#include "rsx_persistent.h"
 #include "voxelgrid.h"
 
 namespace {
@@ -758,16 +759,28 @@ namespace vg {
 
 namespace {
 
-int workgroups_for(int64_t n) {
-  const int64_t w = (n + 1023) / 1024;
-  return (int)(w < 1 ? 1 : (w > CO_MAX_W ? CO_MAX_W : w));
+// workgroups per cloud: one per 1024 points, at most CO_MAX_W -- and, two clouds per launch, never more than HALF of what the
+// device keeps resident at once (rsx_persistent.h: occupancy query x CU count; a CU-masked or partitioned device shrinks it)
+int resident_half(int device) {
+  static int cache[64];
+  const int d = (device < 0 || device >= 64) ? 0 : device;
+  if (!cache[d]) {
+    const int lim = rsx::persistent::resident_limit(reinterpret_cast<const void *>(&vg_coop_kernel), CO_NT, 0, device);
+    cache[d] = lim < 2 ? 1 : lim / 2;
+  }
+  return cache[d];
+}
+int workgroups_for(int64_t n, int device) {
+  int64_t w = (n + 1023) / 1024;
+  const int cap = resident_half(device) < CO_MAX_W ? resident_half(device) : CO_MAX_W;
+  return (int)(w < 1 ? 1 : (w > cap ? cap : w));
 }
 
 // buffers of one cloud's job; the barrier counters are zeroed when the buffer is first allocated (the kernel leaves them zero)
 int prepare_job(rsx_voxelgrid *h, const void *d_pts, int64_t n, int64_t stride, int32_t ioff, const Mat34 *T, float leaf, int64_t max_out,
                 hipStream_t s, CoJob *J) {
   if (n > 0x7fffffff) return fail(RSX_ERR_RANGE, "more than 2^31-1 points");
-  const int W = workgroups_for(n);
+  const int W = workgroups_for(n, h->device);
   RSX_TRY(h->params.reserve(sizeof(VgParams), s, false));
   RSX_TRY(h->keys.reserve((size_t)n * 4 + 16, s, false));
   RSX_TRY(h->keys2.reserve((size_t)n * 4 + 16, s, false));
@@ -817,6 +830,9 @@ int enqueue(const JobIn *jobs, int njobs, hipStream_t s, DeviceCloud *out) {
     out[k].d_count = &in.h->params.as<VgParams>()->n_out;
   }
   if (njobs == 2) J[1].wg_first = J[0].W;
+  // one grid-barrier kernel at a time per device, ordered on the device (rsx_persistent.h; icp.hip takes the same gate)
+  rsx::persistent::Gate gate(jobs[0].h->device, s);
+  RSX_TRY(gate.status());
   hipLaunchKernelGGL(vg_coop_kernel, dim3((unsigned)(J[0].W + J[1].W)), dim3(CO_NT), 0, s, J[0], J[1]);
   RSX_HIP(hipGetLastError());
   return RSX_OK;

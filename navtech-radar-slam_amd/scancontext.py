@@ -315,23 +315,13 @@ class SCManager:
         return n.value, ms.value
 
     def profile_read_rescoring(self):
-        """-> (exact pair evaluations, queries that scored any candidate) since the last read."""
-        a, b = C.c_int64(), C.c_int64()
-        check(self._L.rsx_sc_profile_read_rescoring(self._h, C.byref(a), C.byref(b)))
-        return a.value, b.value
-
-    def profile_read_rescoring2(self):
-        """-> (candidates through alignment + preview, exact window evaluations, queries that scored any)."""
-        c, a, b = C.c_int64(), C.c_int64(), C.c_int64()
-        check(self._L.rsx_sc_profile_read_rescoring2(self._h, C.byref(c), C.byref(a), C.byref(b)))
-        return c.value, a.value, b.value
-
-    def profile_read_rescoring3(self):
         """-> (candidates, exact window evaluations, queries that scored any, candidates served by the window kernel,
-        candidates that needed a per-wavefront alignment, window shifts evaluated exactly)."""
-        v = (C.c_int64 * 6)()
-        check(self._L.rsx_sc_profile_read_rescoring3(self._h, v))
-        return tuple(int(x) for x in v)
+        candidates that needed a per-wavefront alignment, window shifts evaluated exactly): rsx_sc_rescoring_stats."""
+        from ._rsx import RescoringStats
+        st = RescoringStats()
+        st.struct_size = C.sizeof(RescoringStats)
+        check(self._L.rsx_sc_profile_read_rescoring(self._h, C.byref(st)))
+        return (st.candidates, st.exact_evals, st.queries_rescored, st.window_previews, st.valu_previews, st.exact_window_shifts)
 
     def hit_to_loop(self, hit):
         h = np.zeros(1, dtype=HIT_DTYPE)

@@ -164,3 +164,18 @@ def test_exceptions_thrown_inside_the_library_come_back_as_statuses(rsx):
     assert L.rsx_sc_ringkey_tree_layout(keys.ctypes.data, C.c_int64(1 << 61), vind.ctypes.data, None, None) == -1   # refused, not thrown
     assert L.rsx_sc_ringkey_tree_layout(keys.ctypes.data, C.c_int64(4), vind.ctypes.data, None, None) == 0
     assert sorted(vind.tolist()) == [0, 1, 2, 3]
+
+
+def test_diag_header_is_separate_and_versioned(rsx):
+    """The diagnostic entries live in include/rsx_diag.h, not in the boundary header, and the re-scoring counters come
+    through ONE call with a struct_size-versioned struct (no _rescoring2/_rescoring3 generations)."""
+    main = open(os.path.join(ROOT, "include", "rsx.h")).read()
+    diag = open(os.path.join(ROOT, "include", "rsx_diag.h")).read()
+    for name in ("rsx_sc_profile_read", "rsx_sc_window_previews", "rsx_sc_ringkey_tree_layout", "rsx_selftest_firewall",
+                 "rsx_sc_dominant_kernel_name", "rsx_sc_filter_bounds"):
+        assert name + "(" not in re.sub(r"/\*.*?\*/", "", main, flags=re.S), name
+        assert name + "(" in diag, name
+    assert not re.search(r"rsx_sc_profile_read_rescoring[23]", main + diag)
+    assert C.sizeof(rsx.RescoringStats) == 56
+    L = rsx.lib()
+    assert L.rsx_sc_profile_read_rescoring(None, None) != 0

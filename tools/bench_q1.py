@@ -76,7 +76,7 @@ for n in [int(x) for x in args.sizes.split(",")]:
                     for q0 in range(0, 64, nq):
                         h.query_device(d_q[q0:].data_ptr(), min(nq, 64 - q0), k, full[q0:].data_ptr(), n_eligible=n_elig, stream=st)
                     torch.cuda.synchronize()
-                    r3 = h.profile_read_rescoring3()
+                    r3 = h.profile_read_rescoring()
                     row[name]["stats"] = r3
                     h.profile_enable(False)
             names = list(outs)

@@ -27,4 +27,4 @@ for on in (False, True, False, True):
     torch.cuda.synchronize()
     print(f"counters {'on ' if on else 'off'}: {(time.perf_counter() - t0) / 10 * 1e3:.3f} ms per step")
     if on:
-        m.profile_read_rescoring3()
+        m.profile_read_rescoring()
