@@ -50,6 +50,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -761,7 +762,7 @@ def q1_latency_leg(device, q_descs):
         torch.cuda.synchronize()
         return o
 
-    for n in (32, 1000, 10000, 100000):
+    for n in (32, 1000, 10000, 100000, 200000, 400000):
         descs = synth.random_descriptors(77, n, binary=True)
         h = scancontext.SCManager(device=device, capacity_hint=n + 8)
         h.add_descriptors_f32(descs)
@@ -772,6 +773,22 @@ def q1_latency_leg(device, q_descs):
             out["floor_us"] = dev_us
             out["floor_kernel"] = default_kernel
             h.close()
+            continue
+        if n > 100000:
+            # past the 256 MiB Infinity Cache (the stream is 2672 B per entry: 534 MB at 200 k, 1.07 GB at 400 k): back-to-back
+            # calls re-stream the same database, and at 100 k (267 MB) that could be served on-die -- these two sizes cannot
+            hx = scancontext.SCManager(device=device, capacity_hint=n + 8, filter_mode=1)
+            hx.add_descriptors_f32(descs)
+            same = bool(torch.equal(all_records(hx, 1, 4)[:4], all_records(h, 1, 1)[:4]))
+            hx.close()
+            out[f"n{n}"] = {"us_per_query_stream": dev_us, "queries_per_sec_stream": 1e6 / dev_us, "default_path_kernel": default_kernel,
+                            "first_4_queries_identical_to_exact_all": same,
+                            "algorithmic_bytes": n_elig * ALG_BYTES_PER_PAIR, "bytes_requested": n_elig * 2672,
+                            "hbm_frac": n_elig * ALG_BYTES_PER_PAIR / (dev_us * 1e-6) / (HBM_PEAK_GBS * 1e9),
+                            "hbm_frac_read": n_elig * 2672 / (dev_us * 1e-6) / (HBM_PEAK_GBS * 1e9),
+                            "beyond_infinity_cache": True}
+            h.close()
+            del descs
             continue
         dev_us_k10 = stream_us(h, 10)
         # the host-buffer entry as a C caller pays for it: the C-ABI call alone, argument marshalling outside the loop (the
@@ -1031,6 +1048,64 @@ def roofline_of(wl, launches, kern_ms, n_elig):
                             "fp64-VALU-bound (see DESIGN.md)"}
 
 
+class LegGuard:
+    """N > 1 only.  A secondary leg (another layout, the random / continuous-z / exact-all / 100 k workloads) must never cost the
+    headline: RCCL beyond world 1 has never run on this code (no multi-GPU box in five rounds), and a wedged collective would sit
+    there until the driver's own limit.  Each leg runs under a deadline (RSX_BENCH_LEG_TIMEOUT seconds, default 240).
+      * the leg raises: recorded under `secondary_failures`, the run goes on (if only some ranks raised, the next collective
+        wedges and the deadline of the next leg catches it);
+      * the deadline passes: a rank stuck inside a collective cannot be interrupted, so every rank leaves through os._exit --
+        rank 0 first writes the ONE JSON line with the headline it already holds and the failure recorded.  Exit status 0: the
+        headline is a complete, valid measurement; what is missing says so in the line."""
+
+    def __init__(self, ctx, out, failures, json_fd):
+        self.ctx, self.out, self.failures, self.json_fd = ctx, out, failures, json_fd
+        self.secondary = []
+        self.timeout = float(os.environ.get("RSX_BENCH_LEG_TIMEOUT", "240"))
+        self.active = ctx.world > 1
+        self._lock = threading.Lock()
+
+    def _expire(self, name):
+        with self._lock:
+            msg = f"{name}: no result after {self.timeout:.0f} s (wedged collective?) -- the run was cut here"
+            sys.stderr.write(f"bench.py rank {self.ctx.rank}: {msg}\n")
+            sys.stderr.flush()
+            if self.ctx.rank == 0:
+                self.secondary.append(msg)
+                line = dict(self.out)
+                line["secondary_failures"] = list(self.secondary)
+                line["failures"] = list(self.failures)
+                line["cut_short"] = True
+                os.write(self.json_fd, (json.dumps(line) + "\n").encode())
+            else:
+                time.sleep(1.0)  # rank 0 writes first: the launcher tears the others down when one rank leaves
+            os._exit(0)
+
+    def fault(self, name):
+        """test hook (tests/test_bench_launcher.py, stub backend only): RSX_BENCH_TEST_FAULT = raise:<leg> | sleep:<leg>"""
+        spec = os.environ.get("RSX_BENCH_TEST_FAULT", "")
+        if self.ctx.stub and spec.endswith(":" + name):
+            if spec.startswith("raise:"):
+                raise RuntimeError("injected fault")
+            if spec.startswith("sleep:"):
+                time.sleep(3600)
+
+    def run(self, name, fn):
+        if not self.active:
+            return fn()
+        timer = threading.Timer(self.timeout, self._expire, args=(name,))
+        timer.daemon = True
+        timer.start()
+        try:
+            self.fault(name)
+            return fn()
+        except Exception as e:  # noqa: BLE001
+            self.secondary.append(f"{name}: {type(e).__name__}: {e}"[:300])
+            return None
+        finally:
+            timer.cancel()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1159,19 +1234,18 @@ def main():
             if planted_ok is not None:
                 out["planted_loops_recovered"] = planted_ok
 
+    # every leg below is secondary: at N > 1 each runs under LegGuard (its own try + deadline), so that neither an exception
+    # nor a wedged collective in one of them can cost the headline already in `out`
+    guard = LegGuard(ctx, out, failures, json_fd)
+
     # ---- every layout of this world (query groups x DB shards), same DB, same batch ------------------
     if world > 1 and not args.only_main:
         fill = db_descs if db_descs is not None else descs
         lay = {}
         st_l = max(3, args.steps // 4)
-        for qg in [d for d in range(1, world + 1) if world % d == 0]:
-            if qg not in (1, world, qgroups, auto_qg) and not args.all_layouts:
-                continue   # mixed layouts need torch.distributed subgroups: opt-in (--all-layouts); gloo-tested, never run on RCCL
-            if qg == qgroups:
-                lay[main_wl.ssc.layout] = {"ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
-                                           "exchange_ms_per_step_per_rank": ctx.all_gather_float(main_wl.exchange_ms_per_step), "headline": True}
-                continue
-            wl = Workload(ctx, main_wl.name, k, n_db, query_groups=qg)
+
+        def time_layout(qg=None, filter_shards=False):
+            wl = Workload(ctx, main_wl.name, k, n_db, filter_shards=True) if filter_shards else Workload(ctx, main_wl.name, k, n_db, query_groups=qg)
             wl.add_descriptors(fill)
             wl.set_queries(q_descs, n_elig)
             dtl, prl, _, _ = wl.timed(st_l, 1)
@@ -1179,25 +1253,28 @@ def main():
             if not same:
                 failures.append(f"layout {wl.ssc.layout} disagrees with layout {main_wl.ssc.layout}")
             lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl],
-                                  "exchange_ms_per_step_per_rank": ctx.all_gather_float(wl.exchange_ms_per_step), "identical_to_headline": same,
-                                  "auto_layout": qg == auto_qg}
+                                  "exchange_ms_per_step_per_rank": ctx.all_gather_float(wl.exchange_ms_per_step), "identical_to_headline": same}
+            if not filter_shards:
+                lay[wl.ssc.layout]["auto_layout"] = qg == auto_qg
             wl.close()
+            return True
+
+        for qg in [d for d in range(1, world + 1) if world % d == 0]:
+            if qg not in (1, world, qgroups, auto_qg) and not args.all_layouts:
+                continue   # mixed layouts need torch.distributed subgroups: opt-in (--all-layouts); gloo-tested, never run on RCCL
+            name = f"{qg}x{world // qg}"
+            if qg == qgroups:
+                lay[main_wl.ssc.layout] = {"ms_per_step": dt / args.steps * 1e3, "per_rank_ms_per_step": [t / args.steps * 1e3 for t in per_rank],
+                                           "exchange_ms_per_step_per_rank": guard.run(f"layout {name} (exchange times)", lambda: ctx.all_gather_float(main_wl.exchange_ms_per_step)),
+                                           "headline": True}
+                continue
+            if guard.run(f"layout {name}", lambda qg=qg: time_layout(qg)) is None:
+                lay[name] = {"error": guard.secondary[-1]}
         if not ctx.stub:
             # filter shards over a replicated DB: has run in two processes on one GPU over gloo (tests/test_gpu_sc_layouts.py),
-            # never on RCCL with more than one rank -- a failure here (raised alike on every rank) is recorded, not fatal
-            try:
-                wl = Workload(ctx, main_wl.name, k, n_db, filter_shards=True)
-                wl.add_descriptors(fill)
-                wl.set_queries(q_descs, n_elig)
-                dtl, prl, _, _ = wl.timed(st_l, 1)
-                same = bool(np.array_equal(wl.results(), res))
-                if not same:
-                    failures.append(f"layout {wl.ssc.layout} disagrees with layout {main_wl.ssc.layout}")
-                lay[wl.ssc.layout] = {"ms_per_step": dtl / st_l * 1e3, "per_rank_ms_per_step": [t / st_l * 1e3 for t in prl],
-                                      "exchange_ms_per_step_per_rank": ctx.all_gather_float(wl.exchange_ms_per_step), "identical_to_headline": same}
-                wl.close()
-            except Exception as e:  # noqa: BLE001
-                lay[f"{world}f"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            # never on RCCL with more than one rank
+            if guard.run(f"layout {world}f", lambda: time_layout(filter_shards=True)) is None:
+                lay[f"{world}f"] = {"error": guard.secondary[-1]}
         if rank == 0:
             out["layouts"] = lay
             timed_l = {n: v["ms_per_step"] for n, v in lay.items() if "ms_per_step" in v}
@@ -1211,7 +1288,8 @@ def main():
     # ---- data dependence: the random DB and the exact-all floor, same batch shape --------------
     if not ctx.stub and not args.only_main:
         dd = {}
-        if args.data == "trajectory":
+
+        def leg_random_db():
             descs, rq, r_src, r_rot = random_db_and_queries(n_db, nq)
             wl = Workload(ctx, "random", k, n_db, query_groups=qgroups)
             wl.add_descriptors(descs)
@@ -1228,10 +1306,11 @@ def main():
                                "planted_loops_recovered": rp,
                                "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n_db}_random (round-1 headline data)"}
             wl.close()
-            del descs, rq
+            return True
+
         # the continuous-z family of SURVEY 8d "value distributions": the same drive with every landmark at its own height
         # (z ~ U(-1, 4): non-binary descriptors, no exact ties), DB and queries through the build path, oracle-checked
-        if args.data == "trajectory":
+        def leg_continuous_z():
             c_pts, c_off, cq_pts, cq_off, _ = synth.trajectory_keyframes(1234, n_db, 4321, nq, binary_z=False)
             cb = scancontext.SCManager(device=ctx.local_rank, capacity_hint=n_db + nq + 8)
             for i in range(n_db):
@@ -1262,52 +1341,62 @@ def main():
                 if ident != n_chk:
                     failures.append("continuous-z trajectory: GPU top-k differs from the oracle")
             wl.close()
-            del c_pts, cq_pts, c_all
+            return True
+
         # exact-all: filter off, every (query, entry) pair through the fp64 pair kernel
-        wl = Workload(ctx, "exact_all", k, n_db, filter_mode=1, query_groups=qgroups)
-        wl.add_descriptors(db_descs)
-        wl.set_queries(q_descs, n_elig)
-        dte, _, _, _ = wl.timed(3, 1)
-        same = bool(np.array_equal(wl.results(), res))
-        if not same:
-            failures.append("filtered path and exact-all path disagree")
-        dd["exact_all_floor"] = {"queries_per_sec": nq * 3 / dte, "ms_per_step": dte / 3 * 1e3,
-                                 "exact_evals_per_query": float(len(range(wl.ssc.shard_rank, n_elig, wl.ssc.shard_world))),
-                                 "identical_to_filtered_path": same,
-                                 "note": "filter_mode = 1: every eligible pair scored by the exact fp64 kernel -- what the path "
-                                         "costs when the data lets the filter prune nothing"}
-        wl.close()
+        def leg_exact_all():
+            wl = Workload(ctx, "exact_all", k, n_db, filter_mode=1, query_groups=qgroups)
+            wl.add_descriptors(db_descs)
+            wl.set_queries(q_descs, n_elig)
+            dte, _, _, _ = wl.timed(3, 1)
+            same = bool(np.array_equal(wl.results(), res))
+            if not same:
+                failures.append("filtered path and exact-all path disagree")
+            dd["exact_all_floor"] = {"queries_per_sec": nq * 3 / dte, "ms_per_step": dte / 3 * 1e3,
+                                     "exact_evals_per_query": float(len(range(wl.ssc.shard_rank, n_elig, wl.ssc.shard_world))),
+                                     "identical_to_filtered_path": same,
+                                     "note": "filter_mode = 1: every eligible pair scored by the exact fp64 kernel -- what the path "
+                                             "costs when the data lets the filter prune nothing"}
+            wl.close()
+            return True
+
         # 100k-keyframe DB: where DB shards pay
-        n100 = 100000
-        d100, q100, s100, r100 = random_db_and_queries(n100, nq, seed_db=2234, seed_q=5321)
-        wl = Workload(ctx, "random100k", k, n100, query_groups=qgroups)
-        wl.add_descriptors(d100)
-        wl.set_queries(q100, n100 - 30)
-        st100 = max(3, args.steps // 4)
-        dt100, pr100, _, (ev100, cd100) = wl.timed(st100, 2, profile=True)
-        r = wl.results()
-        ok = s100 < n100 - 30
-        p100 = bool(np.all(r["index"][ok, 0] == s100[ok]) and np.all(r["shift"][ok, 0] == r100[ok]))
-        if not p100:
-            failures.append("100k DB: planted loops not recovered as top-1")
-        wl.close()
-        emu100 = None
-        if world == 1 and not ctx.stub:
-            # BASELINE configs[4]: the per-layout figures for the DB size where sharding is supposed to pay
-            emu100 = layout_emulation_leg(ctx.local_rank, d100, q100, n100 - 30, k, res=r, reps=3)
-            if emu100["filter_shard_records_identical"] is False:
-                failures.append("layout emulation (100k): the filter-shard layout's records differ from the unsharded ones")
-        del d100
-        if rank == 0:
-            out["data_dependence"] = dd
-            if emu100 is not None:
+        def leg_100k():
+            n100 = 100000
+            d100, q100, s100, r100 = random_db_and_queries(n100, nq, seed_db=2234, seed_q=5321)
+            wl = Workload(ctx, "random100k", k, n100, query_groups=qgroups)
+            wl.add_descriptors(d100)
+            wl.set_queries(q100, n100 - 30)
+            st100 = max(3, args.steps // 4)
+            dt100, pr100, _, (ev100, cd100) = wl.timed(st100, 2, profile=True)
+            r = wl.results()
+            ok = s100 < n100 - 30
+            p100 = bool(np.all(r["index"][ok, 0] == s100[ok]) and np.all(r["shift"][ok, 0] == r100[ok]))
+            if not p100:
+                failures.append("100k DB: planted loops not recovered as top-1")
+            wl.close()
+            if world == 1 and not ctx.stub:
+                # BASELINE configs[4]: the per-layout figures for the DB size where sharding is supposed to pay
+                emu100 = layout_emulation_leg(ctx.local_rank, d100, q100, n100 - 30, k, res=r, reps=3)
+                if emu100["filter_shard_records_identical"] is False:
+                    failures.append("layout emulation (100k): the filter-shard layout's records differ from the unsharded ones")
                 out["layout_emulation_100k"] = emu100
-            out["scale_100k"] = {"value": nq * st100 / dt100, "unit": "queries/s", "ms_per_step": dt100 / st100 * 1e3, "steps": st100,
-                                 "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n100}_random", "n_gpus": world, "scaling": "strong",
-                                 "layout": f"{qgroups}x{world // qgroups}",
-                                 "per_rank_ms_per_step": [t / st100 * 1e3 for t in pr100],
-                                 "exact_evals_per_query": ev100 / (nq * st100), "previewed_candidates_per_query": cd100 / (nq * st100),
-                                 "planted_loops_recovered": p100}
+            if rank == 0:
+                out["scale_100k"] = {"value": nq * st100 / dt100, "unit": "queries/s", "ms_per_step": dt100 / st100 * 1e3, "steps": st100,
+                                     "workload": f"scancontext_exhaustive_top{k}_q{nq}_db{n100}_random", "n_gpus": world, "scaling": "strong",
+                                     "layout": f"{qgroups}x{world // qgroups}",
+                                     "per_rank_ms_per_step": [t / st100 * 1e3 for t in pr100],
+                                     "exact_evals_per_query": ev100 / (nq * st100), "previewed_candidates_per_query": cd100 / (nq * st100),
+                                     "planted_loops_recovered": p100}
+            return True
+
+        if args.data == "trajectory":
+            guard.run("data_dependence random_db", leg_random_db)
+            guard.run("data_dependence trajectory_continuous_z", leg_continuous_z)
+        guard.run("data_dependence exact_all_floor", leg_exact_all)
+        if rank == 0:
+            out["data_dependence"] = dd   # (filled in place by the legs above; scale_100k below is its own key)
+        guard.run("scale_100k", leg_100k)
 
     if rank == 0 and not ctx.stub:
         if not args.only_main and world == 1:
@@ -1335,6 +1424,9 @@ def main():
                 lq = out["latency_q1"][nm]
                 if not (lq["forced_paths_identical"] and lq["records_identical_2_to_8_queries_per_call"]):
                     failures.append(f"latency_q1 {nm}: the single-query path, the exact-all path and the filter chain disagree")
+            for nm in ("n200000", "n400000"):
+                if not out["latency_q1"][nm]["first_4_queries_identical_to_exact_all"]:
+                    failures.append(f"latency_q1 {nm}: the single-query path and the exact-all path disagree")
             out["orora"] = orora_leg(ctx.local_rank, args.no_cpu_baseline)
             out["cen2019"] = cen2019_leg(ctx.local_rank)
             out["icp"] = icp_leg(ctx.local_rank)
@@ -1364,6 +1456,8 @@ def main():
                 failures.append(f"GPU top-{k} differs from the oracle on query {chk['first_mismatch']}")
     if rank == 0:
         out["failures"] = failures
+        if guard.secondary:
+            out["secondary_failures"] = guard.secondary
         # BASELINE.json:metric has two halves ("SC loop-queries/sec ... + ORORA scan-pairs/sec"): the second one (and the
         # figures of the stages that feed it) ride inside `config`, the object every record of this line keeps whole
         sec = {}

@@ -330,6 +330,10 @@ typedef struct {
 } rsx_orora_params;
 #define RSX_ORORA_COMPLETE_GRAPH 1 /* rotation TIMs on all K (K-1) / 2 pairs instead of the ring of K (O(K^2) per GNC iteration) */
 #define RSX_ORORA_TEASER_COST 2    /* scalar TLS cost in TEASER++'s form: unweighted residuals + sum of the outliers' bounds */
+#define RSX_ORORA_PMC 4            /* max-clique inlier selection before the solver (upstream: "PMC max-clique prune"): the matches are
+                                      pruned to a maximum clique of the consistency graph  i ~ j  <=>
+                                      | ||src_i - src_j|| - ||dst_i - dst_j|| | < tim_noise_bound  (csrc/pmc.hip, oracle/pmc_ref.h).
+                                      rsx_odometry_default_params turns it on; the device entry needs rsx_orora_reserve first */
 
 typedef struct {
   double x, y, yaw;      /* dst = R(yaw) src + (x, y) */
@@ -341,8 +345,34 @@ typedef struct {
                             run on-chip (LDS), larger ones through an HBM workspace: same results */
 } rsx_orora_result;
 
+/* what the selection did to one pair */
+typedef struct {
+  int32_t size;     /* matches handed to the solver */
+  int32_t max_core; /* largest core number of the consistency graph: no clique is larger than max_core + 1 */
+  int32_t seeds;    /* greedy seeds started (<= 4) */
+  int32_t flags;    /* RSX_ORORA_PMC_* */
+} rsx_orora_pmc_info;
+#define RSX_ORORA_PMC_PROVEN 1       /* size == max_core + 1: the clique is a maximum one */
+#define RSX_ORORA_PMC_PASSTHROUGH 2  /* fewer than 2 or more than rsx_orora_max_clique_matches() matches: not pruned */
+#define RSX_ORORA_PMC_NO_WORKSPACE 4 /* (with PASSTHROUGH) the pair did not fit what rsx_orora_reserve sized: not pruned */
+
 int rsx_orora_default_params(rsx_orora_params *p);
 int rsx_orora_max_correspondences(void);
+int rsx_orora_max_clique_matches(void); /* 2048: pairs with more matches go to the solver unpruned */
+/* Sizes the workspaces of the RSX_ORORA_PMC stage for calls of up to max_total_matches matches (sum over the pairs of a call), so
+ * that the asynchronous device entry never allocates.  The host-buffer entries size them by themselves. */
+int rsx_orora_reserve(rsx_orora *h, int64_t max_total_matches);
+/* The selection on its own (params->tim_noise_bound is the consistency bound; NULL = defaults): out_member[m] = 1 for the
+ * matches kept, laid out like the matches; out_info[n_pairs] (either may be NULL).  Host buffers, synchronous. */
+int rsx_orora_max_clique_batch(rsx_orora *h, const float *src_xy, const float *dst_xy, const int64_t *offsets, int32_t n_pairs,
+                               const rsx_orora_params *params, uint8_t *out_member, rsx_orora_pmc_info *out_info);
+/* device buffers, asynchronous on `stream` */
+int rsx_orora_max_clique_batch_device(rsx_orora *h, const float *d_src_xy, const float *d_dst_xy, const int64_t *d_offsets,
+                                      int32_t n_pairs, const rsx_orora_params *params, uint8_t *d_member, rsx_orora_pmc_info *d_info,
+                                      void *stream);
+/* the info records of the last rsx_orora_register_batch{,_device} call that ran with RSX_ORORA_PMC (synchronises the handle's
+ * last stream; n_pairs as in that call) */
+int rsx_orora_last_pmc_info(rsx_orora *h, rsx_orora_pmc_info *out_info, int32_t n_pairs);
 int rsx_orora_create(int device, rsx_orora **out);
 int rsx_orora_destroy(rsx_orora *h);
 /* n_pairs scan pairs; pair i owns matches [offsets[i], offsets[i+1]) of the concatenated

@@ -52,6 +52,11 @@ class RescoringStats(C.Structure):  # rsx_sc_rescoring_stats (include/rsx_diag.h
                 ("exact_window_shifts", C.c_int64)]
 
 
+ORORA_PMC = 4  # rsx_orora_params.flags: max-clique inlier selection before the solver
+ORORA_PMC_PROVEN, ORORA_PMC_PASSTHROUGH, ORORA_PMC_NO_WORKSPACE = 1, 2, 4
+PMC_INFO_DTYPE = np.dtype([("size", "<i4"), ("max_core", "<i4"), ("seeds", "<i4"), ("flags", "<i4")])
+
+
 class ScDetection(C.Structure):
     _fields_ = [("loop_id", C.c_int32), ("yaw_diff_rad", C.c_float), ("min_dist", C.c_double), ("nn_idx", C.c_int32),
                 ("query_idx", C.c_int32), ("searched", C.c_int32), ("reserved", C.c_int32), ("dist_thres", C.c_double)]
@@ -131,7 +136,8 @@ SYMBOLS = [
     "rsx_scs_add_points", "rsx_scs_add_descriptors_f32", "rsx_scs_get_descriptor", "rsx_scs_query",
     "rsx_scs_detect_loop_closure",
     "rsx_orora_default_params", "rsx_orora_max_correspondences", "rsx_orora_create", "rsx_orora_destroy",
-    "rsx_orora_register_batch", "rsx_orora_register_batch_device",
+    "rsx_orora_register_batch", "rsx_orora_register_batch_device", "rsx_orora_max_clique_matches", "rsx_orora_reserve",
+    "rsx_orora_max_clique_batch", "rsx_orora_max_clique_batch_device", "rsx_orora_last_pmc_info",
     "rsx_cen2019_default_params", "rsx_cen2019_create", "rsx_cen2019_destroy", "rsx_cen2019_extract",
     "rsx_cen2019_extract_batch", "rsx_cen2019_extract_batch_device",
     "rsx_frontend_default_params", "rsx_frontend_create", "rsx_frontend_destroy", "rsx_frontend_cartesian",
@@ -229,6 +235,10 @@ def lib():
         L.rsx_orora_destroy.argtypes = [vp]
         L.rsx_orora_register_batch.argtypes = [vp, vp, vp, vp, i32, C.POINTER(OroraParams), vp]
         L.rsx_orora_register_batch_device.argtypes = [vp, vp, vp, vp, i32, C.POINTER(OroraParams), vp, vp]
+        L.rsx_orora_reserve.argtypes = [vp, i64]
+        L.rsx_orora_max_clique_batch.argtypes = [vp, vp, vp, vp, i32, C.POINTER(OroraParams), vp, vp]
+        L.rsx_orora_max_clique_batch_device.argtypes = [vp, vp, vp, vp, i32, C.POINTER(OroraParams), vp, vp, vp]
+        L.rsx_orora_last_pmc_info.argtypes = [vp, vp, i32]
         L.rsx_cen2019_default_params.argtypes = [C.POINTER(Cen2019Params)]
         L.rsx_cen2019_create.argtypes = [C.c_int, i32, i32, C.POINTER(vp)]
         L.rsx_cen2019_destroy.argtypes = [vp]

@@ -10,7 +10,8 @@
 //     rsx_frontend_describe_batch_device        n keypoint sets
 //     rsx_frontend_match_consecutive_device     all consecutive pairs, both directions
 //     odo_cross / odo_gather                    cross check (the two directions must agree) + correspondence lists
-//     rsx_orora_register_batch_device           all pairs of the window in one call (csrc/orora.hip)
+//     rsx_orora_register_batch_device           all pairs of the window in one call (csrc/orora.hip): max-clique inlier
+//                                               selection (csrc/pmc.hip, RSX_ORORA_PMC: on by default here) + the solver
 // -- with every intermediate (keypoints, descriptors, matches, correspondences) in HBM; one upload of the images and one
 // download of 48 bytes per scan (+ the keypoints when the caller wants /orora/cloud_local).  The last scan of a window
 // stays on the device as the "previous scan" of the next one.  Pose composition stays on the host (sequential, trivial).
@@ -246,6 +247,7 @@ int rsx_odometry_default_params(rsx_odometry_params *p) try {
   rsx_cen2019_default_params(&p->cen);
   rsx_frontend_default_params(&p->frontend);
   rsx_orora_default_params(&p->orora);
+  p->orora.flags |= RSX_ORORA_PMC;  // the upstream pipeline prunes the matches to the max clique before the solver (csrc/pmc.hip)
   p->radar_resolution = 0.0595f;  // Navtech CIR204-H range bin [m] (MulRan)
   p->col_offset = 11;             // metadata bytes in front of every polar_oxford_form row
   p->max_keypoints = 16384;  // = rsx_orora_max_correspondences(): a pair can never exceed the solver's capacity
@@ -271,6 +273,7 @@ int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t
   int st = rsx_cen2019_create(p.device, rows, cols, &h->cen);
   if (st == RSX_OK) st = rsx_frontend_create(p.device, rows, cols, &p.frontend, &h->fe);
   if (st == RSX_OK) st = rsx_orora_create(p.device, &h->reg);
+  if (st == RSX_OK && (p.orora.flags & RSX_ORORA_PMC)) st = rsx_orora_reserve(h->reg, (int64_t)MAX_WINDOW * p.max_keypoints);
   if (st == RSX_OK) {
     hipError_t e = hipSetDevice(p.device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);

@@ -19,6 +19,7 @@
 #include <new>
 
 #include "rsx_common.h"
+#include "pmc.h"
 
 namespace {
 
@@ -708,6 +709,24 @@ __device__ void register_pair(const float2 *__restrict__ src, const float2 *__re
   OPROF(3);
 }
 
+// the max-clique inlier selection (csrc/pmc.hip), when the call asked for it: pair i's selected matches lie at
+// [offsets[i], offsets[i] + cnt[i]) of the sel arrays, in their original order; cnt[i] < 0 = the pair passed through
+// unpruned (fewer than 2 / more than 2048 matches): the solver reads the caller's arrays
+struct Selection {
+  const float2 *src, *dst;
+  const int32_t *cnt;
+  __device__ __forceinline__ void apply(int pair, const float2 *&s, const float2 *&d, int64_t &k) const {
+    if (cnt) {
+      const int c = cnt[pair];
+      if (c >= 0) {
+        k = c;
+        s = src;
+        d = dst;
+      }
+    }
+  }
+};
+
 using LdsLayout = Layout<256, MAXK_LDS>;
 constexpr int LDS_TOTAL = LdsLayout::TOTAL + LDS_RED;
 static_assert(2 * LDS_TOTAL <= 160 * 1024, "LDS budget: two workgroups per CU");
@@ -715,12 +734,14 @@ static_assert(2 * LDS_TOTAL <= 160 * 1024, "LDS budget: two workgroups per CU");
 // on-chip kernel: one workgroup per pair; pairs that do not fit are written to the big list
 __global__ __launch_bounds__(256, 2) void orora_register_kernel(const float2 *__restrict__ src, const float2 *__restrict__ dst,
                                                              const int64_t *__restrict__ offsets, int n_pairs, Params p,
-                                                             rsx_orora_result *__restrict__ out, int *__restrict__ big_list) {
+                                                             rsx_orora_result *__restrict__ out, int *__restrict__ big_list, Selection sel) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int pair = blockIdx.x;
   if (pair >= n_pairs) return;
   const int64_t o = offsets[pair];
-  const int64_t K64 = offsets[pair + 1] - o;
+  int64_t K64 = offsets[pair + 1] - o;
+  const float2 *ps = src, *pd = dst;
+  sel.apply(pair, ps, pd, K64);
   if (K64 < 2 || K64 > MAXK_LDS) {
     if (threadIdx.x == 0) {
       if (K64 > MAXK_LDS && K64 <= MAXK_BIG) {
@@ -735,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void orora_register_kernel(const float2 *__
     }
     return;
   }
-  register_pair<256, MAXK_LDS>(src, dst, o, (int)K64, p, smem, reinterpret_cast<double *>(smem + LdsLayout::TOTAL), out + pair);
+  register_pair<256, MAXK_LDS>(ps, pd, o, (int)K64, p, smem, reinterpret_cast<double *>(smem + LdsLayout::TOTAL), out + pair);
 }
 
 using BigLayout = Layout<1024, MAXK_BIG>;
@@ -745,14 +766,17 @@ constexpr int BIG_BLOCKS = 32;
 __global__ __launch_bounds__(1024) void orora_register_big_kernel(const float2 *__restrict__ src, const float2 *__restrict__ dst,
                                                                   const int64_t *__restrict__ offsets, Params p,
                                                                   rsx_orora_result *__restrict__ out, const int *__restrict__ big_list,
-                                                                  char *__restrict__ workspace) {
+                                                                  char *__restrict__ workspace, Selection sel) {
   __shared__ double red_lds[48];
   const int n_big = big_list[0];
   char *ws = workspace + (size_t)blockIdx.x * BigLayout::TOTAL;
   for (int b = blockIdx.x; b < n_big; b += gridDim.x) {
     const int pair = big_list[1 + b];
     const int64_t o = offsets[pair];
-    register_pair<1024, MAXK_BIG>(src, dst, o, (int)(offsets[pair + 1] - o), p, ws, red_lds, out + pair);
+    int64_t K64 = offsets[pair + 1] - o;
+    const float2 *ps = src, *pd = dst;
+    sel.apply(pair, ps, pd, K64);
+    register_pair<1024, MAXK_BIG>(ps, pd, o, (int)K64, p, ws, red_lds, out + pair);
   }
 }
 
@@ -764,8 +788,24 @@ struct rsx_orora {
   hipStream_t stream = nullptr;
   rsx::DevBuf src, dst, off, res;
   rsx::DevBuf big_list, big_ws;  // pairs of more than 2048 matches: their indices, and the HBM arrays of the workgroups that score them
+  // RSX_ORORA_PMC: the selection's workspaces (csrc/pmc.hip) and what it hands to the solver
+  rsx::pmc::Workspace pmc_ws;
+  rsx::DevBuf sel_src, sel_dst, sel_cnt, pmc_info, member;
+  int64_t sel_cap = 0;             // matches sel_src / sel_dst hold (rsx_orora_reserve)
+  hipStream_t last_stream = nullptr;  // of the last PMC call (rsx_orora_last_pmc_info waits for it)
+  int32_t last_pmc_pairs = 0;
   bool attr_set = false;
 };
+
+namespace {
+int reserve_selection(rsx_orora *h, int64_t total, hipStream_t s) {
+  if (total <= h->sel_cap) return RSX_OK;
+  RSX_TRY(h->sel_src.reserve((size_t)total * 8, s, false));
+  RSX_TRY(h->sel_dst.reserve((size_t)total * 8, s, false));
+  h->sel_cap = (int64_t)(h->sel_src.bytes < h->sel_dst.bytes ? h->sel_src.bytes : h->sel_dst.bytes) / 8;
+  return RSX_OK;
+}
+}  // namespace
 
 using rsx::fail;
 
@@ -814,6 +854,7 @@ int rsx_orora_destroy(rsx_orora *h) try {
   h->res.release();
   h->big_list.release();
   h->big_ws.release();
+  for (rsx::DevBuf *b : {&h->pmc_ws.slabs, &h->pmc_ws.counter, &h->sel_src, &h->sel_dst, &h->sel_cnt, &h->pmc_info, &h->member}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
@@ -850,12 +891,25 @@ int rsx_orora_register_batch_device(rsx_orora *h, const float *d_src_xy, const f
   RSX_TRY(h->big_list.reserve((size_t)(n_pairs + 1) * sizeof(int), s, false));
   RSX_TRY(h->big_ws.reserve((size_t)BIG_BLOCKS * BigLayout::TOTAL, s, false));
   RSX_HIP(hipMemsetAsync(h->big_list.p, 0, sizeof(int), s));
+  Selection sel{nullptr, nullptr, nullptr};
+  if (dp.flags & RSX_ORORA_PMC) {
+    // max-clique inlier selection first (csrc/pmc.hip): the solver then reads each pair's selected matches
+    if (h->sel_cap <= 0) return fail(RSX_ERR_BAD_ARG, "RSX_ORORA_PMC on the device entry needs rsx_orora_reserve(max_total_matches) first");
+    RSX_TRY(h->sel_cnt.reserve((size_t)n_pairs * 4, s, false));
+    RSX_TRY(h->pmc_info.reserve((size_t)n_pairs * sizeof(rsx_orora_pmc_info), s, false));
+    RSX_TRY(rsx::pmc::launch(h->pmc_ws, h->device, reinterpret_cast<const float2 *>(d_src_xy), reinterpret_cast<const float2 *>(d_dst_xy),
+                             d_offsets, n_pairs, dp.tim_noise_bound, nullptr, h->pmc_info.as<rsx_orora_pmc_info>(), h->sel_src.as<float2>(),
+                             h->sel_dst.as<float2>(), h->sel_cnt.as<int32_t>(), h->sel_cap, s));
+    sel = Selection{h->sel_src.as<float2>(), h->sel_dst.as<float2>(), h->sel_cnt.as<int32_t>()};
+    h->last_stream = s;
+    h->last_pmc_pairs = n_pairs;
+  }
   hipLaunchKernelGGL(orora_register_kernel, dim3(n_pairs), dim3(256), LDS_TOTAL, s,
                      reinterpret_cast<const float2 *>(d_src_xy), reinterpret_cast<const float2 *>(d_dst_xy), d_offsets,
-                     n_pairs, kp, d_out, h->big_list.as<int>());
+                     n_pairs, kp, d_out, h->big_list.as<int>(), sel);
   hipLaunchKernelGGL(orora_register_big_kernel, dim3(BIG_BLOCKS), dim3(1024), 0, s,
                      reinterpret_cast<const float2 *>(d_src_xy), reinterpret_cast<const float2 *>(d_dst_xy), d_offsets, kp, d_out,
-                     h->big_list.as<int>(), h->big_ws.as<char>());
+                     h->big_list.as<int>(), h->big_ws.as<char>(), sel);
   RSX_HIP(hipGetLastError());
 #if RSX_ORORA_PROF
   {
@@ -885,6 +939,7 @@ int rsx_orora_register_batch(rsx_orora *h, const float *src_xy, const float *dst
     RSX_TRY(h->dst.reserve((size_t)(m ? m : 1) * 8, s, false));
     RSX_TRY(h->off.reserve((size_t)(n_pairs + 1) * 8, s, false));
     RSX_TRY(h->res.reserve((size_t)n_pairs * sizeof(rsx_orora_result), s, false));
+    if (params && (params->flags & RSX_ORORA_PMC)) RSX_TRY(reserve_selection(h, m ? m : 1, s));
     if (m) {
       RSX_HIP(hipMemcpyAsync(h->src.p, src_xy, (size_t)m * 8, hipMemcpyHostToDevice, s));
       RSX_HIP(hipMemcpyAsync(h->dst.p, dst_xy, (size_t)m * 8, hipMemcpyHostToDevice, s));
@@ -896,6 +951,70 @@ int rsx_orora_register_batch(rsx_orora *h, const float *src_xy, const float *dst
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipMemcpyAsync(out, h->res.p, (size_t)n_pairs * sizeof(rsx_orora_result), hipMemcpyDeviceToHost, h->stream));
   RSX_HIP(hipStreamSynchronize(h->stream));
+  return RSX_OK;
+} RSX_CATCH_ALL
+
+int rsx_orora_max_clique_matches(void) { return rsx::pmc::MAX_K; }
+
+int rsx_orora_reserve(rsx_orora *h, int64_t max_total_matches) try {
+  if (!h || max_total_matches < 1) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipSetDevice(h->device));
+  return reserve_selection(h, max_total_matches, h->stream);
+} RSX_CATCH_ALL
+
+int rsx_orora_max_clique_batch_device(rsx_orora *h, const float *d_src_xy, const float *d_dst_xy, const int64_t *d_offsets, int32_t n_pairs,
+                                      const rsx_orora_params *params, uint8_t *d_member, rsx_orora_pmc_info *d_info, void *stream) try {
+  if (!h || !d_src_xy || !d_dst_xy || !d_offsets || n_pairs < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (n_pairs == 0) return RSX_OK;
+  rsx_orora_params dp;
+  rsx_orora_default_params(&dp);
+  if (params) dp = *params;
+  std::lock_guard<std::mutex> lk(h->mu);
+  RSX_HIP(hipSetDevice(h->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+  return rsx::pmc::launch(h->pmc_ws, h->device, reinterpret_cast<const float2 *>(d_src_xy), reinterpret_cast<const float2 *>(d_dst_xy), d_offsets,
+                          n_pairs, dp.tim_noise_bound, d_member, d_info, nullptr, nullptr, nullptr, 0, s);
+} RSX_CATCH_ALL
+
+int rsx_orora_max_clique_batch(rsx_orora *h, const float *src_xy, const float *dst_xy, const int64_t *offsets, int32_t n_pairs,
+                               const rsx_orora_params *params, uint8_t *out_member, rsx_orora_pmc_info *out_info) try {
+  if (!h || !src_xy || !dst_xy || !offsets || n_pairs < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (n_pairs == 0) return RSX_OK;
+  const int64_t m = offsets[n_pairs];
+  if (m < 0 || offsets[0] != 0) return fail(RSX_ERR_BAD_ARG, "offsets must start at 0 and be non-decreasing");
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    RSX_HIP(hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    RSX_TRY(h->src.reserve((size_t)(m ? m : 1) * 8, s, false));
+    RSX_TRY(h->dst.reserve((size_t)(m ? m : 1) * 8, s, false));
+    RSX_TRY(h->off.reserve((size_t)(n_pairs + 1) * 8, s, false));
+    RSX_TRY(h->member.reserve((size_t)(m ? m : 1), s, false));
+    RSX_TRY(h->pmc_info.reserve((size_t)n_pairs * sizeof(rsx_orora_pmc_info), s, false));
+    if (m) {
+      RSX_HIP(hipMemcpyAsync(h->src.p, src_xy, (size_t)m * 8, hipMemcpyHostToDevice, s));
+      RSX_HIP(hipMemcpyAsync(h->dst.p, dst_xy, (size_t)m * 8, hipMemcpyHostToDevice, s));
+    }
+    RSX_HIP(hipMemcpyAsync(h->off.p, offsets, (size_t)(n_pairs + 1) * 8, hipMemcpyHostToDevice, s));
+  }
+  RSX_TRY(rsx_orora_max_clique_batch_device(h, h->src.as<float>(), h->dst.as<float>(), h->off.as<int64_t>(), n_pairs, params,
+                                            h->member.as<uint8_t>(), h->pmc_info.as<rsx_orora_pmc_info>(), h->stream));
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (out_member && m) RSX_HIP(hipMemcpyAsync(out_member, h->member.p, (size_t)m, hipMemcpyDeviceToHost, h->stream));
+  if (out_info) RSX_HIP(hipMemcpyAsync(out_info, h->pmc_info.p, (size_t)n_pairs * sizeof(rsx_orora_pmc_info), hipMemcpyDeviceToHost, h->stream));
+  RSX_HIP(hipStreamSynchronize(h->stream));
+  return RSX_OK;
+} RSX_CATCH_ALL
+
+int rsx_orora_last_pmc_info(rsx_orora *h, rsx_orora_pmc_info *out_info, int32_t n_pairs) try {
+  if (!h || !out_info || n_pairs < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (n_pairs > h->last_pmc_pairs) return fail(RSX_ERR_BAD_ARG, "the last RSX_ORORA_PMC call had %d pairs", h->last_pmc_pairs);
+  if (n_pairs == 0) return RSX_OK;
+  RSX_HIP(hipSetDevice(h->device));
+  RSX_HIP(hipStreamSynchronize(h->last_stream));
+  RSX_HIP(hipMemcpy(out_info, h->pmc_info.p, (size_t)n_pairs * sizeof(rsx_orora_pmc_info), hipMemcpyDeviceToHost));
   return RSX_OK;
 } RSX_CATCH_ALL
 

@@ -1,0 +1,354 @@
+// pmc.hip -- max-clique inlier selection on gfx950: the stage between the matcher and the ORORA solver ("PMC max-clique
+// prune").  Upstream takes it from TEASER++ / the PMC library; neither is in the reference
+// checkout (the ORORA submodule is an empty directory: /root/reference/.gitmodules:1-3, README.md:19,26-29), so this follows
+// the construction restated in oracle/pmc_ref.{h,c} -- PARITY UNPINNED -- and reproduces that oracle's selection exactly.
+//
+//   consistency graph   vertices = the K matches of a pair; i ~ j iff | ||src_i - src_j|| - ||dst_i - dst_j|| | < tau, evaluated
+//                       without square roots in fp64 (pmc_ref.h: s = (A + B) - tau^2; edge <=> s < 0 || s^2 < 4 A B)
+//   core numbers        level-synchronous peeling (exact; the result is unique)
+//   greedy clique       seeds and candidates in (core descending, index ascending) order, <= MAX_SEEDS seeds
+//
+// Mapping.  One 256-thread workgroup per pair, pairs pulled from a queue (their cost goes with K^2: 300 .. 1500 matches in
+// the bench).  A VERTEX SET IS ONE REGISTER PER LANE OF A WAVEFRONT: 64 lanes x 32 bits = 2048 vertices, vertex u = bit
+// u / 64 of lane u % 64 (lane-interleaved, so that lane l of the adjacency build reads points l, 64 + l, ...: consecutive LDS
+// addresses).  Set intersection = one v_and against a 256-byte adjacency row (one coalesced load), |P| = v_bcnt + a wave
+// reduction, "is u in P" = v_readlane + shift.  The adjacency of the pair in flight lives in a 512 KB slab of HBM per
+// resident workgroup (L2 / Infinity Cache resident: written once, read once by the peeling and once per picked vertex).
+//   phase A  4 waves, row i of the graph per wave iteration: 64 lanes x ceil(K / 64) columns of the fp64 predicate -> one
+//            word per lane -> one 256-byte row store; degree by popcount
+//   phase B  core numbers: frontier = alive vertices of degree <= level (all threads), each frontier vertex's row & alive
+//            decrements its neighbours' degrees (LDS atomics, a wave per frontier vertex); empty frontier -> level = the
+//            smallest remaining degree
+//   phase C  bitonic sort of (2047 - core) << 11 | index in LDS -> `order`
+//   phase D  wave 0: the greedy walk.  64 candidates of `order` are tested against P at once (ds_bpermute + ballot), the rows
+//            of the next four members are loaded together, each is re-tested against the shrinking P before it joins
+//   output   member flags, the selected matches compacted in their original order for the solver, one info record
+// Roofline: the build is fp64-VALU bound (K^2 / 2 ... K^2 predicates of ~20 fp64 operations per pair); the walk is a
+// dependent chain per pair (load row -> and -> popcount), hidden by running 3 workgroups per CU.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "pmc.h"
+
+namespace {
+
+using rsx::pmc::MAX_K;
+using rsx::pmc::MAX_SEEDS;
+constexpr int NT = 256;
+constexpr int ROWW = 64;  // words per adjacency row
+
+struct Args {
+  const float2 *src, *dst;
+  const int64_t *offsets;
+  int n_pairs;
+  double tau2;
+  uint32_t *slabs;
+  unsigned *counter;
+  uint8_t *member;
+  rsx_orora_pmc_info *info;
+  float2 *sel_src, *sel_dst;
+  int32_t *sel_cnt;
+  int64_t sel_cap;  // matches the sel arrays hold
+};
+
+struct Lds {
+  float2 src[MAX_K];  // phase A; afterwards: the sort keys (uint32_t[MAX_K])
+  float2 dst[MAX_K];  // phase A; afterwards: the frontier list (uint16_t[MAX_K])
+  int deg[MAX_K];
+  uint16_t core[MAX_K];
+  uint32_t alive[ROWW];
+  uint32_t best[ROWW];
+  int red[8];
+  int nfront, level, max_core, pair, best_n, seeds;
+};
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
+  return v;
+}
+
+// the edge predicate of oracle/pmc_ref.h, operation for operation (this file is compiled with -ffp-contract=off)
+__device__ __forceinline__ bool edge(double six, double siy, double dix, double diy, float2 sj, float2 dj, double tau2) {
+  const double dax = (double)sj.x - six, day = (double)sj.y - siy;
+  const double dbx = (double)dj.x - dix, dby = (double)dj.y - diy;
+  const double A = dax * dax + day * day;
+  const double B = dbx * dbx + dby * dby;
+  const double sm = (A + B) - tau2;
+  return (sm < 0.0) || (sm * sm < 4.0 * (A * B));
+}
+
+__global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
+  __shared__ Lds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  uint32_t *adj = a.slabs + (size_t)blockIdx.x * (rsx::pmc::SLAB_BYTES / 4);
+  uint32_t *keys = reinterpret_cast<uint32_t *>(L.src);
+  uint16_t *front = reinterpret_cast<uint16_t *>(L.dst);
+
+  for (;;) {
+    __syncthreads();  // the previous pair's LDS is dead
+    if (tid == 0) L.pair = (int)atomicAdd(a.counter, 1u);
+    __syncthreads();
+    const int pair = L.pair;
+    if (pair >= a.n_pairs) break;
+    const int64_t o = a.offsets[pair];
+    const int64_t K64 = a.offsets[pair + 1] - o;
+    const bool no_room = a.sel_src && o + K64 > a.sel_cap;
+    if (K64 < 2 || K64 > MAX_K || no_room) {  // nothing to prune with / too large for the stage: every match passes
+      if (a.member)
+        for (int64_t i = tid; i < K64; i += NT) a.member[o + i] = 1;
+      if (tid == 0) {
+        if (a.sel_cnt) a.sel_cnt[pair] = -1;  // the solver reads the caller's arrays
+        if (a.info)
+          a.info[pair] = rsx_orora_pmc_info{(int32_t)(K64 > 0 ? K64 : 0), 0, 0,
+                                            RSX_ORORA_PMC_PASSTHROUGH | (no_room && K64 >= 2 && K64 <= MAX_K ? RSX_ORORA_PMC_NO_WORKSPACE : 0)};
+      }
+      continue;
+    }
+    const int K = (int)K64, nc = (K + 63) >> 6;
+
+    // ---- phase A: points into LDS, adjacency rows into the slab, degrees ----
+    for (int i = tid; i < K; i += NT) {
+      L.src[i] = a.src[o + i];
+      L.dst[i] = a.dst[o + i];
+    }
+    if (tid < ROWW) {
+      uint32_t w = 0;  // alive = every vertex < K
+      for (int c = 0; c < nc; c++) w |= (c * 64 + tid < K) ? (1u << c) : 0u;
+      L.alive[tid] = w;
+      L.best[tid] = 0;
+    }
+    __syncthreads();
+    for (int i = wave; i < K; i += NT / 64) {
+      const float2 si = L.src[i], di = L.dst[i];
+      const double six = si.x, siy = si.y, dix = di.x, diy = di.y;
+      uint32_t w = 0;
+      for (int c = 0; c < nc; c++) {
+        const int j = c * 64 + lane;
+        if (j < K && j != i && edge(six, siy, dix, diy, L.src[j], L.dst[j], a.tau2)) w |= 1u << c;
+      }
+      adj[(size_t)i * ROWW + lane] = w;
+      const int d = wave_sum_i(__popc(w));
+      if (lane == 0) L.deg[i] = d;
+    }
+    if (tid == 0) {
+      L.level = 0;
+      L.max_core = 0;
+    }
+    __syncthreads();
+
+    // ---- phase B: core numbers by level-synchronous peeling ----
+    for (;;) {
+      if (tid == 0) L.nfront = 0;
+      __syncthreads();
+      const int level = L.level;
+      int my_min = 0x7fffffff;
+      for (int v = tid; v < K; v += NT) {
+        if ((L.alive[v & 63] >> (v >> 6)) & 1u) {
+          const int d = L.deg[v];
+          if (d <= level) {
+            front[atomicAdd(&L.nfront, 1)] = (uint16_t)v;
+            L.core[v] = (uint16_t)level;
+            atomicAnd(&L.alive[v & 63], ~(1u << (v >> 6)));
+          } else {
+            my_min = min(my_min, d);
+          }
+        }
+      }
+      my_min = wave_min_i(my_min);
+      if (lane == 0) L.red[wave] = my_min;
+      __syncthreads();
+      const int nf = L.nfront;
+      if (nf == 0) {
+        const int m = min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3]));
+        if (m == 0x7fffffff) break;  // nothing alive: done
+        __syncthreads();
+        if (tid == 0) L.level = m;   // jump to the smallest remaining degree
+        continue;
+      }
+      for (int f = wave; f < nf; f += NT / 64) {
+        const int u = front[f];
+        uint32_t w = adj[(size_t)u * ROWW + lane] & L.alive[lane];
+        while (w) {
+          const int c = __ffs((int)w) - 1;
+          w &= w - 1;
+          atomicSub(&L.deg[c * 64 + lane], 1);
+        }
+      }
+      if (tid == 0) L.max_core = level;  // levels only grow: the last one that removed something is the largest core number
+    }
+    __syncthreads();
+    const int max_core = L.max_core;
+
+    // ---- phase C: order = vertices by (core descending, index ascending) ----
+    int n2 = 64;
+    while (n2 < K) n2 <<= 1;
+    for (int i = tid; i < n2; i += NT) keys[i] = i < K ? (((uint32_t)(2047 - L.core[i])) << 11) | (uint32_t)i : 0xffffffffu;
+    __syncthreads();
+    for (int k2 = 2; k2 <= n2; k2 <<= 1)
+      for (int j = k2 >> 1; j > 0; j >>= 1) {
+        for (int i = tid; i < n2; i += NT) {
+          const int p = i ^ j;
+          if (p > i) {
+            const uint32_t x = keys[i], y = keys[p];
+            if (((i & k2) == 0) == (x > y)) {
+              keys[i] = y;
+              keys[p] = x;
+            }
+          }
+        }
+        __syncthreads();
+      }
+
+    // ---- phase D: the greedy clique (wave 0) ----
+    if (wave == 0) {
+      uint32_t best = 0, cm = 0;
+      int best_n = 0, seeds = 0, cm_for = -1;
+      for (int t = 0; t < K && seeds < MAX_SEEDS; t++) {
+        const int v = __builtin_amdgcn_readfirstlane((int)(keys[t] & 2047u));
+        if ((int)L.core[v] + 1 <= best_n || best_n == max_core + 1) break;
+        seeds++;
+        if (cm_for != best_n) {  // candidates must have core >= |best|
+          cm = 0;
+          for (int c = 0; c < nc; c++) {
+            const int u = c * 64 + lane;
+            if (u < K && (int)L.core[u] >= best_n) cm |= 1u << c;
+          }
+          cm_for = best_n;
+        }
+        uint32_t P = adj[(size_t)v * ROWW + lane] & cm;
+        uint32_t C = (lane == (v & 63)) ? (1u << (v >> 6)) : 0u;
+        int n = 1, np = __builtin_amdgcn_readfirstlane(wave_sum_i(__popc(P)));
+        bool abandoned = n + np <= best_n;
+        for (int s = 0; s < K && np > 0 && !abandoned; s += 64) {
+          const int idx = s + lane;
+          const int u = idx < K ? (int)(keys[idx] & 2047u) : 0;
+          const uint32_t pw = (uint32_t)__shfl((int)P, u & 63);
+          unsigned long long mask = __ballot(idx < K && ((pw >> (u >> 6)) & 1u));
+          while (mask && np > 0 && !abandoned) {
+            // the next (up to) four candidates of this chunk that were in P when the mask was taken: rows loaded together
+            int cu[4];
+            uint32_t row[4];
+            int got = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              cu[q] = -1;
+              row[q] = 0;
+              if (mask) {
+                const int i0 = __ffsll((long long)mask) - 1;
+                mask &= mask - 1;
+                cu[q] = __builtin_amdgcn_readlane(u, i0);
+                row[q] = adj[(size_t)cu[q] * ROWW + lane];
+                got++;
+              }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              if (q < got && np > 0 && !abandoned) {
+                const int uq = cu[q];
+                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)P, uq & 63);
+                if ((pq >> (uq >> 6)) & 1u) {  // still in P: joins the clique
+                  if (lane == (uq & 63)) C |= 1u << (uq >> 6);
+                  n++;
+                  P &= row[q];
+                  np = __builtin_amdgcn_readfirstlane(wave_sum_i(__popc(P)));
+                  if (n + np <= best_n) abandoned = true;
+                }
+              }
+            }
+          }
+        }
+        if (!abandoned && n > best_n) {
+          best_n = n;
+          best = C;
+        }
+      }
+      L.best[lane] = best;
+      if (lane == 0) {
+        L.best_n = best_n;
+        L.seeds = seeds;
+      }
+    }
+    __syncthreads();
+
+    // ---- output: flags, the selected matches in their original order, the info record ----
+    const int best_n = L.best_n;
+    int run = 0;
+    for (int base = 0; base < K; base += NT) {
+      const int v = base + tid;
+      const bool sel = v < K && ((L.best[v & 63] >> (v >> 6)) & 1u);
+      if (v < K && a.member) a.member[o + v] = sel ? 1 : 0;
+      const unsigned long long bal = __ballot(sel);
+      if (lane == 0) L.red[4 + wave] = __popcll(bal);
+      __syncthreads();
+      int before = run, total = 0;
+      for (int w = 0; w < NT / 64; w++) {
+        if (w < wave) before += L.red[4 + w];
+        total += L.red[4 + w];
+      }
+      if (sel && a.sel_src) {
+        const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
+        a.sel_src[o + pos] = a.src[o + v];
+        a.sel_dst[o + pos] = a.dst[o + v];
+      }
+      run += total;
+      __syncthreads();
+    }
+    if (tid == 0) {
+      if (a.sel_cnt) a.sel_cnt[pair] = best_n;
+      if (a.info) a.info[pair] = rsx_orora_pmc_info{best_n, max_core, L.seeds, best_n == max_core + 1 ? RSX_ORORA_PMC_PROVEN : 0};
+    }
+  }
+}
+
+}  // namespace
+
+namespace rsx {
+namespace pmc {
+
+int launch(Workspace &ws, int device, const float2 *d_src, const float2 *d_dst, const int64_t *d_offsets, int n_pairs, double tau,
+           uint8_t *d_member, rsx_orora_pmc_info *d_info, float2 *d_sel_src, float2 *d_sel_dst, int32_t *d_sel_cnt, int64_t sel_cap, hipStream_t s) {
+  if (n_pairs <= 0) return RSX_OK;
+  if (!(tau > 0.0)) return rsx::fail(RSX_ERR_BAD_ARG, "the consistency bound (tim_noise_bound) must be positive");
+  if (!ws.n_wg) {  // as many workgroups as the device runs at once (they pull pairs from a queue; no barrier between them)
+    int cus = 0, per_cu = 0;
+    RSX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+    RSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&pmc_select_kernel), NT, 0));
+    ws.n_wg = (cus < 1 ? 1 : cus) * (per_cu < 1 ? 1 : per_cu);
+  }
+  const int g = n_pairs < ws.n_wg ? n_pairs : ws.n_wg;
+  RSX_TRY(ws.slabs.reserve((size_t)g * SLAB_BYTES, s, false));
+  RSX_TRY(ws.counter.reserve(64, s, false));
+  RSX_HIP(hipMemsetAsync(ws.counter.p, 0, 4, s));
+  Args a;
+  a.src = d_src;
+  a.dst = d_dst;
+  a.offsets = d_offsets;
+  a.n_pairs = n_pairs;
+  a.tau2 = tau * tau;
+  a.slabs = ws.slabs.as<uint32_t>();
+  a.counter = ws.counter.as<unsigned>();
+  a.member = d_member;
+  a.info = d_info;
+  a.sel_src = d_sel_src;
+  a.sel_dst = d_sel_dst;
+  a.sel_cnt = d_sel_cnt;
+  a.sel_cap = sel_cap;
+  hipLaunchKernelGGL(pmc_select_kernel, dim3((unsigned)g), dim3(NT), 0, s, a);
+  RSX_HIP(hipGetLastError());
+  return RSX_OK;
+}
+
+}  // namespace pmc
+}  // namespace rsx

@@ -16,8 +16,9 @@
 //     rsx_orora_register_batch  matched points -> SE(2) motion
 //     rsx_frontend_*            polar -> Cartesian image, ORB-style descriptors at the keypoints, brute-force Hamming
 //                               knnMatch(2) + ratio test (what upstream does with cv::remap / cv::ORB / cv::BFMatcher)
-// Upstream also prunes the matches with a PMC max-clique step before the solver; that stays out (host heuristic,
-// SURVEY 8f): the ratio test + a cross check feed ORORA, whose GNC / consensus stages reject the remaining outliers.
+// Between matcher and solver the matches are pruned to the max clique of their distance-consistency graph, as upstream does
+// with the PMC library (round 6: csrc/pmc.hip behind RSX_ORORA_PMC, on by default; `--no-pmc` feeds the solver every
+// cross-checked ratio match, the pipeline of rounds 3-5).
 // `--matcher nn` selects the round-1 stand-in instead (mutual nearest neighbours in the sensor frame, no descriptors).
 //
 // Output: one line per frame on stdout / --out file:  stamp_ns x y yaw n_keypoints n_matches
@@ -171,7 +172,7 @@ int main(int argc, char **argv) {
   try {
     std::string seq_dir, out_path, record_path, matcher = "orb";
     int max_frames = -1, device = 0, window = 0, threads = 0;
-    bool per_scan = false, timing = false;
+    bool per_scan = false, timing = false, use_pmc = true;
     double rate_hz = 0.0;
     float gate = 6.0f;
     for (int i = 1; i < argc; i++) {
@@ -183,6 +184,7 @@ int main(int argc, char **argv) {
       else if (a == "--matcher" && i + 1 < argc) matcher = argv[++i];  // orb (default) | nn
       else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);    // scans per rsx_odometry_push (default: the library's window)
       else if (a == "--threads" && i + 1 < argc) threads = std::atoi(argv[++i]);  // PNG decode threads (default: hardware concurrency, <= 64)
+      else if (a == "--no-pmc") use_pmc = false;                                   // skip the max-clique inlier selection before the solver
       else if (a == "--per-scan") per_scan = true;                                // the round-2 loop: one scan per call, host vectors in between
       else if (a == "--timing") timing = true;                                    // decode / pipeline seconds on stderr
       else if (a.rfind("seq_dir:=", 0) == 0) seq_dir = a.substr(9);  // roslaunch-style arg
@@ -194,7 +196,7 @@ int main(int argc, char **argv) {
     }
     (void)rate_hz;  // only the ROS publishers are paced
     if (seq_dir.empty())
-      die("usage: odometry <seq_dir> [--out poses.txt] [--max_frames N] [--matcher orb|nn] [--window W] [--threads T] [--per-scan] [--timing]");
+      die("usage: odometry <seq_dir> [--out poses.txt] [--max_frames N] [--matcher orb|nn] [--window W] [--threads T] [--per-scan] [--no-pmc] [--timing]");
     const std::string dir = seq_dir + "/polar_oxford_form";
     std::vector<std::string> files;
     if (DIR *d = opendir(dir.c_str())) {
@@ -297,6 +299,7 @@ int main(int argc, char **argv) {
       op.device = device;
       op.radar_resolution = kResolution;
       op.col_offset = kMeta;
+      if (!use_pmc) op.orora.flags &= ~RSX_ORORA_PMC;
       rsx_odometry *odo = nullptr;
       check(rsx_odometry_create(&op, rows, cols, &odo), "rsx_odometry_create");
       const int W = window > 0 ? std::min(window, 4096) : rsx_odometry_window();
@@ -482,7 +485,10 @@ int main(int argc, char **argv) {
         const int64_t offsets[2] = {0, (int64_t)n_match};
         rsx_orora_result r;
         // src = current scan, dst = previous scan: the motion of the sensor expressed in the previous frame
-        check(rsx_orora_register_batch(reg, dst.data(), src.data(), offsets, 1, nullptr, &r), "rsx_orora_register_batch");
+        rsx_orora_params rp;
+        check(rsx_orora_default_params(&rp), "rsx_orora_default_params");
+        if (use_pmc) rp.flags |= RSX_ORORA_PMC;
+        check(rsx_orora_register_batch(reg, dst.data(), src.data(), offsets, 1, &rp, &r), "rsx_orora_register_batch");
         compose(r);
       }
       emit(fi, cur.stamp_ns, n, n_match, cur.xy.data());

@@ -7,7 +7,7 @@ import ctypes as C
 import numpy as np
 
 from . import _rsx
-from ._rsx import ORORA_RESULT_DTYPE, OroraParams, check, lib
+from ._rsx import ORORA_PMC, ORORA_RESULT_DTYPE, PMC_INFO_DTYPE, OroraParams, check, lib  # noqa: F401
 
 
 def default_params():
@@ -56,3 +56,24 @@ class Orora:
     def register_batch_device(self, src_ptr, dst_ptr, off_ptr, n_pairs, out_ptr, params=None, stream=0):
         pp = C.byref(params) if params is not None else None
         check(self._L.rsx_orora_register_batch_device(self._h, src_ptr, dst_ptr, off_ptr, n_pairs, pp, out_ptr, stream))
+
+    def reserve(self, max_total_matches):
+        """sizes the workspaces of the RSX_ORORA_PMC stage for the asynchronous device entry"""
+        check(self._L.rsx_orora_reserve(self._h, int(max_total_matches)))
+
+    def max_clique_batch(self, src_xy, dst_xy, offsets, params=None):
+        """the max-clique inlier selection on its own -> (member uint8 (M,), info (n_pairs,) PMC_INFO_DTYPE)"""
+        src = np.ascontiguousarray(src_xy, dtype=np.float32)
+        dst = np.ascontiguousarray(dst_xy, dtype=np.float32)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = off.size - 1
+        member = np.zeros(int(off[-1]), dtype=np.uint8)
+        info = np.zeros(n, dtype=PMC_INFO_DTYPE)
+        pp = C.byref(params) if params is not None else None
+        check(self._L.rsx_orora_max_clique_batch(self._h, src.ctypes.data, dst.ctypes.data, off.ctypes.data, n, pp, member.ctypes.data, info.ctypes.data))
+        return member, info
+
+    def last_pmc_info(self, n_pairs):
+        info = np.zeros(n_pairs, dtype=PMC_INFO_DTYPE)
+        check(self._L.rsx_orora_last_pmc_info(self._h, info.ctypes.data, n_pairs))
+        return info

@@ -7,8 +7,9 @@ Per scan, as SURVEY.md section 3.4 / Appendix B records the published pipeline:
     cen2019 keypoints (oracle/cen2019_ref.c) -> metres in the sensor frame -> Cartesian image + ORB-style descriptors
     (oracle/frontend_ref.c) -> knnMatch(2) + ratio in both directions, kept when they agree -> ORORA (oracle/orora_ref.c)
     with src = this scan's points, dst = the previous scan's points: p_previous = R(yaw) p_this + (x, y)
-and the accumulated pose is the composition of those motions.  PMC max-clique pruning between matcher and solver is out
-of scope."""
+and the accumulated pose is the composition of those motions.  Between matcher and solver sits the max-clique inlier
+selection ("PMC max-clique prune"; oracle/pmc_ref.c), on by default since round 6 (`pmc=False`: the chain of
+rounds 3-5, every cross-checked match to the solver)."""
 import numpy as np
 
 from . import pyoracle as po
@@ -20,7 +21,7 @@ def compose(p, rel):
 
 
 def run(images, azimuths, resolution=0.0595, col_offset=11, max_points=10000, min_range=58, ratio=0.8, max_keypoints=16384,
-        orora_params=None, W=964, cart_res=0.2592):
+        orora_params=None, W=964, cart_res=0.2592, pmc=True):
     """images: (n, rows, row_stride) uint8; azimuths (rows,) or (n, rows).  -> list of per-scan dicts
     {n_keypoints, n_matches, result (ORORA_RESULT_DTYPE record or None for the first scan), xy, pose (accumulated)}."""
     images = np.asarray(images)
@@ -43,8 +44,14 @@ def run(images, azimuths, resolution=0.0595, col_offset=11, max_points=10000, mi
             ii = np.nonzero(fwd >= 0)[0]
             ii = ii[bwd[fwd[ii]] == ii]
             src, dst = xy[fwd[ii]], prev[0][ii]
-            r = po.orora_register_batch(src, dst, np.array([0, len(ii)], dtype=np.int64), params=orora_params)[0]
-            rec["n_matches"], rec["result"] = len(ii), r
+            rec["n_matches"] = len(ii)
+            if pmc:
+                tau = (orora_params or po.orora_default_params()).tim_noise_bound
+                member, info = po.pmc_select_batch(src, dst, np.array([0, len(ii)], dtype=np.int64), tau)
+                src, dst = src[member.astype(bool)], dst[member.astype(bool)]
+                rec["n_selected"], rec["pmc_info"] = len(src), info[0]
+            r = po.orora_register_batch(src, dst, np.array([0, len(src)], dtype=np.int64), params=orora_params)[0]
+            rec["result"] = r
             if r["status"] == 0:
                 pose = compose(pose, (r["x"], r["y"], r["yaw"]))
         rec["pose"] = pose.copy()

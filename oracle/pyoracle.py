@@ -409,6 +409,70 @@ def orora_scalar_tls(x, beta):
 
 
 # ------------------------------------------------------------------------------------------
+# max-clique inlier selection before the solver (oracle/pmc_ref.c) -- PARITY UNPINNED, see pmc_ref.h
+# ------------------------------------------------------------------------------------------
+PMC_INFO_DTYPE = np.dtype([("size", "<i4"), ("max_core", "<i4"), ("seeds", "<i4"), ("flags", "<i4")])
+PMC_PROVEN, PMC_PASSTHROUGH, PMC_MAX_K = 1, 2, 2048
+
+
+def pmc_adjacency(src, dst, tau):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    dst = np.ascontiguousarray(dst, dtype=np.float32)
+    k = len(src)
+    adj = np.zeros((k, k), dtype=np.uint8)
+    L = lib()
+    L.pmcref_adjacency.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]
+    L.pmcref_adjacency.restype = None
+    L.pmcref_adjacency(src.ctypes.data, dst.ctypes.data, k, float(tau), adj.ctypes.data)
+    return adj
+
+
+def pmc_core_numbers(adj):
+    adj = np.ascontiguousarray(adj, dtype=np.uint8)
+    k = len(adj)
+    core = np.zeros(k, dtype=np.int32)
+    L = lib()
+    L.pmcref_core_numbers.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    L.pmcref_core_numbers.restype = None
+    L.pmcref_core_numbers(adj.ctypes.data, k, core.ctypes.data)
+    return core
+
+
+def pmc_select_batch(src, dst, offsets, tau, nthreads=1):
+    """-> (member uint8[M] concatenated like the matches, info[n_pairs])"""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    dst = np.ascontiguousarray(dst, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    n = offsets.size - 1
+    member = np.zeros(int(offsets[-1]), dtype=np.uint8)
+    info = np.zeros(n, dtype=PMC_INFO_DTYPE)
+    L = lib()
+    L.pmcref_select_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int]
+    L.pmcref_select_batch.restype = None
+    L.pmcref_select_batch(src.ctypes.data, dst.ctypes.data, offsets.ctypes.data, n, float(tau), member.ctypes.data, info.ctypes.data, nthreads)
+    return member, info
+
+
+def pmc_exact_size(adj, lb=0, max_nodes=2_000_000):
+    adj = np.ascontiguousarray(adj, dtype=np.uint8)
+    L = lib()
+    L.pmcref_exact_size.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
+    L.pmcref_exact_size.restype = C.c_int32
+    return int(L.pmcref_exact_size(adj.ctypes.data, len(adj), int(lb), int(max_nodes)))
+
+
+def pmc_compact(src, dst, offsets, member):
+    """the matches a selection keeps, in their original order, with their offsets: what the solver is fed"""
+    keep = member.astype(bool)
+    offsets = np.asarray(offsets, dtype=np.int64)
+    cnt = np.add.reduceat(keep.astype(np.int64), offsets[:-1]) if len(offsets) > 1 else np.zeros(0, dtype=np.int64)
+    cnt[np.diff(offsets) == 0] = 0
+    new_off = np.zeros(len(offsets), dtype=np.int64)
+    new_off[1:] = np.cumsum(cnt)
+    return np.ascontiguousarray(src[keep]), np.ascontiguousarray(dst[keep]), new_off
+
+
+# ------------------------------------------------------------------------------------------
 # cen2019 (oracle/cen2019_ref.c) -- PARITY UNPINNED, see the header of cen2019_ref.c
 # ------------------------------------------------------------------------------------------
 def cen2019_extract(img, cols=None, col_offset=11, max_points=10000, min_range=58, max_targets=200000, debug=False):

@@ -94,3 +94,28 @@ def test_bench_refuses_more_gpus_than_visible():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=300)
     assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout)
+
+
+def test_a_secondary_layout_that_raises_does_not_cost_the_headline():
+    """N > 1: every secondary leg runs in its own try (bench.LegGuard); the failure is recorded, the headline printed, rc 0."""
+    p, lines = _run(2, {"RSX_BENCH_TEST_FAULT": "raise:layout 2x1"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["failures"] == [] and out["layouts"]["1x2"]["headline"] is True
+    assert "injected fault" in out["layouts"]["2x1"]["error"]
+    assert any("layout 2x1" in m for m in out["secondary_failures"])
+
+
+def test_a_secondary_layout_that_wedges_is_cut_at_its_deadline():
+    """... and under a deadline: a leg that never returns (a wedged collective cannot be interrupted) ends the run through
+    os._exit on every rank, after rank 0 has written the one JSON line with the headline and the failure."""
+    import time
+    t0 = time.time()
+    p, lines = _run(2, {"RSX_BENCH_TEST_FAULT": "sleep:layout 2x1", "RSX_BENCH_LEG_TIMEOUT": "5"})
+    assert time.time() - t0 < 300
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert len(lines) == 1, (p.stdout, p.stderr[-1500:])
+    out = json.loads(lines[0])
+    assert out["value"] > 0 and out["cut_short"] is True and out["n_gpus"] == 2
+    assert any("layout 2x1" in m and "no result after 5 s" in m for m in out["secondary_failures"])
