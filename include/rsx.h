@@ -108,6 +108,7 @@ typedef struct {
 #define RSX_SC_SUM_EIGEN_SSE2 0
 #define RSX_SC_SUM_SEQ 1
 #define RSX_SC_SUM_EIGEN_AVX_FMA 2
+#define RSX_SC_SUM_EIGEN34_AVX_FMA 3 /* as 2 against Eigen 3.4: its AVX horizontal add is (l0 + l2) + (l1 + l3), 3.3's (l0 + l1) + (l2 + l3) */
 
 typedef enum {
   RSX_SC_MODE_CANDIDATE = 0, /* reference semantics: ring-key 3-NN then 3 pair distances (SC.cpp:331-422) */

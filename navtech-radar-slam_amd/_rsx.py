@@ -15,7 +15,7 @@ NUM_RING, NUM_SECTOR, DESC_SIZE, MAX_TOPK = 20, 60, 1200, 32
 MODE_CANDIDATE, MODE_EXHAUSTIVE = 0, 1
 FILTER_AUTO, FILTER_OFF, FILTER_FORCE, FILTER_Q1 = 0, 1, 2, 3   # rsx_sc_params.filter_mode
 KIND_AUTO, KIND_DIRECT, KIND_SPECTRAL, KIND_SPECTRAL2 = 0, 1, 2, 3
-SUM_EIGEN_SSE2, SUM_SEQ, SUM_EIGEN_AVX_FMA = 0, 1, 2   # rsx_sc_params.sum_order (how the reference was built)
+SUM_EIGEN_SSE2, SUM_SEQ, SUM_EIGEN_AVX_FMA, SUM_EIGEN34_AVX_FMA = 0, 1, 2, 3   # rsx_sc_params.sum_order (how the reference was built)
 default_filter_kind = KIND_AUTO   # what SCManager(filter_kind=KIND_AUTO) passes on (tests flip it to cover both forms)
 
 HIT_DTYPE = np.dtype([("dist", "<f8"), ("index", "<i4"), ("shift", "<i4")])

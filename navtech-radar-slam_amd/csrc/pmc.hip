@@ -91,7 +91,11 @@ __device__ __forceinline__ bool edge(double six, double siy, double dix, double 
 
 __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
   __shared__ Lds L;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Everything a whole wavefront decides goes through an SGPR (readfirstlane): hipcc cannot see that `wave`, or a value every
+  // thread read from the same LDS word, is uniform, and structurises such branches with exec masks -- the first build of the
+  // peeling loop `if (tid == 0) L.level = m; continue;` parked lane 0's store behind a loop the other 63 lanes of its wave
+  // could not leave without it (the kernel never returned).  Uniform values in SGPRs make those branches scalar.
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   uint32_t *adj = a.slabs + (size_t)blockIdx.x * (rsx::pmc::SLAB_BYTES / 4);
   uint32_t *keys = reinterpret_cast<uint32_t *>(L.src);
   uint16_t *front = reinterpret_cast<uint16_t *>(L.dst);
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
     __syncthreads();  // the previous pair's LDS is dead
     if (tid == 0) L.pair = (int)atomicAdd(a.counter, 1u);
     __syncthreads();
-    const int pair = L.pair;
+    const int pair = __builtin_amdgcn_readfirstlane(L.pair);
     if (pair >= a.n_pairs) break;
     const int64_t o = a.offsets[pair];
     const int64_t K64 = a.offsets[pair + 1] - o;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
       }
       continue;
     }
-    const int K = (int)K64, nc = (K + 63) >> 6;
+    const int K = __builtin_amdgcn_readfirstlane((int)K64), nc = (K + 63) >> 6;
 
     // ---- phase A: points into LDS, adjacency rows into the slab, degrees ----
     for (int i = tid; i < K; i += NT) {
@@ -148,11 +152,11 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
     }
     __syncthreads();
 
-    // ---- phase B: core numbers by level-synchronous peeling ----
-    for (;;) {
+    // ---- phase B: core numbers by level-synchronous peeling (one exit, three barriers per round) ----
+    for (bool peeling = true; peeling;) {
       if (tid == 0) L.nfront = 0;
       __syncthreads();
-      const int level = L.level;
+      const int level = __builtin_amdgcn_readfirstlane(L.level);
       int my_min = 0x7fffffff;
       for (int v = tid; v < K; v += NT) {
         if ((L.alive[v & 63] >> (v >> 6)) & 1u) {
@@ -169,27 +173,26 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
       my_min = wave_min_i(my_min);
       if (lane == 0) L.red[wave] = my_min;
       __syncthreads();
-      const int nf = L.nfront;
+      const int nf = __builtin_amdgcn_readfirstlane(L.nfront);
       if (nf == 0) {
-        const int m = min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3]));
-        if (m == 0x7fffffff) break;  // nothing alive: done
-        __syncthreads();
-        if (tid == 0) L.level = m;   // jump to the smallest remaining degree
-        continue;
-      }
-      for (int f = wave; f < nf; f += NT / 64) {
-        const int u = front[f];
-        uint32_t w = adj[(size_t)u * ROWW + lane] & L.alive[lane];
-        while (w) {
-          const int c = __ffs((int)w) - 1;
-          w &= w - 1;
-          atomicSub(&L.deg[c * 64 + lane], 1);
+        const int m = __builtin_amdgcn_readfirstlane(min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3])));
+        if (m == 0x7fffffff) peeling = false;  // nothing alive: done
+        else if (tid == 0) L.level = m;        // jump to the smallest remaining degree
+      } else {
+        for (int f = wave; f < nf; f += NT / 64) {
+          const int u = __builtin_amdgcn_readfirstlane((int)front[f]);
+          uint32_t w = adj[(size_t)u * ROWW + lane] & L.alive[lane];
+          while (w) {
+            const int c = __ffs((int)w) - 1;
+            w &= w - 1;
+            atomicSub(&L.deg[c * 64 + lane], 1);
+          }
         }
+        if (tid == 0) L.max_core = level;  // levels only grow: the last one that removed something is the largest core number
       }
-      if (tid == 0) L.max_core = level;  // levels only grow: the last one that removed something is the largest core number
+      __syncthreads();  // every wave has read nfront / red and finished its decrements before the next round resets them
     }
-    __syncthreads();
-    const int max_core = L.max_core;
+    const int max_core = __builtin_amdgcn_readfirstlane(L.max_core);
 
     // ---- phase C: order = vertices by (core descending, index ascending) ----
     int n2 = 64;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
     __syncthreads();
 
     // ---- output: flags, the selected matches in their original order, the info record ----
-    const int best_n = L.best_n;
+    const int best_n = __builtin_amdgcn_readfirstlane(L.best_n);
     int run = 0;
     for (int base = 0; base < K; base += NT) {
       const int v = base + tid;

@@ -702,7 +702,7 @@ int rsx_sc_create(const rsx_sc_params *p, rsx_sc **out) try {
     return fail(RSX_ERR_BAD_ARG, "kernels are specialised for SEARCH_RADIUS 3 (search_ratio 0.1, SC.h:96)");
   if (d.tree_making_period < 1 || d.num_exclude_recent < 0) return fail(RSX_ERR_BAD_ARG, "bad detector params");
   if (d.filter_mode < 0 || d.filter_mode > 3) return fail(RSX_ERR_BAD_ARG, "filter_mode must be 0 (auto), 1 (off), 2 (force) or 3 (single-query path)");
-  if (d.sum_order < 0 || d.sum_order > RSX_SC_SUM_EIGEN_AVX_FMA) return fail(RSX_ERR_BAD_ARG, "sum_order must be RSX_SC_SUM_EIGEN_SSE2, _SEQ or _EIGEN_AVX_FMA");
+  if (d.sum_order < 0 || d.sum_order > RSX_SC_SUM_EIGEN34_AVX_FMA) return fail(RSX_ERR_BAD_ARG, "sum_order must be RSX_SC_SUM_EIGEN_SSE2, _SEQ, _EIGEN_AVX_FMA or _EIGEN34_AVX_FMA");
   if (d.filter_kind < 0 || d.filter_kind > 3)
     return fail(RSX_ERR_BAD_ARG, "filter_kind must be 0 (auto), 1 (direct), 2 (spectral) or 3 (spectral, two waves per SIMD)");
   int ndev = rsx_device_count();

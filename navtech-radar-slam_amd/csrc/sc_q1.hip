@@ -760,11 +760,11 @@ int launch_q1(const DbView &db, const float *d_q, int32_t nq, int64_t n_items, i
   if (n_items < 0) n_items = 0;
   if (n_items >= (1ll << 31)) return fail(RSX_ERR_RANGE, "the single-query path addresses local slots with 31 bits");
   {  // 68 KiB of dynamic LDS: opt in once per device (and summation order: each is a kernel of its own)
-    static std::atomic<unsigned long long> attr_set[3] = {};
+    static std::atomic<unsigned long long> attr_set[4] = {};
     int dev = 0;
     RSX_HIP(hipGetDevice(&dev));
     const unsigned long long bit = 1ull << (dev & 63);
-    const int so = (db.sum_order >= 0 && db.sum_order <= 2) ? db.sum_order : 0;
+    const int so = (db.sum_order >= 0 && db.sum_order <= 3) ? db.sum_order : 0;
     if (!(attr_set[so].load(std::memory_order_relaxed) & bit)) {
       hipError_t e = hipSuccess;
       RSX_SO_DISPATCH(so, e = hipFuncSetAttribute(reinterpret_cast<const void *>(&sc_q1_kernel<SO>), hipFuncAttributeMaxDynamicSharedMemorySize, Q1_LDS));

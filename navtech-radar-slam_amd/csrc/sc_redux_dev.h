@@ -18,13 +18,13 @@ namespace rsx {
 namespace sc {
 namespace dev {
 
-constexpr int SO_SSE2 = RSX_SC_SUM_EIGEN_SSE2, SO_SEQ = RSX_SC_SUM_SEQ, SO_AVX_FMA = RSX_SC_SUM_EIGEN_AVX_FMA;
+constexpr int SO_SSE2 = RSX_SC_SUM_EIGEN_SSE2, SO_SEQ = RSX_SC_SUM_SEQ, SO_AVX_FMA = RSX_SC_SUM_EIGEN_AVX_FMA, SO_AVX34_FMA = RSX_SC_SUM_EIGEN34_AVX_FMA;
 
 // sum over i < N of a(i) * b(i) (PROD) or of a(i); a, b: callables int -> double
 template <int SO, int N, bool PROD, typename A, typename B>
 __device__ __forceinline__ double redux_impl(A a, B b) {
   constexpr int P = SO == SO_SEQ ? 1 : (SO == SO_SSE2 ? 2 : 4);
-  constexpr bool fused = SO == SO_AVX_FMA;
+  constexpr bool fused = SO == SO_AVX_FMA || SO == SO_AVX34_FMA;
   auto first = [&](int i) -> double {
     if constexpr (PROD) return a(i) * b(i);
     else return a(i);
@@ -69,6 +69,7 @@ __device__ __forceinline__ double redux_impl(A a, B b) {
     }
     double res;
     if constexpr (P == 2) res = r0[0] + r0[1];
+    else if constexpr (SO == SO_AVX34_FMA) res = (r0[0] + r0[2]) + (r0[1] + r0[3]);  // predux, Eigen 3.4 (AVX: two 128-bit halves added first)
     else res = (r0[0] + r0[1]) + (r0[2] + r0[3]);  // predux, Eigen 3.3
 #pragma unroll
     for (int i = aligned; i < N; i++) res = acc(res, i);
@@ -87,7 +88,7 @@ __device__ __forceinline__ double redux_prod(A a, B b) {
 // the same for run-time n / order (sc_helpers.hip: one wavefront per call, nothing to tune); a[i * sa], b[i * sb] (b may be null)
 __device__ inline double redux_rt(int so, int n, const double *a, int sa, const double *b, int sb) {
   const int P = so == SO_SEQ ? 1 : (so == SO_SSE2 ? 2 : 4);
-  const bool fused = so == SO_AVX_FMA;
+  const bool fused = so == SO_AVX_FMA || so == SO_AVX34_FMA;
   auto first = [&](int i) { return b ? a[i * sa] * b[i * sb] : a[i * sa]; };
   auto acc = [&](double r, int i) {
     if (!b) return r + a[i * sa];
@@ -112,7 +113,7 @@ __device__ inline double redux_rt(int so, int n, const double *a, int sa, const 
       if (aligned > aligned2)
         for (int l = 0; l < P; l++) r0[l] = acc(r0[l], aligned2 + l);
     }
-    res = P == 2 ? r0[0] + r0[1] : (r0[0] + r0[1]) + (r0[2] + r0[3]);
+    res = P == 2 ? r0[0] + r0[1] : (so == SO_AVX34_FMA ? (r0[0] + r0[2]) + (r0[1] + r0[3]) : (r0[0] + r0[1]) + (r0[2] + r0[3]));
     for (int i = aligned; i < n; i++) res = acc(res, i);
   } else {
     res = first(0);
@@ -135,6 +136,10 @@ __device__ inline double redux_rt(int so, int n, const double *a, int sa, const 
       } break;                                        \
       case RSX_SC_SUM_EIGEN_AVX_FMA: {                \
         constexpr int SO = RSX_SC_SUM_EIGEN_AVX_FMA;  \
+        CALL;                                         \
+      } break;                                        \
+      case RSX_SC_SUM_EIGEN34_AVX_FMA: {              \
+        constexpr int SO = RSX_SC_SUM_EIGEN34_AVX_FMA; \
         CALL;                                         \
       } break;                                        \
       default: {                                      \

@@ -1130,19 +1130,31 @@ struct S2Lane {
 // every piece of a tile, over the 4 producer waves: piece c belongs to producer c % 4.  WHOLE pieces, no lane predicate:
 // what a piece reads beyond the tile's last query is the next query's image or the allocation's slack (sp_nq4 rounds the
 // batch up to whole tiles, spec_qimg_bytes adds 1 KiB) and lands in the unused end of the tile buffer
-__device__ __forceinline__ void dma_issue_all(const TileDma &d, int sub, int lane) {
-  const int wu = __builtin_amdgcn_readfirstlane(sub);
+#ifndef S2_OPT_DMASPLIT
+#define S2_OPT_DMASPLIT 0   // 1 (round-6 experiment): the late waves issue stream pieces 4..7 mod 8 of the next tile before their stage 1
+#endif
+// STREAM pieces of a tile for one issuer out of NI: pieces first, first + NI, ...
+template <int NI>
+__device__ __forceinline__ void dma_issue_stream(const TileDma &d, int first, int lane) {
+  const int wu = __builtin_amdgcn_readfirstlane(first);
   unsigned lo = (unsigned)lane;
   asm volatile("" : "+v"(lo));
   const unsigned voff = lo * 16u;
   const char *gs = d.gsrc + wu * 1024;
   char *ls = d.ldst + wu * 1024;
 #pragma unroll
-  for (int j = 0; j < (SP_STREAM_PIECES + 3) / 4; j++) {   // stream pieces wu + 4 j
-    if (wu + 4 * j < SP_STREAM_PIECES)
-      __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(gs + j * 4096) + voff),
-                                       (AS3 void *)(ls + j * 4096), 16, 0, 0);
+  for (int j = 0; j < (SP_STREAM_PIECES + NI - 1) / NI; j++) {
+    if (wu + NI * j < SP_STREAM_PIECES)
+      __builtin_amdgcn_global_load_lds(reinterpret_cast<const AS1 void *>(reinterpret_cast<uintptr_t>(gs + j * NI * 1024) + voff),
+                                       (AS3 void *)(ls + j * NI * 1024), 16, 0, 0);
   }
+}
+__device__ __forceinline__ void dma_issue_all(const TileDma &d, int sub, int lane) {
+  const int wu = __builtin_amdgcn_readfirstlane(sub);
+  unsigned lo = (unsigned)lane;
+  asm volatile("" : "+v"(lo));
+  const unsigned voff = lo * 16u;
+  dma_issue_stream<S2_OPT_DMASPLIT ? 8 : 4>(d, sub, lane);
   if (d.nbytes_m) {  // the tile's flag word: a query with an empty column
     const int m0 = (wu - SP_STREAM_PIECES) & 3;  // first mask piece of this wave
     const char *gm = d.gsrc_m + m0 * 1024;
@@ -1211,6 +1223,7 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
                    smem + S2_TILES_OFF + (p % S2_NBUF) * SP_PHASE_BYTES, nqs * SP_QS, flagword ? nqs * SP_MASK_BYTES : 0};
   };
   if (HALF == 1) dma_issue_all(tile_dma(0, scalar_load_u32(qflags)), sub, lane);  // tile 0: overlaps the B loads below
+  else if (S2_OPT_DMASPLIT) dma_issue_stream<8>(tile_dma(0, 0u), sub + 4, lane);
 
   half8 B[NF];
   {
@@ -1548,6 +1561,7 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
       }
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+s"(flag_next)::"memory");
     } else {
+      if (S2_OPT_DMASPLIT && k + 1 < nphase) dma_issue_stream<8>(tile_dma(k + 1, 0u), sub + 4, lane);  // stream pieces 4 + sub, 12 + sub
       if (do_s1) {
         stage1(k, own);
         lap(0);  // stage 1 incl. the last packing
@@ -1560,7 +1574,8 @@ __device__ __forceinline__ void spec2_segment(const SpecArgs &a, char *smem, uns
         for (int i = 0; i < 8; i++) held[0][i] = own[0][JB + i], held[1][i] = own[1][JB + i];
       }
       // this wave issues no DMA; its stores stay in flight (nothing waits for them before the end of the segment)
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (S2_OPT_DMASPLIT) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (its pieces of tile k + 1 -- and the tail's store)
+      else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     lap(4);  // exchange writes / end-of-interval wait
     __builtin_amdgcn_s_barrier();

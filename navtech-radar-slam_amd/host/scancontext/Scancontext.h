@@ -355,7 +355,7 @@ class SCManager {
   void setSumOrder(int order) {
     std::lock_guard<std::mutex> lk(mu_);
     if (h_ || hs_) throw std::runtime_error("setSumOrder after the GPU handle was created");
-    if (order < RSX_SC_SUM_EIGEN_SSE2 || order > RSX_SC_SUM_EIGEN_AVX_FMA) throw std::runtime_error("setSumOrder: unknown order");
+    if (order < RSX_SC_SUM_EIGEN_SSE2 || order > RSX_SC_SUM_EIGEN34_AVX_FMA) throw std::runtime_error("setSumOrder: unknown order");
     sum_order_ = order;
   }
   void setDevice(int device) {  // before first use

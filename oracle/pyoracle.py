@@ -27,7 +27,7 @@ def build(force=False):
     stale = (not os.path.exists(so)) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     if force or stale:
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
-    ref_sos = [os.path.join(_HERE, "_ref", f) for f in ("libref_kdtree.so", "libref_sc_seq.so", "libref_sc_sse2.so", "libref_sc_avxfma.so")]
+    ref_sos = [os.path.join(_HERE, "_ref", f) for f in ("libref_kdtree.so", "libref_sc_seq.so", "libref_sc_sse2.so", "libref_sc_avxfma.so", "libref_sc_avxfma34.so")]
     if os.path.isdir("/root/reference/pgo/SC-A-LOAM/include/scancontext"):
         ref_srcs = [os.path.join(_HERE, "ref_kdtree.cpp"), os.path.join(_HERE, "ref_sc.cpp"), os.path.join(_HERE, "standin", "Eigen", "Dense")]
         stale_ref = any((not os.path.exists(so)) or any(os.path.getmtime(x) > os.path.getmtime(so) for x in ref_srcs) for so in ref_sos)
@@ -637,8 +637,8 @@ def map_build(clouds, poses, skip=2, leaf=0.4):
 # ------------------------------------------------------------------------------------------
 # The reference's own Scancontext.cpp, compiled unmodified against oracle/standin (oracle/ref_sc.cpp)
 # ------------------------------------------------------------------------------------------
-ORDER_SEQ, ORDER_EIGEN_SSE2, ORDER_EIGEN_AVX_FMA = 0, 1, 2
-REF_SC_VARIANTS = {ORDER_SEQ: "seq", ORDER_EIGEN_SSE2: "sse2", ORDER_EIGEN_AVX_FMA: "avxfma"}
+ORDER_SEQ, ORDER_EIGEN_SSE2, ORDER_EIGEN_AVX_FMA, ORDER_EIGEN34_AVX_FMA = 0, 1, 2, 3
+REF_SC_VARIANTS = {ORDER_SEQ: "seq", ORDER_EIGEN_SSE2: "sse2", ORDER_EIGEN_AVX_FMA: "avxfma", ORDER_EIGEN34_AVX_FMA: "avxfma34"}
 
 
 def set_sum_order(order):
@@ -658,7 +658,7 @@ class RefSC:
         p = os.path.join(_HERE, "_ref", f"libref_sc_{REF_SC_VARIANTS[order]}.so")
         if not os.path.exists(p):
             raise FileNotFoundError(p)
-        if order == ORDER_EIGEN_AVX_FMA and " fma " not in open("/proc/cpuinfo").read():
+        if order in (ORDER_EIGEN_AVX_FMA, ORDER_EIGEN34_AVX_FMA) and " fma " not in open("/proc/cpuinfo").read():
             raise FileNotFoundError("host CPU has no FMA: cannot run " + p)
         R = C.CDLL(p)
         R.ref_sc_build_info.restype = C.c_char_p

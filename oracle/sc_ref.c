@@ -36,7 +36,7 @@
 static int g_sum_order = SCREF_ORDER_EIGEN_SSE2;
 
 void scref_set_sum_order(int order) {
-  if (order >= SCREF_ORDER_SEQ && order <= SCREF_ORDER_EIGEN_AVX_FMA) g_sum_order = order;
+  if (order >= SCREF_ORDER_SEQ && order <= SCREF_ORDER_EIGEN34_AVX_FMA) g_sum_order = order;
 }
 int scref_get_sum_order(void) { return g_sum_order; }
 
@@ -49,7 +49,7 @@ static inline double madd(double a, double b, double acc, int fused) {
 /* sum_i a[i]*b[i] (b != NULL) or sum_i a[i] (b == NULL) in the selected order */
 static double redux(int n, const double *a, const double *b) {
   const int P = g_sum_order == SCREF_ORDER_SEQ ? 1 : (g_sum_order == SCREF_ORDER_EIGEN_SSE2 ? 2 : 4);
-  const int fused = g_sum_order == SCREF_ORDER_EIGEN_AVX_FMA;
+  const int fused = g_sum_order == SCREF_ORDER_EIGEN_AVX_FMA || g_sum_order == SCREF_ORDER_EIGEN34_AVX_FMA;
   if (n == 0) return 0.0;
   const int aligned2 = (n / (2 * P)) * (2 * P), aligned = (n / P) * P;
   double res;
@@ -68,7 +68,9 @@ static double redux(int n, const double *a, const double *b) {
         for (int l = 0; l < P; l++)
           r0[l] = b ? madd(a[aligned2 + l], b[aligned2 + l], r0[l], fused) : r0[l] + a[aligned2 + l];
     }
-    res = P == 2 ? r0[0] + r0[1] : (r0[0] + r0[1]) + (r0[2] + r0[3]); /* predux, Eigen 3.3 */
+    if (P == 2) res = r0[0] + r0[1];
+    else if (g_sum_order == SCREF_ORDER_EIGEN34_AVX_FMA) res = (r0[0] + r0[2]) + (r0[1] + r0[3]); /* predux, Eigen 3.4 (AVX) */
+    else res = (r0[0] + r0[1]) + (r0[2] + r0[3]);                                            /* predux, Eigen 3.3 */
     for (int i = aligned; i < n; i++) res = b ? madd(a[i], b[i], res, fused) : res + a[i];
   } else {
     res = b ? a[0] * b[0] : a[0];

@@ -14,7 +14,7 @@ from navtech_radar_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 # product constant -> oracle constant
-ORDERS = {"sse2": (0, 1), "seq": (1, 0), "avx_fma": (2, 2)}
+ORDERS = {"sse2": (0, 1), "seq": (1, 0), "avx_fma": (2, 2), "avx34_fma": (3, 3)}
 
 
 @pytest.fixture(scope="module")
@@ -104,7 +104,7 @@ def test_detector_against_the_matching_build_of_the_reference(sc, oracle, order)
     # nanoflann's kd-tree search (diff * diff + ...), which moves the ORDER of tied ring-key neighbours -- outside what
     # sum_order models (the Eigen sums); its pair function is pinned above, its candidate stage is not
     rm = None
-    if oracle.ref_lib() is not None and oo != oracle.ORDER_EIGEN_AVX_FMA:
+    if oracle.ref_lib() is not None and oo not in (oracle.ORDER_EIGEN_AVX_FMA, oracle.ORDER_EIGEN34_AVX_FMA):
         try:
             rm = oracle.RefManager(oo, dist_thres=0.45)
         except Exception:

@@ -13,7 +13,7 @@ import pytest
 
 from navtech_radar_slam_amd import synth
 
-ORDERS = [0, 1, 2]
+ORDERS = [0, 1, 2, 3]
 
 
 def _ref(oracle, order):
