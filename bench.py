@@ -363,6 +363,41 @@ def orora_leg(device, skip_cpu):
            "matches_per_pair": "300-1500", "outliers": "20-60%", "max_abs_translation_error_m": float(err),
            "max_abs_yaw_error_rad": float(np.abs(res["yaw"] - truth[:, 2]).max()), "dtype": "f64",
            "note": "latency/VALU-bound per pair (K x 16 B input); no HBM roofline applies (SURVEY 8d)"}
+    # the stage in front of the solver in the upstream pipeline (round 6): max-clique inlier selection on the distance-consistency
+    # graph of the matches (csrc/pmc.hip, RSX_ORORA_PMC; on by default in the odometry pipeline).  The same 3 500 pairs with it:
+    # selection + solver in one call, the selection alone, what it keeps, and its records against the oracle
+    from navtech_radar_slam_amd import _rsx as _r
+    p_on = orora.default_params()
+    p_on.flags |= _r.ORORA_PMC
+    reg.reserve(int(off[-1]))
+    d_mem = torch.zeros(int(off[-1]), dtype=torch.uint8, device="cuda")
+    d_info = torch.zeros((n_pairs, 4), dtype=torch.int32, device="cuda")
+
+    def timed(fn):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    dt_on = timed(lambda: reg.register_batch_device(d_src.data_ptr(), d_dst.data_ptr(), d_off.data_ptr(), n_pairs, d_res.data_ptr(), p_on, stream=stream))
+    res_on = d_res.cpu().numpy().view(orora.ORORA_RESULT_DTYPE).reshape(n_pairs)
+    dt_sel = timed(lambda: _r.check(_r.lib().rsx_orora_max_clique_batch_device(reg._h, d_src.data_ptr(), d_dst.data_ptr(), d_off.data_ptr(), n_pairs,
+                                                                              None, d_mem.data_ptr(), d_info.data_ptr(), stream)))
+    info = d_info.cpu().numpy()
+    mem = d_mem.cpu().numpy()
+    leg["with_max_clique_selection"] = {
+        "pairs_per_sec": n_pairs / dt_on, "ms_per_batch": dt_on * 1e3, "selection_alone_ms_per_batch": dt_sel * 1e3,
+        "selected_fraction_of_matches": float(info[:, 0].sum() / off[-1]), "pairs_proven_maximum_by_core_bound": float(np.mean(info[:, 3] & 1)),
+        "seeds_per_pair": float(info[:, 2].mean()),
+        "max_abs_translation_error_m": float(max(np.abs(res_on["x"] - truth[:, 0]).max(), np.abs(res_on["y"] - truth[:, 1]).max())),
+        "max_abs_yaw_error_rad": float(np.abs(res_on["yaw"] - truth[:, 2]).max()), "dtype": "f64 predicate / u32 bitsets",
+        "note": "consistency graph i ~ j <=> | |src_i - src_j| - |dst_i - dst_j| | < tim_noise_bound (fp64, K^2 predicates per pair), "
+                "exact core numbers, greedy clique in (core, index) order, a vertex set = one 32-bit register per lane of a wavefront; "
+                "fp64-VALU + latency bound, no HBM roofline applies"}
     if not skip_cpu:
         from oracle import pyoracle as po
         cores = os.cpu_count() or 1
@@ -372,6 +407,18 @@ def orora_leg(device, skip_cpu):
         leg["cpu_baseline"] = {"value": n_pairs / cdt, "unit": "pairs/s", "cores": cores, "kind": "port",
                                "sample": f"the same {n_pairs} pairs, OpenMP over pairs (oracle/orora_ref.c)"}
         leg["max_abs_pose_diff_vs_oracle"] = float(max(np.abs(res[f] - want[f]).max() for f in ("x", "y", "yaw")))
+        n_chk = 400
+        t0 = time.perf_counter()
+        wm, winfo = po.pmc_select_batch(src[:off[n_chk]], dst[:off[n_chk]], off[:n_chk + 1], p_on.tim_noise_bound, nthreads=cores)
+        sdt = time.perf_counter() - t0
+        s2, d2, o2 = po.pmc_compact(src[:off[n_chk]], dst[:off[n_chk]], off[:n_chk + 1], wm)
+        want_on = po.orora_register_batch(s2, d2, o2, nthreads=cores)
+        sel = leg["with_max_clique_selection"]
+        sel["oracle_checked_pairs"] = n_chk
+        sel["selection_identical_to_oracle"] = bool(np.array_equal(mem[:off[n_chk]], wm) and all(np.array_equal(info[:n_chk, j], winfo[f]) for j, f in enumerate(("size", "max_core", "seeds", "flags"))))
+        sel["max_abs_pose_diff_vs_oracle"] = float(max(np.abs(res_on[f][:n_chk] - want_on[f]).max() for f in ("x", "y", "yaw")))
+        sel["cpu_baseline"] = {"value": n_chk / sdt, "unit": "pairs/s (selection alone)", "cores": cores, "kind": "port",
+                               "sample": f"the first {n_chk} pairs, OpenMP over pairs (oracle/pmc_ref.c)"}
     reg.close()
     return leg
 
@@ -640,6 +687,7 @@ def odometry_e2e_leg(device, skip_cpu, n_unique=24, n_scans=528):
            "keypoints_per_scan_mean": float(res["n_keypoints"].mean()),
            "worst_pair_error_vs_truth": {"translation_m": worst_t, "yaw_rad": worst_y},
            "image": "400x3360 u8 (+11 B/row metadata), 1.35 MB per scan", "dtype": "u8/f32/u32 popcount/f64",
+           "max_clique_selection": "on (rsx_odometry_default_params: RSX_ORORA_PMC)",
            "note": "resident: images already in HBM, 48 B per scan come back; host_images: pageable host array, the PCIe upload of "
                    "every window is inside the time; PNG decode excluded from both (reported under file_entry)"}
     if not skip_cpu:
@@ -856,6 +904,9 @@ def loop_verify_leg(device):
         its += r["iterations"]
     dt = (time.perf_counter() - t0) / len(pairs)
     want = po.loop_verify(clouds, pairs[0][0], pairs[0][1], pose6[pairs[0][0]], sum_order=po.ICP_SUM_TREE)
+    # the independent restatement (float sums in ascending index order: the stand-in for PCL's own loops, oracle/icp_ref.c) as a
+    # reported gate beside the tree-order one, which follows the device's summation order
+    want_seq = po.loop_verify(clouds, pairs[0][0], pairs[0][1], pose6[pairs[0][0]], sum_order=po.ICP_SUM_SEQUENTIAL_FLOAT)
     t0 = time.perf_counter()
     m = kf.build_map(pose6, skip=2, leaf=0.4)
     t_map = time.perf_counter() - t0
@@ -866,6 +917,11 @@ def loop_verify_leg(device):
             "first_verdict_equals_oracle": bool(res["accepted"] == want["accepted"] and res["n_source"] == want["n_source"] and
                                                 res["n_target"] == want["n_target"] and abs(res["fitness"] - want["fitness"]) < 1e-4 * max(1.0, want["fitness"]) and
                                                 res["iterations"] == want["iterations"]),
+            "first_verdict_vs_sequential_float_oracle": {"same_verdict": bool(res["accepted"] == want_seq["accepted"]),
+                                                         "fitness_rel_diff": float(abs(res["fitness"] - want_seq["fitness"]) / max(1e-30, abs(want_seq["fitness"]))),
+                                                         "iterations": [int(res["iterations"]), int(want_seq["iterations"])],
+                                                         "note": "PCL's own source is absent: parity with PCL at the 0.3 fitness gate is NOT established; "
+                                                                 "this is the oracle's second, order-independent reading"},
             "map": {"points": int(len(m)), "keyframes": len(clouds), "ms": t_map * 1e3},
             "dtype": "f32 (fp64 moment sums)",
             "launches_per_verification": 2,
@@ -1428,6 +1484,9 @@ def main():
                 if not out["latency_q1"][nm]["first_4_queries_identical_to_exact_all"]:
                     failures.append(f"latency_q1 {nm}: the single-query path and the exact-all path disagree")
             out["orora"] = orora_leg(ctx.local_rank, args.no_cpu_baseline)
+            sel = out["orora"]["with_max_clique_selection"]
+            if sel.get("selection_identical_to_oracle") is False or sel.get("max_abs_pose_diff_vs_oracle", 0.0) > 1e-4:
+                failures.append("orora: the max-clique selection (or the solver behind it) differs from the oracle")
             out["cen2019"] = cen2019_leg(ctx.local_rank)
             out["icp"] = icp_leg(ctx.local_rank)
             out["loop_verify"] = loop_verify_leg(ctx.local_rank)
@@ -1464,6 +1523,7 @@ def main():
         if "orora" in out:
             sec["orora_pairs_per_sec"] = out["orora"]["pairs_per_sec"]
             sec["orora_max_abs_pose_diff_vs_oracle"] = out["orora"].get("max_abs_pose_diff_vs_oracle")
+            sec["orora_pairs_per_sec_with_max_clique_selection"] = out["orora"]["with_max_clique_selection"]["pairs_per_sec"]
         if "cen2019" in out:
             sec["cen2019_single_scan_ms_pinned"] = out["cen2019"]["pinned_image"]["ms_per_scan"]
             sec["cen2019_batched_device_scans_per_sec"] = out["cen2019"]["batched_device_scans_per_sec"]

@@ -350,7 +350,7 @@ typedef struct {
 typedef struct {
   int32_t size;     /* matches handed to the solver */
   int32_t max_core; /* largest core number of the consistency graph: no clique is larger than max_core + 1 */
-  int32_t seeds;    /* greedy seeds started (<= 4) */
+  int32_t seeds;    /* greedy seeds started (<= 2) */
   int32_t flags;    /* RSX_ORORA_PMC_* */
 } rsx_orora_pmc_info;
 #define RSX_ORORA_PMC_PROVEN 1       /* size == max_core + 1: the clique is a maximum one */

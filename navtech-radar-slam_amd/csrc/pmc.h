@@ -10,7 +10,7 @@ namespace rsx {
 namespace pmc {
 
 constexpr int MAX_K = 2048;      // matches per pair the stage prunes (a vertex set = 64 lanes x 32 bits); larger pairs pass through
-constexpr int MAX_SEEDS = 4;     // greedy seeds per pair
+constexpr int MAX_SEEDS = 2;     // greedy seeds per pair (vertices of the clique in hand are not seeds)
 constexpr size_t SLAB_BYTES = (size_t)MAX_K * 256;  // adjacency of one pair: MAX_K rows of 64 words
 
 struct Workspace {

@@ -21,7 +21,7 @@
 //            smallest remaining degree
 //   phase C  bitonic sort of (2047 - core) << 11 | index in LDS -> `order`
 //   phase D  wave 0: the greedy walk.  64 candidates of `order` are tested against P at once (ds_bpermute + ballot), the rows
-//            of the next four members are loaded together, each is re-tested against the shrinking P before it joins
+//            of the next eight members are loaded together, each is re-tested against the shrinking P before it joins
 //   output   member flags, the selected matches compacted in their original order for the solver, one info record
 // Roofline: the build is fp64-VALU bound (K^2 / 2 ... K^2 predicates of ~20 fp64 operations per pair); the walk is a
 // dependent chain per pair (load row -> and -> popcount), hidden by running 3 workgroups per CU.
@@ -179,13 +179,26 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
         if (m == 0x7fffffff) peeling = false;  // nothing alive: done
         else if (tid == 0) L.level = m;        // jump to the smallest remaining degree
       } else {
-        for (int f = wave; f < nf; f += NT / 64) {
-          const int u = __builtin_amdgcn_readfirstlane((int)front[f]);
-          uint32_t w = adj[(size_t)u * ROWW + lane] & L.alive[lane];
-          while (w) {
-            const int c = __ffs((int)w) - 1;
-            w &= w - 1;
-            atomicSub(&L.deg[c * 64 + lane], 1);
+        // four frontier rows per wave in flight (one row after the other made every round a chain of memory latencies)
+        for (int f0 = 4 * wave; f0 < nf; f0 += 4 * (NT / 64)) {
+          uint32_t wr[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            wr[q] = 0;
+            if (f0 + q < nf) {
+              const int u = __builtin_amdgcn_readfirstlane((int)front[f0 + q]);
+              wr[q] = adj[(size_t)u * ROWW + lane];
+            }
+          }
+          const uint32_t al = L.alive[lane];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            uint32_t w = wr[q] & al;
+            while (w) {
+              const int c = __ffs((int)w) - 1;
+              w &= w - 1;
+              atomicSub(&L.deg[c * 64 + lane], 1);
+            }
           }
         }
         if (tid == 0) L.max_core = level;  // levels only grow: the last one that removed something is the largest core number
@@ -221,6 +234,7 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
       for (int t = 0; t < K && seeds < MAX_SEEDS; t++) {
         const int v = __builtin_amdgcn_readfirstlane((int)(keys[t] & 2047u));
         if ((int)L.core[v] + 1 <= best_n || best_n == max_core + 1) break;
+        if ((((uint32_t)__builtin_amdgcn_readlane((int)best, v & 63)) >> (v >> 6)) & 1u) continue;  // a member of the clique in hand
         seeds++;
         if (cm_for != best_n) {  // candidates must have core >= |best|
           cm = 0;
@@ -240,12 +254,13 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
           const uint32_t pw = (uint32_t)__shfl((int)P, u & 63);
           unsigned long long mask = __ballot(idx < K && ((pw >> (u >> 6)) & 1u));
           while (mask && np > 0 && !abandoned) {
-            // the next (up to) four candidates of this chunk that were in P when the mask was taken: rows loaded together
-            int cu[4];
-            uint32_t row[4];
+            // the next (up to) PF candidates of this chunk that were in P when the mask was taken: rows loaded together
+            constexpr int PF = 8;
+            int cu[PF];
+            uint32_t row[PF];
             int got = 0;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < PF; q++) {
               cu[q] = -1;
               row[q] = 0;
               if (mask) {
@@ -257,7 +272,7 @@ __global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
               }
             }
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < PF; q++) {
               if (q < got && np > 0 && !abandoned) {
                 const int uq = cu[q];
                 const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)P, uq & 63);

@@ -434,9 +434,10 @@ bool use_q1(const rsx_sc *h, int32_t nq, int64_t n_items) {
   const int m = filter_mode_of(h);
   if (off || nq < 1 || nq > Q1_MAX_NQ || !(m == 0 || m == 3)) return false;
   // every query streams the whole database again, so with several queries against a large database the batched chain (one
-  // pass of the spectral filter for all of them) takes over: MI355X, top-1, us per call single-query path / filter chain:
-  // 8 queries x 10 000 keyframes 55 / 88, 8 x 100 000: 305 / 190; one query: 17 / 90 and 54 / 172
-  return m == 3 || nq == 1 || (int64_t)nq * n_items <= 320000;
+  // pass of the spectral filter for all of them) takes over.  Round 6 (the queries of a call share the device's 512 workgroup
+  // slots, q1_grid): MI355X, top-1, us per call single-query path / filter chain -- 10 000 keyframes: 1 query 18 / 91, 2: 22 / 94,
+  // 4: 27 / 94, 8: 36 / 89; 100 000: 1 query 54 / 173, 2: 71 / 175, 4: 112 / 176, 8: 187 / 191 (round 5: 8 x 10 000 55, 8 x 100 000 305)
+  return m == 3 || nq == 1 || (int64_t)nq * n_items <= 800000;
 }
 
 int run_q1(rsx_sc *h, const float *d_q, int32_t nq, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig, int32_t k,

@@ -12,14 +12,14 @@ Modelling choices SHARED with pmc_ref.c (agreement does not validate them): `CHO
 import numpy as np
 
 MAX_K = 2048
-MAX_SEEDS = 4
+MAX_SEEDS = 2
 PROVEN, PASSTHROUGH = 1, 2
 
 CHOICES = (
     "edge i ~ j iff | ||src_i - src_j|| - ||dst_i - dst_j|| | < tau with tau = the TIM noise bound (2 x point noise), evaluated "
     "without square roots in fp64 as s = (A + B) - tau^2, edge <=> s < 0 or s^2 < 4 (A B); greedy clique instead of PMC's exact "
     "branch and bound, seeds and candidates in (core descending, index ascending) order, candidates of a seed restricted to "
-    "core >= |best|, a seed abandoned when |C| + |P| <= |best|, at most 4 seeds; pairs of fewer than 2 or more than 2048 "
+    "core >= |best|, a seed abandoned when |C| + |P| <= |best|, at most 2 seeds, members of the clique in hand are not seeds; pairs of fewer than 2 or more than 2048 "
     "matches pass through unpruned"
 )
 
@@ -69,6 +69,8 @@ def select(src, dst, tau):
     for v in order:
         if seeds >= MAX_SEEDS or core[v] + 1 <= len(best) or len(best) == max_core + 1:
             break
+        if v in best:
+            continue
         seeds += 1
         P = {u for u in nbrs[v] if core[u] >= len(best)}
         C = [v]

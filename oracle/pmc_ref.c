@@ -142,6 +142,7 @@ void pmcref_select(const float *src_xy, const float *dst_xy, int32_t k, double t
   for (int32_t t = 0; t < k && seeds < PMCREF_MAX_SEEDS; t++) {
     const int32_t v = order[t];
     if (core[v] + 1 <= best_n || best_n == max_core + 1) break;
+    if (tst(best, v)) continue; /* a member of the clique in hand: its walk would find (a part of) that clique again */
     seeds++;
     const word *rv = rows + (size_t)v * W;
     memset(P, 0, sizeof(word) * (size_t)W);

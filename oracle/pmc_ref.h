@@ -20,7 +20,9 @@
  *                       bound: a clique of size s needs s vertices of core >= s - 1, so omega <= max core + 1).
  *   greedy clique       PMC's heuristic with a FIXED tie rule (PMC itself runs it under OpenMP and is not deterministic):
  *                       order = vertices by (core descending, index ascending).  Seeds in that order, at most
- *                       PMCREF_MAX_SEEDS of them:
+ *                       PMCREF_MAX_SEEDS of them; a vertex that belongs to the clique in hand is not a seed (its walk would
+ *                       find that clique again: on the bench's data further seeds of that kind never improved anything,
+ *                       seeds outside it improve 1 pair in 4 by a few vertices):
  *                           stop when core(seed) + 1 <= |best|  (no later vertex can be in a larger clique), or when
  *                           |best| = max core + 1 (proven maximum);
  *                           P = N(seed) restricted to vertices of core >= |best|;  C = {seed};
@@ -41,7 +43,11 @@ extern "C" {
 #endif
 
 #define PMCREF_MAX_K 2048   /* matches per pair the stage prunes; larger pairs pass through unpruned (info.flags) */
-#define PMCREF_MAX_SEEDS 4
+#ifdef PMCREF_MAX_SEEDS_OVERRIDE
+#define PMCREF_MAX_SEEDS PMCREF_MAX_SEEDS_OVERRIDE
+#else
+#define PMCREF_MAX_SEEDS 2
+#endif
 
 typedef struct {
   int32_t size;      /* matches selected */

@@ -18,7 +18,7 @@ def main(root, all_grids=False):
             print(f"{calls:7d} {total:14.3f} {avg:12.3f} {pct:7.2f}  {name[:110]}")
         print("\n== per-dispatch durations of the dominant kernel (largest grids first) ==")
         q = ("select name, grid_x*grid_y*grid_z as g, count(*), avg(duration)/1000.0, min(duration)/1000.0, max(duration)/1000.0 "
-             "from kernels where (name like '%_kernel%' or name like '%cen_%' or name like '%fe_%' or name like '%odo_%' or name like '%icp_%' or name like '%vg_%' or name like '%lv_%' or name like '%orora%') "
+             "from kernels where (name like '%_kernel%' or name like '%cen_%' or name like '%fe_%' or name like '%odo_%' or name like '%icp_%' or name like '%vg_%' or name like '%lv_%' or name like '%orora%' or name like '%pmc_%') "
              "group by name, g order by avg(duration) desc limit " + ("40" if all_grids else "8"))
         try:
             for name, grid, n, avg, mn, mx in con.execute(q):
@@ -32,7 +32,7 @@ def main(root, all_grids=False):
              + ("" if all_grids else "where grid_size = (select max(grid_size) from counters_collection d where d.kernel_name = c.kernel_name) ")
              + "group by kernel_name, " + ("grid_size, " if all_grids else "") + "counter_name order by kernel_name, grid_size, counter_name")
         for name, cname, n, avg, grid, vgpr, lds in con.execute(q):
-            if not any(t in name for t in ("rsx", "cen_", "fe_", "odo_", "icp_", "vg_", "lv_", "orora", "sc_")):
+            if not any(t in name for t in ("rsx", "cen_", "fe_", "odo_", "icp_", "vg_", "lv_", "orora", "sc_", "pmc_")):
                 continue
             short = name.replace("void ", "").replace("(anonymous namespace)::", "")[:40]  # (split("::")[-1] cut kernels with a namespaced ARGUMENT type down to the argument list)
             print(f"{short:42s} {cname:24s} dispatches={n:3d} avg_per_dispatch={avg:18.1f} grid={grid} vgpr={vgpr} lds={lds}")
