@@ -12,11 +12,12 @@ namespace pmc {
 constexpr int MAX_K = 2048;      // matches per pair the stage prunes (a vertex set = 64 lanes x 32 bits); larger pairs pass through
 constexpr int MAX_SEEDS = 2;     // greedy seeds per pair (vertices of the clique in hand are not seeds)
 constexpr size_t SLAB_BYTES = (size_t)MAX_K * 256;  // adjacency of one pair: MAX_K rows of 64 words
+constexpr int META_BYTES = 8 * MAX_K + 256;      // per pair between the kernels: core numbers, order, degrees, header
+constexpr int CHUNK = 2048;                      // pairs per launch group (1 GiB of slabs): larger batches run in several
 
 struct Workspace {
-  rsx::DevBuf slabs;    // one adjacency slab per resident workgroup
-  rsx::DevBuf counter;  // the pair queue's head
-  int n_wg = 0;         // workgroups of a launch (what the device keeps resident, from the occupancy query)
+  rsx::DevBuf slabs;  // one adjacency slab per pair of a chunk
+  rsx::DevBuf meta;   // one record per pair of a chunk
 };
 
 // member (optional): 1 / 0 per match, laid out like the matches; info (optional): one per pair; sel_src / sel_dst / sel_cnt

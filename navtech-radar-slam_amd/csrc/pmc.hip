@@ -8,23 +8,25 @@
 //   core numbers        level-synchronous peeling (exact; the result is unique)
 //   greedy clique       seeds and candidates in (core descending, index ascending) order, <= MAX_SEEDS seeds
 //
-// Mapping.  One 256-thread workgroup per pair, pairs pulled from a queue (their cost goes with K^2: 300 .. 1500 matches in
-// the bench).  A VERTEX SET IS ONE REGISTER PER LANE OF A WAVEFRONT: 64 lanes x 32 bits = 2048 vertices, vertex u = bit
-// u / 64 of lane u % 64 (lane-interleaved, so that lane l of the adjacency build reads points l, 64 + l, ...: consecutive LDS
+// Mapping.  A VERTEX SET IS ONE REGISTER PER LANE OF A WAVEFRONT: 64 lanes x 32 bits = 2048 vertices, vertex u = bit u / 64 of
+// lane u % 64 (lane-interleaved, so that lane l of the adjacency build reads points l, 64 + l, ...: consecutive LDS
 // addresses).  Set intersection = one v_and against a 256-byte adjacency row (one coalesced load), |P| = v_bcnt + a wave
-// reduction, "is u in P" = v_readlane + shift.  The adjacency of the pair in flight lives in a 512 KB slab of HBM per
-// resident workgroup (L2 / Infinity Cache resident: written once, read once by the peeling and once per picked vertex).
-//   phase A  4 waves, row i of the graph per wave iteration: 64 lanes x ceil(K / 64) columns of the fp64 predicate -> one
-//            word per lane -> one 256-byte row store; degree by popcount
-//   phase B  core numbers: frontier = alive vertices of degree <= level (all threads), each frontier vertex's row & alive
-//            decrements its neighbours' degrees (LDS atomics, a wave per frontier vertex); empty frontier -> level = the
-//            smallest remaining degree
-//   phase C  bitonic sort of (2047 - core) << 11 | index in LDS -> `order`
-//   phase D  wave 0: the greedy walk.  64 candidates of `order` are tested against P at once (ds_bpermute + ballot), the rows
-//            of the next eight members are loaded together, each is re-tested against the shrinking P before it joins
-//   output   member flags, the selected matches compacted in their original order for the solver, one info record
-// Roofline: the build is fp64-VALU bound (K^2 / 2 ... K^2 predicates of ~20 fp64 operations per pair); the walk is a
-// dependent chain per pair (load row -> and -> popcount), hidden by running 3 workgroups per CU.
+// reduction, "is u in P" = v_readlane + shift.  The adjacency of a pair lives in a 512 KB slab of HBM (written once, read
+// once by the peeling and once per picked vertex).  Three kernels per chunk of <= CHUNK pairs, one workgroup per pair, each
+// with the shape ITS phase wants (the first build ran all phases in one 256-thread workgroup with 45 KB of LDS: three
+// workgroups per CU, and during the walk one of their twelve wavefronts at work -- 6.6 ms per 3 500 pairs):
+//   pmc_build_kernel   256 threads, points in LDS: row i of the graph per wave iteration, 64 lanes x ceil(K / 64) columns of
+//                      the fp64 predicate -> one word per lane -> one 256-byte row store; degree by popcount
+//   pmc_cores_kernel   256 threads: core numbers by level-synchronous peeling -- frontier = alive vertices of degree <=
+//                      level (all threads), the frontier rows & alive decrement their neighbours' degrees (LDS atomics, four
+//                      rows in flight per wave); empty frontier -> level = the smallest remaining degree -- then a bitonic
+//                      sort of (2047 - core) << 11 | index in LDS -> `order`
+//   pmc_walk_kernel    ONE WAVEFRONT per pair (up to 20 pairs per CU): the greedy walk.  64 candidates of `order` are
+//                      tested against P at once (ds_bpermute + ballot), the rows of the next eight members are loaded
+//                      together, each is re-tested against the shrinking P before it joins; then member flags, the selected
+//                      matches compacted in their original order for the solver, one info record
+// Roofline: the build is fp64-VALU bound (K^2 predicates of ~20 fp64 operations per pair); peeling and walk are dependent
+// chains per pair (barrier / load row -> and -> popcount), hidden by the number of pairs in flight.
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -37,30 +39,23 @@ using rsx::pmc::MAX_K;
 using rsx::pmc::MAX_SEEDS;
 constexpr int NT = 256;
 constexpr int ROWW = 64;  // words per adjacency row
+// per-pair record between the kernels: core numbers, the order, the degrees, the largest core number
+constexpr int META_CORE = 0, META_ORDER = 2 * MAX_K, META_DEG = 4 * MAX_K, META_HDR = 8 * MAX_K;
+constexpr int META_BYTES = rsx::pmc::META_BYTES;
+static_assert(META_HDR + 64 <= META_BYTES, "meta layout");
 
 struct Args {
   const float2 *src, *dst;
   const int64_t *offsets;
-  int n_pairs;
+  int n_pairs, first;  // this launch: pairs [first, first + gridDim.x)
   double tau2;
-  uint32_t *slabs;
-  unsigned *counter;
+  uint32_t *slabs;     // [chunk][MAX_K][ROWW]
+  char *meta;          // [chunk][META_BYTES]
   uint8_t *member;
   rsx_orora_pmc_info *info;
   float2 *sel_src, *sel_dst;
   int32_t *sel_cnt;
   int64_t sel_cap;  // matches the sel arrays hold
-};
-
-struct Lds {
-  float2 src[MAX_K];  // phase A; afterwards: the sort keys (uint32_t[MAX_K])
-  float2 dst[MAX_K];  // phase A; afterwards: the frontier list (uint16_t[MAX_K])
-  int deg[MAX_K];
-  uint16_t core[MAX_K];
-  uint32_t alive[ROWW];
-  uint32_t best[ROWW];
-  int red[8];
-  int nfront, level, max_core, pair, best_n, seeds;
 };
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -71,11 +66,6 @@ __device__ __forceinline__ int wave_sum_i(int v) {
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) v = min(v, __shfl_xor(v, off));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = max(v, __shfl_xor(v, off));
   return v;
 }
 
@@ -89,244 +79,277 @@ __device__ __forceinline__ bool edge(double six, double siy, double dix, double 
   return (sm < 0.0) || (sm * sm < 4.0 * (A * B));
 }
 
-__global__ __launch_bounds__(NT) void pmc_select_kernel(Args a) {
-  __shared__ Lds L;
-  // Everything a whole wavefront decides goes through an SGPR (readfirstlane): hipcc cannot see that `wave`, or a value every
-  // thread read from the same LDS word, is uniform, and structurises such branches with exec masks -- the first build of the
-  // peeling loop `if (tid == 0) L.level = m; continue;` parked lane 0's store behind a loop the other 63 lanes of its wave
-  // could not leave without it (the kernel never returned).  Uniform values in SGPRs make those branches scalar.
+// the pair of this workgroup: false = not pruned (fewer than 2 / more than MAX_K matches / no room in the sel arrays)
+struct Pair {
+  int pair, K;
+  int64_t o, K64;
+  bool no_room;
+};
+__device__ __forceinline__ bool pair_of(const Args &a, Pair &p) {
+  p.pair = a.first + (int)blockIdx.x;
+  p.o = a.offsets[p.pair];
+  p.K64 = a.offsets[p.pair + 1] - p.o;
+  p.no_room = a.sel_src && p.o + p.K64 > a.sel_cap;
+  p.K = (int)p.K64;
+  return !(p.K64 < 2 || p.K64 > MAX_K || p.no_room);
+}
+
+// Everything a whole wavefront decides goes through an SGPR (readfirstlane): hipcc cannot see that `wave`, or a value every
+// thread read from the same LDS word, is uniform, and structurises such branches with exec masks -- the first build of the
+// peeling loop `if (tid == 0) L.level = m; continue;` parked lane 0's store behind a loop the other 63 lanes of its wave
+// could not leave without it (the kernel never returned).  Uniform values in SGPRs make those branches scalar.
+
+__global__ __launch_bounds__(NT) void pmc_build_kernel(Args a) {
+  __shared__ float2 s_src[MAX_K], s_dst[MAX_K];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Pair p;
+  if (!pair_of(a, p)) return;
+  const int K = p.K, nc = (K + 63) >> 6;
   uint32_t *adj = a.slabs + (size_t)blockIdx.x * (rsx::pmc::SLAB_BYTES / 4);
-  uint32_t *keys = reinterpret_cast<uint32_t *>(L.src);
-  uint16_t *front = reinterpret_cast<uint16_t *>(L.dst);
+  int *deg = reinterpret_cast<int *>(a.meta + (size_t)blockIdx.x * META_BYTES + META_DEG);
+  for (int i = tid; i < K; i += NT) {
+    s_src[i] = a.src[p.o + i];
+    s_dst[i] = a.dst[p.o + i];
+  }
+  __syncthreads();
+  for (int i = wave; i < K; i += NT / 64) {
+    const float2 si = s_src[i], di = s_dst[i];
+    const double six = si.x, siy = si.y, dix = di.x, diy = di.y;
+    uint32_t w = 0;
+    for (int c = 0; c < nc; c++) {
+      const int j = c * 64 + lane;
+      if (j < K && j != i && edge(six, siy, dix, diy, s_src[j], s_dst[j], a.tau2)) w |= 1u << c;
+    }
+    adj[(size_t)i * ROWW + lane] = w;
+    const int d = wave_sum_i(__popc(w));
+    if (lane == 0) deg[i] = d;
+  }
+}
 
-  for (;;) {
-    __syncthreads();  // the previous pair's LDS is dead
-    if (tid == 0) L.pair = (int)atomicAdd(a.counter, 1u);
+struct CoreLds {
+  int deg[MAX_K];
+  uint32_t keys[MAX_K];    // the sort keys; before the sort: the frontier list (uint16_t[MAX_K])
+  uint16_t core[MAX_K];
+  uint32_t alive[ROWW];
+  int red[4];
+  int nfront, level, max_core;
+};
+
+__global__ __launch_bounds__(NT) void pmc_cores_kernel(Args a) {
+  __shared__ CoreLds L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  Pair p;
+  if (!pair_of(a, p)) return;
+  const int K = p.K, nc = (K + 63) >> 6;
+  const uint32_t *adj = a.slabs + (size_t)blockIdx.x * (rsx::pmc::SLAB_BYTES / 4);
+  char *meta = a.meta + (size_t)blockIdx.x * META_BYTES;
+  uint16_t *front = reinterpret_cast<uint16_t *>(L.keys);
+  {
+    const int *deg = reinterpret_cast<const int *>(meta + META_DEG);
+    for (int i = tid; i < K; i += NT) L.deg[i] = deg[i];
+  }
+  if (tid < ROWW) {
+    uint32_t w = 0;  // alive = every vertex < K
+    for (int c = 0; c < nc; c++) w |= (c * 64 + tid < K) ? (1u << c) : 0u;
+    L.alive[tid] = w;
+  }
+  if (tid == 0) {
+    L.level = 0;
+    L.max_core = 0;
+  }
+  __syncthreads();
+
+  // ---- core numbers by level-synchronous peeling (one exit, three barriers per round) ----
+  for (bool peeling = true; peeling;) {
+    if (tid == 0) L.nfront = 0;
     __syncthreads();
-    const int pair = __builtin_amdgcn_readfirstlane(L.pair);
-    if (pair >= a.n_pairs) break;
-    const int64_t o = a.offsets[pair];
-    const int64_t K64 = a.offsets[pair + 1] - o;
-    const bool no_room = a.sel_src && o + K64 > a.sel_cap;
-    if (K64 < 2 || K64 > MAX_K || no_room) {  // nothing to prune with / too large for the stage: every match passes
-      if (a.member)
-        for (int64_t i = tid; i < K64; i += NT) a.member[o + i] = 1;
-      if (tid == 0) {
-        if (a.sel_cnt) a.sel_cnt[pair] = -1;  // the solver reads the caller's arrays
-        if (a.info)
-          a.info[pair] = rsx_orora_pmc_info{(int32_t)(K64 > 0 ? K64 : 0), 0, 0,
-                                            RSX_ORORA_PMC_PASSTHROUGH | (no_room && K64 >= 2 && K64 <= MAX_K ? RSX_ORORA_PMC_NO_WORKSPACE : 0)};
+    const int level = __builtin_amdgcn_readfirstlane(L.level);
+    int my_min = 0x7fffffff;
+    for (int v = tid; v < K; v += NT) {
+      if ((L.alive[v & 63] >> (v >> 6)) & 1u) {
+        const int d = L.deg[v];
+        if (d <= level) {
+          front[atomicAdd(&L.nfront, 1)] = (uint16_t)v;
+          L.core[v] = (uint16_t)level;
+          atomicAnd(&L.alive[v & 63], ~(1u << (v >> 6)));
+        } else {
+          my_min = min(my_min, d);
+        }
       }
-      continue;
     }
-    const int K = __builtin_amdgcn_readfirstlane((int)K64), nc = (K + 63) >> 6;
-
-    // ---- phase A: points into LDS, adjacency rows into the slab, degrees ----
-    for (int i = tid; i < K; i += NT) {
-      L.src[i] = a.src[o + i];
-      L.dst[i] = a.dst[o + i];
-    }
-    if (tid < ROWW) {
-      uint32_t w = 0;  // alive = every vertex < K
-      for (int c = 0; c < nc; c++) w |= (c * 64 + tid < K) ? (1u << c) : 0u;
-      L.alive[tid] = w;
-      L.best[tid] = 0;
-    }
+    my_min = wave_min_i(my_min);
+    if (lane == 0) L.red[wave] = my_min;
     __syncthreads();
-    for (int i = wave; i < K; i += NT / 64) {
-      const float2 si = L.src[i], di = L.dst[i];
-      const double six = si.x, siy = si.y, dix = di.x, diy = di.y;
-      uint32_t w = 0;
+    const int nf = __builtin_amdgcn_readfirstlane(L.nfront);
+    if (nf == 0) {
+      const int m = __builtin_amdgcn_readfirstlane(min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3])));
+      if (m == 0x7fffffff) peeling = false;  // nothing alive: done
+      else if (tid == 0) L.level = m;        // jump to the smallest remaining degree
+    } else {
+      // four frontier rows per wave in flight (one row after the other made every round a chain of memory latencies)
+      for (int f0 = 4 * wave; f0 < nf; f0 += 4 * (NT / 64)) {
+        uint32_t wr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          wr[q] = 0;
+          if (f0 + q < nf) {
+            const int u = __builtin_amdgcn_readfirstlane((int)front[f0 + q]);
+            wr[q] = adj[(size_t)u * ROWW + lane];
+          }
+        }
+        const uint32_t al = L.alive[lane];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          uint32_t w = wr[q] & al;
+          while (w) {
+            const int c = __ffs((int)w) - 1;
+            w &= w - 1;
+            atomicSub(&L.deg[c * 64 + lane], 1);
+          }
+        }
+      }
+      if (tid == 0) L.max_core = level;  // levels only grow: the last one that removed something is the largest core number
+    }
+    __syncthreads();  // every wave has read nfront / red and finished its decrements before the next round resets them
+  }
+
+  // ---- order = vertices by (core descending, index ascending) ----
+  int n2 = 64;
+  while (n2 < K) n2 <<= 1;
+  for (int i = tid; i < n2; i += NT) L.keys[i] = i < K ? (((uint32_t)(2047 - L.core[i])) << 11) | (uint32_t)i : 0xffffffffu;
+  __syncthreads();
+  for (int k2 = 2; k2 <= n2; k2 <<= 1)
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < n2; i += NT) {
+        const int q = i ^ j;
+        if (q > i) {
+          const uint32_t x = L.keys[i], y = L.keys[q];
+          if (((i & k2) == 0) == (x > y)) {
+            L.keys[i] = y;
+            L.keys[q] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  uint16_t *g_core = reinterpret_cast<uint16_t *>(meta + META_CORE), *g_order = reinterpret_cast<uint16_t *>(meta + META_ORDER);
+  for (int i = tid; i < K; i += NT) {
+    g_core[i] = L.core[i];
+    g_order[i] = (uint16_t)(L.keys[i] & 2047u);
+  }
+  if (tid == 0) *reinterpret_cast<int *>(meta + META_HDR) = L.max_core;
+}
+
+__global__ __launch_bounds__(64) void pmc_walk_kernel(Args a) {
+  __shared__ uint16_t s_core[MAX_K], s_order[MAX_K];
+  const int lane = threadIdx.x;
+  Pair p;
+  if (!pair_of(a, p)) {  // nothing to prune with / too large for the stage: every match passes
+    if (a.member)
+      for (int64_t i = lane; i < p.K64; i += 64) a.member[p.o + i] = 1;
+    if (lane == 0) {
+      if (a.sel_cnt) a.sel_cnt[p.pair] = -1;  // the solver reads the caller's arrays
+      if (a.info)
+        a.info[p.pair] = rsx_orora_pmc_info{(int32_t)(p.K64 > 0 ? p.K64 : 0), 0, 0,
+                                            RSX_ORORA_PMC_PASSTHROUGH | (p.no_room && p.K64 >= 2 && p.K64 <= MAX_K ? RSX_ORORA_PMC_NO_WORKSPACE : 0)};
+    }
+    return;
+  }
+  const int K = __builtin_amdgcn_readfirstlane(p.K), nc = (K + 63) >> 6;
+  const uint32_t *adj = a.slabs + (size_t)blockIdx.x * (rsx::pmc::SLAB_BYTES / 4);
+  const char *meta = a.meta + (size_t)blockIdx.x * META_BYTES;
+  {
+    const uint16_t *g_core = reinterpret_cast<const uint16_t *>(meta + META_CORE), *g_order = reinterpret_cast<const uint16_t *>(meta + META_ORDER);
+    for (int i = lane; i < K; i += 64) {
+      s_core[i] = g_core[i];
+      s_order[i] = g_order[i];
+    }
+  }
+  const int max_core = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(meta + META_HDR));
+  __syncthreads();
+
+  uint32_t best = 0, cm = 0;
+  int best_n = 0, seeds = 0, cm_for = -1;
+  for (int t = 0; t < K && seeds < MAX_SEEDS; t++) {
+    const int v = __builtin_amdgcn_readfirstlane((int)s_order[t]);
+    const int cv = __builtin_amdgcn_readfirstlane((int)s_core[v]);
+    if (cv + 1 <= best_n || best_n == max_core + 1) break;
+    if ((((uint32_t)__builtin_amdgcn_readlane((int)best, v & 63)) >> (v >> 6)) & 1u) continue;  // a member of the clique in hand
+    seeds++;
+    if (cm_for != best_n) {  // candidates must have core >= |best|
+      cm = 0;
       for (int c = 0; c < nc; c++) {
-        const int j = c * 64 + lane;
-        if (j < K && j != i && edge(six, siy, dix, diy, L.src[j], L.dst[j], a.tau2)) w |= 1u << c;
+        const int u = c * 64 + lane;
+        if (u < K && (int)s_core[u] >= best_n) cm |= 1u << c;
       }
-      adj[(size_t)i * ROWW + lane] = w;
-      const int d = wave_sum_i(__popc(w));
-      if (lane == 0) L.deg[i] = d;
+      cm_for = best_n;
     }
-    if (tid == 0) {
-      L.level = 0;
-      L.max_core = 0;
-    }
-    __syncthreads();
-
-    // ---- phase B: core numbers by level-synchronous peeling (one exit, three barriers per round) ----
-    for (bool peeling = true; peeling;) {
-      if (tid == 0) L.nfront = 0;
-      __syncthreads();
-      const int level = __builtin_amdgcn_readfirstlane(L.level);
-      int my_min = 0x7fffffff;
-      for (int v = tid; v < K; v += NT) {
-        if ((L.alive[v & 63] >> (v >> 6)) & 1u) {
-          const int d = L.deg[v];
-          if (d <= level) {
-            front[atomicAdd(&L.nfront, 1)] = (uint16_t)v;
-            L.core[v] = (uint16_t)level;
-            atomicAnd(&L.alive[v & 63], ~(1u << (v >> 6)));
-          } else {
-            my_min = min(my_min, d);
-          }
-        }
-      }
-      my_min = wave_min_i(my_min);
-      if (lane == 0) L.red[wave] = my_min;
-      __syncthreads();
-      const int nf = __builtin_amdgcn_readfirstlane(L.nfront);
-      if (nf == 0) {
-        const int m = __builtin_amdgcn_readfirstlane(min(min(L.red[0], L.red[1]), min(L.red[2], L.red[3])));
-        if (m == 0x7fffffff) peeling = false;  // nothing alive: done
-        else if (tid == 0) L.level = m;        // jump to the smallest remaining degree
-      } else {
-        // four frontier rows per wave in flight (one row after the other made every round a chain of memory latencies)
-        for (int f0 = 4 * wave; f0 < nf; f0 += 4 * (NT / 64)) {
-          uint32_t wr[4];
+    uint32_t P = adj[(size_t)v * ROWW + lane] & cm;
+    uint32_t C = (lane == (v & 63)) ? (1u << (v >> 6)) : 0u;
+    int n = 1, np = __builtin_amdgcn_readfirstlane(wave_sum_i(__popc(P)));
+    bool abandoned = n + np <= best_n;
+    for (int s = 0; s < K && np > 0 && !abandoned; s += 64) {
+      const int idx = s + lane;
+      const int u = idx < K ? (int)s_order[idx] : 0;
+      const uint32_t pw = (uint32_t)__shfl((int)P, u & 63);
+      unsigned long long mask = __ballot(idx < K && ((pw >> (u >> 6)) & 1u));
+      while (mask && np > 0 && !abandoned) {
+        // the next (up to) PF candidates of this chunk that were in P when the mask was taken: rows loaded together
+        constexpr int PF = 8;
+        int cu[PF];
+        uint32_t row[PF];
+        int got = 0;
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            wr[q] = 0;
-            if (f0 + q < nf) {
-              const int u = __builtin_amdgcn_readfirstlane((int)front[f0 + q]);
-              wr[q] = adj[(size_t)u * ROWW + lane];
-            }
+        for (int q = 0; q < PF; q++) {
+          cu[q] = -1;
+          row[q] = 0;
+          if (mask) {
+            const int i0 = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            cu[q] = __builtin_amdgcn_readlane(u, i0);
+            row[q] = adj[(size_t)cu[q] * ROWW + lane];
+            got++;
           }
-          const uint32_t al = L.alive[lane];
+        }
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            uint32_t w = wr[q] & al;
-            while (w) {
-              const int c = __ffs((int)w) - 1;
-              w &= w - 1;
-              atomicSub(&L.deg[c * 64 + lane], 1);
+        for (int q = 0; q < PF; q++) {
+          if (q < got && np > 0 && !abandoned) {
+            const int uq = cu[q];
+            const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)P, uq & 63);
+            if ((pq >> (uq >> 6)) & 1u) {  // still in P: joins the clique
+              if (lane == (uq & 63)) C |= 1u << (uq >> 6);
+              n++;
+              P &= row[q];
+              np = __builtin_amdgcn_readfirstlane(wave_sum_i(__popc(P)));
+              if (n + np <= best_n) abandoned = true;
             }
           }
         }
-        if (tid == 0) L.max_core = level;  // levels only grow: the last one that removed something is the largest core number
       }
-      __syncthreads();  // every wave has read nfront / red and finished its decrements before the next round resets them
     }
-    const int max_core = __builtin_amdgcn_readfirstlane(L.max_core);
+    if (!abandoned && n > best_n) {
+      best_n = n;
+      best = C;
+    }
+  }
 
-    // ---- phase C: order = vertices by (core descending, index ascending) ----
-    int n2 = 64;
-    while (n2 < K) n2 <<= 1;
-    for (int i = tid; i < n2; i += NT) keys[i] = i < K ? (((uint32_t)(2047 - L.core[i])) << 11) | (uint32_t)i : 0xffffffffu;
-    __syncthreads();
-    for (int k2 = 2; k2 <= n2; k2 <<= 1)
-      for (int j = k2 >> 1; j > 0; j >>= 1) {
-        for (int i = tid; i < n2; i += NT) {
-          const int p = i ^ j;
-          if (p > i) {
-            const uint32_t x = keys[i], y = keys[p];
-            if (((i & k2) == 0) == (x > y)) {
-              keys[i] = y;
-              keys[p] = x;
-            }
-          }
-        }
-        __syncthreads();
-      }
-
-    // ---- phase D: the greedy clique (wave 0) ----
-    if (wave == 0) {
-      uint32_t best = 0, cm = 0;
-      int best_n = 0, seeds = 0, cm_for = -1;
-      for (int t = 0; t < K && seeds < MAX_SEEDS; t++) {
-        const int v = __builtin_amdgcn_readfirstlane((int)(keys[t] & 2047u));
-        if ((int)L.core[v] + 1 <= best_n || best_n == max_core + 1) break;
-        if ((((uint32_t)__builtin_amdgcn_readlane((int)best, v & 63)) >> (v >> 6)) & 1u) continue;  // a member of the clique in hand
-        seeds++;
-        if (cm_for != best_n) {  // candidates must have core >= |best|
-          cm = 0;
-          for (int c = 0; c < nc; c++) {
-            const int u = c * 64 + lane;
-            if (u < K && (int)L.core[u] >= best_n) cm |= 1u << c;
-          }
-          cm_for = best_n;
-        }
-        uint32_t P = adj[(size_t)v * ROWW + lane] & cm;
-        uint32_t C = (lane == (v & 63)) ? (1u << (v >> 6)) : 0u;
-        int n = 1, np = __builtin_amdgcn_readfirstlane(wave_sum_i(__popc(P)));
-        bool abandoned = n + np <= best_n;
-        for (int s = 0; s < K && np > 0 && !abandoned; s += 64) {
-          const int idx = s + lane;
-          const int u = idx < K ? (int)(keys[idx] & 2047u) : 0;
-          const uint32_t pw = (uint32_t)__shfl((int)P, u & 63);
-          unsigned long long mask = __ballot(idx < K && ((pw >> (u >> 6)) & 1u));
-          while (mask && np > 0 && !abandoned) {
-            // the next (up to) PF candidates of this chunk that were in P when the mask was taken: rows loaded together
-            constexpr int PF = 8;
-            int cu[PF];
-            uint32_t row[PF];
-            int got = 0;
-#pragma unroll
-            for (int q = 0; q < PF; q++) {
-              cu[q] = -1;
-              row[q] = 0;
-              if (mask) {
-                const int i0 = __ffsll((long long)mask) - 1;
-                mask &= mask - 1;
-                cu[q] = __builtin_amdgcn_readlane(u, i0);
-                row[q] = adj[(size_t)cu[q] * ROWW + lane];
-                got++;
-              }
-            }
-#pragma unroll
-            for (int q = 0; q < PF; q++) {
-              if (q < got && np > 0 && !abandoned) {
-                const int uq = cu[q];
-                const uint32_t pq = (uint32_t)__builtin_amdgcn_readlane((int)P, uq & 63);
-                if ((pq >> (uq >> 6)) & 1u) {  // still in P: joins the clique
-                  if (lane == (uq & 63)) C |= 1u << (uq >> 6);
-                  n++;
-                  P &= row[q];
-                  np = __builtin_amdgcn_readfirstlane(wave_sum_i(__popc(P)));
-                  if (n + np <= best_n) abandoned = true;
-                }
-              }
-            }
-          }
-        }
-        if (!abandoned && n > best_n) {
-          best_n = n;
-          best = C;
-        }
-      }
-      L.best[lane] = best;
-      if (lane == 0) {
-        L.best_n = best_n;
-        L.seeds = seeds;
-      }
+  // ---- output: flags, the selected matches in their original order, the info record ----
+  int run = 0;
+  for (int c = 0; c < nc; c++) {  // vertex c * 64 + lane = bit c of this lane's word
+    const int v = c * 64 + lane;
+    const bool sel = v < K && ((best >> c) & 1u);
+    if (v < K && a.member) a.member[p.o + v] = sel ? 1 : 0;
+    const unsigned long long bal = __ballot(sel);
+    if (sel && a.sel_src) {
+      const int pos = run + __popcll(bal & ((1ull << lane) - 1ull));
+      a.sel_src[p.o + pos] = a.src[p.o + v];
+      a.sel_dst[p.o + pos] = a.dst[p.o + v];
     }
-    __syncthreads();
-
-    // ---- output: flags, the selected matches in their original order, the info record ----
-    const int best_n = __builtin_amdgcn_readfirstlane(L.best_n);
-    int run = 0;
-    for (int base = 0; base < K; base += NT) {
-      const int v = base + tid;
-      const bool sel = v < K && ((L.best[v & 63] >> (v >> 6)) & 1u);
-      if (v < K && a.member) a.member[o + v] = sel ? 1 : 0;
-      const unsigned long long bal = __ballot(sel);
-      if (lane == 0) L.red[4 + wave] = __popcll(bal);
-      __syncthreads();
-      int before = run, total = 0;
-      for (int w = 0; w < NT / 64; w++) {
-        if (w < wave) before += L.red[4 + w];
-        total += L.red[4 + w];
-      }
-      if (sel && a.sel_src) {
-        const int pos = before + __popcll(bal & ((1ull << lane) - 1ull));
-        a.sel_src[o + pos] = a.src[o + v];
-        a.sel_dst[o + pos] = a.dst[o + v];
-      }
-      run += total;
-      __syncthreads();
-    }
-    if (tid == 0) {
-      if (a.sel_cnt) a.sel_cnt[pair] = best_n;
-      if (a.info) a.info[pair] = rsx_orora_pmc_info{best_n, max_core, L.seeds, best_n == max_core + 1 ? RSX_ORORA_PMC_PROVEN : 0};
-    }
+    run += __popcll(bal);
+  }
+  if (lane == 0) {
+    if (a.sel_cnt) a.sel_cnt[p.pair] = best_n;
+    if (a.info) a.info[p.pair] = rsx_orora_pmc_info{best_n, max_core, seeds, best_n == max_core + 1 ? RSX_ORORA_PMC_PROVEN : 0};
   }
 }
 
@@ -337,18 +360,12 @@ namespace pmc {
 
 int launch(Workspace &ws, int device, const float2 *d_src, const float2 *d_dst, const int64_t *d_offsets, int n_pairs, double tau,
            uint8_t *d_member, rsx_orora_pmc_info *d_info, float2 *d_sel_src, float2 *d_sel_dst, int32_t *d_sel_cnt, int64_t sel_cap, hipStream_t s) {
+  (void)device;
   if (n_pairs <= 0) return RSX_OK;
   if (!(tau > 0.0)) return rsx::fail(RSX_ERR_BAD_ARG, "the consistency bound (tim_noise_bound) must be positive");
-  if (!ws.n_wg) {  // as many workgroups as the device runs at once (they pull pairs from a queue; no barrier between them)
-    int cus = 0, per_cu = 0;
-    RSX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
-    RSX_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(&pmc_select_kernel), NT, 0));
-    ws.n_wg = (cus < 1 ? 1 : cus) * (per_cu < 1 ? 1 : per_cu);
-  }
-  const int g = n_pairs < ws.n_wg ? n_pairs : ws.n_wg;
-  RSX_TRY(ws.slabs.reserve((size_t)g * SLAB_BYTES, s, false));
-  RSX_TRY(ws.counter.reserve(64, s, false));
-  RSX_HIP(hipMemsetAsync(ws.counter.p, 0, 4, s));
+  const int chunk = n_pairs < CHUNK ? n_pairs : CHUNK;
+  RSX_TRY(ws.slabs.reserve((size_t)chunk * SLAB_BYTES, s, false));
+  RSX_TRY(ws.meta.reserve((size_t)chunk * META_BYTES, s, false));
   Args a;
   a.src = d_src;
   a.dst = d_dst;
@@ -356,14 +373,20 @@ int launch(Workspace &ws, int device, const float2 *d_src, const float2 *d_dst, 
   a.n_pairs = n_pairs;
   a.tau2 = tau * tau;
   a.slabs = ws.slabs.as<uint32_t>();
-  a.counter = ws.counter.as<unsigned>();
+  a.meta = ws.meta.as<char>();
   a.member = d_member;
   a.info = d_info;
   a.sel_src = d_sel_src;
   a.sel_dst = d_sel_dst;
   a.sel_cnt = d_sel_cnt;
   a.sel_cap = sel_cap;
-  hipLaunchKernelGGL(pmc_select_kernel, dim3((unsigned)g), dim3(NT), 0, s, a);
+  for (int first = 0; first < n_pairs; first += chunk) {
+    const int n = n_pairs - first < chunk ? n_pairs - first : chunk;
+    a.first = first;
+    hipLaunchKernelGGL(pmc_build_kernel, dim3((unsigned)n), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(pmc_cores_kernel, dim3((unsigned)n), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(pmc_walk_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
+  }
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 }
