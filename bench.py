@@ -407,18 +407,20 @@ def orora_leg(device, skip_cpu):
         leg["cpu_baseline"] = {"value": n_pairs / cdt, "unit": "pairs/s", "cores": cores, "kind": "port",
                                "sample": f"the same {n_pairs} pairs, OpenMP over pairs (oracle/orora_ref.c)"}
         leg["max_abs_pose_diff_vs_oracle"] = float(max(np.abs(res[f] - want[f]).max() for f in ("x", "y", "yaw")))
-        n_chk = 400
+        n_chk = n_pairs   # the selection is integer work: every pair of the batch is compared
         t0 = time.perf_counter()
         wm, winfo = po.pmc_select_batch(src[:off[n_chk]], dst[:off[n_chk]], off[:n_chk + 1], p_on.tim_noise_bound, nthreads=cores)
         sdt = time.perf_counter() - t0
-        s2, d2, o2 = po.pmc_compact(src[:off[n_chk]], dst[:off[n_chk]], off[:n_chk + 1], wm)
+        n_reg = 400
+        s2, d2, o2 = po.pmc_compact(src[:off[n_reg]], dst[:off[n_reg]], off[:n_reg + 1], wm[:off[n_reg]])
         want_on = po.orora_register_batch(s2, d2, o2, nthreads=cores)
         sel = leg["with_max_clique_selection"]
         sel["oracle_checked_pairs"] = n_chk
         sel["selection_identical_to_oracle"] = bool(np.array_equal(mem[:off[n_chk]], wm) and all(np.array_equal(info[:n_chk, j], winfo[f]) for j, f in enumerate(("size", "max_core", "seeds", "flags"))))
-        sel["max_abs_pose_diff_vs_oracle"] = float(max(np.abs(res_on[f][:n_chk] - want_on[f]).max() for f in ("x", "y", "yaw")))
+        sel["solver_checked_pairs"] = n_reg
+        sel["max_abs_pose_diff_vs_oracle"] = float(max(np.abs(res_on[f][:n_reg] - want_on[f]).max() for f in ("x", "y", "yaw")))
         sel["cpu_baseline"] = {"value": n_chk / sdt, "unit": "pairs/s (selection alone)", "cores": cores, "kind": "port",
-                               "sample": f"the first {n_chk} pairs, OpenMP over pairs (oracle/pmc_ref.c)"}
+                               "sample": f"the same {n_chk} pairs, OpenMP over pairs (oracle/pmc_ref.c)"}
     reg.close()
     return leg
 

@@ -854,7 +854,8 @@ int rsx_orora_destroy(rsx_orora *h) try {
   h->res.release();
   h->big_list.release();
   h->big_ws.release();
-  for (rsx::DevBuf *b : {&h->pmc_ws.slabs, &h->pmc_ws.meta, &h->sel_src, &h->sel_dst, &h->sel_cnt, &h->pmc_info, &h->member}) b->release();
+  h->pmc_ws.release();
+  for (rsx::DevBuf *b : {&h->sel_src, &h->sel_dst, &h->sel_cnt, &h->pmc_info, &h->member}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;

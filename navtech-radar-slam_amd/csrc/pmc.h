@@ -13,11 +13,15 @@ constexpr int MAX_K = 2048;      // matches per pair the stage prunes (a vertex 
 constexpr int MAX_SEEDS = 2;     // greedy seeds per pair (vertices of the clique in hand are not seeds)
 constexpr size_t SLAB_BYTES = (size_t)MAX_K * 256;  // adjacency of one pair: MAX_K rows of 64 words
 constexpr int META_BYTES = 8 * MAX_K + 256;      // per pair between the kernels: core numbers, order, degrees, header
-constexpr int CHUNK = 2048;                      // pairs per launch group (1 GiB of slabs): larger batches run in several
+constexpr int CHUNK = 4096;                      // pairs per launch group (2 GiB of slabs); larger batches run as several
 
 struct Workspace {
   rsx::DevBuf slabs;  // one adjacency slab per pair of a chunk
   rsx::DevBuf meta;   // one record per pair of a chunk
+  void release() {
+    slabs.release();
+    meta.release();
+  }
 };
 
 // member (optional): 1 / 0 per match, laid out like the matches; info (optional): one per pair; sel_src / sel_dst / sel_cnt

@@ -12,11 +12,13 @@
 // lane u % 64 (lane-interleaved, so that lane l of the adjacency build reads points l, 64 + l, ...: consecutive LDS
 // addresses).  Set intersection = one v_and against a 256-byte adjacency row (one coalesced load), |P| = v_bcnt + a wave
 // reduction, "is u in P" = v_readlane + shift.  The adjacency of a pair lives in a 512 KB slab of HBM (written once, read
-// once by the peeling and once per picked vertex).  Three kernels per chunk of <= CHUNK pairs, one workgroup per pair, each
-// with the shape ITS phase wants (the first build ran all phases in one 256-thread workgroup with 45 KB of LDS: three
-// workgroups per CU, and during the walk one of their twelve wavefronts at work -- 6.6 ms per 3 500 pairs):
-//   pmc_build_kernel   256 threads, points in LDS: row i of the graph per wave iteration, 64 lanes x ceil(K / 64) columns of
-//                      the fp64 predicate -> one word per lane -> one 256-byte row store; degree by popcount
+// once by the peeling and once per picked vertex).  Three kernels per chunk of <= CHUNK pairs, each with the shape ITS phase
+// wants (the first build ran all phases in one 256-thread workgroup per pair with 45 KB of LDS: three workgroups per CU, during
+// the walk one of their twelve wavefronts at work, every predicate in fp64 -- 6.6 ms per 3 500 pairs; now 4.1):
+//   pmc_build_kernel   a workgroup per block of 256 ROWS of a pair (the cost of a pair goes with K^2: whole pairs left the chip
+//                      at 1.9 of 4 waves per SIMD), points in LDS: row i of the graph per wave iteration, 64 lanes x
+//                      ceil(K / 64) columns of the predicate -- decided in fp32 wherever fp32 can, edge_f32 -- two columns per
+//                      step with the next two on their way -> one word per lane -> one 256-byte row store; degree by popcount
 //   pmc_cores_kernel   256 threads: core numbers by level-synchronous peeling -- frontier = alive vertices of degree <=
 //                      level (all threads), the frontier rows & alive decrement their neighbours' degrees (LDS atomics, four
 //                      rows in flight per wave); empty frontier -> level = the smallest remaining degree -- then a bitonic
@@ -25,8 +27,9 @@
 //                      tested against P at once (ds_bpermute + ballot), the rows of the next eight members are loaded
 //                      together, each is re-tested against the shrinking P before it joins; then member flags, the selected
 //                      matches compacted in their original order for the solver, one info record
-// Roofline: the build is fp64-VALU bound (K^2 predicates of ~20 fp64 operations per pair); peeling and walk are dependent
-// chains per pair (barrier / load row -> and -> popcount), hidden by the number of pairs in flight.
+// Roofline: the build is VALU-issue bound (SQ_ACTIVE_INST_VALU = 100 % of the SIMD cycles at ~31 instructions per pair of
+// matches: 2.6 of the 4.1 ms); peeling and walk are dependent chains per pair (barrier / load row -> and -> popcount) that last
+// as long as the longest pair's, hidden by the number of pairs in flight (0.9 + 0.6 ms).
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -58,10 +61,12 @@ struct Args {
   int64_t sel_cap;  // matches the sel arrays hold
 };
 
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-  return v;
+__device__ __forceinline__ int wave_sum_i(int x) {  // every lane: the sum over the 64 lanes (DPP + v_readlane: no LDS round trips)
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);  // row_mirror: every lane = its row's sum
+  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 }
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -99,30 +104,73 @@ __device__ __forceinline__ bool pair_of(const Args &a, Pair &p) {
 // peeling loop `if (tid == 0) L.level = m; continue;` parked lane 0's store behind a loop the other 63 lanes of its wave
 // could not leave without it (the kernel never returned).  Uniform values in SGPRs make those branches scalar.
 
+// The same predicate decided in fp32 wherever fp32 can decide it (round 6).  The fp64 form alone made the build 5.2 ms of a
+// 7.9 ms selection -- not for its fp64 rate but for its instruction count: a wave64 VALU instruction is 4 cycles of its SIMD
+// (SQ_ACTIVE_INST_VALU = SQ_INSTS_VALU quad-cycles) and the step was 36 of them.  In fp32, with u = 2^-24: A, B carry a relative
+// error <= 4.2 u, v_sqrt_f32 is good to 1 ulp (2 u), so da = sqrt A, db = sqrt B are within 4.1 u of the true distances and
+// x = da - db within 4.1 u (da + db) + u |x| of the true difference.  Hence, with e = 8 u (da + db):
+//     |x| + e < tau (1 - 4 u)   =>  edge,        |x| - e > tau (1 + 4 u)   =>  no edge
+// (tau as a float is within u of the bound, u |x| ~ u tau; the fp64 form of oracle/pmc_ref.h errs by ~1e-16; slack ~4 u (da + db)).
+// Whatever is left -- pairs within ~3e-4 m of the bound at 150 m range, NaN coordinates -- takes the fp64 form; a wavefront
+// skips it when none of its 64 lanes needs it (tests/test_gpu_pmc.py::test_edges_at_the_bound).
+__device__ __forceinline__ void edge_f32(float2 si, float2 di, float2 sj, float2 dj, float tau_lo, float tau_hi, bool &yes, bool &no) {
+  const float dax = sj.x - si.x, day = sj.y - si.y, dbx = dj.x - di.x, dby = dj.y - di.y;
+  const float A = __fmaf_rn(day, day, dax * dax), B = __fmaf_rn(dby, dby, dbx * dbx);
+  const float da = __builtin_amdgcn_sqrtf(A), db = __builtin_amdgcn_sqrtf(B);
+  const float x = fabsf(da - db), e = (da + db) * 0x1p-21f;
+  yes = x + e < tau_lo;
+  no = x - e > tau_hi;
+}
+
+// pmc_build_kernel: rows [256 blockIdx.y, + 256) of the consistency graph of pair blockIdx.x (rows into the slab, degrees into
+// the pair's record).  A workgroup per ROW BLOCK, not per pair: the cost of a pair goes with K^2 (x 25 between 300 and 1500
+// matches), and with one workgroup per pair the chip ran at 1.9 of 4 waves per SIMD (SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE) waiting
+// for the long ones.  Two columns per step, the next two already on their way from LDS.
+constexpr int BUILD_ROWS = 256;
 __global__ __launch_bounds__(NT) void pmc_build_kernel(Args a) {
   __shared__ float2 s_src[MAX_K], s_dst[MAX_K];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   Pair p;
   if (!pair_of(a, p)) return;
-  const int K = p.K, nc = (K + 63) >> 6;
+  const int K = p.K, nc = (K + 63) >> 6, nc2 = (nc + 1) & ~1;
+  const int row0 = (int)blockIdx.y * BUILD_ROWS;
+  if (row0 >= K) return;
+  const int row1 = row0 + BUILD_ROWS < K ? row0 + BUILD_ROWS : K;
   uint32_t *adj = a.slabs + (size_t)blockIdx.x * (rsx::pmc::SLAB_BYTES / 4);
-  int *deg = reinterpret_cast<int *>(a.meta + (size_t)blockIdx.x * META_BYTES + META_DEG);
-  for (int i = tid; i < K; i += NT) {
-    s_src[i] = a.src[p.o + i];
-    s_dst[i] = a.dst[p.o + i];
+  int *g_deg = reinterpret_cast<int *>(a.meta + (size_t)blockIdx.x * META_BYTES + META_DEG);
+  for (int i = tid; i < nc2 * 64 && i < MAX_K; i += NT) {  // (slots past K hold zeros: finite, and masked below)
+    s_src[i] = i < K ? a.src[p.o + i] : float2{0.0f, 0.0f};
+    s_dst[i] = i < K ? a.dst[p.o + i] : float2{0.0f, 0.0f};
   }
   __syncthreads();
-  for (int i = wave; i < K; i += NT / 64) {
+  const float tau = (float)sqrt(a.tau2), tau_lo = tau * (1.0f - 0x1p-22f), tau_hi = tau * (1.0f + 0x1p-22f);
+  for (int i = row0 + wave; i < row1; i += NT / 64) {
     const float2 si = s_src[i], di = s_dst[i];
-    const double six = si.x, siy = si.y, dix = di.x, diy = di.y;
     uint32_t w = 0;
-    for (int c = 0; c < nc; c++) {
-      const int j = c * 64 + lane;
-      if (j < K && j != i && edge(six, siy, dix, diy, s_src[j], s_dst[j], a.tau2)) w |= 1u << c;
+    float2 sj0 = s_src[lane], dj0 = s_dst[lane], sj1 = s_src[(64 + lane) & (MAX_K - 1)], dj1 = s_dst[(64 + lane) & (MAX_K - 1)];
+    for (int c = 0; c < nc; c += 2) {
+      const float2 a0 = sj0, b0 = dj0, a1 = sj1, b1 = dj1;
+      const int jn = ((c + 2) * 64 + lane) & (MAX_K - 1);  // (the read past the last pair of columns is harmless and unused)
+      sj0 = s_src[jn];
+      dj0 = s_dst[jn];
+      sj1 = s_src[(jn + 64) & (MAX_K - 1)];
+      dj1 = s_dst[(jn + 64) & (MAX_K - 1)];
+      bool y0, n0, y1, n1;
+      edge_f32(si, di, a0, b0, tau_lo, tau_hi, y0, n0);
+      edge_f32(si, di, a1, b1, tau_lo, tau_hi, y1, n1);
+      if (__ballot(!(y0 || n0) || !(y1 || n1)) != 0ull) {  // (wave-uniform) somebody is too close to the bound for fp32
+        const double six = si.x, siy = si.y, dix = di.x, diy = di.y;
+        const bool e0 = edge(six, siy, dix, diy, a0, b0, a.tau2), e1 = edge(six, siy, dix, diy, a1, b1, a.tau2);
+        y0 = (y0 || n0) ? y0 : e0;
+        y1 = (y1 || n1) ? y1 : e1;
+      }
+      const int j0 = c * 64 + lane, j1 = j0 + 64;
+      w |= (y0 && j0 < K && j0 != i) ? (1u << c) : 0u;
+      w |= (y1 && j1 < K && j1 != i) ? (2u << c) : 0u;
     }
     adj[(size_t)i * ROWW + lane] = w;
     const int d = wave_sum_i(__popc(w));
-    if (lane == 0) deg[i] = d;
+    if (lane == 0) g_deg[i] = d;
   }
 }
 
@@ -358,6 +406,11 @@ __global__ __launch_bounds__(64) void pmc_walk_kernel(Args a) {
 namespace rsx {
 namespace pmc {
 
+// Chunks of <= CHUNK pairs, one after the other on the caller's stream.  (Measured and not kept: two chunks in flight, the
+// VALU-bound build of chunk c + 1 on the caller's stream beside the peeling + walk of chunk c on a side stream -- the
+// peeling and the walk last as long as their LONGEST pair's chain of barriers and memory latencies whatever the number of
+// pairs (0.5 - 0.65 ms each for 875 pairs as for 2 048), so four chunks of 875 pairs cost 5.3 ms against 5.0 ms for two
+// chunks in sequence, and one chunk of all 3 500 is the fastest.)
 int launch(Workspace &ws, int device, const float2 *d_src, const float2 *d_dst, const int64_t *d_offsets, int n_pairs, double tau,
            uint8_t *d_member, rsx_orora_pmc_info *d_info, float2 *d_sel_src, float2 *d_sel_dst, int32_t *d_sel_cnt, int64_t sel_cap, hipStream_t s) {
   (void)device;
@@ -383,7 +436,7 @@ int launch(Workspace &ws, int device, const float2 *d_src, const float2 *d_dst, 
   for (int first = 0; first < n_pairs; first += chunk) {
     const int n = n_pairs - first < chunk ? n_pairs - first : chunk;
     a.first = first;
-    hipLaunchKernelGGL(pmc_build_kernel, dim3((unsigned)n), dim3(NT), 0, s, a);
+    hipLaunchKernelGGL(pmc_build_kernel, dim3((unsigned)n, (unsigned)(MAX_K / BUILD_ROWS)), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pmc_cores_kernel, dim3((unsigned)n), dim3(NT), 0, s, a);
     hipLaunchKernelGGL(pmc_walk_kernel, dim3((unsigned)n), dim3(64), 0, s, a);
   }

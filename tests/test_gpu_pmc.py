@@ -125,3 +125,48 @@ def test_device_entry_needs_a_reservation_and_survives_too_small_a_one(reg, orac
     res = d_res.cpu().numpy().view(_rsx.ORORA_RESULT_DTYPE).reshape(12)
     assert (res["status"] == 0).all()
     fresh.close()
+
+
+def test_edges_at_the_bound(reg, oracle):
+    """The build decides a pair of matches in fp32 where fp32 can and falls back to the oracle's fp64 form otherwise
+    (csrc/pmc.hip edge_f32): thousands of two-match pairs whose distance difference lies within 0 .. 1e-2 of the bound on
+    either side (K = 2: the selection keeps both matches iff they are consistent), exact equality included (strict <: no
+    edge), duplicates (A = 0 or B = 0), far-away points, a tiny and a huge bound; and lines of 64 matches whose neighbours
+    sit exactly on / just inside the bound."""
+    from navtech_radar_slam_amd import orora
+    rng = np.random.default_rng(21)
+    src, dst, off = [], [], [0]
+
+    def add(s, d):
+        src.append(np.asarray(s, dtype=np.float64).reshape(-1, 2))
+        dst.append(np.asarray(d, dtype=np.float64).reshape(-1, 2))
+        off.append(off[-1] + len(src[-1]))
+
+    for eps in (0.0, 1e-9, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2):
+        for sign in (-1.0, 1.0):
+            for _ in range(250):
+                r = rng.uniform(0.05, 400.0) if rng.random() < 0.8 else rng.uniform(0.0, 2.0)
+                grow = rng.choice([-1.0, 1.0])
+                r2 = max(0.0, r + grow * (TAU + sign * eps))
+                phi, psi = rng.uniform(0, 2 * np.pi, 2)
+                o1, o2 = rng.uniform(-200, 200, 2), rng.uniform(-200, 200, 2)
+                add([o1, o1 + r * np.array([np.cos(phi), np.sin(phi)])], [o2, o2 + r2 * np.array([np.cos(psi), np.sin(psi)])])
+    for a, b in ((3.0, 4.5), (3.0, 1.5), (3.0, 4.499999), (3.0, 4.500001), (0.0, 1.5), (0.0, 1.4999999), (1e4, 1e4 + 1.5), (1e4, 1e4 + 1.49)):
+        add([[0, 0], [a, 0]], [[0, 0], [b, 0]])          # axis-aligned, exactly representable: |da - db| == the bound -> no edge
+        add([[5, 5], [5, 5 + a]], [[-7, 2], [-7 + b, 2]])
+    add([[1, 1], [1, 1]], [[2, 2], [2, 3.4]])             # A = 0
+    add([[1, 1], [1, 2.6]], [[2, 2], [2, 2]])             # B = 0
+    i = np.arange(64, dtype=np.float64)
+    add(np.stack([i, 0 * i], 1), np.stack([2.5 * i, 0 * i], 1))             # neighbours exactly on the bound: no edges at all
+    add(np.stack([i, 0 * i], 1), np.stack([2.4999998 * i, 0 * i], 1))       # ... just inside: a path
+    add(np.stack([0 * i, 3 * i], 1), np.stack([4.5 * i, 0 * i], 1))
+    src = np.concatenate(src).astype(np.float32); dst = np.concatenate(dst).astype(np.float32); off = np.array(off, dtype=np.int64)
+    for tau in (TAU, 1e-3, 37.5):
+        p = orora.default_params()
+        p.tim_noise_bound = tau
+        m, info = reg.max_clique_batch(src, dst, off, p)
+        wm, winfo = oracle.pmc_select_batch(src, dst, off, tau, nthreads=8)
+        _same_selection(m, info, wm, winfo)
+    two = np.diff(off) == 2
+    m, info = reg.max_clique_batch(src, dst, off)
+    assert 0.3 < np.mean(info["size"][two] == 2) < 0.7     # both sides of the bound are populated
