@@ -14,7 +14,7 @@
 // reduction, "is u in P" = v_readlane + shift.  The adjacency of a pair lives in a 512 KB slab of HBM (written once, read
 // once by the peeling and once per picked vertex).  Three kernels per chunk of <= CHUNK pairs, each with the shape ITS phase
 // wants (the first build ran all phases in one 256-thread workgroup per pair with 45 KB of LDS: three workgroups per CU, during
-// the walk one of their twelve wavefronts at work, every predicate in fp64 -- 6.6 ms per 3 500 pairs; now 4.1):
+// the walk one of their twelve wavefronts at work, every predicate in fp64 -- 6.6 ms per 3 500 pairs; now 3.8):
 //   pmc_build_kernel   a workgroup per block of 256 ROWS of a pair (the cost of a pair goes with K^2: whole pairs left the chip
 //                      at 1.9 of 4 waves per SIMD), points in LDS: row i of the graph per wave iteration, 64 lanes x
 //                      ceil(K / 64) columns of the predicate -- decided in fp32 wherever fp32 can, edge_f32 -- two columns per
@@ -28,7 +28,7 @@
 //                      together, each is re-tested against the shrinking P before it joins; then member flags, the selected
 //                      matches compacted in their original order for the solver, one info record
 // Roofline: the build is VALU-issue bound (SQ_ACTIVE_INST_VALU = 100 % of the SIMD cycles at ~31 instructions per pair of
-// matches: 2.6 of the 4.1 ms); peeling and walk are dependent chains per pair (barrier / load row -> and -> popcount) that last
+// matches: 2.4 of the 3.8 ms); peeling and walk are dependent chains per pair (barrier / load row -> and -> popcount) that last
 // as long as the longest pair's, hidden by the number of pairs in flight (0.9 + 0.6 ms).
 #include <hip/hip_runtime.h>
 
@@ -113,9 +113,10 @@ __device__ __forceinline__ bool pair_of(const Args &a, Pair &p) {
 // (tau as a float is within u of the bound, u |x| ~ u tau; the fp64 form of oracle/pmc_ref.h errs by ~1e-16; slack ~4 u (da + db)).
 // Whatever is left -- pairs within ~3e-4 m of the bound at 150 m range, NaN coordinates -- takes the fp64 form; a wavefront
 // skips it when none of its 64 lanes needs it (tests/test_gpu_pmc.py::test_edges_at_the_bound).
-__device__ __forceinline__ void edge_f32(float2 si, float2 di, float2 sj, float2 dj, float tau_lo, float tau_hi, bool &yes, bool &no) {
-  const float dax = sj.x - si.x, day = sj.y - si.y, dbx = dj.x - di.x, dby = dj.y - di.y;
-  const float A = __fmaf_rn(day, day, dax * dax), B = __fmaf_rn(dby, dby, dbx * dbx);
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void edge_f32(f2v si, f2v di, f2v sj, f2v dj, float tau_lo, float tau_hi, bool &yes, bool &no) {
+  const f2v da2 = (sj - si) * (sj - si), db2 = (dj - di) * (dj - di);  // (v_pk_add_f32 / v_pk_mul_f32: x and y in one instruction)
+  const float A = da2.x + da2.y, B = db2.x + db2.y;                      // relative error <= 4.2 u, as with the fused form
   const float da = __builtin_amdgcn_sqrtf(A), db = __builtin_amdgcn_sqrtf(B);
   const float x = fabsf(da - db), e = (da + db) * 0x1p-21f;
   yes = x + e < tau_lo;
@@ -144,30 +145,37 @@ __global__ __launch_bounds__(NT) void pmc_build_kernel(Args a) {
   }
   __syncthreads();
   const float tau = (float)sqrt(a.tau2), tau_lo = tau * (1.0f - 0x1p-22f), tau_hi = tau * (1.0f + 0x1p-22f);
+  uint32_t vm = 0;  // this lane's columns that exist: bit c <=> c * 64 + lane < K
+  for (int c = 0; c < nc; c++) vm |= (c * 64 + lane < K) ? (1u << c) : 0u;
+  const f2v *v_src = reinterpret_cast<const f2v *>(s_src), *v_dst = reinterpret_cast<const f2v *>(s_dst);
   for (int i = row0 + wave; i < row1; i += NT / 64) {
-    const float2 si = s_src[i], di = s_dst[i];
+    const f2v si = v_src[i], di = v_dst[i];
+    // columns from the last pair down to the first: a row's word is built by shifting the new bit in from the right
+    // (w = w + w + bit: a compare into vcc and one add-with-carry), the pair after next already on its way from LDS
     uint32_t w = 0;
-    float2 sj0 = s_src[lane], dj0 = s_dst[lane], sj1 = s_src[(64 + lane) & (MAX_K - 1)], dj1 = s_dst[(64 + lane) & (MAX_K - 1)];
-    for (int c = 0; c < nc; c += 2) {
-      const float2 a0 = sj0, b0 = dj0, a1 = sj1, b1 = dj1;
-      const int jn = ((c + 2) * 64 + lane) & (MAX_K - 1);  // (the read past the last pair of columns is harmless and unused)
-      sj0 = s_src[jn];
-      dj0 = s_dst[jn];
-      sj1 = s_src[(jn + 64) & (MAX_K - 1)];
-      dj1 = s_dst[(jn + 64) & (MAX_K - 1)];
+    int c = nc2 - 2;
+    f2v sj0 = v_src[c * 64 + lane], dj0 = v_dst[c * 64 + lane], sj1 = v_src[c * 64 + 64 + lane], dj1 = v_dst[c * 64 + 64 + lane];
+    for (; c >= 0; c -= 2) {
+      const f2v a0 = sj0, b0 = dj0, a1 = sj1, b1 = dj1;
+      const int jn = ((c - 2) * 64 + lane) & (MAX_K - 1);  // (the read before the first pair of columns is harmless and unused)
+      sj0 = v_src[jn];
+      dj0 = v_dst[jn];
+      sj1 = v_src[(jn + 64) & (MAX_K - 1)];
+      dj1 = v_dst[(jn + 64) & (MAX_K - 1)];
       bool y0, n0, y1, n1;
       edge_f32(si, di, a0, b0, tau_lo, tau_hi, y0, n0);
       edge_f32(si, di, a1, b1, tau_lo, tau_hi, y1, n1);
       if (__ballot(!(y0 || n0) || !(y1 || n1)) != 0ull) {  // (wave-uniform) somebody is too close to the bound for fp32
         const double six = si.x, siy = si.y, dix = di.x, diy = di.y;
-        const bool e0 = edge(six, siy, dix, diy, a0, b0, a.tau2), e1 = edge(six, siy, dix, diy, a1, b1, a.tau2);
+        const bool e0 = edge(six, siy, dix, diy, float2{a0.x, a0.y}, float2{b0.x, b0.y}, a.tau2),
+                   e1 = edge(six, siy, dix, diy, float2{a1.x, a1.y}, float2{b1.x, b1.y}, a.tau2);
         y0 = (y0 || n0) ? y0 : e0;
         y1 = (y1 || n1) ? y1 : e1;
       }
-      const int j0 = c * 64 + lane, j1 = j0 + 64;
-      w |= (y0 && j0 < K && j0 != i) ? (1u << c) : 0u;
-      w |= (y1 && j1 < K && j1 != i) ? (2u << c) : 0u;
+      w = (w << 2) | (y1 ? 2u : 0u) | (y0 ? 1u : 0u);
     }
+    w &= vm;                                                   // columns past K
+    if (lane == (i & 63)) w &= ~(1u << (i >> 6));              // no self loop
     adj[(size_t)i * ROWW + lane] = w;
     const int d = wave_sum_i(__popc(w));
     if (lane == 0) g_deg[i] = d;
