@@ -602,7 +602,35 @@ def slam_stream_leg(device, db_pts, db_off, n_kf=3000, every=4):
             j += 1
     loops_c = sum(1 for g_ in got if g_[1][0] >= 0)
     loops_e = sum(1 for g_ in got if g_[2][0] >= 0)
-    return {"keyframes": n_kf, "keyframes_per_sec": n_kf / dt, "seconds": dt, "queries": len(got), "loops_candidate_mode": loops_c,
+    # the same stream from C++ (host/sc_shim_demo --stream: the SCManager shim, two managers, the clouds read into memory
+    # first): what the loop costs without the Python harness around every call
+    cpp = None
+    exe = os.path.join(ROOT, "navtech-radar-slam_amd", "host", "sc_shim_demo")
+    if os.path.exists(exe):
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".clouds", delete=False) as tf:
+            path = tf.name
+            tf.write(np.int32(n_kf).tobytes())
+            for i in range(n_kf):
+                c = np.ascontiguousarray(db_pts[db_off[i]:db_off[i + 1], :4], dtype=np.float32)
+                tf.write(np.int32(len(c)).tobytes())
+                tf.write(c.tobytes())
+        try:
+            r = subprocess.run([exe, "--stream", path, "--every", str(every)], capture_output=True, text=True, timeout=300)
+            line = [ln for ln in r.stdout.splitlines() if ln.startswith("STREAM")]
+            dets = [ln.split() for ln in r.stdout.splitlines() if ln.startswith("DET")]
+            if r.returncode == 0 and line:
+                kv = dict(x.split("=") for x in line[0].split()[1:])
+                same = len(dets) == len(got) and all(int(d[1]) == g_[0] and int(d[2]) == g_[1][0] and int(d[4]) == g_[2][0] and
+                                                     abs(float(d[3]) - g_[1][1]) < 1e-6 and abs(float(d[5]) - g_[2][1]) < 1e-6 for d, g_ in zip(dets, got))
+                cpp = {"keyframes_per_sec": float(kv["keyframes_per_sec"]), "seconds": float(kv["seconds"]), "detections": int(kv["detections"]),
+                       "detections_identical_to_python_harness": bool(same),
+                       "note": "host/sc_shim_demo --stream: the C++ SCManager shim (Scancontext.h), log lines off"}
+            else:
+                cpp = {"error": (r.stderr or r.stdout)[-300:]}
+        finally:
+            os.unlink(path)
+    return {"keyframes": n_kf, "keyframes_per_sec": n_kf / dt, "seconds": dt, "cpp_host": cpp, "queries": len(got), "loops_candidate_mode": loops_c,
             "loops_exhaustive_mode": loops_e, "candidate_mode_identical_to_oracle": int(same_c), "exhaustive_mode_identical_to_oracle": int(same_e),
             "workload": f"streaming_slam_emulation_{n_kf}_trajectory_keyframes_detect_every_{every}",
             "note": "BASELINE configs[3] on one MI355X (two handles fed in parallel: candidate and exhaustive detector); the "
@@ -1507,6 +1535,8 @@ def main():
                 ss = out["slam_stream"]
                 if ss["candidate_mode_identical_to_oracle"] != ss["queries"] or ss["exhaustive_mode_identical_to_oracle"] != ss["queries"]:
                     failures.append("streaming SLAM emulation differs from the oracle")
+                if ss.get("cpp_host") and ss["cpp_host"].get("detections_identical_to_python_harness") is False:
+                    failures.append("streaming SLAM emulation: the C++ host's detections differ from the Python harness's")
         if not args.no_cpu_baseline:
             if db_pts is None:
                 raise SystemExit("cpu_baseline needs --data trajectory (the oracle rebuilds the DB from the clouds)")

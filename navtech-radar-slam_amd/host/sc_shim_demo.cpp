@@ -3,6 +3,7 @@
 // Build: g++ -std=c++17 -I../../include -Iscancontext/.. sc_shim_demo.cpp -L.. -lrsx -pthread
 // Prints one line per detected loop in the reference's own format (PGO.cpp:566).
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -89,8 +90,66 @@ static int replay(const char *path, const std::vector<int> &devices, bool exhaus
   return 0;
 }
 
+// --stream <file> [--every N]: the streaming-SLAM emulation of bench.py (BASELINE configs[3]) from C++ -- every keyframe of the
+// file goes into TWO managers (the reference's candidate detector and the exhaustive one), every N-th keyframe both detect.
+// The clouds are read into memory first; timed: the loop of makeAndSaveScancontextAndKeys / detectLoopClosureID calls only.
+// stdout: one "DET i cand_id cand_yaw exh_id exh_yaw" line per detection, then "STREAM keyframes=.. detections=.. seconds=.. keyframes_per_sec=..".
+static int stream(const char *path, int every) {
+  FILE *f = std::fopen(path, "rb");
+  if (!f) {
+    std::fprintf(stderr, "cannot open %s\n", path);
+    return 1;
+  }
+  int32_t n_clouds = 0;
+  if (std::fread(&n_clouds, 4, 1, f) != 1) return 1;
+  std::vector<std::vector<Pt>> clouds((size_t)n_clouds);
+  std::vector<float> raw;
+  for (int i = 0; i < n_clouds; i++) {
+    int32_t n = 0;
+    if (std::fread(&n, 4, 1, f) != 1) return 1;
+    raw.resize((size_t)n * 4);
+    if (n && std::fread(raw.data(), 16, (size_t)n, f) != (size_t)n) return 1;
+    for (int j = 0; j < n; j++) clouds[(size_t)i].push_back(Pt{raw[4 * j], raw[4 * j + 1], raw[4 * j + 2], raw[4 * j + 3], {}});
+  }
+  std::fclose(f);
+  SCManager cand, exh;
+  cand.setSCdistThres(0.45);
+  exh.setSCdistThres(0.45);
+  exh.setExhaustive(true);
+  cand.setVerbose(false);  // (the reference's "[Loop found] / [Not loop]" line per detection: stdout is not what is timed here)
+  exh.setVerbose(false);
+  cand.handle();
+  exh.handle();
+  struct Det {
+    int i, c_id, e_id;
+    float c_yaw, e_yaw;
+  };
+  std::vector<Det> dets;
+  dets.reserve((size_t)n_clouds / (every > 0 ? every : 1) + 1);
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n_clouds; i++) {
+    const std::vector<Pt> &c = clouds[(size_t)i];
+    cand.makeAndSaveScancontextAndKeys(c.empty() ? nullptr : &c[0].x, c.size(), sizeof(Pt));
+    exh.makeAndSaveScancontextAndKeys(c.empty() ? nullptr : &c[0].x, c.size(), sizeof(Pt));
+    if (every > 0 && i % every == every - 1) {
+      const auto a = cand.detectLoopClosureID(), b = exh.detectLoopClosureID();
+      dets.push_back(Det{i, a.first, b.first, a.second, b.second});
+    }
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (const Det &d : dets) std::printf("DET %d %d %.9g %d %.9g\n", d.i, d.c_id, (double)d.c_yaw, d.e_id, (double)d.e_yaw);
+  std::printf("STREAM keyframes=%d detections=%zu seconds=%.6f keyframes_per_sec=%.1f\n", n_clouds, dets.size(), dt, n_clouds / dt);
+  return 0;
+}
+
 int main(int argc, char **argv) {
   try {
+    if (argc >= 3 && std::string(argv[1]) == "--stream") {
+      int every = 4;
+      for (int i = 3; i + 1 < argc; i++)
+        if (std::string(argv[i]) == "--every") every = std::atoi(argv[i + 1]);
+      return stream(argv[2], every);
+    }
     if (argc >= 3 && std::string(argv[1]) == "--replay") {
       std::vector<int> devices;
       bool exhaustive = false;
