@@ -438,7 +438,10 @@ typedef struct {
   float ratio;              /* default nearest-neighbour distance ratio of rsx_frontend_match callers (0.8) */
   int32_t flags;            /* RSX_FRONTEND_*; 0 = default */
 } rsx_frontend_params;
-#define RSX_FRONTEND_THREE_PASS 1 /* remap, blur rows, blur columns as three kernels instead of one fused tile kernel (same images) */
+#define RSX_FRONTEND_THREE_PASS 1     /* remap, blur rows, blur columns as three kernels instead of the one strip kernel (same images) */
+#define RSX_FRONTEND_EXACT_AZIMUTH 2  /* decide every pixel's azimuth row by the fp64 division (default: a reciprocal multiply with a proven \
+                                         margin, the division only where the margin does not decide; same images) */
+#define RSX_FRONTEND_TILES 4          /* the 32 x 32 LDS-tile kernel of round 3 instead of the strip kernel (same images) */
 
 int rsx_frontend_default_params(rsx_frontend_params *p);
 /* one handle per polar image shape (rows azimuths x cols range bins) */

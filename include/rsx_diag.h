@@ -22,6 +22,11 @@ extern "C" {
  * RSX_ERR_INTERNAL.  Needs no device. */
 int rsx_selftest_firewall(int kind);
 
+/* Parity helper of the ORORA front end: Cartesian image `image` of the handle's last rsx_frontend_cartesian* call and its
+ * 7 x 7 Gaussian-smoothed copy (W x W floats each; either pointer may be null) -- the smoothed image is otherwise only
+ * observable through the descriptors that sample it (oracle/frontend_ref.c: feref_cart_remap, feref_blur). */
+int rsx_frontend_read_images(rsx_frontend *h, int32_t image, float *out_cart, float *out_blur);
+
 /* Introspection of the candidate stage (host only, no device needed): the ring-key search tree the detector would build
  * over `n` keys of 20 floats -- nanoflann's tree (KDTreeVectorOfVectorsAdaptor.h:49-117, leaf size 10, Scancontext.cpp:284,356)
  * rebuilt node for node, because the order in which tied neighbours come back is the order of its leaves.  out_vind[n] =

@@ -143,6 +143,7 @@ SYMBOLS = [
     "rsx_frontend_default_params", "rsx_frontend_create", "rsx_frontend_destroy", "rsx_frontend_cartesian",
     "rsx_frontend_describe", "rsx_frontend_match",
     "rsx_frontend_cartesian_batch_device", "rsx_frontend_cartesian_batch_device_az", "rsx_frontend_describe_batch_device", "rsx_frontend_match_consecutive_device",
+    "rsx_frontend_read_images",
     "rsx_odometry_default_params", "rsx_odometry_create", "rsx_odometry_destroy", "rsx_odometry_reset", "rsx_odometry_window",
     "rsx_odometry_push", "rsx_odometry_push_device", "rsx_host_alloc_pinned", "rsx_host_free_pinned",
     "rsx_voxelgrid_create", "rsx_voxelgrid_destroy", "rsx_voxelgrid_filter", "rsx_sc_add_points_downsampled",
@@ -254,6 +255,8 @@ def lib():
         L.rsx_frontend_describe.argtypes = [vp, vp, i32, vp, vp]
         L.rsx_frontend_match.argtypes = [vp, vp, vp, i32, vp, vp, i32, C.c_float, vp, vp, vp]
         L.rsx_frontend_cartesian_batch_device.argtypes = [vp, vp, i32, i64, i32, i32, vp, C.c_float, vp]
+        L.rsx_frontend_cartesian_batch_device_az.argtypes = [vp, vp, i32, i64, i32, i32, vp, i64, C.c_float, vp]
+        L.rsx_frontend_read_images.argtypes = [vp, i32, vp, vp]
         L.rsx_frontend_describe_batch_device.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
         L.rsx_frontend_match_consecutive_device.argtypes = [vp, vp, vp, vp, i32, i32, i32, C.c_float, vp, vp, vp]
         L.rsx_odometry_default_params.argtypes = [C.POINTER(OdometryParams)]

@@ -171,6 +171,189 @@ __global__ __launch_bounds__(256) void fe_cart_fused(const uint8_t *__restrict__
   }
 }
 
+// Round 6: the same two images from ONE WAVEFRONT PER COLUMN STRIP, no LDS tiles and no barriers.  A wavefront owns 58
+// output columns (+ 3 halo columns either side = its 64 lanes) of one image and walks a segment of rows top to bottom:
+//   * the remapped pixel c(y, x) of its lane (evaluated at the reflected coordinate outside the image, like the tile form);
+//   * the row pass h(y, x) = sum_t g[t] c(y, x + t - 3), added left to right, from the six neighbouring lanes (ds_bpermute);
+//   * the column pass from a 7-deep register window of h: blur(y - 3, x) = sum_t g[t] h(y - 6 + t, x), added top to bottom.
+// Per pixel the same fp32 operations in the same order as fe_remap / fe_blur<true> / fe_blur<false>, so bit-identical.
+// Against the 32 x 32 tile form: 64 / 58 x (seg + 6) / seg = 1.13-1.16 remap evaluations per pixel instead of 1.41, the
+// index arithmetic per group of rows instead of per pixel, and RG pixels of a lane in flight at once (their two map loads, then
+// their polar taps, issued together: the tile form waited for every tap of every pixel in turn).  The four waves of a block
+// take four IMAGES of the same strip, so the strip's map lines (12 bytes per pixel, the largest input) are fetched once per block.
+//
+// The azimuth row (th - az0) / step is an fp64 division per pixel and image in the oracle.  Here: q = (th - az0) * (1 / step),
+// which is within 3 * 2^-53 relative of the correctly rounded quotient d; after the wrap into [0, rows) the two differ by
+// less than delta = rows * 2^-48 (the wraps are exact subtractions or one rounded addition each).  If the wrapped value is
+// further than delta from 0 and from rows -- the only images of the wrap's thresholds -- and w - delta and w + delta round to
+// the SAME float, then so does the oracle's value (rounding is monotone): the float is returned.  Otherwise (probability
+// ~2^-24 per pixel, and every pixel exactly on the first azimuth) the exact az_row_of decides.  `delta_scale` widens delta
+// for the test that drives a large share of the pixels through the exact branch.
+constexpr int SW = 64 - 2 * FH;  // 58 output columns per wavefront
+#ifndef FE_LW
+#define FE_LW 16
+#endif
+#ifndef FE_TARGET
+#define FE_TARGET 8192
+#endif
+// The polar taps are where the time goes (measured: the kernel with its taps replaced by coalesced loads runs in 0.64 of the
+// time, without the smoothing or without the azimuth arithmetic in the same time): 64 lanes on 64 consecutive Cartesian pixels
+// of one row reach across up to 380 range bins and several azimuth rows, a dozen cache lines per load instruction.  So the
+// taps are fetched in a SQUARER lane layout -- LW columns x 64 / LW rows per instruction (16 x 4: a quarter of the reach in
+// range) -- over a block of 64 columns x RG = 64 / LW rows, the remapped pixels cross to the one-lane-per-column layout of
+// the smoothing through LDS (one write, seven reads per pixel, no barrier: a wavefront's LDS operations execute in order),
+// and the two range taps of an azimuth row come as ONE 16-bit load.
+constexpr int LW = FE_LW, RG = 64 / LW;  // gather layout: LW columns x RG rows per instruction; RG rows per group
+constexpr int CROW = 64 + 2 * 4 + (LW == 16 ? 8 : 0);  // floats per staged row (4 pad either side; 80: rows of a 16 x 4 layout on disjoint banks)
+
+struct AzGrid {
+  double az0, rst, R, delta;
+};
+
+__device__ __forceinline__ float az_row_screened(double th, const AzGrid &G, const float *__restrict__ az, int rows) {
+  const double q = (th - G.az0) * G.rst;
+  double w = q;
+  if (q >= G.R) w = q - G.R;
+  if (q < 0.0) w = q + G.R;
+  const float lo = (float)(w - G.delta), hi = (float)(w + G.delta);
+  if (w > G.delta && w < G.R - G.delta && lo == hi) return lo;  // (|q| >= 2 rows, NaN, a zero or negative step: all fail here)
+  return az_row_of(th, az, rows);
+}
+
+__global__ __launch_bounds__(256) void fe_cart_strip(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int row_stride,
+                                                     int col_offset, int W, const float *__restrict__ map_rb, const double *__restrict__ map_th,
+                                                     const float *__restrict__ az, int64_t az_stride, const float *__restrict__ g,
+                                                     float *__restrict__ carts, float *__restrict__ blurs, int n_images, int seg,
+                                                     double delta_scale) {
+  __shared__ float s_tab[256];  // byte -> byte / 255, correctly rounded
+  __shared__ float s_c[4][RG][CROW];
+  s_tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // work item of this wavefront: (image, row segment), images fastest -- the four waves of a block share a strip and, with
+  // four or more images, a segment: one fetch of the strip's map lines serves them all
+  const int item = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + wave));
+  const int segment = item / n_images, image = item - segment * n_images;
+  if ((int64_t)segment * seg >= W) return;
+  const uint8_t *img = imgs + (int64_t)image * img_stride + col_offset;
+  float *cart = carts + (int64_t)image * W * W, *blur = blurs + (int64_t)image * W * W;
+  const float *azi = az + (int64_t)image * az_stride;
+  AzGrid G;
+  G.az0 = (double)azi[0];
+  G.rst = 1.0 / ((double)azi[1] - G.az0);
+  G.R = (double)rows;
+  G.delta = G.R * 0x1p-48 * delta_scale;
+  float gk[7];
+#pragma unroll
+  for (int t = 0; t < 7; t++) gk[t] = g[t];
+
+  auto col_of = [&](int c) {  // reflected image column of the strip's column c (0 .. 63), clamped far beyond the edge (values unused)
+    const int ur = (int)blockIdx.y * SW + c - FH;
+    int u = ur < 0 ? -ur : ur;
+    if (u >= W) u = 2 * W - 2 - u;
+    return u < 0 ? 0 : u;
+  };
+  auto row_of = [&](int y) {  // reflected row of the image, clamped for rows past the segment's halo (unused)
+    int v = y < 0 ? -y : y;
+    if (v >= W) v = 2 * W - 2 - v;
+    return v < 0 ? 0 : (v >= W ? W - 1 : v);
+  };
+  // smoothing layout: lane = column of the strip
+  const int u_raw = (int)blockIdx.y * SW + lane - FH;
+  const bool inner = lane >= FH && lane < FH + SW && u_raw < W;
+  // gather layout: lane = (row jr of the group, column cc of a block of LW); its RG pixels of a group: columns LW * k + cc of row jr
+  const int jr = lane / LW, cc = lane - jr * LW;
+  int ug[RG];
+#pragma unroll
+  for (int k = 0; k < RG; k++) ug[k] = col_of(LW * k + cc);
+  float *stage_w = &s_c[wave][jr][4 + cc];            // + LW * k
+  const float *stage_r = &s_c[wave][0][4 + lane - FH];  // + CROW * j + t
+  const int y0 = segment * seg, y1 = (y0 + seg < W) ? y0 + seg : W;
+
+  float hw[7];
+#pragma unroll
+  for (int t = 0; t < 7; t++) hw[t] = 0.0f;
+  float rb_n[RG];
+  double th_n[RG];
+  {
+    const int v = row_of(y0 - FH + jr);
+#pragma unroll
+    for (int k = 0; k < RG; k++) {
+      const int64_t i = (int64_t)v * W + ug[k];
+      rb_n[k] = map_rb[i];
+      th_n[k] = map_th[i];
+    }
+  }
+  for (int yb = y0 - FH; yb < y1 + FH; yb += RG) {
+    float rb[RG];
+    double th[RG];
+#pragma unroll
+    for (int k = 0; k < RG; k++) rb[k] = rb_n[k], th[k] = th_n[k];
+    if (yb + RG < y1 + FH) {
+      const int v = row_of(yb + RG + jr);
+#pragma unroll
+      for (int k = 0; k < RG; k++) {
+        const int64_t i = (int64_t)v * W + ug[k];
+        rb_n[k] = map_rb[i];
+        th_n[k] = map_th[i];
+      }
+    }
+    float fr[RG], fa[RG];
+    int r0[RG], bs[RG];
+    uint16_t w0[RG], w1[RG];
+#pragma unroll
+    for (int k = 0; k < RG; k++) {
+      const float ab = az_row_screened(th[k], G, azi, rows);
+      const float r0f = floorf(rb[k]), a0f = floorf(ab);
+      fr[k] = rb[k] - r0f;
+      fa[k] = ab - a0f;
+      r0[k] = (int)r0f;
+      int a0 = (int)a0f;
+      if (a0 >= rows) a0 -= rows;
+      const int a1 = (a0 + 1 == rows) ? 0 : a0 + 1;
+      // the two range taps of an azimuth row as ONE 16-bit load at base = r0 clamped into [0, cols - 2]: base == r0 inside the
+      // image; r0 == -1: the pair's low byte is tap 1; r0 == cols - 1: its high byte is tap 0; taps outside are zeroed below
+      bs[k] = r0[k] < 0 ? 0 : (r0[k] > cols - 2 ? cols - 2 : r0[k]);
+      __builtin_memcpy(&w0[k], img + (uint32_t)(a0 * row_stride + bs[k]), 2);
+      __builtin_memcpy(&w1[k], img + (uint32_t)(a1 * row_stride + bs[k]), 2);
+    }
+#pragma unroll
+    for (int k = 0; k < RG; k++) {
+      const bool in0 = r0[k] >= 0 && r0[k] < cols, in1 = r0[k] + 1 >= 0 && r0[k] + 1 < cols;
+      const bool at = r0[k] == bs[k];  // tap 0 = low byte and tap 1 = high byte
+      const uint32_t b00 = at ? (w0[k] & 255u) : (w0[k] >> 8), b01 = at ? (w0[k] >> 8) : (w0[k] & 255u);
+      const uint32_t b10 = at ? (w1[k] & 255u) : (w1[k] >> 8), b11 = at ? (w1[k] >> 8) : (w1[k] & 255u);
+      const float p00 = in0 ? s_tab[b00] : 0.0f, p01 = in1 ? s_tab[b01] : 0.0f;
+      const float p10 = in0 ? s_tab[b10] : 0.0f, p11 = in1 ? s_tab[b11] : 0.0f;
+      const float top = p00 + fr[k] * (p01 - p00);
+      const float bot = p10 + fr[k] * (p11 - p10);
+      stage_w[LW * k] = top + fa[k] * (bot - top);
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < RG; j++) {
+      const int y = yb + j;
+      if (y >= y1 + FH) break;  // (uniform)
+      float ct[7];
+#pragma unroll
+      for (int t = 0; t < 7; t++) ct[t] = stage_r[CROW * j + t];
+      if (inner && y >= y0 && y < y1) cart[(int64_t)y * W + u_raw] = ct[3];
+      float h = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 7; t++) h = h + gk[t] * ct[t];
+#pragma unroll
+      for (int t = 0; t < 6; t++) hw[t] = hw[t + 1];
+      hw[6] = h;
+      float sum = 0.0f;
+#pragma unroll
+      for (int t = 0; t < 7; t++) sum = sum + gk[t] * hw[t];
+      const int yo = y - FH;
+      if (inner && yo >= y0 && yo < y1) blur[(int64_t)yo * W + u_raw] = sum;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // metric keypoints (x forward, y right) -> nearest Cartesian pixel (u, v), in double like the host form of
 // rsx_frontend_describe: blockIdx.y = image, xy [image][stride][2], counts[image] keypoints each
 __global__ __launch_bounds__(256) void fe_uv(const float *__restrict__ xy, const int32_t *__restrict__ counts, int stride, double cmr,
@@ -403,6 +586,8 @@ struct rsx_frontend {
   bool have_image = false;
   int batch_n = 0;  // Cartesian images held by the last rsx_frontend_cartesian* call
   bool three_pass = false;  // RSX_FRONTEND_THREE_PASS: remap and the two blur passes as separate kernels
+  bool tiles = false;       // RSX_FRONTEND_TILES: the 32 x 32 tile kernel of round 3 instead of the strip kernel
+  bool exact_az = false;    // RSX_FRONTEND_EXACT_AZIMUTH: every azimuth row through the fp64 division
 };
 
 using rsx::fail;
@@ -483,6 +668,8 @@ int rsx_frontend_create(int device, int32_t rows, int32_t cols, const rsx_fronte
   h->W = dp.cart_pixel_width;
   h->cart_res = (double)dp.cart_resolution;
   h->three_pass = (dp.flags & RSX_FRONTEND_THREE_PASS) != 0;
+  h->tiles = (dp.flags & RSX_FRONTEND_TILES) != 0;
+  h->exact_az = (dp.flags & RSX_FRONTEND_EXACT_AZIMUTH) != 0;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
   if (e != hipSuccess) {
@@ -564,6 +751,20 @@ static int cartesian_device(rsx_frontend *h, const uint8_t *d_imgs, int n, int64
                        h->map_th.as<double>(), d_az, az_stride, h->cart.as<float>());
     hipLaunchKernelGGL(fe_blur<true>, grid, dim3(256), 0, s, h->cart.as<float>(), W, g, h->tmp.as<float>());
     hipLaunchKernelGGL(fe_blur<false>, grid, dim3(256), 0, s, h->tmp.as<float>(), W, g, h->blur.as<float>());
+  } else if (!h->tiles) {
+    // row segments: enough (image, strip, segment) wavefronts to fill the device about once (8 per SIMD), segments of >= 32 rows
+    const int strips = (W + SW - 1) / SW;
+    int target = FE_TARGET;
+    if (const char *e = rsx::exp_env("RSX_FE_WAVES")) target = std::atoi(e);
+    int segs = (int)((target + (int64_t)strips * n / 2) / ((int64_t)strips * n));
+    if (segs > W / 32) segs = W / 32;
+    if (segs < 1) segs = 1;
+    const int seg = (W + segs - 1) / segs;
+    segs = (W + seg - 1) / seg;
+    const dim3 grid((unsigned)(((int64_t)n * segs + 3) / 4), (unsigned)strips);
+    hipLaunchKernelGGL(fe_cart_strip, grid, dim3(256), 0, s, d_imgs, img_stride, h->rows, h->cols, row_stride, col_offset, W,
+                       h->map_rb.as<float>(), h->map_th.as<double>(), d_az, az_stride, g, h->cart.as<float>(), h->blur.as<float>(), n, seg,
+                       h->exact_az ? 0x1p60 : 1.0);
   } else {
     const dim3 grid((unsigned)((W + FT - 1) / FT), (unsigned)((W + FT - 1) / FT), (unsigned)n);
     hipLaunchKernelGGL(fe_cart_fused, grid, dim3(256), 0, s, d_imgs, img_stride, h->rows, h->cols, row_stride, col_offset, W,
@@ -621,6 +822,18 @@ int rsx_frontend_cartesian_batch_device_az(rsx_frontend *h, const uint8_t *d_img
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
   RSX_TRY(ensure_map(h, resolution, s));
   return cartesian_device(h, d_imgs, n_images, image_stride_bytes, row_stride, col_offset, d_azimuths, azimuth_stride_floats, s);
+} RSX_CATCH_ALL
+
+int rsx_frontend_read_images(rsx_frontend *h, int32_t image, float *out_cart, float *out_blur) try {
+  if (!h || image < 0) return fail(RSX_ERR_BAD_ARG, "bad arg");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (!h->have_image || image >= h->batch_n) return fail(RSX_ERR_BAD_ARG, "no Cartesian image %d in the handle", image);
+  RSX_HIP(hipSetDevice(h->device));
+  RSX_HIP(hipDeviceSynchronize());  // (a diagnostic: whatever stream produced the images)
+  const size_t bytes = (size_t)h->W * h->W * sizeof(float);
+  if (out_cart) RSX_HIP(hipMemcpy(out_cart, static_cast<const char *>(h->cart.p) + bytes * image, bytes, hipMemcpyDeviceToHost));
+  if (out_blur) RSX_HIP(hipMemcpy(out_blur, static_cast<const char *>(h->blur.p) + bytes * image, bytes, hipMemcpyDeviceToHost));
+  return RSX_OK;
 } RSX_CATCH_ALL
 
 int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *out_desc, uint8_t *out_valid) try {

@@ -40,6 +40,19 @@ class Frontend:
                                              out.ctypes.data if want_image else None))
         return out
 
+    def cartesian_batch_device(self, d_imgs, n, image_stride, row_stride, d_az, az_stride, resolution, col_offset=11, stream=None):
+        """n images resident in HBM (d_imgs: device address) with per-image azimuth grids on the device (d_az, az_stride floats apart;
+        0: one grid): asynchronous on `stream` (None: the handle's)."""
+        check(self._L.rsx_frontend_cartesian_batch_device_az(self._h, d_imgs, n, image_stride, row_stride, col_offset, d_az, az_stride,
+                                                             float(resolution), stream))
+
+    def read_images(self, image=0):
+        """(Cartesian image, smoothed copy) of slot `image` of the last cartesian call (rsx_diag.h parity helper)."""
+        cart = np.empty((self.W, self.W), dtype=np.float32)
+        blur = np.empty((self.W, self.W), dtype=np.float32)
+        check(self._L.rsx_frontend_read_images(self._h, image, cart.ctypes.data, blur.ctypes.data))
+        return cart, blur
+
     def describe(self, xy):
         xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
         n = xy.shape[0]

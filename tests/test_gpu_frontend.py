@@ -16,10 +16,14 @@ def fe():
     return frontend
 
 
-@pytest.mark.parametrize("W,res,flags", [(964, 0.2592, 0), (501, 0.5, 0), (964, 0.2592, 1), (70, 3.0, 0)])
+@pytest.mark.parametrize("W,res,flags", [(964, 0.2592, 0), (501, 0.5, 0), (964, 0.2592, 1), (70, 3.0, 0), (964, 0.2592, 2), (501, 0.5, 4),
+                                         (70, 3.0, 2), (45, 6.0, 0)])
 def test_frontend_bit_exact(fe, oracle, W, res, flags):
-    """flags = 1 (RSX_FRONTEND_THREE_PASS): remap / blur rows / blur columns as separate kernels; default: the fused tile
-    kernel.  Both must give the oracle's images (W = 70: tiles that hang over the image edge, reflected halos everywhere)."""
+    """flags = 1 (RSX_FRONTEND_THREE_PASS): remap / blur rows / blur columns as separate kernels; 4 (RSX_FRONTEND_TILES): the
+    32 x 32 LDS-tile kernel; default: the strip kernel (one wavefront per 58 columns, azimuth rows by reciprocal multiply where
+    the margin decides); 2 (RSX_FRONTEND_EXACT_AZIMUTH): the strip kernel with EVERY azimuth row through its fp64-division
+    branch.  All must give the oracle's images (W = 70 / 45: strips and tiles that hang over the image edge, reflected halos
+    everywhere, one or two strips, segments shorter than the image)."""
     rows, cols = 400, 3360
     p = fe.default_params()
     p.cart_pixel_width, p.cart_resolution, p.flags = W, res, flags
@@ -31,6 +35,8 @@ def test_frontend_bit_exact(fe, oracle, W, res, flags):
         cart_g = g.cartesian(img, az, synth.RADAR_RESOLUTION)
         cart_o = o.cartesian(img, az, synth.RADAR_RESOLUTION)
         assert np.array_equal(cart_g, cart_o)
+        cart_r, blur_r = g.read_images(0)
+        assert np.array_equal(cart_r, cart_o) and np.array_equal(blur_r, o.blur)   # the smoothed copy itself, not only through descriptors
         rng = np.random.default_rng(seed)
         a, r = centres[:, 0], centres[:, 1]
         rr = (r + 0.5) * synth.RADAR_RESOLUTION
@@ -50,3 +56,43 @@ def test_frontend_bit_exact(fe, oracle, W, res, flags):
     idx, _, _ = g.match(descs[0][0], descs[0][1], descs[1][0], descs[1][1], 0.8)
     assert W != 964 or (idx >= 0).sum() > 20                                                       # the rotated scene is recognised
     g.close()
+
+
+def test_strip_kernel_batch_with_per_image_grids(fe, oracle):
+    """A batch resident in HBM, every image with its OWN azimuth grid (offset first azimuth, a slightly different step, one grid
+    whose first azimuth is a pixel's angle exactly, one that starts half a turn round): image by image the oracle's Cartesian
+    image and smoothed copy, with 5 images (the four wavefronts of a block straddle images and row segments) and with the
+    azimuth screen forced through its exact branch."""
+    import torch
+    rows, cols, W, res = 400, 3360, 964, 0.2592
+    imgs, azs = [], []
+    for k in range(5):
+        img, az, _ = synth.polar_image(20 + k, n_targets=500)
+        az = az.astype(np.float64)
+        if k == 1:
+            az = az + 0.0123
+        if k == 2:
+            az = az * (1.0 + 3e-4) + 0.5 * (az[1] - az[0])
+        if k == 3:
+            az = az + float(np.arctan2(1.0, 3.0))                    # a pixel direction of the even-width grid, up to rounding
+        if k == 4:
+            az = az + np.pi
+        imgs.append(img)
+        azs.append(az.astype(np.float32))
+    batch = np.ascontiguousarray(np.stack(imgs))
+    az_all = np.ascontiguousarray(np.stack(azs))
+    d_img = torch.from_numpy(batch).cuda()
+    d_az = torch.from_numpy(az_all).cuda()
+    for flags in (0, 2, 4):
+        p = fe.default_params()
+        p.cart_pixel_width, p.cart_resolution, p.flags = W, res, flags
+        g = fe.Frontend(rows, cols, params=p)
+        g.cartesian_batch_device(d_img.data_ptr(), 5, batch.shape[1] * batch.shape[2], batch.shape[2], d_az.data_ptr(), rows,
+                                 synth.RADAR_RESOLUTION)
+        for k in range(5):
+            o = oracle.FrontendRef(rows, cols, W, res)
+            cart_o = o.cartesian(imgs[k], azs[k], synth.RADAR_RESOLUTION)
+            cart_g, blur_g = g.read_images(k)
+            assert np.array_equal(cart_g, cart_o), (flags, k)
+            assert np.array_equal(blur_g, o.blur), (flags, k)
+        g.close()
