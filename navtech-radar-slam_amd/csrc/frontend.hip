@@ -225,9 +225,10 @@ __global__ __launch_bounds__(256) void fe_cart_strip(const uint8_t *__restrict__
                                                      const float *__restrict__ az, int64_t az_stride, const float *__restrict__ g,
                                                      float *__restrict__ carts, float *__restrict__ blurs, int n_images, int seg,
                                                      double delta_scale) {
-  __shared__ float s_tab[256];  // byte -> byte / 255, correctly rounded
+  __shared__ float s_tab[257];  // byte -> byte / 255, correctly rounded; [256] = 0
   __shared__ float s_c[4][RG][CROW];
   s_tab[threadIdx.x] = __fdiv_rn((float)threadIdx.x, 255.0f);
+  if (threadIdx.x == 0) s_tab[256] = 0.0f;
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // work item of this wavefront: (image, row segment), images fastest -- the four waves of a block share a strip and, with
@@ -320,11 +321,11 @@ __global__ __launch_bounds__(256) void fe_cart_strip(const uint8_t *__restrict__
 #pragma unroll
     for (int k = 0; k < RG; k++) {
       const bool in0 = r0[k] >= 0 && r0[k] < cols, in1 = r0[k] + 1 >= 0 && r0[k] + 1 < cols;
-      const bool at = r0[k] == bs[k];  // tap 0 = low byte and tap 1 = high byte
-      const uint32_t b00 = at ? (w0[k] & 255u) : (w0[k] >> 8), b01 = at ? (w0[k] >> 8) : (w0[k] & 255u);
-      const uint32_t b10 = at ? (w1[k] & 255u) : (w1[k] >> 8), b11 = at ? (w1[k] >> 8) : (w1[k] & 255u);
-      const float p00 = in0 ? s_tab[b00] : 0.0f, p01 = in1 ? s_tab[b01] : 0.0f;
-      const float p10 = in0 ? s_tab[b10] : 0.0f, p11 = in1 ? s_tab[b11] : 0.0f;
+      const uint32_t s0 = r0[k] == bs[k] ? 0u : 8u, s1 = 8u - s0;  // tap 0 = low byte and tap 1 = high byte where base == r0
+      // (s_tab[256] = 0: a tap outside the image is a table index, not a branch)
+      const uint32_t b00 = in0 ? ((w0[k] >> s0) & 255u) : 256u, b01 = in1 ? ((w0[k] >> s1) & 255u) : 256u;
+      const uint32_t b10 = in0 ? ((w1[k] >> s0) & 255u) : 256u, b11 = in1 ? ((w1[k] >> s1) & 255u) : 256u;
+      const float p00 = s_tab[b00], p01 = s_tab[b01], p10 = s_tab[b10], p11 = s_tab[b11];
       const float top = p00 + fr[k] * (p01 - p00);
       const float bot = p10 + fr[k] * (p11 - p10);
       stage_w[LW * k] = top + fa[k] * (bot - top);
@@ -752,12 +753,12 @@ static int cartesian_device(rsx_frontend *h, const uint8_t *d_imgs, int n, int64
     hipLaunchKernelGGL(fe_blur<true>, grid, dim3(256), 0, s, h->cart.as<float>(), W, g, h->tmp.as<float>());
     hipLaunchKernelGGL(fe_blur<false>, grid, dim3(256), 0, s, h->tmp.as<float>(), W, g, h->blur.as<float>());
   } else if (!h->tiles) {
-    // row segments: enough (image, strip, segment) wavefronts to fill the device about once (8 per SIMD), segments of >= 32 rows
-    const int strips = (W + SW - 1) / SW;
-    int target = FE_TARGET;
-    if (const char *e = rsx::exp_env("RSX_FE_WAVES")) target = std::atoi(e);
-    int segs = (int)((target + (int64_t)strips * n / 2) / ((int64_t)strips * n));
-    if (segs > W / 32) segs = W / 32;
+    // row segments: enough (image, strip, segment) wavefronts to fill the device about once (8 per SIMD), but segments of 16 rows or
+    // more (22 evaluated for 16 kept) -- 8 for fewer than four images, where the device is not full either way (measured, 1 / 4 /
+    // 16 / 64 images: 11.5 / 24.5 / 69 / 305-338 us; the tile kernel: 15 / 37 / 131 / 557)
+    const int strips = (W + SW - 1) / SW, min_seg = n < 4 ? 8 : 16;
+    int segs = (int)((FE_TARGET + (int64_t)strips * n / 2) / ((int64_t)strips * n));
+    if (segs > W / min_seg) segs = W / min_seg;
     if (segs < 1) segs = 1;
     const int seg = (W + segs - 1) / segs;
     segs = (W + seg - 1) / seg;

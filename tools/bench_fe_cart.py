@@ -26,7 +26,7 @@ for flags in flag_list:
         call()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
+    reps = 50
     e0.record()
     for _ in range(reps):
         call()
