@@ -371,20 +371,56 @@ __global__ __launch_bounds__(256) void fe_uv(const float *__restrict__ xy, const
 // ONE WAVEFRONT PER KEYPOINT (round 3; rounds 1-2: one thread per keypoint walking the 709-pixel patch and the 256 pairs
 // alone).  The intensity-centroid moments are defined ORDER-INDEPENDENTLY, like OpenCV's integer IC_Angle on its 8-bit
 // image: I_q = llrint(I * 2^24), m10 = sum dx * I_q, m01 = sum dy * I_q in int64 -- so the 64 lanes take the patch pixels
-// of the 31 x 31 raster in stride and a butterfly adds them; the direction is the first maximum over the 30 bins of
+// in stride and the lanes' sums are added; the direction is the first maximum over the 30 bins of
 // (double)m10 * c_b + (double)m01 * s_b (one multiply each, one add: no contraction); the 256 comparisons are 4 ballots.
 // A block of 4 waves walks the keypoints k = 4 * blockIdx.x + wave, + 4 * gridDim.x, ...
+// Round 6: the 709 pixels of the disc come from a table (12 per lane, the table padded with (0, 0) offsets whose weight is
+// zero; before: 16 raster steps with a division by 31 and the circle test), I_q from the fp32 product -- I * 2^24 is exact in
+// fp32 as in fp64 and the image holds values in [0, 1], far inside int32 -- and the lanes' sums and the maximum over the bins
+// by DPP (before: 36 dependent ds_bpermute round trips a keypoint, most of its time).
+__device__ __forceinline__ int fe_wave_sum_i32(int x) {  // every lane: the sum over the 64 lanes
+  x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xf, 0xf, true);  // row_mirror: every lane = its row's sum
+  return __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+}
+__device__ __forceinline__ long long fe_wave_sum_i64(long long p) {  // |p| < 2^40 per lane: as 16 low bits + the rest, two int32 sums
+  const int lo = fe_wave_sum_i32((int)(p & 0xffff)), hi = fe_wave_sum_i32((int)(p >> 16));
+  return ((long long)hi << 16) + (long long)lo;
+}
+template <int CTRL>
+__device__ __forceinline__ double fe_dpp_f64(double x) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)u, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp((int)(unsigned)(u >> 32), (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+#ifndef FE_DESC_BLOCKS
+#define FE_DESC_BLOCKS 128
+#endif
+constexpr int DISC_IT = 12;  // 709 pixels of the radius-15 disc over 64 lanes
 __global__ __launch_bounds__(256) void fe_describe(const float *__restrict__ carts, const float *__restrict__ blurs, int W,
                                                    const int32_t *__restrict__ uvs, int n, const int32_t *__restrict__ counts, int stride,
                                                    const float *__restrict__ dir_cs, const int8_t *__restrict__ pairs,
-                                                   uint32_t *__restrict__ descs, uint8_t *__restrict__ valids) {
+                                                   const int8_t *__restrict__ disc, uint32_t *__restrict__ descs, uint8_t *__restrict__ valids) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (counts) n = counts[blockIdx.y] < stride ? counts[blockIdx.y] : stride;
+  if ((int)blockIdx.x * 4 + wave >= n) return;
   const float *cart = carts + (int64_t)blockIdx.y * W * W, *blur = blurs + (int64_t)blockIdx.y * W * W;
   const int32_t *uv = uvs + (int64_t)blockIdx.y * stride * 2;
   uint32_t *desc = descs + (int64_t)blockIdx.y * stride * 8;
   uint8_t *valid = valids + (int64_t)blockIdx.y * stride;
-  constexpr int SIDE = 2 * HALF_PATCH + 1;
+  int dxs[DISC_IT], dys[DISC_IT], offs[DISC_IT];  // this lane's pixels of the disc: the same for every keypoint
+#pragma unroll
+  for (int it = 0; it < DISC_IT; it++) {
+    const char2 d = *reinterpret_cast<const char2 *>(disc + 2 * (it * 64 + lane));
+    dxs[it] = d.x;
+    dys[it] = d.y;
+    offs[it] = d.y * W + d.x;
+  }
+  double dcs = 0.0, dsn = 0.0;
+  if (lane < NBINS) dcs = (double)dir_cs[2 * lane], dsn = (double)dir_cs[2 * lane + 1];
   for (int k = blockIdx.x * 4 + wave; k < n; k += gridDim.x * 4) {
     const int u = uv[2 * k], v = uv[2 * k + 1];
     const bool ok = !(u < BORDER || v < BORDER || u >= W - BORDER || v >= W - BORDER);  // wave-uniform
@@ -393,38 +429,50 @@ __global__ __launch_bounds__(256) void fe_describe(const float *__restrict__ car
       if (lane == 0) valid[k] = 0;
       continue;
     }
-    long long m10 = 0, m01 = 0;
-    for (int idx = lane; idx < SIDE * SIDE; idx += 64) {
-      const int dy = idx / SIDE - HALF_PATCH, dx = idx - (dy + HALF_PATCH) * SIDE - HALF_PATCH;
-      if (dx * dx + dy * dy > HALF_PATCH * HALF_PATCH) continue;
-      const long long iq = __double2ll_rn((double)cart[(int64_t)(v + dy) * W + (u + dx)] * 16777216.0);
-      m10 += (long long)dx * iq;
-      m01 += (long long)dy * iq;
-    }
+    const float *cc = cart + ((int64_t)v * W + u);
+    float cv[DISC_IT];
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-      m10 += __shfl_xor(m10, o);
-      m01 += __shfl_xor(m01, o);
+    for (int it = 0; it < DISC_IT; it++) cv[it] = cc[offs[it]];
+    long long m10 = 0, m01 = 0;
+#pragma unroll
+    for (int it = 0; it < DISC_IT; it++) {
+      const int iq = __float2int_rn(cv[it] * 16777216.0f);
+      m10 += (long long)dxs[it] * iq;
+      m01 += (long long)dys[it] * iq;
     }
-    const double dm10 = (double)m10, dm01 = (double)m01;
+    const double dm10 = (double)fe_wave_sum_i64(m10), dm01 = (double)fe_wave_sum_i64(m01);
     double dd = -INFINITY;
     if (lane < NBINS) {
-      const double a = dm10 * (double)dir_cs[2 * lane], b = dm01 * (double)dir_cs[2 * lane + 1];
+      const double a = dm10 * dcs, b = dm01 * dsn;
       dd = a + b;
     }
+    // maximum over the lanes (finite values in the first 30, -inf elsewhere: fmax is a plain maximum): inside the rows of 16 by
+    // DPP, the 30 bins live in rows 0 and 1
     double mx = dd;
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    mx = fmax(mx, fe_dpp_f64<0xB1>(mx));
+    mx = fmax(mx, fe_dpp_f64<0x4E>(mx));
+    mx = fmax(mx, fe_dpp_f64<0x141>(mx));
+    mx = fmax(mx, fe_dpp_f64<0x140>(mx));
+    {
+      const unsigned long long u0 = (unsigned long long)__double_as_longlong(mx);
+      const unsigned l0 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u0, 0), h0 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u0 >> 32), 0);
+      const unsigned l1 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u0, 16), h1 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u0 >> 32), 16);
+      mx = fmax(__longlong_as_double((long long)(((unsigned long long)h0 << 32) | l0)), __longlong_as_double((long long)(((unsigned long long)h1 << 32) | l1)));
+    }
     const unsigned long long at = __ballot(lane < NBINS && dd == mx);
     const int bin = at ? __ffsll((long long)at) - 1 : 0;  // first maximum (NaN cannot occur: finite integers)
     const int8_t *pp = pairs + (int64_t)bin * NPAIRS * 4;
+    const float *bc = blur + ((int64_t)v * W + u);
+    float av[4], bv[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      const int i = 64 * j + lane;
-      const char4 p4 = *reinterpret_cast<const char4 *>(pp + 4 * i);
-      const float a = blur[(int64_t)(v + p4.y) * W + (u + p4.x)];
-      const float b = blur[(int64_t)(v + p4.w) * W + (u + p4.z)];
-      const unsigned long long bits = __ballot(a < b);  // bit i of byte i / 8, little-endian words
+      const char4 p4 = *reinterpret_cast<const char4 *>(pp + 4 * (64 * j + lane));
+      av[j] = bc[p4.y * W + p4.x];
+      bv[j] = bc[p4.w * W + p4.z];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const unsigned long long bits = __ballot(av[j] < bv[j]);  // bit i of byte i / 8, little-endian words
       if (lane == 0) {
         desc[(int64_t)k * 8 + 2 * j] = (uint32_t)bits;
         desc[(int64_t)k * 8 + 2 * j + 1] = (uint32_t)(bits >> 32);
@@ -534,7 +582,11 @@ __global__ __launch_bounds__(256) void fe_match_consecutive(const uint32_t *__re
     uint32_t me[8];
 #pragma unroll
     for (int w = 0; w < 8; w++) me[w] = live ? q[(int64_t)iq * 8 + w] : 0u;
-    int d1 = 1 << 30, d2 = 1 << 30, i1 = 0x7fffffff;
+    // the two smallest (distance, train index) pairs as ONE number each, distance << 20 | index (distances <= 256, indices
+    // below `stride` <= 2^20): "smaller distance, then the smaller train index" is the numbers' order, the second smallest
+    // number carries the second smallest distance (a tie of two entries counts twice, as in the sequential scan), and an
+    // update is min / max / min instead of two compares and five selects
+    uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu;
     for (int j0 = 0; j0 < ntv; j0 += 256) {
       __syncthreads();
       const int jt = j0 + threadIdx.x;
@@ -544,33 +596,23 @@ __global__ __launch_bounds__(256) void fe_match_consecutive(const uint32_t *__re
       si[threadIdx.x] = it;
       __syncthreads();
       const int lim = ntv - j0 < 256 ? ntv - j0 : 256;
-      for (int jj = part; jj < lim; jj += 4) {  // ascending train index within this lane's share
-        int d = 0;
+      for (int jj = part; jj < lim; jj += 4) {
+        uint32_t d = 0;
 #pragma unroll
-        for (int w = 0; w < 8; w++) d += __popc(me[w] ^ st[jj * 8 + w]);
-        if (d < d1) {
-          d2 = d1;
-          d1 = d;
-          i1 = si[jj];
-        } else if (d < d2) {
-          d2 = d;
-        }
+        for (int w = 0; w < 8; w++) d += (uint32_t)__popc(me[w] ^ st[jj * 8 + w]);
+        const uint32_t key = (d << 20) | (uint32_t)si[jj];
+        k2 = min(k2, max(k1, key));
+        k1 = min(k1, key);
       }
     }
-    // merge the four shares: the sequential scan keeps the smallest distance with the smallest train index (train
-    // indices ascend along the list, each lane saw its share in order) and the second smallest distance overall
 #pragma unroll
-    for (int o = 1; o <= 2; o <<= 1) {
-      const int od1 = __shfl_xor(d1, o), od2 = __shfl_xor(d2, o), oi1 = __shfl_xor(i1, o);
-      const bool mine_first = d1 < od1 || (d1 == od1 && i1 < oi1);
-      const int nd2 = mine_first ? (d2 < od1 ? d2 : od1) : (od2 < d1 ? od2 : d1);
-      if (!mine_first) {
-        d1 = od1;
-        i1 = oi1;
-      }
-      d2 = nd2;
+    for (int o = 1; o <= 2; o <<= 1) {  // merge the four shares
+      const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, o), o2 = (uint32_t)__shfl_xor((int)k2, o);
+      k2 = min(max(k1, o1), min(k2, o2));
+      k1 = min(k1, o1);
     }
-    if (live && part == 0) out_idx[iq] = (d1 < (1 << 30) && d2 < (1 << 30) && (float)d1 < ratio * (float)d2) ? i1 : -1;
+    const int d1 = (int)(k1 >> 20), d2 = (int)(k2 >> 20), i1 = (int)(k1 & 0xfffffu);
+    if (live && part == 0) out_idx[iq] = (k1 != 0xffffffffu && k2 != 0xffffffffu && (float)d1 < ratio * (float)d2) ? i1 : -1;
   }
 }
 
@@ -633,7 +675,21 @@ void build_tables(float *gauss7, float *dir_cs, int8_t *pairs) {
   }
 }
 
-constexpr size_t TAB_GAUSS = 0, TAB_DIR = 64, TAB_PAIRS = 64 + NBINS * 2 * 4, TAB_BYTES = TAB_PAIRS + (size_t)NBINS * NPAIRS * 4;
+constexpr size_t TAB_GAUSS = 0, TAB_DIR = 64, TAB_PAIRS = 64 + NBINS * 2 * 4, TAB_DISC = TAB_PAIRS + (size_t)NBINS * NPAIRS * 4,
+                 TAB_BYTES = TAB_DISC + (size_t)DISC_IT * 64 * 2;
+
+// (dx, dy) of the disc's pixels in raster order, padded with (0, 0) -- weight zero in both moments -- to 12 x 64 entries
+void build_disc(int8_t *disc) {
+  int n = 0;
+  for (int dy = -HALF_PATCH; dy <= HALF_PATCH; dy++)
+    for (int dx = -HALF_PATCH; dx <= HALF_PATCH; dx++)
+      if (dx * dx + dy * dy <= HALF_PATCH * HALF_PATCH) {
+        disc[2 * n] = (int8_t)dx;
+        disc[2 * n + 1] = (int8_t)dy;
+        n++;
+      }
+  for (; n < DISC_IT * 64; n++) disc[2 * n] = disc[2 * n + 1] = 0;
+}
 
 double cart_min_range(int W, double cart_res) { return (W % 2 == 0) ? (W / 2 - 0.5) * cart_res : (W / 2) * cart_res; }
 
@@ -686,6 +742,7 @@ int rsx_frontend_create(int device, int32_t rows, int32_t cols, const rsx_fronte
     std::vector<uint8_t> tab(TAB_BYTES, 0);
     build_tables(reinterpret_cast<float *>(&tab[TAB_GAUSS]), reinterpret_cast<float *>(&tab[TAB_DIR]),
                  reinterpret_cast<int8_t *>(&tab[TAB_PAIRS]));
+    build_disc(reinterpret_cast<int8_t *>(&tab[TAB_DISC]));
     e = hipMemcpy(h->tables.p, tab.data(), TAB_BYTES, hipMemcpyHostToDevice);
     if (e != hipSuccess) st = fail(RSX_ERR_HIP, "tables: %s", hipGetErrorString(e));
   }
@@ -858,7 +915,8 @@ int rsx_frontend_describe(rsx_frontend *h, const float *xy, int32_t n, uint8_t *
   const char *tab = static_cast<const char *>(h->tables.p);
   hipLaunchKernelGGL(fe_describe, dim3((unsigned)((n + 3) / 4 < 2048 ? (n + 3) / 4 : 2048)), dim3(256), 0, s, h->cart.as<float>(), h->blur.as<float>(), h->W,
                      h->uv.as<int32_t>(), n, (const int32_t *)nullptr, n, reinterpret_cast<const float *>(tab + TAB_DIR),
-                     reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), h->desc.as<uint32_t>(), h->valid.as<uint8_t>());
+                     reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), reinterpret_cast<const int8_t *>(tab + TAB_DISC), h->desc.as<uint32_t>(),
+                     h->valid.as<uint8_t>());
   RSX_HIP(hipGetLastError());
   RSX_HIP(hipMemcpyAsync(out_desc, h->desc.p, (size_t)n * 32, hipMemcpyDeviceToHost, s));
   RSX_HIP(hipMemcpyAsync(out_valid, h->valid.p, (size_t)n, hipMemcpyDeviceToHost, s));
@@ -878,10 +936,13 @@ int rsx_frontend_describe_batch_device(rsx_frontend *h, const float *d_xy, const
   hipLaunchKernelGGL(fe_uv, dim3((unsigned)((max_targets + 255) / 256), (unsigned)n_images), dim3(256), 0, s, d_xy, d_counts, max_targets, cmr,
                      h->cart_res, h->uv.as<int32_t>());
   const char *tab = static_cast<const char *>(h->tables.p);
-  // 512 blocks of 4 waves per image walk the image's keypoints (the counts live on the device)
-  hipLaunchKernelGGL(fe_describe, dim3((unsigned)((max_targets + 3) / 4 < 512 ? (max_targets + 3) / 4 : 512), (unsigned)n_images), dim3(256), 0, s, h->cart.as<float>(),
+  // FE_DESC_BLOCKS (128) blocks of 4 waves per image walk the image's keypoints (the counts live on the device); 512 blocks -- most
+  // of whose waves find nothing to do -- took 113 us per 64-scan window where 64 or 128 take 91, 256: 99.  (Requesting the next
+  // keypoint's patch while the current one is finished: 110 us -- twelve more registers held across the direction and pair phases.)
+  hipLaunchKernelGGL(fe_describe, dim3((unsigned)((max_targets + 3) / 4 < FE_DESC_BLOCKS ? (max_targets + 3) / 4 : FE_DESC_BLOCKS), (unsigned)n_images), dim3(256), 0, s, h->cart.as<float>(),
                      h->blur.as<float>(), h->W, h->uv.as<int32_t>(), 0, d_counts, max_targets, reinterpret_cast<const float *>(tab + TAB_DIR),
-                     reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), reinterpret_cast<uint32_t *>(d_desc), d_valid);
+                     reinterpret_cast<const int8_t *>(tab + TAB_PAIRS), reinterpret_cast<const int8_t *>(tab + TAB_DISC),
+                     reinterpret_cast<uint32_t *>(d_desc), d_valid);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 } RSX_CATCH_ALL
@@ -891,6 +952,7 @@ int rsx_frontend_match_consecutive_device(rsx_frontend *h, const uint8_t *d_desc
                                           int32_t *d_bwd, void *stream) try {
   if (!h || !d_desc || !d_valid || !d_counts || !d_fwd || !d_bwd || max_targets < 1 || first_slot < 0 || n_pairs < 0)
     return fail(RSX_ERR_BAD_ARG, "bad arg");
+  if (max_targets > (1 << 20)) return fail(RSX_ERR_BAD_ARG, "max_targets above 2^20 (the matcher packs a train index into 20 bits)");
   if (n_pairs == 0) return RSX_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
