@@ -93,18 +93,32 @@ __global__ __launch_bounds__(256) void odo_gather(const float2 *__restrict__ sta
 
 }  // namespace
 
+// Round 6: TWO windows in flight.  A window is two stages: EXTRACTION (cen2019, Cartesian images, descriptors: the wide
+// kernels, independent of every other window) and MATCHING (consecutive matches, cross check, max-clique selection, solver:
+// a chain of small grids -- one or two workgroups per pair -- that leaves most of the device idle, and the only stage that
+// needs the previous window).  They run on two streams: while window g is matched, window g + 1 is extracted.  What the two
+// stages hand over -- keypoints, descriptors, counts, slots 0 .. n of a SET -- exists twice (window g works in set g & 1);
+// the extraction stage ends by copying its last scan into slot 0 of the OTHER set ("the previous scan" of window g + 1).
+//   extraction stream:  E(g):   [wait M(g-2)]  cen2019, Cartesian, describe -> set g&1   [wait M(g-1)]  carry -> set (g+1)&1 slot 0
+//   matching stream:    M(g):   [wait E(g)]    match, cross, gather, select + solve -> pinned results g&1
+// The host enqueues M(g), then E(g + 1), and only then waits for M(g).
+struct OdoSet {
+  rsx::DevBuf az, targets, xy, counts, desc, valid;  // slot 0 = the previous scan, slots 1 .. MAX_WINDOW = the window
+  void *pin = nullptr;  // pinned: counts[MAX_WINDOW + 1], pair_cnt[MAX_WINDOW], results[MAX_WINDOW], then the staged azimuth grids
+};
+
 struct rsx_odometry {
   int device = 0, rows = 0, cols = 0;
   rsx_odometry_params prm{};
   std::mutex mu;
-  hipStream_t stream = nullptr, copy_stream = nullptr;
-  hipEvent_t ev_up = nullptr;
+  hipStream_t stream = nullptr, match_stream = nullptr, copy_stream = nullptr;
+  hipEvent_t ev_up = nullptr, ev_e[2] = {nullptr, nullptr}, ev_m[2] = {nullptr, nullptr};
   rsx_cen2019 *cen = nullptr;
   rsx_frontend *fe = nullptr;
   rsx_orora *reg = nullptr;
-  // slot 0 = the previous scan (carried over between windows), slots 1 .. MAX_WINDOW = the window
-  rsx::DevBuf imgs, imgs2, az, targets, xy, counts, desc, valid, fwd, bwd, stage_src, stage_dst, pair_cnt, src, dst, offsets, results;
-  void *h_pin = nullptr;  // pinned: counts[MAX_WINDOW + 1], pair_cnt[MAX_WINDOW], results[MAX_WINDOW]
+  OdoSet set[2];
+  rsx::DevBuf imgs, imgs2, fwd, bwd, stage_src, stage_dst, pair_cnt, src, dst, offsets, results;
+  uint64_t windows = 0;  // windows enqueued since creation: window g works in set[g & 1]
   bool have_prev = false;
 };
 
@@ -113,17 +127,20 @@ using rsx::fail;
 namespace {
 
 constexpr size_t PIN_COUNTS = 0, PIN_PAIRS = 4 * (MAX_WINDOW + 1), PIN_RES = PIN_PAIRS + 4 * MAX_WINDOW + 4,
-                 PIN_BYTES = PIN_RES + sizeof(rsx_orora_result) * MAX_WINDOW;
+                 PIN_AZ = (PIN_RES + sizeof(rsx_orora_result) * MAX_WINDOW + 255) / 256 * 256;
+size_t pin_bytes(const rsx_odometry *h) { return PIN_AZ + (size_t)h->rows * 4 * MAX_WINDOW; }
 
 int reserve_all(rsx_odometry *h, size_t ibytes, hipStream_t s) {
   const size_t K = (size_t)h->prm.max_keypoints, S = MAX_WINDOW + 1;
   RSX_TRY(h->imgs.reserve(ibytes * MAX_WINDOW, s, false));
-  RSX_TRY(h->az.reserve((size_t)h->rows * 4 * MAX_WINDOW, s, false));
-  RSX_TRY(h->targets.reserve(S * K * 8, s, false));
-  RSX_TRY(h->xy.reserve(S * K * 8, s, true));
-  RSX_TRY(h->counts.reserve(S * 4, s, true));
-  RSX_TRY(h->desc.reserve(S * K * 32, s, true));
-  RSX_TRY(h->valid.reserve(S * K, s, true));
+  for (OdoSet &q : h->set) {
+    RSX_TRY(q.az.reserve((size_t)h->rows * 4 * MAX_WINDOW, s, false));
+    RSX_TRY(q.targets.reserve(S * K * 8, s, false));
+    RSX_TRY(q.xy.reserve(S * K * 8, s, true));
+    RSX_TRY(q.counts.reserve(S * 4, s, true));
+    RSX_TRY(q.desc.reserve(S * K * 32, s, true));
+    RSX_TRY(q.valid.reserve(S * K, s, true));
+  }
   RSX_TRY(h->fwd.reserve((size_t)MAX_WINDOW * K * 4, s, false));
   RSX_TRY(h->bwd.reserve((size_t)MAX_WINDOW * K * 4, s, false));
   RSX_TRY(h->stage_src.reserve((size_t)MAX_WINDOW * K * 8, s, false));
@@ -136,29 +153,55 @@ int reserve_all(rsx_odometry *h, size_t ibytes, hipStream_t s) {
   return RSX_OK;
 }
 
-// one window of n <= MAX_WINDOW scans whose images are at d_imgs (device): every launch and the result copies, asynchronous
-int enqueue_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, const float *azimuths,
-                   int32_t azimuths_per_image, hipStream_t s) {
+// E(g): window g (n <= MAX_WINDOW scans whose images are at d_imgs, device) through cen2019, the Cartesian images and the
+// descriptors into set g & 1, then its last scan into slot 0 of the other set.  Asynchronous on the extraction stream.
+int enqueue_extract(rsx_odometry *h, uint64_t g, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, const float *azimuths,
+                    int32_t azimuths_per_image) {
+  hipStream_t s = h->stream;
+  OdoSet &q = h->set[g & 1], &nx = h->set[(g + 1) & 1];
   const int K = h->prm.max_keypoints;
   const size_t slot_xy = (size_t)K * 2;
-  // the azimuth grids go to the device once: cen2019's polar -> Cartesian and the Cartesian image both read them there
+  RSX_HIP(hipStreamWaitEvent(s, h->ev_m[g & 1], 0));  // M(g - 2) read this set (a no-op before the event's first record)
+  // the azimuth grids go to the device once: cen2019's polar -> Cartesian and the Cartesian image both read them there.
+  // Staged in pinned memory so that the copy does not wait for the stream (the area was last read by E(g - 2): long done)
   const size_t na = (size_t)h->rows * (azimuths_per_image ? n : 1);
-  RSX_HIP(hipMemcpyAsync(h->az.p, azimuths, na * 4, hipMemcpyHostToDevice, s));
-  int32_t *d_counts = h->counts.as<int32_t>();
-  RSX_TRY(rsx_cen2019_extract_batch_device(h->cen, d_imgs, n, img_stride, row_stride, h->prm.col_offset, &h->prm.cen, h->az.as<float>(),
-                                           azimuths_per_image, h->prm.radar_resolution, h->targets.as<int32_t>() + slot_xy,
-                                           h->xy.as<float>() + slot_xy, K, d_counts + 1, s));
+  float *paz = reinterpret_cast<float *>(static_cast<char *>(q.pin) + PIN_AZ);
+  std::memcpy(paz, azimuths, na * 4);
+  RSX_HIP(hipMemcpyAsync(q.az.p, paz, na * 4, hipMemcpyHostToDevice, s));
+  int32_t *d_counts = q.counts.as<int32_t>();
+  RSX_TRY(rsx_cen2019_extract_batch_device(h->cen, d_imgs, n, img_stride, row_stride, h->prm.col_offset, &h->prm.cen, q.az.as<float>(),
+                                           azimuths_per_image, h->prm.radar_resolution, q.targets.as<int32_t>() + slot_xy,
+                                           q.xy.as<float>() + slot_xy, K, d_counts + 1, s));
   // the Cartesian image of scan i through scan i's OWN azimuth grid (already in HBM for cen2019): results do not depend on
   // how the sequence is cut into windows, and nothing about the grids is looked at on the host
-  RSX_TRY(rsx_frontend_cartesian_batch_device_az(h->fe, d_imgs, n, img_stride, row_stride, h->prm.col_offset, h->az.as<float>(),
+  RSX_TRY(rsx_frontend_cartesian_batch_device_az(h->fe, d_imgs, n, img_stride, row_stride, h->prm.col_offset, q.az.as<float>(),
                                                  azimuths_per_image ? (int64_t)h->rows : 0, h->prm.radar_resolution, s));
-  RSX_TRY(rsx_frontend_describe_batch_device(h->fe, h->xy.as<float>() + slot_xy, d_counts + 1, n, K, h->desc.as<uint8_t>() + (size_t)K * 32,
-                                             h->valid.as<uint8_t>() + (size_t)K, s));
+  RSX_TRY(rsx_frontend_describe_batch_device(h->fe, q.xy.as<float>() + slot_xy, d_counts + 1, n, K, q.desc.as<uint8_t>() + (size_t)K * 32,
+                                             q.valid.as<uint8_t>() + (size_t)K, s));
+  // the last scan of the window becomes the previous scan of the next one (slot 0 of the other set, which M(g - 1) reads)
+  RSX_HIP(hipStreamWaitEvent(s, h->ev_m[(g + 1) & 1], 0));
+  RSX_HIP(hipMemcpyAsync(nx.xy.p, q.xy.as<float>() + (size_t)n * slot_xy, slot_xy * 4, hipMemcpyDeviceToDevice, s));
+  RSX_HIP(hipMemcpyAsync(nx.desc.p, q.desc.as<uint8_t>() + (size_t)n * K * 32, (size_t)K * 32, hipMemcpyDeviceToDevice, s));
+  RSX_HIP(hipMemcpyAsync(nx.valid.p, q.valid.as<uint8_t>() + (size_t)n * K, (size_t)K, hipMemcpyDeviceToDevice, s));
+  RSX_HIP(hipMemcpyAsync(nx.counts.p, d_counts + n, 4, hipMemcpyDeviceToDevice, s));
+  RSX_HIP(hipEventRecord(h->ev_e[g & 1], s));
+  return RSX_OK;
+}
+
+// M(g): the consecutive pairs of window g (with the previous scan in slot 0 when there is one) matched, selected and solved,
+// the results on their way to the set's pinned area.  Asynchronous on the matching stream.  *first_out: 0 when slot 0 takes part.
+int enqueue_match(rsx_odometry *h, uint64_t g, int n, int *first_out) {
+  hipStream_t s = h->match_stream;
+  OdoSet &q = h->set[g & 1];
+  const int K = h->prm.max_keypoints;
+  RSX_HIP(hipStreamWaitEvent(s, h->ev_e[g & 1], 0));
+  int32_t *d_counts = q.counts.as<int32_t>();
   const int first = h->have_prev ? 0 : 1, n_pairs = n - first;
+  *first_out = first;
   if (n_pairs > 0) {
-    RSX_TRY(rsx_frontend_match_consecutive_device(h->fe, h->desc.as<uint8_t>(), h->valid.as<uint8_t>(), d_counts, K, first, n_pairs,
+    RSX_TRY(rsx_frontend_match_consecutive_device(h->fe, q.desc.as<uint8_t>(), q.valid.as<uint8_t>(), d_counts, K, first, n_pairs,
                                                   h->prm.frontend.ratio, h->fwd.as<int32_t>(), h->bwd.as<int32_t>(), s));
-    hipLaunchKernelGGL(odo_cross, dim3((unsigned)n_pairs), dim3(256), 0, s, h->xy.as<float>(), d_counts, K, first, h->fwd.as<int32_t>(),
+    hipLaunchKernelGGL(odo_cross, dim3((unsigned)n_pairs), dim3(256), 0, s, q.xy.as<float>(), d_counts, K, first, h->fwd.as<int32_t>(),
                        h->bwd.as<int32_t>(), h->stage_src.as<float2>(), h->stage_dst.as<float2>(), h->pair_cnt.as<int32_t>());
     hipLaunchKernelGGL(odo_gather, dim3((unsigned)n_pairs), dim3(256), 0, s, h->stage_src.as<float2>(), h->stage_dst.as<float2>(),
                        h->pair_cnt.as<int32_t>(), n_pairs, K, h->src.as<float2>(), h->dst.as<float2>(), h->offsets.as<int64_t>());
@@ -166,57 +209,55 @@ int enqueue_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_st
     RSX_TRY(rsx_orora_register_batch_device(h->reg, h->src.as<float>(), h->dst.as<float>(), h->offsets.as<int64_t>(), n_pairs, &h->prm.orora,
                                             h->results.as<rsx_orora_result>(), s));
   }
-  char *pin = static_cast<char *>(h->h_pin);
+  char *pin = static_cast<char *>(q.pin);
   RSX_HIP(hipMemcpyAsync(pin + PIN_COUNTS, d_counts, (size_t)(n + 1) * 4, hipMemcpyDeviceToHost, s));
   if (n_pairs > 0) {
     RSX_HIP(hipMemcpyAsync(pin + PIN_PAIRS, h->pair_cnt.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s));
     RSX_HIP(hipMemcpyAsync(pin + PIN_RES, h->results.p, (size_t)n_pairs * sizeof(rsx_orora_result), hipMemcpyDeviceToHost, s));
   }
+  RSX_HIP(hipEventRecord(h->ev_m[g & 1], s));
+  h->have_prev = true;
   return RSX_OK;
 }
 
-// wait for the window enqueued last, fill out[0..n) (+ the keypoints), hand the last scan over to the next window
-int finish_window(rsx_odometry *h, int n, rsx_odometry_scan *out, float *out_xy, int32_t max_xy, hipStream_t s) {
+// wait for M(g), fill out[0..n) (+ the keypoints)
+int finish_window(rsx_odometry *h, uint64_t g, int n, int first, rsx_odometry_scan *out, float *out_xy, int32_t max_xy) {
+  OdoSet &q = h->set[g & 1];
   const int K = h->prm.max_keypoints;
   const size_t slot_xy = (size_t)K * 2;
-  int32_t *d_counts = h->counts.as<int32_t>();
-  char *pin = static_cast<char *>(h->h_pin);
-  RSX_HIP(hipStreamSynchronize(s));
+  char *pin = static_cast<char *>(q.pin);
+  RSX_HIP(hipEventSynchronize(h->ev_m[g & 1]));
   const int32_t *hc = reinterpret_cast<const int32_t *>(pin + PIN_COUNTS), *hp = reinterpret_cast<const int32_t *>(pin + PIN_PAIRS);
   const rsx_orora_result *hr = reinterpret_cast<const rsx_orora_result *>(pin + PIN_RES);
   for (int i = 0; i < n; i++) {
     rsx_odometry_scan &o = out[i];
     std::memset(&o, 0, sizeof(o));
     o.n_keypoints = hc[1 + i];
-    const int pj = h->have_prev ? i : i - 1;  // index of the pair (scan i-1, scan i) in this window
-    if (pj >= 0) {
-      o.reg = hr[pj];
-      o.n_matches = hp[pj];
+    const int pair = first ? i - 1 : i;  // index of the pair (scan i-1, scan i) in this window
+    if (pair >= 0) {
+      o.reg = hr[pair];
+      o.n_matches = hp[pair];
     } else {
       o.reg.status = 3;  // the first scan of a sequence: there is no previous scan
     }
   }
-  if (out_xy && max_xy > 0) {
+  if (out_xy && max_xy > 0) {  // (set g & 1 is not written again before E(g + 2), which the host enqueues after this returns)
+    hipStream_t s = h->match_stream;
     for (int i = 0; i < n; i++) {
       const int c = hc[1 + i] < K ? hc[1 + i] : K, wn = c < max_xy ? c : max_xy;
       if (wn > 0)
-        RSX_HIP(hipMemcpyAsync(out_xy + (size_t)i * max_xy * 2, h->xy.as<float>() + (size_t)(1 + i) * slot_xy, (size_t)wn * 8, hipMemcpyDeviceToHost, s));
+        RSX_HIP(hipMemcpyAsync(out_xy + (size_t)i * max_xy * 2, q.xy.as<float>() + (size_t)(1 + i) * slot_xy, (size_t)wn * 8, hipMemcpyDeviceToHost, s));
     }
     RSX_HIP(hipStreamSynchronize(s));
   }
-  // the last scan of the window becomes the previous scan of the next one
-  RSX_HIP(hipMemcpyAsync(h->xy.p, h->xy.as<float>() + (size_t)n * slot_xy, slot_xy * 4, hipMemcpyDeviceToDevice, s));
-  RSX_HIP(hipMemcpyAsync(h->desc.p, h->desc.as<uint8_t>() + (size_t)n * K * 32, (size_t)K * 32, hipMemcpyDeviceToDevice, s));
-  RSX_HIP(hipMemcpyAsync(h->valid.p, h->valid.as<uint8_t>() + (size_t)n * K, (size_t)K, hipMemcpyDeviceToDevice, s));
-  RSX_HIP(hipMemcpyAsync(h->counts.p, d_counts + n, 4, hipMemcpyDeviceToDevice, s));
-  h->have_prev = true;
   return RSX_OK;
 }
 
-int run_window(rsx_odometry *h, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, const float *azimuths,
-               int32_t azimuths_per_image, rsx_odometry_scan *out, float *out_xy, int32_t max_xy, hipStream_t s) {
-  RSX_TRY(enqueue_window(h, d_imgs, n, img_stride, row_stride, azimuths, azimuths_per_image, s));
-  return finish_window(h, n, out, out_xy, max_xy, s);
+// after an error in the middle of a sequence: nothing in flight, the next scan starts a new sequence
+void abandon(rsx_odometry *h) {
+  (void)hipStreamSynchronize(h->stream);
+  (void)hipStreamSynchronize(h->match_stream);
+  h->have_prev = false;
 }
 
 int check_layout(rsx_odometry *h, int32_t n, int64_t image_stride_bytes, int32_t row_stride) {
@@ -277,9 +318,14 @@ int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t
   if (st == RSX_OK) {
     hipError_t e = hipSetDevice(p.device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->match_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipHostMalloc(&h->h_pin, PIN_BYTES, hipHostMallocDefault);
+    for (int i = 0; i < 2; i++) {
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_e[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_m[i], hipEventDisableTiming);
+      if (e == hipSuccess) e = hipHostMalloc(&h->set[i].pin, pin_bytes(h), hipHostMallocDefault);
+    }
     if (e != hipSuccess) st = fail(e == hipErrorOutOfMemory ? RSX_ERR_OOM : RSX_ERR_HIP, "odometry create: %s", hipGetErrorString(e));
   }
   if (st != RSX_OK) {
@@ -294,16 +340,24 @@ int rsx_odometry_destroy(rsx_odometry *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
   if (h->stream) (void)hipStreamSynchronize(h->stream);
+  if (h->match_stream) (void)hipStreamSynchronize(h->match_stream);
   if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-  for (rsx::DevBuf *b : {&h->imgs, &h->imgs2, &h->az, &h->targets, &h->xy, &h->counts, &h->desc, &h->valid, &h->fwd, &h->bwd, &h->stage_src, &h->stage_dst,
-                         &h->pair_cnt, &h->src, &h->dst, &h->offsets, &h->results})
+  for (rsx::DevBuf *b : {&h->imgs, &h->imgs2, &h->fwd, &h->bwd, &h->stage_src, &h->stage_dst, &h->pair_cnt, &h->src, &h->dst, &h->offsets, &h->results})
     b->release();
-  if (h->h_pin) (void)hipHostFree(h->h_pin);
+  for (OdoSet &q : h->set) {
+    for (rsx::DevBuf *b : {&q.az, &q.targets, &q.xy, &q.counts, &q.desc, &q.valid}) b->release();
+    if (q.pin) (void)hipHostFree(q.pin);
+  }
   rsx_cen2019_destroy(h->cen);
   rsx_frontend_destroy(h->fe);
   rsx_orora_destroy(h->reg);
   if (h->ev_up) (void)hipEventDestroy(h->ev_up);
+  for (int i = 0; i < 2; i++) {
+    if (h->ev_e[i]) (void)hipEventDestroy(h->ev_e[i]);
+    if (h->ev_m[i]) (void)hipEventDestroy(h->ev_m[i]);
+  }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+  if (h->match_stream) (void)hipStreamDestroy(h->match_stream);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
@@ -326,15 +380,25 @@ int rsx_odometry_push_device(rsx_odometry *h, const uint8_t *d_imgs, int32_t n_s
   RSX_TRY(check_azimuths(h, azimuths, azimuths_per_image, n_scans));
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
-  hipStream_t s = h->stream;
-  RSX_TRY(reserve_all(h, 0, s));
-  for (int b0 = 0; b0 < n_scans; b0 += MAX_WINDOW) {
-    const int n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
-    RSX_TRY(run_window(h, d_imgs + (int64_t)b0 * image_stride_bytes, n, image_stride_bytes, row_stride,
-                       azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0), azimuths_per_image, out + b0,
-                       out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy, s));
+  RSX_TRY(reserve_all(h, 0, h->stream));
+  auto window = [&](int w, uint64_t g) -> int {  // E(g) of the call's window w
+    const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
+    return enqueue_extract(h, g, d_imgs + (int64_t)b0 * image_stride_bytes, n, image_stride_bytes, row_stride,
+                           azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0), azimuths_per_image);
+  };
+  const int nwin = (n_scans + MAX_WINDOW - 1) / MAX_WINDOW;
+  int st = window(0, h->windows);
+  for (int w = 0; w < nwin && st == RSX_OK; w++) {
+    const uint64_t g = h->windows + (uint64_t)w;
+    const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
+    int first = 0;
+    st = enqueue_match(h, g, n, &first);
+    if (st == RSX_OK && w + 1 < nwin) st = window(w + 1, g + 1);  // the next window's extraction runs beside this window's matching
+    if (st == RSX_OK) st = finish_window(h, g, n, first, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy);
   }
-  return RSX_OK;
+  h->windows += (uint64_t)nwin;
+  if (st != RSX_OK) abandon(h);
+  return st;
 } RSX_CATCH_ALL
 
 int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int64_t image_stride_bytes, int32_t row_stride,
@@ -365,19 +429,28 @@ int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int
     return RSX_OK;
   };
   void *bufs[2] = {h->imgs.p, h->imgs2.p};
-  RSX_TRY(upload(0, n_scans < MAX_WINDOW ? n_scans : MAX_WINDOW, bufs[0]));
-  int w = 0;
-  for (int b0 = 0; b0 < n_scans; b0 += MAX_WINDOW, w++) {
-    const int n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
-    RSX_HIP(hipStreamWaitEvent(s, h->ev_up, 0));
-    RSX_TRY(enqueue_window(h, static_cast<const uint8_t *>(bufs[w & 1]), n, (int64_t)ibytes, row_stride,
-                           azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0), azimuths_per_image, s));
-    const int b1 = b0 + MAX_WINDOW;
-    // (buffer (w + 1) & 1 was read by window w - 1, which finish_window has already waited for)
-    if (b1 < n_scans) RSX_TRY(upload(b1, n_scans - b1 < MAX_WINDOW ? n_scans - b1 : MAX_WINDOW, bufs[(w + 1) & 1]));
-    RSX_TRY(finish_window(h, n, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy, s));
+  auto window = [&](int w, uint64_t g) -> int {  // E(g) of the call's window w, behind its upload
+    const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
+    RSX_HIP(hipStreamWaitEvent(h->stream, h->ev_up, 0));
+    return enqueue_extract(h, g, static_cast<const uint8_t *>(bufs[w & 1]), n, (int64_t)ibytes, row_stride,
+                           azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0), azimuths_per_image);
+  };
+  const int nwin = (n_scans + MAX_WINDOW - 1) / MAX_WINDOW;
+  int st = upload(0, n_scans < MAX_WINDOW ? n_scans : MAX_WINDOW, bufs[0]);
+  if (st == RSX_OK) st = window(0, h->windows);
+  for (int w = 0; w < nwin && st == RSX_OK; w++) {
+    const uint64_t g = h->windows + (uint64_t)w;
+    const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW, b1 = b0 + MAX_WINDOW;
+    int first = 0;
+    st = enqueue_match(h, g, n, &first);
+    // (image buffer (w + 1) & 1 was read by the extraction of window w - 1, which the matching of w - 1 -- waited for -- followed)
+    if (st == RSX_OK && b1 < n_scans) st = upload(b1, n_scans - b1 < MAX_WINDOW ? n_scans - b1 : MAX_WINDOW, bufs[(w + 1) & 1]);
+    if (st == RSX_OK && b1 < n_scans) st = window(w + 1, g + 1);
+    if (st == RSX_OK) st = finish_window(h, g, n, first, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy);
   }
-  return RSX_OK;
+  h->windows += (uint64_t)nwin;
+  if (st != RSX_OK) abandon(h);
+  return st;
 } RSX_CATCH_ALL
 
 int rsx_host_alloc_pinned(size_t bytes, void **out) try {
