@@ -1281,17 +1281,23 @@ int rsx_sc_query_device(rsx_sc *h, const float *d_q, int32_t nq, int32_t k, int6
 } RSX_CATCH_ALL
 
 // How the host-buffer entry cuts a batch into pieces: the upload of the first piece is the only one nothing hides, every
-// later piece is `growth` times the one before -- a piece is scored ~3x slower than PCIe delivers the next (8192 queries vs
-// 10 000 keyframes on MI355X: 0.33 ms of scoring, 0.09 ms of upload per 1024 queries at the 54 GB/s measured), so the upload
-// of piece c + 1 ends long before the scoring of piece c does, and few large pieces lose less to the per-launch tails than
-// many small ones.  Measured plans (top-10, same box, ms per call / fraction of the resident step's 2.72 ms):
-// whole 3.56 / 0.76, 512:2.5 3.13 / 0.87, 1024:1.0 3.25 / 0.84, 1024:1.5 3.11 / 0.88, 1024:2.5 (1024 + 2560 + 4608)
-// 3.04 / 0.89, 256:4.0 3.01-3.10; on ONE stream 1024:2.5 is 3.20 / 0.85.  Batches below 4 pieces' worth stay whole.
-// RSX_SC_HOST_PIECES=first[:growth_x10] (experiments build) overrides; first = 0 keeps every batch whole.
+// later piece is `growth` times the one before -- a piece is filtered ~2.4x slower than PCIe delivers the next (8192 queries vs
+// 10 000 keyframes on MI355X: 0.21 ms of filter, 0.09 ms of upload per 1024 queries at the 54 GB/s measured), so the upload
+// of piece c + 1 ends before the filter of piece c does.
+// Round 6: only the FILTER runs piece by piece; short lists, window previews and re-scoring run once over the whole batch
+// (rsx_sc_query, `one_tail`).  Timeline of one call, 512:2.5 = 512 + 1280 + 3200 + 3200 queries, top-10 (rocprofv3 kernel + copy
+// trace, tools/host_timeline.py): first upload 50 us + 20 us to the first kernel; filter launches 139 + 313 + 753 + 745 =
+// 1950 us (the whole batch in one launch: 1750 -- a piece of 3200 queries fills 234 of the 256 workgroups of its one round, a piece of
+// 512 fills 78: the filter amortises a 304-register tile load over >= 16 query tiles per unit and cannot cut finer); the stages
+// behind it 826 us as in the resident step; read-back + synchronise ~50 us.  Measured plans (ms per call pageable / pinned,
+// fraction of the resident step's 2.58 ms; tools/ab_host_pieces.py, one box): round 5's three chains on two streams 1024:2.5
+// 2.98 / 3.00 = 0.87 / 0.87; one tail 1024:2.5 2.96 / 2.92, **512:2.5 2.86 / 2.91 = 0.90 / 0.89**, 512:2.0 2.88 / 2.93, 256:3.0
+// 2.86 / 2.91, 256:2.5 2.93 / 3.01, 128:3.0 2.89 / 2.88, 1024:1.5 2.93 / 2.94, 2048:2.0 2.95 / 3.04.  Batches below 4 pieces'
+// worth stay whole.  RSX_SC_HOST_PIECES=first[:growth_x10] (experiments build) overrides; first = 0 keeps every batch whole.
 int host_pieces(int32_t nq, int32_t *sizes) {
   static const std::pair<int, int> cfg = [] {
     const char *e = rsx::exp_env("RSX_SC_HOST_PIECES");
-    std::pair<int, int> r{1024, 25};
+    std::pair<int, int> r{512, 25};
     if (e && *e) {
       r.first = atoi(e);
       const char *c = strchr(e, ':');
@@ -1359,7 +1365,59 @@ int rsx_sc_query(rsx_sc *h, const float *q, int32_t nq, int32_t k, int64_t n_eli
       RSX_HIP(hipEventRecord(h->up_ev[c], h->up_stream));
       return RSX_OK;
     };
+    // Round 6: where the whole batch goes through ONE filter workspace (the usual case: 8192 queries against 10 000 entries), only
+    // the FILTER runs piece by piece -- keys, query images and bound rows of piece c while piece c + 1 goes up -- and the stages
+    // behind it (short lists, window previews, re-scoring) run ONCE over the whole batch: their fixed costs (~90 us of dependent
+    // small kernels per piece) are what the piecewise chains paid three times.  RSX_SC_HOST_TAIL=pieces (experiments build)
+    // keeps the chains.
+    static const bool one_tail_allowed = [] {
+      const char *e = rsx::exp_env("RSX_SC_HOST_TAIL");
+      return !(e && e[0] == 'p');
+    }();
+    const int64_t items = local_count_below(h, n_eligible), elig_all = n_eligible < 0 ? h->n_global : n_eligible;
+    const bool one_tail = one_tail_allowed && !use_q1(h, nq, items) && use_filter(h, nq, items) && filter_batch(items, nq) >= nq;
+    auto filter_pieces_one_tail = [&]() -> int {
+      hipStream_t s = h->stream;
+      h->w = &h->ws[0];
+      RSX_TRY(filter_reserve(h, items, nq, s));
+      QueryView all;
+      {  // (prepare_queries without its launch: the keys are built piece by piece)
+        h->st.valid = false;
+        RSX_TRY(h->w->q_vkey.reserve((size_t)nq * NS * sizeof(double), s, false));
+        RSX_TRY(h->w->q_norm.reserve((size_t)nq * NS * sizeof(double), s, false));
+        RSX_TRY(h->w->q_rkey.reserve((size_t)nq * NR * sizeof(float), s, false));
+        all.desc = h->q_desc.as<float>();
+        all.vkey = h->w->q_vkey.as<double>();
+        all.norm = h->w->q_norm.as<double>();
+        all.nq = nq;
+      }
+      const int64_t ld = (items + 31) / 32 * 32;
+      lb_t *lb = h->w->f_lb.as<lb_t>();
+      RSX_TRY(upload(0, 0));
+      int64_t q0 = 0;
+      for (int c = 0; c < np; c++) {
+        RSX_HIP(hipStreamWaitEvent(s, h->up_ev[c], 0));
+        RSX_TRY(launch_keys(all.desc + q0 * DS, sizes[c], h->w->q_vkey.as<double>() + q0 * NS, h->w->q_norm.as<double>() + q0 * NS,
+                            h->w->q_rkey.as<float>() + q0 * NR, s, h->p.sum_order));
+        QueryView piece = all;
+        piece.desc = all.desc + q0 * DS;
+        piece.vkey = all.vkey + q0 * NS;
+        piece.norm = all.norm + q0 * NS;
+        piece.nq = sizes[c];
+        RSX_TRY(run_filter(h, piece, items, lb + q0 * ld, ld, nullptr, s));  // (the query images of a piece are consumed by its own launch)
+        q0 += sizes[c];
+        if (c + 1 < np) RSX_TRY(upload(c + 1, q0));
+      }
+      const DbView db = db_view(h);
+      RSX_TRY(launch_select(db, lb, ld, items, nq, elig_all, nullptr, first_round_target(), h->w->f_cand.as<RescoreEntry>(),
+                            h->w->f_cnt.as<int32_t>(), h->w->f_thr.as<float>(), s));
+      if (use_window())
+        RSX_TRY(launch_window(db, all, h->w->f_wimg.p, h->w->f_cand.as<RescoreEntry>(), h->w->f_cnt.as<int32_t>(), k, filter_eps(),
+                              h->w->f_win.as<WindowPreview>(), s, 0));
+      return rescore(h, all, items, elig_all, nullptr, 0, RESCORE_ALL_ROUNDS, nullptr, nullptr, k, h->topk.as<rsx_sc_hit>(), s);
+    };
     auto all_pieces = [&]() -> int {
+      if (one_tail) return filter_pieces_one_tail();
       // lane B starts behind whatever the caller's earlier calls left on the main stream (DB appends ...)
       RSX_HIP(hipEventRecord(h->lane_ev, h->stream));
       RSX_HIP(hipStreamWaitEvent(h->stream_b, h->lane_ev, 0));

@@ -192,16 +192,18 @@ def test_rccl_exchange_world_one(sc):
     one.close()
 
 
-@pytest.mark.parametrize("nq", [4095, 4096, 5555, 8192])
-def test_host_entry_in_pieces_equals_the_device_entry(sc, nq):
-    """rsx_sc_query uploads a large batch in pieces and scores each while the next one goes up (sc_api.cpp host_pieces):
-    the records must be those of one device-resident call over the whole batch, from pageable and from pinned memory,
-    for sizes below the cut (4095: one piece), at it, ragged, and the bench's."""
+@pytest.mark.parametrize("nq,n_db", [(2047, 1500), (2048, 1500), (4096, 1500), (5555, 1500), (8192, 1500), (4096, 24)])
+def test_host_entry_in_pieces_equals_the_device_entry(sc, nq, n_db):
+    """rsx_sc_query uploads a large batch in pieces (sc_api.cpp host_pieces) and filters each while the next one goes up, the
+    stages behind the filter once over the whole batch; where the filter does not apply (24 entries: every pair scored exactly)
+    each piece runs its own chain.  The records must be those of one device-resident call over the whole batch, from pageable
+    and from pinned memory, for sizes below the cut (2047: one piece), at it, ragged, and the bench's."""
     import torch
     from navtech_radar_slam_amd import _rsx
     k = 3
-    db = synth.random_descriptors(11, 1500, binary=True)
+    db = synth.random_descriptors(11, n_db, binary=True)
     db[5].reshape(60, 20)[10:25] = 0
+    n_el = n_db - n_db // 15
     q = synth.random_descriptors(12, nq, binary=True)
     q[::7] = db[np.arange(len(q[::7])) % len(db)]          # revisits: exact ties between pieces and entries
     q[3].reshape(60, 20)[:30] = 0                          # a query with empty columns (the filter's slow path)
@@ -209,16 +211,16 @@ def test_host_entry_in_pieces_equals_the_device_entry(sc, nq):
     g.add_descriptors_f32(db)
     dq = torch.from_numpy(q).cuda()
     ref = torch.zeros((nq, k, 2), dtype=torch.float64, device="cuda")
-    g.query_device(dq.data_ptr(), nq, k, ref.data_ptr(), n_eligible=1400, stream=torch.cuda.current_stream().cuda_stream)
+    g.query_device(dq.data_ptr(), nq, k, ref.data_ptr(), n_eligible=n_el, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     ref = ref.cpu().numpy().view(sc.HIT_DTYPE).reshape(nq, k)
-    got = g.query(q, k=k, n_eligible=1400)
+    got = g.query(q, k=k, n_eligible=n_el)
     assert np.array_equal(got, ref)
     with _rsx.PinnedArray((nq, 1200), np.float32) as pq, _rsx.PinnedArray((nq, k), sc.HIT_DTYPE) as po:
         pq.a[:] = q
-        g.query(pq.a, k=k, n_eligible=1400, out=po.a)
+        g.query(pq.a, k=k, n_eligible=n_el, out=po.a)
         assert np.array_equal(po.a, ref)
-        g.query(pq.a[:100], k=k, n_eligible=1400, out=po.a[:100])   # a small batch right after: workspaces reused
+        g.query(pq.a[:100], k=k, n_eligible=n_el, out=po.a[:100])   # a small batch right after: workspaces reused
         assert np.array_equal(po.a[:100], ref[:100])
     g.close()
 

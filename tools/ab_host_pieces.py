@@ -31,12 +31,15 @@ def main():
     plans = os.environ.get("AB_PLANS", "0 512:25 256:25 1024:25 512:20 512:30 768:22 1024:20").split()
     code = open(os.path.join(ROOT, "tools", "_ab_host_child.py")).read()
     for p in plans:
-        lanes = "2"
+        lanes, tail = "2", "one"
+        if p.endswith("@p"):  # the round-5 form: every piece its own filter / select / window / re-scoring chain
+            p, tail = p[:-2], "pieces"
         if p.endswith("/1"):
             p, lanes = p[:-2], "1"
-        env = dict(os.environ, RSX_SC_HOST_PIECES=p, RSX_SC_HOST_LANES=lanes, RSX_LIB_PATH=os.path.join(ROOT, "abtest", "librsx_exp.so"))
+        env = dict(os.environ, RSX_SC_HOST_PIECES=p, RSX_SC_HOST_LANES=lanes, RSX_SC_HOST_TAIL=tail,
+                   RSX_LIB_PATH=os.path.join(ROOT, "abtest", "librsx_exp.so"))
         r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=ROOT)
-        print(p, "lanes", lanes, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:])
+        print(p, "lanes", lanes, "tail", tail, r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-400:])
 
 
 if __name__ == "__main__":
