@@ -96,3 +96,36 @@ def test_strip_kernel_batch_with_per_image_grids(fe, oracle):
             assert np.array_equal(cart_g, cart_o), (flags, k)
             assert np.array_equal(blur_g, o.blur), (flags, k)
         g.close()
+
+
+def test_strip_kernel_equals_the_three_kernel_form_on_unusual_grids_and_shapes(fe):
+    """Grids and shapes no radar delivers but a caller can pass on the device path (nothing is validated there): a descending
+    grid, a step of a thousandth of a bin, a first azimuth many turns away, a zero step (NaN rows), 7 azimuths, 3 range bins,
+    a padded row stride with no metadata columns.  There is no oracle for these; the strip kernel (reciprocal multiply + exact
+    branch, 16-bit tap pairs, LDS transposition) must give the three-kernel form's images (exact division, byte taps) bit for bit."""
+    import torch
+    rng = np.random.default_rng(8)
+    cases = []
+    for rows, cols, stride, off, W, res in ((400, 3360, 3371, 11, 301, 0.9), (7, 3, 8, 0, 64, 0.05), (33, 100, 128, 5, 97, 0.7)):
+        base = (np.arange(rows) * (2 * np.pi / rows)).astype(np.float32)
+        grids = [base, base[::-1].copy(), (base * 1e-3).astype(np.float32), (base + np.float32(100.0)).astype(np.float32),
+                 np.zeros(rows, np.float32), (base * 3.7 - 1.0).astype(np.float32)]
+        cases.append((rows, cols, stride, off, W, res, grids))
+    for rows, cols, stride, off, W, res, grids in cases:
+        n = len(grids)
+        imgs = rng.integers(0, 256, (n, rows, stride), dtype=np.uint8)
+        d_img = torch.from_numpy(imgs).cuda()
+        d_az = torch.from_numpy(np.ascontiguousarray(np.stack(grids))).cuda()
+        out = {}
+        for flags in (1, 0, 2):
+            p = fe.default_params()
+            p.cart_pixel_width, p.cart_resolution, p.flags = W, res, flags
+            g = fe.Frontend(rows, cols, params=p)
+            g.cartesian_batch_device(d_img.data_ptr(), n, rows * stride, stride, d_az.data_ptr(), rows, 0.3, col_offset=off)
+            out[flags] = [g.read_images(k) for k in range(n)]
+            g.close()
+        for k in range(n):
+            for flags in (0, 2):
+                for a, b in zip(out[flags][k], out[1][k]):
+                    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (rows, cols, W, k, flags)
+        assert np.isfinite(out[0][0][0]).all() and out[0][0][0].max() > 0
