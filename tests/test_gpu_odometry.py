@@ -200,3 +200,39 @@ def test_degenerate_scans(sequence, oracle):
     for i in range(1, 4):
         w = c2[i]["result"]
         assert r2["status"][i] == w["status"] and max(abs(r2[f][i] - w[f]) for f in ("x", "y", "yaw")) < 1e-4
+
+
+def test_two_windows_in_flight_change_nothing(sequence):
+    """More scans than a window in ONE call: the extraction of window g + 1 runs beside the matching / selection / solver chain
+    of window g, the hand-over sets alternate, and the last scan of a window is carried into the other set (csrc/odometry.hip).
+    150 scans (the drive run back and forth) in one call = windows of 64 + 64 + 22, from host memory and resident in HBM, must
+    give the bytes of calls cut at 1 / 64 / 3 / 65 / 17 scans (every call its own windows, set parity continuing across calls),
+    and a reset in the middle must start a new sequence."""
+    import torch
+    from navtech_radar_slam_amd import odometry
+    imgs, az, poses, stamps = sequence
+    order, i, step = [], 0, 1
+    while len(order) < 150:
+        order.append(i)
+        if not 0 <= i + step < len(imgs):
+            step = -step
+        i += step
+    seq = np.ascontiguousarray(imgs[np.asarray(order)])
+    od = odometry.Odometry(400, 3360)
+    whole = od.push(seq, az)
+    assert whole["status"][0] == 3 and (whole["status"][1:] == 0).all()
+    od.reset()
+    cuts = np.cumsum([0, 1, 64, 3, 65, 17])
+    assert cuts[-1] == 150
+    parts = np.concatenate([od.push(seq[a:b], az) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert parts.tobytes() == whole.tobytes()
+    od.reset()
+    d = torch.from_numpy(seq).cuda()
+    torch.cuda.synchronize()
+    dev = od.push(seq, az, device_ptr=d.data_ptr())
+    assert dev.tobytes() == whole.tobytes()
+    dev2 = od.push(seq[:70], az, device_ptr=d.data_ptr())              # continues the sequence: scan 0 now has a previous scan
+    assert dev2["status"][0] == 0 and dev2[1:].tobytes() == whole[1:70].tobytes()
+    od.reset()
+    again = od.push(seq[64:140], az)                                   # a new sequence that starts in the middle
+    assert again["status"][0] == 3 and again[1:].tobytes() == whole[65:140].tobytes()
