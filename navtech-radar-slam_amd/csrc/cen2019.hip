@@ -104,67 +104,110 @@ __device__ __forceinline__ unsigned long long kmean_of(float mh) { return (unsig
 // pixels, a wave agrees on its maximum D, and only the pixels that reach D (a handful per wave) form their float g -- with the
 // same two correctly rounded divisions and the same subtraction the byte -> float table of the other passes holds.  Before:
 // a 256-entry division table per block (and its barrier) and two LDS look-ups, a subtraction and a maximum for EVERY pixel.
+// Round 6: the bytes stay packed.  Four pixels a dword: the byte sum is one v_sad_u8 per dword; the absolute differences
+// |b(p+1) - b(p-1)| are formed on the even and the odd bytes of the dword as two 16-bit lanes each (v_pk_max / v_pk_min /
+// v_pk_sub_u16 on the stream shifted one byte left and right, v_alignbyte) and folded into ONE packed running maximum per
+// thread over all rows of the block; the rules at the ends of a row (reflect 101: the first and the last pixel have d = 0;
+// nothing past the row) are six row-independent masks per thread, so there is no second code path for the edge wavefronts.
+// The block agrees on its integer maximum D ONCE (not a wavefront per row), and only a thread that reached D goes back to
+// its words -- kept in registers, 4 per row -- to form the float g of the pixels with d = D.  (Round 4 evaluated its
+// "handful of lanes" branch in every wavefront and row, since some lane always reaches its own wave's maximum: two
+// correctly rounded divisions under an exec mask, 8 pixels deep, for each of the 86 M pixels' wavefronts.)
 constexpr int ST_ROWS = 8;  // azimuths per block of cen_stats / cen_collect in a batch (a single scan keeps one per block: 400 blocks fill the chip, 50 would not)
-template <int C, int NT>
+typedef unsigned short cen_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_absdiff_u16(unsigned a, unsigned b) {
+  const cen_u16x2 x = __builtin_bit_cast(cen_u16x2, a), y = __builtin_bit_cast(cen_u16x2, b);
+  return __builtin_bit_cast(unsigned, (cen_u16x2)(__builtin_elementwise_max(x, y) - __builtin_elementwise_min(x, y)));
+}
+__device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(cen_u16x2, a), __builtin_bit_cast(cen_u16x2, b)));
+}
+template <int C, int NT, int NR>  // NR = rows of a block (ST_ROWS in a batch, 1 for a single scan): the block keeps their words in registers
 __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
-                                                int off, Scal *scal, int rpb) {
+                                                int off, Scal *scal) {
   static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
-  constexpr int NWD = C / 4 + 2;
+  constexpr int ND = C / 4, NWD = ND + 2, rpb = NR;
   __shared__ unsigned s_sum[NT / 64];
   __shared__ float s_max[NT / 64];
+  __shared__ int s_d[NT / 64];
   Scal *sc = scal + blockIdx.y;
   const int p0 = threadIdx.x * C;
+  // which bytes count: in the sum, pixels inside the row; in the maximum, pixels 1 .. cols - 2 (even bytes of dword k in
+  // emask[k], odd bytes in omask[k], as 16-bit lanes)
+  unsigned smask[ND], emask[ND], omask[ND];
+#pragma unroll
+  for (int k = 0; k < ND; k++) {
+    smask[k] = emask[k] = omask[k] = 0u;
+#pragma unroll
+    for (int bb = 0; bb < 4; bb++) {
+      const int p = p0 + 4 * k + bb;
+      if (p < cols) smask[k] |= 0xffu << (8 * bb);
+      if (p >= 1 && p <= cols - 2) ((bb & 1) ? omask[k] : emask[k]) |= 0xffffu << (16 * (bb >> 1));
+    }
+  }
   unsigned sb = 0;  // <= ST_ROWS * C * 255 per thread, a wave's sum stays far below 2^32
-  float mg = 0.0f;
+  unsigned pmax = 0;  // two 16-bit running maxima
+  unsigned kw[NR][NWD], kmis[NR];
+  // the stream of a row realigned to the thread's first pixel: V[0] = pixels p0 - 4 .. p0 - 1, V[1 + k] = dword k, V[ND + 1] = the pixels behind
+  auto realign = [&](const unsigned (&w)[NWD], unsigned mis, unsigned (&V)[ND + 2]) {
+#pragma unroll
+    for (int k = 0; k < ND + 1; k++) V[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], mis);
+    V[ND + 1] = __builtin_amdgcn_alignbyte(0u, w[ND + 1], mis);
+  };
   // rpb azimuths per block: a row is 3360 bytes, a block per row was mostly block start-up
-  for (int rr = 0; rr < rpb; rr++) {
+#pragma unroll
+  for (int rr = 0; rr < NR; rr++) {
     const int a = blockIdx.x * rpb + rr;
-    if (a >= rows) break;  // (uniform)
-    const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
-    unsigned w[NWD];
+    unsigned(&w)[NWD] = kw[rr];
 #pragma unroll
     for (int j = 0; j < NWD; j++) w[j] = 0u;
+    kmis[rr] = 0u;
+    if (a >= rows) continue;  // (uniform; the words stay zero: no d, no sum)
+    const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
     const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
     const unsigned mis = (unsigned)(addr & 3u);
     const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
+    kmis[rr] = mis;
     if (p0 < cols) {
       if (p0 > 0) w[0] = wp[-1];
 #pragma unroll
       for (int j = 0; j < NWD - 1; j++)
         if (p0 + 4 * j - (int)mis < cols) w[1 + j] = wp[j];
     }
-    unsigned bt[C + 2];
+    unsigned V[ND + 2];
+    realign(w, mis, V);
 #pragma unroll
-    for (int i = -1; i <= C; i++) {
-      const int jw = (i + 4) >> 2;
-      const unsigned v = __builtin_amdgcn_alignbyte(w[jw + 1 < NWD ? jw + 1 : NWD - 1], w[jw], mis);
-      bt[i + 1] = (v >> (8 * ((i + 4) & 3))) & 0xffu;
+    for (int k = 0; k < ND; k++) {
+      const unsigned X = V[1 + k];
+      const unsigned L = __builtin_amdgcn_alignbyte(X, V[k], 3);      // pixels p - 1 of the dword's four
+      const unsigned R = __builtin_amdgcn_alignbyte(V[2 + k], X, 1);  // pixels p + 1
+      sb = __builtin_amdgcn_sad_u8(X & smask[k], 0u, sb);
+      const unsigned de = pk_absdiff_u16(L & 0x00ff00ffu, R & 0x00ff00ffu), dodd = pk_absdiff_u16((L >> 8) & 0x00ff00ffu, (R >> 8) & 0x00ff00ffu);
+      pmax = pk_max_u16(pmax, de & emask[k]);
+      pmax = pk_max_u16(pmax, dodd & omask[k]);
     }
-    int dmax = -1;
-    int dd[C];
+  }
+  const int dmax = (int)((pmax & 0xffffu) > (pmax >> 16) ? (pmax & 0xffffu) : (pmax >> 16));
+  const int dwv = wave_max_i32(dmax);
+  if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = dwv;
+  __syncthreads();
+  int D = 0;
 #pragma unroll
-    for (int i = 0; i < C; i++) {
-      const int p = p0 + i;
-      dd[i] = -1;
-      if (p < cols) {
-        sb += bt[i + 1];
-        if (cols > 1) {
-          const int bp = (int)((p + 1 < cols) ? bt[i + 2] : bt[i]), bm = (int)((p >= 1) ? bt[i] : bt[i + 2]);  // reflect 101
-          const int d = bp > bm ? bp - bm : bm - bp;
-          dd[i] = d;
-          dmax = d > dmax ? d : dmax;
-        }
-      }
-    }
-    const int dw = wave_max_i32(dmax);
-    if (dw >= 0 && dmax == dw) {  // (rare lanes)
+  for (int wv = 0; wv < NT / 64; wv++) D = s_d[wv] > D ? s_d[wv] : D;
+  float mg = 0.0f;
+  if (D > 0 && dmax == D) {  // (a thread or two per block; D = 0: every gradient of the block is exactly 0)
+#pragma unroll
+    for (int rr = 0; rr < NR; rr++) {
+      unsigned V[ND + 2];
+      realign(kw[rr], kmis[rr], V);
 #pragma unroll
       for (int i = 0; i < C; i++) {
-        if (dd[i] == dw) {
-          const int p = p0 + i;
-          const unsigned bp = (p + 1 < cols) ? bt[i + 2] : bt[i], bm = (p >= 1) ? bt[i] : bt[i + 2];
+        const int p = p0 + i;
+        const unsigned bm = (i == 0) ? (V[0] >> 24) : ((V[1 + ((i - 1) >> 2)] >> (8 * ((i - 1) & 3))) & 0xffu);
+        const unsigned bp = (V[1 + ((i + 1) >> 2)] >> (8 * ((i + 1) & 3))) & 0xffu;
+        const int d = bp > bm ? (int)(bp - bm) : (int)(bm - bp);
+        if (p >= 1 && p <= cols - 2 && d == D)
           mg = fmaxf(mg, fabsf(__fsub_rn(__fdiv_rn((float)bp, 255.0f), __fdiv_rn((float)bm, 255.0f))));
-        }
       }
     }
   }
@@ -1084,8 +1127,11 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   Scal *sc = h->scal.as<Scal>();
   const dim3 grid((unsigned)rows, (unsigned)nb);
   const int rpb = (int64_t)rows * nb >= 8192 ? ST_ROWS : 1;
-  hipLaunchKernelGGL((cen_stats<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
-                     stride, off, sc, rpb);
+  if (rpb > 1)
+    hipLaunchKernelGGL((cen_stats<C, NT, ST_ROWS>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows,
+                       cols, stride, off, sc);
+  else
+    hipLaunchKernelGGL((cen_stats<C, NT, 1>), dim3((unsigned)rows, (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
   hipLaunchKernelGGL(cen_scalars, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, sc, nb, (int64_t)rows * cols);
   const int hrpb = rpb > 1 ? HIST_ROWS : 1;
   hipLaunchKernelGGL((cen_hist<C, NT>), dim3((unsigned)((rows + hrpb - 1) / hrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
