@@ -1055,7 +1055,7 @@ def layout_emulation_leg(device, db_descs, q_descs, n_elig, k, res=None, reps=5)
 def host_entry_leg(mgr, q_descs, n_elig, k, resident_ms, reps=20):
     """the same batch through the synchronous HOST-buffer entry (rsx_sc_query): host queries in
     (nq x 4800 B over PCIe), host records out (nq x k x 16 B), upload and download inside the time.  The call cuts the batch
-    into pieces and uploads piece c + 1 while piece c is scored (sc_api.cpp host_pieces); timed from pageable memory (what a
+    into pieces and uploads piece c + 1 while piece c is filtered (sc_api.cpp host_pieces); timed from pageable memory (what a
     caller with a plain malloc'd buffer gets) and from page-locked memory (rsx_host_alloc_pinned)."""
     from importlib import import_module
     _rsx = import_module("navtech-radar-slam_amd._rsx")
@@ -1080,8 +1080,9 @@ def host_entry_leg(mgr, q_descs, n_elig, k, resident_ms, reps=20):
             "vs_resident": resident_ms / (dt_pageable * 1e3), "pinned_vs_resident": resident_ms / (dt_pinned * 1e3),
             "pinned_identical_to_pageable": same,
             "h2d_bytes": int(q_descs.nbytes), "d2h_bytes": nq * k * 16,
-            "note": "rsx_sc_query: H2D of the queries in pieces, each scored (filter/select/re-score) while the next one goes up, + D2H "
-                    "of the records; one synchronous call.  vs_resident = the headline's ms_per_step (queries already in HBM) / this"}
+            "note": "rsx_sc_query: H2D of the queries in pieces, each FILTERED while the next one goes up, short lists / window previews / "
+                    "re-scoring once over the whole batch, + D2H of the records; one synchronous call.  vs_resident = the headline's "
+                    "ms_per_step (queries already in HBM) / this"}
 
 
 def roofline_of(wl, launches, kern_ms, n_elig):
