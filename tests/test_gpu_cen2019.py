@@ -108,3 +108,29 @@ def test_wide_rows(cen, oracle):
     for mp in (25, 10000):
         assert np.array_equal(ex.extract(img, col_offset=0, max_points=mp, min_range=3),
                               oracle.cen2019_extract(img, col_offset=0, max_points=mp, min_range=3)), mp
+
+
+def test_large_batch_of_an_odd_shape(cen, oracle):
+    """Batches of rows x images >= 8192 take the several-azimuths-per-block forms of the row kernels (8 per block in cen_stats /
+    cen_collect, 4 in cen_hist, 2 in cen_runs).  53 azimuths (not a multiple of 8, 4 or 2: the last block of every kernel runs
+    past the image), 1003 range bins (the last thread of a row holds 3 pixels, the row base is misaligned differently in every
+    row), 160 images, two of them constant: every image bit-identical to the oracle."""
+    rng = np.random.default_rng(31)
+    rows, cols, nb = 53, 1003, 160
+    imgs = rng.gamma(2.0, 14.0, size=(nb, rows, cols)).clip(0, 255).astype(np.uint8)
+    for b in range(nb):
+        for _ in range(30):
+            a, r = int(rng.integers(0, rows)), int(rng.integers(3, cols - 6))
+            imgs[b, a, r:r + 3] = rng.integers(140, 255, 3)
+            imgs[b, (a + 1) % rows, r:r + 3] = rng.integers(140, 255, 3)
+    imgs[7] = 33
+    imgs[100] = 255
+    imgs[5, :, 0] = 255          # the largest gradient next to the first pixel of every row
+    imgs[6, :, cols - 1] = 255   # ... and at the last one (both have d = 0 there by the reflect rule)
+    ex = cen.Cen2019(rows, cols)
+    assert rows * nb >= 8192
+    for mp in (10000, 40):
+        tg = ex.extract_batch(imgs, col_offset=0, max_points=mp, min_range=2)
+        for b in range(nb):
+            want = oracle.cen2019_extract(imgs[b], col_offset=0, max_points=mp, min_range=2)
+            assert np.array_equal(tg[b], want), (mp, b, len(tg[b]), len(want))
