@@ -46,6 +46,15 @@ class Frontend:
         check(self._L.rsx_frontend_cartesian_batch_device_az(self._h, d_imgs, n, image_stride, row_stride, col_offset, d_az, az_stride,
                                                              float(resolution), stream))
 
+    def describe_batch_device(self, d_xy, d_counts, n_images, max_targets, d_desc, d_valid, stream=None):
+        """descriptors of the keypoints of every image of the last cartesian_batch_device call (device addresses; asynchronous)"""
+        check(self._L.rsx_frontend_describe_batch_device(self._h, d_xy, d_counts, n_images, max_targets, d_desc, d_valid, stream))
+
+    def match_consecutive_device(self, d_desc, d_valid, d_counts, max_targets, first_slot, n_pairs, ratio, d_fwd, d_bwd, stream=None):
+        """knnMatch(2) + ratio between consecutive keypoint sets, both directions (device addresses; asynchronous)"""
+        check(self._L.rsx_frontend_match_consecutive_device(self._h, d_desc, d_valid, d_counts, max_targets, first_slot, n_pairs,
+                                                            float(ratio), d_fwd, d_bwd, stream))
+
     def read_images(self, image=0):
         """(Cartesian image, smoothed copy) of slot `image` of the last cartesian call (rsx_diag.h parity helper)."""
         cart = np.empty((self.W, self.W), dtype=np.float32)

@@ -129,3 +129,61 @@ def test_strip_kernel_equals_the_three_kernel_form_on_unusual_grids_and_shapes(f
                 for a, b in zip(out[flags][k], out[1][k]):
                     assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (rows, cols, W, k, flags)
         assert np.isfinite(out[0][0][0]).all() and out[0][0][0].max() > 0
+
+
+def test_batched_describe_and_consecutive_matching_equal_the_oracle(fe, oracle):
+    """The device-resident forms the odometry pipeline chains (rsx_frontend_describe_batch_device: one wavefront per keypoint from
+    a table of the disc's pixels, lane sums by DPP, 128 blocks per image; rsx_frontend_match_consecutive_device: compacted valid
+    lists, four lanes per query, packed (distance, index) minima): 6 images with 0 / 1 / 3 / 900 / 2100 / 2100 keypoints in slots
+    of 2304, many of them in or beyond the image border, descriptors and validity byte for byte, every consecutive pair's matches in
+    both directions against oracle.match on the same descriptors (incl. pairs with an empty side)."""
+    import torch
+    rows, cols, W, res = 400, 3360, 964, 0.2592
+    n, K = 6, 2304
+    counts = np.array([0, 1, 3, 900, 2100, 2100], dtype=np.int32)
+    rng = np.random.default_rng(77)
+    imgs, azs, xys = [], [], np.zeros((n, K, 2), dtype=np.float32)
+    for k in range(n):
+        img, az, centres = synth.polar_image(40 + (k % 3), n_targets=900, noise_seed=60 + k)     # images 3.. share scenes with 0..2
+        imgs.append(img)
+        azs.append(az)
+        a, r = centres[:, 0], centres[:, 1]
+        rr = (r + 0.5) * synth.RADAR_RESOLUTION
+        pts = np.stack([rr * np.cos(az[a]), rr * np.sin(az[a])], axis=1).astype(np.float32)
+        pts = np.concatenate([pts, rng.uniform(-135, 135, (K, 2)).astype(np.float32)])[:K]
+        xys[k] = pts
+    batch = np.ascontiguousarray(np.stack(imgs))
+    d_img, d_az = torch.from_numpy(batch).cuda(), torch.from_numpy(np.ascontiguousarray(np.stack(azs))).cuda()
+    d_xy, d_cnt = torch.from_numpy(xys).cuda(), torch.from_numpy(counts).cuda()
+    d_desc = torch.zeros((n, K, 32), dtype=torch.uint8, device="cuda")
+    d_valid = torch.zeros((n, K), dtype=torch.uint8, device="cuda")
+    d_fwd = torch.full((n - 1, K), -7, dtype=torch.int32, device="cuda")
+    d_bwd = torch.full((n - 1, K), -7, dtype=torch.int32, device="cuda")
+    p = fe.default_params()
+    p.cart_pixel_width, p.cart_resolution = W, res
+    g = fe.Frontend(rows, cols, params=p)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        g.cartesian_batch_device(d_img.data_ptr(), n, batch.shape[1] * batch.shape[2], batch.shape[2], d_az.data_ptr(), rows,
+                                 synth.RADAR_RESOLUTION, stream=s.cuda_stream)
+        g.describe_batch_device(d_xy.data_ptr(), d_cnt.data_ptr(), n, K, d_desc.data_ptr(), d_valid.data_ptr(), stream=s.cuda_stream)
+        g.match_consecutive_device(d_desc.data_ptr(), d_valid.data_ptr(), d_cnt.data_ptr(), K, 0, n - 1, 0.8, d_fwd.data_ptr(),
+                                   d_bwd.data_ptr(), stream=s.cuda_stream)
+    s.synchronize()
+    desc, valid, fwd, bwd = d_desc.cpu().numpy(), d_valid.cpu().numpy(), d_fwd.cpu().numpy(), d_bwd.cpu().numpy()
+    want = []
+    for k in range(n):
+        o = oracle.FrontendRef(rows, cols, W, res)
+        o.cartesian(imgs[k], azs[k], synth.RADAR_RESOLUTION)
+        do, vo = o.describe(xys[k, :counts[k]])
+        assert np.array_equal(valid[k, :counts[k]], vo) and np.array_equal(desc[k, :counts[k]], do), k
+        want.append((do, vo, o))
+    assert 0 < want[4][1].sum() < counts[4]
+    for j in range(n - 1):
+        (qa, va, o), (qb, vb, _) = want[j], want[j + 1]
+        f_idx, _, _ = o.match(qa, va, qb, vb, 0.8)
+        b_idx, _, _ = o.match(qb, vb, qa, va, 0.8)
+        assert np.array_equal(fwd[j, :counts[j]], f_idx), j
+        assert np.array_equal(bwd[j, :counts[j + 1]], b_idx), j
+    assert (fwd[4, :counts[4]] >= 0).sum() > 20           # the same scene under another noise realisation is recognised
+    g.close()
