@@ -88,10 +88,10 @@ typedef struct {
   int32_t shard_rank;         /* default 0 */
   int32_t shard_world;        /* default 1 */
   int64_t capacity_hint;      /* initial DB capacity in entries (grows by doubling) */
-  /* exhaustive queries: 0 = auto (up to 8 queries per call -- the live detector asks one, PGO.cpp:561,577 -- take the
+  /* exhaustive queries: 0 = auto (up to 16 queries per call -- the live detector asks one, PGO.cpp:561,577 -- take the
    * one-launch single-query path, sc_q1.hip; batched queries go through the MFMA lower-bound filter and only
    * the entries that can still reach the top-k are scored by the exact fp64 kernel), 1 = always
-   * score every entry exactly, 2 = always the batched filter chain, 3 = the single-query path wherever it applies (<= 8
+   * score every entry exactly, 2 = always the batched filter chain, 3 = the single-query path wherever it applies (<= 16
    * queries per call; auto otherwise).  Results are identical in every mode. */
   int32_t filter_mode;
   /* which form of the filter: 0 = default (3: spectral, two waves per SIMD), 1 = direct (60-shift correlation as one K = 1200

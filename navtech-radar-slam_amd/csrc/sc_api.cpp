@@ -437,7 +437,8 @@ bool use_q1(const rsx_sc *h, int32_t nq, int64_t n_items) {
   // pass of the spectral filter for all of them) takes over.  Round 6 (the queries of a call share the device's 512 workgroup
   // slots, q1_grid): MI355X, top-1, us per call single-query path / filter chain -- 10 000 keyframes: 1 query 18 / 91, 2: 22 / 94,
   // 4: 27 / 94, 8: 36 / 89; 100 000: 1 query 54 / 173, 2: 71 / 175, 4: 112 / 176, 8: 187 / 191 (round 5: 8 x 10 000 55, 8 x 100 000 305)
-  return m == 3 || nq == 1 || (int64_t)nq * n_items <= 800000;
+  // 9 .. 16 queries (32 workgroups each): 10 000 keyframes 12 queries 47 / 92, 16: 53 / 87; 50 000: 8 queries 103 / 127, 12: 167 / 134, 16: 176 / 147
+  return m == 3 || nq == 1 || (int64_t)nq * n_items <= (nq <= 8 ? 800000 : 400000);
 }
 
 int run_q1(rsx_sc *h, const float *d_q, int32_t nq, int64_t n_items, int64_t n_eligible, const int64_t *d_q_elig, int32_t k,

@@ -221,7 +221,7 @@ const char *window_kernel_name();
 // exclude exactly, all inside one launch; records identical to launch_pairs / the filtered path.
 // ws: q1_workspace_bytes() of device memory; d_ticket: q1_ticket_bytes() of arrival counters, zero before the first launch
 // (every launch leaves them zero again) and touched by nothing else
-constexpr int Q1_MAX_NQ = 8;
+constexpr int Q1_MAX_NQ = 16;
 int q1_grid(int64_t n_items, int32_t k, int32_t nq);
 size_t q1_workspace_bytes(int64_t n_items, int32_t nq, int32_t k);
 size_t q1_ticket_bytes();

@@ -36,7 +36,7 @@ def queries_of(descs, nq, seed):
 
 @pytest.mark.parametrize("binary", [True, False])
 @pytest.mark.parametrize("k", [1, 10, 32])
-@pytest.mark.parametrize("nq", [1, 3, 8])
+@pytest.mark.parametrize("nq", [1, 3, 8, 16])
 def test_q1_matches_oracle(sc, oracle, binary, k, nq):
     n = 2500 + 5
     descs = make_db(7 + binary, n, binary)

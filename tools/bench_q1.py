@@ -49,7 +49,7 @@ for n in [int(x) for x in args.sizes.split(",")]:
                 reps = args.reps if name != "exact_all" or n <= 10000 else max(10, args.reps // 10)
                 out = torch.zeros((64, k, 2), dtype=torch.float64, device="cuda")
                 for i in range(8):
-                    h.query_device(d_q[(i * nq) % (64 - nq):].data_ptr(), nq, k, out.data_ptr(), n_eligible=n_elig, stream=st)
+                    h.query_device(d_q[(i * nq) % max(1, 64 - nq):].data_ptr(), nq, k, out.data_ptr(), n_eligible=n_elig, stream=st)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for i in range(reps):
