@@ -73,6 +73,24 @@ SPEC_FLOP_PER_PAIR = 2 * (9280 + 960 + 3600)  # (the mask correlation is skipped
 # ----------------------------------------------------------------------------------------------
 # launcher
 # ----------------------------------------------------------------------------------------------
+
+def usable_cores():
+    """Host cores this process may actually use: the visible CPUs, cut by the affinity mask and by the cgroup's CPU quota (the GPU
+    boxes of this pool show 256 CPUs under a quota of 16: 256 threads there are throttled, not 16 times faster than 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -90,7 +108,7 @@ def spawn_ranks(n, dry_run):
             raise SystemExit(f"bench.py: --gpus {n} but only {have} GPU(s) visible; refusing to measure {have} GPU(s) {n} times")
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
-    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // n)))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cores() // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -278,7 +296,7 @@ def cpu_baseline_and_check(db_pts, db_off, q_descs, n_elig, k, gpu_hits, min_che
         because it does not allocate, is timed the same way (`port_value`) and its exhaustive top-k records are the
         checker: the first `nq` queries of the timed batch, GPU records vs oracle records."""
     from oracle import pyoracle as po
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     m = po.Manager()
     for i in range(len(db_off) - 1):          # the oracle builds its own descriptors from the same clouds
         m.add_points(db_pts[db_off[i]:db_off[i + 1]])
@@ -317,7 +335,8 @@ def cpu_baseline_and_check(db_pts, db_off, q_descs, n_elig, k, gpu_hits, min_che
                 "sample": f"{nr} queries of the timed batch x all {len(db)} eligible keyframes through the reference's own "
                           f"distanceBtnScanContext (oracle/_ref/libref_sc_sse2.so = Scancontext.cpp:116-148 compiled unmodified, "
                           f"{ref.build_info()}), OpenMP over (query, 64-entry block) on {cores} threads; 1 thread: {1.0 / r1:.2f} queries/s",
-                "one_thread_value": 1.0 / r1, "top1_equal_to_oracle": agree, "queries": nr,
+                "one_thread_value": 1.0 / r1, "top1_equal_to_oracle": agree, "queries": nr, "visible_cpus": os.cpu_count(),
+                "cores_note": "threads = the cores this process may use (affinity mask and cgroup CPU quota, usable_cores())",
                 "port_value": port["value"], "port_one_thread_value": one_thread_qps,
                 "port_note": f"oracle/sc_ref.c (the non-allocating restatement, bit-identical results): {nq} exhaustive top-{k} "
                              f"queries, OpenMP over queries"}
@@ -400,7 +419,7 @@ def orora_leg(device, skip_cpu):
                 "fp64-VALU + latency bound, no HBM roofline applies"}
     if not skip_cpu:
         from oracle import pyoracle as po
-        cores = os.cpu_count() or 1
+        cores = usable_cores()
         t0 = time.perf_counter()
         want = po.orora_register_batch(src, dst, off, nthreads=cores)
         cdt = time.perf_counter() - t0
@@ -579,7 +598,7 @@ def slam_stream_leg(device, db_pts, db_off, n_kf=3000, every=4):
     exh.close()
     # the oracle on the same stream (candidate mode; exhaustive = scan of the same frozen prefix)
     o = po.Manager(dist_thres=0.45)
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     j = 0
     same_c = same_e = 0
     counter, tree = 0, 0
@@ -1421,7 +1440,7 @@ def main():
                 for i in range(n_db):
                     om.add_points(c_pts[c_off[i]:c_off[i + 1]])
                 n_chk = 128
-                want = om.exhaustive_batch(c_all[n_db:n_db + n_chk].astype(np.float64), n_eligible=n_elig, k=k, nthreads=os.cpu_count() or 1)
+                want = om.exhaustive_batch(c_all[n_db:n_db + n_chk].astype(np.float64), n_eligible=n_elig, k=k, nthreads=usable_cores())
                 ident = int(sum(bool(np.array_equal(rc[i], want[i])) for i in range(n_chk)))
                 dd["trajectory_continuous_z"]["oracle_checked_queries"] = n_chk
                 dd["trajectory_continuous_z"]["oracle_identical_queries"] = ident

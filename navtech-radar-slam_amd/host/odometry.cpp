@@ -32,6 +32,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -43,6 +44,7 @@
 #include <thread>
 #include <vector>
 
+#include "png_gray8.h"
 #include "rosmsg.h"
 #include "rsx.h"
 
@@ -61,74 +63,26 @@ constexpr float kResolution = 0.0595f;  // Navtech CIR204-H range bin [m]
 
 [[noreturn]] void die(const std::string &m) { throw std::runtime_error(m); }
 
+// host cores this process may use: hardware threads, cut by the cgroup v2 CPU quota when there is one
+int usable_cores() {
+  int n = (int)std::max(1u, std::thread::hardware_concurrency());
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char quota[32] = {0};
+    long long period = 0;
+    if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0) {
+      const long long q = std::atoll(quota);
+      if (q > 0) n = (int)std::min<long long>(n, (q + period - 1) / period);
+    }
+    std::fclose(f);
+  }
+  return std::max(1, n);
+}
+
 void check(int status, const char *what) {
   if (status != RSX_OK) die(std::string(what) + ": rsx status " + std::to_string(status) + ": " + rsx_last_error_string());
 }
 
-uint32_t be32(const uint8_t *p) { return (uint32_t(p[0]) << 24) | (uint32_t(p[1]) << 16) | (uint32_t(p[2]) << 8) | p[3]; }
-
-// minimal PNG reader: 8-bit grayscale, non-interlaced (what MulRan's polar_oxford_form uses)
-std::vector<uint8_t> read_png_gray8(const std::string &path, int *width, int *height) {
-  FILE *f = std::fopen(path.c_str(), "rb");
-  if (!f) die("cannot open " + path);
-  std::vector<uint8_t> buf;
-  uint8_t tmp[65536];
-  size_t n;
-  while ((n = std::fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + n);
-  std::fclose(f);
-  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
-  if (buf.size() < 8 || std::memcmp(buf.data(), sig, 8) != 0) die(path + ": not a PNG");
-  size_t pos = 8;
-  int w = 0, h = 0;
-  std::vector<uint8_t> idat;
-  while (pos + 12 <= buf.size()) {
-    const uint32_t len = be32(&buf[pos]);
-    const char *type = reinterpret_cast<const char *>(&buf[pos + 4]);
-    if (pos + 12 + len > buf.size()) die(path + ": truncated chunk");
-    const uint8_t *data = &buf[pos + 8];
-    if (!std::memcmp(type, "IHDR", 4)) {
-      w = (int)be32(data);
-      h = (int)be32(data + 4);
-      if (data[8] != 8 || data[9] != 0 || data[12] != 0) die(path + ": only 8-bit grayscale non-interlaced PNG is supported");
-    } else if (!std::memcmp(type, "IDAT", 4)) {
-      idat.insert(idat.end(), data, data + len);
-    } else if (!std::memcmp(type, "IEND", 4)) {
-      break;
-    }
-    pos += 12 + len;
-  }
-  if (w <= 0 || h <= 0) die(path + ": no IHDR");
-  std::vector<uint8_t> raw((size_t)h * (w + 1));
-  uLongf out_len = raw.size();
-  if (uncompress(raw.data(), &out_len, idat.data(), idat.size()) != Z_OK || out_len != raw.size()) die(path + ": inflate failed");
-  std::vector<uint8_t> img((size_t)h * w);
-  for (int y = 0; y < h; y++) {  // undo the per-row filters (bpp = 1)
-    const uint8_t ft = raw[(size_t)y * (w + 1)];
-    const uint8_t *in = &raw[(size_t)y * (w + 1) + 1];
-    uint8_t *out = &img[(size_t)y * w];
-    const uint8_t *up = y ? &img[(size_t)(y - 1) * w] : nullptr;
-    for (int x = 0; x < w; x++) {
-      const int a = x ? out[x - 1] : 0, b = up ? up[x] : 0, c = (x && up) ? up[x - 1] : 0;
-      int pred = 0;
-      switch (ft) {
-        case 0: pred = 0; break;
-        case 1: pred = a; break;
-        case 2: pred = b; break;
-        case 3: pred = (a + b) >> 1; break;
-        case 4: {
-          const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-          pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-          break;
-        }
-        default: die(path + ": bad PNG filter");
-      }
-      out[x] = (uint8_t)(in[x] + pred);
-    }
-  }
-  *width = w;
-  *height = h;
-  return img;
-}
+using rsxhost::read_png_gray8;  // png_gray8.h
 
 struct Scan {
   int64_t stamp_ns = 0;
@@ -182,8 +136,8 @@ int main(int argc, char **argv) {
       else if (a == "--max_frames" && i + 1 < argc) max_frames = std::atoi(argv[++i]);
       else if (a == "--gate" && i + 1 < argc) gate = (float)std::atof(argv[++i]);
       else if (a == "--matcher" && i + 1 < argc) matcher = argv[++i];  // orb (default) | nn
-      else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);    // scans per rsx_odometry_push (default: the library's window)
-      else if (a == "--threads" && i + 1 < argc) threads = std::atoi(argv[++i]);  // PNG decode threads (default: hardware concurrency, <= 64)
+      else if (a == "--window" && i + 1 < argc) window = std::atoi(argv[++i]);    // scans per rsx_odometry_push (default: two of the library's windows)
+      else if (a == "--threads" && i + 1 < argc) threads = std::atoi(argv[++i]);  // PNG decode threads (default: twice the usable cores, <= 64)
       else if (a == "--no-pmc") use_pmc = false;                                   // skip the max-clique inlier selection before the solver
       else if (a == "--per-scan") per_scan = true;                                // the round-2 loop: one scan per call, host vectors in between
       else if (a == "--timing") timing = true;                                    // decode / pipeline seconds on stderr
@@ -302,8 +256,12 @@ int main(int argc, char **argv) {
       if (!use_pmc) op.orora.flags &= ~RSX_ORORA_PMC;
       rsx_odometry *odo = nullptr;
       check(rsx_odometry_create(&op, rows, cols, &odo), "rsx_odometry_create");
-      const int W = window > 0 ? std::min(window, 4096) : rsx_odometry_window();
-      const int T = threads > 0 ? threads : (int)std::max(1u, std::min(64u, std::thread::hardware_concurrency()));  // (256 threads: the launch thread starves, 1.9 k against 2.5 k scans/s)
+      // scans per rsx_odometry_push: two of the library's internal windows, so that inside a call the upload and the extraction of
+      // the second overlap the matching of the first (the pinned buffers are 2 x W images)
+      const int W = window > 0 ? std::min(window, 4096) : 2 * rsx_odometry_window();
+      // decode threads: twice the cores this process may use -- the visible CPUs cut by the cgroup's CPU quota (a container
+      // that shows 256 CPUs under a quota of 16 throttles 64 busy threads: 2.1-2.6 k scans/s where 32 threads reach 3.6-3.8 k)
+      const int T = threads > 0 ? threads : std::max(1, std::min(64, 2 * usable_cores()));
       const size_t ibytes = (size_t)rows * w0;
       struct Win {
         uint8_t *img = nullptr;
@@ -319,44 +277,95 @@ int main(int argc, char **argv) {
         wn.az.resize((size_t)W * rows);
         wn.stamp.resize((size_t)W);
       }
+      // the decode pool: T threads for the whole sequence (round 6; rounds 3-5 started a window's threads anew, 63 thread
+      // starts per window), every PNG inflated and unfiltered straight into its slot of the page-locked window
       std::string decode_error;
-      auto decode_window = [&](size_t f0, Win *wn) {
-        wn->n = (int)std::min((size_t)W, files.size() - f0);
+      struct Pool {
+        std::mutex mu;
+        std::condition_variable cv_job, cv_done;
+        std::vector<std::thread> threads;
+        size_t f0 = 0;
+        Win *wn = nullptr;
         std::atomic<int> next{0};
+        int generation = 0, busy = 0;
+        bool stop = false;
         std::atomic<long long> cpu_ns{0};
-        std::mutex err_mu;
-        auto work = [&]() {
+      } pool;
+      auto decode_one = [&](size_t f0, Win *wn, int i, rsxhost::PngScratch &scratch) {
+        const auto t0 = clk::now();
+        int w = 0, h = 0;
+        uint8_t *dst = wn->img + (size_t)i * ibytes;
+        rsxhost::read_png_gray8_into(dir + "/" + files[f0 + (size_t)i], dst, ibytes, &w, &h, scratch);
+        if (h != rows || w != w0) die(files[f0 + (size_t)i] + ": image shape changed");
+        int64_t st = 0;
+        std::memcpy(&st, dst, 8);  // little-endian int64 at bytes 0-7 of the first row
+        if (st <= 0) st = std::atoll(files[f0 + (size_t)i].c_str());
+        wn->stamp[(size_t)i] = st;
+        for (int a = 0; a < rows; a++) {
+          uint16_t cnt;
+          std::memcpy(&cnt, dst + (size_t)a * w + 8, 2);
+          wn->az[(size_t)i * rows + a] = (float)((double)cnt * 2.0 * M_PI / 5600.0);
+        }
+        pool.cpu_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count();
+      };
+      auto worker = [&]() {
+        rsxhost::PngScratch scratch;
+        int seen = 0;
+        for (;;) {
+          size_t f0;
+          Win *wn;
+          {
+            std::unique_lock<std::mutex> lk(pool.mu);
+            pool.cv_job.wait(lk, [&] { return pool.stop || pool.generation != seen; });
+            if (pool.stop) return;
+            seen = pool.generation;
+            f0 = pool.f0;
+            wn = pool.wn;
+          }
           for (;;) {
-            const int i = next.fetch_add(1);
-            if (i >= wn->n) return;
+            const int i = pool.next.fetch_add(1);
+            if (i >= wn->n) break;
             try {
-              const auto t0 = clk::now();
-              int w = 0, h = 0;
-              const std::vector<uint8_t> img = read_png_gray8(dir + "/" + files[f0 + (size_t)i], &w, &h);
-              if (h != rows || w != w0) die(files[f0 + (size_t)i] + ": image shape changed");
-              std::memcpy(wn->img + (size_t)i * ibytes, img.data(), ibytes);
-              int64_t st = 0;
-              std::memcpy(&st, &img[0], 8);  // little-endian int64 at bytes 0-7 of the first row
-              if (st <= 0) st = std::atoll(files[f0 + (size_t)i].c_str());
-              wn->stamp[(size_t)i] = st;
-              for (int a = 0; a < rows; a++) {
-                uint16_t cnt;
-                std::memcpy(&cnt, &img[(size_t)a * w + 8], 2);
-                wn->az[(size_t)i * rows + a] = (float)((double)cnt * 2.0 * M_PI / 5600.0);
-              }
-              cpu_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(clk::now() - t0).count();
+              decode_one(f0, wn, i, scratch);
             } catch (const std::exception &e) {
-              std::lock_guard<std::mutex> lk(err_mu);
+              std::lock_guard<std::mutex> lk(pool.mu);
               if (decode_error.empty()) decode_error = e.what();
             }
           }
-        };
-        std::vector<std::thread> pool;
-        const int nt = std::min(T, wn->n);
-        for (int t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (std::thread &t : pool) t.join();
-        wn->decode_cpu_s = 1e-9 * (double)cpu_ns.load();
+          {
+            std::lock_guard<std::mutex> lk(pool.mu);
+            if (--pool.busy == 0) pool.cv_done.notify_all();
+          }
+        }
+      };
+      for (int t = 0; t < T; t++) pool.threads.emplace_back(worker);
+      struct PoolStop {  // (also when something below throws)
+        Pool &p;
+        ~PoolStop() {
+          {
+            std::lock_guard<std::mutex> lk(p.mu);
+            p.stop = true;
+          }
+          p.cv_job.notify_all();
+          for (std::thread &t : p.threads) t.join();
+        }
+      } pool_stop{pool};
+      // hands window [f0, f0 + W) to the pool and returns; wait_window() blocks until it is decoded
+      auto start_window = [&](size_t f0, Win *wn) {
+        wn->n = (int)std::min((size_t)W, files.size() - f0);
+        std::lock_guard<std::mutex> lk(pool.mu);
+        pool.f0 = f0;
+        pool.wn = wn;
+        pool.next.store(0);
+        pool.cpu_ns.store(0);
+        pool.busy = T;
+        pool.generation++;
+        pool.cv_job.notify_all();
+      };
+      auto wait_window = [&](Win *wn) {
+        std::unique_lock<std::mutex> lk(pool.mu);
+        pool.cv_done.wait(lk, [&] { return pool.busy == 0; });
+        wn->decode_cpu_s = 1e-9 * (double)pool.cpu_ns.load();
       };
 #ifdef RSX_WITH_ROS
       const bool want_xy = true;
@@ -368,15 +377,15 @@ int main(int argc, char **argv) {
       std::vector<rsx_odometry_scan> res((size_t)W);
       double decode_cpu = 0, decode_wait = 0, push_s = 0;
       const auto t_all = clk::now();
-      std::future<void> fut = std::async(std::launch::async, decode_window, (size_t)0, &wins[0]);
+      start_window(0, &wins[0]);
       size_t fi = 0;
       for (size_t f0 = 0, wi = 0; f0 < files.size(); f0 += (size_t)W, wi++) {
         const auto tw = clk::now();
-        fut.get();
+        Win &wn = wins[wi & 1];
+        wait_window(&wn);
         decode_wait += std::chrono::duration<double>(clk::now() - tw).count();
         if (!decode_error.empty()) die(decode_error);
-        Win &wn = wins[wi & 1];
-        if (f0 + (size_t)W < files.size()) fut = std::async(std::launch::async, decode_window, f0 + (size_t)W, &wins[(wi + 1) & 1]);
+        if (f0 + (size_t)W < files.size()) start_window(f0 + (size_t)W, &wins[(wi + 1) & 1]);
         decode_cpu += wn.decode_cpu_s;
         const auto tp = clk::now();
         check(rsx_odometry_push(odo, wn.img, wn.n, (int64_t)ibytes, w0, wn.az.data(), 1, res.data(), want_xy ? xy.data() : nullptr, max_xy),
