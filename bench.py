@@ -1581,6 +1581,9 @@ def main():
             sec["cen2019_batched_device_scans_per_sec"] = out["cen2019"]["batched_device_scans_per_sec"]
         if "odometry_e2e" in out:
             sec["odometry_scans_per_sec_resident"] = out["odometry_e2e"].get("scans_per_sec_resident")
+            fe_ = out["odometry_e2e"].get("file_entry")
+            if isinstance(fe_, dict) and "total_scans_per_sec" in fe_:
+                sec["odometry_png_files_scans_per_sec"] = fe_["total_scans_per_sec"]   # host/odometry incl. the PNG inflate
         if "latency_q1" in out:
             sec["single_query_us"] = {nm: v.get("us_per_query_stream") for nm, v in out["latency_q1"].items() if isinstance(v, dict) and "us_per_query_stream" in v}
         if "host_entry" in out:
