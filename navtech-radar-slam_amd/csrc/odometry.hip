@@ -93,15 +93,19 @@ __global__ __launch_bounds__(256) void odo_gather(const float2 *__restrict__ sta
 
 }  // namespace
 
-// Round 6: TWO windows in flight.  A window is two stages: EXTRACTION (cen2019, Cartesian images, descriptors: the wide
+// Round 6: several windows in flight.  A window is two stages: EXTRACTION (cen2019, Cartesian images, descriptors: the wide
 // kernels, independent of every other window) and MATCHING (consecutive matches, cross check, max-clique selection, solver:
 // a chain of small grids -- one or two workgroups per pair -- that leaves most of the device idle, and the only stage that
-// needs the previous window).  They run on two streams: while window g is matched, window g + 1 is extracted.  What the two
-// stages hand over -- keypoints, descriptors, counts, slots 0 .. n of a SET -- exists twice (window g works in set g & 1);
-// the extraction stage ends by copying its last scan into slot 0 of the OTHER set ("the previous scan" of window g + 1).
-//   extraction stream:  E(g):   [wait M(g-2)]  cen2019, Cartesian, describe -> set g&1   [wait M(g-1)]  carry -> set (g+1)&1 slot 0
-//   matching stream:    M(g):   [wait E(g)]    match, cross, gather, select + solve -> pinned results g&1
-// The host enqueues M(g), then E(g + 1), and only then waits for M(g).
+// needs the previous window).  While window g is matched, windows g + 1 AND g + 2 are extracted, on two extraction LANES (a
+// stream, a cen2019 handle and a front-end handle each; window g takes lane g & 1): the extraction chain has its own narrow
+// launches (the selection kernels of cen2019: one workgroup per image) that a second chain fills -- two independent handles
+// on one device reach 66.7 k scans/s where one with a single lane reaches 59.3 k.  What the stages hand over -- keypoints,
+// descriptors, counts, slots 0 .. n of a SET -- exists three times (window g works in set g % 3); the extraction stage ends
+// by copying its last scan into slot 0 of the NEXT set ("the previous scan" of window g + 1).
+//   lane g & 1:        E(g):   [wait M(g-3)]  cen2019, Cartesian, describe -> set g%3   [wait M(g-2)]  carry -> set (g+1)%3 slot 0
+//   matching stream:   M(g):   [wait E(g), E(g-1)]  match, cross, gather, select + solve -> pinned results g%3
+// The host enqueues M(g), then E(g + 2), and only then waits for M(g).
+constexpr int N_SETS = 3, N_LANES = 2;
 struct OdoSet {
   rsx::DevBuf az, targets, xy, counts, desc, valid;  // slot 0 = the previous scan, slots 1 .. MAX_WINDOW = the window
   void *pin = nullptr;  // pinned: counts[MAX_WINDOW + 1], pair_cnt[MAX_WINDOW], results[MAX_WINDOW], then the staged azimuth grids
@@ -111,14 +115,14 @@ struct rsx_odometry {
   int device = 0, rows = 0, cols = 0;
   rsx_odometry_params prm{};
   std::mutex mu;
-  hipStream_t stream = nullptr, match_stream = nullptr, copy_stream = nullptr;
-  hipEvent_t ev_up = nullptr, ev_e[2] = {nullptr, nullptr}, ev_m[2] = {nullptr, nullptr};
-  rsx_cen2019 *cen = nullptr;
-  rsx_frontend *fe = nullptr;
+  hipStream_t lane_stream[N_LANES] = {}, match_stream = nullptr, copy_stream = nullptr;
+  hipEvent_t ev_up = nullptr, ev_e[N_SETS] = {}, ev_m[N_SETS] = {};
+  rsx_cen2019 *cen[N_LANES] = {};
+  rsx_frontend *fe[N_LANES] = {};
   rsx_orora *reg = nullptr;
-  OdoSet set[2];
-  rsx::DevBuf imgs, imgs2, fwd, bwd, stage_src, stage_dst, pair_cnt, src, dst, offsets, results;
-  uint64_t windows = 0;  // windows enqueued since creation: window g works in set[g & 1]
+  OdoSet set[N_SETS];
+  rsx::DevBuf imgs[N_SETS], fwd, bwd, stage_src, stage_dst, pair_cnt, src, dst, offsets, results;
+  uint64_t windows = 0;  // windows enqueued since creation: window g works in set[g % N_SETS] on lane g & 1
   bool have_prev = false;
 };
 
@@ -132,7 +136,7 @@ size_t pin_bytes(const rsx_odometry *h) { return PIN_AZ + (size_t)h->rows * 4 * 
 
 int reserve_all(rsx_odometry *h, size_t ibytes, hipStream_t s) {
   const size_t K = (size_t)h->prm.max_keypoints, S = MAX_WINDOW + 1;
-  RSX_TRY(h->imgs.reserve(ibytes * MAX_WINDOW, s, false));
+  for (rsx::DevBuf &b : h->imgs) RSX_TRY(b.reserve(ibytes * MAX_WINDOW, s, false));
   for (OdoSet &q : h->set) {
     RSX_TRY(q.az.reserve((size_t)h->rows * 4 * MAX_WINDOW, s, false));
     RSX_TRY(q.targets.reserve(S * K * 8, s, false));
@@ -154,37 +158,39 @@ int reserve_all(rsx_odometry *h, size_t ibytes, hipStream_t s) {
 }
 
 // E(g): window g (n <= MAX_WINDOW scans whose images are at d_imgs, device) through cen2019, the Cartesian images and the
-// descriptors into set g & 1, then its last scan into slot 0 of the other set.  Asynchronous on the extraction stream.
+// descriptors into set g % 3, then its last scan into slot 0 of the next set.  Asynchronous on the stream of lane g & 1.
 int enqueue_extract(rsx_odometry *h, uint64_t g, const uint8_t *d_imgs, int n, int64_t img_stride, int32_t row_stride, const float *azimuths,
                     int32_t azimuths_per_image) {
-  hipStream_t s = h->stream;
-  OdoSet &q = h->set[g & 1], &nx = h->set[(g + 1) & 1];
+  const int lane = (int)(g & 1);
+  hipStream_t s = h->lane_stream[lane];
+  OdoSet &q = h->set[g % N_SETS], &nx = h->set[(g + 1) % N_SETS];
   const int K = h->prm.max_keypoints;
   const size_t slot_xy = (size_t)K * 2;
-  RSX_HIP(hipStreamWaitEvent(s, h->ev_m[g & 1], 0));  // M(g - 2) read this set (a no-op before the event's first record)
+  RSX_HIP(hipStreamWaitEvent(s, h->ev_m[g % N_SETS], 0));  // M(g - 3) read this set (a no-op before the event's first record)
   // the azimuth grids go to the device once: cen2019's polar -> Cartesian and the Cartesian image both read them there.
-  // Staged in pinned memory so that the copy does not wait for the stream (the area was last read by E(g - 2): long done)
+  // Staged in pinned memory so that the copy does not wait for the stream (the area was last read by E(g - 3): long done)
   const size_t na = (size_t)h->rows * (azimuths_per_image ? n : 1);
   float *paz = reinterpret_cast<float *>(static_cast<char *>(q.pin) + PIN_AZ);
   std::memcpy(paz, azimuths, na * 4);
   RSX_HIP(hipMemcpyAsync(q.az.p, paz, na * 4, hipMemcpyHostToDevice, s));
   int32_t *d_counts = q.counts.as<int32_t>();
-  RSX_TRY(rsx_cen2019_extract_batch_device(h->cen, d_imgs, n, img_stride, row_stride, h->prm.col_offset, &h->prm.cen, q.az.as<float>(),
+  RSX_TRY(rsx_cen2019_extract_batch_device(h->cen[lane], d_imgs, n, img_stride, row_stride, h->prm.col_offset, &h->prm.cen, q.az.as<float>(),
                                            azimuths_per_image, h->prm.radar_resolution, q.targets.as<int32_t>() + slot_xy,
                                            q.xy.as<float>() + slot_xy, K, d_counts + 1, s));
   // the Cartesian image of scan i through scan i's OWN azimuth grid (already in HBM for cen2019): results do not depend on
   // how the sequence is cut into windows, and nothing about the grids is looked at on the host
-  RSX_TRY(rsx_frontend_cartesian_batch_device_az(h->fe, d_imgs, n, img_stride, row_stride, h->prm.col_offset, q.az.as<float>(),
+  RSX_TRY(rsx_frontend_cartesian_batch_device_az(h->fe[lane], d_imgs, n, img_stride, row_stride, h->prm.col_offset, q.az.as<float>(),
                                                  azimuths_per_image ? (int64_t)h->rows : 0, h->prm.radar_resolution, s));
-  RSX_TRY(rsx_frontend_describe_batch_device(h->fe, q.xy.as<float>() + slot_xy, d_counts + 1, n, K, q.desc.as<uint8_t>() + (size_t)K * 32,
+  RSX_TRY(rsx_frontend_describe_batch_device(h->fe[lane], q.xy.as<float>() + slot_xy, d_counts + 1, n, K, q.desc.as<uint8_t>() + (size_t)K * 32,
                                              q.valid.as<uint8_t>() + (size_t)K, s));
-  // the last scan of the window becomes the previous scan of the next one (slot 0 of the other set, which M(g - 1) reads)
-  RSX_HIP(hipStreamWaitEvent(s, h->ev_m[(g + 1) & 1], 0));
+  // the last scan of the window becomes the previous scan of the next one (slot 0 of the next set, which M(g - 2) read; the
+  // next window's own extraction, on the other lane, writes slots 1 .. n of that set only)
+  RSX_HIP(hipStreamWaitEvent(s, h->ev_m[(g + 1) % N_SETS], 0));
   RSX_HIP(hipMemcpyAsync(nx.xy.p, q.xy.as<float>() + (size_t)n * slot_xy, slot_xy * 4, hipMemcpyDeviceToDevice, s));
   RSX_HIP(hipMemcpyAsync(nx.desc.p, q.desc.as<uint8_t>() + (size_t)n * K * 32, (size_t)K * 32, hipMemcpyDeviceToDevice, s));
   RSX_HIP(hipMemcpyAsync(nx.valid.p, q.valid.as<uint8_t>() + (size_t)n * K, (size_t)K, hipMemcpyDeviceToDevice, s));
   RSX_HIP(hipMemcpyAsync(nx.counts.p, d_counts + n, 4, hipMemcpyDeviceToDevice, s));
-  RSX_HIP(hipEventRecord(h->ev_e[g & 1], s));
+  RSX_HIP(hipEventRecord(h->ev_e[g % N_SETS], s));
   return RSX_OK;
 }
 
@@ -192,14 +198,15 @@ int enqueue_extract(rsx_odometry *h, uint64_t g, const uint8_t *d_imgs, int n, i
 // the results on their way to the set's pinned area.  Asynchronous on the matching stream.  *first_out: 0 when slot 0 takes part.
 int enqueue_match(rsx_odometry *h, uint64_t g, int n, int *first_out) {
   hipStream_t s = h->match_stream;
-  OdoSet &q = h->set[g & 1];
+  OdoSet &q = h->set[g % N_SETS];
   const int K = h->prm.max_keypoints;
-  RSX_HIP(hipStreamWaitEvent(s, h->ev_e[g & 1], 0));
+  RSX_HIP(hipStreamWaitEvent(s, h->ev_e[g % N_SETS], 0));
+  RSX_HIP(hipStreamWaitEvent(s, h->ev_e[(g + N_SETS - 1) % N_SETS], 0));  // E(g - 1): its carry into slot 0 (the other lane's stream)
   int32_t *d_counts = q.counts.as<int32_t>();
   const int first = h->have_prev ? 0 : 1, n_pairs = n - first;
   *first_out = first;
   if (n_pairs > 0) {
-    RSX_TRY(rsx_frontend_match_consecutive_device(h->fe, q.desc.as<uint8_t>(), q.valid.as<uint8_t>(), d_counts, K, first, n_pairs,
+    RSX_TRY(rsx_frontend_match_consecutive_device(h->fe[g & 1], q.desc.as<uint8_t>(), q.valid.as<uint8_t>(), d_counts, K, first, n_pairs,
                                                   h->prm.frontend.ratio, h->fwd.as<int32_t>(), h->bwd.as<int32_t>(), s));
     hipLaunchKernelGGL(odo_cross, dim3((unsigned)n_pairs), dim3(256), 0, s, q.xy.as<float>(), d_counts, K, first, h->fwd.as<int32_t>(),
                        h->bwd.as<int32_t>(), h->stage_src.as<float2>(), h->stage_dst.as<float2>(), h->pair_cnt.as<int32_t>());
@@ -215,18 +222,18 @@ int enqueue_match(rsx_odometry *h, uint64_t g, int n, int *first_out) {
     RSX_HIP(hipMemcpyAsync(pin + PIN_PAIRS, h->pair_cnt.p, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, s));
     RSX_HIP(hipMemcpyAsync(pin + PIN_RES, h->results.p, (size_t)n_pairs * sizeof(rsx_orora_result), hipMemcpyDeviceToHost, s));
   }
-  RSX_HIP(hipEventRecord(h->ev_m[g & 1], s));
+  RSX_HIP(hipEventRecord(h->ev_m[g % N_SETS], s));
   h->have_prev = true;
   return RSX_OK;
 }
 
 // wait for M(g), fill out[0..n) (+ the keypoints)
 int finish_window(rsx_odometry *h, uint64_t g, int n, int first, rsx_odometry_scan *out, float *out_xy, int32_t max_xy) {
-  OdoSet &q = h->set[g & 1];
+  OdoSet &q = h->set[g % N_SETS];
   const int K = h->prm.max_keypoints;
   const size_t slot_xy = (size_t)K * 2;
   char *pin = static_cast<char *>(q.pin);
-  RSX_HIP(hipEventSynchronize(h->ev_m[g & 1]));
+  RSX_HIP(hipEventSynchronize(h->ev_m[g % N_SETS]));
   const int32_t *hc = reinterpret_cast<const int32_t *>(pin + PIN_COUNTS), *hp = reinterpret_cast<const int32_t *>(pin + PIN_PAIRS);
   const rsx_orora_result *hr = reinterpret_cast<const rsx_orora_result *>(pin + PIN_RES);
   for (int i = 0; i < n; i++) {
@@ -241,7 +248,7 @@ int finish_window(rsx_odometry *h, uint64_t g, int n, int first, rsx_odometry_sc
       o.reg.status = 3;  // the first scan of a sequence: there is no previous scan
     }
   }
-  if (out_xy && max_xy > 0) {  // (set g & 1 is not written again before E(g + 2), which the host enqueues after this returns)
+  if (out_xy && max_xy > 0) {  // (set g % 3 is not written again before E(g + 3), which the host enqueues after this returns)
     hipStream_t s = h->match_stream;
     for (int i = 0; i < n; i++) {
       const int c = hc[1 + i] < K ? hc[1 + i] : K, wn = c < max_xy ? c : max_xy;
@@ -255,7 +262,7 @@ int finish_window(rsx_odometry *h, uint64_t g, int n, int first, rsx_odometry_sc
 
 // after an error in the middle of a sequence: nothing in flight, the next scan starts a new sequence
 void abandon(rsx_odometry *h) {
-  (void)hipStreamSynchronize(h->stream);
+  for (hipStream_t ls : h->lane_stream) (void)hipStreamSynchronize(ls);
   (void)hipStreamSynchronize(h->match_stream);
   h->have_prev = false;
 }
@@ -311,17 +318,21 @@ int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t
   h->rows = rows;
   h->cols = cols;
   h->prm = p;
-  int st = rsx_cen2019_create(p.device, rows, cols, &h->cen);
-  if (st == RSX_OK) st = rsx_frontend_create(p.device, rows, cols, &p.frontend, &h->fe);
+  int st = RSX_OK;
+  for (int l = 0; l < N_LANES && st == RSX_OK; l++) {
+    st = rsx_cen2019_create(p.device, rows, cols, &h->cen[l]);
+    if (st == RSX_OK) st = rsx_frontend_create(p.device, rows, cols, &p.frontend, &h->fe[l]);
+  }
   if (st == RSX_OK) st = rsx_orora_create(p.device, &h->reg);
   if (st == RSX_OK && (p.orora.flags & RSX_ORORA_PMC)) st = rsx_orora_reserve(h->reg, (int64_t)MAX_WINDOW * p.max_keypoints);
   if (st == RSX_OK) {
     hipError_t e = hipSetDevice(p.device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    for (hipStream_t &ls : h->lane_stream)
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&ls, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->match_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_up, hipEventDisableTiming);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < N_SETS; i++) {
       if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_e[i], hipEventDisableTiming);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_m[i], hipEventDisableTiming);
       if (e == hipSuccess) e = hipHostMalloc(&h->set[i].pin, pin_bytes(h), hipHostMallocDefault);
@@ -339,26 +350,31 @@ int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t
 int rsx_odometry_destroy(rsx_odometry *h) try {
   if (!h) return RSX_OK;
   (void)hipSetDevice(h->device);
-  if (h->stream) (void)hipStreamSynchronize(h->stream);
+  for (hipStream_t ls : h->lane_stream)
+    if (ls) (void)hipStreamSynchronize(ls);
   if (h->match_stream) (void)hipStreamSynchronize(h->match_stream);
   if (h->copy_stream) (void)hipStreamSynchronize(h->copy_stream);
-  for (rsx::DevBuf *b : {&h->imgs, &h->imgs2, &h->fwd, &h->bwd, &h->stage_src, &h->stage_dst, &h->pair_cnt, &h->src, &h->dst, &h->offsets, &h->results})
+  for (rsx::DevBuf &b : h->imgs) b.release();
+  for (rsx::DevBuf *b : {&h->fwd, &h->bwd, &h->stage_src, &h->stage_dst, &h->pair_cnt, &h->src, &h->dst, &h->offsets, &h->results})
     b->release();
   for (OdoSet &q : h->set) {
     for (rsx::DevBuf *b : {&q.az, &q.targets, &q.xy, &q.counts, &q.desc, &q.valid}) b->release();
     if (q.pin) (void)hipHostFree(q.pin);
   }
-  rsx_cen2019_destroy(h->cen);
-  rsx_frontend_destroy(h->fe);
+  for (int l = 0; l < N_LANES; l++) {
+    rsx_cen2019_destroy(h->cen[l]);
+    rsx_frontend_destroy(h->fe[l]);
+  }
   rsx_orora_destroy(h->reg);
   if (h->ev_up) (void)hipEventDestroy(h->ev_up);
-  for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < N_SETS; i++) {
     if (h->ev_e[i]) (void)hipEventDestroy(h->ev_e[i]);
     if (h->ev_m[i]) (void)hipEventDestroy(h->ev_m[i]);
   }
   if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
   if (h->match_stream) (void)hipStreamDestroy(h->match_stream);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  for (hipStream_t ls : h->lane_stream)
+    if (ls) (void)hipStreamDestroy(ls);
   delete h;
   return RSX_OK;
 } RSX_CATCH_ALL
@@ -380,7 +396,7 @@ int rsx_odometry_push_device(rsx_odometry *h, const uint8_t *d_imgs, int32_t n_s
   RSX_TRY(check_azimuths(h, azimuths, azimuths_per_image, n_scans));
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
-  RSX_TRY(reserve_all(h, 0, h->stream));
+  RSX_TRY(reserve_all(h, 0, h->match_stream));
   auto window = [&](int w, uint64_t g) -> int {  // E(g) of the call's window w
     const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
     return enqueue_extract(h, g, d_imgs + (int64_t)b0 * image_stride_bytes, n, image_stride_bytes, row_stride,
@@ -388,12 +404,13 @@ int rsx_odometry_push_device(rsx_odometry *h, const uint8_t *d_imgs, int32_t n_s
   };
   const int nwin = (n_scans + MAX_WINDOW - 1) / MAX_WINDOW;
   int st = window(0, h->windows);
+  if (st == RSX_OK && nwin > 1) st = window(1, h->windows + 1);
   for (int w = 0; w < nwin && st == RSX_OK; w++) {
     const uint64_t g = h->windows + (uint64_t)w;
     const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
     int first = 0;
     st = enqueue_match(h, g, n, &first);
-    if (st == RSX_OK && w + 1 < nwin) st = window(w + 1, g + 1);  // the next window's extraction runs beside this window's matching
+    if (st == RSX_OK && w + 2 < nwin) st = window(w + 2, g + 2);  // two extractions run beside this window's matching
     if (st == RSX_OK) st = finish_window(h, g, n, first, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy);
   }
   h->windows += (uint64_t)nwin;
@@ -409,15 +426,13 @@ int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int
   RSX_TRY(check_azimuths(h, azimuths, azimuths_per_image, n_scans));
   std::lock_guard<std::mutex> lk(h->mu);
   RSX_HIP(hipSetDevice(h->device));
-  hipStream_t s = h->stream;
   const size_t ibytes = (size_t)h->rows * row_stride;
-  RSX_TRY(reserve_all(h, ibytes, s));
-  // two image buffers: the upload of window w + 1 (copy stream) runs while the kernels of window w do (compute stream)
+  RSX_TRY(reserve_all(h, ibytes, h->match_stream));
+  // three image buffers: the upload of window w + 2 (copy stream) runs while the kernels of windows w and w + 1 do
   struct CopyDone {  // the caller's host images must not be in flight when this call returns, error or not
     hipStream_t cs;
     ~CopyDone() { (void)hipStreamSynchronize(cs); }
   } copy_done{h->copy_stream};
-  RSX_TRY(h->imgs2.reserve(n_scans > MAX_WINDOW ? ibytes * MAX_WINDOW : 0, s, false));
   auto upload = [&](int b0, int n, void *dst) -> int {
     const uint8_t *src = imgs + (int64_t)b0 * image_stride_bytes;
     if (n == 1 || image_stride_bytes == (int64_t)ibytes) {
@@ -428,24 +443,22 @@ int rsx_odometry_push(rsx_odometry *h, const uint8_t *imgs, int32_t n_scans, int
     RSX_HIP(hipEventRecord(h->ev_up, h->copy_stream));
     return RSX_OK;
   };
-  void *bufs[2] = {h->imgs.p, h->imgs2.p};
   auto window = [&](int w, uint64_t g) -> int {  // E(g) of the call's window w, behind its upload
     const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
-    RSX_HIP(hipStreamWaitEvent(h->stream, h->ev_up, 0));
-    return enqueue_extract(h, g, static_cast<const uint8_t *>(bufs[w & 1]), n, (int64_t)ibytes, row_stride,
+    RSX_TRY(upload(b0, n, h->imgs[w % N_SETS].p));  // (the buffer was read by the extraction of window w - 3: long done)
+    RSX_HIP(hipStreamWaitEvent(h->lane_stream[g & 1], h->ev_up, 0));
+    return enqueue_extract(h, g, h->imgs[w % N_SETS].as<uint8_t>(), n, (int64_t)ibytes, row_stride,
                            azimuths + (azimuths_per_image ? (size_t)b0 * h->rows : 0), azimuths_per_image);
   };
   const int nwin = (n_scans + MAX_WINDOW - 1) / MAX_WINDOW;
-  int st = upload(0, n_scans < MAX_WINDOW ? n_scans : MAX_WINDOW, bufs[0]);
-  if (st == RSX_OK) st = window(0, h->windows);
+  int st = window(0, h->windows);
+  if (st == RSX_OK && nwin > 1) st = window(1, h->windows + 1);
   for (int w = 0; w < nwin && st == RSX_OK; w++) {
     const uint64_t g = h->windows + (uint64_t)w;
-    const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW, b1 = b0 + MAX_WINDOW;
+    const int b0 = w * MAX_WINDOW, n = n_scans - b0 < MAX_WINDOW ? n_scans - b0 : MAX_WINDOW;
     int first = 0;
     st = enqueue_match(h, g, n, &first);
-    // (image buffer (w + 1) & 1 was read by the extraction of window w - 1, which the matching of w - 1 -- waited for -- followed)
-    if (st == RSX_OK && b1 < n_scans) st = upload(b1, n_scans - b1 < MAX_WINDOW ? n_scans - b1 : MAX_WINDOW, bufs[(w + 1) & 1]);
-    if (st == RSX_OK && b1 < n_scans) st = window(w + 1, g + 1);
+    if (st == RSX_OK && w + 2 < nwin) st = window(w + 2, g + 2);
     if (st == RSX_OK) st = finish_window(h, g, n, first, out + b0, out_xy ? out_xy + (size_t)b0 * max_xy * 2 : nullptr, max_xy);
   }
   h->windows += (uint64_t)nwin;
