@@ -513,6 +513,8 @@ typedef struct {
 } rsx_odometry_scan;
 
 int rsx_odometry_default_params(rsx_odometry_params *p);
+/* (device memory of a handle for 400 x 3360 scans: about 4 GB -- two extraction lanes of a 64-scan window each, three sets of
+ * keypoints / descriptors, allocated at the first push; three windows of a sequence are in flight inside a call) */
 int rsx_odometry_create(const rsx_odometry_params *params, int32_t rows, int32_t cols, rsx_odometry **out);
 int rsx_odometry_destroy(rsx_odometry *h);
 int rsx_odometry_reset(rsx_odometry *h); /* forget the previous scan: the next scan starts a new sequence */

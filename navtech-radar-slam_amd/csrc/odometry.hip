@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int MAX_WINDOW = 64;  // scans per internal launch chain (workspace: ~26 MB per scan)
+constexpr int MAX_WINDOW = 64;  // scans per internal launch chain (workspace: ~26 MB per scan and extraction lane, two lanes)
 
 // one block per consecutive pair j (slots A = first + j, B = A + 1): keep prev keypoint i when fwd[i] = k >= 0 and
 // bwd[k] = i, in ascending i (the order the host loop of round 2 produced); src = the CURRENT scan's point, dst = the
