@@ -711,7 +711,7 @@ def odometry_e2e_leg(device, skip_cpu, n_unique=24, n_scans=528):
     order = np.asarray(order)
     seq = np.ascontiguousarray(imgs[order])
     od = odometry.Odometry(400, 3360, device=device)
-    od.push(seq[:70], az)                                          # warm-up: workspaces, the Cartesian map
+    od.push(seq[:200], az)                                         # warm-up: workspaces of both extraction lanes and all three sets, the Cartesian maps
     od.reset()
     t0 = time.perf_counter()
     res = od.push(seq, az)

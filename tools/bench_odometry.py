@@ -19,7 +19,7 @@ seq = np.ascontiguousarray(imgs[np.asarray(order)])
 od = odometry.Odometry(400, 3360)
 d = torch.from_numpy(seq).cuda()
 torch.cuda.synchronize()
-od.push(seq[:70], az)
+od.push(seq[:200] if len(seq) >= 200 else seq, az)
 for _ in range(reps):
     od.reset()
     t0 = time.perf_counter()
