@@ -279,12 +279,13 @@ __device__ __forceinline__ bool edge_wave(int cols) {
   return wp0 == 0 || wp0 + 64 * C >= cols;
 }
 
+// (p0 = the chunk's first pixel, edge = the chunk's wavefront holds the row's first pixel or reaches its end: the block kernels pass
+// threadIdx.x * C and edge_wave, the wave-per-row kernel its own)
 template <int C, int NT>
-__device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg,
-                                           float rcp_maxg, float (&h)[C], unsigned &neg) {
+__device__ __forceinline__ void row_load_h_at(const RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg,
+                                              float rcp_maxg, float (&h)[C], unsigned &neg, const int p0, const bool edge) {
   static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
   constexpr int NWD = C / 4 + 2;  // aligned words [-1 .. C / 4] relative to (row + p0) & ~3
-  const int p0 = threadIdx.x * C;
   neg = 0;
   unsigned w[NWD];
 #pragma unroll
@@ -309,7 +310,6 @@ __device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t
   // reflect 101 at the two ends of the row: the neighbour of bin 0 on the left is bin 1, of the last bin on the right the one
   // before it -- written into the neighbour slots, so that every pixel of every thread runs the SAME code below (rounds 3-4: a
   // second, branchy copy of the pixel code for the first and the last threads, executed by the whole wavefront around them)
-  const bool edge = edge_wave<C>(cols);
   if (edge) {
     if (p0 == 0) ft[0] = ft[2];
 #pragma unroll
@@ -336,6 +336,36 @@ __device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t
         neg &= ~(1u << i);
       }
   }
+}
+template <int C, int NT>
+__device__ __forceinline__ void row_load_h(const RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg,
+                                           float rcp_maxg, float (&h)[C], unsigned &neg) {
+  row_load_h_at(L, row, cols, mean, maxg, rcp_maxg, h, neg, (int)threadIdx.x * C, edge_wave<C>(cols));
+}
+
+// The sign bits alone (round 6, cen_runs' light path): s < 0 <=> t[b] < mean (the difference of two floats keeps its sign) <=> b < T
+// with T = the number of bytes whose t[b] lies below the mean (t is increasing) -- no table look-up, no arithmetic: the chunk's
+// bytes against one threshold.  Same words, same alignment, same rule past the row end as row_load_h.
+template <int C>
+__device__ __forceinline__ unsigned row_load_neg(const uint8_t *__restrict__ row, int cols, unsigned T, const int p0) {
+  static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
+  constexpr int NWD = C / 4 + 1;  // aligned words [0 .. C / 4] relative to (row + p0) & ~3
+  if (p0 >= cols) return 0u;
+  unsigned w[NWD];
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
+  const unsigned mis = (unsigned)(addr & 3u);
+  const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
+#pragma unroll
+  for (int j = 0; j < NWD; j++) w[j] = (p0 + 4 * j - (int)mis < cols) ? wp[j] : 0u;
+  unsigned neg = 0;
+#pragma unroll
+  for (int i = C - 1; i >= 0; i--) {
+    const unsigned v = __builtin_amdgcn_alignbyte(w[(i >> 2) + 1 < NWD ? (i >> 2) + 1 : NWD - 1], w[i >> 2], mis);  // bytes mis .. mis+3 of (hi:lo)
+    const unsigned b = (v >> (8 * (i & 3))) & 0xffu;
+    asm("v_cmp_lt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(neg) : "v"(b), "v"(T) : "vcc");
+  }
+  if (p0 + C > cols) neg &= (1u << (cols - p0)) - 1u;  // pixels past the end of the row: not neg
+  return neg;
 }
 
 __device__ __forceinline__ unsigned long long key_of(float hv, unsigned pixel) {
@@ -433,6 +463,16 @@ __device__ __forceinline__ unsigned wave_incl_max_u32(unsigned x) {
   return x;
 }
 
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {  // (uniform) the maximum over the 64 lanes
+  auto mx = [](unsigned a, unsigned b) { return a > b ? a : b; };
+  x = mx(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  x = mx(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  x = mx(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x141, 0xf, 0xf, false));  // row_half_mirror
+  x = mx(x, (unsigned)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x140, 0xf, 0xf, false));  // row_mirror: every lane = its row's maximum
+  return mx(mx((unsigned)__builtin_amdgcn_readlane((int)x, 0), (unsigned)__builtin_amdgcn_readlane((int)x, 16)),
+            mx((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
+}
+
 // facts of the thread's C pixels of one row; pixels past the row end are walls: non-neg, below every h
 template <int C>
 struct RowChunk {
@@ -443,20 +483,31 @@ struct RowChunk {
 };
 
 // h, neg and the non-neg prefix counts of the row.  The caller has filled L.tab; contains two block barriers.
+// light (wave-uniform; cen_runs): the wavefront is known to hold no pixel whose h matters -- only the sign bits are formed, from the
+// bytes against neg_T (row_load_neg); h and ord(h) of its pixels read 0
 template <int C, int NT>
 __device__ __forceinline__ void row_chunk(RowLds<C, NT> &L, const uint8_t *__restrict__ row, int cols, float mean, float maxg, float rcp_maxg,
-                                          RowChunk<C> &R) {
+                                          RowChunk<C> &R, bool light = false, unsigned neg_T = 0u) {
   constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
   constexpr int NW = NT / 64;
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   __syncthreads();  // previous users of L are done, L.tab is visible
-  row_load_h(L, row, cols, mean, maxg, rcp_maxg, R.h, R.neg);
+  if (light) {
+    R.neg = row_load_neg<C>(row, cols, neg_T, (int)threadIdx.x * C);
 #pragma unroll
-  for (int i = 0; i < C; i++) R.ordh[i] = ord_f32(R.h[i] + 0.0f);  // (-0.0) + 0.0 = +0.0
-  if (edge_wave<C>(cols)) {
+    for (int i = 0; i < C; i++) {
+      R.h[i] = 0.0f;
+      R.ordh[i] = 0u;
+    }
+  } else {
+    row_load_h(L, row, cols, mean, maxg, rcp_maxg, R.h, R.neg);
 #pragma unroll
-    for (int i = 0; i < C; i++)
-      if ((int)threadIdx.x * C + i >= cols) R.ordh[i] = 0u;  // walls
+    for (int i = 0; i < C; i++) R.ordh[i] = ord_f32(R.h[i] + 0.0f);  // (-0.0) + 0.0 = +0.0
+    if (edge_wave<C>(cols)) {
+#pragma unroll
+      for (int i = 0; i < C; i++)
+        if ((int)threadIdx.x * C + i >= cols) R.ordh[i] = 0u;  // walls
+    }
   }
   const unsigned cnt = (unsigned)__popc(~R.neg & FULL);
   const unsigned incl = wave_incl_add(cnt, lane);
@@ -558,7 +609,8 @@ template <int C> constexpr int kTopShift = C <= 8 ? 8 : 16;
 constexpr int HIST_ROWS = 4;  // azimuths per block of cen_hist in a batch: the table, the zeroed block histogram and its flush (atomics into the image's 4096 bins: a quarter of the kernel at one row per block) once for all of them (8: the same 210 us)
 template <int C, int NT>
 __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
-                                               Scal *scal, unsigned *__restrict__ hist, OpRec<C> *__restrict__ opener, int rpb) {
+                                               Scal *scal, unsigned *__restrict__ hist, OpRec<C> *__restrict__ opener,
+                                               unsigned *__restrict__ wavemax, int rpb) {
   __shared__ RowLds<C, NT> L;
   __shared__ __attribute__((aligned(16))) unsigned s_hist[NBIN];
   __shared__ long long s_fix[NT / 64];
@@ -582,6 +634,14 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
     RowChunk<C> R;
     row_chunk(L, row, cols, mean, maxg, rcp_maxg, R);
     const unsigned opens = row_opens(L, R, cols);
+    {  // for cen_runs: the largest ord(h) among the wavefront's pixels of this row -- a wavefront whose maximum lies below the
+       // limit's holds no hit and never looks at its h again (walls read 0)
+      unsigned m = R.ordh[0];
+#pragma unroll
+      for (int i = 1; i < C; i++) m = R.ordh[i] > m ? R.ordh[i] : m;
+      m = wave_max_u32(m);
+      if ((threadIdx.x & 63) == 0) wavemax[((int64_t)blockIdx.y * rows + a) * (NT / 64) + (threadIdx.x >> 6)] = m;
+    }
     int top = 0;  // 1 + the highest histogram bin an opener of this thread fell into (0: the thread has no opener)
 #pragma unroll
     for (int i = 0; i < C; i++) {  // (past the row end h = 0 and no opener bit is set)
@@ -889,10 +949,14 @@ __global__ __launch_bounds__(1024) void cen_resolve(Scal *scal, const unsigned l
 // Then one segmented max-scan over the marked runs at r >= min_range: every run that an unmarked pixel closes is recorded as
 // (first bin, last bin, bin of the first maximum of h); the row's mark bits go to HBM for the neighbours' adjacency test.
 constexpr int RUNS_ROWS = 2;  // azimuths per block of cen_runs in a batch
+#ifndef CEN_RUNS_WAVES
+#define CEN_RUNS_WAVES 8  // waves per SIMD the register budget of cen_runs<8, 512> is cut for (8: 62 VGPRs, four row blocks per CU)
+#endif
 template <int C, int NT>
-__global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 512 ? CEN_RUNS_WAVES : 4))) void cen_runs(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off,
                                                Scal *scal, int min_range, int row_cap, uint2 *__restrict__ row_runs,
-                                               unsigned *__restrict__ row_nruns, MarkT<C> *__restrict__ markbits, int rpb) {
+                                               unsigned *__restrict__ row_nruns, MarkT<C> *__restrict__ markbits,
+                                               const unsigned *__restrict__ wavemax, int rpb) {
   constexpr unsigned FULL = (C == 32) ? 0xffffffffu : ((1u << C) - 1u);
   __shared__ RowLds<C, NT> L;
   __shared__ __attribute__((aligned(16))) uint8_t s_run[C * NT + 16];  // flag of neg run number k: some toucher is a hit
@@ -904,6 +968,9 @@ __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs,
   const float mean = sc->mean, maxg = __uint_as_float(sc->max_g_bits), rcp_maxg = sc->rcp_maxg;
   const unsigned long long klimit = sc->klimit;
   row_table(L);
+  // a pixel can be a hit (key < limit) only with ord(h) >= ~(limit >> 32); s < 0 <=> byte < neg_T (row_load_neg)
+  const unsigned ord_min = ~(unsigned)(klimit >> 32);
+  const unsigned neg_T = (unsigned)__syncthreads_count(threadIdx.x < 256 && L.tab[threadIdx.x < 256 ? threadIdx.x : 0] < mean);  // (a thread reads the entry it wrote)
   const int p0 = threadIdx.x * C;
   if (threadIdx.x < NW) {
     s_k[threadIdx.x] = 0.0;
@@ -919,12 +986,18 @@ __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs,
       for (int i = threadIdx.x; i < (C * NT + 16) / 16; i += NT) z[i] = uint4{0u, 0u, 0u, 0u};
     }
     RowChunk<C> R;
-    row_chunk(L, row, cols, mean, maxg, rcp_maxg, R);  // (its barriers also publish the zeroed flags)
+    // Round 6: hits are sparse (bench images: 0.7 % of the pixels, 37 % of the wavefronts of a row hold one).  cen_hist left the
+    // largest ord(h) of every wavefront and row: a wavefront below the limit forms its sign bits from the bytes alone (light:
+    // no table, no h) and, with no mark among its pixels either, publishes the identities of the three scans and skips them
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool light = (unsigned)__builtin_amdgcn_readfirstlane((int)wavemax[((int64_t)img * rows + a) * NW + w]) < ord_min;
+    row_chunk(L, row, cols, mean, maxg, rcp_maxg, R, light, neg_T);  // (its barriers also publish the zeroed flags)
     const unsigned nn = ~R.neg & FULL;
     // hit(p) = key(p) < limit, key = ~ord(h) << 32 | pixel: straight from the chunk's ord(h) (a wall's is 0: the largest key
     // there is, never a hit -- no test against the row's end)
     unsigned hit = 0;
     const unsigned pix0 = (unsigned)a * (unsigned)cols + (unsigned)p0;
+    if (!light) {
 #pragma unroll
     for (int i = 0; i < C; i++) {
       const unsigned long long key = ((unsigned long long)(~R.ordh[i]) << 32) | (unsigned long long)(pix0 + (unsigned)i);
@@ -934,6 +1007,7 @@ __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs,
         s_run[c] = 1;                                // a neg pixel: its own run; a non-neg pixel: the run on its left ...
         if ((nn >> i) & 1u) s_run[c + 1] = 1;        // ... and the run on its right
       }
+    }
     }
     __syncthreads();
     // marks: a non-neg pixel iff it is a hit, a neg pixel iff its run's flag is set (walls are non-neg and no hits)
@@ -945,12 +1019,25 @@ __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs,
     }
     const unsigned marked = (nn & hit) | (R.neg & flags);
     if (p0 < cols) markbits[((int64_t)img * rows + a) * NT + threadIdx.x] = (MarkT<C>)marked;
+    // a wavefront without a marked pixel has nothing to say in the scans below; a LIGHT wavefront with marks (neg pixels of a run
+    // that a hit elsewhere flagged) gets the h of its pixels now -- the arg-max of a run may fall on them (a run cut at rmin)
+    const bool wave_marks = __ballot(marked != 0u) != 0ull;  // (wave-uniform)
+    if (light && wave_marks) {
+      unsigned neg2;
+      row_load_h(L, row, cols, mean, maxg, rcp_maxg, R.h, neg2);
+#pragma unroll
+      for (int i = 0; i < C; i++) R.ordh[i] = ord_f32(R.h[i] + 0.0f);
+      if (edge_wave<C>(cols)) {
+#pragma unroll
+        for (int i = 0; i < C; i++)
+          if (p0 + i >= cols) R.ordh[i] = 0u;
+      }
+    }
     // ---- closed runs of marked pixels at r >= rmin: (first bin, last bin, bin of the first maximum of h).  live = marked and
     // r >= rmin; a run starts where the pixel before is not live, and counts once an UNMARKED pixel closes it (a run that
     // reaches the end of the row does not).  Two plain max-scans (sc_key's trick): S(p) = 1 + the bin of the latest start
     // at or before p, then K(p) = S(p) | ord(h) | ~bin in one positive double -- the latest run beats everything before it,
     // inside it the largest h wins and among equals the lowest bin -- so the value at a run's last pixel is the run's result.
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int rmin = min_range < 0 ? 0 : min_range;
     const unsigned ge = p0 >= rmin ? FULL : (p0 + C <= rmin ? 0u : (FULL & ~((1u << (rmin - p0)) - 1u)));  // bit i: p >= rmin
     const unsigned live = marked & ge;
@@ -961,66 +1048,262 @@ __global__ __launch_bounds__(NT) void cen_runs(const uint8_t *__restrict__ imgs,
       if (lane == 0) L.edge[w] = e0 | (e1 << 1);
     }
     __syncthreads();
-    if (lane == 0) lprev = w > 0 ? (L.edge[w > 0 ? w - 1 : 0] >> 1) & 1u : 0u;
-    if (lane == 63) mnext = w + 1 < NT / 64 ? L.edge[w + 1 < NT / 64 ? w + 1 : 0] & 1u : 0u;
-    const unsigned start = live & ~(((live << 1) | lprev) & FULL);
-    const unsigned in_row = p0 + C < cols ? FULL : (p0 + 1 >= cols ? 0u : ((1u << (cols - 1 - p0)) - 1u));  // bit i: p + 1 < cols
-    const unsigned close = live & ~((marked >> 1) | (mnext << (C - 1))) & in_row;
-    // S: 1 + bin of the latest start (0: none yet)
-    const unsigned sloc = start ? (unsigned)(p0 + (31 - __builtin_clz(start)) + 1) : 0u;
-    unsigned sin;
-    {
+    unsigned start = 0, close = 0, sin = 0;
+    if (wave_marks) {
+      if (lane == 0) lprev = w > 0 ? (L.edge[w > 0 ? w - 1 : 0] >> 1) & 1u : 0u;
+      if (lane == 63) mnext = w + 1 < NT / 64 ? L.edge[w + 1 < NT / 64 ? w + 1 : 0] & 1u : 0u;
+      start = live & ~(((live << 1) | lprev) & FULL);
+      const unsigned in_row = p0 + C < cols ? FULL : (p0 + 1 >= cols ? 0u : ((1u << (cols - 1 - p0)) - 1u));  // bit i: p + 1 < cols
+      close = live & ~((marked >> 1) | (mnext << (C - 1))) & in_row;
+      // S: 1 + bin of the latest start (0: none yet)
+      const unsigned sloc = start ? (unsigned)(p0 + (31 - __builtin_clz(start)) + 1) : 0u;
       const unsigned x = wave_incl_max_u32(sloc);  // inclusive over the wavefront (positions only grow, so max = latest)
       if (lane == 63) s_cnt[NW + w] = x;
       sin = dpp_u32<0x138>(x);  // exclusive
+    } else if (lane == 63) {
+      s_cnt[NW + w] = 0u;  // (no start in this wavefront)
     }
     __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NW; k++) {
-      const unsigned v = s_cnt[NW + w - 1 - k];
-      sin = v > sin ? v : sin;
-    }
     // K = 1 << 62 | S << 46 | ord(h) << 14 | ~bin: the high word is one v_alignbit of (S | 1 << 16, ord(h)), the low word one
     // v_lshl_or; a pixel that is not live gets a high word of 0 (a tiny positive double below every key, whatever the low word)
     double kin[C];
-    double run = 0.0;
-    const unsigned sinx = sin | 0x10000u, pbx = (unsigned)p0 + 32u + 0x10000u, c0 = 0x3fffu - ((unsigned)p0 & 0x3fffu);  // (p0 is a multiple of C: no carry into the next 16384)
+    double kx = 0.0;
+    unsigned cnt = 0, inc = 0;
+    if (wave_marks) {
 #pragma unroll
-    for (int i = 0; i < C; i++) {
-      const unsigned below = start & ((2u << i) - 1u);  // starts of the chunk at or before i
-      const unsigned spx = below ? pbx - (unsigned)__builtin_clz(below) : sinx;
-      const unsigned hi = __builtin_amdgcn_alignbit(spx, R.ordh[i], 18);
-      const unsigned lo = (R.ordh[i] << 14) | (c0 - (unsigned)i);
-      const double kd = __hiloint2double((int)(((live >> i) & 1u) ? hi : 0u), (int)lo);
-      run = kmax(run, kd);
-      kin[i] = run;
+      for (int k = 0; k < NW; k++) {
+        const unsigned v = s_cnt[NW + w - 1 - k];
+        sin = v > sin ? v : sin;
+      }
+      double run = 0.0;
+      const unsigned sinx = sin | 0x10000u, pbx = (unsigned)p0 + 32u + 0x10000u, c0 = 0x3fffu - ((unsigned)p0 & 0x3fffu);  // (p0 is a multiple of C: no carry into the next 16384)
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        const unsigned below = start & ((2u << i) - 1u);  // starts of the chunk at or before i
+        const unsigned spx = below ? pbx - (unsigned)__builtin_clz(below) : sinx;
+        const unsigned hi = __builtin_amdgcn_alignbit(spx, R.ordh[i], 18);
+        const unsigned lo = (R.ordh[i] << 14) | (c0 - (unsigned)i);
+        const double kd = __hiloint2double((int)(((live >> i) & 1u) ? hi : 0u), (int)lo);
+        run = kmax(run, kd);
+        kin[i] = run;
+      }
+      const double ki = wave_incl_max<false>(run, lane);
+      kx = dpp_f64<0x138>(ki);
+      if (lane == 63) s_k[NW + w] = ki;
+      // (the compaction's counts travel with the same barrier)
+      cnt = (unsigned)__popc(close);
+      inc = wave_incl_add(cnt, lane);
+      if (lane == 63) s_cnt2[NW + w] = inc;
+    } else {
+#pragma unroll
+      for (int i = 0; i < C; i++) kin[i] = 0.0;
+      if (lane == 63) {
+        s_k[NW + w] = 0.0;
+        s_cnt2[NW + w] = 0u;
+      }
     }
-    const double ki = wave_incl_max<false>(run, lane);
-    double kx = dpp_f64<0x138>(ki);
-    if (lane == 63) s_k[NW + w] = ki;
-    // (the compaction's counts travel with the same barrier)
-    const unsigned cnt = (unsigned)__popc(close);
-    const unsigned inc = wave_incl_add(cnt, lane);
-    if (lane == 63) s_cnt2[NW + w] = inc;
     __syncthreads();
     unsigned before = 0;
 #pragma unroll
-    for (int k = 0; k < NW; k++) {
-      kx = kmax(kx, s_k[NW + w - 1 - k]);
-      before += s_cnt2[NW + w - 1 - k];
-    }
-    unsigned pos = before + inc - cnt;
-    uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
+    for (int k = 0; k < NW; k++) before += s_cnt2[NW + w - 1 - k];
+    if (wave_marks) {
 #pragma unroll
-    for (int i = 0; i < C; i++) {
-      if ((close >> i) & 1u) {
-        const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
-        const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
-        ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
+      for (int k = 0; k < NW; k++) kx = kmax(kx, s_k[NW + w - 1 - k]);
+      unsigned pos = before + inc - cnt;
+      uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        if ((close >> i) & 1u) {
+          const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
+          const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
+          ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
+        }
       }
     }
     if (threadIdx.x == NT - 1) row_nruns[(int64_t)img * rows + a] = before + inc;  // the last thread's inclusive count
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// cen_runs, ONE WAVEFRONT PER AZIMUTH (round 6; rows of <= 4096 bins).  The workgroup-per-azimuth form above is one chain of
+// six barriers per row and every scan crosses its eight wavefronts through LDS; since a wavefront that holds no hit has
+// nearly nothing to do (light path), its row time was the time of the busiest wavefront and the others waited (counters:
+// 17 % fewer vector instructions, SQ_WAIT_ANY up by the same cycles, the same 174 us).  Here a wavefront walks ITS row in
+// chunks of 512 bins, the scans' totals travel from chunk to chunk in SGPRs, the run flags live in the wavefront's own
+// 4 KB of LDS -- no barrier after the table, no idle eighth wavefront, and a chunk below the limit costs its sign bits.
+//   pass 1 (all chunks)  sign bits, ord(h) (chunks that can hold a hit), non-neg prefix counts, hits -> run flags
+//   pass 2a              marks (flag reads), mark bits to HBM
+//   pass 2b              closed runs: the three scans chunk by chunk, chunks without a mark skipped
+// Same records, same mark bits as cen_runs, which stays for rows wider than 4096 bins (tests/test_gpu_cen2019.py: MulRan shape and
+// the odd shapes through this kernel, test_wide_rows through the block form) and for A / B runs (RSX_CEN_RUNS=block, experiments build).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int RW_WAVES = 4;             // wavefronts (= azimuths) per workgroup
+constexpr int RW_CH = 8;                // chunks of 512 bins: rows of <= 4096 bins
+constexpr int RW_FLAGS = 4096 + 64;     // run flags of one wavefront (a run's number = the non-neg pixels before it <= 4096 + walls)
+#ifndef RW_OCC
+#define RW_OCC 4  // waves per SIMD the register budget is cut for
+#endif
+__global__ __launch_bounds__(64 * RW_WAVES) __attribute__((amdgpu_waves_per_eu(RW_OCC))) void cen_runs_wave(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
+                                                                int off, Scal *scal, int min_range, int row_cap, uint2 *__restrict__ row_runs,
+                                                                unsigned *__restrict__ row_nruns, MarkT<8> *__restrict__ markbits,
+                                                                const unsigned *__restrict__ wavemax) {
+  constexpr int C = 8, NTR = 64 * RW_CH;  // NTR: chunks (threads of the block form) a row's records are laid out for
+  constexpr unsigned FULL = 0xffu;
+  __shared__ RowLds<C, NTR> L;  // (the byte -> float table)
+  __shared__ __attribute__((aligned(16))) uint8_t s_flags[RW_WAVES][RW_FLAGS];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int img = blockIdx.y, a = (int)blockIdx.x * RW_WAVES + w;
+  Scal *sc = scal + img;
+  const float mean = sc->mean, maxg = __uint_as_float(sc->max_g_bits), rcp_maxg = sc->rcp_maxg;
+  const unsigned long long klimit = sc->klimit;
+  row_table(L);
+  const unsigned ord_min = ~(unsigned)(klimit >> 32);
+  const unsigned neg_T = (unsigned)__syncthreads_count(L.tab[threadIdx.x] < mean);  // (256 threads: a thread reads the entry it wrote)
+  if (a >= rows) return;  // (wave-uniform; no barrier below)
+  const uint8_t *row = imgs + (int64_t)img * img_stride + off + (int64_t)a * stride;
+  const int nch = (cols + 64 * C - 1) / (64 * C);
+  uint8_t *s_run = s_flags[w];
+  for (int i = lane; i < RW_FLAGS / 16; i += 64) reinterpret_cast<uint4 *>(s_run)[i] = uint4{0u, 0u, 0u, 0u};
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // ---- pass 1 ----
+  unsigned neg[RW_CH], hit[RW_CH], excl[RW_CH], ordh[RW_CH][C];
+  unsigned carry_nn = 0;
+  unsigned long long any_flag = 0ull;
+#pragma unroll
+  for (int ch = 0; ch < RW_CH; ch++) {
+    neg[ch] = 0u;
+    hit[ch] = 0u;
+    excl[ch] = 0u;
+#pragma unroll
+    for (int i = 0; i < C; i++) ordh[ch][i] = 0u;
+    if (ch < nch) {  // (uniform)
+      const int p0 = (ch * 64 + lane) * C;
+      const bool light = (unsigned)__builtin_amdgcn_readfirstlane((int)wavemax[((int64_t)img * rows + a) * RW_CH + ch]) < ord_min;
+      if (light) {
+        neg[ch] = row_load_neg<C>(row, cols, neg_T, p0);
+      } else {
+        float h[C];
+        const bool edge = ch == 0 || (ch + 1) * 64 * C >= cols;
+        row_load_h_at(L, row, cols, mean, maxg, rcp_maxg, h, neg[ch], p0, edge);
+#pragma unroll
+        for (int i = 0; i < C; i++) ordh[ch][i] = ord_f32(h[i] + 0.0f);  // (-0.0) + 0.0 = +0.0
+        if (edge) {
+#pragma unroll
+          for (int i = 0; i < C; i++)
+            if (p0 + i >= cols) ordh[ch][i] = 0u;  // walls
+        }
+      }
+      const unsigned nn = ~neg[ch] & FULL;
+      const unsigned cnt = (unsigned)__popc(nn);
+      const unsigned incl = wave_incl_add(cnt, lane);
+      excl[ch] = carry_nn + incl - cnt;
+      carry_nn += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+      if (!light) {
+        const unsigned pix0 = (unsigned)a * (unsigned)cols + (unsigned)p0;
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          const unsigned long long key = ((unsigned long long)(~ordh[ch][i]) << 32) | (unsigned long long)(pix0 + (unsigned)i);
+          if (key < klimit) {
+            hit[ch] |= 1u << i;
+            const unsigned c = excl[ch] + (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels before p = the number of the run p is in / that ends at p
+            s_run[c] = 1;                                // a neg pixel: its own run; a non-neg pixel: the run on its left ...
+            if ((nn >> i) & 1u) s_run[c + 1] = 1;        // ... and the run on its right
+          }
+        }
+        any_flag |= __ballot(hit[ch] != 0u);
+      }
+    }
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wavefront's own LDS stores, in order: the flags are readable)
+
+  // ---- pass 2a: marks ----
+  unsigned marked[RW_CH];
+#pragma unroll
+  for (int ch = 0; ch < RW_CH; ch++) {
+    marked[ch] = 0u;
+    if (ch < nch) {
+      const int p0 = (ch * 64 + lane) * C;
+      if (any_flag != 0ull) {  // (uniform) the row has a hit: a neg pixel is marked iff its run's flag is set
+        const unsigned nn = ~neg[ch] & FULL;
+        unsigned flags = 0;
+#pragma unroll
+        for (int i = C - 1; i >= 0; i--) {
+          const unsigned f = s_run[excl[ch] + (unsigned)__popc(nn & ((1u << i) - 1u))];
+          asm("v_cmp_ne_u32_e32 vcc, 0, %1\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(flags) : "v"(f) : "vcc");
+        }
+        marked[ch] = (~neg[ch] & FULL & hit[ch]) | (neg[ch] & flags);
+      } else {
+        marked[ch] = 0u;  // (a row without a hit has no mark)
+      }
+      if (p0 < cols) markbits[((int64_t)img * rows + a) * NTR + ch * 64 + lane] = (MarkT<C>)marked[ch];
+    }
+  }
+
+  // ---- pass 2b: closed runs (cen_runs' scans, their totals carried from chunk to chunk) ----
+  const int rmin = min_range < 0 ? 0 : min_range;
+  unsigned lprev_c = 0u, s_carry = 0u, pos_base = 0u;
+  double k_carry = 0.0;
+  uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
+#pragma unroll
+  for (int ch = 0; ch < RW_CH; ch++) {
+    if (ch < nch) {
+      const bool any = __ballot(marked[ch] != 0u) != 0ull;  // (uniform)
+      if (!any) {
+        lprev_c = 0u;
+      } else {
+        const int p0 = (ch * 64 + lane) * C;
+        const unsigned ge = p0 >= rmin ? FULL : (p0 + C <= rmin ? 0u : (FULL & ~((1u << (rmin - p0)) - 1u)));  // bit i: p >= rmin
+        const unsigned live = marked[ch] & ge;
+        unsigned lprev = dpp_u32<0x138>((live >> (C - 1)) & 1u);  // previous thread's last pixel live
+        unsigned mnext = dpp_u32<0x130>(marked[ch] & 1u);         // next thread's first pixel marked
+        if (lane == 0) lprev = lprev_c;
+        const unsigned next0 = ch + 1 < RW_CH ? (unsigned)__builtin_amdgcn_readlane((int)(marked[ch + 1 < RW_CH ? ch + 1 : ch] & 1u), 0) : 0u;
+        if (lane == 63) mnext = next0;
+        const unsigned start = live & ~(((live << 1) | lprev) & FULL);
+        const unsigned in_row = p0 + C < cols ? FULL : (p0 + 1 >= cols ? 0u : ((1u << (cols - 1 - p0)) - 1u));  // bit i: p + 1 < cols
+        const unsigned close = live & ~((marked[ch] >> 1) | (mnext << (C - 1))) & in_row;
+        const unsigned sloc = start ? (unsigned)(p0 + (31 - __builtin_clz(start)) + 1) : 0u;
+        const unsigned x = wave_incl_max_u32(sloc);
+        unsigned sin = dpp_u32<0x138>(x);
+        sin = s_carry > sin ? s_carry : sin;
+        {
+          const unsigned xt = (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+          s_carry = xt > s_carry ? xt : s_carry;
+        }
+        double kin[C];
+        double run = 0.0;
+        const unsigned sinx = sin | 0x10000u, pbx = (unsigned)p0 + 32u + 0x10000u, c0 = 0x3fffu - ((unsigned)p0 & 0x3fffu);
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          const unsigned below = start & ((2u << i) - 1u);
+          const unsigned spx = below ? pbx - (unsigned)__builtin_clz(below) : sinx;
+          const unsigned hi = __builtin_amdgcn_alignbit(spx, ordh[ch][i], 18);
+          const unsigned lo = (ordh[ch][i] << 14) | (c0 - (unsigned)i);
+          const double kd = __hiloint2double((int)(((live >> i) & 1u) ? hi : 0u), (int)lo);
+          run = kmax(run, kd);
+          kin[i] = run;
+        }
+        const double ki = wave_incl_max<false>(run, lane);
+        const double kx = kmax(dpp_f64<0x138>(ki), k_carry);
+        k_carry = kmax(k_carry, readlane_f64(ki, 63));
+        const unsigned cnt = (unsigned)__popc(close);
+        const unsigned inc = wave_incl_add(cnt, lane);
+        unsigned pos = pos_base + inc - cnt;
+        pos_base += (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          if ((close >> i) & 1u) {
+            const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
+            const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
+            ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
+          }
+        }
+        lprev_c = (unsigned)__builtin_amdgcn_readlane((int)((live >> (C - 1)) & 1u), 63);
+      }
+    }
+  }
+  if (lane == 0) row_nruns[(int64_t)img * rows + a] = pos_base;
 }
 
 // the adjacency test of the method: a closed run yields a keypoint when the azimuth below or above (wrap-around) has a
@@ -1109,7 +1392,7 @@ struct rsx_cen2019 {
   int device = 0, rows = 0, cols = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, row_runs, row_nruns, markbits;
+  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, row_runs, row_nruns, markbits, wavemax;
   rsx::DevBuf one;          // single-scan entry: [count | targets | xy] in one piece, read back with one copy
   void *one_host = nullptr;  // its pinned mirror
   size_t one_host_bytes = 0;
@@ -1135,16 +1418,25 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   hipLaunchKernelGGL(cen_scalars, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, sc, nb, (int64_t)rows * cols);
   const int hrpb = rpb > 1 ? HIST_ROWS : 1;
   hipLaunchKernelGGL((cen_hist<C, NT>), dim3((unsigned)((rows + hrpb - 1) / hrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
-                     stride, off, sc, h->hist.as<unsigned>(), h->opener.as<OpRec<C>>(), hrpb);
+                     stride, off, sc, h->hist.as<unsigned>(), h->opener.as<OpRec<C>>(), h->wavemax.as<unsigned>(), hrpb);
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
   hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<OpRec<C>>(),
                      h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(1024), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
   const int rrpb = rpb > 1 ? RUNS_ROWS : 1;
-  hipLaunchKernelGGL((cen_runs<C, NT>), dim3((unsigned)((rows + rrpb - 1) / rrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
-                     stride, off, sc, p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
-                     h->markbits.as<MarkT<C>>(), rrpb);
+  static const bool block_form = [] { const char *e = rsx::exp_env("RSX_CEN_RUNS"); return e && e[0] == 'b'; }();  // experiments build: RSX_CEN_RUNS=block
+  if constexpr (C == 8 && NT == 64 * RW_CH) {
+    if (!block_form && rpb > 1) {  // a batch: a wavefront per azimuth (cen_runs_wave; a single scan's 400 wavefronts would walk their rows one chunk after the other: 17 us against 7)
+      hipLaunchKernelGGL(cen_runs_wave, dim3((unsigned)((rows + RW_WAVES - 1) / RW_WAVES), (unsigned)nb), dim3(64 * RW_WAVES), 0, s, d_imgs, img_stride,
+                         rows, cols, stride, off, sc, p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
+                         h->markbits.as<MarkT<C>>(), h->wavemax.as<unsigned>());
+    }
+  }
+  if (!(C == 8 && NT == 64 * RW_CH) || block_form || rpb <= 1)
+    hipLaunchKernelGGL((cen_runs<C, NT>), dim3((unsigned)((rows + rrpb - 1) / rrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
+                       stride, off, sc, p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
+                       h->markbits.as<MarkT<C>>(), h->wavemax.as<unsigned>(), rrpb);
   hipLaunchKernelGGL((cen_adjacent<C, NT>), grid, dim3(256), 0, s, rows, cols, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
                      h->markbits.as<MarkT<C>>(), h->row_out.as<int>(), h->row_n.as<unsigned>());
   hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
@@ -1171,6 +1463,7 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
       RSX_TRY(h->markbits.reserve((size_t)n * rows * nt * (cols <= 8 * 512 ? 1 : 2), s, false));
       RSX_TRY(h->row_runs.reserve((size_t)n * rows * row_cap * 8, s, false));
       RSX_TRY(h->row_nruns.reserve((size_t)n * rows * 4, s, false));
+      RSX_TRY(h->wavemax.reserve((size_t)n * rows * (nt / 64) * 4, s, false));  // largest ord(h) per wavefront and row (cen_hist -> cen_runs)
     }
     RSX_HIP(hipMemsetAsync(h->scal.p, 0, (size_t)n * sizeof(Scal), s));
     RSX_HIP(hipMemsetAsync(h->hist.p, 0, (size_t)n * NBIN * 4, s));
@@ -1238,7 +1531,7 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) try {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->one_host) (void)hipHostFree(h->one_host);
   h->one.release();
-  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits}) b->release();
+  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits, &h->wavemax}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
