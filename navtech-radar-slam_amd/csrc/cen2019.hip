@@ -679,6 +679,174 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// cen_hist, ONE WAVEFRONT PER AZIMUTH (round 6; batches, rows of <= 4096 bins; the reasoning of cen_runs_wave below: no
+// barrier per row, no idle eighth wavefront, no scan total through LDS).  A wavefront walks its row in chunks of 512 bins:
+//   forward   bytes -> h, ord(h), sign bits; non-neg prefix counts; the forward maxima F and the comparisons h(p) > F(p - 1);
+//             fixed-point sum of h; the chunk's largest ord(h) (for cen_runs); ord(h), sign bits and counts stay in registers
+//   backward  (last chunk first) the backward maxima G, h(p) >= G(p + 1), the opener bits, their histogram bins (h back
+//             from ord(h): the same bin), the records
+// The scan totals travel from chunk to chunk in SGPRs.  Four azimuths (wavefronts) per workgroup share the 4096-bin LDS
+// histogram and its flush, as HIST_ROWS = 4 did.  Same records, histogram and sums as cen_hist.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int HW_WAVES = 4;  // wavefronts (= azimuths) per workgroup
+constexpr int HW_CH = 8;     // chunks of 512 bins: rows of <= 4096 bins
+#ifndef HW_OCC
+#define HW_OCC 3
+#endif
+__global__ __launch_bounds__(64 * HW_WAVES) __attribute__((amdgpu_waves_per_eu(HW_OCC))) void cen_hist_wave(
+    const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off, Scal *scal, unsigned *__restrict__ hist,
+    OpRec<8> *__restrict__ opener, unsigned *__restrict__ wavemax) {
+  constexpr int C = 8, NTR = 64 * HW_CH;
+  constexpr unsigned FULL = 0xffu;
+  __shared__ RowLds<C, NTR> L;  // (the byte -> float table)
+  __shared__ __attribute__((aligned(16))) unsigned s_hist[NBIN];
+  __shared__ long long s_fix[HW_WAVES];
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int img = blockIdx.y, a = (int)blockIdx.x * HW_WAVES + w;
+  Scal *sc = scal + img;
+  unsigned *gh = hist + (size_t)img * NBIN;
+  const float mean = sc->mean, maxg = __uint_as_float(sc->max_g_bits), rcp_maxg = sc->rcp_maxg;
+  row_table(L);
+  for (int b = threadIdx.x; b < NBIN / 4; b += 64 * HW_WAVES) reinterpret_cast<uint4 *>(s_hist)[b] = uint4{0u, 0u, 0u, 0u};
+  __syncthreads();
+  long long fix = 0;
+  if (a < rows) {  // (wave-uniform)
+    const uint8_t *row = imgs + (int64_t)img * img_stride + (int64_t)a * stride + off;
+    const int nch = (cols + 64 * C - 1) / (64 * C);
+    constexpr float M = 12582912.0f, S = 1048576.0f;  // (cen_hist: the fixed-point sum)
+    unsigned ahi = 0, alo = 0;
+    unsigned neg[HW_CH], excl[HW_CH], cl[HW_CH], ordh[HW_CH][C];
+    unsigned carry_nn = 0;
+    double f_carry = 0.0;
+    // ---- forward ----
+#pragma unroll
+    for (int ch = 0; ch < HW_CH; ch++) {
+      neg[ch] = 0u;
+      excl[ch] = 0u;
+      cl[ch] = 0u;
+#pragma unroll
+      for (int i = 0; i < C; i++) ordh[ch][i] = 0u;
+      if (ch < nch) {  // (uniform)
+        const int p0 = (ch * 64 + lane) * C;
+        float h[C];
+        const bool edge = ch == 0 || (ch + 1) * 64 * C >= cols;
+        row_load_h_at(L, row, cols, mean, maxg, rcp_maxg, h, neg[ch], p0, edge);
+#pragma unroll
+        for (int i = 0; i < C; i++) ordh[ch][i] = ord_f32(h[i] + 0.0f);  // (-0.0) + 0.0 = +0.0
+        if (edge) {
+#pragma unroll
+          for (int i = 0; i < C; i++)
+            if (p0 + i >= cols) ordh[ch][i] = 0u;  // walls
+        }
+        {  // the chunk's largest ord(h), for cen_runs
+          unsigned m = ordh[ch][0];
+#pragma unroll
+          for (int i = 1; i < C; i++) m = ordh[ch][i] > m ? ordh[ch][i] : m;
+          m = wave_max_u32(m);
+          if (lane == 0) wavemax[((int64_t)img * rows + a) * HW_CH + ch] = m;
+        }
+#pragma unroll
+        for (int i = 0; i < C; i++) {  // (past the row end h = 0)
+          const float t = __fmaf_rn(h[i], S, M);
+          ahi += __float_as_uint(t) - 0x4B400000u;
+          const float r = __fmaf_rn(h[i], S, -__fsub_rn(t, M));  // x - rint(x), exact
+          alo += __float_as_uint(__fmaf_rn(r, S, M)) - 0x4B400000u;
+        }
+        if ((ch & 1) || ch + 1 >= nch) {  // (uniform) 16 pixels a lane at most between two sums, as in cen_hist
+          const int fhi = wave_sum_i32((int)ahi), flo = wave_sum_i32((int)alo);
+          fix += ((long long)fhi << 20) + (long long)flo;
+          ahi = alo = 0;
+        }
+        const unsigned nn = ~neg[ch] & FULL;
+        const unsigned cnt = (unsigned)__popc(nn);
+        const unsigned incl = wave_incl_add(cnt, lane);
+        excl[ch] = carry_nn + incl - cnt;
+        carry_nn += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        // forward maxima (row_opens): thread-local, across the lanes, across the chunks
+        double fl[C];
+        double run = 0.0;
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          fl[i] = run;
+          const unsigned seg = excl[ch] + (unsigned)__popc(nn & ((2u << i) - 1u));  // non-neg pixels in [0, p]
+          run = kmax(run, sc_key(seg, ordh[ch][i]));
+        }
+        const double fi = wave_incl_max<false>(run, lane);
+        const double fx = kmax(dpp_f64<0x138>(fi), f_carry);
+        f_carry = kmax(f_carry, readlane_f64(fi, 63));
+        unsigned c = 0;
+#pragma unroll
+        for (int i = C - 1; i >= 0; i--) {
+          const unsigned f = sc_lo(kmax(fx, fl[i]));
+          asm("v_cmp_gt_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(c) : "v"(ordh[ch][i]), "v"(f) : "vcc");  // h(p) >  F(p - 1)
+        }
+        cl[ch] = c;
+      }
+    }
+    // ---- backward ----
+    double b_carry = 0.0;
+#pragma unroll
+    for (int ch = HW_CH - 1; ch >= 0; ch--) {
+      if (ch < nch) {
+        const int p0 = (ch * 64 + lane) * C;
+        const unsigned nn = ~neg[ch] & FULL;
+        double bl[C];
+        double run = 0.0;
+#pragma unroll
+        for (int i = C - 1; i >= 0; i--) {
+          bl[i] = run;
+          const unsigned seg = (unsigned)(NTR * C) + 64u - excl[ch] - (unsigned)__popc(nn & ((1u << i) - 1u));  // a constant minus the non-neg pixels before p: larger to the left
+          run = kmax(run, sc_key(seg, ordh[ch][i]));
+        }
+        const double bi = wave_incl_max<true>(run, lane);
+        const double bx = kmax(dpp_f64<0x130>(bi), b_carry);
+        b_carry = kmax(b_carry, readlane_f64(bi, 0));
+        unsigned cr = 0;
+#pragma unroll
+        for (int i = C - 1; i >= 0; i--) {
+          const unsigned b = sc_lo(kmax(bx, bl[i]));
+          asm("v_cmp_ge_u32_e32 vcc, %1, %2\n\tv_addc_co_u32_e32 %0, vcc, %0, %0, vcc" : "+v"(cr) : "v"(ordh[ch][i]), "v"(b) : "vcc");  // h(p) >= G(p + 1)
+        }
+        unsigned eprev = dpp_u32<0x138>((neg[ch] >> (C - 1)) & 1u);  // previous thread's last pixel neg
+        unsigned enext = dpp_u32<0x130>(neg[ch] & 1u);               // next thread's first pixel neg
+        const unsigned pv = ch > 0 ? (unsigned)__builtin_amdgcn_readlane((int)((neg[ch > 0 ? ch - 1 : 0] >> (C - 1)) & 1u), 63) : 0u;
+        const unsigned nx = ch + 1 < HW_CH ? (unsigned)__builtin_amdgcn_readlane((int)(neg[ch + 1 < HW_CH ? ch + 1 : ch] & 1u), 0) : 0u;
+        if (lane == 0) eprev = pv;
+        if (lane == 63) enext = nx;
+        const unsigned nn_left = ((nn << 1) | (eprev ? 0u : 1u)) & FULL;       // bit i: pixel p - 1 is non-neg
+        const unsigned nn_right = (nn >> 1) | ((enext ? 0u : 1u) << (C - 1));  // bit i: pixel p + 1 is non-neg (past the row end: walls)
+        const unsigned first = p0 == 0 ? 1u : 0u;
+        const unsigned left_ok = first | (nn & nn_left) | cl[ch];
+        const unsigned right_ok = (nn & nn_right) | cr;
+        const unsigned valid = p0 >= cols ? 0u : (p0 + C <= cols ? FULL : ((1u << (cols - p0)) - 1u));
+        const unsigned opens = left_ok & right_ok & valid;
+        int top = 0;
+#pragma unroll
+        for (int i = 0; i < C; i++) {
+          if ((opens >> i) & 1u) {
+            const unsigned o = ordh[ch][i];
+            const float hv = __uint_as_float((o & 0x80000000u) ? (o ^ 0x80000000u) : ~o);  // ord_f32 backwards (-0.0 came in as +0.0: the same bin)
+            const int b = h_bin(hv);
+            atomicAdd(&s_hist[b], 1u);
+            top = b + 1 > top ? b + 1 : top;
+          }
+        }
+        if (p0 < cols) opener[((int64_t)img * rows + a) * NTR + ch * 64 + lane] = (OpRec<C>)(opens | ((unsigned)((top + 31) >> 5) << kTopShift<C>));
+      }
+    }
+  }
+  if (lane == 0) s_fix[w] = fix;
+  __syncthreads();
+  for (int b = threadIdx.x; b < NBIN; b += 64 * HW_WAVES)
+    if (s_hist[b]) atomicAdd(&gh[b], s_hist[b]);
+  if (threadIdx.x == 0) {
+    long long f = 0;
+    for (int ww = 0; ww < HW_WAVES; ww++) f += s_fix[ww];
+    atomicAdd(reinterpret_cast<unsigned long long *>(&sc->fix_sum), (unsigned long long)f);
+  }
+}
+
 // one block of 256 threads per image: the bin of the max_points-th opener
 __global__ __launch_bounds__(256) void cen_pick(Scal *scal, const unsigned *__restrict__ hist, int max_points) {
   constexpr int NT = 256;
@@ -1417,8 +1585,18 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
     hipLaunchKernelGGL((cen_stats<C, NT, 1>), dim3((unsigned)rows, (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
   hipLaunchKernelGGL(cen_scalars, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, sc, nb, (int64_t)rows * cols);
   const int hrpb = rpb > 1 ? HIST_ROWS : 1;
-  hipLaunchKernelGGL((cen_hist<C, NT>), dim3((unsigned)((rows + hrpb - 1) / hrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
-                     stride, off, sc, h->hist.as<unsigned>(), h->opener.as<OpRec<C>>(), h->wavemax.as<unsigned>(), hrpb);
+  static const bool hist_block_form = [] { const char *e = rsx::exp_env("RSX_CEN_HIST"); return e && e[0] == 'b'; }();  // experiments build: RSX_CEN_HIST=block
+  bool hist_done = false;
+  if constexpr (C == 8 && NT == 64 * HW_CH) {
+    if (!hist_block_form && rpb > 1) {  // a batch: a wavefront per azimuth
+      hipLaunchKernelGGL(cen_hist_wave, dim3((unsigned)((rows + HW_WAVES - 1) / HW_WAVES), (unsigned)nb), dim3(64 * HW_WAVES), 0, s, d_imgs, img_stride,
+                         rows, cols, stride, off, sc, h->hist.as<unsigned>(), h->opener.as<OpRec<C>>(), h->wavemax.as<unsigned>());
+      hist_done = true;
+    }
+  }
+  if (!hist_done)
+    hipLaunchKernelGGL((cen_hist<C, NT>), dim3((unsigned)((rows + hrpb - 1) / hrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
+                       stride, off, sc, h->hist.as<unsigned>(), h->opener.as<OpRec<C>>(), h->wavemax.as<unsigned>(), hrpb);
   hipLaunchKernelGGL(cen_pick, dim3((unsigned)nb), dim3(256), 0, s, sc, h->hist.as<unsigned>(), p.max_points);
   hipLaunchKernelGGL((cen_collect<C, NT>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->opener.as<OpRec<C>>(),
                      h->list.as<unsigned long long>(), (int64_t)rows * cols, rpb);

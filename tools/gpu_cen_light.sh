@@ -3,7 +3,7 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 (timeout 900 python -m pytest tests/test_gpu_cen2019.py tests/test_gpu_odometry.py -x -q 2>&1 | tail -15) > gpurun_out/gpu_tests_cen.log 2>&1
 tail -6 gpurun_out/gpu_tests_cen.log
-for lib in "" abtest/librsx_cen_o5.so abtest/librsx_cen_o3.so "" abtest/librsx_pmcbase.so; do
+for lib in "" abtest/librsx_pmcbase.so "" abtest/librsx_pmcbase.so; do
   echo "== lib: ${lib:-product}"
   if [ -n "$lib" ]; then export RSX_LIB_PATH=$PWD/$lib; else unset RSX_LIB_PATH; fi
   timeout 300 python tools/bench_cen2019.py 20 64 2>&1 | grep -v amdgpu.ids
