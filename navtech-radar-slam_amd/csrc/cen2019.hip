@@ -1477,23 +1477,24 @@ __global__ __launch_bounds__(64 * RW_WAVES) __attribute__((amdgpu_waves_per_eu(R
 // the adjacency test of the method: a closed run yields a keypoint when the azimuth below or above (wrap-around) has a
 // marked pixel inside the run's range span.  One block per (azimuth, image) over the runs cen_runs recorded and the mark
 // bits of the two neighbours (C bits per chunk); ordered compaction of the survivors' arg-max bins.
+// (Round 6: a WAVEFRONT per azimuth, four azimuths per workgroup -- a row has a few dozen runs; the workgroup per azimuth staged the
+// neighbours' 2 x 420 mark bytes in LDS behind a barrier and compacted through two more: 29 us per 64 scans for 1.3 M runs.)
+constexpr int ADJ_WAVES = 4;
 template <int C, int NT>
-__global__ __launch_bounds__(256) void cen_adjacent(int rows, int cols, int row_cap, const uint2 *__restrict__ row_runs,
-                                                    const unsigned *__restrict__ row_nruns, const MarkT<C> *__restrict__ markbits,
-                                                    int *__restrict__ row_out, unsigned *__restrict__ row_n) {
-  __shared__ unsigned short s_nb[NT];  // marks of the two neighbours, OR-ed
-  __shared__ unsigned s_w[4];
-  const int a = blockIdx.x, img = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(64 * ADJ_WAVES) void cen_adjacent(int rows, int cols, int row_cap, const uint2 *__restrict__ row_runs,
+                                                               const unsigned *__restrict__ row_nruns, const MarkT<C> *__restrict__ markbits,
+                                                               int *__restrict__ row_out, unsigned *__restrict__ row_n) {
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int a = (int)blockIdx.x * ADJ_WAVES + w, img = blockIdx.y;
+  if (a >= rows) return;  // (wave-uniform; no barrier in this kernel)
   const MarkT<C> *below = markbits + ((int64_t)img * rows + (a - 1 + rows) % rows) * NT;
   const MarkT<C> *above = markbits + ((int64_t)img * rows + (a + 1) % rows) * NT;
-  for (int t = threadIdx.x; t < NT; t += 256) s_nb[t] = t * C < cols ? (unsigned short)(below[t] | above[t]) : (unsigned short)0;  // (chunks past the row's end were not written)
-  __syncthreads();
-  const unsigned n = row_nruns[(int64_t)img * rows + a];
+  const unsigned n = (unsigned)__builtin_amdgcn_readfirstlane((int)row_nruns[(int64_t)img * rows + a]);
   const uint2 *runs = row_runs + ((int64_t)img * rows + a) * row_cap;
   int *ro = row_out + ((int64_t)img * rows + a) * row_cap;
   unsigned done = 0;
-  for (unsigned base = 0; base < n; base += 256) {
-    const unsigned j = base + threadIdx.x;
+  for (unsigned base = 0; base < n; base += 64) {
+    const unsigned j = base + (unsigned)lane;
     bool keep = false;
     int arg = 0;
     if (j < n) {
@@ -1503,22 +1504,15 @@ __global__ __launch_bounds__(256) void cen_adjacent(int rows, int cols, int row_
       for (int wd = first / C; wd <= last / C && !keep; wd++) {
         const int lo = wd == first / C ? first % C : 0, hi = wd == last / C ? last % C : C - 1;
         const unsigned mask = ((1u << (hi + 1)) - 1u) & ~((1u << lo) - 1u);
-        keep = (s_nb[wd] & mask) != 0;
+        const unsigned nb = wd * C < cols ? (unsigned)below[wd] | (unsigned)above[wd] : 0u;  // (chunks past the row's end were not written)
+        keep = (nb & mask) != 0;
       }
     }
     const unsigned long long bal = __ballot(keep);
-    if (lane == 0) s_w[wave] = (unsigned)__popcll(bal);
-    __syncthreads();
-    unsigned before = done, total = 0;
-    for (int w = 0; w < 4; w++) {
-      if (w < wave) before += s_w[w];
-      total += s_w[w];
-    }
-    if (keep) ro[before + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = arg;
-    done += total;
-    __syncthreads();
+    if (keep) ro[done + (unsigned)__popcll(bal & ((1ull << lane) - 1ull))] = arg;
+    done += (unsigned)__popcll(bal);
   }
-  if (threadIdx.x == 0) row_n[(int64_t)img * rows + a] = done;
+  if (lane == 0) row_n[(int64_t)img * rows + a] = done;
 }
 
 // one wavefront per (azimuth, image): row-major packing of the rows' keypoints, polar -> Cartesian
@@ -1615,7 +1609,7 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
     hipLaunchKernelGGL((cen_runs<C, NT>), dim3((unsigned)((rows + rrpb - 1) / rrpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols,
                        stride, off, sc, p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
                        h->markbits.as<MarkT<C>>(), h->wavemax.as<unsigned>(), rrpb);
-  hipLaunchKernelGGL((cen_adjacent<C, NT>), grid, dim3(256), 0, s, rows, cols, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
+  hipLaunchKernelGGL((cen_adjacent<C, NT>), dim3((unsigned)((rows + ADJ_WAVES - 1) / ADJ_WAVES), (unsigned)nb), dim3(64 * ADJ_WAVES), 0, s, rows, cols, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
                      h->markbits.as<MarkT<C>>(), h->row_out.as<int>(), h->row_n.as<unsigned>());
   hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
                      resolution, max_targets, d_targets, d_xy, d_counts);
