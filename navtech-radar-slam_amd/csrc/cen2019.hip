@@ -683,7 +683,8 @@ __global__ __launch_bounds__(NT) void cen_hist(const uint8_t *__restrict__ imgs,
 // cen_hist, ONE WAVEFRONT PER AZIMUTH (round 6; batches, rows of <= 4096 bins; the reasoning of cen_runs_wave below: no
 // barrier per row, no idle eighth wavefront, no scan total through LDS).  A wavefront walks its row in chunks of 512 bins:
 //   forward   bytes -> h, ord(h), sign bits; non-neg prefix counts; the forward maxima F and the comparisons h(p) > F(p - 1);
-//             fixed-point sum of h; the chunk's largest ord(h) (for cen_runs); ord(h), sign bits and counts stay in registers
+//             fixed-point sum of h; per thread the sign bits and the bin of its largest h (for cen_runs_wave); ord(h), sign bits
+//             and counts stay in registers
 //   backward  (last chunk first) the backward maxima G, h(p) >= G(p + 1), the opener bits, their histogram bins (h back
 //             from ord(h): the same bin), the records
 // The scan totals travel from chunk to chunk in SGPRs.  Four azimuths (wavefronts) per workgroup share the 4096-bin LDS
@@ -696,7 +697,7 @@ constexpr int HW_CH = 8;     // chunks of 512 bins: rows of <= 4096 bins
 #endif
 __global__ __launch_bounds__(64 * HW_WAVES) __attribute__((amdgpu_waves_per_eu(HW_OCC))) void cen_hist_wave(
     const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride, int off, Scal *scal, unsigned *__restrict__ hist,
-    OpRec<8> *__restrict__ opener, unsigned *__restrict__ wavemax) {
+    OpRec<8> *__restrict__ opener, unsigned short *__restrict__ negmax) {
   constexpr int C = 8, NTR = 64 * HW_CH;
   constexpr unsigned FULL = 0xffu;
   __shared__ RowLds<C, NTR> L;  // (the byte -> float table)
@@ -738,13 +739,6 @@ __global__ __launch_bounds__(64 * HW_WAVES) __attribute__((amdgpu_waves_per_eu(H
 #pragma unroll
           for (int i = 0; i < C; i++)
             if (p0 + i >= cols) ordh[ch][i] = 0u;  // walls
-        }
-        {  // the chunk's largest ord(h), for cen_runs
-          unsigned m = ordh[ch][0];
-#pragma unroll
-          for (int i = 1; i < C; i++) m = ordh[ch][i] > m ? ordh[ch][i] : m;
-          m = wave_max_u32(m);
-          if (lane == 0) wavemax[((int64_t)img * rows + a) * HW_CH + ch] = m;
         }
 #pragma unroll
         for (int i = 0; i < C; i++) {  // (past the row end h = 0)
@@ -831,6 +825,15 @@ __global__ __launch_bounds__(64 * HW_WAVES) __attribute__((amdgpu_waves_per_eu(H
             atomicAdd(&s_hist[b], 1u);
             top = b + 1 > top ? b + 1 : top;
           }
+        }
+        if (p0 < cols) {  // for cen_runs_wave: the chunk's sign bits and how high its h reaches (histogram bin / 16 of the largest h:
+                          // monotone in h), 2 bytes per 8 pixels -- cen_runs_wave looks at the image bytes of the few threads
+                          // that can hold a hit only
+          unsigned m = ordh[ch][0];
+#pragma unroll
+          for (int i = 1; i < C; i++) m = ordh[ch][i] > m ? ordh[ch][i] : m;
+          const float hm = __uint_as_float((m & 0x80000000u) ? (m ^ 0x80000000u) : ~m);  // ord_f32 backwards
+          negmax[((int64_t)img * rows + a) * NTR + ch * 64 + lane] = (unsigned short)(neg[ch] | ((unsigned)(h_bin(hm) >> 4) << 8));
         }
         if (p0 < cols) opener[((int64_t)img * rows + a) * NTR + ch * 64 + lane] = (OpRec<C>)(opens | ((unsigned)((top + 31) >> 5) << kTopShift<C>));
       }
@@ -1293,97 +1296,142 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 512 ? 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// cen_runs, ONE WAVEFRONT PER AZIMUTH (round 6; rows of <= 4096 bins).  The workgroup-per-azimuth form above is one chain of
+// cen_runs, ONE WAVEFRONT PER AZIMUTH (round 6; batches, rows of <= 4096 bins).  The workgroup-per-azimuth form above is one chain of
 // six barriers per row and every scan crosses its eight wavefronts through LDS; since a wavefront that holds no hit has
 // nearly nothing to do (light path), its row time was the time of the busiest wavefront and the others waited (counters:
 // 17 % fewer vector instructions, SQ_WAIT_ANY up by the same cycles, the same 174 us).  Here a wavefront walks ITS row in
 // chunks of 512 bins, the scans' totals travel from chunk to chunk in SGPRs, the run flags live in the wavefront's own
-// 4 KB of LDS -- no barrier after the table, no idle eighth wavefront, and a chunk below the limit costs its sign bits.
-//   pass 1 (all chunks)  sign bits, ord(h) (chunks that can hold a hit), non-neg prefix counts, hits -> run flags
-//   pass 2a              marks (flag reads), mark bits to HBM
-//   pass 2b              closed runs: the three scans chunk by chunk, chunks without a mark skipped
-// Same records, same mark bits as cen_runs, which stays for rows wider than 4096 bins (tests/test_gpu_cen2019.py: MulRan shape and
-// the odd shapes through this kernel, test_wide_rows through the block form) and for A / B runs (RSX_CEN_RUNS=block, experiments build).
+// 4 KB of LDS -- no barrier after the table, no idle eighth wavefront.  And it does not read the image: cen_hist_wave left,
+// per thread (8 bins), the sign bits and the histogram bin / 16 of its largest h; hits are sparse (0.7 % of the pixels, ~14 of
+// a row's 420 threads can hold one), so the threads whose record reaches the limit's bin are COMPACTED -- a list in the
+// wavefront's LDS -- and one pass of 64 lanes evaluates h for the candidates of the whole row (more than 64: further passes)
+// where the chunk-wise form ran the full evaluation for 70 % of the chunks.
+//   pass 1a (all chunks)  records -> sign bits, non-neg prefix counts, the candidate list
+//   pass 1b               h, ord(h), hits of the listed threads -> run flags; results back to their owners through LDS
+//   pass 2a               marks (flag reads), mark bits to HBM
+//   pass 2b               closed runs: the three scans chunk by chunk, chunks without a mark skipped
+// Same records, same mark bits as cen_runs, which stays for single scans and rows wider than 4096 bins (tests/test_gpu_cen2019.py:
+// batches through this kernel, single scans and test_wide_rows through the block form) and for A / B runs (RSX_CEN_RUNS=block,
+// experiments build).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int RW_WAVES = 4;             // wavefronts (= azimuths) per workgroup
 constexpr int RW_CH = 8;                // chunks of 512 bins: rows of <= 4096 bins
 constexpr int RW_FLAGS = 4096 + 64;     // run flags of one wavefront (a run's number = the non-neg pixels before it <= 4096 + walls)
+struct RwLds {                          // one wavefront's
+  uint8_t flags[RW_FLAGS];
+  unsigned short list[64 * RW_CH];      // candidate threads (chunk * 64 + lane), in row order
+  unsigned cexcl[64 * RW_CH];           // their non-neg prefix counts
+  unsigned res[64][9 + 1];              // one pass of 64 candidates: hit bits, ord(h) of the 8 pixels (+ 1: bank spread)
+};
 #ifndef RW_OCC
-#define RW_OCC 4  // waves per SIMD the register budget is cut for
+#define RW_OCC 3  // waves per SIMD the register budget is cut for (4: spills; 3, 4, 5 measured alike before the candidate list)
 #endif
 __global__ __launch_bounds__(64 * RW_WAVES) __attribute__((amdgpu_waves_per_eu(RW_OCC))) void cen_runs_wave(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
                                                                 int off, Scal *scal, int min_range, int row_cap, uint2 *__restrict__ row_runs,
                                                                 unsigned *__restrict__ row_nruns, MarkT<8> *__restrict__ markbits,
-                                                                const unsigned *__restrict__ wavemax) {
+                                                                const unsigned short *__restrict__ negmax) {
   constexpr int C = 8, NTR = 64 * RW_CH;  // NTR: chunks (threads of the block form) a row's records are laid out for
   constexpr unsigned FULL = 0xffu;
   __shared__ RowLds<C, NTR> L;  // (the byte -> float table)
-  __shared__ __attribute__((aligned(16))) uint8_t s_flags[RW_WAVES][RW_FLAGS];
+  __shared__ __attribute__((aligned(16))) RwLds s_w[RW_WAVES];
   const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int img = blockIdx.y, a = (int)blockIdx.x * RW_WAVES + w;
   Scal *sc = scal + img;
   const float mean = sc->mean, maxg = __uint_as_float(sc->max_g_bits), rcp_maxg = sc->rcp_maxg;
   const unsigned long long klimit = sc->klimit;
   row_table(L);
-  const unsigned ord_min = ~(unsigned)(klimit >> 32);
-  const unsigned neg_T = (unsigned)__syncthreads_count(L.tab[threadIdx.x] < mean);  // (256 threads: a thread reads the entry it wrote)
+  __syncthreads();
   if (a >= rows) return;  // (wave-uniform; no barrier below)
+  // a pixel can be a hit (key < limit) only with ord(h) >= ~(limit >> 32), i.e. h >= the limit's h, i.e. (h_bin is monotone) with
+  // its bin >= the limit's: the candidate threads are those whose record reaches bin / 16 of the limit (a NaN pattern gives 0: all)
+  const unsigned ord_min = ~(unsigned)(klimit >> 32);
+  const unsigned t8 = (unsigned)h_bin(__uint_as_float((ord_min & 0x80000000u) ? (ord_min ^ 0x80000000u) : ~ord_min)) >> 4;
   const uint8_t *row = imgs + (int64_t)img * img_stride + off + (int64_t)a * stride;
   const int nch = (cols + 64 * C - 1) / (64 * C);
-  uint8_t *s_run = s_flags[w];
+  RwLds &W = s_w[w];
+  uint8_t *s_run = W.flags;
   for (int i = lane; i < RW_FLAGS / 16; i += 64) reinterpret_cast<uint4 *>(s_run)[i] = uint4{0u, 0u, 0u, 0u};
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
-  // ---- pass 1 ----
+  // ---- pass 1a ----
   unsigned neg[RW_CH], hit[RW_CH], excl[RW_CH], ordh[RW_CH][C];
-  unsigned carry_nn = 0;
-  unsigned long long any_flag = 0ull;
+  int slot[RW_CH];  // this thread's place in the candidate list (-1: not a candidate)
+  unsigned carry_nn = 0, n_cand = 0;
+  const unsigned short *recs = negmax + ((int64_t)img * rows + a) * NTR;
 #pragma unroll
   for (int ch = 0; ch < RW_CH; ch++) {
     neg[ch] = 0u;
     hit[ch] = 0u;
     excl[ch] = 0u;
+    slot[ch] = -1;
 #pragma unroll
     for (int i = 0; i < C; i++) ordh[ch][i] = 0u;
     if (ch < nch) {  // (uniform)
       const int p0 = (ch * 64 + lane) * C;
-      const bool light = (unsigned)__builtin_amdgcn_readfirstlane((int)wavemax[((int64_t)img * rows + a) * RW_CH + ch]) < ord_min;
-      if (light) {
-        neg[ch] = row_load_neg<C>(row, cols, neg_T, p0);
-      } else {
-        float h[C];
-        const bool edge = ch == 0 || (ch + 1) * 64 * C >= cols;
-        row_load_h_at(L, row, cols, mean, maxg, rcp_maxg, h, neg[ch], p0, edge);
-#pragma unroll
-        for (int i = 0; i < C; i++) ordh[ch][i] = ord_f32(h[i] + 0.0f);  // (-0.0) + 0.0 = +0.0
-        if (edge) {
-#pragma unroll
-          for (int i = 0; i < C; i++)
-            if (p0 + i >= cols) ordh[ch][i] = 0u;  // walls
-        }
-      }
+      const unsigned rec = p0 < cols ? (unsigned)recs[ch * 64 + lane] : 0u;  // (threads past the row's end wrote nothing: walls, not neg)
+      neg[ch] = rec & FULL;
       const unsigned nn = ~neg[ch] & FULL;
       const unsigned cnt = (unsigned)__popc(nn);
       const unsigned incl = wave_incl_add(cnt, lane);
       excl[ch] = carry_nn + incl - cnt;
       carry_nn += (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-      if (!light) {
-        const unsigned pix0 = (unsigned)a * (unsigned)cols + (unsigned)p0;
-#pragma unroll
-        for (int i = 0; i < C; i++) {
-          const unsigned long long key = ((unsigned long long)(~ordh[ch][i]) << 32) | (unsigned long long)(pix0 + (unsigned)i);
-          if (key < klimit) {
-            hit[ch] |= 1u << i;
-            const unsigned c = excl[ch] + (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels before p = the number of the run p is in / that ends at p
-            s_run[c] = 1;                                // a neg pixel: its own run; a non-neg pixel: the run on its left ...
-            if ((nn >> i) & 1u) s_run[c + 1] = 1;        // ... and the run on its right
-          }
-        }
-        any_flag |= __ballot(hit[ch] != 0u);
+      const bool cand = p0 < cols && (rec >> 8) >= t8;
+      const unsigned long long cm = __ballot(cand);
+      if (cand) {
+        slot[ch] = (int)(n_cand + (unsigned)__popcll(cm & ((1ull << lane) - 1ull)));
+        W.list[slot[ch]] = (unsigned short)(ch * 64 + lane);
+        W.cexcl[slot[ch]] = excl[ch];
       }
+      n_cand += (unsigned)__popcll(cm);
     }
   }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wavefront's own LDS stores, in order: the flags are readable)
+  n_cand = (unsigned)__builtin_amdgcn_readfirstlane((int)n_cand);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the wavefront's own LDS stores, in order)
+
+  // ---- pass 1b: the listed threads, 64 per pass ----
+  unsigned long long any_flag = 0ull;
+  for (unsigned base = 0; base < n_cand; base += 64) {  // (uniform)
+    const unsigned idx = base + (unsigned)lane;
+    if (idx < n_cand) {
+      const int t = (int)W.list[idx];
+      const int p0 = t * C;
+      const unsigned ex = W.cexcl[idx];
+      float h[C];
+      unsigned ng;
+      row_load_h_at(L, row, cols, mean, maxg, rcp_maxg, h, ng, p0, true);  // (edge rules under their own per-lane conditions)
+      const unsigned nn = ~ng & FULL;
+      const unsigned pix0 = (unsigned)a * (unsigned)cols + (unsigned)p0;
+      unsigned hb = 0;
+#pragma unroll
+      for (int i = 0; i < C; i++) {
+        unsigned o = ord_f32(h[i] + 0.0f);  // (-0.0) + 0.0 = +0.0
+        if (p0 + i >= cols) o = 0u;         // walls
+        W.res[lane][1 + i] = o;
+        const unsigned long long key = ((unsigned long long)(~o) << 32) | (unsigned long long)(pix0 + (unsigned)i);
+        if (key < klimit) {
+          hb |= 1u << i;
+          const unsigned c = ex + (unsigned)__popc(nn & ((1u << i) - 1u));  // non-neg pixels before p = the number of the run p is in / that ends at p
+          s_run[c] = 1;                                // a neg pixel: its own run; a non-neg pixel: the run on its left ...
+          if ((nn >> i) & 1u) s_run[c + 1] = 1;        // ... and the run on its right
+        }
+      }
+      W.res[lane][0] = hb;
+      any_flag |= __ballot(hb != 0u);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // back to the owners: thread (ch, lane) with a slot in this pass
+#pragma unroll
+    for (int ch = 0; ch < RW_CH; ch++) {
+      const int sl = slot[ch] - (int)base;
+      if (sl >= 0 && sl < 64) {
+        hit[ch] = W.res[sl][0];
+#pragma unroll
+        for (int i = 0; i < C; i++) ordh[ch][i] = W.res[sl][1 + i];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the next pass overwrites the slots)
+  }
+  any_flag = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(any_flag >> 32)) << 32) |
+             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)any_flag);
 
   // ---- pass 2a: marks ----
   unsigned marked[RW_CH];
@@ -1516,11 +1564,13 @@ __global__ __launch_bounds__(64 * ADJ_WAVES) void cen_adjacent(int rows, int col
 }
 
 // one wavefront per (azimuth, image): row-major packing of the rows' keypoints, polar -> Cartesian
-__global__ __launch_bounds__(64) void cen_pack(Scal *scal, int rows, int row_cap, const int *__restrict__ row_out,
-                                               const unsigned *__restrict__ row_n, const float *__restrict__ az, int64_t az_stride,
-                                               float resolution, int max_targets, int *__restrict__ targets, float *__restrict__ xy,
-                                               int *__restrict__ counts) {
-  const int a = blockIdx.x, img = blockIdx.y, lane = threadIdx.x;
+constexpr int PACK_WAVES = 4;  // azimuths per workgroup
+__global__ __launch_bounds__(64 * PACK_WAVES) void cen_pack(Scal *scal, int rows, int row_cap, const int *__restrict__ row_out,
+                                                            const unsigned *__restrict__ row_n, const float *__restrict__ az, int64_t az_stride,
+                                                            float resolution, int max_targets, int *__restrict__ targets, float *__restrict__ xy,
+                                                            int *__restrict__ counts) {
+  const int a = (int)blockIdx.x * PACK_WAVES + (int)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), img = blockIdx.y, lane = threadIdx.x & 63;
+  if (a >= rows) return;  // (wave-uniform; no barrier in this kernel)
   const unsigned *rn = row_n + (int64_t)img * rows;
   unsigned before = 0;
   for (int r = lane; r < a; r += 64) before += rn[r];
@@ -1554,7 +1604,7 @@ struct rsx_cen2019 {
   int device = 0, rows = 0, cols = 0;
   std::mutex mu;
   hipStream_t stream = nullptr;
-  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, row_runs, row_nruns, markbits, wavemax;
+  rsx::DevBuf img, scal, hist, list, row_out, row_n, targets, xy, az, counts, opener, row_runs, row_nruns, markbits, wavemax, negmax;
   rsx::DevBuf one;          // single-scan entry: [count | targets | xy] in one piece, read back with one copy
   void *one_host = nullptr;  // its pinned mirror
   size_t one_host_bytes = 0;
@@ -1584,7 +1634,7 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   if constexpr (C == 8 && NT == 64 * HW_CH) {
     if (!hist_block_form && rpb > 1) {  // a batch: a wavefront per azimuth
       hipLaunchKernelGGL(cen_hist_wave, dim3((unsigned)((rows + HW_WAVES - 1) / HW_WAVES), (unsigned)nb), dim3(64 * HW_WAVES), 0, s, d_imgs, img_stride,
-                         rows, cols, stride, off, sc, h->hist.as<unsigned>(), h->opener.as<OpRec<C>>(), h->wavemax.as<unsigned>());
+                         rows, cols, stride, off, sc, h->hist.as<unsigned>(), h->opener.as<OpRec<C>>(), h->negmax.as<unsigned short>());
       hist_done = true;
     }
   }
@@ -1602,7 +1652,7 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
     if (!block_form && rpb > 1) {  // a batch: a wavefront per azimuth (cen_runs_wave; a single scan's 400 wavefronts would walk their rows one chunk after the other: 17 us against 7)
       hipLaunchKernelGGL(cen_runs_wave, dim3((unsigned)((rows + RW_WAVES - 1) / RW_WAVES), (unsigned)nb), dim3(64 * RW_WAVES), 0, s, d_imgs, img_stride,
                          rows, cols, stride, off, sc, p.min_range, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
-                         h->markbits.as<MarkT<C>>(), h->wavemax.as<unsigned>());
+                         h->markbits.as<MarkT<C>>(), h->negmax.as<unsigned short>());
     }
   }
   if (!(C == 8 && NT == 64 * RW_CH) || block_form || rpb <= 1)
@@ -1611,7 +1661,7 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
                        h->markbits.as<MarkT<C>>(), h->wavemax.as<unsigned>(), rrpb);
   hipLaunchKernelGGL((cen_adjacent<C, NT>), dim3((unsigned)((rows + ADJ_WAVES - 1) / ADJ_WAVES), (unsigned)nb), dim3(64 * ADJ_WAVES), 0, s, rows, cols, row_cap, h->row_runs.as<uint2>(), h->row_nruns.as<unsigned>(),
                      h->markbits.as<MarkT<C>>(), h->row_out.as<int>(), h->row_n.as<unsigned>());
-  hipLaunchKernelGGL(cen_pack, grid, dim3(64), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
+  hipLaunchKernelGGL(cen_pack, dim3((unsigned)((rows + PACK_WAVES - 1) / PACK_WAVES), (unsigned)nb), dim3(64 * PACK_WAVES), 0, s, sc, rows, row_cap, h->row_out.as<int>(), h->row_n.as<unsigned>(), d_az, az_stride,
                      resolution, max_targets, d_targets, d_xy, d_counts);
 }
 
@@ -1636,6 +1686,7 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
       RSX_TRY(h->row_runs.reserve((size_t)n * rows * row_cap * 8, s, false));
       RSX_TRY(h->row_nruns.reserve((size_t)n * rows * 4, s, false));
       RSX_TRY(h->wavemax.reserve((size_t)n * rows * (nt / 64) * 4, s, false));  // largest ord(h) per wavefront and row (cen_hist -> cen_runs)
+      RSX_TRY(h->negmax.reserve((size_t)n * rows * nt * 2, s, false));           // sign bits | bin / 16 of the largest h per thread (cen_hist_wave -> cen_runs_wave)
     }
     RSX_HIP(hipMemsetAsync(h->scal.p, 0, (size_t)n * sizeof(Scal), s));
     RSX_HIP(hipMemsetAsync(h->hist.p, 0, (size_t)n * NBIN * 4, s));
@@ -1703,7 +1754,7 @@ int rsx_cen2019_destroy(rsx_cen2019 *h) try {
   if (h->stream) (void)hipStreamSynchronize(h->stream);
   if (h->one_host) (void)hipHostFree(h->one_host);
   h->one.release();
-  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits, &h->wavemax}) b->release();
+  for (rsx::DevBuf *b : {&h->img, &h->scal, &h->hist, &h->list, &h->row_out, &h->row_n, &h->targets, &h->xy, &h->az, &h->counts, &h->opener, &h->row_runs, &h->row_nruns, &h->markbits, &h->wavemax, &h->negmax}) b->release();
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
   return RSX_OK;
