@@ -473,6 +473,15 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {  // (uniform) the
             mx((unsigned)__builtin_amdgcn_readlane((int)x, 32), (unsigned)__builtin_amdgcn_readlane((int)x, 48)));
 }
 
+__device__ __forceinline__ unsigned long long dev_wave_max_u64(unsigned long long v) {  // (rare paths: shuffles)
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    const unsigned long long x = ((unsigned long long)(unsigned)__shfl_xor((int)(unsigned)(v >> 32), o) << 32) | (unsigned long long)(unsigned)__shfl_xor((int)(unsigned)v, o);
+    v = x > v ? x : v;
+  }
+  return v;
+}
+
 // facts of the thread's C pixels of one row; pixels past the row end are walls: non-neg, below every h
 template <int C>
 struct RowChunk {
@@ -1461,6 +1470,12 @@ __global__ __launch_bounds__(64 * RW_WAVES) __attribute__((amdgpu_waves_per_eu(R
   unsigned lprev_c = 0u, s_carry = 0u, pos_base = 0u;
   double k_carry = 0.0;
   uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
+  // A run's arg-max is exact as long as the run holds a hit (a hit's h is known and beats every other pixel of its run; among
+  // equals the hit has the lower bin).  Every run of MARKED pixels holds one -- but the part of it at r >= min_range may not
+  // (a dark stretch flagged by a bright pixel below min_range): such a record is recognised by its key (ord(h) below the
+  // limit's) and redone from the image bytes after the scans, all 64 lanes on that one run.  At most one per row.
+  unsigned fix_pos = 0u, fix_span = 0u;
+  bool fix = false;
 #pragma unroll
   for (int ch = 0; ch < RW_CH; ch++) {
     if (ch < nch) {
@@ -1512,6 +1527,11 @@ __global__ __launch_bounds__(64 * RW_WAVES) __attribute__((amdgpu_waves_per_eu(R
           if ((close >> i) & 1u) {
             const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
             const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
+            if ((unsigned)(k >> 14) < ord_min) {  // (no hit in [first, last]: see above)
+              fix = true;
+              fix_pos = pos;
+              fix_span = first | ((unsigned)(p0 + i) << 16);
+            }
             ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
           }
         }
@@ -1520,6 +1540,19 @@ __global__ __launch_bounds__(64 * RW_WAVES) __attribute__((amdgpu_waves_per_eu(R
     }
   }
   if (lane == 0) row_nruns[(int64_t)img * rows + a] = pos_base;
+  for (unsigned long long fm = __ballot(fix); fm != 0ull; fm &= fm - 1ull) {  // (uniform)
+    const int src = __ffsll((long long)fm) - 1;
+    const unsigned span = (unsigned)__builtin_amdgcn_readlane((int)fix_span, src), at = (unsigned)__builtin_amdgcn_readlane((int)fix_pos, src);
+    const int first = (int)(span & 0xffffu), last = (int)(span >> 16);
+    unsigned long long best = 0ull;  // ord(h) << 32 | ~bin: the largest h, among equals the lowest bin
+    for (int q = first + lane; q <= last; q += 64) {
+      const unsigned o = ord_f32(pixel_h(row, cols, q, mean, maxg, rcp_maxg) + 0.0f);
+      const unsigned long long kq = ((unsigned long long)o << 32) | (unsigned long long)(~(unsigned)q);
+      best = kq > best ? kq : best;
+    }
+    best = dev_wave_max_u64(best);
+    if (lane == 0) ro[at].y = ~(unsigned)best;
+  }
 }
 
 // the adjacency test of the method: a closed run yields a keypoint when the azimuth below or above (wrap-around) has a

@@ -134,3 +134,53 @@ def test_large_batch_of_an_odd_shape(cen, oracle):
         for b in range(nb):
             want = oracle.cen2019_extract(imgs[b], col_offset=0, max_points=mp, min_range=2)
             assert np.array_equal(tg[b], want), (mp, b, len(tg[b]), len(want))
+
+
+def test_wavefront_per_azimuth_forms(cen, oracle):
+    """Batches of rows x images >= 8192 with rows of <= 4096 bins take cen_hist_wave / cen_runs_wave (a wavefront per azimuth, the
+    row in chunks of 512 bins, scan totals carried between the chunks, the candidate threads of a row compacted into one pass).
+    What those kernels can get wrong that the block forms cannot: runs and maxima that cross a chunk boundary, a run cut at
+    min_range whose arg-max lies in a thread without a hit, more than 64 candidate threads in a row (several passes of the
+    compacted evaluation), saturated plateaus (thousands of tied hits: every thread of a chunk a candidate), long dark
+    stretches flagged by one bright pixel at their end, rows whose last chunk holds a few bins only, 4096-bin rows (eight
+    full chunks, no walls) -- every image bit-identical to the oracle, at two budgets and three min_range values."""
+    rng = np.random.default_rng(77)
+    for rows, cols, nb in ((64, 3360, 128), (33, 4096, 256), (41, 520, 200), (128, 1537, 64)):
+        assert rows * nb >= 8192
+        imgs = rng.gamma(2.0, 9.0, size=(nb, rows, cols)).clip(0, 255).astype(np.uint8)
+        for b in range(nb):
+            kind = b % 8
+            if kind == 0:    # bright blobs astride every chunk boundary
+                for c in range(512, cols - 8, 512):
+                    a = int(rng.integers(0, rows))
+                    imgs[b, a, c - 3:c + 4] = rng.integers(150, 255, 7)
+                    imgs[b, (a + 1) % rows, c - 2:c + 3] = rng.integers(150, 255, 5)
+            elif kind == 1:  # saturated plateaus: tied hits, whole chunks of candidates
+                for _ in range(6):
+                    a, r = int(rng.integers(0, rows - 2)), int(rng.integers(0, max(1, cols - 700)))
+                    imgs[b, a:a + 2, r:r + int(rng.integers(80, 700))] = 255
+            elif kind == 2:  # dark stretches (below the mean) ended by one bright pixel; the first stretch spans min_range
+                imgs[b, :, : min(cols, 900)] = rng.integers(0, 3, (rows, min(cols, 900)))
+                for a in range(0, rows, 3):
+                    imgs[b, a, 1] = 250
+                    imgs[b, (a + 1) % rows, 2] = 240
+                    imgs[b, a, min(cols, 900) - 1] = 255
+            elif kind == 3:  # two-level image: three distinct h in all
+                imgs[b] = np.where(rng.uniform(size=(rows, cols)) < 0.15, 210, 25)
+            elif kind == 4:  # many isolated bright pixels: far more than 64 candidate threads in a row
+                m = rng.uniform(size=(rows, cols)) < 0.04
+                imgs[b][m] = rng.integers(120, 255, int(m.sum()))
+            elif kind == 5:  # constant
+                imgs[b] = 17 + b % 3
+            # 6, 7: the speckle as it is
+        ex = cen.Cen2019(rows, cols)
+        for mp, mr in ((10000, 58), (60, 0), (10000, 3), (100000, 58)):
+            mr = min(mr, cols // 4)
+            tg = ex.extract_batch(imgs, col_offset=0, max_points=mp, min_range=mr)
+            for b in range(nb):
+                if b % 8 in (6, 7) and b >= 32:
+                    continue  # (the plain speckle images: four of each are enough for the oracle's time)
+                want = oracle.cen2019_extract(imgs[b], col_offset=0, max_points=mp, min_range=mr)
+                assert np.array_equal(tg[b], want), (rows, cols, mp, mr, b, b % 8, len(tg[b]), len(want))
+                if b < 8:  # the same images one by one: the workgroup-per-azimuth forms with their light path (single scans)
+                    assert np.array_equal(ex.extract(imgs[b], col_offset=0, max_points=mp, min_range=mr), want), (rows, cols, mp, mr, b, "single")
