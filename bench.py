@@ -480,9 +480,10 @@ def cen2019_leg(device):
     """Third part of the path: cen2019 keypoint extraction on MulRan-shape polar scans (400 azimuths x
     3360 range bins, 11 metadata bytes per row).  Three figures: the synchronous single-scan host entry (1.35 MB PCIe upload
     and keypoint download inside), the batched host entry, and the batched device entry (images resident in HBM, nothing
-    returns to the host).  Roofline: SURVEY 8d prices a scan at 1.344 MB of compulsory bytes; the chain reads the image
-    three times (stats, openers, runs: profiles/r05_cen2019_rocprofv3.txt) and is VALU-bound (per-row scans), so the HBM
-    fraction is reported for the record, not as the bound."""
+    returns to the host).  Roofline: SURVEY 8d prices a scan at 1.344 MB of compulsory bytes; the batched chain reads the image
+    twice (stats, openers; the runs pass works on 2 + 2 bytes per 8 pixels of records and the bytes of a row's ~14 candidate
+    threads: profiles/r06_cen2019_wave_rocprofv3.txt) and is VALU-issue-bound (per-row scans: 88-99 % of the SIMD cycles), so
+    the HBM fraction is reported for the record, not as the bound."""
     import ctypes as C
     import torch
     from navtech_radar_slam_amd import _rsx, cen2019, synth
@@ -535,11 +536,15 @@ def cen2019_leg(device):
             "keypoints_last_scan": int(n), "dtype": "u8/f32/u64 keys", "includes": "H2D image + D2H keypoints (host-buffer entry)",
             "pinned_image": {"scans_per_sec": 1.0 / dt_pin, "ms_per_scan": dt_pin * 1e3, "same_keypoint_count": bool(same_pin)},
             "batched_host_scans_per_sec": 1.0 / dt_b, "batched_device_scans_per_sec": 1.0 / dt_d, "batch": batch,
-            "launches_per_scan_or_batch": 11, "image_reads": 3, "intermediate_bytes_per_pixel": 0.375, "algorithmic_bytes_per_scan": alg,
+            "launches_per_scan_or_batch": 11, "image_reads": {"batched": 2, "single_scan": 3},
+            "intermediate_bytes_per_pixel": {"batched": 0.625, "single_scan": 0.375}, "algorithmic_bytes_per_scan": alg,
             "hbm_algorithmic_GBps_batched_device": alg / dt_d / 1e9, "hbm_frac_batched_device": alg / dt_d / 1e9 / HBM_PEAK_GBS,
             "note": "no sort, no host sync -- the greedy region marking in closed form; round 5: per-run maxima as plain v_max_f64 "
                     "scans of (segment | ord(h)) keys, marks as an OR over run flags, 2 + 1 bytes per 8 pixels between the passes; "
-                    "11 launches per call whatever the batch (two memsets + 9 kernels); three reads of the image, VALU-bound, not HBM-bound"}
+                    "11 launches per call whatever the batch (two memsets + 9 kernels).  Round 6: in a batch the row kernels run one "
+                    "WAVEFRONT per azimuth (chunks of 512 bins, scan totals in SGPRs, no barrier per row); the runs pass reads no image "
+                    "-- per thread 2 + 2 bytes of records, the ~14 threads of a row that can hold a hit compacted into one pass; "
+                    "single scans keep the workgroup-per-azimuth forms.  VALU-issue-bound, not HBM-bound"}
 
 
 def allpairs_leg(device, n=100000, k=10):
