@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT <= 512 ? 
 //   pass 2a               marks (flag reads), mark bits to HBM
 //   pass 2b               closed runs: the three scans chunk by chunk, chunks without a mark skipped
 // Same records, same mark bits as cen_runs, which stays for single scans and rows wider than 4096 bins (tests/test_gpu_cen2019.py:
-// batches through this kernel, single scans and test_wide_rows through the block form) and for A / B runs (RSX_CEN_RUNS=block,
+// batches through this kernel, single scans and test_wide_rows through the block form) and for A / B runs (RSX_CEN_FORMS=block,
 // experiments build).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int RW_WAVES = 4;             // wavefronts (= azimuths) per workgroup
@@ -1662,7 +1662,9 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
     hipLaunchKernelGGL((cen_stats<C, NT, 1>), dim3((unsigned)rows, (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
   hipLaunchKernelGGL(cen_scalars, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, sc, nb, (int64_t)rows * cols);
   const int hrpb = rpb > 1 ? HIST_ROWS : 1;
-  static const bool hist_block_form = [] { const char *e = rsx::exp_env("RSX_CEN_HIST"); return e && e[0] == 'b'; }();  // experiments build: RSX_CEN_HIST=block
+  // (experiments build: RSX_CEN_FORMS=block runs the workgroup-per-azimuth forms of cen_hist AND cen_runs in a batch too -- the two go
+  // together: cen_runs_wave reads the per-thread records only cen_hist_wave writes, cen_runs the per-wavefront maxima of cen_hist)
+  static const bool hist_block_form = [] { const char *e = rsx::exp_env("RSX_CEN_FORMS"); return e && e[0] == 'b'; }();
   bool hist_done = false;
   if constexpr (C == 8 && NT == 64 * HW_CH) {
     if (!hist_block_form && rpb > 1) {  // a batch: a wavefront per azimuth
@@ -1680,7 +1682,7 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   hipLaunchKernelGGL(cen_resolve, dim3((unsigned)nb), dim3(1024), 0, s, sc, h->list.as<unsigned long long>(), (int64_t)rows * cols, rows, cols,
                      p.max_points);
   const int rrpb = rpb > 1 ? RUNS_ROWS : 1;
-  static const bool block_form = [] { const char *e = rsx::exp_env("RSX_CEN_RUNS"); return e && e[0] == 'b'; }();  // experiments build: RSX_CEN_RUNS=block
+  const bool block_form = !hist_done;  // (the form cen_hist took)
   if constexpr (C == 8 && NT == 64 * RW_CH) {
     if (!block_form && rpb > 1) {  // a batch: a wavefront per azimuth (cen_runs_wave; a single scan's 400 wavefronts would walk their rows one chunk after the other: 17 us against 7)
       hipLaunchKernelGGL(cen_runs_wave, dim3((unsigned)((rows + RW_WAVES - 1) / RW_WAVES), (unsigned)nb), dim3(64 * RW_WAVES), 0, s, d_imgs, img_stride,
