@@ -129,7 +129,6 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
   constexpr int ND = C / 4, NWD = ND + 2, rpb = NR;
   __shared__ unsigned s_sum[NT / 64];
   __shared__ float s_max[NT / 64];
-  __shared__ int s_d[NT / 64];
   Scal *sc = scal + blockIdx.y;
   const int p0 = threadIdx.x * C;
   // which bytes count: in the sum, pixels inside the row; in the maximum, pixels 1 .. cols - 2 (even bytes of dword k in
@@ -147,6 +146,12 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
   }
   unsigned sb = 0;  // <= ST_ROWS * C * 255 per thread, a wave's sum stays far below 2^32
   unsigned pmax = 0;  // two 16-bit running maxima
+  unsigned pm[NR];    // ... and per row: the thread that reached D goes back to the ROW(S) that did, not to all NR (round 6: the branch --
+                      // one lane at work while the block waits at the barrier -- and the two barriers around it are 16 of the kernel's
+                      // 39 us: 23.6 us with the branch compiled out; per-row maxima: 36.  A wavefront-level D with two atomics per
+                      // wavefront instead of the barriers: 59 us, and 68 for a single scan -- 3 200 atomics on one word)
+#pragma unroll
+  for (int rr = 0; rr < NR; rr++) pm[rr] = 0u;
   unsigned kw[NR][NWD], kmis[NR];
   // the stream of a row realigned to the thread's first pixel: V[0] = pixels p0 - 4 .. p0 - 1, V[1 + k] = dword k, V[ND + 1] = the pixels behind
   auto realign = [&](const unsigned (&w)[NWD], unsigned mis, unsigned (&V)[ND + 2]) {
@@ -183,21 +188,21 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
       const unsigned R = __builtin_amdgcn_alignbyte(V[2 + k], X, 1);  // pixels p + 1
       sb = __builtin_amdgcn_sad_u8(X & smask[k], 0u, sb);
       const unsigned de = pk_absdiff_u16(L & 0x00ff00ffu, R & 0x00ff00ffu), dodd = pk_absdiff_u16((L >> 8) & 0x00ff00ffu, (R >> 8) & 0x00ff00ffu);
-      pmax = pk_max_u16(pmax, de & emask[k]);
-      pmax = pk_max_u16(pmax, dodd & omask[k]);
+      pm[rr] = pk_max_u16(pm[rr], de & emask[k]);
+      pm[rr] = pk_max_u16(pm[rr], dodd & omask[k]);
     }
+    pmax = pk_max_u16(pmax, pm[rr]);
   }
   const int dmax = (int)((pmax & 0xffffu) > (pmax >> 16) ? (pmax & 0xffffu) : (pmax >> 16));
-  const int dwv = wave_max_i32(dmax);
-  if ((threadIdx.x & 63) == 0) s_d[threadIdx.x >> 6] = dwv;
-  __syncthreads();
-  int D = 0;
-#pragma unroll
-  for (int wv = 0; wv < NT / 64; wv++) D = s_d[wv] > D ? s_d[wv] : D;
+  // D = the WAVEFRONT's largest difference (round 6; before: the block's, through LDS and a barrier -- every wavefront waited for the
+  // slowest and then for the one lane that went back to its words).  A wavefront whose D lies below the image's contributes a
+  // smaller g: harmless under the maximum.
+  const int D = wave_max_i32(dmax);
   float mg = 0.0f;
   if (D > 0 && dmax == D) {  // (a thread or two per block; D = 0: every gradient of the block is exactly 0)
 #pragma unroll
     for (int rr = 0; rr < NR; rr++) {
+      if ((int)((pm[rr] & 0xffffu) > (pm[rr] >> 16) ? (pm[rr] & 0xffffu) : (pm[rr] >> 16)) != D) continue;
       unsigned V[ND + 2];
       realign(kw[rr], kmis[rr], V);
 #pragma unroll
