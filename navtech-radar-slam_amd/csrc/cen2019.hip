@@ -298,7 +298,10 @@ __device__ __forceinline__ void row_load_h_at(const RowLds<C, NT> &L, const uint
   const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
   const unsigned mis = (unsigned)(addr & 3u);
   const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
-  if (p0 < cols) {
+  if (!edge) {  // (uniform) an inner wavefront: 0 < p0 and p0 + C + 4 <= cols for every lane -- all words exist, no lane-wise guards
+#pragma unroll
+    for (int j = 0; j < NWD; j++) w[j] = wp[j - 1];
+  } else if (p0 < cols) {
     if (p0 > 0) w[0] = wp[-1];
 #pragma unroll
     for (int j = 0; j < NWD - 1; j++)
