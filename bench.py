@@ -536,12 +536,12 @@ def cen2019_leg(device):
             "keypoints_last_scan": int(n), "dtype": "u8/f32/u64 keys", "includes": "H2D image + D2H keypoints (host-buffer entry)",
             "pinned_image": {"scans_per_sec": 1.0 / dt_pin, "ms_per_scan": dt_pin * 1e3, "same_keypoint_count": bool(same_pin)},
             "batched_host_scans_per_sec": 1.0 / dt_b, "batched_device_scans_per_sec": 1.0 / dt_d, "batch": batch,
-            "launches_per_scan_or_batch": 11, "image_reads": {"batched": 2, "single_scan": 3},
+            "launches_per_scan_or_batch": 10, "image_reads": {"batched": 2, "single_scan": 3},
             "intermediate_bytes_per_pixel": {"batched": 0.625, "single_scan": 0.375}, "algorithmic_bytes_per_scan": alg,
             "hbm_algorithmic_GBps_batched_device": alg / dt_d / 1e9, "hbm_frac_batched_device": alg / dt_d / 1e9 / HBM_PEAK_GBS,
             "note": "no sort, no host sync -- the greedy region marking in closed form; round 5: per-run maxima as plain v_max_f64 "
                     "scans of (segment | ord(h)) keys, marks as an OR over run flags, 2 + 1 bytes per 8 pixels between the passes; "
-                    "11 launches per call whatever the batch (two memsets + 9 kernels).  Round 6: in a batch the row kernels run one "
+                    "10 launches per call whatever the batch (one memset + 9 kernels).  Round 6: in a batch the row kernels run one "
                     "WAVEFRONT per azimuth (chunks of 512 bins, scan totals in SGPRs, no barrier per row); the runs pass reads no image "
                     "-- per thread 2 + 2 bytes of records, the ~14 threads of a row that can hold a hit compacted into one pass; "
                     "single scans keep the workgroup-per-azimuth forms.  VALU-issue-bound, not HBM-bound"}

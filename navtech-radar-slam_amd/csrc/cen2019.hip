@@ -124,12 +124,16 @@ __device__ __forceinline__ unsigned pk_max_u16(unsigned a, unsigned b) {
 }
 template <int C, int NT, int NR>  // NR = rows of a block (ST_ROWS in a batch, 1 for a single scan): the block keeps their words in registers
 __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs, int64_t img_stride, int rows, int cols, int stride,
-                                                int off, Scal *scal) {
+                                                int off, Scal *scal, unsigned *__restrict__ hist) {
   static_assert(C % 4 == 0, "a thread's chunk is whole dwords");
   constexpr int ND = C / 4, NWD = ND + 2, rpb = NR;
   __shared__ unsigned s_sum[NT / 64];
   __shared__ float s_max[NT / 64];
   Scal *sc = scal + blockIdx.y;
+  // (the image's selection histogram is zeroed here, by the image's first block -- cen_hist runs behind a kernel boundary; it was a
+  // memset of its own: one launch of the chain's eleven)
+  if (blockIdx.x == 0)
+    for (int b = threadIdx.x; b < NBIN / 4; b += NT) reinterpret_cast<uint4 *>(hist + (size_t)blockIdx.y * NBIN)[b] = uint4{0u, 0u, 0u, 0u};
   const int p0 = threadIdx.x * C;
   // which bytes count: in the sum, pixels inside the row; in the maximum, pixels 1 .. cols - 2 (even bytes of dword k in
   // emask[k], odd bytes in omask[k], as 16-bit lanes)
@@ -1665,9 +1669,9 @@ void launch_chain(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, int
   const int rpb = (int64_t)rows * nb >= 8192 ? ST_ROWS : 1;
   if (rpb > 1)
     hipLaunchKernelGGL((cen_stats<C, NT, ST_ROWS>), dim3((unsigned)((rows + rpb - 1) / rpb), (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows,
-                       cols, stride, off, sc);
+                       cols, stride, off, sc, h->hist.as<unsigned>());
   else
-    hipLaunchKernelGGL((cen_stats<C, NT, 1>), dim3((unsigned)rows, (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc);
+    hipLaunchKernelGGL((cen_stats<C, NT, 1>), dim3((unsigned)rows, (unsigned)nb), dim3(NT), 0, s, d_imgs, img_stride, rows, cols, stride, off, sc, h->hist.as<unsigned>());
   hipLaunchKernelGGL(cen_scalars, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, s, sc, nb, (int64_t)rows * cols);
   const int hrpb = rpb > 1 ? HIST_ROWS : 1;
   // (experiments build: RSX_CEN_FORMS=block runs the workgroup-per-azimuth forms of cen_hist AND cen_runs in a batch too -- the two go
@@ -1732,7 +1736,6 @@ int extract_device(rsx_cen2019 *h, const uint8_t *d_imgs, int64_t img_stride, in
       RSX_TRY(h->negmax.reserve((size_t)n * rows * nt * 2, s, false));           // sign bits | bin / 16 of the largest h per thread (cen_hist_wave -> cen_runs_wave)
     }
     RSX_HIP(hipMemsetAsync(h->scal.p, 0, (size_t)n * sizeof(Scal), s));
-    RSX_HIP(hipMemsetAsync(h->hist.p, 0, (size_t)n * NBIN * 4, s));
     const uint8_t *im = d_imgs + (int64_t)b0 * img_stride;
     int *tg = d_targets + (int64_t)b0 * max_targets * 2;
     float *pxy = d_xy ? d_xy + (int64_t)b0 * max_targets * 2 : nullptr;
