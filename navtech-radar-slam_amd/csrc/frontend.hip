@@ -616,6 +616,164 @@ __global__ __launch_bounds__(256) void fe_match_consecutive(const uint32_t *__re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// fe_match_consecutive on the MATRIX cores (round 6).  A Hamming distance is a K = 256 contraction: with the bits as +-1,
+// a . b = 256 - 2 hamming(a, b).  v_mfma_f32_32x32x64_f8f6f4 takes 64 fp8 values per lane pair and instruction, so FOUR of them
+// give the 32 x 32 distances of a tile of 32 train descriptors against a wavefront's 32 queries -- exact small integers in fp32 --
+// where the vector form spends 8 x (LDS read + xor + popcount) per pair and lane (27 instructions: 75 M pairs per 64-scan window,
+// 113 us).  Rows = train descriptors (the A operand, a tile staged in LDS as fp8 bytes by the block's 256 threads -- one
+// descriptor dword = 32 bytes each: 4 bits -> 4 bytes by one multiply, (n x 0x00204081) & 0x01010101, shifted into the sign
+// bits of 0x38 = 1.0 -- rows 272 bytes apart: conflict-free ds_read_b128), columns = queries (the B operand, expanded once, in
+// registers), so a lane holds ONE query's distances to 16 train descriptors per tile and keeps that query's two smallest
+// (distance << 20 | train index) keys itself -- min / max / min per value, the order of the sequential scan as before -- with
+// no traffic between the lanes until the two halves of the wavefront (rows r and r + 4) are merged at the end.
+// A block = 4 wavefronts = 128 queries over double-buffered train tiles, one barrier per tile.
+// ---------------------------------------------------------------------------------------------------------------
+typedef int fe_i32x8 __attribute__((ext_vector_type(8)));
+typedef float fe_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int MM_QB = 128;          // queries per block (32 per wavefront)
+constexpr int MM_ROW = 256 + 16;    // bytes between two train rows of a staged tile
+#ifndef FE_MM_RT
+#define FE_MM_RT 1
+#endif
+#ifndef FE_MM_GX
+#define FE_MM_GX 16  // query blocks per (pair, direction) in the grid (a block strides over the rest)
+#endif
+constexpr int MM_RT = FE_MM_RT;     // 32-row train tiles per stage (one barrier per stage)
+__device__ __forceinline__ void fe_expand32(uint32_t bits, uint32_t (&out)[8]) {  // bit -> fp8 e4m3 byte: 0 -> 1.0 (0x38), 1 -> -1.0 (0xb8)
+#pragma unroll
+  for (int g = 0; g < 8; g++) out[g] = ((((bits >> (4 * g)) & 0xfu) * 0x00204081u) & 0x01010101u) << 7 | 0x38383838u;
+}
+__global__ __launch_bounds__(256) void fe_match_consecutive_mfma(const uint32_t *__restrict__ descs, const uint8_t *__restrict__ valids,
+                                                                 const int32_t *__restrict__ counts, int stride, int first,
+                                                                 const int32_t *__restrict__ vidx, const int32_t *__restrict__ vcount, float ratio,
+                                                                 int32_t *__restrict__ fwd, int32_t *__restrict__ bwd) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_a[2][MM_RT * 32 * MM_ROW];
+  __shared__ __attribute__((aligned(16))) uint32_t s_i[2][MM_RT * 32];
+  // blockIdx.x = pair and direction, blockIdx.y = query block: workgroups go to the XCDs round robin by their linear index, and with
+  // the query block as the fast index (16 per pair, 6 of them with work) the work sat on 6 of the 8 XCDs
+  const int j = (int)blockIdx.x >> 1, dir = (int)blockIdx.x & 1;
+  const int qblk = blockIdx.y, nqblk = gridDim.y;
+  const int qs = j + dir, ts = j + 1 - dir;  // slots relative to `first`
+  const int nq = counts[first + qs] < stride ? counts[first + qs] : stride;
+  const uint32_t *q = descs + (int64_t)(first + qs) * stride * 8, *t = descs + (int64_t)(first + ts) * stride * 8;
+  const int32_t *qi = vidx + (int64_t)qs * stride, *ti = vidx + (int64_t)ts * stride;
+  int32_t *out_idx = (dir ? bwd : fwd) + (int64_t)j * stride;
+  for (int i = qblk * 256 + threadIdx.x; i < nq; i += nqblk * 256)
+    if (!valids[(int64_t)(first + qs) * stride + i]) out_idx[i] = -1;
+  const int nqv = vcount[qs], ntv = vcount[ts];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5;
+  constexpr int TR = MM_RT * 32;  // train rows per stage
+  const int ntiles = (ntv + TR - 1) / TR;
+  // staging: thread = (row r, dword w) of each 32-row tile of a stage.  The train indices of stage tl + 3 and the descriptor dwords
+  // of stage tl + 2 are requested while stage tl is multiplied; the dwords of stage tl + 1 -- requested two stages ago -- are
+  // expanded into the other buffer at the end of the iteration.  (First build: index and dword loaded, one after the other, in
+  // the iteration before their tile -- two memory round trips in front of every barrier, 25 tiles a query block: 105 us in the
+  // pipeline against the vector form's 121.)
+  const int sr = threadIdx.x >> 3, sw = threadIdx.x & 7;
+  struct Idx { int v[MM_RT]; };
+  struct Bits { uint32_t v[MM_RT]; };
+  auto idx_of = [&](int tile) -> Idx {
+    Idx r;
+#pragma unroll
+    for (int u = 0; u < MM_RT; u++) {
+      const int jt = tile * TR + 32 * u + sr;
+      r.v[u] = (tile < ntiles && jt < ntv) ? ti[jt] : -1;
+    }
+    return r;
+  };
+  auto bits_of = [&](const Idx &it) -> Bits {
+    Bits r;
+#pragma unroll
+    for (int u = 0; u < MM_RT; u++) r.v[u] = it.v[u] >= 0 ? t[(int64_t)it.v[u] * 8 + sw] : 0u;
+    return r;
+  };
+  auto put = [&](const Idx &it, const Bits &bits, int buf) {
+#pragma unroll
+    for (int u = 0; u < MM_RT; u++) {
+      uint32_t e[8];
+      fe_expand32(bits.v[u], e);
+      uint4 *dst = reinterpret_cast<uint4 *>(&s_a[buf][(32 * u + sr) * MM_ROW + sw * 32]);
+      dst[0] = uint4{e[0], e[1], e[2], e[3]};
+      dst[1] = uint4{e[4], e[5], e[6], e[7]};
+      if (sw == 0) s_i[buf][32 * u + sr] = it.v[u] >= 0 ? (uint32_t)it.v[u] : 0xffffffffu;  // (a row past the list: its key saturates to "nothing")
+    }
+  };
+  for (int q0 = qblk * MM_QB; q0 < nqv; q0 += nqblk * MM_QB) {  // (uniform per block)
+    const int jq = q0 + wave * 32 + (lane & 31);
+    const bool live = jq < nqv;
+    const int iq = live ? qi[jq] : 0;
+    Idx it0 = idx_of(0), it1 = idx_of(1), it2 = idx_of(2);
+    fe_i32x8 bq[4];
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+      uint32_t e[8];
+      fe_expand32(live ? q[(int64_t)iq * 8 + 2 * st + half] : 0u, e);
+      bq[st] = fe_i32x8{(int)e[0], (int)e[1], (int)e[2], (int)e[3], (int)e[4], (int)e[5], (int)e[6], (int)e[7]};
+    }
+    uint32_t k1 = 0xffffffffu, k2 = 0xffffffffu;
+    float thr = -1.0e9f;
+    Bits b1 = bits_of(it1);  // stage 1's dwords (stage 0's go straight into the buffer)
+    __syncthreads();  // (the tile buffers of the previous query block are free)
+    if (ntiles > 0) put(it0, bits_of(it0), 0);
+    for (int tl = 0; tl < ntiles; tl++) {
+      const Bits b2 = bits_of(it2);     // stage tl + 2
+      const Idx it3 = idx_of(tl + 3);
+      __syncthreads();  // stage tl is in its buffer; everybody is done with stage tl - 1
+      const int buf = tl & 1;
+      fe_f32x16 acc[MM_RT];
+#pragma unroll
+      for (int u = 0; u < MM_RT; u++) {
+        acc[u] = fe_f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 4; st++) {
+          const uint4 *src = reinterpret_cast<const uint4 *>(&s_a[buf][(32 * u + (lane & 31)) * MM_ROW + (2 * st + half) * 32]);
+          const uint4 a0 = src[0], a1 = src[1];
+          const fe_i32x8 av = {(int)a0.x, (int)a0.y, (int)a0.z, (int)a0.w, (int)a1.x, (int)a1.y, (int)a1.z, (int)a1.w};
+          acc[u] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(av, bq[st], acc[u], 0, 0, 0, 0, 0, 0);
+        }
+      }
+      // D: this lane = query column lane & 31, rows (reg & 3) + 8 (reg >> 2) + 4 half.  A value can change the lane's two keys only
+      // if its distance does not exceed the second one's, i.e. its dot product reaches thr = 256 - 2 d2: after the first tiles
+      // that is rare (random descriptors lie 128 +- 8 apart, a query's second-best match near 100), so the values are
+      // compared as floats -- one instruction each -- and the six-instruction key update runs only in the tiles where some lane
+      // of the wavefront has such a value (the other lanes' updates change nothing)
+#pragma unroll
+      for (int u = 0; u < MM_RT; u++) {
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < 16; r++) any |= acc[u][r] >= thr;
+        if (__ballot(any) != 0ull) {  // (uniform)
+#pragma unroll
+          for (int g = 0; g < 4; g++) {
+            const uint4 id = *reinterpret_cast<const uint4 *>(&s_i[buf][32 * u + 8 * g + 4 * half]);
+            const uint32_t ids[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              const uint32_t d = (uint32_t)__builtin_fmaf(acc[u][4 * g + r], -0.5f, 128.0f);  // hamming = 128 - dot / 2, exact
+              const uint32_t key = (d << 20) | ids[r];
+              k2 = min(k2, max(k1, key));
+              k1 = min(k1, key);
+            }
+          }
+          thr = 256.0f - 2.0f * (float)(k2 >> 20);  // (k2 = "nothing yet": far below every dot product)
+        }
+      }
+      if (tl + 1 < ntiles) put(it1, b1, buf ^ 1);
+      it1 = it2;
+      it2 = it3;
+      b1 = b2;
+    }
+    {  // the other half of the wavefront saw the other 16 rows of every tile
+      const uint32_t o1 = (uint32_t)__shfl_xor((int)k1, 32), o2 = (uint32_t)__shfl_xor((int)k2, 32);
+      k2 = min(max(k1, o1), min(k2, o2));
+      k1 = min(k1, o1);
+    }
+    const int d1 = (int)(k1 >> 20), d2 = (int)(k2 >> 20), i1 = (int)(k1 & 0xfffffu);
+    if (live && half == 0) out_idx[iq] = (k1 != 0xffffffffu && k2 != 0xffffffffu && (float)d1 < ratio * (float)d2) ? i1 : -1;
+  }
+}
+
 }  // namespace
 
 struct rsx_frontend {
@@ -961,9 +1119,15 @@ int rsx_frontend_match_consecutive_device(rsx_frontend *h, const uint8_t *d_desc
   RSX_TRY(h->vcount.reserve((size_t)(n_pairs + 1) * 4, s, false));
   hipLaunchKernelGGL(fe_compact_valid, dim3((unsigned)(n_pairs + 1)), dim3(256), 0, s, d_valid, d_counts, max_targets, first_slot,
                      h->vidx.as<int32_t>(), h->vcount.as<int32_t>());
-  hipLaunchKernelGGL(fe_match_consecutive, dim3((unsigned)((max_targets + FM_Q - 1) / FM_Q < 32 ? (max_targets + FM_Q - 1) / FM_Q : 32), (unsigned)n_pairs, 2), dim3(256), 0, s,
-                     reinterpret_cast<const uint32_t *>(d_desc), d_valid, d_counts, max_targets, first_slot, h->vidx.as<int32_t>(),
-                     h->vcount.as<int32_t>(), ratio, d_fwd, d_bwd);
+  static const bool valu_form = [] { const char *e = rsx::exp_env("RSX_FE_MATCH"); return e && e[0] == 'v'; }();  // experiments build: RSX_FE_MATCH=valu
+  if (valu_form)
+    hipLaunchKernelGGL(fe_match_consecutive, dim3((unsigned)((max_targets + FM_Q - 1) / FM_Q < 32 ? (max_targets + FM_Q - 1) / FM_Q : 32), (unsigned)n_pairs, 2), dim3(256), 0, s,
+                       reinterpret_cast<const uint32_t *>(d_desc), d_valid, d_counts, max_targets, first_slot, h->vidx.as<int32_t>(),
+                       h->vcount.as<int32_t>(), ratio, d_fwd, d_bwd);
+  else
+    hipLaunchKernelGGL(fe_match_consecutive_mfma, dim3((unsigned)(2 * n_pairs), (unsigned)((max_targets + MM_QB - 1) / MM_QB < FE_MM_GX ? (max_targets + MM_QB - 1) / MM_QB : FE_MM_GX)), dim3(256), 0, s,
+                       reinterpret_cast<const uint32_t *>(d_desc), d_valid, d_counts, max_targets, first_slot, h->vidx.as<int32_t>(),
+                       h->vcount.as<int32_t>(), ratio, d_fwd, d_bwd);
   RSX_HIP(hipGetLastError());
   return RSX_OK;
 } RSX_CATCH_ALL
