@@ -187,3 +187,52 @@ def test_batched_describe_and_consecutive_matching_equal_the_oracle(fe, oracle):
         assert np.array_equal(bwd[j, :counts[j + 1]], b_idx), j
     assert (fwd[4, :counts[4]] >= 0).sum() > 20           # the same scene under another noise realisation is recognised
     g.close()
+
+
+def test_consecutive_matching_sizes_and_ties(fe, oracle):
+    """rsx_frontend_match_consecutive_device alone (the matrix-core matcher: four fp8 MFMAs per 32 x 32 tile of +-1 descriptors, a lane
+    keeps one query's two smallest (distance << 20 | index) keys): list sizes around its tile and block sizes (31 / 32 / 33 / 127 /
+    128 / 129 valid descriptors, none, one), more valid queries than one pass of the grid takes (4100 > 16 x 128: a block strides
+    over query blocks), descriptors drawn from a small pool (exact duplicates: distance 0 several times -- the smaller train index
+    wins and the ratio test fails; equal second-best distances), all-zero and all-one descriptors, invalid keypoints sprinkled in --
+    every pair in both directions against oracle.match."""
+    import torch
+    rng = np.random.default_rng(123)
+    K = 4352
+    counts = np.array([4100, 33, 32, 31, 129, 128, 127, 0, 1, 4100, 700], dtype=np.int32)
+    n = len(counts)
+    pool = rng.integers(0, 256, (40, 32), dtype=np.uint8)
+    pool[0] = 0
+    pool[1] = 255
+    desc = np.zeros((n, K, 32), dtype=np.uint8)
+    valid = np.zeros((n, K), dtype=np.uint8)
+    for k in range(n):
+        c = counts[k]
+        d = rng.integers(0, 256, (c, 32), dtype=np.uint8)
+        dup = rng.uniform(size=c) < 0.3
+        d[dup] = pool[rng.integers(0, len(pool), int(dup.sum()))]
+        near = rng.uniform(size=c) < 0.2          # a pool entry with one or two bits flipped
+        if near.any():
+            base = pool[rng.integers(0, len(pool), int(near.sum()))].copy()
+            base[np.arange(len(base)), rng.integers(0, 32, len(base))] ^= (1 << rng.integers(0, 8, len(base))).astype(np.uint8)
+            d[near] = base
+        desc[k, :c] = d
+        valid[k, :c] = (rng.uniform(size=c) < (0.97 if k in (0, 9) else 0.8)).astype(np.uint8) if c > 1 else 1
+    d_desc, d_valid, d_cnt = torch.from_numpy(desc).cuda(), torch.from_numpy(valid).cuda(), torch.from_numpy(counts).cuda()
+    d_fwd = torch.full((n - 1, K), -7, dtype=torch.int32, device="cuda")
+    d_bwd = torch.full((n - 1, K), -7, dtype=torch.int32, device="cuda")
+    g = fe.Frontend(400, 3360)
+    g.match_consecutive_device(d_desc.data_ptr(), d_valid.data_ptr(), d_cnt.data_ptr(), K, 0, n - 1, 0.8, d_fwd.data_ptr(), d_bwd.data_ptr())
+    torch.cuda.synchronize()
+    fwd, bwd = d_fwd.cpu().numpy(), d_bwd.cpu().numpy()
+    o = oracle.FrontendRef(400, 3360, 964, 0.2592)
+    some = 0
+    for j in range(n - 1):
+        qa, va, qb, vb = desc[j, :counts[j]], valid[j, :counts[j]], desc[j + 1, :counts[j + 1]], valid[j + 1, :counts[j + 1]]
+        f_idx, _, _ = o.match(qa, va, qb, vb, 0.8)
+        b_idx, _, _ = o.match(qb, vb, qa, va, 0.8)
+        assert np.array_equal(fwd[j, :counts[j]], f_idx), (j, int((fwd[j, :counts[j]] != f_idx).sum()))
+        assert np.array_equal(bwd[j, :counts[j + 1]], b_idx), (j, int((bwd[j, :counts[j + 1]] != b_idx).sum()))
+        some += int((f_idx >= 0).sum())
+    assert some > 50
+    g.close()
