@@ -173,9 +173,11 @@ __global__ __launch_bounds__(NT) void cen_stats(const uint8_t *__restrict__ imgs
     kmis[rr] = 0u;
     if (a >= rows) continue;  // (uniform; the words stay zero: no d, no sum)
     const uint8_t *row = imgs + (int64_t)blockIdx.y * img_stride + (int64_t)a * stride + off;
-    const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
-    const unsigned mis = (unsigned)(addr & 3u);
-    const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
+    const uint8_t *pp0 = row + p0;  // (pointer arithmetic, not integers: the loads stay global_load, not flat_load)
+
+    const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(pp0) & 3u);
+
+    const unsigned *wp = reinterpret_cast<const unsigned *>(pp0 - mis);
     kmis[rr] = mis;
     if (p0 < cols) {
       if (p0 > 0) w[0] = wp[-1];
@@ -299,9 +301,11 @@ __device__ __forceinline__ void row_load_h_at(const RowLds<C, NT> &L, const uint
   unsigned w[NWD];
 #pragma unroll
   for (int j = 0; j < NWD; j++) w[j] = 0u;
-  const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
-  const unsigned mis = (unsigned)(addr & 3u);
-  const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
+  const uint8_t *pp0 = row + p0;  // (pointer arithmetic, not integers: the loads stay global_load, not flat_load)
+
+  const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(pp0) & 3u);
+
+  const unsigned *wp = reinterpret_cast<const unsigned *>(pp0 - mis);
   if (!edge) {  // (uniform) an inner wavefront: 0 < p0 and p0 + C + 4 <= cols for every lane -- all words exist, no lane-wise guards
 #pragma unroll
     for (int j = 0; j < NWD; j++) w[j] = wp[j - 1];
@@ -364,9 +368,11 @@ __device__ __forceinline__ unsigned row_load_neg(const uint8_t *__restrict__ row
   constexpr int NWD = C / 4 + 1;  // aligned words [0 .. C / 4] relative to (row + p0) & ~3
   if (p0 >= cols) return 0u;
   unsigned w[NWD];
-  const uintptr_t addr = reinterpret_cast<uintptr_t>(row) + (uintptr_t)p0;
-  const unsigned mis = (unsigned)(addr & 3u);
-  const unsigned *wp = reinterpret_cast<const unsigned *>(addr - mis);
+  const uint8_t *pp0 = row + p0;  // (pointer arithmetic, not integers: the loads stay global_load, not flat_load)
+
+  const unsigned mis = (unsigned)(reinterpret_cast<uintptr_t>(pp0) & 3u);
+
+  const unsigned *wp = reinterpret_cast<const unsigned *>(pp0 - mis);
 #pragma unroll
   for (int j = 0; j < NWD; j++) w[j] = (p0 + 4 * j - (int)mis < cols) ? wp[j] : 0u;
   unsigned neg = 0;
