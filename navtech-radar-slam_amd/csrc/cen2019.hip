@@ -1348,7 +1348,7 @@ struct RwLds {                          // one wavefront's
   uint8_t flags[RW_FLAGS];
   unsigned short list[64 * RW_CH];      // candidate threads (chunk * 64 + lane), in row order
   unsigned cexcl[64 * RW_CH];           // their non-neg prefix counts
-  unsigned res[64][9 + 1];              // one pass of 64 candidates: hit bits, ord(h) of the 8 pixels (+ 1: bank spread)
+  unsigned res[64][10 + 1];             // one pass of 64 candidates: hit bits, ord(h) of the 8 pixels; pass 2b: bits, p0, ord(h) (+ 1: bank spread)
 };
 #ifndef RW_OCC
 #define RW_OCC 3  // waves per SIMD the register budget is cut for (4: spills; 3, 4, 5 measured alike before the candidate list)
@@ -1483,19 +1483,21 @@ __global__ __launch_bounds__(64 * RW_WAVES) __attribute__((amdgpu_waves_per_eu(R
     }
   }
 
-  // ---- pass 2b: closed runs (cen_runs' scans, their totals carried from chunk to chunk) ----
+  // ---- pass 2b: closed runs.  Marks are as sparse as hits (a dozen threads of a row hold a live pixel), so the three scans do not
+  // run chunk by chunk (five of a row's seven chunks hold a mark: 5 x 170 instructions) but ONCE per 64 LIVE THREADS: start and
+  // close bits are formed in chunk order (the neighbours' bits by DPP, cheap), the threads with a live pixel are compacted --
+  // their bits and ord(h) handed over through the wavefront's LDS, as in pass 1b -- and the scans of cen_runs run over the
+  // list: positions only grow along it and every start a live pixel can belong to is in it, so "the latest start" and "the
+  // largest key of the latest run" mean what they meant in row order ----
   const int rmin = min_range < 0 ? 0 : min_range;
-  unsigned lprev_c = 0u, s_carry = 0u, pos_base = 0u;
-  double k_carry = 0.0;
   uint2 *ro = row_runs + ((int64_t)img * rows + a) * row_cap;
-  // A run's arg-max is exact as long as the run holds a hit (a hit's h is known and beats every other pixel of its run; among
-  // equals the hit has the lower bin).  Every run of MARKED pixels holds one -- but the part of it at r >= min_range may not
-  // (a dark stretch flagged by a bright pixel below min_range): such a record is recognised by its key (ord(h) below the
-  // limit's) and redone from the image bytes after the scans, all 64 lanes on that one run.  At most one per row.
-  unsigned fix_pos = 0u, fix_span = 0u;
-  bool fix = false;
+  unsigned lsc[RW_CH];  // live | start << 8 | close << 16 of the chunk's 8 pixels
+  int lslot[RW_CH];
+  unsigned n_live = 0, lprev_c = 0u;
 #pragma unroll
   for (int ch = 0; ch < RW_CH; ch++) {
+    lsc[ch] = 0u;
+    lslot[ch] = -1;
     if (ch < nch) {
       const bool any = __ballot(marked[ch] != 0u) != 0ull;  // (uniform)
       if (!any) {
@@ -1512,48 +1514,87 @@ __global__ __launch_bounds__(64 * RW_WAVES) __attribute__((amdgpu_waves_per_eu(R
         const unsigned start = live & ~(((live << 1) | lprev) & FULL);
         const unsigned in_row = p0 + C < cols ? FULL : (p0 + 1 >= cols ? 0u : ((1u << (cols - 1 - p0)) - 1u));  // bit i: p + 1 < cols
         const unsigned close = live & ~((marked[ch] >> 1) | (mnext << (C - 1))) & in_row;
-        const unsigned sloc = start ? (unsigned)(p0 + (31 - __builtin_clz(start)) + 1) : 0u;
-        const unsigned x = wave_incl_max_u32(sloc);
-        unsigned sin = dpp_u32<0x138>(x);
-        sin = s_carry > sin ? s_carry : sin;
-        {
-          const unsigned xt = (unsigned)__builtin_amdgcn_readlane((int)x, 63);
-          s_carry = xt > s_carry ? xt : s_carry;
-        }
-        double kin[C];
-        double run = 0.0;
-        const unsigned sinx = sin | 0x10000u, pbx = (unsigned)p0 + 32u + 0x10000u, c0 = 0x3fffu - ((unsigned)p0 & 0x3fffu);
-#pragma unroll
-        for (int i = 0; i < C; i++) {
-          const unsigned below = start & ((2u << i) - 1u);
-          const unsigned spx = below ? pbx - (unsigned)__builtin_clz(below) : sinx;
-          const unsigned hi = __builtin_amdgcn_alignbit(spx, ordh[ch][i], 18);
-          const unsigned lo = (ordh[ch][i] << 14) | (c0 - (unsigned)i);
-          const double kd = __hiloint2double((int)(((live >> i) & 1u) ? hi : 0u), (int)lo);
-          run = kmax(run, kd);
-          kin[i] = run;
-        }
-        const double ki = wave_incl_max<false>(run, lane);
-        const double kx = kmax(dpp_f64<0x138>(ki), k_carry);
-        k_carry = kmax(k_carry, readlane_f64(ki, 63));
-        const unsigned cnt = (unsigned)__popc(close);
-        const unsigned inc = wave_incl_add(cnt, lane);
-        unsigned pos = pos_base + inc - cnt;
-        pos_base += (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
-#pragma unroll
-        for (int i = 0; i < C; i++) {
-          if ((close >> i) & 1u) {
-            const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
-            const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
-            if ((unsigned)(k >> 14) < ord_min) {  // (no hit in [first, last]: see above)
-              fix = true;
-              fix_pos = pos;
-              fix_span = first | ((unsigned)(p0 + i) << 16);
-            }
-            ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
-          }
-        }
+        lsc[ch] = live | (start << 8) | (close << 16);
+        const unsigned long long lm = __ballot(live != 0u);
+        if (live != 0u) lslot[ch] = (int)(n_live + (unsigned)__popcll(lm & ((1ull << lane) - 1ull)));
+        n_live += (unsigned)__popcll(lm);
         lprev_c = (unsigned)__builtin_amdgcn_readlane((int)((live >> (C - 1)) & 1u), 63);
+      }
+    }
+  }
+  n_live = (unsigned)__builtin_amdgcn_readfirstlane((int)n_live);
+  // A run's arg-max is exact as long as the run holds a hit (a hit's h is known and beats every other pixel of its run; among
+  // equals the hit has the lower bin).  Every run of MARKED pixels holds one -- but the part of it at r >= min_range may not
+  // (a dark stretch flagged by a bright pixel below min_range): such a record is recognised by its key (ord(h) below the
+  // limit's) and redone from the image bytes after the scans, all 64 lanes on that one run.  At most one per row.
+  unsigned fix_pos = 0u, fix_span = 0u;
+  bool fix = false;
+  unsigned s_carry = 0u, pos_base = 0u;
+  double k_carry = 0.0;
+  for (unsigned base = 0; base < n_live; base += 64) {  // (uniform)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (the slots of the pass before are read)
+#pragma unroll
+    for (int ch = 0; ch < RW_CH; ch++) {
+      const int sl = lslot[ch] - (int)base;
+      if (sl >= 0 && sl < 64) {
+        W.res[sl][0] = lsc[ch];
+        W.res[sl][1] = (unsigned)((ch * 64 + lane) * C);
+#pragma unroll
+        for (int i = 0; i < C; i++) W.res[sl][2 + i] = ordh[ch][i];
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const bool act = base + (unsigned)lane < n_live;
+    unsigned e_lsc = 0u, e_p0 = 0u, e_o[C];
+#pragma unroll
+    for (int i = 0; i < C; i++) e_o[i] = 0u;
+    if (act) {
+      e_lsc = W.res[lane][0];
+      e_p0 = W.res[lane][1];
+#pragma unroll
+      for (int i = 0; i < C; i++) e_o[i] = W.res[lane][2 + i];
+    }
+    const unsigned live = e_lsc & FULL, start = (e_lsc >> 8) & FULL, close = (e_lsc >> 16) & FULL;
+    const int p0 = (int)e_p0;
+    const unsigned sloc = start ? (unsigned)(p0 + (31 - __builtin_clz(start)) + 1) : 0u;
+    const unsigned x = wave_incl_max_u32(sloc);
+    unsigned sin = dpp_u32<0x138>(x);
+    sin = s_carry > sin ? s_carry : sin;
+    {
+      const unsigned xt = (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+      s_carry = xt > s_carry ? xt : s_carry;
+    }
+    double kin[C];
+    double run = 0.0;
+    const unsigned sinx = sin | 0x10000u, pbx = (unsigned)p0 + 32u + 0x10000u, c0 = 0x3fffu - ((unsigned)p0 & 0x3fffu);
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      const unsigned below = start & ((2u << i) - 1u);
+      const unsigned spx = below ? pbx - (unsigned)__builtin_clz(below) : sinx;
+      const unsigned hi = __builtin_amdgcn_alignbit(spx, e_o[i], 18);
+      const unsigned lo = (e_o[i] << 14) | (c0 - (unsigned)i);
+      const double kd = __hiloint2double((int)(((live >> i) & 1u) ? hi : 0u), (int)lo);
+      run = kmax(run, kd);
+      kin[i] = run;
+    }
+    const double ki = wave_incl_max<false>(run, lane);
+    const double kx = kmax(dpp_f64<0x138>(ki), k_carry);
+    k_carry = kmax(k_carry, readlane_f64(ki, 63));
+    const unsigned cnt = (unsigned)__popc(close);
+    const unsigned inc = wave_incl_add(cnt, lane);
+    unsigned pos = pos_base + inc - cnt;
+    pos_base += (unsigned)__builtin_amdgcn_readlane((int)inc, 63);
+#pragma unroll
+    for (int i = 0; i < C; i++) {
+      if ((close >> i) & 1u) {
+        const unsigned long long k = (unsigned long long)__double_as_longlong(kmax(kx, kin[i]));
+        const unsigned first = (unsigned)((k >> 46) & 0x7fffu) - 1u, arg = 0x3fffu - (unsigned)(k & 0x3fffu);
+        if ((unsigned)(k >> 14) < ord_min) {  // (no hit in [first, last]: see above)
+          fix = true;
+          fix_pos = pos;
+          fix_span = first | ((unsigned)(p0 + i) << 16);
+        }
+        ro[pos++] = uint2{first | ((unsigned)(p0 + i) << 16), arg};  // first | last << 16, arg-max bin
       }
     }
   }
