@@ -26,7 +26,10 @@
 
 namespace {
 
-constexpr int MAX_WINDOW = 64;  // scans per internal launch chain (workspace: ~26 MB per scan and extraction lane, two lanes)
+#ifndef RSX_ODO_WINDOW
+#define RSX_ODO_WINDOW 64
+#endif
+constexpr int MAX_WINDOW = RSX_ODO_WINDOW;  // scans per internal launch chain (workspace: ~26 MB per scan and extraction lane, two lanes)
 
 // one block per consecutive pair j (slots A = first + j, B = A + 1): keep prev keypoint i when fwd[i] = k >= 0 and
 // bwd[k] = i, in ascending i (the order the host loop of round 2 produced); src = the CURRENT scan's point, dst = the
